@@ -1,0 +1,375 @@
+// Host side of the provider: the gates bccsp/sw applies BEFORE any curve arithmetic, the error
+// vocabulary of the reference, and the block-level batch verifier that feeds the GPU.
+//
+// Mirrors (same names / argument meaning / error text):
+//   bccsp/utils/ecdsa.go:43-67   UnmarshalECDSASignature      -> fab::bccsp::UnmarshalECDSASignature
+//   bccsp/utils/ecdsa.go:84-92   IsLowS                       -> fab::bccsp::IsLowS
+//   bccsp/sw/ecdsa.go:41-57      verifyECDSA                  -> GPUCSP::Verify / VerifyBatch
+//   bccsp/sw/impl.go:247-270     CSP.Verify argument checks   -> GPUCSP::Verify
+//   bccsp/sw/impl.go:177-194     CSP.Hash                     -> GPUCSP::Hash
+//   bccsp/sw/keyimport.go:103-134 public-key import           -> GPUCSP::KeyImport (on-curve gate)
+//   msp/identities.go:169-196    identity.Verify              -> GPUCSP::IdentityVerifyBatch
+// There is no CPU implementation of the curve arithmetic or of SHA-256 in here: every verdict comes
+// from the HIP kernels through the C ABI; without a device fabgpu_init fails and so does this layer.
+#include "bccsp_host.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+#include "p256_point.h"
+
+namespace fab {
+namespace bccsp {
+
+// ------------------------------------------------------------------------------------------------
+// encoding/asn1 (Go) strictness for SEQUENCE { INTEGER r, INTEGER s }
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct TL {
+    size_t len = 0;
+    const char* err = nullptr;
+};
+
+// Go asn1.go parseTagAndLength + the tag comparison of parseField, for a single expected identifier octet.
+TL parse_tl(const uint8_t* b, size_t n, size_t& off, uint8_t want) {
+    TL r;
+    uint8_t id = b[off++];
+    if ((id & 0x1F) == 0x1F) {
+        // base-128 tag number: whatever it decodes to it is neither SEQUENCE(16) nor INTEGER(2) in minimal form
+        r.err = "asn1: structure error: tags don't match";
+        // Go may report a syntax error first (truncated / non-minimal tag); all are unmarshalling failures
+        return r;
+    }
+    if (off >= n) { r.err = "asn1: syntax error: truncated tag or length"; return r; }
+    uint8_t l0 = b[off++];
+    if (!(l0 & 0x80)) {
+        r.len = l0;
+    } else {
+        int nb = l0 & 0x7F;
+        if (nb == 0) { r.err = "asn1: syntax error: indefinite length found (not DER)"; return r; }
+        size_t L = 0;
+        for (int i = 0; i < nb; i++) {
+            if (off >= n) { r.err = "asn1: syntax error: truncated tag or length"; return r; }
+            if (L >= ((size_t)1 << 23)) { r.err = "asn1: structure error: length too large"; return r; }
+            L = (L << 8) | b[off++];
+            if (L == 0) { r.err = "asn1: structure error: superfluous leading zeros in length"; return r; }
+        }
+        if (L < 0x80) { r.err = "asn1: structure error: non-minimal length"; return r; }
+        r.len = L;
+    }
+    if (id != want) { r.err = "asn1: structure error: tags don't match"; return r; }
+    if (r.len > n - off) { r.err = "asn1: syntax error: data truncated"; return r; }
+    return r;
+}
+
+const char* parse_bigint(const uint8_t* b, size_t n, size_t& off, BigInt& out) {
+    if (off == n) return "asn1: syntax error: sequence truncated";
+    TL tl = parse_tl(b, n, off, 0x02);
+    if (tl.err) return tl.err;
+    const uint8_t* p = b + off;
+    size_t L = tl.len;
+    off += L;
+    if (L == 0) return "asn1: structure error: empty integer";
+    if (L > 1 && ((p[0] == 0x00 && !(p[1] & 0x80)) || (p[0] == 0xFF && (p[1] & 0x80))))
+        return "asn1: structure error: integer not minimally-encoded";
+    out.negative = (p[0] & 0x80) != 0;
+    out.twos.assign(p, p + L);
+    return nullptr;
+}
+
+}  // namespace
+
+bool BigInt::is_zero() const {
+    for (uint8_t c : twos) if (c) return false;
+    return true;
+}
+int BigInt::sign() const { return negative ? -1 : (is_zero() ? 0 : 1); }
+// magnitude bytes (big-endian, no leading zeros) of a non-negative value
+std::vector<uint8_t> BigInt::magnitude() const {
+    std::vector<uint8_t> m;
+    if (!negative) {
+        size_t i = 0;
+        while (i < twos.size() && twos[i] == 0) i++;
+        m.assign(twos.begin() + i, twos.end());
+    } else {  // two's complement negate
+        m = twos;
+        for (auto& c : m) c = (uint8_t)~c;
+        for (size_t i = m.size(); i-- > 0;) { if (++m[i] != 0) break; }
+        size_t i = 0;
+        while (i < m.size() && m[i] == 0) i++;
+        m.erase(m.begin(), m.begin() + i);
+    }
+    return m;
+}
+std::string BigInt::decimal() const {  // big.Int %s
+    std::vector<uint8_t> m = magnitude();
+    if (m.empty()) return "0";
+    std::string digits;
+    while (!m.empty()) {
+        uint32_t rem = 0;
+        std::vector<uint8_t> q;
+        q.reserve(m.size());
+        for (uint8_t c : m) {
+            uint32_t cur = (rem << 8) | c;
+            uint8_t d = (uint8_t)(cur / 10);
+            rem = cur % 10;
+            if (!q.empty() || d) q.push_back(d);
+        }
+        digits.push_back((char)('0' + rem));
+        m.swap(q);
+    }
+    if (negative) digits.push_back('-');
+    std::reverse(digits.begin(), digits.end());
+    return digits;
+}
+bool BigInt::fits256() const { return !negative && magnitude().size() <= 32; }
+void BigInt::to_be32(uint8_t* out) const {  // low 256 bits of the magnitude
+    std::vector<uint8_t> m = magnitude();
+    memset(out, 0, 32);
+    size_t k = std::min<size_t>(32, m.size());
+    memcpy(out + 32 - k, m.data() + (m.size() - k), k);
+}
+
+// bccsp/utils/ecdsa.go:43-67
+Error UnmarshalECDSASignature(const uint8_t* raw, size_t len, BigInt& R, BigInt& S) {
+    const char* aerr = nullptr;
+    do {
+        if (len == 0) { aerr = "asn1: syntax error: sequence truncated"; break; }
+        size_t off = 0;
+        TL tl = parse_tl(raw, len, off, 0x30);
+        if (tl.err) { aerr = tl.err; break; }
+        const uint8_t* in = raw + off;   // bytes after the SEQUENCE are `rest`: discarded (ecdsa.go:46)
+        size_t ioff = 0;
+        if ((aerr = parse_bigint(in, tl.len, ioff, R))) break;
+        if ((aerr = parse_bigint(in, tl.len, ioff, S))) break;
+        // trailing content inside the SEQUENCE is allowed by Go's struct parser
+    } while (0);
+    if (aerr) return Error(std::string("failed unmashalling signature [") + aerr + "]");
+    if (R.sign() != 1) return Error("invalid signature, R must be larger than zero");
+    if (S.sign() != 1) return Error("invalid signature, S must be larger than zero");
+    return Error();
+}
+
+static const uint8_t HALF_N_BE[32] = {0x7f, 0xff, 0xff, 0xff, 0x80, 0x00, 0x00, 0x00, 0x7f, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
+                                      0xde, 0x73, 0x7d, 0x56, 0xd3, 0x8b, 0xcf, 0x42, 0x79, 0xdc, 0xe5, 0x61, 0x7e, 0x31, 0x92, 0xa8};
+const char* HALF_ORDER_DECIMAL = "57896044605178124381348723474703786764998477612067880171211129530534256022184";
+
+// bccsp/utils/ecdsa.go:84-92: s.Cmp(halfOrder) != 1
+bool IsLowS(const BigInt& S) {
+    if (S.negative) return true;
+    if (!S.fits256()) return false;
+    uint8_t s32[32];
+    S.to_be32(s32);
+    return memcmp(s32, HALF_N_BE, 32) <= 0;
+}
+
+bool PublicKeyOnCurve(const uint8_t* qx32, const uint8_t* qy32) {
+    const u256 P = FAB_P256_P;
+    u256 x, y, mx, my;
+    from_be32(x, qx32);
+    from_be32(y, qy32);
+    if (!lt256(x, P) || !lt256(y, P)) return false;
+    fp_to_mont(mx, x);
+    fp_to_mont(my, y);
+    return on_curve_mont(mx, my);
+}
+
+void HashToInt(const uint8_t* digest, size_t len, uint8_t* e32) {
+    if (len > 32) len = 32;
+    memset(e32, 0, 32);
+    memcpy(e32 + 32 - len, digest, len);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GPUCSP
+// ------------------------------------------------------------------------------------------------
+Error GPUCSP::New(const fabgpu_cfg* cfg, std::unique_ptr<GPUCSP>& out) {
+    fabgpu_ctx* ctx = nullptr;
+    int rc = fabgpu_init(cfg, &ctx);
+    if (rc != FABGPU_OK) return Error(std::string("Failed initializing GPU BCCSP: ") + fabgpu_strerror(rc));
+    out.reset(new GPUCSP(ctx));
+    return Error();
+}
+GPUCSP::~GPUCSP() { fabgpu_shutdown(ctx_); }
+
+// bccsp/sw/keyimport.go:103-112 (ECDSAGoPublicKeyImportOpts) with the curve check x509 parsing implies
+Error GPUCSP::KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out) const {
+    if (!qx32 || !qy32) return Error("Invalid raw. It must not be nil.");
+    memcpy(out.x, qx32, 32);
+    memcpy(out.y, qy32, 32);
+    out.on_curve = PublicKeyOnCurve(qx32, qy32);
+    return Error();
+}
+
+// bccsp/sw/impl.go:177-194
+Error GPUCSP::Hash(const uint8_t* msg, size_t len, const HashOpts* opts, std::vector<uint8_t>& digest) const {
+    if (opts == nullptr) return Error("Invalid opts. It must not be nil.");
+    if (opts->algorithm != "SHA256") return Error("Unsupported 'HashOpt' provided [" + opts->algorithm + "]");
+    uint32_t off[2] = {0, (uint32_t)len};
+    digest.assign(32, 0);
+    int rc = fabgpu_sha256_batch(ctx_, 1, msg, off, digest.data());
+    if (rc != FABGPU_OK) return Error(std::string("Failed hashing with opts [SHA256]: ") + fabgpu_strerror(rc));
+    return Error();
+}
+
+namespace {
+// outcome of the pre-arithmetic gates for one item; `submit` means the device decides
+struct Gate {
+    bool submit = false;
+    VerifyResult res;
+    uint8_t r32[32], s32[32], e32[32];
+};
+
+Gate gate_item(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) {
+    Gate g;
+    memset(g.r32, 0, 32); memset(g.s32, 0, 32); memset(g.e32, 0, 32);
+    g.r32[31] = g.s32[31] = 1;
+    // bccsp/sw/impl.go:249-257
+    if (k == nullptr) { g.res = {false, Error("Invalid Key. It must not be nil.")}; return g; }
+    if (siglen == 0) { g.res = {false, Error("Invalid signature. Cannot be empty.")}; return g; }
+    if (dlen == 0) { g.res = {false, Error("Invalid digest. Cannot be empty.")}; return g; }
+    const std::string wrap = "Failed verifing with opts [<nil>]: ";   // errors.Wrapf at impl.go:266
+    BigInt R, S;
+    Error e = UnmarshalECDSASignature(sig, siglen, R, S);
+    if (!e.ok()) { g.res = {false, Error(wrap + "Failed unmashalling signature [" + e.msg + "]")}; return g; }
+    if (!IsLowS(S)) {
+        g.res = {false, Error(wrap + "Invalid S. Must be smaller than half the order [" + S.decimal() + "][" + HALF_ORDER_DECIMAL + "].")};
+        return g;
+    }
+    if (!R.fits256()) { g.res = {false, Error()}; return g; }   // r >= 2^256 > n: ecdsa.Verify returns false
+    if (!k->on_curve) {
+        g.res = {false, Error("public key is not on P-256: the GPU provider does not decide this tuple (use bccsp/sw)")};
+        g.res.needs_sw = true;
+        return g;
+    }
+    R.to_be32(g.r32);
+    S.to_be32(g.s32);
+    HashToInt(digest, dlen, g.e32);
+    g.submit = true;
+    return g;
+}
+}  // namespace
+
+// bccsp/sw/impl.go:247-270 -> bccsp/sw/ecdsa.go:41-57, batched
+Error GPUCSP::VerifyBatch(const std::vector<VerifyItem>& items, std::vector<VerifyResult>& results) const {
+    const size_t n = items.size();
+    results.assign(n, VerifyResult());
+    std::vector<uint8_t> qx(n * 32), qy(n * 32), e(n * 32), r(n * 32), s(n * 32), st(n);
+    std::vector<uint64_t> bits((n + 63) / 64);
+    std::vector<uint8_t> submitted(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const VerifyItem& it = items[i];
+        Gate g = gate_item(it.key, it.sig, it.siglen, it.digest, it.dlen);
+        results[i] = g.res;
+        submitted[i] = g.submit;
+        // non-submitted slots carry a harmless dummy tuple so the batch stays dense
+        static const uint8_t GX[32] = {0x6b, 0x17, 0xd1, 0xf2, 0xe1, 0x2c, 0x42, 0x47, 0xf8, 0xbc, 0xe6, 0xe5, 0x63, 0xa4, 0x40, 0xf2,
+                                       0x77, 0x03, 0x7d, 0x81, 0x2d, 0xeb, 0x33, 0xa0, 0xf4, 0xa1, 0x39, 0x45, 0xd8, 0x98, 0xc2, 0x96};
+        static const uint8_t GY[32] = {0x4f, 0xe3, 0x42, 0xe2, 0xfe, 0x1a, 0x7f, 0x9b, 0x8e, 0xe7, 0xeb, 0x4a, 0x7c, 0x0f, 0x9e, 0x16,
+                                       0x2b, 0xce, 0x33, 0x57, 0x6b, 0x31, 0x5e, 0xce, 0xcb, 0xb6, 0x40, 0x68, 0x37, 0xbf, 0x51, 0xf5};
+        memcpy(&qx[32 * i], g.submit ? it.key->x : GX, 32);
+        memcpy(&qy[32 * i], g.submit ? it.key->y : GY, 32);
+        memcpy(&e[32 * i], g.e32, 32);
+        memcpy(&r[32 * i], g.r32, 32);
+        memcpy(&s[32 * i], g.s32, 32);
+    }
+    if (n == 0) return Error();
+    int rc = fabgpu_p256_verify_batch(ctx_, n, qx.data(), qy.data(), e.data(), r.data(), s.data(), bits.data(), st.data());
+    if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
+    for (size_t i = 0; i < n; i++) {
+        if (!submitted[i]) continue;
+        bool bit = (bits[i >> 6] >> (i & 63)) & 1;
+        // after the host gates the device can only answer valid / arithmetic reject / r >= n
+        results[i].valid = bit && st[i] == FABGPU_ST_VALID;
+        results[i].err = Error();
+        if (st[i] == FABGPU_ST_HIGH_S || st[i] == FABGPU_ST_OFF_CURVE)   // cannot happen: host gate already decided
+            return Error("internal inconsistency between host gate and device status");
+    }
+    return Error();
+}
+
+VerifyResult GPUCSP::Verify(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) const {
+    std::vector<VerifyItem> items(1);
+    items[0] = {k, sig, siglen, digest, dlen};
+    std::vector<VerifyResult> res;
+    Error e = VerifyBatch(items, res);
+    if (!e.ok()) {
+        VerifyResult r;
+        r.err = e;
+        r.infrastructure = true;
+        return r;
+    }
+    return res[0];
+}
+
+// msp/identities.go:169-196 over a flattened batch: digest = Hash(msg); Verify(pk, sig, digest); the hash is fused
+// into the verify kernel.  out[i]: "" (nil) or the error text identity.Verify would return.
+Error GPUCSP::IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::vector<std::string>& out) const {
+    const size_t n = items.size();
+    out.assign(n, std::string());
+    if (n == 0) return Error();
+    std::vector<uint8_t> qx(n * 32), qy(n * 32), r(n * 32), s(n * 32), st(n), arena;
+    std::vector<uint32_t> off(n + 1);
+    std::vector<uint64_t> bits((n + 63) / 64);
+    std::vector<uint8_t> submitted(n, 0);
+    static const uint8_t one_digest[1] = {1};
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) total += items[i].msglen;
+    if (total > 0xFFFFFFF0ull) return Error("message arena exceeds 32-bit offsets");
+    arena.reserve(total + 4);
+    for (size_t i = 0; i < n; i++) {
+        const IdentityItem& it = items[i];
+        off[i] = (uint32_t)arena.size();
+        arena.insert(arena.end(), it.msg, it.msg + it.msglen);
+        // the digest is non-empty by construction (SHA-256), so only key / signature gates apply here
+        Gate g = gate_item(it.key, it.sig, it.siglen, one_digest, 1);
+        submitted[i] = g.submit;
+        if (!g.submit) {
+            if (g.res.err.ok()) out[i] = "The signature is invalid";
+            else out[i] = "could not determine the validity of the signature: " + g.res.err.msg;
+        }
+        const ECDSAPublicKey* k = it.key;
+        if (g.submit) { memcpy(&qx[32 * i], k->x, 32); memcpy(&qy[32 * i], k->y, 32); }
+        else { qx[32 * i + 31] = 1; qy[32 * i + 31] = 1; }   // off-curve filler: device answers status 4, ignored
+        memcpy(&r[32 * i], g.r32, 32);
+        memcpy(&s[32 * i], g.s32, 32);
+    }
+    off[n] = (uint32_t)arena.size();
+    int rc = fabgpu_sha256_p256_verify_batch(ctx_, n, arena.data(), off.data(), qx.data(), qy.data(), r.data(), s.data(), bits.data(), st.data());
+    if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
+    for (size_t i = 0; i < n; i++) {
+        if (!submitted[i]) continue;
+        bool ok = ((bits[i >> 6] >> (i & 63)) & 1) && st[i] == FABGPU_ST_VALID;
+        out[i] = ok ? "" : "The signature is invalid";
+    }
+    return Error();
+}
+
+}  // namespace bccsp
+}  // namespace fab
+
+// ------------------------------------------------------------------------------------------------
+// C entry points of include/fabgpu.h that are pure host logic
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int fabgpu_ecdsa_unmarshal_signature(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32, int* flags) {
+    fab::bccsp::BigInt R, S;
+    fab::bccsp::Error e = fab::bccsp::UnmarshalECDSASignature(sig, len, R, S);
+    if (!e.ok()) {
+        if (e.msg.find("R must be larger") != std::string::npos) return 2;
+        if (e.msg.find("S must be larger") != std::string::npos) return 3;
+        return 1;
+    }
+    if (r32) R.to_be32(r32);
+    if (s32) S.to_be32(s32);
+    if (flags) *flags = (R.fits256() ? 0 : 1) | (S.fits256() ? 0 : 2);
+    return 0;
+}
+int fabgpu_ecdsa_is_low_s(const uint8_t* s32) { return memcmp(s32, fab::bccsp::HALF_N_BE, 32) <= 0 ? 1 : 0; }
+int fabgpu_p256_pubkey_on_curve(const uint8_t* qx32, const uint8_t* qy32) { return fab::bccsp::PublicKeyOnCurve(qx32, qy32) ? 1 : 0; }
+void fabgpu_hash_to_int(const uint8_t* digest, size_t len, uint8_t* e32) { fab::bccsp::HashToInt(digest, len, e32); }
+
+}  // extern "C"

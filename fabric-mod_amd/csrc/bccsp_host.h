@@ -1,0 +1,88 @@
+// C++ host mirror of the reference's BCCSP surface for the block-validation signature path.
+// Same names, argument meaning and error text as bccsp/bccsp.go:90-134 (Hash / Verify / KeyImport),
+// bccsp/utils/ecdsa.go and msp/identities.go:169-196; every verdict comes from the GPU through
+// include/fabgpu.h.  The Go provider shown in INTEGRATION.md is the production binding; this layer is what
+// the parity tests drive (Go is not installed in the build image).
+#pragma once
+#include <stdint.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/fabgpu.h"
+
+namespace fab {
+namespace bccsp {
+
+struct Error {  // Go `error`: empty == nil
+    std::string msg;
+    bool nil = true;
+    Error() {}
+    explicit Error(const std::string& m) : msg(m), nil(false) {}
+    bool ok() const { return nil; }
+};
+
+struct BigInt {  // *big.Int as produced by encoding/asn1: two's complement, minimal
+    std::vector<uint8_t> twos;
+    bool negative = false;
+    bool is_zero() const;
+    int sign() const;
+    std::vector<uint8_t> magnitude() const;
+    std::string decimal() const;
+    bool fits256() const;
+    void to_be32(uint8_t* out) const;
+};
+
+Error UnmarshalECDSASignature(const uint8_t* raw, size_t len, BigInt& R, BigInt& S);  // bccsp/utils/ecdsa.go:43-67
+bool IsLowS(const BigInt& S);                                                          // bccsp/utils/ecdsa.go:84-92
+bool PublicKeyOnCurve(const uint8_t* qx32, const uint8_t* qy32);
+void HashToInt(const uint8_t* digest, size_t len, uint8_t* e32);
+extern const char* HALF_ORDER_DECIMAL;
+
+struct ECDSAPublicKey {  // bccsp/sw/ecdsakey.go:72-117 (X, Y only)
+    uint8_t x[32], y[32];
+    bool on_curve = false;
+};
+struct HashOpts {  // bccsp/hashopts.go:20-70
+    std::string algorithm;  // "SHA256" is the only family on this path (msp/identities.go:216-224)
+};
+struct VerifyItem {
+    const ECDSAPublicKey* key;
+    const uint8_t* sig;
+    size_t siglen;
+    const uint8_t* digest;
+    size_t dlen;
+};
+struct VerifyResult {  // (valid bool, err error)
+    bool valid = false;
+    Error err;
+    bool needs_sw = false;        // tuple the GPU provider refuses to decide (off-curve key)
+    bool infrastructure = false;  // device failure: caller falls back to bccsp/sw
+};
+struct IdentityItem {
+    const ECDSAPublicKey* key;
+    const uint8_t* msg;
+    size_t msglen;
+    const uint8_t* sig;
+    size_t siglen;
+};
+
+class GPUCSP {
+   public:
+    static Error New(const fabgpu_cfg* cfg, std::unique_ptr<GPUCSP>& out);
+    ~GPUCSP();
+    Error KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out) const;
+    Error Hash(const uint8_t* msg, size_t len, const HashOpts* opts, std::vector<uint8_t>& digest) const;
+    VerifyResult Verify(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) const;
+    Error VerifyBatch(const std::vector<VerifyItem>& items, std::vector<VerifyResult>& results) const;
+    Error IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::vector<std::string>& out) const;
+    fabgpu_ctx* ctx() const { return ctx_; }
+
+   private:
+    explicit GPUCSP(fabgpu_ctx* c) : ctx_(c) {}
+    fabgpu_ctx* ctx_;
+};
+
+}  // namespace bccsp
+}  // namespace fab

@@ -1,0 +1,311 @@
+// C-ABI shim (include/fabgpu.h) over the HIP kernels: context, staging, launches.
+// One context = one GPU + one HIP stream; host entry points stage through pinned buffers the context
+// owns (nothing of the caller's memory is retained after return - cgo pointer rules).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/fabgpu.h"
+#include "kernels.h"
+#include "p256_tables.h"
+
+using namespace fab;
+
+namespace {
+
+struct Buf {  // growable pinned-host + device pair
+    void* h = nullptr;
+    void* d = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return FABGPU_OK;
+        release();
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipHostMalloc(&h, want, hipHostMallocDefault) != hipSuccess) { h = nullptr; return FABGPU_ENOMEM; }
+        if (hipMalloc(&d, want) != hipSuccess) { hipHostFree(h); h = nullptr; d = nullptr; return FABGPU_ENOMEM; }
+        cap = want;
+        return FABGPU_OK;
+    }
+    void release() {
+        if (h) hipHostFree(h);
+        if (d) hipFree(d);
+        h = d = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct fabgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_gtab = nullptr;
+    std::mutex mu;
+    Buf fields;   // qx|qy|e|r|s
+    Buf arena;    // message bytes
+    Buf offs;     // u32 offsets
+    Buf out;      // verdict words | status bytes | digests
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        hipGetDevice(&prev);
+        if (prev != dev) hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) hipSetDevice(prev);
+    }
+};
+
+int hip_to_rc(hipError_t e) { return e == hipSuccess ? FABGPU_OK : (e == hipErrorOutOfMemory ? FABGPU_ENOMEM : FABGPU_ELAUNCH); }
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int fabgpu_abi_version(void) { return FABGPU_ABI_VERSION; }
+
+const char* fabgpu_strerror(int code) {
+    switch (code) {
+        case FABGPU_OK: return "ok";
+        case FABGPU_EINVAL: return "invalid argument";
+        case FABGPU_ENODEV: return "no usable gfx950 device (HIP runtime/device unavailable); fall back to bccsp/sw";
+        case FABGPU_ENOMEM: return "host or device allocation failed";
+        case FABGPU_ELAUNCH: return "HIP launch/copy/execution failure";
+        case FABGPU_ETOOBIG: return "batch or arena exceeds 32-bit offsets";
+        default: return "unknown fabgpu error";
+    }
+}
+
+int fabgpu_device_count(fabgpu_ctx*) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return FABGPU_ENODEV;
+    return n;
+}
+
+int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
+    if (!out) return FABGPU_EINVAL;
+    *out = nullptr;
+    if (cfg && cfg->flags != 0) return FABGPU_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return FABGPU_ENODEV;
+    }
+    if (dev >= ndev) return FABGPU_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return FABGPU_ENODEV;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FABGPU_ENODEV;  // the code object is gfx950-only
+    fabgpu_ctx* ctx = new (std::nothrow) fabgpu_ctx();
+    if (!ctx) return FABGPU_ENOMEM;
+    ctx->device = dev;
+    DeviceGuard g(dev);
+    int rc = FABGPU_OK;
+    do {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        std::vector<uint32_t> tab(G_TABLE_WORDS);
+        build_g_comb_table(tab.data());
+        if (hipMalloc((void**)&ctx->d_gtab, sizeof(uint32_t) * G_TABLE_WORDS) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
+        if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(uint32_t) * G_TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
+        if (cfg && cfg->max_batch) {
+            size_t n = cfg->max_batch;
+            if ((rc = ctx->fields.ensure(n * 160)) || (rc = ctx->offs.ensure((n + 1) * 4)) || (rc = ctx->out.ensure(n * 41 + 64))) break;
+        }
+        if (cfg && cfg->max_arena) {
+            if ((rc = ctx->arena.ensure((size_t)cfg->max_arena + 128))) break;
+        }
+    } while (0);
+    if (rc != FABGPU_OK) {
+        fabgpu_shutdown(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return FABGPU_OK;
+}
+
+void fabgpu_shutdown(fabgpu_ctx* ctx) {
+    if (!ctx) return;
+    {
+        DeviceGuard g(ctx->device);
+        if (ctx->stream) hipStreamSynchronize(ctx->stream);
+        ctx->fields.release();
+        ctx->arena.release();
+        ctx->offs.release();
+        ctx->out.release();
+        if (ctx->d_gtab) hipFree(ctx->d_gtab);
+        if (ctx->ev0) hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) hipEventDestroy(ctx->ev1);
+        if (ctx->stream) hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+float fabgpu_last_kernel_ms(fabgpu_ctx* ctx) {
+    if (!ctx || !ctx->timed) return -1.0f;
+    DeviceGuard g(ctx->device);
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ---- device-resident entry points ----------------------------------------------------------------
+int fabgpu_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* qx, const void* qy, const void* e, const void* r,
+                                 const void* s, void* verdict_bits, void* status, void* stream) {
+    if (!ctx || (n && (!qx || !qy || !e || !r || !s || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0xFFFFFFF0ull) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipEventRecord(ctx->ev0, st);
+    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, verdict_bits, status, st);
+    hipEventRecord(ctx->ev1, st);
+    ctx->timed = true;
+    return hip_to_rc(err);
+}
+
+int fabgpu_sha256_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off, void* digests,
+                            void* stream) {
+    if (!ctx || (n && (!arena || !off || !digests))) return FABGPU_EINVAL;
+    if (n > 0xFFFFFFF0ull || arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipEventRecord(ctx->ev0, st);
+    hipError_t err = launch_sha256_batch((uint32_t)n, arena, arena_bytes, off, digests, st);
+    hipEventRecord(ctx->ev1, st);
+    ctx->timed = true;
+    return hip_to_rc(err);
+}
+
+int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
+                                        const void* qx, const void* qy, const void* r, const void* s, void* verdict_bits,
+                                        void* status, void* stream) {
+    if (!ctx || (n && (!arena || !off || !qx || !qy || !r || !s || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0xFFFFFFF0ull || arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipEventRecord(ctx->ev0, st);
+    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, verdict_bits, status, st);
+    hipEventRecord(ctx->ev1, st);
+    ctx->timed = true;
+    return hip_to_rc(err);
+}
+
+// ---- host-pointer entry points (what the cgo provider binds) -----------------------------------------
+int fabgpu_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r,
+                             const uint8_t* s, uint64_t* verdict_bits, uint8_t* status) {
+    if (!ctx || (n && (!qx || !qy || !e || !r || !s || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    const size_t fb = n * 32, words = (n + 63) / 64;
+    const size_t st_off = round_up(words * 8, 64);
+    int rc;
+    if ((rc = ctx->fields.ensure(5 * fb)) || (rc = ctx->out.ensure(st_off + n))) return rc;
+    uint8_t* h = (uint8_t*)ctx->fields.h;
+    memcpy(h, qx, fb); memcpy(h + fb, qy, fb); memcpy(h + 2 * fb, e, fb); memcpy(h + 3 * fb, r, fb); memcpy(h + 4 * fb, s, fb);
+    uint8_t* d = (uint8_t*)ctx->fields.d;
+    uint8_t* dout = (uint8_t*)ctx->out.d;
+    hipError_t err = hipMemcpyAsync(d, h, 5 * fb, hipMemcpyHostToDevice, ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    rc = fabgpu_p256_verify_batch_dev(ctx, n, d, d + fb, d + 2 * fb, d + 3 * fb, d + 4 * fb, dout, status ? dout + st_off : nullptr, ctx->stream);
+    if (rc) return rc;
+    err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    memcpy(verdict_bits, ctx->out.h, words * 8);
+    if (status) memcpy(status, (uint8_t*)ctx->out.h + st_off, n);
+    return FABGPU_OK;
+}
+
+// copy the span of the arena the offsets reference; returns rebased offsets in ctx->offs.h
+static int stage_messages(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off, size_t* arena_bytes_out) {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (off[i + 1] < off[i]) return FABGPU_EINVAL;
+        if (off[i] < lo) lo = off[i];
+        if (off[i + 1] > hi) hi = off[i + 1];
+    }
+    if (n == 0) { lo = hi = 0; }
+    size_t span = hi >= lo ? (size_t)hi - lo : 0;
+    int rc;
+    if ((rc = ctx->arena.ensure(round_up(span, 4) + 128)) || (rc = ctx->offs.ensure((n + 1) * 4))) return rc;
+    if (span) memcpy(ctx->arena.h, arena + lo, span);
+    memset((uint8_t*)ctx->arena.h + span, 0, round_up(span, 4) + 64 - span);
+    uint32_t* ho = (uint32_t*)ctx->offs.h;
+    for (size_t i = 0; i <= n; i++) ho[i] = off[i] - lo;
+    hipError_t err = hipMemcpyAsync(ctx->arena.d, ctx->arena.h, round_up(span, 4) + 64, hipMemcpyHostToDevice, ctx->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(ctx->offs.d, ctx->offs.h, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+    *arena_bytes_out = round_up(span, 4) + 64;
+    return hip_to_rc(err);
+}
+
+int fabgpu_sha256_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off, uint8_t* digests) {
+    if (!ctx || (n && (!off || !digests))) return FABGPU_EINVAL;
+    if (n > 0x7FFFFFF0ull / 32) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    if (!arena && off[n] != off[0]) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    size_t ab = 0;
+    int rc = stage_messages(ctx, n, arena, off, &ab);
+    if (rc) return rc;
+    if ((rc = ctx->out.ensure(n * 32))) return rc;
+    rc = fabgpu_sha256_batch_dev(ctx, n, ctx->arena.d, ab, ctx->offs.d, ctx->out.d, ctx->stream);
+    if (rc) return rc;
+    hipError_t err = hipMemcpyAsync(ctx->out.h, ctx->out.d, n * 32, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    memcpy(digests, ctx->out.h, n * 32);
+    return FABGPU_OK;
+}
+
+int fabgpu_sha256_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off, const uint8_t* qx,
+                                    const uint8_t* qy, const uint8_t* r, const uint8_t* s, uint64_t* verdict_bits, uint8_t* status) {
+    if (!ctx || (n && (!off || !qx || !qy || !r || !s || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    if (!arena && off[n] != off[0]) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    size_t ab = 0;
+    int rc = stage_messages(ctx, n, arena, off, &ab);
+    if (rc) return rc;
+    const size_t fb = n * 32, words = (n + 63) / 64;
+    const size_t st_off = round_up(words * 8, 64);
+    if ((rc = ctx->fields.ensure(4 * fb)) || (rc = ctx->out.ensure(st_off + n))) return rc;
+    uint8_t* h = (uint8_t*)ctx->fields.h;
+    memcpy(h, qx, fb); memcpy(h + fb, qy, fb); memcpy(h + 2 * fb, r, fb); memcpy(h + 3 * fb, s, fb);
+    uint8_t* d = (uint8_t*)ctx->fields.d;
+    uint8_t* dout = (uint8_t*)ctx->out.d;
+    hipError_t err = hipMemcpyAsync(d, h, 4 * fb, hipMemcpyHostToDevice, ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    rc = fabgpu_sha256_p256_verify_batch_dev(ctx, n, ctx->arena.d, ab, ctx->offs.d, d, d + fb, d + 2 * fb, d + 3 * fb, dout,
+                                             status ? dout + st_off : nullptr, ctx->stream);
+    if (rc) return rc;
+    err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    memcpy(verdict_bits, ctx->out.h, words * 8);
+    if (status) memcpy(status, (uint8_t*)ctx->out.h + st_off, n);
+    return FABGPU_OK;
+}
+
+}  // extern "C"

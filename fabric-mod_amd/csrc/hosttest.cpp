@@ -1,0 +1,66 @@
+// HOST-ONLY TEST HOOKS - built into libfabgpu_hosttest.so, never into the product library libfabgpu.so.
+// They run the SAME header code the kernels are compiled from (fp256.h / p256_point.h / p256_tables.h) on
+// the CPU so that the arithmetic and the verification core can be unit-tested in a container without a GPU.
+// Nothing in the product path links or loads this file.
+#include <string.h>
+
+#include <vector>
+
+#include "p256_tables.h"
+
+using namespace fab;
+
+static const uint32_t* gtab() {
+    static std::vector<uint32_t> tab = [] { std::vector<uint32_t> t(G_TABLE_WORDS); build_g_comb_table(t.data()); return t; }();
+    return tab.data();
+}
+
+extern "C" {
+
+// op: 0 fp_mul 1 fp_sqr 2 fp_add 3 fp_sub 4 fp_to_mont 5 fp_from_mont 6 fn_mul 7 fn_sqr 8 fn_to_mont 9 fn_from_mont 10 fn_inv 11 fp_inv
+void hosttest_fieldop(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
+    u256 a, b, r;
+    from_be32(a, a32);
+    from_be32(b, b32);
+    switch (op) {
+        case 0: fp_mul(r, a, b); break;
+        case 1: fp_sqr(r, a); break;
+        case 2: fp_add(r, a, b); break;
+        case 3: fp_sub(r, a, b); break;
+        case 4: fp_to_mont(r, a); break;
+        case 5: fp_from_mont(r, a); break;
+        case 6: fn_mul(r, a, b); break;
+        case 7: fn_sqr(r, a); break;
+        case 8: fn_to_mont(r, a); break;
+        case 9: fn_from_mont(r, a); break;
+        case 10: fn_inv(r, a); break;
+        case 11: fp_inv(r, a); break;
+        default: r = zero256();
+    }
+    to_be32(out32, r);
+}
+
+// the verification core on the CPU, same template the kernel instantiates
+void hosttest_verify_core(size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r, const uint8_t* s,
+                          uint8_t* status) {
+    FlatGTab gt{gtab()};
+    for (size_t i = 0; i < n; i++) {
+        u256 vqx, vqy, ve, vr, vs;
+        from_be32(vqx, qx + 32 * i); from_be32(vqy, qy + 32 * i); from_be32(ve, e + 32 * i);
+        from_be32(vr, r + 32 * i); from_be32(vs, s + 32 * i);
+        jac qtab[16];
+        status[i] = (uint8_t)p256_verify_core(vqx, vqy, ve, vr, vs, gt, qtab);
+    }
+}
+
+// comb table entry (window, digit) in plain affine coordinates
+void hosttest_gtab_entry(int window, int digit, uint8_t* x32, uint8_t* y32) {
+    FlatGTab gt{gtab()};
+    u256 x, y, px, py;
+    gt.load(window, (uint32_t)digit, x, y);
+    fp_from_mont(px, x);
+    fp_from_mont(py, y);
+    to_be32(x32, px);
+    to_be32(y32, py);
+}
+}

@@ -1,0 +1,218 @@
+// HIP kernels for gfx950 (MI355X / CDNA4): batched SHA-256, batched ECDSA P-256 verify, and the fused
+// hash+verify kernel.  One signature / message per lane, 64-lane wavefronts, verdicts packed with a
+// wave ballot.  No MFMA: this is 32-bit integer VALU work (v_mad_u64_u32 / v_addc_co_u32 carry chains
+// for the big-number part, v_alignbit / v_xor / v_add for SHA-256).
+//
+// Replaces (reference, all CPU): bccsp/sw/hash.go:29-33, bccsp/sw/ecdsa.go:41-57 -> crypto/ecdsa.Verify,
+// called per signature from msp/identities.go:169-196.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "p256_tables.h"
+
+namespace fab {
+
+// ------------------------------------------------------------------------------------------------
+// SHA-256 (FIPS 180-4), one message per lane, ragged arena
+// ------------------------------------------------------------------------------------------------
+__device__ __constant__ uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+__device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i & 15];
+        uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+// Hash message [start, start+len) of the arena; arena_words = number of readable dwords of the arena
+// allocation (loads are clamped to it, so no out-of-bounds read whatever the offsets say).
+// The block loop bound is made wave-uniform (max over the wave); lanes past their own block count idle.
+__device__ __forceinline__ void sha256_lane(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t start,
+                                            uint32_t len, bool active, uint32_t h[8]) {
+    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+    h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+    uint32_t nblk = active ? ((len + 9 + 63) >> 6) : 0;
+    uint32_t maxblk = nblk;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        uint32_t other = __shfl_xor(maxblk, o, 64);
+        maxblk = other > maxblk ? other : maxblk;
+    }
+    maxblk = __builtin_amdgcn_readfirstlane(maxblk);
+    const uint32_t shift = start & 3u;                 // byte misalignment of this lane's message
+    const uint32_t last_word = arena_words ? arena_words - 1 : 0;
+    for (uint32_t blk = 0; blk < maxblk; blk++) {
+        uint32_t w[16];
+        uint32_t pos = blk << 6;                       // byte position of this block inside the message
+        uint32_t wi = (start + pos) >> 2;              // first aligned dword
+        uint32_t raw[17];
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            uint32_t idx = wi + k;
+            idx = idx < last_word ? idx : last_word;
+            raw[k] = arena32[idx];
+        }
+        bool full = pos + 64 <= len;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            // little-endian funnel shift to the message's byte phase, then to big-endian
+            uint32_t v = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], shift);
+            v = __builtin_bswap32(v);
+            if (!full) {
+                uint32_t p = pos + 4 * k;              // byte position of this word
+                int32_t rem = (int32_t)len - (int32_t)p;  // message bytes left at this word
+                uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * rem)));
+                v &= keep;
+                if (rem >= 0 && rem < 4) v |= 0x80u << (24 - 8 * rem);
+            }
+            w[k] = v;
+        }
+        if (blk + 1 == nblk) {                          // the lane's final block carries the bit length
+            w[14] = len >> 29;
+            w[15] = len << 3;
+        }
+        if (blk < nblk) sha256_compress(h, w);
+    }
+}
+
+__global__ void __launch_bounds__(256) sha256_batch_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                            const uint32_t* __restrict__ off, uint32_t* __restrict__ digests) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < n;
+    uint32_t ic = active ? i : (n - 1);
+    uint32_t start = off[ic], end = off[ic + 1];
+    uint32_t h[8];
+    sha256_lane(arena32, arena_words, start, end - start, active, h);
+    if (active) {
+        uint4* out = reinterpret_cast<uint4*>(digests + 8 * (size_t)i);
+        out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+        out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ECDSA P-256 verify
+// ------------------------------------------------------------------------------------------------
+// 32-byte big-endian field i of an SoA array -> limbs. Two coalesced 16-byte loads per lane.
+__device__ __forceinline__ void load_be_field(u256& v, const uint8_t* __restrict__ base, uint32_t i) {
+    const uint4* p = reinterpret_cast<const uint4*>(base + 32 * (size_t)i);
+    uint4 hi = p[0], lo = p[1];
+    v.w[7] = __builtin_bswap32(hi.x); v.w[6] = __builtin_bswap32(hi.y);
+    v.w[5] = __builtin_bswap32(hi.z); v.w[4] = __builtin_bswap32(hi.w);
+    v.w[3] = __builtin_bswap32(lo.x); v.w[2] = __builtin_bswap32(lo.y);
+    v.w[1] = __builtin_bswap32(lo.z); v.w[0] = __builtin_bswap32(lo.w);
+}
+
+__device__ __forceinline__ void stage_gtab(uint32_t* lds, const uint32_t* __restrict__ gtab) {
+    const uint4* src = reinterpret_cast<const uint4*>(gtab);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (int k = threadIdx.x; k < G_TABLE_WORDS / 4; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void emit_verdict(uint32_t i, bool active, uint32_t st, uint64_t* __restrict__ verdict_bits,
+                                             uint8_t* __restrict__ status) {
+    uint64_t ballot = __ballot(active && st == ST_VALID);
+    if ((threadIdx.x & 63) == 0 && active) verdict_bits[i >> 6] = ballot;   // i is a multiple of 64 here
+    if (status != nullptr && active) status[i] = (uint8_t)st;
+}
+
+__global__ void __launch_bounds__(VERIFY_BLOCK) p256_verify_kernel(uint32_t n, const uint8_t* __restrict__ qx, const uint8_t* __restrict__ qy,
+                                                                    const uint8_t* __restrict__ e, const uint8_t* __restrict__ r,
+                                                                    const uint8_t* __restrict__ s, const uint32_t* __restrict__ gtab,
+                                                                    uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint32_t g_lds[G_TABLE_WORDS];
+    stage_gtab(g_lds, gtab);
+    uint32_t i = blockIdx.x * VERIFY_BLOCK + threadIdx.x;
+    bool active = i < n;
+    uint32_t ic = active ? i : (n - 1);
+    u256 vqx, vqy, ve, vr, vs;
+    load_be_field(vqx, qx, ic);
+    load_be_field(vqy, qy, ic);
+    load_be_field(ve, e, ic);
+    load_be_field(vr, r, ic);
+    load_be_field(vs, s, ic);
+    jac qtab[16];
+    FlatGTab gt{g_lds};
+    uint32_t st = p256_verify_core(vqx, vqy, ve, vr, vs, gt, qtab);
+    emit_verdict(i, active, st, verdict_bits, status);
+}
+
+// identity.Verify fused: e = SHA-256(msg) stays in registers
+__global__ void __launch_bounds__(VERIFY_BLOCK) sha256_p256_verify_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                                           const uint32_t* __restrict__ off, const uint8_t* __restrict__ qx,
+                                                                           const uint8_t* __restrict__ qy, const uint8_t* __restrict__ r,
+                                                                           const uint8_t* __restrict__ s, const uint32_t* __restrict__ gtab,
+                                                                           uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint32_t g_lds[G_TABLE_WORDS];
+    stage_gtab(g_lds, gtab);
+    uint32_t i = blockIdx.x * VERIFY_BLOCK + threadIdx.x;
+    bool active = i < n;
+    uint32_t ic = active ? i : (n - 1);
+    uint32_t start = off[ic], end = off[ic + 1];
+    uint32_t h[8];
+    sha256_lane(arena32, arena_words, start, end - start, active, h);
+    u256 vqx, vqy, ve, vr, vs;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];   // digest big-endian -> integer limbs
+    load_be_field(vqx, qx, ic);
+    load_be_field(vqy, qy, ic);
+    load_be_field(vr, r, ic);
+    load_be_field(vs, s, ic);
+    jac qtab[16];
+    FlatGTab gt{g_lds};
+    uint32_t st = p256_verify_core(vqx, vqy, ve, vr, vs, gt, qtab);
+    emit_verdict(i, active, st, verdict_bits, status);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (host)
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(sha256_batch_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                       (const uint32_t*)off, (uint32_t*)digests);
+    return hipGetLastError();
+}
+hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
+                              const void* gtab, void* verdict_bits, void* status, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((n + VERIFY_BLOCK - 1) / VERIFY_BLOCK), block(VERIFY_BLOCK);
+    hipLaunchKernelGGL(p256_verify_kernel, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
+                       (const uint8_t*)r, (const uint8_t*)s, (const uint32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+    return hipGetLastError();
+}
+hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
+                                     const void* qy, const void* r, const void* s, const void* gtab, void* verdict_bits,
+                                     void* status, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((n + VERIFY_BLOCK - 1) / VERIFY_BLOCK), block(VERIFY_BLOCK);
+    hipLaunchKernelGGL(sha256_p256_verify_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                       (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
+                       (const uint32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+    return hipGetLastError();
+}
+
+}  // namespace fab

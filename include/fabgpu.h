@@ -1,0 +1,126 @@
+/*
+ * fabgpu.h - C ABI of the MI355X block-validation signature verifier.
+ *
+ * This is the drop-in boundary for ONE path of trustbloc/fabric-mod (Hyperledger Fabric 2.2):
+ *     msp/identities.go:169-196   identity.Verify  = bccsp.Hash(msg) ; bccsp.Verify(pk, sig, digest)
+ *     bccsp/bccsp.go:90-134       the bccsp.BCCSP interface (Hash / Verify / KeyImport)
+ *     bccsp/sw/impl.go:177-194    CSP.Hash         -> bccsp/sw/hash.go:29-33 (SHA-256)
+ *     bccsp/sw/impl.go:247-270    CSP.Verify       -> bccsp/sw/ecdsa.go:41-57 verifyECDSA
+ *     bccsp/utils/ecdsa.go:43-92  UnmarshalECDSASignature / IsLowS
+ * A Go provider (fabric-mod_amd/go/bccsp/gpu, shown in INTEGRATION.md) embeds bccsp/sw exactly like
+ * bccsp/pkcs11/pkcs11.go:35-52 does and binds the entry points below through cgo.  Nothing like this
+ * ABI exists in the reference (it is 100 % Go); SURVEY.md section 8(b) fixes its shape.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ types, no callbacks, no exceptions cross this boundary;
+ *   - every function returns FABGPU_OK (0) or a negative FABGPU_E* infrastructure error.  A non-zero
+ *     return NEVER means "signature invalid": the Go side must then fall back to bccsp/sw, because
+ *     verdicts are consensus-critical (core/committer/txvalidator/v20/validator.go:261);
+ *   - signature verdicts are data: one bit per tuple in `verdict_bits` (bit i%64 of word i/64, 1 = the
+ *     reference would return (true, nil)) and optionally one byte per tuple in `status`;
+ *   - host-pointer entry points copy inputs into staging the library owns before returning (cgo
+ *     pointer rules: nothing is retained); `_dev` entry points take HIP device pointers and a HIP
+ *     stream and are asynchronous on that stream;
+ *   - all big integers are 32-byte big-endian, struct-of-arrays: field[i] at base + 32*i.
+ *   - a context is bound to one GPU; one context per GPU, calls on one context are serialised
+ *     internally (bccsp.Verify is called from up to validatorPoolSize goroutines,
+ *     core/committer/txvalidator/v20/validator.go:198-208).
+ */
+#ifndef FABGPU_H
+#define FABGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FABGPU_ABI_VERSION 1
+
+/* ---- return codes (infrastructure only) ---- */
+#define FABGPU_OK 0
+#define FABGPU_EINVAL (-1)     /* NULL / inconsistent arguments */
+#define FABGPU_ENODEV (-2)     /* no usable gfx950 device / HIP runtime failure at init */
+#define FABGPU_ENOMEM (-3)     /* host or device allocation failed */
+#define FABGPU_ELAUNCH (-4)    /* kernel launch / execution / copy failed */
+#define FABGPU_ETOOBIG (-5)    /* batch or arena larger than the ABI's 32-bit offsets allow */
+
+/* ---- per-tuple status codes (data) ----
+ * What bccsp/sw would have returned for the tuple, see SURVEY.md Appendix A:
+ *   0  (true,  nil)
+ *   1  (false, nil)  arithmetic reject, including the point at infinity
+ *   2  (false, err)  "Invalid S. Must be smaller than half the order" (bccsp/sw/ecdsa.go:52-54)
+ *   3  r or s is zero (error at bccsp/utils/ecdsa.go:59-64) or r >= n ((false, nil) inside ecdsa.Verify)
+ *   4  public key is not a point of P-256: the reference can only reach this through
+ *      ECDSAGoPublicKeyImportOpts (bccsp/sw/keyimport.go:103-112); the caller must use bccsp/sw. */
+#define FABGPU_ST_VALID 0
+#define FABGPU_ST_BAD_MATH 1
+#define FABGPU_ST_HIGH_S 2
+#define FABGPU_ST_RANGE 3
+#define FABGPU_ST_OFF_CURVE 4
+
+typedef struct fabgpu_ctx fabgpu_ctx;
+
+typedef struct fabgpu_cfg {
+    int32_t device;      /* HIP device ordinal; -1 = the current device */
+    uint32_t max_batch;  /* staging pre-allocation hint in tuples (0 = grow on demand) */
+    uint32_t max_arena;  /* staging pre-allocation hint in message bytes (0 = grow on demand) */
+    uint32_t flags;      /* reserved, must be 0 */
+} fabgpu_cfg;
+
+/* Lifecycle.  Replaces sw.NewWithParams (bccsp/sw/new.go:39-98) for the accelerated verbs. */
+int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out);
+void fabgpu_shutdown(fabgpu_ctx* ctx);
+int fabgpu_device_count(fabgpu_ctx* ctx); /* ctx may be NULL; <0 on error */
+const char* fabgpu_strerror(int code);
+int fabgpu_abi_version(void);
+
+/* Batched ecdsa.Verify with the bccsp/sw gates (bccsp/sw/ecdsa.go:41-57 after DER decoding).
+ * e[i] is hashToInt(digest) left-padded to 32 bytes.  verdict_bits: ceil(n/64) words, required.
+ * status: n bytes or NULL. */
+int fabgpu_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e,
+                             const uint8_t* r, const uint8_t* s, uint64_t* verdict_bits, uint8_t* status);
+
+/* Batched CSP.Hash(msg, SHA256Opts) (bccsp/sw/hash.go:29-33).  Message i = arena[off[i], off[i+1]);
+ * off has n+1 entries, off[0] may be non-zero, messages may overlap / be empty. digests: n x 32 bytes. */
+int fabgpu_sha256_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off, uint8_t* digests);
+
+/* identity.Verify over a flattened batch (msp/identities.go:169-196): SHA-256 fused ahead of the verify;
+ * the digest never leaves the chip. */
+int fabgpu_sha256_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off,
+                                    const uint8_t* qx, const uint8_t* qy, const uint8_t* r, const uint8_t* s,
+                                    uint64_t* verdict_bits, uint8_t* status);
+
+/* Device-resident variants: all pointers are HIP device pointers (16-byte aligned), `stream` is a
+ * hipStream_t (NULL = the null stream).  Asynchronous; the caller synchronises the stream.
+ * arena_bytes = readable size of the arena allocation. */
+int fabgpu_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* qx, const void* qy, const void* e, const void* r,
+                                 const void* s, void* verdict_bits, void* status, void* stream);
+int fabgpu_sha256_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
+                            void* digests, void* stream);
+int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
+                                        const void* qx, const void* qy, const void* r, const void* s,
+                                        void* verdict_bits, void* status, void* stream);
+/* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
+ * launch stream (bench.py's roofline leg).  <0 if nothing was launched or events are pending. */
+float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);
+
+/* ---- host-side gates the Go provider calls before marshalling a tuple (pure CPU, no device) ---- */
+
+/* utils.UnmarshalECDSASignature (bccsp/utils/ecdsa.go:43-67) with Go encoding/asn1 strictness.
+ * Returns 0 ok; 1 asn1 failure; 2 R <= 0; 3 S <= 0.  r32/s32: low 256 bits big-endian;
+ * *flags bit0: R >= 2^256, bit1: S >= 2^256 (such values can only fail the range / low-S gates). */
+int fabgpu_ecdsa_unmarshal_signature(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32, int* flags);
+/* utils.IsLowS (bccsp/utils/ecdsa.go:84-92): 1 if s <= n>>1 else 0. */
+int fabgpu_ecdsa_is_low_s(const uint8_t* s32);
+/* Key-import gate (what x509.ParseCertificate guarantees for bccsp/sw/keyimport.go:114-134 keys):
+ * 1 if (x,y) is a point of P-256 with x,y < p, else 0. */
+int fabgpu_p256_pubkey_on_curve(const uint8_t* qx32, const uint8_t* qy32);
+/* hashToInt (Go crypto/ecdsa): leftmost 32 bytes of the digest, left-padded with zeros into e32. */
+void fabgpu_hash_to_int(const uint8_t* digest, size_t len, uint8_t* e32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FABGPU_H */

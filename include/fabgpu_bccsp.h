@@ -1,0 +1,53 @@
+/*
+ * fabgpu_bccsp.h - flat C view of the C++ host mirror (fabric-mod_amd/csrc/bccsp_host.h) so that the
+ * Python parity tests (and any other FFI) can drive the provider with the reference's vocabulary:
+ *   bccsp/sw/impl.go:177-194   CSP.Hash        -> fabgpu_csp_hash
+ *   bccsp/sw/impl.go:247-270   CSP.Verify      -> fabgpu_csp_verify / fabgpu_csp_verify_batch
+ *   msp/identities.go:169-196  identity.Verify -> fabgpu_csp_identity_verify_batch
+ * Error strings are the Go `error` text ("" == nil).  All functions return 0, or a negative FABGPU_E* when the
+ * device failed (the caller then falls back to bccsp/sw).  The production binding is cgo over fabgpu.h
+ * (INTEGRATION.md); this header adds no new capability.
+ */
+#ifndef FABGPU_BCCSP_H
+#define FABGPU_BCCSP_H
+#include "fabgpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fabgpu_csp fabgpu_csp;
+
+int fabgpu_csp_new(const fabgpu_cfg* cfg, fabgpu_csp** out, char* err, size_t errcap);
+void fabgpu_csp_free(fabgpu_csp* csp);
+fabgpu_ctx* fabgpu_csp_ctx(fabgpu_csp* csp);
+
+/* alg == NULL mirrors opts == nil. */
+int fabgpu_csp_hash(fabgpu_csp* csp, const uint8_t* msg, size_t len, const char* alg, uint8_t* digest32, char* err, size_t errcap);
+
+/* qx == NULL mirrors k == nil.  *valid = 0/1; err = Go error text or "".  *flags bit0: tuple must be decided by bccsp/sw. */
+int fabgpu_csp_verify(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,
+                      const uint8_t* digest, size_t dlen, int* valid, int* flags, char* err, size_t errcap);
+
+/* n keys (n x 32), ragged signatures and digests; valid: n bytes; errs: n * errstride chars (NUL terminated, truncated). */
+int fabgpu_csp_verify_batch(fabgpu_csp* csp, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* sig_arena,
+                            const uint32_t* sig_off, const uint8_t* dig_arena, const uint32_t* dig_off, uint8_t* valid,
+                            char* errs, size_t errstride);
+
+/* identity.Verify(msg, sig) for n (key, msg, sig) triples; errs[i] == "" means nil. */
+int fabgpu_csp_identity_verify_batch(fabgpu_csp* csp, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* msg_arena,
+                                     const uint32_t* msg_off, const uint8_t* sig_arena, const uint32_t* sig_off, char* errs,
+                                     size_t errstride);
+
+/* Synthetic block generator: n tuples, fresh P-256 keypair per signature, low-S, `invalid_permille`
+ * of them mutated (equal parts 1: flipped digest bit, 2: wrong key, 3: s -> n-s, 4: r+1); kind[i] in 0..4 records the
+ * mutation.  e_in (n x 32) gives the digests to sign (e.g. SHA-256 of synthetic messages computed by
+ * fabgpu_sha256_batch); NULL draws random digests.  e_out receives the digest the verifier should be given (for kind 1
+ * it differs from the signed one in one bit; callers in hash mode flip a message bit instead).  Pure host code,
+ * deterministic in (seed, n, e_in). */
+int fabgpu_synth_batch(size_t n, uint64_t seed, uint32_t invalid_permille, const uint8_t* e_in, uint8_t* qx, uint8_t* qy,
+                       uint8_t* e_out, uint8_t* r, uint8_t* s, uint8_t* kind, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
