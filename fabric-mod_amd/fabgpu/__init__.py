@@ -1,0 +1,388 @@
+"""fabgpu - Python host binding of the MI355X block-validation signature verifier.
+
+The reference is Go; this image has no Go toolchain, so the parity tests drive the C ABI
+(include/fabgpu.h) and the C++ host mirror (include/fabgpu_bccsp.h) through ctypes with the
+reference's vocabulary:
+
+    bccsp/bccsp.go:90-134          BCCSP.Hash / Verify / KeyImport   -> GPUCSP.hash / verify / key_import
+    bccsp/utils/ecdsa.go:43-92     UnmarshalECDSASignature / IsLowS  -> unmarshal_ecdsa_signature / is_low_s
+    msp/identities.go:169-196      identity.Verify                   -> Identity.verify
+    internal/pkg/txflags           one verdict per tx                -> validate_block_endorsements
+
+There is no CPU implementation of SHA-256 or of the curve arithmetic behind this module: if
+libfabgpu.so is missing or no gfx950 device is present, construction raises (it never falls back).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfabgpu.so")
+
+FABGPU_OK = 0
+ST_VALID, ST_BAD_MATH, ST_HIGH_S, ST_RANGE, ST_OFF_CURVE = 0, 1, 2, 3, 4
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+
+class FabgpuError(RuntimeError):
+    """Infrastructure failure (non-zero FABGPU_E*): the Go provider would fall back to bccsp/sw."""
+
+
+class BCCSPError(Exception):
+    """A non-nil Go `error` from the provider (same text as bccsp/sw)."""
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("max_batch", ctypes.c_uint32), ("max_arena", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32)]
+
+
+# every symbol include/fabgpu.h and include/fabgpu_bccsp.h declare (tests check the export list)
+ABI_SYMBOLS = [
+    "fabgpu_init", "fabgpu_shutdown", "fabgpu_device_count", "fabgpu_strerror", "fabgpu_abi_version",
+    "fabgpu_p256_verify_batch", "fabgpu_sha256_batch", "fabgpu_sha256_p256_verify_batch",
+    "fabgpu_p256_verify_batch_dev", "fabgpu_sha256_batch_dev", "fabgpu_sha256_p256_verify_batch_dev",
+    "fabgpu_last_kernel_ms", "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
+    "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
+    "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_hash", "fabgpu_csp_verify",
+    "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_synth_batch",
+]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libfabgpu.so (built in-tree by __graft_entry__.build()). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise FabgpuError("libfabgpu.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % _LIB_PATH)
+    L = ctypes.CDLL(_LIB_PATH)
+    L.fabgpu_strerror.restype = ctypes.c_char_p
+    L.fabgpu_strerror.argtypes = [ctypes.c_int]
+    L.fabgpu_init.argtypes = [ctypes.POINTER(_Cfg), ctypes.POINTER(_vp)]
+    L.fabgpu_shutdown.argtypes = [_vp]
+    L.fabgpu_shutdown.restype = None
+    L.fabgpu_device_count.argtypes = [_vp]
+    L.fabgpu_p256_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u8p, _u8p, _u64p, _u8p]
+    L.fabgpu_sha256_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p]
+    L.fabgpu_sha256_p256_verify_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p, _u8p, _u8p, _u8p, _u64p, _u8p]
+    L.fabgpu_p256_verify_batch_dev.argtypes = [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.fabgpu_sha256_batch_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp]
+    L.fabgpu_sha256_p256_verify_batch_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.fabgpu_last_kernel_ms.argtypes = [_vp]
+    L.fabgpu_last_kernel_ms.restype = ctypes.c_float
+    L.fabgpu_ecdsa_unmarshal_signature.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    L.fabgpu_ecdsa_is_low_s.argtypes = [ctypes.c_char_p]
+    L.fabgpu_p256_pubkey_on_curve.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    L.fabgpu_hash_to_int.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p]
+    L.fabgpu_hash_to_int.restype = None
+    L.fabgpu_csp_new.argtypes = [ctypes.POINTER(_Cfg), ctypes.POINTER(_vp), ctypes.c_char_p, _sz]
+    L.fabgpu_csp_free.argtypes = [_vp]
+    L.fabgpu_csp_free.restype = None
+    L.fabgpu_csp_ctx.argtypes = [_vp]
+    L.fabgpu_csp_ctx.restype = _vp
+    L.fabgpu_csp_hash.argtypes = [_vp, ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz]
+    L.fabgpu_csp_verify.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz,
+                                    ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
+    L.fabgpu_csp_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u32p, _u8p, _u32p, _u8p, ctypes.c_char_p, _sz]
+    L.fabgpu_csp_identity_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u32p, _u8p, _u32p, ctypes.c_char_p, _sz]
+    L.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
+    _lib = L
+    return L
+
+
+def strerror(code: int) -> str:
+    return load().fabgpu_strerror(code).decode()
+
+
+def _check(rc: int, what: str):
+    if rc != FABGPU_OK:
+        raise FabgpuError("%s failed: %s (%d)" % (what, strerror(rc), rc))
+
+
+def _a8(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _p8(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_u8p)
+
+
+def unpack_bits(words: np.ndarray, n: int) -> np.ndarray:
+    """verdict bitmap (u64 words, bit i%64 of word i/64) -> bool[n]."""
+    b = np.unpackbits(np.ascontiguousarray(words, dtype="<u8").view(np.uint8), bitorder="little")
+    return b[:n].astype(bool)
+
+
+# ------------------------------------------------------------------------------------------------
+# host gates (pure CPU)
+# ------------------------------------------------------------------------------------------------
+def unmarshal_ecdsa_signature(raw: bytes) -> Tuple[int, bytes, bytes, int]:
+    """utils.UnmarshalECDSASignature (bccsp/utils/ecdsa.go:43-67): (rc, r32, s32, flags)."""
+    r = ctypes.create_string_buffer(32)
+    s = ctypes.create_string_buffer(32)
+    fl = ctypes.c_int(0)
+    rc = load().fabgpu_ecdsa_unmarshal_signature(raw, len(raw), r, s, ctypes.byref(fl))
+    return rc, r.raw, s.raw, fl.value
+
+
+def is_low_s(s32: bytes) -> bool:
+    return bool(load().fabgpu_ecdsa_is_low_s(s32))
+
+
+def pubkey_on_curve(qx32: bytes, qy32: bytes) -> bool:
+    return bool(load().fabgpu_p256_pubkey_on_curve(qx32, qy32))
+
+
+def hash_to_int(digest: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    load().fabgpu_hash_to_int(digest, len(digest), out)
+    return out.raw
+
+
+def synth_batch(n: int, seed: int = 20260921, invalid_permille: int = 0, e_in: Optional[np.ndarray] = None, threads: int = 0):
+    """Synthetic tuples; see include/fabgpu_bccsp.h fabgpu_synth_batch."""
+    qx, qy, e, r, s = (np.zeros((n, 32), np.uint8) for _ in range(5))
+    kind = np.zeros(n, np.uint8)
+    ein = None if e_in is None else _a8(e_in)
+    _check(load().fabgpu_synth_batch(n, seed, invalid_permille, _p8(ein), _p8(qx), _p8(qy), _p8(e), _p8(r), _p8(s), _p8(kind), threads),
+           "fabgpu_synth_batch")
+    return dict(qx=qx, qy=qy, e=e, r=r, s=s, kind=kind)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw C-ABI context (what the cgo provider binds)
+# ------------------------------------------------------------------------------------------------
+class Context:
+    def __init__(self, device: int = -1, max_batch: int = 0, max_arena: int = 0):
+        L = load()
+        cfg = _Cfg(device, max_batch, max_arena, 0)
+        h = _vp()
+        _check(L.fabgpu_init(ctypes.byref(cfg), ctypes.byref(h)), "fabgpu_init")
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fabgpu_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def device_count(self) -> int:
+        return self._L.fabgpu_device_count(self._h)
+
+    def p256_verify_batch(self, qx, qy, e, r, s, want_status=True):
+        qx, qy, e, r, s = map(_a8, (qx, qy, e, r, s))
+        n = qx.shape[0] if qx.ndim == 2 else qx.size // 32
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.uint8) if want_status else None
+        _check(self._L.fabgpu_p256_verify_batch(self._h, n, _p8(qx), _p8(qy), _p8(e), _p8(r), _p8(s),
+                                                 bits.ctypes.data_as(_u64p), _p8(st)), "fabgpu_p256_verify_batch")
+        return unpack_bits(bits, n), st
+
+    def sha256_batch(self, arena, off):
+        arena = _a8(arena)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = off.size - 1
+        out = np.zeros((n, 32), dtype=np.uint8)
+        _check(self._L.fabgpu_sha256_batch(self._h, n, _p8(arena), off.ctypes.data_as(_u32p), _p8(out)), "fabgpu_sha256_batch")
+        return out
+
+    def sha256_p256_verify_batch(self, arena, off, qx, qy, r, s, want_status=True):
+        arena, qx, qy, r, s = map(_a8, (arena, qx, qy, r, s))
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = off.size - 1
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.uint8) if want_status else None
+        _check(self._L.fabgpu_sha256_p256_verify_batch(self._h, n, _p8(arena), off.ctypes.data_as(_u32p), _p8(qx), _p8(qy), _p8(r),
+                                                        _p8(s), bits.ctypes.data_as(_u64p), _p8(st)), "fabgpu_sha256_p256_verify_batch")
+        return unpack_bits(bits, n), st
+
+    # device-resident variants: arguments are integer device addresses (torch tensor .data_ptr())
+    def p256_verify_batch_dev(self, n, qx, qy, e, r, s, verdict_bits, status, stream=0):
+        _check(self._L.fabgpu_p256_verify_batch_dev(self._h, n, qx, qy, e, r, s, verdict_bits, status or None, stream or None),
+               "fabgpu_p256_verify_batch_dev")
+
+    def sha256_batch_dev(self, n, arena, arena_bytes, off, digests, stream=0):
+        _check(self._L.fabgpu_sha256_batch_dev(self._h, n, arena, arena_bytes, off, digests, stream or None), "fabgpu_sha256_batch_dev")
+
+    def sha256_p256_verify_batch_dev(self, n, arena, arena_bytes, off, qx, qy, r, s, verdict_bits, status, stream=0):
+        _check(self._L.fabgpu_sha256_p256_verify_batch_dev(self._h, n, arena, arena_bytes, off, qx, qy, r, s, verdict_bits,
+                                                            status or None, stream or None), "fabgpu_sha256_p256_verify_batch_dev")
+
+    def last_kernel_ms(self) -> float:
+        return float(self._L.fabgpu_last_kernel_ms(self._h))
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's vocabulary
+# ------------------------------------------------------------------------------------------------
+class ECDSAPublicKey:
+    """bccsp/sw/ecdsakey.go:72-117 (X, Y of an ecdsa.PublicKey on P-256)."""
+
+    def __init__(self, x: int, y: int):
+        self.x, self.y = x, y
+
+    def xy_bytes(self) -> Tuple[bytes, bytes]:
+        return self.x.to_bytes(32, "big"), self.y.to_bytes(32, "big")
+
+
+class SHA256Opts:
+    """bccsp/hashopts.go:20-70"""
+    algorithm = "SHA256"
+
+
+class SHA3_256Opts:
+    algorithm = "SHA3_256"
+
+
+class GPUCSP:
+    """The accelerated verbs of bccsp.BCCSP (bccsp/bccsp.go:90-134); everything else the Go provider delegates to bccsp/sw."""
+
+    def __init__(self, device: int = -1):
+        L = load()
+        cfg = _Cfg(device, 0, 0, 0)
+        h = _vp()
+        err = ctypes.create_string_buffer(512)
+        rc = L.fabgpu_csp_new(ctypes.byref(cfg), ctypes.byref(h), err, 512)
+        if rc != FABGPU_OK:
+            raise FabgpuError(err.value.decode() or strerror(rc))
+        self._h, self._L = h, L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fabgpu_csp_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def key_import(self, raw, opts=None) -> ECDSAPublicKey:
+        """KeyImport(raw, &bccsp.ECDSAGoPublicKeyImportOpts{}) (bccsp/sw/keyimport.go:103-112): raw = (X, Y)."""
+        if raw is None:
+            raise BCCSPError("Invalid raw. It must not be nil.")
+        return ECDSAPublicKey(int(raw[0]), int(raw[1]))
+
+    def hash(self, msg: Optional[bytes], opts) -> bytes:
+        """CSP.Hash (bccsp/sw/impl.go:177-194)."""
+        out = ctypes.create_string_buffer(32)
+        err = ctypes.create_string_buffer(512)
+        alg = None if opts is None else opts.algorithm.encode()
+        msg = msg or b""
+        _check(self._L.fabgpu_csp_hash(self._h, msg, len(msg), alg, out, err, 512), "fabgpu_csp_hash")
+        if err.value:
+            raise BCCSPError(err.value.decode())
+        return out.raw
+
+    def verify(self, k: Optional[ECDSAPublicKey], signature: bytes, digest: bytes, opts=None) -> bool:
+        """CSP.Verify (bccsp/sw/impl.go:247-270): returns valid, raises BCCSPError where Go returns (false, err)."""
+        valid = ctypes.c_int(0)
+        flags = ctypes.c_int(0)
+        err = ctypes.create_string_buffer(1024)
+        qx, qy = (None, None) if k is None else k.xy_bytes()
+        _check(self._L.fabgpu_csp_verify(self._h, qx, qy, signature, len(signature), digest, len(digest), ctypes.byref(valid),
+                                         ctypes.byref(flags), err, 1024), "fabgpu_csp_verify")
+        if err.value:
+            raise BCCSPError(err.value.decode())
+        return bool(valid.value)
+
+    def verify_batch(self, keys: Sequence[ECDSAPublicKey], sigs: Sequence[bytes], digests: Sequence[bytes]):
+        """n independent CSP.Verify calls in one launch: list of (valid, error-text-or-None)."""
+        n = len(keys)
+        qx = np.frombuffer(b"".join(k.x.to_bytes(32, "big") for k in keys), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+        qy = np.frombuffer(b"".join(k.y.to_bytes(32, "big") for k in keys), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+        sa, so = _ragged(sigs)
+        da, do = _ragged(digests)
+        valid = np.zeros(n, np.uint8)
+        stride = 512
+        errs = ctypes.create_string_buffer(max(1, n * stride))
+        _check(self._L.fabgpu_csp_verify_batch(self._h, n, _p8(qx), _p8(qy), _p8(sa), so.ctypes.data_as(_u32p), _p8(da),
+                                               do.ctypes.data_as(_u32p), _p8(valid), errs, stride), "fabgpu_csp_verify_batch")
+        out = []
+        for i in range(n):
+            e = errs.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode()
+            out.append((bool(valid[i]), e or None))
+        return out
+
+    def identity_verify_batch(self, keys: Sequence[ECDSAPublicKey], msgs: Sequence[bytes], sigs: Sequence[bytes]) -> List[Optional[str]]:
+        """identity.Verify (msp/identities.go:169-196) for n triples: None (nil) or the error text."""
+        n = len(keys)
+        qx = np.frombuffer(b"".join(k.x.to_bytes(32, "big") for k in keys), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+        qy = np.frombuffer(b"".join(k.y.to_bytes(32, "big") for k in keys), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+        ma, mo = _ragged(msgs)
+        sa, so = _ragged(sigs)
+        stride = 512
+        errs = ctypes.create_string_buffer(max(1, n * stride))
+        _check(self._L.fabgpu_csp_identity_verify_batch(self._h, n, _p8(qx), _p8(qy), _p8(ma), mo.ctypes.data_as(_u32p), _p8(sa),
+                                                        so.ctypes.data_as(_u32p), errs, stride), "fabgpu_csp_identity_verify_batch")
+        return [(errs.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode() or None) for i in range(n)]
+
+
+def _ragged(items: Sequence[bytes]):
+    off = np.zeros(len(items) + 1, dtype=np.uint32)
+    if items:
+        off[1:] = np.cumsum([len(x) for x in items])
+    arena = np.frombuffer(b"".join(items) + b"\0", dtype=np.uint8).copy()
+    return arena, off
+
+
+class Identity:
+    """msp.identity restricted to Verify (msp/identities.go:169-196)."""
+
+    def __init__(self, csp: GPUCSP, pk: ECDSAPublicKey, hash_family: str = "SHA2"):
+        self.csp, self.pk, self.hash_family = csp, pk, hash_family
+
+    def verify(self, msg: bytes, sig: bytes) -> None:
+        """Returns None (nil) or raises BCCSPError with identity.Verify's error text."""
+        if self.hash_family != "SHA2":
+            raise BCCSPError("hash familiy not recognized [%s]" % self.hash_family) if self.hash_family != "SHA3" else \
+                BCCSPError("failed computing digest: SHA3 is served by bccsp/sw, not by the GPU provider")
+        err = self.csp.identity_verify_batch([self.pk], [msg], [sig])[0]
+        if err:
+            raise BCCSPError(err)
+
+
+def validate_block_endorsements(csp: GPUCSP, txs) -> np.ndarray:
+    """Block-level pre-verify pass: txs = list of (prp, [(endorser_bytes, key, sig), ...]).
+    Signed message of endorsement j is prp || endorser_j (validator_keylevel.go:247-249).  Returns one flag per tx:
+    True iff every endorsement verifies (verify-all-then-evaluate, common/cauthdsl/policy.go:92-94)."""
+    keys, msgs, sigs, owner = [], [], [], []
+    for t, (prp, ends) in enumerate(txs):
+        for endorser, key, sig in ends:
+            keys.append(key)
+            msgs.append(prp + endorser)
+            sigs.append(sig)
+            owner.append(t)
+    errs = csp.identity_verify_batch(keys, msgs, sigs)
+    ok = np.ones(len(txs), dtype=bool)
+    for t, e in zip(owner, errs):
+        if e is not None:
+            ok[t] = False
+    return ok

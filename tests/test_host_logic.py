@@ -1,0 +1,190 @@
+"""CPU-side tests of the product's host logic and boundary (no GPU needed):
+the C-ABI library loads and exports every declared symbol, fails loudly without a device, the DER / low-S /
+curve gates agree with the oracle and the golden vectors, and the very header code the kernels are compiled
+from (run on the CPU through libfabgpu_hosttest.so) is bit-exact against the oracle."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bccsp_sw_oracle as po
+import coracle
+import fabgpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def _load(name):
+    return json.load(open(os.path.join(G, name)))["vectors"]
+
+
+def _h32(x):
+    return bytes.fromhex(x.rjust(64, "0"))
+
+
+@pytest.fixture(scope="module")
+def hosttest():
+    p = os.path.join(ROOT, "fabric-mod_amd", "lib", "libfabgpu_hosttest.so")
+    if not os.path.exists(p):
+        import __graft_entry__ as g
+        g.build()
+    return ctypes.CDLL(p)
+
+
+def test_library_exports_every_declared_symbol():
+    L = fabgpu.load()
+    declared = set()
+    for h in ("fabgpu.h", "fabgpu_bccsp.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        declared |= set(re.findall(r"\b(fabgpu_[a-z0-9_]+)\s*\(", src))
+    assert declared == set(fabgpu.ABI_SYMBOLS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.fabgpu_abi_version() == 1
+    assert fabgpu.strerror(0) == "ok" and "bccsp/sw" in fabgpu.strerror(-2)
+
+
+def test_no_device_fails_loudly_never_falls_back():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(fabgpu.FabgpuError):
+        fabgpu.Context()
+    with pytest.raises(fabgpu.FabgpuError):
+        fabgpu.GPUCSP()
+    # argument validation does not need a device
+    L = fabgpu.load()
+    assert L.fabgpu_init(None, None) == -1
+    assert L.fabgpu_p256_verify_batch(None, 1, None, None, None, None, None, None, None) == -1
+
+
+def test_der_gate_matches_golden_and_oracle():
+    for v in _load("der_kats.json"):
+        raw = bytes.fromhex(v["der"])
+        rc, r, s, fl = fabgpu.unmarshal_ecdsa_signature(raw)
+        orc = coracle.der_unmarshal(raw)
+        assert (rc != 0) == (not v["ok"]), v["name"]
+        assert rc == orc[0], v["name"]
+        if v["ok"]:
+            assert (r, s, fl) == orc[1:], v["name"]
+            assert int.from_bytes(r, "big") == int(v["r"], 16) % (1 << 256)
+    # fuzz: mutate good signatures byte-wise, product parser == oracle parser == python restatement
+    rng = np.random.default_rng(3)
+    good = [bytes.fromhex(v["sig_der"]) for v in _load("ref_cert_kats.json")[:40]]
+    for g in good:
+        for _ in range(60):
+            b = bytearray(g)
+            k = rng.integers(0, 4)
+            if k == 0:
+                b[rng.integers(0, len(b))] = rng.integers(0, 256)
+            elif k == 1:
+                del b[rng.integers(0, len(b))]
+            elif k == 2:
+                b.insert(rng.integers(0, len(b)), rng.integers(0, 256))
+            else:
+                b = b[: rng.integers(0, len(b))]
+            raw = bytes(b)
+            rc, r, s, fl = fabgpu.unmarshal_ecdsa_signature(raw)
+            assert (rc, r, s, fl) == coracle.der_unmarshal(raw) if rc == 0 else rc == coracle.der_unmarshal(raw)[0], raw.hex()
+            try:
+                R, S = po.unmarshal_ecdsa_signature(raw)
+                assert rc == 0 and int.from_bytes(r, "big") == R % (1 << 256)
+            except po.BCCSPError:
+                assert rc != 0
+
+
+def test_low_s_curve_and_hash_to_int_gates():
+    assert fabgpu.is_low_s(po.HALF_N.to_bytes(32, "big"))
+    assert not fabgpu.is_low_s((po.HALF_N + 1).to_bytes(32, "big"))
+    assert fabgpu.is_low_s((1).to_bytes(32, "big"))
+    for v in _load("edge_kats.json"):
+        want = po.on_curve(int(v["qx"], 16), int(v["qy"], 16))
+        assert fabgpu.pubkey_on_curve(_h32(v["qx"]), _h32(v["qy"])) == want, v["name"]
+    for d in (b"\x01", b"\x00" * 5, bytes(range(32)), bytes(range(40)), bytes(range(64))):
+        assert int.from_bytes(fabgpu.hash_to_int(d), "big") == po.hash_to_int(d)
+
+
+def test_field_arithmetic_headers_against_python_ints(hosttest):
+    P, N, R = po.P, po.N, 1 << 256
+    Ri, Rni = pow(R, -1, P), pow(R, -1, N)
+
+    def fop(op, a, b=0):
+        out = ctypes.create_string_buffer(32)
+        hosttest.hosttest_fieldop(op, a.to_bytes(32, "big"), b.to_bytes(32, "big"), out)
+        return int.from_bytes(out.raw, "big")
+    import random
+    rng = random.Random(11)
+    special = [0, 1, 2, P - 1, P - 2, 1 << 255, (1 << 224) - 1, (1 << 96) - 1, (1 << 192) + 1, P - (1 << 96)]
+    pairs = [(a % P, b % P) for a in special for b in special] + [(rng.randrange(P), rng.randrange(P)) for _ in range(1500)]
+    for a, b in pairs:
+        assert fop(0, a, b) == a * b * Ri % P
+        assert fop(1, a) == a * a * Ri % P
+        assert fop(2, a, b) == (a + b) % P
+        assert fop(3, a, b) == (a - b) % P
+        assert fop(4, a) == a * R % P and fop(5, a) == a * Ri % P
+        an, bn = a % N, b % N
+        assert fop(6, an, bn) == an * bn * Rni % N and fop(7, an) == an * an * Rni % N
+        assert fop(8, an) == an * R % N and fop(9, an) == an * Rni % N
+    for a in (P, P + 7, R - 1, N, N + 1):   # to_mont accepts any 256-bit input (off-range keys / digests)
+        assert fop(4, a) == a * R % P and fop(8, a) == a * R % N
+    for _ in range(10):
+        a = rng.randrange(1, N)
+        assert fop(10, a * R % N) == pow(a, -1, N) * R % N
+        a = rng.randrange(1, P)
+        assert fop(11, a * R % P) == pow(a, -1, P) * R % P
+
+
+def test_generator_comb_table(hosttest):
+    for w, d in [(0, 1), (0, 2), (0, 15), (1, 1), (7, 9), (31, 15), (63, 1), (63, 15)]:
+        x = ctypes.create_string_buffer(32)
+        y = ctypes.create_string_buffer(32)
+        hosttest.hosttest_gtab_entry(w, d, x, y)
+        assert (int.from_bytes(x.raw, "big"), int.from_bytes(y.raw, "big")) == po.pt_mul(d << (4 * w), (po.GX, po.GY))
+
+
+def _core(hosttest, qx, qy, e, r, s):
+    n = qx.shape[0]
+    st = np.zeros(n, np.uint8)
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    hosttest.hosttest_verify_core(ctypes.c_size_t(n), p(qx), p(qy), p(e), p(r), p(s), p(st))
+    return st
+
+
+def _arr(items):
+    return np.frombuffer(b"".join(items), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def test_verify_core_headers_on_golden_and_edge_vectors(hosttest):
+    vs = [v for v in _load("edge_kats.json") if len(v["e"]) == 64 and 0 <= int(v["r"], 16) < 1 << 256 and 0 <= int(v["s"], 16) < 1 << 256]
+    st = _core(hosttest, *[_arr([_h32(v[k]) for v in vs]) for k in ("qx", "qy", "e", "r", "s")])
+    for v, got in zip(vs, st):
+        assert got == v["status"], v["name"]
+    cs = _load("ref_cert_kats.json")
+    st = _core(hosttest, *[_arr([_h32(v[k]) for v in cs]) for k in ("qx", "qy", "e", "r", "s")])
+    for v, got in zip(cs, st):
+        want = po.ST_HIGH_S if not v["low_s"] else (po.ST_VALID if v["expect_valid"] else po.ST_BAD_MATH)
+        assert got == want, v["source"]
+
+
+def test_verify_core_headers_random_vs_oracle(hosttest):
+    b = coracle.make_batch(1500, seed=99, invalid_frac=0.25)
+    st = _core(hosttest, b["qx"], b["qy"], b["e"], b["r"], b["s"])
+    assert (st == coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])).all()
+
+
+def test_synth_generator_is_checked_by_independent_implementations():
+    b = fabgpu.synth_batch(800, seed=20260921, invalid_permille=200, threads=4)
+    assert (fabgpu.synth_batch(800, seed=20260921, invalid_permille=200, threads=1)["s"] == b["s"]).all()  # thread-count independent
+    st = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
+    assert (st == coracle.ossl_verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])).all()
+    want = np.array([0, 1, 1, 2, 1], dtype=np.uint8)[b["kind"]]
+    assert (st == want).all()
+    assert (b["kind"] != 0).sum() == 160
+    e_in = np.random.default_rng(1).integers(0, 256, (50, 32), dtype=np.uint8)
+    c = fabgpu.synth_batch(50, seed=7, e_in=e_in)
+    assert (c["e"] == e_in).all() and (coracle.verify_batch(c["qx"], c["qy"], c["e"], c["r"], c["s"]) == 0).all()
