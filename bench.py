@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tx", type=int, default=N_TX, help="tx per block (default = BASELINE configs[1]; other values are exploration only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,7 +65,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
-    n = N_TX * N_ENDORSE
+    n_tx = args.tx
+    n = n_tx * N_ENDORSE
     ctx = fabgpu.Context(device=local_rank, max_batch=n)
     block = fabgpu.synth_batch(n, seed=SEED + rank, invalid_permille=10)
     dev = {k: torch.from_numpy(block[k]).cuda() for k in ("qx", "qy", "e", "r", "s")}
@@ -127,11 +129,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: block of 10k tx x 3 endorsements = 30000 P-256 tuples per GPU, "
+            "config": {"workload": ("BASELINE.json configs[1]" if n_tx == N_TX else "EXPLORATION (not the BASELINE config)") + ": block of %d tx x 3 endorsements = %d P-256 tuples per GPU, " % (n_tx, n) +
                                    "verify-only kernel via the C ABI, fresh keypair per signature, 1% invalid",
-                       "tuples_per_gpu": n, "tx_per_block": N_TX, "endorsements_per_tx": N_ENDORSE, "seed": SEED,
+                       "tuples_per_gpu": n, "tx_per_block": n_tx, "endorsements_per_tx": N_ENDORSE, "seed": SEED,
                        "parallelism": "1 block per GPU%s" % (" + RCCL all-gather of verdict bitmaps" if world > 1 else "")},
-            "validated_tx_per_s": N_TX * world / (dt / args.steps),
+            "validated_tx_per_s": n_tx * world / (dt / args.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "p256_verify_kernel", "kernel_ms": kernel_s * 1e3,
                          "kernel_ms_lib_events": kernel_ms,

@@ -21,6 +21,16 @@
 #else
 #define FAB_HD inline __attribute__((always_inline))
 #endif
+// The multiply / square bodies are real functions in device code (one copy each, arguments and result in
+// VGPRs): fully inlined, the verify kernel was 380 KB of straight-line code and thrashed the 64 KB
+// instruction cache (measured 4x slower than its instruction count, profiles/r01_bench_v0_inlined.txt).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FAB_FN __device__ __attribute__((noinline))
+#elif defined(__HIP__)
+#define FAB_FN __host__ __device__ inline
+#else
+#define FAB_FN inline
+#endif
 
 namespace fab {
 
@@ -229,16 +239,22 @@ FAB_HD void redc_p(u256& r, uint32_t t[16]) {
     sel256(r, (top != 0) | (br == 0), y, x);
 }
 
-FAB_HD void fp_mul(u256& r, const u256& a, const u256& b) {
+FAB_FN u256 fp_mul_fn(u256 a, u256 b) {
     uint32_t t[16];
+    u256 r;
     mul512(t, a, b);
     redc_p(r, t);
+    return r;
 }
-FAB_HD void fp_sqr(u256& r, const u256& a) {
+FAB_FN u256 fp_sqr_fn(u256 a) {
     uint32_t t[16];
+    u256 r;
     sqr512(t, a);
     redc_p(r, t);
+    return r;
 }
+FAB_HD void fp_mul(u256& r, const u256& a, const u256& b) { r = fp_mul_fn(a, b); }
+FAB_HD void fp_sqr(u256& r, const u256& a) { r = fp_sqr_fn(a); }
 FAB_HD void fp_add(u256& r, const u256& a, const u256& b) {
     const u256 P = FAB_P256_P;
     u256 t, u;
@@ -317,16 +333,15 @@ FAB_HD void redc_n(u256& r, uint32_t t[16]) {
     uint32_t br = sub256(y, x, N);
     sel256(r, (top != 0) | (br == 0), y, x);
 }
-FAB_HD void fn_mul(u256& r, const u256& a, const u256& b) {
+FAB_FN u256 fn_mul_fn(u256 a, u256 b) {
     uint32_t t[16];
+    u256 r;
     mul512(t, a, b);
     redc_n(r, t);
+    return r;
 }
-FAB_HD void fn_sqr(u256& r, const u256& a) {
-    uint32_t t[16];
-    sqr512(t, a);
-    redc_n(r, t);
-}
+FAB_HD void fn_mul(u256& r, const u256& a, const u256& b) { r = fn_mul_fn(a, b); }
+FAB_HD void fn_sqr(u256& r, const u256& a) { r = fn_mul_fn(a, a); }
 FAB_HD void fn_to_mont(u256& r, const u256& a) {
     const u256 R2 = FAB_P256_N_R2;
     fn_mul(r, a, R2);

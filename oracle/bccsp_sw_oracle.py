@@ -279,7 +279,7 @@ def csp_verify(key: Optional[Tuple[int, int]], signature: bytes, digest: bytes) 
     try:
         return verify_ecdsa(key[0], key[1], signature, digest)
     except BCCSPError as e:
-        raise BCCSPError("Failed verifing with opts [%%!v(<nil>)]: %s" % e)
+        raise BCCSPError("Failed verifing with opts [<nil>]: %s" % e)
 
 
 def identity_verify(key: Tuple[int, int], msg: bytes, sig: bytes) -> Optional[str]:
