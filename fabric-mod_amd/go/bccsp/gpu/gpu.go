@@ -1,0 +1,189 @@
+// +build fabgpu
+
+// Package gpu is the reference-side binding of libfabgpu.so: a bccsp.BCCSP that embeds bccsp/sw exactly the
+// way bccsp/pkcs11/pkcs11.go:35-52 does and overrides KeyImport (to hold X,Y), Hash and Verify.
+// Drop this directory into the reference tree as bccsp/gpu and build the peer with GO_TAGS=fabgpu
+// (same mechanism as the pkcs11 tag, Makefile:80,209).  NOT compiled in this repository: the build image has
+// no Go toolchain; the C ABI it binds is exercised by the Python/ctypes tests instead.
+package gpu
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../../lib -lfabgpu
+#include <stdlib.h>
+#include "fabgpu.h"
+*/
+import "C"
+
+import (
+	"crypto/ecdsa"
+	"crypto/elliptic"
+	"crypto/sha256"
+	"crypto/x509"
+	"fmt"
+	"math/big"
+	"sync"
+	"unsafe"
+
+	"github.com/hyperledger/fabric/bccsp"
+	"github.com/hyperledger/fabric/bccsp/sw"
+	"github.com/hyperledger/fabric/bccsp/utils"
+	"github.com/pkg/errors"
+)
+
+// impl mirrors bccsp/pkcs11/pkcs11.go:35-52: everything not overridden is served by the embedded sw CSP.
+type impl struct {
+	bccsp.BCCSP
+	ctx  *C.fabgpu_ctx
+	memo sync.Map // verdict memo seeded by PreVerifyBlock: key = sha256(X|Y|sig|digest) -> memoEntry
+}
+
+type memoEntry struct {
+	valid  bool
+	status uint8
+}
+
+// gpuPublicKey carries X,Y so Verify never needs the unexported sw key type (bccsp/sw/ecdsakey.go:72-74).
+type gpuPublicKey struct {
+	bccsp.Key // the sw key (SKI, Bytes, ...)
+	pub       *ecdsa.PublicKey
+	onCurve   bool
+}
+
+// New is what bccsp/factory would call for ProviderName "GPU" (see INTEGRATION.md).
+func New(swCSP bccsp.BCCSP, device int) (bccsp.BCCSP, error) {
+	cfg := C.fabgpu_cfg{device: C.int32_t(device)}
+	var ctx *C.fabgpu_ctx
+	if rc := C.fabgpu_init(&cfg, &ctx); rc != 0 {
+		return nil, errors.Errorf("Failed initializing GPU BCCSP: %s", C.GoString(C.fabgpu_strerror(rc)))
+	}
+	return &impl{BCCSP: swCSP, ctx: ctx}, nil
+}
+
+// KeyImport: own the public-key import opts so that X,Y are reachable (pattern: bccsp/pkcs11/pkcs11.go:148-179).
+func (csp *impl) KeyImport(raw interface{}, opts bccsp.KeyImportOpts) (bccsp.Key, error) {
+	k, err := csp.BCCSP.KeyImport(raw, opts)
+	if err != nil {
+		return nil, err
+	}
+	var pub *ecdsa.PublicKey
+	switch opts.(type) {
+	case *bccsp.X509PublicKeyImportOpts:
+		if cert, ok := raw.(*x509.Certificate); ok {
+			pub, _ = cert.PublicKey.(*ecdsa.PublicKey)
+		}
+	case *bccsp.ECDSAGoPublicKeyImportOpts:
+		pub, _ = raw.(*ecdsa.PublicKey)
+	}
+	if pub == nil || pub.Curve != elliptic.P256() {
+		return k, nil // not ours: sw handles it
+	}
+	return &gpuPublicKey{Key: k, pub: pub, onCurve: pub.Curve.IsOnCurve(pub.X, pub.Y)}, nil
+}
+
+func be32(v *big.Int) []byte { b := make([]byte, 32); v.FillBytes(b); return b } // Go >= 1.15; 1.14: pad v.Bytes()
+
+// Verify keeps bccsp/sw's argument checks and error text (bccsp/sw/impl.go:247-270, ecdsa.go:41-57).
+func (csp *impl) Verify(k bccsp.Key, signature, digest []byte, opts bccsp.SignerOpts) (bool, error) {
+	gk, ok := k.(*gpuPublicKey)
+	if !ok || !gk.onCurve || len(signature) == 0 || len(digest) == 0 {
+		if ok {
+			k = gk.Key
+		}
+		return csp.BCCSP.Verify(k, signature, digest, opts) // nil key, other key types, off-curve keys, empty args
+	}
+	r, s, err := utils.UnmarshalECDSASignature(signature)
+	if err != nil {
+		return false, errors.Wrapf(fmt.Errorf("Failed unmashalling signature [%s]", err), "Failed verifing with opts [%v]", opts)
+	}
+	if lowS, _ := utils.IsLowS(gk.pub, s); !lowS {
+		return false, errors.Wrapf(fmt.Errorf("Invalid S. Must be smaller than half the order [%s][%s].", s,
+			utils.GetCurveHalfOrdersAt(gk.pub.Curve)), "Failed verifing with opts [%v]", opts)
+	}
+	if r.BitLen() > 256 {
+		return false, nil // r >= n
+	}
+	if e, hit := csp.memo.Load(memoKey(gk.pub, signature, digest)); hit {
+		return e.(memoEntry).valid, nil // seeded by PreVerifyBlock for this exact (key, sig, digest)
+	}
+	// memo miss: single-tuple launch (correct, slow); high-rate callers go through PreVerifyBlock
+	var e32 [32]byte
+	C.fabgpu_hash_to_int((*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), (*C.uint8_t)(unsafe.Pointer(&e32[0])))
+	qx, qy, rb, sb := be32(gk.pub.X), be32(gk.pub.Y), be32(r), be32(s)
+	var bits C.uint64_t
+	var st C.uint8_t
+	rc := C.fabgpu_p256_verify_batch(csp.ctx, 1, (*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])),
+		(*C.uint8_t)(unsafe.Pointer(&e32[0])), (*C.uint8_t)(unsafe.Pointer(&rb[0])), (*C.uint8_t)(unsafe.Pointer(&sb[0])), &bits, &st)
+	if rc != 0 { // infrastructure failure: never a verdict, fall back (SURVEY section 5 "determinism under failure")
+		return csp.BCCSP.Verify(gk.Key, signature, digest, opts)
+	}
+	return bits&1 == 1, nil
+}
+
+// Hash: single small hashes stay on the CPU (a PCIe round trip costs more than SHA-256 of a few KB);
+// block-sized batches go through PreVerifyBlock's fused hash+verify launch.
+func (csp *impl) Hash(msg []byte, opts bccsp.HashOpts) ([]byte, error) { return csp.BCCSP.Hash(msg, opts) }
+
+func memoKey(pub *ecdsa.PublicKey, sig, digest []byte) [32]byte {
+	h := sha256.New()
+	h.Write(be32(pub.X)); h.Write(be32(pub.Y)); h.Write(sig); h.Write(digest)
+	var k [32]byte
+	copy(k[:], h.Sum(nil))
+	return k
+}
+
+// Tuple is one (identity key, signed message, DER signature) of a block, extracted exactly as
+// core/common/validation/msgvalidation.go:274 (creator) and
+// core/common/validation/statebased/validator_keylevel.go:246-258 (endorsements: prp || endorser) do.
+type Tuple struct {
+	Key bccsp.Key
+	Msg []byte
+	Sig []byte
+}
+
+// PreVerifyBlock verifies every tuple of a block in ONE fused hash+verify launch and seeds the verdict memo that
+// Verify consults, so the unchanged validators (v20/validator.go:194-210) hit the memo instead of the CPU.
+func (csp *impl) PreVerifyBlock(tuples []Tuple) error {
+	n := len(tuples)
+	if n == 0 {
+		return nil
+	}
+	qx, qy, rr, ss := make([]byte, 32*n), make([]byte, 32*n), make([]byte, 32*n), make([]byte, 32*n)
+	off := make([]uint32, n+1)
+	var arena []byte
+	keep := make([]bool, n)
+	for i, t := range tuples {
+		off[i] = uint32(len(arena))
+		gk, ok := t.Key.(*gpuPublicKey)
+		r, s, err := utils.UnmarshalECDSASignature(t.Sig)
+		low := false
+		if err == nil {
+			low, _ = utils.IsLowS(gk.pub, s)
+		}
+		if !ok || !gk.onCurve || err != nil || !low || r.BitLen() > 256 {
+			rr[32*i+31], ss[32*i+31], qx[32*i+31], qy[32*i+31] = 1, 1, 1, 1 // filler; Verify's own gates answer these
+			continue
+		}
+		keep[i] = true
+		arena = append(arena, t.Msg...)
+		copy(qx[32*i:], be32(gk.pub.X)); copy(qy[32*i:], be32(gk.pub.Y)); copy(rr[32*i:], be32(r)); copy(ss[32*i:], be32(s))
+	}
+	off[n] = uint32(len(arena))
+	arena = append(arena, 0)
+	bits := make([]uint64, (n+63)/64)
+	st := make([]uint8, n)
+	rc := C.fabgpu_sha256_p256_verify_batch(csp.ctx, C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&arena[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])),
+		(*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])), (*C.uint8_t)(unsafe.Pointer(&rr[0])),
+		(*C.uint8_t)(unsafe.Pointer(&ss[0])), (*C.uint64_t)(unsafe.Pointer(&bits[0])), (*C.uint8_t)(unsafe.Pointer(&st[0])))
+	if rc != 0 {
+		return errors.Errorf("fabgpu: %s", C.GoString(C.fabgpu_strerror(rc))) // caller ignores: validators then use sw via Verify
+	}
+	for i, t := range tuples {
+		if !keep[i] {
+			continue
+		}
+		d := sha256.Sum256(t.Msg) // memo key only; the verdict came from the GPU
+		csp.memo.Store(memoKey(t.Key.(*gpuPublicKey).pub, t.Sig, d[:]), memoEntry{valid: bits[i/64]>>(uint(i)%64)&1 == 1, status: st[i]})
+	}
+	return nil
+}
