@@ -11,7 +11,7 @@
 
 #include "../../include/fabgpu.h"
 #include "kernels.h"
-#include "p256_tables.h"
+#include "p256_tables29.h"
 
 using namespace fab;
 
@@ -43,7 +43,7 @@ struct Buf {  // growable pinned-host + device pair
 struct fabgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    uint32_t* d_gtab = nullptr;
+    int32_t* d_gtab = nullptr;
     std::mutex mu;
     Buf fields;   // qx|qy|e|r|s
     Buf arena;    // message bytes
@@ -117,10 +117,10 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
-        std::vector<uint32_t> tab(G_TABLE_WORDS);
-        build_g_comb_table(tab.data());
-        if (hipMalloc((void**)&ctx->d_gtab, sizeof(uint32_t) * G_TABLE_WORDS) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
-        if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(uint32_t) * G_TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
+        std::vector<int32_t> tab(G29_TABLE_WORDS);
+        build_g_comb_table29(tab.data());
+        if (hipMalloc((void**)&ctx->d_gtab, sizeof(int32_t) * G29_TABLE_WORDS) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
+        if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(int32_t) * G29_TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
         if (cfg && cfg->max_batch) {
             size_t n = cfg->max_batch;
             if ((rc = ctx->fields.ensure(n * 160)) || (rc = ctx->offs.ensure((n + 1) * 4)) || (rc = ctx->out.ensure(n * 41 + 64))) break;

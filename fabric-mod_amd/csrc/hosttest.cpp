@@ -6,7 +6,8 @@
 
 #include <vector>
 
-#include "p256_tables.h"
+#define FE29_CHECK 1
+#include "p256_tables29.h"
 
 using namespace fab;
 
@@ -15,7 +16,53 @@ static const uint32_t* gtab() {
     return tab.data();
 }
 
+static const int32_t* gtab29() {
+    static std::vector<int32_t> tab = [] { std::vector<int32_t> t(G29_TABLE_WORDS); build_g_comb_table29(t.data()); return t; }();
+    return tab.data();
+}
+
 extern "C" {
+
+// fe29 field ops on plain integers (32 big-endian bytes in, out): the op is carried out in the Montgomery domain
+// op: 0 mul 1 sqr 2 add 3 sub 4 (a+b)*(a-b) with lazy operands 5 is_zero(a-b)
+void hosttest_fe29_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
+    u256 a, b, r = zero256();
+    from_be32(a, a32);
+    from_be32(b, b32);
+    fe fa, fb, fr, t1, t2;
+    fe_to_mont(fa, a);
+    fe_to_mont(fb, b);
+    switch (op) {
+        case 0: fe_mul(fr, fa, fb); break;
+        case 1: fe_sqr(fr, fa); break;
+        case 2: fe_add(fr, fa, fb); break;
+        case 3: fe_sub(fr, fa, fb); break;
+        case 4: fe_add(t1, fa, fb); fe_sub(t2, fa, fb); fe_mul(fr, t1, t2); break;
+        case 5: fe_sub(t1, fa, fb); fr = fa; r.w[0] = fe_is_zero(t1) ? 1 : 0; to_be32(out32, r); return;
+        default: fr = fa;
+    }
+    fe_from_mont(r, fr);
+    to_be32(out32, r);
+}
+// which: 0 = mod n, 1 = mod p
+void hosttest_modinv(int which, const uint8_t* a32, uint8_t* out32) {
+    const modinv_info NI = MODINV_N_INFO, PI = MODINV_P_INFO;
+    u256 a, r;
+    from_be32(a, a32);
+    modinv(r, a, which ? PI : NI);
+    to_be32(out32, r);
+}
+void hosttest_verify_core29(size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r, const uint8_t* s,
+                            uint8_t* status) {
+    FlatGTab29 gt{gtab29()};
+    for (size_t i = 0; i < n; i++) {
+        u256 vqx, vqy, ve, vr, vs;
+        from_be32(vqx, qx + 32 * i); from_be32(vqy, qy + 32 * i); from_be32(ve, e + 32 * i);
+        from_be32(vr, r + 32 * i); from_be32(vs, s + 32 * i);
+        jac29 qtab[16];
+        status[i] = (uint8_t)p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
+    }
+}
 
 // op: 0 fp_mul 1 fp_sqr 2 fp_add 3 fp_sub 4 fp_to_mont 5 fp_from_mont 6 fn_mul 7 fn_sqr 8 fn_to_mont 9 fn_from_mont 10 fn_inv 11 fp_inv
 void hosttest_fieldop(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {

@@ -9,7 +9,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
-#include "p256_tables.h"
+#include "p256_verify29.h"
 
 namespace fab {
 
@@ -124,10 +124,10 @@ __device__ __forceinline__ void load_be_field(u256& v, const uint8_t* __restrict
     v.w[1] = __builtin_bswap32(lo.z); v.w[0] = __builtin_bswap32(lo.w);
 }
 
-__device__ __forceinline__ void stage_gtab(uint32_t* lds, const uint32_t* __restrict__ gtab) {
+__device__ __forceinline__ void stage_gtab(int32_t* lds, const int32_t* __restrict__ gtab) {
     const uint4* src = reinterpret_cast<const uint4*>(gtab);
     uint4* dst = reinterpret_cast<uint4*>(lds);
-    for (int k = threadIdx.x; k < G_TABLE_WORDS / 4; k += blockDim.x) dst[k] = src[k];
+    for (int k = threadIdx.x; k < G29_TABLE_WORDS / 4; k += blockDim.x) dst[k] = src[k];
     __syncthreads();
 }
 
@@ -140,9 +140,9 @@ __device__ __forceinline__ void emit_verdict(uint32_t i, bool active, uint32_t s
 
 __global__ void __launch_bounds__(VERIFY_BLOCK) p256_verify_kernel(uint32_t n, const uint8_t* __restrict__ qx, const uint8_t* __restrict__ qy,
                                                                     const uint8_t* __restrict__ e, const uint8_t* __restrict__ r,
-                                                                    const uint8_t* __restrict__ s, const uint32_t* __restrict__ gtab,
+                                                                    const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
                                                                     uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint32_t g_lds[G_TABLE_WORDS];
+    __shared__ __attribute__((aligned(16))) int32_t g_lds[G29_TABLE_WORDS];
     stage_gtab(g_lds, gtab);
     uint32_t i = blockIdx.x * VERIFY_BLOCK + threadIdx.x;
     bool active = i < n;
@@ -153,9 +153,9 @@ __global__ void __launch_bounds__(VERIFY_BLOCK) p256_verify_kernel(uint32_t n, c
     load_be_field(ve, e, ic);
     load_be_field(vr, r, ic);
     load_be_field(vs, s, ic);
-    jac qtab[16];
-    FlatGTab gt{g_lds};
-    uint32_t st = p256_verify_core(vqx, vqy, ve, vr, vs, gt, qtab);
+    jac29 qtab[16];
+    FlatGTab29 gt{g_lds};
+    uint32_t st = p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
     emit_verdict(i, active, st, verdict_bits, status);
 }
 
@@ -163,9 +163,9 @@ __global__ void __launch_bounds__(VERIFY_BLOCK) p256_verify_kernel(uint32_t n, c
 __global__ void __launch_bounds__(VERIFY_BLOCK) sha256_p256_verify_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
                                                                            const uint32_t* __restrict__ off, const uint8_t* __restrict__ qx,
                                                                            const uint8_t* __restrict__ qy, const uint8_t* __restrict__ r,
-                                                                           const uint8_t* __restrict__ s, const uint32_t* __restrict__ gtab,
+                                                                           const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
                                                                            uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint32_t g_lds[G_TABLE_WORDS];
+    __shared__ __attribute__((aligned(16))) int32_t g_lds[G29_TABLE_WORDS];
     stage_gtab(g_lds, gtab);
     uint32_t i = blockIdx.x * VERIFY_BLOCK + threadIdx.x;
     bool active = i < n;
@@ -180,9 +180,9 @@ __global__ void __launch_bounds__(VERIFY_BLOCK) sha256_p256_verify_kernel(uint32
     load_be_field(vqy, qy, ic);
     load_be_field(vr, r, ic);
     load_be_field(vs, s, ic);
-    jac qtab[16];
-    FlatGTab gt{g_lds};
-    uint32_t st = p256_verify_core(vqx, vqy, ve, vr, vs, gt, qtab);
+    jac29 qtab[16];
+    FlatGTab29 gt{g_lds};
+    uint32_t st = p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
     emit_verdict(i, active, st, verdict_bits, status);
 }
 
@@ -201,7 +201,7 @@ hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const 
     if (n == 0) return hipSuccess;
     dim3 grid((n + VERIFY_BLOCK - 1) / VERIFY_BLOCK), block(VERIFY_BLOCK);
     hipLaunchKernelGGL(p256_verify_kernel, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
-                       (const uint8_t*)r, (const uint8_t*)s, (const uint32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+                       (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
@@ -211,7 +211,7 @@ hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena
     dim3 grid((n + VERIFY_BLOCK - 1) / VERIFY_BLOCK), block(VERIFY_BLOCK);
     hipLaunchKernelGGL(sha256_p256_verify_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                        (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
-                       (const uint32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+                       (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
 
