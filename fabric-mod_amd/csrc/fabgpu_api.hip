@@ -51,7 +51,52 @@ struct fabgpu_ctx {
     Buf out;      // verdict words | status bytes | digests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // Workspaces for the verify kernels' per-lane j*Q tables.  A launch borrows one and marks it busy until an event
+    // recorded behind the kernel completes, so launches racing on different streams never share one.
+    struct QWs {
+        void* p = nullptr;
+        size_t bytes = 0;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+    };
+    std::vector<QWs> qws;
+    std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
+    int acquire_qws(size_t bytes, size_t* idx);
+    void release_qws(size_t idx, hipStream_t st) {
+        std::lock_guard<std::mutex> lk(qmu);
+        if (hipEventRecord(qws[idx].done, st) == hipSuccess) qws[idx].pending = true;
+    }
 };
+
+int fabgpu_ctx::acquire_qws(size_t bytes, size_t* idx) {
+    std::lock_guard<std::mutex> lk(qmu);
+    for (size_t i = 0; i < qws.size(); i++) {
+        QWs& w = qws[i];
+        if (w.pending && hipEventQuery(w.done) != hipSuccess) continue;   // still in flight on some stream
+        w.pending = false;
+        if (w.bytes < bytes) {
+            if (w.p) hipFree(w.p);
+            w.p = nullptr;
+            w.bytes = 0;
+            if (hipMalloc(&w.p, bytes) != hipSuccess) return FABGPU_ENOMEM;
+            w.bytes = bytes;
+        }
+        w.pending = true;   // reserved; release_qws() arms the event
+        *idx = i;
+        return FABGPU_OK;
+    }
+    QWs w;
+    if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) return FABGPU_ENODEV;
+    if (hipMalloc(&w.p, bytes) != hipSuccess) {
+        hipEventDestroy(w.done);
+        return FABGPU_ENOMEM;
+    }
+    w.bytes = bytes;
+    w.pending = true;
+    qws.push_back(w);
+    *idx = qws.size() - 1;
+    return FABGPU_OK;
+}
 
 namespace {
 
@@ -147,6 +192,10 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->offs.release();
         ctx->out.release();
         if (ctx->d_gtab) hipFree(ctx->d_gtab);
+        for (auto& w : ctx->qws) {
+            if (w.p) hipFree(w.p);
+            if (w.done) hipEventDestroy(w.done);
+        }
         if (ctx->ev0) hipEventDestroy(ctx->ev0);
         if (ctx->ev1) hipEventDestroy(ctx->ev1);
         if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -171,9 +220,13 @@ int fabgpu_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* qx, cons
     if (n == 0) return FABGPU_OK;
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
+    size_t wi = 0;
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n), &wi);
+    if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
-    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, verdict_bits, status, st);
+    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, st);
     hipEventRecord(ctx->ev1, st);
+    ctx->release_qws(wi, st);
     ctx->timed = true;
     return hip_to_rc(err);
 }
@@ -200,9 +253,13 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
     if (n == 0) return FABGPU_OK;
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
+    size_t wi = 0;
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n), &wi);
+    if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
-    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, verdict_bits, status, st);
+    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, st);
     hipEventRecord(ctx->ev1, st);
+    ctx->release_qws(wi, st);
     ctx->timed = true;
     return hip_to_rc(err);
 }

@@ -24,7 +24,7 @@ static const int32_t* gtab29() {
 extern "C" {
 
 // fe29 field ops on plain integers (32 big-endian bytes in, out): the op is carried out in the Montgomery domain
-// op: 0 mul 1 sqr 2 add 3 sub 4 (a+b)*(a-b) with lazy operands 5 is_zero(a-b)
+// op: 0 mul 1 sqr 2 add 3 sub 4 (a+b)*(a-b) with lazy operands 5 is_zero(a-b) 6 round trip
 void hosttest_fe29_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
     u256 a, b, r = zero256();
     from_be32(a, a32);
@@ -39,6 +39,7 @@ void hosttest_fe29_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* o
         case 3: fe_sub(fr, fa, fb); break;
         case 4: fe_add(t1, fa, fb); fe_sub(t2, fa, fb); fe_mul(fr, t1, t2); break;
         case 5: fe_sub(t1, fa, fb); fr = fa; r.w[0] = fe_is_zero(t1) ? 1 : 0; to_be32(out32, r); return;
+        case 6: fr = fa; break;   // to_mont / from_mont round trip (any 256-bit input)
         default: fr = fa;
     }
     fe_from_mont(r, fr);
@@ -52,6 +53,16 @@ void hosttest_modinv(int which, const uint8_t* a32, uint8_t* out32) {
     modinv(r, a, which ? PI : NI);
     to_be32(out32, r);
 }
+void hosttest_gtab29_entry(int window, int digit, uint8_t* x32, uint8_t* y32) {
+    FlatGTab29 gt{gtab29()};
+    fe x, y;
+    u256 px, py;
+    gt.load(window, (uint32_t)digit, x, y);
+    fe_from_mont(px, x);
+    fe_from_mont(py, y);
+    to_be32(x32, px);
+    to_be32(y32, py);
+}
 void hosttest_verify_core29(size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r, const uint8_t* s,
                             uint8_t* status) {
     FlatGTab29 gt{gtab29()};
@@ -59,7 +70,7 @@ void hosttest_verify_core29(size_t n, const uint8_t* qx, const uint8_t* qy, cons
         u256 vqx, vqy, ve, vr, vs;
         from_be32(vqx, qx + 32 * i); from_be32(vqy, qy + 32 * i); from_be32(ve, e + 32 * i);
         from_be32(vr, r + 32 * i); from_be32(vs, s + 32 * i);
-        jac29 qtab[16];
+        LocalQTab29 qtab;
         status[i] = (uint8_t)p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
     }
 }

@@ -5,12 +5,21 @@
 #include <stdint.h>
 
 namespace fab {
-constexpr int VERIFY_BLOCK = 256;  // 4 wavefronts share one LDS copy of the generator comb table
+constexpr int VERIFY_MAX_WGS = 256;       // persistent workgroup slots: one per CU (the comb table takes 80 KiB of the CU's 160 KiB LDS)
+constexpr int VERIFY_SMALL_MAX = 65536;   // up to here 256-thread workgroups (1 wave/SIMD), beyond 512-thread ones (2 waves/SIMD)
+// workspace of the per-lane j*Q tables: 16 entries x 7 uint4 per lane
+constexpr size_t QWS_UINT4_PER_LANE = (size_t)16 * 7;
 
+struct VerifyGeom {
+    uint32_t block;   // threads per workgroup
+    uint32_t wgs;     // workgroups launched (= workspace slots)
+};
+VerifyGeom verify_geom(uint32_t n);
+size_t verify_workspace_bytes(uint32_t n);
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
-                              const void* gtab, void* verdict_bits, void* status, hipStream_t st);
+                              const void* gtab, void* qws, void* verdict_bits, void* status, hipStream_t st);
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
-                                     const void* qy, const void* r, const void* s, const void* gtab, void* verdict_bits,
-                                     void* status, hipStream_t st);
+                                     const void* qy, const void* r, const void* s, const void* gtab, void* qws,
+                                     void* verdict_bits, void* status, hipStream_t st);
 }  // namespace fab

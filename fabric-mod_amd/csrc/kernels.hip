@@ -138,52 +138,99 @@ __device__ __forceinline__ void emit_verdict(uint32_t i, bool active, uint32_t s
     if (status != nullptr && active) status[i] = (uint8_t)st;
 }
 
-__global__ void __launch_bounds__(VERIFY_BLOCK) p256_verify_kernel(uint32_t n, const uint8_t* __restrict__ qx, const uint8_t* __restrict__ qy,
+// Per-lane table j*Q in a global-memory workspace (not private/scratch memory: the runtime caps a dispatch's scratch
+// at ~140 MiB, which at 1.8 KB per lane admitted only ~1270 wavefronts and held the kernel at one wave per SIMD).
+// Layout per workgroup slot: [entry 16][group 7][lane BLOCK] x 16 bytes - entry j of lane t is seven uint4 (27 limbs + pad),
+// consecutive lanes are consecutive 16-byte cells, so a store (all lanes the same j) is fully coalesced and a gather by
+// digit touches at most 15 distinct 4 KiB rows per group.
+template <int BLOCK>
+struct GlobalQTab29 {
+    uint4* lane;   // workspace of this workgroup slot + threadIdx.x
+    __device__ __forceinline__ void store(int j, const jac29& p) {
+        uint4* e = lane + (size_t)j * 7 * BLOCK;
+        e[0 * BLOCK] = make_uint4(p.X.v[0], p.X.v[1], p.X.v[2], p.X.v[3]);
+        e[1 * BLOCK] = make_uint4(p.X.v[4], p.X.v[5], p.X.v[6], p.X.v[7]);
+        e[2 * BLOCK] = make_uint4(p.X.v[8], p.Y.v[0], p.Y.v[1], p.Y.v[2]);
+        e[3 * BLOCK] = make_uint4(p.Y.v[3], p.Y.v[4], p.Y.v[5], p.Y.v[6]);
+        e[4 * BLOCK] = make_uint4(p.Y.v[7], p.Y.v[8], p.Z.v[0], p.Z.v[1]);
+        e[5 * BLOCK] = make_uint4(p.Z.v[2], p.Z.v[3], p.Z.v[4], p.Z.v[5]);
+        e[6 * BLOCK] = make_uint4(p.Z.v[6], p.Z.v[7], p.Z.v[8], 0);
+    }
+    __device__ __forceinline__ void load(uint32_t d, jac29& p) const {
+        const uint4* e = lane + (size_t)d * 7 * BLOCK;
+        uint4 a = e[0 * BLOCK], b = e[1 * BLOCK], c = e[2 * BLOCK], dd = e[3 * BLOCK];
+        uint4 f = e[4 * BLOCK], g = e[5 * BLOCK], h = e[6 * BLOCK];
+        p.X.v[0] = a.x; p.X.v[1] = a.y; p.X.v[2] = a.z; p.X.v[3] = a.w;
+        p.X.v[4] = b.x; p.X.v[5] = b.y; p.X.v[6] = b.z; p.X.v[7] = b.w;
+        p.X.v[8] = c.x; p.Y.v[0] = c.y; p.Y.v[1] = c.z; p.Y.v[2] = c.w;
+        p.Y.v[3] = dd.x; p.Y.v[4] = dd.y; p.Y.v[5] = dd.z; p.Y.v[6] = dd.w;
+        p.Y.v[7] = f.x; p.Y.v[8] = f.y; p.Z.v[0] = f.z; p.Z.v[1] = f.w;
+        p.Z.v[2] = g.x; p.Z.v[3] = g.y; p.Z.v[4] = g.z; p.Z.v[5] = g.w;
+        p.Z.v[6] = h.x; p.Z.v[7] = h.y; p.Z.v[8] = h.z;
+    }
+};
+
+// Persistent workgroups: a bounded number of slots, each staging the comb table into LDS once and walking the
+// BLOCK-signature tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  (the workspace is sized by slots, not by the batch).
+// The 72 KiB table is allocated as 80 KiB of LDS, so only ONE workgroup fits a CU: BLOCK = 256 puts one wave on each SIMD
+// (best latency: a 30 000-signature block is 469 waves for 1024 SIMDs), BLOCK = 512 two waves per SIMD (large batches;
+// measured 1.4x the SIMD throughput of one wave).
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2) p256_verify_kernel(uint32_t n, const uint8_t* __restrict__ qx, const uint8_t* __restrict__ qy,
                                                                     const uint8_t* __restrict__ e, const uint8_t* __restrict__ r,
                                                                     const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
-                                                                    uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+                                                                    uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
+                                                                    uint8_t* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) int32_t g_lds[G29_TABLE_WORDS];
     stage_gtab(g_lds, gtab);
-    uint32_t i = blockIdx.x * VERIFY_BLOCK + threadIdx.x;
-    bool active = i < n;
-    uint32_t ic = active ? i : (n - 1);
-    u256 vqx, vqy, ve, vr, vs;
-    load_be_field(vqx, qx, ic);
-    load_be_field(vqy, qy, ic);
-    load_be_field(ve, e, ic);
-    load_be_field(vr, r, ic);
-    load_be_field(vs, s, ic);
-    jac29 qtab[16];
+    GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
     FlatGTab29 gt{g_lds};
-    uint32_t st = p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
-    emit_verdict(i, active, st, verdict_bits, status);
+    const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * BLOCK + threadIdx.x;
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        u256 vqx, vqy, ve, vr, vs;
+        load_be_field(vqx, qx, ic);
+        load_be_field(vqy, qy, ic);
+        load_be_field(ve, e, ic);
+        load_be_field(vr, r, ic);
+        load_be_field(vs, s, ic);
+        uint32_t st = p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
+        emit_verdict(i, active, st, verdict_bits, status);
+    }
 }
 
 // identity.Verify fused: e = SHA-256(msg) stays in registers
-__global__ void __launch_bounds__(VERIFY_BLOCK) sha256_p256_verify_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
                                                                            const uint32_t* __restrict__ off, const uint8_t* __restrict__ qx,
                                                                            const uint8_t* __restrict__ qy, const uint8_t* __restrict__ r,
                                                                            const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
-                                                                           uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+                                                                           uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
+                                                                           uint8_t* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) int32_t g_lds[G29_TABLE_WORDS];
     stage_gtab(g_lds, gtab);
-    uint32_t i = blockIdx.x * VERIFY_BLOCK + threadIdx.x;
-    bool active = i < n;
-    uint32_t ic = active ? i : (n - 1);
-    uint32_t start = off[ic], end = off[ic + 1];
-    uint32_t h[8];
-    sha256_lane(arena32, arena_words, start, end - start, active, h);
-    u256 vqx, vqy, ve, vr, vs;
-#pragma unroll
-    for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];   // digest big-endian -> integer limbs
-    load_be_field(vqx, qx, ic);
-    load_be_field(vqy, qy, ic);
-    load_be_field(vr, r, ic);
-    load_be_field(vs, s, ic);
-    jac29 qtab[16];
+    GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
     FlatGTab29 gt{g_lds};
-    uint32_t st = p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
-    emit_verdict(i, active, st, verdict_bits, status);
+    const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * BLOCK + threadIdx.x;
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        uint32_t start = off[ic], end = off[ic + 1];
+        uint32_t h[8];
+        sha256_lane(arena32, arena_words, start, end - start, active, h);
+        u256 vqx, vqy, ve, vr, vs;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];   // digest big-endian -> integer limbs
+        load_be_field(vqx, qx, ic);
+        load_be_field(vqy, qy, ic);
+        load_be_field(vr, r, ic);
+        load_be_field(vs, s, ic);
+        uint32_t st = p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
+        emit_verdict(i, active, st, verdict_bits, status);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -196,22 +243,45 @@ hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes
                        (const uint32_t*)off, (uint32_t*)digests);
     return hipGetLastError();
 }
+// Launch geometry: up to 65 536 signatures (one 256-thread workgroup per CU) favour latency, beyond that throughput.
+VerifyGeom verify_geom(uint32_t n) {
+    VerifyGeom g;
+    g.block = n <= (uint32_t)VERIFY_SMALL_MAX ? 256 : 512;
+    uint32_t tiles = (n + g.block - 1) / g.block;
+    g.wgs = tiles < (uint32_t)VERIFY_MAX_WGS ? tiles : (uint32_t)VERIFY_MAX_WGS;
+    return g;
+}
+size_t verify_workspace_bytes(uint32_t n) {
+    VerifyGeom g = verify_geom(n);
+    return (size_t)g.wgs * g.block * QWS_UINT4_PER_LANE * 16;
+}
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
-                              const void* gtab, void* verdict_bits, void* status, hipStream_t st) {
+                              const void* gtab, void* qws, void* verdict_bits, void* status, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    dim3 grid((n + VERIFY_BLOCK - 1) / VERIFY_BLOCK), block(VERIFY_BLOCK);
-    hipLaunchKernelGGL(p256_verify_kernel, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
-                       (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+    VerifyGeom g = verify_geom(n);
+    dim3 grid(g.wgs), block(g.block);
+    if (g.block == 256)
+        hipLaunchKernelGGL(p256_verify_kernel<256>, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
+                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+    else
+        hipLaunchKernelGGL(p256_verify_kernel<512>, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
+                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
-                                     const void* qy, const void* r, const void* s, const void* gtab, void* verdict_bits,
-                                     void* status, hipStream_t st) {
+                                     const void* qy, const void* r, const void* s, const void* gtab, void* qws,
+                                     void* verdict_bits, void* status, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    dim3 grid((n + VERIFY_BLOCK - 1) / VERIFY_BLOCK), block(VERIFY_BLOCK);
-    hipLaunchKernelGGL(sha256_p256_verify_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                       (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
-                       (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+    VerifyGeom g = verify_geom(n);
+    dim3 grid(g.wgs), block(g.block);
+    if (g.block == 256)
+        hipLaunchKernelGGL(sha256_p256_verify_kernel<256>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                           (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
+                           (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+    else
+        hipLaunchKernelGGL(sha256_p256_verify_kernel<512>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                           (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
+                           (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
 

@@ -151,11 +151,18 @@ FAB_HD void pt_add_mixed29(jac29& r, const jac29& a, const fe& bx, const fe& by,
     r.X = x3;
 }
 
-// The verification core.  GTab provides  void load(int window, uint32_t digit /*1..15*/, fe& x, fe& y).
-// qtab: 16 jac29 entries of per-lane storage (entry 0 is filler).  Inputs are plain integers; e is hashToInt(digest).
-template <class GTab>
+// Per-lane table j*Q (j = 0..15, entry 0 is filler) kept in a plain array: host builds and tests.
+struct LocalQTab29 {
+    jac29 t[16];
+    FAB_HD void store(int j, const jac29& p) { t[j] = p; }
+    FAB_HD void load(uint32_t d, jac29& p) const { p = t[d]; }
+};
+
+// The verification core.  GTab provides  void load(int window, uint32_t digit /*1..15*/, fe& x, fe& y);
+// QTab provides store(j, point) / load(digit, point) over 16 per-lane entries.  Inputs are plain integers; e is hashToInt(digest).
+template <class GTab, class QTab>
 FAB_HD uint32_t p256_verify_core29(const u256& qx, const u256& qy, const u256& e, const u256& r, const u256& s,
-                                   const GTab& gtab, jac29* qtab) {
+                                   const GTab& gtab, QTab& qtab) {
     const u256 P = FAB_P256_P;
     const u256 N = FAB_P256_N;
     const fe ONE = {FE29_R1};
@@ -184,19 +191,20 @@ FAB_HD uint32_t p256_verify_core29(const u256& qx, const u256& qy, const u256& e
     fn_mul(u2, t, w);
 
     // --- per-lane table j*Q, j = 1..15 ---
-    qtab[0] = Q;
-    qtab[1] = Q;
+    qtab.store(0, Q);
+    qtab.store(1, Q);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
     for (int j = 2; j < 16; j += 2) {
         jac29 d, a;
         fe h, rr;
-        jac29 half = qtab[j >> 1];
+        jac29 half;
+        qtab.load((uint32_t)(j >> 1), half);
         pt_dbl29(d, half);
-        qtab[j] = d;
+        qtab.store(j, d);
         pt_add_mixed29(a, d, Q.X, Q.Y, h, rr);
-        qtab[j + 1] = a;
+        qtab.store(j + 1, a);
     }
 
     // --- T = u2 * Q ---
@@ -206,18 +214,19 @@ FAB_HD uint32_t p256_verify_core29(const u256& qx, const u256& qy, const u256& e
 #pragma unroll 1
 #endif
     for (int i = 63; i >= 0; i--) {
+        uint32_t d = nibble(u2, i);
+        jac29 ent;
+        qtab.load(d, ent);                             // issued ahead of the doublings: the gather latency hides behind them
         if (i != 63) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
             for (int k = 0; k < 4; k++) {
-                jac29 d;
-                pt_dbl29(d, T);
-                T = d;
+                jac29 dd;
+                pt_dbl29(dd, T);
+                T = dd;
             }
         }
-        uint32_t d = nibble(u2, i);
-        jac29 ent = qtab[d];
         jac29 sum;
         fe h, rr;
         pt_add29(sum, T, ent, h, rr);

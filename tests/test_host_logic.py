@@ -147,11 +147,68 @@ def test_generator_comb_table(hosttest):
         assert (int.from_bytes(x.raw, "big"), int.from_bytes(y.raw, "big")) == po.pt_mul(d << (4 * w), (po.GX, po.GY))
 
 
-def _core(hosttest, qx, qy, e, r, s):
+def test_fe29_field_arithmetic_against_python_ints(hosttest):
+    """fe29.h (the signed 29-bit-limb field the kernels compute in), C bodies, with the accumulator/limb overflow
+    assertions of the FE29_CHECK build armed: lazy sums/differences as operands, canonical zero test, round trips."""
+    P = po.P
+
+    def op(o, a, b=0):
+        out = ctypes.create_string_buffer(32)
+        hosttest.hosttest_fe29_op(o, a.to_bytes(32, "big"), b.to_bytes(32, "big"), out)
+        return int.from_bytes(out.raw, "big")
+    import random
+    rng = random.Random(29)
+    special = [0, 1, 2, P - 1, P - 2, 1 << 255, (1 << 256) - 1, (1 << 224) - 1, (1 << 96) - 1, 1 << 29, (1 << 29) - 1,
+               1 << 28, (1 << 28) - 1, P >> 1, int("1fffffff" * 8, 16), int("10000000" * 8, 16)]
+    pairs = [(a, b) for a in special for b in special] + [(rng.randrange(1 << 256), rng.randrange(1 << 256)) for _ in range(1500)]
+    for a, b in pairs:
+        assert op(0, a, b) == a * b % P
+        assert op(1, a) == a * a % P
+        assert op(2, a, b) == (a + b) % P
+        assert op(3, a, b) == (a - b) % P
+        assert op(4, a, b) == (a + b) * (a - b) % P
+        assert op(5, a, b) == (1 if (a - b) % P == 0 else 0)
+        assert op(6, a) == a % P
+
+
+def test_safegcd_inversion_against_python_pow(hosttest):
+    """modinv30.h: fixed 20 x 30 division steps, mod n (the kernel's w = s^-1) and mod p."""
+    import random
+    rng = random.Random(30)
+
+    def inv(which, a):
+        out = ctypes.create_string_buffer(32)
+        hosttest.hosttest_modinv(which, a.to_bytes(32, "big"), out)
+        return int.from_bytes(out.raw, "big")
+    for which, m in ((0, po.N), (1, po.P)):
+        vals = [1, 2, 3, m - 1, m - 2, m >> 1, (m >> 1) + 1, 1 << 255, (1 << 200) + 1, (1 << 30) - 1, 1 << 30] + \
+               [1 << k for k in range(0, 256, 17)] + [rng.randrange(1, m) for _ in range(3000)]
+        for a in vals:
+            assert inv(which, a % m) == pow(a % m, -1, m), (which, hex(a))
+        assert inv(which, 0) == 0
+
+
+def test_generator_comb_table_fe29(hosttest):
+    for w, d in [(0, 1), (0, 2), (0, 15), (1, 1), (7, 9), (31, 15), (63, 1), (63, 15)]:
+        x = ctypes.create_string_buffer(32)
+        y = ctypes.create_string_buffer(32)
+        hosttest.hosttest_gtab29_entry(w, d, x, y)
+        assert (int.from_bytes(x.raw, "big"), int.from_bytes(y.raw, "big")) == po.pt_mul(d << (4 * w), (po.GX, po.GY))
+
+
+@pytest.fixture(params=["core29", "core_u256"])
+def core_fn(request, hosttest):
+    """core29 = the verification core the kernels are compiled from (p256_verify29.h); core_u256 = the saturated-limb
+    core kept for the host tools (p256_point.h)."""
+    fn = hosttest.hosttest_verify_core29 if request.param == "core29" else hosttest.hosttest_verify_core
+    return fn
+
+
+def _core(core_fn, qx, qy, e, r, s):
     n = qx.shape[0]
     st = np.zeros(n, np.uint8)
     p = lambda a: np.ascontiguousarray(a).ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
-    hosttest.hosttest_verify_core(ctypes.c_size_t(n), p(qx), p(qy), p(e), p(r), p(s), p(st))
+    core_fn(ctypes.c_size_t(n), p(qx), p(qy), p(e), p(r), p(s), p(st))
     return st
 
 
@@ -159,21 +216,21 @@ def _arr(items):
     return np.frombuffer(b"".join(items), dtype=np.uint8).reshape(-1, 32).copy()
 
 
-def test_verify_core_headers_on_golden_and_edge_vectors(hosttest):
+def test_verify_core_headers_on_golden_and_edge_vectors(core_fn):
     vs = [v for v in _load("edge_kats.json") if len(v["e"]) == 64 and 0 <= int(v["r"], 16) < 1 << 256 and 0 <= int(v["s"], 16) < 1 << 256]
-    st = _core(hosttest, *[_arr([_h32(v[k]) for v in vs]) for k in ("qx", "qy", "e", "r", "s")])
+    st = _core(core_fn, *[_arr([_h32(v[k]) for v in vs]) for k in ("qx", "qy", "e", "r", "s")])
     for v, got in zip(vs, st):
         assert got == v["status"], v["name"]
     cs = _load("ref_cert_kats.json")
-    st = _core(hosttest, *[_arr([_h32(v[k]) for v in cs]) for k in ("qx", "qy", "e", "r", "s")])
+    st = _core(core_fn, *[_arr([_h32(v[k]) for v in cs]) for k in ("qx", "qy", "e", "r", "s")])
     for v, got in zip(cs, st):
         want = po.ST_HIGH_S if not v["low_s"] else (po.ST_VALID if v["expect_valid"] else po.ST_BAD_MATH)
         assert got == want, v["source"]
 
 
-def test_verify_core_headers_random_vs_oracle(hosttest):
+def test_verify_core_headers_random_vs_oracle(core_fn):
     b = coracle.make_batch(1500, seed=99, invalid_frac=0.25)
-    st = _core(hosttest, b["qx"], b["qy"], b["e"], b["r"], b["s"])
+    st = _core(core_fn, b["qx"], b["qy"], b["e"], b["r"], b["s"])
     assert (st == coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])).all()
 
 
