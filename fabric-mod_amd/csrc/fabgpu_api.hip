@@ -162,10 +162,10 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
-        std::vector<int32_t> tab(G29_TABLE_WORDS);
-        build_g_comb_table29(tab.data());
-        if (hipMalloc((void**)&ctx->d_gtab, sizeof(int32_t) * G29_TABLE_WORDS) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
-        if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(int32_t) * G29_TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
+        std::vector<int32_t> tab(G8_TABLE_WORDS);
+        build_g8_comb_table(tab.data());
+        if (hipMalloc((void**)&ctx->d_gtab, sizeof(int32_t) * G8_TABLE_WORDS) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
+        if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(int32_t) * G8_TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
         if (cfg && cfg->max_batch) {
             size_t n = cfg->max_batch;
             if ((rc = ctx->fields.ensure(n * 160)) || (rc = ctx->offs.ensure((n + 1) * 4)) || (rc = ctx->out.ensure(n * 41 + 64))) break;

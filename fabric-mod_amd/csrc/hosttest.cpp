@@ -17,7 +17,7 @@ static const uint32_t* gtab() {
 }
 
 static const int32_t* gtab29() {
-    static std::vector<int32_t> tab = [] { std::vector<int32_t> t(G29_TABLE_WORDS); build_g_comb_table29(t.data()); return t; }();
+    static std::vector<int32_t> tab = [] { std::vector<int32_t> t(G8_TABLE_WORDS); build_g8_comb_table(t.data()); return t; }();
     return tab.data();
 }
 
@@ -54,7 +54,7 @@ void hosttest_modinv(int which, const uint8_t* a32, uint8_t* out32) {
     to_be32(out32, r);
 }
 void hosttest_gtab29_entry(int window, int digit, uint8_t* x32, uint8_t* y32) {
-    FlatGTab29 gt{gtab29()};
+    G8Tab gt{gtab29()};
     fe x, y;
     u256 px, py;
     gt.load(window, (uint32_t)digit, x, y);
@@ -63,9 +63,41 @@ void hosttest_gtab29_entry(int window, int digit, uint8_t* x32, uint8_t* y32) {
     to_be32(x32, px);
     to_be32(y32, py);
 }
+// R = u1*G + u2*Q through the kernel's CombinedMult (arbitrary scalars < n, u2 != 0): affine x, y out; returns 1 for infinity
+int hosttest_combined_mult29(const uint8_t* u1_32, const uint8_t* u2_32, const uint8_t* qx32, const uint8_t* qy32, uint8_t* x32, uint8_t* y32) {
+    G8Tab gt{gtab29()};
+    const fe ONE = {FE29_R1};
+    u256 u1, u2, qx, qy;
+    from_be32(u1, u1_32); from_be32(u2, u2_32); from_be32(qx, qx32); from_be32(qy, qy32);
+    jac29 Q, R;
+    fe_to_mont(Q.X, qx);
+    fe_to_mont(Q.Y, qy);
+    Q.Z = ONE;
+    LocalQTab29 qtab;
+    bool inf;
+    p256_combined_mult29(R, inf, u1, u2, Q, gt, qtab);
+    if (inf) return 1;
+    // affine: x = X / Z^2, y = Y / Z^3 with the safegcd inversion mod p
+    const modinv_info PI = MODINV_P_INFO;
+    u256 zp, zi, x, y;
+    fe_from_mont(zp, R.Z);
+    modinv(zi, zp, PI);
+    fe fzi, zi2, zi3, fx, fy;
+    fe_to_mont(fzi, zi);
+    fe_sqr(zi2, fzi);
+    fe_mul(zi3, zi2, fzi);
+    fe_weak_norm(R.Y, R.Y);
+    fe_mul(fx, R.X, zi2);
+    fe_mul(fy, R.Y, zi3);
+    fe_from_mont(x, fx);
+    fe_from_mont(y, fy);
+    to_be32(x32, x);
+    to_be32(y32, y);
+    return 0;
+}
 void hosttest_verify_core29(size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r, const uint8_t* s,
                             uint8_t* status) {
-    FlatGTab29 gt{gtab29()};
+    G8Tab gt{gtab29()};
     for (size_t i = 0; i < n; i++) {
         u256 vqx, vqy, ve, vr, vs;
         from_be32(vqx, qx + 32 * i); from_be32(vqy, qy + 32 * i); from_be32(ve, e + 32 * i);

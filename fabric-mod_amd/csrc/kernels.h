@@ -5,8 +5,8 @@
 #include <stdint.h>
 
 namespace fab {
-constexpr int VERIFY_MAX_WGS = 256;       // persistent workgroup slots: one per CU (the comb table takes 80 KiB of the CU's 160 KiB LDS)
-constexpr int VERIFY_SMALL_MAX = 65536;   // up to here 256-thread workgroups (1 wave/SIMD), beyond 512-thread ones (2 waves/SIMD)
+constexpr int VERIFY_BLOCK = 256;         // 4 wavefronts per workgroup, one per SIMD
+constexpr int VERIFY_MAX_WGS = 256;       // persistent workgroup slots: one per CU (see kernels.hip for why not two)
 // workspace of the per-lane j*Q tables: 16 entries x 7 uint4 per lane
 constexpr size_t QWS_UINT4_PER_LANE = (size_t)16 * 7;
 

@@ -124,13 +124,6 @@ __device__ __forceinline__ void load_be_field(u256& v, const uint8_t* __restrict
     v.w[1] = __builtin_bswap32(lo.z); v.w[0] = __builtin_bswap32(lo.w);
 }
 
-__device__ __forceinline__ void stage_gtab(int32_t* lds, const int32_t* __restrict__ gtab) {
-    const uint4* src = reinterpret_cast<const uint4*>(gtab);
-    uint4* dst = reinterpret_cast<uint4*>(lds);
-    for (int k = threadIdx.x; k < G29_TABLE_WORDS / 4; k += blockDim.x) dst[k] = src[k];
-    __syncthreads();
-}
-
 __device__ __forceinline__ void emit_verdict(uint32_t i, bool active, uint32_t st, uint64_t* __restrict__ verdict_bits,
                                              uint8_t* __restrict__ status) {
     uint64_t ballot = __ballot(active && st == ST_VALID);
@@ -140,14 +133,14 @@ __device__ __forceinline__ void emit_verdict(uint32_t i, bool active, uint32_t s
 
 // Per-lane table j*Q in a global-memory workspace (not private/scratch memory: the runtime caps a dispatch's scratch
 // at ~140 MiB, which at 1.8 KB per lane admitted only ~1270 wavefronts and held the kernel at one wave per SIMD).
-// Layout per workgroup slot: [entry 16][group 7][lane BLOCK] x 16 bytes - entry j of lane t is seven uint4 (27 limbs + pad),
+// Layout per workgroup slot: [entry j-1, j = 1..16][group 7][lane BLOCK] x 16 bytes - entry j of lane t is seven uint4 (27 limbs + pad),
 // consecutive lanes are consecutive 16-byte cells, so a store (all lanes the same j) is fully coalesced and a gather by
 // digit touches at most 15 distinct 4 KiB rows per group.
 template <int BLOCK>
 struct GlobalQTab29 {
     uint4* lane;   // workspace of this workgroup slot + threadIdx.x
     __device__ __forceinline__ void store(int j, const jac29& p) {
-        uint4* e = lane + (size_t)j * 7 * BLOCK;
+        uint4* e = lane + (size_t)(j - 1) * 7 * BLOCK;
         e[0 * BLOCK] = make_uint4(p.X.v[0], p.X.v[1], p.X.v[2], p.X.v[3]);
         e[1 * BLOCK] = make_uint4(p.X.v[4], p.X.v[5], p.X.v[6], p.X.v[7]);
         e[2 * BLOCK] = make_uint4(p.X.v[8], p.Y.v[0], p.Y.v[1], p.Y.v[2]);
@@ -157,7 +150,7 @@ struct GlobalQTab29 {
         e[6 * BLOCK] = make_uint4(p.Z.v[6], p.Z.v[7], p.Z.v[8], 0);
     }
     __device__ __forceinline__ void load(uint32_t d, jac29& p) const {
-        const uint4* e = lane + (size_t)d * 7 * BLOCK;
+        const uint4* e = lane + (size_t)(d - 1) * 7 * BLOCK;
         uint4 a = e[0 * BLOCK], b = e[1 * BLOCK], c = e[2 * BLOCK], dd = e[3 * BLOCK];
         uint4 f = e[4 * BLOCK], g = e[5 * BLOCK], h = e[6 * BLOCK];
         p.X.v[0] = a.x; p.X.v[1] = a.y; p.X.v[2] = a.z; p.X.v[3] = a.w;
@@ -172,19 +165,17 @@ struct GlobalQTab29 {
 
 // Persistent workgroups: a bounded number of slots, each staging the comb table into LDS once and walking the
 // BLOCK-signature tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  (the workspace is sized by slots, not by the batch).
-// The 72 KiB table is allocated as 80 KiB of LDS, so only ONE workgroup fits a CU: BLOCK = 256 puts one wave on each SIMD
-// (best latency: a 30 000-signature block is 469 waves for 1024 SIMDs), BLOCK = 512 two waves per SIMD (large batches;
-// measured 1.4x the SIMD throughput of one wave).
+// One 256-thread workgroup per CU = one wave per SIMD.  A second wave per SIMD was measured (BLOCK = 512, round-1 PMC runs in
+// profiles/): each wave then takes 1.5x the cycles, but the chip also drops from ~2.0 to ~1.6 GHz - the integer multiplier
+// array is power-limited - so whole-job throughput does not move; one wave per SIMD keeps the latency of a block minimal.
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 2) p256_verify_kernel(uint32_t n, const uint8_t* __restrict__ qx, const uint8_t* __restrict__ qy,
                                                                     const uint8_t* __restrict__ e, const uint8_t* __restrict__ r,
                                                                     const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
                                                                     uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
                                                                     uint8_t* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) int32_t g_lds[G29_TABLE_WORDS];
-    stage_gtab(g_lds, gtab);
     GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
-    FlatGTab29 gt{g_lds};
+    G8Tab gt{gtab};
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;
@@ -209,10 +200,8 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n
                                                                            const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
                                                                            uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
                                                                            uint8_t* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) int32_t g_lds[G29_TABLE_WORDS];
-    stage_gtab(g_lds, gtab);
     GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
-    FlatGTab29 gt{g_lds};
+    G8Tab gt{gtab};
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;
@@ -243,10 +232,9 @@ hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes
                        (const uint32_t*)off, (uint32_t*)digests);
     return hipGetLastError();
 }
-// Launch geometry: up to 65 536 signatures (one 256-thread workgroup per CU) favour latency, beyond that throughput.
 VerifyGeom verify_geom(uint32_t n) {
     VerifyGeom g;
-    g.block = n <= (uint32_t)VERIFY_SMALL_MAX ? 256 : 512;
+    g.block = VERIFY_BLOCK;
     uint32_t tiles = (n + g.block - 1) / g.block;
     g.wgs = tiles < (uint32_t)VERIFY_MAX_WGS ? tiles : (uint32_t)VERIFY_MAX_WGS;
     return g;
@@ -260,12 +248,8 @@ hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const 
     if (n == 0) return hipSuccess;
     VerifyGeom g = verify_geom(n);
     dim3 grid(g.wgs), block(g.block);
-    if (g.block == 256)
-        hipLaunchKernelGGL(p256_verify_kernel<256>, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
-                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
-    else
-        hipLaunchKernelGGL(p256_verify_kernel<512>, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
-                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+    hipLaunchKernelGGL(p256_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
+                       (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
@@ -274,14 +258,9 @@ hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena
     if (n == 0) return hipSuccess;
     VerifyGeom g = verify_geom(n);
     dim3 grid(g.wgs), block(g.block);
-    if (g.block == 256)
-        hipLaunchKernelGGL(sha256_p256_verify_kernel<256>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                           (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
-                           (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
-    else
-        hipLaunchKernelGGL(sha256_p256_verify_kernel<512>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                           (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
-                           (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+    hipLaunchKernelGGL(sha256_p256_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                       (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
+                       (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
-// Host-side precomputation of the generator comb table in the fe29 representation (64 windows x 15 affine points,
-// T[i][j] = j * 2^(4 i) * G, Montgomery form with R = 2^261, balanced 29-bit digits), in the LDS layout of
-// p256_verify29.h::g29_index.  Built once per fabgpu_init from the u256 table (p256_tables.h) and uploaded to each device.
+// Host-side precomputation of the generator comb table in the fe29 representation: 32 windows x 255 affine points,
+// T[w][d] = d * 2^(8 w) * G, Montgomery form with R = 2^261, balanced 29-bit digits, layout p256_verify29.h::g8_index.
+// Built once per fabgpu_init with the host u256 arithmetic (fp256.h / p256_point.h) and uploaded to each device.
 #pragma once
 #include <vector>
 
@@ -9,25 +9,59 @@
 
 namespace fab {
 
-inline void build_g_comb_table29(int32_t* words) {
-    std::vector<uint32_t> old(G_TABLE_WORDS);
-    build_g_comb_table(old.data());
-    FlatGTab gt{old.data()};
-    for (int i = 0; i < G29_TABLE_WORDS; i++) words[i] = 0;
-    for (int w = 0; w < G29_WINDOWS; w++) {
-        for (int j = 1; j <= G29_ENTRIES; j++) {
-            u256 xm, ym, x, y;
-            gt.load(w, (uint32_t)j, xm, ym);
+inline void build_g8_comb_table(int32_t* words) {
+    for (int i = 0; i < G8_TABLE_WORDS; i++) words[i] = 0;
+    const u256 gxp = FAB_P256_GX_PLAIN, gyp = FAB_P256_GY_PLAIN;
+    const u256 ONE = FAB_P256_R1;
+    jac base;  // 2^(8 w) G
+    fp_to_mont(base.X, gxp);
+    fp_to_mont(base.Y, gyp);
+    base.Z = ONE;
+    std::vector<jac> pts(256);
+    for (int w = 0; w < G8_WINDOWS; w++) {
+        u256 bx, by;
+        jac_to_affine_mont(bx, by, base);
+        pts[1] = base;
+        for (int d = 2; d < 256; d++) {
+            if ((d & 1) == 0) {
+                pt_dbl(pts[d], pts[d >> 1]);
+            } else {
+                bool hz, rz;
+                pt_add_mixed(pts[d], pts[d - 1], bx, by, hz, rz);
+            }
+        }
+        // one inversion for the whole window (Montgomery's trick), host only
+        std::vector<u256> pre(256), zi(256);
+        pre[1] = pts[1].Z;
+        for (int d = 2; d < 256; d++) fp_mul(pre[d], pre[d - 1], pts[d].Z);
+        u256 inv;
+        fp_inv(inv, pre[255]);
+        for (int d = 255; d >= 2; d--) {
+            fp_mul(zi[d], inv, pre[d - 1]);
+            fp_mul(inv, inv, pts[d].Z);
+        }
+        zi[1] = inv;
+        for (int d = 1; d < 256; d++) {
+            u256 zi2, zi3, xm, ym, x, y;
+            fp_sqr(zi2, zi[d]);
+            fp_mul(zi3, zi2, zi[d]);
+            fp_mul(xm, pts[d].X, zi2);
+            fp_mul(ym, pts[d].Y, zi3);
             fp_from_mont(x, xm);
             fp_from_mont(y, ym);
             fe fx, fy;
             fe_to_mont(fx, x);
             fe_to_mont(fy, y);
+            int32_t* e = words + g8_index(w, (uint32_t)d);
             for (int l = 0; l < 9; l++) {
-                words[g29_index(w, 0, l, j - 1)] = fx.v[l];
-                words[g29_index(w, 1, l, j - 1)] = fy.v[l];
+                e[l] = fx.v[l];
+                e[9 + l] = fy.v[l];
             }
         }
+        // next window: 2^8 * base = 2 * pts[128]
+        jac nb;
+        pt_dbl(nb, pts[128]);
+        base = nb;
     }
 }
 

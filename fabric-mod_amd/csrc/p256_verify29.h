@@ -4,8 +4,8 @@
 // bccsp/sw/ecdsa.go:56.  Structure (DESIGN.md "Kernels"):
 //   * one signature per lane; lane-uniform control flow (flags + selects);
 //   * w = s^-1 mod n by safegcd (modinv30.h); u1 = e w, u2 = r w by Montgomery products mod n (fp256.h);
-//   * u2*Q : fixed 4-bit windows over a 15-entry per-lane Jacobian table in private memory;
-//   * u1*G : 64-window comb over a precomputed affine table staged in LDS, mixed additions only;
+//   * u2*Q : 52 signed 5-bit (Booth) windows over a 16-entry per-lane Jacobian table in a global workspace;
+//   * u1*G : 32-window 8-bit comb over a precomputed affine table resident in L2, mixed additions only;
 //   * the two partial sums stay in SEPARATE accumulators, so for an on-curve Q no addition inside either loop can
 //     meet P == +-Q (proof in DESIGN.md); only the final addition handles doubling / infinity explicitly;
 //   * no field inversion: x(R) mod n == r is tested as X == r Z^2 or X == (r + n) Z^2.
@@ -22,26 +22,31 @@ struct jac29 {
     fe X, Y, Z;  // invariants between operations: L(X) = 1, L(Y) <= 3, L(Z) = 1
 };
 
-constexpr int G29_WINDOWS = 64;   // 4-bit comb windows over u1
-constexpr int G29_ENTRIES = 15;   // digits 1..15
-// LDS / global layout of the comb table: [window][coord(2)][limb(9)][digit-1 (16 slots, 15 used)] i32.  For a fixed
-// (window, coord, limb) the 16 digits are 16 consecutive dwords: lanes with different digits hit different banks,
-// equal digits broadcast (ds_read_b32 services 32 lanes per cycle over 32 banks).
-constexpr int G29_TABLE_WORDS = G29_WINDOWS * 2 * 9 * 16;
-FAB_HD int g29_index(int window, int coord, int limb, int digit_minus_1) {
-    return ((window * 2 + coord) * 9 + limb) * 16 + digit_minus_1;
-}
-struct FlatGTab29 {
+// Generator comb table: 32 windows of 8 bits over u1, T[w][d] = d * 2^(8 w) * G for d = 1..255 as affine Montgomery fe29
+// points.  640 KiB - it lives in global memory and stays resident in every XCD's 4 MiB L2; each lane gathers one
+// 80-byte entry (five 16-byte loads) per window, issued one window ahead so the L2 latency hides behind the previous
+// mixed addition.  (A 4-bit comb fits LDS but needs 64 additions instead of 32; the additions, not the gathers, are what
+// this kernel pays for - see DESIGN.md.)
+constexpr int G8_WINDOWS = 32;
+constexpr int G8_ENTRY_WORDS = 20;                       // x[9] y[9] pad[2]: 80 bytes, 16-byte aligned
+constexpr int G8_TABLE_WORDS = G8_WINDOWS * 256 * G8_ENTRY_WORDS;   // entry 0 of each window is unused (zero)
+FAB_HD int g8_index(int window, uint32_t digit) { return (window * 256 + (int)digit) * G8_ENTRY_WORDS; }
+struct alignas(16) g8_quad {
+    int32_t x, y, z, w;
+};
+struct G8Tab {
     const int32_t* w;
     FAB_HD void load(int window, uint32_t digit, fe& x, fe& y) const {
-        const int32_t* base = w + g29_index(window, 0, 0, (int)digit - 1);
-#pragma unroll
-        for (int l = 0; l < 9; l++) {
-            x.v[l] = base[l * 16];
-            y.v[l] = base[(9 + l) * 16];
-        }
+        const g8_quad* e = reinterpret_cast<const g8_quad*>(w + g8_index(window, digit));   // five global_load_dwordx4
+        g8_quad a = e[0], b = e[1], c = e[2], d = e[3], f = e[4];
+        x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+        x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+        x.v[8] = c.x; y.v[0] = c.y; y.v[1] = c.z; y.v[2] = c.w;
+        y.v[3] = d.x; y.v[4] = d.y; y.v[5] = d.z; y.v[6] = d.w;
+        y.v[7] = f.x; y.v[8] = f.y;
     }
 };
+FAB_HD uint32_t scalar_byte(const u256& k, int i) { return (k.w[i >> 2] >> ((i & 3) * 8)) & 255u; }
 
 FAB_HD void sel_jac29(jac29& r, bool c, const jac29& a, const jac29& b) {
     fe_sel(r.X, c, a.X, b.X);
@@ -151,15 +156,171 @@ FAB_HD void pt_add_mixed29(jac29& r, const jac29& a, const fe& bx, const fe& by,
     r.X = x3;
 }
 
-// Per-lane table j*Q (j = 0..15, entry 0 is filler) kept in a plain array: host builds and tests.
+constexpr int Q5_WINDOWS = 52;   // signed 5-bit windows over u2 (52 * 5 = 260 >= 257 bits)
+
+// Per-lane table j*Q, j = 1..16, kept in a plain array: host builds and tests.
 struct LocalQTab29 {
     jac29 t[16];
-    FAB_HD void store(int j, const jac29& p) { t[j] = p; }
-    FAB_HD void load(uint32_t d, jac29& p) const { p = t[d]; }
+    FAB_HD void store(int j, const jac29& p) { t[j - 1] = p; }
+    FAB_HD void load(uint32_t d, jac29& p) const { p = t[d - 1]; }
 };
 
-// The verification core.  GTab provides  void load(int window, uint32_t digit /*1..15*/, fe& x, fe& y);
-// QTab provides store(j, point) / load(digit, point) over 16 per-lane entries.  Inputs are plain integers; e is hashToInt(digest).
+// R = u1*G + u2*Q for an on-curve affine Q (Montgomery form) and u1, u2 < n, u2 != 0: the CombinedMult of the reference's
+// crypto/elliptic.  r_inf reports the point at infinity (then Rr is meaningless).
+template <class GTab, class QTab>
+FAB_HD void p256_combined_mult29(jac29& Rr, bool& r_inf, const u256& u1, const u256& u2, const jac29& Q, const GTab& gtab, QTab& qtab) {
+    const fe ONE = {FE29_R1};
+
+    // --- per-lane table j*Q, j = 1..16 (8 doublings + 7 mixed additions) ---
+    qtab.store(1, Q);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int j = 2; j <= 16; j += 2) {
+        jac29 d, a, half;
+        fe h, rr;
+        qtab.load((uint32_t)(j >> 1), half);
+        pt_dbl29(d, half);
+        qtab.store(j, d);
+        if (j < 16) {
+            pt_add_mixed29(a, d, Q.X, Q.Y, h, rr);
+            qtab.store(j + 1, a);
+        }
+    }
+
+    // --- T = u2 * Q : 52 signed 5-bit (Booth) windows, digit_i = -16 k[5i+4] + 8 k[5i+3] + .. + k[5i] + k[5i-1] in [-16, 16];
+    //     51 x 5 doublings and at most 52 additions of +-|digit| Q.  (No addition can meet P == +-Q: DESIGN.md.) ---
+    uint32_t kw[9];
+#pragma unroll
+    for (int i = 0; i < 8; i++) kw[i] = u2.w[i];
+    kw[8] = 0;
+    jac29 T = Q;
+    bool t_inf = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = Q5_WINDOWS - 1; i >= 0; i--) {
+        uint32_t six;                                  // bits 5i-1 .. 5i+4 of u2 (bit -1 = 0)
+        if (i == 0) {
+            six = (kw[0] << 1) & 63u;
+        } else {
+            int p = 5 * i - 1;
+            uint64_t two = ((uint64_t)kw[(p >> 5) + 1] << 32) | kw[p >> 5];
+            six = (uint32_t)(two >> (p & 31)) & 63u;
+        }
+        int32_t digit = (int32_t)((six >> 1) & 15u) + (int32_t)(six & 1u) - (int32_t)((six >> 5) << 4);
+        bool neg = digit < 0;
+        uint32_t mag = (uint32_t)(neg ? -digit : digit);
+        jac29 ent;
+        qtab.load(mag ? mag : 1u, ent);                // issued ahead of the doublings: the gather latency hides behind them
+        if (i != Q5_WINDOWS - 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+            for (int k = 0; k < 5; k++) {
+                jac29 dd;
+                pt_dbl29(dd, T);
+                T = dd;
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 9; l++) ent.Y.v[l] = neg ? -ent.Y.v[l] : ent.Y.v[l];
+        jac29 sum;
+        fe h, rr;
+        pt_add29(sum, T, ent, h, rr);
+        bool take_ent = t_inf & (mag != 0);
+        bool take_sum = (!t_inf) & (mag != 0);
+        sel_jac29(T, take_sum, sum, T);
+        sel_jac29(T, take_ent, ent, T);
+        t_inf = t_inf & (mag == 0);
+    }
+
+    for (int j = 2; j < 16; j += 2) {
+        jac29 d, a, half;
+        fe h, rr;
+        qtab.load((uint32_t)(j >> 1), half);
+        pt_dbl29(d, half);
+        qtab.store(j, d);
+        pt_add_mixed29(a, d, Q.X, Q.Y, h, rr);
+        qtab.store(j + 1, a);
+    }
+    jac29 T = Q;
+    bool t_inf = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = 63; i >= 0; i--) {
+        uint32_t d = nibble(u2, i);
+        jac29 ent;
+        qtab.load(d ? d : 1u, ent);
+        if (i != 63) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+            for (int k = 0; k < 4; k++) {
+                jac29 dd;
+                pt_dbl29(dd, T);
+                T = dd;
+            }
+        }
+        jac29 sum;
+        fe h, rr;
+        pt_add29(sum, T, ent, h, rr);
+        bool take_ent = t_inf & (d != 0);
+        bool take_sum = (!t_inf) & (d != 0);
+        sel_jac29(T, take_sum, sum, T);
+        sel_jac29(T, take_ent, ent, T);
+        t_inf = t_inf & (d == 0);
+    }
+
+#endif
+    // --- S = u1 * G (8-bit comb, mixed additions only; next window's entry is gathered while this one is added) ---
+    jac29 S = Q;
+    bool s_inf = true;
+    uint32_t nd = scalar_byte(u1, 0);
+    fe nx, ny;
+    gtab.load(0, nd ? nd : 1u, nx, ny);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = 0; i < G8_WINDOWS; i++) {
+        uint32_t d = nd;
+        jac29 ent, sum;
+        fe h, rr;
+        ent.X = nx;
+        ent.Y = ny;
+        ent.Z = ONE;
+        int inext = i + 1 < G8_WINDOWS ? i + 1 : i;
+        nd = scalar_byte(u1, inext);
+        gtab.load(inext, nd ? nd : 1u, nx, ny);
+        pt_add_mixed29(sum, S, ent.X, ent.Y, h, rr);
+        bool take_ent = s_inf & (d != 0);
+        bool take_sum = (!s_inf) & (d != 0);
+        sel_jac29(S, take_sum, sum, S);
+        sel_jac29(S, take_ent, ent, S);
+        s_inf = s_inf & (d == 0);
+    }
+
+    // --- R = S + T with the exceptional cases of the group law (Appendix A step 8) ---
+    jac29 Rp, Rd;
+    fe h, rr;
+    pt_add29(Rp, S, T, h, rr);
+    bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
+    pt_dbl29(Rd, T);
+    r_inf = t_inf & s_inf;                       // cannot happen for u2 != 0; kept for completeness
+    bool use_T = s_inf & !t_inf;
+    bool use_S = t_inf & !s_inf;
+    bool both = !s_inf & !t_inf;
+    bool use_dbl = both & hz & rz;                    // S == T
+    r_inf = r_inf | (both & hz & !rz);                // S == -T  -> point at infinity
+    Rr = Rp;
+    sel_jac29(Rr, use_dbl, Rd, Rr);
+    sel_jac29(Rr, use_T, T, Rr);
+    sel_jac29(Rr, use_S, S, Rr);
+}
+
+// The verification core.  GTab provides  void load(int window, uint32_t digit /*1..255*/, fe& x, fe& y);
+// QTab provides store(j, point) / load(j, point) for the 16 per-lane entries j = 1..16.  Inputs are plain integers; e is hashToInt(digest).
 template <class GTab, class QTab>
 FAB_HD uint32_t p256_verify_core29(const u256& qx, const u256& qy, const u256& e, const u256& r, const u256& s,
                                    const GTab& gtab, QTab& qtab) {
@@ -190,90 +351,9 @@ FAB_HD uint32_t p256_verify_core29(const u256& qx, const u256& qy, const u256& e
     fn_to_mont(t, r);
     fn_mul(u2, t, w);
 
-    // --- per-lane table j*Q, j = 1..15 ---
-    qtab.store(0, Q);
-    qtab.store(1, Q);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-    for (int j = 2; j < 16; j += 2) {
-        jac29 d, a;
-        fe h, rr;
-        jac29 half;
-        qtab.load((uint32_t)(j >> 1), half);
-        pt_dbl29(d, half);
-        qtab.store(j, d);
-        pt_add_mixed29(a, d, Q.X, Q.Y, h, rr);
-        qtab.store(j + 1, a);
-    }
-
-    // --- T = u2 * Q ---
-    jac29 T = Q;
-    bool t_inf = true;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-    for (int i = 63; i >= 0; i--) {
-        uint32_t d = nibble(u2, i);
-        jac29 ent;
-        qtab.load(d, ent);                             // issued ahead of the doublings: the gather latency hides behind them
-        if (i != 63) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-            for (int k = 0; k < 4; k++) {
-                jac29 dd;
-                pt_dbl29(dd, T);
-                T = dd;
-            }
-        }
-        jac29 sum;
-        fe h, rr;
-        pt_add29(sum, T, ent, h, rr);
-        bool take_ent = t_inf & (d != 0);
-        bool take_sum = (!t_inf) & (d != 0);
-        sel_jac29(T, take_sum, sum, T);
-        sel_jac29(T, take_ent, ent, T);
-        t_inf = t_inf & (d == 0);
-    }
-
-    // --- S = u1 * G (comb) ---
-    jac29 S = Q;
-    bool s_inf = true;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-    for (int i = 0; i < G29_WINDOWS; i++) {
-        uint32_t d = nibble(u1, i);
-        jac29 ent, sum;
-        fe h, rr;
-        gtab.load(i, d ? d : 1u, ent.X, ent.Y);
-        ent.Z = ONE;
-        pt_add_mixed29(sum, S, ent.X, ent.Y, h, rr);
-        bool take_ent = s_inf & (d != 0);
-        bool take_sum = (!s_inf) & (d != 0);
-        sel_jac29(S, take_sum, sum, S);
-        sel_jac29(S, take_ent, ent, S);
-        s_inf = s_inf & (d == 0);
-    }
-
-    // --- R = S + T with the exceptional cases of the group law (Appendix A step 8) ---
-    jac29 Rp, Rd;
-    fe h, rr;
-    pt_add29(Rp, S, T, h, rr);
-    bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
-    pt_dbl29(Rd, T);
-    bool r_inf = t_inf & s_inf;                       // cannot happen for u2 != 0; kept for completeness
-    bool use_T = s_inf & !t_inf;
-    bool use_S = t_inf & !s_inf;
-    bool both = !s_inf & !t_inf;
-    bool use_dbl = both & hz & rz;                    // S == T
-    r_inf = r_inf | (both & hz & !rz);                // S == -T  -> point at infinity
-    jac29 Rr = Rp;
-    sel_jac29(Rr, use_dbl, Rd, Rr);
-    sel_jac29(Rr, use_T, T, Rr);
-    sel_jac29(Rr, use_S, S, Rr);
-    // a Jacobian Z == 0 also encodes infinity (doubling a point of order 2 cannot happen on a prime-order curve; kept cheap)
+    jac29 Rr;
+    bool r_inf;
+    p256_combined_mult29(Rr, r_inf, u1, u2, Q, gtab, qtab);
 
     // --- x(R) mod n == r  without inverting Z ---
     const u256 PMN = FAB_P256_P_MINUS_N;

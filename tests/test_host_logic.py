@@ -189,11 +189,53 @@ def test_safegcd_inversion_against_python_pow(hosttest):
 
 
 def test_generator_comb_table_fe29(hosttest):
-    for w, d in [(0, 1), (0, 2), (0, 15), (1, 1), (7, 9), (31, 15), (63, 1), (63, 15)]:
+    """8-bit comb: T[w][d] = d * 2^(8 w) * G, every window at its corners plus a sweep of window 0 and 31."""
+    cases = [(w, d) for w in range(32) for d in (1, 2, 127, 128, 255)] + [(0, d) for d in range(1, 256)] + [(31, d) for d in range(1, 256, 7)]
+    for w, d in cases:
         x = ctypes.create_string_buffer(32)
         y = ctypes.create_string_buffer(32)
         hosttest.hosttest_gtab29_entry(w, d, x, y)
-        assert (int.from_bytes(x.raw, "big"), int.from_bytes(y.raw, "big")) == po.pt_mul(d << (4 * w), (po.GX, po.GY))
+        assert (int.from_bytes(x.raw, "big"), int.from_bytes(y.raw, "big")) == po.pt_mul(d << (8 * w), (po.GX, po.GY)), (w, d)
+
+
+def test_combined_mult_adversarial_scalars(hosttest):
+    """u1*G + u2*Q through the kernel's CombinedMult for scalar patterns that stress the window recodings: every signed
+    5-bit (Booth) digit in {-16..16} at the bottom, middle and top window, runs of ones (carry chains through all 52
+    windows), u1 = 0, single bits, n-1, and the exceptional final additions u1*G == +-u2*Q."""
+    import random
+    rng = random.Random(52)
+    N = po.N
+    G = (po.GX, po.GY)
+
+    def run(u1, u2, Q):
+        x = ctypes.create_string_buffer(32)
+        y = ctypes.create_string_buffer(32)
+        inf = hosttest.hosttest_combined_mult29(u1.to_bytes(32, "big"), u2.to_bytes(32, "big"), Q[0].to_bytes(32, "big"),
+                                                Q[1].to_bytes(32, "big"), x, y)
+        return None if inf else (int.from_bytes(x.raw, "big"), int.from_bytes(y.raw, "big"))
+
+    def want(u1, u2, Q):
+        return po.pt_add(po.pt_mul(u1, G) if u1 else None, po.pt_mul(u2, Q))
+    dq = rng.randrange(1, N)
+    Q = po.pt_mul(dq, G)
+    u2s = [1, 2, 15, 16, 17, 31, 32, 33, (1 << 255), (1 << 256) % N, N - 1, N - 2, N - 16, N - 17, N >> 1, (1 << 250) - 1,
+           int("5" * 64, 16) % N, int("a" * 63, 16), int("f" * 63, 16), int("84210" * 12, 16) % N, int("7bdef" * 12, 16) % N]
+    for w in (0, 1, 25, 50, 51):
+        for d in range(1, 32):
+            v = (d << (5 * w)) % N
+            if v:
+                u2s.append(v)
+    u2s += [rng.randrange(1, N) for _ in range(40)]
+    u1s = [0, 1, 255, 256, (1 << 248), N - 1, int("ff00" * 16, 16) % N, int("01" * 32, 16)] + [rng.randrange(N) for _ in range(8)]
+    for k, u2 in enumerate(u2s):
+        u1 = u1s[k % len(u1s)]
+        assert run(u1, u2, Q) == want(u1, u2, Q), (hex(u1), hex(u2))
+    for u1 in u1s:
+        assert run(u1, 12345, Q) == want(u1, 12345, Q), hex(u1)
+    # exceptional final addition: u1*G == u2*Q (doubling) and u1*G == -u2*Q (infinity): u1 = +-u2*dq
+    for u2 in (1, 7, rng.randrange(1, N)):
+        assert run(u2 * dq % N, u2, Q) == po.pt_mul(2 * u2 * dq % N, G)
+        assert run((-u2 * dq) % N, u2, Q) is None
 
 
 @pytest.fixture(params=["core29", "core_u256"])
