@@ -235,45 +235,6 @@ FAB_HD void p256_combined_mult29(jac29& Rr, bool& r_inf, const u256& u1, const u
         t_inf = t_inf & (mag == 0);
     }
 
-    for (int j = 2; j < 16; j += 2) {
-        jac29 d, a, half;
-        fe h, rr;
-        qtab.load((uint32_t)(j >> 1), half);
-        pt_dbl29(d, half);
-        qtab.store(j, d);
-        pt_add_mixed29(a, d, Q.X, Q.Y, h, rr);
-        qtab.store(j + 1, a);
-    }
-    jac29 T = Q;
-    bool t_inf = true;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-    for (int i = 63; i >= 0; i--) {
-        uint32_t d = nibble(u2, i);
-        jac29 ent;
-        qtab.load(d ? d : 1u, ent);
-        if (i != 63) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-            for (int k = 0; k < 4; k++) {
-                jac29 dd;
-                pt_dbl29(dd, T);
-                T = dd;
-            }
-        }
-        jac29 sum;
-        fe h, rr;
-        pt_add29(sum, T, ent, h, rr);
-        bool take_ent = t_inf & (d != 0);
-        bool take_sum = (!t_inf) & (d != 0);
-        sel_jac29(T, take_sum, sum, T);
-        sel_jac29(T, take_ent, ent, T);
-        t_inf = t_inf & (d == 0);
-    }
-
-#endif
     // --- S = u1 * G (8-bit comb, mixed additions only; next window's entry is gathered while this one is added) ---
     jac29 S = Q;
     bool s_inf = true;
