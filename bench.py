@@ -30,10 +30,13 @@ SEED = 20260921
 ALGO_BYTES_PER_VERIFY = 160.125          # 5 x 32 B in, 1 bit out
 MAC_PER_VERIFY = 3.1e5                   # SURVEY.md 8(d) canonical u32 multiply-accumulate count per verify
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8 TB/s spec
-# integer-ALU peak: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz x r_mul, r_mul = measured issue rate of
-# v_mad_u64_u32 relative to full-rate VALU (fabric-mod_amd/csrc/ubench.hip, recorded in DESIGN.md)
-R_MUL = 0.25
-VALU_PEAK_MAC = 256 * 4 * 32 * 2.4e9 * R_MUL
+# integer-MAC ceiling, MEASURED on MI355X by fabric-mod_amd/csrc/ubench.hip (profiles/r01_ubench_instruction_costs.txt):
+# independent v_mad_u64_u32 streams at 4 waves/SIMD on all 1024 SIMDs retire one wave-instruction per 1.902 ns per SIMD
+# (wall clock, i.e. at whatever frequency the chip sustains for a pure multiplier stream) = 64 lanes / 1.902 ns x 1024 SIMDs.
+VALU_PEAK_MAC = 64 / 1.902e-9 * 1024
+# v_mad_i64_i32 the verify kernel actually executes per signature (static count x trip counts; rocprof
+# SQ_INSTS_VALU_INT64 = 437 k per lane includes the 64-bit shifts): 263 dbl x 792 + 53 add x 1728 + 39 madd x 1179 + ~5 k
+EXECUTED_MAC_PER_VERIFY = 3.51e5
 
 
 def main():
@@ -119,6 +122,12 @@ def main():
         assert (fabgpu.unpack_bits(m[rank], n) == got).all(), "all-gathered bitmap differs from the local one"
 
     if rank == 0:
+        # HBM/fabric bytes per launch from the rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic.json:
+        # 2 x FETCH_SIZE per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), only valid for the BASELINE workload
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if n_tx == N_TX and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("traffic_gb_per_launch") * 1e9   # bytes per launch
         ms_per_step = dt / args.steps * 1e3
         total = n * world
         value = total / (dt / args.steps)
@@ -135,12 +144,14 @@ def main():
                        "parallelism": "1 block per GPU%s" % (" + RCCL all-gather of verdict bitmaps" if world > 1 else "")},
             "validated_tx_per_s": n_tx * world / (dt / args.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "p256_verify_kernel", "kernel_ms": kernel_s * 1e3,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (algorithmic: %d)" % int(ALGO_BYTES_PER_VERIFY * n), "kernel": "p256_verify_kernel", "kernel_ms": kernel_s * 1e3,
                          "kernel_ms_lib_events": kernel_ms,
                          "note": "integer-VALU-bound, not HBM-bound (SURVEY 8(d)): see valu_roofline"},
             "valu_roofline": {"bound": "u32-mac", "achieved": n / kernel_s * MAC_PER_VERIFY, "peak": VALU_PEAK_MAC, "unit": "MAC/s",
-                              "frac": n / kernel_s * MAC_PER_VERIFY / VALU_PEAK_MAC, "r_mul": R_MUL,
-                              "model": "3.1e5 u32 MACs per verify (SURVEY 8(d) canonical count)"},
+                              "frac": n / kernel_s * MAC_PER_VERIFY / VALU_PEAK_MAC,
+                              "model": "3.1e5 u32 MACs per verify (SURVEY 8(d) canonical count); peak = measured v_mad_u64_u32 ceiling of csrc/ubench.hip",
+                              "executed_mac_per_verify": EXECUTED_MAC_PER_VERIFY,
+                              "executed_frac": n / kernel_s * EXECUTED_MAC_PER_VERIFY / VALU_PEAK_MAC},
             "parity": "verdict bitmap bit-identical to generator ground truth on the timed input",
         }
         if world == 1 and not args.no_cpu_baseline:
