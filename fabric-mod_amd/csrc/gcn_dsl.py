@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""A tiny straight-line "assembler DSL" for the gfx950 instruction streams of the fe29 field / point arithmetic.
+
+A Program is a list of abstract instructions over symbolic registers:
+    fe registers   nine 32-bit VGPR limbs each, named "<fe>.<i>"
+    "acc"          the 64-bit column accumulator, hard-wired to v[0:1] (inline asm cannot name half of a 64-bit operand)
+    constants      wave-uniform SGPR operands (the Montgomery multipliers 2^9, 2^18, -2^21, 2^24, the rounding 2^28,
+                   and the lane-parity mask of the two-lanes-per-signature programs)
+Two back ends consume the same list:
+    emit_asm()     one GNU inline-asm statement (operands numbered outputs-first), every instruction encoded in 8 bytes
+                   (VOP3, VOP2+DPP, or VOP2+literal) so that a `.p2align 3` block never leaves 8-byte alignment, with the
+                   gfx940-family hazard "VALU writes a VGPR, a DPP instruction reads it as its DPP source: 2 wait states"
+                   padded by s_nop where the program order does not already provide the distance (only v_mov / v_add / v_sub
+                   are used in DPP form: v_subrev_u32_dpp did not compute src1 - dpp(src0) on MI355X, probed in gputest.hip);
+    run()          a reference interpreter with exact 32/64-bit wrap-around semantics on an explicit (even, odd) lane
+                   pair - tests/test_pair_programs.py executes the very programs the kernels run against big-integer
+                   point arithmetic, without a GPU.
+"""
+
+M32 = (1 << 32) - 1
+M64 = (1 << 64) - 1
+
+
+def s32(x):
+    x &= M32
+    return x - (1 << 32) if x >> 31 else x
+
+
+def s64(x):
+    x &= M64
+    return x - (1 << 64) if x >> 63 else x
+
+
+CONSTS = {"c9": 512, "c18": 262144, "cm21": -2097152, "c24": 16777216, "c28": 268435456}
+RED = [(3, "c9"), (6, "c18"), (7, "cm21"), (8, "c24")]
+
+
+class Program:
+    def __init__(self, name):
+        self.name = name
+        self.ins = []          # (op, dst, *srcs)
+        self.fes = {}          # fe name -> kind: "io" | "tmp" | "in"
+        self.order = []        # declaration order
+
+    # ---- declarations -------------------------------------------------------------------------------------------
+    def fe(self, name, kind):
+        assert kind in ("io", "tmp", "in") and name not in self.fes
+        self.fes[name] = kind
+        self.order.append(name)
+        return [f"{name}.{i}" for i in range(9)]
+
+    # ---- elementwise helpers (nine limbs) ---------------------------------------------------------------------
+    def add(self, d, a, b):
+        for i in range(9):
+            self.ins.append(("add", d[i], a[i], b[i]))
+
+    def sub(self, d, a, b):
+        for i in range(9):
+            self.ins.append(("sub", d[i], a[i], b[i]))
+
+    def neg(self, d, a):
+        for i in range(9):
+            self.ins.append(("sub", d[i], 0, a[i]))
+
+    def shl(self, d, a, n):
+        for i in range(9):
+            self.ins.append(("shl", d[i], a[i], n))
+
+    def shladd(self, d, a, n, b):             # d = (a << n) + b
+        for i in range(9):
+            self.ins.append(("shladd", d[i], a[i], n, b[i]))
+
+    def sel(self, d, odd, even):              # d = lane is odd ? odd : even
+        for i in range(9):
+            self.ins.append(("sel", d[i], odd[i], even[i]))
+
+    def mov(self, d, a):
+        for i in range(9):
+            self.ins.append(("mov", d[i], a[i]))
+
+    def swp(self, d, a):                      # d = partner's a
+        for i in range(9):
+            self.ins.append(("swp_mov", d[i], a[i]))
+
+    def swp_sub(self, d, a, b):               # d = partner's a - own b
+        for i in range(9):
+            self.ins.append(("swp_sub", d[i], a[i], b[i]))
+
+    def swp_add(self, d, a, b):               # d = partner's a + own b
+        for i in range(9):
+            self.ins.append(("swp_add", d[i], a[i], b[i]))
+
+    def wnorm(self, d, a, c):
+        """One parallel carry pass (fe_weak_norm): d = a with digits back in [-2^28, 2^28] (+-carry).  c: scratch fe."""
+        for i in range(8):
+            self.ins.append(("addc", c[i], a[i], "c28"))          # a + 2^28
+            self.ins.append(("ashr", c[i], c[i], 29))             # carry out of limb i
+        self.ins.append(("bfe29", d[0], a[0]))
+        for i in range(1, 8):
+            self.ins.append(("bfe29", c[8], a[i]))                # c[8] is free scratch
+            self.ins.append(("add", d[i], c[8], c[i - 1]))
+        self.ins.append(("add", d[8], a[8], c[7]))
+
+    # ---- Montgomery product / square (fe29.h FE29_REDUCE_COLUMN) ---------------------------------------------------
+    def _columns(self, r, products):
+        first = True
+        for k in range(17):
+            for (x, y) in products(k):
+                self.ins.append(("mad0" if first else "mad", "acc", x, y))
+                first = False
+            for (dd, c) in RED:
+                if k >= dd and k - dd <= 8:
+                    self.ins.append(("mad", "acc", r[k - dd], c))
+            if k <= 8:
+                self.ins.append(("q29", r[k], "acc"))             # r[k] = acc & (2^29-1)   (quotient digit)
+                self.ins.append(("ashr64", "acc", 29))
+            else:
+                self.ins.append(("bfe29", r[k - 9], "acc"))       # balanced output digit
+                self.ins.append(("round28", "acc"))               # acc += 2^28
+                self.ins.append(("ashr64", "acc", 29))
+                if k == 16:
+                    self.ins.append(("movacc", r[8], "acc"))
+
+    def mul(self, r, a, b):
+        assert r[0] != a[0] and r[0] != b[0], "mul destination must not alias a source"
+        self._columns(r, lambda k: [(a[i], b[k - i]) for i in range(9) if 0 <= k - i < 9])
+
+    def sqr(self, r, a, t):
+        """t: scratch fe for the doubled limbs (8 used)."""
+        assert r[0] != a[0] and t[0] != a[0] and t[0] != r[0]
+        for i in range(8):
+            self.ins.append(("shl", t[i], a[i], 1))
+
+        def prods(k):
+            out = []
+            for i in range(9):
+                j = k - i
+                if j > i and j < 9:
+                    out.append((t[i], a[j]))
+                if j == i:
+                    out.append((a[i], a[i]))
+            return out
+        self._columns(r, prods)
+
+    # ---- interpreter -------------------------------------------------------------------------------------------------
+    def run(self, regs_even, regs_odd):
+        """regs_*: dict "fe.i" -> int (io / in registers must be present).  Executes on the lane pair, returns the dicts."""
+        L = [dict(regs_even), dict(regs_odd)]
+        acc = [0, 0]
+
+        def val(lane, x):
+            if isinstance(x, int):
+                return x
+            if x in CONSTS:
+                return CONSTS[x]
+            return L[lane][x]
+        for ins in self.ins:
+            op = ins[0]
+            if op in ("swp_mov", "swp_sub", "swp_add"):
+                new = []
+                for lane in (0, 1):
+                    p = val(1 - lane, ins[2])
+                    if op == "swp_mov":
+                        v = p
+                    elif op == "swp_sub":
+                        v = p - val(lane, ins[3])
+                    else:
+                        v = p + val(lane, ins[3])
+                    new.append(s32(v))
+                for lane in (0, 1):
+                    L[lane][ins[1]] = new[lane]
+                continue
+            for lane in (0, 1):
+                R = L[lane]
+                if op == "add":
+                    R[ins[1]] = s32(val(lane, ins[2]) + val(lane, ins[3]))
+                elif op == "addc":
+                    R[ins[1]] = s32(val(lane, ins[2]) + val(lane, ins[3]))
+                elif op == "sub":
+                    R[ins[1]] = s32(val(lane, ins[2]) - val(lane, ins[3]))
+                elif op == "shl":
+                    R[ins[1]] = s32(val(lane, ins[2]) << ins[3])
+                elif op == "shladd":
+                    R[ins[1]] = s32((val(lane, ins[2]) << ins[3]) + val(lane, ins[4]))
+                elif op == "ashr":
+                    R[ins[1]] = s32(val(lane, ins[2])) >> ins[3]
+                elif op == "sel":
+                    R[ins[1]] = val(lane, ins[2]) if lane == 1 else val(lane, ins[3])
+                elif op == "mov":
+                    R[ins[1]] = val(lane, ins[2])
+                elif op == "bfe29":
+                    x = acc[lane] if ins[2] == "acc" else val(lane, ins[2])
+                    x &= (1 << 29) - 1
+                    R[ins[1]] = x - (1 << 29) if x >> 28 else x
+                elif op == "mad0":
+                    acc[lane] = s64(s32(val(lane, ins[2])) * s32(val(lane, ins[3])))
+                elif op == "mad":
+                    acc[lane] = s64(acc[lane] + s32(val(lane, ins[2])) * s32(val(lane, ins[3])))
+                elif op == "q29":
+                    R[ins[1]] = acc[lane] & ((1 << 29) - 1)
+                elif op == "ashr64":
+                    acc[lane] = s64(acc[lane]) >> ins[2]
+                elif op == "round28":
+                    acc[lane] = s64(acc[lane] + (1 << 28))
+                elif op == "movacc":
+                    R[ins[1]] = s32(acc[lane])
+                else:
+                    raise ValueError(op)
+        return L[0], L[1]
+
+    # ---- asm back end -------------------------------------------------------------------------------------------------
+    def emit_asm(self, macro_args):
+        """macro_args: dict fe name -> C expression of the `fe` lvalue.  Returns (text of the #define, stats)."""
+        outs, ins_ = [], []
+        num = {}
+        for name in self.order:
+            if self.fes[name] in ("io", "tmp"):
+                for i in range(9):
+                    num[f"{name}.{i}"] = len(outs)
+                    outs.append('"%sv"((%s).v[%d])' % ("+" if self.fes[name] == "io" else "=&", macro_args[name], i))
+        for name in self.order:
+            if self.fes[name] == "in":
+                for i in range(9):
+                    num[f"{name}.{i}"] = len(outs) + len(ins_)
+                    ins_.append('"v"((%s).v[%d])' % (macro_args[name], i))
+        for c in ("c9", "c18", "cm21", "c24", "c28"):
+            num[c] = len(outs) + len(ins_)
+            ins_.append('"s"(%d)' % CONSTS[c])
+        num["c28q"] = len(outs) + len(ins_)
+        ins_.append('"s"((int64_t)268435456)')
+        num["mask"] = len(outs) + len(ins_)
+        ins_.append('"s"((uint64_t)0xAAAAAAAAAAAAAAAAull)')
+
+        def o(x):
+            if isinstance(x, int):
+                return str(x)
+            return "%%%d" % num[x]
+        DPP = " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        lines = []
+        last_write = {}
+        nops = 0
+        count = 0
+
+        def put(text, writes=None, dpp_src=None):
+            nonlocal nops, count
+            if dpp_src is not None and dpp_src in last_write:
+                between = count - last_write[dpp_src] - 1
+                if between < 2:
+                    lines.append("s_nop %d" % (2 - between - 1))
+                    nops += 1
+                    count += 1
+            lines.append(text)
+            if writes is not None:
+                last_write[writes] = count
+            count += 1
+        for ins in self.ins:
+            op = ins[0]
+            if op == "add" or op == "addc":
+                put("v_add_u32_e64 %s, %s, %s" % (o(ins[1]), o(ins[2]), o(ins[3])), ins[1])
+            elif op == "sub":
+                put("v_sub_u32_e64 %s, %s, %s" % (o(ins[1]), o(ins[2]), o(ins[3])), ins[1])
+            elif op == "shl":
+                put("v_lshlrev_b32_e64 %s, %d, %s" % (o(ins[1]), ins[3], o(ins[2])), ins[1])
+            elif op == "shladd":
+                put("v_lshl_add_u32 %s, %s, %d, %s" % (o(ins[1]), o(ins[2]), ins[3], o(ins[4])), ins[1])
+            elif op == "ashr":
+                put("v_ashrrev_i32_e64 %s, %d, %s" % (o(ins[1]), ins[3], o(ins[2])), ins[1])
+            elif op == "sel":
+                put("v_cndmask_b32_e64 %s, %s, %s, %s" % (o(ins[1]), o(ins[3]), o(ins[2]), o("mask")), ins[1])
+            elif op == "mov":
+                put("v_mov_b32_e64 %s, %s" % (o(ins[1]), o(ins[2])), ins[1])
+            elif op == "swp_mov":
+                put("v_mov_b32_dpp %s, %s%s" % (o(ins[1]), o(ins[2]), DPP), ins[1], dpp_src=ins[2])
+            elif op == "swp_sub":
+                put("v_sub_u32_dpp %s, %s, %s%s" % (o(ins[1]), o(ins[2]), o(ins[3]), DPP), ins[1], dpp_src=ins[2])
+            elif op == "swp_add":
+                put("v_add_u32_dpp %s, %s, %s%s" % (o(ins[1]), o(ins[2]), o(ins[3]), DPP), ins[1], dpp_src=ins[2])
+            elif op == "bfe29":
+                put("v_bfe_i32 %s, %s, 0, 29" % (o(ins[1]), "v0" if ins[2] == "acc" else o(ins[2])), ins[1])
+            elif op == "mad0":
+                put("v_mad_i64_i32 v[0:1], vcc, %s, %s, 0" % (o(ins[2]), o(ins[3])))
+            elif op == "mad":
+                put("v_mad_i64_i32 v[0:1], vcc, %s, %s, v[0:1]" % (o(ins[2]), o(ins[3])))
+            elif op == "q29":
+                put("v_and_b32 %s, 0x1fffffff, v0" % o(ins[1]), ins[1])
+            elif op == "ashr64":
+                put("v_ashrrev_i64 v[0:1], %d, v[0:1]" % ins[2])
+            elif op == "round28":
+                put("v_lshl_add_u64 v[0:1], v[0:1], 0, %s" % o("c28q"))
+            elif op == "movacc":
+                put("v_mov_b32_e64 %s, v0" % o(ins[1]), ins[1])
+            else:
+                raise ValueError(op)
+        args = ", ".join(macro_args[n].strip("()") for n in self.order)
+        text = ["// %s: %d instructions (%d v_mad_i64_i32, %d hazard s_nop)" % (
+            self.name, len(lines), sum(l.startswith("v_mad") for l in lines), nops)]
+        text.append("#define %s(%s) \\" % (self.name, args))
+        text.append("    asm( \\")
+        text.append("        FE29_GCN_ALIGN \\")
+        for l in lines:
+            text.append('        "%s\\n\\t" \\' % l)
+        text.append("        : %s \\" % ", ".join(outs))
+        text.append("        : %s \\" % ", ".join(ins_))
+        text.append('        : "v0", "v1", "vcc")')
+        return "\n".join(text) + "\n", {"instructions": len(lines), "nops": nops}

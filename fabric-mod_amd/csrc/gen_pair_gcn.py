@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generates pair29_gcn.h: point doubling / addition / mixed addition on secp256r1 with TWO LANES PER SIGNATURE.
+
+Why: BASELINE config 2 (30 000 signatures) is 469 wavefronts for 1024 SIMDs and every wave issues one VALU instruction per
+~4.2 cycles whatever it is - the one-signature-per-lane kernel is bound by the LENGTH of its instruction stream.  The
+eight field products of a doubling have dependency depth four, the sixteen of an addition depth eight: on a lane pair
+(even lane "E", odd lane "O", exchanged with DPP quad_perm:[1,0,3,2]) the stream is 779 / 1455 / 1169 instructions
+instead of 1339 / 2678 / 1900.
+
+Lane roles are static.  Between operations   E holds A = X, B = Y   and   O holds B = Z   (O's A is don't-care).
+Every step is ONE field product executed by both lanes on lane-specific operands (v_cndmask on the lane-parity mask
+builds them); squarings are paired with squarings so the cheaper square stream is kept.  The formulas and limb bounds
+are exactly those of p256_verify29.h (pt_dbl29 / pt_add29 / pt_add_mixed29).
+
+tests/test_pair_programs.py runs these very programs in gcn_dsl.Program.run() against big-integer point arithmetic.
+
+Run:  python3 gen_pair_gcn.py > pair29_gcn.h   (the Makefile does this)
+"""
+from gcn_dsl import Program
+
+
+def build_pair_dbl():
+    """(A, B) <- 2 * (A, B).   in: L(X) <= 2, L(Y) <= 3, L(Z) <= 3;  out: L(X) = 1, L(Y) = 3, L(Z) = 1."""
+    p = Program("PAIR29_DBL")
+    A = p.fe("A", "io")
+    B = p.fe("B", "io")
+    U1 = p.fe("U1", "tmp")
+    U2 = p.fe("U2", "tmp")
+    U3 = p.fe("U3", "tmp")
+    W3 = p.fe("W3", "tmp")
+    P1 = p.fe("P1", "tmp")
+    P2 = p.fe("P2", "tmp")
+    T0 = p.fe("T0", "tmp")
+    T1 = p.fe("T1", "tmp")
+    TD = p.fe("TD", "tmp")
+    p.sqr(U1, B, TD)                 # E: gamma = Y^2            O: delta = Z^2
+    p.swp_sub(P1, A, U1)             #                           O: X - delta
+    p.swp_add(P2, A, U1)             #                           O: X + delta
+    p.shl(T0, A, 2)                  # E: 4X
+    p.sel(P1, P1, T0)
+    p.sel(P2, P2, U1)                # E: gamma
+    p.mul(U2, P1, P2)                # E: beta4 = 4 X gamma      O: m = (X - delta)(X + delta)
+    p.shladd(T0, U2, 1, U2)          #                           O: alpha = 3m
+    p.shl(T1, U1, 1)                 # E: 2 gamma
+    p.sel(W3, T0, T1)
+    p.sqr(U3, W3, TD)                # E: gg = 4 gamma^2         O: a2 = alpha^2
+    p.shl(T0, U2, 1)                 # E: 2 beta4
+    p.swp_sub(T1, U3, T0)            # E: alpha^2 - 8 beta   (L3)
+    p.wnorm(A, T1, TD)               # E: X3
+    p.sub(T0, U2, A)                 # E: beta4 - X3         (L2)
+    p.swp(T1, W3)                    # E: alpha
+    p.swp(P1, B)                     #                           O: Y
+    p.shl(P1, P1, 1)                 #                           O: 2Y
+    p.sel(P1, P1, T1)
+    p.sel(P2, B, T0)                 #                           O: Z
+    p.mul(U1, P1, P2)                # E: yy = alpha (4 beta - X3)   O: Z3 = 2 Y Z
+    p.shl(T0, U3, 1)                 # E: 2 gg
+    p.sub(T0, U1, T0)                # E: Y3 = yy - 8 gamma^2 (L3)
+    p.sel(B, U1, T0)
+    return p
+
+
+def build_pair_add():
+    """(A, B) <- (A, B) + P2 with P2 handed over CROSSED:  E: C = Z2,  O: C = X2, D = Y2.
+    in: L(X1) <= 2, L(Y1) <= 3, L(Z1) = 1, L(X2) = 1, L(Y2) <= 3, L(Z2) = 1;  out: L(X) = 1, L(Y) = 2, L(Z) = 1.
+    H (both lanes: h = u2 - u1) and RR (E: s2 - s1) are left for the caller's P == +-Q test."""
+    p = Program("PAIR29_ADD")
+    A = p.fe("A", "io")
+    B = p.fe("B", "io")
+    H = p.fe("H", "tmp")
+    RR = p.fe("RR", "tmp")
+    W = p.fe("W", "tmp")
+    U1 = p.fe("U1", "tmp")
+    U2 = p.fe("U2", "tmp")
+    U3 = p.fe("U3", "tmp")
+    U4 = p.fe("U4", "tmp")
+    U6 = p.fe("U6", "tmp")
+    P1 = p.fe("P1", "tmp")
+    P2 = p.fe("P2", "tmp")
+    T0 = p.fe("T0", "tmp")
+    T1 = p.fe("T1", "tmp")
+    TD = p.fe("TD", "tmp")
+    C = p.fe("C", "in")
+    D = p.fe("D", "in")
+    p.sel(W, B, C)                   # E: Z2                     O: Z1
+    p.sqr(U1, W, TD)                 # E: z2z2                   O: z1z1
+    p.sel(P1, C, A)                  # E: X1                     O: X2
+    p.mul(U2, P1, U1)                # E: u1 = X1 z2z2           O: u2 = X2 z1z1
+    p.mul(U3, W, U1)                 # E: Z2^3                   O: Z1^3
+    p.sel(P1, D, B)                  # E: Y1                     O: Y2
+    p.mul(U4, P1, U3)                # E: s1                     O: s2
+    p.swp_sub(H, U2, U2)             # E: h = u2 - u1            O: -h
+    p.swp_sub(RR, U4, U4)            # E: rr = s2 - s1           O: -rr
+    p.neg(T0, H)
+    p.sel(H, T0, H)                  # h on both lanes
+    p.sel(P1, RR, H)
+    U5 = W                           # W is dead
+    p.sqr(U5, P1, TD)                # E: hh                     O: r2 = rr^2
+    p.swp(T0, U5)                    #                           O: hh
+    p.sel(P1, H, U2)                 # E: u1                     O: h
+    p.sel(P2, T0, U5)                # hh on both lanes
+    p.mul(U6, P1, P2)                # E: v = u1 hh              O: hhh
+    p.shl(T0, U6, 1)                 # E: 2v
+    p.swp_add(T0, U6, T0)            # E: hhh + 2v
+    p.swp_sub(T1, U5, T0)            # E: r2 - hhh - 2v      (L4)
+    p.wnorm(A, T1, TD)               # E: X3
+    p.sub(T0, U6, A)                 # E: v - X3             (L2)
+    p.swp(T1, C)                     #                           O: Z2
+    p.sel(P1, B, RR)                 # E: rr                     O: Z1
+    p.sel(P2, T1, T0)
+    U7 = U1                          # U1 is dead
+    p.mul(U7, P1, P2)                # E: y1 = rr (v - X3)       O: zz = Z1 Z2
+    p.swp(T0, U6)                    # E: hhh
+    p.sel(P1, U7, U4)                # E: s1                     O: zz
+    p.sel(P2, H, T0)                 # E: hhh                    O: h
+    U8 = U3                          # U3 is dead
+    p.mul(U8, P1, P2)                # E: y2 = s1 hhh            O: Z3 = zz h
+    p.sub(T0, U7, U8)                # E: Y3 = y1 - y2       (L2)
+    p.sel(B, U8, T0)
+    return p
+
+
+def build_pair_madd():
+    """(A, B) <- (A, B) + (x2, y2) affine, handed over as  E: C = x2,  O: D = y2.
+    in: L(X1) = 1, L(Y1) <= 3, L(Z1) = 1, x2 / y2 normalised;  out: L(X) = 1, L(Y) = 2, L(Z) = 1."""
+    p = Program("PAIR29_MADD")
+    A = p.fe("A", "io")
+    B = p.fe("B", "io")
+    U1 = p.fe("U1", "tmp")
+    U2 = p.fe("U2", "tmp")
+    U3 = p.fe("U3", "tmp")
+    U4 = p.fe("U4", "tmp")
+    H = p.fe("H", "tmp")
+    RR = p.fe("RR", "tmp")
+    P1 = p.fe("P1", "tmp")
+    P2 = p.fe("P2", "tmp")
+    T0 = p.fe("T0", "tmp")
+    T1 = p.fe("T1", "tmp")
+    TD = p.fe("TD", "tmp")
+    C = p.fe("C", "in")
+    D = p.fe("D", "in")
+    p.sqr(U1, B, TD)                 #                           O: z1z1
+    p.swp(T0, U1)                    # E: z1z1
+    p.sel(P1, B, C)                  # E: x2                     O: Z1
+    p.sel(P2, U1, T0)                # z1z1 on both lanes
+    p.mul(U2, P1, P2)                # E: u2 = x2 z1z1           O: Z1^3
+    p.sub(H, U2, A)                  # E: h = u2 - X1        (L2)
+    p.sel(P1, D, H)                  # E: h                      O: y2
+    p.sel(P2, U2, H)                 # E: h                      O: Z1^3
+    p.mul(U3, P1, P2)                # E: hh                     O: s2
+    p.swp_sub(T0, B, U3)             #                           O: Y1 - s2 = -rr   (L4)
+    p.wnorm(RR, T0, TD)              #                           O: -rr
+    p.sel(P1, RR, U3)                # E: hh                     O: -rr
+    p.sel(P2, RR, H)                 # E: h                      O: -rr
+    p.mul(U4, P1, P2)                # E: hhh                    O: r2
+    p.swp(T0, H)                     #                           O: h
+    p.sel(P1, B, A)                  # E: X1                     O: Z1
+    p.sel(P2, T0, U3)                # E: hh                     O: h
+    U5 = U1                          # U1 is dead
+    p.mul(U5, P1, P2)                # E: v = X1 hh              O: Z3 = Z1 h
+    p.shl(T0, U5, 1)                 # E: 2v
+    p.swp_sub(T1, U4, U4)            # E: r2 - hhh
+    p.sub(T1, T1, T0)                # E: r2 - hhh - 2v      (L4)
+    p.wnorm(A, T1, TD)               # E: X3
+    p.sub(T0, A, U5)                 # E: X3 - v             (L2)
+    p.swp(T1, T0)                    #                           O: X3 - v
+    p.sel(P1, RR, B)                 # E: Y1                     O: -rr
+    p.sel(P2, T1, U4)                # E: hhh                    O: X3 - v
+    U6 = U3                          # U3 is dead
+    p.mul(U6, P1, P2)                # E: y2 = Y1 hhh            O: y1 = (-rr)(X3 - v)
+    p.swp_sub(T0, U6, U6)            # E: Y3 = y1 - y2       (L2)
+    p.sel(B, U5, T0)                 #                           O: Z3
+    return p
+
+
+PROGRAMS = [build_pair_dbl, build_pair_add, build_pair_madd]
+
+
+def main():
+    print("// GENERATED by gen_pair_gcn.py - do not edit.  Two-lanes-per-signature point operations (see gen_pair_gcn.py).")
+    print("#pragma once")
+    print('#include "fe29_gcn.h"   // FE29_GCN_ALIGN')
+    print()
+    for b in PROGRAMS:
+        prog = b()
+        args = {n: "(%s)" % n for n in prog.order}
+        text, stats = prog.emit_asm(args)
+        print(text)
+
+
+if __name__ == "__main__":
+    main()

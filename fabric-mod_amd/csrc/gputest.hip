@@ -1,0 +1,186 @@
+// GPU-SIDE TEST HOOKS - built into libfabgpu_gputest.so, never into the product library.  They run single generated
+// instruction streams (pair29_gcn.h) on one wavefront so that tests/test_gpu_parity.py can compare every output register
+// with the reference interpreter of gcn_dsl.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "p256_pair29.h"
+#include "p256_tables29.h"
+
+using namespace fab;
+
+// in : per lane A[9] B[9] C[9] D[9];  out: per lane A[9] B[9] H[9] RR[9]
+__global__ void __launch_bounds__(64, 1) gputest_pair_kernel(int op, const int32_t* __restrict__ in, int32_t* __restrict__ out) {
+    const int32_t* p = in + threadIdx.x * 36;
+    pair_pt P;
+    fe C, D;
+    for (int i = 0; i < 9; i++) {
+        P.A.v[i] = p[i];
+        P.B.v[i] = p[9 + i];
+        C.v[i] = p[18 + i];
+        D.v[i] = p[27 + i];
+    }
+    PAIR_TMPS;
+    for (int i = 0; i < 9; i++) tH.v[i] = tRR.v[i] = 0;
+    if (op == 3) {   // ISA probe: out A = v_subrev_u32_dpp(A, B), out B = v_sub_u32_dpp(A, B), out H = v_add_u32_dpp(A, B), out RR = v_mov_b32_dpp(A)
+        fe a = P.A, b = P.B;
+        for (int i = 0; i < 9; i++) {
+            asm volatile("s_nop 4\n\tv_subrev_u32_dpp %0, %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_sub_u32_dpp %1, %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_u32_dpp %2, %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 4"
+                         : "=&v"(P.A.v[i]), "=&v"(P.B.v[i]), "=&v"(tH.v[i]), "=&v"(tRR.v[i])
+                         : "v"(a.v[i]), "v"(b.v[i]));
+        }
+    } else if (op == 0) {
+        PAIR_DBL(P);
+    } else if (op == 1) {
+        PAIR_ADD(P, C, D);
+    } else {
+        PAIR_MADD(P, C, D);
+    }
+    int32_t* o = out + threadIdx.x * 36;
+    for (int i = 0; i < 9; i++) {
+        o[i] = P.A.v[i];
+        o[9 + i] = P.B.v[i];
+        o[18 + i] = tH.v[i];
+        o[27 + i] = tRR.v[i];
+    }
+}
+
+extern "C" int gputest_pair_op(int op, const int32_t* in, int32_t* out) {
+    int32_t *din = nullptr, *dout = nullptr;
+    const size_t bytes = 64 * 36 * sizeof(int32_t);
+    if (hipMalloc((void**)&din, bytes) != hipSuccess || hipMalloc((void**)&dout, bytes) != hipSuccess) return -1;
+    hipMemcpy(din, in, bytes, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(gputest_pair_kernel, dim3(1), dim3(64), 0, 0, op, din, dout);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+    hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    hipFree(din);
+    hipFree(dout);
+    return rc;
+}
+
+// R = u1*G + u2*Q through pair_combined_mult29 on one wavefront (32 signatures).  in: 32 x (u1, u2, qx, qy) big-endian 32-byte
+// fields;  out: per lane A[9] B[9] r_inf
+__global__ void __launch_bounds__(64, 1) gputest_pair_combined_kernel(const uint8_t* __restrict__ in, const int32_t* __restrict__ gtab,
+                                                                       uint4* __restrict__ qws, int32_t* __restrict__ out) {
+    const bool odd = (threadIdx.x & 1) != 0;
+    const uint32_t k = threadIdx.x >> 1;
+    u256 u1, u2, qx, qy;
+    from_be32(u1, in + 128 * k);
+    from_be32(u2, in + 128 * k + 32);
+    from_be32(qx, in + 128 * k + 64);
+    from_be32(qy, in + 128 * k + 96);
+    fe QX, QY;
+    fe_to_mont(QX, qx);
+    fe_to_mont(QY, qy);
+    PairQTab<32> qtab{qws + k};
+    pair_pt R;
+    bool inf;
+    pair_combined_mult29(R, inf, u1, u2, QX, QY, gtab, qtab, odd);
+    int32_t* o = out + threadIdx.x * 19;
+    for (int i = 0; i < 9; i++) {
+        o[i] = R.A.v[i];
+        o[9 + i] = R.B.v[i];
+    }
+    o[18] = inf ? 1 : 0;
+}
+
+extern "C" int gputest_pair_combined(const uint8_t* in, int32_t* out) {
+    std::vector<int32_t> tab(G8_TABLE_WORDS);
+    build_g8_comb_table(tab.data());
+    uint8_t* din = nullptr;
+    int32_t *dtab = nullptr, *dout = nullptr;
+    uint4* dws = nullptr;
+    if (hipMalloc((void**)&din, 32 * 128) != hipSuccess || hipMalloc((void**)&dtab, sizeof(int32_t) * G8_TABLE_WORDS) != hipSuccess ||
+        hipMalloc((void**)&dout, 64 * 19 * 4) != hipSuccess || hipMalloc((void**)&dws, (size_t)16 * 8 * 32 * 16) != hipSuccess)
+        return -1;
+    hipMemcpy(din, in, 32 * 128, hipMemcpyHostToDevice);
+    hipMemcpy(dtab, tab.data(), sizeof(int32_t) * G8_TABLE_WORDS, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(gputest_pair_combined_kernel, dim3(1), dim3(64), 0, 0, din, dtab, dws, dout);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+    hipMemcpy(out, dout, 64 * 19 * 4, hipMemcpyDeviceToHost);
+    hipFree(din); hipFree(dtab); hipFree(dout); hipFree(dws);
+    return rc;
+}
+
+// Debug probe of p256_verify_pair29: same statements, intermediate values written out.
+// in: 32 x (qx, qy, e, r, s);  out per lane: u1[8] u2[8] A[9] B[9] flags(st, ok1, ok2, r_inf, early)
+__global__ void __launch_bounds__(64, 1) gputest_pair_verify_kernel(const uint8_t* __restrict__ in, const int32_t* __restrict__ gtab,
+                                                                     uint4* __restrict__ qws, int32_t* __restrict__ out) {
+    const bool odd = (threadIdx.x & 1) != 0;
+    const uint32_t k = threadIdx.x >> 1;
+    u256 qx, qy, e, r, s;
+    from_be32(qx, in + 160 * k);
+    from_be32(qy, in + 160 * k + 32);
+    from_be32(e, in + 160 * k + 64);
+    from_be32(r, in + 160 * k + 96);
+    from_be32(s, in + 160 * k + 128);
+    PairQTab<32> qtab{qws + k};
+    const u256 P = FAB_P256_P;
+    const u256 N = FAB_P256_N;
+    uint32_t early = range_status(r, s);
+    bool q_in_field = lt256(qx, P) & lt256(qy, P);
+    fe QX, QY;
+    fe_to_mont(QX, qx);
+    fe_to_mont(QY, qy);
+    bool q_ok = q_in_field & on_curve29(QX, QY);
+    if (early == ST_VALID && !q_ok) early = ST_OFF_CURVE;
+    u256 w, u1, u2, ered, t;
+    {
+        const modinv_info NI = MODINV_N_INFO;
+        modinv(w, s, NI);
+    }
+    uint32_t br = sub256(t, e, N);
+    sel256(ered, br == 0, t, e);
+    fn_to_mont(t, ered);
+    fn_mul(u1, t, w);
+    fn_to_mont(t, r);
+    fn_mul(u2, t, w);
+    pair_pt Rr;
+    bool r_inf;
+    pair_combined_mult29(Rr, r_inf, u1, u2, QX, QY, gtab, qtab, odd);
+    fe zz, rm, rhs, rhs_e, d;
+    fe_sqr(zz, Rr.B);
+    fe_to_mont(rm, r);
+    fe_mul(rhs, rm, zz);
+    pair_swap_fe(rhs_e, rhs);
+    fe_sub(d, Rr.A, rhs_e);
+    bool ok1 = fe_is_zero(d);
+    uint32_t st = p256_verify_pair29(qx, qy, e, r, s, gtab, qtab, odd);
+    int32_t* o = out + threadIdx.x * 48;
+    for (int i = 0; i < 8; i++) {
+        o[i] = (int32_t)u1.w[i];
+        o[8 + i] = (int32_t)u2.w[i];
+    }
+    for (int i = 0; i < 9; i++) {
+        o[16 + i] = Rr.A.v[i];
+        o[25 + i] = Rr.B.v[i];
+    }
+    o[34] = (int32_t)st;
+    o[35] = ok1;
+    o[36] = r_inf;
+    o[37] = (int32_t)early;
+    for (int i = 0; i < 9; i++) o[38 + i] = rhs_e.v[i];
+}
+
+extern "C" int gputest_pair_verify(const uint8_t* in, int32_t* out) {
+    std::vector<int32_t> tab(G8_TABLE_WORDS);
+    build_g8_comb_table(tab.data());
+    uint8_t* din = nullptr;
+    int32_t *dtab = nullptr, *dout = nullptr;
+    uint4* dws = nullptr;
+    if (hipMalloc((void**)&din, 32 * 160) != hipSuccess || hipMalloc((void**)&dtab, sizeof(int32_t) * G8_TABLE_WORDS) != hipSuccess ||
+        hipMalloc((void**)&dout, 64 * 48 * 4) != hipSuccess || hipMalloc((void**)&dws, (size_t)16 * 8 * 32 * 16) != hipSuccess)
+        return -1;
+    hipMemcpy(din, in, 32 * 160, hipMemcpyHostToDevice);
+    hipMemcpy(dtab, tab.data(), sizeof(int32_t) * G8_TABLE_WORDS, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(gputest_pair_verify_kernel, dim3(1), dim3(64), 0, 0, din, dtab, dws, dout);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+    hipMemcpy(out, dout, 64 * 48 * 4, hipMemcpyDeviceToHost);
+    hipFree(din); hipFree(dtab); hipFree(dout); hipFree(dws);
+    return rc;
+}

@@ -1,0 +1,281 @@
+// ECDSA P-256 verification with TWO LANES PER SIGNATURE (device only) - the small-batch variant of p256_verify29.h.
+//
+// Same algorithm, same gates, same window recodings, same tables as p256_verify_core29 (which it must agree with bit for
+// bit: tests/test_gpu_parity.py runs both against the oracle); what changes is the shape of the instruction stream.  A
+// 30 000-signature block is 469 wavefronts on 1024 SIMDs and one wave issues one VALU instruction per ~4.2 cycles, so the
+// kernel time is the LENGTH of the per-wave stream.  Lanes 2k (E) and 2k+1 (O) share signature k: the point operations are
+// the generated programs of pair29_gcn.h (787 / 1463 / 1185 instructions for dbl / add / madd against 1339 / 2678 / 1900),
+// every field product is executed by both lanes on different operands, limbs cross lanes with DPP quad_perm:[1,0,3,2].
+// Between operations  E holds A = X, B = Y  and  O holds B = Z.  The scalar part (gates, s^-1 mod n, u1, u2, digits) is
+// computed redundantly by both lanes.
+//
+// Replaces crypto/ecdsa.Verify reached from bccsp/sw/ecdsa.go:56.
+#pragma once
+#include "p256_verify29.h"
+#include "pair29_gcn.h"
+
+namespace fab {
+
+struct pair_pt {
+    fe A, B;   // E: X, Y      O: don't-care, Z
+};
+
+__device__ __forceinline__ int32_t pair_swap_i32(int32_t v) {   // partner lane's value (quad_perm:[1,0,3,2])
+    return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+}
+__device__ __forceinline__ void pair_swap_fe(fe& r, const fe& a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = pair_swap_i32(a.v[i]);
+}
+__device__ __forceinline__ void pair_sel(pair_pt& r, bool c, const pair_pt& a, const pair_pt& b) {
+    fe_sel(r.A, c, a.A, b.A);
+    fe_sel(r.B, c, a.B, b.B);
+}
+
+#define PAIR_TMPS fe tU1, tU2, tU3, tU4, tU6, tW, tH, tRR, tP1, tP2, tT0, tT1, tTD
+#define PAIR_DBL(P) PAIR29_DBL((P).A, (P).B, tU1, tU2, tU3, tW, tP1, tP2, tT0, tT1, tTD)
+#define PAIR_ADD(P, C, D) PAIR29_ADD((P).A, (P).B, tH, tRR, tW, tU1, tU2, tU3, tU4, tU6, tP1, tP2, tT0, tT1, tTD, C, D)
+#define PAIR_MADD(P, C, D) PAIR29_MADD((P).A, (P).B, tU1, tU2, tU3, tU4, tH, tRR, tP1, tP2, tT0, tT1, tTD, C, D)
+
+// Per-signature table j*Q (j = 1..16) in the global workspace.  Per workgroup slot: [entry][q 0..7][pair NP] x 16 bytes;
+// q 0..4 = X[9] Y[9] pad, q 5..7 = Z[9] pad.  E stores / owns the X,Y quads, O the Z quads.
+template <int NP>
+struct PairQTab {
+    uint4* pair;   // workspace of this workgroup slot + pair index
+    __device__ __forceinline__ uint4* cell(int j, int q) const { return pair + ((size_t)(j - 1) * 8 + q) * NP; }
+    __device__ __forceinline__ void store_state(int j, const pair_pt& p, bool odd) const {
+        if (!odd) {
+            *cell(j, 0) = make_uint4(p.A.v[0], p.A.v[1], p.A.v[2], p.A.v[3]);
+            *cell(j, 1) = make_uint4(p.A.v[4], p.A.v[5], p.A.v[6], p.A.v[7]);
+            *cell(j, 2) = make_uint4(p.A.v[8], p.B.v[0], p.B.v[1], p.B.v[2]);
+            *cell(j, 3) = make_uint4(p.B.v[3], p.B.v[4], p.B.v[5], p.B.v[6]);
+            *cell(j, 4) = make_uint4(p.B.v[7], p.B.v[8], 0, 0);
+        } else {
+            *cell(j, 5) = make_uint4(p.B.v[0], p.B.v[1], p.B.v[2], p.B.v[3]);
+            *cell(j, 6) = make_uint4(p.B.v[4], p.B.v[5], p.B.v[6], p.B.v[7]);
+            *cell(j, 7) = make_uint4(p.B.v[8], 0, 0, 0);
+        }
+    }
+    // five 16-byte loads, the same code on both lanes: E reads q = q0 + k clamped to 7, O reads q = k
+    __device__ __forceinline__ void load5(uint32_t j, int q0, uint4 (&l)[5]) const {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int q = q0 + k;
+            l[k] = *cell((int)j, q > 7 ? 7 : q);
+        }
+    }
+    // state layout: E gets (X, Y), O gets B = Z
+    __device__ __forceinline__ void load_state(uint32_t j, pair_pt& p, bool odd) const {
+        uint4 l[5];
+        load5(j, odd ? 5 : 0, l);
+        p.A.v[0] = l[0].x; p.A.v[1] = l[0].y; p.A.v[2] = l[0].z; p.A.v[3] = l[0].w;
+        p.A.v[4] = l[1].x; p.A.v[5] = l[1].y; p.A.v[6] = l[1].z; p.A.v[7] = l[1].w;
+        p.A.v[8] = l[2].x;
+        fe y;
+        y.v[0] = l[2].y; y.v[1] = l[2].z; y.v[2] = l[2].w;
+        y.v[3] = l[3].x; y.v[4] = l[3].y; y.v[5] = l[3].z; y.v[6] = l[3].w;
+        y.v[7] = l[4].x; y.v[8] = l[4].y;
+        fe_sel(p.B, odd, p.A, y);       // O: the first nine words it read are Z
+    }
+    // crossed layout for PAIR_ADD: E gets C = Z2, O gets C = X2, D = Y2 (E's D is garbage)
+    __device__ __forceinline__ void load_crossed(uint32_t j, fe& C, fe& D, bool odd) const {
+        uint4 l[5];
+        load5(j, odd ? 0 : 5, l);
+        C.v[0] = l[0].x; C.v[1] = l[0].y; C.v[2] = l[0].z; C.v[3] = l[0].w;
+        C.v[4] = l[1].x; C.v[5] = l[1].y; C.v[6] = l[1].z; C.v[7] = l[1].w;
+        C.v[8] = l[2].x;
+        D.v[0] = l[2].y; D.v[1] = l[2].z; D.v[2] = l[2].w;
+        D.v[3] = l[3].x; D.v[4] = l[3].y; D.v[5] = l[3].z; D.v[6] = l[3].w;
+        D.v[7] = l[4].x; D.v[8] = l[4].y;
+    }
+};
+
+// E gets x2, O gets y2 of comb entry (window, digit) in the SAME nine registers (they are passed as both C and D of PAIR_MADD)
+__device__ __forceinline__ void pair_g8_load(const int32_t* __restrict__ gtab, int window, uint32_t digit, bool odd, fe& xy) {
+    const int32_t* e = gtab + g8_index(window, digit) + (odd ? 9 : 0);
+#pragma unroll
+    for (int l = 0; l < 9; l++) xy.v[l] = e[l];
+}
+
+// R = u1*G + u2*Q on a lane pair.  Q: affine Montgomery (both lanes hold both coordinates).  Returns the pair state of R;
+// r_inf as in p256_combined_mult29.
+template <class QTab>
+__device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, const u256& u1, const u256& u2, const fe& QX, const fe& QY,
+                                                     const int32_t* __restrict__ gtab, const QTab& qtab, bool odd) {
+    const fe ONE = {FE29_R1};
+    PAIR_TMPS;
+    pair_pt Qp;
+    Qp.A = QX;
+    fe_sel(Qp.B, odd, ONE, QY);
+
+    // --- per-signature table j*Q, j = 1..16 ---
+    qtab.store_state(1, Qp, odd);
+#pragma unroll 1
+    for (int j = 2; j <= 16; j += 2) {
+        pair_pt d;
+        qtab.load_state((uint32_t)(j >> 1), d, odd);
+        PAIR_DBL(d);
+        qtab.store_state(j, d, odd);
+        if (j < 16) {
+            PAIR_MADD(d, QX, QY);
+            qtab.store_state(j + 1, d, odd);
+        }
+    }
+
+    // --- T = u2 * Q : 52 signed 5-bit windows (same recoding as p256_combined_mult29) ---
+    uint32_t kw[9];
+#pragma unroll
+    for (int i = 0; i < 8; i++) kw[i] = u2.w[i];
+    kw[8] = 0;
+    pair_pt T = Qp;
+    bool t_inf = true;
+#pragma unroll 1
+    for (int i = Q5_WINDOWS - 1; i >= 0; i--) {
+        uint32_t six;
+        if (i == 0) {
+            six = (kw[0] << 1) & 63u;
+        } else {
+            int p = 5 * i - 1;
+            uint64_t two = ((uint64_t)kw[(p >> 5) + 1] << 32) | kw[p >> 5];
+            six = (uint32_t)(two >> (p & 31)) & 63u;
+        }
+        int32_t digit = (int32_t)((six >> 1) & 15u) + (int32_t)(six & 1u) - (int32_t)((six >> 5) << 4);
+        bool neg = digit < 0;
+        uint32_t mag = (uint32_t)(neg ? -digit : digit);
+        fe C, D;
+        qtab.load_crossed(mag ? mag : 1u, C, D, odd);   // issued ahead of the doublings
+        if (i != Q5_WINDOWS - 1) {
+#pragma unroll 1
+            for (int k = 0; k < 5; k++) PAIR_DBL(T);
+        }
+#pragma unroll
+        for (int l = 0; l < 9; l++) D.v[l] = neg ? -D.v[l] : D.v[l];   // -Y2 (lives on O)
+        pair_pt sum = T;
+        PAIR_ADD(sum, C, D);
+        bool take_ent = t_inf & (mag != 0);
+        bool take_sum = (!t_inf) & (mag != 0);
+        pair_sel(T, take_sum, sum, T);
+        if (__any(take_ent)) {   // wave-uniform: only the first non-zero window(s) of a wave convert the entry to state layout
+            pair_pt ent;
+            fe sc, sd;
+            pair_swap_fe(sc, C);            // E: X2     O: Z2
+            pair_swap_fe(sd, D);            // E: Y2
+            ent.A = sc;
+            fe_sel(ent.B, odd, sc, sd);
+            pair_sel(T, take_ent, ent, T);
+        }
+        t_inf = t_inf & (mag == 0);
+    }
+
+    // --- S = u1 * G : 32-window 8-bit comb ---
+    pair_pt S = Qp;
+    bool s_inf = true;
+    uint32_t nd = scalar_byte(u1, 0);
+    fe nxy;
+    pair_g8_load(gtab, 0, nd ? nd : 1u, odd, nxy);
+#pragma unroll 1
+    for (int i = 0; i < G8_WINDOWS; i++) {
+        uint32_t d = nd;
+        fe xy = nxy;
+        int inext = i + 1 < G8_WINDOWS ? i + 1 : i;
+        nd = scalar_byte(u1, inext);
+        pair_g8_load(gtab, inext, nd ? nd : 1u, odd, nxy);
+        pair_pt sum = S;
+        PAIR_MADD(sum, xy, xy);
+        bool take_ent = s_inf & (d != 0);
+        bool take_sum = (!s_inf) & (d != 0);
+        pair_sel(S, take_sum, sum, S);
+        if (__any(take_ent)) {
+            pair_pt ent;
+            fe sy;
+            pair_swap_fe(sy, xy);           // E: y2
+            ent.A = xy;                     // E: x2
+            fe_sel(ent.B, odd, ONE, sy);
+            pair_sel(S, take_ent, ent, S);
+        }
+        s_inf = s_inf & (d == 0);
+    }
+
+    // --- R = S + T with the exceptional cases of the group law ---
+    fe C, D, sa, sb;
+    pair_swap_fe(sa, T.A);                  // O: X_T
+    pair_swap_fe(sb, T.B);                  // E: Z_T    O: Y_T
+    fe_sel(C, odd, sa, sb);
+    D = sb;
+    pair_pt Rp = S;
+    PAIR_ADD(Rp, C, D);
+    bool hz = fe_is_zero(tH);               // h on both lanes
+    bool rz_own = fe_is_zero(tRR);          // rr lives on E
+    int32_t rz_other = pair_swap_i32(rz_own ? 1 : 0);
+    bool rz = odd ? (rz_other != 0) : rz_own;
+    pair_pt Rd = T;
+    PAIR_DBL(Rd);
+    r_inf = t_inf & s_inf;
+    bool use_T = s_inf & !t_inf;
+    bool use_S = t_inf & !s_inf;
+    bool both = !s_inf & !t_inf;
+    bool use_dbl = both & hz & rz;
+    r_inf = r_inf | (both & hz & !rz);
+    Rr = Rp;
+    pair_sel(Rr, use_dbl, Rd, Rr);
+    pair_sel(Rr, use_T, T, Rr);
+    pair_sel(Rr, use_S, S, Rr);
+}
+
+// Status of one tuple, valid on the EVEN lane of the pair.
+template <class QTab>
+__device__ __forceinline__ uint32_t p256_verify_pair29(const u256& qx, const u256& qy, const u256& e, const u256& r, const u256& s,
+                                                        const int32_t* __restrict__ gtab, const QTab& qtab, bool odd) {
+    const u256 P = FAB_P256_P;
+    const u256 N = FAB_P256_N;
+    uint32_t early = range_status(r, s);
+
+    bool q_in_field = lt256(qx, P) & lt256(qy, P);
+    fe QX, QY;
+    fe_to_mont(QX, qx);
+    fe_to_mont(QY, qy);
+    bool q_ok = q_in_field & on_curve29(QX, QY);
+    if (early == ST_VALID && !q_ok) early = ST_OFF_CURVE;
+
+    u256 w, u1, u2, ered, t;
+    {
+        const modinv_info NI = MODINV_N_INFO;
+        modinv(w, s, NI);
+    }
+    uint32_t br = sub256(t, e, N);
+    sel256(ered, br == 0, t, e);
+    fn_to_mont(t, ered);
+    fn_mul(u1, t, w);
+    fn_to_mont(t, r);
+    fn_mul(u2, t, w);
+
+    pair_pt Rr;
+    bool r_inf;
+    pair_combined_mult29(Rr, r_inf, u1, u2, QX, QY, gtab, qtab, odd);
+
+    // --- x(R) mod n == r : Z^2 and r Z^2 on O, the comparison with X on E ---
+    const u256 PMN = FAB_P256_P_MINUS_N;
+    fe zz, rm, rhs, rhs_e, d;
+    u256 r2;
+    fe_sqr(zz, Rr.B);                                  // O: Z^2
+    fe_to_mont(rm, r);
+    fe_mul(rhs, rm, zz);
+    pair_swap_fe(rhs_e, rhs);                          // E: r Z^2
+    // NB the swapped operand is the MINUEND: hipcc folds the DPP move into the subtraction, and for "own - partner" it emits
+    // v_subrev_u32_dpp, which on MI355X does not compute src1 - dpp(src0) (probed in gputest.hip op 3; the Makefile rejects
+    // any build whose device code contains that opcode).
+    fe_sub(d, rhs_e, Rr.A);
+    bool ok = fe_is_zero(d);
+    add256(r2, r, N);
+    fe_to_mont(rm, r2);
+    fe_mul(rhs, rm, zz);
+    pair_swap_fe(rhs_e, rhs);
+    fe_sub(d, rhs_e, Rr.A);
+    ok = ok | (lt256(r, PMN) & fe_is_zero(d));
+    ok = ok & !r_inf;
+
+    uint32_t st = ok ? ST_VALID : ST_BAD_MATH;
+    return early != ST_VALID ? early : st;
+}
+
+}  // namespace fab

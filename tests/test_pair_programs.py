@@ -1,0 +1,184 @@
+"""CPU execution of the two-lanes-per-signature GCN programs (fabric-mod_amd/csrc/gen_pair_gcn.py) in the reference
+interpreter of gcn_dsl.py: the exact instruction lists the pair kernel runs, with 32/64-bit wrap-around semantics and an
+explicit (even, odd) lane pair, checked against big-integer point arithmetic of the oracle.  Chained so that the lazy
+limb ranges the kernel produces (L(Y) = 3 after a doubling, L(Y) = 2 after an addition) are what the next program eats."""
+import os
+import random
+import sys
+
+import pytest
+
+import bccsp_sw_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fabric-mod_amd", "csrc"))
+import gen_pair_gcn as gp  # noqa: E402
+
+P = po.P
+R = 1 << 261
+RI = pow(R, -1, P)
+
+
+def bal(x):
+    d = []
+    for _ in range(8):
+        t = x & ((1 << 29) - 1)
+        if t >> 28:
+            t -= 1 << 29
+        d.append(t)
+        x = (x - t) >> 29
+    d.append(x)
+    return d
+
+
+def to_fe(x):
+    return bal(x * R % P)
+
+
+def val(regs, name):
+    return sum(regs["%s.%d" % (name, i)] << (29 * i) for i in range(9)) * RI % P
+
+
+def put(regs, name, digits):
+    for i in range(9):
+        regs["%s.%d" % (name, i)] = digits[i]
+
+
+def jac_of(pt, rng):
+    z = rng.randrange(1, P)
+    return (pt[0] * z * z % P, pt[1] * z * z * z % P, z)
+
+
+def affine(X, Y, Z):
+    zi = pow(Z, -1, P)
+    return (X * zi * zi % P, Y * zi * zi * zi % P)
+
+
+class Pair:
+    """Lane-pair state between programs: E holds A = X, B = Y; O holds B = Z."""
+
+    def __init__(self, X, Y, Z, rng):
+        self.e, self.o = {}, {}
+        put(self.e, "A", to_fe(X)); put(self.e, "B", to_fe(Y))
+        put(self.o, "A", [rng.randrange(-(1 << 28), 1 << 28) for _ in range(9)]); put(self.o, "B", to_fe(Z))
+
+    def point(self):
+        return affine(val(self.e, "A"), val(self.e, "B"), val(self.o, "B"))
+
+    def run(self, prog, extra_e=None, extra_o=None):
+        e = {k: v for k, v in self.e.items() if k[0] in "AB"}
+        o = {k: v for k, v in self.o.items() if k[0] in "AB"}
+        e.update(extra_e or {}); o.update(extra_o or {})
+        self.e, self.o = prog.run(e, o)
+        for regs in (self.e, self.o):          # every limb must still be a 32-bit value
+            assert all(-(1 << 31) <= v < (1 << 31) for v in regs.values())
+
+
+@pytest.fixture(scope="module")
+def progs():
+    return {"dbl": gp.build_pair_dbl(), "add": gp.build_pair_add(), "madd": gp.build_pair_madd()}
+
+
+def test_program_sizes(progs):
+    sizes = {}
+    for k, p in progs.items():
+        text, st = p.emit_asm({n: "(%s)" % n for n in p.order})
+        sizes[k] = st
+        assert "s_nop" not in text or st["nops"] < 8
+    # the point of the exercise: well under the one-lane streams (1339 / 2678 / 1900 instructions)
+    assert sizes["dbl"]["instructions"] < 850 and sizes["add"]["instructions"] < 1600 and sizes["madd"]["instructions"] < 1300
+
+
+def test_pair_scalar_multiplication_chain(progs):
+    """Left-to-right double-and-add of a random 48-bit scalar with Jacobian table entries (pair add) and affine ones
+    (pair madd), against the oracle after every step."""
+    rng = random.Random(77)
+    G = (po.GX, po.GY)
+    for trial in range(3):
+        base = po.pt_mul(rng.randrange(1, po.N), G)
+        k = rng.randrange(1 << 47, 1 << 48)
+        st = Pair(*jac_of(base, rng), rng)
+        acc = base
+        for bit in bin(k)[3:]:
+            st.run(progs["dbl"])
+            acc = po.pt_add(acc, acc)
+            assert st.point() == acc
+            if bit == "1":
+                if rng.random() < 0.5:
+                    X2, Y2, Z2 = jac_of(base, rng)
+                    ce, co = {}, {}
+                    put(ce, "C", to_fe(Z2)); put(ce, "D", [0] * 9)
+                    put(co, "C", to_fe(X2)); put(co, "D", to_fe(Y2))
+                    st.run(progs["add"], ce, co)
+                    # H on both lanes and RR on E are the caller's exceptional-case probes: non-zero here
+                    assert val(st.e, "H") != 0 and val(st.o, "H") == val(st.e, "H") and val(st.e, "RR") != 0
+                else:
+                    ce, co = {}, {}
+                    put(ce, "C", to_fe(base[0])); put(ce, "D", [0] * 9)
+                    put(co, "C", [0] * 9); put(co, "D", to_fe(base[1]))
+                    st.run(progs["madd"], ce, co)
+                acc = po.pt_add(acc, base)
+                assert st.point() == acc
+
+
+def test_pair_add_reports_the_exceptional_cases(progs):
+    rng = random.Random(78)
+    G = (po.GX, po.GY)
+    pt = po.pt_mul(rng.randrange(1, po.N), G)
+    for sign in (1, -1):
+        st = Pair(*jac_of(pt, rng), rng)
+        X2, Y2, Z2 = jac_of((pt[0], pt[1] * sign % P), rng)
+        ce, co = {}, {}
+        put(ce, "C", to_fe(Z2)); put(ce, "D", [0] * 9)
+        put(co, "C", to_fe(X2)); put(co, "D", to_fe(Y2))
+        st.run(progs["add"], ce, co)
+        assert val(st.e, "H") == 0                      # same x: P == +-Q
+        assert (val(st.e, "RR") == 0) == (sign == 1)    # and same y: the doubling case
+
+
+@pytest.mark.gpu
+def test_generated_streams_on_gpu_match_the_interpreter_register_for_register(progs):
+    """One wavefront (32 lane pairs) runs each generated asm statement; every output limb of every lane - including the
+    don't-care lanes - must equal what gcn_dsl.Program.run() computes for the same inputs."""
+    import ctypes
+
+    import numpy as np
+    lib = ctypes.CDLL(os.path.join(ROOT, "fabric-mod_amd", "lib", "libfabgpu_gputest.so"))
+    rng = random.Random(79)
+    G = (po.GX, po.GY)
+    for op, name in ((0, "dbl"), (1, "add"), (2, "madd")):
+        inp = np.zeros((64, 36), dtype=np.int32)
+        want = {}
+        for k in range(32):
+            p1 = po.pt_mul(rng.randrange(1, po.N), G)
+            p2 = po.pt_mul(rng.randrange(1, po.N), G)
+            X1, Y1, Z1 = jac_of(p1, rng)
+            X2, Y2, Z2 = jac_of(p2, rng)
+            junk = lambda: [rng.randrange(-(1 << 28), 1 << 28) for _ in range(9)]
+            e = {"A": to_fe(X1), "B": to_fe(Y1)}
+            o = {"A": junk(), "B": to_fe(Z1)}
+            if name == "add":
+                e.update(C=to_fe(Z2), D=junk()); o.update(C=to_fe(X2), D=to_fe(Y2))
+            elif name == "madd":
+                e.update(C=to_fe(p2[0]), D=junk()); o.update(C=junk(), D=to_fe(p2[1]))
+            else:
+                e.update(C=junk(), D=junk()); o.update(C=junk(), D=junk())
+            for lane, regs in ((2 * k, e), (2 * k + 1, o)):
+                inp[lane] = regs["A"] + regs["B"] + regs["C"] + regs["D"]
+            re, ro = {}, {}
+            for nm in "ABCD":
+                put(re, nm, e[nm]); put(ro, nm, o[nm])
+            want[k] = progs[name].run(re, ro)
+        out = np.zeros((64, 36), dtype=np.int32)
+        rc = lib.gputest_pair_op(op, inp.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        names = ["A", "B"] + (["H", "RR"] if name == "add" else [])
+        bad = set()
+        for k in range(32):
+            for lane, regs in ((2 * k, want[k][0]), (2 * k + 1, want[k][1])):
+                for j, nm in enumerate(names):
+                    got = [int(v) for v in out[lane, 9 * j:9 * j + 9]]
+                    exp = [regs["%s.%d" % (nm, i)] for i in range(9)]
+                    if got != exp:
+                        bad.add((nm, "odd" if lane & 1 else "even", tuple(i for i in range(9) if got[i] != exp[i])))
+        assert not bad, (name, sorted(bad))
