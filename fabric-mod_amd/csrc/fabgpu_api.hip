@@ -42,6 +42,7 @@ struct Buf {  // growable pinned-host + device pair
 
 struct fabgpu_ctx {
     int device = 0;
+    bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
     hipStream_t stream = nullptr;
     int32_t* d_gtab = nullptr;
     std::mutex mu;
@@ -143,7 +144,7 @@ int fabgpu_device_count(fabgpu_ctx*) {
 int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!out) return FABGPU_EINVAL;
     *out = nullptr;
-    if (cfg && cfg->flags != 0) return FABGPU_EINVAL;
+    if (cfg && (cfg->flags & ~(uint32_t)FABGPU_FLAG_ONE_LANE_ONLY) != 0) return FABGPU_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
     int dev = cfg ? cfg->device : -1;
@@ -157,6 +158,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     fabgpu_ctx* ctx = new (std::nothrow) fabgpu_ctx();
     if (!ctx) return FABGPU_ENOMEM;
     ctx->device = dev;
+    ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
     DeviceGuard g(dev);
     int rc = FABGPU_OK;
     do {
@@ -221,10 +223,10 @@ int fabgpu_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* qx, cons
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
-    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, true), &wi);
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
     if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
-    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, st);
+    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, st);
     hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = true;

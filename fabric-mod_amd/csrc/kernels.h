@@ -21,7 +21,7 @@ VerifyGeom verify_geom(uint32_t n, bool allow_pair);
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair);
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
-                              const void* gtab, void* qws, void* verdict_bits, void* status, hipStream_t st);
+                              const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
                                      const void* qy, const void* r, const void* s, const void* gtab, void* qws,
                                      void* verdict_bits, void* status, hipStream_t st);

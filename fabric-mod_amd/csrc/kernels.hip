@@ -287,9 +287,9 @@ size_t verify_workspace_bytes(uint32_t n, bool allow_pair) {
     return (size_t)g.wgs * g.block * QWS_UINT4_PER_LANE * 16;
 }
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
-                              const void* gtab, void* qws, void* verdict_bits, void* status, hipStream_t st) {
+                              const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    VerifyGeom g = verify_geom(n, true);
+    VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair) {
         hipLaunchKernelGGL(p256_verify_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,

@@ -24,6 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfabgpu.so")
 
 FABGPU_OK = 0
+FLAG_ONE_LANE_ONLY = 1   # fabgpu.h FABGPU_FLAG_ONE_LANE_ONLY
 ST_VALID, ST_BAD_MATH, ST_HIGH_S, ST_RANGE, ST_OFF_CURVE = 0, 1, 2, 3, 4
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -169,9 +170,9 @@ def synth_batch(n: int, seed: int = 20260921, invalid_permille: int = 0, e_in: O
 # raw C-ABI context (what the cgo provider binds)
 # ------------------------------------------------------------------------------------------------
 class Context:
-    def __init__(self, device: int = -1, max_batch: int = 0, max_arena: int = 0):
+    def __init__(self, device: int = -1, max_batch: int = 0, max_arena: int = 0, flags: int = 0):
         L = load()
-        cfg = _Cfg(device, max_batch, max_arena, 0)
+        cfg = _Cfg(device, max_batch, max_arena, flags)
         h = _vp()
         _check(L.fabgpu_init(ctypes.byref(cfg), ctypes.byref(h)), "fabgpu_init")
         self._h = h

@@ -62,11 +62,14 @@ extern "C" {
 
 typedef struct fabgpu_ctx fabgpu_ctx;
 
+/* fabgpu_cfg.flags */
+#define FABGPU_FLAG_ONE_LANE_ONLY 1u /* never use the two-lanes-per-signature kernel (parity tests run both variants) */
+
 typedef struct fabgpu_cfg {
     int32_t device;      /* HIP device ordinal; -1 = the current device */
     uint32_t max_batch;  /* staging pre-allocation hint in tuples (0 = grow on demand) */
     uint32_t max_arena;  /* staging pre-allocation hint in message bytes (0 = grow on demand) */
-    uint32_t flags;      /* reserved, must be 0 */
+    uint32_t flags;      /* FABGPU_FLAG_* bits, normally 0; unknown bits are rejected */
 } fabgpu_cfg;
 
 /* Lifecycle.  Replaces sw.NewWithParams (bccsp/sw/new.go:39-98) for the accelerated verbs. */

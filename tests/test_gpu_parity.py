@@ -31,9 +31,11 @@ def _arr(items):
     return np.frombuffer(b"".join(items), dtype=np.uint8).reshape(-1, 32).copy()
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = fabgpu.Context(device=0)
+@pytest.fixture(scope="module", params=["auto", "one-lane"])
+def ctx(request):
+    """auto = the product default (two lanes per signature up to 32 768 tuples, one lane beyond);
+    one-lane = FABGPU_FLAG_ONE_LANE_ONLY, so that every fixture and edge vector also goes through the one-lane kernel."""
+    c = fabgpu.Context(device=0, flags=fabgpu.FLAG_ONE_LANE_ONLY if request.param == "one-lane" else 0)
     yield c
     c.close()
 
@@ -73,7 +75,7 @@ def test_edge_vectors(ctx):
 
 
 # ---- seeded random batches vs oracle, ragged sizes ---------------------------------------------------
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 255, 256, 257, 1000, 4097])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4097, 32767, 32768, 32769])
 def test_verify_batch_sizes(ctx, n):
     b = coracle.make_batch(n, seed=1000 + n, invalid_frac=0.2 if n > 4 else 0.0)
     bits, st = ctx.p256_verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
