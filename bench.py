@@ -34,8 +34,9 @@ HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8 TB/s spec
 # independent v_mad_u64_u32 streams at 4 waves/SIMD on all 1024 SIMDs retire one wave-instruction per 1.902 ns per SIMD
 # (wall clock, i.e. at whatever frequency the chip sustains for a pure multiplier stream) = 64 lanes / 1.902 ns x 1024 SIMDs.
 VALU_PEAK_MAC = 64 / 1.902e-9 * 1024
-# v_mad_i64_i32 the verify kernel actually executes per signature (static count x trip counts; rocprof
-# SQ_INSTS_VALU_INT64 = 437 k per lane includes the 64-bit shifts): 263 dbl x 792 + 53 add x 1728 + 39 madd x 1179 + ~5 k
+# v_mad_i64_i32 the verify kernels actually execute per signature (static count x trip counts):
+# 263 dbl x 792 + 53 add x 1728 + 39 madd x 1179 + ~5 k with one lane per signature; the two-lane kernel executes the same
+# products (2 lanes x (263 x 396 + 53 x 864 + 39 x 666)) plus the scalar part twice.
 EXECUTED_MAC_PER_VERIFY = 3.51e5
 
 
@@ -144,7 +145,8 @@ def main():
                        "parallelism": "1 block per GPU%s" % (" + RCCL all-gather of verdict bitmaps" if world > 1 else "")},
             "validated_tx_per_s": n_tx * world / (dt / args.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (algorithmic: %d)" % int(ALGO_BYTES_PER_VERIFY * n), "kernel": "p256_verify_kernel", "kernel_ms": kernel_s * 1e3,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (algorithmic: %d)" % int(ALGO_BYTES_PER_VERIFY * n),
+                         "kernel": "p256_verify_pair_kernel<256> (two lanes per signature)" if n <= 32768 else "p256_verify_kernel<256>", "kernel_ms": kernel_s * 1e3,
                          "kernel_ms_lib_events": kernel_ms,
                          "note": "integer-VALU-bound, not HBM-bound (SURVEY 8(d)): see valu_roofline"},
             "valu_roofline": {"bound": "u32-mac", "achieved": n / kernel_s * MAC_PER_VERIFY, "peak": VALU_PEAK_MAC, "unit": "MAC/s",
