@@ -256,10 +256,10 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
-    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, false), &wi);
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
     if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
-    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, st);
+    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, st);
     hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = true;

@@ -24,5 +24,5 @@ hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const 
                               const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
                                      const void* qy, const void* r, const void* s, const void* gtab, void* qws,
-                                     void* verdict_bits, void* status, hipStream_t st);
+                                     void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
 }  // namespace fab

@@ -192,6 +192,22 @@ __global__ void __launch_bounds__(BLOCK, 2) p256_verify_kernel(uint32_t n, const
     }
 }
 
+// 32 verdicts per wave sit on the even lanes: squeeze the even bits of the ballot into one u32 half-word
+__device__ __forceinline__ void pair_emit_verdict(uint32_t i, uint32_t n, bool active, bool odd, uint32_t st, uint32_t* __restrict__ verdict32,
+                                                  uint8_t* __restrict__ status) {
+    uint64_t x = __ballot(active && !odd && st == ST_VALID) & 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    x = (x | (x >> 16)) & 0x00000000ffffffffull;
+    if ((threadIdx.x & 63) == 0 && active) {       // i is a multiple of 32 here
+        verdict32[i >> 5] = (uint32_t)x;
+        if (i + 32 >= n && ((i >> 5) & 1u) == 0) verdict32[(i >> 5) + 1] = 0;   // no wave owns the upper half of the last word
+    }
+    if (status != nullptr && active && !odd) status[i] = (uint8_t)st;
+}
+
 // Two lanes per signature (p256_pair29.h): 128 signatures per 256-thread workgroup, for batches that cannot fill the chip
 // with one signature per lane.  Lane 2k / 2k+1 of a wave own signature k; the even lane carries the verdict.
 template <int BLOCK>
@@ -217,18 +233,41 @@ __global__ void __launch_bounds__(BLOCK, 1) p256_verify_pair_kernel(uint32_t n, 
         load_be_field(vr, r, ic);
         load_be_field(vs, s, ic);
         uint32_t st = p256_verify_pair29(vqx, vqy, ve, vr, vs, gtab, qtab, odd);
-        // 32 verdicts per wave sit on the even lanes: squeeze the even bits of the ballot into one u32 half-word
-        uint64_t x = __ballot(active && !odd && st == ST_VALID) & 0x5555555555555555ull;
-        x = (x | (x >> 1)) & 0x3333333333333333ull;
-        x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
-        x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
-        x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
-        x = (x | (x >> 16)) & 0x00000000ffffffffull;
-        if ((threadIdx.x & 63) == 0 && active) {       // i is a multiple of 32 here
-            verdict32[i >> 5] = (uint32_t)x;
-            if (i + 32 >= n && ((i >> 5) & 1u) == 0) verdict32[(i >> 5) + 1] = 0;   // no wave owns the upper half of the last word
-        }
-        if (status != nullptr && active && !odd) status[i] = (uint8_t)st;
+        pair_emit_verdict(i, n, active, odd, st, verdict32, status);
+    }
+}
+
+// identity.Verify fused, two lanes per signature: both lanes of a pair hash the (same) message - the hash is 18 % of the
+// stream and does not split across lanes - and keep the digest in registers.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_pair_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                                                const uint32_t* __restrict__ off, const uint8_t* __restrict__ qx,
+                                                                                const uint8_t* __restrict__ qy, const uint8_t* __restrict__ r,
+                                                                                const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
+                                                                                uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
+                                                                                uint8_t* __restrict__ status) {
+    constexpr int NP = BLOCK / 2;
+    const bool odd = (threadIdx.x & 1) != 0;
+    const uint32_t pairidx = threadIdx.x >> 1;
+    PairQTab<NP> qtab{qws + (size_t)blockIdx.x * (QWS_PAIR_UINT4_PER_SIG * NP) + pairidx};
+    uint32_t* verdict32 = reinterpret_cast<uint32_t*>(verdict_bits);
+    const uint32_t ntiles = (n + NP - 1) / NP;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * NP + pairidx;
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        uint32_t start = off[ic], end = off[ic + 1];
+        uint32_t h[8];
+        sha256_lane(arena32, arena_words, start, end - start, active, h);
+        u256 vqx, vqy, ve, vr, vs;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];
+        load_be_field(vqx, qx, ic);
+        load_be_field(vqy, qy, ic);
+        load_be_field(vr, r, ic);
+        load_be_field(vs, s, ic);
+        uint32_t st = p256_verify_pair29(vqx, vqy, ve, vr, vs, gtab, qtab, odd);
+        pair_emit_verdict(i, n, active, odd, st, verdict32, status);
     }
 }
 
@@ -302,10 +341,16 @@ hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const 
 }
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
                                      const void* qy, const void* r, const void* s, const void* gtab, void* qws,
-                                     void* verdict_bits, void* status, hipStream_t st) {
+                                     void* verdict_bits, void* status, bool allow_pair, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    VerifyGeom g = verify_geom(n, false);
+    VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
+    if (g.pair) {
+        hipLaunchKernelGGL(sha256_p256_verify_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                           (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
+                           (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(sha256_p256_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                        (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
                        (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
