@@ -95,6 +95,22 @@ int hosttest_combined_mult29(const uint8_t* u1_32, const uint8_t* u2_32, const u
     to_be32(y32, y);
     return 0;
 }
+// the keyed core (registered public key: comb table of Q built like the device would) on the CPU
+void hosttest_verify_keyed_core29(size_t n, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* e, const uint8_t* r, const uint8_t* s,
+                                  uint8_t* status) {
+    G8Tab gt{gtab29()};
+    u256 qx, qy;
+    from_be32(qx, qx32);
+    from_be32(qy, qy32);
+    std::vector<int32_t> kt(G8_TABLE_WORDS);
+    build_comb8_table(kt.data(), qx, qy);
+    G8Tab kk{kt.data()};
+    for (size_t i = 0; i < n; i++) {
+        u256 ve, vr, vs;
+        from_be32(ve, e + 32 * i); from_be32(vr, r + 32 * i); from_be32(vs, s + 32 * i);
+        status[i] = (uint8_t)p256_verify_keyed_core29(ve, vr, vs, gt, kk);
+    }
+}
 void hosttest_verify_core29(size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r, const uint8_t* s,
                             uint8_t* status) {
     G8Tab gt{gtab29()};

@@ -32,7 +32,7 @@ __device__ __forceinline__ void pair_sel(pair_pt& r, bool c, const pair_pt& a, c
     fe_sel(r.B, c, a.B, b.B);
 }
 
-#define PAIR_TMPS fe tU1, tU2, tU3, tU4, tU6, tW, tH, tRR, tP1, tP2, tT0, tT1, tTD
+#define PAIR_TMPS __attribute__((unused)) fe tU1, tU2, tU3, tU4, tU6, tW, tH, tRR, tP1, tP2, tT0, tT1, tTD
 #define PAIR_DBL(P) PAIR29_DBL((P).A, (P).B, tU1, tU2, tU3, tW, tP1, tP2, tT0, tT1, tTD)
 #define PAIR_ADD(P, C, D) PAIR29_ADD((P).A, (P).B, tH, tRR, tW, tU1, tU2, tU3, tU4, tU6, tP1, tP2, tT0, tT1, tTD, C, D)
 #define PAIR_MADD(P, C, D) PAIR29_MADD((P).A, (P).B, tU1, tU2, tU3, tU4, tH, tRR, tP1, tP2, tT0, tT1, tTD, C, D)
@@ -95,6 +95,68 @@ __device__ __forceinline__ void pair_g8_load(const int32_t* __restrict__ gtab, i
     const int32_t* e = gtab + g8_index(window, digit) + (odd ? 9 : 0);
 #pragma unroll
     for (int l = 0; l < 9; l++) xy.v[l] = e[l];
+}
+
+// S = k * B over an 8-bit comb table of B on a lane pair (comb8_mult29).  seed: any valid point in pair state.
+__device__ __forceinline__ void pair_comb8_mult29(pair_pt& S, bool& s_inf, const u256& k, const int32_t* __restrict__ tab, const pair_pt& seed,
+                                                  bool odd) {
+    const fe ONE = {FE29_R1};
+    PAIR_TMPS;
+    S = seed;
+    s_inf = true;
+    uint32_t nd = scalar_byte(k, 0);
+    fe nxy;
+    pair_g8_load(tab, 0, nd ? nd : 1u, odd, nxy);
+#pragma unroll 1
+    for (int i = 0; i < G8_WINDOWS; i++) {
+        uint32_t d = nd;
+        fe xy = nxy;
+        int inext = i + 1 < G8_WINDOWS ? i + 1 : i;
+        nd = scalar_byte(k, inext);
+        pair_g8_load(tab, inext, nd ? nd : 1u, odd, nxy);
+        pair_pt sum = S;
+        PAIR_MADD(sum, xy, xy);
+        bool take_ent = s_inf & (d != 0);
+        bool take_sum = (!s_inf) & (d != 0);
+        pair_sel(S, take_sum, sum, S);
+        if (__any(take_ent)) {
+            pair_pt ent;
+            fe sy;
+            pair_swap_fe(sy, xy);           // E: y2
+            ent.A = xy;                     // E: x2
+            fe_sel(ent.B, odd, ONE, sy);
+            pair_sel(S, take_ent, ent, S);
+        }
+        s_inf = s_inf & (d == 0);
+    }
+}
+
+// R = S + T on a lane pair with the exceptional cases of the group law (final_add29).
+__device__ __forceinline__ void pair_final_add29(pair_pt& Rr, bool& r_inf, const pair_pt& S, bool s_inf, const pair_pt& T, bool t_inf, bool odd) {
+    PAIR_TMPS;
+    fe C, D, sa, sb;
+    pair_swap_fe(sa, T.A);                  // O: X_T
+    pair_swap_fe(sb, T.B);                  // E: Z_T    O: Y_T
+    fe_sel(C, odd, sa, sb);
+    D = sb;
+    pair_pt Rp = S;
+    PAIR_ADD(Rp, C, D);
+    bool hz = fe_is_zero(tH);               // h on both lanes
+    bool rz_own = fe_is_zero(tRR);          // rr lives on E
+    int32_t rz_other = pair_swap_i32(rz_own ? 1 : 0);
+    bool rz = odd ? (rz_other != 0) : rz_own;
+    pair_pt Rd = T;
+    PAIR_DBL(Rd);
+    r_inf = t_inf & s_inf;
+    bool use_T = s_inf & !t_inf;
+    bool use_S = t_inf & !s_inf;
+    bool both = !s_inf & !t_inf;
+    bool use_dbl = both & hz & rz;
+    r_inf = r_inf | (both & hz & !rz);
+    Rr = Rp;
+    pair_sel(Rr, use_dbl, Rd, Rr);
+    pair_sel(Rr, use_T, T, Rr);
+    pair_sel(Rr, use_S, S, Rr);
 }
 
 // R = u1*G + u2*Q on a lane pair.  Q: affine Montgomery (both lanes hold both coordinates).  Returns the pair state of R;
@@ -167,59 +229,51 @@ __device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, c
         t_inf = t_inf & (mag == 0);
     }
 
-    // --- S = u1 * G : 32-window 8-bit comb ---
-    pair_pt S = Qp;
-    bool s_inf = true;
-    uint32_t nd = scalar_byte(u1, 0);
-    fe nxy;
-    pair_g8_load(gtab, 0, nd ? nd : 1u, odd, nxy);
-#pragma unroll 1
-    for (int i = 0; i < G8_WINDOWS; i++) {
-        uint32_t d = nd;
-        fe xy = nxy;
-        int inext = i + 1 < G8_WINDOWS ? i + 1 : i;
-        nd = scalar_byte(u1, inext);
-        pair_g8_load(gtab, inext, nd ? nd : 1u, odd, nxy);
-        pair_pt sum = S;
-        PAIR_MADD(sum, xy, xy);
-        bool take_ent = s_inf & (d != 0);
-        bool take_sum = (!s_inf) & (d != 0);
-        pair_sel(S, take_sum, sum, S);
-        if (__any(take_ent)) {
-            pair_pt ent;
-            fe sy;
-            pair_swap_fe(sy, xy);           // E: y2
-            ent.A = xy;                     // E: x2
-            fe_sel(ent.B, odd, ONE, sy);
-            pair_sel(S, take_ent, ent, S);
-        }
-        s_inf = s_inf & (d == 0);
-    }
+    // --- S = u1 * G (8-bit comb), then R = S + T ---
+    pair_pt S;
+    bool s_inf;
+    pair_comb8_mult29(S, s_inf, u1, gtab, Qp, odd);
+    pair_final_add29(Rr, r_inf, S, s_inf, T, t_inf, odd);
+}
 
-    // --- R = S + T with the exceptional cases of the group law ---
-    fe C, D, sa, sb;
-    pair_swap_fe(sa, T.A);                  // O: X_T
-    pair_swap_fe(sb, T.B);                  // E: Z_T    O: Y_T
-    fe_sel(C, odd, sa, sb);
-    D = sb;
-    pair_pt Rp = S;
-    PAIR_ADD(Rp, C, D);
-    bool hz = fe_is_zero(tH);               // h on both lanes
-    bool rz_own = fe_is_zero(tRR);          // rr lives on E
-    int32_t rz_other = pair_swap_i32(rz_own ? 1 : 0);
-    bool rz = odd ? (rz_other != 0) : rz_own;
-    pair_pt Rd = T;
-    PAIR_DBL(Rd);
-    r_inf = t_inf & s_inf;
-    bool use_T = s_inf & !t_inf;
-    bool use_S = t_inf & !s_inf;
-    bool both = !s_inf & !t_inf;
-    bool use_dbl = both & hz & rz;
-    r_inf = r_inf | (both & hz & !rz);
-    Rr = Rp;
-    pair_sel(Rr, use_dbl, Rd, Rr);
-    pair_sel(Rr, use_T, T, Rr);
-    pair_sel(Rr, use_S, S, Rr);
+// R = u1*G + u2*Q with both points on comb tables (registered key): 64 pair mixed additions.
+__device__ __forceinline__ void pair_combined_mult_keyed29(pair_pt& Rr, bool& r_inf, const u256& u1, const u256& u2,
+                                                           const int32_t* __restrict__ gtab, const int32_t* __restrict__ ktab, bool odd) {
+    const fe ONE = {FE29_R1};
+    fe gx, gy;
+    G8Tab gt{gtab};
+    gt.load(0, 1u, gx, gy);
+    pair_pt seed, S, T;
+    seed.A = gx;
+    fe_sel(seed.B, odd, ONE, gy);
+    bool s_inf, t_inf;
+    pair_comb8_mult29(T, t_inf, u2, ktab, seed, odd);
+    pair_comb8_mult29(S, s_inf, u1, gtab, seed, odd);
+    pair_final_add29(Rr, r_inf, S, s_inf, T, t_inf, odd);
+}
+
+// x(R) mod n == r on a pair: Z^2 and r Z^2 on O, the comparison with X on E.  The result is valid on the EVEN lane.
+// NB the swapped operand is the MINUEND: hipcc folds the DPP move into the subtraction, and for "own - partner" it emits
+// v_subrev_u32_dpp, which on MI355X does not compute src1 - dpp(src0) (probed in gputest.hip op 3; the Makefile rejects
+// any build whose device code contains that opcode).
+__device__ __forceinline__ bool pair_x_equals_r29(const pair_pt& Rr, bool r_inf, const u256& r) {
+    const u256 N = FAB_P256_N;
+    const u256 PMN = FAB_P256_P_MINUS_N;
+    fe zz, rm, rhs, rhs_e, d;
+    u256 r2;
+    fe_sqr(zz, Rr.B);                                  // O: Z^2
+    fe_to_mont(rm, r);
+    fe_mul(rhs, rm, zz);
+    pair_swap_fe(rhs_e, rhs);                          // E: r Z^2
+    fe_sub(d, rhs_e, Rr.A);
+    bool ok = fe_is_zero(d);
+    add256(r2, r, N);
+    fe_to_mont(rm, r2);
+    fe_mul(rhs, rm, zz);
+    pair_swap_fe(rhs_e, rhs);
+    fe_sub(d, rhs_e, Rr.A);
+    ok = ok | (lt256(r, PMN) & fe_is_zero(d));
+    return ok & !r_inf;
 }
 
 // Status of one tuple, valid on the EVEN lane of the pair.
@@ -227,7 +281,6 @@ template <class QTab>
 __device__ __forceinline__ uint32_t p256_verify_pair29(const u256& qx, const u256& qy, const u256& e, const u256& r, const u256& s,
                                                         const int32_t* __restrict__ gtab, const QTab& qtab, bool odd) {
     const u256 P = FAB_P256_P;
-    const u256 N = FAB_P256_N;
     uint32_t early = range_status(r, s);
 
     bool q_in_field = lt256(qx, P) & lt256(qy, P);
@@ -237,43 +290,27 @@ __device__ __forceinline__ uint32_t p256_verify_pair29(const u256& qx, const u25
     bool q_ok = q_in_field & on_curve29(QX, QY);
     if (early == ST_VALID && !q_ok) early = ST_OFF_CURVE;
 
-    u256 w, u1, u2, ered, t;
-    {
-        const modinv_info NI = MODINV_N_INFO;
-        modinv(w, s, NI);
-    }
-    uint32_t br = sub256(t, e, N);
-    sel256(ered, br == 0, t, e);
-    fn_to_mont(t, ered);
-    fn_mul(u1, t, w);
-    fn_to_mont(t, r);
-    fn_mul(u2, t, w);
+    u256 u1, u2;
+    ecdsa_scalars29(u1, u2, e, r, s);
 
     pair_pt Rr;
     bool r_inf;
     pair_combined_mult29(Rr, r_inf, u1, u2, QX, QY, gtab, qtab, odd);
+    bool ok = pair_x_equals_r29(Rr, r_inf, r);
+    uint32_t st = ok ? ST_VALID : ST_BAD_MATH;
+    return early != ST_VALID ? early : st;
+}
 
-    // --- x(R) mod n == r : Z^2 and r Z^2 on O, the comparison with X on E ---
-    const u256 PMN = FAB_P256_P_MINUS_N;
-    fe zz, rm, rhs, rhs_e, d;
-    u256 r2;
-    fe_sqr(zz, Rr.B);                                  // O: Z^2
-    fe_to_mont(rm, r);
-    fe_mul(rhs, rm, zz);
-    pair_swap_fe(rhs_e, rhs);                          // E: r Z^2
-    // NB the swapped operand is the MINUEND: hipcc folds the DPP move into the subtraction, and for "own - partner" it emits
-    // v_subrev_u32_dpp, which on MI355X does not compute src1 - dpp(src0) (probed in gputest.hip op 3; the Makefile rejects
-    // any build whose device code contains that opcode).
-    fe_sub(d, rhs_e, Rr.A);
-    bool ok = fe_is_zero(d);
-    add256(r2, r, N);
-    fe_to_mont(rm, r2);
-    fe_mul(rhs, rm, zz);
-    pair_swap_fe(rhs_e, rhs);
-    fe_sub(d, rhs_e, Rr.A);
-    ok = ok | (lt256(r, PMN) & fe_is_zero(d));
-    ok = ok & !r_inf;
-
+// Registered key (p256_verify_keyed_core29): status valid on the EVEN lane.
+__device__ __forceinline__ uint32_t p256_verify_keyed_pair29(const u256& e, const u256& r, const u256& s, const int32_t* __restrict__ gtab,
+                                                              const int32_t* __restrict__ ktab, bool odd) {
+    uint32_t early = range_status(r, s);
+    u256 u1, u2;
+    ecdsa_scalars29(u1, u2, e, r, s);
+    pair_pt Rr;
+    bool r_inf;
+    pair_combined_mult_keyed29(Rr, r_inf, u1, u2, gtab, ktab, odd);
+    bool ok = pair_x_equals_r29(Rr, r_inf, r);
     uint32_t st = ok ? ST_VALID : ST_BAD_MATH;
     return early != ST_VALID ? early : st;
 }

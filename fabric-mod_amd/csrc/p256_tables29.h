@@ -1,5 +1,5 @@
-// Host-side precomputation of the generator comb table in the fe29 representation: 32 windows x 255 affine points,
-// T[w][d] = d * 2^(8 w) * G, Montgomery form with R = 2^261, balanced 29-bit digits, layout p256_verify29.h::g8_index.
+// Host-side precomputation of 8-bit comb tables in the fe29 representation: 32 windows x 255 affine points,
+// T[w][d] = d * 2^(8 w) * B for B = the generator (once per fabgpu_init) or a registered public key (fabgpu_p256_key_register), Montgomery form with R = 2^261, balanced 29-bit digits, layout p256_verify29.h::g8_index.
 // Built once per fabgpu_init with the host u256 arithmetic (fp256.h / p256_point.h) and uploaded to each device.
 #pragma once
 #include <vector>
@@ -9,13 +9,13 @@
 
 namespace fab {
 
-inline void build_g8_comb_table(int32_t* words) {
+// words: G8_TABLE_WORDS.  (bx, by): an affine point of the curve, plain integers (the generator, or a registered public key).
+inline void build_comb8_table(int32_t* words, const u256& bxp, const u256& byp) {
     for (int i = 0; i < G8_TABLE_WORDS; i++) words[i] = 0;
-    const u256 gxp = FAB_P256_GX_PLAIN, gyp = FAB_P256_GY_PLAIN;
     const u256 ONE = FAB_P256_R1;
-    jac base;  // 2^(8 w) G
-    fp_to_mont(base.X, gxp);
-    fp_to_mont(base.Y, gyp);
+    jac base;  // 2^(8 w) B
+    fp_to_mont(base.X, bxp);
+    fp_to_mont(base.Y, byp);
     base.Z = ONE;
     std::vector<jac> pts(256);
     for (int w = 0; w < G8_WINDOWS; w++) {
@@ -63,6 +63,10 @@ inline void build_g8_comb_table(int32_t* words) {
         pt_dbl(nb, pts[128]);
         base = nb;
     }
+}
+inline void build_g8_comb_table(int32_t* words) {
+    const u256 gxp = FAB_P256_GX_PLAIN, gyp = FAB_P256_GY_PLAIN;
+    build_comb8_table(words, gxp, gyp);
 }
 
 }  // namespace fab

@@ -165,11 +165,96 @@ struct LocalQTab29 {
     FAB_HD void load(uint32_t d, jac29& p) const { p = t[d - 1]; }
 };
 
+// S = k * B over an 8-bit comb table of B (32 mixed additions; the next window's entry is gathered while this one is added).
+// No addition can meet P == +-Q: the partial sum is < 2^(8 i) B while the addend is d 2^(8 i) B.  seed: any valid point.
+template <class GTab>
+FAB_HD void comb8_mult29(jac29& S, bool& s_inf, const u256& k, const GTab& tab, const jac29& seed) {
+    const fe ONE = {FE29_R1};
+    S = seed;
+    s_inf = true;
+    uint32_t nd = scalar_byte(k, 0);
+    fe nx, ny;
+    tab.load(0, nd ? nd : 1u, nx, ny);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = 0; i < G8_WINDOWS; i++) {
+        uint32_t d = nd;
+        jac29 ent, sum;
+        fe h, rr;
+        ent.X = nx;
+        ent.Y = ny;
+        ent.Z = ONE;
+        int inext = i + 1 < G8_WINDOWS ? i + 1 : i;
+        nd = scalar_byte(k, inext);
+        tab.load(inext, nd ? nd : 1u, nx, ny);
+        pt_add_mixed29(sum, S, ent.X, ent.Y, h, rr);
+        bool take_ent = s_inf & (d != 0);
+        bool take_sum = (!s_inf) & (d != 0);
+        sel_jac29(S, take_sum, sum, S);
+        sel_jac29(S, take_ent, ent, S);
+        s_inf = s_inf & (d == 0);
+    }
+}
+
+// R = S + T with the exceptional cases of the group law (Appendix A step 8): doubling when S == T, infinity when S == -T.
+FAB_HD void final_add29(jac29& Rr, bool& r_inf, const jac29& S, bool s_inf, const jac29& T, bool t_inf) {
+    jac29 Rp, Rd;
+    fe h, rr;
+    pt_add29(Rp, S, T, h, rr);
+    bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
+    pt_dbl29(Rd, T);
+    r_inf = t_inf & s_inf;
+    bool use_T = s_inf & !t_inf;
+    bool use_S = t_inf & !s_inf;
+    bool both = !s_inf & !t_inf;
+    bool use_dbl = both & hz & rz;                    // S == T
+    r_inf = r_inf | (both & hz & !rz);                // S == -T  -> point at infinity
+    Rr = Rp;
+    sel_jac29(Rr, use_dbl, Rd, Rr);
+    sel_jac29(Rr, use_T, T, Rr);
+    sel_jac29(Rr, use_S, S, Rr);
+}
+
+// x(R) mod n == r without inverting Z:  X == r Z^2  or  (r < p - n and X == (r + n) Z^2)
+FAB_HD bool x_equals_r29(const jac29& Rr, bool r_inf, const u256& r) {
+    const u256 N = FAB_P256_N;
+    const u256 PMN = FAB_P256_P_MINUS_N;
+    fe zz, rm, rhs, d;
+    u256 r2;
+    fe_sqr(zz, Rr.Z);                                  // [1x1]
+    fe_to_mont(rm, r);
+    fe_mul(rhs, rm, zz);
+    fe_sub(d, Rr.X, rhs);
+    bool ok = fe_is_zero(d);
+    add256(r2, r, N);                                  // only meaningful when r < p - n (no wrap)
+    fe_to_mont(rm, r2);
+    fe_mul(rhs, rm, zz);
+    fe_sub(d, Rr.X, rhs);
+    ok = ok | (lt256(r, PMN) & fe_is_zero(d));
+    return ok & !r_inf;
+}
+
+// w = s^-1, u1 = e w, u2 = r w  (mod n)
+FAB_HD void ecdsa_scalars29(u256& u1, u256& u2, const u256& e, const u256& r, const u256& s) {
+    const u256 N = FAB_P256_N;
+    u256 w, ered, t;
+    {
+        const modinv_info NI = MODINV_N_INFO;
+        modinv(w, s, NI);                       // s >= n only on lanes already rejected by the low-S gate
+    }
+    uint32_t br = sub256(t, e, N);              // e < 2^256 < 2n: one conditional subtraction
+    sel256(ered, br == 0, t, e);
+    fn_to_mont(t, ered);
+    fn_mul(u1, t, w);                           // (e R)(w) / R
+    fn_to_mont(t, r);
+    fn_mul(u2, t, w);
+}
+
 // R = u1*G + u2*Q for an on-curve affine Q (Montgomery form) and u1, u2 < n, u2 != 0: the CombinedMult of the reference's
 // crypto/elliptic.  r_inf reports the point at infinity (then Rr is meaningless).
 template <class GTab, class QTab>
 FAB_HD void p256_combined_mult29(jac29& Rr, bool& r_inf, const u256& u1, const u256& u2, const jac29& Q, const GTab& gtab, QTab& qtab) {
-    const fe ONE = {FE29_R1};
 
     // --- per-lane table j*Q, j = 1..16 (8 doublings + 7 mixed additions) ---
     qtab.store(1, Q);
@@ -235,49 +320,25 @@ FAB_HD void p256_combined_mult29(jac29& Rr, bool& r_inf, const u256& u1, const u
         t_inf = t_inf & (mag == 0);
     }
 
-    // --- S = u1 * G (8-bit comb, mixed additions only; next window's entry is gathered while this one is added) ---
-    jac29 S = Q;
-    bool s_inf = true;
-    uint32_t nd = scalar_byte(u1, 0);
-    fe nx, ny;
-    gtab.load(0, nd ? nd : 1u, nx, ny);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-    for (int i = 0; i < G8_WINDOWS; i++) {
-        uint32_t d = nd;
-        jac29 ent, sum;
-        fe h, rr;
-        ent.X = nx;
-        ent.Y = ny;
-        ent.Z = ONE;
-        int inext = i + 1 < G8_WINDOWS ? i + 1 : i;
-        nd = scalar_byte(u1, inext);
-        gtab.load(inext, nd ? nd : 1u, nx, ny);
-        pt_add_mixed29(sum, S, ent.X, ent.Y, h, rr);
-        bool take_ent = s_inf & (d != 0);
-        bool take_sum = (!s_inf) & (d != 0);
-        sel_jac29(S, take_sum, sum, S);
-        sel_jac29(S, take_ent, ent, S);
-        s_inf = s_inf & (d == 0);
-    }
+    // --- S = u1 * G (8-bit comb), then R = S + T ---
+    jac29 S;
+    bool s_inf;
+    comb8_mult29(S, s_inf, u1, gtab, Q);
+    final_add29(Rr, r_inf, S, s_inf, T, t_inf);
+}
 
-    // --- R = S + T with the exceptional cases of the group law (Appendix A step 8) ---
-    jac29 Rp, Rd;
-    fe h, rr;
-    pt_add29(Rp, S, T, h, rr);
-    bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
-    pt_dbl29(Rd, T);
-    r_inf = t_inf & s_inf;                       // cannot happen for u2 != 0; kept for completeness
-    bool use_T = s_inf & !t_inf;
-    bool use_S = t_inf & !s_inf;
-    bool both = !s_inf & !t_inf;
-    bool use_dbl = both & hz & rz;                    // S == T
-    r_inf = r_inf | (both & hz & !rz);                // S == -T  -> point at infinity
-    Rr = Rp;
-    sel_jac29(Rr, use_dbl, Rd, Rr);
-    sel_jac29(Rr, use_T, T, Rr);
-    sel_jac29(Rr, use_S, S, Rr);
+// R = u1*G + u2*Q with BOTH points on precomputed 8-bit comb tables (a registered public key): 64 mixed additions, no
+// doublings, no per-lane table.  seed: any valid point (used as filler while an accumulator is still at infinity).
+template <class GTab>
+FAB_HD void p256_combined_mult_keyed29(jac29& Rr, bool& r_inf, const u256& u1, const u256& u2, const GTab& gtab, const GTab& ktab) {
+    const fe ONE = {FE29_R1};
+    jac29 seed, S, T;
+    bool s_inf, t_inf;
+    gtab.load(0, 1u, seed.X, seed.Y);
+    seed.Z = ONE;
+    comb8_mult29(T, t_inf, u2, ktab, seed);
+    comb8_mult29(S, s_inf, u1, gtab, seed);
+    final_add29(Rr, r_inf, S, s_inf, T, t_inf);
 }
 
 // The verification core.  GTab provides  void load(int window, uint32_t digit /*1..255*/, fe& x, fe& y);
@@ -286,7 +347,6 @@ template <class GTab, class QTab>
 FAB_HD uint32_t p256_verify_core29(const u256& qx, const u256& qy, const u256& e, const u256& r, const u256& s,
                                    const GTab& gtab, QTab& qtab) {
     const u256 P = FAB_P256_P;
-    const u256 N = FAB_P256_N;
     const fe ONE = {FE29_R1};
     uint32_t early = range_status(r, s);
 
@@ -299,39 +359,27 @@ FAB_HD uint32_t p256_verify_core29(const u256& qx, const u256& qy, const u256& e
     bool q_ok = q_in_field & on_curve29(Q.X, Q.Y);
     if (early == ST_VALID && !q_ok) early = ST_OFF_CURVE;
 
-    // --- scalars: w = s^-1, u1 = e w, u2 = r w  (mod n) ---
-    u256 w, u1, u2, ered, t;
-    {
-        const modinv_info NI = MODINV_N_INFO;
-        modinv(w, s, NI);                       // s >= n only on lanes already rejected by the low-S gate
-    }
-    uint32_t br = sub256(t, e, N);              // e < 2^256 < 2n: one conditional subtraction
-    sel256(ered, br == 0, t, e);
-    fn_to_mont(t, ered);
-    fn_mul(u1, t, w);                           // (e R)(w) / R
-    fn_to_mont(t, r);
-    fn_mul(u2, t, w);
+    u256 u1, u2;
+    ecdsa_scalars29(u1, u2, e, r, s);
 
     jac29 Rr;
     bool r_inf;
     p256_combined_mult29(Rr, r_inf, u1, u2, Q, gtab, qtab);
+    bool ok = x_equals_r29(Rr, r_inf, r);
+    uint32_t st = ok ? ST_VALID : ST_BAD_MATH;
+    return early != ST_VALID ? early : st;
+}
 
-    // --- x(R) mod n == r  without inverting Z ---
-    const u256 PMN = FAB_P256_P_MINUS_N;
-    fe zz, rm, rhs, d;
-    u256 r2;
-    fe_sqr(zz, Rr.Z);                                  // [1x1]
-    fe_to_mont(rm, r);
-    fe_mul(rhs, rm, zz);
-    fe_sub(d, Rr.X, rhs);
-    bool ok = fe_is_zero(d);
-    add256(r2, r, N);                                  // only meaningful when r < p - n (no wrap)
-    fe_to_mont(rm, r2);
-    fe_mul(rhs, rm, zz);
-    fe_sub(d, Rr.X, rhs);
-    ok = ok | (lt256(r, PMN) & fe_is_zero(d));
-    ok = ok & !r_inf;
-
+// The same verification for a REGISTERED key (curve membership was checked at registration): ktab is the key's comb table.
+template <class GTab>
+FAB_HD uint32_t p256_verify_keyed_core29(const u256& e, const u256& r, const u256& s, const GTab& gtab, const GTab& ktab) {
+    uint32_t early = range_status(r, s);
+    u256 u1, u2;
+    ecdsa_scalars29(u1, u2, e, r, s);
+    jac29 Rr;
+    bool r_inf;
+    p256_combined_mult_keyed29(Rr, r_inf, u1, u2, gtab, ktab);
+    bool ok = x_equals_r29(Rr, r_inf, r);
     uint32_t st = ok ? ST_VALID : ST_BAD_MATH;
     return early != ST_VALID ? early : st;
 }
