@@ -7,6 +7,8 @@
 
 #include <mutex>
 #include <new>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "../../include/fabgpu.h"
@@ -61,6 +63,14 @@ struct fabgpu_ctx {
         bool pending = false;
     };
     std::vector<QWs> qws;
+    // Registered public keys: one 640 KiB comb table each, resident on the device; d_ktabs mirrors the pointer array.
+    std::mutex kmu;
+    std::vector<int32_t*> ktabs;
+    std::map<std::string, uint32_t> key_ids;   // qx||qy -> id
+    const int32_t** d_ktabs = nullptr;
+    size_t d_ktabs_cap = 0;
+    std::vector<void*> retired;   // outgrown d_ktabs arrays, freed at shutdown
+    Buf keyed;        // staging of the keyed host-pointer entry point: key_id | e | r | s
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
     int acquire_qws(size_t bytes, size_t* idx);
     void release_qws(size_t idx, hipStream_t st) {
@@ -194,6 +204,9 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->offs.release();
         ctx->out.release();
         if (ctx->d_gtab) hipFree(ctx->d_gtab);
+        for (auto* t : ctx->ktabs) hipFree(t);
+        for (auto* t : ctx->retired) hipFree(t);
+        if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
             if (w.done) hipEventDestroy(w.done);
@@ -266,6 +279,83 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
     return hip_to_rc(err);
 }
 
+// ---- registered public keys -------------------------------------------------------------------------
+int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
+    if (!ctx || !qx32 || !qy32 || !key_id) return FABGPU_EINVAL;
+    if (!fabgpu_p256_pubkey_on_curve(qx32, qy32)) return FABGPU_EINVAL;   // KeyImport gate: such keys stay with bccsp/sw
+    std::string k((const char*)qx32, 32);
+    k.append((const char*)qy32, 32);
+    std::lock_guard<std::mutex> lk(ctx->kmu);
+    auto it = ctx->key_ids.find(k);
+    if (it != ctx->key_ids.end()) {
+        *key_id = it->second;
+        return FABGPU_OK;
+    }
+    if (ctx->ktabs.size() >= FABGPU_MAX_KEYS) return FABGPU_ENOMEM;
+    DeviceGuard g(ctx->device);
+    u256 qx, qy;
+    from_be32(qx, qx32);
+    from_be32(qy, qy32);
+    std::vector<int32_t> tab(G8_TABLE_WORDS);
+    build_comb8_table(tab.data(), qx, qy);
+    int32_t* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(int32_t) * G8_TABLE_WORDS) != hipSuccess) return FABGPU_ENOMEM;
+    if (hipMemcpy(d, tab.data(), sizeof(int32_t) * G8_TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(d);
+        return FABGPU_ELAUNCH;
+    }
+    // grow the device-side pointer array by doubling; the old array is only released at shutdown, so launches already in
+    // flight on other streams keep reading a valid (shorter) array
+    if (ctx->ktabs.size() + 1 > ctx->d_ktabs_cap) {
+        size_t cap = ctx->d_ktabs_cap ? ctx->d_ktabs_cap * 2 : 64;
+        const int32_t** nd = nullptr;
+        if (hipMalloc((void**)&nd, cap * sizeof(int32_t*)) != hipSuccess) {
+            hipFree(d);
+            return FABGPU_ENOMEM;
+        }
+        if (!ctx->ktabs.empty()) hipMemcpy((void*)nd, ctx->ktabs.data(), ctx->ktabs.size() * sizeof(int32_t*), hipMemcpyHostToDevice);
+        if (ctx->d_ktabs) ctx->retired.push_back((void*)ctx->d_ktabs);
+        ctx->d_ktabs = nd;
+        ctx->d_ktabs_cap = cap;
+    }
+    if (hipMemcpy((void*)(ctx->d_ktabs + ctx->ktabs.size()), &d, sizeof(int32_t*), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(d);
+        return FABGPU_ELAUNCH;
+    }
+    ctx->ktabs.push_back(d);
+    *key_id = (uint32_t)(ctx->ktabs.size() - 1);
+    ctx->key_ids[k] = *key_id;
+    return FABGPU_OK;
+}
+
+int fabgpu_p256_key_count(fabgpu_ctx* ctx) {
+    if (!ctx) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->kmu);
+    return (int)ctx->ktabs.size();
+}
+
+int fabgpu_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* key_id, const void* e, const void* r, const void* s,
+                                       void* verdict_bits, void* status, void* stream) {
+    if (!ctx || (n && (!key_id || !e || !r || !s || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0xFFFFFFF0ull) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    uint32_t nkeys;
+    const int32_t** kt;
+    {
+        std::lock_guard<std::mutex> lk(ctx->kmu);
+        nkeys = (uint32_t)ctx->ktabs.size();
+        kt = ctx->d_ktabs;
+    }
+    if (nkeys == 0) return FABGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipEventRecord(ctx->ev0, st);
+    hipError_t err = launch_p256_verify_keyed((uint32_t)n, key_id, nkeys, (const void*)kt, e, r, s, ctx->d_gtab, verdict_bits, status, ctx->allow_pair, st);
+    hipEventRecord(ctx->ev1, st);
+    ctx->timed = true;
+    return hip_to_rc(err);
+}
+
 // ---- host-pointer entry points (what the cgo provider binds) -----------------------------------------
 int fabgpu_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r,
                              const uint8_t* s, uint64_t* verdict_bits, uint8_t* status) {
@@ -285,6 +375,33 @@ int fabgpu_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* qx, const
     hipError_t err = hipMemcpyAsync(d, h, 5 * fb, hipMemcpyHostToDevice, ctx->stream);
     if (err != hipSuccess) return hip_to_rc(err);
     rc = fabgpu_p256_verify_batch_dev(ctx, n, d, d + fb, d + 2 * fb, d + 3 * fb, d + 4 * fb, dout, status ? dout + st_off : nullptr, ctx->stream);
+    if (rc) return rc;
+    err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    memcpy(verdict_bits, ctx->out.h, words * 8);
+    if (status) memcpy(status, (uint8_t*)ctx->out.h + st_off, n);
+    return FABGPU_OK;
+}
+
+int fabgpu_p256_verify_batch_keyed(fabgpu_ctx* ctx, size_t n, const uint32_t* key_id, const uint8_t* e, const uint8_t* r, const uint8_t* s,
+                                   uint64_t* verdict_bits, uint8_t* status) {
+    if (!ctx || (n && (!key_id || !e || !r || !s || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0x7FFFFFF0ull / 100) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    const size_t fb = n * 32, kb = round_up(n * 4, 64), words = (n + 63) / 64;
+    const size_t st_off = round_up(words * 8, 64);
+    int rc;
+    if ((rc = ctx->keyed.ensure(kb + 3 * fb)) || (rc = ctx->out.ensure(st_off + n))) return rc;
+    uint8_t* h = (uint8_t*)ctx->keyed.h;
+    memcpy(h, key_id, n * 4); memcpy(h + kb, e, fb); memcpy(h + kb + fb, r, fb); memcpy(h + kb + 2 * fb, s, fb);
+    uint8_t* d = (uint8_t*)ctx->keyed.d;
+    uint8_t* dout = (uint8_t*)ctx->out.d;
+    hipError_t err = hipMemcpyAsync(d, h, kb + 3 * fb, hipMemcpyHostToDevice, ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    rc = fabgpu_p256_verify_batch_keyed_dev(ctx, n, d, d + kb, d + kb + fb, d + kb + 2 * fb, dout, status ? dout + st_off : nullptr, ctx->stream);
     if (rc) return rc;
     err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);

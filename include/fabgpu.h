@@ -105,6 +105,22 @@ int fabgpu_sha256_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t
 int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
                                         const void* qx, const void* qy, const void* r, const void* s,
                                         void* verdict_bits, void* status, void* stream);
+/* ---- registered public keys (bccsp.KeyImport, bccsp/bccsp.go:112; pattern bccsp/pkcs11/pkcs11.go:148-179) ----
+ * A Fabric block is signed by few distinct identities (endorsers, orderers; msp/cache/cache.go:14-18 caches 100).
+ * Registering a public key builds a 640 KiB comb table for it on the device once; batches that name registered keys by
+ * id verify with 64 mixed additions and no doublings (about 3.5x fewer instructions than a fresh key).  Verdicts are
+ * bit-identical to fabgpu_p256_verify_batch on the same (key, e, r, s).
+ * fabgpu_p256_key_register: idempotent per (qx, qy); FABGPU_EINVAL for a point that is not on P-256 (the KeyImport gate:
+ * such keys stay with bccsp/sw), FABGPU_ENOMEM when FABGPU_MAX_KEYS tables exist.  A key id out of range in a batch
+ * yields status 4 for that tuple. */
+#define FABGPU_MAX_KEYS 4096
+int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id);
+int fabgpu_p256_key_count(fabgpu_ctx* ctx);
+int fabgpu_p256_verify_batch_keyed(fabgpu_ctx* ctx, size_t n, const uint32_t* key_id, const uint8_t* e, const uint8_t* r,
+                                   const uint8_t* s, uint64_t* verdict_bits, uint8_t* status);
+int fabgpu_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* key_id, const void* e, const void* r, const void* s,
+                                       void* verdict_bits, void* status, void* stream);
+
 /* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
  * launch stream (bench.py's roofline leg).  <0 if nothing was launched or events are pending. */
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);

@@ -148,3 +148,49 @@ def make_batch(n, seed, invalid_frac=0.0, digests=None):
                 rv = (int.from_bytes(r[i].tobytes(), "big") + 1) % (1 << 256)
                 r[i] = np.frombuffer(rv.to_bytes(32, "big"), dtype=np.uint8)
     return dict(qx=qx, qy=qy, e=e, r=r, s=s, kind=kind)
+
+
+def make_pool_batch(n, seed, nkeys=16, invalid_frac=0.0):
+    """Like make_batch, but the signers are drawn from a pool of `nkeys` keypairs (the realistic Fabric shape: few distinct
+    endorsers per block).  Adds key_index (n, into the pool) and pool_qx / pool_qy (nkeys x 32).
+    Invalid mix: flipped digest bit / signature by another pool key / high-S mirror / r+1."""
+    rng = np.random.default_rng(seed)
+
+    def scalars(m):
+        a = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+        a[:, 0] &= 0x7F
+        a[:, 31] |= 1
+        return a
+    dpool = scalars(nkeys)
+    key_index = rng.integers(0, nkeys, size=n).astype(np.uint32)
+    d, k = dpool[key_index], scalars(n)
+    e = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    qx = np.zeros((n, 32), np.uint8); qy = np.zeros((n, 32), np.uint8)
+    r = np.zeros((n, 32), np.uint8); s = np.zeros((n, 32), np.uint8)
+    lib().oracle_p256_make_batch(ctypes.c_size_t(n), _p(np.ascontiguousarray(d)), _p(k), _p(e), _p(qx), _p(qy), _p(r), _p(s))
+    pool_qx = np.zeros((nkeys, 32), np.uint8); pool_qy = np.zeros((nkeys, 32), np.uint8)
+    for j in range(nkeys):
+        i = int(np.nonzero(key_index == j)[0][0]) if (key_index == j).any() else None
+        if i is not None:
+            pool_qx[j], pool_qy[j] = qx[i], qy[i]
+        else:
+            lib().oracle_p256_pubkey(_p(np.ascontiguousarray(dpool[j])), _p(pool_qx[j:j + 1]), _p(pool_qy[j:j + 1]))
+    kind = np.zeros(n, dtype=np.uint8)
+    nbad = int(round(n * invalid_frac))
+    if nbad:
+        idx = rng.choice(n, size=nbad, replace=False)
+        for j, i in enumerate(idx):
+            m = 1 + j % 4
+            kind[i] = m
+            if m == 1:
+                e[i, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+            elif m == 2:
+                key_index[i] = (key_index[i] + 1) % nkeys
+                qx[i], qy[i] = pool_qx[key_index[i]], pool_qy[key_index[i]]
+            elif m == 3:
+                sv = N_INT - int.from_bytes(s[i].tobytes(), "big")
+                s[i] = np.frombuffer(sv.to_bytes(32, "big"), dtype=np.uint8)
+            else:
+                rv = (int.from_bytes(r[i].tobytes(), "big") + 1) % (1 << 256)
+                r[i] = np.frombuffer(rv.to_bytes(32, "big"), dtype=np.uint8)
+    return dict(qx=qx, qy=qy, e=e, r=r, s=s, kind=kind, key_index=key_index, pool_qx=pool_qx, pool_qy=pool_qy)

@@ -119,6 +119,41 @@ def test_full_size_cfg4_properties(ctx):
     assert (st[sample] == want).all()
 
 
+# ---- registered public keys (bccsp.KeyImport -> per-key comb table) --------------------------------------
+@pytest.mark.parametrize("n,nkeys", [(1, 1), (33, 2), (500, 16), (4097, 16), (33000, 16)])
+def test_registered_keys_pool_vs_oracle_and_vs_the_unkeyed_kernel(ctx, n, nkeys):
+    b = coracle.make_pool_batch(n, seed=4242 + n, nkeys=nkeys, invalid_frac=0.2 if n > 4 else 0.0)
+    ids = np.array([ctx.key_register(b["pool_qx"][j].tobytes(), b["pool_qy"][j].tobytes()) for j in range(nkeys)], dtype=np.uint32)
+    assert len(set(ids.tolist())) == nkeys
+    assert ctx.key_register(b["pool_qx"][0].tobytes(), b["pool_qy"][0].tobytes()) == ids[0]        # idempotent
+    bits, st = ctx.p256_verify_batch_keyed(ids[b["key_index"]], b["e"], b["r"], b["s"])
+    want = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
+    assert (st == want).all() and (bits == (want == 0)).all()
+    bits2, st2 = ctx.p256_verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
+    assert (st2 == st).all() and (bits2 == bits).all()
+
+
+def test_registered_keys_every_signer_its_own_key_edge_vectors_and_bad_ids(ctx):
+    # the edge vectors (x(R) >= n, u1 = 0, final addition = doubling / infinity, window corners ...) through the keyed path
+    vs = [v for v in _load("edge_kats.json") if len(v["e"]) == 64 and po.on_curve(int(v["qx"], 16), int(v["qy"], 16))
+          and 0 <= int(v["r"], 16) < 1 << 256 and 0 <= int(v["s"], 16) < 1 << 256]
+    assert len(vs) > 60
+    ids = np.array([ctx.key_register(_h32(v["qx"]), _h32(v["qy"])) for v in vs], dtype=np.uint32)
+    bits, st = ctx.p256_verify_batch_keyed(ids, *[_arr([_h32(v[k]) for v in vs]) for k in ("e", "r", "s")])
+    for v, b, s in zip(vs, bits, st):
+        assert s == v["status"] and b == (v["status"] == 0), v["name"]
+    # off-curve keys are refused at registration (the KeyImport gate), unknown ids come back as status 4, never as a verdict
+    off = [v for v in _load("edge_kats.json") if not po.on_curve(int(v["qx"], 16), int(v["qy"], 16)) and int(v["qx"], 16) < 1 << 256 and int(v["qy"], 16) < 1 << 256]
+    assert off
+    for v in off:
+        with pytest.raises(fabgpu.FabgpuError):
+            ctx.key_register(_h32(v["qx"]), _h32(v["qy"]))
+    b = coracle.make_batch(5, seed=9)
+    kid = ctx.key_register(b["qx"][0].tobytes(), b["qy"][0].tobytes())
+    bits, st = ctx.p256_verify_batch_keyed(np.array([kid, 0xFFFFFFF0, kid + 100000], dtype=np.uint32), b["e"][:3], b["r"][:3], b["s"][:3])
+    assert list(st) == [0, 4, 4] and list(bits) == [True, False, False]
+
+
 # ---- SHA-256 ----------------------------------------------------------------------------------------
 def test_sha256_like_reference_TestSHA(ctx):
     rng = np.random.default_rng(5)

@@ -276,6 +276,19 @@ def test_verify_core_headers_random_vs_oracle(core_fn):
     assert (st == coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])).all()
 
 
+def test_keyed_core_headers_vs_oracle(hosttest):
+    """p256_verify_keyed_core29 (registered public key: both scalar multiplications on comb tables) on the CPU."""
+    b = coracle.make_pool_batch(400, seed=31, nkeys=3, invalid_frac=0.25)
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    want = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
+    for j in range(3):
+        m = b["key_index"] == j
+        e, r, s = (np.ascontiguousarray(b[k][m]) for k in ("e", "r", "s"))
+        st = np.zeros(int(m.sum()), np.uint8)
+        hosttest.hosttest_verify_keyed_core29(ctypes.c_size_t(int(m.sum())), p(b["pool_qx"][j]), p(b["pool_qy"][j]), p(e), p(r), p(s), p(st))
+        assert (st == want[m]).all()
+
+
 def test_synth_generator_is_checked_by_independent_implementations():
     b = fabgpu.synth_batch(800, seed=20260921, invalid_permille=200, threads=4)
     assert (fabgpu.synth_batch(800, seed=20260921, invalid_permille=200, threads=1)["s"] == b["s"]).all()  # thread-count independent
