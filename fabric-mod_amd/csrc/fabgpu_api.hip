@@ -356,6 +356,29 @@ int fabgpu_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* ke
     return hip_to_rc(err);
 }
 
+int fabgpu_sha256_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
+                                              const void* key_id, const void* r, const void* s, void* verdict_bits, void* status, void* stream) {
+    if (!ctx || (n && (!arena || !off || !key_id || !r || !s || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0xFFFFFFF0ull || arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    uint32_t nkeys;
+    const int32_t** kt;
+    {
+        std::lock_guard<std::mutex> lk(ctx->kmu);
+        nkeys = (uint32_t)ctx->ktabs.size();
+        kt = ctx->d_ktabs;
+    }
+    if (nkeys == 0) return FABGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipEventRecord(ctx->ev0, st);
+    hipError_t err = launch_sha256_p256_verify_keyed((uint32_t)n, arena, arena_bytes, off, key_id, nkeys, (const void*)kt, r, s, ctx->d_gtab, verdict_bits,
+                                                     status, ctx->allow_pair, st);
+    hipEventRecord(ctx->ev1, st);
+    ctx->timed = true;
+    return hip_to_rc(err);
+}
+
 // ---- host-pointer entry points (what the cgo provider binds) -----------------------------------------
 int fabgpu_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r,
                              const uint8_t* s, uint64_t* verdict_bits, uint8_t* status) {
@@ -475,6 +498,37 @@ int fabgpu_sha256_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* ar
     if (err != hipSuccess) return hip_to_rc(err);
     rc = fabgpu_sha256_p256_verify_batch_dev(ctx, n, ctx->arena.d, ab, ctx->offs.d, d, d + fb, d + 2 * fb, d + 3 * fb, dout,
                                              status ? dout + st_off : nullptr, ctx->stream);
+    if (rc) return rc;
+    err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    memcpy(verdict_bits, ctx->out.h, words * 8);
+    if (status) memcpy(status, (uint8_t*)ctx->out.h + st_off, n);
+    return FABGPU_OK;
+}
+
+int fabgpu_sha256_p256_verify_batch_keyed(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off, const uint32_t* key_id,
+                                          const uint8_t* r, const uint8_t* s, uint64_t* verdict_bits, uint8_t* status) {
+    if (!ctx || (n && (!off || !key_id || !r || !s || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    if (!arena && off[n] != off[0]) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    size_t ab = 0;
+    int rc = stage_messages(ctx, n, arena, off, &ab);
+    if (rc) return rc;
+    const size_t fb = n * 32, kb = round_up(n * 4, 64), words = (n + 63) / 64;
+    const size_t st_off = round_up(words * 8, 64);
+    if ((rc = ctx->keyed.ensure(kb + 2 * fb)) || (rc = ctx->out.ensure(st_off + n))) return rc;
+    uint8_t* h = (uint8_t*)ctx->keyed.h;
+    memcpy(h, key_id, n * 4); memcpy(h + kb, r, fb); memcpy(h + kb + fb, s, fb);
+    uint8_t* d = (uint8_t*)ctx->keyed.d;
+    uint8_t* dout = (uint8_t*)ctx->out.d;
+    hipError_t err = hipMemcpyAsync(d, h, kb + 2 * fb, hipMemcpyHostToDevice, ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    rc = fabgpu_sha256_p256_verify_batch_keyed_dev(ctx, n, ctx->arena.d, ab, ctx->offs.d, d, d + kb, d + kb + fb, dout,
+                                                   status ? dout + st_off : nullptr, ctx->stream);
     if (rc) return rc;
     err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);

@@ -27,4 +27,7 @@ hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena
                                      void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
 hipError_t launch_p256_verify_keyed(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* e, const void* r, const void* s,
                                     const void* gtab, void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
+hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* key_id, uint32_t nkeys,
+                                           const void* ktabs, const void* r, const void* s, const void* gtab, void* verdict_bits, void* status,
+                                           bool allow_pair, hipStream_t st);
 }  // namespace fab

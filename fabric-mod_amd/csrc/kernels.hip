@@ -292,6 +292,69 @@ __global__ void __launch_bounds__(BLOCK, 1) p256_verify_keyed_pair_kernel(uint32
     }
 }
 
+// identity.Verify fused, registered keys: SHA-256 then the keyed core; the digest stays in registers.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                                                 const uint32_t* __restrict__ off, const uint32_t* __restrict__ key_id,
+                                                                                 uint32_t nkeys, const int32_t* const* __restrict__ ktabs,
+                                                                                 const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
+                                                                                 const int32_t* __restrict__ gtab, uint64_t* __restrict__ verdict_bits,
+                                                                                 uint8_t* __restrict__ status) {
+    G8Tab gt{gtab};
+    const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * BLOCK + threadIdx.x;
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        uint32_t start = off[ic], end = off[ic + 1];
+        uint32_t h[8];
+        sha256_lane(arena32, arena_words, start, end - start, active, h);
+        uint32_t kid = key_id[ic];
+        bool kok = kid < nkeys;
+        G8Tab kt{ktabs[kok ? kid : 0]};
+        u256 ve, vr, vs;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];
+        load_be_field(vr, r, ic);
+        load_be_field(vs, s, ic);
+        uint32_t st = p256_verify_keyed_core29(ve, vr, vs, gt, kt);
+        if (!kok) st = ST_OFF_CURVE;
+        emit_verdict(i, active, st, verdict_bits, status);
+    }
+}
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_keyed_pair_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                                                      const uint32_t* __restrict__ off, const uint32_t* __restrict__ key_id,
+                                                                                      uint32_t nkeys, const int32_t* const* __restrict__ ktabs,
+                                                                                      const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
+                                                                                      const int32_t* __restrict__ gtab, uint64_t* __restrict__ verdict_bits,
+                                                                                      uint8_t* __restrict__ status) {
+    constexpr int NP = BLOCK / 2;
+    const bool odd = (threadIdx.x & 1) != 0;
+    const uint32_t pairidx = threadIdx.x >> 1;
+    uint32_t* verdict32 = reinterpret_cast<uint32_t*>(verdict_bits);
+    const uint32_t ntiles = (n + NP - 1) / NP;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * NP + pairidx;
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        uint32_t start = off[ic], end = off[ic + 1];
+        uint32_t h[8];
+        sha256_lane(arena32, arena_words, start, end - start, active, h);
+        uint32_t kid = key_id[ic];
+        bool kok = kid < nkeys;
+        const int32_t* kt = ktabs[kok ? kid : 0];
+        u256 ve, vr, vs;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];
+        load_be_field(vr, r, ic);
+        load_be_field(vs, s, ic);
+        uint32_t st = p256_verify_keyed_pair29(ve, vr, vs, gtab, kt, odd);
+        if (!kok) st = ST_OFF_CURVE;
+        pair_emit_verdict(i, n, active, odd, st, verdict32, status);
+    }
+}
+
 // identity.Verify fused, two lanes per signature: both lanes of a pair hash the (same) message - the hash is 18 % of the
 // stream and does not split across lanes - and keep the digest in registers.
 template <int BLOCK>
@@ -423,6 +486,23 @@ hipError_t launch_p256_verify_keyed(uint32_t n, const void* key_id, uint32_t nke
     else
         hipLaunchKernelGGL(p256_verify_keyed_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
                            (const uint8_t*)e, (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+    return hipGetLastError();
+}
+
+hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* key_id, uint32_t nkeys,
+                                           const void* ktabs, const void* r, const void* s, const void* gtab, void* verdict_bits, void* status,
+                                           bool allow_pair, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    VerifyGeom g = verify_geom(n, allow_pair);
+    dim3 grid(g.wgs), block(g.block);
+    if (g.pair)
+        hipLaunchKernelGGL(sha256_p256_verify_keyed_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena,
+                           (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
+                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+    else
+        hipLaunchKernelGGL(sha256_p256_verify_keyed_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena,
+                           (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
+                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
 

@@ -53,6 +53,7 @@ ABI_SYMBOLS = [
     "fabgpu_p256_verify_batch", "fabgpu_sha256_batch", "fabgpu_sha256_p256_verify_batch",
     "fabgpu_p256_verify_batch_dev", "fabgpu_sha256_batch_dev", "fabgpu_sha256_p256_verify_batch_dev",
     "fabgpu_p256_key_register", "fabgpu_p256_key_count", "fabgpu_p256_verify_batch_keyed", "fabgpu_p256_verify_batch_keyed_dev",
+    "fabgpu_sha256_p256_verify_batch_keyed", "fabgpu_sha256_p256_verify_batch_keyed_dev",
     "fabgpu_last_kernel_ms", "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_hash", "fabgpu_csp_verify",
@@ -90,6 +91,8 @@ def load():
     L.fabgpu_p256_key_count.argtypes = [_vp]
     L.fabgpu_p256_verify_batch_keyed.argtypes = [_vp, _sz, _u32p, _u8p, _u8p, _u8p, _u64p, _u8p]
     L.fabgpu_p256_verify_batch_keyed_dev.argtypes = [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.fabgpu_sha256_p256_verify_batch_keyed.argtypes = [_vp, _sz, _u8p, _u32p, _u32p, _u8p, _u8p, _u64p, _u8p]
+    L.fabgpu_sha256_p256_verify_batch_keyed_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.fabgpu_last_kernel_ms.argtypes = [_vp]
     L.fabgpu_last_kernel_ms.restype = ctypes.c_float
     L.fabgpu_ecdsa_unmarshal_signature.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
@@ -258,6 +261,22 @@ class Context:
         _check(self._L.fabgpu_p256_verify_batch_keyed(self._h, n, key_id.ctypes.data_as(_u32p), _p8(e), _p8(r), _p8(s),
                                                        bits.ctypes.data_as(_u64p), _p8(st)), "fabgpu_p256_verify_batch_keyed")
         return unpack_bits(bits, n), st
+
+    def sha256_p256_verify_batch_keyed(self, arena, off, key_id, r, s, want_status=True):
+        arena, r, s = map(_a8, (arena, r, s))
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        key_id = np.ascontiguousarray(key_id, dtype=np.uint32)
+        n = off.size - 1
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.uint8) if want_status else None
+        _check(self._L.fabgpu_sha256_p256_verify_batch_keyed(self._h, n, _p8(arena), off.ctypes.data_as(_u32p), key_id.ctypes.data_as(_u32p),
+                                                              _p8(r), _p8(s), bits.ctypes.data_as(_u64p), _p8(st)),
+               "fabgpu_sha256_p256_verify_batch_keyed")
+        return unpack_bits(bits, n), st
+
+    def sha256_p256_verify_batch_keyed_dev(self, n, arena, arena_bytes, off, key_id, r, s, verdict_bits, status, stream=0):
+        _check(self._L.fabgpu_sha256_p256_verify_batch_keyed_dev(self._h, n, arena, arena_bytes, off, key_id, r, s, verdict_bits,
+                                                                  status or None, stream or None), "fabgpu_sha256_p256_verify_batch_keyed_dev")
 
     def p256_verify_batch_keyed_dev(self, n, key_id, e, r, s, verdict_bits, status, stream=0):
         _check(self._L.fabgpu_p256_verify_batch_keyed_dev(self._h, n, key_id, e, r, s, verdict_bits, status or None, stream or None),

@@ -120,6 +120,12 @@ int fabgpu_p256_verify_batch_keyed(fabgpu_ctx* ctx, size_t n, const uint32_t* ke
                                    const uint8_t* s, uint64_t* verdict_bits, uint8_t* status);
 int fabgpu_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* key_id, const void* e, const void* r, const void* s,
                                        void* verdict_bits, void* status, void* stream);
+/* identity.Verify (msp/identities.go:169-196) for registered keys: SHA-256 fused ahead of the keyed verify. */
+int fabgpu_sha256_p256_verify_batch_keyed(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off, const uint32_t* key_id,
+                                          const uint8_t* r, const uint8_t* s, uint64_t* verdict_bits, uint8_t* status);
+int fabgpu_sha256_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
+                                              const void* key_id, const void* r, const void* s, void* verdict_bits, void* status,
+                                              void* stream);
 
 /* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
  * launch stream (bench.py's roofline leg).  <0 if nothing was launched or events are pending. */

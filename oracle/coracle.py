@@ -150,7 +150,7 @@ def make_batch(n, seed, invalid_frac=0.0, digests=None):
     return dict(qx=qx, qy=qy, e=e, r=r, s=s, kind=kind)
 
 
-def make_pool_batch(n, seed, nkeys=16, invalid_frac=0.0):
+def make_pool_batch(n, seed, nkeys=16, invalid_frac=0.0, digests=None):
     """Like make_batch, but the signers are drawn from a pool of `nkeys` keypairs (the realistic Fabric shape: few distinct
     endorsers per block).  Adds key_index (n, into the pool) and pool_qx / pool_qy (nkeys x 32).
     Invalid mix: flipped digest bit / signature by another pool key / high-S mirror / r+1."""
@@ -164,7 +164,7 @@ def make_pool_batch(n, seed, nkeys=16, invalid_frac=0.0):
     dpool = scalars(nkeys)
     key_index = rng.integers(0, nkeys, size=n).astype(np.uint32)
     d, k = dpool[key_index], scalars(n)
-    e = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    e = rng.integers(0, 256, size=(n, 32), dtype=np.uint8) if digests is None else _c(digests).copy()
     qx = np.zeros((n, 32), np.uint8); qy = np.zeros((n, 32), np.uint8)
     r = np.zeros((n, 32), np.uint8); s = np.zeros((n, 32), np.uint8)
     lib().oracle_p256_make_batch(ctypes.c_size_t(n), _p(np.ascontiguousarray(d)), _p(k), _p(e), _p(qx), _p(qy), _p(r), _p(s))

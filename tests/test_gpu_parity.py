@@ -154,6 +154,21 @@ def test_registered_keys_every_signer_its_own_key_edge_vectors_and_bad_ids(ctx):
     assert list(st) == [0, 4, 4] and list(bits) == [True, False, False]
 
 
+def test_registered_keys_fused_hash_verify_vs_oracle(ctx):
+    n = 3000
+    rng = np.random.default_rng(18)
+    lens = rng.integers(0, 2500, size=n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    arena = rng.integers(0, 256, size=int(off[-1]) + 1, dtype=np.uint8)
+    b = coracle.make_pool_batch(n, seed=19, nkeys=8, invalid_frac=0.2, digests=coracle.sha256_batch(arena, off))
+    ids = np.array([ctx.key_register(b["pool_qx"][j].tobytes(), b["pool_qy"][j].tobytes()) for j in range(8)], dtype=np.uint32)
+    bits, st = ctx.sha256_p256_verify_batch_keyed(arena, off, ids[b["key_index"]], b["r"], b["s"])
+    want = coracle.sha256_verify_batch(arena, off, b["qx"], b["qy"], b["r"], b["s"])
+    assert (st == want).all() and (bits == (want == 0)).all()
+    bits2, st2 = ctx.sha256_p256_verify_batch(arena, off, b["qx"], b["qy"], b["r"], b["s"])
+    assert (st2 == st).all() and (bits2 == bits).all()
+
+
 # ---- SHA-256 ----------------------------------------------------------------------------------------
 def test_sha256_like_reference_TestSHA(ctx):
     rng = np.random.default_rng(5)
