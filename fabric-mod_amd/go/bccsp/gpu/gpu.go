@@ -48,6 +48,7 @@ type gpuPublicKey struct {
 	bccsp.Key // the sw key (SKI, Bytes, ...)
 	pub       *ecdsa.PublicKey
 	onCurve   bool
+	keyID     int64 // fabgpu_p256_key_register id of this key's comb table on the device, -1 = none
 }
 
 // New is what bccsp/factory would call for ProviderName "GPU" (see INTEGRATION.md).
@@ -78,7 +79,18 @@ func (csp *impl) KeyImport(raw interface{}, opts bccsp.KeyImportOpts) (bccsp.Key
 	if pub == nil || pub.Curve != elliptic.P256() {
 		return k, nil // not ours: sw handles it
 	}
-	return &gpuPublicKey{Key: k, pub: pub, onCurve: pub.Curve.IsOnCurve(pub.X, pub.Y)}, nil
+	gk := &gpuPublicKey{Key: k, pub: pub, onCurve: pub.Curve.IsOnCurve(pub.X, pub.Y), keyID: -1}
+	if gk.onCurve {
+		// Long-lived identities (endorsers, orderers: msp/cache/cache.go:14-18 keeps 100 of them) get a comb table on the
+		// device, ~6 ms once per key; their signatures then verify without doublings.  Failure (table memory exhausted)
+		// just leaves keyID = -1: the fresh-key kernels are used.
+		qx, qy := be32(pub.X), be32(pub.Y)
+		var id C.uint32_t
+		if rc := C.fabgpu_p256_key_register(csp.ctx, (*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])), &id); rc == 0 {
+			gk.keyID = int64(id)
+		}
+	}
+	return gk, nil
 }
 
 func be32(v *big.Int) []byte { b := make([]byte, 32); v.FillBytes(b); return b } // Go >= 1.15; 1.14: pad v.Bytes()
@@ -149,6 +161,8 @@ func (csp *impl) PreVerifyBlock(tuples []Tuple) error {
 		return nil
 	}
 	qx, qy, rr, ss := make([]byte, 32*n), make([]byte, 32*n), make([]byte, 32*n), make([]byte, 32*n)
+	ids := make([]uint32, n) // key ids; the keyed launch is used when every kept tuple has one
+	allKeyed := true
 	off := make([]uint32, n+1)
 	var arena []byte
 	keep := make([]bool, n)
@@ -165,6 +179,11 @@ func (csp *impl) PreVerifyBlock(tuples []Tuple) error {
 			continue
 		}
 		keep[i] = true
+		if gk.keyID >= 0 {
+			ids[i] = uint32(gk.keyID)
+		} else {
+			allKeyed = false
+		}
 		arena = append(arena, t.Msg...)
 		copy(qx[32*i:], be32(gk.pub.X)); copy(qy[32*i:], be32(gk.pub.Y)); copy(rr[32*i:], be32(r)); copy(ss[32*i:], be32(s))
 	}
@@ -172,9 +191,16 @@ func (csp *impl) PreVerifyBlock(tuples []Tuple) error {
 	arena = append(arena, 0)
 	bits := make([]uint64, (n+63)/64)
 	st := make([]uint8, n)
-	rc := C.fabgpu_sha256_p256_verify_batch(csp.ctx, C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&arena[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])),
-		(*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])), (*C.uint8_t)(unsafe.Pointer(&rr[0])),
-		(*C.uint8_t)(unsafe.Pointer(&ss[0])), (*C.uint64_t)(unsafe.Pointer(&bits[0])), (*C.uint8_t)(unsafe.Pointer(&st[0])))
+	var rc C.int
+	if allKeyed { // fillers carry id 0 (any registered key) and r = s = 1: their verdict is ignored (keep[i] == false)
+		rc = C.fabgpu_sha256_p256_verify_batch_keyed(csp.ctx, C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&arena[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])),
+			(*C.uint32_t)(unsafe.Pointer(&ids[0])), (*C.uint8_t)(unsafe.Pointer(&rr[0])), (*C.uint8_t)(unsafe.Pointer(&ss[0])),
+			(*C.uint64_t)(unsafe.Pointer(&bits[0])), (*C.uint8_t)(unsafe.Pointer(&st[0])))
+	} else {
+		rc = C.fabgpu_sha256_p256_verify_batch(csp.ctx, C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&arena[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])),
+			(*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])), (*C.uint8_t)(unsafe.Pointer(&rr[0])),
+			(*C.uint8_t)(unsafe.Pointer(&ss[0])), (*C.uint64_t)(unsafe.Pointer(&bits[0])), (*C.uint8_t)(unsafe.Pointer(&st[0])))
+	}
 	if rc != 0 {
 		return errors.Errorf("fabgpu: %s", C.GoString(C.fabgpu_strerror(rc))) // caller ignores: validators then use sw via Verify
 	}
