@@ -39,6 +39,15 @@ int fabgpu_csp_new(const fabgpu_cfg* cfg, fabgpu_csp** out, char* err, size_t er
 void fabgpu_csp_free(fabgpu_csp* csp) { delete csp; }
 fabgpu_ctx* fabgpu_csp_ctx(fabgpu_csp* csp) { return csp ? csp->csp->ctx() : nullptr; }
 
+int fabgpu_csp_key_import(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, int* on_curve, char* err, size_t errcap) {
+    if (!csp) return FABGPU_EINVAL;
+    ECDSAPublicKey k;
+    Error e = csp->csp->KeyImport(qx32, qy32, k, true);
+    put_err(err, errcap, e.ok() ? "" : e.msg);
+    if (on_curve) *on_curve = k.on_curve ? 1 : 0;
+    return FABGPU_OK;
+}
+
 int fabgpu_csp_hash(fabgpu_csp* csp, const uint8_t* msg, size_t len, const char* alg, uint8_t* digest32, char* err, size_t errcap) {
     if (!csp || !digest32) return FABGPU_EINVAL;
     HashOpts o;

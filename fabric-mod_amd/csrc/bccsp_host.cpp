@@ -195,12 +195,35 @@ Error GPUCSP::New(const fabgpu_cfg* cfg, std::unique_ptr<GPUCSP>& out) {
 GPUCSP::~GPUCSP() { fabgpu_shutdown(ctx_); }
 
 // bccsp/sw/keyimport.go:103-112 (ECDSAGoPublicKeyImportOpts) with the curve check x509 parsing implies
-Error GPUCSP::KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out) const {
+Error GPUCSP::KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out, bool device_table) const {
     if (!qx32 || !qy32) return Error("Invalid raw. It must not be nil.");
     memcpy(out.x, qx32, 32);
     memcpy(out.y, qy32, 32);
     out.on_curve = PublicKeyOnCurve(qx32, qy32);
+    // a long-lived identity's key gets its comb table on the device (best effort: on failure the fresh-key kernels serve it)
+    if (out.on_curve && device_table) {
+        uint32_t id = 0;
+        (void)fabgpu_p256_key_register(ctx_, qx32, qy32, &id);
+    }
     return Error();
+}
+
+// key ids of the submitted items if EVERY submitted item's key is registered (then the keyed kernels apply)
+static bool all_registered(fabgpu_ctx* ctx, size_t n, const std::vector<uint8_t>& submitted, const uint8_t* qx, const uint8_t* qy,
+                           std::vector<uint32_t>& ids) {
+    ids.assign(n, 0);
+    uint32_t any = 0;
+    bool have = false;
+    for (size_t i = 0; i < n; i++) {
+        if (!submitted[i]) continue;
+        if (fabgpu_p256_key_lookup(ctx, qx + 32 * i, qy + 32 * i, &ids[i]) != FABGPU_OK) return false;
+        any = ids[i];
+        have = true;
+    }
+    if (!have) return false;
+    for (size_t i = 0; i < n; i++)
+        if (!submitted[i]) ids[i] = any;   // fillers: any registered key, the verdict is ignored
+    return true;
 }
 
 // bccsp/sw/impl.go:177-194
@@ -276,7 +299,10 @@ Error GPUCSP::VerifyBatch(const std::vector<VerifyItem>& items, std::vector<Veri
         memcpy(&s[32 * i], g.s32, 32);
     }
     if (n == 0) return Error();
-    int rc = fabgpu_p256_verify_batch(ctx_, n, qx.data(), qy.data(), e.data(), r.data(), s.data(), bits.data(), st.data());
+    std::vector<uint32_t> ids;
+    int rc = all_registered(ctx_, n, submitted, qx.data(), qy.data(), ids)
+                 ? fabgpu_p256_verify_batch_keyed(ctx_, n, ids.data(), e.data(), r.data(), s.data(), bits.data(), st.data())
+                 : fabgpu_p256_verify_batch(ctx_, n, qx.data(), qy.data(), e.data(), r.data(), s.data(), bits.data(), st.data());
     if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
     for (size_t i = 0; i < n; i++) {
         if (!submitted[i]) continue;
@@ -337,7 +363,10 @@ Error GPUCSP::IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::v
         memcpy(&s[32 * i], g.s32, 32);
     }
     off[n] = (uint32_t)arena.size();
-    int rc = fabgpu_sha256_p256_verify_batch(ctx_, n, arena.data(), off.data(), qx.data(), qy.data(), r.data(), s.data(), bits.data(), st.data());
+    std::vector<uint32_t> ids;
+    int rc = all_registered(ctx_, n, submitted, qx.data(), qy.data(), ids)
+                 ? fabgpu_sha256_p256_verify_batch_keyed(ctx_, n, arena.data(), off.data(), ids.data(), r.data(), s.data(), bits.data(), st.data())
+                 : fabgpu_sha256_p256_verify_batch(ctx_, n, arena.data(), off.data(), qx.data(), qy.data(), r.data(), s.data(), bits.data(), st.data());
     if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
     for (size_t i = 0; i < n; i++) {
         if (!submitted[i]) continue;

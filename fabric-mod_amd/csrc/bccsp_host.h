@@ -72,7 +72,9 @@ class GPUCSP {
    public:
     static Error New(const fabgpu_cfg* cfg, std::unique_ptr<GPUCSP>& out);
     ~GPUCSP();
-    Error KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out) const;
+    // device_table: also build the key's comb table on the device (fabgpu_p256_key_register) - what the provider does for a
+    // key imported through BCCSP.KeyImport; false for keys merely unmarshalled from a flat batch.
+    Error KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out, bool device_table = false) const;
     Error Hash(const uint8_t* msg, size_t len, const HashOpts* opts, std::vector<uint8_t>& digest) const;
     VerifyResult Verify(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) const;
     Error VerifyBatch(const std::vector<VerifyItem>& items, std::vector<VerifyResult>& results) const;

@@ -328,6 +328,17 @@ int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t
     return FABGPU_OK;
 }
 
+int fabgpu_p256_key_lookup(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
+    if (!ctx || !qx32 || !qy32 || !key_id) return FABGPU_EINVAL;
+    std::string k((const char*)qx32, 32);
+    k.append((const char*)qy32, 32);
+    std::lock_guard<std::mutex> lk(ctx->kmu);
+    auto it = ctx->key_ids.find(k);
+    if (it == ctx->key_ids.end()) return 1;
+    *key_id = it->second;
+    return FABGPU_OK;
+}
+
 int fabgpu_p256_key_count(fabgpu_ctx* ctx) {
     if (!ctx) return FABGPU_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->kmu);

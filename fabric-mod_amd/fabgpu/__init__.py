@@ -52,11 +52,11 @@ ABI_SYMBOLS = [
     "fabgpu_init", "fabgpu_shutdown", "fabgpu_device_count", "fabgpu_strerror", "fabgpu_abi_version",
     "fabgpu_p256_verify_batch", "fabgpu_sha256_batch", "fabgpu_sha256_p256_verify_batch",
     "fabgpu_p256_verify_batch_dev", "fabgpu_sha256_batch_dev", "fabgpu_sha256_p256_verify_batch_dev",
-    "fabgpu_p256_key_register", "fabgpu_p256_key_count", "fabgpu_p256_verify_batch_keyed", "fabgpu_p256_verify_batch_keyed_dev",
+    "fabgpu_p256_key_register", "fabgpu_p256_key_lookup", "fabgpu_p256_key_count", "fabgpu_p256_verify_batch_keyed", "fabgpu_p256_verify_batch_keyed_dev",
     "fabgpu_sha256_p256_verify_batch_keyed", "fabgpu_sha256_p256_verify_batch_keyed_dev",
     "fabgpu_last_kernel_ms", "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
-    "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_hash", "fabgpu_csp_verify",
+    "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_synth_batch",
 ]
 
@@ -88,6 +88,7 @@ def load():
     L.fabgpu_sha256_batch_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp]
     L.fabgpu_sha256_p256_verify_batch_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.fabgpu_p256_key_register.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, _u32p]
+    L.fabgpu_p256_key_lookup.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, _u32p]
     L.fabgpu_p256_key_count.argtypes = [_vp]
     L.fabgpu_p256_verify_batch_keyed.argtypes = [_vp, _sz, _u32p, _u8p, _u8p, _u8p, _u64p, _u8p]
     L.fabgpu_p256_verify_batch_keyed_dev.argtypes = [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -105,6 +106,7 @@ def load():
     L.fabgpu_csp_free.restype = None
     L.fabgpu_csp_ctx.argtypes = [_vp]
     L.fabgpu_csp_ctx.restype = _vp
+    L.fabgpu_csp_key_import.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
     L.fabgpu_csp_hash.argtypes = [_vp, ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz]
     L.fabgpu_csp_verify.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz,
                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
@@ -332,11 +334,19 @@ class GPUCSP:
         except Exception:
             pass
 
+    def key_count(self) -> int:
+        """Number of public keys whose comb table is resident on the device."""
+        return self._L.fabgpu_p256_key_count(self._L.fabgpu_csp_ctx(self._h))
+
     def key_import(self, raw, opts=None) -> ECDSAPublicKey:
         """KeyImport(raw, &bccsp.ECDSAGoPublicKeyImportOpts{}) (bccsp/sw/keyimport.go:103-112): raw = (X, Y)."""
         if raw is None:
             raise BCCSPError("Invalid raw. It must not be nil.")
-        return ECDSAPublicKey(int(raw[0]), int(raw[1]))
+        k = ECDSAPublicKey(int(raw[0]), int(raw[1]))
+        if 0 <= k.x < 1 << 256 and 0 <= k.y < 1 << 256:      # the provider registers the key's comb table on the device
+            err = ctypes.create_string_buffer(256)
+            _check(self._L.fabgpu_csp_key_import(self._h, k.x.to_bytes(32, "big"), k.y.to_bytes(32, "big"), None, err, 256), "fabgpu_csp_key_import")
+        return k
 
     def hash(self, msg: Optional[bytes], opts) -> bytes:
         """CSP.Hash (bccsp/sw/impl.go:177-194)."""

@@ -115,6 +115,7 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
  * yields status 4 for that tuple. */
 #define FABGPU_MAX_KEYS 4096
 int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id);
+int fabgpu_p256_key_lookup(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id); /* 0 found, 1 not registered */
 int fabgpu_p256_key_count(fabgpu_ctx* ctx);
 int fabgpu_p256_verify_batch_keyed(fabgpu_ctx* ctx, size_t n, const uint32_t* key_id, const uint8_t* e, const uint8_t* r,
                                    const uint8_t* s, uint64_t* verdict_bits, uint8_t* status);

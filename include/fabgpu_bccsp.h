@@ -21,6 +21,11 @@ int fabgpu_csp_new(const fabgpu_cfg* cfg, fabgpu_csp** out, char* err, size_t er
 void fabgpu_csp_free(fabgpu_csp* csp);
 fabgpu_ctx* fabgpu_csp_ctx(fabgpu_csp* csp);
 
+/* BCCSP.KeyImport for a P-256 public key (bccsp/sw/keyimport.go:103-134; pattern bccsp/pkcs11/pkcs11.go:148-179): checks
+ * curve membership and registers the key's comb table on the device (fabgpu_p256_key_register), so that batches whose
+ * signers were all imported this way run on the keyed kernels.  err: "" or the Go error text. */
+int fabgpu_csp_key_import(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, int* on_curve, char* err, size_t errcap);
+
 /* alg == NULL mirrors opts == nil. */
 int fabgpu_csp_hash(fabgpu_csp* csp, const uint8_t* msg, size_t len, const char* alg, uint8_t* digest32, char* err, size_t errcap);
 

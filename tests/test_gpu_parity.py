@@ -347,6 +347,20 @@ def test_block_endorsement_prepass(csp):
             ends.append((ident, pk, po.marshal_ecdsa_signature(r, s)))
         txs.append((prp, ends)); want.append(ok)
     assert (fabgpu.validate_block_endorsements(csp, txs) == np.array(want)).all()
+    # the same block once the endorsers came in through BCCSP.KeyImport: every signer is registered, the pass runs on the
+    # keyed fused kernel (fabgpu_sha256_p256_verify_batch_keyed) and must say exactly the same
+    before = csp.key_count()
+    for d, pk, ident in endorsers:
+        csp.key_import((pk.x, pk.y))
+    assert csp.key_count() == before + 4
+    assert (fabgpu.validate_block_endorsements(csp, txs) == np.array(want)).all()
+    # ... and a block with one endorser that was never imported falls back to the fresh-key kernel, same verdicts
+    d5, pk5 = _keypair(77)
+    ident5 = bytes(rng.integers(0, 256, size=832, dtype=np.uint8))
+    prp = bytes(rng.integers(0, 256, size=1024, dtype=np.uint8))
+    r, s = po.sign_raw(d5, hashlib.sha256(prp + ident5).digest(), 12345)
+    txs2 = txs + [(prp, [(ident5, pk5, po.marshal_ecdsa_signature(r, s))])]
+    assert (fabgpu.validate_block_endorsements(csp, txs2) == np.array(want + [True])).all()
 
 
 def test_device_resident_entry_points_on_torch_stream(ctx):
