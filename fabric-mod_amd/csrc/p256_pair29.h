@@ -97,6 +97,81 @@ __device__ __forceinline__ void pair_g8_load(const int32_t* __restrict__ gtab, i
     for (int l = 0; l < 9; l++) xy.v[l] = e[l];
 }
 
+// w = x^-1 mod M on a lane pair (modinv30.h).  The 30 division steps of a batch are computed by both lanes; then the EVEN
+// lane applies the transition matrix to (f, g) and the ODD lane to (d, e) - one update per lane per batch instead of two.
+// Both run the (d, e) update code: for (f, g) the modulus correction is forced to zero (t (f, g) is divisible by 2^30 by
+// construction, so the same shift is exact).  The result is returned on both lanes.
+__device__ __forceinline__ void pair_modinv(u256& out, const u256& x, const modinv_info& mi, bool odd) {
+    s30 a, b;                      // E: (f, g)      O: (d, e)
+    s30 gx;
+    s30_from_u256(gx, x);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        a.v[i] = odd ? 0 : mi.modulus.v[i];
+        b.v[i] = odd ? (i == 0 ? 1 : 0) : gx.v[i];
+    }
+    int32_t zeta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 20; it++) {
+        int32_t fo = pair_swap_i32(a.v[0]), go = pair_swap_i32(b.v[0]);
+        uint32_t f0 = (uint32_t)(odd ? fo : a.v[0]), g0 = (uint32_t)(odd ? go : b.v[0]);
+        trans2x2 t;
+        zeta = modinv_divsteps30(zeta, f0, g0, t);
+        // modinv_update_de with the correction masked off on the even lane
+        int32_t sa = a.v[8] >> 31, sb = b.v[8] >> 31;
+        int32_t ma = (t.u & sa) + (t.v & sb);
+        int32_t mb = (t.q & sa) + (t.r & sb);
+        int64_t ca = (int64_t)t.u * a.v[0] + (int64_t)t.v * b.v[0];
+        int64_t cb = (int64_t)t.q * a.v[0] + (int64_t)t.r * b.v[0];
+        ma -= (int32_t)((mi.inv30 * (uint32_t)ca + (uint32_t)ma) & (uint32_t)MI_M30);
+        mb -= (int32_t)((mi.inv30 * (uint32_t)cb + (uint32_t)mb) & (uint32_t)MI_M30);
+        ma = odd ? ma : 0;
+        mb = odd ? mb : 0;
+        ca += (int64_t)mi.modulus.v[0] * ma;
+        cb += (int64_t)mi.modulus.v[0] * mb;
+        ca >>= 30;
+        cb >>= 30;
+#pragma unroll
+        for (int i = 1; i < 9; i++) {
+            ca += (int64_t)t.u * a.v[i] + (int64_t)t.v * b.v[i] + (int64_t)mi.modulus.v[i] * ma;
+            cb += (int64_t)t.q * a.v[i] + (int64_t)t.r * b.v[i] + (int64_t)mi.modulus.v[i] * mb;
+            a.v[i - 1] = (int32_t)((uint32_t)ca & (uint32_t)MI_M30);
+            b.v[i - 1] = (int32_t)((uint32_t)cb & (uint32_t)MI_M30);
+            ca >>= 30;
+            cb >>= 30;
+        }
+        a.v[8] = (int32_t)ca;
+        b.v[8] = (int32_t)cb;
+    }
+    // E: f = +-1 in a;  O: d in a.  The inverse is d * sign(f): normalise on O, then hand the result to E.
+    int32_t fsign_e = a.v[8] >> 31;
+    int32_t fsign = pair_swap_i32(fsign_e);       // O: sign of f
+    modinv_normalize(a, odd ? fsign : 0, mi);
+    u256 w;
+    s30_to_u256(w, a);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int32_t o = pair_swap_i32((int32_t)w.w[i]);
+        out.w[i] = odd ? w.w[i] : (uint32_t)o;
+    }
+}
+
+// ecdsa_scalars29 with the inversion shared by the pair
+__device__ __forceinline__ void pair_ecdsa_scalars29(u256& u1, u256& u2, const u256& e, const u256& r, const u256& s, bool odd) {
+    const u256 N = FAB_P256_N;
+    u256 w, ered, t;
+    {
+        const modinv_info NI = MODINV_N_INFO;
+        pair_modinv(w, s, NI, odd);
+    }
+    uint32_t br = sub256(t, e, N);
+    sel256(ered, br == 0, t, e);
+    fn_to_mont(t, ered);
+    fn_mul(u1, t, w);
+    fn_to_mont(t, r);
+    fn_mul(u2, t, w);
+}
+
 // S = k * B over an 8-bit comb table of B on a lane pair (comb8_mult29).  seed: any valid point in pair state.
 __device__ __forceinline__ void pair_comb8_mult29(pair_pt& S, bool& s_inf, const u256& k, const int32_t* __restrict__ tab, const pair_pt& seed,
                                                   bool odd) {
@@ -291,7 +366,7 @@ __device__ __forceinline__ uint32_t p256_verify_pair29(const u256& qx, const u25
     if (early == ST_VALID && !q_ok) early = ST_OFF_CURVE;
 
     u256 u1, u2;
-    ecdsa_scalars29(u1, u2, e, r, s);
+    pair_ecdsa_scalars29(u1, u2, e, r, s, odd);
 
     pair_pt Rr;
     bool r_inf;
@@ -306,7 +381,7 @@ __device__ __forceinline__ uint32_t p256_verify_keyed_pair29(const u256& e, cons
                                                               const int32_t* __restrict__ ktab, bool odd) {
     uint32_t early = range_status(r, s);
     u256 u1, u2;
-    ecdsa_scalars29(u1, u2, e, r, s);
+    pair_ecdsa_scalars29(u1, u2, e, r, s, odd);
     pair_pt Rr;
     bool r_inf;
     pair_combined_mult_keyed29(Rr, r_inf, u1, u2, gtab, ktab, odd);
