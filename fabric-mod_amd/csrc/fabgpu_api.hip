@@ -174,10 +174,10 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
-        std::vector<int32_t> tab(G8_TABLE_WORDS);
-        build_g8_comb_table(tab.data());
-        if (hipMalloc((void**)&ctx->d_gtab, sizeof(int32_t) * G8_TABLE_WORDS) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
-        if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(int32_t) * G8_TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
+        std::vector<int32_t> tab(GTab16::TABLE_WORDS);   // 80 MiB, ~0.2 s on 16 host threads
+        build_g_comb_table16(tab.data());
+        if (hipMalloc((void**)&ctx->d_gtab, sizeof(int32_t) * GTab16::TABLE_WORDS) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
+        if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(int32_t) * GTab16::TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
         if (cfg && cfg->max_batch) {
             size_t n = cfg->max_batch;
             if ((rc = ctx->fields.ensure(n * 160)) || (rc = ctx->offs.ensure((n + 1) * 4)) || (rc = ctx->out.ensure(n * 41 + 64))) break;
@@ -296,11 +296,11 @@ int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t
     u256 qx, qy;
     from_be32(qx, qx32);
     from_be32(qy, qy32);
-    std::vector<int32_t> tab(G8_TABLE_WORDS);
-    build_comb8_table(tab.data(), qx, qy);
+    std::vector<int32_t> tab(KeyTab8::TABLE_WORDS);
+    build_key_comb_table8(tab.data(), qx, qy);
     int32_t* d = nullptr;
-    if (hipMalloc((void**)&d, sizeof(int32_t) * G8_TABLE_WORDS) != hipSuccess) return FABGPU_ENOMEM;
-    if (hipMemcpy(d, tab.data(), sizeof(int32_t) * G8_TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc((void**)&d, sizeof(int32_t) * KeyTab8::TABLE_WORDS) != hipSuccess) return FABGPU_ENOMEM;
+    if (hipMemcpy(d, tab.data(), sizeof(int32_t) * KeyTab8::TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) {
         hipFree(d);
         return FABGPU_ELAUNCH;
     }

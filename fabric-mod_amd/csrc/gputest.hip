@@ -90,16 +90,16 @@ __global__ void __launch_bounds__(64, 1) gputest_pair_combined_kernel(const uint
 }
 
 extern "C" int gputest_pair_combined(const uint8_t* in, int32_t* out) {
-    std::vector<int32_t> tab(G8_TABLE_WORDS);
-    build_g8_comb_table(tab.data());
+    std::vector<int32_t> tab(GTab16::TABLE_WORDS);
+    build_g_comb_table16(tab.data());
     uint8_t* din = nullptr;
     int32_t *dtab = nullptr, *dout = nullptr;
     uint4* dws = nullptr;
-    if (hipMalloc((void**)&din, 32 * 128) != hipSuccess || hipMalloc((void**)&dtab, sizeof(int32_t) * G8_TABLE_WORDS) != hipSuccess ||
+    if (hipMalloc((void**)&din, 32 * 128) != hipSuccess || hipMalloc((void**)&dtab, sizeof(int32_t) * GTab16::TABLE_WORDS) != hipSuccess ||
         hipMalloc((void**)&dout, 64 * 19 * 4) != hipSuccess || hipMalloc((void**)&dws, (size_t)16 * 8 * 32 * 16) != hipSuccess)
         return -1;
     hipMemcpy(din, in, 32 * 128, hipMemcpyHostToDevice);
-    hipMemcpy(dtab, tab.data(), sizeof(int32_t) * G8_TABLE_WORDS, hipMemcpyHostToDevice);
+    hipMemcpy(dtab, tab.data(), sizeof(int32_t) * GTab16::TABLE_WORDS, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(gputest_pair_combined_kernel, dim3(1), dim3(64), 0, 0, din, dtab, dws, dout);
     int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
     hipMemcpy(out, dout, 64 * 19 * 4, hipMemcpyDeviceToHost);
@@ -168,16 +168,16 @@ __global__ void __launch_bounds__(64, 1) gputest_pair_verify_kernel(const uint8_
 }
 
 extern "C" int gputest_pair_verify(const uint8_t* in, int32_t* out) {
-    std::vector<int32_t> tab(G8_TABLE_WORDS);
-    build_g8_comb_table(tab.data());
+    std::vector<int32_t> tab(GTab16::TABLE_WORDS);
+    build_g_comb_table16(tab.data());
     uint8_t* din = nullptr;
     int32_t *dtab = nullptr, *dout = nullptr;
     uint4* dws = nullptr;
-    if (hipMalloc((void**)&din, 32 * 160) != hipSuccess || hipMalloc((void**)&dtab, sizeof(int32_t) * G8_TABLE_WORDS) != hipSuccess ||
+    if (hipMalloc((void**)&din, 32 * 160) != hipSuccess || hipMalloc((void**)&dtab, sizeof(int32_t) * GTab16::TABLE_WORDS) != hipSuccess ||
         hipMalloc((void**)&dout, 64 * 48 * 4) != hipSuccess || hipMalloc((void**)&dws, (size_t)16 * 8 * 32 * 16) != hipSuccess)
         return -1;
     hipMemcpy(din, in, 32 * 160, hipMemcpyHostToDevice);
-    hipMemcpy(dtab, tab.data(), sizeof(int32_t) * G8_TABLE_WORDS, hipMemcpyHostToDevice);
+    hipMemcpy(dtab, tab.data(), sizeof(int32_t) * GTab16::TABLE_WORDS, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(gputest_pair_verify_kernel, dim3(1), dim3(64), 0, 0, din, dtab, dws, dout);
     int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
     hipMemcpy(out, dout, 64 * 48 * 4, hipMemcpyDeviceToHost);

@@ -17,7 +17,7 @@ static const uint32_t* gtab() {
 }
 
 static const int32_t* gtab29() {
-    static std::vector<int32_t> tab = [] { std::vector<int32_t> t(G8_TABLE_WORDS); build_g8_comb_table(t.data()); return t; }();
+    static std::vector<int32_t> tab = [] { std::vector<int32_t> t(GTab16::TABLE_WORDS); build_g_comb_table16(t.data()); return t; }();
     return tab.data();
 }
 
@@ -54,7 +54,7 @@ void hosttest_modinv(int which, const uint8_t* a32, uint8_t* out32) {
     to_be32(out32, r);
 }
 void hosttest_gtab29_entry(int window, int digit, uint8_t* x32, uint8_t* y32) {
-    G8Tab gt{gtab29()};
+    GTab16 gt{gtab29()};
     fe x, y;
     u256 px, py;
     gt.load(window, (uint32_t)digit, x, y);
@@ -65,7 +65,7 @@ void hosttest_gtab29_entry(int window, int digit, uint8_t* x32, uint8_t* y32) {
 }
 // R = u1*G + u2*Q through the kernel's CombinedMult (arbitrary scalars < n, u2 != 0): affine x, y out; returns 1 for infinity
 int hosttest_combined_mult29(const uint8_t* u1_32, const uint8_t* u2_32, const uint8_t* qx32, const uint8_t* qy32, uint8_t* x32, uint8_t* y32) {
-    G8Tab gt{gtab29()};
+    GTab16 gt{gtab29()};
     const fe ONE = {FE29_R1};
     u256 u1, u2, qx, qy;
     from_be32(u1, u1_32); from_be32(u2, u2_32); from_be32(qx, qx32); from_be32(qy, qy32);
@@ -98,13 +98,13 @@ int hosttest_combined_mult29(const uint8_t* u1_32, const uint8_t* u2_32, const u
 // the keyed core (registered public key: comb table of Q built like the device would) on the CPU
 void hosttest_verify_keyed_core29(size_t n, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* e, const uint8_t* r, const uint8_t* s,
                                   uint8_t* status) {
-    G8Tab gt{gtab29()};
+    GTab16 gt{gtab29()};
     u256 qx, qy;
     from_be32(qx, qx32);
     from_be32(qy, qy32);
-    std::vector<int32_t> kt(G8_TABLE_WORDS);
-    build_comb8_table(kt.data(), qx, qy);
-    G8Tab kk{kt.data()};
+    std::vector<int32_t> kt(KeyTab8::TABLE_WORDS);
+    build_key_comb_table8(kt.data(), qx, qy);
+    KeyTab8 kk{kt.data()};
     for (size_t i = 0; i < n; i++) {
         u256 ve, vr, vs;
         from_be32(ve, e + 32 * i); from_be32(vr, r + 32 * i); from_be32(vs, s + 32 * i);
@@ -113,7 +113,7 @@ void hosttest_verify_keyed_core29(size_t n, const uint8_t* qx32, const uint8_t* 
 }
 void hosttest_verify_core29(size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r, const uint8_t* s,
                             uint8_t* status) {
-    G8Tab gt{gtab29()};
+    GTab16 gt{gtab29()};
     for (size_t i = 0; i < n; i++) {
         u256 vqx, vqy, ve, vr, vs;
         from_be32(vqx, qx + 32 * i); from_be32(vqy, qy + 32 * i); from_be32(ve, e + 32 * i);

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(BLOCK, 2) p256_verify_kernel(uint32_t n, const
                                                                     uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
                                                                     uint8_t* __restrict__ status) {
     GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
-    G8Tab gt{gtab};
+    GTab16 gt{gtab};
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(BLOCK, 2) p256_verify_keyed_kernel(uint32_t n,
                                                                           const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                                                                           const int32_t* __restrict__ gtab, uint64_t* __restrict__ verdict_bits,
                                                                           uint8_t* __restrict__ status) {
-    G8Tab gt{gtab};
+    GTab16 gt{gtab};
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(BLOCK, 2) p256_verify_keyed_kernel(uint32_t n,
         uint32_t ic = active ? i : (n - 1);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
-        G8Tab kt{ktabs[kok ? kid : 0]};
+        KeyTab8 kt{ktabs[kok ? kid : 0]};
         u256 ve, vr, vs;
         load_be_field(ve, e, ic);
         load_be_field(vr, r, ic);
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_kernel(uint
                                                                                  const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                                                                                  const int32_t* __restrict__ gtab, uint64_t* __restrict__ verdict_bits,
                                                                                  uint8_t* __restrict__ status) {
-    G8Tab gt{gtab};
+    GTab16 gt{gtab};
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_kernel(uint
         sha256_lane(arena32, arena_words, start, end - start, active, h);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
-        G8Tab kt{ktabs[kok ? kid : 0]};
+        KeyTab8 kt{ktabs[kok ? kid : 0]};
         u256 ve, vr, vs;
 #pragma unroll
         for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n
                                                                            uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
                                                                            uint8_t* __restrict__ status) {
     GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
-    G8Tab gt{gtab};
+    GTab16 gt{gtab};
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;

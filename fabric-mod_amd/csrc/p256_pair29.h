@@ -91,8 +91,9 @@ struct PairQTab {
 };
 
 // E gets x2, O gets y2 of comb entry (window, digit) in the SAME nine registers (they are passed as both C and D of PAIR_MADD)
-__device__ __forceinline__ void pair_g8_load(const int32_t* __restrict__ gtab, int window, uint32_t digit, bool odd, fe& xy) {
-    const int32_t* e = gtab + g8_index(window, digit) + (odd ? 9 : 0);
+template <class Tab>
+__device__ __forceinline__ void pair_comb_load(const int32_t* __restrict__ tab, int window, uint32_t digit, bool odd, fe& xy) {
+    const int32_t* e = tab + Tab::index(window, digit) + (odd ? 9 : 0);
 #pragma unroll
     for (int l = 0; l < 9; l++) xy.v[l] = e[l];
 }
@@ -172,23 +173,24 @@ __device__ __forceinline__ void pair_ecdsa_scalars29(u256& u1, u256& u2, const u
     fn_mul(u2, t, w);
 }
 
-// S = k * B over an 8-bit comb table of B on a lane pair (comb8_mult29).  seed: any valid point in pair state.
-__device__ __forceinline__ void pair_comb8_mult29(pair_pt& S, bool& s_inf, const u256& k, const int32_t* __restrict__ tab, const pair_pt& seed,
-                                                  bool odd) {
+// S = k * B over a comb table of B on a lane pair (comb_mult29).  seed: any valid point in pair state.
+template <class Tab>
+__device__ __forceinline__ void pair_comb_mult29(pair_pt& S, bool& s_inf, const u256& k, const int32_t* __restrict__ tab, const pair_pt& seed,
+                                                 bool odd) {
     const fe ONE = {FE29_R1};
     PAIR_TMPS;
     S = seed;
     s_inf = true;
-    uint32_t nd = scalar_byte(k, 0);
+    uint32_t nd = Tab::digit(k, 0);
     fe nxy;
-    pair_g8_load(tab, 0, nd ? nd : 1u, odd, nxy);
+    pair_comb_load<Tab>(tab, 0, nd ? nd : 1u, odd, nxy);
 #pragma unroll 1
-    for (int i = 0; i < G8_WINDOWS; i++) {
+    for (int i = 0; i < Tab::WINDOWS; i++) {
         uint32_t d = nd;
         fe xy = nxy;
-        int inext = i + 1 < G8_WINDOWS ? i + 1 : i;
-        nd = scalar_byte(k, inext);
-        pair_g8_load(tab, inext, nd ? nd : 1u, odd, nxy);
+        int inext = i + 1 < Tab::WINDOWS ? i + 1 : i;
+        nd = Tab::digit(k, inext);
+        pair_comb_load<Tab>(tab, inext, nd ? nd : 1u, odd, nxy);
         pair_pt sum = S;
         PAIR_MADD(sum, xy, xy);
         bool take_ent = s_inf & (d != 0);
@@ -304,26 +306,26 @@ __device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, c
         t_inf = t_inf & (mag == 0);
     }
 
-    // --- S = u1 * G (8-bit comb), then R = S + T ---
+    // --- S = u1 * G (16-bit comb), then R = S + T ---
     pair_pt S;
     bool s_inf;
-    pair_comb8_mult29(S, s_inf, u1, gtab, Qp, odd);
+    pair_comb_mult29<GTab16>(S, s_inf, u1, gtab, Qp, odd);
     pair_final_add29(Rr, r_inf, S, s_inf, T, t_inf, odd);
 }
 
-// R = u1*G + u2*Q with both points on comb tables (registered key): 64 pair mixed additions.
+// R = u1*G + u2*Q with both points on comb tables (registered key): 16 + 32 pair mixed additions.
 __device__ __forceinline__ void pair_combined_mult_keyed29(pair_pt& Rr, bool& r_inf, const u256& u1, const u256& u2,
                                                            const int32_t* __restrict__ gtab, const int32_t* __restrict__ ktab, bool odd) {
     const fe ONE = {FE29_R1};
     fe gx, gy;
-    G8Tab gt{gtab};
+    GTab16 gt{gtab};
     gt.load(0, 1u, gx, gy);
     pair_pt seed, S, T;
     seed.A = gx;
     fe_sel(seed.B, odd, ONE, gy);
     bool s_inf, t_inf;
-    pair_comb8_mult29(T, t_inf, u2, ktab, seed, odd);
-    pair_comb8_mult29(S, s_inf, u1, gtab, seed, odd);
+    pair_comb_mult29<KeyTab8>(T, t_inf, u2, ktab, seed, odd);
+    pair_comb_mult29<GTab16>(S, s_inf, u1, gtab, seed, odd);
     pair_final_add29(Rr, r_inf, S, s_inf, T, t_inf, odd);
 }
 

@@ -5,7 +5,7 @@
 //   * one signature per lane; lane-uniform control flow (flags + selects);
 //   * w = s^-1 mod n by safegcd (modinv30.h); u1 = e w, u2 = r w by Montgomery products mod n (fp256.h);
 //   * u2*Q : 52 signed 5-bit (Booth) windows over a 16-entry per-lane Jacobian table in a global workspace;
-//   * u1*G : 32-window 8-bit comb over a precomputed affine table resident in L2, mixed additions only;
+//   * u1*G : 16-window 16-bit comb over a precomputed affine table (80 MiB, Infinity-Cache resident), mixed additions only;
 //   * the two partial sums stay in SEPARATE accumulators, so for an on-curve Q no addition inside either loop can
 //     meet P == +-Q (proof in DESIGN.md); only the final addition handles doubling / infinity explicitly;
 //   * no field inversion: x(R) mod n == r is tested as X == r Z^2 or X == (r + n) Z^2.
@@ -22,23 +22,32 @@ struct jac29 {
     fe X, Y, Z;  // invariants between operations: L(X) = 1, L(Y) <= 3, L(Z) = 1
 };
 
-// Generator comb table: 32 windows of 8 bits over u1, T[w][d] = d * 2^(8 w) * G for d = 1..255 as affine Montgomery fe29
-// points.  640 KiB - it lives in global memory and stays resident in every XCD's 4 MiB L2; each lane gathers one
-// 80-byte entry (five 16-byte loads) per window, issued one window ahead so the L2 latency hides behind the previous
-// mixed addition.  (A 4-bit comb fits LDS but needs 64 additions instead of 32; the additions, not the gathers, are what
-// this kernel pays for - see DESIGN.md.)
-constexpr int G8_WINDOWS = 32;
-constexpr int G8_ENTRY_WORDS = 20;                       // x[9] y[9] pad[2]: 80 bytes, 16-byte aligned
-constexpr int G8_TABLE_WORDS = G8_WINDOWS * 256 * G8_ENTRY_WORDS;   // entry 0 of each window is unused (zero)
-FAB_HD int g8_index(int window, uint32_t digit) { return (window * 256 + (int)digit) * G8_ENTRY_WORDS; }
-struct alignas(16) g8_quad {
+// Comb tables: WINDOWS = 256 / BITS windows over a scalar k, T[w][d] = d * 2^(BITS w) * B for d = 1 .. 2^BITS - 1 as affine
+// Montgomery fe29 points (80-byte entries x[9] y[9] pad[2], 16-byte aligned; entry 0 of each window is unused).  k * B is then
+// WINDOWS mixed additions and no doubling.  Two instances:
+//   * the generator, BITS = 16: 16 windows, 80 MiB, built once per fabgpu_init, resident in the 256 MiB Infinity Cache;
+//   * a registered public key, BITS = 8: 32 windows, 640 KiB per key (fabgpu_p256_key_register), L2-resident.
+// Each lane gathers one entry (five 16-byte loads) per window, issued one window ahead so that the latency hides behind the
+// previous mixed addition.  (History: a 4-bit generator comb staged in LDS needed 64 additions and, at 72 KiB -> 80 KiB
+// allocated, pinned occupancy; the 8-bit comb from L2 needed 32; the additions, not the gathers, are what the kernel pays for.)
+constexpr int COMB_ENTRY_WORDS = 20;
+struct alignas(16) comb_quad {
     int32_t x, y, z, w;
 };
-struct G8Tab {
+template <int BITS>
+struct CombTab {
+    static constexpr int WINDOWS = 256 / BITS;
+    static constexpr size_t TABLE_WORDS = (size_t)WINDOWS * (1u << BITS) * COMB_ENTRY_WORDS;
+    static_assert(256 % BITS == 0 && BITS <= 16, "window width must divide 256");
     const int32_t* w;
+    FAB_HD static size_t index(int window, uint32_t digit) { return ((size_t)window * (1u << BITS) + digit) * COMB_ENTRY_WORDS; }
+    FAB_HD static uint32_t digit(const u256& k, int i) {          // bits [BITS i, BITS i + BITS) of k (never straddles a word)
+        int bit = BITS * i;
+        return (k.w[bit >> 5] >> (bit & 31)) & ((1u << BITS) - 1u);
+    }
     FAB_HD void load(int window, uint32_t digit, fe& x, fe& y) const {
-        const g8_quad* e = reinterpret_cast<const g8_quad*>(w + g8_index(window, digit));   // five global_load_dwordx4
-        g8_quad a = e[0], b = e[1], c = e[2], d = e[3], f = e[4];
+        const comb_quad* e = reinterpret_cast<const comb_quad*>(w + index(window, digit));   // five global_load_dwordx4
+        comb_quad a = e[0], b = e[1], c = e[2], d = e[3], f = e[4];
         x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
         x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
         x.v[8] = c.x; y.v[0] = c.y; y.v[1] = c.z; y.v[2] = c.w;
@@ -46,7 +55,8 @@ struct G8Tab {
         y.v[7] = f.x; y.v[8] = f.y;
     }
 };
-FAB_HD uint32_t scalar_byte(const u256& k, int i) { return (k.w[i >> 2] >> ((i & 3) * 8)) & 255u; }
+typedef CombTab<16> GTab16;   // the generator
+typedef CombTab<8> KeyTab8;   // a registered public key
 
 FAB_HD void sel_jac29(jac29& r, bool c, const jac29& a, const jac29& b) {
     fe_sel(r.X, c, a.X, b.X);
@@ -165,28 +175,28 @@ struct LocalQTab29 {
     FAB_HD void load(uint32_t d, jac29& p) const { p = t[d - 1]; }
 };
 
-// S = k * B over an 8-bit comb table of B (32 mixed additions; the next window's entry is gathered while this one is added).
-// No addition can meet P == +-Q: the partial sum is < 2^(8 i) B while the addend is d 2^(8 i) B.  seed: any valid point.
-template <class GTab>
-FAB_HD void comb8_mult29(jac29& S, bool& s_inf, const u256& k, const GTab& tab, const jac29& seed) {
+// S = k * B over a comb table of B (Tab::WINDOWS mixed additions; the next window's entry is gathered while this one is added).
+// No addition can meet P == +-Q: the partial sum is < 2^(BITS i) B while the addend is d 2^(BITS i) B.  seed: any valid point.
+template <class Tab>
+FAB_HD void comb_mult29(jac29& S, bool& s_inf, const u256& k, const Tab& tab, const jac29& seed) {
     const fe ONE = {FE29_R1};
     S = seed;
     s_inf = true;
-    uint32_t nd = scalar_byte(k, 0);
+    uint32_t nd = Tab::digit(k, 0);
     fe nx, ny;
     tab.load(0, nd ? nd : 1u, nx, ny);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (int i = 0; i < G8_WINDOWS; i++) {
+    for (int i = 0; i < Tab::WINDOWS; i++) {
         uint32_t d = nd;
         jac29 ent, sum;
         fe h, rr;
         ent.X = nx;
         ent.Y = ny;
         ent.Z = ONE;
-        int inext = i + 1 < G8_WINDOWS ? i + 1 : i;
-        nd = scalar_byte(k, inext);
+        int inext = i + 1 < Tab::WINDOWS ? i + 1 : i;
+        nd = Tab::digit(k, inext);
         tab.load(inext, nd ? nd : 1u, nx, ny);
         pt_add_mixed29(sum, S, ent.X, ent.Y, h, rr);
         bool take_ent = s_inf & (d != 0);
@@ -323,21 +333,21 @@ FAB_HD void p256_combined_mult29(jac29& Rr, bool& r_inf, const u256& u1, const u
     // --- S = u1 * G (8-bit comb), then R = S + T ---
     jac29 S;
     bool s_inf;
-    comb8_mult29(S, s_inf, u1, gtab, Q);
+    comb_mult29(S, s_inf, u1, gtab, Q);
     final_add29(Rr, r_inf, S, s_inf, T, t_inf);
 }
 
-// R = u1*G + u2*Q with BOTH points on precomputed 8-bit comb tables (a registered public key): 64 mixed additions, no
+// R = u1*G + u2*Q with BOTH points on precomputed comb tables (a registered public key): 16 + 32 mixed additions, no
 // doublings, no per-lane table.  seed: any valid point (used as filler while an accumulator is still at infinity).
-template <class GTab>
-FAB_HD void p256_combined_mult_keyed29(jac29& Rr, bool& r_inf, const u256& u1, const u256& u2, const GTab& gtab, const GTab& ktab) {
+template <class GTab, class KTab>
+FAB_HD void p256_combined_mult_keyed29(jac29& Rr, bool& r_inf, const u256& u1, const u256& u2, const GTab& gtab, const KTab& ktab) {
     const fe ONE = {FE29_R1};
     jac29 seed, S, T;
     bool s_inf, t_inf;
     gtab.load(0, 1u, seed.X, seed.Y);
     seed.Z = ONE;
-    comb8_mult29(T, t_inf, u2, ktab, seed);
-    comb8_mult29(S, s_inf, u1, gtab, seed);
+    comb_mult29(T, t_inf, u2, ktab, seed);
+    comb_mult29(S, s_inf, u1, gtab, seed);
     final_add29(Rr, r_inf, S, s_inf, T, t_inf);
 }
 
@@ -371,8 +381,8 @@ FAB_HD uint32_t p256_verify_core29(const u256& qx, const u256& qy, const u256& e
 }
 
 // The same verification for a REGISTERED key (curve membership was checked at registration): ktab is the key's comb table.
-template <class GTab>
-FAB_HD uint32_t p256_verify_keyed_core29(const u256& e, const u256& r, const u256& s, const GTab& gtab, const GTab& ktab) {
+template <class GTab, class KTab>
+FAB_HD uint32_t p256_verify_keyed_core29(const u256& e, const u256& r, const u256& s, const GTab& gtab, const KTab& ktab) {
     uint32_t early = range_status(r, s);
     u256 u1, u2;
     ecdsa_scalars29(u1, u2, e, r, s);

@@ -189,13 +189,14 @@ def test_safegcd_inversion_against_python_pow(hosttest):
 
 
 def test_generator_comb_table_fe29(hosttest):
-    """8-bit comb: T[w][d] = d * 2^(8 w) * G, every window at its corners plus a sweep of window 0 and 31."""
-    cases = [(w, d) for w in range(32) for d in (1, 2, 127, 128, 255)] + [(0, d) for d in range(1, 256)] + [(31, d) for d in range(1, 256, 7)]
+    """16-bit generator comb: T[w][d] = d * 2^(16 w) * G, every window at its corners plus sweeps of windows 0 and 15."""
+    cases = [(w, d) for w in range(16) for d in (1, 2, 3, 255, 256, 32767, 32768, 65535)] + [(0, d) for d in range(1, 600)] + \
+            [(15, d) for d in range(1, 65536, 977)]
     for w, d in cases:
         x = ctypes.create_string_buffer(32)
         y = ctypes.create_string_buffer(32)
         hosttest.hosttest_gtab29_entry(w, d, x, y)
-        assert (int.from_bytes(x.raw, "big"), int.from_bytes(y.raw, "big")) == po.pt_mul(d << (8 * w), (po.GX, po.GY)), (w, d)
+        assert (int.from_bytes(x.raw, "big"), int.from_bytes(y.raw, "big")) == po.pt_mul(d << (16 * w), (po.GX, po.GY)), (w, d)
 
 
 def test_combined_mult_adversarial_scalars(hosttest):
@@ -226,7 +227,7 @@ def test_combined_mult_adversarial_scalars(hosttest):
             if v:
                 u2s.append(v)
     u2s += [rng.randrange(1, N) for _ in range(40)]
-    u1s = [0, 1, 255, 256, (1 << 248), N - 1, int("ff00" * 16, 16) % N, int("01" * 32, 16)] + [rng.randrange(N) for _ in range(8)]
+    u1s = [0, 1, 255, 256, 65535, 65536, (1 << 240), (1 << 248), N - 1, int("ff00" * 16, 16) % N, int("ffff0000" * 8, 16) % N, int("0001" * 16, 16)] + [rng.randrange(N) for _ in range(8)]
     for k, u2 in enumerate(u2s):
         u1 = u1s[k % len(u1s)]
         assert run(u1, u2, Q) == want(u1, u2, Q), (hex(u1), hex(u2))
