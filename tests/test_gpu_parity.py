@@ -379,3 +379,36 @@ def test_device_resident_entry_points_on_torch_stream(ctx):
     assert (status.cpu().numpy() == want).all()
     assert (fabgpu.unpack_bits(words.cpu().numpy().view(np.uint64), n) == (want == 0)).all()
     assert ctx.last_kernel_ms() > 0
+
+
+def test_concurrent_launches_on_two_streams_get_separate_workspaces(ctx):
+    """bccsp.Verify is called from many goroutines (v20/validator.go:198-208): two host threads launch on two streams at
+    once; each launch must borrow its own per-lane-table workspace from the pool."""
+    import threading
+
+    import torch
+    results = {}
+
+    def worker(tag, seed, n):
+        torch.cuda.set_device(0)
+        st = torch.cuda.Stream()
+        b = fabgpu.synth_batch(n, seed=seed, invalid_permille=100)
+        dev = {k: torch.from_numpy(b[k]).cuda() for k in ("qx", "qy", "e", "r", "s")}
+        words = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ok = True
+        for _ in range(6):
+            words.zero_()
+            st.wait_stream(torch.cuda.current_stream())
+            ctx.p256_verify_batch_dev(n, dev["qx"].data_ptr(), dev["qy"].data_ptr(), dev["e"].data_ptr(), dev["r"].data_ptr(),
+                                      dev["s"].data_ptr(), words.data_ptr(), 0, st.cuda_stream)
+            st.synchronize()
+            got = fabgpu.unpack_bits(words.cpu().numpy().view(np.uint64), n)
+            ok = ok and bool((got == (b["kind"] == 0)).all())
+        results[tag] = ok
+    ths = [threading.Thread(target=worker, args=("a", 101, 20000)), threading.Thread(target=worker, args=("b", 202, 70000))]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert results == {"a": True, "b": True}
