@@ -71,6 +71,7 @@ struct fabgpu_ctx {
     size_t d_ktabs_cap = 0;
     std::vector<void*> retired;   // outgrown d_ktabs arrays, freed at shutdown
     Buf keyed;        // staging of the keyed host-pointer entry point: key_id | e | r | s
+    Buf pre;          // staging of prefixed batches: pre_off | pre_idx | mid-states
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
     int acquire_qws(size_t bytes, size_t* idx);
     void release_qws(size_t idx, hipStream_t st) {
@@ -272,7 +273,7 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
     int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
     if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
-    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, st);
+    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, ShaPrefixArgs(), st);
     hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = true;
@@ -384,7 +385,7 @@ int fabgpu_sha256_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const v
     hipStream_t st = (hipStream_t)stream;
     hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_sha256_p256_verify_keyed((uint32_t)n, arena, arena_bytes, off, key_id, nkeys, (const void*)kt, r, s, ctx->d_gtab, verdict_bits,
-                                                     status, ctx->allow_pair, st);
+                                                     status, ctx->allow_pair, ShaPrefixArgs(), st);
     hipEventRecord(ctx->ev1, st);
     ctx->timed = true;
     return hip_to_rc(err);
@@ -546,6 +547,136 @@ int fabgpu_sha256_p256_verify_batch_keyed(fabgpu_ctx* ctx, size_t n, const uint8
     if (err != hipSuccess) return hip_to_rc(err);
     memcpy(verdict_bits, ctx->out.h, words * 8);
     if (status) memcpy(status, (uint8_t*)ctx->out.h + st_off, n);
+    return FABGPU_OK;
+}
+
+// ---- identity.Verify over a described batch: optional shared prefixes, fresh or registered keys ------------------------
+int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batch* b, void* mid_scratch, void* stream) {
+    if (!ctx || !b) return FABGPU_EINVAL;
+    const size_t n = b->n;
+    if (n == 0) return FABGPU_OK;
+    const bool keyed = b->key_id != nullptr;
+    const bool prefixed = b->n_prefixes != 0 && b->pre_idx != nullptr;
+    if (!b->arena || !b->off || !b->r || !b->s || !b->verdict_bits || (!keyed && (!b->qx || !b->qy))) return FABGPU_EINVAL;
+    if (prefixed && (!b->pre_off || !mid_scratch)) return FABGPU_EINVAL;
+    if (n > 0xFFFFFFF0ull || b->arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
+    ShaPrefixArgs pa;
+    if (prefixed) {
+        pa.m = b->n_prefixes;
+        pa.pre_off = b->pre_off;
+        pa.pre_idx = b->pre_idx;
+        pa.mid_scratch = mid_scratch;
+    }
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err;
+    if (keyed) {
+        uint32_t nkeys;
+        const int32_t** kt;
+        {
+            std::lock_guard<std::mutex> lk(ctx->kmu);
+            nkeys = (uint32_t)ctx->ktabs.size();
+            kt = ctx->d_ktabs;
+        }
+        if (nkeys == 0) return FABGPU_EINVAL;
+        hipEventRecord(ctx->ev0, st);
+        err = launch_sha256_p256_verify_keyed((uint32_t)n, b->arena, b->arena_bytes, b->off, b->key_id, nkeys, (const void*)kt, b->r, b->s, ctx->d_gtab,
+                                              b->verdict_bits, b->status, ctx->allow_pair, pa, st);
+        hipEventRecord(ctx->ev1, st);
+    } else {
+        size_t wi = 0;
+        int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
+        if (rc != FABGPU_OK) return rc;
+        hipEventRecord(ctx->ev0, st);
+        err = launch_sha256_p256_verify((uint32_t)n, b->arena, b->arena_bytes, b->off, b->qx, b->qy, b->r, b->s, ctx->d_gtab, ctx->qws[wi].p,
+                                        b->verdict_bits, b->status, ctx->allow_pair, pa, st);
+        hipEventRecord(ctx->ev1, st);
+        ctx->release_qws(wi, st);
+    }
+    ctx->timed = true;
+    return hip_to_rc(err);
+}
+
+int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b) {
+    if (!ctx || !b) return FABGPU_EINVAL;
+    const size_t n = b->n;
+    if (n == 0) return FABGPU_OK;
+    const bool keyed = b->key_id != nullptr;
+    const uint32_t m = (b->n_prefixes != 0 && b->pre_idx != nullptr) ? b->n_prefixes : 0;
+    if (!b->off || !b->r || !b->s || !b->verdict_bits || (!keyed && (!b->qx || !b->qy)) || (m && !b->pre_off)) return FABGPU_EINVAL;
+    if (n > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
+    const uint8_t* arena = (const uint8_t*)b->arena;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    // the span of the arena that messages and prefixes reference
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (b->off[i + 1] < b->off[i]) return FABGPU_EINVAL;
+        if (b->off[i] < lo) lo = b->off[i];
+        if (b->off[i + 1] > hi) hi = b->off[i + 1];
+    }
+    for (uint32_t p = 0; p < m; p++) {
+        if (b->pre_off[p + 1] < b->pre_off[p]) return FABGPU_EINVAL;
+        if (b->pre_off[p] < lo) lo = b->pre_off[p];
+        if (b->pre_off[p + 1] > hi) hi = b->pre_off[p + 1];
+    }
+    size_t span = hi >= lo ? (size_t)hi - lo : 0;
+    if (span && !arena) return FABGPU_EINVAL;
+    const size_t fb = n * 32, ib = round_up(n * 4, 64), pob = round_up(((size_t)m + 1) * 4, 64), words = (n + 63) / 64;
+    const size_t st_off = round_up(words * 8, 64), ab = round_up(span, 4) + 64;
+    int rc;
+    if ((rc = ctx->arena.ensure(ab + 64)) || (rc = ctx->offs.ensure((n + 1) * 4)) || (rc = ctx->fields.ensure(4 * fb + ib)) ||
+        (rc = ctx->out.ensure(st_off + n)) || (rc = ctx->pre.ensure(pob + ib + (size_t)m * 32 + 64)))
+        return rc;
+    if (span) memcpy(ctx->arena.h, arena + lo, span);
+    memset((uint8_t*)ctx->arena.h + span, 0, ab - span);
+    uint32_t* ho = (uint32_t*)ctx->offs.h;
+    for (size_t i = 0; i <= n; i++) ho[i] = b->off[i] - lo;
+    uint8_t* ph = (uint8_t*)ctx->pre.h;
+    if (m) {
+        uint32_t* po = (uint32_t*)ph;
+        for (uint32_t p = 0; p <= m; p++) po[p] = b->pre_off[p] - lo;
+        memcpy(ph + pob, b->pre_idx, n * 4);
+    }
+    uint8_t* fh = (uint8_t*)ctx->fields.h;
+    if (keyed) {
+        memcpy(fh, b->key_id, n * 4);
+        memcpy(fh + ib, b->r, fb); memcpy(fh + ib + fb, b->s, fb);
+    } else {
+        memcpy(fh, b->qx, fb); memcpy(fh + fb, b->qy, fb); memcpy(fh + 2 * fb, b->r, fb); memcpy(fh + 3 * fb, b->s, fb);
+    }
+    hipError_t err = hipMemcpyAsync(ctx->arena.d, ctx->arena.h, ab, hipMemcpyHostToDevice, ctx->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(ctx->offs.d, ctx->offs.h, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (err == hipSuccess && m) err = hipMemcpyAsync(ctx->pre.d, ctx->pre.h, pob + ib, hipMemcpyHostToDevice, ctx->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(ctx->fields.d, ctx->fields.h, keyed ? ib + 2 * fb : 4 * fb, hipMemcpyHostToDevice, ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    uint8_t* fd = (uint8_t*)ctx->fields.d;
+    uint8_t* pd = (uint8_t*)ctx->pre.d;
+    uint8_t* dout = (uint8_t*)ctx->out.d;
+    fabgpu_identity_batch d = *b;
+    d.arena = ctx->arena.d;
+    d.arena_bytes = ab;
+    d.off = (const uint32_t*)ctx->offs.d;
+    d.n_prefixes = m;
+    d.pre_off = m ? (const uint32_t*)pd : nullptr;
+    d.pre_idx = m ? (const uint32_t*)(pd + pob) : nullptr;
+    if (keyed) {
+        d.key_id = (const uint32_t*)fd;
+        d.qx = d.qy = nullptr;
+        d.r = fd + ib;
+        d.s = fd + ib + fb;
+    } else {
+        d.qx = fd; d.qy = fd + fb; d.r = fd + 2 * fb; d.s = fd + 3 * fb;
+    }
+    d.verdict_bits = dout;
+    d.status = b->status ? dout + st_off : nullptr;
+    rc = fabgpu_identity_verify_batch_dev(ctx, &d, m ? pd + pob + ib : nullptr, ctx->stream);
+    if (rc) return rc;
+    err = hipMemcpyAsync(ctx->out.h, dout, b->status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    memcpy(b->verdict_bits, ctx->out.h, words * 8);
+    if (b->status) memcpy(b->status, (uint8_t*)ctx->out.h + st_off, n);
     return FABGPU_OK;
 }
 

@@ -12,6 +12,14 @@ constexpr int VERIFY_PAIR_MAX = 32768;    // up to here two lanes per signature 
 constexpr size_t QWS_UINT4_PER_LANE = (size_t)16 * 7;
 constexpr size_t QWS_PAIR_UINT4_PER_SIG = (size_t)16 * 8;
 
+// Shared message prefixes of a fused batch (device pointers): prefix p = arena[pre_off[p], pre_off[p+1]), message i continues
+// prefix pre_idx[i] (0xFFFFFFFF = none); mid_scratch: m x 32 bytes for the mid-states.  m = 0 / pre_idx = nullptr: no prefixes.
+struct ShaPrefixArgs {
+    uint32_t m = 0;
+    const void* pre_off = nullptr;
+    const void* pre_idx = nullptr;
+    void* mid_scratch = nullptr;
+};
 struct VerifyGeom {
     uint32_t block;   // threads per workgroup
     uint32_t wgs;     // workgroups launched (= workspace slots)
@@ -24,10 +32,10 @@ hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const 
                               const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
                                      const void* qy, const void* r, const void* s, const void* gtab, void* qws,
-                                     void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
+                                     void* verdict_bits, void* status, bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st);
 hipError_t launch_p256_verify_keyed(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* e, const void* r, const void* s,
                                     const void* gtab, void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
 hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* key_id, uint32_t nkeys,
                                            const void* ktabs, const void* r, const void* s, const void* gtab, void* verdict_bits, void* status,
-                                           bool allow_pair, hipStream_t st);
+                                           bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st);
 }  // namespace fab

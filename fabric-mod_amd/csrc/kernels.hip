@@ -45,13 +45,15 @@ __device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
-// Hash message [start, start+len) of the arena; arena_words = number of readable dwords of the arena
-// allocation (loads are clamped to it, so no out-of-bounds read whatever the offsets say).
-// The block loop bound is made wave-uniform (max over the wave); lanes past their own block count idle.
-__device__ __forceinline__ void sha256_lane(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t start,
-                                            uint32_t len, bool active, uint32_t h[8]) {
-    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
-    h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+// SHA-256 of a lane's byte stream  A || B  continuing from state h (the IV, or the mid-state of a shared prefix):
+//   A = arena[sa, sa + a), a < 64   (the tail of a shared prefix that did not fill a block; a = 0 without prefix)
+//   B = arena[sb, sb + b)           (the lane's own bytes)
+// base = bytes already absorbed into h (a multiple of 64); the length field is base + a + b.
+// arena_words = readable dwords of the arena allocation: every load index is clamped to [0, arena_words), so no out-of-bounds
+// read whatever the offsets say.  The block loop bound is wave-uniform (max over the wave); lanes past their count idle.
+__device__ __forceinline__ void sha256_stream(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t h[8], uint32_t sa, uint32_t a,
+                                              uint32_t sb, uint32_t b, uint32_t base, bool active, bool any_prefix) {
+    const uint32_t len = a + b;                        // stream bytes still to absorb
     uint32_t nblk = active ? ((len + 9 + 63) >> 6) : 0;
     uint32_t maxblk = nblk;
 #pragma unroll
@@ -60,40 +62,143 @@ __device__ __forceinline__ void sha256_lane(const uint32_t* __restrict__ arena32
         maxblk = other > maxblk ? other : maxblk;
     }
     maxblk = __builtin_amdgcn_readfirstlane(maxblk);
-    const uint32_t shift = start & 3u;                 // byte misalignment of this lane's message
-    const uint32_t last_word = arena_words ? arena_words - 1 : 0;
+    const int32_t vstart = (int32_t)sb - (int32_t)a;   // B's bytes sit at stream position a: virtual start of the B stream
+    const uint32_t shift = (uint32_t)vstart & 3u;      // byte misalignment of the B stream
+    const int32_t last_word = arena_words ? (int32_t)arena_words - 1 : 0;
     for (uint32_t blk = 0; blk < maxblk; blk++) {
         uint32_t w[16];
-        uint32_t pos = blk << 6;                       // byte position of this block inside the message
-        uint32_t wi = (start + pos) >> 2;              // first aligned dword
+        uint32_t pos = blk << 6;                       // byte position of this block inside the stream
+        int32_t wi = (vstart + (int32_t)pos) >> 2;     // first aligned dword (may be negative in block 0 of a prefixed lane)
         uint32_t raw[17];
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            int32_t idx = wi + k;
+            idx = idx < last_word ? idx : last_word;
+            idx = idx > 0 ? idx : 0;
+            raw[k] = arena32[idx];
+        }
+        bool full = pos + 64 <= len;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            // little-endian funnel shift to the stream's byte phase, then to big-endian
+            uint32_t v = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], shift);
+            w[k] = __builtin_bswap32(v);
+        }
+        if (any_prefix && blk == 0) {                  // wave-uniform: merge the prefix tail A into the first block
+            const uint32_t shiftA = sa & 3u;
+            const int32_t wa = (int32_t)(sa >> 2);
+            uint32_t rawA[17];
+#pragma unroll
+            for (int k = 0; k < 17; k++) {
+                int32_t idx = wa + k;
+                idx = idx < last_word ? idx : last_word;
+                rawA[k] = arena32[idx];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint32_t va = __builtin_bswap32(__builtin_amdgcn_alignbyte(rawA[k + 1], rawA[k], shiftA));
+                int32_t na = (int32_t)a - 4 * k;        // bytes of this word that belong to A
+                uint32_t keepA = na >= 4 ? 0xFFFFFFFFu : (na <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * na)));
+                w[k] = (va & keepA) | (w[k] & ~keepA);
+            }
+        }
+        if (!full) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint32_t p = pos + 4 * k;              // byte position of this word
+                int32_t rem = (int32_t)len - (int32_t)p;  // stream bytes left at this word
+                uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * rem)));
+                uint32_t v = w[k] & keep;
+                if (rem >= 0 && rem < 4) v |= 0x80u << (24 - 8 * rem);
+                w[k] = v;
+            }
+        }
+        if (blk + 1 == nblk) {                          // the lane's final block carries the bit length of the whole message
+            uint32_t total = base + len;
+            w[14] = total >> 29;
+            w[15] = total << 3;
+        }
+        if (blk < nblk) sha256_compress(h, w);
+    }
+}
+
+__device__ __forceinline__ void sha256_iv(uint32_t h[8]) {
+    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+    h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+}
+// Hash message [start, start+len) of the arena.
+__device__ __forceinline__ void sha256_lane(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t start,
+                                            uint32_t len, bool active, uint32_t h[8]) {
+    sha256_iv(h);
+    sha256_stream(arena32, arena_words, h, 0, 0, start, len, 0, active, false);
+}
+
+// Shared prefixes (the endorsements of one transaction all sign  prp || endorser_i,
+// core/common/validation/statebased/validator_keylevel.go:246-258): prefix p = arena[pre_off[p], pre_off[p+1]).
+// The mid-state kernel absorbs the whole 64-byte blocks of every prefix once; a message that names prefix p continues from
+// mid[p] with the prefix's last (len mod 64) bytes followed by its own suffix.
+struct sha_prefixes {
+    const uint32_t* pre_idx;   // per message: prefix index, or 0xFFFFFFFF for none; nullptr = the batch has no prefixes
+    const uint32_t* pre_off;   // m + 1 offsets into the arena
+    const uint32_t* mid;       // m x 8 words, written by sha256_midstate_kernel
+    uint32_t m;
+};
+__global__ void __launch_bounds__(256) sha256_midstate_kernel(uint32_t m, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                               const uint32_t* __restrict__ pre_off, uint32_t* __restrict__ mid) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = p < m;
+    uint32_t pc = active ? p : (m - 1);
+    uint32_t start = pre_off[pc], len = pre_off[pc + 1] - start;
+    uint32_t nfull = active ? (len >> 6) : 0, maxfull = nfull;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        uint32_t other = __shfl_xor(maxfull, o, 64);
+        maxfull = other > maxfull ? other : maxfull;
+    }
+    maxfull = __builtin_amdgcn_readfirstlane(maxfull);
+    uint32_t h[8];
+    sha256_iv(h);
+    const uint32_t shift = start & 3u;
+    const uint32_t last_word = arena_words ? arena_words - 1 : 0;
+    for (uint32_t blk = 0; blk < maxfull; blk++) {
+        uint32_t w[16], raw[17];
+        uint32_t wi = (start + (blk << 6)) >> 2;
 #pragma unroll
         for (int k = 0; k < 17; k++) {
             uint32_t idx = wi + k;
             idx = idx < last_word ? idx : last_word;
             raw[k] = arena32[idx];
         }
-        bool full = pos + 64 <= len;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            // little-endian funnel shift to the message's byte phase, then to big-endian
-            uint32_t v = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], shift);
-            v = __builtin_bswap32(v);
-            if (!full) {
-                uint32_t p = pos + 4 * k;              // byte position of this word
-                int32_t rem = (int32_t)len - (int32_t)p;  // message bytes left at this word
-                uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * rem)));
-                v &= keep;
-                if (rem >= 0 && rem < 4) v |= 0x80u << (24 - 8 * rem);
-            }
-            w[k] = v;
-        }
-        if (blk + 1 == nblk) {                          // the lane's final block carries the bit length
-            w[14] = len >> 29;
-            w[15] = len << 3;
-        }
-        if (blk < nblk) sha256_compress(h, w);
+        for (int k = 0; k < 16; k++) w[k] = __builtin_bswap32(__builtin_amdgcn_alignbyte(raw[k + 1], raw[k], shift));
+        if (blk < nfull) sha256_compress(h, w);
     }
+    if (active) {
+        uint4* o = reinterpret_cast<uint4*>(mid + 8 * (size_t)p);
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    }
+}
+// The digest of message i of a (possibly prefixed) batch, in h.
+__device__ __forceinline__ void sha256_message(const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
+                                               const sha_prefixes& pre, uint32_t ic, bool active, uint32_t h[8]) {
+    uint32_t start = off[ic], len = off[ic + 1] - start;
+    if (pre.pre_idx == nullptr) {                       // wave-uniform
+        sha256_lane(arena32, arena_words, start, len, active, h);
+        return;
+    }
+    uint32_t pi = pre.pre_idx[ic];
+    bool has = pi < pre.m;
+    uint32_t ps = has ? pre.pre_off[pi] : 0, pl = has ? pre.pre_off[pi + 1] - ps : 0;
+    uint32_t base = pl & ~63u, tail = pl & 63u;
+    sha256_iv(h);
+    if (has && base) {
+        const uint4* mp = reinterpret_cast<const uint4*>(pre.mid + 8 * (size_t)pi);
+        uint4 m0 = mp[0], m1 = mp[1];
+        h[0] = m0.x; h[1] = m0.y; h[2] = m0.z; h[3] = m0.w;
+        h[4] = m1.x; h[5] = m1.y; h[6] = m1.z; h[7] = m1.w;
+    }
+    sha256_stream(arena32, arena_words, h, ps + base, tail, start, len, base, active, true);
 }
 
 __global__ void __launch_bounds__(256) sha256_batch_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
@@ -299,16 +404,15 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_kernel(uint
                                                                                  uint32_t nkeys, const int32_t* const* __restrict__ ktabs,
                                                                                  const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                                                                                  const int32_t* __restrict__ gtab, uint64_t* __restrict__ verdict_bits,
-                                                                                 uint8_t* __restrict__ status) {
+                                                                                 uint8_t* __restrict__ status, sha_prefixes pre) {
     GTab16 gt{gtab};
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;
         bool active = i < n;
         uint32_t ic = active ? i : (n - 1);
-        uint32_t start = off[ic], end = off[ic + 1];
         uint32_t h[8];
-        sha256_lane(arena32, arena_words, start, end - start, active, h);
+        sha256_message(arena32, arena_words, off, pre, ic, active, h);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
         KeyTab8 kt{ktabs[kok ? kid : 0]};
@@ -328,7 +432,7 @@ __global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_keyed_pair_kernel
                                                                                       uint32_t nkeys, const int32_t* const* __restrict__ ktabs,
                                                                                       const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                                                                                       const int32_t* __restrict__ gtab, uint64_t* __restrict__ verdict_bits,
-                                                                                      uint8_t* __restrict__ status) {
+                                                                                      uint8_t* __restrict__ status, sha_prefixes pre) {
     constexpr int NP = BLOCK / 2;
     const bool odd = (threadIdx.x & 1) != 0;
     const uint32_t pairidx = threadIdx.x >> 1;
@@ -338,9 +442,8 @@ __global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_keyed_pair_kernel
         uint32_t i = tile * NP + pairidx;
         bool active = i < n;
         uint32_t ic = active ? i : (n - 1);
-        uint32_t start = off[ic], end = off[ic + 1];
         uint32_t h[8];
-        sha256_lane(arena32, arena_words, start, end - start, active, h);
+        sha256_message(arena32, arena_words, off, pre, ic, active, h);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
         const int32_t* kt = ktabs[kok ? kid : 0];
@@ -363,7 +466,7 @@ __global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_pair_kernel(uint3
                                                                                 const uint8_t* __restrict__ qy, const uint8_t* __restrict__ r,
                                                                                 const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
                                                                                 uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
-                                                                                uint8_t* __restrict__ status) {
+                                                                                uint8_t* __restrict__ status, sha_prefixes pre) {
     constexpr int NP = BLOCK / 2;
     const bool odd = (threadIdx.x & 1) != 0;
     const uint32_t pairidx = threadIdx.x >> 1;
@@ -374,9 +477,8 @@ __global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_pair_kernel(uint3
         uint32_t i = tile * NP + pairidx;
         bool active = i < n;
         uint32_t ic = active ? i : (n - 1);
-        uint32_t start = off[ic], end = off[ic + 1];
         uint32_t h[8];
-        sha256_lane(arena32, arena_words, start, end - start, active, h);
+        sha256_message(arena32, arena_words, off, pre, ic, active, h);
         u256 vqx, vqy, ve, vr, vs;
 #pragma unroll
         for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];
@@ -396,7 +498,7 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n
                                                                            const uint8_t* __restrict__ qy, const uint8_t* __restrict__ r,
                                                                            const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
                                                                            uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits,
-                                                                           uint8_t* __restrict__ status) {
+                                                                           uint8_t* __restrict__ status, sha_prefixes pre) {
     GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
     GTab16 gt{gtab};
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
@@ -404,9 +506,8 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n
         uint32_t i = tile * BLOCK + threadIdx.x;
         bool active = i < n;
         uint32_t ic = active ? i : (n - 1);
-        uint32_t start = off[ic], end = off[ic + 1];
         uint32_t h[8];
-        sha256_lane(arena32, arena_words, start, end - start, active, h);
+        sha256_message(arena32, arena_words, off, pre, ic, active, h);
         u256 vqx, vqy, ve, vr, vs;
 #pragma unroll
         for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];   // digest big-endian -> integer limbs
@@ -422,6 +523,19 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n
 // ------------------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------------------
+// Runs the mid-state kernel for a prefixed batch (no-op otherwise) and returns the descriptor the fused kernels take.
+static sha_prefixes launch_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st) {
+    sha_prefixes pre{nullptr, nullptr, nullptr, 0};
+    if (pa.m == 0 || pa.pre_idx == nullptr) return pre;
+    dim3 grid((pa.m + 255) / 256), block(256);
+    hipLaunchKernelGGL(sha256_midstate_kernel, grid, block, 0, st, pa.m, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                       (const uint32_t*)pa.pre_off, (uint32_t*)pa.mid_scratch);
+    pre.pre_idx = (const uint32_t*)pa.pre_idx;
+    pre.pre_off = (const uint32_t*)pa.pre_off;
+    pre.mid = (const uint32_t*)pa.mid_scratch;
+    pre.m = pa.m;
+    return pre;
+}
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st) {
     if (n == 0) return hipSuccess;
     dim3 grid((n + 255) / 256), block(256);
@@ -459,19 +573,20 @@ hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const 
 }
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
                                      const void* qy, const void* r, const void* s, const void* gtab, void* qws,
-                                     void* verdict_bits, void* status, bool allow_pair, hipStream_t st) {
+                                     void* verdict_bits, void* status, bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    sha_prefixes pre = launch_midstates(arena, arena_bytes, pa, st);
     VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair) {
         hipLaunchKernelGGL(sha256_p256_verify_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                            (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
-                           (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+                           (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, pre);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(sha256_p256_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                        (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
-                       (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+                       (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, pre);
     return hipGetLastError();
 }
 
@@ -491,18 +606,19 @@ hipError_t launch_p256_verify_keyed(uint32_t n, const void* key_id, uint32_t nke
 
 hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* key_id, uint32_t nkeys,
                                            const void* ktabs, const void* r, const void* s, const void* gtab, void* verdict_bits, void* status,
-                                           bool allow_pair, hipStream_t st) {
+                                           bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    sha_prefixes pre = launch_midstates(arena, arena_bytes, pa, st);
     VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair)
         hipLaunchKernelGGL(sha256_p256_verify_keyed_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena,
                            (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
-                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status, pre);
     else
         hipLaunchKernelGGL(sha256_p256_verify_keyed_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena,
                            (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
-                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+                           (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status, pre);
     return hipGetLastError();
 }
 

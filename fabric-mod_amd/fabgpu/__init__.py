@@ -42,6 +42,14 @@ class BCCSPError(Exception):
     """A non-nil Go `error` from the provider (same text as bccsp/sw)."""
 
 
+class _IdBatch(ctypes.Structure):
+    """fabgpu_identity_batch (include/fabgpu.h)."""
+    _fields_ = [("n", ctypes.c_size_t), ("arena", ctypes.c_void_p), ("arena_bytes", ctypes.c_size_t), ("off", ctypes.c_void_p),
+                ("n_prefixes", ctypes.c_uint32), ("pre_off", ctypes.c_void_p), ("pre_idx", ctypes.c_void_p), ("qx", ctypes.c_void_p),
+                ("qy", ctypes.c_void_p), ("key_id", ctypes.c_void_p), ("r", ctypes.c_void_p), ("s", ctypes.c_void_p),
+                ("verdict_bits", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
 class _Cfg(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("max_batch", ctypes.c_uint32), ("max_arena", ctypes.c_uint32),
                 ("flags", ctypes.c_uint32)]
@@ -54,6 +62,7 @@ ABI_SYMBOLS = [
     "fabgpu_p256_verify_batch_dev", "fabgpu_sha256_batch_dev", "fabgpu_sha256_p256_verify_batch_dev",
     "fabgpu_p256_key_register", "fabgpu_p256_key_lookup", "fabgpu_p256_key_count", "fabgpu_p256_verify_batch_keyed", "fabgpu_p256_verify_batch_keyed_dev",
     "fabgpu_sha256_p256_verify_batch_keyed", "fabgpu_sha256_p256_verify_batch_keyed_dev",
+    "fabgpu_identity_verify_batch", "fabgpu_identity_verify_batch_dev",
     "fabgpu_last_kernel_ms", "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
@@ -94,6 +103,8 @@ def load():
     L.fabgpu_p256_verify_batch_keyed_dev.argtypes = [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.fabgpu_sha256_p256_verify_batch_keyed.argtypes = [_vp, _sz, _u8p, _u32p, _u32p, _u8p, _u8p, _u64p, _u8p]
     L.fabgpu_sha256_p256_verify_batch_keyed_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.fabgpu_identity_verify_batch.argtypes = [_vp, ctypes.POINTER(_IdBatch)]
+    L.fabgpu_identity_verify_batch_dev.argtypes = [_vp, ctypes.POINTER(_IdBatch), _vp, _vp]
     L.fabgpu_last_kernel_ms.argtypes = [_vp]
     L.fabgpu_last_kernel_ms.restype = ctypes.c_float
     L.fabgpu_ecdsa_unmarshal_signature.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
@@ -279,6 +290,36 @@ class Context:
     def sha256_p256_verify_batch_keyed_dev(self, n, arena, arena_bytes, off, key_id, r, s, verdict_bits, status, stream=0):
         _check(self._L.fabgpu_sha256_p256_verify_batch_keyed_dev(self._h, n, arena, arena_bytes, off, key_id, r, s, verdict_bits,
                                                                   status or None, stream or None), "fabgpu_sha256_p256_verify_batch_keyed_dev")
+
+    def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True):
+        """fabgpu_identity_verify_batch: message i = [prefix pre_idx[i]] || arena[off[i], off[i+1]); keys by value or by id."""
+        arena, r, s = map(_a8, (arena, r, s))
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = off.size - 1
+        keep = [arena, off, r, s]
+        b = _IdBatch()
+        b.n = n
+        b.arena, b.off, b.r, b.s = arena.ctypes.data, off.ctypes.data, r.ctypes.data, s.ctypes.data
+        if key_id is not None:
+            key_id = np.ascontiguousarray(key_id, dtype=np.uint32); keep.append(key_id)
+            b.key_id = key_id.ctypes.data
+        else:
+            qx, qy = _a8(qx), _a8(qy); keep += [qx, qy]
+            b.qx, b.qy = qx.ctypes.data, qy.ctypes.data
+        if pre_idx is not None:
+            pre_off = np.ascontiguousarray(pre_off, dtype=np.uint32); pre_idx = np.ascontiguousarray(pre_idx, dtype=np.uint32)
+            keep += [pre_off, pre_idx]
+            b.n_prefixes, b.pre_off, b.pre_idx = pre_off.size - 1, pre_off.ctypes.data, pre_idx.ctypes.data
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.uint8) if want_status else None
+        b.verdict_bits = bits.ctypes.data
+        b.status = st.ctypes.data if want_status else None
+        _check(self._L.fabgpu_identity_verify_batch(self._h, ctypes.byref(b)), "fabgpu_identity_verify_batch")
+        return unpack_bits(bits, n), st
+
+    def identity_verify_batch_dev(self, desc: "_IdBatch", mid_scratch, stream=0):
+        _check(self._L.fabgpu_identity_verify_batch_dev(self._h, ctypes.byref(desc), mid_scratch or None, stream or None),
+               "fabgpu_identity_verify_batch_dev")
 
     def p256_verify_batch_keyed_dev(self, n, key_id, e, r, s, verdict_bits, status, stream=0):
         _check(self._L.fabgpu_p256_verify_batch_keyed_dev(self._h, n, key_id, e, r, s, verdict_bits, status or None, stream or None),

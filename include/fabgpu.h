@@ -128,6 +128,34 @@ int fabgpu_sha256_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const v
                                               const void* key_id, const void* r, const void* s, void* verdict_bits, void* status,
                                               void* stream);
 
+/* ---- identity.Verify over a DESCRIBED batch: shared message prefixes, fresh or registered keys ----
+ * The endorsements of one transaction all sign  prp || endorser_i  (core/common/validation/statebased/
+ * validator_keylevel.go:246-258): the proposal-response payload is a shared PREFIX.  A batch may list m prefixes
+ * (prefix p = arena[pre_off[p], pre_off[p+1])) and name one per message (pre_idx[i], 0xFFFFFFFF = none); message i is then
+ * prefix || arena[off[i], off[i+1]).  The whole 64-byte blocks of every prefix are hashed once (SHA-256 mid-state), the
+ * messages continue from there.  Keys: either (qx, qy) per message or key_id per message (registered keys), not both.
+ * Verdicts are those of fabgpu_sha256_p256_verify_batch on the concatenated messages.
+ * Host variant: all pointers are host memory.  _dev: all pointers are device memory, arena_bytes = readable size of the
+ * arena allocation, mid_scratch = n_prefixes x 32 bytes of device scratch, asynchronous on `stream`. */
+typedef struct fabgpu_identity_batch {
+    size_t n;
+    const void* arena;
+    size_t arena_bytes;          /* _dev only */
+    const uint32_t* off;         /* n + 1 */
+    uint32_t n_prefixes;         /* 0 = no prefixes */
+    const uint32_t* pre_off;     /* n_prefixes + 1 */
+    const uint32_t* pre_idx;     /* n */
+    const void* qx;              /* n x 32, or NULL with key_id */
+    const void* qy;
+    const uint32_t* key_id;      /* n, or NULL with qx / qy */
+    const void* r;
+    const void* s;
+    void* verdict_bits;          /* ceil(n/64) x u64 */
+    void* status;                /* n bytes or NULL */
+} fabgpu_identity_batch;
+int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch);
+int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch, void* mid_scratch, void* stream);
+
 /* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
  * launch stream (bench.py's roofline leg).  <0 if nothing was launched or events are pending. */
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);

@@ -169,6 +169,60 @@ def test_registered_keys_fused_hash_verify_vs_oracle(ctx):
     assert (st2 == st).all() and (bits2 == bits).all()
 
 
+@pytest.mark.parametrize("keyed", [False, True])
+def test_identity_batch_with_shared_prefixes_vs_hashlib_and_oracle(ctx, keyed):
+    """fabgpu_identity_verify_batch: message = prefix || suffix with the prefix hashed once (mid-state).  Prefix lengths
+    around every multiple of 64 (so the re-read tail is 0..63 bytes), arbitrary alignments, empty suffixes, messages without
+    a prefix, prefixes nobody uses.  The digests are pinned by hashlib on the concatenation, the verdicts by the oracle and by
+    the un-prefixed fused kernel on the materialised messages."""
+    rng = np.random.default_rng(64)
+    plens = [0, 1, 55, 56, 63, 64, 65, 119, 120, 127, 128, 129, 191, 192, 1023, 1024, 1025, 1856] + [int(x) for x in rng.integers(0, 300, size=12)]
+    m = len(plens)
+    n = 1500
+    pre_idx = rng.integers(0, m, size=n).astype(np.uint32)
+    pre_idx[rng.random(n) < 0.1] = 0xFFFFFFFF
+    slens = rng.integers(0, 200, size=n)
+    slens[rng.random(n) < 0.05] = 0
+    # arena: a little junk, the prefixes back to back, more junk, the suffixes
+    parts, pre_off, off = [bytes(rng.integers(0, 256, size=3, dtype=np.uint8))], [], []
+    pos = 3
+    prefixes = []
+    for L in plens:
+        p = bytes(rng.integers(0, 256, size=L, dtype=np.uint8)); prefixes.append(p)
+        pre_off.append(pos); parts.append(p); pos += L
+    pre_off.append(pos)
+    parts.append(b"\xAA" * 5); pos += 5
+    suffixes = []
+    for L in slens:
+        sfx = bytes(rng.integers(0, 256, size=int(L), dtype=np.uint8)); suffixes.append(sfx)
+        off.append(pos); parts.append(sfx); pos += int(L)
+    off.append(pos)
+    arena = np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8)
+    msgs = [(prefixes[pi] if pi != 0xFFFFFFFF else b"") + sfx for pi, sfx in zip(pre_idx.tolist(), suffixes)]
+    dig = np.frombuffer(b"".join(hashlib.sha256(mm).digest() for mm in msgs), dtype=np.uint8).reshape(n, 32)
+    b = coracle.make_pool_batch(n, seed=65, nkeys=6, invalid_frac=0.2, digests=dig)
+    want = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])          # e = the hashlib digest (or its mutation)
+    want_hash = want.copy()
+    want_hash[b["kind"] == 1] = 0                                                   # kind 1 flipped e only: the message decides
+    kw = {}
+    if keyed:
+        ids = np.array([ctx.key_register(b["pool_qx"][j].tobytes(), b["pool_qy"][j].tobytes()) for j in range(6)], dtype=np.uint32)
+        kw["key_id"] = ids[b["key_index"]]
+    else:
+        kw.update(qx=b["qx"], qy=b["qy"])
+    bits, st = ctx.identity_verify_batch(arena, np.array(off, dtype=np.uint32), b["r"], b["s"], pre_off=np.array(pre_off, dtype=np.uint32),
+                                         pre_idx=pre_idx, **kw)
+    assert (st == want_hash).all() and (bits == (want_hash == 0)).all()
+    # the same messages materialised, through the plain fused entry point
+    moff = np.concatenate([[0], np.cumsum([len(x) for x in msgs])]).astype(np.uint32)
+    marena = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8)
+    bits2, st2 = ctx.sha256_p256_verify_batch(marena, moff, b["qx"], b["qy"], b["r"], b["s"])
+    assert (st2 == st).all() and (bits2 == bits).all()
+    # and without any prefix the described entry point equals the plain one
+    bits3, st3 = ctx.identity_verify_batch(marena, moff, b["r"], b["s"], **kw)
+    assert (st3 == st).all()
+
+
 # ---- SHA-256 ----------------------------------------------------------------------------------------
 def test_sha256_like_reference_TestSHA(ctx):
     rng = np.random.default_rng(5)
