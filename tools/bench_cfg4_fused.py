@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--tx", type=int, default=100000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prefixed", action="store_true", help="hand the prp of each tx over once as a shared prefix (mid-state reuse)")
+    ap.add_argument("--keys", type=int, default=0, help="sign with a pool of this many REGISTERED keys instead of a fresh key per signature")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -33,15 +35,40 @@ def main():
     arena[:, 1024:] = endorser
     off = (np.arange(n + 1, dtype=np.uint64) * 1856).astype(np.uint32)
     dig = np.frombuffer(b"".join(hashlib.sha256(arena[i].tobytes()).digest() for i in range(n)), dtype=np.uint8).reshape(n, 32)
-    b = fabgpu.synth_batch(n, seed=20260921, invalid_permille=10, e_in=dig)
     ctx = fabgpu.Context(device=0, max_batch=n)
-    t = {k: torch.from_numpy(v).cuda() for k, v in dict(arena=arena.reshape(-1), off=off.view(np.int32), qx=b["qx"], qy=b["qy"], r=b["r"], s=b["s"]).items()}
+    if args.keys:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import coracle
+        b = coracle.make_pool_batch(n, seed=20260921, nkeys=args.keys, invalid_frac=0.01, digests=dig)
+        ids = np.array([ctx.key_register(b["pool_qx"][j].tobytes(), b["pool_qy"][j].tobytes()) for j in range(args.keys)], dtype=np.uint32)
+        kid = torch.from_numpy(ids[b["key_index"]].view(np.int32)).cuda()
+    else:
+        b = fabgpu.synth_batch(n, seed=20260921, invalid_permille=10, e_in=dig)
+    if args.prefixed:   # arena = all prp back to back, then all endorser suffixes
+        flat = np.concatenate([prp.reshape(-1), endorser.reshape(-1)])
+        pre_off = (np.arange(args.tx + 1, dtype=np.uint64) * 1024).astype(np.uint32)
+        pre_idx = np.repeat(np.arange(args.tx, dtype=np.uint32), 3)
+        off = (args.tx * 1024 + np.arange(n + 1, dtype=np.uint64) * 832).astype(np.uint32)
+    else:
+        flat = arena.reshape(-1)
+    t = {k: torch.from_numpy(v).cuda() for k, v in dict(arena=flat, off=off.view(np.int32), qx=b["qx"], qy=b["qy"], r=b["r"], s=b["s"]).items()}
     words = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream()
+    desc = fabgpu._IdBatch()
+    desc.n, desc.arena, desc.arena_bytes, desc.off = n, t["arena"].data_ptr(), t["arena"].numel(), t["off"].data_ptr()
+    desc.r, desc.s, desc.verdict_bits = t["r"].data_ptr(), t["s"].data_ptr(), words.data_ptr()
+    if args.keys:
+        desc.key_id = kid.data_ptr()
+    else:
+        desc.qx, desc.qy = t["qx"].data_ptr(), t["qy"].data_ptr()
+    mid = None
+    if args.prefixed:
+        tp = {"pre_off": torch.from_numpy(pre_off.view(np.int32)).cuda(), "pre_idx": torch.from_numpy(pre_idx.view(np.int32)).cuda()}
+        mid = torch.zeros(args.tx * 8, dtype=torch.int32, device="cuda")
+        desc.n_prefixes, desc.pre_off, desc.pre_idx = args.tx, tp["pre_off"].data_ptr(), tp["pre_idx"].data_ptr()
 
     def step():
-        ctx.sha256_p256_verify_batch_dev(n, t["arena"].data_ptr(), t["arena"].numel(), t["off"].data_ptr(), t["qx"].data_ptr(), t["qy"].data_ptr(),
-                                         t["r"].data_ptr(), t["s"].data_ptr(), words.data_ptr(), 0, stream.cuda_stream)
+        ctx.identity_verify_batch_dev(desc, mid.data_ptr() if mid is not None else 0, stream.cuda_stream)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -53,9 +80,15 @@ def main():
     got = fabgpu.unpack_bits(words.cpu().numpy().view(np.uint64), n)
     # kind 1 mutates e_out only: in hash mode the message decides, so those tuples stay valid
     want = (b["kind"] == 0) | (b["kind"] == 1)
+    if args.keys:
+        import coracle
+        w = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
+        want = (w == 0) | (b["kind"] == 1)
     assert (got == want).all(), "fused verdicts differ from the generator's ground truth"
     print(json.dumps({"metric": "fused SHA-256 + ECDSA P-256 verifies/sec", "value": n / dt, "unit": "verifies/s", "ms_per_step": dt * 1e3,
-                      "config": {"workload": "BASELINE.json configs[3]: %d tx x 3 messages of 1856 B, fused hash+verify, 1 GPU" % args.tx, "tuples": n,
+                      "config": {"workload": "BASELINE.json configs[3]: %d tx x 3 messages of 1856 B, fused hash+verify, 1 GPU%s%s" % (
+                          args.tx, ", prp handed over once per tx (mid-state reuse)" if args.prefixed else "",
+                          ", pool of %d registered keys" % args.keys if args.keys else ""), "tuples": n,
                                  "message_bytes": 1856}, "hashed_GB_per_s": n * 1856 / dt / 1e9, "validated_tx_per_s": args.tx / dt,
                       "parity": "verdict bitmap equals the generator's ground truth"}))
     ctx.close()
