@@ -14,7 +14,8 @@ are exactly those of p256_verify29.h (pt_dbl29 / pt_add29 / pt_add_mixed29).
 
 tests/test_pair_programs.py runs these very programs in gcn_dsl.Program.run() against big-integer point arithmetic.
 
-Run:  python3 gen_pair_gcn.py > pair29_gcn.h   (the Makefile does this)
+Run:  python3 gen_pair_gcn.py > pair29_gcn.h ; python3 gen_pair_gcn.py field > fe29_gcn.h   (the Makefile does this)
+The single-lane field product / square of fe29.h are generated from the same DSL (build_fe_mul / build_fe_sqr).
 """
 from gcn_dsl import Program
 
@@ -173,19 +174,58 @@ def build_pair_madd():
     return p
 
 
+def build_fe_mul():
+    """R = A * B / 2^261 mod p (fe29.h fe_mul_body); R must not alias A or B."""
+    p = Program("FE29_GCN_MUL")
+    R = p.fe("R", "tmp")
+    A = p.fe("A", "in")
+    B = p.fe("B", "in")
+    p.mul(R, A, B)
+    return p
+
+
+def build_fe_sqr():
+    """R = A * A / 2^261 mod p (fe29.h fe_sqr_body); T: scratch for the doubled limbs."""
+    p = Program("FE29_GCN_SQR")
+    R = p.fe("R", "tmp")
+    T = p.fe("T", "tmp")
+    A = p.fe("A", "in")
+    p.sqr(R, A, T)
+    return p
+
+
+FIELD_PROGRAMS = [build_fe_mul, build_fe_sqr]
 PROGRAMS = [build_pair_dbl, build_pair_add, build_pair_madd]
 
+ALIGN_NOTE = """// Every instruction below is 8 bytes (VOP3, VOP2 + DPP, or VOP2 + 32-bit literal): a block started on an 8-byte boundary stays
+// on 8-byte boundaries throughout (8-byte instructions at 4-mod-8 addresses cost 8.5 % of kernel time, measured).
+#ifndef FE29_GCN_ALIGN
+#define FE29_GCN_ALIGN ".p2align 3\\n\\t"
+#endif
+"""
 
-def main():
-    print("// GENERATED by gen_pair_gcn.py - do not edit.  Two-lanes-per-signature point operations (see gen_pair_gcn.py).")
-    print("#pragma once")
-    print('#include "fe29_gcn.h"   // FE29_GCN_ALIGN')
-    print()
-    for b in PROGRAMS:
+
+def emit(path_kind):
+    progs = FIELD_PROGRAMS if path_kind == "field" else PROGRAMS
+    if path_kind == "field":
+        print("// GENERATED by gen_pair_gcn.py field - do not edit.  gfx950 instruction streams of fe_mul / fe_sqr (fe29.h).")
+        print("#pragma once")
+        print(ALIGN_NOTE)
+    else:
+        print("// GENERATED by gen_pair_gcn.py - do not edit.  Two-lanes-per-signature point operations (see gen_pair_gcn.py).")
+        print("#pragma once")
+        print('#include "fe29_gcn.h"   // FE29_GCN_ALIGN')
+        print()
+    for b in progs:
         prog = b()
         args = {n: "(%s)" % n for n in prog.order}
         text, stats = prog.emit_asm(args)
         print(text)
+
+
+def main():
+    import sys
+    emit("field" if len(sys.argv) > 1 and sys.argv[1] == "field" else "pair")
 
 
 if __name__ == "__main__":

@@ -89,6 +89,24 @@ def test_program_sizes(progs):
     assert sizes["dbl"]["instructions"] < 850 and sizes["add"]["instructions"] < 1600 and sizes["madd"]["instructions"] < 1300
 
 
+def test_field_product_and_square_programs():
+    """FE29_GCN_MUL / FE29_GCN_SQR (the single-lane streams of fe29.h) come from the same DSL: run them in the interpreter."""
+    rng = random.Random(76)
+    mul, sqr = gp.build_fe_mul(), gp.build_fe_sqr()
+    for _ in range(40):
+        a, b = rng.randrange(P), rng.randrange(P)
+        e, o = {}, {}
+        put(e, "A", to_fe(a)); put(e, "B", to_fe(b)); put(o, "A", to_fe(b)); put(o, "B", to_fe(a))
+        re, ro = mul.run(e, o)
+        assert val(re, "R") == a * b % P and val(ro, "R") == a * b % P
+        lazy = [x + y for x, y in zip(to_fe(a), to_fe(b))]            # L = 2 operand: (a + b)^2
+        e2, o2 = {}, {}
+        put(e2, "A", lazy); put(o2, "A", to_fe(a))
+        re, ro = sqr.run(e2, o2)
+        assert val(re, "R") == (a + b) * (a + b) % P and val(ro, "R") == a * a % P
+        assert all(-(1 << 28) <= re["R.%d" % i] <= (1 << 28) for i in range(8))   # balanced output digits
+
+
 def test_pair_scalar_multiplication_chain(progs):
     """Left-to-right double-and-add of a random 48-bit scalar with Jacobian table entries (pair add) and affine ones
     (pair madd), against the oracle after every step."""
