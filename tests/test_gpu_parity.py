@@ -16,7 +16,8 @@ import coracle
 import fabgpu
 
 pytestmark = pytest.mark.gpu
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
 
 
 def _load(name):
@@ -53,6 +54,17 @@ def test_native_library_is_the_thing_running(ctx):
     assert ctx.device_count() >= 1
     with open("/proc/self/maps") as f:
         assert "libfabgpu.so" in f.read()
+
+
+def test_plain_c_program_verifies_the_rfc6979_vector_through_the_c_abi(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(fabgpu.lib_path())
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "abi_smoke.c"),
+                    "-L" + libdir, "-lfabgpu", "-o", exe], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "verdict=1 status=0" in out.stdout, out.stdout + out.stderr
 
 
 # ---- golden fixtures -----------------------------------------------------------------------------

@@ -49,6 +49,22 @@ def test_library_exports_every_declared_symbol():
     assert fabgpu.strerror(0) == "ok" and "bccsp/sw" in fabgpu.strerror(-2)
 
 
+def test_headers_are_plain_c_and_a_c_program_links(tmp_path):
+    """The drop-in boundary is a C ABI: tools/abi_smoke.c (C99, no C++) includes both headers, links against libfabgpu.so and,
+    without a GPU, reports FABGPU_ENODEV and exits 0 (the caller would keep using bccsp/sw); on an MI355X it verifies the
+    RFC 6979 A.2.5 P-256/SHA-256 "sample" signature (low-S mirrored) through the fused entry point."""
+    import subprocess
+    fabgpu.load()
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "fabric-mod_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "abi_smoke.c"),
+                    "-L" + libdir, "-lfabgpu", "-o", exe], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "verdict=1 status=0" in out.stdout or "bccsp/sw" in out.stdout
+
+
 def test_no_device_fails_loudly_never_falls_back():
     import torch
     if torch.cuda.is_available():
