@@ -86,6 +86,25 @@ def test_edge_vectors(ctx):
         assert s == v["status"] and b == (v["status"] == 0), v["name"]
 
 
+def test_rfc6979_public_vectors(ctx):
+    f = json.load(open(os.path.join(G, "rfc6979_p256_sha256.json")))
+    qx, qy = _h32(f["qx"]), _h32(f["qy"])
+    rows = []
+    for v in f["vectors"]:
+        s = int(v["s"], 16)
+        rows.append((v["message"].encode(), _h32(v["r"]), _h32(v["s"]), po.ST_VALID if po.is_low_s(s) else po.ST_HIGH_S))
+        rows.append((v["message"].encode(), _h32(v["r"]), (po.N - s).to_bytes(32, "big"), po.ST_VALID if po.is_low_s(po.N - s) else po.ST_HIGH_S))
+    msgs = [m for m, _, _, _ in rows]
+    off = np.concatenate([[0], np.cumsum([len(m) for m in msgs])]).astype(np.uint32)
+    arena = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8)
+    n = len(rows)
+    bits, st = ctx.sha256_p256_verify_batch(arena, off, _arr([qx] * n), _arr([qy] * n), _arr([r for _, r, _, _ in rows]), _arr([s for _, _, s, _ in rows]))
+    assert list(st) == [w for _, _, _, w in rows] and list(bits) == [w == 0 for _, _, _, w in rows]
+    kid = ctx.key_register(qx, qy)
+    bits2, st2 = ctx.sha256_p256_verify_batch_keyed(arena, off, np.full(n, kid, dtype=np.uint32), _arr([r for _, r, _, _ in rows]), _arr([s for _, _, s, _ in rows]))
+    assert (st2 == st).all()
+
+
 # ---- seeded random batches vs oracle, ragged sizes ---------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4097, 32767, 32768, 32769])
 def test_verify_batch_sizes(ctx, n):

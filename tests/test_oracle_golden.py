@@ -155,3 +155,20 @@ def test_identity_verify_flow():
     assert coracle.bccsp_verify(qx, qy, sig, hashlib.sha256(msg).digest()) == 0
     assert coracle.bccsp_verify(qx, qy, sig, hashlib.sha256(msg + b"x").digest()) == 1
     assert coracle.bccsp_verify(qx, qy, bad, hashlib.sha256(msg).digest()) == 2
+
+
+def test_rfc6979_public_vectors_pin_the_oracle():
+    """RFC 6979 A.2.5 (P-256 / SHA-256): vectors published independently of the reference and of this repository."""
+    f = json.load(open(os.path.join(G, "rfc6979_p256_sha256.json")))
+    qx, qy, d = int(f["qx"], 16), int(f["qy"], 16), int(f["private_key"], 16)
+    assert po.pt_mul(d, (po.GX, po.GY)) == (qx, qy)
+    for v in f["vectors"]:
+        dig = hashlib.sha256(v["message"].encode()).digest()
+        r, s = int(v["r"], 16), int(v["s"], 16)
+        assert po.ecdsa_verify_raw(qx, qy, dig, r, s)
+        want = po.ST_VALID if po.is_low_s(s) else po.ST_HIGH_S
+        assert coracle.verify_one(_h32(f["qx"]), _h32(f["qy"]), dig, _h32(v["r"]), _h32(v["s"])) == want
+        assert coracle.verify_one(_h32(f["qx"]), _h32(f["qy"]), dig, _h32(v["r"]), (po.N - s).to_bytes(32, "big")) == \
+            (po.ST_VALID if po.is_low_s(po.N - s) else po.ST_HIGH_S)
+        assert coracle.verify_one(_h32(f["qx"]), _h32(f["qy"]), hashlib.sha256(b"x" + v["message"].encode()).digest(), _h32(v["r"]),
+                                  min(s, po.N - s).to_bytes(32, "big")) == po.ST_BAD_MATH
