@@ -559,8 +559,10 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
     const bool prefixed = b->n_prefixes != 0 && b->pre_idx != nullptr;
     if (!b->arena || !b->off || !b->r || !b->s || !b->verdict_bits || (!keyed && (!b->qx || !b->qy))) return FABGPU_EINVAL;
     if (prefixed && (!b->pre_off || !mid_scratch)) return FABGPU_EINVAL;
+    if (b->flags & ~(uint32_t)FABGPU_IDB_SPANS) return FABGPU_EINVAL;
     if (n > 0xFFFFFFF0ull || b->arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
     ShaPrefixArgs pa;
+    pa.spans = (b->flags & FABGPU_IDB_SPANS) != 0;
     if (prefixed) {
         pa.m = b->n_prefixes;
         pa.pre_off = b->pre_off;
@@ -609,33 +611,38 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     // the span of the arena that messages and prefixes reference
+    const bool spans = (b->flags & FABGPU_IDB_SPANS) != 0;
+    if (b->flags & ~(uint32_t)FABGPU_IDB_SPANS) return FABGPU_EINVAL;
+    const size_t noff = spans ? 2 * n : n + 1, npre = m ? (spans ? 2 * (size_t)m : (size_t)m + 1) : 0;
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
     for (size_t i = 0; i < n; i++) {
-        if (b->off[i + 1] < b->off[i]) return FABGPU_EINVAL;
-        if (b->off[i] < lo) lo = b->off[i];
-        if (b->off[i + 1] > hi) hi = b->off[i + 1];
+        uint32_t s0 = b->off[spans ? 2 * i : i], s1 = b->off[spans ? 2 * i + 1 : i + 1];
+        if (s1 < s0) return FABGPU_EINVAL;
+        if (s0 < lo) lo = s0;
+        if (s1 > hi) hi = s1;
     }
     for (uint32_t p = 0; p < m; p++) {
-        if (b->pre_off[p + 1] < b->pre_off[p]) return FABGPU_EINVAL;
-        if (b->pre_off[p] < lo) lo = b->pre_off[p];
-        if (b->pre_off[p + 1] > hi) hi = b->pre_off[p + 1];
+        uint32_t s0 = b->pre_off[spans ? 2 * p : p], s1 = b->pre_off[spans ? 2 * p + 1 : p + 1];
+        if (s1 < s0) return FABGPU_EINVAL;
+        if (s0 < lo) lo = s0;
+        if (s1 > hi) hi = s1;
     }
     size_t span = hi >= lo ? (size_t)hi - lo : 0;
     if (span && !arena) return FABGPU_EINVAL;
-    const size_t fb = n * 32, ib = round_up(n * 4, 64), pob = round_up(((size_t)m + 1) * 4, 64), words = (n + 63) / 64;
+    const size_t fb = n * 32, ib = round_up(n * 4, 64), pob = round_up((npre + 1) * 4, 64), words = (n + 63) / 64;
     const size_t st_off = round_up(words * 8, 64), ab = round_up(span, 4) + 64;
     int rc;
-    if ((rc = ctx->arena.ensure(ab + 64)) || (rc = ctx->offs.ensure((n + 1) * 4)) || (rc = ctx->fields.ensure(4 * fb + ib)) ||
+    if ((rc = ctx->arena.ensure(ab + 64)) || (rc = ctx->offs.ensure(noff * 4)) || (rc = ctx->fields.ensure(4 * fb + ib)) ||
         (rc = ctx->out.ensure(st_off + n)) || (rc = ctx->pre.ensure(pob + ib + (size_t)m * 32 + 64)))
         return rc;
     if (span) memcpy(ctx->arena.h, arena + lo, span);
     memset((uint8_t*)ctx->arena.h + span, 0, ab - span);
     uint32_t* ho = (uint32_t*)ctx->offs.h;
-    for (size_t i = 0; i <= n; i++) ho[i] = b->off[i] - lo;
+    for (size_t i = 0; i < noff; i++) ho[i] = b->off[i] - lo;
     uint8_t* ph = (uint8_t*)ctx->pre.h;
     if (m) {
         uint32_t* po = (uint32_t*)ph;
-        for (uint32_t p = 0; p <= m; p++) po[p] = b->pre_off[p] - lo;
+        for (size_t p = 0; p < npre; p++) po[p] = b->pre_off[p] - lo;
         memcpy(ph + pob, b->pre_idx, n * 4);
     }
     uint8_t* fh = (uint8_t*)ctx->fields.h;
@@ -646,7 +653,7 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
         memcpy(fh, b->qx, fb); memcpy(fh + fb, b->qy, fb); memcpy(fh + 2 * fb, b->r, fb); memcpy(fh + 3 * fb, b->s, fb);
     }
     hipError_t err = hipMemcpyAsync(ctx->arena.d, ctx->arena.h, ab, hipMemcpyHostToDevice, ctx->stream);
-    if (err == hipSuccess) err = hipMemcpyAsync(ctx->offs.d, ctx->offs.h, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(ctx->offs.d, ctx->offs.h, noff * 4, hipMemcpyHostToDevice, ctx->stream);
     if (err == hipSuccess && m) err = hipMemcpyAsync(ctx->pre.d, ctx->pre.h, pob + ib, hipMemcpyHostToDevice, ctx->stream);
     if (err == hipSuccess) err = hipMemcpyAsync(ctx->fields.d, ctx->fields.h, keyed ? ib + 2 * fb : 4 * fb, hipMemcpyHostToDevice, ctx->stream);
     if (err != hipSuccess) return hip_to_rc(err);

@@ -19,6 +19,7 @@ struct ShaPrefixArgs {
     const void* pre_off = nullptr;
     const void* pre_idx = nullptr;
     void* mid_scratch = nullptr;
+    bool spans = false;   // off / pre_off hold (start, end) pairs
 };
 struct VerifyGeom {
     uint32_t block;   // threads per workgroup

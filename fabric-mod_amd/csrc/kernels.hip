@@ -139,16 +139,17 @@ __device__ __forceinline__ void sha256_lane(const uint32_t* __restrict__ arena32
 // mid[p] with the prefix's last (len mod 64) bytes followed by its own suffix.
 struct sha_prefixes {
     const uint32_t* pre_idx;   // per message: prefix index, or 0xFFFFFFFF for none; nullptr = the batch has no prefixes
-    const uint32_t* pre_off;   // m + 1 offsets into the arena
+    const uint32_t* pre_off;   // m + 1 offsets into the arena (spans: m (start, end) pairs)
     const uint32_t* mid;       // m x 8 words, written by sha256_midstate_kernel
     uint32_t m;
+    uint32_t spans;            // 1: off / pre_off hold (start, end) pairs instead of n + 1 consecutive offsets
 };
 __global__ void __launch_bounds__(256) sha256_midstate_kernel(uint32_t m, const uint32_t* __restrict__ arena32, uint32_t arena_words,
-                                                               const uint32_t* __restrict__ pre_off, uint32_t* __restrict__ mid) {
+                                                               const uint32_t* __restrict__ pre_off, uint32_t spans, uint32_t* __restrict__ mid) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = p < m;
     uint32_t pc = active ? p : (m - 1);
-    uint32_t start = pre_off[pc], len = pre_off[pc + 1] - start;
+    uint32_t start = pre_off[spans ? 2 * pc : pc], len = pre_off[spans ? 2 * pc + 1 : pc + 1] - start;
     uint32_t nfull = active ? (len >> 6) : 0, maxfull = nfull;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -182,14 +183,14 @@ __global__ void __launch_bounds__(256) sha256_midstate_kernel(uint32_t m, const 
 // The digest of message i of a (possibly prefixed) batch, in h.
 __device__ __forceinline__ void sha256_message(const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
                                                const sha_prefixes& pre, uint32_t ic, bool active, uint32_t h[8]) {
-    uint32_t start = off[ic], len = off[ic + 1] - start;
+    uint32_t start = off[pre.spans ? 2 * ic : ic], len = off[pre.spans ? 2 * ic + 1 : ic + 1] - start;
     if (pre.pre_idx == nullptr) {                       // wave-uniform
         sha256_lane(arena32, arena_words, start, len, active, h);
         return;
     }
     uint32_t pi = pre.pre_idx[ic];
     bool has = pi < pre.m;
-    uint32_t ps = has ? pre.pre_off[pi] : 0, pl = has ? pre.pre_off[pi + 1] - ps : 0;
+    uint32_t ps = has ? pre.pre_off[pre.spans ? 2 * pi : pi] : 0, pl = has ? pre.pre_off[pre.spans ? 2 * pi + 1 : pi + 1] - ps : 0;
     uint32_t base = pl & ~63u, tail = pl & 63u;
     sha256_iv(h);
     if (has && base) {
@@ -525,11 +526,11 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n
 // ------------------------------------------------------------------------------------------------
 // Runs the mid-state kernel for a prefixed batch (no-op otherwise) and returns the descriptor the fused kernels take.
 static sha_prefixes launch_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st) {
-    sha_prefixes pre{nullptr, nullptr, nullptr, 0};
+    sha_prefixes pre{nullptr, nullptr, nullptr, 0, pa.spans ? 1u : 0u};
     if (pa.m == 0 || pa.pre_idx == nullptr) return pre;
     dim3 grid((pa.m + 255) / 256), block(256);
     hipLaunchKernelGGL(sha256_midstate_kernel, grid, block, 0, st, pa.m, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                       (const uint32_t*)pa.pre_off, (uint32_t*)pa.mid_scratch);
+                       (const uint32_t*)pa.pre_off, pre.spans, (uint32_t*)pa.mid_scratch);
     pre.pre_idx = (const uint32_t*)pa.pre_idx;
     pre.pre_off = (const uint32_t*)pa.pre_off;
     pre.mid = (const uint32_t*)pa.mid_scratch;

@@ -47,7 +47,7 @@ class _IdBatch(ctypes.Structure):
     _fields_ = [("n", ctypes.c_size_t), ("arena", ctypes.c_void_p), ("arena_bytes", ctypes.c_size_t), ("off", ctypes.c_void_p),
                 ("n_prefixes", ctypes.c_uint32), ("pre_off", ctypes.c_void_p), ("pre_idx", ctypes.c_void_p), ("qx", ctypes.c_void_p),
                 ("qy", ctypes.c_void_p), ("key_id", ctypes.c_void_p), ("r", ctypes.c_void_p), ("s", ctypes.c_void_p),
-                ("verdict_bits", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+                ("verdict_bits", ctypes.c_void_p), ("status", ctypes.c_void_p), ("flags", ctypes.c_uint32)]
 
 
 class _Cfg(ctypes.Structure):
@@ -291,14 +291,15 @@ class Context:
         _check(self._L.fabgpu_sha256_p256_verify_batch_keyed_dev(self._h, n, arena, arena_bytes, off, key_id, r, s, verdict_bits,
                                                                   status or None, stream or None), "fabgpu_sha256_p256_verify_batch_keyed_dev")
 
-    def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True):
+    def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True, spans=False):
         """fabgpu_identity_verify_batch: message i = [prefix pre_idx[i]] || arena[off[i], off[i+1]); keys by value or by id."""
         arena, r, s = map(_a8, (arena, r, s))
         off = np.ascontiguousarray(off, dtype=np.uint32)
-        n = off.size - 1
+        n = off.size // 2 if spans else off.size - 1
         keep = [arena, off, r, s]
         b = _IdBatch()
         b.n = n
+        b.flags = 1 if spans else 0
         b.arena, b.off, b.r, b.s = arena.ctypes.data, off.ctypes.data, r.ctypes.data, s.ctypes.data
         if key_id is not None:
             key_id = np.ascontiguousarray(key_id, dtype=np.uint32); keep.append(key_id)
@@ -309,7 +310,7 @@ class Context:
         if pre_idx is not None:
             pre_off = np.ascontiguousarray(pre_off, dtype=np.uint32); pre_idx = np.ascontiguousarray(pre_idx, dtype=np.uint32)
             keep += [pre_off, pre_idx]
-            b.n_prefixes, b.pre_off, b.pre_idx = pre_off.size - 1, pre_off.ctypes.data, pre_idx.ctypes.data
+            b.n_prefixes, b.pre_off, b.pre_idx = (pre_off.size // 2 if spans else pre_off.size - 1), pre_off.ctypes.data, pre_idx.ctypes.data
         bits = np.zeros((n + 63) // 64, dtype=np.uint64)
         st = np.zeros(n, dtype=np.uint8) if want_status else None
         b.verdict_bits = bits.ctypes.data

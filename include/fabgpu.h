@@ -152,7 +152,10 @@ typedef struct fabgpu_identity_batch {
     const void* s;
     void* verdict_bits;          /* ceil(n/64) x u64 */
     void* status;                /* n bytes or NULL */
+    uint32_t flags;              /* FABGPU_IDB_* */
 } fabgpu_identity_batch;
+#define FABGPU_IDB_SPANS 1u /* off holds n (start, end) pairs and pre_off n_prefixes pairs: messages are arbitrary sub-slices of the arena
+                             (a marshalled block), not consecutive */
 int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch);
 int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch, void* mid_scratch, void* stream);
 

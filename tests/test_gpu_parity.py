@@ -252,6 +252,15 @@ def test_identity_batch_with_shared_prefixes_vs_hashlib_and_oracle(ctx, keyed):
     # and without any prefix the described entry point equals the plain one
     bits3, st3 = ctx.identity_verify_batch(marena, moff, b["r"], b["s"], **kw)
     assert (st3 == st).all()
+    # span mode (FABGPU_IDB_SPANS): the same messages as (start, end) pairs in a permuted order, prefixes as pairs too
+    perm = rng.permutation(n)
+    offa = np.array(off, dtype=np.uint32)
+    spans = np.stack([offa[:-1][perm], offa[1:][perm]], axis=1).reshape(-1)
+    poa = np.array(pre_off, dtype=np.uint32)
+    pspans = np.stack([poa[:-1], poa[1:]], axis=1).reshape(-1)
+    kw2 = {k: v[perm] for k, v in kw.items()}
+    bits4, st4 = ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True, **kw2)
+    assert (st4 == st[perm]).all() and (bits4 == bits[perm]).all()
 
 
 # ---- SHA-256 ----------------------------------------------------------------------------------------
