@@ -116,4 +116,50 @@ int fabgpu_csp_identity_verify_batch(fabgpu_csp* csp, size_t n, const uint8_t* q
     return FABGPU_OK;
 }
 
+int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len, uint32_t* n_tx, uint8_t* tx_flags, uint8_t* tx_type,
+                               uint32_t cap_tx, uint32_t* n_tuples, uint32_t* tuple_tx, uint8_t* tuple_kind, uint8_t* tuple_status,
+                               uint32_t cap_tuples) {
+    if (!csp || !block || !n_tx || !n_tuples) return FABGPU_EINVAL;
+    BlockVerdicts v;
+    Error e = csp->csp->PreVerifyBlock(block, len, v);
+    if (!e.ok()) return e.msg.find("does not parse") != std::string::npos ? FABGPU_EINVAL : FABGPU_ELAUNCH;
+    *n_tx = v.n_tx;
+    *n_tuples = (uint32_t)v.tuple_tx.size();
+    if (v.n_tx > cap_tx || v.tuple_tx.size() > cap_tuples) return FABGPU_ETOOBIG;   // counts are set: retry with room
+    if (tx_flags && v.n_tx) memcpy(tx_flags, v.tx_flags.data(), v.n_tx);
+    if (tx_type && v.n_tx) memcpy(tx_type, v.tx_type.data(), v.n_tx);
+    size_t nt = v.tuple_tx.size();
+    if (tuple_tx && nt) memcpy(tuple_tx, v.tuple_tx.data(), nt * 4);
+    if (tuple_kind && nt) memcpy(tuple_kind, v.tuple_kind.data(), nt);
+    if (tuple_status && nt) memcpy(tuple_status, v.tuple_status.data(), nt);
+    return FABGPU_OK;
+}
+
+// pure host: structure of a marshalled block as the pre-verify pass sees it
+int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
+                       char* channel_id, size_t channel_cap) {
+    if (!block || !n_tx || !n_tuples) return FABGPU_EINVAL;
+    ParsedBlock pb;
+    if (!ParseBlock(block, len, pb)) return FABGPU_EINVAL;
+    *n_tx = pb.n_tx;
+    *n_tuples = (uint32_t)pb.tuples.size();
+    if (n_prefixes) *n_prefixes = (uint32_t)pb.prefixes.size();
+    if (tx_type)
+        for (uint32_t t = 0; t < pb.n_tx && t < cap_tx; t++) tx_type[t] = pb.tx_type[t];
+    put_err(channel_id, channel_cap, pb.first_channel_id);
+    return FABGPU_OK;
+}
+
+// pure host: P-256 public key of a PEM (is_pem != 0) or DER x509 certificate; 0 ok, 1 not a P-256 certificate
+int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t* qx32, uint8_t* qy32) {
+    if (!cert || !qx32 || !qy32) return FABGPU_EINVAL;
+    std::vector<uint8_t> der;
+    if (is_pem) {
+        if (!PemToDer(cert, len, der)) return 1;
+        cert = der.data();
+        len = der.size();
+    }
+    return CertDerToP256(cert, len, qx32, qy32) ? 0 : 1;
+}
+
 }  // extern "C"

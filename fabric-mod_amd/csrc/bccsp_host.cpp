@@ -376,6 +376,134 @@ Error GPUCSP::IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::v
     return Error();
 }
 
+// ------------------------------------------------------------------------------------------------
+// block-level pre-verify pass (block_prepass.h)
+// ------------------------------------------------------------------------------------------------
+Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const {
+    out = BlockVerdicts();
+    ParsedBlock pb;
+    if (!block || !ParseBlock(block, len, pb)) return Error("block does not parse as common.Block");
+    const size_t nt = pb.tuples.size();
+    out.n_tx = pb.n_tx;
+    out.tx_type = pb.tx_type;
+    out.tx_flags.assign(pb.n_tx, TX_ALL_SIGNATURES_VALID);
+    for (uint32_t t = 0; t < pb.n_tx; t++)
+        if (!pb.tx_understood[t]) out.tx_flags[t] = TX_NOT_UNDERSTOOD;
+    out.tuple_tx.resize(nt);
+    out.tuple_kind.resize(nt);
+    out.tuple_status.assign(nt, FABGPU_ST_VALID);
+    // identities -> keys (cached across blocks), signatures -> (r, s) through the reference's gates
+    std::vector<uint32_t> sub;                       // tuples the device decides
+    std::vector<uint8_t> qx, qy, r, s;
+    std::vector<uint32_t> ids;
+    bool all_keyed = true;
+    static const uint8_t one_digest[1] = {1};
+    for (size_t i = 0; i < nt; i++) {
+        const BlockTuple& tp = pb.tuples[i];
+        out.tuple_tx[i] = tp.tx;
+        out.tuple_kind[i] = tp.kind;
+        CachedIdentity ci;
+        {
+            std::string key((const char*)block + tp.identity.off, tp.identity.len);
+            std::lock_guard<std::mutex> lk(idmu_);
+            auto it = idcache_.find(key);
+            if (it == idcache_.end()) {
+                out.distinct_identities++;
+                ci.p256 = IdentityToP256(block + tp.identity.off, tp.identity.len, ci.qx, ci.qy) && PublicKeyOnCurve(ci.qx, ci.qy);
+                if (ci.p256) {
+                    uint32_t id = 0;
+                    if (fabgpu_p256_key_register(ctx_, ci.qx, ci.qy, &id) == FABGPU_OK) ci.key_id = id;
+                }
+                idcache_[key] = ci;
+            } else {
+                ci = it->second;
+            }
+        }
+        if (!ci.p256) {
+            out.tuple_status[i] = TUPLE_ST_NEEDS_SW;
+            continue;
+        }
+        if (tp.sig.len == 0) {
+            out.tuple_status[i] = TUPLE_ST_EMPTY_SIG;
+            continue;
+        }
+        ECDSAPublicKey k;
+        memcpy(k.x, ci.qx, 32);
+        memcpy(k.y, ci.qy, 32);
+        k.on_curve = true;
+        Gate g = gate_item(&k, block + tp.sig.off, tp.sig.len, one_digest, 1);
+        if (!g.submit) {
+            if (g.res.err.ok()) out.tuple_status[i] = FABGPU_ST_RANGE;                                   // r >= n: (false, nil)
+            else if (g.res.err.msg.find("Invalid S") != std::string::npos) out.tuple_status[i] = FABGPU_ST_HIGH_S;
+            else out.tuple_status[i] = TUPLE_ST_BAD_DER;
+            continue;
+        }
+        sub.push_back((uint32_t)i);
+        qx.insert(qx.end(), ci.qx, ci.qx + 32);
+        qy.insert(qy.end(), ci.qy, ci.qy + 32);
+        r.insert(r.end(), g.r32, g.r32 + 32);
+        s.insert(s.end(), g.s32, g.s32 + 32);
+        ids.push_back(ci.key_id >= 0 ? (uint32_t)ci.key_id : 0);
+        if (ci.key_id < 0) all_keyed = false;
+    }
+    const size_t n = sub.size();
+    if (n) {
+        std::vector<uint32_t> off(2 * n), pre_idx(n), pre_off(2 * pb.prefixes.size() + 2);
+        for (size_t p = 0; p < pb.prefixes.size(); p++) {
+            pre_off[2 * p] = pb.prefixes[p].off;
+            pre_off[2 * p + 1] = pb.prefixes[p].off + pb.prefixes[p].len;
+        }
+        for (size_t j = 0; j < n; j++) {
+            const BlockTuple& tp = pb.tuples[sub[j]];
+            off[2 * j] = tp.suffix.off;
+            off[2 * j + 1] = tp.suffix.off + tp.suffix.len;
+            pre_idx[j] = tp.prefix_index >= 0 ? (uint32_t)tp.prefix_index : 0xFFFFFFFFu;
+        }
+        std::vector<uint64_t> bits((n + 63) / 64);
+        std::vector<uint8_t> st(n);
+        fabgpu_identity_batch d;
+        memset(&d, 0, sizeof(d));
+        d.n = n;
+        d.arena = block;
+        d.off = off.data();
+        d.n_prefixes = (uint32_t)pb.prefixes.size();
+        d.pre_off = pre_off.data();
+        d.pre_idx = pre_idx.data();
+        if (all_keyed) {
+            d.key_id = ids.data();
+        } else {
+            d.qx = qx.data();
+            d.qy = qy.data();
+        }
+        d.r = r.data();
+        d.s = s.data();
+        d.verdict_bits = bits.data();
+        d.status = st.data();
+        d.flags = FABGPU_IDB_SPANS;
+        int rc = fabgpu_identity_verify_batch(ctx_, &d);
+        if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
+        for (size_t j = 0; j < n; j++) {
+            bool bit = (bits[j >> 6] >> (j & 63)) & 1;
+            out.tuple_status[sub[j]] = (bit && st[j] == FABGPU_ST_VALID) ? FABGPU_ST_VALID : (st[j] == FABGPU_ST_VALID ? FABGPU_ST_BAD_MATH : st[j]);
+        }
+    }
+    // per-transaction summary: not understood > bad creator signature > bad endorsement > "ask bccsp/sw" > all valid
+    std::vector<uint8_t> bad_creator(pb.n_tx, 0), bad_end(pb.n_tx, 0), sw(pb.n_tx, 0);
+    for (size_t i = 0; i < nt; i++) {
+        uint8_t stt = out.tuple_status[i];
+        if (stt == FABGPU_ST_VALID) continue;
+        uint32_t t = out.tuple_tx[i];
+        if (stt == TUPLE_ST_NEEDS_SW) sw[t] = 1;
+        else if (out.tuple_kind[i] == TUPLE_CREATOR) bad_creator[t] = 1;
+        else bad_end[t] = 1;
+    }
+    for (uint32_t t = 0; t < pb.n_tx; t++) {
+        if (out.tx_flags[t] == TX_NOT_UNDERSTOOD) continue;
+        out.tx_flags[t] = bad_creator[t] ? TX_BAD_CREATOR_SIGNATURE : bad_end[t] ? TX_BAD_ENDORSEMENT : sw[t] ? TX_NEEDS_SW : TX_ALL_SIGNATURES_VALID;
+    }
+    return Error();
+}
+
 }  // namespace bccsp
 }  // namespace fab
 

@@ -10,7 +10,11 @@
 #include <string>
 #include <vector>
 
+#include <map>
+#include <mutex>
+
 #include "../../include/fabgpu.h"
+#include "block_prepass.h"
 
 namespace fab {
 namespace bccsp {
@@ -68,6 +72,16 @@ struct IdentityItem {
     size_t siglen;
 };
 
+struct BlockVerdicts {
+    uint32_t n_tx = 0;
+    std::vector<uint8_t> tx_flags;        // TX_* per transaction
+    std::vector<uint8_t> tx_type;         // ChannelHeader.type (255: envelope not parsed)
+    std::vector<uint32_t> tuple_tx;       // per tuple: owning transaction
+    std::vector<uint8_t> tuple_kind;      // TUPLE_CREATOR / TUPLE_ENDORSEMENT
+    std::vector<uint8_t> tuple_status;    // device status 0..4 or TUPLE_ST_*
+    uint32_t distinct_identities = 0;     // identities of this block that were not in the cache yet
+};
+
 class GPUCSP {
    public:
     static Error New(const fabgpu_cfg* cfg, std::unique_ptr<GPUCSP>& out);
@@ -79,11 +93,21 @@ class GPUCSP {
     VerifyResult Verify(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) const;
     Error VerifyBatch(const std::vector<VerifyItem>& items, std::vector<VerifyResult>& results) const;
     Error IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::vector<std::string>& out) const;
+    // Block-level pre-verify pass (block_prepass.h): one fused launch for every creator / endorsement signature of the block.
+    Error PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const;
     fabgpu_ctx* ctx() const { return ctx_; }
 
    private:
     explicit GPUCSP(fabgpu_ctx* c) : ctx_(c) {}
     fabgpu_ctx* ctx_;
+    // identity cache of the pre-verify pass (msp/cache/cache.go): SerializedIdentity bytes -> P-256 key + device key id
+    struct CachedIdentity {
+        bool p256 = false;
+        uint8_t qx[32], qy[32];
+        int64_t key_id = -1;
+    };
+    mutable std::mutex idmu_;
+    mutable std::map<std::string, CachedIdentity> idcache_;
 };
 
 }  // namespace bccsp

@@ -1,0 +1,279 @@
+// Block walker + identity decoding of the pre-verify pass (block_prepass.h).  Host only, no device code, no crypto:
+// protobuf wire format, PEM/base64, and just enough DER to reach SubjectPublicKeyInfo.
+#include "block_prepass.h"
+
+#include <string.h>
+
+namespace fab {
+namespace bccsp {
+
+namespace {
+
+// ---- protobuf wire format ---------------------------------------------------------------------------------------
+struct PbField {
+    uint32_t num = 0, wt = 0;
+    uint64_t varint = 0;
+    const uint8_t* data = nullptr;   // wire type 2
+    size_t len = 0;
+};
+struct PbReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool ok = true;
+    PbReader(const uint8_t* b, size_t n) : p(b), end(b + n) {}
+    bool varint(uint64_t& v) {
+        v = 0;
+        for (int shift = 0; shift < 64; shift += 7) {
+            if (p >= end) return false;
+            uint8_t c = *p++;
+            v |= (uint64_t)(c & 0x7F) << shift;
+            if (!(c & 0x80)) return true;
+        }
+        return false;
+    }
+    // next field; false at the end of the buffer or on malformed input (then ok == false)
+    bool next(PbField& f) {
+        if (p >= end) return false;
+        uint64_t key;
+        if (!varint(key)) return ok = false;
+        f.num = (uint32_t)(key >> 3);
+        f.wt = (uint32_t)(key & 7);
+        f.data = nullptr;
+        f.len = 0;
+        switch (f.wt) {
+            case 0: return varint(f.varint) ? true : (ok = false);
+            case 1: if (end - p < 8) return ok = false; p += 8; return true;
+            case 5: if (end - p < 4) return ok = false; p += 4; return true;
+            case 2: {
+                uint64_t n;
+                if (!varint(n) || n > (uint64_t)(end - p)) return ok = false;
+                f.data = p;
+                f.len = (size_t)n;
+                p += n;
+                return true;
+            }
+            default: return ok = false;
+        }
+    }
+};
+
+// first occurrence of length-delimited field `num`
+bool pb_bytes(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t& outlen) {
+    PbReader r(b, n);
+    PbField f;
+    while (r.next(f))
+        if (f.num == num && f.wt == 2) {
+            out = f.data;
+            outlen = f.len;
+            return true;
+        }
+    return false;
+}
+
+Span span_of(const uint8_t* base, const uint8_t* p, size_t n) {
+    Span s;
+    s.off = (uint32_t)(p - base);
+    s.len = (uint32_t)n;
+    return s;
+}
+
+// ---- DER ------------------------------------------------------------------------------------------------------------------
+struct Der {
+    const uint8_t* p;
+    const uint8_t* end;
+    // reads one TLV header; on success tag / content / len describe it and p is advanced past the whole element
+    bool tlv(uint8_t& tag, const uint8_t*& content, size_t& len) {
+        if (end - p < 2) return false;
+        tag = *p++;
+        size_t l = *p++;
+        if (l & 0x80) {
+            int nb = (int)(l & 0x7F);
+            if (nb == 0 || nb > 4 || end - p < nb) return false;
+            l = 0;
+            for (int i = 0; i < nb; i++) l = (l << 8) | *p++;
+        }
+        if ((size_t)(end - p) < l) return false;
+        content = p;
+        len = l;
+        p += l;
+        return true;
+    }
+};
+
+const uint8_t OID_EC_PUBLIC_KEY[] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x02, 0x01};          // 1.2.840.10045.2.1
+const uint8_t OID_PRIME256V1[] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x03, 0x01, 0x07};       // 1.2.840.10045.3.1.7
+
+int b64val(uint8_t c) {
+    if (c >= 'A' && c <= 'Z') return c - 'A';
+    if (c >= 'a' && c <= 'z') return c - 'a' + 26;
+    if (c >= '0' && c <= '9') return c - '0' + 52;
+    if (c == '+') return 62;
+    if (c == '/') return 63;
+    return -1;
+}
+
+}  // namespace
+
+bool PemToDer(const uint8_t* pem, size_t len, std::vector<uint8_t>& der) {
+    static const char BEGIN[] = "-----BEGIN CERTIFICATE-----";
+    static const char END[] = "-----END CERTIFICATE-----";
+    const size_t bl = sizeof(BEGIN) - 1, el = sizeof(END) - 1;
+    size_t i = 0;
+    while (i + bl <= len && memcmp(pem + i, BEGIN, bl) != 0) i++;
+    if (i + bl > len) return false;
+    i += bl;
+    der.clear();
+    uint32_t acc = 0;
+    int bits = 0;
+    for (; i < len; i++) {
+        uint8_t c = pem[i];
+        if (c == '-') break;
+        if (c == '=' || c == '\n' || c == '\r' || c == ' ' || c == '\t') continue;
+        int v = b64val(c);
+        if (v < 0) return false;
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            der.push_back((uint8_t)(acc >> bits));
+        }
+    }
+    if (i + el > len || memcmp(pem + i, END, el) != 0) return false;
+    return !der.empty();
+}
+
+bool CertDerToP256(const uint8_t* der, size_t len, uint8_t qx[32], uint8_t qy[32]) {
+    Der top{der, der + len};
+    uint8_t tag;
+    const uint8_t* c;
+    size_t l;
+    if (!top.tlv(tag, c, l) || tag != 0x30) return false;             // Certificate
+    Der cert{c, c + l};
+    if (!cert.tlv(tag, c, l) || tag != 0x30) return false;            // TBSCertificate
+    Der tbs{c, c + l};
+    if (!tbs.tlv(tag, c, l)) return false;
+    if (tag == 0xA0) {                                                // [0] version (absent in v1 certificates)
+        if (!tbs.tlv(tag, c, l)) return false;
+    }
+    if (tag != 0x02) return false;                                    // serialNumber
+    for (int k = 0; k < 4; k++)                                       // signature, issuer, validity, subject
+        if (!tbs.tlv(tag, c, l) || tag != 0x30) return false;
+    if (!tbs.tlv(tag, c, l) || tag != 0x30) return false;             // subjectPublicKeyInfo
+    Der spki{c, c + l};
+    if (!spki.tlv(tag, c, l) || tag != 0x30) return false;            // AlgorithmIdentifier
+    Der alg{c, c + l};
+    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != sizeof(OID_EC_PUBLIC_KEY) || memcmp(c, OID_EC_PUBLIC_KEY, l) != 0) return false;
+    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != sizeof(OID_PRIME256V1) || memcmp(c, OID_PRIME256V1, l) != 0) return false;
+    if (!spki.tlv(tag, c, l) || tag != 0x03) return false;            // BIT STRING: 00 04 X Y
+    if (l != 66 || c[0] != 0x00 || c[1] != 0x04) return false;
+    memcpy(qx, c + 2, 32);
+    memcpy(qy, c + 34, 32);
+    return true;
+}
+
+bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy[32]) {
+    const uint8_t* idb;
+    size_t idl;
+    if (!pb_bytes(ident, len, 2, idb, idl)) return false;             // msp.SerializedIdentity{1 mspid, 2 id_bytes}
+    std::vector<uint8_t> der;
+    if (!PemToDer(idb, idl, der)) return false;
+    return CertDerToP256(der.data(), der.size(), qx, qy);
+}
+
+bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out) {
+    out = ParsedBlock();
+    if (len > 0xFFFFFFF0ull) return false;
+    const uint8_t* data;
+    size_t dlen;
+    if (!pb_bytes(block, len, 2, data, dlen)) return false;           // common.Block{1 header, 2 data, 3 metadata}
+    PbReader envs(data, dlen);                                        // common.BlockData{1 repeated bytes data}
+    PbField f;
+    while (envs.next(f)) {
+        if (f.num != 1 || f.wt != 2) continue;
+        const uint32_t tx = out.n_tx++;
+        out.tx_type.push_back(255);
+        out.tx_understood.push_back(0);
+        const uint8_t *payload, *sig, *hdr, *pdata, *chdr, *shdr, *creator;
+        size_t payload_l, sig_l, hdr_l, pdata_l, chdr_l, shdr_l, creator_l;
+        // common.Envelope{1 payload, 2 signature}
+        if (!pb_bytes(f.data, f.len, 1, payload, payload_l)) continue;
+        if (!pb_bytes(f.data, f.len, 2, sig, sig_l)) { sig = payload; sig_l = 0; }
+        // common.Payload{1 header, 2 data}; common.Header{1 channel_header, 2 signature_header}
+        if (!pb_bytes(payload, payload_l, 1, hdr, hdr_l)) continue;
+        if (!pb_bytes(hdr, hdr_l, 1, chdr, chdr_l) || !pb_bytes(hdr, hdr_l, 2, shdr, shdr_l)) continue;
+        // common.ChannelHeader{1 type (varint), ..., 4 channel_id}
+        uint8_t type = 0;   // proto3 default: MESSAGE
+        {
+            PbReader r(chdr, chdr_l);
+            PbField g;
+            while (r.next(g)) {
+                if (g.num == 1 && g.wt == 0) type = (uint8_t)g.varint;
+                if (g.num == 4 && g.wt == 2 && tx == 0) out.first_channel_id.assign((const char*)g.data, g.len);
+            }
+            if (!r.ok) continue;
+        }
+        out.tx_type[tx] = type;
+        // common.SignatureHeader{1 creator, 2 nonce}
+        if (!pb_bytes(shdr, shdr_l, 1, creator, creator_l)) continue;
+        BlockTuple ct;
+        ct.tx = tx;
+        ct.kind = TUPLE_CREATOR;
+        ct.identity = span_of(block, creator, creator_l);
+        ct.suffix = span_of(block, payload, payload_l);
+        ct.sig = span_of(block, sig, sig_l);
+        size_t first_tuple = out.tuples.size();
+        out.tuples.push_back(ct);
+        if (type != 3) {                                               // only ENDORSER_TRANSACTION carries endorsements
+            out.tx_understood[tx] = 1;
+            continue;
+        }
+        if (!pb_bytes(payload, payload_l, 2, pdata, pdata_l)) { out.tuples.resize(first_tuple); continue; }
+        // peer.Transaction{1 repeated actions}; TransactionAction{1 header, 2 payload}
+        bool good = true;
+        PbReader acts(pdata, pdata_l);
+        PbField a;
+        while (acts.next(a)) {
+            if (a.num != 1 || a.wt != 2) continue;
+            const uint8_t *ap, *cea, *prp;
+            size_t ap_l, cea_l, prp_l;
+            // ChaincodeActionPayload{1 chaincode_proposal_payload, 2 action}; ChaincodeEndorsedAction{1 proposal_response_payload, 2 endorsements}
+            if (!pb_bytes(a.data, a.len, 2, ap, ap_l) || !pb_bytes(ap, ap_l, 2, cea, cea_l) || !pb_bytes(cea, cea_l, 1, prp, prp_l)) {
+                good = false;
+                break;
+            }
+            int32_t pidx = (int32_t)out.prefixes.size();
+            out.prefixes.push_back(span_of(block, prp, prp_l));
+            PbReader ends(cea, cea_l);
+            PbField e;
+            while (ends.next(e)) {
+                if (e.num != 2 || e.wt != 2) continue;
+                const uint8_t *endorser, *esig;
+                size_t endorser_l, esig_l;
+                // peer.Endorsement{1 endorser, 2 signature}
+                if (!pb_bytes(e.data, e.len, 1, endorser, endorser_l)) { good = false; break; }
+                if (!pb_bytes(e.data, e.len, 2, esig, esig_l)) { esig = endorser; esig_l = 0; }
+                BlockTuple et;
+                et.tx = tx;
+                et.kind = TUPLE_ENDORSEMENT;
+                et.identity = span_of(block, endorser, endorser_l);
+                et.prefix = span_of(block, prp, prp_l);
+                et.prefix_index = pidx;
+                et.suffix = et.identity;                               // message = prp || endorser
+                et.sig = span_of(block, esig, esig_l);
+                out.tuples.push_back(et);
+            }
+            if (!ends.ok) good = false;
+            if (!good) break;
+        }
+        if (!acts.ok) good = false;
+        if (!good) {
+            out.tuples.resize(first_tuple);                            // leave the whole transaction to the Go validators
+            continue;
+        }
+        out.tx_understood[tx] = 1;
+    }
+    return envs.ok;
+}
+
+}  // namespace bccsp
+}  // namespace fab

@@ -1,0 +1,72 @@
+// Block-level pre-verify pass: walks a marshalled common.Block once, extracts every
+// (identity, message, signature) the validators will ask bccsp to verify, and verifies them in ONE fused launch.
+//
+//   creator signature      identity = SignatureHeader.creator, message = Envelope.payload, signature = Envelope.signature
+//                          (core/common/validation/msgvalidation.go:258-298, checkSignatureFromCreator :26-64)
+//   endorsement signature  identity = Endorsement.endorser, message = proposal_response_payload || Endorsement.endorser,
+//                          signature = Endorsement.signature   (core/common/validation/statebased/validator_keylevel.go:246-258)
+//
+// The block buffer itself is the message arena (FABGPU_IDB_SPANS); each action's proposal_response_payload is a shared
+// prefix hashed once; every identity seen is imported once (x509 -> P-256 point -> fabgpu_p256_key_register: the msp
+// identity cache + BCCSP.KeyImport of the reference, msp/cache/cache.go, msp/mspimpl.go:408-421) so that the block runs on
+// the keyed kernels.  What stays with the Go validators: identity validation (chain, revocation, OUs), endorsement policy
+// evaluation, MVCC.  This pass only answers "would identity.Verify return nil?" for every tuple and seeds the verdict memo.
+//
+// Wire format: protobuf field numbers of github.com/hyperledger/fabric-protos-go (common/common.proto, peer/transaction.proto,
+// peer/proposal_response.proto, msp/identities.proto) - not in the reference tree; the outer layers are pinned by the
+// reference's own block fixtures (tests/test_block_prepass.py).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace fab {
+namespace bccsp {
+
+struct Span {
+    uint32_t off = 0, len = 0;   // into the block buffer
+};
+
+enum : uint8_t { TUPLE_CREATOR = 0, TUPLE_ENDORSEMENT = 1 };
+// per-tuple outcome: 0..4 = the device status codes of include/fabgpu.h, plus
+enum : uint8_t {
+    TUPLE_ST_BAD_DER = 5,        // UnmarshalECDSASignature fails / r,s <= 0: identity.Verify returns an error
+    TUPLE_ST_NEEDS_SW = 6,       // identity is not a PEM x509 certificate with a P-256 key (idemix, other curves): bccsp/sw decides
+    TUPLE_ST_EMPTY_SIG = 7,      // empty signature
+};
+// per-transaction summary
+enum : uint8_t {
+    TX_ALL_SIGNATURES_VALID = 0,
+    TX_BAD_CREATOR_SIGNATURE = 1,   // TxValidationCode_BAD_CREATOR_SIGNATURE territory
+    TX_BAD_ENDORSEMENT = 2,         // at least one endorsement signature does not verify
+    TX_NOT_UNDERSTOOD = 3,          // envelope / payload / transaction did not parse as expected: left to the Go validators
+    TX_NEEDS_SW = 4,                // some identity must be verified by bccsp/sw
+};
+
+struct BlockTuple {
+    uint32_t tx = 0;
+    uint8_t kind = TUPLE_CREATOR;
+    Span identity, prefix, suffix, sig;   // prefix.len == 0 for creator tuples
+    int32_t prefix_index = -1;
+};
+struct ParsedBlock {
+    uint32_t n_tx = 0;
+    std::vector<uint8_t> tx_type;         // ChannelHeader.type per envelope (-> 255 if not parsed)
+    std::vector<uint8_t> tx_understood;
+    std::vector<Span> prefixes;
+    std::vector<BlockTuple> tuples;
+    std::string first_channel_id;         // of envelope 0 (fixture pin)
+};
+
+// Pure parsing (no device): false only if the outer Block / BlockData framing is broken.
+bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out);
+// SerializedIdentity{mspid, id_bytes = PEM x509} -> uncompressed P-256 point.  false: not such an identity.
+bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy[32]);
+// DER x509 certificate -> P-256 SubjectPublicKeyInfo point (exposed for tests against the reference's certificate fixtures)
+bool CertDerToP256(const uint8_t* der, size_t len, uint8_t qx[32], uint8_t qy[32]);
+bool PemToDer(const uint8_t* pem, size_t len, std::vector<uint8_t>& der);
+
+}  // namespace bccsp
+}  // namespace fab

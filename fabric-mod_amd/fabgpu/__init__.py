@@ -66,7 +66,8 @@ ABI_SYMBOLS = [
     "fabgpu_last_kernel_ms", "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
-    "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_synth_batch",
+    "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
+    "fabgpu_synth_batch",
 ]
 
 _lib = None
@@ -123,6 +124,9 @@ def load():
                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
     L.fabgpu_csp_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u32p, _u8p, _u32p, _u8p, ctypes.c_char_p, _sz]
     L.fabgpu_csp_identity_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u32p, _u8p, _u32p, ctypes.c_char_p, _sz]
+    L.fabgpu_csp_block_preverify.argtypes = [_vp, _u8p, _sz, _u32p, _u8p, _u8p, ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_uint32]
+    L.fabgpu_block_parse.argtypes = [_u8p, _sz, _u32p, _u32p, _u32p, _u8p, ctypes.c_uint32, ctypes.c_char_p, _sz]
+    L.fabgpu_x509_p256_pubkey.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
     _lib = L
     return L
@@ -467,6 +471,52 @@ class Identity:
         err = self.csp.identity_verify_batch([self.pk], [msg], [sig])[0]
         if err:
             raise BCCSPError(err)
+
+
+TX_ALL_SIGNATURES_VALID, TX_BAD_CREATOR_SIGNATURE, TX_BAD_ENDORSEMENT, TX_NOT_UNDERSTOOD, TX_NEEDS_SW = 0, 1, 2, 3, 4
+TUPLE_ST_BAD_DER, TUPLE_ST_NEEDS_SW, TUPLE_ST_EMPTY_SIG = 5, 6, 7
+
+
+def block_parse(block: bytes):
+    """Structure of a marshalled common.Block as the pre-verify pass sees it (pure host): dict(n_tx, n_tuples, n_prefixes,
+    tx_type, channel_id)."""
+    L = load()
+    buf = np.frombuffer(block, dtype=np.uint8)
+    n_tx, n_tup, n_pre = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+    cap = 1 << 20
+    tx_type = np.zeros(cap, dtype=np.uint8)
+    ch = ctypes.create_string_buffer(256)
+    rc = L.fabgpu_block_parse(_p8(buf), buf.size, ctypes.byref(n_tx), ctypes.byref(n_tup), ctypes.byref(n_pre), _p8(tx_type), cap, ch, 256)
+    if rc != FABGPU_OK:
+        raise FabgpuError("fabgpu_block_parse failed: %s (%d)" % (strerror(rc), rc))
+    return dict(n_tx=n_tx.value, n_tuples=n_tup.value, n_prefixes=n_pre.value, tx_type=tx_type[:n_tx.value].copy(), channel_id=ch.value.decode(errors="replace"))
+
+
+def x509_p256_pubkey(cert: bytes, pem: bool = True) -> Optional[Tuple[bytes, bytes]]:
+    """(qx, qy) of a P-256 x509 certificate, or None."""
+    qx, qy = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    rc = load().fabgpu_x509_p256_pubkey(cert, len(cert), 1 if pem else 0, qx, qy)
+    return (qx.raw, qy.raw) if rc == 0 else None
+
+
+def preverify_block(csp: "GPUCSP", block: bytes):
+    """fabgpu_csp_block_preverify: every creator / endorsement signature of a marshalled block in one fused launch.
+    Returns dict(tx_flags, tx_type, tuple_tx, tuple_kind, tuple_status)."""
+    buf = np.frombuffer(block, dtype=np.uint8)
+    cap_tx, cap_tu = 1024, 4096
+    while True:
+        n_tx, n_tu = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        tx_flags, tx_type = np.zeros(cap_tx, np.uint8), np.zeros(cap_tx, np.uint8)
+        t_tx, t_kind, t_st = np.zeros(cap_tu, np.uint32), np.zeros(cap_tu, np.uint8), np.zeros(cap_tu, np.uint8)
+        rc = csp._L.fabgpu_csp_block_preverify(csp._h, _p8(buf), buf.size, ctypes.byref(n_tx), _p8(tx_flags), _p8(tx_type), cap_tx, ctypes.byref(n_tu),
+                                               t_tx.ctypes.data_as(_u32p), _p8(t_kind), _p8(t_st), cap_tu)
+        if rc == -5:   # FABGPU_ETOOBIG: counts are set
+            cap_tx, cap_tu = max(cap_tx, n_tx.value), max(cap_tu, n_tu.value)
+            continue
+        _check(rc, "fabgpu_csp_block_preverify")
+        a, b = n_tx.value, n_tu.value
+        return dict(tx_flags=tx_flags[:a].copy(), tx_type=tx_type[:a].copy(), tuple_tx=t_tx[:b].copy(), tuple_kind=t_kind[:b].copy(),
+                    tuple_status=t_st[:b].copy())
 
 
 def validate_block_endorsements(csp: GPUCSP, txs) -> np.ndarray:

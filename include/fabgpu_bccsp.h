@@ -52,6 +52,23 @@ int fabgpu_csp_identity_verify_batch(fabgpu_csp* csp, size_t n, const uint8_t* q
 int fabgpu_synth_batch(size_t n, uint64_t seed, uint32_t invalid_permille, const uint8_t* e_in, uint8_t* qx, uint8_t* qy,
                        uint8_t* e_out, uint8_t* r, uint8_t* s, uint8_t* kind, int threads);
 
+/* ---- block-level pre-verify pass (extensions/validation/validation.go:48-64 is the hook) ----
+ * One fused launch for every signature of a marshalled common.Block:
+ *   creator:      SignatureHeader.creator over Envelope.payload            (core/common/validation/msgvalidation.go:258-298)
+ *   endorsements: Endorsement.endorser over prp || Endorsement.endorser    (.../statebased/validator_keylevel.go:246-258)
+ * Identities (PEM x509, P-256) are imported once and cached (device comb tables), the block buffer is the message arena,
+ * each proposal_response_payload is hashed once.  tx_flags[t]: 0 every signature verifies, 1 creator signature bad,
+ * 2 an endorsement signature bad, 3 not understood (left to the Go validators), 4 an identity needs bccsp/sw.
+ * tuple_status[i]: 0..4 as in fabgpu.h, 5 signature does not unmarshal, 6 identity needs bccsp/sw, 7 empty signature.
+ * Returns FABGPU_ETOOBIG with *n_tx / *n_tuples set when the caller's arrays are too small. */
+int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len, uint32_t* n_tx, uint8_t* tx_flags, uint8_t* tx_type,
+                               uint32_t cap_tx, uint32_t* n_tuples, uint32_t* tuple_tx, uint8_t* tuple_kind, uint8_t* tuple_status,
+                               uint32_t cap_tuples);
+/* pure host helpers of the pass (no device): block structure, and the P-256 key of an x509 certificate */
+int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
+                       char* channel_id, size_t channel_cap);
+int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t* qx32, uint8_t* qy32);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,161 @@
+"""Block-level pre-verify pass: the C++ block walker + x509 key extraction on the CPU, the whole pass
+on the GPU.  Synthetic blocks come from tests/blockbuilder.py (an independent encoder), identities from
+tests/golden/block_identities.json (openssl-generated, test-only keys), signatures from the oracle."""
+import glob
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bccsp_sw_oracle as po
+import blockbuilder as bb
+import fabgpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IDS = json.load(open(os.path.join(ROOT, "tests", "golden", "block_identities.json")))["identities"]
+REF = "/root/reference"
+
+
+def test_x509_key_extraction_on_generated_identities():
+    for i in IDS:
+        got = fabgpu.x509_p256_pubkey(i["pem"].encode())
+        if i["curve"] == "prime256v1":
+            assert got == (bytes.fromhex(i["qx"].rjust(64, "0")), bytes.fromhex(i["qy"].rjust(64, "0")))
+            assert po.pt_mul(int(i["d"], 16), (po.GX, po.GY)) == (int(i["qx"], 16), int(i["qy"], 16))   # the fixture's key pair is consistent
+        else:
+            assert got is None                               # P-384: not ours
+    assert fabgpu.x509_p256_pubkey(b"-----BEGIN CERTIFICATE-----\nAAAA\n-----END CERTIFICATE-----\n") is None
+    assert fabgpu.x509_p256_pubkey(b"not a pem") is None
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_x509_key_extraction_equals_openssl_on_the_reference_certificates():
+    """Every certificate fixture of the reference: the C++ SPKI walker and `openssl x509 -pubkey` agree on (curve, Qx, Qy)."""
+    pems = sorted(glob.glob(REF + "/**/*.pem", recursive=True))
+    checked = 0
+    for path in pems:
+        txt = open(path, "rb").read()
+        if b"BEGIN CERTIFICATE" not in txt:
+            continue
+        r = subprocess.run(["openssl", "x509", "-in", path, "-noout", "-text"], capture_output=True, text=True)
+        if r.returncode != 0:
+            continue
+        is_p256 = "ASN1 OID: prime256v1" in r.stdout
+        got = fabgpu.x509_p256_pubkey(txt)
+        assert (got is not None) == is_p256, path
+        if is_p256:
+            import re
+            pub = re.sub(r"[^0-9a-f]", "", re.search(r"pub:\s*((?:[0-9a-f:]+\s*)+)ASN1 OID", r.stdout).group(1))
+            assert got[0].hex() == pub[2:66] and got[1].hex() == pub[66:130], path
+            checked += 1
+    assert checked >= 100
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_block_walker_on_the_reference_block_fixtures():
+    """The reference's own marshalled blocks pin the outer layers of the walker (Block, BlockData, Envelope, Payload, Header,
+    ChannelHeader, SignatureHeader): one CONFIG envelope on the expected channel."""
+    seen = 0
+    for path, channel in ((REF + "/orderer/common/cluster/testdata/mychannel.block", "mychannel"),
+                          (REF + "/orderer/consensus/etcdraft/testdata/mychannel.block", "mychannel")):
+        if not os.path.exists(path):
+            continue
+        p = fabgpu.block_parse(open(path, "rb").read())
+        assert p["n_tx"] == 1 and p["channel_id"] == channel and list(p["tx_type"]) == [1]      # HeaderType CONFIG
+        assert p["n_prefixes"] == 0 and p["n_tuples"] <= 1
+        seen += 1
+    assert seen >= 1
+
+
+def _sign(ident, msg, k):
+    r, s = po.sign_raw(int(ident["d"], 16), hashlib.sha256(msg).digest(), k)
+    return r, s
+
+
+def build_block(n_tx, rng, corrupt=True):
+    """n_tx endorser transactions x 3 endorsements by 4 endorsers, 2 creators; returns (block bytes, expected tx flags)."""
+    p256 = [i for i in IDS if i["curve"] == "prime256v1"]
+    p384 = [i for i in IDS if i["curve"] != "prime256v1"][0]
+    sid = {i["cn"]: bb.serialized_identity("Org1MSP", i["pem"]) for i in IDS}
+    endorsers, creators = p256[:4], p256[4:6]
+    envs, want = [], []
+    for t in range(n_tx):
+        creator = creators[t % 2]
+        cbytes = sid[creator["cn"]]
+        prp = bytes(rng.integers(0, 256, size=int(rng.integers(100, 1200)), dtype=np.uint8))
+        ccpp = bytes(rng.integers(0, 256, size=200, dtype=np.uint8))
+        mode = (t % 11) if corrupt else 0
+        ends = []
+        for j in rng.choice(4, size=3, replace=False):
+            e = endorsers[j]
+            ebytes = sid[e["cn"]]
+            r, s = _sign(e, prp + ebytes, int(rng.integers(1, 1 << 62)))
+            sig = po.marshal_ecdsa_signature(r, s)
+            ends.append([ebytes, sig, r, s])
+        flag = fabgpu.TX_ALL_SIGNATURES_VALID
+        if mode == 3:                                   # a tampered endorsement (r + 1)
+            ends[1][1] = po.marshal_ecdsa_signature(ends[1][2] + 1, ends[1][3]); flag = fabgpu.TX_BAD_ENDORSEMENT
+        if mode == 4:                                   # a high-S endorsement: bccsp/sw rejects it with an error
+            ends[0][1] = po.marshal_ecdsa_signature(ends[0][2], po.N - ends[0][3]); flag = fabgpu.TX_BAD_ENDORSEMENT
+        if mode == 5:                                   # garbage DER
+            ends[2][1] = b"\x30\x03\x02\x01"; flag = fabgpu.TX_BAD_ENDORSEMENT
+        if mode == 6:                                   # an endorser with a P-384 identity: bccsp/sw must decide
+            ends[2][0] = sid[p384["cn"]]; flag = fabgpu.TX_NEEDS_SW
+        typ = 3
+        if mode == 7:
+            typ = 1                                     # a CONFIG envelope: only the creator signature is checked
+        payload = bb.endorser_tx_payload(typ, "mychannel", "tx%d" % t, cbytes, bytes(rng.integers(0, 256, size=24, dtype=np.uint8)),
+                                         [(ccpp, prp, [(e[0], e[1]) for e in ends])])
+        if mode == 8:                                   # transaction bytes that are not a peer.Transaction
+            hdr = bb.fbytes(1, bb.channel_header(3, "mychannel", "tx%d" % t)) + bb.fbytes(2, bb.signature_header(cbytes, b"n"))
+            payload = bb.fbytes(1, hdr) + bb.fbytes(2, b"\x0a\xff\xff\xff\xff\x0f" + b"junk")
+            flag = fabgpu.TX_NOT_UNDERSTOOD
+        r, s = _sign(creator, payload, int(rng.integers(1, 1 << 62)))
+        if mode == 9:                                   # creator signed something else
+            r, s = _sign(creator, payload + b"!", 99); flag = fabgpu.TX_BAD_CREATOR_SIGNATURE
+        if mode == 10 and flag == 0:                    # bad creator AND bad endorsement: the creator outranks
+            ends_bad = po.marshal_ecdsa_signature(ends[0][2] + 1, ends[0][3])
+            payload = bb.endorser_tx_payload(3, "mychannel", "tx%d" % t, cbytes, b"nonce", [(ccpp, prp, [(ends[0][0], ends_bad)] + [(e[0], e[1]) for e in ends[1:]])])
+            r, s = _sign(creator, payload + b"?", 77); flag = fabgpu.TX_BAD_CREATOR_SIGNATURE
+        envs.append(bb.envelope(payload, po.marshal_ecdsa_signature(r, s)))
+        want.append(flag)
+    return bb.block(7, envs), np.array(want, dtype=np.uint8)
+
+
+def test_block_walker_on_synthetic_blocks():
+    rng = np.random.default_rng(5)
+    blk, want = build_block(44, rng)
+    p = fabgpu.block_parse(blk)
+    assert p["n_tx"] == 44 and p["channel_id"] == "mychannel"
+    n_cfg = sum(1 for t in range(44) if t % 11 == 7)
+    n_bad = sum(1 for t in range(44) if t % 11 == 8)
+    assert list(p["tx_type"]).count(1) == n_cfg and list(p["tx_type"]).count(3) == 44 - n_cfg
+    assert p["n_tuples"] == (44 - n_bad) + 3 * (44 - n_cfg - n_bad) and p["n_prefixes"] == 44 - n_cfg - n_bad
+    with pytest.raises(fabgpu.FabgpuError):
+        fabgpu.block_parse(b"\x12\xff\xff\xff\xff\x0f")              # BlockData length runs past the buffer
+
+
+@pytest.mark.gpu
+def test_preverify_pass_end_to_end():
+    csp = fabgpu.GPUCSP(device=0)
+    rng = np.random.default_rng(6)
+    blk, want = build_block(220, rng)
+    before = csp.key_count()
+    out = fabgpu.preverify_block(csp, blk)
+    assert (out["tx_flags"] == want).all()
+    assert csp.key_count() == before + 6                                  # 4 endorsers + 2 creators registered once, the P-384 one never
+    out2 = fabgpu.preverify_block(csp, blk)                               # identities now come from the cache
+    assert (out2["tx_flags"] == want).all() and (out2["tuple_status"] == out["tuple_status"]).all() and csp.key_count() == before + 6
+    # per-tuple detail: exactly the corrupted tuples are non-zero
+    st = out["tuple_status"]
+    assert set(np.unique(st)) <= {0, 1, 2, 5, 6}
+    assert (st == fabgpu.TUPLE_ST_NEEDS_SW).sum() == sum(1 for t in range(220) if t % 11 == 6)
+    assert (st == 2).sum() == sum(1 for t in range(220) if t % 11 == 4)
+    assert (st == fabgpu.TUPLE_ST_BAD_DER).sum() == sum(1 for t in range(220) if t % 11 == 5)
+    # a clean block: every transaction valid
+    blk3, want3 = build_block(64, rng, corrupt=False)
+    assert (fabgpu.preverify_block(csp, blk3)["tx_flags"] == 0).all() and (want3 == 0).all()
+    csp.close()
