@@ -253,6 +253,36 @@ Gate gate_item(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const
     if (k == nullptr) { g.res = {false, Error("Invalid Key. It must not be nil.")}; return g; }
     if (siglen == 0) { g.res = {false, Error("Invalid signature. Cannot be empty.")}; return g; }
     if (dlen == 0) { g.res = {false, Error("Invalid digest. Cannot be empty.")}; return g; }
+    // Fast path for the overwhelmingly common shape - a minimal DER SEQUENCE { INTEGER r, INTEGER s } with positive r, s below
+    // 2^256 and low s - which the general parser below would accept with exactly these values; anything else (long-form
+    // lengths, trailing bytes, negative or zero integers, high s, oversize r ...) takes the general path and its error texts.
+    if (k->on_curve && siglen >= 8 && siglen <= 72 && sig[0] == 0x30 && sig[1] == siglen - 2 && sig[2] == 0x02) {
+        size_t lr = sig[3];
+        if (lr >= 1 && lr <= 33 && 4 + lr + 2 <= siglen && sig[4 + lr] == 0x02) {
+            size_t ls = sig[5 + lr];
+            const uint8_t* pr = sig + 4;
+            const uint8_t* ps = sig + 6 + lr;
+            auto minimal_positive = [](const uint8_t* p, size_t l) {
+                if (p[0] & 0x80) return false;                                  // negative
+                if (p[0] == 0) return l > 1 && (p[1] & 0x80) != 0 && l <= 33;   // a leading zero must be needed (also excludes zero)
+                return l <= 32;
+            };
+            if (ls >= 1 && ls <= 33 && 6 + lr + ls == siglen && minimal_positive(pr, lr) && minimal_positive(ps, ls)) {
+                if (pr[0] == 0) { pr++; lr--; }
+                if (ps[0] == 0) { ps++; ls--; }
+                memset(g.r32, 0, 32); memset(g.s32, 0, 32);
+                memcpy(g.r32 + 32 - lr, pr, lr);
+                memcpy(g.s32 + 32 - ls, ps, ls);
+                if (memcmp(g.s32, HALF_N_BE, 32) <= 0) {                        // low-S: the device decides (r >= n included)
+                    HashToInt(digest, dlen, g.e32);
+                    g.submit = true;
+                    return g;
+                }
+                memset(g.r32, 0, 32); memset(g.s32, 0, 32);
+                g.r32[31] = g.s32[31] = 1;
+            }
+        }
+    }
     const std::string wrap = "Failed verifing with opts [<nil>]: ";   // errors.Wrapf at impl.go:266
     BigInt R, S;
     Error e = UnmarshalECDSASignature(sig, siglen, R, S);
@@ -380,9 +410,13 @@ Error GPUCSP::IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::v
 // block-level pre-verify pass (block_prepass.h)
 // ------------------------------------------------------------------------------------------------
 Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const {
-    out = BlockVerdicts();
     ParsedBlock pb;
     if (!block || !ParseBlock(block, len, pb)) return Error("block does not parse as common.Block");
+    return PreVerifyParsed(block, pb, out);
+}
+
+Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out) const {
+    out = BlockVerdicts();
     const size_t nt = pb.tuples.size();
     out.n_tx = pb.n_tx;
     out.tx_type = pb.tx_type;
@@ -398,12 +432,28 @@ Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& ou
     std::vector<uint32_t> ids;
     bool all_keyed = true;
     static const uint8_t one_digest[1] = {1};
+    // a block names few identities: a per-call front cache (memcmp against the identities already met in this block) keeps
+    // the shared map - and its 700-byte key copies - off the per-tuple path
+    struct Front {
+        const uint8_t* p;
+        uint32_t len;
+        CachedIdentity ci;
+    };
+    std::vector<Front> front;
+    qx.reserve(nt * 32); qy.reserve(nt * 32); r.reserve(nt * 32); s.reserve(nt * 32); ids.reserve(nt); sub.reserve(nt);
     for (size_t i = 0; i < nt; i++) {
         const BlockTuple& tp = pb.tuples[i];
         out.tuple_tx[i] = tp.tx;
         out.tuple_kind[i] = tp.kind;
         CachedIdentity ci;
-        {
+        bool hit = false;
+        for (const Front& f : front)
+            if (f.len == tp.identity.len && memcmp(f.p, block + tp.identity.off, f.len) == 0) {
+                ci = f.ci;
+                hit = true;
+                break;
+            }
+        if (!hit) {
             std::string key((const char*)block + tp.identity.off, tp.identity.len);
             std::lock_guard<std::mutex> lk(idmu_);
             auto it = idcache_.find(key);
@@ -418,6 +468,7 @@ Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& ou
             } else {
                 ci = it->second;
             }
+            if (front.size() < 64) front.push_back({block + tp.identity.off, tp.identity.len, ci});
         }
         if (!ci.p256) {
             out.tuple_status[i] = TUPLE_ST_NEEDS_SW;

@@ -95,6 +95,7 @@ class GPUCSP {
     Error IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::vector<std::string>& out) const;
     // Block-level pre-verify pass (block_prepass.h): one fused launch for every creator / endorsement signature of the block.
     Error PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const;
+    Error PreVerifyParsed(const uint8_t* block, const ParsedBlock& parsed, BlockVerdicts& out) const;
     fabgpu_ctx* ctx() const { return ctx_; }
 
    private:
