@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 
 #include "p256_point.h"
 
@@ -426,76 +427,106 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     out.tuple_tx.resize(nt);
     out.tuple_kind.resize(nt);
     out.tuple_status.assign(nt, FABGPU_ST_VALID);
-    // identities -> keys (cached across blocks), signatures -> (r, s) through the reference's gates
+    // identities -> keys (cached across blocks), signatures -> (r, s) through the reference's gates.  Tuples are independent:
+    // blocks of 4096+ tuples are gated on worker threads (contiguous ranges), then compacted in order.
+    struct Gated {
+        uint8_t qx[32], qy[32], r[32], s[32];
+        int64_t key_id;
+        bool submit;
+    };
+    std::vector<Gated> gt(nt);
+    std::vector<uint32_t> new_ids(1, 0);
+    auto gate_range = [&](size_t lo, size_t hi, uint32_t* fresh) {
+        static const uint8_t one_digest[1] = {1};
+        // a block names few identities: a per-thread front cache (memcmp against the identities already met) keeps the shared
+        // map - and its 700-byte key copies - off the per-tuple path
+        struct Front {
+            const uint8_t* p;
+            uint32_t len;
+            CachedIdentity ci;
+        };
+        std::vector<Front> front;
+        for (size_t i = lo; i < hi; i++) {
+            const BlockTuple& tp = pb.tuples[i];
+            Gated& g0 = gt[i];
+            g0.submit = false;
+            out.tuple_tx[i] = tp.tx;
+            out.tuple_kind[i] = tp.kind;
+            CachedIdentity ci;
+            bool hit = false;
+            for (const Front& f : front)
+                if (f.len == tp.identity.len && memcmp(f.p, block + tp.identity.off, f.len) == 0) {
+                    ci = f.ci;
+                    hit = true;
+                    break;
+                }
+            if (!hit) {
+                std::string key((const char*)block + tp.identity.off, tp.identity.len);
+                std::lock_guard<std::mutex> lk(idmu_);
+                auto it = idcache_.find(key);
+                if (it == idcache_.end()) {
+                    (*fresh)++;
+                    ci.p256 = IdentityToP256(block + tp.identity.off, tp.identity.len, ci.qx, ci.qy) && PublicKeyOnCurve(ci.qx, ci.qy);
+                    if (ci.p256) {
+                        uint32_t id = 0;
+                        if (fabgpu_p256_key_register(ctx_, ci.qx, ci.qy, &id) == FABGPU_OK) ci.key_id = id;
+                    }
+                    idcache_[key] = ci;
+                } else {
+                    ci = it->second;
+                }
+                if (front.size() < 64) front.push_back({block + tp.identity.off, tp.identity.len, ci});
+            }
+            if (!ci.p256) {
+                out.tuple_status[i] = TUPLE_ST_NEEDS_SW;
+                continue;
+            }
+            if (tp.sig.len == 0) {
+                out.tuple_status[i] = TUPLE_ST_EMPTY_SIG;
+                continue;
+            }
+            ECDSAPublicKey k;
+            memcpy(k.x, ci.qx, 32);
+            memcpy(k.y, ci.qy, 32);
+            k.on_curve = true;
+            Gate g = gate_item(&k, block + tp.sig.off, tp.sig.len, one_digest, 1);
+            if (!g.submit) {
+                if (g.res.err.ok()) out.tuple_status[i] = FABGPU_ST_RANGE;                                   // r >= n: (false, nil)
+                else if (g.res.err.msg.find("Invalid S") != std::string::npos) out.tuple_status[i] = FABGPU_ST_HIGH_S;
+                else out.tuple_status[i] = TUPLE_ST_BAD_DER;
+                continue;
+            }
+            memcpy(g0.qx, ci.qx, 32); memcpy(g0.qy, ci.qy, 32); memcpy(g0.r, g.r32, 32); memcpy(g0.s, g.s32, 32);
+            g0.key_id = ci.key_id;
+            g0.submit = true;
+        }
+    };
+    int nthreads = nt >= 4096 ? 8 : 1;
+    if (nthreads == 1) {
+        gate_range(0, nt, &new_ids[0]);
+    } else {
+        new_ids.assign(nthreads, 0);
+        std::vector<std::thread> th;
+        for (int w = 0; w < nthreads; w++)
+            th.emplace_back([&, w] { gate_range(nt * w / nthreads, nt * (w + 1) / nthreads, &new_ids[w]); });
+        for (auto& x : th) x.join();
+    }
+    for (uint32_t v : new_ids) out.distinct_identities += v;
     std::vector<uint32_t> sub;                       // tuples the device decides
     std::vector<uint8_t> qx, qy, r, s;
     std::vector<uint32_t> ids;
     bool all_keyed = true;
-    static const uint8_t one_digest[1] = {1};
-    // a block names few identities: a per-call front cache (memcmp against the identities already met in this block) keeps
-    // the shared map - and its 700-byte key copies - off the per-tuple path
-    struct Front {
-        const uint8_t* p;
-        uint32_t len;
-        CachedIdentity ci;
-    };
-    std::vector<Front> front;
     qx.reserve(nt * 32); qy.reserve(nt * 32); r.reserve(nt * 32); s.reserve(nt * 32); ids.reserve(nt); sub.reserve(nt);
     for (size_t i = 0; i < nt; i++) {
-        const BlockTuple& tp = pb.tuples[i];
-        out.tuple_tx[i] = tp.tx;
-        out.tuple_kind[i] = tp.kind;
-        CachedIdentity ci;
-        bool hit = false;
-        for (const Front& f : front)
-            if (f.len == tp.identity.len && memcmp(f.p, block + tp.identity.off, f.len) == 0) {
-                ci = f.ci;
-                hit = true;
-                break;
-            }
-        if (!hit) {
-            std::string key((const char*)block + tp.identity.off, tp.identity.len);
-            std::lock_guard<std::mutex> lk(idmu_);
-            auto it = idcache_.find(key);
-            if (it == idcache_.end()) {
-                out.distinct_identities++;
-                ci.p256 = IdentityToP256(block + tp.identity.off, tp.identity.len, ci.qx, ci.qy) && PublicKeyOnCurve(ci.qx, ci.qy);
-                if (ci.p256) {
-                    uint32_t id = 0;
-                    if (fabgpu_p256_key_register(ctx_, ci.qx, ci.qy, &id) == FABGPU_OK) ci.key_id = id;
-                }
-                idcache_[key] = ci;
-            } else {
-                ci = it->second;
-            }
-            if (front.size() < 64) front.push_back({block + tp.identity.off, tp.identity.len, ci});
-        }
-        if (!ci.p256) {
-            out.tuple_status[i] = TUPLE_ST_NEEDS_SW;
-            continue;
-        }
-        if (tp.sig.len == 0) {
-            out.tuple_status[i] = TUPLE_ST_EMPTY_SIG;
-            continue;
-        }
-        ECDSAPublicKey k;
-        memcpy(k.x, ci.qx, 32);
-        memcpy(k.y, ci.qy, 32);
-        k.on_curve = true;
-        Gate g = gate_item(&k, block + tp.sig.off, tp.sig.len, one_digest, 1);
-        if (!g.submit) {
-            if (g.res.err.ok()) out.tuple_status[i] = FABGPU_ST_RANGE;                                   // r >= n: (false, nil)
-            else if (g.res.err.msg.find("Invalid S") != std::string::npos) out.tuple_status[i] = FABGPU_ST_HIGH_S;
-            else out.tuple_status[i] = TUPLE_ST_BAD_DER;
-            continue;
-        }
+        const Gated& g0 = gt[i];
+        if (!g0.submit) continue;
         sub.push_back((uint32_t)i);
-        qx.insert(qx.end(), ci.qx, ci.qx + 32);
-        qy.insert(qy.end(), ci.qy, ci.qy + 32);
-        r.insert(r.end(), g.r32, g.r32 + 32);
-        s.insert(s.end(), g.s32, g.s32 + 32);
-        ids.push_back(ci.key_id >= 0 ? (uint32_t)ci.key_id : 0);
-        if (ci.key_id < 0) all_keyed = false;
+        qx.insert(qx.end(), g0.qx, g0.qx + 32);
+        qy.insert(qy.end(), g0.qy, g0.qy + 32);
+        r.insert(r.end(), g0.r, g0.r + 32);
+        s.insert(s.end(), g0.s, g0.s + 32);
+        ids.push_back(g0.key_id >= 0 ? (uint32_t)g0.key_id : 0);
+        if (g0.key_id < 0) all_keyed = false;
     }
     const size_t n = sub.size();
     if (n) {

@@ -4,6 +4,9 @@
 
 #include <string.h>
 
+#include <thread>
+#include <utility>
+
 namespace fab {
 namespace bccsp {
 
@@ -180,99 +183,138 @@ bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy
     return CertDerToP256(der.data(), der.size(), qx, qy);
 }
 
-bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out) {
+namespace {
+// one envelope -> its tuples (prefix indices local to `out`)
+void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, uint32_t tx, ParsedBlock& out, uint8_t& tx_type, uint8_t& understood) {
+    tx_type = 255;
+    understood = 0;
+    const uint8_t *payload, *sig, *hdr, *pdata, *chdr, *shdr, *creator;
+    size_t payload_l, sig_l, hdr_l, pdata_l, chdr_l, shdr_l, creator_l;
+    // common.Envelope{1 payload, 2 signature}
+    if (!pb_bytes(env, env_len, 1, payload, payload_l)) return;
+    if (!pb_bytes(env, env_len, 2, sig, sig_l)) { sig = payload; sig_l = 0; }
+    // common.Payload{1 header, 2 data}; common.Header{1 channel_header, 2 signature_header}
+    if (!pb_bytes(payload, payload_l, 1, hdr, hdr_l)) return;
+    if (!pb_bytes(hdr, hdr_l, 1, chdr, chdr_l) || !pb_bytes(hdr, hdr_l, 2, shdr, shdr_l)) return;
+    // common.ChannelHeader{1 type (varint), ..., 4 channel_id}
+    uint8_t type = 0;   // proto3 default: MESSAGE
+    {
+        PbReader r(chdr, chdr_l);
+        PbField g;
+        while (r.next(g)) {
+            if (g.num == 1 && g.wt == 0) type = (uint8_t)g.varint;
+            if (g.num == 4 && g.wt == 2 && tx == 0) out.first_channel_id.assign((const char*)g.data, g.len);
+        }
+        if (!r.ok) return;
+    }
+    tx_type = type;
+    // common.SignatureHeader{1 creator, 2 nonce}
+    if (!pb_bytes(shdr, shdr_l, 1, creator, creator_l)) return;
+    BlockTuple ct;
+    ct.tx = tx;
+    ct.kind = TUPLE_CREATOR;
+    ct.identity = span_of(block, creator, creator_l);
+    ct.suffix = span_of(block, payload, payload_l);
+    ct.sig = span_of(block, sig, sig_l);
+    size_t first_tuple = out.tuples.size();
+    out.tuples.push_back(ct);
+    if (type != 3) {                                               // only ENDORSER_TRANSACTION carries endorsements
+        understood = 1;
+        return;
+    }
+    if (!pb_bytes(payload, payload_l, 2, pdata, pdata_l)) { out.tuples.resize(first_tuple); return; }
+    // peer.Transaction{1 repeated actions}; TransactionAction{1 header, 2 payload}
+    bool good = true;
+    PbReader acts(pdata, pdata_l);
+    PbField a;
+    while (acts.next(a)) {
+        if (a.num != 1 || a.wt != 2) continue;
+        const uint8_t *ap, *cea, *prp;
+        size_t ap_l, cea_l, prp_l;
+        // ChaincodeActionPayload{1 chaincode_proposal_payload, 2 action}; ChaincodeEndorsedAction{1 proposal_response_payload, 2 endorsements}
+        if (!pb_bytes(a.data, a.len, 2, ap, ap_l) || !pb_bytes(ap, ap_l, 2, cea, cea_l) || !pb_bytes(cea, cea_l, 1, prp, prp_l)) {
+            good = false;
+            break;
+        }
+        int32_t pidx = (int32_t)out.prefixes.size();
+        out.prefixes.push_back(span_of(block, prp, prp_l));
+        PbReader ends(cea, cea_l);
+        PbField e;
+        while (ends.next(e)) {
+            if (e.num != 2 || e.wt != 2) continue;
+            const uint8_t *endorser, *esig;
+            size_t endorser_l, esig_l;
+            // peer.Endorsement{1 endorser, 2 signature}
+            if (!pb_bytes(e.data, e.len, 1, endorser, endorser_l)) { good = false; break; }
+            if (!pb_bytes(e.data, e.len, 2, esig, esig_l)) { esig = endorser; esig_l = 0; }
+            BlockTuple et;
+            et.tx = tx;
+            et.kind = TUPLE_ENDORSEMENT;
+            et.identity = span_of(block, endorser, endorser_l);
+            et.prefix = span_of(block, prp, prp_l);
+            et.prefix_index = pidx;
+            et.suffix = et.identity;                               // message = prp || endorser
+            et.sig = span_of(block, esig, esig_l);
+            out.tuples.push_back(et);
+        }
+        if (!ends.ok) good = false;
+        if (!good) break;
+    }
+    if (!acts.ok) good = false;
+    if (!good) {
+        out.tuples.resize(first_tuple);                            // leave the whole transaction to the Go validators
+        return;
+    }
+    understood = 1;
+}
+}  // namespace
+
+bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_threads) {
     out = ParsedBlock();
     if (len > 0xFFFFFFF0ull) return false;
     const uint8_t* data;
     size_t dlen;
     if (!pb_bytes(block, len, 2, data, dlen)) return false;           // common.Block{1 header, 2 data, 3 metadata}
-    PbReader envs(data, dlen);                                        // common.BlockData{1 repeated bytes data}
-    PbField f;
-    while (envs.next(f)) {
-        if (f.num != 1 || f.wt != 2) continue;
-        const uint32_t tx = out.n_tx++;
-        out.tx_type.push_back(255);
-        out.tx_understood.push_back(0);
-        const uint8_t *payload, *sig, *hdr, *pdata, *chdr, *shdr, *creator;
-        size_t payload_l, sig_l, hdr_l, pdata_l, chdr_l, shdr_l, creator_l;
-        // common.Envelope{1 payload, 2 signature}
-        if (!pb_bytes(f.data, f.len, 1, payload, payload_l)) continue;
-        if (!pb_bytes(f.data, f.len, 2, sig, sig_l)) { sig = payload; sig_l = 0; }
-        // common.Payload{1 header, 2 data}; common.Header{1 channel_header, 2 signature_header}
-        if (!pb_bytes(payload, payload_l, 1, hdr, hdr_l)) continue;
-        if (!pb_bytes(hdr, hdr_l, 1, chdr, chdr_l) || !pb_bytes(hdr, hdr_l, 2, shdr, shdr_l)) continue;
-        // common.ChannelHeader{1 type (varint), ..., 4 channel_id}
-        uint8_t type = 0;   // proto3 default: MESSAGE
-        {
-            PbReader r(chdr, chdr_l);
-            PbField g;
-            while (r.next(g)) {
-                if (g.num == 1 && g.wt == 0) type = (uint8_t)g.varint;
-                if (g.num == 4 && g.wt == 2 && tx == 0) out.first_channel_id.assign((const char*)g.data, g.len);
-            }
-            if (!r.ok) continue;
-        }
-        out.tx_type[tx] = type;
-        // common.SignatureHeader{1 creator, 2 nonce}
-        if (!pb_bytes(shdr, shdr_l, 1, creator, creator_l)) continue;
-        BlockTuple ct;
-        ct.tx = tx;
-        ct.kind = TUPLE_CREATOR;
-        ct.identity = span_of(block, creator, creator_l);
-        ct.suffix = span_of(block, payload, payload_l);
-        ct.sig = span_of(block, sig, sig_l);
-        size_t first_tuple = out.tuples.size();
-        out.tuples.push_back(ct);
-        if (type != 3) {                                               // only ENDORSER_TRANSACTION carries endorsements
-            out.tx_understood[tx] = 1;
-            continue;
-        }
-        if (!pb_bytes(payload, payload_l, 2, pdata, pdata_l)) { out.tuples.resize(first_tuple); continue; }
-        // peer.Transaction{1 repeated actions}; TransactionAction{1 header, 2 payload}
-        bool good = true;
-        PbReader acts(pdata, pdata_l);
-        PbField a;
-        while (acts.next(a)) {
-            if (a.num != 1 || a.wt != 2) continue;
-            const uint8_t *ap, *cea, *prp;
-            size_t ap_l, cea_l, prp_l;
-            // ChaincodeActionPayload{1 chaincode_proposal_payload, 2 action}; ChaincodeEndorsedAction{1 proposal_response_payload, 2 endorsements}
-            if (!pb_bytes(a.data, a.len, 2, ap, ap_l) || !pb_bytes(ap, ap_l, 2, cea, cea_l) || !pb_bytes(cea, cea_l, 1, prp, prp_l)) {
-                good = false;
-                break;
-            }
-            int32_t pidx = (int32_t)out.prefixes.size();
-            out.prefixes.push_back(span_of(block, prp, prp_l));
-            PbReader ends(cea, cea_l);
-            PbField e;
-            while (ends.next(e)) {
-                if (e.num != 2 || e.wt != 2) continue;
-                const uint8_t *endorser, *esig;
-                size_t endorser_l, esig_l;
-                // peer.Endorsement{1 endorser, 2 signature}
-                if (!pb_bytes(e.data, e.len, 1, endorser, endorser_l)) { good = false; break; }
-                if (!pb_bytes(e.data, e.len, 2, esig, esig_l)) { esig = endorser; esig_l = 0; }
-                BlockTuple et;
-                et.tx = tx;
-                et.kind = TUPLE_ENDORSEMENT;
-                et.identity = span_of(block, endorser, endorser_l);
-                et.prefix = span_of(block, prp, prp_l);
-                et.prefix_index = pidx;
-                et.suffix = et.identity;                               // message = prp || endorser
-                et.sig = span_of(block, esig, esig_l);
-                out.tuples.push_back(et);
-            }
-            if (!ends.ok) good = false;
-            if (!good) break;
-        }
-        if (!acts.ok) good = false;
-        if (!good) {
-            out.tuples.resize(first_tuple);                            // leave the whole transaction to the Go validators
-            continue;
-        }
-        out.tx_understood[tx] = 1;
+    std::vector<std::pair<const uint8_t*, size_t>> envs;              // common.BlockData{1 repeated bytes data}
+    {
+        PbReader r(data, dlen);
+        PbField f;
+        while (r.next(f))
+            if (f.num == 1 && f.wt == 2) envs.emplace_back(f.data, f.len);
+        if (!r.ok) return false;
     }
-    return envs.ok;
+    const uint32_t n = (uint32_t)envs.size();
+    out.n_tx = n;
+    out.tx_type.assign(n, 255);
+    out.tx_understood.assign(n, 0);
+    int nt = (n >= 1024 && max_threads > 1) ? (max_threads > 16 ? 16 : max_threads) : 1;
+    if (nt == 1) {
+        for (uint32_t t = 0; t < n; t++) parse_envelope(block, envs[t].first, envs[t].second, t, out, out.tx_type[t], out.tx_understood[t]);
+        return true;
+    }
+    // envelopes are independent: contiguous ranges on worker threads, merged in order (prefix indices rebased)
+    std::vector<ParsedBlock> part(nt);
+    std::vector<std::thread> th;
+    for (int w = 0; w < nt; w++)
+        th.emplace_back([&, w] {
+            uint32_t lo = (uint32_t)((uint64_t)n * w / nt), hi = (uint32_t)((uint64_t)n * (w + 1) / nt);
+            for (uint32_t t = lo; t < hi; t++) parse_envelope(block, envs[t].first, envs[t].second, t, part[w], out.tx_type[t], out.tx_understood[t]);
+        });
+    for (auto& x : th) x.join();
+    out.first_channel_id = part[0].first_channel_id;
+    size_t ntup = 0, npre = 0;
+    for (auto& p : part) { ntup += p.tuples.size(); npre += p.prefixes.size(); }
+    out.tuples.reserve(ntup);
+    out.prefixes.reserve(npre);
+    for (auto& p : part) {
+        int32_t base = (int32_t)out.prefixes.size();
+        out.prefixes.insert(out.prefixes.end(), p.prefixes.begin(), p.prefixes.end());
+        for (BlockTuple tp : p.tuples) {
+            if (tp.prefix_index >= 0) tp.prefix_index += base;
+            out.tuples.push_back(tp);
+        }
+    }
+    return true;
 }
 
 }  // namespace bccsp

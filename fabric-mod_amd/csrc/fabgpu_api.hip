@@ -635,8 +635,13 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     if ((rc = ctx->arena.ensure(ab + 64)) || (rc = ctx->offs.ensure(noff * 4)) || (rc = ctx->fields.ensure(4 * fb + ib)) ||
         (rc = ctx->out.ensure(st_off + n)) || (rc = ctx->pre.ensure(pob + ib + (size_t)m * 32 + 64)))
         return rc;
-    if (span) memcpy(ctx->arena.h, arena + lo, span);
-    memset((uint8_t*)ctx->arena.h + span, 0, ab - span);
+    // small arenas go through the pinned staging buffer; big ones (a marshalled block) are handed to the driver directly -
+    // one copy less on the host (the tail padding the kernels may touch is zeroed on the device)
+    const bool direct = span >= ((size_t)4 << 20);
+    if (!direct) {
+        if (span) memcpy(ctx->arena.h, arena + lo, span);
+        memset((uint8_t*)ctx->arena.h + span, 0, ab - span);
+    }
     uint32_t* ho = (uint32_t*)ctx->offs.h;
     for (size_t i = 0; i < noff; i++) ho[i] = b->off[i] - lo;
     uint8_t* ph = (uint8_t*)ctx->pre.h;
@@ -652,7 +657,13 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     } else {
         memcpy(fh, b->qx, fb); memcpy(fh + fb, b->qy, fb); memcpy(fh + 2 * fb, b->r, fb); memcpy(fh + 3 * fb, b->s, fb);
     }
-    hipError_t err = hipMemcpyAsync(ctx->arena.d, ctx->arena.h, ab, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t err;
+    if (direct) {
+        err = hipMemcpyAsync(ctx->arena.d, arena + lo, span, hipMemcpyHostToDevice, ctx->stream);
+        if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)ctx->arena.d + span, 0, ab - span, ctx->stream);
+    } else {
+        err = hipMemcpyAsync(ctx->arena.d, ctx->arena.h, ab, hipMemcpyHostToDevice, ctx->stream);
+    }
     if (err == hipSuccess) err = hipMemcpyAsync(ctx->offs.d, ctx->offs.h, noff * 4, hipMemcpyHostToDevice, ctx->stream);
     if (err == hipSuccess && m) err = hipMemcpyAsync(ctx->pre.d, ctx->pre.h, pob + ib, hipMemcpyHostToDevice, ctx->stream);
     if (err == hipSuccess) err = hipMemcpyAsync(ctx->fields.d, ctx->fields.h, keyed ? ib + 2 * fb : 4 * fb, hipMemcpyHostToDevice, ctx->stream);
