@@ -1,7 +1,8 @@
-// HIP kernels for gfx950 (MI355X / CDNA4): batched SHA-256, batched ECDSA P-256 verify, and the fused
-// hash+verify kernel.  One signature / message per lane, 64-lane wavefronts, verdicts packed with a
-// wave ballot.  No MFMA: this is 32-bit integer VALU work (v_mad_u64_u32 / v_addc_co_u32 carry chains
-// for the big-number part, v_alignbit / v_xor / v_add for SHA-256).
+// HIP kernels for gfx950 (MI355X / CDNA4): batched SHA-256 (with shared-prefix mid-states), batched ECDSA P-256 verify -
+// one signature per lane, or two lanes per signature for batches that cannot fill the chip - for fresh and for registered
+// public keys, and the fused hash+verify kernels.  64-lane wavefronts, verdicts packed with a wave ballot.  No MFMA: this is
+// integer VALU work (v_mad_i64_i32 on 29-bit signed limbs for the big-number part - fe29.h, generated streams in fe29_gcn.h /
+// pair29_gcn.h - and v_alignbit / v_xor / v_add for SHA-256).
 //
 // Replaces (reference, all CPU): bccsp/sw/hash.go:29-33, bccsp/sw/ecdsa.go:41-57 -> crypto/ecdsa.Verify,
 // called per signature from msp/identities.go:169-196.
@@ -269,8 +270,8 @@ struct GlobalQTab29 {
     }
 };
 
-// Persistent workgroups: a bounded number of slots, each staging the comb table into LDS once and walking the
-// BLOCK-signature tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  (the workspace is sized by slots, not by the batch).
+// Persistent workgroups: a bounded number of slots, each walking the BLOCK-signature tiles  blockIdx.x, blockIdx.x + gridDim.x, ...
+// (the per-lane j*Q workspace is sized by slots, not by the batch).
 // One 256-thread workgroup per CU = one wave per SIMD.  A second wave per SIMD was measured (BLOCK = 512, round-1 PMC runs in
 // profiles/): each wave then takes 1.5x the cycles, but the chip also drops from ~2.0 to ~1.6 GHz - the integer multiplier
 // array is power-limited - so whole-job throughput does not move; one wave per SIMD keeps the latency of a block minimal.
