@@ -1,0 +1,141 @@
+// Idemix pseudonym-signature verification on FP256BN's G1 (y^2 = x^3 + 3 over the 256-bit BN prime), fe29 representation.
+//
+// What it replaces: idemix/nymsignature.go:74-109 (NymSignature.Ver), reached from msp/idemixmsp.go:584-599 through
+// bccsp/idemix/handlers/nymsigner.go:62-95 and bccsp/idemix/bridge/nymsignaturescheme.go:66-89; the arithmetic under it is
+// github.com/hyperledger/fabric-amcl amcl/FP256BN (ECP.Mul2, ECP.Mul, ECP.Sub, ECP.ToBytes; third-party, go.mod:44).
+//
+//     t  = HSk * s_sk + HRand * s_rnym - Nym * c                       (three G1 scalar multiplications, NO pairing)
+//     c' = H("sign" || t || Nym || ipk.Hash || msg) mod r ;  valid  <=>  c == H(c' || nonce) mod r
+//
+// Structure on the device (one signature per lane, lane-uniform control flow):
+//   * HSk and HRand are fixed per issuer: each gets an 8-bit comb table at fabgpu_idemix_issuer_register (32 mixed additions
+//     per scalar, no doublings) - the same CombTab<8> layout as a registered P-256 key;
+//   * Nym is fresh per signature: c * Nym by 52 signed 5-bit windows over a per-lane table (ec29.h: var_base_mult29);
+//   * the three partial results stay in separate accumulators and are merged by two final additions that handle doubling and
+//     the point at infinity explicitly;
+//   * one inversion mod p (safegcd, modinv30.h) gives the affine t that the hash needs.
+// Inputs outside the domain on which the CPU oracle is pinned to the reference's fixtures (oracle/idemix_oracle.py: Nym off the
+// curve or with coordinates >= p, s-values >= r, t at infinity) are NOT decided here: the status says "ask bccsp/sw".
+//
+// Limb bookkeeping: products annotated [L(a) x L(b)] in units of 2^28; the bound for this field is 12 (bn29.h).
+#pragma once
+#include "bn29.h"
+#include "ec29.h"
+#include "modinv30.h"
+
+namespace fab {
+
+typedef jac_t<fbn> jacbn;
+
+// status codes of the nym-signature verbs (include/fabgpu.h FABGPU_NYM_*)
+enum : uint32_t {
+    NYM_VALID = 0,
+    NYM_BAD_PROOF = 1,     // "pseudonym signature invalid: zero-knowledge proof is invalid" (idemix/nymsignature.go:105)
+    NYM_NEEDS_SW = 6,      // outside the pinned domain: the caller must ask bccsp/sw
+};
+
+// y^2 == x^3 + 3, Montgomery form, x and y normalised
+FAB_HD bool bn_on_curve29(const fbn& x, const fbn& y) {
+    const fbn B = {BN29_B_MONT};
+    fbn l, x2, x3, d;
+    fe_sqr(l, y);          // [1x1]
+    fe_sqr(x2, x);         // [1x1]
+    fe_mul(x3, x2, x);     // [1x1]
+    fe_sub(d, l, x3);      // L2
+    fe_sub(d, d, B);       // L3
+    return fe_is_zero(d);
+}
+
+// Doubling, a = 0 (dbl-2009-l with D = 4 X Y^2 as one product): 3M + 4S.
+// in: L(X) <= 2, L(Y) <= 3, L(Z) <= 2.   out: L(X) = 1, L(Y) = 3, L(Z) = 2.
+FAB_HD void pt_dbl29(jacbn& r, const jacbn& a) {
+    fbn A, Bq, b2, c4, x4, D, E, F, t, x3, yy, yz;
+    fe_sqr(A, a.X);                // [2x2]
+    fe_sqr(Bq, a.Y);               // [3x3]
+    fe_add(b2, Bq, Bq);            // L2
+    fe_sqr(c4, b2);                // [2x2]  4 Y^4
+    fe_add(x4, a.X, a.X);
+    fe_add(x4, x4, x4);            // 4X   L(X) = 1 on every path that reaches a doubling -> L4 (L8 is the int32 edge)
+    fe_mul(D, x4, Bq);             // [4x1]  4 X Y^2
+    fe_add(E, A, A);
+    fe_add(E, E, A);               // 3 X^2   L3
+    fe_sqr(F, E);                  // [3x3]
+    fe_sub(t, F, D);
+    fe_sub(t, t, D);               // E^2 - 2D   L3
+    fe_weak_norm(x3, t);           // L1
+    fe_sub(t, D, x3);              // L2
+    fe_mul(yy, E, t);              // [3x2]
+    fe_sub(yy, yy, c4);
+    fe_sub(r.Y, yy, c4);           // E (D - X3) - 8 Y^4   L3
+    fe_mul(yz, a.Y, a.Z);          // [3x2]
+    fe_add(r.Z, yz, yz);           // 2 Y Z   L2
+    r.X = x3;
+}
+
+FAB_HD void bn_neg29(jacbn& p) {
+#pragma unroll
+    for (int l = 0; l < 9; l++) p.Y.v[l] = -p.Y.v[l];
+}
+
+// x < m ?  (both plain 256-bit integers)
+FAB_HD bool bn_lt(const u256& x, const u256& m) { return lt256(x, m); }
+
+// The commitment t of the verification equation, affine, as plain integers in [0, p).
+// Returns NYM_VALID when (tx, ty) is meaningful, NYM_BAD_PROOF when c >= r (an unreduced ProofC can never equal a value
+// reduced mod r: idemix/nymsignature.go:104 compares BIGs), NYM_NEEDS_SW outside the pinned domain.
+// KTab: comb tables of HSk and HRand; QTab: per-lane store(j, point) / load(j, point), j = 1..16.
+template <class KTab, class QTab>
+FAB_HD uint32_t bn_nym_commitment29(u256& tx, u256& ty, const u256& nx, const u256& ny, const u256& c, const u256& s_sk,
+                                    const u256& s_rnym, const KTab& hsk, const KTab& hrand, QTab& qtab) {
+    const u256 P = FAB_BN_P, R = FAB_BN_R;
+    uint32_t early = NYM_VALID;
+    if (!bn_lt(c, R)) early = NYM_BAD_PROOF;
+    bool dom = bn_lt(nx, P) & bn_lt(ny, P) & bn_lt(s_sk, R) & bn_lt(s_rnym, R);
+
+    jacbn N;
+    fe_to_mont(N.X, nx);
+    fe_to_mont(N.Y, ny);
+    fe_set_one(N.Z);
+    dom = dom & bn_on_curve29(N.X, N.Y);
+
+    jacbn seed, S1, S2, U, T, W;
+    bool s1_inf, s2_inf, u_inf, t_inf, w_inf;
+    hsk.load(0, 1u, seed.X, seed.Y);
+    fe_set_one(seed.Z);
+    comb_mult29(S1, s1_inf, s_sk, hsk, seed);
+    comb_mult29(S2, s2_inf, s_rnym, hrand, seed);
+    final_add29(U, u_inf, S1, s1_inf, S2, s2_inf);
+    var_base_mult29(T, t_inf, c, N, qtab);
+    bn_neg29(T);
+    final_add29(W, w_inf, U, u_inf, T, t_inf);
+
+    // affine t: one inversion mod p
+    u256 zp, zi;
+    fe_from_mont(zp, W.Z);
+    {
+        const modinv_info PI = MODINV_BNP_INFO;
+        modinv(zi, zp, PI);
+    }
+    fbn zm, zi2, zi3, ax, ay;
+    fe_to_mont(zm, zi);
+    fe_sqr(zi2, zm);               // [1x1]
+    fe_mul(zi3, zi2, zm);          // [1x1]
+    fe_mul(ax, W.X, zi2);          // [1x1]
+    fe_mul(ay, W.Y, zi3);          // [3x1]
+    fe_from_mont(tx, ax);
+    fe_from_mont(ty, ay);
+
+    if (early != NYM_VALID) return early;
+    if (!dom || w_inf) return NYM_NEEDS_SW;
+    return NYM_VALID;
+}
+
+// x mod r for x < 2^256 (r > 2^255: one conditional subtraction) - the Mod of HashModOrder, idemix/util.go:49
+FAB_HD void bn_mod_order(u256& out, const u256& x) {
+    const u256 R = FAB_BN_R;
+    u256 t;
+    uint32_t br = sub256(t, x, R);
+    sel256(out, br == 0, t, x);
+}
+
+}  // namespace fab

@@ -13,6 +13,7 @@
 
 #include "../../include/fabgpu.h"
 #include "kernels.h"
+#include "bn_tables29.h"
 #include "p256_tables29.h"
 
 using namespace fab;
@@ -70,6 +71,13 @@ struct fabgpu_ctx {
     const int32_t** d_ktabs = nullptr;
     size_t d_ktabs_cap = 0;
     std::vector<void*> retired;   // outgrown d_ktabs arrays, freed at shutdown
+    // Registered idemix issuers: a fixed-capacity device array of slots (idemix_kernels.hip IssuerDev); a slot is written
+    // before n_issuers is raised, so launches in flight never read a half-written one.
+    std::mutex imu;
+    void* d_issuers = nullptr;
+    std::vector<int32_t*> itabs;                  // two comb tables per issuer
+    std::map<std::string, uint32_t> issuer_ids;   // hsk || hrand || hash -> id
+    Buf nym;          // staging of the nym host-pointer entry point: issuer_id | six fields
     Buf keyed;        // staging of the keyed host-pointer entry point: key_id | e | r | s
     Buf pre;          // staging of prefixed batches: pre_off | pre_idx | mid-states
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
@@ -207,6 +215,9 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         if (ctx->d_gtab) hipFree(ctx->d_gtab);
         for (auto* t : ctx->ktabs) hipFree(t);
         for (auto* t : ctx->retired) hipFree(t);
+        for (auto* t : ctx->itabs) hipFree(t);
+        if (ctx->d_issuers) hipFree(ctx->d_issuers);
+        ctx->nym.release();
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
@@ -274,6 +285,109 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
     if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, ShaPrefixArgs(), st);
+    hipEventRecord(ctx->ev1, st);
+    ctx->release_qws(wi, st);
+    ctx->timed = true;
+    return hip_to_rc(err);
+}
+
+// ---- idemix pseudonym signatures --------------------------------------------------------------------
+int fabgpu_bn256_g1_on_curve(const uint8_t* x32, const uint8_t* y32) {
+    if (!x32 || !y32) return 0;
+    const u256 P = FAB_BN_P;
+    u256 x, y;
+    from_be32(x, x32);
+    from_be32(y, y32);
+    if (!lt256(x, P) || !lt256(y, P)) return 0;
+    fbn fx, fy;
+    fe_to_mont(fx, x);
+    fe_to_mont(fy, y);
+    return bn_on_curve29(fx, fy) ? 1 : 0;
+}
+
+int fabgpu_idemix_issuer_register(fabgpu_ctx* ctx, const uint8_t* hsk_x32, const uint8_t* hsk_y32, const uint8_t* hrand_x32,
+                                  const uint8_t* hrand_y32, const uint8_t* ipk_hash32, uint32_t* issuer_id) {
+    if (!ctx || !hsk_x32 || !hsk_y32 || !hrand_x32 || !hrand_y32 || !ipk_hash32 || !issuer_id) return FABGPU_EINVAL;
+    if (!fabgpu_bn256_g1_on_curve(hsk_x32, hsk_y32) || !fabgpu_bn256_g1_on_curve(hrand_x32, hrand_y32)) return FABGPU_EINVAL;
+    std::string k((const char*)hsk_x32, 32);
+    k.append((const char*)hsk_y32, 32);
+    k.append((const char*)hrand_x32, 32);
+    k.append((const char*)hrand_y32, 32);
+    k.append((const char*)ipk_hash32, 32);
+    std::lock_guard<std::mutex> lk(ctx->imu);
+    auto it = ctx->issuer_ids.find(k);
+    if (it != ctx->issuer_ids.end()) {
+        *issuer_id = it->second;
+        return FABGPU_OK;
+    }
+    const size_t cur = ctx->itabs.size() / 2;
+    if (cur >= FABGPU_MAX_ISSUERS) return FABGPU_ENOMEM;
+    DeviceGuard g(ctx->device);
+    const size_t slot = idemix_issuer_dev_bytes();
+    if (!ctx->d_issuers && hipMalloc(&ctx->d_issuers, slot * FABGPU_MAX_ISSUERS) != hipSuccess) {
+        ctx->d_issuers = nullptr;
+        return FABGPU_ENOMEM;
+    }
+    const size_t tb = sizeof(int32_t) * KeyTab8::TABLE_WORDS;
+    std::vector<int32_t> tab(KeyTab8::TABLE_WORDS);
+    int32_t* d[2] = {nullptr, nullptr};
+    const uint8_t* bx[2] = {hsk_x32, hrand_x32};
+    const uint8_t* by[2] = {hsk_y32, hrand_y32};
+    for (int b = 0; b < 2; b++) {
+        u256 x, y;
+        from_be32(x, bx[b]);
+        from_be32(y, by[b]);
+        build_bn_comb_table8(tab.data(), x, y);
+        if (hipMalloc((void**)&d[b], tb) != hipSuccess || hipMemcpy(d[b], tab.data(), tb, hipMemcpyHostToDevice) != hipSuccess) {
+            if (d[0]) hipFree(d[0]);
+            if (d[1]) hipFree(d[1]);
+            return FABGPU_ENOMEM;
+        }
+    }
+    std::vector<uint8_t> hs(slot);
+    idemix_issuer_dev_fill(hs.data(), d[0], d[1], ipk_hash32);
+    if (hipMemcpy((uint8_t*)ctx->d_issuers + cur * slot, hs.data(), slot, hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(d[0]);
+        hipFree(d[1]);
+        return FABGPU_ELAUNCH;
+    }
+    ctx->itabs.push_back(d[0]);
+    ctx->itabs.push_back(d[1]);
+    *issuer_id = (uint32_t)cur;
+    ctx->issuer_ids[k] = *issuer_id;
+    return FABGPU_OK;
+}
+
+int fabgpu_idemix_issuer_count(fabgpu_ctx* ctx) {
+    if (!ctx) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->imu);
+    return (int)(ctx->itabs.size() / 2);
+}
+
+int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
+                                       const void* issuer_id, const void* nym_x, const void* nym_y, const void* proof_c,
+                                       const void* proof_s_sk, const void* proof_s_r_nym, const void* nonce, void* verdict_bits,
+                                       void* status, void* stream) {
+    if (!ctx || (n && (!arena || !off || !nym_x || !nym_y || !proof_c || !proof_s_sk || !proof_s_r_nym || !nonce || !verdict_bits)))
+        return FABGPU_EINVAL;
+    if (n > 0xFFFFFFF0ull || arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    uint32_t n_issuers;
+    const void* issuers;
+    {
+        std::lock_guard<std::mutex> lk(ctx->imu);
+        n_issuers = (uint32_t)(ctx->itabs.size() / 2);
+        issuers = ctx->d_issuers;
+    }
+    if (n_issuers == 0) return FABGPU_EINVAL;   // nothing registered: every tuple would need bccsp/sw
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    size_t wi = 0;
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, false), &wi);
+    if (rc != FABGPU_OK) return rc;
+    hipEventRecord(ctx->ev0, st);
+    hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
+                                              proof_s_sk, proof_s_r_nym, nonce, ctx->qws[wi].p, verdict_bits, status, st);
     hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = true;
@@ -510,6 +624,40 @@ int fabgpu_sha256_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* ar
     if (err != hipSuccess) return hip_to_rc(err);
     rc = fabgpu_sha256_p256_verify_batch_dev(ctx, n, ctx->arena.d, ab, ctx->offs.d, d, d + fb, d + 2 * fb, d + 3 * fb, dout,
                                              status ? dout + st_off : nullptr, ctx->stream);
+    if (rc) return rc;
+    err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    memcpy(verdict_bits, ctx->out.h, words * 8);
+    if (status) memcpy(status, (uint8_t*)ctx->out.h + st_off, n);
+    return FABGPU_OK;
+}
+
+int fabgpu_idemix_nym_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off, const uint32_t* issuer_id,
+                                   const uint8_t* nym_x, const uint8_t* nym_y, const uint8_t* proof_c, const uint8_t* proof_s_sk,
+                                   const uint8_t* proof_s_r_nym, const uint8_t* nonce, uint64_t* verdict_bits, uint8_t* status) {
+    if (!ctx || (n && (!off || !nym_x || !nym_y || !proof_c || !proof_s_sk || !proof_s_r_nym || !nonce || !verdict_bits))) return FABGPU_EINVAL;
+    if (n > 0x7FFFFFF0ull / 200) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    if (!arena && off[n] != off[0]) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    size_t ab = 0;
+    int rc = stage_messages(ctx, n, arena, off, &ab);
+    if (rc) return rc;
+    const size_t fb = n * 32, kb = round_up(n * 4, 64), words = (n + 63) / 64;
+    const size_t st_off = round_up(words * 8, 64);
+    if ((rc = ctx->nym.ensure(kb + 6 * fb)) || (rc = ctx->out.ensure(st_off + n))) return rc;
+    uint8_t* h = (uint8_t*)ctx->nym.h;
+    if (issuer_id) memcpy(h, issuer_id, n * 4);
+    const uint8_t* src[6] = {nym_x, nym_y, proof_c, proof_s_sk, proof_s_r_nym, nonce};
+    for (int f = 0; f < 6; f++) memcpy(h + kb + f * fb, src[f], fb);
+    uint8_t* d = (uint8_t*)ctx->nym.d;
+    uint8_t* dout = (uint8_t*)ctx->out.d;
+    hipError_t err = hipMemcpyAsync(d, h, kb + 6 * fb, hipMemcpyHostToDevice, ctx->stream);
+    if (err != hipSuccess) return hip_to_rc(err);
+    rc = fabgpu_idemix_nym_verify_batch_dev(ctx, n, ctx->arena.d, ab, ctx->offs.d, issuer_id ? d : nullptr, d + kb, d + kb + fb, d + kb + 2 * fb,
+                                            d + kb + 3 * fb, d + kb + 4 * fb, d + kb + 5 * fb, dout, status ? dout + st_off : nullptr, ctx->stream);
     if (rc) return rc;
     err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);

@@ -7,6 +7,7 @@
 #include <vector>
 
 #define FE29_CHECK 1
+#include "bn_tables29.h"
 #include "p256_tables29.h"
 
 using namespace fab;
@@ -168,5 +169,73 @@ void hosttest_gtab_entry(int window, int digit, uint8_t* x32, uint8_t* y32) {
     fp_from_mont(py, y);
     to_be32(x32, px);
     to_be32(y32, py);
+}
+// ---- FP256BN (idemix) ----
+// op: 0 mul 1 sqr 2 (a+b)*(a-b) lazy 3 is_zero(a-b) 4 round trip 5 (3a)^2 6 (4a)*b
+void hosttest_bn29_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
+    u256 a, b, r = zero256();
+    from_be32(a, a32);
+    from_be32(b, b32);
+    fbn fa, fb, fr, t1, t2;
+    fe_to_mont(fa, a);
+    fe_to_mont(fb, b);
+    switch (op) {
+        case 0: fe_mul(fr, fa, fb); break;
+        case 1: fe_sqr(fr, fa); break;
+        case 2: fe_add(t1, fa, fb); fe_sub(t2, fa, fb); fe_mul(fr, t1, t2); break;
+        case 3: fe_sub(t1, fa, fb); r.w[0] = fe_is_zero(t1) ? 1 : 0; to_be32(out32, r); return;
+        case 5: fe_add(t1, fa, fa); fe_add(t1, t1, fa); fe_sqr(fr, t1); break;
+        case 6: fe_add(t1, fa, fa); fe_add(t1, t1, t1); fe_mul(fr, t1, fb); break;
+        default: fr = fa;
+    }
+    fe_from_mont(r, fr);
+    to_be32(out32, r);
+}
+void hosttest_bn_modinv(const uint8_t* a32, uint8_t* out32) {
+    const modinv_info PI = MODINV_BNP_INFO;
+    u256 a, r;
+    from_be32(a, a32);
+    modinv(r, a, PI);
+    to_be32(out32, r);
+}
+struct BnIssuerTabs {
+    std::vector<int32_t> hsk, hrand;
+};
+void* hosttest_bn_issuer_new(const uint8_t* hskx, const uint8_t* hsky, const uint8_t* hrx, const uint8_t* hry) {
+    BnIssuerTabs* t = new BnIssuerTabs;
+    t->hsk.resize(KeyTab8::TABLE_WORDS);
+    t->hrand.resize(KeyTab8::TABLE_WORDS);
+    u256 x, y;
+    from_be32(x, hskx); from_be32(y, hsky);
+    build_bn_comb_table8(t->hsk.data(), x, y);
+    from_be32(x, hrx); from_be32(y, hry);
+    build_bn_comb_table8(t->hrand.data(), x, y);
+    return t;
+}
+void hosttest_bn_issuer_free(void* p) { delete (BnIssuerTabs*)p; }
+// which: 0 HSk 1 HRand
+void hosttest_bn_tab_entry(void* p, int which, int window, int digit, uint8_t* x32, uint8_t* y32) {
+    BnIssuerTabs* t = (BnIssuerTabs*)p;
+    KeyTab8 kt{which ? t->hrand.data() : t->hsk.data()};
+    fbn x, y;
+    u256 px, py;
+    kt.load(window, (uint32_t)digit, x, y);
+    fe_from_mont(px, x);
+    fe_from_mont(py, y);
+    to_be32(x32, px);
+    to_be32(y32, py);
+}
+// the commitment t = HSk s_sk + HRand s_rnym - Nym c through the kernel's core; returns its status
+int hosttest_bn_nym_commitment(void* p, const uint8_t* nx32, const uint8_t* ny32, const uint8_t* c32, const uint8_t* ssk32,
+                               const uint8_t* srn32, uint8_t* tx32, uint8_t* ty32) {
+    BnIssuerTabs* t = (BnIssuerTabs*)p;
+    KeyTab8 hsk{t->hsk.data()}, hrand{t->hrand.data()};
+    u256 nx, ny, c, ssk, srn, tx, ty;
+    from_be32(nx, nx32); from_be32(ny, ny32); from_be32(c, c32); from_be32(ssk, ssk32); from_be32(srn, srn32);
+    LocalQTab<fbn> qtab;
+    uint32_t st = bn_nym_commitment29(tx, ty, nx, ny, c, ssk, srn, hsk, hrand, qtab);
+    to_be32(tx32, tx);
+    to_be32(ty32, ty);
+    return (int)st;
 }
 }

@@ -1,0 +1,158 @@
+// HIP kernel for gfx950 (MI355X / CDNA4): batched idemix pseudonym-signature verification on FP256BN, one signature per
+// lane, the two SHA-256 of the Fiat-Shamir challenge fused behind the point arithmetic (the commitment t never leaves the
+// registers).  Integer VALU work, no MFMA.
+//
+// Replaces (reference, all CPU): idemix/nymsignature.go:74-109, called per creator signature from msp/idemixmsp.go:584-599
+// through bccsp/idemix/handlers/nymsigner.go:62-95.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bn_nym29.h"
+#include "device_common.h"
+#include "kernels.h"
+
+namespace fab {
+
+// 32-byte big-endian field (a u256's words, most significant first) into the header words at byte offset OFF
+template <int OFF>
+__device__ __forceinline__ void put_be32(uint32_t* hw, const u256& v) {
+    constexpr int W = OFF / 4, S = OFF % 4;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t be = v.w[7 - j];
+        if (S == 0) {
+            hw[W + j] = be;
+        } else {
+            hw[W + j] |= be >> (8 * S);
+            hw[W + j + 1] |= be << (32 - 8 * S);
+        }
+    }
+}
+
+// idemix/nymsignature.go:89-107 for one lane.  proofData = "sign" || 04 t.x t.y || 04 nym.x nym.y || ipk.Hash || msg :
+// a 166-byte header the lane assembles in registers (two whole SHA blocks + 38 bytes that share the third block with the
+// start of the message), then the message from the arena; c = digest mod r; ProofC' = SHA-256(c || nonce) mod r.
+__device__ __forceinline__ bool nym_challenge_matches(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t start, uint32_t len,
+                                                      bool active, const u256& tx, const u256& ty, const u256& nx, const u256& ny,
+                                                      const uint32_t ipk_hash[8], const u256& nonce, const u256& proof_c) {
+    uint32_t hw[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) hw[k] = 0;
+    hw[0] = 0x7369676eu;                 // "sign" (idemix/signature.go:19)
+    hw[1] = 0x04u << 24;                 // byte 4: uncompressed-point tag of t
+    put_be32<5>(hw, tx);
+    put_be32<37>(hw, ty);
+    hw[17] |= 0x04u << 16;               // byte 69: tag of nym
+    put_be32<70>(hw, nx);
+    put_be32<102>(hw, ny);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {        // ipk.Hash at byte 134
+        hw[33 + j] |= ipk_hash[j] >> 16;
+        hw[34 + j] |= ipk_hash[j] << 16;
+    }
+    uint32_t h[8], w[16];
+    sha256_iv(h);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = hw[k];
+    sha256_compress(h, w);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = hw[16 + k];
+    sha256_compress(h, w);
+    uint32_t tailw[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) tailw[k] = hw[32 + k];
+    ShaTailRegs tail{tailw};
+    sha256_stream_t(arena32, arena_words, h, tail, 38u, start, len, 128u, active, true);
+
+    u256 d, c;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d.w[k] = h[7 - k];
+    bn_mod_order(c, d);
+    // second hash: c (32 bytes) || nonce (32 bytes) = one block, then the padding block of a 64-byte message
+    sha256_iv(h);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        w[j] = c.w[7 - j];
+        w[8 + j] = nonce.w[7 - j];
+    }
+    sha256_compress(h, w);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = 0;
+    w[0] = 0x80000000u;
+    w[15] = 512u;
+    sha256_compress(h, w);
+#pragma unroll
+    for (int k = 0; k < 8; k++) d.w[k] = h[7 - k];
+    bn_mod_order(c, d);
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) diff |= c.w[k] ^ proof_c.w[k];
+    return diff == 0;
+}
+
+// One registered issuer on the device: comb tables of HSk and HRand, ipk.Hash as big-endian words.
+struct IssuerDev {
+    const int32_t* hsk;
+    const int32_t* hrand;
+    uint32_t hash[8];
+};
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2)
+    idemix_nym_verify_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
+                             const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
+                             const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
+                             const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
+                             uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+    GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
+    const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * BLOCK + threadIdx.x;
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        uint32_t iss = issuer_id != nullptr ? issuer_id[ic] : 0u;
+        bool iss_ok = iss < n_issuers;
+        const IssuerDev* id = issuers + (iss_ok ? iss : 0u);
+        KeyTab8 hsk{id->hsk}, hrand{id->hrand};
+        u256 nx, ny, c, ssk, srn, nn, tx, ty;
+        load_be_field(nx, nym_x, ic);
+        load_be_field(ny, nym_y, ic);
+        load_be_field(c, proof_c, ic);
+        load_be_field(ssk, s_sk, ic);
+        load_be_field(srn, s_rnym, ic);
+        load_be_field(nn, nonce, ic);
+        uint32_t st = bn_nym_commitment29(tx, ty, nx, ny, c, ssk, srn, hsk, hrand, qtab);
+        uint32_t ih[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) ih[k] = id->hash[k];
+        uint32_t start = off[ic], len = off[ic + 1] - start;
+        bool match = nym_challenge_matches(arena32, arena_words, start, len, active, tx, ty, nx, ny, ih, nn, c);
+        if (st == NYM_VALID) st = match ? NYM_VALID : NYM_BAD_PROOF;
+        if (!iss_ok) st = NYM_NEEDS_SW;
+        emit_verdict(i, active, st, verdict_bits, status);
+    }
+}
+
+size_t idemix_issuer_dev_bytes() { return sizeof(IssuerDev); }
+void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hrand, const uint8_t hash32[32]) {
+    IssuerDev* s = (IssuerDev*)host_slot;
+    s->hsk = (const int32_t*)d_hsk;
+    s->hrand = (const int32_t*)d_hrand;
+    for (int k = 0; k < 8; k++)
+        s->hash[k] = ((uint32_t)hash32[4 * k] << 24) | ((uint32_t)hash32[4 * k + 1] << 16) | ((uint32_t)hash32[4 * k + 2] << 8) | hash32[4 * k + 3];
+}
+
+hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
+                                    uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
+                                    const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    VerifyGeom g = verify_geom(n, false);
+    dim3 grid(g.wgs), block(g.block);
+    hipLaunchKernelGGL(idemix_nym_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                       (const uint32_t*)off, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
+                       (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
+                       (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+    return hipGetLastError();
+}
+
+}  // namespace fab

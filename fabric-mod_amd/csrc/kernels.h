@@ -39,4 +39,14 @@ hipError_t launch_p256_verify_keyed(uint32_t n, const void* key_id, uint32_t nke
 hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* key_id, uint32_t nkeys,
                                            const void* ktabs, const void* r, const void* s, const void* gtab, void* verdict_bits, void* status,
                                            bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st);
+
+// ---- idemix_kernels.hip: idemix pseudonym signatures on FP256BN ----
+// A registered issuer occupies one slot of idemix_issuer_dev_bytes() bytes in a device array; fill a host copy of the slot
+// with idemix_issuer_dev_fill (device pointers of the two comb tables + ipk.Hash) and copy it up.
+size_t idemix_issuer_dev_bytes();
+void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hrand, const uint8_t hash32[32]);
+// one signature per lane; workspace as launch_p256_verify with allow_pair = false
+hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
+                                    uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
+                                    const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, hipStream_t st);
 }  // namespace fab

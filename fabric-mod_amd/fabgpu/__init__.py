@@ -63,6 +63,8 @@ ABI_SYMBOLS = [
     "fabgpu_p256_key_register", "fabgpu_p256_key_lookup", "fabgpu_p256_key_count", "fabgpu_p256_verify_batch_keyed", "fabgpu_p256_verify_batch_keyed_dev",
     "fabgpu_sha256_p256_verify_batch_keyed", "fabgpu_sha256_p256_verify_batch_keyed_dev",
     "fabgpu_identity_verify_batch", "fabgpu_identity_verify_batch_dev",
+    "fabgpu_idemix_issuer_register", "fabgpu_idemix_issuer_count", "fabgpu_idemix_nym_verify_batch", "fabgpu_idemix_nym_verify_batch_dev",
+    "fabgpu_bn256_g1_on_curve",
     "fabgpu_last_kernel_ms", "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
@@ -106,6 +108,11 @@ def load():
     L.fabgpu_sha256_p256_verify_batch_keyed_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.fabgpu_identity_verify_batch.argtypes = [_vp, ctypes.POINTER(_IdBatch)]
     L.fabgpu_identity_verify_batch_dev.argtypes = [_vp, ctypes.POINTER(_IdBatch), _vp, _vp]
+    L.fabgpu_idemix_issuer_register.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _u32p]
+    L.fabgpu_idemix_issuer_count.argtypes = [_vp]
+    L.fabgpu_idemix_nym_verify_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u32p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u64p, _u8p]
+    L.fabgpu_idemix_nym_verify_batch_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.fabgpu_bn256_g1_on_curve.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_last_kernel_ms.argtypes = [_vp]
     L.fabgpu_last_kernel_ms.restype = ctypes.c_float
     L.fabgpu_ecdsa_unmarshal_signature.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
@@ -173,6 +180,10 @@ def is_low_s(s32: bytes) -> bool:
 
 def pubkey_on_curve(qx32: bytes, qy32: bytes) -> bool:
     return bool(load().fabgpu_p256_pubkey_on_curve(qx32, qy32))
+
+
+def bn256_g1_on_curve(x32: bytes, y32: bytes) -> bool:
+    return bool(load().fabgpu_bn256_g1_on_curve(bytes(x32), bytes(y32)))
 
 
 def hash_to_int(digest: bytes) -> bytes:
@@ -294,6 +305,36 @@ class Context:
     def sha256_p256_verify_batch_keyed_dev(self, n, arena, arena_bytes, off, key_id, r, s, verdict_bits, status, stream=0):
         _check(self._L.fabgpu_sha256_p256_verify_batch_keyed_dev(self._h, n, arena, arena_bytes, off, key_id, r, s, verdict_bits,
                                                                   status or None, stream or None), "fabgpu_sha256_p256_verify_batch_keyed_dev")
+
+    # idemix pseudonym signatures (FP256BN): an issuer is registered once, batches name it by id
+    def idemix_issuer_register(self, hsk_xy: Tuple[bytes, bytes], hrand_xy: Tuple[bytes, bytes], ipk_hash32: bytes) -> int:
+        iid = ctypes.c_uint32(0)
+        _check(self._L.fabgpu_idemix_issuer_register(self._h, bytes(hsk_xy[0]), bytes(hsk_xy[1]), bytes(hrand_xy[0]), bytes(hrand_xy[1]),
+                                                      bytes(ipk_hash32), ctypes.byref(iid)), "fabgpu_idemix_issuer_register")
+        return int(iid.value)
+
+    def idemix_issuer_count(self) -> int:
+        return self._L.fabgpu_idemix_issuer_count(self._h)
+
+    def idemix_nym_verify_batch(self, arena, off, nym_x, nym_y, proof_c, proof_s_sk, proof_s_r_nym, nonce, issuer_id=None, want_status=True):
+        """NymSignature.Ver over a batch: message i = arena[off[i], off[i+1]); fields n x 32 big-endian bytes."""
+        arena, nym_x, nym_y, proof_c, proof_s_sk, proof_s_r_nym, nonce = map(_a8, (arena, nym_x, nym_y, proof_c, proof_s_sk, proof_s_r_nym, nonce))
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = off.size - 1
+        iid = None if issuer_id is None else np.ascontiguousarray(issuer_id, dtype=np.uint32)
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.uint8) if want_status else None
+        _check(self._L.fabgpu_idemix_nym_verify_batch(self._h, n, _p8(arena), off.ctypes.data_as(_u32p),
+                                                       iid.ctypes.data_as(_u32p) if iid is not None else None, _p8(nym_x), _p8(nym_y),
+                                                       _p8(proof_c), _p8(proof_s_sk), _p8(proof_s_r_nym), _p8(nonce),
+                                                       bits.ctypes.data_as(_u64p), _p8(st)), "fabgpu_idemix_nym_verify_batch")
+        return unpack_bits(bits, n), st
+
+    def idemix_nym_verify_batch_dev(self, n, arena, arena_bytes, off, issuer_id, nym_x, nym_y, proof_c, proof_s_sk, proof_s_r_nym, nonce,
+                                    verdict_bits, status, stream=0):
+        _check(self._L.fabgpu_idemix_nym_verify_batch_dev(self._h, n, arena, arena_bytes, off, issuer_id or None, nym_x, nym_y, proof_c,
+                                                           proof_s_sk, proof_s_r_nym, nonce, verdict_bits, status or None, stream or None),
+               "fabgpu_idemix_nym_verify_batch_dev")
 
     def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True, spans=False):
         """fabgpu_identity_verify_batch: message i = [prefix pre_idx[i]] || arena[off[i], off[i+1]); keys by value or by id."""

@@ -159,6 +159,39 @@ typedef struct fabgpu_identity_batch {
 int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch);
 int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch, void* mid_scratch, void* stream);
 
+/* ---- idemix pseudonym signatures on FP256BN (BASELINE config 5) ----
+ * NymSignature.Ver (idemix/nymsignature.go:74-109), reached per CREATOR signature from msp/idemixmsp.go:584-599 through
+ * bccsp/idemix/handlers/nymsigner.go:62-95:  t = HSk*s_sk + HRand*s_rnym - Nym*c  (three G1 scalar multiplications, no
+ * pairing), then two SHA-256:  valid <=> c == H(H("sign" || t || Nym || ipk.Hash || msg) mod r || nonce) mod r.
+ *
+ * An ISSUER (bccsp.IdemixIssuerPublicKeyImportOpts -> bccsp/idemix/handlers/issuer.go) is registered once: comb tables for
+ * its two bases HSk and HRand (2 x 640 KiB on the device) and its ipk.Hash.  fabgpu_idemix_issuer_register is idempotent per
+ * (HSk, HRand, hash); FABGPU_EINVAL when a base is not a point of G1 with coordinates < p, FABGPU_ENOMEM beyond
+ * FABGPU_MAX_ISSUERS.
+ *
+ * Batch layout: SoA, 32-byte big-endian fields (nym_x, nym_y: the coordinates of the pseudonym as NewPublicNymFromBytes
+ * splits them, bccsp/idemix/bridge/user.go:72-86; proof_c, proof_s_sk, proof_s_r_nym, nonce: the four fields of the
+ * NymSignature message, idemix/idemix.proto), message i = arena[off[i], off[i+1]), issuer_id[i] (NULL = issuer 0 for all).
+ * status: FABGPU_NYM_VALID, FABGPU_NYM_BAD_PROOF ("pseudonym signature invalid: zero-knowledge proof is invalid"), or
+ * FABGPU_NYM_NEEDS_SW for inputs the device does not decide - Nym not on the curve or with a coordinate >= p (amcl turns
+ * such input into the point at infinity), an s-value >= r, a commitment t at infinity, an unknown issuer id: ask bccsp/sw.
+ * The verdict bit is set only for FABGPU_NYM_VALID. */
+#define FABGPU_MAX_ISSUERS 64
+#define FABGPU_NYM_VALID 0
+#define FABGPU_NYM_BAD_PROOF 1
+#define FABGPU_NYM_NEEDS_SW 6
+int fabgpu_idemix_issuer_register(fabgpu_ctx* ctx, const uint8_t* hsk_x32, const uint8_t* hsk_y32, const uint8_t* hrand_x32,
+                                  const uint8_t* hrand_y32, const uint8_t* ipk_hash32, uint32_t* issuer_id);
+int fabgpu_idemix_issuer_count(fabgpu_ctx* ctx);
+int fabgpu_idemix_nym_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* arena, const uint32_t* off, const uint32_t* issuer_id,
+                                   const uint8_t* nym_x, const uint8_t* nym_y, const uint8_t* proof_c, const uint8_t* proof_s_sk,
+                                   const uint8_t* proof_s_r_nym, const uint8_t* nonce, uint64_t* verdict_bits, uint8_t* status);
+int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
+                                       const void* issuer_id, const void* nym_x, const void* nym_y, const void* proof_c,
+                                       const void* proof_s_sk, const void* proof_s_r_nym, const void* nonce, void* verdict_bits,
+                                       void* status, void* stream);
+/* 1 if (x, y) is a point of FP256BN's G1 (y^2 = x^3 + 3) with x, y < p, else 0  (pure CPU) */
+int fabgpu_bn256_g1_on_curve(const uint8_t* x32, const uint8_t* y32);
 /* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
  * launch stream (bench.py's roofline leg).  <0 if nothing was launched or events are pending. */
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);
