@@ -4,6 +4,7 @@
 
 #include "../../include/fabgpu_bccsp.h"
 #include "bccsp_host.h"
+#include "idemix_host.h"
 
 using namespace fab::bccsp;
 
@@ -164,4 +165,46 @@ int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t
     return CertDerToP256(cert, len, qx32, qy32) ? 0 : 1;
 }
 
+// ---- idemix (idemix_host.h) ----
+int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap) {
+    if (!csp || !issuer_id) return FABGPU_EINVAL;
+    IdemixCSP ic(csp->csp->ctx());
+    IdemixIssuerPublicKey k;
+    Error e = ic.IssuerKeyImport(ipk_raw, len, k);
+    put_err(err, errcap, e.ok() ? "" : e.msg);
+    *issuer_id = e.ok() ? k.issuer_id : -1;
+    return FABGPU_OK;
+}
+
+// n (nym key, signature, message) triples under ONE issuer key (what an idemix MSP verifies: msp/idemixmsp.go:584-599).
+// nym keys and signatures are ragged byte strings exactly as the reference's KeyImport / Verify receive them.
+// valid[i] 0/1; flags[i] bit0: bccsp/idemix must decide this tuple; errs[i] = Go error text or "".
+int fabgpu_csp_idemix_nym_verify_batch(fabgpu_csp* csp, int64_t issuer_id, size_t n, const uint8_t* nym_arena, const uint32_t* nym_off,
+                                       const uint8_t* sig_arena, const uint32_t* sig_off, const uint8_t* msg_arena, const uint32_t* msg_off,
+                                       uint8_t* valid, uint8_t* flags, char* errs, size_t errstride) {
+    if (!csp || (n && (!nym_off || !sig_off || !msg_off || !valid || !flags || !errs || !errstride))) return FABGPU_EINVAL;
+    IdemixCSP ic(csp->csp->ctx());
+    IdemixIssuerPublicKey ipk;
+    ipk.issuer_id = issuer_id;
+    std::vector<NymPublicKey> keys(n);
+    std::vector<uint8_t> key_ok(n);
+    std::vector<NymVerifyItem> items(n);
+    std::vector<std::string> import_err(n);
+    for (size_t i = 0; i < n; i++) {
+        Error e = ic.NymKeyImport(nym_arena + nym_off[i], nym_off[i + 1] - nym_off[i], keys[i]);
+        key_ok[i] = e.ok();
+        if (!e.ok()) import_err[i] = e.msg;
+        items[i] = {e.ok() ? &keys[i] : nullptr, &ipk, sig_arena + sig_off[i], sig_off[i + 1] - sig_off[i], msg_arena + msg_off[i],
+                    msg_off[i + 1] - msg_off[i]};
+    }
+    std::vector<VerifyResult> res;
+    Error e = ic.NymVerifyBatch(items, res);
+    if (!e.ok()) return FABGPU_ELAUNCH;
+    for (size_t i = 0; i < n; i++) {
+        valid[i] = res[i].valid ? 1 : 0;
+        flags[i] = res[i].needs_sw ? 1 : 0;
+        put_err(errs + i * errstride, errstride, key_ok[i] ? (res[i].err.ok() ? "" : res[i].err.msg) : import_err[i]);
+    }
+    return FABGPU_OK;
+}
 }  // extern "C"

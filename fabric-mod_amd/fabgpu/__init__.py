@@ -69,6 +69,7 @@ ABI_SYMBOLS = [
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
+    "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch",
     "fabgpu_synth_batch",
 ]
 
@@ -133,6 +134,8 @@ def load():
     L.fabgpu_csp_identity_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u32p, _u8p, _u32p, ctypes.c_char_p, _sz]
     L.fabgpu_csp_block_preverify.argtypes = [_vp, _u8p, _sz, _u32p, _u8p, _u8p, ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_uint32]
     L.fabgpu_block_parse.argtypes = [_u8p, _sz, _u32p, _u32p, _u32p, _u8p, ctypes.c_uint32, ctypes.c_char_p, _sz]
+    L.fabgpu_csp_idemix_issuer_import.argtypes = [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, _sz]
+    L.fabgpu_csp_idemix_nym_verify_batch.argtypes = [_vp, ctypes.c_int64, _sz, _u8p, _u32p, _u8p, _u32p, _u8p, _u32p, _u8p, _u8p, ctypes.c_char_p, _sz]
     L.fabgpu_x509_p256_pubkey.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
     _lib = L
@@ -488,6 +491,32 @@ class GPUCSP:
         _check(self._L.fabgpu_csp_identity_verify_batch(self._h, n, _p8(qx), _p8(qy), _p8(ma), mo.ctypes.data_as(_u32p), _p8(sa),
                                                         so.ctypes.data_as(_u32p), errs, stride), "fabgpu_csp_identity_verify_batch")
         return [(errs.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode() or None) for i in range(n)]
+
+    # ---- idemix creator signatures (bccsp/idemix/handlers) ----
+    def idemix_issuer_import(self, ipk_raw: bytes) -> int:
+        """IssuerPublicKeyImporter.KeyImport for the accelerated part: registers HSk / HRand / Hash; -1 = not accelerated."""
+        iid = ctypes.c_int64(-1)
+        err = ctypes.create_string_buffer(512)
+        _check(self._L.fabgpu_csp_idemix_issuer_import(self._h, bytes(ipk_raw), len(ipk_raw), ctypes.byref(iid), err, 512),
+               "fabgpu_csp_idemix_issuer_import")
+        if err.value:
+            raise BCCSPError(err.value.decode())
+        return int(iid.value)
+
+    def idemix_nym_verify_batch(self, issuer_id: int, nym_keys: Sequence[bytes], sigs: Sequence[bytes], msgs: Sequence[bytes]):
+        """NymVerifier.Verify for n tuples: list of (valid, needs_sw, error text or None)."""
+        n = len(sigs)
+        ka, ko = _ragged(nym_keys)
+        sa, so = _ragged(sigs)
+        ma, mo = _ragged(msgs)
+        stride = 256
+        valid = np.zeros(max(1, n), np.uint8)
+        flags = np.zeros(max(1, n), np.uint8)
+        errs = ctypes.create_string_buffer(max(1, n * stride))
+        _check(self._L.fabgpu_csp_idemix_nym_verify_batch(self._h, issuer_id, n, _p8(ka), ko.ctypes.data_as(_u32p), _p8(sa), so.ctypes.data_as(_u32p),
+                                                          _p8(ma), mo.ctypes.data_as(_u32p), _p8(valid), _p8(flags), errs, stride),
+               "fabgpu_csp_idemix_nym_verify_batch")
+        return [(bool(valid[i]), bool(flags[i] & 1), errs.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode() or None) for i in range(n)]
 
 
 def _ragged(items: Sequence[bytes]):

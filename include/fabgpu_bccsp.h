@@ -69,6 +69,18 @@ int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_
                        char* channel_id, size_t channel_cap);
 int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t* qx32, uint8_t* qy32);
 
+/* ---- idemix pseudonym signatures (creator signatures of idemix MSPs): host mirror of bccsp/idemix/handlers ----
+ * fabgpu_csp_idemix_issuer_import: IssuerPublicKeyImporter.KeyImport (bccsp/idemix/handlers/issuer.go:115-136) for the
+ * accelerated part - takes the marshalled idemix.IssuerPublicKey, registers HSk / HRand / Hash on the device.
+ * *issuer_id = -1 with err == "": a key the device does not take (the proof inside the key is checked by bccsp/idemix).
+ * fabgpu_csp_idemix_nym_verify_batch: NymVerifier.Verify (bccsp/idemix/handlers/nymsigner.go:62-95) over n tuples under one
+ * issuer: nym public keys as NymPublicKeyImporter.KeyImport receives them (x || y), marshalled idemix.NymSignature bytes,
+ * messages.  valid[i] 0/1; flags[i] bit0: tuple left to bccsp/idemix; errs[i] = Go error text ("" == nil). */
+int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap);
+int fabgpu_csp_idemix_nym_verify_batch(fabgpu_csp* csp, int64_t issuer_id, size_t n, const uint8_t* nym_arena, const uint32_t* nym_off,
+                                       const uint8_t* sig_arena, const uint32_t* sig_off, const uint8_t* msg_arena, const uint32_t* msg_off,
+                                       uint8_t* valid, uint8_t* flags, char* errs, size_t errstride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,3 +97,59 @@ def test_block_sized_batch_by_replication(env):
     assert np.array_equal(st, expect[pick])
     assert np.array_equal(ok, expect[pick] == 0)
     assert ctx.last_kernel_ms() > 0
+
+
+# ---- the host mirror of bccsp/idemix/handlers (NymVerifier.Verify), driven with the reference's vocabulary ------------------
+def test_nym_verifier_mirror_semantics():
+    import json
+    import os
+    import random
+    from idemix_common import ROOT
+    fx = fixtures()
+    raw_ipk = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_fixtures.json")))["msps"]["MSP1OU1"]["ipk"])
+    ipk, sk = fx["MSP1OU1"]["ipk"], fx["MSP1OU1"]["signer"].sk
+    csp = fabgpu.GPUCSP()
+    try:
+        iid = csp.idemix_issuer_import(raw_ipk)
+        assert iid >= 0
+        assert csp.idemix_issuer_import(raw_ipk) == iid                       # idempotent
+        with pytest.raises(fabgpu.BCCSPError, match="invalid raw, it must not be nil"):
+            csp.idemix_issuer_import(b"")
+        rng = random.Random(31)
+        nym, r_nym = io.make_nym(sk, ipk, rng)
+        key = be32(nym[0]) + be32(nym[1])
+        msg = b"creator payload bytes"
+        sig = io.nym_sign(sk, nym, r_nym, ipk, msg, rng)
+        good = io.nym_signature_marshal(sig)
+        flipped = io.nym_signature_marshal(dict(sig, nonce=be32(int.from_bytes(sig["nonce"], "big") ^ 1)))
+        short = io.nym_signature_marshal(dict(sig, proof_s_sk=sig["proof_s_sk"][:31]))
+        reordered = (io.pb_bytes_field(4, sig["nonce"]) + io.pb_bytes_field(2, sig["proof_s_sk"]) + io.pb_bytes_field(1, sig["proof_c"])
+                     + io.pb_bytes_field(3, sig["proof_s_r_nym"]))           # field order is free in protobuf
+        cases = [
+            (key, good, msg),            # 0 valid
+            (key, good, msg + b"!"),     # 1 other message
+            (key, flipped, msg),         # 2 tampered nonce
+            (key, b"", msg),             # 3 empty signature
+            (key, b"\xff\xff\xff", msg), # 4 not a protobuf message
+            (key, short, msg),           # 5 a 31-byte field: amcl-internal -> bccsp/idemix decides
+            (key[:63], good, msg),       # 6 odd-sized nym key: bccsp/idemix decides
+            (b"", good, msg),            # 7 empty nym key: KeyImport error
+            (key, reordered, msg),       # 8 valid
+            (key, good + io.pb_bytes_field(9, b"unknown field"), msg),   # 9 unknown fields are skipped by proto.Unmarshal
+        ]
+        res = csp.idemix_nym_verify_batch(iid, [c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+        assert res[0] == (True, False, None)
+        assert res[1] == (False, False, "pseudonym signature invalid: zero-knowledge proof is invalid")
+        assert res[2] == (False, False, "pseudonym signature invalid: zero-knowledge proof is invalid")
+        assert res[3] == (False, False, "invalid signature, it must not be empty")
+        assert res[4][0] is False and res[4][2].startswith("error unmarshalling signature")
+        assert res[5] == (False, True, None)
+        assert res[6] == (False, True, None)
+        assert res[7] == (False, False, "invalid raw, it must not be nil")
+        assert res[8] == (True, False, None)
+        assert res[9] == (True, False, None)
+        # an issuer the device does not know: everything is left to bccsp/idemix
+        res = csp.idemix_nym_verify_batch(-1, [key], [good], [msg])
+        assert res[0] == (False, True, None)
+    finally:
+        csp.close()
