@@ -10,7 +10,8 @@
 // Structure on the device (one signature per lane, lane-uniform control flow):
 //   * HSk and HRand are fixed per issuer: each gets an 8-bit comb table at fabgpu_idemix_issuer_register (32 mixed additions
 //     per scalar, no doublings) - the same CombTab<8> layout as a registered P-256 key;
-//   * Nym is fresh per signature: c * Nym by 52 signed 5-bit windows over a per-lane table (ec29.h: var_base_mult29);
+//   * Nym is fresh per signature: c * Nym = k1 * Nym + k2 * phi(Nym) with the GLV endomorphism phi(x, y) = (beta x, y) and
+//     |k1|, |k2| < 2^129: 27 signed 5-bit windows over one per-lane table, 130 doublings instead of 255 (ec29.h: glv_mult29);
 //   * the three partial results stay in separate accumulators and are merged by two final additions that handle doubling and
 //     the point at infinity explicitly;
 //   * one inversion mod p (safegcd, modinv30.h) gives the affine t that the hash needs.
@@ -80,6 +81,54 @@ FAB_HD void bn_neg29(jacbn& p) {
 // x < m ?  (both plain 256-bit integers)
 FAB_HD bool bn_lt(const u256& x, const u256& m) { return lt256(x, m); }
 
+// GLV decomposition of a scalar for phi(x, y) = (beta x, y) = lambda (x, y), lambda = 36u^4 - 1:  k = k1 + k2 lambda (mod r) with
+// |k1|, |k2| < 2^129.  With the reduced lattice basis v1 = (a1, b1), v2 = (a2, b2) of {(a, b): a + b lambda = 0 mod r}:
+//     c1 ~ b2 k / r,  c2 ~ -b1 k / r;   k1 = k - c1 a1 - c2 a2,   k2 = -c1 b1 - c2 b2
+// ANY integers c1, c2 give a correct decomposition (only the size of k1, k2 depends on how well they approximate the
+// quotients), so the quotients are taken as floor(k G / 2^384) with precomputed G = floor(2^384 b / r): no division on the
+// device, and the bound 2^129 is checked exhaustively-at-random in tests/test_idemix_oracle.py against gen_bn_consts.py.
+// Out: magnitudes and signs.  (Arithmetic is mod 2^256, two's complement; a1, a2, -b1, b2 are positive.)
+FAB_HD void bn_glv_decompose(u256& m1, bool& n1, u256& m2, bool& n2, const u256& k) {
+    const u256 G1 = FAB_BN_GLV_G1, G2 = FAB_BN_GLV_G2, A1 = FAB_BN_GLV_A1, A2 = FAB_BN_GLV_A2, NB1 = FAB_BN_GLV_NB1, B2 = FAB_BN_GLV_B2;
+    uint32_t t[16];
+    u256 c1 = zero256(), c2 = zero256(), hi = zero256(), p, k1, k2;
+    mul512(t, k, G1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) c1.w[i] = t[12 + i];              // (k G1) >> 384
+    mul512(t, k, G2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        c2.w[i] = t[12 + i];
+        hi.w[i] = k.w[4 + i];                                     // k >> 128  (G2 stands for 2^256 + G2)
+    }
+    add256(c2, c2, hi);
+    // k1 = k - c1 a1 - c2 a2
+    mul512(t, c1, A1);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p.w[i] = t[i];
+    sub256(k1, k, p);
+    mul512(t, c2, A2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p.w[i] = t[i];
+    sub256(k1, k1, p);
+    // k2 = c1 (-b1) - c2 b2
+    mul512(t, c1, NB1);
+#pragma unroll
+    for (int i = 0; i < 8; i++) k2.w[i] = t[i];
+    mul512(t, c2, B2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p.w[i] = t[i];
+    sub256(k2, k2, p);
+    const u256 Z = zero256();
+    u256 neg;
+    n1 = (k1.w[7] >> 31) != 0;
+    sub256(neg, Z, k1);
+    sel256(m1, n1, neg, k1);
+    n2 = (k2.w[7] >> 31) != 0;
+    sub256(neg, Z, k2);
+    sel256(m2, n2, neg, k2);
+}
+
 // The commitment t of the verification equation, affine, as plain integers in [0, p).
 // Returns NYM_VALID when (tx, ty) is meaningful, NYM_BAD_PROOF when c >= r (an unreduced ProofC can never equal a value
 // reduced mod r: idemix/nymsignature.go:104 compares BIGs), NYM_NEEDS_SW outside the pinned domain.
@@ -105,7 +154,12 @@ FAB_HD uint32_t bn_nym_commitment29(u256& tx, u256& ty, const u256& nx, const u2
     comb_mult29(S1, s1_inf, s_sk, hsk, seed);
     comb_mult29(S2, s2_inf, s_rnym, hrand, seed);
     final_add29(U, u_inf, S1, s1_inf, S2, s2_inf);
-    var_base_mult29(T, t_inf, c, N, qtab);
+    // c * Nym through the GLV endomorphism: c = k1 + k2 lambda, 130 doublings instead of 255
+    u256 m1, m2;
+    bool n1, n2, exc;
+    bn_glv_decompose(m1, n1, m2, n2, c);
+    const fbn BETA = {BN29_BETA_MONT};
+    glv_mult29(T, t_inf, exc, m1, n1, m2, n2, N, BETA, qtab);
     bn_neg29(T);
     final_add29(W, w_inf, U, u_inf, T, t_inf);
 
@@ -126,7 +180,7 @@ FAB_HD uint32_t bn_nym_commitment29(u256& tx, u256& ty, const u256& nx, const u2
     fe_from_mont(ty, ay);
 
     if (early != NYM_VALID) return early;
-    if (!dom || w_inf) return NYM_NEEDS_SW;
+    if (!dom || w_inf || exc) return NYM_NEEDS_SW;
     return NYM_VALID;
 }
 

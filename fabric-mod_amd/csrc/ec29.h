@@ -189,7 +189,7 @@ FAB_HD void final_add29(jac_t<F>& Rr, bool& r_inf, const jac_t<F>& S, bool s_inf
 // 52 signed 5-bit (Booth) windows, digit_i = -16 k[5i+4] + 8 k[5i+3] + .. + k[5i] + k[5i-1] in [-16, 16]: 51 x 5 doublings
 // and at most 52 additions of +-|digit| Q.  (No addition can meet P == +-Q: DESIGN.md.)  t_inf: k == 0.
 template <class F, class QTab>
-FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t<F>& Q, QTab& qtab) {
+FAB_HD void build_lane_table29(const jac_t<F>& Q, QTab& qtab) {
     qtab.store(1, Q);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
@@ -205,6 +205,23 @@ FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t
             qtab.store(j + 1, a);
         }
     }
+}
+// signed 5-bit Booth digit i of a little-endian word array (NW words of scalar + one zero word): bits 5i-1 .. 5i+4, bit -1 = 0
+template <int NW>
+FAB_HD int32_t booth5_digit(const uint32_t (&kw)[NW], int i) {
+    uint32_t six;
+    if (i == 0) {
+        six = (kw[0] << 1) & 63u;
+    } else {
+        int p = 5 * i - 1;
+        uint64_t two = ((uint64_t)kw[(p >> 5) + 1] << 32) | kw[p >> 5];
+        six = (uint32_t)(two >> (p & 31)) & 63u;
+    }
+    return (int32_t)((six >> 1) & 15u) + (int32_t)(six & 1u) - (int32_t)((six >> 5) << 4);
+}
+template <class F, class QTab>
+FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t<F>& Q, QTab& qtab) {
+    build_lane_table29(Q, qtab);
 
     uint32_t kw[9];
 #pragma unroll
@@ -216,15 +233,7 @@ FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t
 #pragma unroll 1
 #endif
     for (int i = Q5_WINDOWS - 1; i >= 0; i--) {
-        uint32_t six;                                  // bits 5i-1 .. 5i+4 of k (bit -1 = 0)
-        if (i == 0) {
-            six = (kw[0] << 1) & 63u;
-        } else {
-            int p = 5 * i - 1;
-            uint64_t two = ((uint64_t)kw[(p >> 5) + 1] << 32) | kw[p >> 5];
-            six = (uint32_t)(two >> (p & 31)) & 63u;
-        }
-        int32_t digit = (int32_t)((six >> 1) & 15u) + (int32_t)(six & 1u) - (int32_t)((six >> 5) << 4);
+        int32_t digit = booth5_digit(kw, i);
         bool neg = digit < 0;
         uint32_t mag = (uint32_t)(neg ? -digit : digit);
         jac_t<F> ent;
@@ -249,6 +258,75 @@ FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t
         sel_jac29(T, take_sum, sum, T);
         sel_jac29(T, take_ent, ent, T);
         t_inf = t_inf & (mag == 0);
+    }
+}
+
+// T = +-m1 * Q +- m2 * phi(Q) for an efficiently computable endomorphism phi(x, y) = (beta x, y) (GLV): both magnitudes below
+// 2^134, so 27 signed 5-bit windows interleaved over ONE accumulator - 26 x 5 doublings and at most 54 additions, half the
+// doublings of var_base_mult29 on the full scalar.  Entries of phi(Q)'s table are the entries of Q's with X scaled by beta
+// (Jacobian: beta x = beta X / Z^2), one product per addition instead of a second table.
+// Unlike the single-scalar loop, the interleaved one has no proof that an addition never meets P == +-Q (the accumulator is
+// (a + b lambda) Q for partial scalars a, b): every addition that is taken tests h == 0, and `exc` reports the event - the
+// caller must then discard T.  (For honest inputs the event needs a + b lambda = +-d (mod r) with small d: it does not occur.)
+constexpr int GLV_WINDOWS = 27;
+template <class F, class QTab>
+FAB_HD void glv_mult29(jac_t<F>& T, bool& t_inf, bool& exc, const u256& m1, bool n1, const u256& m2, bool n2, const jac_t<F>& Q, const F& beta,
+                       QTab& qtab) {
+    build_lane_table29(Q, qtab);
+    uint32_t k1[6], k2[6];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        k1[i] = m1.w[i];
+        k2[i] = m2.w[i];
+    }
+    k1[5] = 0;
+    k2[5] = 0;
+    T = Q;
+    t_inf = true;
+    exc = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = GLV_WINDOWS - 1; i >= 0; i--) {
+        int32_t d1 = booth5_digit(k1, i), d2 = booth5_digit(k2, i);
+        uint32_t g1 = (uint32_t)(d1 < 0 ? -d1 : d1), g2 = (uint32_t)(d2 < 0 ? -d2 : d2);
+        jac_t<F> e1, e2;
+        qtab.load(g1 ? g1 : 1u, e1);                   // both gathers issued ahead of the doublings
+        qtab.load(g2 ? g2 : 1u, e2);
+        if (i != GLV_WINDOWS - 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+            for (int k5 = 0; k5 < 5; k5++) {
+                jac_t<F> dd;
+                pt_dbl29(dd, T);
+                T = dd;
+            }
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int half = 0; half < 2; half++) {
+            jac_t<F> ent = half ? e2 : e1;
+            uint32_t mag = half ? g2 : g1;
+            bool neg = half ? ((d2 < 0) != n2) : ((d1 < 0) != n1);
+            if (half) {
+                F bx;
+                fe_mul(bx, ent.X, beta);                // [1x1]
+                ent.X = bx;
+            }
+#pragma unroll
+            for (int l = 0; l < 9; l++) ent.Y.v[l] = neg ? -ent.Y.v[l] : ent.Y.v[l];
+            jac_t<F> sum;
+            F h, rr;
+            pt_add29(sum, T, ent, h, rr);
+            bool take_ent = t_inf & (mag != 0);
+            bool take_sum = (!t_inf) & (mag != 0);
+            exc = exc | (take_sum & fe_is_zero(h));
+            sel_jac29(T, take_sum, sum, T);
+            sel_jac29(T, take_ent, ent, T);
+            t_inf = t_inf & (mag == 0);
+        }
     }
 }
 

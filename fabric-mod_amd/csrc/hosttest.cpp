@@ -238,4 +238,45 @@ int hosttest_bn_nym_commitment(void* p, const uint8_t* nx32, const uint8_t* ny32
     to_be32(ty32, ty);
     return (int)st;
 }
+// GLV decomposition of the device: k = +-m1 +- m2 lambda (mod r); flags bit0 = k1 negative, bit1 = k2 negative
+int hosttest_bn_glv_decompose(const uint8_t* k32, uint8_t* m1_32, uint8_t* m2_32) {
+    u256 k, m1, m2;
+    bool n1, n2;
+    from_be32(k, k32);
+    bn_glv_decompose(m1, n1, m2, n2, k);
+    to_be32(m1_32, m1);
+    to_be32(m2_32, m2);
+    return (n1 ? 1 : 0) | (n2 ? 2 : 0);
+}
+// +-m1 Q +- m2 phi(Q) through glv_mult29; with identity_beta the "endomorphism" is the identity, which makes collisions
+// (accumulator == addend) constructible: the return value has bit0 = infinity, bit1 = collision reported.
+int hosttest_bn_glv_mult(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* m1_32, int n1, const uint8_t* m2_32, int n2, int identity_beta,
+                         uint8_t* x32, uint8_t* y32) {
+    u256 qx, qy, m1, m2;
+    from_be32(qx, qx32); from_be32(qy, qy32); from_be32(m1, m1_32); from_be32(m2, m2_32);
+    jacbn Q, T;
+    fe_to_mont(Q.X, qx);
+    fe_to_mont(Q.Y, qy);
+    fe_set_one(Q.Z);
+    fbn beta = {BN29_BETA_MONT};
+    if (identity_beta) fe_set_one(beta);
+    LocalQTab<fbn> qtab;
+    bool inf, exc;
+    glv_mult29(T, inf, exc, m1, n1 != 0, m2, n2 != 0, Q, beta, qtab);
+    const modinv_info PI = MODINV_BNP_INFO;
+    u256 zp, zi, x, y;
+    fe_from_mont(zp, T.Z);
+    modinv(zi, zp, PI);
+    fbn zm, z2, z3, ax, ay;
+    fe_to_mont(zm, zi);
+    fe_sqr(z2, zm);
+    fe_mul(z3, z2, zm);
+    fe_mul(ax, T.X, z2);
+    fe_mul(ay, T.Y, z3);
+    fe_from_mont(x, ax);
+    fe_from_mont(y, ay);
+    to_be32(x32, x);
+    to_be32(y32, y);
+    return (inf ? 1 : 0) | (exc ? 2 : 0);
+}
 }

@@ -130,9 +130,11 @@ def test_bn_comb_tables_and_commitment(hosttest, fx):
 
         rng = random.Random(13)
         R = io.R
-        special = [(0, None, None), (None, 0, None), (None, None, 0), (None, 0, 0), (R - 1, None, None), (None, R - 1, R - 1), (1, 1, 1),
+        lam = (36 * io.U**4 - 1) % R
+        special = [(lam, None, None), (lam + 1, None, None), (R - lam, None, None), ((1 << 128) + 1, None, None),
+                   (0, None, None), (None, 0, None), (None, None, 0), (None, 0, 0), (R - 1, None, None), (None, R - 1, R - 1), (1, 1, 1),
                    (1 << 255, 1 << 255, 1 << 255), ((1 << 255) - 1, 0xFF << 248, 1 << 248)]
-        for it in range(40):
+        for it in range(44):
             nym, r_nym = io.make_nym(sk, ipk, rng)
             c, s1, s2 = rng.randrange(R), rng.randrange(R), rng.randrange(R)
             if it < len(special):
@@ -153,6 +155,50 @@ def test_bn_comb_tables_and_commitment(hosttest, fx):
         assert commit((io.P, nym[1]), 5, 1, 1)[0] == io.NYM_NEEDS_SW
     finally:
         hosttest.hosttest_bn_issuer_free(h)
+
+
+def test_glv_decomposition_and_double_scalar_loop(hosttest, fx):
+    """c * Nym on the device goes through k = k1 + k2 lambda; the decomposition must be exact mod r and short, and the
+    interleaved loop must report (not hide) a collision between accumulator and addend."""
+    R, P = io.R, io.P
+    lam = (36 * io.U**4 - 1) % R
+    assert (lam * lam + lam + 1) % R == 0
+    rng = random.Random(17)
+    m1b, m2b = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    worst = 0
+    ks = [0, 1, 2, R - 1, R - 2, lam, lam + 1, lam - 1, R // 2, 1 << 255, (1 << 256) - 1, R, R + 1, (1 << 128) - 1, 1 << 128]
+    ks += [rng.randrange(1 << 256) for _ in range(20000)]
+    for k in ks:
+        fl = hosttest.hosttest_bn_glv_decompose(be32(k), m1b, m2b)
+        m1, m2 = int.from_bytes(m1b.raw, "big"), int.from_bytes(m2b.raw, "big")
+        k1 = -m1 if fl & 1 else m1
+        k2 = -m2 if fl & 2 else m2
+        assert (k1 + k2 * lam - k) % R == 0, hex(k)
+        worst = max(worst, m1, m2)
+    assert worst < 1 << 130                       # 27 windows of 5 bits cover 134
+    # the endomorphism itself: phi(x, y) = (beta x, y) = lambda (x, y) on fixture points
+    ipk = fx["MSP1OU1"]["ipk"]
+    hosttest.hosttest_bn_glv_mult.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
+    ox, oy = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+
+    def glv(Q, m1, n1, m2, n2, ident=0):
+        fl = hosttest.hosttest_bn_glv_mult(be32(Q[0]), be32(Q[1]), be32(m1), n1, be32(m2), n2, ident, ox, oy)
+        return fl, (int.from_bytes(ox.raw, "big"), int.from_bytes(oy.raw, "big"))
+
+    Q = ipk.h_rand
+    assert glv(Q, 0, 0, 1, 0) == (0, io.g1_mul(Q, lam))
+    assert glv(Q, 0, 0, 1, 1) == (0, io.g1_neg(io.g1_mul(Q, lam)))
+    for _ in range(12):
+        m1, m2 = rng.randrange(1 << 129), rng.randrange(1 << 129)
+        n1, n2 = rng.randrange(2), rng.randrange(2)
+        want = io.g1_mul(Q, ((-m1 if n1 else m1) + (-m2 if n2 else m2) * lam) % R)
+        assert glv(Q, m1, n1, m2, n2) == (0, want)
+    assert glv(Q, 0, 0, 0, 0)[0] & 1                                  # infinity
+    # collisions, made constructible by an identity "endomorphism": Q + Q and Q - Q inside one window
+    assert glv(Q, 1, 0, 1, 0, ident=1)[0] & 2
+    assert glv(Q, 1, 0, 1, 1, ident=1)[0] & 2
+    assert glv(Q, 5, 0, 3, 0, ident=1) == (0, io.g1_mul(Q, 8))      # no collision: plain sum
 
 
 def test_g1_gate_of_the_c_abi(fx):
