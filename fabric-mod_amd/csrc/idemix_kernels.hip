@@ -97,6 +97,10 @@ struct IssuerDev {
     uint32_t hash[8];
 };
 
+// Register budget: bounded at two workgroups per CU (256 registers per wave) although the launcher asks for one per CU.  Measured
+// (r01, MI355X): with the whole file (bound 1, no spills) the kernel alone is 2 % faster, but a wave then owns its SIMD and the
+// ECDSA kernel of a mixed batch (BASELINE config 5, the other stream) can no longer share the CU: 300 000 mixed signatures went
+// from 6.2 ms to 7.4 ms.  The spills (258 VGPRs, 13 k scratch accesses per wave against 850 k VALU instructions) are the cheaper evil.
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 2)
     idemix_nym_verify_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,

@@ -29,8 +29,18 @@ import (
 // NymVerifier answers on the GPU when it can and asks the wrapped software verifier otherwise.
 type NymVerifier struct {
 	SW      *handlers.NymVerifier // the reference's verifier: fallback for every tuple the device does not decide
-	Ctx     *C.fabgpu_ctx         // shared with the ECDSA provider (bccsp/gpu)
+	Ctx     *C.fabgpu_ctx         // this verifier's own device context (cgo types are per package: not shared with bccsp/gpu)
 	issuers sync.Map              // string(ipk bytes) -> int64 issuer id, -1 = not accelerated
+}
+
+// New is what bccsp/idemix/bccsp.go:60-62 calls under the fabgpu build tag; on any device error the caller keeps sw.
+func New(sw *handlers.NymVerifier, device int) (*NymVerifier, error) {
+	cfg := C.fabgpu_cfg{device: C.int32_t(device)}
+	var ctx *C.fabgpu_ctx
+	if rc := C.fabgpu_init(&cfg, &ctx); rc != 0 {
+		return nil, errors.Errorf("Failed initializing GPU idemix verifier: %s", C.GoString(C.fabgpu_strerror(rc)))
+	}
+	return &NymVerifier{SW: sw, Ctx: ctx}, nil
 }
 
 func (v *NymVerifier) issuerID(ipk bccsp.Key) int64 {
