@@ -166,6 +166,12 @@ int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t
 }
 
 // ---- idemix (idemix_host.h) ----
+int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id) {
+    if (!csp || !mspid || !ipk_raw || !issuer_id) return FABGPU_EINVAL;
+    *issuer_id = csp->csp->RegisterIdemixMSP(mspid, ipk_raw, len);
+    return FABGPU_OK;
+}
+
 int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap) {
     if (!csp || !issuer_id) return FABGPU_EINVAL;
     IdemixCSP ic(csp->csp->ctx());

@@ -12,6 +12,7 @@
 // There is no CPU implementation of the curve arithmetic or of SHA-256 in here: every verdict comes
 // from the HIP kernels through the C ABI; without a device fabgpu_init fails and so does this layer.
 #include "bccsp_host.h"
+#include "idemix_host.h"
 
 #include <string.h>
 
@@ -416,6 +417,16 @@ Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& ou
     return PreVerifyParsed(block, pb, out);
 }
 
+int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len) const {
+    IdemixCSP ic(ctx_);
+    IdemixIssuerPublicKey k;
+    Error e = ic.IssuerKeyImport(ipk_raw, len, k);
+    if (!e.ok()) return -1;
+    std::lock_guard<std::mutex> lk(idmu_);
+    idemix_msps_[mspid] = k.issuer_id;
+    return k.issuer_id;
+}
+
 Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out) const {
     out = BlockVerdicts();
     const size_t nt = pb.tuples.size();
@@ -430,10 +441,16 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     // identities -> keys (cached across blocks), signatures -> (r, s) through the reference's gates.  Tuples are independent:
     // blocks of 4096+ tuples are gated on worker threads (contiguous ranges), then compacted in order.
     struct Gated {
-        uint8_t qx[32], qy[32], r[32], s[32];
-        int64_t key_id;
-        bool submit;
+        uint8_t qx[32], qy[32], r[32], s[32];   // idemix tuple: qx, qy = pseudonym; r, s = ProofC, ProofSSk
+        uint8_t srn[32], nonce[32];              // idemix only: ProofSRNym, Nonce
+        int64_t key_id;                          // idemix: issuer id
+        bool submit, nym;
     };
+    std::map<std::string, int64_t> idemix_msps;
+    {
+        std::lock_guard<std::mutex> lk(idmu_);
+        idemix_msps = idemix_msps_;
+    }
     std::vector<Gated> gt(nt);
     std::vector<uint32_t> new_ids(1, 0);
     auto gate_range = [&](size_t lo, size_t hi, uint32_t* fresh) {
@@ -450,6 +467,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             const BlockTuple& tp = pb.tuples[i];
             Gated& g0 = gt[i];
             g0.submit = false;
+            g0.nym = false;
             out.tuple_tx[i] = tp.tx;
             out.tuple_kind[i] = tp.kind;
             CachedIdentity ci;
@@ -461,6 +479,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                     break;
                 }
             if (!hit) {
+                bool transient = false;
                 std::string key((const char*)block + tp.identity.off, tp.identity.len);
                 std::lock_guard<std::mutex> lk(idmu_);
                 auto it = idcache_.find(key);
@@ -471,11 +490,31 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                         uint32_t id = 0;
                         if (fabgpu_p256_key_register(ctx_, ci.qx, ci.qy, &id) == FABGPU_OK) ci.key_id = id;
                     }
-                    idcache_[key] = ci;
+                    // idemix identities carry a fresh pseudonym per transaction: caching them would only grow the map
+                    std::string ms;
+                    uint8_t tnx[32], tny[32];
+                    transient = !ci.p256 && IdentityToIdemixNym(block + tp.identity.off, tp.identity.len, ms, tnx, tny);
+                    if (!transient) idcache_[key] = ci;
                 } else {
                     ci = it->second;
                 }
-                if (front.size() < 64) front.push_back({block + tp.identity.off, tp.identity.len, ci});
+                if (!transient && front.size() < 64) front.push_back({block + tp.identity.off, tp.identity.len, ci});
+            }
+            if (!ci.p256 && tp.kind == TUPLE_CREATOR && !idemix_msps.empty()) {
+                // an idemix creator (never an endorser: docs/source/idemix.rst:171-176)?  identity.Verify is then
+                // NymSignature.Ver under the MSP's issuer key (msp/idemixmsp.go:584-599)
+                std::string mspid;
+                if (IdentityToIdemixNym(block + tp.identity.off, tp.identity.len, mspid, g0.qx, g0.qy)) {
+                    auto im = idemix_msps.find(mspid);
+                    NymSignatureFields sf;
+                    if (im != idemix_msps.end() && im->second >= 0 && tp.sig.len != 0 && UnmarshalNymSignature(block + tp.sig.off, tp.sig.len, sf) &&
+                        sf.len[0] == 32 && sf.len[1] == 32 && sf.len[2] == 32 && sf.len[3] == 32) {
+                        memcpy(g0.r, sf.f[0], 32); memcpy(g0.s, sf.f[1], 32); memcpy(g0.srn, sf.f[2], 32); memcpy(g0.nonce, sf.f[3], 32);
+                        g0.key_id = im->second;
+                        g0.nym = true;
+                        continue;
+                    }
+                }
             }
             if (!ci.p256) {
                 out.tuple_status[i] = TUPLE_ST_NEEDS_SW;
@@ -567,6 +606,43 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         for (size_t j = 0; j < n; j++) {
             bool bit = (bits[j >> 6] >> (j & 63)) & 1;
             out.tuple_status[sub[j]] = (bit && st[j] == FABGPU_ST_VALID) ? FABGPU_ST_VALID : (st[j] == FABGPU_ST_VALID ? FABGPU_ST_BAD_MATH : st[j]);
+        }
+    }
+    // idemix creators: their messages (the envelope payloads) are gathered into one arena for the nym kernel
+    {
+        std::vector<uint32_t> ns;
+        for (size_t i = 0; i < nt; i++)
+            if (gt[i].nym) ns.push_back((uint32_t)i);
+        const size_t m = ns.size();
+        if (m) {
+            std::vector<uint8_t> cols[6], arena;
+            std::vector<uint32_t> iss(m), noff(m + 1, 0);
+            size_t total = 0;
+            for (size_t j = 0; j < m; j++) total += pb.tuples[ns[j]].suffix.len;
+            if (total > 0x7FFFFFFFull) return Error("idemix creator messages exceed 2 GiB");
+            arena.reserve(total + 1);
+            for (int k = 0; k < 6; k++) cols[k].reserve(m * 32);
+            for (size_t j = 0; j < m; j++) {
+                const Gated& g0 = gt[ns[j]];
+                const BlockTuple& tp = pb.tuples[ns[j]];
+                cols[0].insert(cols[0].end(), g0.qx, g0.qx + 32);
+                cols[1].insert(cols[1].end(), g0.qy, g0.qy + 32);
+                cols[2].insert(cols[2].end(), g0.r, g0.r + 32);
+                cols[3].insert(cols[3].end(), g0.s, g0.s + 32);
+                cols[4].insert(cols[4].end(), g0.srn, g0.srn + 32);
+                cols[5].insert(cols[5].end(), g0.nonce, g0.nonce + 32);
+                iss[j] = (uint32_t)g0.key_id;
+                arena.insert(arena.end(), block + tp.suffix.off, block + tp.suffix.off + tp.suffix.len);
+                noff[j + 1] = (uint32_t)arena.size();
+            }
+            if (arena.empty()) arena.push_back(0);
+            std::vector<uint64_t> bits((m + 63) / 64);
+            std::vector<uint8_t> st(m);
+            int rc = fabgpu_idemix_nym_verify_batch(ctx_, m, arena.data(), noff.data(), iss.data(), cols[0].data(), cols[1].data(), cols[2].data(),
+                                                    cols[3].data(), cols[4].data(), cols[5].data(), bits.data(), st.data());
+            if (rc != FABGPU_OK) return Error(std::string("GPU nym verify failed: ") + fabgpu_strerror(rc));
+            for (size_t j = 0; j < m; j++)   // FABGPU_NYM_VALID = 0, BAD_PROOF = 1 (= "signature invalid"), NEEDS_SW = 6 = TUPLE_ST_NEEDS_SW
+                out.tuple_status[ns[j]] = st[j];
         }
     }
     // per-transaction summary: not understood > bad creator signature > bad endorsement > "ask bccsp/sw" > all valid

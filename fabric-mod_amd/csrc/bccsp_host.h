@@ -96,6 +96,9 @@ class GPUCSP {
     // Block-level pre-verify pass (block_prepass.h): one fused launch for every creator / endorsement signature of the block.
     Error PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const;
     Error PreVerifyParsed(const uint8_t* block, const ParsedBlock& parsed, BlockVerdicts& out) const;
+    // An idemix MSP of the channel (msp/idemixmsp.go:99-173 Setup): its creators' pseudonym signatures are then verified by the
+    // pre-verify pass too.  ipk_raw: marshalled idemix.IssuerPublicKey.  Returns the device issuer id, or -1 (not accelerated).
+    int64_t RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len) const;
     fabgpu_ctx* ctx() const { return ctx_; }
 
    private:
@@ -109,6 +112,7 @@ class GPUCSP {
     };
     mutable std::mutex idmu_;
     mutable std::map<std::string, CachedIdentity> idcache_;
+    mutable std::map<std::string, int64_t> idemix_msps_;   // mspid -> device issuer id (guarded by idmu_)
 };
 
 }  // namespace bccsp

@@ -183,6 +183,24 @@ bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy
     return CertDerToP256(der.data(), der.size(), qx, qy);
 }
 
+bool IdentityToIdemixNym(const uint8_t* ident, size_t len, std::string& mspid, uint8_t nx[32], uint8_t ny[32]) {
+    const uint8_t *idb, *ms;
+    size_t idl, msl;
+    if (!pb_bytes(ident, len, 2, idb, idl) || !pb_bytes(ident, len, 1, ms, msl)) return false;
+    PbReader r(idb, idl);
+    PbField f;
+    bool hx = false, hy = false, proof = false;
+    while (r.next(f)) {
+        if (f.wt != 2) continue;
+        if (f.num == 1 && f.len == 32) { memcpy(nx, f.data, 32); hx = true; }
+        if (f.num == 2 && f.len == 32) { memcpy(ny, f.data, 32); hy = true; }
+        if (f.num == 5) proof = true;
+    }
+    if (!r.ok || !hx || !hy || !proof) return false;
+    mspid.assign((const char*)ms, msl);
+    return true;
+}
+
 namespace {
 // one envelope -> its tuples (prefix indices local to `out`)
 void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, uint32_t tx, ParsedBlock& out, uint8_t& tx_type, uint8_t& understood) {

@@ -68,6 +68,10 @@ bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy
 // DER x509 certificate -> P-256 SubjectPublicKeyInfo point (exposed for tests against the reference's certificate fixtures)
 bool CertDerToP256(const uint8_t* der, size_t len, uint8_t qx[32], uint8_t qy[32]);
 bool PemToDer(const uint8_t* pem, size_t len, std::vector<uint8_t>& der);
+// SerializedIdentity{mspid, id_bytes = msp.SerializedIdemixIdentity{1 nym_x, 2 nym_y, 3 ou, 4 role, 5 proof}} (what
+// idemixidentity.Serialize writes, msp/idemixmsp.go:605-640) -> MSP id and the 32-byte pseudonym coordinates.
+// false: not such an identity (or coordinates of another size: those stay with bccsp/idemix).
+bool IdentityToIdemixNym(const uint8_t* ident, size_t len, std::string& mspid, uint8_t nx[32], uint8_t ny[32]);
 
 }  // namespace bccsp
 }  // namespace fab

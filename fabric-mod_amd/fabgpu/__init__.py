@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
-    "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch",
+    "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register",
     "fabgpu_synth_batch",
 ]
 
@@ -134,6 +134,7 @@ def load():
     L.fabgpu_csp_identity_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u32p, _u8p, _u32p, ctypes.c_char_p, _sz]
     L.fabgpu_csp_block_preverify.argtypes = [_vp, _u8p, _sz, _u32p, _u8p, _u8p, ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_uint32]
     L.fabgpu_block_parse.argtypes = [_u8p, _sz, _u32p, _u32p, _u32p, _u8p, ctypes.c_uint32, ctypes.c_char_p, _sz]
+    L.fabgpu_csp_idemix_msp_register.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64)]
     L.fabgpu_csp_idemix_issuer_import.argtypes = [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, _sz]
     L.fabgpu_csp_idemix_nym_verify_batch.argtypes = [_vp, ctypes.c_int64, _sz, _u8p, _u32p, _u8p, _u32p, _u8p, _u32p, _u8p, _u8p, ctypes.c_char_p, _sz]
     L.fabgpu_x509_p256_pubkey.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
@@ -501,6 +502,13 @@ class GPUCSP:
                "fabgpu_csp_idemix_issuer_import")
         if err.value:
             raise BCCSPError(err.value.decode())
+        return int(iid.value)
+
+    def idemix_msp_register(self, mspid: str, ipk_raw: bytes) -> int:
+        """An idemix MSP of the channel: preverify_block then verifies its creators' pseudonym signatures too."""
+        iid = ctypes.c_int64(-1)
+        _check(self._L.fabgpu_csp_idemix_msp_register(self._h, mspid.encode(), bytes(ipk_raw), len(ipk_raw), ctypes.byref(iid)),
+               "fabgpu_csp_idemix_msp_register")
         return int(iid.value)
 
     def idemix_nym_verify_batch(self, issuer_id: int, nym_keys: Sequence[bytes], sigs: Sequence[bytes], msgs: Sequence[bytes]):

@@ -76,6 +76,9 @@ int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t
  * fabgpu_csp_idemix_nym_verify_batch: NymVerifier.Verify (bccsp/idemix/handlers/nymsigner.go:62-95) over n tuples under one
  * issuer: nym public keys as NymPublicKeyImporter.KeyImport receives them (x || y), marshalled idemix.NymSignature bytes,
  * messages.  valid[i] 0/1; flags[i] bit0: tuple left to bccsp/idemix; errs[i] = Go error text ("" == nil). */
+/* An idemix MSP of the channel (msp/idemixmsp.go:99-173): after this call fabgpu_csp_block_preverify also verifies the pseudonym
+ * signatures of creators serialized under `mspid` (tuple_status 0 valid / 1 invalid / 6 left to bccsp/idemix). */
+int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id);
 int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap);
 int fabgpu_csp_idemix_nym_verify_batch(fabgpu_csp* csp, int64_t issuer_id, size_t n, const uint8_t* nym_arena, const uint32_t* nym_off,
                                        const uint8_t* sig_arena, const uint32_t* sig_off, const uint8_t* msg_arena, const uint32_t* msg_off,

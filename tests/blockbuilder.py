@@ -28,6 +28,11 @@ def serialized_identity(mspid: str, pem: str) -> bytes:
     return fbytes(1, mspid.encode()) + fbytes(2, pem.encode())
 
 
+def serialized_idemix_identity(mspid: str, nym_x: bytes, nym_y: bytes, ou: bytes = b"\x0a\x03OU1", role: bytes = b"\x08\x01", proof: bytes = b"proof") -> bytes:
+    """msp.SerializedIdentity{mspid, id_bytes = msp.SerializedIdemixIdentity{1 nym_x, 2 nym_y, 3 ou, 4 role, 5 proof}} (msp/idemixmsp.go:605-640)"""
+    return fbytes(1, mspid.encode()) + fbytes(2, fbytes(1, nym_x) + fbytes(2, nym_y) + fbytes(3, ou) + fbytes(4, role) + fbytes(5, proof))
+
+
 def channel_header(typ: int, channel: str, txid: str) -> bytes:
     return (fvarint(1, typ) if typ else b"") + fvarint(2, 0 + 1) + fbytes(4, channel.encode()) + fbytes(5, txid.encode()) + fvarint(6, 0 + 7)
 

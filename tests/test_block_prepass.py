@@ -159,3 +159,82 @@ def test_preverify_pass_end_to_end():
     blk3, want3 = build_block(64, rng, corrupt=False)
     assert (fabgpu.preverify_block(csp, blk3)["tx_flags"] == 0).all() and (want3 == 0).all()
     csp.close()
+
+
+# ---- blocks whose creators are idemix identities (BASELINE config 5 at the block level) -----------------------------------
+def build_mixed_block(n_tx, rng, idemix_every=5):
+    """As build_block(corrupt=False), but every idemix_every-th transaction is created by an idemix identity of IdemixMSP1 whose
+    envelope signature is a NymSignature; some of those are tampered.  Returns (block, expected tx flags, #idemix creators)."""
+    import random as pyrandom
+    import idemix_oracle as io
+    from idemix_common import be32, fixtures
+    fx = fixtures()
+    ipk, sk = fx["MSP1OU1"]["ipk"], fx["MSP1OU1"]["signer"].sk
+    prng = pyrandom.Random(int(rng.integers(1, 1 << 30)))
+    p256 = [i for i in IDS if i["curve"] == "prime256v1"]
+    sid = {i["cn"]: bb.serialized_identity("Org1MSP", i["pem"]) for i in IDS}
+    endorsers, creators = p256[:4], p256[4:6]
+    envs, want, n_idemix = [], [], 0
+    for t in range(n_tx):
+        prp = bytes(rng.integers(0, 256, size=int(rng.integers(100, 1200)), dtype=np.uint8))
+        ccpp = bytes(rng.integers(0, 256, size=200, dtype=np.uint8))
+        ends = []
+        for j in rng.choice(4, size=3, replace=False):
+            e = endorsers[j]
+            r, s = _sign(e, prp + sid[e["cn"]], int(rng.integers(1, 1 << 62)))
+            ends.append((sid[e["cn"]], po.marshal_ecdsa_signature(r, s)))
+        flag = fabgpu.TX_ALL_SIGNATURES_VALID
+        if t % idemix_every == 0:
+            n_idemix += 1
+            nym, r_nym = io.make_nym(sk, ipk, prng)
+            which = (t // idemix_every) % 6
+            mspid = "IdemixMSP1" if which != 4 else "UnknownIdemixMSP"
+            cbytes = bb.serialized_idemix_identity(mspid, be32(nym[0]), be32(nym[1]))
+            payload = bb.endorser_tx_payload(3, "mychannel", "tx%d" % t, cbytes, b"nonce%d" % t, [(ccpp, prp, ends)])
+            sig = io.nym_sign(sk, nym, r_nym, ipk, payload, prng)
+            if which == 2:                                # signed another payload
+                sig = io.nym_sign(sk, nym, r_nym, ipk, payload + b"!", prng); flag = fabgpu.TX_BAD_CREATOR_SIGNATURE
+            if which == 3:                                # a 31-byte field: amcl-internal, left to bccsp/idemix
+                sig = dict(sig, nonce=sig["nonce"][:31]); flag = fabgpu.TX_NEEDS_SW
+            if which == 4:                                # an idemix MSP nobody registered
+                flag = fabgpu.TX_NEEDS_SW
+            if which == 5:                                # s-value >= r: outside the device's domain
+                sig = dict(sig, proof_s_sk=be32(io.R + 5)); flag = fabgpu.TX_NEEDS_SW
+            envs.append(bb.envelope(payload, io.nym_signature_marshal(sig)))
+        else:
+            creator = creators[t % 2]
+            payload = bb.endorser_tx_payload(3, "mychannel", "tx%d" % t, sid[creator["cn"]], b"nonce%d" % t, [(ccpp, prp, ends)])
+            r, s = _sign(creator, payload, int(rng.integers(1, 1 << 62)))
+            envs.append(bb.envelope(payload, po.marshal_ecdsa_signature(r, s)))
+        want.append(flag)
+    return bb.block(9, envs), np.array(want, dtype=np.uint8), n_idemix
+
+
+def test_walker_sees_idemix_creators_as_ordinary_tuples():
+    rng = np.random.default_rng(8)
+    blk, want, n_idemix = build_mixed_block(30, rng)
+    p = fabgpu.block_parse(blk)
+    assert p["n_tx"] == 30 and p["n_tuples"] == 30 * 4 and n_idemix == 6
+
+
+@pytest.mark.gpu
+def test_preverify_pass_with_idemix_creators():
+    import json
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    raw_ipk = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_fixtures.json")))["msps"]["MSP1OU1"]["ipk"])
+    csp = fabgpu.GPUCSP(device=0)
+    rng = np.random.default_rng(9)
+    blk, want, n_idemix = build_mixed_block(120, rng)
+    # before the MSP is registered every idemix creator is left to bccsp/idemix
+    out0 = fabgpu.preverify_block(csp, blk)
+    idemix_tx = np.arange(120) % 5 == 0
+    assert (out0["tx_flags"][idemix_tx] == fabgpu.TX_NEEDS_SW).all() and (out0["tx_flags"][~idemix_tx] == 0).all()
+    assert csp.idemix_msp_register("IdemixMSP1", raw_ipk) >= 0
+    out = fabgpu.preverify_block(csp, blk)
+    assert (out["tx_flags"] == want).all(), list(zip(np.nonzero(out["tx_flags"] != want)[0], out["tx_flags"][out["tx_flags"] != want]))
+    creators = out["tuple_kind"] == fabgpu.TUPLE_CREATOR if hasattr(fabgpu, "TUPLE_CREATOR") else out["tuple_kind"] == 0
+    assert (out["tuple_status"][~creators] == 0).all()
+    assert (out["tx_flags"] == fabgpu.TX_BAD_CREATOR_SIGNATURE).sum() == sum(1 for t in range(0, 120, 5) if (t // 5) % 6 == 2)
+    assert fabgpu.preverify_block(csp, blk)["tx_flags"].tolist() == want.tolist()          # repeatable; pseudonyms are not cached
+    csp.close()
