@@ -11,6 +11,9 @@
 #pragma once
 #include "bn29_consts.h"
 #include "fe29.h"
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "bn29_gcn.h"
+#endif
 
 namespace fab {
 
@@ -84,8 +87,29 @@ FAB_FN fbn fbn_sqr_fn(fbn a) {
     }
     return r;
 }
-FAB_HD void fe_mul(fbn& r, const fbn& a, const fbn& b) { r = fbn_mul_fn(a, b); }
-FAB_HD void fe_sqr(fbn& r, const fbn& a) { r = fbn_sqr_fn(a); }
+// On the device the product is ONE generated asm statement (bn29_gcn.h, gcn_dsl.py with a GenericField: 214 / 186 instructions,
+// all 8-byte encodings, no hazard padding), inlined like P-256's: every loop body of the nym kernel (a doubling 11 KB, an
+// addition 31 KB, a mixed addition 19 KB) still fits the 64 KB instruction cache.  The C bodies above are the host build and
+// the specification; BN29_CALL_FIELD_FNS keeps them as real functions on the device too (the round-1 baseline: 246 / 215
+// instructions plus ~30 of call overhead per product).
+FAB_HD void fe_mul(fbn& r, const fbn& a, const fbn& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BN29_CALL_FIELD_FNS)
+    fbn t;
+    BN29_GCN_MUL(t, a, b);
+    r = t;
+#else
+    r = fbn_mul_fn(a, b);
+#endif
+}
+FAB_HD void fe_sqr(fbn& r, const fbn& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BN29_CALL_FIELD_FNS)
+    fbn t, dbl;
+    BN29_GCN_SQR(t, dbl, a);
+    r = t;
+#else
+    r = fbn_sqr_fn(a);
+#endif
+}
 
 FAB_HD void fe_set_one(fbn& r) {
     const fbn ONE = {BN29_R1};

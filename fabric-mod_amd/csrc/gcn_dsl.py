@@ -35,9 +35,28 @@ CONSTS = {"c9": 512, "c18": 262144, "cm21": -2097152, "c24": 16777216, "c28": 26
 RED = [(3, "c9"), (6, "c18"), (7, "cm21"), (8, "c24")]
 
 
+class GenericField:
+    """A prime without structure: Montgomery reduction by quotient digits q = column * n0 mod 2^29 and nine MACs q * p_j with p
+    as balanced digits (bn29.h).  The constants travel as SGPR operands pb0..pb8 and n0."""
+
+    def __init__(self, p_balanced, n0):
+        assert len(p_balanced) == 9
+        self.pb = list(p_balanced)
+        self.n0 = n0
+
+    def consts(self):
+        d = {"pb%d" % j: self.pb[j] for j in range(9)}
+        d["n0"] = self.n0
+        return d
+
+
 class Program:
-    def __init__(self, name):
+    def __init__(self, name, field=None):
         self.name = name
+        self.field = field     # None: the P-256 prime (reduction by the four constants of RED); GenericField otherwise
+        self.consts = dict(CONSTS)
+        if field is not None:
+            self.consts.update(field.consts())
         self.ins = []          # (op, dst, *srcs)
         self.fes = {}          # fe name -> kind: "io" | "tmp" | "in"
         self.order = []        # declaration order
@@ -108,11 +127,21 @@ class Program:
             for (x, y) in products(k):
                 self.ins.append(("mad0" if first else "mad", "acc", x, y))
                 first = False
-            for (dd, c) in RED:
-                if k >= dd and k - dd <= 8:
-                    self.ins.append(("mad", "acc", r[k - dd], c))
+            if self.field is None:
+                for (dd, c) in RED:
+                    if k >= dd and k - dd <= 8:
+                        self.ins.append(("mad", "acc", r[k - dd], c))
+            else:
+                for i in range(9):
+                    j = k - i
+                    if i < k and 0 <= j < 9:
+                        self.ins.append(("mad", "acc", r[i], "pb%d" % j))
             if k <= 8:
-                self.ins.append(("q29", r[k], "acc"))             # r[k] = acc & (2^29-1)   (quotient digit)
+                if self.field is None:
+                    self.ins.append(("q29", r[k], "acc"))         # r[k] = acc & (2^29-1)   (quotient digit: p = -1 mod 2^29)
+                else:
+                    self.ins.append(("qn0", r[k], "acc"))         # r[k] = (acc * n0) & (2^29-1)
+                    self.ins.append(("mad", "acc", r[k], "pb0"))
                 self.ins.append(("ashr64", "acc", 29))
             else:
                 self.ins.append(("bfe29", r[k - 9], "acc"))       # balanced output digit
@@ -151,8 +180,8 @@ class Program:
         def val(lane, x):
             if isinstance(x, int):
                 return x
-            if x in CONSTS:
-                return CONSTS[x]
+            if x in self.consts:
+                return self.consts[x]
             return L[lane][x]
         for ins in self.ins:
             op = ins[0]
@@ -198,6 +227,8 @@ class Program:
                     acc[lane] = s64(acc[lane] + s32(val(lane, ins[2])) * s32(val(lane, ins[3])))
                 elif op == "q29":
                     R[ins[1]] = acc[lane] & ((1 << 29) - 1)
+                elif op == "qn0":
+                    R[ins[1]] = ((acc[lane] & M32) * self.consts["n0"]) & ((1 << 29) - 1)
                 elif op == "ashr64":
                     acc[lane] = s64(acc[lane]) >> ins[2]
                 elif op == "round28":
@@ -223,9 +254,10 @@ class Program:
                 for i in range(9):
                     num[f"{name}.{i}"] = len(outs) + len(ins_)
                     ins_.append('"v"((%s).v[%d])' % (macro_args[name], i))
-        for c in ("c9", "c18", "cm21", "c24", "c28"):
+        cnames = ("c9", "c18", "cm21", "c24", "c28") if self.field is None else tuple("pb%d" % j for j in range(9)) + ("n0", "c28")
+        for c in cnames:
             num[c] = len(outs) + len(ins_)
-            ins_.append('"s"(%d)' % CONSTS[c])
+            ins_.append('"s"(%d)' % self.consts[c])
         num["c28q"] = len(outs) + len(ins_)
         ins_.append('"s"((int64_t)268435456)')
         num["mask"] = len(outs) + len(ins_)
@@ -283,6 +315,9 @@ class Program:
                 put("v_mad_i64_i32 v[0:1], vcc, %s, %s, v[0:1]" % (o(ins[2]), o(ins[3])))
             elif op == "q29":
                 put("v_and_b32 %s, 0x1fffffff, v0" % o(ins[1]), ins[1])
+            elif op == "qn0":
+                put("v_mul_lo_u32 %s, v0, %s" % (o(ins[1]), o("n0")), ins[1])
+                put("v_and_b32 %s, 0x1fffffff, %s" % (o(ins[1]), o(ins[1])), ins[1])
             elif op == "ashr64":
                 put("v_ashrrev_i64 v[0:1], %d, v[0:1]" % ins[2])
             elif op == "round28":

@@ -17,7 +17,7 @@ tests/test_pair_programs.py runs these very programs in gcn_dsl.Program.run() ag
 Run:  python3 gen_pair_gcn.py > pair29_gcn.h ; python3 gen_pair_gcn.py field > fe29_gcn.h   (the Makefile does this)
 The single-lane field product / square of fe29.h are generated from the same DSL (build_fe_mul / build_fe_sqr).
 """
-from gcn_dsl import Program
+from gcn_dsl import GenericField, Program
 
 
 def build_pair_dbl():
@@ -194,7 +194,32 @@ def build_fe_sqr():
     return p
 
 
+def bn_field():
+    import gen_bn_consts as c
+    return GenericField(c.balanced(c.P), (-pow(c.P, -1, 1 << 29)) % (1 << 29))
+
+
+def build_bn_mul():
+    """R = A * B / 2^261 mod the FP256BN prime (bn29.h); R must not alias A or B."""
+    p = Program("BN29_GCN_MUL", bn_field())
+    R = p.fe("R", "tmp")
+    A = p.fe("A", "in")
+    B = p.fe("B", "in")
+    p.mul(R, A, B)
+    return p
+
+
+def build_bn_sqr():
+    p = Program("BN29_GCN_SQR", bn_field())
+    R = p.fe("R", "tmp")
+    T = p.fe("T", "tmp")
+    A = p.fe("A", "in")
+    p.sqr(R, A, T)
+    return p
+
+
 FIELD_PROGRAMS = [build_fe_mul, build_fe_sqr]
+BN_FIELD_PROGRAMS = [build_bn_mul, build_bn_sqr]
 PROGRAMS = [build_pair_dbl, build_pair_add, build_pair_madd]
 
 ALIGN_NOTE = """// Every instruction below is 8 bytes (VOP3, VOP2 + DPP, or VOP2 + 32-bit literal): a block started on an 8-byte boundary stays
@@ -206,8 +231,13 @@ ALIGN_NOTE = """// Every instruction below is 8 bytes (VOP3, VOP2 + DPP, or VOP2
 
 
 def emit(path_kind):
-    progs = FIELD_PROGRAMS if path_kind == "field" else PROGRAMS
-    if path_kind == "field":
+    progs = {"field": FIELD_PROGRAMS, "bnfield": BN_FIELD_PROGRAMS}.get(path_kind, PROGRAMS)
+    if path_kind == "bnfield":
+        print("// GENERATED by gen_pair_gcn.py bnfield - do not edit.  gfx950 instruction streams of the FP256BN field product (bn29.h).")
+        print("#pragma once")
+        print('#include "fe29_gcn.h"   // FE29_GCN_ALIGN')
+        print()
+    elif path_kind == "field":
         print("// GENERATED by gen_pair_gcn.py field - do not edit.  gfx950 instruction streams of fe_mul / fe_sqr (fe29.h).")
         print("#pragma once")
         print(ALIGN_NOTE)
@@ -225,7 +255,7 @@ def emit(path_kind):
 
 def main():
     import sys
-    emit("field" if len(sys.argv) > 1 and sys.argv[1] == "field" else "pair")
+    emit(sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("field", "bnfield") else "pair")
 
 
 if __name__ == "__main__":

@@ -107,6 +107,41 @@ def test_field_product_and_square_programs():
         assert all(-(1 << 28) <= re["R.%d" % i] <= (1 << 28) for i in range(8))   # balanced output digits
 
 
+def test_bn_field_product_and_square_programs():
+    """BN29_GCN_MUL / BN29_GCN_SQR (bn29.h on the device): the DSL's generic-prime reduction, run in the interpreter against big
+    integers mod the FP256BN prime, with lazy operands up to the bound of that field (L(a) L(b) <= 12)."""
+    import gen_bn_consts as bc
+    BP = bc.P
+    BRI = pow(R, -1, BP)
+
+    def to_bn(x):
+        return bal(x * R % BP)
+
+    def bval(regs, name):
+        return sum(regs["%s.%d" % (name, i)] << (29 * i) for i in range(9)) * BRI % BP
+    rng = random.Random(77)
+    mul, sqr = gp.build_bn_mul(), gp.build_bn_sqr()
+    assert sum(1 for i in mul.ins if i[0] in ("mad", "mad0")) == 162 and sum(1 for i in sqr.ins if i[0] in ("mad", "mad0")) == 126
+    edge = [0, 1, BP - 1, BP - 2, (1 << 255) % BP]
+    cases = [(a, b) for a in edge for b in edge] + [(rng.randrange(BP), rng.randrange(BP)) for _ in range(60)]
+    for a, b in cases:
+        e, o = {}, {}
+        put(e, "A", to_bn(a)); put(e, "B", to_bn(b)); put(o, "A", to_bn(b)); put(o, "B", to_bn(a))
+        re, ro = mul.run(e, o)
+        assert bval(re, "R") == a * b % BP and bval(ro, "R") == a * b % BP
+        l3 = [3 * x for x in to_bn(a)]                                 # L = 3 operand, squared: 9 <= 12
+        l4 = [4 * x for x in to_bn(a)]
+        e2, o2 = {}, {}
+        put(e2, "A", l3); put(o2, "A", to_bn(b))
+        re, ro = sqr.run(e2, o2)
+        assert bval(re, "R") == 9 * a * a % BP and bval(ro, "R") == b * b % BP
+        assert all(-(1 << 28) <= re["R.%d" % i] <= (1 << 28) for i in range(8))
+        e3, o3 = {}, {}
+        put(e3, "A", l4); put(e3, "B", l3); put(o3, "A", l3); put(o3, "B", l4)   # L = 4 x 3 = 12: the edge of the bound
+        re, ro = mul.run(e3, o3)
+        assert bval(re, "R") == 12 * a * a % BP
+
+
 def test_pair_scalar_multiplication_chain(progs):
     """Left-to-right double-and-add of a random 48-bit scalar with Jacobian table entries (pair add) and affine ones
     (pair madd), against the oracle after every step."""
