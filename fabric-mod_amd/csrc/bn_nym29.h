@@ -129,23 +129,47 @@ FAB_HD void bn_glv_decompose(u256& m1, bool& n1, u256& m2, bool& n2, const u256&
     sel256(m2, n2, neg, k2);
 }
 
-// The commitment t of the verification equation, affine, as plain integers in [0, p).
-// Returns NYM_VALID when (tx, ty) is meaningful, NYM_BAD_PROOF when c >= r (an unreduced ProofC can never equal a value
-// reduced mod r: idemix/nymsignature.go:104 compares BIGs), NYM_NEEDS_SW outside the pinned domain.
-// KTab: comb tables of HSk and HRand; QTab: per-lane store(j, point) / load(j, point), j = 1..16.
-template <class KTab, class QTab>
-FAB_HD uint32_t bn_nym_commitment29(u256& tx, u256& ty, const u256& nx, const u256& ny, const u256& c, const u256& s_sk,
-                                    const u256& s_rnym, const KTab& hsk, const KTab& hrand, QTab& qtab) {
+// ---- pieces shared by the one-lane and the two-lane form of the commitment -------------------------------------------------
+// input gates + the pseudonym in Montgomery form.  early: NYM_BAD_PROOF when c >= r (an unreduced ProofC can never equal a value
+// reduced mod r: idemix/nymsignature.go:104 compares BIGs); dom: inside the pinned domain.
+FAB_HD void bn_nym_gates29(uint32_t& early, bool& dom, jacbn& N, const u256& nx, const u256& ny, const u256& c, const u256& s_sk,
+                           const u256& s_rnym) {
     const u256 P = FAB_BN_P, R = FAB_BN_R;
-    uint32_t early = NYM_VALID;
-    if (!bn_lt(c, R)) early = NYM_BAD_PROOF;
-    bool dom = bn_lt(nx, P) & bn_lt(ny, P) & bn_lt(s_sk, R) & bn_lt(s_rnym, R);
-
-    jacbn N;
+    early = bn_lt(c, R) ? (uint32_t)NYM_VALID : (uint32_t)NYM_BAD_PROOF;
+    dom = bn_lt(nx, P) & bn_lt(ny, P) & bn_lt(s_sk, R) & bn_lt(s_rnym, R);
     fe_to_mont(N.X, nx);
     fe_to_mont(N.Y, ny);
     fe_set_one(N.Z);
     dom = dom & bn_on_curve29(N.X, N.Y);
+}
+// Jacobian -> affine plain integers in [0, p): one inversion mod p (safegcd)
+FAB_HD void bn_affine29(u256& tx, u256& ty, const jacbn& W) {
+    u256 zp, zi;
+    fe_from_mont(zp, W.Z);
+    {
+        const modinv_info PI = MODINV_BNP_INFO;
+        modinv(zi, zp, PI);
+    }
+    fbn zm, zi2, zi3, ax, ay;
+    fe_to_mont(zm, zi);
+    fe_sqr(zi2, zm);               // [1x1]
+    fe_mul(zi3, zi2, zm);          // [1x1]
+    fe_mul(ax, W.X, zi2);          // [1x1]
+    fe_mul(ay, W.Y, zi3);          // [3x1]
+    fe_from_mont(tx, ax);
+    fe_from_mont(ty, ay);
+}
+
+// The commitment t of the verification equation, affine, as plain integers in [0, p) - one signature per lane.
+// Returns NYM_VALID when (tx, ty) is meaningful, NYM_BAD_PROOF when c >= r, NYM_NEEDS_SW outside the pinned domain.
+// KTab: comb tables of HSk and HRand; QTab: per-lane store(j, point) / load(j, point), j = 1..16.
+template <class KTab, class QTab>
+FAB_HD uint32_t bn_nym_commitment29(u256& tx, u256& ty, const u256& nx, const u256& ny, const u256& c, const u256& s_sk,
+                                    const u256& s_rnym, const KTab& hsk, const KTab& hrand, QTab& qtab) {
+    uint32_t early;
+    bool dom;
+    jacbn N;
+    bn_nym_gates29(early, dom, N, nx, ny, c, s_sk, s_rnym);
 
     jacbn seed, S1, S2, U, T, W;
     bool s1_inf, s2_inf, u_inf, t_inf, w_inf;
@@ -162,25 +186,68 @@ FAB_HD uint32_t bn_nym_commitment29(u256& tx, u256& ty, const u256& nx, const u2
     glv_mult29(T, t_inf, exc, m1, n1, m2, n2, N, BETA, qtab);
     bn_neg29(T);
     final_add29(W, w_inf, U, u_inf, T, t_inf);
-
-    // affine t: one inversion mod p
-    u256 zp, zi;
-    fe_from_mont(zp, W.Z);
-    {
-        const modinv_info PI = MODINV_BNP_INFO;
-        modinv(zi, zp, PI);
-    }
-    fbn zm, zi2, zi3, ax, ay;
-    fe_to_mont(zm, zi);
-    fe_sqr(zi2, zm);               // [1x1]
-    fe_mul(zi3, zi2, zm);          // [1x1]
-    fe_mul(ax, W.X, zi2);          // [1x1]
-    fe_mul(ay, W.Y, zi3);          // [3x1]
-    fe_from_mont(tx, ax);
-    fe_from_mont(ty, ay);
+    bn_affine29(tx, ty, W);
 
     if (early != NYM_VALID) return early;
     if (!dom || w_inf || exc) return NYM_NEEDS_SW;
+    return NYM_VALID;
+}
+
+// ---- two lanes per signature (batches that cannot fill the chip: the idemix creators of one block) ---------------------------
+// The verification equation splits into two halves with IDENTICAL instruction streams on different data:
+//     even lane:  HSk   * s_sk   -  k1 * Nym            odd lane:  HRand * s_rnym  -  k2 * phi(Nym)         (c = k1 + k2 lambda)
+// - one comb multiplication (32 mixed additions) and one 27-window single-scalar Booth multiplication (130 doublings, 27
+// additions) each, instead of two combs and an interleaved 54-addition loop on one lane: the length of a lane's stream,
+// which is what a small batch's latency is made of, drops by a third.  The single-scalar loop keeps the proof that no
+// addition meets P == +-Q (|k_i| < 2^129 < r), so there is no collision flag in this form.  The lanes then exchange their
+// partial sums (27 limbs by DPP) and both finish t = (even) + (odd), the inversion and the hashes; the even lane reports.
+//
+// Part 1 is what one lane computes on its own; the caller exchanges (DPP on the device, plain copies in the host tests) and
+// calls part 2.
+struct bn_nym_half {
+    jacbn P;          // this lane's partial sum
+    bool inf;
+    uint32_t early;   // gates (identical on both lanes)
+    bool dom;
+};
+template <class KTab, class QTab>
+FAB_HD void bn_nym_split_part1(bn_nym_half& out, bool odd, const u256& nx, const u256& ny, const u256& c, const u256& s_sk, const u256& s_rnym,
+                               const KTab& hsk, const KTab& hrand, QTab& qtab) {
+    jacbn N;
+    bn_nym_gates29(out.early, out.dom, N, nx, ny, c, s_sk, s_rnym);
+    // this lane's base table and scalar
+    KTab tab{odd ? hrand.w : hsk.w};
+    u256 sc;
+    sel256(sc, odd, s_rnym, s_sk);
+    jacbn seed, S, T;
+    bool s_inf, t_inf;
+    hsk.load(0, 1u, seed.X, seed.Y);
+    fe_set_one(seed.Z);
+    comb_mult29(S, s_inf, sc, tab, seed);
+    // this lane's half of c * Nym
+    u256 m1, m2, m;
+    bool n1, n2;
+    bn_glv_decompose(m1, n1, m2, n2, c);
+    sel256(m, odd, m2, m1);
+    bool neg = odd ? n2 : n1;
+    const fbn BETA = {BN29_BETA_MONT};
+    fbn bx;
+    fe_mul(bx, N.X, BETA);                       // [1x1]  phi(Nym) = (beta x, y)
+    fe_sel(N.X, odd, bx, N.X);
+    booth_mult29<GLV_WINDOWS>(T, t_inf, m, N, qtab);
+    // partial = S - (+-T): subtracting, so the Y of T flips unless the half-scalar was negative
+#pragma unroll
+    for (int l = 0; l < 9; l++) T.Y.v[l] = neg ? T.Y.v[l] : -T.Y.v[l];
+    final_add29(out.P, out.inf, S, s_inf, T, t_inf);
+}
+// mine / theirs: the two partial sums (addition is commutative: both lanes arrive at the same t)
+FAB_HD uint32_t bn_nym_split_part2(u256& tx, u256& ty, const bn_nym_half& mine, const jacbn& theirs, bool theirs_inf) {
+    jacbn W;
+    bool w_inf;
+    final_add29(W, w_inf, mine.P, mine.inf, theirs, theirs_inf);
+    bn_affine29(tx, ty, W);
+    if (mine.early != NYM_VALID) return mine.early;
+    if (!mine.dom || w_inf) return NYM_NEEDS_SW;
     return NYM_VALID;
 }
 

@@ -238,4 +238,23 @@ struct GlobalQTab29 {
     }
 };
 
+// 32 verdicts per wave sit on the even lanes: squeeze the even bits of the ballot into one u32 half-word
+__device__ __forceinline__ void pair_emit_verdict(uint32_t i, uint32_t n, bool active, bool odd, uint32_t st, uint32_t* __restrict__ verdict32,
+                                                  uint8_t* __restrict__ status) {
+    uint64_t x = __ballot(active && !odd && st == 0u) & 0x5555555555555555ull;   // 0 = valid (ST_VALID, NYM_VALID)
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    x = (x | (x >> 16)) & 0x00000000ffffffffull;
+    if ((threadIdx.x & 63) == 0 && active) {       // i is a multiple of 32 here
+        verdict32[i >> 5] = (uint32_t)x;
+        if (i + 32 >= n && ((i >> 5) & 1u) == 0) verdict32[(i >> 5) + 1] = 0;   // no wave owns the upper half of the last word
+    }
+    if (status != nullptr && active && !odd) status[i] = (uint8_t)st;
+}
+
+// partner lane of a two-lanes-per-signature kernel (quad_perm:[1,0,3,2])
+__device__ __forceinline__ int32_t lane_pair_swap(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }
+
 }  // namespace fab

@@ -184,10 +184,10 @@ FAB_HD void final_add29(jac_t<F>& Rr, bool& r_inf, const jac_t<F>& S, bool s_inf
     sel_jac29(Rr, use_S, S, Rr);
 }
 
-// T = k * Q for an arbitrary (on-curve, affine, Montgomery-form) point Q of prime order and k below that order:
+// T = k * Q for an arbitrary (on-curve, affine, Montgomery-form) point Q of prime order and k < 2^(5 WINDOWS - 1), below that order:
 // a per-lane table j*Q, j = 1..16 (8 doublings + 7 mixed additions; QTab provides store(j, point) / load(j, point)), then
-// 52 signed 5-bit (Booth) windows, digit_i = -16 k[5i+4] + 8 k[5i+3] + .. + k[5i] + k[5i-1] in [-16, 16]: 51 x 5 doublings
-// and at most 52 additions of +-|digit| Q.  (No addition can meet P == +-Q: DESIGN.md.)  t_inf: k == 0.
+// WINDOWS signed 5-bit (Booth) windows, digit_i = -16 k[5i+4] + 8 k[5i+3] + .. + k[5i] + k[5i-1] in [-16, 16]: (WINDOWS - 1) x 5
+// doublings and at most WINDOWS additions of +-|digit| Q.  (No addition can meet P == +-Q: DESIGN.md.)  t_inf: k == 0.
 template <class F, class QTab>
 FAB_HD void build_lane_table29(const jac_t<F>& Q, QTab& qtab) {
     qtab.store(1, Q);
@@ -219,8 +219,9 @@ FAB_HD int32_t booth5_digit(const uint32_t (&kw)[NW], int i) {
     }
     return (int32_t)((six >> 1) & 15u) + (int32_t)(six & 1u) - (int32_t)((six >> 5) << 4);
 }
-template <class F, class QTab>
-FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t<F>& Q, QTab& qtab) {
+template <int WINDOWS, class F, class QTab>
+FAB_HD void booth_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t<F>& Q, QTab& qtab) {
+    static_assert(WINDOWS >= 1 && WINDOWS <= Q5_WINDOWS, "5-bit windows over at most 260 bits");
     build_lane_table29(Q, qtab);
 
     uint32_t kw[9];
@@ -232,13 +233,13 @@ FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (int i = Q5_WINDOWS - 1; i >= 0; i--) {
+    for (int i = WINDOWS - 1; i >= 0; i--) {
         int32_t digit = booth5_digit(kw, i);
         bool neg = digit < 0;
         uint32_t mag = (uint32_t)(neg ? -digit : digit);
         jac_t<F> ent;
         qtab.load(mag ? mag : 1u, ent);                // issued ahead of the doublings: the gather latency hides behind them
-        if (i != Q5_WINDOWS - 1) {
+        if (i != WINDOWS - 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
@@ -259,6 +260,11 @@ FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t
         sel_jac29(T, take_ent, ent, T);
         t_inf = t_inf & (mag == 0);
     }
+}
+// the full-width form: k below the group order, 52 windows
+template <class F, class QTab>
+FAB_HD void var_base_mult29(jac_t<F>& T, bool& t_inf, const u256& k, const jac_t<F>& Q, QTab& qtab) {
+    booth_mult29<Q5_WINDOWS>(T, t_inf, k, Q, qtab);
 }
 
 // T = +-m1 * Q +- m2 * phi(Q) for an efficiently computable endomorphism phi(x, y) = (beta x, y) (GLV): both magnitudes below

@@ -383,11 +383,11 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
-    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, false), &wi);
+    int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
     if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
-                                              proof_s_sk, proof_s_r_nym, nonce, ctx->qws[wi].p, verdict_bits, status, st);
+                                              proof_s_sk, proof_s_r_nym, nonce, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, st);
     hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = true;

@@ -279,4 +279,23 @@ int hosttest_bn_glv_mult(const uint8_t* qx32, const uint8_t* qy32, const uint8_t
     to_be32(y32, y);
     return (inf ? 1 : 0) | (exc ? 2 : 0);
 }
+// the two-lanes-per-signature form of the commitment: both halves on the CPU, the exchange as plain copies
+int hosttest_bn_nym_commitment_split(void* p, const uint8_t* nx32, const uint8_t* ny32, const uint8_t* c32, const uint8_t* ssk32,
+                                     const uint8_t* srn32, uint8_t* tx32, uint8_t* ty32) {
+    BnIssuerTabs* t = (BnIssuerTabs*)p;
+    KeyTab8 hsk{t->hsk.data()}, hrand{t->hrand.data()};
+    u256 nx, ny, c, ssk, srn, txe, tye, txo, tyo;
+    from_be32(nx, nx32); from_be32(ny, ny32); from_be32(c, c32); from_be32(ssk, ssk32); from_be32(srn, srn32);
+    LocalQTab<fbn> qe, qo;
+    bn_nym_half he, ho;
+    bn_nym_split_part1(he, false, nx, ny, c, ssk, srn, hsk, hrand, qe);
+    bn_nym_split_part1(ho, true, nx, ny, c, ssk, srn, hsk, hrand, qo);
+    uint32_t se = bn_nym_split_part2(txe, tye, he, ho.P, ho.inf);
+    uint32_t so = bn_nym_split_part2(txo, tyo, ho, he.P, he.inf);
+    to_be32(tx32, txe);
+    to_be32(ty32, tye);
+    if (se != so) return -1;                                               // the two lanes must agree on the status ...
+    if (se == NYM_VALID && (!eq256(txe, txo) || !eq256(tye, tyo))) return -2;   // ... and, when it is meaningful, on t
+    return (int)se;
+}
 }

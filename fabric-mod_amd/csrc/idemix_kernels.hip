@@ -137,6 +137,58 @@ __global__ void __launch_bounds__(BLOCK, 2)
     }
 }
 
+// Two lanes per signature (bn_nym29.h "two lanes per signature"): 128 signatures per 256-thread workgroup, for batches that
+// cannot fill the chip with one signature per lane - the idemix creators of one block.  Lane 2k / 2k+1 of a wave own signature k;
+// each computes one half of the verification equation, the halves are exchanged by DPP, the even lane carries the verdict.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2)
+    idemix_nym_verify_split_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
+                                   const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
+                                   const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
+                                   const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
+                                   uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+    GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
+    constexpr uint32_t PER_WG = BLOCK / 2;
+    const uint32_t ntiles = (n + PER_WG - 1) / PER_WG;
+    const bool odd = (threadIdx.x & 1u) != 0;
+    uint32_t* verdict32 = reinterpret_cast<uint32_t*>(verdict_bits);
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * PER_WG + (threadIdx.x >> 1);
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        uint32_t iss = issuer_id != nullptr ? issuer_id[ic] : 0u;
+        bool iss_ok = iss < n_issuers;
+        const IssuerDev* id = issuers + (iss_ok ? iss : 0u);
+        KeyTab8 hsk{id->hsk}, hrand{id->hrand};
+        u256 nx, ny, c, ssk, srn, nn, tx, ty;
+        load_be_field(nx, nym_x, ic);
+        load_be_field(ny, nym_y, ic);
+        load_be_field(c, proof_c, ic);
+        load_be_field(ssk, s_sk, ic);
+        load_be_field(srn, s_rnym, ic);
+        load_be_field(nn, nonce, ic);
+        bn_nym_half mine;
+        bn_nym_split_part1(mine, odd, nx, ny, c, ssk, srn, hsk, hrand, qtab);
+        jacbn theirs;
+#pragma unroll
+        for (int l = 0; l < 9; l++) {
+            theirs.X.v[l] = lane_pair_swap(mine.P.X.v[l]);
+            theirs.Y.v[l] = lane_pair_swap(mine.P.Y.v[l]);
+            theirs.Z.v[l] = lane_pair_swap(mine.P.Z.v[l]);
+        }
+        bool theirs_inf = lane_pair_swap(mine.inf ? 1 : 0) != 0;
+        uint32_t st = bn_nym_split_part2(tx, ty, mine, theirs, theirs_inf);
+        uint32_t ih[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) ih[k] = id->hash[k];
+        uint32_t start = off[ic], len = off[ic + 1] - start;
+        bool match = nym_challenge_matches(arena32, arena_words, start, len, active, tx, ty, nx, ny, ih, nn, c);
+        if (st == NYM_VALID) st = match ? NYM_VALID : NYM_BAD_PROOF;
+        if (!iss_ok) st = NYM_NEEDS_SW;
+        pair_emit_verdict(i, n, active, odd, st, verdict32, status);
+    }
+}
+
 size_t idemix_issuer_dev_bytes() { return sizeof(IssuerDev); }
 void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hrand, const uint8_t hash32[32]) {
     IssuerDev* s = (IssuerDev*)host_slot;
@@ -146,12 +198,25 @@ void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hr
         s->hash[k] = ((uint32_t)hash32[4 * k] << 24) | ((uint32_t)hash32[4 * k + 1] << 16) | ((uint32_t)hash32[4 * k + 2] << 8) | hash32[4 * k + 3];
 }
 
+size_t idemix_workspace_bytes(uint32_t n, bool allow_split) {
+    VerifyGeom g = verify_geom(n, allow_split);
+    return (size_t)g.wgs * g.block * QWS_UINT4_PER_LANE * 16;
+}
+
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
-                                    const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, hipStream_t st) {
+                                    const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
+                                    hipStream_t st) {
     if (n == 0) return hipSuccess;
-    VerifyGeom g = verify_geom(n, false);
+    VerifyGeom g = verify_geom(n, allow_split);
     dim3 grid(g.wgs), block(g.block);
+    if (g.pair) {
+        hipLaunchKernelGGL(idemix_nym_verify_split_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                           (const uint32_t*)off, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
+                           (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
+                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(idemix_nym_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                        (const uint32_t*)off, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                        (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,

@@ -12,10 +12,12 @@ from idemix_common import be32, fixtures, make_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def env():
+@pytest.fixture(scope="module", params=["auto", "one-lane"])
+def env(request):
+    """auto: batches up to 32 768 run on the two-lanes-per-signature kernel, larger ones on the one-lane kernel;
+    one-lane = FABGPU_FLAG_ONE_LANE_ONLY, so that every case also goes through the one-lane kernel."""
     fx = fixtures()
-    ctx = fabgpu.Context()
+    ctx = fabgpu.Context(device=0, flags=fabgpu.FLAG_ONE_LANE_ONLY if request.param == "one-lane" else 0)
     issuers = []
     for name in ("MSP1OU1", "MSP2OU1"):
         ipk = fx[name]["ipk"]
@@ -83,19 +85,20 @@ def test_every_message_length_class(env):
 
 
 def test_block_sized_batch_by_replication(env):
+    """30 000 (a block), the two-lane limit 32 768 and its neighbours, and a batch of several rounds"""
     ctx, issuers = env
     base = make_batch(issuers, 300, 17)
     arena, off, iid, cols, expect = base.arrays()
-    n = 30000
-    rng = np.random.default_rng(5)
-    pick = rng.integers(0, 300, size=n)
-    lens = (off[1:] - off[:-1])[pick]
-    off2 = np.zeros(n + 1, dtype=np.uint32)
-    off2[1:] = np.cumsum(lens)
-    arena2 = np.concatenate([arena[off[i]:off[i + 1]] for i in pick]) if lens.sum() else arena
-    ok, st = ctx.idemix_nym_verify_batch(arena2, off2, *[c[pick] for c in cols], issuer_id=iid[pick])
-    assert np.array_equal(st, expect[pick])
-    assert np.array_equal(ok, expect[pick] == 0)
+    for n in (30000, 32767, 32768, 32769, 70000):
+        rng = np.random.default_rng(n)
+        pick = rng.integers(0, 300, size=n)
+        lens = (off[1:] - off[:-1])[pick]
+        off2 = np.zeros(n + 1, dtype=np.uint32)
+        off2[1:] = np.cumsum(lens)
+        arena2 = np.concatenate([arena[off[i]:off[i + 1]] for i in pick])
+        ok, st = ctx.idemix_nym_verify_batch(arena2, off2, *[c[pick] for c in cols], issuer_id=iid[pick])
+        assert np.array_equal(st, expect[pick]), n
+        assert np.array_equal(ok, expect[pick] == 0), n
     assert ctx.last_kernel_ms() > 0
 
 

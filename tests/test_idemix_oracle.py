@@ -29,6 +29,7 @@ def hosttest():
     L.hosttest_bn_issuer_free.argtypes = [ctypes.c_void_p]
     L.hosttest_bn_tab_entry.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
     L.hosttest_bn_nym_commitment.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 7
+    L.hosttest_bn_nym_commitment_split.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 7
     return L
 
 
@@ -125,8 +126,14 @@ def test_bn_comb_tables_and_commitment(hosttest, fx):
                 assert (int.from_bytes(ox.raw, "big"), int.from_bytes(oy.raw, "big")) == io.g1_mul(base, d << (8 * w)), (which, w, d)
 
         def commit(nym, c, s1, s2):
+            """one lane per signature and two lanes per signature must tell the same story"""
             st = hosttest.hosttest_bn_nym_commitment(h, be32(nym[0]), be32(nym[1]), be32(c), be32(s1), be32(s2), ox, oy)
-            return st, (int.from_bytes(ox.raw, "big"), int.from_bytes(oy.raw, "big"))
+            t = (int.from_bytes(ox.raw, "big"), int.from_bytes(oy.raw, "big"))
+            st2 = hosttest.hosttest_bn_nym_commitment_split(h, be32(nym[0]), be32(nym[1]), be32(c), be32(s1), be32(s2), ox, oy)
+            assert st2 == st, (st, st2)
+            if st == 0:
+                assert t == (int.from_bytes(ox.raw, "big"), int.from_bytes(oy.raw, "big"))
+            return st, t
 
         rng = random.Random(13)
         R = io.R
