@@ -165,6 +165,31 @@ int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t
     return CertDerToP256(cert, len, qx32, qy32) ? 0 : 1;
 }
 
+// pure host: the TxID / proposal-hash checks the pass derives from a marshalled block (for tests that recompute them with a CPU hash)
+int fabgpu_block_hash_checks(const uint8_t* block, size_t len, uint32_t cap, uint32_t* n_checks, uint32_t* tx, uint8_t* kind, uint32_t* spans6,
+                             uint32_t* expect2) {
+    if (!block || !n_checks) return FABGPU_EINVAL;
+    ParsedBlock pb;
+    if (!ParseBlock(block, len, pb)) return FABGPU_EINVAL;
+    *n_checks = (uint32_t)pb.hash_checks.size();
+    if (pb.hash_checks.size() > cap) return FABGPU_ETOOBIG;
+    for (size_t j = 0; j < pb.hash_checks.size(); j++) {
+        const BlockHashCheck& hc = pb.hash_checks[j];
+        if (tx) tx[j] = hc.tx;
+        if (kind) kind[j] = hc.kind;
+        if (spans6)
+            for (int p = 0; p < 3; p++) {
+                spans6[6 * j + 2 * p] = hc.piece[p].off;
+                spans6[6 * j + 2 * p + 1] = hc.piece[p].off + hc.piece[p].len;
+            }
+        if (expect2) {
+            expect2[2 * j] = hc.expect.off;
+            expect2[2 * j + 1] = hc.expect.off + hc.expect.len;
+        }
+    }
+    return FABGPU_OK;
+}
+
 // ---- idemix (idemix_host.h) ----
 int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id) {
     if (!csp || !mspid || !ipk_raw || !issuer_id) return FABGPU_EINVAL;

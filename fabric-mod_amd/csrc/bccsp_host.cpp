@@ -14,6 +14,7 @@
 #include "bccsp_host.h"
 #include "idemix_host.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -568,6 +569,8 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         if (g0.key_id < 0) all_keyed = false;
     }
     const size_t n = sub.size();
+    std::vector<uint8_t> hash_digests;
+    bool hashes_done = false;
     if (n) {
         std::vector<uint32_t> off(2 * n), pre_idx(n), pre_off(2 * pb.prefixes.size() + 2);
         for (size_t p = 0; p < pb.prefixes.size(); p++) {
@@ -601,6 +604,22 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         d.verdict_bits = bits.data();
         d.status = st.data();
         d.flags = FABGPU_IDB_SPANS;
+        // the TxID and proposal-hash digests of the endorser transactions ride along (one upload of the block, one submission)
+        const size_t nh = getenv("FABGPU_PASS_SKIP_HASH_CHECKS") ? 0 : pb.hash_checks.size();   // the switch exists for A/B timing only
+        std::vector<uint32_t> gsp(nh * 6);
+        hash_digests.assign(nh * 32, 0);
+        for (size_t j = 0; j < nh; j++)
+            for (int p = 0; p < 3; p++) {
+                const Span& sp = pb.hash_checks[j].piece[p];
+                gsp[6 * j + 2 * p] = sp.off;
+                gsp[6 * j + 2 * p + 1] = sp.off + sp.len;
+            }
+        if (nh) {
+            d.n_gather = (uint32_t)nh;
+            d.gather_spans = gsp.data();
+            d.gather_digests = hash_digests.data();
+            hashes_done = true;
+        }
         int rc = fabgpu_identity_verify_batch(ctx_, &d);
         if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
         for (size_t j = 0; j < n; j++) {
@@ -645,7 +664,18 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                 out.tuple_status[ns[j]] = st[j];
         }
     }
-    // per-transaction summary: not understood > bad creator signature > bad endorsement > "ask bccsp/sw" > all valid
+    // TxID / proposal hash: compare what the device computed with what the block claims.  (No ECDSA tuple went to the device -
+    // a block of idemix creators only, say - means no submission the hashes could ride on: those checks stay with the Go validators.)
+    std::vector<uint8_t> bad_txid(pb.n_tx, 0), bad_phash(pb.n_tx, 0);
+    if (hashes_done)
+        for (size_t j = 0; j < pb.hash_checks.size(); j++) {
+            const BlockHashCheck& hc = pb.hash_checks[j];
+            if (HashCheckMatches(block, hc, hash_digests.data() + 32 * j)) continue;
+            if (hc.kind == HASH_TXID) bad_txid[hc.tx] = 1;
+            else bad_phash[hc.tx] = 1;
+        }
+    // per-transaction summary, in the order ValidateTransaction and then VSCC would reject (core/common/validation/msgvalidation.go:
+    // 248-320): not understood > bad creator signature > bad TxID > bad proposal hash > bad endorsement > "ask bccsp/sw" > all valid
     std::vector<uint8_t> bad_creator(pb.n_tx, 0), bad_end(pb.n_tx, 0), sw(pb.n_tx, 0);
     for (size_t i = 0; i < nt; i++) {
         uint8_t stt = out.tuple_status[i];
@@ -657,7 +687,12 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     }
     for (uint32_t t = 0; t < pb.n_tx; t++) {
         if (out.tx_flags[t] == TX_NOT_UNDERSTOOD) continue;
-        out.tx_flags[t] = bad_creator[t] ? TX_BAD_CREATOR_SIGNATURE : bad_end[t] ? TX_BAD_ENDORSEMENT : sw[t] ? TX_NEEDS_SW : TX_ALL_SIGNATURES_VALID;
+        out.tx_flags[t] = bad_creator[t] ? TX_BAD_CREATOR_SIGNATURE
+                          : bad_txid[t]  ? TX_BAD_TXID
+                          : bad_phash[t] ? TX_BAD_PROPOSAL_HASH
+                          : bad_end[t]   ? TX_BAD_ENDORSEMENT
+                          : sw[t]        ? TX_NEEDS_SW
+                                         : TX_ALL_SIGNATURES_VALID;
     }
     return Error();
 }

@@ -183,6 +183,16 @@ bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy
     return CertDerToP256(der.data(), der.size(), qx, qy);
 }
 
+bool HashCheckMatches(const uint8_t* block, const BlockHashCheck& hc, const uint8_t digest[32]) {
+    const uint8_t* e = block + hc.expect.off;
+    if (hc.kind == HASH_PROPOSAL) return hc.expect.len == 32 && memcmp(e, digest, 32) == 0;
+    if (hc.expect.len != 64) return false;
+    static const char HEX[] = "0123456789abcdef";                 // hex.EncodeToString: lowercase
+    for (int i = 0; i < 32; i++)
+        if (e[2 * i] != (uint8_t)HEX[digest[i] >> 4] || e[2 * i + 1] != (uint8_t)HEX[digest[i] & 15]) return false;
+    return true;
+}
+
 bool IdentityToIdemixNym(const uint8_t* ident, size_t len, std::string& mspid, uint8_t nx[32], uint8_t ny[32]) {
     const uint8_t *idb, *ms;
     size_t idl, msl;
@@ -216,12 +226,14 @@ void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, ui
     if (!pb_bytes(hdr, hdr_l, 1, chdr, chdr_l) || !pb_bytes(hdr, hdr_l, 2, shdr, shdr_l)) return;
     // common.ChannelHeader{1 type (varint), ..., 4 channel_id}
     uint8_t type = 0;   // proto3 default: MESSAGE
+    Span txid_span;     // ChannelHeader.tx_id (field 5)
     {
         PbReader r(chdr, chdr_l);
         PbField g;
         while (r.next(g)) {
             if (g.num == 1 && g.wt == 0) type = (uint8_t)g.varint;
             if (g.num == 4 && g.wt == 2 && tx == 0) out.first_channel_id.assign((const char*)g.data, g.len);
+            if (g.num == 5 && g.wt == 2) txid_span = span_of(block, g.data, g.len);
         }
         if (!r.ok) return;
     }
@@ -234,13 +246,24 @@ void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, ui
     ct.identity = span_of(block, creator, creator_l);
     ct.suffix = span_of(block, payload, payload_l);
     ct.sig = span_of(block, sig, sig_l);
-    size_t first_tuple = out.tuples.size();
+    size_t first_tuple = out.tuples.size(), first_check = out.hash_checks.size();
     out.tuples.push_back(ct);
+    if (type == 3) {                                               // CheckTxID: endorser transactions only (msgvalidation.go:283-296)
+        const uint8_t* nonce;
+        size_t nonce_l;
+        BlockHashCheck hc;
+        hc.tx = tx;
+        hc.kind = HASH_TXID;
+        if (pb_bytes(shdr, shdr_l, 2, nonce, nonce_l)) hc.piece[0] = span_of(block, nonce, nonce_l);
+        hc.piece[1] = ct.identity;
+        hc.expect = txid_span;
+        out.hash_checks.push_back(hc);
+    }
     if (type != 3) {                                               // only ENDORSER_TRANSACTION carries endorsements
         understood = 1;
         return;
     }
-    if (!pb_bytes(payload, payload_l, 2, pdata, pdata_l)) { out.tuples.resize(first_tuple); return; }
+    if (!pb_bytes(payload, payload_l, 2, pdata, pdata_l)) { out.tuples.resize(first_tuple); out.hash_checks.resize(first_check); return; }
     // peer.Transaction{1 repeated actions}; TransactionAction{1 header, 2 payload}
     bool good = true;
     PbReader acts(pdata, pdata_l);
@@ -256,6 +279,18 @@ void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, ui
         }
         int32_t pidx = (int32_t)out.prefixes.size();
         out.prefixes.push_back(span_of(block, prp, prp_l));
+        {   // GetProposalHash2 of this action
+            const uint8_t *ahdr, *ccpp, *ph;
+            size_t ahdr_l, ccpp_l, ph_l;
+            BlockHashCheck hc;
+            hc.tx = tx;
+            hc.kind = HASH_PROPOSAL;
+            hc.piece[0] = span_of(block, chdr, chdr_l);
+            if (pb_bytes(a.data, a.len, 1, ahdr, ahdr_l)) hc.piece[1] = span_of(block, ahdr, ahdr_l);
+            if (pb_bytes(ap, ap_l, 1, ccpp, ccpp_l)) hc.piece[2] = span_of(block, ccpp, ccpp_l);
+            if (pb_bytes(prp, prp_l, 1, ph, ph_l)) hc.expect = span_of(block, ph, ph_l);   // ProposalResponsePayload{1 proposal_hash, 2 extension}
+            out.hash_checks.push_back(hc);
+        }
         PbReader ends(cea, cea_l);
         PbField e;
         while (ends.next(e)) {
@@ -281,6 +316,7 @@ void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, ui
     if (!acts.ok) good = false;
     if (!good) {
         out.tuples.resize(first_tuple);                            // leave the whole transaction to the Go validators
+        out.hash_checks.resize(first_check);
         return;
     }
     understood = 1;
@@ -331,6 +367,7 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
             if (tp.prefix_index >= 0) tp.prefix_index += base;
             out.tuples.push_back(tp);
         }
+        out.hash_checks.insert(out.hash_checks.end(), p.hash_checks.begin(), p.hash_checks.end());
     }
     return true;
 }

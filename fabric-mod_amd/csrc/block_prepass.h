@@ -43,6 +43,21 @@ enum : uint8_t {
     TX_BAD_ENDORSEMENT = 2,         // at least one endorsement signature does not verify
     TX_NOT_UNDERSTOOD = 3,          // envelope / payload / transaction did not parse as expected: left to the Go validators
     TX_NEEDS_SW = 4,                // some identity must be verified by bccsp/sw
+    TX_BAD_TXID = 5,                // ChannelHeader.tx_id != hex(SHA-256(nonce || creator)): TxValidationCode_BAD_PROPOSAL_TXID
+    TX_BAD_PROPOSAL_HASH = 6,       // an action's SHA-256(channel header || action header || proposal payload) != prp.proposal_hash
+};
+// The two other SHA-256 computations ValidateTransaction makes per endorser transaction:
+//   HASH_TXID           protoutil.CheckTxID (protoutil/proputils.go:357-375, called at core/common/validation/msgvalidation.go:288):
+//                       SHA-256(SignatureHeader.nonce || SignatureHeader.creator), compared with ChannelHeader.tx_id as lowercase hex
+//   HASH_PROPOSAL       protoutil.GetProposalHash2 (protoutil/txutils.go:431-447, called at msgvalidation.go:233-241), per action:
+//                       SHA-256(Header.channel_header || TransactionAction.header || ChaincodeActionPayload.chaincode_proposal_payload),
+//                       compared with ProposalResponsePayload.proposal_hash
+enum : uint8_t { HASH_TXID = 0, HASH_PROPOSAL = 1 };
+struct BlockHashCheck {
+    uint32_t tx = 0;
+    uint8_t kind = HASH_TXID;
+    Span piece[3];                  // the message is their concatenation (unused pieces have len 0)
+    Span expect;                    // HASH_TXID: 64 hex characters; HASH_PROPOSAL: 32 raw bytes; anything else cannot match
 };
 
 struct BlockTuple {
@@ -57,6 +72,7 @@ struct ParsedBlock {
     std::vector<uint8_t> tx_understood;
     std::vector<Span> prefixes;
     std::vector<BlockTuple> tuples;
+    std::vector<BlockHashCheck> hash_checks;   // endorser transactions only
     std::string first_channel_id;         // of envelope 0 (fixture pin)
 };
 
@@ -68,6 +84,8 @@ bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy
 // DER x509 certificate -> P-256 SubjectPublicKeyInfo point (exposed for tests against the reference's certificate fixtures)
 bool CertDerToP256(const uint8_t* der, size_t len, uint8_t qx[32], uint8_t qy[32]);
 bool PemToDer(const uint8_t* pem, size_t len, std::vector<uint8_t>& der);
+// does the 32-byte digest equal what the block says (hex string for HASH_TXID, raw bytes for HASH_PROPOSAL)?
+bool HashCheckMatches(const uint8_t* block, const BlockHashCheck& hc, const uint8_t digest[32]);
 // SerializedIdentity{mspid, id_bytes = msp.SerializedIdemixIdentity{1 nym_x, 2 nym_y, 3 ou, 4 role, 5 proof}} (what
 // idemixidentity.Serialize writes, msp/idemixmsp.go:605-640) -> MSP id and the 32-byte pseudonym coordinates.
 // false: not such an identity (or coordinates of another size: those stay with bccsp/idemix).

@@ -78,6 +78,9 @@ struct fabgpu_ctx {
     std::vector<int32_t*> itabs;                  // two comb tables per issuer
     std::map<std::string, uint32_t> issuer_ids;   // hsk || hrand || hash -> id
     Buf nym;          // staging of the nym host-pointer entry point: issuer_id | six fields
+    Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
+    void* d_gscr = nullptr;   // device scratch the gather kernel stitches the messages into
+    size_t gscr_cap = 0;
     Buf keyed;        // staging of the keyed host-pointer entry point: key_id | e | r | s
     Buf pre;          // staging of prefixed batches: pre_off | pre_idx | mid-states
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
@@ -218,6 +221,8 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         for (auto* t : ctx->itabs) hipFree(t);
         if (ctx->d_issuers) hipFree(ctx->d_issuers);
         ctx->nym.release();
+        ctx->gath.release();
+        if (ctx->d_gscr) hipFree(ctx->d_gscr);
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
@@ -709,6 +714,8 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
     if (prefixed && (!b->pre_off || !mid_scratch)) return FABGPU_EINVAL;
     if (b->flags & ~(uint32_t)FABGPU_IDB_SPANS) return FABGPU_EINVAL;
     if (n > 0xFFFFFFF0ull || b->arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
+    if (b->n_gather && (!b->gather_spans || !b->gather_digests || !b->gather_off || !b->gather_scratch || b->gather_scratch_bytes > 0xFFFFFFFFull))
+        return FABGPU_EINVAL;
     ShaPrefixArgs pa;
     pa.spans = (b->flags & FABGPU_IDB_SPANS) != 0;
     if (prefixed) {
@@ -744,6 +751,9 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
         ctx->release_qws(wi, st);
     }
     ctx->timed = true;
+    if (err == hipSuccess && b->n_gather)   // behind the verification on the same stream; not part of fabgpu_last_kernel_ms
+        err = launch_gather_sha256(b->n_gather, b->arena, b->arena_bytes, b->gather_spans, b->gather_off, b->gather_scratch, b->gather_scratch_bytes,
+                                   b->gather_digests, st);
     return hip_to_rc(err);
 }
 
@@ -775,6 +785,18 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
         if (s0 < lo) lo = s0;
         if (s1 > hi) hi = s1;
     }
+    const uint32_t ng = b->n_gather;
+    if (ng && (!b->gather_spans || !b->gather_digests)) return FABGPU_EINVAL;
+    uint64_t gtotal = 0;
+    for (size_t j = 0; j < (size_t)ng * 3; j++) {
+        uint32_t s0 = b->gather_spans[2 * j], s1 = b->gather_spans[2 * j + 1];
+        if (s1 < s0) return FABGPU_EINVAL;
+        if (s1 == s0) continue;
+        if (s0 < lo) lo = s0;
+        if (s1 > hi) hi = s1;
+        gtotal += s1 - s0;
+    }
+    if (gtotal > 0x7FFFFFF0ull) return FABGPU_ETOOBIG;
     size_t span = hi >= lo ? (size_t)hi - lo : 0;
     if (span && !arena) return FABGPU_EINVAL;
     const size_t fb = n * 32, ib = round_up(n * 4, 64), pob = round_up((npre + 1) * 4, 64), words = (n + 63) / 64;
@@ -836,13 +858,47 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     }
     d.verdict_bits = dout;
     d.status = b->status ? dout + st_off : nullptr;
+    const size_t gsb = round_up((size_t)ng * 24, 64), gob = round_up(((size_t)ng + 1) * 4, 64), gscr = round_up((size_t)gtotal, 4) + 64;
+    if (ng) {
+        if ((rc = ctx->gath.ensure(gsb + gob + (size_t)ng * 32))) return rc;
+        if (ctx->gscr_cap < gscr) {
+            if (ctx->d_gscr) hipFree(ctx->d_gscr);
+            ctx->d_gscr = nullptr;
+            ctx->gscr_cap = 0;
+            if (hipMalloc(&ctx->d_gscr, gscr + gscr / 4) != hipSuccess) return FABGPU_ENOMEM;
+            ctx->gscr_cap = gscr + gscr / 4;
+        }
+        uint32_t* gs = (uint32_t*)ctx->gath.h;
+        uint32_t* go = (uint32_t*)((uint8_t*)ctx->gath.h + gsb);
+        uint32_t run = 0;
+        for (uint32_t j = 0; j < ng; j++) {
+            go[j] = run;
+            for (int p = 0; p < 3; p++) {
+                uint32_t s0 = b->gather_spans[6 * (size_t)j + 2 * p], s1 = b->gather_spans[6 * (size_t)j + 2 * p + 1];
+                gs[6 * (size_t)j + 2 * p] = s1 > s0 ? s0 - lo : 0;
+                gs[6 * (size_t)j + 2 * p + 1] = s1 > s0 ? s1 - lo : 0;
+                run += s1 - s0;
+            }
+        }
+        go[ng] = run;
+        err = hipMemcpyAsync(ctx->gath.d, ctx->gath.h, gsb + gob, hipMemcpyHostToDevice, ctx->stream);
+        if (err != hipSuccess) return hip_to_rc(err);
+        d.gather_spans = (const uint32_t*)ctx->gath.d;
+        d.gather_off = (const uint32_t*)((uint8_t*)ctx->gath.d + gsb);
+        d.gather_digests = (uint8_t*)ctx->gath.d + gsb + gob;
+        d.gather_scratch = ctx->d_gscr;
+        d.gather_scratch_bytes = gscr;
+    }
     rc = fabgpu_identity_verify_batch_dev(ctx, &d, m ? pd + pob + ib : nullptr, ctx->stream);
     if (rc) return rc;
     err = hipMemcpyAsync(ctx->out.h, dout, b->status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess && ng)
+        err = hipMemcpyAsync((uint8_t*)ctx->gath.h + gsb + gob, (uint8_t*)ctx->gath.d + gsb + gob, (size_t)ng * 32, hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
     if (err != hipSuccess) return hip_to_rc(err);
     memcpy(b->verdict_bits, ctx->out.h, words * 8);
     if (b->status) memcpy(b->status, (uint8_t*)ctx->out.h + st_off, n);
+    if (ng) memcpy(b->gather_digests, (uint8_t*)ctx->gath.h + gsb + gob, (size_t)ng * 32);
     return FABGPU_OK;
 }
 

@@ -307,6 +307,28 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n
     }
 }
 
+// Stitches the pieces of gathered messages (fabgpu_identity_batch.gather_spans) into consecutive bytes: one WAVEFRONT per message,
+// lane l moving bytes l, l + 64, ... of each piece (byte granularity because the pieces sit at arbitrary offsets of the block
+// buffer; coalesced 64-byte rows).  A lane-per-message byte loop was measured first: its ~1500 dependent load/store round
+// trips per lane cost 2 ms per 10 000-transaction block.
+__global__ void __launch_bounds__(256) gather_spans_kernel(uint32_t n, const uint8_t* __restrict__ arena, uint32_t arena_bytes,
+                                                            const uint32_t* __restrict__ spans, const uint32_t* __restrict__ out_off,
+                                                            uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= n) return;
+    uint32_t o = out_off[i];
+    const uint32_t oe = out_off[i + 1];
+    for (int p = 0; p < 3; p++) {
+        uint32_t s = spans[6 * (size_t)i + 2 * p], e = spans[6 * (size_t)i + 2 * p + 1];
+        e = e < arena_bytes ? e : arena_bytes;
+        if (e <= s) continue;
+        uint32_t len = e - s;
+        len = len < oe - o ? len : oe - o;
+        for (uint32_t b = lane; b < len; b += 64) out[o + b] = arena[s + b];
+        o += len;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------------------
@@ -330,6 +352,17 @@ hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes
                        (const uint32_t*)off, (uint32_t*)digests);
     return hipGetLastError();
 }
+hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,
+                                size_t scratch_bytes, void* digests, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((n + 3) / 4), block(256);   // four wavefronts = four messages per workgroup
+    hipLaunchKernelGGL(gather_spans_kernel, grid, block, 0, st, n, (const uint8_t*)arena, (uint32_t)arena_bytes, (const uint32_t*)spans,
+                       (const uint32_t*)out_off, (uint8_t*)scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_sha256_batch(n, scratch, scratch_bytes, out_off, digests, st);
+}
+
 VerifyGeom verify_geom(uint32_t n, bool allow_pair) {
     VerifyGeom g;
     g.block = VERIFY_BLOCK;

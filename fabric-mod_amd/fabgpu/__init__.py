@@ -47,7 +47,9 @@ class _IdBatch(ctypes.Structure):
     _fields_ = [("n", ctypes.c_size_t), ("arena", ctypes.c_void_p), ("arena_bytes", ctypes.c_size_t), ("off", ctypes.c_void_p),
                 ("n_prefixes", ctypes.c_uint32), ("pre_off", ctypes.c_void_p), ("pre_idx", ctypes.c_void_p), ("qx", ctypes.c_void_p),
                 ("qy", ctypes.c_void_p), ("key_id", ctypes.c_void_p), ("r", ctypes.c_void_p), ("s", ctypes.c_void_p),
-                ("verdict_bits", ctypes.c_void_p), ("status", ctypes.c_void_p), ("flags", ctypes.c_uint32)]
+                ("verdict_bits", ctypes.c_void_p), ("status", ctypes.c_void_p), ("flags", ctypes.c_uint32),
+                ("n_gather", ctypes.c_uint32), ("gather_spans", ctypes.c_void_p), ("gather_digests", ctypes.c_void_p),
+                ("gather_off", ctypes.c_void_p), ("gather_scratch", ctypes.c_void_p), ("gather_scratch_bytes", ctypes.c_size_t)]
 
 
 class _Cfg(ctypes.Structure):
@@ -69,7 +71,7 @@ ABI_SYMBOLS = [
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
-    "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register",
+    "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_block_hash_checks",
     "fabgpu_synth_batch",
 ]
 
@@ -137,6 +139,7 @@ def load():
     L.fabgpu_csp_idemix_msp_register.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64)]
     L.fabgpu_csp_idemix_issuer_import.argtypes = [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, _sz]
     L.fabgpu_csp_idemix_nym_verify_batch.argtypes = [_vp, ctypes.c_int64, _sz, _u8p, _u32p, _u8p, _u32p, _u8p, _u32p, _u8p, _u8p, ctypes.c_char_p, _sz]
+    L.fabgpu_block_hash_checks.argtypes = [_u8p, _sz, ctypes.c_uint32, _u32p, _u32p, _u8p, _u32p, _u32p]
     L.fabgpu_x509_p256_pubkey.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
     _lib = L
@@ -340,8 +343,10 @@ class Context:
                                                            proof_s_sk, proof_s_r_nym, nonce, verdict_bits, status or None, stream or None),
                "fabgpu_idemix_nym_verify_batch_dev")
 
-    def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True, spans=False):
-        """fabgpu_identity_verify_batch: message i = [prefix pre_idx[i]] || arena[off[i], off[i+1]); keys by value or by id."""
+    def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True, spans=False,
+                              gather_spans=None):
+        """fabgpu_identity_verify_batch: message i = [prefix pre_idx[i]] || arena[off[i], off[i+1]); keys by value or by id.
+        gather_spans (m x 6 u32: three (start, end) pieces per gathered message): also returns their m x 32 digest bytes."""
         arena, r, s = map(_a8, (arena, r, s))
         off = np.ascontiguousarray(off, dtype=np.uint32)
         n = off.size // 2 if spans else off.size - 1
@@ -364,7 +369,15 @@ class Context:
         st = np.zeros(n, dtype=np.uint8) if want_status else None
         b.verdict_bits = bits.ctypes.data
         b.status = st.ctypes.data if want_status else None
+        dig = None
+        if gather_spans is not None:
+            gather_spans = np.ascontiguousarray(gather_spans, dtype=np.uint32).reshape(-1, 6)
+            dig = np.zeros((gather_spans.shape[0], 32), dtype=np.uint8)
+            keep += [gather_spans, dig]
+            b.n_gather, b.gather_spans, b.gather_digests = gather_spans.shape[0], gather_spans.ctypes.data, dig.ctypes.data
         _check(self._L.fabgpu_identity_verify_batch(self._h, ctypes.byref(b)), "fabgpu_identity_verify_batch")
+        if dig is not None:
+            return unpack_bits(bits, n), st, dig
         return unpack_bits(bits, n), st
 
     def identity_verify_batch_dev(self, desc: "_IdBatch", mid_scratch, stream=0):
@@ -552,6 +565,7 @@ class Identity:
 
 
 TX_ALL_SIGNATURES_VALID, TX_BAD_CREATOR_SIGNATURE, TX_BAD_ENDORSEMENT, TX_NOT_UNDERSTOOD, TX_NEEDS_SW = 0, 1, 2, 3, 4
+TX_BAD_TXID, TX_BAD_PROPOSAL_HASH = 5, 6
 TUPLE_ST_BAD_DER, TUPLE_ST_NEEDS_SW, TUPLE_ST_EMPTY_SIG = 5, 6, 7
 
 
@@ -568,6 +582,25 @@ def block_parse(block: bytes):
     if rc != FABGPU_OK:
         raise FabgpuError("fabgpu_block_parse failed: %s (%d)" % (strerror(rc), rc))
     return dict(n_tx=n_tx.value, n_tuples=n_tup.value, n_prefixes=n_pre.value, tx_type=tx_type[:n_tx.value].copy(), channel_id=ch.value.decode(errors="replace"))
+
+
+def block_hash_checks(block: bytes):
+    """The TxID / proposal-hash checks the pre-verify pass derives from a block: list of (tx, kind, [(start, end)] * 3, (start, end))."""
+    buf = np.frombuffer(block, dtype=np.uint8)
+    cap = 4096
+    while True:
+        n = ctypes.c_uint32(0)
+        tx, kind = np.zeros(cap, np.uint32), np.zeros(cap, np.uint8)
+        sp, ex = np.zeros(cap * 6, np.uint32), np.zeros(cap * 2, np.uint32)
+        rc = load().fabgpu_block_hash_checks(_p8(buf), buf.size, cap, ctypes.byref(n), tx.ctypes.data_as(_u32p), _p8(kind), sp.ctypes.data_as(_u32p),
+                                             ex.ctypes.data_as(_u32p))
+        if rc == -5:
+            cap = n.value
+            continue
+        _check(rc, "fabgpu_block_hash_checks")
+        m = n.value
+        return [(int(tx[j]), int(kind[j]), [(int(sp[6 * j + 2 * p]), int(sp[6 * j + 2 * p + 1])) for p in range(3)], (int(ex[2 * j]), int(ex[2 * j + 1])))
+                for j in range(m)]
 
 
 def x509_p256_pubkey(cert: bytes, pem: bool = True) -> Optional[Tuple[bytes, bytes]]:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FABGPU_ABI_VERSION 1
+#define FABGPU_ABI_VERSION 2
 
 /* ---- return codes (infrastructure only) ---- */
 #define FABGPU_OK 0
@@ -153,6 +153,18 @@ typedef struct fabgpu_identity_batch {
     void* verdict_bits;          /* ceil(n/64) x u64 */
     void* status;                /* n bytes or NULL */
     uint32_t flags;              /* FABGPU_IDB_* */
+    /* Optional: more SHA-256 digests over the SAME arena in the same submission - the TxID and proposal-hash checks of
+     * ValidateTransaction (protoutil/proputils.go:357-375, protoutil/txutils.go:431-447).  Message j is the
+     * concatenation of up to three arena spans gather_spans[6j .. 6j+5] = (start, end) x 3 (an unused piece has start == end);
+     * a gather kernel stitches them on the device, the batched SHA-256 kernel hashes them.  n_gather = 0: none.
+     * _dev additionally needs gather_off (n_gather + 1 running offsets of the stitched messages) and gather_scratch
+     * (gather_off[n_gather] + 64 bytes of device scratch); the host variant computes and owns both. */
+    uint32_t n_gather;
+    const uint32_t* gather_spans;    /* n_gather x 6 */
+    void* gather_digests;            /* n_gather x 32 bytes, out */
+    const uint32_t* gather_off;      /* _dev only */
+    void* gather_scratch;            /* _dev only */
+    size_t gather_scratch_bytes;     /* _dev only: size of the gather_scratch allocation */
 } fabgpu_identity_batch;
 #define FABGPU_IDB_SPANS 1u /* off holds n (start, end) pairs and pre_off n_prefixes pairs: messages are arbitrary sub-slices of the arena
                              (a marshalled block), not consecutive */

@@ -57,8 +57,11 @@ int fabgpu_synth_batch(size_t n, uint64_t seed, uint32_t invalid_permille, const
  *   creator:      SignatureHeader.creator over Envelope.payload            (core/common/validation/msgvalidation.go:258-298)
  *   endorsements: Endorsement.endorser over prp || Endorsement.endorser    (.../statebased/validator_keylevel.go:246-258)
  * Identities (PEM x509, P-256) are imported once and cached (device comb tables), the block buffer is the message arena,
- * each proposal_response_payload is hashed once.  tx_flags[t]: 0 every signature verifies, 1 creator signature bad,
- * 2 an endorsement signature bad, 3 not understood (left to the Go validators), 4 an identity needs bccsp/sw.
+ * each proposal_response_payload is hashed once.  The two other SHA-256 checks of ValidateTransaction ride along in the same
+ * submission: CheckTxID (protoutil/proputils.go:366-375) and the proposal hash of every action (protoutil/txutils.go:431-447,
+ * core/common/validation/msgvalidation.go:233-241).  tx_flags[t], in the order the reference would reject: 3 not understood
+ * (left to the Go validators), 1 creator signature bad, 5 TxID does not match, 6 a proposal hash does not match, 2 an
+ * endorsement signature bad, 4 an identity needs bccsp/sw, 0 everything checks.
  * tuple_status[i]: 0..4 as in fabgpu.h, 5 signature does not unmarshal, 6 identity needs bccsp/sw, 7 empty signature.
  * Returns FABGPU_ETOOBIG with *n_tx / *n_tuples set when the caller's arrays are too small. */
 int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len, uint32_t* n_tx, uint8_t* tx_flags, uint8_t* tx_type,
@@ -68,6 +71,10 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
 int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
                        char* channel_id, size_t channel_cap);
 int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t* qx32, uint8_t* qy32);
+/* the hash checks of a block: kind 0 = TxID (expect = 64 hex characters), 1 = proposal hash (expect = 32 bytes); message = the
+ * concatenation of the three (start, end) spans; all offsets into the block buffer.  FABGPU_ETOOBIG with *n_checks set if cap is small. */
+int fabgpu_block_hash_checks(const uint8_t* block, size_t len, uint32_t cap, uint32_t* n_checks, uint32_t* tx, uint8_t* kind, uint32_t* spans6,
+                             uint32_t* expect2);
 
 /* ---- idemix pseudonym signatures (creator signatures of idemix MSPs): host mirror of bccsp/idemix/handlers ----
  * fabgpu_csp_idemix_issuer_import: IssuerPublicKeyImporter.KeyImport (bccsp/idemix/handlers/issuer.go:115-136) for the

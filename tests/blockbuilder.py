@@ -52,6 +52,36 @@ def endorser_tx_payload(typ, channel, txid, creator, nonce, actions) -> bytes:
     return fbytes(1, hdr) + fbytes(2, tx)
 
 
+def compute_txid(nonce: bytes, creator: bytes) -> str:
+    """protoutil.ComputeTxID (protoutil/proputils.go:357-364)"""
+    import hashlib
+    return hashlib.sha256(nonce + creator).hexdigest()
+
+
+def proposal_hash(typ, channel, txid, creator, nonce, ccpp: bytes) -> bytes:
+    """protoutil.GetProposalHash2 (protoutil/txutils.go:431-447): channel header || the action's signature header || proposal payload"""
+    import hashlib
+    return hashlib.sha256(channel_header(typ, channel, txid) + signature_header(creator, nonce) + ccpp).digest()
+
+
+def proposal_response_payload(phash: bytes, extension: bytes) -> bytes:
+    """peer.ProposalResponsePayload{1 proposal_hash, 2 extension}"""
+    return fbytes(1, phash) + fbytes(2, extension)
+
+
+def consistent_endorser_tx(channel, creator, nonce, ccpp, extension, sign_endorsements, bad_txid=False, bad_phash=False):
+    """An ENDORSER_TRANSACTION payload whose TxID and proposal hash are what the reference's validators recompute.
+    sign_endorsements(prp) -> [(endorser identity bytes, signature bytes), ...].  Returns (payload bytes, prp bytes)."""
+    txid = compute_txid(nonce, creator)
+    if bad_txid:
+        txid = txid[:-1] + ("0" if txid[-1] != "0" else "1")
+    ph = proposal_hash(3, channel, txid, creator, nonce, ccpp)
+    if bad_phash:
+        ph = bytes([ph[0] ^ 1]) + ph[1:]
+    prp = proposal_response_payload(ph, extension)
+    return endorser_tx_payload(3, channel, txid, creator, nonce, [(ccpp, prp, sign_endorsements(prp))]), prp
+
+
 def envelope(payload: bytes, signature: bytes) -> bytes:
     return fbytes(1, payload) + fbytes(2, signature)
 

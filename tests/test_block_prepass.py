@@ -76,7 +76,8 @@ def _sign(ident, msg, k):
 
 
 def build_block(n_tx, rng, corrupt=True):
-    """n_tx endorser transactions x 3 endorsements by 4 endorsers, 2 creators; returns (block bytes, expected tx flags)."""
+    """n_tx endorser transactions x 3 endorsements by 4 endorsers, 2 creators, TxIDs and proposal hashes as the reference's
+    validators recompute them; returns (block bytes, expected tx flags)."""
     p256 = [i for i in IDS if i["curve"] == "prime256v1"]
     p384 = [i for i in IDS if i["curve"] != "prime256v1"][0]
     sid = {i["cn"]: bb.serialized_identity("Org1MSP", i["pem"]) for i in IDS}
@@ -85,55 +86,69 @@ def build_block(n_tx, rng, corrupt=True):
     for t in range(n_tx):
         creator = creators[t % 2]
         cbytes = sid[creator["cn"]]
-        prp = bytes(rng.integers(0, 256, size=int(rng.integers(100, 1200)), dtype=np.uint8))
+        ext = bytes(rng.integers(0, 256, size=int(rng.integers(100, 1200)), dtype=np.uint8))
         ccpp = bytes(rng.integers(0, 256, size=200, dtype=np.uint8))
-        mode = (t % 11) if corrupt else 0
-        ends = []
-        for j in rng.choice(4, size=3, replace=False):
-            e = endorsers[j]
-            ebytes = sid[e["cn"]]
-            r, s = _sign(e, prp + ebytes, int(rng.integers(1, 1 << 62)))
-            sig = po.marshal_ecdsa_signature(r, s)
-            ends.append([ebytes, sig, r, s])
-        flag = fabgpu.TX_ALL_SIGNATURES_VALID
-        if mode == 3:                                   # a tampered endorsement (r + 1)
-            ends[1][1] = po.marshal_ecdsa_signature(ends[1][2] + 1, ends[1][3]); flag = fabgpu.TX_BAD_ENDORSEMENT
-        if mode == 4:                                   # a high-S endorsement: bccsp/sw rejects it with an error
-            ends[0][1] = po.marshal_ecdsa_signature(ends[0][2], po.N - ends[0][3]); flag = fabgpu.TX_BAD_ENDORSEMENT
-        if mode == 5:                                   # garbage DER
-            ends[2][1] = b"\x30\x03\x02\x01"; flag = fabgpu.TX_BAD_ENDORSEMENT
-        if mode == 6:                                   # an endorser with a P-384 identity: bccsp/sw must decide
-            ends[2][0] = sid[p384["cn"]]; flag = fabgpu.TX_NEEDS_SW
-        typ = 3
-        if mode == 7:
-            typ = 1                                     # a CONFIG envelope: only the creator signature is checked
-        payload = bb.endorser_tx_payload(typ, "mychannel", "tx%d" % t, cbytes, bytes(rng.integers(0, 256, size=24, dtype=np.uint8)),
-                                         [(ccpp, prp, [(e[0], e[1]) for e in ends])])
+        nonce = bytes(rng.integers(0, 256, size=24, dtype=np.uint8))
+        mode = (t % 13) if corrupt else 0
+        picks = list(rng.choice(4, size=3, replace=False))
+        flag = [fabgpu.TX_ALL_SIGNATURES_VALID]
+
+        def sign_ends(prp, t=t, mode=mode, picks=picks, flag=flag):
+            ends = []
+            for j in picks:
+                e = endorsers[j]
+                ebytes = sid[e["cn"]]
+                r, s = _sign(e, prp + ebytes, int(rng.integers(1, 1 << 62)))
+                ends.append([ebytes, po.marshal_ecdsa_signature(r, s), r, s])
+            if mode == 3:                               # a tampered endorsement (r + 1)
+                ends[1][1] = po.marshal_ecdsa_signature(ends[1][2] + 1, ends[1][3]); flag[0] = fabgpu.TX_BAD_ENDORSEMENT
+            if mode == 4:                               # a high-S endorsement: bccsp/sw rejects it with an error
+                ends[0][1] = po.marshal_ecdsa_signature(ends[0][2], po.N - ends[0][3]); flag[0] = fabgpu.TX_BAD_ENDORSEMENT
+            if mode == 5:                               # garbage DER
+                ends[2][1] = b"\x30\x03\x02\x01"; flag[0] = fabgpu.TX_BAD_ENDORSEMENT
+            if mode == 6:                               # an endorser with a P-384 identity: bccsp/sw must decide
+                ends[2][0] = sid[p384["cn"]]; flag[0] = fabgpu.TX_NEEDS_SW
+            if mode == 10:                              # bad creator AND bad endorsement: the creator outranks
+                ends[0][1] = po.marshal_ecdsa_signature(ends[0][2] + 1, ends[0][3])
+            return [(e[0], e[1]) for e in ends]
+        payload, prp = bb.consistent_endorser_tx("mychannel", cbytes, nonce, ccpp, ext, sign_ends, bad_txid=(mode == 11), bad_phash=(mode == 12))
+        if mode == 11:
+            flag[0] = fabgpu.TX_BAD_TXID
+        if mode == 12:
+            flag[0] = fabgpu.TX_BAD_PROPOSAL_HASH
+        if mode == 7:                                   # a CONFIG envelope: only the creator signature is checked (no TxID check either)
+            payload = bb.endorser_tx_payload(1, "mychannel", "not-a-hash", cbytes, nonce, [(ccpp, prp, [])])
         if mode == 8:                                   # transaction bytes that are not a peer.Transaction
-            hdr = bb.fbytes(1, bb.channel_header(3, "mychannel", "tx%d" % t)) + bb.fbytes(2, bb.signature_header(cbytes, b"n"))
+            hdr = bb.fbytes(1, bb.channel_header(3, "mychannel", bb.compute_txid(b"n", cbytes))) + bb.fbytes(2, bb.signature_header(cbytes, b"n"))
             payload = bb.fbytes(1, hdr) + bb.fbytes(2, b"\x0a\xff\xff\xff\xff\x0f" + b"junk")
-            flag = fabgpu.TX_NOT_UNDERSTOOD
+            flag[0] = fabgpu.TX_NOT_UNDERSTOOD
         r, s = _sign(creator, payload, int(rng.integers(1, 1 << 62)))
-        if mode == 9:                                   # creator signed something else
-            r, s = _sign(creator, payload + b"!", 99); flag = fabgpu.TX_BAD_CREATOR_SIGNATURE
-        if mode == 10 and flag == 0:                    # bad creator AND bad endorsement: the creator outranks
-            ends_bad = po.marshal_ecdsa_signature(ends[0][2] + 1, ends[0][3])
-            payload = bb.endorser_tx_payload(3, "mychannel", "tx%d" % t, cbytes, b"nonce", [(ccpp, prp, [(ends[0][0], ends_bad)] + [(e[0], e[1]) for e in ends[1:]])])
-            r, s = _sign(creator, payload + b"?", 77); flag = fabgpu.TX_BAD_CREATOR_SIGNATURE
+        if mode == 9 or mode == 10:                     # creator signed something else
+            r, s = _sign(creator, payload + b"!", 99); flag[0] = fabgpu.TX_BAD_CREATOR_SIGNATURE
         envs.append(bb.envelope(payload, po.marshal_ecdsa_signature(r, s)))
-        want.append(flag)
+        want.append(flag[0])
     return bb.block(7, envs), np.array(want, dtype=np.uint8)
 
 
 def test_block_walker_on_synthetic_blocks():
     rng = np.random.default_rng(5)
-    blk, want = build_block(44, rng)
+    blk, want = build_block(52, rng)
     p = fabgpu.block_parse(blk)
-    assert p["n_tx"] == 44 and p["channel_id"] == "mychannel"
-    n_cfg = sum(1 for t in range(44) if t % 11 == 7)
-    n_bad = sum(1 for t in range(44) if t % 11 == 8)
-    assert list(p["tx_type"]).count(1) == n_cfg and list(p["tx_type"]).count(3) == 44 - n_cfg
-    assert p["n_tuples"] == (44 - n_bad) + 3 * (44 - n_cfg - n_bad) and p["n_prefixes"] == 44 - n_cfg - n_bad
+    assert p["n_tx"] == 52 and p["channel_id"] == "mychannel"
+    n_cfg = sum(1 for t in range(52) if t % 13 == 7)
+    n_bad = sum(1 for t in range(52) if t % 13 == 8)
+    assert list(p["tx_type"]).count(1) == n_cfg and list(p["tx_type"]).count(3) == 52 - n_cfg
+    assert p["n_tuples"] == (52 - n_bad) + 3 * (52 - n_cfg - n_bad) and p["n_prefixes"] == 52 - n_cfg - n_bad
+    # the TxID / proposal-hash checks: recomputed here with hashlib from the spans the walker reports
+    checks = fabgpu.block_hash_checks(blk)
+    assert len(checks) == 2 * (52 - n_cfg - n_bad)
+    bad = {}
+    for tx, kind, pieces, (e0, e1) in checks:
+        digest = hashlib.sha256(b"".join(blk[a:b] for a, b in pieces)).digest()
+        ok = (blk[e0:e1] == digest.hex().encode()) if kind == 0 else (blk[e0:e1] == digest)
+        if not ok:
+            bad[tx] = kind
+    assert bad == {t: (0 if t % 13 == 11 else 1) for t in range(52) if t % 13 in (11, 12)}
     with pytest.raises(fabgpu.FabgpuError):
         fabgpu.block_parse(b"\x12\xff\xff\xff\xff\x0f")              # BlockData length runs past the buffer
 
@@ -152,9 +167,11 @@ def test_preverify_pass_end_to_end():
     # per-tuple detail: exactly the corrupted tuples are non-zero
     st = out["tuple_status"]
     assert set(np.unique(st)) <= {0, 1, 2, 5, 6}
-    assert (st == fabgpu.TUPLE_ST_NEEDS_SW).sum() == sum(1 for t in range(220) if t % 11 == 6)
-    assert (st == 2).sum() == sum(1 for t in range(220) if t % 11 == 4)
-    assert (st == fabgpu.TUPLE_ST_BAD_DER).sum() == sum(1 for t in range(220) if t % 11 == 5)
+    assert (st == fabgpu.TUPLE_ST_NEEDS_SW).sum() == sum(1 for t in range(220) if t % 13 == 6)
+    assert (st == 2).sum() == sum(1 for t in range(220) if t % 13 == 4)
+    assert (st == fabgpu.TUPLE_ST_BAD_DER).sum() == sum(1 for t in range(220) if t % 13 == 5)
+    assert (out["tx_flags"] == fabgpu.TX_BAD_TXID).sum() == sum(1 for t in range(220) if t % 13 == 11)
+    assert (out["tx_flags"] == fabgpu.TX_BAD_PROPOSAL_HASH).sum() == sum(1 for t in range(220) if t % 13 == 12)
     # a clean block: every transaction valid
     blk3, want3 = build_block(64, rng, corrupt=False)
     assert (fabgpu.preverify_block(csp, blk3)["tx_flags"] == 0).all() and (want3 == 0).all()
@@ -176,13 +193,17 @@ def build_mixed_block(n_tx, rng, idemix_every=5):
     endorsers, creators = p256[:4], p256[4:6]
     envs, want, n_idemix = [], [], 0
     for t in range(n_tx):
-        prp = bytes(rng.integers(0, 256, size=int(rng.integers(100, 1200)), dtype=np.uint8))
+        ext = bytes(rng.integers(0, 256, size=int(rng.integers(100, 1200)), dtype=np.uint8))
         ccpp = bytes(rng.integers(0, 256, size=200, dtype=np.uint8))
-        ends = []
-        for j in rng.choice(4, size=3, replace=False):
-            e = endorsers[j]
-            r, s = _sign(e, prp + sid[e["cn"]], int(rng.integers(1, 1 << 62)))
-            ends.append((sid[e["cn"]], po.marshal_ecdsa_signature(r, s)))
+        picks = list(rng.choice(4, size=3, replace=False))
+
+        def sign_ends(prp, picks=picks):
+            ends = []
+            for j in picks:
+                e = endorsers[j]
+                r, s = _sign(e, prp + sid[e["cn"]], int(rng.integers(1, 1 << 62)))
+                ends.append((sid[e["cn"]], po.marshal_ecdsa_signature(r, s)))
+            return ends
         flag = fabgpu.TX_ALL_SIGNATURES_VALID
         if t % idemix_every == 0:
             n_idemix += 1
@@ -190,7 +211,7 @@ def build_mixed_block(n_tx, rng, idemix_every=5):
             which = (t // idemix_every) % 6
             mspid = "IdemixMSP1" if which != 4 else "UnknownIdemixMSP"
             cbytes = bb.serialized_idemix_identity(mspid, be32(nym[0]), be32(nym[1]))
-            payload = bb.endorser_tx_payload(3, "mychannel", "tx%d" % t, cbytes, b"nonce%d" % t, [(ccpp, prp, ends)])
+            payload, _ = bb.consistent_endorser_tx("mychannel", cbytes, b"nonce%d" % t, ccpp, ext, sign_ends)
             sig = io.nym_sign(sk, nym, r_nym, ipk, payload, prng)
             if which == 2:                                # signed another payload
                 sig = io.nym_sign(sk, nym, r_nym, ipk, payload + b"!", prng); flag = fabgpu.TX_BAD_CREATOR_SIGNATURE
@@ -203,7 +224,7 @@ def build_mixed_block(n_tx, rng, idemix_every=5):
             envs.append(bb.envelope(payload, io.nym_signature_marshal(sig)))
         else:
             creator = creators[t % 2]
-            payload = bb.endorser_tx_payload(3, "mychannel", "tx%d" % t, sid[creator["cn"]], b"nonce%d" % t, [(ccpp, prp, ends)])
+            payload, _ = bb.consistent_endorser_tx("mychannel", sid[creator["cn"]], b"nonce%d" % t, ccpp, ext, sign_ends)
             r, s = _sign(creator, payload, int(rng.integers(1, 1 << 62)))
             envs.append(bb.envelope(payload, po.marshal_ecdsa_signature(r, s)))
         want.append(flag)
