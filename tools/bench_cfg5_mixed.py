@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--idemix-share", type=float, default=0.2)
     ap.add_argument("--msg-len", type=int, default=4608, help="creator message bytes (SURVEY 8(d): 4 608)")
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=12, help="untimed launches per timed leg (the chip needs ~10 ms of work to leave its idle clocks)")
     ap.add_argument("--base", type=int, default=192, help="distinct oracle-signed pseudonym signatures that the batch replicates")
     args = ap.parse_args()
     import random
