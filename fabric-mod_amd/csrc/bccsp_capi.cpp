@@ -121,13 +121,15 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
                                uint32_t cap_tx, uint32_t* n_tuples, uint32_t* tuple_tx, uint8_t* tuple_kind, uint8_t* tuple_status,
                                uint32_t cap_tuples) {
     if (!csp || !block || !n_tx || !n_tuples) return FABGPU_EINVAL;
+    GPUCSP::BlockUpload up;
+    csp->csp->StartBlockUpload(up, block, len);            // the block travels while it is walked
     ParsedBlock pb;
     if (!ParseBlock(block, len, pb)) return FABGPU_EINVAL;
     *n_tx = pb.n_tx;
     *n_tuples = (uint32_t)pb.tuples.size();
     if (pb.n_tx > cap_tx || pb.tuples.size() > cap_tuples) return FABGPU_ETOOBIG;   // counts are set: retry with room (nothing was launched)
     BlockVerdicts v;
-    Error e = csp->csp->PreVerifyParsed(block, pb, v);
+    Error e = csp->csp->PreVerifyParsed(block, pb, v, &up);
     if (!e.ok()) return FABGPU_ELAUNCH;
     if (tx_flags && v.n_tx) memcpy(tx_flags, v.tx_flags.data(), v.n_tx);
     if (tx_type && v.n_tx) memcpy(tx_type, v.tx_type.data(), v.n_tx);

@@ -412,10 +412,21 @@ Error GPUCSP::IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::v
 // ------------------------------------------------------------------------------------------------
 // block-level pre-verify pass (block_prepass.h)
 // ------------------------------------------------------------------------------------------------
+void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len) const {
+    size_t min_bytes = (size_t)4 << 20;                 // small blocks ride with the submission through pinned staging
+    if (const char* e = getenv("FABGPU_PASS_STAGE_MIN_BYTES")) min_bytes = (size_t)strtoull(e, nullptr, 10);   // tests force the staged path
+    if (!block || len < min_bytes) return;
+    fabgpu_ctx* c = ctx_;
+    BlockUpload* u = &up;
+    up.th = std::thread([c, u, block, len] { u->rc = fabgpu_arena_stage(c, block, len, &u->token); });
+}
+
 Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const {
+    BlockUpload up;
+    StartBlockUpload(up, block, len);                     // the block travels while it is walked and its signatures are gated
     ParsedBlock pb;
     if (!block || !ParseBlock(block, len, pb)) return Error("block does not parse as common.Block");
-    return PreVerifyParsed(block, pb, out);
+    return PreVerifyParsed(block, pb, out, &up);
 }
 
 int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len) const {
@@ -428,7 +439,7 @@ int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_r
     return k.issuer_id;
 }
 
-Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out) const {
+Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, BlockUpload* up) const {
     out = BlockVerdicts();
     const size_t nt = pb.tuples.size();
     out.n_tx = pb.n_tx;
@@ -620,7 +631,15 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             d.gather_digests = hash_digests.data();
             hashes_done = true;
         }
-        int rc = fabgpu_identity_verify_batch(ctx_, &d);
+        uint64_t tok = up ? up->join() : 0;
+        int rc = FABGPU_EINVAL;
+        if (tok) {
+            d.flags = FABGPU_IDB_SPANS | FABGPU_IDB_ARENA_STAGED;
+            d.stage_token = tok;
+            rc = fabgpu_identity_verify_batch(ctx_, &d);      // FABGPU_EINVAL: somebody else's upload replaced ours -> resubmit with the bytes
+            d.flags = FABGPU_IDB_SPANS;
+        }
+        if (!tok || rc == FABGPU_EINVAL) rc = fabgpu_identity_verify_batch(ctx_, &d);
         if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
         for (size_t j = 0; j < n; j++) {
             bool bit = (bits[j >> 6] >> (j & 63)) & 1;

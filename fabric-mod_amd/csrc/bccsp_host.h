@@ -12,6 +12,7 @@
 
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "../../include/fabgpu.h"
 #include "block_prepass.h"
@@ -95,7 +96,23 @@ class GPUCSP {
     Error IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::vector<std::string>& out) const;
     // Block-level pre-verify pass (block_prepass.h): one fused launch for every creator / endorsement signature of the block.
     Error PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const;
-    Error PreVerifyParsed(const uint8_t* block, const ParsedBlock& parsed, BlockVerdicts& out) const;
+    struct BlockUpload;
+    // up: an upload of the block started ahead (StartBlockUpload); joined right before the submission.  nullptr: the block
+    // travels with the submission.
+    Error PreVerifyParsed(const uint8_t* block, const ParsedBlock& parsed, BlockVerdicts& out, BlockUpload* up = nullptr) const;
+    // Starts the upload of a block on a helper thread (blocks of 4 MiB and more) so that it travels while the caller parses
+    // and gates; join() returns the token for PreVerifyParsed (0 if nothing was staged).
+    struct BlockUpload {
+        std::thread th;
+        uint64_t token = 0;
+        int rc = -1;
+        uint64_t join() {
+            if (th.joinable()) th.join();
+            return rc == 0 ? token : 0;
+        }
+        ~BlockUpload() { if (th.joinable()) th.join(); }
+    };
+    void StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len) const;
     // An idemix MSP of the channel (msp/idemixmsp.go:99-173 Setup): its creators' pseudonym signatures are then verified by the
     // pre-verify pass too.  ipk_raw: marshalled idemix.IssuerPublicKey.  Returns the device issuer id, or -1 (not accelerated).
     int64_t RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len) const;

@@ -81,6 +81,11 @@ struct fabgpu_ctx {
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
     void* d_gscr = nullptr;   // device scratch the gather kernel stitches the messages into
     size_t gscr_cap = 0;
+    // fabgpu_arena_stage: an arena uploaded ahead of the batch that refers to it
+    std::mutex smu;
+    void* d_staged = nullptr;
+    size_t staged_cap = 0, staged_len = 0;
+    uint64_t staged_token = 0;
     Buf keyed;        // staging of the keyed host-pointer entry point: key_id | e | r | s
     Buf pre;          // staging of prefixed batches: pre_off | pre_idx | mid-states
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
@@ -223,6 +228,7 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->nym.release();
         ctx->gath.release();
         if (ctx->d_gscr) hipFree(ctx->d_gscr);
+        if (ctx->d_staged) hipFree(ctx->d_staged);
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
@@ -757,6 +763,32 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
     return hip_to_rc(err);
 }
 
+int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token) {
+    if (!ctx || !arena || !token || len == 0) return FABGPU_EINVAL;
+    if (len > 0xFFFFFF00ull) return FABGPU_ETOOBIG;
+    std::lock_guard<std::mutex> lk(ctx->smu);
+    DeviceGuard g(ctx->device);
+    const size_t need = round_up(len, 4) + 128;
+    if (ctx->staged_cap < need) {
+        // a batch in flight may still read the old buffer: it was submitted under ctx->mu and synchronises before returning,
+        // and it holds no pointer past that; take mu to be sure nobody is between "token checked" and "kernels done"
+        std::lock_guard<std::mutex> lk2(ctx->mu);
+        if (ctx->d_staged) hipFree(ctx->d_staged);
+        ctx->d_staged = nullptr;
+        ctx->staged_cap = 0;
+        if (hipMalloc(&ctx->d_staged, need + need / 8) != hipSuccess) return FABGPU_ENOMEM;
+        ctx->staged_cap = need + need / 8;
+    }
+    ctx->staged_token++;                                   // the previous upload is gone from here on
+    ctx->staged_len = 0;
+    hipError_t err = hipMemcpy(ctx->d_staged, arena, len, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemset((uint8_t*)ctx->d_staged + len, 0, need - len);
+    if (err != hipSuccess) return hip_to_rc(err);
+    ctx->staged_len = len;
+    *token = ctx->staged_token;
+    return FABGPU_OK;
+}
+
 int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b) {
     if (!ctx || !b) return FABGPU_EINVAL;
     const size_t n = b->n;
@@ -766,11 +798,18 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     if (!b->off || !b->r || !b->s || !b->verdict_bits || (!keyed && (!b->qx || !b->qy)) || (m && !b->pre_off)) return FABGPU_EINVAL;
     if (n > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
     const uint8_t* arena = (const uint8_t*)b->arena;
+    const bool spans = (b->flags & FABGPU_IDB_SPANS) != 0;
+    const bool staged = (b->flags & FABGPU_IDB_ARENA_STAGED) != 0;
+    if (b->flags & ~(uint32_t)(FABGPU_IDB_SPANS | FABGPU_IDB_ARENA_STAGED)) return FABGPU_EINVAL;
+    // a staged arena: the stager is kept out until this batch has run.  Lock order everywhere: smu, then mu.
+    std::unique_lock<std::mutex> slk(ctx->smu, std::defer_lock);
+    if (staged) {
+        slk.lock();
+        if (b->stage_token == 0 || b->stage_token != ctx->staged_token || ctx->staged_len == 0) return FABGPU_EINVAL;   // replaced meanwhile
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     // the span of the arena that messages and prefixes reference
-    const bool spans = (b->flags & FABGPU_IDB_SPANS) != 0;
-    if (b->flags & ~(uint32_t)FABGPU_IDB_SPANS) return FABGPU_EINVAL;
     const size_t noff = spans ? 2 * n : n + 1, npre = m ? (spans ? 2 * (size_t)m : (size_t)m + 1) : 0;
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
     for (size_t i = 0; i < n; i++) {
@@ -798,17 +837,23 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     }
     if (gtotal > 0x7FFFFFF0ull) return FABGPU_ETOOBIG;
     size_t span = hi >= lo ? (size_t)hi - lo : 0;
-    if (span && !arena) return FABGPU_EINVAL;
+    if (staged) {
+        if (hi > ctx->staged_len) return FABGPU_EINVAL;
+        lo = 0;                                           // offsets are offsets into the staged bytes
+        span = ctx->staged_len;
+    } else if (span && !arena) {
+        return FABGPU_EINVAL;
+    }
     const size_t fb = n * 32, ib = round_up(n * 4, 64), pob = round_up((npre + 1) * 4, 64), words = (n + 63) / 64;
     const size_t st_off = round_up(words * 8, 64), ab = round_up(span, 4) + 64;
     int rc;
-    if ((rc = ctx->arena.ensure(ab + 64)) || (rc = ctx->offs.ensure(noff * 4)) || (rc = ctx->fields.ensure(4 * fb + ib)) ||
+    if ((!staged && (rc = ctx->arena.ensure(ab + 64))) || (rc = ctx->offs.ensure(noff * 4)) || (rc = ctx->fields.ensure(4 * fb + ib)) ||
         (rc = ctx->out.ensure(st_off + n)) || (rc = ctx->pre.ensure(pob + ib + (size_t)m * 32 + 64)))
         return rc;
     // small arenas go through the pinned staging buffer; big ones (a marshalled block) are handed to the driver directly -
     // one copy less on the host (the tail padding the kernels may touch is zeroed on the device)
     const bool direct = span >= ((size_t)4 << 20);
-    if (!direct) {
+    if (!staged && !direct) {
         if (span) memcpy(ctx->arena.h, arena + lo, span);
         memset((uint8_t*)ctx->arena.h + span, 0, ab - span);
     }
@@ -828,7 +873,9 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
         memcpy(fh, b->qx, fb); memcpy(fh + fb, b->qy, fb); memcpy(fh + 2 * fb, b->r, fb); memcpy(fh + 3 * fb, b->s, fb);
     }
     hipError_t err;
-    if (direct) {
+    if (staged) {
+        err = hipSuccess;                                 // fabgpu_arena_stage put the bytes (and their zero tail) there
+    } else if (direct) {
         err = hipMemcpyAsync(ctx->arena.d, arena + lo, span, hipMemcpyHostToDevice, ctx->stream);
         if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)ctx->arena.d + span, 0, ab - span, ctx->stream);
     } else {
@@ -842,8 +889,9 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     uint8_t* pd = (uint8_t*)ctx->pre.d;
     uint8_t* dout = (uint8_t*)ctx->out.d;
     fabgpu_identity_batch d = *b;
-    d.arena = ctx->arena.d;
-    d.arena_bytes = ab;
+    d.flags = b->flags & FABGPU_IDB_SPANS;
+    d.arena = staged ? ctx->d_staged : ctx->arena.d;
+    d.arena_bytes = staged ? round_up(span, 4) + 64 : ab;
     d.off = (const uint32_t*)ctx->offs.d;
     d.n_prefixes = m;
     d.pre_off = m ? (const uint32_t*)pd : nullptr;

@@ -49,7 +49,8 @@ class _IdBatch(ctypes.Structure):
                 ("qy", ctypes.c_void_p), ("key_id", ctypes.c_void_p), ("r", ctypes.c_void_p), ("s", ctypes.c_void_p),
                 ("verdict_bits", ctypes.c_void_p), ("status", ctypes.c_void_p), ("flags", ctypes.c_uint32),
                 ("n_gather", ctypes.c_uint32), ("gather_spans", ctypes.c_void_p), ("gather_digests", ctypes.c_void_p),
-                ("gather_off", ctypes.c_void_p), ("gather_scratch", ctypes.c_void_p), ("gather_scratch_bytes", ctypes.c_size_t)]
+                ("gather_off", ctypes.c_void_p), ("gather_scratch", ctypes.c_void_p), ("gather_scratch_bytes", ctypes.c_size_t),
+                ("stage_token", ctypes.c_uint64)]
 
 
 class _Cfg(ctypes.Structure):
@@ -64,7 +65,7 @@ ABI_SYMBOLS = [
     "fabgpu_p256_verify_batch_dev", "fabgpu_sha256_batch_dev", "fabgpu_sha256_p256_verify_batch_dev",
     "fabgpu_p256_key_register", "fabgpu_p256_key_lookup", "fabgpu_p256_key_count", "fabgpu_p256_verify_batch_keyed", "fabgpu_p256_verify_batch_keyed_dev",
     "fabgpu_sha256_p256_verify_batch_keyed", "fabgpu_sha256_p256_verify_batch_keyed_dev",
-    "fabgpu_identity_verify_batch", "fabgpu_identity_verify_batch_dev",
+    "fabgpu_identity_verify_batch", "fabgpu_identity_verify_batch_dev", "fabgpu_arena_stage",
     "fabgpu_idemix_issuer_register", "fabgpu_idemix_issuer_count", "fabgpu_idemix_nym_verify_batch", "fabgpu_idemix_nym_verify_batch_dev",
     "fabgpu_bn256_g1_on_curve",
     "fabgpu_last_kernel_ms", "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
@@ -109,6 +110,7 @@ def load():
     L.fabgpu_p256_verify_batch_keyed_dev.argtypes = [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.fabgpu_sha256_p256_verify_batch_keyed.argtypes = [_vp, _sz, _u8p, _u32p, _u32p, _u8p, _u8p, _u64p, _u8p]
     L.fabgpu_sha256_p256_verify_batch_keyed_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.fabgpu_arena_stage.argtypes = [_vp, _u8p, _sz, ctypes.POINTER(ctypes.c_uint64)]
     L.fabgpu_identity_verify_batch.argtypes = [_vp, ctypes.POINTER(_IdBatch)]
     L.fabgpu_identity_verify_batch_dev.argtypes = [_vp, ctypes.POINTER(_IdBatch), _vp, _vp]
     L.fabgpu_idemix_issuer_register.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _u32p]
@@ -343,8 +345,15 @@ class Context:
                                                            proof_s_sk, proof_s_r_nym, nonce, verdict_bits, status or None, stream or None),
                "fabgpu_idemix_nym_verify_batch_dev")
 
+    def arena_stage(self, arena) -> int:
+        """fabgpu_arena_stage: upload ahead of the batch that refers to the bytes; returns the token."""
+        arena = _a8(arena)
+        tok = ctypes.c_uint64(0)
+        _check(self._L.fabgpu_arena_stage(self._h, _p8(arena), arena.size, ctypes.byref(tok)), "fabgpu_arena_stage")
+        return int(tok.value)
+
     def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True, spans=False,
-                              gather_spans=None):
+                              gather_spans=None, stage_token=0):
         """fabgpu_identity_verify_batch: message i = [prefix pre_idx[i]] || arena[off[i], off[i+1]); keys by value or by id.
         gather_spans (m x 6 u32: three (start, end) pieces per gathered message): also returns their m x 32 digest bytes."""
         arena, r, s = map(_a8, (arena, r, s))
@@ -353,7 +362,8 @@ class Context:
         keep = [arena, off, r, s]
         b = _IdBatch()
         b.n = n
-        b.flags = 1 if spans else 0
+        b.flags = (1 if spans else 0) | (2 if stage_token else 0)
+        b.stage_token = stage_token
         b.arena, b.off, b.r, b.s = arena.ctypes.data, off.ctypes.data, r.ctypes.data, s.ctypes.data
         if key_id is not None:
             key_id = np.ascontiguousarray(key_id, dtype=np.uint32); keep.append(key_id)

@@ -165,9 +165,17 @@ typedef struct fabgpu_identity_batch {
     const uint32_t* gather_off;      /* _dev only */
     void* gather_scratch;            /* _dev only */
     size_t gather_scratch_bytes;     /* _dev only: size of the gather_scratch allocation */
+    uint64_t stage_token;            /* host variant with FABGPU_IDB_ARENA_STAGED: the token fabgpu_arena_stage returned */
 } fabgpu_identity_batch;
 #define FABGPU_IDB_SPANS 1u /* off holds n (start, end) pairs and pre_off n_prefixes pairs: messages are arbitrary sub-slices of the arena
                              (a marshalled block), not consecutive */
+#define FABGPU_IDB_ARENA_STAGED 2u /* host variant: the arena is already on the device (fabgpu_arena_stage); `arena` is ignored, all
+                                    offsets are offsets into the staged bytes */
+/* Uploads `len` bytes to a context-owned device buffer and returns when they are there; *token names the upload.  Meant to run on
+ * a helper thread WHILE the caller still prepares the batch that refers to these bytes (the block pre-verify pass parses a
+ * 50 MB block while it travels).  A later fabgpu_identity_verify_batch with FABGPU_IDB_ARENA_STAGED and this token uses the
+ * staged bytes; if another upload replaced them meanwhile the call returns FABGPU_EINVAL and the caller resubmits unstaged. */
+int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token);
 int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch);
 int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch, void* mid_scratch, void* stream);
 

@@ -259,3 +259,20 @@ def test_preverify_pass_with_idemix_creators():
     assert (out["tx_flags"] == fabgpu.TX_BAD_CREATOR_SIGNATURE).sum() == sum(1 for t in range(0, 120, 5) if (t // 5) % 6 == 2)
     assert fabgpu.preverify_block(csp, blk)["tx_flags"].tolist() == want.tolist()          # repeatable; pseudonyms are not cached
     csp.close()
+
+
+@pytest.mark.gpu
+def test_preverify_pass_with_the_block_uploaded_ahead(monkeypatch):
+    """Blocks of 4 MiB and more travel to the device on a helper thread while they are parsed (fabgpu_arena_stage); the test
+    blocks are smaller, so the threshold is lowered: same flags either way, corrupted transactions included."""
+    csp = fabgpu.GPUCSP(device=0)
+    rng = np.random.default_rng(16)
+    blk, want = build_block(130, rng)
+    plain = fabgpu.preverify_block(csp, blk)
+    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    staged = fabgpu.preverify_block(csp, blk)
+    assert (plain["tx_flags"] == want).all() and (staged["tx_flags"] == want).all()
+    assert (staged["tuple_status"] == plain["tuple_status"]).all()
+    for _ in range(3):                                                       # uploads replace each other; every pass still answers
+        assert (fabgpu.preverify_block(csp, blk)["tx_flags"] == want).all()
+    csp.close()

@@ -261,6 +261,30 @@ def test_identity_batch_with_shared_prefixes_vs_hashlib_and_oracle(ctx, keyed):
     kw2 = {k: v[perm] for k, v in kw.items()}
     bits4, st4 = ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True, **kw2)
     assert (st4 == st[perm]).all() and (bits4 == bits[perm]).all()
+    # gathered hashes riding along (the TxID / proposal-hash checks of the block pass): messages stitched from up to three spans
+    g = []
+    want_g = []
+    for j in range(50):
+        pieces = []
+        for _ in range(int(rng.integers(0, 4))):
+            a0 = int(rng.integers(0, arena.size - 1))
+            pieces.append((a0, min(arena.size - 1, a0 + int(rng.integers(0, 400)))))
+        while len(pieces) < 3:
+            pieces.insert(int(rng.integers(0, len(pieces) + 1)), (7, 7))                  # unused piece: start == end
+        g.append([x for pr in pieces for x in pr])
+        want_g.append(hashlib.sha256(b"".join(arena[a0:a1].tobytes() for a0, a1 in pieces)).digest())
+    bits5, st5, dig5 = ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True,
+                                                 gather_spans=np.array(g, dtype=np.uint32), **kw2)
+    assert (st5 == st4).all() and [d.tobytes() for d in dig5] == want_g
+    # the arena staged ahead (fabgpu_arena_stage): same answers; a token that a newer upload replaced is refused
+    tok = ctx.arena_stage(arena)
+    bits6, st6, dig6 = ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True,
+                                                 gather_spans=np.array(g, dtype=np.uint32), stage_token=tok, **kw2)
+    assert (st6 == st4).all() and (bits6 == bits4).all() and [d.tobytes() for d in dig6] == want_g
+    tok2 = ctx.arena_stage(arena[:100])
+    assert tok2 != tok
+    with pytest.raises(fabgpu.FabgpuError):
+        ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True, stage_token=tok, **kw2)
 
 
 # ---- SHA-256 ----------------------------------------------------------------------------------------
