@@ -1,6 +1,10 @@
 // Flat C wrappers (include/fabgpu_bccsp.h) over the C++ host mirror, for ctypes / other FFIs.
 #include <stdio.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include "../../include/fabgpu_bccsp.h"
 #include "bccsp_host.h"
@@ -121,15 +125,26 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
                                uint32_t cap_tx, uint32_t* n_tuples, uint32_t* tuple_tx, uint8_t* tuple_kind, uint8_t* tuple_status,
                                uint32_t cap_tuples) {
     if (!csp || !block || !n_tx || !n_tuples) return FABGPU_EINVAL;
+    const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;          // stage breakdown on stderr (tools/bench_block.py --timing)
+    auto t0 = std::chrono::steady_clock::now();
     GPUCSP::BlockUpload up;
     csp->csp->StartBlockUpload(up, block, len);            // the block travels while it is walked
     ParsedBlock pb;
-    if (!ParseBlock(block, len, pb)) return FABGPU_EINVAL;
+    if (!ParseBlock(block, len, pb, 16)) return FABGPU_EINVAL;
+    auto t1 = std::chrono::steady_clock::now();
     *n_tx = pb.n_tx;
     *n_tuples = (uint32_t)pb.tuples.size();
     if (pb.n_tx > cap_tx || pb.tuples.size() > cap_tuples) return FABGPU_ETOOBIG;   // counts are set: retry with room (nothing was launched)
     BlockVerdicts v;
     Error e = csp->csp->PreVerifyParsed(block, pb, v, &up);
+    if (timing) {
+        auto t2 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        fprintf(stderr, "fabgpu pass: walk %.2f ms, gates + submission + flags %.2f ms (gates %.2f, wait for upload %.2f, device call %.2f)\n", ms(t0, t1),
+                ms(t1, t2), v.ms_gates, v.ms_upload_wait, v.ms_device);
+    }
     if (!e.ok()) return FABGPU_ELAUNCH;
     if (tx_flags && v.n_tx) memcpy(tx_flags, v.tx_flags.data(), v.n_tx);
     if (tx_type && v.n_tx) memcpy(tx_type, v.tx_type.data(), v.n_tx);

@@ -18,6 +18,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <functional>
 #include <thread>
 
 #include "p256_point.h"
@@ -425,7 +427,7 @@ Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& ou
     BlockUpload up;
     StartBlockUpload(up, block, len);                     // the block travels while it is walked and its signatures are gated
     ParsedBlock pb;
-    if (!block || !ParseBlock(block, len, pb)) return Error("block does not parse as common.Block");
+    if (!block || !ParseBlock(block, len, pb, 16)) return Error("block does not parse as common.Block");
     return PreVerifyParsed(block, pb, out, &up);
 }
 
@@ -452,18 +454,17 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     out.tuple_status.assign(nt, FABGPU_ST_VALID);
     // identities -> keys (cached across blocks), signatures -> (r, s) through the reference's gates.  Tuples are independent:
     // blocks of 4096+ tuples are gated on worker threads (contiguous ranges), then compacted in order.
-    struct Gated {
-        uint8_t qx[32], qy[32], r[32], s[32];   // idemix tuple: qx, qy = pseudonym; r, s = ProofC, ProofSSk
-        uint8_t srn[32], nonce[32];              // idemix only: ProofSRNym, Nonce
-        int64_t key_id;                          // idemix: issuer id
-        bool submit, nym;
-    };
+    // One pass at a time per provider: the scratch below (8 MB for a 40 000-tuple block) is reused from block to block instead of
+    // being allocated - and page-faulted in - per call.
+    std::lock_guard<std::mutex> pass_lk(pass_mu_);
+    typedef PassScratch::Gated Gated;
     std::map<std::string, int64_t> idemix_msps;
     {
         std::lock_guard<std::mutex> lk(idmu_);
         idemix_msps = idemix_msps_;
     }
-    std::vector<Gated> gt(nt);
+    std::vector<Gated>& gt = ps_.gt;
+    if (gt.size() < nt) gt.resize(nt);
     std::vector<uint32_t> new_ids(1, 0);
     auto gate_range = [&](size_t lo, size_t hi, uint32_t* fresh) {
         static const uint8_t one_digest[1] = {1};
@@ -552,47 +553,70 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             g0.submit = true;
         }
     };
-    int nthreads = nt >= 4096 ? 8 : 1;
-    if (nthreads == 1) {
-        gate_range(0, nt, &new_ids[0]);
-    } else {
-        new_ids.assign(nthreads, 0);
-        std::vector<std::thread> th;
-        for (int w = 0; w < nthreads; w++)
-            th.emplace_back([&, w] { gate_range(nt * w / nthreads, nt * (w + 1) / nthreads, &new_ids[w]); });
-        for (auto& x : th) x.join();
-    }
-    for (uint32_t v : new_ids) out.distinct_identities += v;
-    std::vector<uint32_t> sub;                       // tuples the device decides
-    std::vector<uint8_t> qx, qy, r, s;
-    std::vector<uint32_t> ids;
-    bool all_keyed = true;
-    qx.reserve(nt * 32); qy.reserve(nt * 32); r.reserve(nt * 32); s.reserve(nt * 32); ids.reserve(nt); sub.reserve(nt);
-    for (size_t i = 0; i < nt; i++) {
-        const Gated& g0 = gt[i];
-        if (!g0.submit) continue;
-        sub.push_back((uint32_t)i);
-        qx.insert(qx.end(), g0.qx, g0.qx + 32);
-        qy.insert(qy.end(), g0.qy, g0.qy + 32);
-        r.insert(r.end(), g0.r, g0.r + 32);
-        s.insert(s.end(), g0.s, g0.s + 32);
-        ids.push_back(g0.key_id >= 0 ? (uint32_t)g0.key_id : 0);
-        if (g0.key_id < 0) all_keyed = false;
-    }
-    const size_t n = sub.size();
-    std::vector<uint8_t> hash_digests;
-    bool hashes_done = false;
-    if (n) {
-        std::vector<uint32_t> off(2 * n), pre_idx(n), pre_off(2 * pb.prefixes.size() + 2);
-        for (size_t p = 0; p < pb.prefixes.size(); p++) {
-            pre_off[2 * p] = pb.prefixes[p].off;
-            pre_off[2 * p + 1] = pb.prefixes[p].off + pb.prefixes[p].len;
+    auto clk0 = std::chrono::steady_clock::now();
+    const int nthreads = nt >= 16384 ? 16 : (nt >= 4096 ? 8 : 1);
+    auto in_threads = [&](const std::function<void(int, size_t, size_t)>& fn) {       // fn(worker, lo, hi) over contiguous tuple ranges
+        if (nthreads == 1) {
+            fn(0, 0, nt);
+            return;
         }
-        for (size_t j = 0; j < n; j++) {
-            const BlockTuple& tp = pb.tuples[sub[j]];
+        std::vector<std::thread> th;
+        for (int w = 0; w < nthreads; w++) th.emplace_back([&, w] { fn(w, nt * w / nthreads, nt * (w + 1) / nthreads); });
+        for (auto& x : th) x.join();
+    };
+    new_ids.assign(nthreads, 0);
+    in_threads([&](int w, size_t lo, size_t hi) { gate_range(lo, hi, &new_ids[w]); });
+    for (uint32_t v : new_ids) out.distinct_identities += v;
+    out.ms_gates = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk0).count();
+    // compaction of the tuples the device decides, in order, on the same workers: count per range, scan, copy
+    std::vector<size_t> cnt(nthreads + 1, 0);
+    std::vector<uint8_t> keyed_w(nthreads, 1);
+    in_threads([&](int w, size_t lo, size_t hi) {
+        size_t c = 0;
+        for (size_t i = lo; i < hi; i++)
+            if (gt[i].submit) {
+                c++;
+                if (gt[i].key_id < 0) keyed_w[w] = 0;
+            }
+        cnt[w + 1] = c;
+    });
+    for (int w = 0; w < nthreads; w++) cnt[w + 1] += cnt[w];
+    const size_t n = cnt[nthreads];
+    bool all_keyed = true;
+    for (uint8_t k : keyed_w) all_keyed = all_keyed && k;
+    std::vector<uint32_t>&sub = ps_.sub, &ids = ps_.ids, &off = ps_.off, &pre_idx = ps_.pre_idx;
+    std::vector<uint8_t>&qx = ps_.qx, &qy = ps_.qy, &r = ps_.r, &s = ps_.s;
+    if (sub.size() < n) {
+        sub.resize(n); ids.resize(n); off.resize(2 * n); pre_idx.resize(n);
+        qx.resize(n * 32); qy.resize(n * 32); r.resize(n * 32); s.resize(n * 32);
+    }
+    in_threads([&](int w, size_t lo, size_t hi) {
+        size_t j = cnt[w];
+        for (size_t i = lo; i < hi; i++) {
+            const Gated& g0 = gt[i];
+            if (!g0.submit) continue;
+            const BlockTuple& tp = pb.tuples[i];
+            sub[j] = (uint32_t)i;
+            if (!all_keyed) {                           // keys go by value only when some identity has no device table
+                memcpy(&qx[32 * j], g0.qx, 32);
+                memcpy(&qy[32 * j], g0.qy, 32);
+            }
+            memcpy(&r[32 * j], g0.r, 32);
+            memcpy(&s[32 * j], g0.s, 32);
+            ids[j] = g0.key_id >= 0 ? (uint32_t)g0.key_id : 0;
             off[2 * j] = tp.suffix.off;
             off[2 * j + 1] = tp.suffix.off + tp.suffix.len;
             pre_idx[j] = tp.prefix_index >= 0 ? (uint32_t)tp.prefix_index : 0xFFFFFFFFu;
+            j++;
+        }
+    });
+    std::vector<uint8_t> hash_digests;
+    bool hashes_done = false;
+    if (n) {
+        std::vector<uint32_t> pre_off(2 * pb.prefixes.size() + 2);
+        for (size_t p = 0; p < pb.prefixes.size(); p++) {
+            pre_off[2 * p] = pb.prefixes[p].off;
+            pre_off[2 * p + 1] = pb.prefixes[p].off + pb.prefixes[p].len;
         }
         std::vector<uint64_t> bits((n + 63) / 64);
         std::vector<uint8_t> st(n);
@@ -631,7 +655,10 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             d.gather_digests = hash_digests.data();
             hashes_done = true;
         }
+        auto clk1 = std::chrono::steady_clock::now();
         uint64_t tok = up ? up->join() : 0;
+        auto clk2 = std::chrono::steady_clock::now();
+        out.ms_upload_wait = std::chrono::duration<double, std::milli>(clk2 - clk1).count();
         int rc = FABGPU_EINVAL;
         if (tok) {
             d.flags = FABGPU_IDB_SPANS | FABGPU_IDB_ARENA_STAGED;
@@ -640,6 +667,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             d.flags = FABGPU_IDB_SPANS;
         }
         if (!tok || rc == FABGPU_EINVAL) rc = fabgpu_identity_verify_batch(ctx_, &d);
+        out.ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk2).count();
         if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
         for (size_t j = 0; j < n; j++) {
             bool bit = (bits[j >> 6] >> (j & 63)) & 1;

@@ -81,6 +81,7 @@ struct BlockVerdicts {
     std::vector<uint8_t> tuple_kind;      // TUPLE_CREATOR / TUPLE_ENDORSEMENT
     std::vector<uint8_t> tuple_status;    // device status 0..4 or TUPLE_ST_*
     uint32_t distinct_identities = 0;     // identities of this block that were not in the cache yet
+    double ms_gates = 0, ms_upload_wait = 0, ms_device = 0;   // where the pass spent its time (host clock)
 };
 
 class GPUCSP {
@@ -130,6 +131,20 @@ class GPUCSP {
     mutable std::mutex idmu_;
     mutable std::map<std::string, CachedIdentity> idcache_;
     mutable std::map<std::string, int64_t> idemix_msps_;   // mspid -> device issuer id (guarded by idmu_)
+    // scratch of the pre-verify pass, reused from block to block (guarded by pass_mu_)
+    struct PassScratch {
+        struct Gated {
+            uint8_t qx[32], qy[32], r[32], s[32];   // idemix tuple: qx, qy = pseudonym; r, s = ProofC, ProofSSk
+            uint8_t srn[32], nonce[32];              // idemix only: ProofSRNym, Nonce
+            int64_t key_id;                          // idemix: issuer id
+            bool submit, nym;
+        };
+        std::vector<Gated> gt;
+        std::vector<uint32_t> sub, ids, off, pre_idx;
+        std::vector<uint8_t> qx, qy, r, s;
+    };
+    mutable std::mutex pass_mu_;
+    mutable PassScratch ps_;
 };
 
 }  // namespace bccsp

@@ -624,7 +624,9 @@ def preverify_block(csp: "GPUCSP", block: bytes):
     """fabgpu_csp_block_preverify: every creator / endorsement signature of a marshalled block in one fused launch.
     Returns dict(tx_flags, tx_type, tuple_tx, tuple_kind, tuple_status)."""
     buf = np.frombuffer(block, dtype=np.uint8)
-    cap_tx, cap_tu = 1024, 4096
+    # room for the answers: remembered from the previous block of this provider (a caller that knows its block passes
+    # len(block.Data.Data) and the endorsement count; a too-small guess costs a second walk AND a wasted upload)
+    cap_tx, cap_tu = getattr(csp, "_pass_caps", (1024, 4096))
     while True:
         n_tx, n_tu = ctypes.c_uint32(0), ctypes.c_uint32(0)
         tx_flags, tx_type = np.zeros(cap_tx, np.uint8), np.zeros(cap_tx, np.uint8)
@@ -633,6 +635,7 @@ def preverify_block(csp: "GPUCSP", block: bytes):
                                                t_tx.ctypes.data_as(_u32p), _p8(t_kind), _p8(t_st), cap_tu)
         if rc == -5:   # FABGPU_ETOOBIG: counts are set
             cap_tx, cap_tu = max(cap_tx, n_tx.value), max(cap_tu, n_tu.value)
+            csp._pass_caps = (cap_tx, cap_tu)
             continue
         _check(rc, "fabgpu_csp_block_preverify")
         a, b = n_tx.value, n_tu.value
