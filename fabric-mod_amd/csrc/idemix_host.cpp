@@ -126,7 +126,10 @@ Error IdemixCSP::NymVerifyBatch(const std::vector<NymVerifyItem>& items, std::ve
         if (!it.sig || it.siglen == 0) { r.err = Error("invalid signature, it must not be empty"); continue; }
         NymSignatureFields sf;
         if (!UnmarshalNymSignature(it.sig, it.siglen, sf)) {
-            r.err = Error("error unmarshalling signature");                                      // bridge/nymsignaturescheme.go:85 (wrapped proto error)
+            // Bytes this walker does not accept.  golang/protobuf's Unmarshal (bridge/nymsignaturescheme.go:83-86) is more
+            // permissive in places (it skips unknown groups, for one), and a verdict is consensus-relevant: no error text is
+            // invented here - bccsp/idemix decides, and words its own error.
+            r.needs_sw = true;
             continue;
         }
         // FP256BN.FromBytes reads exactly 32 bytes: other sizes panic or truncate inside amcl -> bccsp/sw decides

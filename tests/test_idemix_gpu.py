@@ -133,7 +133,7 @@ def test_nym_verifier_mirror_semantics():
             (key, good, msg + b"!"),     # 1 other message
             (key, flipped, msg),         # 2 tampered nonce
             (key, b"", msg),             # 3 empty signature
-            (key, b"\xff\xff\xff", msg), # 4 not a protobuf message
+            (key, b"\xff\xff\xff", msg), # 4 bytes the walker does not accept: bccsp/idemix decides (and words the error)
             (key, short, msg),           # 5 a 31-byte field: amcl-internal -> bccsp/idemix decides
             (key[:63], good, msg),       # 6 odd-sized nym key: bccsp/idemix decides
             (b"", good, msg),            # 7 empty nym key: KeyImport error
@@ -145,7 +145,7 @@ def test_nym_verifier_mirror_semantics():
         assert res[1] == (False, False, "pseudonym signature invalid: zero-knowledge proof is invalid")
         assert res[2] == (False, False, "pseudonym signature invalid: zero-knowledge proof is invalid")
         assert res[3] == (False, False, "invalid signature, it must not be empty")
-        assert res[4][0] is False and res[4][2].startswith("error unmarshalling signature")
+        assert res[4] == (False, True, None)
         assert res[5] == (False, True, None)
         assert res[6] == (False, True, None)
         assert res[7] == (False, False, "invalid raw, it must not be nil")
