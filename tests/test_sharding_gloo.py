@@ -83,3 +83,54 @@ def test_shard_geometry():
         for w in (1, 2, 3, 8):
             spans = [sharding.shard_range(n, r, w) for r in range(w)]
             assert sum(h - l for l, h in spans) == n
+
+
+# ---- BASELINE config 5: a mixed batch (ECDSA + idemix pseudonym signatures) across ranks -------------------------------------
+def _mixed_worker(rank, world, port, n_ec, n_nym, q):
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "fabric-mod_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import coracle
+    import idemix_oracle as io
+    from fabgpu import sharding
+    from idemix_common import fixtures, make_batch
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    b = coracle.make_batch(n_ec, seed=515, invalid_frac=0.2)              # the same block on every rank
+    fx = fixtures()
+    nb = make_batch([(fx[m]["ipk"], fx[m]["signer"].sk) for m in ("MSP1OU1", "MSP2OU1")], n_nym, 516)
+    merged = []
+    # the two sub-batches are sharded independently by the same rule: each kernel gets a contiguous, 64-aligned range
+    lo, hi = sharding.shard_range(n_ec, rank, world)
+    st = coracle.verify_batch(b["qx"][lo:hi], b["qy"][lo:hi], b["e"][lo:hi], b["r"][lo:hi], b["s"][lo:hi]) if hi > lo else np.zeros(0, np.uint8)
+    merged.append(sharding.allgather_verdicts(torch.from_numpy(_pack(st == 0, sharding.shard_words(n_ec, world)).view(np.int64).copy()), n_ec, world))
+    lo2, hi2 = sharding.shard_range(n_nym, rank, world)
+    st2 = np.array([nb.expect[i] for i in range(lo2, hi2)], dtype=np.uint8)   # the oracle's verdicts stand in for the nym kernel
+    merged.append(sharding.allgather_verdicts(torch.from_numpy(_pack(st2 == 0, sharding.shard_words(n_nym, world)).view(np.int64).copy()), n_nym, world))
+    q.put((rank, [m.numpy().view(np.uint64).copy() for m in merged], (lo, hi), (lo2, hi2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_mixed_batch_of_config_5():
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import coracle
+    from idemix_common import fixtures, make_batch
+    n_ec, n_nym = 800, 200                                                 # 80 % / 20 %
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, world, port, n_ec, n_nym, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b = coracle.make_batch(n_ec, seed=515, invalid_frac=0.2)
+    want_ec = _pack(coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"]) == 0, (n_ec + 63) // 64)
+    fx = fixtures()
+    nb = make_batch([(fx[m]["ipk"], fx[m]["signer"].sk) for m in ("MSP1OU1", "MSP2OU1")], n_nym, 516)
+    want_nym = _pack(np.array(nb.expect) == 0, (n_nym + 63) // 64)
+    for rank, (m_ec, m_nym), r1, r2 in res:
+        assert (m_ec == want_ec).all() and (m_nym == want_nym).all(), rank
+    assert sorted(r[2] for r in res)[0][0] == 0 and sorted(r[3] for r in res)[-1][1] == n_nym
