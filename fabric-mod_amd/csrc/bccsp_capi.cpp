@@ -129,7 +129,7 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
     auto t0 = std::chrono::steady_clock::now();
     GPUCSP::BlockUpload up;
     csp->csp->StartBlockUpload(up, block, len);            // the block travels while it is walked
-    ParsedBlock pb;
+    static thread_local ParsedBlock pb;                     // storage reused from block to block (a few MB: no page faults per block)
     if (!ParseBlock(block, len, pb, 16)) return FABGPU_EINVAL;
     auto t1 = std::chrono::steady_clock::now();
     *n_tx = pb.n_tx;

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <functional>
 #include <thread>
@@ -426,7 +427,7 @@ void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len)
 Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const {
     BlockUpload up;
     StartBlockUpload(up, block, len);                     // the block travels while it is walked and its signatures are gated
-    ParsedBlock pb;
+    static thread_local ParsedBlock pb;                   // storage reused from block to block
     if (!block || !ParseBlock(block, len, pb, 16)) return Error("block does not parse as common.Block");
     return PreVerifyParsed(block, pb, out, &up);
 }
@@ -565,13 +566,22 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         for (auto& x : th) x.join();
     };
     new_ids.assign(nthreads, 0);
-    in_threads([&](int w, size_t lo, size_t hi) { gate_range(lo, hi, &new_ids[w]); });
-    for (uint32_t v : new_ids) out.distinct_identities += v;
-    out.ms_gates = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk0).count();
-    // compaction of the tuples the device decides, in order, on the same workers: count per range, scan, copy
+    // ONE round of workers (spawning 16 threads costs ~0.25 ms on the bench host, and there used to be three rounds): each gates
+    // its range and counts what it submits, a spin barrier lets everybody see every count, then each compacts its range - in
+    // order - into the submission arrays, which are sized for the worst case up front.
     std::vector<size_t> cnt(nthreads + 1, 0);
     std::vector<uint8_t> keyed_w(nthreads, 1);
+    std::vector<uint32_t>&sub = ps_.sub, &ids = ps_.ids, &off = ps_.off, &pre_idx = ps_.pre_idx;
+    std::vector<uint8_t>&qx = ps_.qx, &qy = ps_.qy, &r = ps_.r, &s = ps_.s;
+    if (sub.size() < nt) {
+        sub.resize(nt); ids.resize(nt); off.resize(2 * nt); pre_idx.resize(nt);
+        qx.resize(nt * 32); qy.resize(nt * 32); r.resize(nt * 32); s.resize(nt * 32);
+    }
+    std::atomic<int> arrived(0);
+    double ms_gates_max = 0;
+    std::mutex gm;
     in_threads([&](int w, size_t lo, size_t hi) {
+        gate_range(lo, hi, &new_ids[w]);
         size_t c = 0;
         for (size_t i = lo; i < hi; i++)
             if (gt[i].submit) {
@@ -579,28 +589,22 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                 if (gt[i].key_id < 0) keyed_w[w] = 0;
             }
         cnt[w + 1] = c;
-    });
-    for (int w = 0; w < nthreads; w++) cnt[w + 1] += cnt[w];
-    const size_t n = cnt[nthreads];
-    bool all_keyed = true;
-    for (uint8_t k : keyed_w) all_keyed = all_keyed && k;
-    std::vector<uint32_t>&sub = ps_.sub, &ids = ps_.ids, &off = ps_.off, &pre_idx = ps_.pre_idx;
-    std::vector<uint8_t>&qx = ps_.qx, &qy = ps_.qy, &r = ps_.r, &s = ps_.s;
-    if (sub.size() < n) {
-        sub.resize(n); ids.resize(n); off.resize(2 * n); pre_idx.resize(n);
-        qx.resize(n * 32); qy.resize(n * 32); r.resize(n * 32); s.resize(n * 32);
-    }
-    in_threads([&](int w, size_t lo, size_t hi) {
-        size_t j = cnt[w];
+        {
+            double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk0).count();
+            std::lock_guard<std::mutex> lk(gm);
+            if (t > ms_gates_max) ms_gates_max = t;
+        }
+        arrived.fetch_add(1, std::memory_order_acq_rel);
+        while (arrived.load(std::memory_order_acquire) < nthreads) std::this_thread::yield();
+        size_t j = 0;
+        for (int v = 0; v < w; v++) j += cnt[v + 1];
         for (size_t i = lo; i < hi; i++) {
             const Gated& g0 = gt[i];
             if (!g0.submit) continue;
             const BlockTuple& tp = pb.tuples[i];
             sub[j] = (uint32_t)i;
-            if (!all_keyed) {                           // keys go by value only when some identity has no device table
-                memcpy(&qx[32 * j], g0.qx, 32);
-                memcpy(&qy[32 * j], g0.qy, 32);
-            }
+            memcpy(&qx[32 * j], g0.qx, 32);
+            memcpy(&qy[32 * j], g0.qy, 32);
             memcpy(&r[32 * j], g0.r, 32);
             memcpy(&s[32 * j], g0.s, 32);
             ids[j] = g0.key_id >= 0 ? (uint32_t)g0.key_id : 0;
@@ -610,6 +614,12 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             j++;
         }
     });
+    for (uint32_t v : new_ids) out.distinct_identities += v;
+    out.ms_gates = ms_gates_max;
+    size_t n = 0;
+    for (int w = 0; w < nthreads; w++) n += cnt[w + 1];
+    bool all_keyed = true;
+    for (uint8_t k : keyed_w) all_keyed = all_keyed && k;
     std::vector<uint8_t> hash_digests;
     bool hashes_done = false;
     if (n) {

@@ -19,6 +19,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -74,10 +75,17 @@ struct ParsedBlock {
     std::vector<BlockTuple> tuples;
     std::vector<BlockHashCheck> hash_checks;   // endorser transactions only
     std::string first_channel_id;         // of envelope 0 (fixture pin)
+    // A ParsedBlock that is handed to ParseBlock again keeps its storage (and that of the per-worker parts below): a provider
+    // that parses block after block does not allocate - and page-fault in - a few MB per block.
+    std::vector<std::unique_ptr<ParsedBlock>> parts;   // scratch of the threaded walk: one per chunk of envelopes
+    void reset() {
+        n_tx = 0;
+        tx_type.clear(); tx_understood.clear(); prefixes.clear(); tuples.clear(); hash_checks.clear(); first_channel_id.clear();
+    }
 };
 
 // Pure parsing (no device): false only if the outer Block / BlockData framing is broken.
-// Blocks of 1024+ envelopes are walked on up to max_threads (<= 16) worker threads.
+// BlockData of 1 MiB and more is walked on up to max_threads (<= 16) worker threads while the calling thread lists the envelopes.
 bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_threads = 8);
 // SerializedIdentity{mspid, id_bytes = PEM x509} -> uncompressed P-256 point.  false: not such an identity.
 bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy[32]);

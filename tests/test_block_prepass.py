@@ -276,3 +276,30 @@ def test_preverify_pass_with_the_block_uploaded_ahead(monkeypatch):
     for _ in range(3):                                                       # uploads replace each other; every pass still answers
         assert (fabgpu.preverify_block(csp, blk)["tx_flags"] == want).all()
     csp.close()
+
+
+def test_threaded_walk_on_a_multi_megabyte_block():
+    """BlockData of 1 MiB and more is listed on the calling thread while worker threads parse the envelopes chunk by chunk (256 per
+    chunk): 700 transactions (3 chunks, 3.5 MB), every count and every hash check must come out as for a small block."""
+    rng = np.random.default_rng(23)
+    sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in IDS if i["curve"] == "prime256v1"]
+    fake = b"\x30\x44\x02\x20" + b"\x11" * 32 + b"\x02\x20" + b"\x22" * 32          # signatures are not looked at by the walker
+    envs = []
+    for t in range(700):
+        payload, _ = bb.consistent_endorser_tx("mychannel", sid[4 + t % 2], bytes(rng.integers(0, 256, size=24, dtype=np.uint8)),
+                                               bytes(rng.integers(0, 256, size=300, dtype=np.uint8)), bytes(rng.integers(0, 256, size=900, dtype=np.uint8)),
+                                               lambda prp: [(sid[j], fake) for j in (0, 1, 2)], bad_txid=(t % 97 == 5), bad_phash=(t % 89 == 7))
+        envs.append(bb.envelope(payload, fake))
+    blk = bb.block(3, envs)
+    assert len(blk) > 3 << 20
+    p = fabgpu.block_parse(blk)
+    assert p["n_tx"] == 700 and p["n_tuples"] == 2800 and p["n_prefixes"] == 700 and p["channel_id"] == "mychannel"
+    assert (np.asarray(p["tx_type"]) == 3).all()
+    checks = fabgpu.block_hash_checks(blk)
+    assert [c[0] for c in checks] == [t for t in range(700) for _ in range(2)]           # in transaction order: TxID, then proposal hash
+    bad = set()
+    for tx, kind, pieces, (e0, e1) in checks:
+        digest = hashlib.sha256(b"".join(blk[a:b] for a, b in pieces)).digest()
+        if not ((blk[e0:e1] == digest.hex().encode()) if kind == 0 else (blk[e0:e1] == digest)):
+            bad.add((tx, kind))
+    assert bad == {(t, 0) for t in range(700) if t % 97 == 5} | {(t, 1) for t in range(700) if t % 89 == 7}
