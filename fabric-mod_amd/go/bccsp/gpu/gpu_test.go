@@ -1,0 +1,135 @@
+// +build fabgpu
+
+// Differential tests of the GPU provider against bccsp/sw, written after the reference's own tests for this path
+// (bccsp/sw/impl_test.go:525-586, 931-964, 1008-1032; bccsp/sw/ecdsa_test.go:47-73; bccsp/utils/ecdsa_test.go:20-88;
+// msp/msp_test.go:494-536).  They run wherever a Go toolchain and an MI355X exist - neither is in the build image of this
+// repository, where the same cases are exercised through the C ABI by tests/test_gpu_parity.py against the CPU oracle.
+package gpu
+
+import (
+	"crypto/ecdsa"
+	"crypto/elliptic"
+	"crypto/rand"
+	"crypto/sha256"
+	"math/big"
+	"testing"
+
+	"github.com/hyperledger/fabric/bccsp"
+	"github.com/hyperledger/fabric/bccsp/sw"
+	"github.com/hyperledger/fabric/bccsp/utils"
+	"github.com/stretchr/testify/require"
+)
+
+func providers(t *testing.T) (bccsp.BCCSP, bccsp.BCCSP) {
+	ref, err := sw.NewDefaultSecurityLevelWithKeystore(sw.NewDummyKeyStore())
+	require.NoError(t, err)
+	g, err := New(ref, 0)
+	if err != nil {
+		t.Skipf("no MI355X here: %s", err)
+	}
+	return g, ref
+}
+
+// same (valid, err == nil, error text) from both providers
+func same(t *testing.T, g, ref bccsp.BCCSP, gk, rk bccsp.Key, sig, digest []byte) {
+	v1, e1 := g.Verify(gk, sig, digest, nil)
+	v2, e2 := ref.Verify(rk, sig, digest, nil)
+	require.Equal(t, v2, v1)
+	require.Equal(t, e2 == nil, e1 == nil)
+	if e2 != nil {
+		require.Equal(t, e2.Error(), e1.Error())
+	}
+}
+
+func importBoth(t *testing.T, g, ref bccsp.BCCSP, pub *ecdsa.PublicKey) (bccsp.Key, bccsp.Key) {
+	gk, err := g.KeyImport(pub, &bccsp.ECDSAGoPublicKeyImportOpts{Temporary: true})
+	require.NoError(t, err)
+	rk, err := ref.KeyImport(pub, &bccsp.ECDSAGoPublicKeyImportOpts{Temporary: true})
+	require.NoError(t, err)
+	return gk, rk
+}
+
+func TestSignVerifyTamperLikeTheReference(t *testing.T) {
+	g, ref := providers(t)
+	for i := 0; i < 200; i++ {
+		priv, _ := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
+		gk, rk := importBoth(t, g, ref, &priv.PublicKey)
+		msg := make([]byte, 1+i*7)
+		rand.Read(msg)
+		digest := sha256.Sum256(msg)
+		r, s, _ := ecdsa.Sign(rand.Reader, priv, digest[:])
+		s, _ = utils.ToLowS(&priv.PublicKey, s)
+		sig, _ := utils.MarshalECDSASignature(r, s)
+		same(t, g, ref, gk, rk, sig, digest[:])
+		digest[3] ^= 0x40 // tampered digest
+		same(t, g, ref, gk, rk, sig, digest[:])
+		digest[3] ^= 0x40
+		hs := new(big.Int).Sub(elliptic.P256().Params().N, s) // high-S twin: (false, error) in bccsp/sw
+		high, _ := utils.MarshalECDSASignature(r, hs)
+		same(t, g, ref, gk, rk, high, digest[:])
+		r1, _ := utils.MarshalECDSASignature(new(big.Int).Add(r, big.NewInt(1)), s)
+		same(t, g, ref, gk, rk, r1, digest[:])
+	}
+}
+
+func TestLowSBoundaryAndDegenerateValues(t *testing.T) {
+	g, ref := providers(t)
+	priv, _ := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
+	gk, rk := importBoth(t, g, ref, &priv.PublicKey)
+	digest := sha256.Sum256([]byte("boundary"))
+	half := utils.GetCurveHalfOrdersAt(elliptic.P256())
+	for _, s := range []*big.Int{half, new(big.Int).Add(half, big.NewInt(1)), big.NewInt(0), big.NewInt(-1), big.NewInt(1)} {
+		for _, r := range []*big.Int{big.NewInt(1), big.NewInt(0), big.NewInt(-1), elliptic.P256().Params().N} {
+			sig, err := utils.MarshalECDSASignature(r, s)
+			if err != nil {
+				continue
+			}
+			same(t, g, ref, gk, rk, sig, digest[:])
+		}
+	}
+}
+
+func TestDERNegativesOfImplTest(t *testing.T) {
+	g, ref := providers(t)
+	priv, _ := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
+	gk, rk := importBoth(t, g, ref, &priv.PublicKey)
+	digest := sha256.Sum256([]byte("der"))
+	for _, sig := range [][]byte{
+		nil, {}, {0x30}, {0x30, 0x00}, {0x30, 0x03, 0x02, 0x01}, {0x30, 0x06, 0x02, 0x01, 0x01, 0x02, 0x01, 0x01, 0x00}, // trailing byte is ignored by asn1.Unmarshal
+		{0x30, 0x07, 0x02, 0x02, 0x00, 0x01, 0x02, 0x01, 0x01},                                                           // non-minimal integer
+		{0x30, 0x81, 0x06, 0x02, 0x01, 0x01, 0x02, 0x01, 0x01},                                                           // long-form length where short would do
+	} {
+		same(t, g, ref, gk, rk, sig, digest[:])
+	}
+	same(t, g, ref, nil, nil, []byte{0x30, 0x00}, digest[:]) // nil key
+	same(t, g, ref, gk, rk, []byte{0x30, 0x06, 0x02, 0x01, 0x01, 0x02, 0x01, 0x01}, nil)
+}
+
+func TestPreVerifyBlockSeedsTheMemo(t *testing.T) {
+	g, ref := providers(t)
+	csp := g.(*impl)
+	var tuples []Tuple
+	var keys []bccsp.Key
+	for i := 0; i < 300; i++ {
+		priv, _ := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
+		gk, _ := importBoth(t, g, ref, &priv.PublicKey)
+		msg := make([]byte, 1856)
+		rand.Read(msg)
+		digest := sha256.Sum256(msg)
+		r, s, _ := ecdsa.Sign(rand.Reader, priv, digest[:])
+		s, _ = utils.ToLowS(&priv.PublicKey, s)
+		if i%10 == 3 {
+			r.Add(r, big.NewInt(1))
+		}
+		sig, _ := utils.MarshalECDSASignature(r, s)
+		tuples = append(tuples, Tuple{Key: gk, Msg: msg, Sig: sig})
+		keys = append(keys, gk)
+	}
+	require.NoError(t, csp.PreVerifyBlock(tuples))
+	for i, tu := range tuples {
+		digest := sha256.Sum256(tu.Msg)
+		ok, err := g.Verify(keys[i], tu.Sig, digest[:], nil) // memo hit
+		require.NoError(t, err)
+		require.Equal(t, i%10 != 3, ok)
+	}
+}
