@@ -1,3 +1,5 @@
+"""Writes /tmp/blk10k.bin: a 10 000-transaction endorser block (reference-consistent TxIDs and proposal hashes, fake signatures) for
+tools/parse_bench.cpp."""
 import sys, os, json, time, hashlib, ctypes
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ('fabric-mod_amd','oracle','tests'): sys.path.insert(0, os.path.join(ROOT,p))

@@ -1,3 +1,7 @@
+// Host-only micro-benchmark of the block walker (fabric-mod_amd/csrc/block_prepass.cpp::ParseBlock) on /tmp/blk10k.bin, the
+// 10 000-transaction block tools/mk_parse_block.py writes (fake signatures: the walker does not look at them).
+//   python tools/mk_parse_block.py && g++ -O3 -std=c++17 -Ifabric-mod_amd/csrc tools/parse_bench.cpp fabric-mod_amd/csrc/block_prepass.cpp -o /tmp/pb -lpthread && /tmp/pb
+// Used to find that the walk's serial part (locating the envelopes) dominates: DESIGN.md section 4.4.
 #include <chrono>
 #include <cstdio>
 #include <vector>
