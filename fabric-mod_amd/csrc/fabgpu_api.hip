@@ -348,7 +348,7 @@ int fabgpu_idemix_issuer_register(fabgpu_ctx* ctx, const uint8_t* hsk_x32, const
         u256 x, y;
         from_be32(x, bx[b]);
         from_be32(y, by[b]);
-        build_bn_comb_table8(tab.data(), x, y);
+        build_bn_comb_table<8>(tab.data(), x, y);
         if (hipMalloc((void**)&d[b], tb) != hipSuccess || hipMemcpy(d[b], tab.data(), tb, hipMemcpyHostToDevice) != hipSuccess) {
             if (d[0]) hipFree(d[0]);
             if (d[1]) hipFree(d[1]);

@@ -298,4 +298,27 @@ int hosttest_bn_nym_commitment_split(void* p, const uint8_t* nx32, const uint8_t
     if (se == NYM_VALID && (!eq256(txe, txo) || !eq256(tye, tyo))) return -2;   // ... and, when it is meaningful, on t
     return (int)se;
 }
+// a 16-bit comb table of one base (what the device uses), built on the CPU: entry (window, digit) in plain affine coordinates.
+// The table (80 MiB) is built once per (x, y) and cached for the following calls.
+void hosttest_bn_tab16_entry(const uint8_t* bx32, const uint8_t* by32, int window, int digit, uint8_t* x32, uint8_t* y32) {
+    static std::vector<int32_t> tab;
+    static u256 cx = zero256(), cy = zero256();
+    u256 bx, by;
+    from_be32(bx, bx32);
+    from_be32(by, by32);
+    if (tab.empty() || !eq256(bx, cx) || !eq256(by, cy)) {
+        tab.assign(GTab16::TABLE_WORDS, 0);
+        build_bn_comb_table<16>(tab.data(), bx, by, 8);
+        cx = bx;
+        cy = by;
+    }
+    GTab16 kt{tab.data()};
+    fbn x, y;
+    u256 px, py;
+    kt.load(window, (uint32_t)digit, x, y);
+    fe_from_mont(px, x);
+    fe_from_mont(py, y);
+    to_be32(x32, px);
+    to_be32(y32, py);
+}
 }

@@ -164,6 +164,19 @@ def test_bn_comb_tables_and_commitment(hosttest, fx):
         hosttest.hosttest_bn_issuer_free(h)
 
 
+def test_the_16_bit_comb_table_of_the_device(hosttest, fx):
+    """The device's issuer tables are 16-bit combs (16 windows x 65 535 entries, 80 MiB per base), built by the same template as
+    the 8-bit ones above: entries d * 2^(16 w) * B at the corners and at random places."""
+    ipk = fx["MSP2OU1"]["ipk"]
+    hosttest.hosttest_bn_tab16_entry.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
+    ox, oy = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    rng = random.Random(19)
+    places = [(0, 1), (0, 2), (0, 65535), (1, 1), (15, 65535), (15, 1), (7, 32768), (8, 257)] + [(rng.randrange(16), rng.randrange(1, 65536)) for _ in range(12)]
+    for w, d in places:
+        hosttest.hosttest_bn_tab16_entry(be32(ipk.h_rand[0]), be32(ipk.h_rand[1]), w, d, ox, oy)
+        assert (int.from_bytes(ox.raw, "big"), int.from_bytes(oy.raw, "big")) == io.g1_mul(ipk.h_rand, d << (16 * w)), (w, d)
+
+
 def test_glv_decomposition_and_double_scalar_loop(hosttest, fx):
     """c * Nym on the device goes through k = k1 + k2 lambda; the decomposition must be exact mod r and short, and the
     interleaved loop must report (not hide) a collision between accumulator and addend."""
