@@ -1,0 +1,52 @@
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#include <string>
+#include "block_prepass.h"
+#include "bccsp_host.h"
+using namespace fab::bccsp;
+int main() {
+    FILE* f = fopen("/tmp/cert.pem", "rb");
+    std::vector<uint8_t> pem(1 << 16);
+    size_t n = fread(pem.data(), 1, pem.size(), f);
+    pem.resize(n);
+    std::vector<uint8_t> der;
+    if (!PemToDer(pem.data(), pem.size(), der)) { printf("base pem does not decode\n"); return 1; }
+    std::mt19937_64 rng(11);
+    size_t ok = 0, sigok = 0;
+    for (int it = 0; it < 200000; it++) {
+        std::vector<uint8_t> d = der;
+        int k = 1 + rng() % 6;
+        for (int j = 0; j < k; j++) {
+            size_t pos = rng() % d.size();
+            switch (rng() % 4) {
+                case 0: d[pos] ^= (uint8_t)(1u << (rng() % 8)); break;
+                case 1: d[pos] = (uint8_t)rng(); break;
+                case 2: d[pos] = 0x84; break;                          // long-form lengths
+                default: if (d.size() > 8) d.resize(d.size() - rng() % 8); break;
+            }
+        }
+        uint8_t* heap = (uint8_t*)malloc(d.size());
+        memcpy(heap, d.data(), d.size());
+        uint8_t qx[32], qy[32];
+        ok += CertDerToP256(heap, d.size(), qx, qy);
+        // the ECDSA signature gate on arbitrary bytes (the tail of the certificate holds a real DER signature)
+        BigInt R, S;
+        size_t off = d.size() > 80 ? d.size() - 72 - rng() % 8 : 0;
+        sigok += UnmarshalECDSASignature(heap + off, d.size() - off, R, S).ok();
+        free(heap);
+        // PEM layer: mutate the text
+        if (it % 8 == 0) {
+            std::vector<uint8_t> p = pem;
+            for (int j = 0; j < 3; j++) p[rng() % p.size()] = (uint8_t)rng();
+            uint8_t* hp = (uint8_t*)malloc(p.size());
+            memcpy(hp, p.data(), p.size());
+            std::vector<uint8_t> out;
+            PemToDer(hp, p.size(), out);
+            free(hp);
+        }
+    }
+    printf("fuzz ok: %zu mutants still gave a P-256 key, %zu signature slices unmarshalled\n", ok, sigok);
+}

@@ -1,0 +1,19 @@
+// Link-time stand-ins for the device entry points: the fuzzers exercise host-side parsers only (no GPU, no libfabgpu.so).
+#include "../../include/fabgpu.h"
+extern "C" {
+int fabgpu_idemix_issuer_register(fabgpu_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*) { return -1; }
+int fabgpu_idemix_nym_verify_batch(fabgpu_ctx*, size_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint8_t*, const uint8_t*, const uint8_t*,
+                                   const uint8_t*, const uint8_t*, const uint8_t*, uint64_t*, uint8_t*) { return -1; }
+const char* fabgpu_strerror(int) { return "stub"; }
+int fabgpu_init(const fabgpu_cfg*, fabgpu_ctx**) { return -1; }
+void fabgpu_shutdown(fabgpu_ctx*) {}
+int fabgpu_p256_verify_batch(fabgpu_ctx*, size_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, uint64_t*, uint8_t*) { return -1; }
+int fabgpu_p256_verify_batch_keyed(fabgpu_ctx*, size_t, const uint32_t*, const uint8_t*, const uint8_t*, const uint8_t*, uint64_t*, uint8_t*) { return -1; }
+int fabgpu_sha256_batch(fabgpu_ctx*, size_t, const uint8_t*, const uint32_t*, uint8_t*) { return -1; }
+int fabgpu_sha256_p256_verify_batch(fabgpu_ctx*, size_t, const uint8_t*, const uint32_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, uint64_t*, uint8_t*) { return -1; }
+int fabgpu_sha256_p256_verify_batch_keyed(fabgpu_ctx*, size_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint8_t*, const uint8_t*, uint64_t*, uint8_t*) { return -1; }
+int fabgpu_p256_key_register(fabgpu_ctx*, const uint8_t*, const uint8_t*, uint32_t*) { return -1; }
+int fabgpu_p256_key_lookup(fabgpu_ctx*, const uint8_t*, const uint8_t*, uint32_t*) { return 1; }
+int fabgpu_identity_verify_batch(fabgpu_ctx*, const fabgpu_identity_batch*) { return -1; }
+int fabgpu_arena_stage(fabgpu_ctx*, const void*, size_t, uint64_t*) { return -1; }
+}
