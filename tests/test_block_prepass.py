@@ -303,3 +303,39 @@ def test_threaded_walk_on_a_multi_megabyte_block():
         if not ((blk[e0:e1] == digest.hex().encode()) if kind == 0 else (blk[e0:e1] == digest)):
             bad.add((tx, kind))
     assert bad == {(t, 0) for t in range(700) if t % 97 == 5} | {(t, 1) for t in range(700) if t % 89 == 7}
+
+
+def test_walkers_survive_mutated_input():
+    """The host-side parsers read untrusted network bytes: a few thousand mutants of a valid block and of a valid certificate must
+    neither crash the process nor report a span outside the buffer.  (The thorough version runs under ASan/UBSan: tools/fuzz/run.sh.)"""
+    rng = np.random.default_rng(41)
+    blk, _ = build_block(12, rng, corrupt=False)
+    base = np.frombuffer(blk, dtype=np.uint8)
+    for it in range(1500):
+        m = base.copy()
+        for _ in range(int(rng.integers(1, 8))):
+            pos = int(rng.integers(0, m.size))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                m[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            elif kind == 1:
+                m[pos] = np.uint8(rng.integers(0, 256))
+            elif kind == 2:
+                m[pos] = 0xFF
+            else:
+                m = m[: m.size - int(rng.integers(0, 16))].copy()
+        raw = m.tobytes()
+        try:
+            p = fabgpu.block_parse(raw)
+        except fabgpu.FabgpuError:
+            continue                                       # outer framing broken: refused, fine
+        assert p["n_tuples"] <= 4 * p["n_tx"] + 4
+        for tx, kind, pieces, (e0, e1) in fabgpu.block_hash_checks(raw):
+            assert all(0 <= a <= b <= len(raw) for a, b in pieces) and 0 <= e0 <= e1 <= len(raw)
+    pem = IDS[0]["pem"].encode()
+    for it in range(1500):
+        b = bytearray(pem)
+        for _ in range(3):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        got = fabgpu.x509_p256_pubkey(bytes(b))
+        assert got is None or (len(got[0]) == 32 and len(got[1]) == 32)
