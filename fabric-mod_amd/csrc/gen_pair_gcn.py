@@ -61,11 +61,11 @@ def build_pair_dbl():
     return p
 
 
-def build_pair_add():
+def build_pair_add(name="PAIR29_ADD", field=None):
     """(A, B) <- (A, B) + P2 with P2 handed over CROSSED:  E: C = Z2,  O: C = X2, D = Y2.
     in: L(X1) <= 2, L(Y1) <= 3, L(Z1) = 1, L(X2) = 1, L(Y2) <= 3, L(Z2) = 1;  out: L(X) = 1, L(Y) = 2, L(Z) = 1.
     H (both lanes: h = u2 - u1) and RR (E: s2 - s1) are left for the caller's P == +-Q test."""
-    p = Program("PAIR29_ADD")
+    p = Program(name, field)
     A = p.fe("A", "io")
     B = p.fe("B", "io")
     H = p.fe("H", "tmp")
@@ -121,10 +121,10 @@ def build_pair_add():
     return p
 
 
-def build_pair_madd():
+def build_pair_madd(name="PAIR29_MADD", field=None):
     """(A, B) <- (A, B) + (x2, y2) affine, handed over as  E: C = x2,  O: D = y2.
     in: L(X1) = 1, L(Y1) <= 3, L(Z1) = 1, x2 / y2 normalised;  out: L(X) = 1, L(Y) = 2, L(Z) = 1."""
-    p = Program("PAIR29_MADD")
+    p = Program(name, field)
     A = p.fe("A", "io")
     B = p.fe("B", "io")
     U1 = p.fe("U1", "tmp")
@@ -220,6 +220,51 @@ def build_bn_sqr():
 
 FIELD_PROGRAMS = [build_fe_mul, build_fe_sqr]
 BN_FIELD_PROGRAMS = [build_bn_mul, build_bn_sqr]
+
+def build_bn_pair_dbl():
+    """(A, B) <- 2 * (A, B) on a curve with a = 0 (FP256BN's G1), two lanes per point, formulas of bn_nym29.h::pt_dbl29:
+        A2 = X^2, Bq = Y^2, c4 = (2 Bq)^2, D = 4 X Bq, E = 3 A2, F = E^2, X3 = F - 2 D, Y3 = E (D - X3) - 2 c4, Z3 = 2 Y Z.
+    Seven field operations in four paired steps (the last one has an idle odd slot).
+    in: L(X) = 1, L(Y) <= 3, L(Z) <= 2;  out: L(X) = 1, L(Y) = 3, L(Z) = 2.   E holds A = X, B = Y; O holds B = Z."""
+    p = Program("PAIRBN_DBL", bn_field())
+    A = p.fe("A", "io")
+    B = p.fe("B", "io")
+    U1 = p.fe("U1", "tmp")
+    U2 = p.fe("U2", "tmp")
+    U3 = p.fe("U3", "tmp")
+    U4 = p.fe("U4", "tmp")
+    P1 = p.fe("P1", "tmp")
+    P2 = p.fe("P2", "tmp")
+    T0 = p.fe("T0", "tmp")
+    T1 = p.fe("T1", "tmp")
+    TD = p.fe("TD", "tmp")
+    p.swp(T0, A)                     #                           O: X
+    p.sel(P1, T0, B)                 # E: Y                      O: X
+    p.sqr(U1, P1, TD)                # E: Bq = Y^2   [3x3]       O: A2 = X^2   [1x1]
+    p.shl(T0, A, 2)                  # E: 4X    (L4)
+    p.swp(T1, B)                     #                           O: Y
+    p.sel(P1, T1, T0)                # E: 4X                     O: Y
+    p.sel(P2, B, U1)                 # E: Bq                     O: Z
+    p.mul(U2, P1, P2)                # E: D = 4 X Bq [4x1]       O: yz = Y Z   [3x2]
+    p.shl(T0, U1, 1)                 # E: 2 Bq  (L2)
+    p.shladd(T1, U1, 1, U1)          #                           O: E3 = 3 A2  (L3)
+    p.sel(P1, T1, T0)                # E: 2 Bq                   O: E3
+    p.sqr(U3, P1, TD)                # E: c4 = 4 Bq^2 [2x2]      O: F = E3^2   [3x3]
+    p.shl(T0, U2, 1)                 # E: 2D    (L2)
+    p.swp_sub(T1, U3, T0)            # E: F - 2D    (L3)
+    p.wnorm(A, T1, TD)               # E: X3
+    p.sub(T0, U2, A)                 # E: D - X3    (L2)
+    p.swp(T1, P1)                    # E: E3 (O's P1)
+    p.mul(U4, T1, T0)                # E: yy = E3 (D - X3) [3x2] O: (idle slot: product of leftovers)
+    p.shl(T0, U3, 1)                 # E: 2 c4  (L2)
+    p.sub(T0, U4, T0)                # E: Y3 = yy - 2 c4  (L3)
+    p.shl(T1, U2, 1)                 #                           O: Z3 = 2 yz  (L2)
+    p.sel(B, T1, T0)
+    return p
+
+
+BN_PAIR_PROGRAMS = [build_bn_pair_dbl, lambda: build_pair_add("PAIRBN_ADD", bn_field()), lambda: build_pair_madd("PAIRBN_MADD", bn_field())]
+
 PROGRAMS = [build_pair_dbl, build_pair_add, build_pair_madd]
 
 ALIGN_NOTE = """// Every instruction below is 8 bytes (VOP3, VOP2 + DPP, or VOP2 + 32-bit literal): a block started on an 8-byte boundary stays
@@ -231,8 +276,15 @@ ALIGN_NOTE = """// Every instruction below is 8 bytes (VOP3, VOP2 + DPP, or VOP2
 
 
 def emit(path_kind):
-    progs = {"field": FIELD_PROGRAMS, "bnfield": BN_FIELD_PROGRAMS}.get(path_kind, PROGRAMS)
-    if path_kind == "bnfield":
+    progs = {"field": FIELD_PROGRAMS, "bnfield": BN_FIELD_PROGRAMS, "bnpair": BN_PAIR_PROGRAMS}.get(path_kind, PROGRAMS)
+    if path_kind == "bnpair":
+        print("// GENERATED by gen_pair_gcn.py bnpair - do not edit.  Two-lanes-per-point operations on FP256BN's G1 (a = 0): PREPARED for a")
+        print("// four-lanes-per-signature idemix kernel (DESIGN.md section 8, next steps); verified in the DSL interpreter against big integers")
+        print("// (tests/test_pair_programs.py), NOT yet included by any kernel.")
+        print("#pragma once")
+        print('#include "fe29_gcn.h"   // FE29_GCN_ALIGN')
+        print()
+    elif path_kind == "bnfield":
         print("// GENERATED by gen_pair_gcn.py bnfield - do not edit.  gfx950 instruction streams of the FP256BN field product (bn29.h).")
         print("#pragma once")
         print('#include "fe29_gcn.h"   // FE29_GCN_ALIGN')
@@ -255,7 +307,7 @@ def emit(path_kind):
 
 def main():
     import sys
-    emit(sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("field", "bnfield") else "pair")
+    emit(sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("field", "bnfield", "bnpair") else "pair")
 
 
 if __name__ == "__main__":

@@ -174,6 +174,72 @@ def test_pair_scalar_multiplication_chain(progs):
                 assert st.point() == acc
 
 
+def test_bn_pair_programs_scalar_multiplication_chain():
+    """PAIRBN_DBL / PAIRBN_ADD / PAIRBN_MADD (pair29_bn_gcn.h: prepared for a four-lanes-per-signature idemix kernel, not yet wired
+    into one): left-to-right double-and-add on FP256BN's G1 in the interpreter, against big-integer point arithmetic after
+    every step, on a fixture base point of the reference."""
+    import gen_bn_consts as bc
+    import idemix_oracle as io
+    from idemix_common import fixtures
+    BP = bc.P
+    BRI = pow(R, -1, BP)
+    progs = {"dbl": gp.build_bn_pair_dbl(), "add": gp.build_pair_add("PAIRBN_ADD", gp.bn_field()), "madd": gp.build_pair_madd("PAIRBN_MADD", gp.bn_field())}
+    sizes = {k: pr.emit_asm({n: "(%s)" % n for n in pr.order})[1]["instructions"] for k, pr in progs.items()}
+    assert sizes["dbl"] < 1000 and sizes["add"] < 1950 and sizes["madd"] < 1550        # one lane: ~1500 / ~3500 / ~2400
+
+    def tb(x):
+        return bal(x * R % BP)
+
+    def bv(regs, name):
+        return sum(regs["%s.%d" % (name, i)] << (29 * i) for i in range(9)) * BRI % BP
+
+    def jac(pt, rng):
+        z = rng.randrange(1, BP)
+        return (pt[0] * z * z % BP, pt[1] * z * z * z % BP, z)
+
+    class BnPair:
+        def __init__(self, X, Y, Z, rng):
+            self.e, self.o = {}, {}
+            put(self.e, "A", tb(X)); put(self.e, "B", tb(Y))
+            put(self.o, "A", [rng.randrange(-(1 << 28), 1 << 28) for _ in range(9)]); put(self.o, "B", tb(Z))
+
+        def point(self):
+            zi = pow(bv(self.o, "B"), -1, BP)
+            return (bv(self.e, "A") * zi * zi % BP, bv(self.e, "B") * zi * zi * zi % BP)
+
+        def run(self, prog, ee=None, eo=None):
+            e = {k: v for k, v in self.e.items() if k[0] in "AB"}
+            o = {k: v for k, v in self.o.items() if k[0] in "AB"}
+            e.update(ee or {}); o.update(eo or {})
+            self.e, self.o = prog.run(e, o)
+            for regs in (self.e, self.o):
+                assert all(-(1 << 31) <= v < (1 << 31) for v in regs.values())
+    rng = random.Random(83)
+    base = fixtures()["MSP1OU1"]["ipk"].h_sk
+    for trial in range(2):
+        k = rng.randrange(1 << 39, 1 << 40)
+        st = BnPair(*jac(base, rng), rng)
+        acc = base
+        for bit in bin(k)[3:]:
+            st.run(progs["dbl"])
+            acc = io.g1_add(acc, acc)
+            assert st.point() == acc
+            if bit == "1":
+                if rng.random() < 0.5:
+                    X2, Y2, Z2 = jac(base, rng)
+                    ce, co = {}, {}
+                    put(ce, "C", tb(Z2)); put(ce, "D", [0] * 9)
+                    put(co, "C", tb(X2)); put(co, "D", tb(Y2))
+                    st.run(progs["add"], ce, co)
+                else:
+                    ce, co = {}, {}
+                    put(ce, "C", tb(base[0])); put(ce, "D", [0] * 9)
+                    put(co, "C", [0] * 9); put(co, "D", tb(base[1]))
+                    st.run(progs["madd"], ce, co)
+                acc = io.g1_add(acc, base)
+                assert st.point() == acc
+
+
 def test_pair_add_reports_the_exceptional_cases(progs):
     rng = random.Random(78)
     G = (po.GX, po.GY)
