@@ -301,3 +301,62 @@ def test_generated_streams_on_gpu_match_the_interpreter_register_for_register(pr
                     if got != exp:
                         bad.add((nm, "odd" if lane & 1 else "even", tuple(i for i in range(9) if got[i] != exp[i])))
         assert not bad, (name, sorted(bad))
+
+
+@pytest.mark.gpu
+def test_bn_pair_streams_on_gpu_match_the_interpreter_register_for_register():
+    """PAIRBN_DBL / ADD / MADD (prepared, not yet used by a kernel): one wavefront runs each generated asm statement, every output
+    limb of every lane must equal the interpreter's."""
+    import ctypes
+
+    import numpy as np
+    import gen_bn_consts as bc
+    import idemix_oracle as io
+    from idemix_common import fixtures
+    BP = bc.P
+    lib = ctypes.CDLL(os.path.join(ROOT, "fabric-mod_amd", "lib", "libfabgpu_gputest.so"))
+    progs = {"dbl": gp.build_bn_pair_dbl(), "add": gp.build_pair_add("PAIRBN_ADD", gp.bn_field()), "madd": gp.build_pair_madd("PAIRBN_MADD", gp.bn_field())}
+    rng = random.Random(91)
+    base = fixtures()["MSP2OU1"]["ipk"].h_rand
+
+    def tb(x):
+        return bal(x * R % BP)
+
+    def jac(pt):
+        z = rng.randrange(1, BP)
+        return (pt[0] * z * z % BP, pt[1] * z * z * z % BP, z)
+    for op, name in ((4, "dbl"), (5, "add"), (6, "madd")):
+        inp = np.zeros((64, 36), dtype=np.int32)
+        want = {}
+        for k in range(32):
+            p1 = io.g1_mul(base, rng.randrange(1, io.R))
+            p2 = io.g1_mul(base, rng.randrange(1, io.R))
+            X1, Y1, Z1 = jac(p1)
+            X2, Y2, Z2 = jac(p2)
+            junk = lambda: [rng.randrange(-(1 << 28), 1 << 28) for _ in range(9)]
+            e = {"A": tb(X1), "B": tb(Y1)}
+            o = {"A": junk(), "B": tb(Z1)}
+            if name == "add":
+                e.update(C=tb(Z2), D=junk()); o.update(C=tb(X2), D=tb(Y2))
+            elif name == "madd":
+                e.update(C=tb(p2[0]), D=junk()); o.update(C=junk(), D=tb(p2[1]))
+            else:
+                e.update(C=junk(), D=junk()); o.update(C=junk(), D=junk())
+            for lane, regs in ((2 * k, e), (2 * k + 1, o)):
+                inp[lane] = regs["A"] + regs["B"] + regs["C"] + regs["D"]
+            re, ro = {}, {}
+            for nm in "ABCD":
+                put(re, nm, e[nm]); put(ro, nm, o[nm])
+            want[k] = progs[name].run(re, ro)
+        out = np.zeros((64, 36), dtype=np.int32)
+        assert lib.gputest_pair_op(op, inp.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        names = ["A", "B"] + (["H", "RR"] if name == "add" else [])
+        bad = set()
+        for k in range(32):
+            for lane, regs in ((2 * k, want[k][0]), (2 * k + 1, want[k][1])):
+                for j, nm in enumerate(names):
+                    got = [int(v) for v in out[lane, 9 * j:9 * j + 9]]
+                    exp = [regs["%s.%d" % (nm, i)] for i in range(9)]
+                    if got != exp:
+                        bad.add((nm, "odd" if lane & 1 else "even", tuple(i for i in range(9) if got[i] != exp[i])))
+        assert not bad, (name, sorted(bad))
