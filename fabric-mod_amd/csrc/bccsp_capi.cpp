@@ -155,6 +155,84 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
     return FABGPU_OK;
 }
 
+int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
+    if (!csp || !ps || !ps->block) return FABGPU_EINVAL;
+    if (ps->flags & ~(uint32_t)(FABGPU_PASS_SEED_MEMO | FABGPU_PASS_NO_BLOCK_SIGS)) return FABGPU_EINVAL;
+    GPUCSP::BlockUpload up;
+    csp->csp->StartBlockUpload(up, ps->block, ps->len);
+    static thread_local ParsedBlock pb;
+    if (!ParseBlock(ps->block, ps->len, pb, 16)) return FABGPU_EINVAL;
+    ps->n_tx = pb.n_tx;
+    ps->n_tuples = (uint32_t)pb.tuples.size();
+    ps->n_block_sigs = pb.n_block_sigs;
+    ps->tail_base = pb.tail_base;
+    ps->tail_len = (uint32_t)pb.tail.size();
+    ps->block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
+    ps->memo_seeded = 0;
+    if (pb.n_tx > ps->cap_tx || pb.tuples.size() > ps->cap_tuples || (ps->tail && pb.tail.size() > ps->tail_cap)) return FABGPU_ETOOBIG;
+    PassOptions opt;
+    opt.seed_memo = (ps->flags & FABGPU_PASS_SEED_MEMO) != 0;
+    opt.want_digests = ps->tuple_digest != nullptr;
+    opt.block_sigs = !(ps->flags & FABGPU_PASS_NO_BLOCK_SIGS);
+    opt.block_seq = ps->block_seq;
+    BlockVerdicts v;
+    Error e = csp->csp->PreVerifyParsed(ps->block, pb, v, &up, opt);
+    if (!e.ok()) return FABGPU_ELAUNCH;
+    const size_t nt = v.tuple_tx.size();
+    if (ps->tx_flags && v.n_tx) memcpy(ps->tx_flags, v.tx_flags.data(), v.n_tx);
+    if (ps->tx_type && v.n_tx) memcpy(ps->tx_type, v.tx_type.data(), v.n_tx);
+    if (ps->tuple_tx && nt) memcpy(ps->tuple_tx, v.tuple_tx.data(), nt * 4);
+    if (ps->tuple_kind && nt) memcpy(ps->tuple_kind, v.tuple_kind.data(), nt);
+    if (ps->tuple_status && nt) memcpy(ps->tuple_status, v.tuple_status.data(), nt);
+    if (ps->tuple_hashed && nt) memcpy(ps->tuple_hashed, v.tuple_hashed.data(), nt);
+    if (ps->tuple_qxy && nt) memcpy(ps->tuple_qxy, v.tuple_qxy.data(), nt * 64);
+    if (ps->tuple_digest && nt) memcpy(ps->tuple_digest, v.tuple_digest.data(), nt * 32);
+    if (ps->tuple_spans)
+        for (size_t i = 0; i < nt; i++) {
+            const BlockTuple& t = pb.tuples[i];
+            const Span* sp[4] = {&t.identity, &t.prefix, &t.suffix, &t.sig};
+            for (int k = 0; k < 4; k++) {
+                ps->tuple_spans[8 * i + 2 * k] = sp[k]->off;
+                ps->tuple_spans[8 * i + 2 * k + 1] = sp[k]->len;
+            }
+        }
+    if (ps->tail && !pb.tail.empty()) memcpy(ps->tail, pb.tail.data(), pb.tail.size());
+    ps->memo_seeded = v.memo_seeded;
+    return FABGPU_OK;
+}
+
+int fabgpu_csp_memo_lookup(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest,
+                           size_t dlen, uint8_t* status) {
+    if (!csp) return 1;
+    return csp->csp->MemoLookup(qx32, qy32, sig, siglen, digest, dlen, status);
+}
+int fabgpu_csp_memo_evict_block(fabgpu_csp* csp, uint64_t block_seq, uint64_t* evicted) {
+    if (!csp) return FABGPU_EINVAL;
+    size_t g = csp->csp->MemoEvictBlock(block_seq);
+    if (evicted) *evicted = g;
+    return FABGPU_OK;
+}
+int fabgpu_csp_memo_stats(fabgpu_csp* csp, uint64_t* entries, uint64_t* hits, uint64_t* misses, uint64_t* evicted) {
+    if (!csp) return FABGPU_EINVAL;
+    csp->csp->MemoStats(entries, hits, misses, evicted);
+    return FABGPU_OK;
+}
+int fabgpu_csp_memo_set_capacity(fabgpu_csp* csp, uint64_t max_entries) {
+    if (!csp) return FABGPU_EINVAL;
+    csp->csp->MemoSetCapacity((size_t)max_entries);
+    return FABGPU_OK;
+}
+int fabgpu_csp_identity_cache_limits(fabgpu_csp* csp, uint64_t max_identities, uint64_t max_registered_keys, uint32_t register_after_hits) {
+    if (!csp) return FABGPU_EINVAL;
+    csp->csp->SetIdentityCacheLimits((size_t)max_identities, (size_t)max_registered_keys, register_after_hits);
+    return FABGPU_OK;
+}
+int fabgpu_csp_identity_cache_size(fabgpu_csp* csp, uint64_t* identities) {
+    if (!csp || !identities) return FABGPU_EINVAL;
+    *identities = csp->csp->IdentityCacheSize();
+    return FABGPU_OK;
+}
+
 // pure host: structure of a marshalled block as the pre-verify pass sees it
 int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
                        char* channel_id, size_t channel_cap) {
@@ -204,6 +282,34 @@ int fabgpu_block_hash_checks(const uint8_t* block, size_t len, uint32_t cap, uin
             expect2[2 * j + 1] = hc.expect.off + hc.expect.len;
         }
     }
+    return FABGPU_OK;
+}
+
+// pure host: every (identity, message, signature) tuple the pass derives from a marshalled block, as spans (start, length) x 4 =
+// identity, prefix, suffix, sig into the VIRTUAL arena  block || zero padding up to *tail_base || tail  (block_prepass.h: the
+// orderer block-signature messages live in the tail).  message = prefix || suffix.
+int fabgpu_block_tuples(const uint8_t* block, size_t len, uint32_t cap, uint32_t* n_tuples, uint32_t* tx, uint8_t* kind, uint32_t* spans8,
+                        uint8_t* tail, uint32_t tail_cap, uint32_t* tail_len, uint32_t* tail_base) {
+    if (!block || !n_tuples) return FABGPU_EINVAL;
+    ParsedBlock pb;
+    if (!ParseBlock(block, len, pb)) return FABGPU_EINVAL;
+    *n_tuples = (uint32_t)pb.tuples.size();
+    if (tail_len) *tail_len = (uint32_t)pb.tail.size();
+    if (tail_base) *tail_base = pb.tail_base;
+    if (pb.tuples.size() > cap || (tail && pb.tail.size() > tail_cap)) return FABGPU_ETOOBIG;
+    for (size_t i = 0; i < pb.tuples.size(); i++) {
+        const BlockTuple& t = pb.tuples[i];
+        if (tx) tx[i] = t.tx;
+        if (kind) kind[i] = t.kind;
+        if (spans8) {
+            const Span* sp[4] = {&t.identity, &t.prefix, &t.suffix, &t.sig};
+            for (int k = 0; k < 4; k++) {
+                spans8[8 * i + 2 * k] = sp[k]->off;
+                spans8[8 * i + 2 * k + 1] = sp[k]->len;
+            }
+        }
+    }
+    if (tail && !pb.tail.empty()) memcpy(tail, pb.tail.data(), pb.tail.size());
     return FABGPU_OK;
 }
 

@@ -424,12 +424,78 @@ void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len)
     up.th = std::thread([c, u, block, len] { u->rc = fabgpu_arena_stage(c, block, len, &u->token); });
 }
 
-Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const {
+Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out, const PassOptions& opt) const {
     BlockUpload up;
     StartBlockUpload(up, block, len);                     // the block travels while it is walked and its signatures are gated
     static thread_local ParsedBlock pb;                   // storage reused from block to block
     if (!block || !ParseBlock(block, len, pb, 16)) return Error("block does not parse as common.Block");
-    return PreVerifyParsed(block, pb, out, &up);
+    return PreVerifyParsed(block, pb, out, &up, opt);
+}
+
+// ---- verdict memo -------------------------------------------------------------------------------------------------------
+std::string GPUCSP::MemoKey(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) {
+    std::string k;
+    k.reserve(64 + 8 + siglen + dlen);
+    k.append((const char*)qx32, 32);
+    k.append((const char*)qy32, 32);
+    const uint32_t sl = (uint32_t)siglen, dl = (uint32_t)dlen;      // length framing: (sig || d[:k], d[k:]) must not collide with (sig, d)
+    k.append((const char*)&sl, 4);
+    k.append((const char*)sig, siglen);
+    k.append((const char*)&dl, 4);
+    k.append((const char*)digest, dlen);
+    return k;
+}
+int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen, uint8_t* status) const {
+    if (!qx32 || !qy32 || !sig || !digest || siglen > 0xFFFF || dlen > 0xFFFF) return 1;
+    const std::string k = MemoKey(qx32, qy32, sig, siglen, digest, dlen);
+    std::lock_guard<std::mutex> lk(memo_mu_);
+    auto it = memo_.find(k);
+    if (it == memo_.end()) {
+        memo_misses_++;
+        return 1;
+    }
+    memo_hits_++;
+    if (status) *status = it->second.status;
+    return 0;
+}
+size_t GPUCSP::MemoEvictBlock(uint64_t block_seq) const {
+    std::lock_guard<std::mutex> lk(memo_mu_);
+    size_t gone = 0;
+    for (auto b = memo_blocks_.begin(); b != memo_blocks_.end();) {
+        if (b->first != block_seq) { ++b; continue; }
+        for (const std::string& k : b->second) {
+            auto it = memo_.find(k);
+            if (it != memo_.end() && it->second.block_seq == block_seq) { memo_.erase(it); gone++; }
+        }
+        b = memo_blocks_.erase(b);
+    }
+    memo_evicted_ += gone;
+    return gone;
+}
+void GPUCSP::MemoStats(uint64_t* entries, uint64_t* hits, uint64_t* misses, uint64_t* evicted) const {
+    std::lock_guard<std::mutex> lk(memo_mu_);
+    if (entries) *entries = memo_.size();
+    if (hits) *hits = memo_hits_;
+    if (misses) *misses = memo_misses_;
+    if (evicted) *evicted = memo_evicted_;
+}
+void GPUCSP::MemoSetCapacity(size_t max_entries) const {
+    std::lock_guard<std::mutex> lk(memo_mu_);
+    memo_cap_ = max_entries ? max_entries : 1;
+}
+void GPUCSP::SetIdentityCacheLimits(size_t max_identities, size_t max_registered_keys, uint32_t register_after_hits) const {
+    std::lock_guard<std::mutex> lk(idmu_);
+    id_max_ = max_identities ? max_identities : 1;
+    id_max_registered_ = max_registered_keys;
+    id_register_after_ = register_after_hits ? register_after_hits : 1;
+    while (idcache_.size() > id_max_) {
+        idcache_.erase(idlru_.back().first);
+        idlru_.pop_back();
+    }
+}
+size_t GPUCSP::IdentityCacheSize() const {
+    std::lock_guard<std::mutex> lk(idmu_);
+    return idcache_.size();
 }
 
 int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len) const {
@@ -442,8 +508,9 @@ int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_r
     return k.issuer_id;
 }
 
-Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, BlockUpload* up) const {
+Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, BlockUpload* up, const PassOptions& opt) const {
     out = BlockVerdicts();
+    const bool want_digests = opt.want_digests || opt.seed_memo;
     const size_t nt = pb.tuples.size();
     out.n_tx = pb.n_tx;
     out.tx_type = pb.tx_type;
@@ -453,6 +520,11 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     out.tuple_tx.resize(nt);
     out.tuple_kind.resize(nt);
     out.tuple_status.assign(nt, FABGPU_ST_VALID);
+    out.tuple_qxy.assign(nt * 64, 0);
+    out.tuple_hashed.assign(nt, 0);
+    if (want_digests) out.tuple_digest.assign(nt * 32, 0);
+    out.n_block_sigs = pb.n_block_sigs;
+    out.block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
     // identities -> keys (cached across blocks), signatures -> (r, s) through the reference's gates.  Tuples are independent:
     // blocks of 4096+ tuples are gated on worker threads (contiguous ranges), then compacted in order.
     // One pass at a time per provider: the scratch below (8 MB for a 40 000-tuple block) is reused from block to block instead of
@@ -467,6 +539,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     std::vector<Gated>& gt = ps_.gt;
     if (gt.size() < nt) gt.resize(nt);
     std::vector<uint32_t> new_ids(1, 0);
+    std::vector<std::string> to_register;                 // guarded by idmu_
     auto gate_range = [&](size_t lo, size_t hi, uint32_t* fresh) {
         static const uint8_t one_digest[1] = {1};
         // a block names few identities: a per-thread front cache (memcmp against the identities already met) keeps the shared
@@ -475,6 +548,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             const uint8_t* p;
             uint32_t len;
             CachedIdentity ci;
+            uint32_t hits;
         };
         std::vector<Front> front;
         for (size_t i = lo; i < hi; i++) {
@@ -484,35 +558,60 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             g0.nym = false;
             out.tuple_tx[i] = tp.tx;
             out.tuple_kind[i] = tp.kind;
+            if (tp.kind == TUPLE_BLOCK_SIG && !opt.block_sigs) {
+                out.tuple_status[i] = TUPLE_ST_SKIPPED;
+                continue;
+            }
             CachedIdentity ci;
             bool hit = false;
-            for (const Front& f : front)
+            for (Front& f : front)
                 if (f.len == tp.identity.len && memcmp(f.p, block + tp.identity.off, f.len) == 0) {
                     ci = f.ci;
+                    f.hits++;
                     hit = true;
                     break;
                 }
             if (!hit) {
-                bool transient = false;
+                bool transient = false, found = false;
                 std::string key((const char*)block + tp.identity.off, tp.identity.len);
-                std::lock_guard<std::mutex> lk(idmu_);
-                auto it = idcache_.find(key);
-                if (it == idcache_.end()) {
+                {
+                    std::lock_guard<std::mutex> lk(idmu_);
+                    auto it = idcache_.find(key);
+                    if (it != idcache_.end()) {
+                        idlru_.splice(idlru_.begin(), idlru_, it->second);      // most recently used
+                        ci = it->second->second;
+                        found = true;
+                    }
+                }
+                if (!found) {
+                    // decoded outside the lock (PEM + DER walk of ~800 untrusted bytes); NO device table here - that is earned
+                    // by being named id_register_after_ times (flush below)
                     (*fresh)++;
                     ci.p256 = IdentityToP256(block + tp.identity.off, tp.identity.len, ci.qx, ci.qy) && PublicKeyOnCurve(ci.qx, ci.qy);
-                    if (ci.p256) {
-                        uint32_t id = 0;
-                        if (fabgpu_p256_key_register(ctx_, ci.qx, ci.qy, &id) == FABGPU_OK) ci.key_id = id;
-                    }
-                    // idemix identities carry a fresh pseudonym per transaction: caching them would only grow the map
+                    // idemix identities carry a fresh pseudonym per transaction: caching them would only churn the cache
                     std::string ms;
                     uint8_t tnx[32], tny[32];
                     transient = !ci.p256 && IdentityToIdemixNym(block + tp.identity.off, tp.identity.len, ms, tnx, tny);
-                    if (!transient) idcache_[key] = ci;
-                } else {
-                    ci = it->second;
+                    if (!transient) {
+                        std::lock_guard<std::mutex> lk(idmu_);
+                        auto it = idcache_.find(key);
+                        if (it == idcache_.end()) {
+                            idlru_.emplace_front(key, ci);
+                            idcache_[key] = idlru_.begin();
+                            while (idcache_.size() > id_max_) {                  // least recently used goes (its device table, if any, stays
+                                idcache_.erase(idlru_.back().first);             // registered: tables are bounded by id_max_registered_)
+                                idlru_.pop_back();
+                            }
+                        } else {
+                            ci = it->second->second;
+                        }
+                    }
                 }
-                if (!transient && front.size() < 64) front.push_back({block + tp.identity.off, tp.identity.len, ci});
+                if (!transient && front.size() < 64) front.push_back({block + tp.identity.off, tp.identity.len, ci, 1});
+            }
+            if (ci.p256) {
+                memcpy(&out.tuple_qxy[64 * i], ci.qx, 32);
+                memcpy(&out.tuple_qxy[64 * i + 32], ci.qy, 32);
             }
             if (!ci.p256 && tp.kind == TUPLE_CREATOR && !idemix_msps.empty()) {
                 // an idemix creator (never an endorser: docs/source/idemix.rst:171-176)?  identity.Verify is then
@@ -552,6 +651,21 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             memcpy(g0.qx, ci.qx, 32); memcpy(g0.qy, ci.qy, 32); memcpy(g0.r, g.r32, 32); memcpy(g0.s, g.s32, 32);
             g0.key_id = ci.key_id;
             g0.submit = true;
+        }
+        // hit counts -> the shared cache; identities that have earned a device table are queued for registration
+        if (!front.empty()) {
+            std::lock_guard<std::mutex> lk(idmu_);
+            for (const Front& f : front) {
+                auto it = idcache_.find(std::string((const char*)f.p, f.len));
+                if (it == idcache_.end()) continue;
+                CachedIdentity& c = it->second->second;
+                c.hits += f.hits;
+                if (c.p256 && c.key_id < 0 && !c.registering && c.hits >= id_register_after_ && id_registered_ < id_max_registered_) {
+                    c.registering = true;
+                    id_registered_++;
+                    to_register.push_back(it->first);
+                }
+            }
         }
     };
     auto clk0 = std::chrono::steady_clock::now();
@@ -649,6 +763,16 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         d.verdict_bits = bits.data();
         d.status = st.data();
         d.flags = FABGPU_IDB_SPANS;
+        if (!pb.tail.empty()) {                           // the orderers' block-signature messages (block_prepass.h TUPLE_BLOCK_SIG)
+            d.tail = pb.tail.data();
+            d.tail_base = pb.tail_base;
+            d.tail_len = (uint32_t)pb.tail.size();
+        }
+        std::vector<uint8_t>& dig = ps_.dig;
+        if (want_digests) {
+            if (dig.size() < n * 32) dig.resize(n * 32);
+            d.digests = dig.data();
+        }
         // the TxID and proposal-hash digests of the endorser transactions ride along (one upload of the block, one submission)
         const size_t nh = getenv("FABGPU_PASS_SKIP_HASH_CHECKS") ? 0 : pb.hash_checks.size();   // the switch exists for A/B timing only
         std::vector<uint32_t> gsp(nh * 6);
@@ -682,6 +806,8 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         for (size_t j = 0; j < n; j++) {
             bool bit = (bits[j >> 6] >> (j & 63)) & 1;
             out.tuple_status[sub[j]] = (bit && st[j] == FABGPU_ST_VALID) ? FABGPU_ST_VALID : (st[j] == FABGPU_ST_VALID ? FABGPU_ST_BAD_MATH : st[j]);
+            out.tuple_hashed[sub[j]] = 1;
+            if (want_digests) memcpy(&out.tuple_digest[32 * (size_t)sub[j]], &dig[32 * j], 32);
         }
     }
     // idemix creators: their messages (the envelope payloads) are gathered into one arena for the nym kernel
@@ -738,6 +864,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         uint8_t stt = out.tuple_status[i];
         if (stt == FABGPU_ST_VALID) continue;
         uint32_t t = out.tuple_tx[i];
+        if (t >= pb.n_tx) continue;                        // block-level tuples (orderer signatures) do not flag a transaction
         if (stt == TUPLE_ST_NEEDS_SW) sw[t] = 1;
         else if (out.tuple_kind[i] == TUPLE_CREATOR) bad_creator[t] = 1;
         else bad_end[t] = 1;
@@ -750,6 +877,56 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                           : bad_end[t]   ? TX_BAD_ENDORSEMENT
                           : sw[t]        ? TX_NEEDS_SW
                                          : TX_ALL_SIGNATURES_VALID;
+    }
+    // identities that earned a device comb table during this block: built and uploaded outside idmu_ (6 ms of host work each)
+    {
+        std::vector<std::pair<std::string, CachedIdentity>> todo;
+        {
+            std::lock_guard<std::mutex> lk(idmu_);
+            for (const std::string& k : to_register) {
+                auto it = idcache_.find(k);
+                if (it != idcache_.end()) todo.emplace_back(k, it->second->second);
+                else id_registered_--;                     // evicted meanwhile
+            }
+        }
+        for (auto& kv : todo) {
+            uint32_t id = 0;
+            const bool ok = fabgpu_p256_key_register(ctx_, kv.second.qx, kv.second.qy, &id) == FABGPU_OK;
+            std::lock_guard<std::mutex> lk(idmu_);
+            auto it = idcache_.find(kv.first);
+            if (it != idcache_.end()) {
+                it->second->second.registering = false;
+                if (ok) it->second->second.key_id = id;
+            }
+            if (!ok) id_registered_--;
+        }
+    }
+    // verdict memo: one entry per tuple the device hashed and decided, keyed on (key, signature bytes, device digest)
+    if (opt.seed_memo) {
+        std::vector<std::string> keys;
+        keys.reserve(nt);
+        std::lock_guard<std::mutex> lk(memo_mu_);
+        for (size_t i = 0; i < nt; i++) {
+            if (!out.tuple_hashed[i] || gt[i].nym) continue;
+            const uint8_t stt = out.tuple_status[i];
+            if (stt > FABGPU_ST_RANGE) continue;           // 0 valid, 1 bad math, 2 high-S, 3 range: what bccsp.Verify decides itself
+            const BlockTuple& tp = pb.tuples[i];
+            std::string k = MemoKey(&out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], block + tp.sig.off, tp.sig.len, &out.tuple_digest[32 * i], 32);
+            MemoEntry& e = memo_[k];
+            e.status = stt;
+            e.block_seq = opt.block_seq;
+            keys.push_back(std::move(k));
+        }
+        out.memo_seeded = (uint32_t)keys.size();
+        if (!keys.empty()) memo_blocks_.emplace_back(opt.block_seq, std::move(keys));
+        while (memo_.size() > memo_cap_ && memo_blocks_.size() > 1) {     // bounded: the oldest block's entries go first
+            auto& b = memo_blocks_.front();
+            for (const std::string& k : b.second) {
+                auto it = memo_.find(k);
+                if (it != memo_.end() && it->second.block_seq == b.first) { memo_.erase(it); memo_evicted_++; }
+            }
+            memo_blocks_.pop_front();
+        }
     }
     return Error();
 }

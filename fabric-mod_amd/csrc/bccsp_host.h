@@ -10,9 +10,12 @@
 #include <string>
 #include <vector>
 
+#include <deque>
+#include <list>
 #include <map>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 
 #include "../../include/fabgpu.h"
 #include "block_prepass.h"
@@ -82,6 +85,22 @@ struct BlockVerdicts {
     std::vector<uint8_t> tuple_status;    // device status 0..4 or TUPLE_ST_*
     uint32_t distinct_identities = 0;     // identities of this block that were not in the cache yet
     double ms_gates = 0, ms_upload_wait = 0, ms_device = 0;   // where the pass spent its time (host clock)
+    // What a consumer needs to attach each verdict to the BYTES it was computed over (never to a position):
+    std::vector<uint8_t> tuple_digest;    // 32 per tuple: SHA-256 of the signed message as the fused kernel computed it; zero unless the
+                                          // device hashed the message (tuple_hashed[i] == 1)
+    std::vector<uint8_t> tuple_hashed;
+    std::vector<uint8_t> tuple_qxy;       // 64 per tuple: the P-256 key the identity carries (zero: none / not P-256)
+    uint32_t n_block_sigs = 0;            // TUPLE_BLOCK_SIG tuples (the last ones)
+    uint8_t block_sigs_understood = 0;
+    uint32_t memo_seeded = 0;             // entries this pass added to the verdict memo
+};
+
+// Options of one pass.
+struct PassOptions {
+    bool want_digests = false;            // fill BlockVerdicts::tuple_digest (costs 32 B per tuple of D2H)
+    bool seed_memo = false;               // remember (key, signature, digest) -> status under `block_seq` (implies want_digests)
+    bool block_sigs = true;               // verify the orderers' block signatures too (MCS.VerifyBlock's SignedData)
+    uint64_t block_seq = 0;
 };
 
 class GPUCSP {
@@ -96,11 +115,26 @@ class GPUCSP {
     Error VerifyBatch(const std::vector<VerifyItem>& items, std::vector<VerifyResult>& results) const;
     Error IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::vector<std::string>& out) const;
     // Block-level pre-verify pass (block_prepass.h): one fused launch for every creator / endorsement signature of the block.
-    Error PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out) const;
+    Error PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out, const PassOptions& opt = PassOptions()) const;
     struct BlockUpload;
     // up: an upload of the block started ahead (StartBlockUpload); joined right before the submission.  nullptr: the block
     // travels with the submission.
-    Error PreVerifyParsed(const uint8_t* block, const ParsedBlock& parsed, BlockVerdicts& out, BlockUpload* up = nullptr) const;
+    Error PreVerifyParsed(const uint8_t* block, const ParsedBlock& parsed, BlockVerdicts& out, BlockUpload* up = nullptr,
+                          const PassOptions& opt = PassOptions()) const;
+    // ---- verdict memo (second half) ----
+    // The pass answers in advance the question the unchanged Go validators will ask one signature at a time:
+    // bccsp.Verify(k, signature, digest) (msp/identities.go:188).  An entry is keyed on exactly those three byte strings - the
+    // key's (X, Y), the DER signature as it sits in the block, the digest the DEVICE computed over the bytes it verified - each
+    // length-framed, so a verdict can only ever be found again by a caller holding the same key, signature and digest.
+    // Lookup: 0 = hit (*status = tuple status: 0 valid; 1 / 2 / 3 / 5 = the reference rejects, its exact error text comes from
+    // bccsp/sw on that one tuple), 1 = miss (ask bccsp/sw).  Bounded: at most memo_capacity entries; the oldest BLOCK goes first.
+    int MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen, uint8_t* status) const;
+    size_t MemoEvictBlock(uint64_t block_seq) const;          // the validator wrapper calls this when Validate(block) returned
+    void MemoStats(uint64_t* entries, uint64_t* hits, uint64_t* misses, uint64_t* evicted) const;
+    void MemoSetCapacity(size_t max_entries) const;
+    // identity cache bounds (msp/cache/cache.go keeps 100 deserialized identities; the pass sees every client certificate too)
+    void SetIdentityCacheLimits(size_t max_identities, size_t max_registered_keys, uint32_t register_after_hits) const;
+    size_t IdentityCacheSize() const;
     // Starts the upload of a block on a helper thread (blocks of 4 MiB and more) so that it travels while the caller parses
     // and gates; join() returns the token for PreVerifyParsed (0 if nothing was staged).
     struct BlockUpload {
@@ -127,9 +161,30 @@ class GPUCSP {
         bool p256 = false;
         uint8_t qx[32], qy[32];
         int64_t key_id = -1;
+        uint32_t hits = 0;              // tuples that named this identity (drives device-table registration)
+        bool registering = false;       // some thread is building the device table right now
     };
+    // Bounded LRU (the reference's msp cache is one: msp/cache/cache.go:14-18, second_chance.go).  Identities come out of
+    // UNVALIDATED blocks, so neither host memory nor device tables may grow with what a block names: at most id_max_ cached
+    // identities; a device comb table (640 KiB, ~6 ms of host work) only for an identity that was named id_register_after_ times,
+    // built outside idmu_, and at most id_max_registered_ of them - everybody else verifies on the fresh-key kernels.
+    typedef std::list<std::pair<std::string, CachedIdentity>> IdList;
     mutable std::mutex idmu_;
-    mutable std::map<std::string, CachedIdentity> idcache_;
+    mutable IdList idlru_;
+    mutable std::unordered_map<std::string, IdList::iterator> idcache_;
+    mutable size_t id_max_ = 4096, id_max_registered_ = 256, id_registered_ = 0;
+    mutable uint32_t id_register_after_ = 64;
+    // verdict memo
+    struct MemoEntry {
+        uint8_t status;
+        uint64_t block_seq;
+    };
+    mutable std::mutex memo_mu_;
+    mutable std::unordered_map<std::string, MemoEntry> memo_;
+    mutable std::deque<std::pair<uint64_t, std::vector<std::string>>> memo_blocks_;   // insertion order: oldest block first
+    mutable size_t memo_cap_ = (size_t)1 << 18;
+    mutable uint64_t memo_hits_ = 0, memo_misses_ = 0, memo_evicted_ = 0;
+    static std::string MemoKey(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
     mutable std::map<std::string, int64_t> idemix_msps_;   // mspid -> device issuer id (guarded by idmu_)
     // scratch of the pre-verify pass, reused from block to block (guarded by pass_mu_)
     struct PassScratch {
@@ -141,7 +196,7 @@ class GPUCSP {
         };
         std::vector<Gated> gt;
         std::vector<uint32_t> sub, ids, off, pre_idx;
-        std::vector<uint8_t> qx, qy, r, s;
+        std::vector<uint8_t> qx, qy, r, s, dig;
     };
     mutable std::mutex pass_mu_;
     mutable PassScratch ps_;

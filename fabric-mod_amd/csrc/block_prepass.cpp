@@ -63,18 +63,44 @@ struct PbReader {
     }
 };
 
-// first occurrence of length-delimited field `num`
-bool pb_bytes(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t& outlen) {
+// Singular length-delimited fields.  golang/protobuf's proto.Unmarshal takes the LAST occurrence of a repeated singular bytes
+// field and MERGES repeated embedded messages; no marshaller ever writes a singular field twice.  A walker that picked "an"
+// occurrence could verify other bytes than the Go validators later see, so this one refuses the ambiguity instead of
+// resolving it: every message is scanned to its end, and a wanted field that repeats (or arrives with another wire type, which
+// Go rejects) makes the whole message "not understood" - the transaction then stays with the Go validators.
+struct Pick {
+    uint32_t num;
+    const uint8_t* p = nullptr;
+    size_t len = 0;
+    int seen = 0;
+    explicit Pick(uint32_t n) : num(n) {}
+};
+// false: malformed wire format, or one of the wanted fields repeated / not length-delimited
+bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
     PbReader r(b, n);
     PbField f;
-    while (r.next(f))
-        if (f.num == num && f.wt == 2) {
-            out = f.data;
-            outlen = f.len;
-            return true;
-        }
-    return false;
+    while (r.next(f)) {
+        if (f.num == 0) return false;                                  // "illegal tag 0" in Go
+        for (int i = 0; i < k; i++)
+            if (want[i].num == f.num) {
+                if (f.wt != 2 || want[i].seen) return false;
+                want[i].seen = 1;
+                want[i].p = f.data;
+                want[i].len = f.len;
+            }
+    }
+    return r.ok;
 }
+// the one wanted field: 1 present once, 0 absent, -1 ambiguous / malformed
+int pb_one(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t& outlen) {
+    Pick w(num);
+    if (!pb_pick(b, n, &w, 1)) return -1;
+    out = w.p;
+    outlen = w.len;
+    return w.seen;
+}
+// compatibility form for callers that only ask "is there exactly one": absent and ambiguous both answer false
+bool pb_bytes(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t& outlen) { return pb_one(b, n, num, out, outlen) == 1; }
 
 Span span_of(const uint8_t* base, const uint8_t* p, size_t n) {
     Span s;
@@ -186,6 +212,42 @@ bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy
     return CertDerToP256(der.data(), der.size(), qx, qy);
 }
 
+namespace {
+void der_len(std::vector<uint8_t>& o, size_t n) {
+    if (n < 128) { o.push_back((uint8_t)n); return; }
+    uint8_t tmp[8];
+    int k = 0;
+    while (n) { tmp[k++] = (uint8_t)(n & 0xFF); n >>= 8; }
+    o.push_back((uint8_t)(0x80 | k));
+    while (k) o.push_back(tmp[--k]);
+}
+void der_octets(std::vector<uint8_t>& o, const uint8_t* p, size_t n) {
+    o.push_back(0x04);
+    der_len(o, n);
+    o.insert(o.end(), p, p + n);
+}
+}  // namespace
+
+void BlockHeaderBytes(uint64_t number, const uint8_t* prev, size_t prev_len, const uint8_t* data_hash, size_t dh_len, std::vector<uint8_t>& out) {
+    std::vector<uint8_t> body;
+    // INTEGER: minimal big-endian two's complement of a non-negative value (a leading 0x00 when the top bit is set)
+    uint8_t be[9];
+    int k = 0;
+    be[k++] = 0;
+    for (int i = 7; i >= 0; i--) be[k++] = (uint8_t)(number >> (8 * i));
+    int first = 0;
+    while (first < 8 && be[first] == 0 && !(be[first + 1] & 0x80)) first++;
+    body.push_back(0x02);
+    der_len(body, (size_t)(9 - first));
+    body.insert(body.end(), be + first, be + 9);
+    der_octets(body, prev, prev_len);
+    der_octets(body, data_hash, dh_len);
+    out.clear();
+    out.push_back(0x30);
+    der_len(out, body.size());
+    out.insert(out.end(), body.begin(), body.end());
+}
+
 bool HashCheckMatches(const uint8_t* block, const BlockHashCheck& hc, const uint8_t digest[32]) {
     const uint8_t* e = block + hc.expect.off;
     if (hc.kind == HASH_PROPOSAL) return hc.expect.len == 32 && memcmp(e, digest, 32) == 0;
@@ -219,107 +281,128 @@ namespace {
 void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, uint32_t tx, ParsedBlock& out, uint8_t& tx_type, uint8_t& understood) {
     tx_type = 255;
     understood = 0;
-    const uint8_t *payload, *sig, *hdr, *pdata, *chdr, *shdr, *creator;
-    size_t payload_l, sig_l, hdr_l, pdata_l, chdr_l, shdr_l, creator_l;
     // common.Envelope{1 payload, 2 signature}
-    if (!pb_bytes(env, env_len, 1, payload, payload_l)) return;
-    if (!pb_bytes(env, env_len, 2, sig, sig_l)) { sig = payload; sig_l = 0; }
+    Pick e_[2] = {Pick(1), Pick(2)};
+    if (!pb_pick(env, env_len, e_, 2) || !e_[0].seen) return;
+    const uint8_t* payload = e_[0].p;
+    const size_t payload_l = e_[0].len;
+    const uint8_t* sig = e_[1].seen ? e_[1].p : payload;
+    const size_t sig_l = e_[1].seen ? e_[1].len : 0;
     // common.Payload{1 header, 2 data}; common.Header{1 channel_header, 2 signature_header}
-    if (!pb_bytes(payload, payload_l, 1, hdr, hdr_l)) return;
-    if (!pb_bytes(hdr, hdr_l, 1, chdr, chdr_l) || !pb_bytes(hdr, hdr_l, 2, shdr, shdr_l)) return;
-    // common.ChannelHeader{1 type (varint), ..., 4 channel_id}
+    Pick p_[2] = {Pick(1), Pick(2)};
+    if (!pb_pick(payload, payload_l, p_, 2) || !p_[0].seen) return;
+    Pick h_[2] = {Pick(1), Pick(2)};
+    if (!pb_pick(p_[0].p, p_[0].len, h_, 2) || !h_[0].seen || !h_[1].seen) return;
+    const uint8_t *chdr = h_[0].p, *shdr = h_[1].p;
+    const size_t chdr_l = h_[0].len, shdr_l = h_[1].len;
+    // common.ChannelHeader{1 type (varint), ..., 4 channel_id, 5 tx_id}
     uint8_t type = 0;   // proto3 default: MESSAGE
     Span txid_span;     // ChannelHeader.tx_id (field 5)
     {
         PbReader r(chdr, chdr_l);
         PbField g;
+        int n_type = 0, n_chan = 0, n_txid = 0;
         while (r.next(g)) {
-            if (g.num == 1 && g.wt == 0) type = (uint8_t)g.varint;
-            if (g.num == 4 && g.wt == 2 && tx == 0) out.first_channel_id.assign((const char*)g.data, g.len);
-            if (g.num == 5 && g.wt == 2) txid_span = span_of(block, g.data, g.len);
+            if (g.num == 0) return;
+            if (g.num == 1) {
+                if (g.wt != 0 || n_type++) return;
+                if (g.varint > 254) return;                            // no HeaderType is that large: leave it to Go
+                type = (uint8_t)g.varint;
+            }
+            if (g.num == 4) {
+                if (g.wt != 2 || n_chan++) return;
+                if (tx == 0) out.first_channel_id.assign((const char*)g.data, g.len);
+            }
+            if (g.num == 5) {
+                if (g.wt != 2 || n_txid++) return;
+                txid_span = span_of(block, g.data, g.len);
+            }
         }
         if (!r.ok) return;
     }
     tx_type = type;
     // common.SignatureHeader{1 creator, 2 nonce}
-    if (!pb_bytes(shdr, shdr_l, 1, creator, creator_l)) return;
+    Pick s_[2] = {Pick(1), Pick(2)};
+    if (!pb_pick(shdr, shdr_l, s_, 2) || !s_[0].seen) return;
     BlockTuple ct;
     ct.tx = tx;
     ct.kind = TUPLE_CREATOR;
-    ct.identity = span_of(block, creator, creator_l);
+    ct.identity = span_of(block, s_[0].p, s_[0].len);
     ct.suffix = span_of(block, payload, payload_l);
     ct.sig = span_of(block, sig, sig_l);
-    size_t first_tuple = out.tuples.size(), first_check = out.hash_checks.size();
+    size_t first_tuple = out.tuples.size(), first_check = out.hash_checks.size(), first_prefix = out.prefixes.size();
     out.tuples.push_back(ct);
-    if (type == 3) {                                               // CheckTxID: endorser transactions only (msgvalidation.go:283-296)
-        const uint8_t* nonce;
-        size_t nonce_l;
-        BlockHashCheck hc;
-        hc.tx = tx;
-        hc.kind = HASH_TXID;
-        if (pb_bytes(shdr, shdr_l, 2, nonce, nonce_l)) hc.piece[0] = span_of(block, nonce, nonce_l);
-        hc.piece[1] = ct.identity;
-        hc.expect = txid_span;
-        out.hash_checks.push_back(hc);
-    }
     if (type != 3) {                                               // only ENDORSER_TRANSACTION carries endorsements
         understood = 1;
         return;
     }
-    if (!pb_bytes(payload, payload_l, 2, pdata, pdata_l)) { out.tuples.resize(first_tuple); out.hash_checks.resize(first_check); return; }
+    {   // CheckTxID: endorser transactions only (msgvalidation.go:283-296)
+        BlockHashCheck hc;
+        hc.tx = tx;
+        hc.kind = HASH_TXID;
+        if (s_[1].seen) hc.piece[0] = span_of(block, s_[1].p, s_[1].len);
+        hc.piece[1] = ct.identity;
+        hc.expect = txid_span;
+        out.hash_checks.push_back(hc);
+    }
+    bool good = p_[1].seen != 0;
     // peer.Transaction{1 repeated actions}; TransactionAction{1 header, 2 payload}
-    bool good = true;
-    PbReader acts(pdata, pdata_l);
+    PbReader acts(good ? p_[1].p : payload, good ? p_[1].len : 0);
     PbField a;
-    while (acts.next(a)) {
-        if (a.num != 1 || a.wt != 2) continue;
-        const uint8_t *ap, *cea, *prp;
-        size_t ap_l, cea_l, prp_l;
+    while (good && acts.next(a)) {
+        if (a.num == 0) { good = false; break; }
+        if (a.num != 1) continue;
+        if (a.wt != 2) { good = false; break; }
         // ChaincodeActionPayload{1 chaincode_proposal_payload, 2 action}; ChaincodeEndorsedAction{1 proposal_response_payload, 2 endorsements}
-        if (!pb_bytes(a.data, a.len, 2, ap, ap_l) || !pb_bytes(ap, ap_l, 2, cea, cea_l) || !pb_bytes(cea, cea_l, 1, prp, prp_l)) {
-            good = false;
-            break;
-        }
+        Pick ta_[2] = {Pick(1), Pick(2)};
+        if (!pb_pick(a.data, a.len, ta_, 2) || !ta_[1].seen) { good = false; break; }
+        Pick cap_[2] = {Pick(1), Pick(2)};
+        if (!pb_pick(ta_[1].p, ta_[1].len, cap_, 2) || !cap_[1].seen) { good = false; break; }
+        const uint8_t* cea = cap_[1].p;
+        const size_t cea_l = cap_[1].len;
+        Pick prp_(1);
+        if (!pb_pick(cea, cea_l, &prp_, 1) || !prp_.seen) { good = false; break; }
+        const uint8_t* prp = prp_.p;
+        const size_t prp_l = prp_.len;
         int32_t pidx = (int32_t)out.prefixes.size();
         out.prefixes.push_back(span_of(block, prp, prp_l));
         {   // GetProposalHash2 of this action
-            const uint8_t *ahdr, *ccpp, *ph;
-            size_t ahdr_l, ccpp_l, ph_l;
             BlockHashCheck hc;
             hc.tx = tx;
             hc.kind = HASH_PROPOSAL;
             hc.piece[0] = span_of(block, chdr, chdr_l);
-            if (pb_bytes(a.data, a.len, 1, ahdr, ahdr_l)) hc.piece[1] = span_of(block, ahdr, ahdr_l);
-            if (pb_bytes(ap, ap_l, 1, ccpp, ccpp_l)) hc.piece[2] = span_of(block, ccpp, ccpp_l);
-            if (pb_bytes(prp, prp_l, 1, ph, ph_l)) hc.expect = span_of(block, ph, ph_l);   // ProposalResponsePayload{1 proposal_hash, 2 extension}
+            if (ta_[0].seen) hc.piece[1] = span_of(block, ta_[0].p, ta_[0].len);
+            if (cap_[0].seen) hc.piece[2] = span_of(block, cap_[0].p, cap_[0].len);
+            Pick ph_(1);                                               // ProposalResponsePayload{1 proposal_hash, 2 extension}
+            if (!pb_pick(prp, prp_l, &ph_, 1)) { good = false; break; }
+            if (ph_.seen) hc.expect = span_of(block, ph_.p, ph_.len);
             out.hash_checks.push_back(hc);
         }
         PbReader ends(cea, cea_l);
         PbField e;
         while (ends.next(e)) {
-            if (e.num != 2 || e.wt != 2) continue;
-            const uint8_t *endorser, *esig;
-            size_t endorser_l, esig_l;
+            if (e.num != 2) continue;
+            if (e.wt != 2) { good = false; break; }
             // peer.Endorsement{1 endorser, 2 signature}
-            if (!pb_bytes(e.data, e.len, 1, endorser, endorser_l)) { good = false; break; }
-            if (!pb_bytes(e.data, e.len, 2, esig, esig_l)) { esig = endorser; esig_l = 0; }
+            Pick en_[2] = {Pick(1), Pick(2)};
+            if (!pb_pick(e.data, e.len, en_, 2) || !en_[0].seen) { good = false; break; }
             BlockTuple et;
             et.tx = tx;
             et.kind = TUPLE_ENDORSEMENT;
-            et.identity = span_of(block, endorser, endorser_l);
+            et.identity = span_of(block, en_[0].p, en_[0].len);
             et.prefix = span_of(block, prp, prp_l);
             et.prefix_index = pidx;
             et.suffix = et.identity;                               // message = prp || endorser
-            et.sig = span_of(block, esig, esig_l);
+            et.sig = en_[1].seen ? span_of(block, en_[1].p, en_[1].len) : span_of(block, en_[0].p, 0);
             out.tuples.push_back(et);
         }
         if (!ends.ok) good = false;
-        if (!good) break;
     }
     if (!acts.ok) good = false;
     if (!good) {
         out.tuples.resize(first_tuple);                            // leave the whole transaction to the Go validators
         out.hash_checks.resize(first_check);
+        out.prefixes.resize(first_prefix);
         return;
     }
     understood = 1;
@@ -342,9 +425,10 @@ struct EnvChunk {
 bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_threads) {
     out.reset();
     if (len > 0xFFFFFFF0ull) return false;
-    const uint8_t* data;
-    size_t dlen;
-    if (!pb_bytes(block, len, 2, data, dlen)) return false;           // common.Block{1 header, 2 data, 3 metadata}
+    Pick top[3] = {Pick(1), Pick(2), Pick(3)};                       // common.Block{1 header, 2 data, 3 metadata}
+    if (!pb_pick(block, len, top, 3) || !top[1].seen) return false;    // (a repeated embedded message would MERGE in Go: refused)
+    const uint8_t* data = top[1].p;
+    const size_t dlen = top[1].len;
     int nt = max_threads > 16 ? 16 : max_threads;
     if (dlen < ((size_t)1 << 20) || nt < 2) nt = 0;                   // small blocks: everything on the calling thread
     // chunk table: an envelope is at least 2 bytes, so dlen / (2 WALK_CHUNK) + 1 chunks is an upper bound nobody reaches;
@@ -420,13 +504,83 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
         out.reset();
         return false;
     }
+    // block level: header fields and the orderer signatures over the block (TUPLE_BLOCK_SIG)
+    out.data = span_of(block, data, dlen);
+    out.tail_base = (uint32_t)((len + 63) / 64 * 64);
+    std::vector<BlockTuple> block_sigs;
+    if (top[0].seen) {
+        // common.BlockHeader{1 number (varint), 2 previous_hash, 3 data_hash}
+        PbReader r(top[0].p, top[0].len);
+        PbField f;
+        int c1 = 0, c2 = 0, c3 = 0;
+        bool ok = true;
+        while (r.next(f)) {
+            if (f.num == 0) ok = false;
+            if (f.num == 1) { if (f.wt != 0 || c1++) ok = false; else out.number = f.varint; }
+            if (f.num == 2) { if (f.wt != 2 || c2++) ok = false; else out.previous_hash = span_of(block, f.data, f.len); }
+            if (f.num == 3) { if (f.wt != 2 || c3++) ok = false; else out.data_hash = span_of(block, f.data, f.len); }
+        }
+        out.has_header = ok && r.ok;
+    }
+    if (out.has_header && top[2].seen) {
+        // common.BlockMetadata{1 repeated bytes metadata}; entry [BlockMetadataIndex_SIGNATURES = 0] is a marshalled
+        // common.Metadata{1 value, 2 repeated MetadataSignature{1 signature_header, 2 signature}}
+        PbReader r(top[2].p, top[2].len);
+        PbField f;
+        const uint8_t* m0 = nullptr;
+        size_t m0_l = 0;
+        bool have = false, ok = true;
+        while (r.next(f)) {
+            if (f.num != 1) continue;
+            if (f.wt != 2) { ok = false; break; }
+            if (!have) { m0 = f.data; m0_l = f.len; have = true; }
+        }
+        ok = ok && r.ok && have;
+        Pick val(1);
+        if (ok && !pb_pick(m0, m0_l, &val, 1)) ok = false;
+        if (ok) {
+            std::vector<uint8_t> hb;
+            BlockHeaderBytes(out.number, block + out.previous_hash.off, out.previous_hash.len, block + out.data_hash.off, out.data_hash.len, hb);
+            PbReader sr(m0, m0_l);
+            PbField g;
+            while (sr.next(g)) {
+                if (g.num != 2) continue;
+                if (g.wt != 2) { ok = false; break; }
+                Pick ms[2] = {Pick(1), Pick(2)};
+                if (!pb_pick(g.data, g.len, ms, 2)) { ok = false; break; }
+                // protoutil.UnmarshalSignatureHeader(signature_header).Creator; an absent header unmarshals to an empty creator
+                Pick cr(1);
+                if (ms[0].seen && !pb_pick(ms[0].p, ms[0].len, &cr, 1)) { ok = false; break; }
+                BlockTuple bt;
+                bt.tx = BLOCK_LEVEL_TX;
+                bt.kind = TUPLE_BLOCK_SIG;
+                bt.identity = cr.seen ? span_of(block, cr.p, cr.len) : span_of(block, block, 0);
+                bt.sig = ms[1].seen ? span_of(block, ms[1].p, ms[1].len) : span_of(block, block, 0);
+                const size_t at = out.tail.size();
+                if (val.seen) out.tail.insert(out.tail.end(), val.p, val.p + val.len);
+                if (ms[0].seen) out.tail.insert(out.tail.end(), ms[0].p, ms[0].p + ms[0].len);
+                out.tail.insert(out.tail.end(), hb.begin(), hb.end());
+                if ((uint64_t)out.tail_base + out.tail.size() > 0xFFFFFFF0ull) { ok = false; break; }
+                bt.suffix.off = out.tail_base + (uint32_t)at;
+                bt.suffix.len = (uint32_t)(out.tail.size() - at);
+                block_sigs.push_back(bt);
+            }
+            if (!sr.ok) ok = false;
+        }
+        if (!ok) {
+            block_sigs.clear();
+            out.tail.clear();
+        }
+        out.block_sigs_understood = ok;
+    }
+    out.n_block_sigs = (uint32_t)block_sigs.size();
     // merge in chunk order
     out.n_tx = n;
     out.tx_type.resize(n);
     out.tx_understood.resize(n);
     size_t ntup = 0, npre = 0, nchk = 0;
     for (uint32_t ci = 0; ci < nchunks; ci++) { ntup += part[ci]->tuples.size(); npre += part[ci]->prefixes.size(); nchk += part[ci]->hash_checks.size(); }
-    out.tuples.reserve(ntup);
+    out.tuples.reserve(ntup + block_sigs.size());
     out.prefixes.reserve(npre);
     out.hash_checks.reserve(nchk);
     for (uint32_t ci = 0; ci < nchunks; ci++) {
@@ -444,6 +598,7 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
                 if (out.tuples[i].prefix_index >= 0) out.tuples[i].prefix_index += base;
         out.hash_checks.insert(out.hash_checks.end(), p.hash_checks.begin(), p.hash_checks.end());
     }
+    out.tuples.insert(out.tuples.end(), block_sigs.begin(), block_sigs.end());   // block-level tuples come last
     return true;
 }
 

@@ -30,12 +30,22 @@ struct Span {
     uint32_t off = 0, len = 0;   // into the block buffer
 };
 
-enum : uint8_t { TUPLE_CREATOR = 0, TUPLE_ENDORSEMENT = 1 };
+// TUPLE_BLOCK_SIG: an orderer's signature over the block (BlockMetadataIndex_SIGNATURES), the SignedData MCS.VerifyBlock hands to
+// the BlockValidation policy (internal/peer/gossip/mcs.go:166-193):
+//     identity = SignatureHeader.creator of MetadataSignature.signature_header
+//     message  = Metadata.value || MetadataSignature.signature_header || protoutil.BlockHeaderBytes(block.Header)
+// BlockHeaderBytes is the ASN.1 DER of {Number INTEGER, PreviousHash OCTET STRING, DataHash OCTET STRING}
+// (protoutil/blockutils.go:38-58) - bytes that are NOT in the marshalled block.  The walker therefore writes each such message
+// into ParsedBlock::tail, and the tuple's suffix span addresses it at offset tail_base + k of a VIRTUAL arena
+// block || zero padding up to tail_base || tail  (fabgpu_identity_batch.tail).  tx = BLOCK_LEVEL_TX for these tuples.
+enum : uint8_t { TUPLE_CREATOR = 0, TUPLE_ENDORSEMENT = 1, TUPLE_BLOCK_SIG = 2 };
+constexpr uint32_t BLOCK_LEVEL_TX = 0xFFFFFFFFu;
 // per-tuple outcome: 0..4 = the device status codes of include/fabgpu.h, plus
 enum : uint8_t {
     TUPLE_ST_BAD_DER = 5,        // UnmarshalECDSASignature fails / r,s <= 0: identity.Verify returns an error
     TUPLE_ST_NEEDS_SW = 6,       // identity is not a PEM x509 certificate with a P-256 key (idemix, other curves): bccsp/sw decides
     TUPLE_ST_EMPTY_SIG = 7,      // empty signature
+    TUPLE_ST_SKIPPED = 8,        // the caller asked the pass not to verify this kind of tuple (block signatures)
 };
 // per-transaction summary
 enum : uint8_t {
@@ -75,12 +85,23 @@ struct ParsedBlock {
     std::vector<BlockTuple> tuples;
     std::vector<BlockHashCheck> hash_checks;   // endorser transactions only
     std::string first_channel_id;         // of envelope 0 (fixture pin)
+    // block level (MCS.VerifyBlock): header fields, the orderer signature messages (see TUPLE_BLOCK_SIG)
+    bool has_header = false;
+    uint64_t number = 0;
+    Span previous_hash, data_hash;        // BlockHeader{2 previous_hash, 3 data_hash}
+    Span data;                            // the BlockData message: BlockDataHash = SHA-256 of its concatenated entries
+    uint32_t n_block_sigs = 0;
+    bool block_sigs_understood = false;   // metadata[SIGNATURES] parsed (possibly to zero signatures)
+    uint32_t tail_base = 0;
+    std::vector<uint8_t> tail;
     // A ParsedBlock that is handed to ParseBlock again keeps its storage (and that of the per-worker parts below): a provider
     // that parses block after block does not allocate - and page-fault in - a few MB per block.
     std::vector<std::unique_ptr<ParsedBlock>> parts;   // scratch of the threaded walk: one per chunk of envelopes
     void reset() {
         n_tx = 0;
         tx_type.clear(); tx_understood.clear(); prefixes.clear(); tuples.clear(); hash_checks.clear(); first_channel_id.clear();
+        has_header = false; number = 0; previous_hash = Span(); data_hash = Span(); data = Span();
+        n_block_sigs = 0; block_sigs_understood = false; tail_base = 0; tail.clear();
     }
 };
 
@@ -92,6 +113,8 @@ bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy
 // DER x509 certificate -> P-256 SubjectPublicKeyInfo point (exposed for tests against the reference's certificate fixtures)
 bool CertDerToP256(const uint8_t* der, size_t len, uint8_t qx[32], uint8_t qy[32]);
 bool PemToDer(const uint8_t* pem, size_t len, std::vector<uint8_t>& der);
+// protoutil.BlockHeaderBytes (protoutil/blockutils.go:38-58): DER of SEQUENCE{INTEGER number, OCTET STRING previous_hash, OCTET STRING data_hash}
+void BlockHeaderBytes(uint64_t number, const uint8_t* prev, size_t prev_len, const uint8_t* data_hash, size_t dh_len, std::vector<uint8_t>& out);
 // does the 32-byte digest equal what the block says (hex string for HASH_TXID, raw bytes for HASH_PROPOSAL)?
 bool HashCheckMatches(const uint8_t* block, const BlockHashCheck& hc, const uint8_t digest[32]);
 // SerializedIdentity{mspid, id_bytes = msp.SerializedIdemixIdentity{1 nym_x, 2 nym_y, 3 ou, 4 role, 5 proof}} (what

@@ -167,7 +167,16 @@ struct sha_prefixes {
     const uint32_t* mid;       // m x 8 words, written by sha256_midstate_kernel
     uint32_t m;
     uint32_t spans;            // 1: off / pre_off hold (start, end) pairs instead of n + 1 consecutive offsets
+    uint32_t* digests;         // optional out: n x 32 bytes, the SHA-256 of every message as the fused kernel computed it (nullptr = none)
 };
+// The digest a fused kernel verified against leaves the chip only when the caller asks for it (the block pass keys its verdict
+// memo on it: bccsp.Verify(k, sig, digest) is what the Go validators will ask, msp/identities.go:188).
+__device__ __forceinline__ void emit_digest(const sha_prefixes& pre, uint32_t i, bool active, const uint32_t h[8]) {
+    if (pre.digests == nullptr || !active) return;
+    uint4* out = reinterpret_cast<uint4*>(pre.digests + 8 * (size_t)i);
+    out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+    out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+}
 // The digest of message i of a (possibly prefixed) batch, in h.
 __device__ __forceinline__ void sha256_message(const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
                                                const sha_prefixes& pre, uint32_t ic, bool active, uint32_t h[8]) {

@@ -55,13 +55,16 @@ struct fabgpu_ctx {
     Buf out;      // verdict words | status bytes | digests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    // Workspaces for the verify kernels' per-lane j*Q tables.  A launch borrows one and marks it busy until an event
-    // recorded behind the kernel completes, so launches racing on different streams never share one.
+    // Workspaces for the verify kernels' per-lane j*Q tables.  A launch borrows one: `reserved` from acquire until release has
+    // recorded an event behind the kernel, `armed` from then until that event completes - two separate flags, because between
+    // acquire and release the event is stale (or was never recorded) and hipEventQuery on it would answer "done".
+    // acquire hands the POINTER out under the lock: the vector may grow while the caller launches.
     struct QWs {
         void* p = nullptr;
         size_t bytes = 0;
         hipEvent_t done = nullptr;
-        bool pending = false;
+        bool reserved = false;   // handed to a launch that has not recorded `done` yet
+        bool armed = false;      // `done` was recorded behind the launch that used it
     };
     std::vector<QWs> qws;
     // Registered public keys: one 640 KiB comb table each, resident on the device; d_ktabs mirrors the pointer array.
@@ -88,20 +91,27 @@ struct fabgpu_ctx {
     uint64_t staged_token = 0;
     Buf keyed;        // staging of the keyed host-pointer entry point: key_id | e | r | s
     Buf pre;          // staging of prefixed batches: pre_off | pre_idx | mid-states
+    Buf tailbuf;      // staging of an identity batch's tail when the arena itself bypasses the pinned buffer
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
-    int acquire_qws(size_t bytes, size_t* idx);
+    int acquire_qws(size_t bytes, size_t* idx, void** p);
     void release_qws(size_t idx, hipStream_t st) {
         std::lock_guard<std::mutex> lk(qmu);
-        if (hipEventRecord(qws[idx].done, st) == hipSuccess) qws[idx].pending = true;
+        QWs& w = qws[idx];
+        // if the record fails the workspace stays reserved forever (never reused): a leak, not a shared table
+        if (hipEventRecord(w.done, st) == hipSuccess) {
+            w.armed = true;
+            w.reserved = false;
+        }
     }
 };
 
-int fabgpu_ctx::acquire_qws(size_t bytes, size_t* idx) {
+int fabgpu_ctx::acquire_qws(size_t bytes, size_t* idx, void** p) {
     std::lock_guard<std::mutex> lk(qmu);
     for (size_t i = 0; i < qws.size(); i++) {
         QWs& w = qws[i];
-        if (w.pending && hipEventQuery(w.done) != hipSuccess) continue;   // still in flight on some stream
-        w.pending = false;
+        if (w.reserved) continue;                                          // somebody is between acquire and release
+        if (w.armed && hipEventQuery(w.done) != hipSuccess) continue;      // still in flight on some stream
+        w.armed = false;
         if (w.bytes < bytes) {
             if (w.p) hipFree(w.p);
             w.p = nullptr;
@@ -109,8 +119,9 @@ int fabgpu_ctx::acquire_qws(size_t bytes, size_t* idx) {
             if (hipMalloc(&w.p, bytes) != hipSuccess) return FABGPU_ENOMEM;
             w.bytes = bytes;
         }
-        w.pending = true;   // reserved; release_qws() arms the event
+        w.reserved = true;
         *idx = i;
+        *p = w.p;
         return FABGPU_OK;
     }
     QWs w;
@@ -120,9 +131,10 @@ int fabgpu_ctx::acquire_qws(size_t bytes, size_t* idx) {
         return FABGPU_ENOMEM;
     }
     w.bytes = bytes;
-    w.pending = true;
+    w.reserved = true;
     qws.push_back(w);
     *idx = qws.size() - 1;
+    *p = w.p;
     return FABGPU_OK;
 }
 
@@ -227,6 +239,9 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         if (ctx->d_issuers) hipFree(ctx->d_issuers);
         ctx->nym.release();
         ctx->gath.release();
+        ctx->tailbuf.release();
+        ctx->keyed.release();
+        ctx->pre.release();
         if (ctx->d_gscr) hipFree(ctx->d_gscr);
         if (ctx->d_staged) hipFree(ctx->d_staged);
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
@@ -259,10 +274,11 @@ int fabgpu_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* qx, cons
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
-    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
+    void* wsp = nullptr;
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp);
     if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
-    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, st);
+    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, wsp, verdict_bits, status, ctx->allow_pair, st);
     hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = true;
@@ -292,10 +308,11 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
-    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
+    void* wsp = nullptr;
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp);
     if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
-    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, ShaPrefixArgs(), st);
+    hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, wsp, verdict_bits, status, ctx->allow_pair, ShaPrefixArgs(), st);
     hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = true;
@@ -394,11 +411,12 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
-    int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
+    void* wsp = nullptr;
+    int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp);
     if (rc != FABGPU_OK) return rc;
     hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
-                                              proof_s_sk, proof_s_r_nym, nonce, ctx->qws[wi].p, verdict_bits, status, ctx->allow_pair, st);
+                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, st);
     hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = true;
@@ -724,6 +742,7 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
         return FABGPU_EINVAL;
     ShaPrefixArgs pa;
     pa.spans = (b->flags & FABGPU_IDB_SPANS) != 0;
+    pa.digests = b->digests;
     if (prefixed) {
         pa.m = b->n_prefixes;
         pa.pre_off = b->pre_off;
@@ -748,10 +767,11 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
         hipEventRecord(ctx->ev1, st);
     } else {
         size_t wi = 0;
-        int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi);
+        void* wsp = nullptr;
+        int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp);
         if (rc != FABGPU_OK) return rc;
         hipEventRecord(ctx->ev0, st);
-        err = launch_sha256_p256_verify((uint32_t)n, b->arena, b->arena_bytes, b->off, b->qx, b->qy, b->r, b->s, ctx->d_gtab, ctx->qws[wi].p,
+        err = launch_sha256_p256_verify((uint32_t)n, b->arena, b->arena_bytes, b->off, b->qx, b->qy, b->r, b->s, ctx->d_gtab, wsp,
                                         b->verdict_bits, b->status, ctx->allow_pair, pa, st);
         hipEventRecord(ctx->ev1, st);
         ctx->release_qws(wi, st);
@@ -768,16 +788,16 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
     if (len > 0xFFFFFF00ull) return FABGPU_ETOOBIG;
     std::lock_guard<std::mutex> lk(ctx->smu);
     DeviceGuard g(ctx->device);
-    const size_t need = round_up(len, 4) + 128;
-    if (ctx->staged_cap < need) {
+    const size_t need = round_up(len, 64) + 128;          // + room for a batch's tail (fabgpu_identity_batch.tail) in the slack below
+    if (ctx->staged_cap < need + (64 << 10)) {
         // a batch in flight may still read the old buffer: it was submitted under ctx->mu and synchronises before returning,
         // and it holds no pointer past that; take mu to be sure nobody is between "token checked" and "kernels done"
         std::lock_guard<std::mutex> lk2(ctx->mu);
         if (ctx->d_staged) hipFree(ctx->d_staged);
         ctx->d_staged = nullptr;
         ctx->staged_cap = 0;
-        if (hipMalloc(&ctx->d_staged, need + need / 8) != hipSuccess) return FABGPU_ENOMEM;
-        ctx->staged_cap = need + need / 8;
+        if (hipMalloc(&ctx->d_staged, need + need / 8 + (64 << 10)) != hipSuccess) return FABGPU_ENOMEM;
+        ctx->staged_cap = need + need / 8 + (64 << 10);
     }
     ctx->staged_token++;                                   // the previous upload is gone from here on
     ctx->staged_len = 0;
@@ -809,20 +829,44 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
-    // the span of the arena that messages and prefixes reference
+    // the span of the arena that messages and prefixes reference; spans at or beyond tail_base address the tail
     const size_t noff = spans ? 2 * n : n + 1, npre = m ? (spans ? 2 * (size_t)m : (size_t)m + 1) : 0;
-    uint32_t lo = 0xFFFFFFFFu, hi = 0;
-    for (size_t i = 0; i < n; i++) {
-        uint32_t s0 = b->off[spans ? 2 * i : i], s1 = b->off[spans ? 2 * i + 1 : i + 1];
-        if (s1 < s0) return FABGPU_EINVAL;
+    const bool has_tail = b->tail != nullptr && b->tail_len != 0;
+    const uint32_t tbase = has_tail ? b->tail_base : 0xFFFFFFFFu;
+    if (has_tail && ((tbase & 63u) || !spans || (uint64_t)tbase + b->tail_len > 0xFFFFFFF0ull)) return FABGPU_EINVAL;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;      // of the caller's arena
+    bool tail_used = false, bad = false;
+    auto see = [&](uint32_t s0, uint32_t s1) {
+        if (s1 < s0) { bad = true; return; }
+        if (s1 == s0) return;
+        if (s0 >= tbase) {
+            if ((uint64_t)s1 > (uint64_t)tbase + b->tail_len) bad = true;
+            tail_used = true;
+            return;
+        }
+        if (s1 > tbase) { bad = true; return; }            // straddles
         if (s0 < lo) lo = s0;
         if (s1 > hi) hi = s1;
+    };
+    for (size_t i = 0; i < n; i++) {
+        uint32_t s0 = b->off[spans ? 2 * i : i], s1 = b->off[spans ? 2 * i + 1 : i + 1];
+        if (!spans) {                                      // consecutive messages: empty ones still bound the span
+            if (s1 < s0) return FABGPU_EINVAL;
+            if (s0 < lo) lo = s0;
+            if (s1 > hi) hi = s1;
+        } else {
+            see(s0, s1);
+        }
     }
     for (uint32_t p = 0; p < m; p++) {
         uint32_t s0 = b->pre_off[spans ? 2 * p : p], s1 = b->pre_off[spans ? 2 * p + 1 : p + 1];
-        if (s1 < s0) return FABGPU_EINVAL;
-        if (s0 < lo) lo = s0;
-        if (s1 > hi) hi = s1;
+        if (!spans) {
+            if (s1 < s0) return FABGPU_EINVAL;
+            if (s0 < lo) lo = s0;
+            if (s1 > hi) hi = s1;
+        } else {
+            see(s0, s1);
+        }
     }
     const uint32_t ng = b->n_gather;
     if (ng && (!b->gather_spans || !b->gather_digests)) return FABGPU_EINVAL;
@@ -831,24 +875,32 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
         uint32_t s0 = b->gather_spans[2 * j], s1 = b->gather_spans[2 * j + 1];
         if (s1 < s0) return FABGPU_EINVAL;
         if (s1 == s0) continue;
+        if (s1 > tbase) return FABGPU_EINVAL;              // gathered pieces come from the caller's arena only
         if (s0 < lo) lo = s0;
         if (s1 > hi) hi = s1;
         gtotal += s1 - s0;
     }
+    if (bad) return FABGPU_EINVAL;
     if (gtotal > 0x7FFFFFF0ull) return FABGPU_ETOOBIG;
-    size_t span = hi >= lo ? (size_t)hi - lo : 0;
+    if (lo == 0xFFFFFFFFu) lo = hi = 0;                    // nothing references the caller's arena
+    if (spans && tail_used) lo = 0;                        // keeps tail_base an absolute offset of the device arena
+    size_t span = hi >= lo ? (size_t)hi - lo : 0;          // bytes taken from the caller's arena
     if (staged) {
         if (hi > ctx->staged_len) return FABGPU_EINVAL;
+        if (tail_used && ((size_t)tbase < round_up(ctx->staged_len, 64) || (size_t)tbase + b->tail_len + 128 > ctx->staged_cap)) return FABGPU_EINVAL;
         lo = 0;                                           // offsets are offsets into the staged bytes
         span = ctx->staged_len;
     } else if (span && !arena) {
         return FABGPU_EINVAL;
     }
+    // extent of the device arena: the caller's bytes, then (if used) zero padding up to tail_base and the tail
+    const size_t extent = tail_used ? (size_t)tbase - lo + b->tail_len : span;
     const size_t fb = n * 32, ib = round_up(n * 4, 64), pob = round_up((npre + 1) * 4, 64), words = (n + 63) / 64;
-    const size_t st_off = round_up(words * 8, 64), ab = round_up(span, 4) + 64;
+    const size_t st_off = round_up(words * 8, 64), ab = round_up(extent, 4) + 64;
+    const size_t dg_off = round_up(st_off + n, 64);        // out buffer: verdict words | status bytes | digests
     int rc;
     if ((!staged && (rc = ctx->arena.ensure(ab + 64))) || (rc = ctx->offs.ensure(noff * 4)) || (rc = ctx->fields.ensure(4 * fb + ib)) ||
-        (rc = ctx->out.ensure(st_off + n)) || (rc = ctx->pre.ensure(pob + ib + (size_t)m * 32 + 64)))
+        (rc = ctx->out.ensure(dg_off + (b->digests ? fb : 0))) || (rc = ctx->pre.ensure(pob + ib + (size_t)m * 32 + 64)))
         return rc;
     // small arenas go through the pinned staging buffer; big ones (a marshalled block) are handed to the driver directly -
     // one copy less on the host (the tail padding the kernels may touch is zeroed on the device)
@@ -856,13 +908,34 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     if (!staged && !direct) {
         if (span) memcpy(ctx->arena.h, arena + lo, span);
         memset((uint8_t*)ctx->arena.h + span, 0, ab - span);
+        if (tail_used) memcpy((uint8_t*)ctx->arena.h + (tbase - lo), b->tail, b->tail_len);
+    }
+    if (tail_used && (staged || direct)) {                 // the tail travels through its own pinned staging
+        if ((rc = ctx->tailbuf.ensure(b->tail_len))) return rc;
+        memcpy(ctx->tailbuf.h, b->tail, b->tail_len);
     }
     uint32_t* ho = (uint32_t*)ctx->offs.h;
-    for (size_t i = 0; i < noff; i++) ho[i] = b->off[i] - lo;
+    if (spans) {
+        for (size_t i = 0; i < n; i++) {                   // an empty span carries no address
+            const uint32_t s0 = b->off[2 * i], s1 = b->off[2 * i + 1];
+            ho[2 * i] = s1 > s0 ? s0 - lo : 0;
+            ho[2 * i + 1] = s1 > s0 ? s1 - lo : 0;
+        }
+    } else {
+        for (size_t i = 0; i < noff; i++) ho[i] = b->off[i] - lo;
+    }
     uint8_t* ph = (uint8_t*)ctx->pre.h;
     if (m) {
         uint32_t* po = (uint32_t*)ph;
-        for (size_t p = 0; p < npre; p++) po[p] = b->pre_off[p] - lo;
+        if (spans) {
+            for (uint32_t p = 0; p < m; p++) {
+                const uint32_t s0 = b->pre_off[2 * p], s1 = b->pre_off[2 * p + 1];
+                po[2 * p] = s1 > s0 ? s0 - lo : 0;
+                po[2 * p + 1] = s1 > s0 ? s1 - lo : 0;
+            }
+        } else {
+            for (size_t p = 0; p < npre; p++) po[p] = b->pre_off[p] - lo;
+        }
         memcpy(ph + pob, b->pre_idx, n * 4);
     }
     uint8_t* fh = (uint8_t*)ctx->fields.h;
@@ -875,9 +948,15 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     hipError_t err;
     if (staged) {
         err = hipSuccess;                                 // fabgpu_arena_stage put the bytes (and their zero tail) there
+        if (tail_used) {
+            err = hipMemcpyAsync((uint8_t*)ctx->d_staged + tbase, ctx->tailbuf.h, b->tail_len, hipMemcpyHostToDevice, ctx->stream);
+            if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)ctx->d_staged + tbase + b->tail_len, 0, 128, ctx->stream);
+        }
     } else if (direct) {
         err = hipMemcpyAsync(ctx->arena.d, arena + lo, span, hipMemcpyHostToDevice, ctx->stream);
         if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)ctx->arena.d + span, 0, ab - span, ctx->stream);
+        if (err == hipSuccess && tail_used)
+            err = hipMemcpyAsync((uint8_t*)ctx->arena.d + (tbase - lo), ctx->tailbuf.h, b->tail_len, hipMemcpyHostToDevice, ctx->stream);
     } else {
         err = hipMemcpyAsync(ctx->arena.d, ctx->arena.h, ab, hipMemcpyHostToDevice, ctx->stream);
     }
@@ -891,7 +970,9 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     fabgpu_identity_batch d = *b;
     d.flags = b->flags & FABGPU_IDB_SPANS;
     d.arena = staged ? ctx->d_staged : ctx->arena.d;
-    d.arena_bytes = staged ? round_up(span, 4) + 64 : ab;
+    d.arena_bytes = staged ? round_up(tail_used ? (size_t)tbase + b->tail_len : span, 4) + 64 : ab;
+    d.tail = nullptr;
+    d.tail_base = d.tail_len = 0;
     d.off = (const uint32_t*)ctx->offs.d;
     d.n_prefixes = m;
     d.pre_off = m ? (const uint32_t*)pd : nullptr;
@@ -906,6 +987,7 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     }
     d.verdict_bits = dout;
     d.status = b->status ? dout + st_off : nullptr;
+    d.digests = b->digests ? dout + dg_off : nullptr;
     const size_t gsb = round_up((size_t)ng * 24, 64), gob = round_up(((size_t)ng + 1) * 4, 64), gscr = round_up((size_t)gtotal, 4) + 64;
     if (ng) {
         if ((rc = ctx->gath.ensure(gsb + gob + (size_t)ng * 32))) return rc;
@@ -939,13 +1021,14 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     }
     rc = fabgpu_identity_verify_batch_dev(ctx, &d, m ? pd + pob + ib : nullptr, ctx->stream);
     if (rc) return rc;
-    err = hipMemcpyAsync(ctx->out.h, dout, b->status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    err = hipMemcpyAsync(ctx->out.h, dout, b->digests ? dg_off + fb : (b->status ? st_off + n : words * 8), hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess && ng)
         err = hipMemcpyAsync((uint8_t*)ctx->gath.h + gsb + gob, (uint8_t*)ctx->gath.d + gsb + gob, (size_t)ng * 32, hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
     if (err != hipSuccess) return hip_to_rc(err);
     memcpy(b->verdict_bits, ctx->out.h, words * 8);
     if (b->status) memcpy(b->status, (uint8_t*)ctx->out.h + st_off, n);
+    if (b->digests) memcpy(b->digests, (uint8_t*)ctx->out.h + dg_off, fb);
     if (ng) memcpy(b->gather_digests, (uint8_t*)ctx->gath.h + gsb + gob, (size_t)ng * 32);
     return FABGPU_OK;
 }

@@ -20,6 +20,7 @@ struct ShaPrefixArgs {
     const void* pre_idx = nullptr;
     void* mid_scratch = nullptr;
     bool spans = false;   // off / pre_off hold (start, end) pairs
+    void* digests = nullptr;   // optional out (device): n x 32 bytes, the digest of every message
 };
 struct VerifyGeom {
     uint32_t block;   // threads per workgroup

@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_kernel(uint
         uint32_t ic = active ? i : (n - 1);
         uint32_t h[8];
         sha256_message(arena32, arena_words, off, pre, ic, active, h);
+        emit_digest(pre, i, active, h);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
         KeyTab8 kt{ktabs[kok ? kid : 0]};
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_keyed_pair_kernel
         uint32_t ic = active ? i : (n - 1);
         uint32_t h[8];
         sha256_message(arena32, arena_words, off, pre, ic, active, h);
+        emit_digest(pre, i, active && !odd, h);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
         const int32_t* kt = ktabs[kok ? kid : 0];
@@ -266,6 +268,7 @@ __global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_pair_kernel(uint3
         uint32_t ic = active ? i : (n - 1);
         uint32_t h[8];
         sha256_message(arena32, arena_words, off, pre, ic, active, h);
+        emit_digest(pre, i, active && !odd, h);
         u256 vqx, vqy, ve, vr, vs;
 #pragma unroll
         for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];
@@ -295,6 +298,7 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_kernel(uint32_t n
         uint32_t ic = active ? i : (n - 1);
         uint32_t h[8];
         sha256_message(arena32, arena_words, off, pre, ic, active, h);
+        emit_digest(pre, i, active, h);
         u256 vqx, vqy, ve, vr, vs;
 #pragma unroll
         for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];   // digest big-endian -> integer limbs
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(256) gather_spans_kernel(uint32_t n, const uin
 // ------------------------------------------------------------------------------------------------
 // Runs the mid-state kernel for a prefixed batch (no-op otherwise) and returns the descriptor the fused kernels take.
 static sha_prefixes launch_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st) {
-    sha_prefixes pre{nullptr, nullptr, nullptr, 0, pa.spans ? 1u : 0u};
+    sha_prefixes pre{nullptr, nullptr, nullptr, 0, pa.spans ? 1u : 0u, (uint32_t*)pa.digests};
     if (pa.m == 0 || pa.pre_idx == nullptr) return pre;
     dim3 grid((pa.m + 255) / 256), block(256);
     hipLaunchKernelGGL(sha256_midstate_kernel, grid, block, 0, st, pa.m, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),

@@ -50,7 +50,19 @@ class _IdBatch(ctypes.Structure):
                 ("verdict_bits", ctypes.c_void_p), ("status", ctypes.c_void_p), ("flags", ctypes.c_uint32),
                 ("n_gather", ctypes.c_uint32), ("gather_spans", ctypes.c_void_p), ("gather_digests", ctypes.c_void_p),
                 ("gather_off", ctypes.c_void_p), ("gather_scratch", ctypes.c_void_p), ("gather_scratch_bytes", ctypes.c_size_t),
-                ("stage_token", ctypes.c_uint64)]
+                ("stage_token", ctypes.c_uint64), ("tail", ctypes.c_void_p), ("tail_base", ctypes.c_uint32), ("tail_len", ctypes.c_uint32),
+                ("digests", ctypes.c_void_p)]
+
+
+class _BlockPass(ctypes.Structure):
+    """fabgpu_block_pass (include/fabgpu_bccsp.h)."""
+    _fields_ = [("block", ctypes.c_void_p), ("len", ctypes.c_size_t), ("block_seq", ctypes.c_uint64), ("flags", ctypes.c_uint32),
+                ("cap_tx", ctypes.c_uint32), ("cap_tuples", ctypes.c_uint32),
+                ("n_tx", ctypes.c_uint32), ("n_tuples", ctypes.c_uint32), ("n_block_sigs", ctypes.c_uint32), ("memo_seeded", ctypes.c_uint32),
+                ("tail_base", ctypes.c_uint32), ("tail_len", ctypes.c_uint32), ("block_sigs_understood", ctypes.c_uint8),
+                ("tx_flags", ctypes.c_void_p), ("tx_type", ctypes.c_void_p), ("tuple_tx", ctypes.c_void_p), ("tuple_kind", ctypes.c_void_p),
+                ("tuple_status", ctypes.c_void_p), ("tuple_spans", ctypes.c_void_p), ("tuple_digest", ctypes.c_void_p),
+                ("tuple_hashed", ctypes.c_void_p), ("tuple_qxy", ctypes.c_void_p), ("tail", ctypes.c_void_p), ("tail_cap", ctypes.c_uint32)]
 
 
 class _Cfg(ctypes.Structure):
@@ -73,7 +85,8 @@ ABI_SYMBOLS = [
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
     "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_block_hash_checks",
-    "fabgpu_synth_batch",
+    "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_evict_block",
+    "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
 ]
 
 _lib = None
@@ -142,6 +155,14 @@ def load():
     L.fabgpu_csp_idemix_issuer_import.argtypes = [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, _sz]
     L.fabgpu_csp_idemix_nym_verify_batch.argtypes = [_vp, ctypes.c_int64, _sz, _u8p, _u32p, _u8p, _u32p, _u8p, _u32p, _u8p, _u8p, ctypes.c_char_p, _sz]
     L.fabgpu_block_hash_checks.argtypes = [_u8p, _sz, ctypes.c_uint32, _u32p, _u32p, _u8p, _u32p, _u32p]
+    L.fabgpu_csp_block_preverify2.argtypes = [_vp, ctypes.POINTER(_BlockPass)]
+    L.fabgpu_csp_memo_lookup.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz, _u8p]
+    L.fabgpu_csp_memo_evict_block.argtypes = [_vp, ctypes.c_uint64, _u64p]
+    L.fabgpu_csp_memo_stats.argtypes = [_vp, _u64p, _u64p, _u64p, _u64p]
+    L.fabgpu_csp_memo_set_capacity.argtypes = [_vp, ctypes.c_uint64]
+    L.fabgpu_csp_identity_cache_limits.argtypes = [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
+    L.fabgpu_csp_identity_cache_size.argtypes = [_vp, _u64p]
+    L.fabgpu_block_tuples.argtypes = [_u8p, _sz, ctypes.c_uint32, _u32p, _u32p, _u8p, _u32p, _u8p, ctypes.c_uint32, _u32p, _u32p]
     L.fabgpu_x509_p256_pubkey.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
     _lib = L
@@ -613,6 +634,36 @@ def block_hash_checks(block: bytes):
                 for j in range(m)]
 
 
+TUPLE_CREATOR, TUPLE_ENDORSEMENT, TUPLE_BLOCK_SIG = 0, 1, 2
+BLOCK_LEVEL_TX = 0xFFFFFFFF
+
+
+def block_tuples(block: bytes):
+    """Every (identity, message, signature) tuple the pre-verify pass derives from a marshalled block (pure host).
+    Returns (tuples, virtual_arena): tuples = list of dict(tx, kind, identity, prefix, suffix, sig) with (start, length) spans into
+    virtual_arena = block || zero padding || tail (the orderer block-signature messages the walker builds; block_prepass.h)."""
+    buf = np.frombuffer(block, dtype=np.uint8)
+    cap, tcap = 4096, 1 << 16
+    while True:
+        n, tl, tb = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+        tx, kind, sp, tail = np.zeros(cap, np.uint32), np.zeros(cap, np.uint8), np.zeros(cap * 8, np.uint32), np.zeros(tcap, np.uint8)
+        rc = load().fabgpu_block_tuples(_p8(buf), buf.size, cap, ctypes.byref(n), tx.ctypes.data_as(_u32p), _p8(kind), sp.ctypes.data_as(_u32p),
+                                        _p8(tail), tcap, ctypes.byref(tl), ctypes.byref(tb))
+        if rc == -5:
+            cap, tcap = max(cap, n.value), max(tcap, tl.value)
+            continue
+        _check(rc, "fabgpu_block_tuples")
+        arena = bytes(block) + b"\0" * (tb.value - len(block)) + bytes(tail[:tl.value])
+        names = ("identity", "prefix", "suffix", "sig")
+        out = []
+        for i in range(n.value):
+            d = dict(tx=int(tx[i]), kind=int(kind[i]))
+            for k, nm in enumerate(names):
+                d[nm] = (int(sp[8 * i + 2 * k]), int(sp[8 * i + 2 * k + 1]))
+            out.append(d)
+        return out, arena
+
+
 def x509_p256_pubkey(cert: bytes, pem: bool = True) -> Optional[Tuple[bytes, bytes]]:
     """(qx, qy) of a P-256 x509 certificate, or None."""
     qx, qy = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
@@ -641,6 +692,60 @@ def preverify_block(csp: "GPUCSP", block: bytes):
         a, b = n_tx.value, n_tu.value
         return dict(tx_flags=tx_flags[:a].copy(), tx_type=tx_type[:a].copy(), tuple_tx=t_tx[:b].copy(), tuple_kind=t_kind[:b].copy(),
                     tuple_status=t_st[:b].copy())
+
+
+PASS_SEED_MEMO, PASS_NO_BLOCK_SIGS = 1, 2
+TUPLE_ST_SKIPPED = 8
+
+
+def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo: bool = False, block_sigs: bool = True):
+    """fabgpu_csp_block_preverify2: the pass with verdicts tied to bytes.  Returns dict(tx_flags, tx_type, tuple_tx, tuple_kind,
+    tuple_status, tuple_spans (n x 8), tuple_digest (n x 32), tuple_hashed, tuple_qxy (n x 64), n_block_sigs, block_sigs_understood,
+    memo_seeded, arena = block || padding || tail)."""
+    buf = np.frombuffer(block, dtype=np.uint8)
+    cap_tx, cap_tu = getattr(csp, "_pass_caps", (1024, 4096))
+    tail_cap = 1 << 16
+    while True:
+        a = dict(tx_flags=np.zeros(cap_tx, np.uint8), tx_type=np.zeros(cap_tx, np.uint8), tuple_tx=np.zeros(cap_tu, np.uint32),
+                 tuple_kind=np.zeros(cap_tu, np.uint8), tuple_status=np.zeros(cap_tu, np.uint8), tuple_spans=np.zeros((cap_tu, 8), np.uint32),
+                 tuple_digest=np.zeros((cap_tu, 32), np.uint8), tuple_hashed=np.zeros(cap_tu, np.uint8), tuple_qxy=np.zeros((cap_tu, 64), np.uint8),
+                 tail=np.zeros(tail_cap, np.uint8))
+        ps = _BlockPass()
+        ps.block, ps.len, ps.block_seq = buf.ctypes.data, buf.size, block_seq
+        ps.flags = (PASS_SEED_MEMO if seed_memo else 0) | (0 if block_sigs else PASS_NO_BLOCK_SIGS)
+        ps.cap_tx, ps.cap_tuples, ps.tail_cap = cap_tx, cap_tu, tail_cap
+        for k, v in a.items():
+            setattr(ps, k, v.ctypes.data)
+        rc = csp._L.fabgpu_csp_block_preverify2(csp._h, ctypes.byref(ps))
+        if rc == -5:
+            cap_tx, cap_tu, tail_cap = max(cap_tx, ps.n_tx), max(cap_tu, ps.n_tuples), max(tail_cap, ps.tail_len)
+            csp._pass_caps = (cap_tx, cap_tu)
+            continue
+        _check(rc, "fabgpu_csp_block_preverify2")
+        nt, nu = ps.n_tx, ps.n_tuples
+        out = {k: (v[:nt].copy() if k.startswith("tx_") else v[:nu].copy()) for k, v in a.items() if k != "tail"}
+        out.update(n_block_sigs=ps.n_block_sigs, block_sigs_understood=bool(ps.block_sigs_understood), memo_seeded=ps.memo_seeded,
+                   arena=bytes(block) + b"\0" * (ps.tail_base - len(block)) + bytes(a["tail"][:ps.tail_len]))
+        return out
+
+
+def memo_lookup(csp: "GPUCSP", qx32: bytes, qy32: bytes, sig: bytes, digest: bytes) -> Optional[int]:
+    """The bccsp.Verify(k, sig, digest) question against the verdict memo: tuple status on a hit, None on a miss (ask bccsp/sw)."""
+    st = ctypes.c_uint8(255)
+    rc = csp._L.fabgpu_csp_memo_lookup(csp._h, qx32, qy32, sig, len(sig), digest, len(digest), ctypes.byref(st))
+    return int(st.value) if rc == 0 else None
+
+
+def memo_evict_block(csp: "GPUCSP", block_seq: int) -> int:
+    g = ctypes.c_uint64(0)
+    _check(csp._L.fabgpu_csp_memo_evict_block(csp._h, block_seq, ctypes.byref(g)), "fabgpu_csp_memo_evict_block")
+    return int(g.value)
+
+
+def memo_stats(csp: "GPUCSP"):
+    v = [ctypes.c_uint64(0) for _ in range(4)]
+    _check(csp._L.fabgpu_csp_memo_stats(csp._h, *[ctypes.byref(x) for x in v]), "fabgpu_csp_memo_stats")
+    return dict(entries=v[0].value, hits=v[1].value, misses=v[2].value, evicted=v[3].value)
 
 
 def validate_block_endorsements(csp: GPUCSP, txs) -> np.ndarray:

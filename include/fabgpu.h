@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FABGPU_ABI_VERSION 2
+#define FABGPU_ABI_VERSION 3
 
 /* ---- return codes (infrastructure only) ---- */
 #define FABGPU_OK 0
@@ -166,6 +166,19 @@ typedef struct fabgpu_identity_batch {
     void* gather_scratch;            /* _dev only */
     size_t gather_scratch_bytes;     /* _dev only: size of the gather_scratch allocation */
     uint64_t stage_token;            /* host variant with FABGPU_IDB_ARENA_STAGED: the token fabgpu_arena_stage returned */
+    /* ABI v3, host variant: a TAIL - bytes that are not in the caller's arena but belong to the batch.  The orderers' signatures over a
+     * block sign  Metadata.value || signature_header || ASN.1(block header)  (internal/peer/gossip/mcs.go:166-193,
+     * protoutil/blockutils.go:38-58): the host builds those few hundred bytes, and they ride in the same submission as the block's
+     * other signatures.  Offsets >= tail_base address tail[offset - tail_base]; tail_base must be >= the end of every arena span used
+     * and a multiple of 64; a span may not straddle tail_base.  tail == NULL or tail_len == 0: none.  (_dev callers simply place such
+     * bytes in their device arena.) */
+    const void* tail;
+    uint32_t tail_base;
+    uint32_t tail_len;
+    /* ABI v3: optional out, n x 32 bytes - the SHA-256 of every message exactly as the fused kernel computed and verified it.
+     * bccsp.Verify(k, signature, digest) is the question the Go validators ask later (msp/identities.go:188), so a verdict memo
+     * must be keyed on this digest, not on a second hash of bytes some other parser extracted.  NULL = digests stay on the chip. */
+    void* digests;
 } fabgpu_identity_batch;
 #define FABGPU_IDB_SPANS 1u /* off holds n (start, end) pairs and pre_off n_prefixes pairs: messages are arbitrary sub-slices of the arena
                              (a marshalled block), not consecutive */

@@ -67,6 +67,56 @@ int fabgpu_synth_batch(size_t n, uint64_t seed, uint32_t invalid_permille, const
 int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len, uint32_t* n_tx, uint8_t* tx_flags, uint8_t* tx_type,
                                uint32_t cap_tx, uint32_t* n_tuples, uint32_t* tuple_tx, uint8_t* tuple_kind, uint8_t* tuple_status,
                                uint32_t cap_tuples);
+/* ---- the pass, second form: verdicts tied to the BYTES they were computed over, the orderers' block signatures, the verdict memo ----
+ * Everything fabgpu_csp_block_preverify returns, plus per tuple: the spans of (identity, prefix, suffix, signature) in the virtual arena
+ * block || padding || tail (see fabgpu_block_tuples), the SHA-256 digest of the signed message AS THE DEVICE COMPUTED IT, and the
+ * P-256 key the identity carries.  A consumer must key on these (never on tuple position): a crafted envelope could make another
+ * parser see other bytes; the walker refuses envelopes with repeated singular fields for the same reason (tx_flags = 3).
+ * Tuples of kind 2 (tx = 0xFFFFFFFF, listed last) are the orderers' signatures over the block - the SignedData MCS.VerifyBlock hands
+ * to the BlockValidation policy (internal/peer/gossip/mcs.go:166-193).  BlockDataHash (one serial SHA-256 over the whole BlockData,
+ * protoutil/blockutils.go:65-68) stays with the caller: a single SHA-256 stream cannot be parallelised.
+ * FABGPU_PASS_SEED_MEMO: every tuple the device hashed and decided is remembered under `block_seq` as
+ * (key X||Y, signature bytes, digest) -> status; fabgpu_csp_memo_lookup answers the bccsp.Verify(k, sig, digest) calls the unchanged
+ * validators make afterwards (msp/identities.go:188) and fabgpu_csp_memo_evict_block drops the block's entries when Validate returns. */
+#define FABGPU_PASS_SEED_MEMO 1u
+#define FABGPU_PASS_NO_BLOCK_SIGS 2u /* do not verify the orderers' block signatures (their tuples report status 8) */
+typedef struct fabgpu_block_pass {
+    /* in */
+    const uint8_t* block;
+    size_t len;
+    uint64_t block_seq;
+    uint32_t flags;              /* FABGPU_PASS_* */
+    uint32_t cap_tx, cap_tuples; /* capacity of the arrays below */
+    /* out: counts (always set; FABGPU_ETOOBIG when a capacity is too small - nothing was launched) */
+    uint32_t n_tx, n_tuples, n_block_sigs, memo_seeded;
+    uint32_t tail_base, tail_len;
+    uint8_t block_sigs_understood; /* 1: metadata[SIGNATURES] parsed (kind-2 tuples are complete) */
+    /* out: arrays, caller-allocated, any may be NULL */
+    uint8_t* tx_flags;           /* cap_tx */
+    uint8_t* tx_type;            /* cap_tx */
+    uint32_t* tuple_tx;          /* cap_tuples */
+    uint8_t* tuple_kind;         /* cap_tuples: 0 creator, 1 endorsement, 2 block signature */
+    uint8_t* tuple_status;       /* cap_tuples */
+    uint32_t* tuple_spans;       /* cap_tuples x 8 */
+    uint8_t* tuple_digest;       /* cap_tuples x 32; zero where tuple_hashed[i] == 0 */
+    uint8_t* tuple_hashed;       /* cap_tuples */
+    uint8_t* tuple_qxy;          /* cap_tuples x 64 */
+    uint8_t* tail;               /* tail_cap bytes: the block-signature messages (optional) */
+    uint32_t tail_cap;
+} fabgpu_block_pass;
+int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* pass);
+/* 0: hit, *status = 0 valid / 1 arithmetic reject / 2 high-S / 3 r out of range (the reference rejects: ask bccsp/sw for its error
+ * text); 1: miss -> bccsp/sw.  Never an infrastructure error: a miss is always a correct answer. */
+int fabgpu_csp_memo_lookup(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest,
+                           size_t dlen, uint8_t* status);
+int fabgpu_csp_memo_evict_block(fabgpu_csp* csp, uint64_t block_seq, uint64_t* evicted);
+int fabgpu_csp_memo_stats(fabgpu_csp* csp, uint64_t* entries, uint64_t* hits, uint64_t* misses, uint64_t* evicted);
+int fabgpu_csp_memo_set_capacity(fabgpu_csp* csp, uint64_t max_entries);
+/* Bounds of the pass's identity cache (identities come out of unvalidated blocks): at most max_identities cached (LRU, like
+ * msp/cache), a device comb table only for an identity named register_after_hits times, at most max_registered_keys tables. */
+int fabgpu_csp_identity_cache_limits(fabgpu_csp* csp, uint64_t max_identities, uint64_t max_registered_keys, uint32_t register_after_hits);
+int fabgpu_csp_identity_cache_size(fabgpu_csp* csp, uint64_t* identities);
+
 /* pure host helpers of the pass (no device): block structure, and the P-256 key of an x509 certificate */
 int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
                        char* channel_id, size_t channel_cap);
@@ -75,6 +125,14 @@ int fabgpu_x509_p256_pubkey(const uint8_t* cert, size_t len, int is_pem, uint8_t
  * concatenation of the three (start, end) spans; all offsets into the block buffer.  FABGPU_ETOOBIG with *n_checks set if cap is small. */
 int fabgpu_block_hash_checks(const uint8_t* block, size_t len, uint32_t cap, uint32_t* n_checks, uint32_t* tx, uint8_t* kind, uint32_t* spans6,
                              uint32_t* expect2);
+
+/* every (identity, message, signature) tuple the pass derives from a block (pure host; tests compare it with an independent decoder
+ * and verify the tuples with the CPU oracle).  spans8[8i..8i+7] = (start, length) of identity, prefix, suffix, sig; the signed message is
+ * prefix || suffix.  Offsets address the virtual arena  block || zero padding up to *tail_base || tail : the orderers' signatures over the
+ * block (kind 2, tx 0xFFFFFFFF; internal/peer/gossip/mcs.go:166-193) sign  Metadata.value || signature_header ||
+ * protoutil.BlockHeaderBytes(header)  - bytes the walker has to build, returned in `tail` (may be NULL). kind: 0 creator, 1 endorsement. */
+int fabgpu_block_tuples(const uint8_t* block, size_t len, uint32_t cap, uint32_t* n_tuples, uint32_t* tx, uint8_t* kind, uint32_t* spans8,
+                        uint8_t* tail, uint32_t tail_cap, uint32_t* tail_len, uint32_t* tail_base);
 
 /* ---- idemix pseudonym signatures (creator signatures of idemix MSPs): host mirror of bccsp/idemix/handlers ----
  * fabgpu_csp_idemix_issuer_import: IssuerPublicKeyImporter.KeyImport (bccsp/idemix/handlers/issuer.go:115-136) for the

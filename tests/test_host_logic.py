@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(fabgpu.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.fabgpu_abi_version() == 2      # 2: fabgpu_identity_batch grew the gather_* fields
+    assert L.fabgpu_abi_version() == 3      # 3: fabgpu_identity_batch grew tail / digests (2: the gather_* fields)
     assert fabgpu.strerror(0) == "ok" and "bccsp/sw" in fabgpu.strerror(-2)
 
 
