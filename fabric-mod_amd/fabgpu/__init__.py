@@ -374,9 +374,11 @@ class Context:
         return int(tok.value)
 
     def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True, spans=False,
-                              gather_spans=None, stage_token=0):
+                              gather_spans=None, stage_token=0, want_digests=False, tail=None, tail_base=0):
         """fabgpu_identity_verify_batch: message i = [prefix pre_idx[i]] || arena[off[i], off[i+1]); keys by value or by id.
-        gather_spans (m x 6 u32: three (start, end) pieces per gathered message): also returns their m x 32 digest bytes."""
+        gather_spans (m x 6 u32: three (start, end) pieces per gathered message): also returns their m x 32 digest bytes.
+        want_digests: also returns (last) the n x 32 message digests as the fused kernel computed them.  tail / tail_base: bytes that
+        are not in the arena but addressed at offsets >= tail_base (spans mode)."""
         arena, r, s = map(_a8, (arena, r, s))
         off = np.ascontiguousarray(off, dtype=np.uint32)
         n = off.size // 2 if spans else off.size - 1
@@ -400,6 +402,15 @@ class Context:
         st = np.zeros(n, dtype=np.uint8) if want_status else None
         b.verdict_bits = bits.ctypes.data
         b.status = st.ctypes.data if want_status else None
+        mdig = None
+        if want_digests:
+            mdig = np.zeros((n, 32), dtype=np.uint8)
+            keep.append(mdig)
+            b.digests = mdig.ctypes.data
+        if tail is not None:
+            tail = _a8(tail)
+            keep.append(tail)
+            b.tail, b.tail_base, b.tail_len = tail.ctypes.data, tail_base, tail.size
         dig = None
         if gather_spans is not None:
             gather_spans = np.ascontiguousarray(gather_spans, dtype=np.uint32).reshape(-1, 6)
@@ -407,9 +418,8 @@ class Context:
             keep += [gather_spans, dig]
             b.n_gather, b.gather_spans, b.gather_digests = gather_spans.shape[0], gather_spans.ctypes.data, dig.ctypes.data
         _check(self._L.fabgpu_identity_verify_batch(self._h, ctypes.byref(b)), "fabgpu_identity_verify_batch")
-        if dig is not None:
-            return unpack_bits(bits, n), st, dig
-        return unpack_bits(bits, n), st
+        res = (unpack_bits(bits, n), st) + ((dig,) if dig is not None else ()) + ((mdig,) if mdig is not None else ())
+        return res
 
     def identity_verify_batch_dev(self, desc: "_IdBatch", mid_scratch, stream=0):
         _check(self._L.fabgpu_identity_verify_batch_dev(self._h, ctypes.byref(desc), mid_scratch or None, stream or None),

@@ -21,52 +21,110 @@
 static const uint8_t HALF_N[32] = {0x7f, 0xff, 0xff, 0xff, 0x80, 0x00, 0x00, 0x00, 0x7f, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
                                    0xde, 0x73, 0x7d, 0x56, 0xd3, 0x8b, 0xcf, 0x42, 0x79, 0xdc, 0xe5, 0x61, 0x7e, 0x31, 0x92, 0xa8};
 
-/* status as include/fabgpu.h: 0 valid, 1 bad math, 2 high-S, 3 range, 4 off-curve */
-static int one(const EC_GROUP *grp, const uint8_t *qx, const uint8_t *qy, const uint8_t *e, const uint8_t *r, const uint8_t *s) {
+/* Per-thread verifier state: everything OpenSSL would otherwise allocate per tuple (EC_KEY, EC_POINT, BIGNUMs, BN_CTX, ECDSA_SIG) is
+ * made once per worker and reused - round 1 built an EC_KEY per tuple with EC_KEY_set_public_key_affine_coordinates (which runs
+ * EC_KEY_check_key: a full extra scalar multiplication by n) inside a 14 ms parallel region, and 256 threads delivered 8 cores' worth. */
+typedef struct {
+    EC_GROUP *grp;
+    EC_KEY *key;
+    EC_POINT *pt;
+    BIGNUM *x, *y, *r, *s;
+    BN_CTX *bn;
+    ECDSA_SIG *sig;
+} worker;
+
+static void worker_init(worker *w) {
+    w->grp = EC_GROUP_new_by_curve_name(NID_X9_62_prime256v1);
+    w->key = EC_KEY_new();
+    EC_KEY_set_group(w->key, w->grp);
+    w->pt = EC_POINT_new(w->grp);
+    w->x = BN_new(); w->y = BN_new();
+    w->bn = BN_CTX_new();
+    w->sig = ECDSA_SIG_new();
+    w->r = BN_new(); w->s = BN_new();
+    ECDSA_SIG_set0(w->sig, w->r, w->s);          /* the signature object owns r and s; they are overwritten in place per tuple */
+}
+static void worker_free(worker *w) {
+    ECDSA_SIG_free(w->sig);
+    BN_CTX_free(w->bn);
+    BN_free(w->x); BN_free(w->y);
+    EC_POINT_free(w->pt);
+    EC_KEY_free(w->key);
+    EC_GROUP_free(w->grp);
+}
+
+/* status as include/fabgpu.h: 0 valid, 1 bad math, 2 high-S, 3 range, 4 off-curve.
+ * bccsp/sw order of the gates: r, s > 0 (utils/ecdsa.go:59-64), low-S (sw/ecdsa.go:47-54), then ecdsa.Verify (r < n inside). */
+static int one(worker *w, const uint8_t *qx, const uint8_t *qy, const uint8_t *e, const uint8_t *r, const uint8_t *s) {
     static const uint8_t zero[32] = {0};
     if (!memcmp(r, zero, 32) || !memcmp(s, zero, 32)) return 3;
     if (memcmp(s, HALF_N, 32) > 0) return 2;
-    int st = 1;
-    EC_KEY *key = EC_KEY_new();
-    EC_KEY_set_group(key, grp);
-    BIGNUM *x = BN_bin2bn(qx, 32, NULL), *y = BN_bin2bn(qy, 32, NULL);
-    if (EC_KEY_set_public_key_affine_coordinates(key, x, y) != 1) st = 4;
-    else {
-        ECDSA_SIG *sig = ECDSA_SIG_new();
-        ECDSA_SIG_set0(sig, BN_bin2bn(r, 32, NULL), BN_bin2bn(s, 32, NULL));
-        const BIGNUM *order = EC_GROUP_get0_order(grp);
-        const BIGNUM *br = ECDSA_SIG_get0_r(sig);
-        if (BN_cmp(br, order) >= 0) st = 3;
-        else st = ECDSA_do_verify(e, 32, sig, key) == 1 ? 0 : 1;
-        ECDSA_SIG_free(sig);
-    }
-    BN_free(x); BN_free(y); EC_KEY_free(key);
-    return st;
+    BN_bin2bn(qx, 32, w->x);
+    BN_bin2bn(qy, 32, w->y);
+    /* on-curve check only (what x509.ParseCertificate guarantees for the reference's keys) - no EC_KEY_check_key */
+    if (EC_POINT_set_affine_coordinates(w->grp, w->pt, w->x, w->y, w->bn) != 1) return 4;
+    if (EC_KEY_set_public_key(w->key, w->pt) != 1) return 4;
+    BN_bin2bn(r, 32, w->r);
+    BN_bin2bn(s, 32, w->s);
+    if (BN_cmp(w->r, EC_GROUP_get0_order(w->grp)) >= 0) return 3;
+    return ECDSA_do_verify(e, 32, w->sig, w->key) == 1 ? 0 : 1;
 }
 
 void ossl_p256_verify_batch(size_t n, const uint8_t *qx, const uint8_t *qy, const uint8_t *e, const uint8_t *r,
                             const uint8_t *s, uint8_t *status) {
 #pragma omp parallel
     {
-        EC_GROUP *grp = EC_GROUP_new_by_curve_name(NID_X9_62_prime256v1);
+        worker w;
+        worker_init(&w);
 #pragma omp for schedule(dynamic, 64)
         for (long i = 0; i < (long)n; i++)
-            status[i] = (uint8_t)one(grp, qx + 32 * i, qy + 32 * i, e + 32 * i, r + 32 * i, s + 32 * i);
-        EC_GROUP_free(grp);
+            status[i] = (uint8_t)one(&w, qx + 32 * i, qy + 32 * i, e + 32 * i, r + 32 * i, s + 32 * i);
+        worker_free(&w);
     }
+}
+
+/* The timed leg of bench.py's cpu_baseline: `reps` passes over the same n tuples on exactly `threads` workers inside ONE parallel
+ * region (thread start-up and per-worker allocation stay outside the clock), statically chunked like validatorPoolSize goroutines
+ * draining a block.  Returns the wall seconds of the slowest worker between two barriers; status is written on the last pass. */
+#include <omp.h>
+double ossl_p256_verify_timed(size_t n, const uint8_t *qx, const uint8_t *qy, const uint8_t *e, const uint8_t *r, const uint8_t *s,
+                              uint8_t *status, int threads, int reps) {
+    double t0 = 0, t1 = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        worker w;
+        worker_init(&w);
+        /* warm: one tuple per worker touches every lazily initialised table of libcrypto */
+        if (n) (void)one(&w, qx, qy, e, r, s);
+#pragma omp barrier
+#pragma omp master
+        t0 = omp_get_wtime();
+        for (int rep = 0; rep < reps; rep++) {
+#pragma omp for schedule(dynamic, 16) nowait
+            for (long i = 0; i < (long)n; i++)
+                status[i] = (uint8_t)one(&w, qx + 32 * i, qy + 32 * i, e + 32 * i, r + 32 * i, s + 32 * i);
+        }
+#pragma omp barrier
+#pragma omp master
+        t1 = omp_get_wtime();
+        worker_free(&w);
+    }
+    return t1 - t0;
 }
 
 void ossl_sha256_p256_verify_batch(size_t n, const uint8_t *arena, const uint32_t *off, const uint8_t *qx, const uint8_t *qy,
                                    const uint8_t *r, const uint8_t *s, uint8_t *status) {
 #pragma omp parallel
     {
-        EC_GROUP *grp = EC_GROUP_new_by_curve_name(NID_X9_62_prime256v1);
+        worker w;
+        worker_init(&w);
 #pragma omp for schedule(dynamic, 64)
         for (long i = 0; i < (long)n; i++) {
             uint8_t d[32];
             SHA256(arena + off[i], off[i + 1] - off[i], d);
-            status[i] = (uint8_t)one(grp, qx + 32 * i, qy + 32 * i, d, r + 32 * i, s + 32 * i);
+            status[i] = (uint8_t)one(&w, qx + 32 * i, qy + 32 * i, d, r + 32 * i, s + 32 * i);
         }
-        EC_GROUP_free(grp);
+        worker_free(&w);
     }
 }

@@ -150,6 +150,74 @@ def test_full_size_cfg4_properties(ctx):
     assert (st[sample] == want).all()
 
 
+def test_full_size_cfg4_fused_kernel_300k(ctx):
+    """BASELINE.json configs[3] through the kernel it names: 100k tx x 3 = 300 000 messages of 1 856 B (prp 1024 shared by a tx's three
+    endorsements + endorser 832), SHA-256 FUSED ahead of the verify in one launch.  Every verdict bit against the generator's ground
+    truth (kind vector), 12 000 tuples - every mutated one among them - status-exact against the C oracle's own SHA-256 + verify,
+    idempotence, and the digests the fused kernel hands out against hashlib."""
+    import hashlib
+    n_tx, n, L = 100000, 300000, 1856
+    rng = np.random.default_rng(20260921)
+    arena = np.empty((n, L), dtype=np.uint8)
+    arena[:, :1024] = np.repeat(rng.integers(0, 256, size=(n_tx, 1024), dtype=np.uint8), 3, axis=0)
+    arena[:, 1024:] = rng.integers(0, 256, size=(n, L - 1024), dtype=np.uint8)
+    off = (np.arange(n + 1, dtype=np.uint64) * L).astype(np.uint32)
+    flat = arena.reshape(-1)
+    dig = ctx.sha256_batch(flat, off)
+    b = fabgpu.synth_batch(n, seed=5, invalid_permille=10, e_in=dig)
+    bits, st = ctx.sha256_p256_verify_batch(flat, off, b["qx"], b["qy"], b["r"], b["s"])
+    # kind 1 mutates e_out only: in hash mode the message decides, so those tuples stay valid
+    want_kind = np.array([0, 0, 1, 2, 1], dtype=np.uint8)[b["kind"]]
+    assert (st == want_kind).all() and (bits == (want_kind == 0)).all()
+    bad = np.nonzero(b["kind"] > 1)[0]
+    samp = np.unique(np.concatenate([bad, rng.choice(n, size=10000, replace=False)]))[:12000]
+    soff = (np.arange(len(samp) + 1, dtype=np.uint64) * L).astype(np.uint32)
+    want = coracle.sha256_verify_batch(arena[samp].reshape(-1), soff, b["qx"][samp], b["qy"][samp], b["r"][samp], b["s"][samp])
+    assert (st[samp] == want).all() and len(bad) > 1500
+    for i in rng.choice(n, size=500, replace=False):
+        assert dig[i].tobytes() == hashlib.sha256(arena[i].tobytes()).digest()
+    bits2, st2 = ctx.sha256_p256_verify_batch(flat, off, b["qx"], b["qy"], b["r"], b["s"])
+    assert (bits2 == bits).all() and (st2 == st).all()
+    # the same block with the prp handed over once per transaction (shared prefix, mid-state reuse) and digests handed out
+    pre = np.ascontiguousarray(arena[::3, :1024]).reshape(-1)
+    suf = np.ascontiguousarray(arena[:, 1024:]).reshape(-1)
+    flat2 = np.concatenate([pre, suf])
+    pre_off = (np.arange(n_tx + 1, dtype=np.uint64) * 1024).astype(np.uint32)
+    off2 = (n_tx * 1024 + np.arange(n + 1, dtype=np.uint64) * (L - 1024)).astype(np.uint32)
+    r3 = ctx.identity_verify_batch(flat2, off2, b["r"], b["s"], qx=b["qx"], qy=b["qy"], pre_off=pre_off, pre_idx=np.repeat(np.arange(n_tx, dtype=np.uint32), 3),
+                                   want_digests=True)
+    assert (r3[1] == st).all() and (r3[0] == bits).all()
+    assert (r3[2] == dig).all()                                       # 300 000 digests out of the fused kernel == the plain SHA-256 kernel's
+
+
+def test_arena_size_boundaries_of_the_32_bit_offsets(ctx):
+    """off[] is u32: the C ABI must refuse what it cannot address (FABGPU_ETOOBIG, an infrastructure error -> bccsp/sw), never wrap."""
+    import ctypes
+    L = fabgpu.load()
+    n = 4
+    z = np.zeros((n, 32), np.uint8)
+    words = np.zeros(1, np.uint64)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    u32 = ctypes.POINTER(ctypes.c_uint32)
+    # device entry point: an arena of 2^32 bytes and more is refused before anything is launched (no such allocation is touched)
+    for fn, args in ((L.fabgpu_sha256_batch_dev, (ctx.handle(), n, 1 << 20, (1 << 32), 1 << 20, 1 << 20, None)),
+                     (L.fabgpu_sha256_p256_verify_batch_dev, (ctx.handle(), n, 1 << 20, (1 << 32) + 5, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 1 << 20, None, None))):
+        assert fn(*args) == -5
+    # host entry point: descending offsets are inconsistent arguments, a tuple count beyond the staging limit is too big
+    off = np.array([0, 10, 5, 20, 30], dtype=np.uint32)
+    assert L.fabgpu_sha256_batch(ctx.handle(), n, np.zeros(64, np.uint8).ctypes.data_as(u8), off.ctypes.data_as(u32), np.zeros((n, 32), np.uint8).ctypes.data_as(u8)) == -1
+    assert L.fabgpu_p256_verify_batch(ctx.handle(), (0x7FFFFFF0 // 160) + 1, z.ctypes.data_as(u8), z.ctypes.data_as(u8), z.ctypes.data_as(u8), z.ctypes.data_as(u8),
+                                      z.ctypes.data_as(u8), words.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), None) == -5
+    # a large but legal arena: 1.2 GB of messages in one launch (2 000 messages of 600 000 bytes: 9 375 blocks per lane)
+    m, ml = 2000, 600000
+    big = np.random.default_rng(9).integers(0, 256, size=m * ml, dtype=np.uint8)
+    boff = (np.arange(m + 1, dtype=np.uint64) * ml).astype(np.uint32)
+    d = ctx.sha256_batch(big, boff)
+    import hashlib
+    for i in (0, 1, 777, m - 1):
+        assert d[i].tobytes() == hashlib.sha256(big[i * ml:(i + 1) * ml].tobytes()).digest()
+
+
 # ---- registered public keys (bccsp.KeyImport -> per-key comb table) --------------------------------------
 @pytest.mark.parametrize("n,nkeys", [(1, 1), (33, 2), (500, 16), (4097, 16), (33000, 16)])
 def test_registered_keys_pool_vs_oracle_and_vs_the_unkeyed_kernel(ctx, n, nkeys):
