@@ -200,13 +200,13 @@ def test_arena_size_boundaries_of_the_32_bit_offsets(ctx):
     u8 = ctypes.POINTER(ctypes.c_uint8)
     u32 = ctypes.POINTER(ctypes.c_uint32)
     # device entry point: an arena of 2^32 bytes and more is refused before anything is launched (no such allocation is touched)
-    for fn, args in ((L.fabgpu_sha256_batch_dev, (ctx.handle(), n, 1 << 20, (1 << 32), 1 << 20, 1 << 20, None)),
-                     (L.fabgpu_sha256_p256_verify_batch_dev, (ctx.handle(), n, 1 << 20, (1 << 32) + 5, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 1 << 20, None, None))):
+    for fn, args in ((L.fabgpu_sha256_batch_dev, (ctx.handle, n, 1 << 20, (1 << 32), 1 << 20, 1 << 20, None)),
+                     (L.fabgpu_sha256_p256_verify_batch_dev, (ctx.handle, n, 1 << 20, (1 << 32) + 5, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 1 << 20, None, None))):
         assert fn(*args) == -5
     # host entry point: descending offsets are inconsistent arguments, a tuple count beyond the staging limit is too big
     off = np.array([0, 10, 5, 20, 30], dtype=np.uint32)
-    assert L.fabgpu_sha256_batch(ctx.handle(), n, np.zeros(64, np.uint8).ctypes.data_as(u8), off.ctypes.data_as(u32), np.zeros((n, 32), np.uint8).ctypes.data_as(u8)) == -1
-    assert L.fabgpu_p256_verify_batch(ctx.handle(), (0x7FFFFFF0 // 160) + 1, z.ctypes.data_as(u8), z.ctypes.data_as(u8), z.ctypes.data_as(u8), z.ctypes.data_as(u8),
+    assert L.fabgpu_sha256_batch(ctx.handle, n, np.zeros(64, np.uint8).ctypes.data_as(u8), off.ctypes.data_as(u32), np.zeros((n, 32), np.uint8).ctypes.data_as(u8)) == -1
+    assert L.fabgpu_p256_verify_batch(ctx.handle, (0x7FFFFFF0 // 160) + 1, z.ctypes.data_as(u8), z.ctypes.data_as(u8), z.ctypes.data_as(u8), z.ctypes.data_as(u8),
                                       z.ctypes.data_as(u8), words.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), None) == -5
     # a large but legal arena: 1.2 GB of messages in one launch (2 000 messages of 600 000 bytes: 9 375 blocks per lane)
     m, ml = 2000, 600000
