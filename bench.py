@@ -143,6 +143,27 @@ def cpu_baseline(block, n, want):
                       "bccsp/sw (Go toolchain absent)"}
 
 
+def inprocess_multi_leg(world):
+    """The product library's own multi-GPU dispatcher (fabgpu_multi_*: one process, G contexts, ncclCommInitAll + ncclAllGather) on the
+    same node, in a SUBPROCESS with a hard timeout so that nothing it does can take the bench line with it.  The other ranks wait at
+    the barrier that follows; their GPUs are idle meanwhile."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                           "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                                                           "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_multi.py"), "--gpus", str(world)], capture_output=True, text=True,
+                           timeout=240, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout after 240 s"}
+    except Exception as e:                                          # never let this leg cost the line
+        return {"error": repr(e)}
+
+
 def fused_cfg3_leg(ctx, torch, np, fabgpu, coracle, steps):
     """BASELINE.json configs[3]: 100 000 tx x 3 endorsements, SHA-256 fused ahead of the verify, 1 GPU."""
     import hashlib
@@ -237,6 +258,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        cpu_group = dist.new_group(backend="gloo")                    # the closing wait is host-side: no rank spins a kernel on its GPU
 
     n_tx = args.tx
     n = n_tx * N_ENDORSE
@@ -368,6 +390,7 @@ def main():
         }
         if strong is not None:
             out["configs2_strong"] = strong
+            out["configs2_inprocess"] = inprocess_multi_leg(world)
         if extras:
             # PCIe-inclusive: the host-pointer ABI exactly as the cgo provider calls it (never `value`)
             ctx.p256_verify_batch(block["qx"], block["qy"], block["e"], block["r"], block["s"], want_status=False)
@@ -393,7 +416,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(block, n, want)                                         # ... and OpenSSL is timed
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=cpu_group)      # ranks > 0 wait here (on the host) while rank 0 runs its extra legs
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

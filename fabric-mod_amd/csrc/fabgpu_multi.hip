@@ -1,0 +1,309 @@
+// One batch, G devices (BASELINE.json configs[2] "same block sharded across 8 MI355X, RCCL all-gather of the
+// verdict bitmap over xGMI"): ONE process, one fabgpu context + one HIP stream per device, the batch cut into contiguous 64-aligned
+// shards (multi_plan.h), every shard uploaded from pinned staging and verified on its device, then ONE ncclAllGather (RCCL) of the
+// shard bitmaps - the merged bitmap is then resident on EVERY device (for a later on-device policy step) - and a single D2H from
+// device 0.  No other data-path collective exists: signatures are independent.
+//
+// RCCL is bound at run time (dlopen "librccl.so.1"): a peer with one GPU, or a box without RCCL, still loads libfabgpu.so; and
+// FABGPU_MULTI_HOST_MERGE replaces the collective by G small D2H copies (the survey's "the host could equally do G small D2H
+// copies") - also what a test uses to run several shards on ONE physical device, which RCCL refuses (duplicate device in a
+// communicator).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/fabgpu.h"
+#include "multi_plan.h"
+
+using namespace fab;
+
+namespace {
+
+// the five RCCL entry points this file needs, resolved once
+struct Rccl {
+    typedef void* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
+    void* so = nullptr;
+    bool ok = false;
+    static constexpr int kUint64 = 5;   // ncclUint64 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5)
+    bool load() {
+        if (ok) return true;
+        so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!so) return false;
+        CommInitAll = (int (*)(comm_t*, int, const int*))dlsym(so, "ncclCommInitAll");
+        CommDestroy = (int (*)(comm_t))dlsym(so, "ncclCommDestroy");
+        GroupStart = (int (*)())dlsym(so, "ncclGroupStart");
+        GroupEnd = (int (*)())dlsym(so, "ncclGroupEnd");
+        AllGather = (int (*)(const void*, void*, size_t, int, comm_t, hipStream_t))dlsym(so, "ncclAllGather");
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather;
+        return ok;
+    }
+};
+
+struct Dev {
+    int ordinal = 0;
+    fabgpu_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    void* h_in = nullptr;      // pinned staging of the shard: fields (+ message bytes + offsets in hash mode)
+    void* d_in = nullptr;
+    size_t in_cap = 0, din_cap = 0;
+    void* d_words = nullptr;   // this shard's verdict words (words_per_rank, zero padded)
+    void* d_merged = nullptr;  // G x words_per_rank after the all-gather
+    void* d_status = nullptr;
+    void* h_out = nullptr;     // pinned: merged words (device 0) / own words (host merge) | status bytes
+    size_t words_cap = 0, merged_cap = 0, status_cap = 0, out_cap = 0;
+};
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int hip_rc(hipError_t e) { return e == hipSuccess ? FABGPU_OK : (e == hipErrorOutOfMemory ? FABGPU_ENOMEM : FABGPU_ELAUNCH); }
+
+int grow(void** p, size_t* cap, size_t need, bool pinned) {
+    if (need <= *cap) return FABGPU_OK;
+    if (*p) { if (pinned) hipHostFree(*p); else hipFree(*p); }
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4 + 256;
+    hipError_t e = pinned ? hipHostMalloc(p, want, hipHostMallocDefault) : hipMalloc(p, want);
+    if (e != hipSuccess) { *p = nullptr; return FABGPU_ENOMEM; }
+    *cap = want;
+    return FABGPU_OK;
+}
+
+}  // namespace
+
+struct fabgpu_multi {
+    std::vector<Dev> dev;
+    std::vector<Rccl::comm_t> comms;
+    Rccl rccl;
+    bool host_merge = false;
+    std::mutex mu;
+};
+
+extern "C" {
+
+int fabgpu_multi_init(const int32_t* devices, int n_devices, uint32_t flags, fabgpu_multi** out) {
+    if (!out || n_devices <= 0 || n_devices > 64) return FABGPU_EINVAL;
+    if (flags & ~(uint32_t)FABGPU_MULTI_HOST_MERGE) return FABGPU_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
+    fabgpu_multi* m = new (std::nothrow) fabgpu_multi();
+    if (!m) return FABGPU_ENOMEM;
+    m->host_merge = (flags & FABGPU_MULTI_HOST_MERGE) != 0;
+    m->dev.resize((size_t)n_devices);
+    int rc = FABGPU_OK;
+    std::vector<int> ords((size_t)n_devices);
+    for (int g = 0; g < n_devices && rc == FABGPU_OK; g++) {
+        const int o = devices ? devices[g] : g;
+        if (o < 0 || o >= ndev) { rc = FABGPU_EINVAL; break; }
+        ords[g] = o;
+        m->dev[g].ordinal = o;
+        fabgpu_cfg cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.device = o;
+        rc = fabgpu_init(&cfg, &m->dev[g].ctx);                 // generator comb table per device: replicated, as the survey says
+        if (rc != FABGPU_OK) break;
+        if (hipSetDevice(o) != hipSuccess || hipStreamCreateWithFlags(&m->dev[g].stream, hipStreamNonBlocking) != hipSuccess) rc = FABGPU_ENODEV;
+    }
+    if (rc == FABGPU_OK && !m->host_merge) {
+        // duplicates cannot form a communicator; a single device needs none
+        bool dup = false;
+        for (int a = 0; a < n_devices; a++)
+            for (int b = a + 1; b < n_devices; b++) dup = dup || ords[a] == ords[b];
+        if (dup) rc = FABGPU_EINVAL;
+        else if (!m->rccl.load()) {
+            if (n_devices == 1) m->host_merge = true;            // nothing to gather from anybody else
+            else rc = FABGPU_ENODEV;
+        } else {
+            m->comms.assign((size_t)n_devices, nullptr);
+            if (m->rccl.CommInitAll(m->comms.data(), n_devices, ords.data()) != 0) {
+                m->comms.clear();
+                if (n_devices == 1) m->host_merge = true;
+                else rc = FABGPU_ENODEV;
+            }
+        }
+    }
+    if (rc != FABGPU_OK) {
+        fabgpu_multi_shutdown(m);
+        return rc;
+    }
+    *out = m;
+    return FABGPU_OK;
+}
+
+void fabgpu_multi_shutdown(fabgpu_multi* m) {
+    if (!m) return;
+    for (size_t g = 0; g < m->dev.size(); g++) {
+        Dev& d = m->dev[g];
+        hipSetDevice(d.ordinal);
+        if (d.stream) hipStreamSynchronize(d.stream);
+    }
+    for (auto c : m->comms)
+        if (c) m->rccl.CommDestroy(c);
+    for (size_t g = 0; g < m->dev.size(); g++) {
+        Dev& d = m->dev[g];
+        hipSetDevice(d.ordinal);
+        if (d.h_in) hipHostFree(d.h_in);
+        if (d.h_out) hipHostFree(d.h_out);
+        if (d.d_in) hipFree(d.d_in);
+        if (d.d_words) hipFree(d.d_words);
+        if (d.d_merged) hipFree(d.d_merged);
+        if (d.d_status) hipFree(d.d_status);
+        if (d.stream) hipStreamDestroy(d.stream);
+        if (d.ctx) fabgpu_shutdown(d.ctx);
+    }
+    delete m;
+}
+
+int fabgpu_multi_device_count(fabgpu_multi* m) { return m ? (int)m->dev.size() : FABGPU_EINVAL; }
+
+// the shard boundaries a batch of n tuples gets on G devices (pure host; off == NULL: by count, else by message bytes)
+int fabgpu_multi_plan(size_t n, const uint32_t* off, uint32_t n_devices, uint64_t* lo, uint64_t* hi, uint64_t* words_per_rank) {
+    if (!n_devices || !lo || !hi) return FABGPU_EINVAL;
+    if (off)
+        for (size_t i = 0; i < n; i++)
+            if (off[i + 1] < off[i]) return FABGPU_EINVAL;
+    ShardPlan p = off ? plan_by_bytes(n, off, n_devices) : plan_by_count(n, n_devices);
+    for (uint32_t g = 0; g < n_devices; g++) {
+        lo[g] = p.lo[g];
+        hi[g] = p.hi[g];
+    }
+    if (words_per_rank) *words_per_rank = p.words_per_rank;
+    return FABGPU_OK;
+}
+
+// arena / off == NULL: verify-only (e given); else fused hash + verify (e ignored)
+static int multi_verify(fabgpu_multi* m, size_t n, const uint8_t* arena, const uint32_t* off, const uint8_t* qx, const uint8_t* qy, const uint8_t* e,
+                        const uint8_t* r, const uint8_t* s, uint64_t* verdict_bits, uint8_t* status) {
+    const bool hash = off != nullptr;
+    if (!m || (n && (!qx || !qy || !r || !s || !verdict_bits || (!hash && !e)))) return FABGPU_EINVAL;
+    if (n > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
+    if (n == 0) return FABGPU_OK;
+    if (hash) {
+        for (size_t i = 0; i < n; i++)
+            if (off[i + 1] < off[i]) return FABGPU_EINVAL;
+        if (!arena && off[n] != off[0]) return FABGPU_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(m->mu);
+    const uint32_t G = (uint32_t)m->dev.size();
+    const ShardPlan p = hash ? plan_by_bytes(n, off, G) : plan_by_count(n, G);
+    const size_t wpr = p.words_per_rank;
+    const int nf = hash ? 4 : 5;
+    int rc = FABGPU_OK;
+    // 1. per device: stage the shard, upload, launch - everything asynchronous on the device's own stream
+    for (uint32_t g = 0; g < G; g++) {
+        Dev& d = m->dev[g];
+        const size_t cnt = p.hi[g] - p.lo[g], fb = cnt * 32;
+        if (hipSetDevice(d.ordinal) != hipSuccess) return FABGPU_ENODEV;
+        size_t msg_bytes = 0, msg_pad = 0, off_bytes = 0;
+        if (hash && cnt) {
+            msg_bytes = (size_t)off[p.hi[g]] - off[p.lo[g]];
+            msg_pad = round_up(msg_bytes, 4) + 128;
+            off_bytes = round_up((cnt + 1) * 4, 64);
+        }
+        const size_t in_need = round_up((size_t)nf * fb, 64) + off_bytes + msg_pad + 64;
+        if ((rc = grow(&d.h_in, &d.in_cap, in_need, true))) return rc;
+        if ((rc = grow(&d.d_in, &d.din_cap, in_need, false))) return rc;
+        if ((rc = grow(&d.d_words, &d.words_cap, wpr * 8 + 64, false)) || (rc = grow(&d.d_merged, &d.merged_cap, (size_t)G * wpr * 8 + 64, false)) ||
+            (rc = grow(&d.h_out, &d.out_cap, (size_t)G * wpr * 8 + 64 + (status ? cnt : 0) + 64, true)) ||
+            (status && (rc = grow(&d.d_status, &d.status_cap, cnt + 64, false))))
+            return rc;
+        hipError_t err = hipMemsetAsync(d.d_words, 0, wpr * 8, d.stream);      // tail ranks contribute zero words
+        if (err != hipSuccess) return hip_rc(err);
+        if (!cnt) continue;
+        uint8_t* h = (uint8_t*)d.h_in;
+        const uint8_t* src[5] = {qx, qy, hash ? r : e, hash ? s : r, s};
+        for (int f = 0; f < nf; f++) memcpy(h + (size_t)f * fb, src[f] + 32 * p.lo[g], fb);
+        const size_t o_off = round_up((size_t)nf * fb, 64), m_off = o_off + off_bytes;
+        if (hash) {
+            uint32_t* ho = (uint32_t*)(h + o_off);
+            const uint32_t base = off[p.lo[g]];
+            for (size_t i = 0; i <= cnt; i++) ho[i] = off[p.lo[g] + i] - base;
+            if (msg_bytes) memcpy(h + m_off, arena + base, msg_bytes);
+            memset(h + m_off + msg_bytes, 0, msg_pad - msg_bytes);
+        }
+        err = hipMemcpyAsync(d.d_in, h, m_off + msg_pad, hipMemcpyHostToDevice, d.stream);
+        if (err != hipSuccess) return hip_rc(err);
+        uint8_t* dd = (uint8_t*)d.d_in;
+        if (hash)
+            rc = fabgpu_sha256_p256_verify_batch_dev(d.ctx, cnt, dd + m_off, msg_pad, dd + o_off, dd, dd + fb, dd + 2 * fb, dd + 3 * fb, d.d_words,
+                                                     status ? d.d_status : nullptr, d.stream);
+        else
+            rc = fabgpu_p256_verify_batch_dev(d.ctx, cnt, dd, dd + fb, dd + 2 * fb, dd + 3 * fb, dd + 4 * fb, d.d_words, status ? d.d_status : nullptr, d.stream);
+        if (rc) return rc;
+        if (status) {
+            err = hipMemcpyAsync((uint8_t*)d.h_out + round_up((size_t)G * wpr * 8, 64), d.d_status, cnt, hipMemcpyDeviceToHost, d.stream);
+            if (err != hipSuccess) return hip_rc(err);
+        }
+    }
+    // 2. the verdict bitmaps: one all-gather over RCCL / xGMI (every device ends up with the merged bitmap), or G small D2H copies
+    if (!m->host_merge) {
+        if (m->rccl.GroupStart() != 0) return FABGPU_ELAUNCH;
+        for (uint32_t g = 0; g < G; g++) {
+            Dev& d = m->dev[g];
+            if (m->rccl.AllGather(d.d_words, d.d_merged, wpr, Rccl::kUint64, m->comms[g], d.stream) != 0) {
+                m->rccl.GroupEnd();
+                return FABGPU_ELAUNCH;
+            }
+        }
+        if (m->rccl.GroupEnd() != 0) return FABGPU_ELAUNCH;
+        Dev& d0 = m->dev[0];
+        hipSetDevice(d0.ordinal);
+        hipError_t err = hipMemcpyAsync(d0.h_out, d0.d_merged, (size_t)G * wpr * 8, hipMemcpyDeviceToHost, d0.stream);
+        if (err != hipSuccess) return hip_rc(err);
+    } else {
+        for (uint32_t g = 0; g < G; g++) {
+            Dev& d = m->dev[g];
+            hipSetDevice(d.ordinal);
+            hipError_t err = hipMemcpyAsync(d.h_out, d.d_words, wpr * 8, hipMemcpyDeviceToHost, d.stream);
+            if (err != hipSuccess) return hip_rc(err);
+        }
+    }
+    // 3. wait, then lay the words out as ONE bitmap (count mode: the gathered buffer already is; bytes mode: shards are ragged)
+    for (uint32_t g = 0; g < G; g++) {
+        Dev& d = m->dev[g];
+        hipSetDevice(d.ordinal);
+        hipError_t err = hipStreamSynchronize(d.stream);
+        if (err != hipSuccess) return hip_rc(err);
+    }
+    const size_t words = (n + 63) / 64;
+    for (uint32_t g = 0; g < G; g++) {
+        const size_t cnt = p.hi[g] - p.lo[g];
+        if (!cnt) continue;
+        const size_t w = (cnt + 63) / 64;
+        const uint64_t* srcw = !m->host_merge ? (const uint64_t*)m->dev[0].h_out + (size_t)g * wpr : (const uint64_t*)m->dev[g].h_out;
+        if (p.word_at[g] + w > words) return FABGPU_ELAUNCH;
+        memcpy(verdict_bits + p.word_at[g], srcw, w * 8);
+        if (status) memcpy(status + p.lo[g], (const uint8_t*)m->dev[g].h_out + round_up((size_t)G * wpr * 8, 64), cnt);
+    }
+    return FABGPU_OK;
+}
+
+int fabgpu_multi_p256_verify_batch(fabgpu_multi* m, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r,
+                                   const uint8_t* s, uint64_t* verdict_bits, uint8_t* status) {
+    return multi_verify(m, n, nullptr, nullptr, qx, qy, e, r, s, verdict_bits, status);
+}
+
+int fabgpu_multi_sha256_p256_verify_batch(fabgpu_multi* m, size_t n, const uint8_t* arena, const uint32_t* off, const uint8_t* qx, const uint8_t* qy,
+                                          const uint8_t* r, const uint8_t* s, uint64_t* verdict_bits, uint8_t* status) {
+    if (!off) return FABGPU_EINVAL;
+    return multi_verify(m, n, arena, off, qx, qy, nullptr, r, s, verdict_bits, status);
+}
+
+// device pointer of the merged bitmap on device g after the last call (G x words_per_rank u64; count mode: the first ceil(n/64)
+// words ARE the bitmap) - what an on-device policy evaluation would read.  NULL when the host merged.
+const void* fabgpu_multi_merged_bitmap_dev(fabgpu_multi* m, int g) {
+    if (!m || g < 0 || (size_t)g >= m->dev.size() || m->host_merge) return nullptr;
+    return m->dev[(size_t)g].d_merged;
+}
+
+}  // extern "C"

@@ -4,11 +4,13 @@
 // Nothing in the product path links or loads this file.
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #define FE29_CHECK 1
 #include "bn_tables29.h"
 #include "p256_tables29.h"
+#include "multi_plan.h"
 
 using namespace fab;
 
@@ -122,6 +124,51 @@ void hosttest_verify_core29(size_t n, const uint8_t* qx, const uint8_t* qy, cons
         LocalQTab29 qtab;
         status[i] = (uint8_t)p256_verify_core29(vqx, vqy, ve, vr, vs, gt, qtab);
     }
+}
+
+// FAKE MULTI-DEVICE BACKEND ("G host threads running the CPU backend + a memcpy all-gather"): the partition, the
+// equal-count exchange and the final layout of fabgpu_multi.hip on a box without GPUs.  Every "device" is a host thread that runs the
+// kernel's verification core (the same header code) over its shard and packs the verdicts into shard words like the wave ballot does;
+// the "all-gather" concatenates the G x words_per_rank words on every rank; rank 0's copy is laid out as one bitmap.
+// off == NULL: shards by count; else by message bytes (the digests e are still given: hashing is not this test's subject).
+// merged_check: set to 1 if every rank ended up with the same gathered buffer.
+int hosttest_multi_verify(size_t n, uint32_t G, const uint32_t* off, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r,
+                          const uint8_t* s, uint64_t* verdict_bits, uint8_t* status, int* merged_check) {
+    if (!G) return -1;
+    const ShardPlan p = off ? plan_by_bytes(n, off, G) : plan_by_count(n, G);
+    const size_t wpr = p.words_per_rank;
+    std::vector<std::vector<uint64_t>> words(G, std::vector<uint64_t>(wpr, 0));
+    gtab29();                                                   // built once, before the threads race for it
+    std::vector<std::thread> th;
+    for (uint32_t g = 0; g < G; g++)
+        th.emplace_back([&, g] {
+            const size_t lo = p.lo[g], cnt = p.hi[g] - p.lo[g];
+            if (!cnt) return;
+            std::vector<uint8_t> st(cnt);
+            hosttest_verify_core29(cnt, qx + 32 * lo, qy + 32 * lo, e + 32 * lo, r + 32 * lo, s + 32 * lo, st.data());
+            for (size_t i = 0; i < cnt; i++) {
+                if (st[i] == 0) words[g][i >> 6] |= (uint64_t)1 << (i & 63);
+                if (status) status[lo + i] = st[i];
+            }
+        });
+    for (auto& t : th) t.join();
+    // the all-gather: every rank receives rank 0's, rank 1's, ... words in rank order
+    std::vector<std::vector<uint64_t>> merged(G, std::vector<uint64_t>((size_t)G * wpr));
+    for (uint32_t dst = 0; dst < G; dst++)
+        for (uint32_t src = 0; src < G; src++)
+            if (wpr) memcpy(merged[dst].data() + (size_t)src * wpr, words[src].data(), wpr * 8);
+    int same = 1;
+    for (uint32_t dst = 1; dst < G; dst++) same = same && merged[dst] == merged[0];
+    if (merged_check) *merged_check = same;
+    const size_t total_words = (n + 63) / 64;
+    for (uint32_t g = 0; g < G; g++) {
+        const size_t cnt = p.hi[g] - p.lo[g];
+        if (!cnt) continue;
+        const size_t w = (cnt + 63) / 64;
+        if (p.word_at[g] + w > total_words) return -2;
+        memcpy(verdict_bits + p.word_at[g], merged[0].data() + (size_t)g * wpr, w * 8);
+    }
+    return 0;
 }
 
 // op: 0 fp_mul 1 fp_sqr 2 fp_add 3 fp_sub 4 fp_to_mont 5 fp_from_mont 6 fn_mul 7 fn_sqr 8 fn_to_mont 9 fn_from_mont 10 fn_inv 11 fp_inv

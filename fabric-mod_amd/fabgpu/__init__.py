@@ -87,6 +87,8 @@ ABI_SYMBOLS = [
     "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_block_hash_checks",
     "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_evict_block",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
+    "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
+    "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev",
 ]
 
 _lib = None
@@ -162,6 +164,15 @@ def load():
     L.fabgpu_csp_memo_set_capacity.argtypes = [_vp, ctypes.c_uint64]
     L.fabgpu_csp_identity_cache_limits.argtypes = [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
     L.fabgpu_csp_identity_cache_size.argtypes = [_vp, _u64p]
+    L.fabgpu_multi_init.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(_vp)]
+    L.fabgpu_multi_shutdown.argtypes = [_vp]
+    L.fabgpu_multi_shutdown.restype = None
+    L.fabgpu_multi_device_count.argtypes = [_vp]
+    L.fabgpu_multi_p256_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u8p, _u8p, _u64p, _u8p]
+    L.fabgpu_multi_sha256_p256_verify_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p, _u8p, _u8p, _u8p, _u64p, _u8p]
+    L.fabgpu_multi_plan.argtypes = [_sz, _u32p, ctypes.c_uint32, _u64p, _u64p, _u64p]
+    L.fabgpu_multi_merged_bitmap_dev.argtypes = [_vp, ctypes.c_int]
+    L.fabgpu_multi_merged_bitmap_dev.restype = _vp
     L.fabgpu_block_tuples.argtypes = [_u8p, _sz, ctypes.c_uint32, _u32p, _u32p, _u8p, _u32p, _u8p, ctypes.c_uint32, _u32p, _u32p]
     L.fabgpu_x509_p256_pubkey.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
@@ -431,6 +442,69 @@ class Context:
 
     def last_kernel_ms(self) -> float:
         return float(self._L.fabgpu_last_kernel_ms(self._h))
+
+
+MULTI_HOST_MERGE = 1
+
+
+def multi_plan(n: int, n_devices: int, off=None):
+    """fabgpu_multi_plan: ([(lo, hi)] per device, words_per_rank) - by count, or by message bytes when off (n + 1 offsets) is given."""
+    lo, hi = np.zeros(n_devices, np.uint64), np.zeros(n_devices, np.uint64)
+    wpr = ctypes.c_uint64(0)
+    o = None
+    if off is not None:
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        o = off.ctypes.data_as(_u32p)
+    _check(load().fabgpu_multi_plan(n, o, n_devices, lo.ctypes.data_as(_u64p), hi.ctypes.data_as(_u64p), ctypes.byref(wpr)), "fabgpu_multi_plan")
+    return [(int(a), int(b)) for a, b in zip(lo, hi)], int(wpr.value)
+
+
+class MultiContext:
+    """fabgpu_multi_*: one batch cut over the GPUs of the node, RCCL all-gather of the verdict bitmaps (SURVEY 8(e), configs[2])."""
+
+    def __init__(self, devices: Sequence[int], host_merge: bool = False):
+        self._L = load()
+        self._h = _vp()
+        d = (ctypes.c_int32 * len(devices))(*devices)
+        rc = self._L.fabgpu_multi_init(d, len(devices), MULTI_HOST_MERGE if host_merge else 0, ctypes.byref(self._h))
+        if rc != FABGPU_OK:
+            raise FabgpuError("fabgpu_multi_init failed: %s (%d)" % (strerror(rc), rc))
+
+    def close(self):
+        if self._h:
+            self._L.fabgpu_multi_shutdown(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_count(self) -> int:
+        return self._L.fabgpu_multi_device_count(self._h)
+
+    def p256_verify_batch(self, qx, qy, e, r, s, want_status=True):
+        qx, qy, e, r, s = map(_a8, (qx, qy, e, r, s))
+        n = qx.size // 32
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.uint8) if want_status else None
+        _check(self._L.fabgpu_multi_p256_verify_batch(self._h, n, _p8(qx), _p8(qy), _p8(e), _p8(r), _p8(s), bits.ctypes.data_as(_u64p), _p8(st)),
+               "fabgpu_multi_p256_verify_batch")
+        return unpack_bits(bits, n), st
+
+    def sha256_p256_verify_batch(self, arena, off, qx, qy, r, s, want_status=True):
+        arena, qx, qy, r, s = map(_a8, (arena, qx, qy, r, s))
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = off.size - 1
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.uint8) if want_status else None
+        _check(self._L.fabgpu_multi_sha256_p256_verify_batch(self._h, n, _p8(arena), off.ctypes.data_as(_u32p), _p8(qx), _p8(qy), _p8(r), _p8(s),
+                                                             bits.ctypes.data_as(_u64p), _p8(st)), "fabgpu_multi_sha256_p256_verify_batch")
+        return unpack_bits(bits, n), st
+
+    def merged_bitmap_dev(self, g: int) -> int:
+        return int(self._L.fabgpu_multi_merged_bitmap_dev(self._h, g) or 0)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -225,6 +225,29 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
                                        void* status, void* stream);
 /* 1 if (x, y) is a point of FP256BN's G1 (y^2 = x^3 + 3) with x, y < p, else 0  (pure CPU) */
 int fabgpu_bn256_g1_on_curve(const uint8_t* x32, const uint8_t* y32);
+/* ---- one batch, G devices (BASELINE.json configs[2]) ----
+ * ONE process drives every GPU of the node: the batch is cut into G contiguous shards whose starts are multiples of 64 tuples
+ * (verify-only: equal counts; hash mode: equal message BYTES), every shard is uploaded from pinned staging and verified on its device
+ * on that device's own stream, then ONE ncclAllGather (RCCL over xGMI) of the per-shard verdict words leaves the merged bitmap resident
+ * on EVERY device (fabgpu_multi_merged_bitmap_dev: for an on-device policy step) and a single D2H from device 0 returns it.  No other
+ * collective: signatures are independent.  Verdicts and statuses are those of fabgpu_p256_verify_batch / fabgpu_sha256_p256_verify_batch
+ * on the whole batch.  devices == NULL: ordinals 0 .. n_devices-1.  RCCL is bound at run time (dlopen); FABGPU_MULTI_HOST_MERGE replaces
+ * the collective by G small D2H copies (and is what allows the same ordinal to appear twice: several shards on one device).
+ * Note: a block that fits one GPU is not made faster by more GPUs - its latency is one wavefront's instruction
+ * stream; this entry point is for batches beyond one GPU's saturation point, N blocks in flight are N contexts. */
+typedef struct fabgpu_multi fabgpu_multi;
+#define FABGPU_MULTI_HOST_MERGE 1u
+int fabgpu_multi_init(const int32_t* devices, int n_devices, uint32_t flags, fabgpu_multi** out);
+void fabgpu_multi_shutdown(fabgpu_multi* m);
+int fabgpu_multi_device_count(fabgpu_multi* m);
+int fabgpu_multi_p256_verify_batch(fabgpu_multi* m, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* e, const uint8_t* r,
+                                   const uint8_t* s, uint64_t* verdict_bits, uint8_t* status);
+int fabgpu_multi_sha256_p256_verify_batch(fabgpu_multi* m, size_t n, const uint8_t* arena, const uint32_t* off, const uint8_t* qx,
+                                          const uint8_t* qy, const uint8_t* r, const uint8_t* s, uint64_t* verdict_bits, uint8_t* status);
+/* the shard boundaries [lo[g], hi[g]) a batch of n tuples gets on n_devices devices (pure host): off == NULL by count, else by bytes */
+int fabgpu_multi_plan(size_t n, const uint32_t* off, uint32_t n_devices, uint64_t* lo, uint64_t* hi, uint64_t* words_per_rank);
+const void* fabgpu_multi_merged_bitmap_dev(fabgpu_multi* m, int g);
+
 /* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
  * launch stream (bench.py's roofline leg).  <0 if nothing was launched or events are pending. */
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);
