@@ -253,11 +253,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
+    # FABGPU_BENCH_BACKEND=gloo is a DRY RUN of the N > 1 code path on a box with fewer GPUs than ranks (all ranks share the devices that
+    # exist, collectives go through host memory); its numbers mean nothing and the line says so.  The driver never sets it.
+    backend = os.environ.get("FABGPU_BENCH_BACKEND", "nccl")
+    dry = backend != "nccl"
+    local_rank = local_rank % torch.cuda.device_count() if dry else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
         cpu_group = dist.new_group(backend="gloo")                    # the closing wait is host-side: no rank spins a kernel on its GPU
 
     n_tx = args.tx
@@ -274,10 +279,19 @@ def main():
         ctx.p256_verify_batch_dev(n, dev["qx"].data_ptr(), dev["qy"].data_ptr(), dev["e"].data_ptr(), dev["r"].data_ptr(),
                                   dev["s"].data_ptr(), words.data_ptr(), 0, stream.cuda_stream)
 
+    def all_gather(dst, src):
+        if not dry:
+            dist.all_gather_into_tensor(dst, src)                     # RCCL over xGMI
+        else:
+            torch.cuda.synchronize()
+            parts = [torch.empty(src.numel(), dtype=src.dtype) for _ in range(world)]
+            dist.all_gather(parts, src.cpu())
+            dst.copy_(torch.cat(parts))
+
     def step():
         verify_only()
         if world > 1:
-            dist.all_gather_into_tensor(merged, words)
+            all_gather(merged, words)
 
     def sync_all():
         if world > 1:
@@ -287,7 +301,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -331,7 +345,7 @@ def main():
             if hi > lo:
                 ctx.p256_verify_batch_dev(hi - lo, sd["qx"].data_ptr(), sd["qy"].data_ptr(), sd["e"].data_ptr(), sd["r"].data_ptr(), sd["s"].data_ptr(),
                                           lw.data_ptr(), 0, stream.cuda_stream)
-            dist.all_gather_into_tensor(mg, lw)
+            all_gather(mg, lw)
         for _ in range(args.warmup):
             sstep()
         sync_all()
@@ -367,7 +381,7 @@ def main():
             "metric": "ECDSA P-256 verifies/sec (whole node)", "value": value, "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
-            "data": "synthetic",
+            "data": "synthetic" + (" - DRY RUN of the multi-rank code path (FABGPU_BENCH_BACKEND=%s): ranks share devices, numbers are meaningless" % backend if dry else ""),
             "config": {"workload": ("BASELINE.json configs[1]" if n_tx == N_TX else "EXPLORATION (not the BASELINE config)") + ": block of %d tx x 3 endorsements = %d P-256 tuples per GPU, " % (n_tx, n) +
                                    "verify-only kernel via the C ABI, fresh keypair per signature, 1% invalid" +
                                    ("; %d GPUs = %d such blocks in flight (one per GPU: blocks-in-flight throughput, NOT one block sharded - that is configs2_strong)" % (world, world) if world > 1 else ""),

@@ -845,6 +845,21 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             if (rc != FABGPU_OK) return Error(std::string("GPU nym verify failed: ") + fabgpu_strerror(rc));
             for (size_t j = 0; j < m; j++)   // FABGPU_NYM_VALID = 0, BAD_PROOF = 1 (= "signature invalid"), NEEDS_SW = 6 = TUPLE_ST_NEEDS_SW
                 out.tuple_status[ns[j]] = st[j];
+            if (want_digests) {
+                // NymVerifier.Verify receives the whole message, not a digest (bccsp/idemix/handlers/nymsigner.go:62-95): the memo
+                // entry of a pseudonym signature is keyed on SHA-256(message) - computed here by the device over the bytes the nym
+                // kernel just verified, and by the Go wrapper over the bytes it is asked about
+                std::vector<uint8_t> nd(m * 32);
+                rc = fabgpu_sha256_batch(ctx_, m, arena.data(), noff.data(), nd.data());
+                if (rc != FABGPU_OK) return Error(std::string("GPU hash failed: ") + fabgpu_strerror(rc));
+                for (size_t j = 0; j < m; j++) {
+                    if (st[j] == FABGPU_NYM_NEEDS_SW) continue;
+                    memcpy(&out.tuple_digest[32 * (size_t)ns[j]], &nd[32 * j], 32);
+                    out.tuple_hashed[ns[j]] = 1;
+                    memcpy(&out.tuple_qxy[64 * (size_t)ns[j]], gt[ns[j]].qx, 32);        // the pseudonym (Nym.x, Nym.y) in the key slot
+                    memcpy(&out.tuple_qxy[64 * (size_t)ns[j] + 32], gt[ns[j]].qy, 32);
+                }
+            }
         }
     }
     // TxID / proposal hash: compare what the device computed with what the block claims.  (No ECDSA tuple went to the device -
@@ -907,9 +922,10 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         keys.reserve(nt);
         std::lock_guard<std::mutex> lk(memo_mu_);
         for (size_t i = 0; i < nt; i++) {
-            if (!out.tuple_hashed[i] || gt[i].nym) continue;
+            if (!out.tuple_hashed[i]) continue;
             const uint8_t stt = out.tuple_status[i];
             if (stt > FABGPU_ST_RANGE) continue;           // 0 valid, 1 bad math, 2 high-S, 3 range: what bccsp.Verify decides itself
+            // (pseudonym signatures: key = Nym.x || Nym.y, digest = SHA-256(message), status 0 valid / 1 proof invalid)
             const BlockTuple& tp = pb.tuples[i];
             std::string k = MemoKey(&out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], block + tp.sig.off, tp.sig.len, &out.tuple_digest[32 * i], 32);
             MemoEntry& e = memo_[k];

@@ -1,0 +1,51 @@
+// +build fabgpu
+
+// GPUFactory: the bccsp/factory side of ProviderName "GPU" (pattern: bccsp/factory/pkcs11factory.go:17-45).
+// Drop into the reference tree as bccsp/factory/gpufactory.go and apply the two `case`s of gpufactory_patch.txt to
+// nopkcs11.go / pkcs11.go (initFactories and GetBCCSPFromOpts switch on the provider name; there is no runtime BCCSP plugin
+// loader in this version - SURVEY.md 8(b) "Selection").  core.yaml:  peer.BCCSP.Default: GPU  (+ the usual SW section, which
+// configures the embedded software provider: hash family, security level, key store).
+// NOT compiled in this repository (no Go toolchain in the build image); Go 1.14 compatible.
+package factory
+
+import (
+	"github.com/hyperledger/fabric/bccsp"
+	"github.com/hyperledger/fabric/bccsp/gpu"
+	"github.com/pkg/errors"
+)
+
+const (
+	// GPUBasedFactoryName is the name of the factory of the MI355X-accelerated BCCSP implementation
+	GPUBasedFactoryName = "GPU"
+)
+
+// GPUOpts is the `GPU:` section of the BCCSP configuration.
+type GPUOpts struct {
+	Device int `mapstructure:"device" json:"device" yaml:"Device"` // HIP device ordinal; -1 = the current device
+}
+
+// GPUFactory is the factory of the GPU-accelerated BCCSP.
+type GPUFactory struct{}
+
+// Name returns the name of this factory
+func (f *GPUFactory) Name() string {
+	return GPUBasedFactoryName
+}
+
+// Get returns an instance of BCCSP using Opts: the software provider built from SwOpts exactly as SWFactory builds it,
+// wrapped by the GPU provider.  If no usable device exists the error is returned: a peer configured for "GPU" should not
+// silently run without one (operators who want the fallback configure "SW").
+func (f *GPUFactory) Get(config *FactoryOpts) (bccsp.BCCSP, error) {
+	if config == nil || config.SwOpts == nil {
+		return nil, errors.New("Invalid config. It must not be nil.")
+	}
+	swCSP, err := (&SWFactory{}).Get(config)
+	if err != nil {
+		return nil, errors.Wrapf(err, "Failed initializing the software BCCSP behind the GPU provider")
+	}
+	device := -1
+	if config.GPUOpts != nil {
+		device = config.GPUOpts.Device
+	}
+	return gpu.New(swCSP, device)
+}

@@ -1,69 +1,136 @@
 // +build fabgpu
 
 // Package gpu is the reference-side binding of libfabgpu.so: a bccsp.BCCSP that embeds bccsp/sw exactly the
-// way bccsp/pkcs11/pkcs11.go:35-52 does and overrides KeyImport (to hold X,Y), Hash and Verify.
+// way bccsp/pkcs11/pkcs11.go:35-52 does and overrides KeyImport (to hold X, Y) and Verify.
+//
 // Drop this directory into the reference tree as bccsp/gpu and build the peer with GO_TAGS=fabgpu
-// (same mechanism as the pkcs11 tag, Makefile:80,209).  NOT compiled in this repository: the build image has
-// no Go toolchain; the C ABI it binds is exercised by the Python/ctypes tests instead.
+// (same mechanism as the pkcs11 tag, Makefile:80,209).  Written for the reference's Go 1.14.4 (Makefile:79):
+// no big.Int.FillBytes, no generics.  NOT compiled in this repository - the build image has no Go toolchain
+// (`go version`: not found); the C ABI it binds is exercised by the Python/ctypes tests instead, and every
+// function here is a thin translation of a C call whose behaviour those tests pin.
+//
+// How the provider earns its keep (SURVEY.md 8(f) rank 1):
+//   1. extensions/validation wraps the channel's validator (preverify.go in this delivery): before the unchanged
+//      v14/v20 validator runs, the whole marshalled block goes to PreVerifyBlock - ONE device submission for every
+//      creator, endorsement and orderer signature of the block, which also seeds the verdict memo inside
+//      libfabgpu.so, keyed on (public key, signature bytes, digest the DEVICE computed).
+//   2. the validators then call identity.Verify per signature as before (msp/identities.go:169-196):
+//      bccsp.Hash stays on the CPU - the digest is what ties the caller's bytes to the memo entry - and
+//      bccsp.Verify finds the verdict in the memo.  A miss, a non-P-256 key, or any rejected signature goes to
+//      bccsp/sw, so error text and semantics are the reference's own in every case but "valid".
+//   3. when Validate returns, the wrapper evicts the block's entries: the memo never grows with the chain.
+// The device never decides alone: a verdict is only ever attached to the three byte strings the validator itself
+// presents, so a block whose bytes the pass parsed differently than the Go unmarshaller (or a device failure)
+// can only produce misses.
 package gpu
 
 /*
 #cgo CFLAGS: -I${SRCDIR}/../../../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../../lib -lfabgpu
 #include <stdlib.h>
+#include <string.h>
 #include "fabgpu.h"
+#include "fabgpu_bccsp.h"
+
+// cgo pointer rule: Go memory handed to C must not itself contain Go pointers, so the descriptor struct (which points at the
+// block and at the flags array, both Go memory) is built on the C stack here, from plain arguments.
+static int fabgpu_go_block_pass(fabgpu_csp* csp, const uint8_t* block, size_t len, uint64_t seq, uint32_t flags, uint8_t* tx_flags,
+                                uint32_t cap_tx, uint32_t cap_tuples, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_block_sigs,
+                                uint32_t* memo_seeded) {
+    fabgpu_block_pass ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.block = block;
+    ps.len = len;
+    ps.block_seq = seq;
+    ps.flags = flags;
+    ps.cap_tx = cap_tx;
+    ps.cap_tuples = cap_tuples;
+    ps.tx_flags = tx_flags;
+    int rc = fabgpu_csp_block_preverify2(csp, &ps);
+    *n_tx = ps.n_tx;
+    *n_tuples = ps.n_tuples;
+    *n_block_sigs = ps.n_block_sigs;
+    *memo_seeded = ps.memo_seeded;
+    return rc;
+}
 */
 import "C"
 
 import (
 	"crypto/ecdsa"
 	"crypto/elliptic"
-	"crypto/sha256"
 	"crypto/x509"
-	"fmt"
 	"math/big"
 	"sync"
 	"unsafe"
 
 	"github.com/hyperledger/fabric/bccsp"
-	"github.com/hyperledger/fabric/bccsp/sw"
-	"github.com/hyperledger/fabric/bccsp/utils"
 	"github.com/pkg/errors"
 )
 
-// impl mirrors bccsp/pkcs11/pkcs11.go:35-52: everything not overridden is served by the embedded sw CSP.
-type impl struct {
-	bccsp.BCCSP
-	ctx  *C.fabgpu_ctx
-	memo sync.Map // verdict memo seeded by PreVerifyBlock: key = sha256(X|Y|sig|digest) -> memoEntry
+// Provider is the concrete type behind the bccsp.BCCSP that New returns; extensions/validation type-asserts for
+// BlockPreVerifier to find out whether the default BCCSP can pre-verify blocks.
+type Provider struct {
+	bccsp.BCCSP // bccsp/sw: everything that is not overridden (pattern: bccsp/pkcs11/pkcs11.go:35-37)
+	csp         *C.fabgpu_csp
+	closeOnce   sync.Once
 }
 
-type memoEntry struct {
-	valid  bool
-	status uint8
+// BlockPreVerifier is what the validator wrapper needs from the default BCCSP.
+type BlockPreVerifier interface {
+	// PreVerifyBlock submits every signature of the marshalled block to the device and seeds the verdict memo under
+	// blockSeq.  A non-nil error is an infrastructure failure: the caller ignores it and validation proceeds on bccsp/sw.
+	PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSummary, error)
+	// EvictBlock drops the memo entries seeded under blockSeq.
+	EvictBlock(blockSeq uint64)
 }
 
-// gpuPublicKey carries X,Y so Verify never needs the unexported sw key type (bccsp/sw/ecdsakey.go:72-74).
+// PassSummary is the per-transaction advice of one pass (never consensus input: the validators decide).
+type PassSummary struct {
+	TxFlags    []uint8 // fabgpu_bccsp.h: 0 all signatures valid, 1 bad creator signature, 2 bad endorsement, 3 not understood, 4 needs bccsp/sw, 5 TxID mismatch, 6 proposal-hash mismatch
+	Tuples     int
+	BlockSigs  int
+	MemoSeeded int
+}
+
+// gpuPublicKey carries X, Y so that Verify never needs the unexported sw key type (bccsp/sw/ecdsakey.go:72-74).
 type gpuPublicKey struct {
-	bccsp.Key // the sw key (SKI, Bytes, ...)
-	pub       *ecdsa.PublicKey
-	onCurve   bool
-	keyID     int64 // fabgpu_p256_key_register id of this key's comb table on the device, -1 = none
+	bccsp.Key        // the sw key (SKI, Bytes, Symmetric, Private, PublicKey)
+	qx, qy    [32]byte
 }
 
-// New is what bccsp/factory would call for ProviderName "GPU" (see INTEGRATION.md).
+// New is what bccsp/factory calls for ProviderName "GPU" (gpufactory.go).  device < 0: the current HIP device.
 func New(swCSP bccsp.BCCSP, device int) (bccsp.BCCSP, error) {
+	if swCSP == nil {
+		return nil, errors.New("Invalid software BCCSP. It must not be nil.")
+	}
 	cfg := C.fabgpu_cfg{device: C.int32_t(device)}
-	var ctx *C.fabgpu_ctx
-	if rc := C.fabgpu_init(&cfg, &ctx); rc != 0 {
+	var csp *C.fabgpu_csp
+	errbuf := make([]byte, 256)
+	if rc := C.fabgpu_csp_new(&cfg, &csp, (*C.char)(unsafe.Pointer(&errbuf[0])), C.size_t(len(errbuf))); rc != 0 {
 		return nil, errors.Errorf("Failed initializing GPU BCCSP: %s", C.GoString(C.fabgpu_strerror(rc)))
 	}
-	return &impl{BCCSP: swCSP, ctx: ctx}, nil
+	return &Provider{BCCSP: swCSP, csp: csp}, nil
 }
 
-// KeyImport: own the public-key import opts so that X,Y are reachable (pattern: bccsp/pkcs11/pkcs11.go:148-179).
-func (csp *impl) KeyImport(raw interface{}, opts bccsp.KeyImportOpts) (bccsp.Key, error) {
-	k, err := csp.BCCSP.KeyImport(raw, opts)
+// Close releases the device context (tests; a peer keeps its BCCSP for life).
+func (p *Provider) Close() {
+	p.closeOnce.Do(func() { C.fabgpu_csp_free(p.csp) })
+}
+
+// be32 is big.Int.FillBytes for Go 1.14: the value as exactly 32 big-endian bytes (callers guarantee BitLen <= 256).
+func be32(v *big.Int, out *[32]byte) {
+	b := v.Bytes()
+	for i := range out {
+		out[i] = 0
+	}
+	copy(out[32-len(b):], b)
+}
+
+// KeyImport owns the public-key import opts so that X, Y are reachable (pattern: bccsp/pkcs11/pkcs11.go:148-179).
+// Everything that is not an on-curve P-256 public key is returned exactly as bccsp/sw made it.
+func (p *Provider) KeyImport(raw interface{}, opts bccsp.KeyImportOpts) (bccsp.Key, error) {
+	k, err := p.BCCSP.KeyImport(raw, opts)
 	if err != nil {
 		return nil, err
 	}
@@ -76,140 +143,109 @@ func (csp *impl) KeyImport(raw interface{}, opts bccsp.KeyImportOpts) (bccsp.Key
 	case *bccsp.ECDSAGoPublicKeyImportOpts:
 		pub, _ = raw.(*ecdsa.PublicKey)
 	}
-	if pub == nil || pub.Curve != elliptic.P256() {
+	if pub == nil || pub.Curve != elliptic.P256() || pub.X == nil || pub.Y == nil {
 		return k, nil // not ours: sw handles it
 	}
-	gk := &gpuPublicKey{Key: k, pub: pub, onCurve: pub.Curve.IsOnCurve(pub.X, pub.Y), keyID: -1}
-	if gk.onCurve {
-		// Long-lived identities (endorsers, orderers: msp/cache/cache.go:14-18 keeps 100 of them) get a comb table on the
-		// device, ~6 ms once per key; their signatures then verify without doublings.  Failure (table memory exhausted)
-		// just leaves keyID = -1: the fresh-key kernels are used.
-		qx, qy := be32(pub.X), be32(pub.Y)
-		var id C.uint32_t
-		if rc := C.fabgpu_p256_key_register(csp.ctx, (*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])), &id); rc == 0 {
-			gk.keyID = int64(id)
-		}
+	if pub.X.Sign() < 0 || pub.Y.Sign() < 0 || pub.X.BitLen() > 256 || pub.Y.BitLen() > 256 || !pub.Curve.IsOnCurve(pub.X, pub.Y) {
+		return k, nil // ECDSAGoPublicKeyImportOpts does not check the point (bccsp/sw/keyimport.go:103-112): such keys stay with sw
 	}
+	gk := &gpuPublicKey{Key: k}
+	be32(pub.X, &gk.qx)
+	be32(pub.Y, &gk.qy)
 	return gk, nil
 }
 
-func be32(v *big.Int) []byte { b := make([]byte, 32); v.FillBytes(b); return b } // Go >= 1.15; 1.14: pad v.Bytes()
-
-// Verify keeps bccsp/sw's argument checks and error text (bccsp/sw/impl.go:247-270, ecdsa.go:41-57).
-func (csp *impl) Verify(k bccsp.Key, signature, digest []byte, opts bccsp.SignerOpts) (bool, error) {
-	gk, ok := k.(*gpuPublicKey)
-	if !ok || !gk.onCurve || len(signature) == 0 || len(digest) == 0 {
-		if ok {
-			k = gk.Key
-		}
-		return csp.BCCSP.Verify(k, signature, digest, opts) // nil key, other key types, off-curve keys, empty args
+// swKey unwraps a key of this provider so that bccsp/sw sees its own type.
+func swKey(k bccsp.Key) bccsp.Key {
+	if gk, ok := k.(*gpuPublicKey); ok && gk != nil {
+		return gk.Key
 	}
-	r, s, err := utils.UnmarshalECDSASignature(signature)
-	if err != nil {
-		return false, errors.Wrapf(fmt.Errorf("Failed unmashalling signature [%s]", err), "Failed verifing with opts [%v]", opts)
-	}
-	if lowS, _ := utils.IsLowS(gk.pub, s); !lowS {
-		return false, errors.Wrapf(fmt.Errorf("Invalid S. Must be smaller than half the order [%s][%s].", s,
-			utils.GetCurveHalfOrdersAt(gk.pub.Curve)), "Failed verifing with opts [%v]", opts)
-	}
-	if r.BitLen() > 256 {
-		return false, nil // r >= n
-	}
-	if e, hit := csp.memo.Load(memoKey(gk.pub, signature, digest)); hit {
-		return e.(memoEntry).valid, nil // seeded by PreVerifyBlock for this exact (key, sig, digest)
-	}
-	// memo miss: single-tuple launch (correct, slow); high-rate callers go through PreVerifyBlock
-	var e32 [32]byte
-	C.fabgpu_hash_to_int((*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), (*C.uint8_t)(unsafe.Pointer(&e32[0])))
-	qx, qy, rb, sb := be32(gk.pub.X), be32(gk.pub.Y), be32(r), be32(s)
-	var bits C.uint64_t
-	var st C.uint8_t
-	rc := C.fabgpu_p256_verify_batch(csp.ctx, 1, (*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])),
-		(*C.uint8_t)(unsafe.Pointer(&e32[0])), (*C.uint8_t)(unsafe.Pointer(&rb[0])), (*C.uint8_t)(unsafe.Pointer(&sb[0])), &bits, &st)
-	if rc != 0 { // infrastructure failure: never a verdict, fall back (SURVEY section 5 "determinism under failure")
-		return csp.BCCSP.Verify(gk.Key, signature, digest, opts)
-	}
-	return bits&1 == 1, nil
-}
-
-// Hash: single small hashes stay on the CPU (a PCIe round trip costs more than SHA-256 of a few KB);
-// block-sized batches go through PreVerifyBlock's fused hash+verify launch.
-func (csp *impl) Hash(msg []byte, opts bccsp.HashOpts) ([]byte, error) { return csp.BCCSP.Hash(msg, opts) }
-
-func memoKey(pub *ecdsa.PublicKey, sig, digest []byte) [32]byte {
-	h := sha256.New()
-	h.Write(be32(pub.X)); h.Write(be32(pub.Y)); h.Write(sig); h.Write(digest)
-	var k [32]byte
-	copy(k[:], h.Sum(nil))
 	return k
 }
 
-// Tuple is one (identity key, signed message, DER signature) of a block, extracted exactly as
-// core/common/validation/msgvalidation.go:274 (creator) and
-// core/common/validation/statebased/validator_keylevel.go:246-258 (endorsements: prp || endorser) do.
-type Tuple struct {
-	Key bccsp.Key
-	Msg []byte
-	Sig []byte
+// Verify: (true, nil) comes from the verdict memo; every other outcome - and every error text - from bccsp/sw
+// (bccsp/sw/impl.go:247-270, ecdsa.go:41-57).  There is deliberately no single-signature device call: one launch
+// costs more than one CPU verification.
+func (p *Provider) Verify(k bccsp.Key, signature, digest []byte, opts bccsp.SignerOpts) (bool, error) {
+	gk, ok := k.(*gpuPublicKey)
+	if ok && gk != nil && len(signature) != 0 && len(digest) != 0 {
+		var st C.uint8_t
+		hit := C.fabgpu_csp_memo_lookup(p.csp, (*C.uint8_t)(unsafe.Pointer(&gk.qx[0])), (*C.uint8_t)(unsafe.Pointer(&gk.qy[0])),
+			(*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)),
+			(*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &st)
+		if hit == 0 && st == C.FABGPU_ST_VALID {
+			return true, nil
+		}
+	}
+	return p.BCCSP.Verify(swKey(k), signature, digest, opts) // nil key, foreign key types, misses, rejects: the reference's own answer
 }
 
-// PreVerifyBlock verifies every tuple of a block in ONE fused hash+verify launch and seeds the verdict memo that
-// Verify consults, so the unchanged validators (v20/validator.go:194-210) hit the memo instead of the CPU.
-func (csp *impl) PreVerifyBlock(tuples []Tuple) error {
-	n := len(tuples)
-	if n == 0 {
-		return nil
+// Sign, Encrypt, Decrypt, KeyDeriv, GetKey reach sw with sw's key type (a gpuPublicKey is only ever a public key, but
+// callers may hand it back, e.g. to Encrypt: unwrap for symmetry with Verify).
+func (p *Provider) Encrypt(k bccsp.Key, plaintext []byte, opts bccsp.EncrypterOpts) ([]byte, error) {
+	return p.BCCSP.Encrypt(swKey(k), plaintext, opts)
+}
+
+// Hash stays on the CPU on purpose: a PCIe round trip costs more than SHA-256 of a few KB, and - more important -
+// the digest the validator computes over ITS bytes is what binds those bytes to a memo entry.
+func (p *Provider) Hash(msg []byte, opts bccsp.HashOpts) ([]byte, error) { return p.BCCSP.Hash(msg, opts) }
+
+// PreVerifyBlock: fabgpu_csp_block_preverify2 with FABGPU_PASS_SEED_MEMO.  blockBytes = proto.Marshal(block).
+func (p *Provider) PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSummary, error) {
+	if len(blockBytes) == 0 {
+		return nil, errors.New("empty block")
 	}
-	qx, qy, rr, ss := make([]byte, 32*n), make([]byte, 32*n), make([]byte, 32*n), make([]byte, 32*n)
-	ids := make([]uint32, n) // key ids; the keyed launch is used when every kept tuple has one
-	allKeyed := true
-	off := make([]uint32, n+1)
-	var arena []byte
-	keep := make([]bool, n)
-	for i, t := range tuples {
-		off[i] = uint32(len(arena))
-		gk, ok := t.Key.(*gpuPublicKey)
-		r, s, err := utils.UnmarshalECDSASignature(t.Sig)
-		low := false
-		if err == nil {
-			low, _ = utils.IsLowS(gk.pub, s)
-		}
-		if !ok || !gk.onCurve || err != nil || !low || r.BitLen() > 256 {
-			rr[32*i+31], ss[32*i+31], qx[32*i+31], qy[32*i+31] = 1, 1, 1, 1 // filler; Verify's own gates answer these
+	capTx, capTuples := C.uint32_t(1024), C.uint32_t(8192)
+	for attempt := 0; attempt < 3; attempt++ {
+		flags := make([]uint8, capTx) // the only array this caller wants back; the memo lives behind the ABI
+		var nTx, nTuples, nBlockSigs, seeded C.uint32_t
+		rc := C.fabgpu_go_block_pass(p.csp, (*C.uint8_t)(unsafe.Pointer(&blockBytes[0])), C.size_t(len(blockBytes)), C.uint64_t(blockSeq),
+			C.FABGPU_PASS_SEED_MEMO, (*C.uint8_t)(unsafe.Pointer(&flags[0])), capTx, capTuples, &nTx, &nTuples, &nBlockSigs, &seeded)
+		if rc == C.FABGPU_ETOOBIG { // counts are set, nothing was launched
+			capTx, capTuples = nTx+16, nTuples+64
 			continue
 		}
-		keep[i] = true
-		if gk.keyID >= 0 {
-			ids[i] = uint32(gk.keyID)
-		} else {
-			allKeyed = false
+		if rc != 0 {
+			return nil, errors.Errorf("fabgpu: %s", C.GoString(C.fabgpu_strerror(rc)))
 		}
-		arena = append(arena, t.Msg...)
-		copy(qx[32*i:], be32(gk.pub.X)); copy(qy[32*i:], be32(gk.pub.Y)); copy(rr[32*i:], be32(r)); copy(ss[32*i:], be32(s))
+		return &PassSummary{TxFlags: flags[:nTx], Tuples: int(nTuples), BlockSigs: int(nBlockSigs), MemoSeeded: int(seeded)}, nil
 	}
-	off[n] = uint32(len(arena))
-	arena = append(arena, 0)
-	bits := make([]uint64, (n+63)/64)
-	st := make([]uint8, n)
-	var rc C.int
-	if allKeyed { // fillers carry id 0 (any registered key) and r = s = 1: their verdict is ignored (keep[i] == false)
-		rc = C.fabgpu_sha256_p256_verify_batch_keyed(csp.ctx, C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&arena[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])),
-			(*C.uint32_t)(unsafe.Pointer(&ids[0])), (*C.uint8_t)(unsafe.Pointer(&rr[0])), (*C.uint8_t)(unsafe.Pointer(&ss[0])),
-			(*C.uint64_t)(unsafe.Pointer(&bits[0])), (*C.uint8_t)(unsafe.Pointer(&st[0])))
-	} else {
-		rc = C.fabgpu_sha256_p256_verify_batch(csp.ctx, C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&arena[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])),
-			(*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])), (*C.uint8_t)(unsafe.Pointer(&rr[0])),
-			(*C.uint8_t)(unsafe.Pointer(&ss[0])), (*C.uint64_t)(unsafe.Pointer(&bits[0])), (*C.uint8_t)(unsafe.Pointer(&st[0])))
+	return nil, errors.New("fabgpu: block shape changed between attempts")
+}
+
+// EvictBlock: fabgpu_csp_memo_evict_block.
+func (p *Provider) EvictBlock(blockSeq uint64) {
+	C.fabgpu_csp_memo_evict_block(p.csp, C.uint64_t(blockSeq), nil)
+}
+
+// MemoLookup exposes the verdict memo to the other verifier of this delivery (bccsp/idemixgpu: pseudonym signatures are memoised
+// under key = Nym.x || Nym.y, digest = SHA-256(message)).  hit == false: ask the software verifier.
+func (p *Provider) MemoLookup(qx, qy *[32]byte, signature, digest []byte) (status uint8, hit bool) {
+	if len(signature) == 0 || len(digest) == 0 {
+		return 0, false
 	}
-	if rc != 0 {
-		return errors.Errorf("fabgpu: %s", C.GoString(C.fabgpu_strerror(rc))) // caller ignores: validators then use sw via Verify
+	var st C.uint8_t
+	rc := C.fabgpu_csp_memo_lookup(p.csp, (*C.uint8_t)(unsafe.Pointer(&qx[0])), (*C.uint8_t)(unsafe.Pointer(&qy[0])),
+		(*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)), (*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &st)
+	return uint8(st), rc == 0
+}
+
+// RegisterIdemixMSP makes the block pass verify the pseudonym signatures of creators serialized under mspID
+// (msp/idemixmsp.go:99-173 Setup calls this with the marshalled idemix.IssuerPublicKey).  false: not accelerated.
+func (p *Provider) RegisterIdemixMSP(mspID string, ipkBytes []byte) bool {
+	if len(ipkBytes) == 0 {
+		return false
 	}
-	for i, t := range tuples {
-		if !keep[i] {
-			continue
-		}
-		d := sha256.Sum256(t.Msg) // memo key only; the verdict came from the GPU
-		csp.memo.Store(memoKey(t.Key.(*gpuPublicKey).pub, t.Sig, d[:]), memoEntry{valid: bits[i/64]>>(uint(i)%64)&1 == 1, status: st[i]})
-	}
-	return nil
+	cs := C.CString(mspID)
+	defer C.free(unsafe.Pointer(cs))
+	var id C.int64_t
+	rc := C.fabgpu_csp_idemix_msp_register(p.csp, cs, (*C.uint8_t)(unsafe.Pointer(&ipkBytes[0])), C.size_t(len(ipkBytes)), &id)
+	return rc == 0 && id >= 0
+}
+
+// MemoStats is for metrics / tests.
+func (p *Provider) MemoStats() (entries, hits, misses, evicted uint64) {
+	var e, h, m, v C.uint64_t
+	C.fabgpu_csp_memo_stats(p.csp, &e, &h, &m, &v)
+	return uint64(e), uint64(h), uint64(m), uint64(v)
 }

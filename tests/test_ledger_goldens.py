@@ -233,7 +233,9 @@ def test_preverify_pass_on_every_block_of_the_reference_ledgers(csp):
             assert flags == list(bytes.fromhex(b["tx_filter"]))          # all zero: VALID where the reference said VALID
         else:
             for t, tx in enumerate(blk["txs"]):
-                assert flags[t] == fabgpu.TX_NEEDS_SW                    # creator identity is not a certificate (outranks the UUID TxID)
+                # creator identity is not a certificate -> bccsp/sw decides (outranks the UUID TxID); the genesis envelopes name no
+                # creator at all -> left to the Go validators
+                assert flags[t] == (fabgpu.TX_NEEDS_SW if tx["creator"][0] else fabgpu.TX_NOT_UNDERSTOOD)
     assert (seen[0], seen[1], seen[2]) == (20, 21, 19)
 
 
