@@ -258,6 +258,24 @@ def test_preverify_pass_with_idemix_creators():
     assert (out["tuple_status"][~creators] == 0).all()
     assert (out["tx_flags"] == fabgpu.TX_BAD_CREATOR_SIGNATURE).sum() == sum(1 for t in range(0, 120, 5) if (t // 5) % 6 == 2)
     assert fabgpu.preverify_block(csp, blk)["tx_flags"].tolist() == want.tolist()          # repeatable; pseudonyms are not cached
+    # the verdict memo also carries the pseudonym signatures: key = Nym.x || Nym.y, digest = SHA-256(message) - what the Go
+    # NymVerifier wrapper recomputes from ITS arguments (fabric-mod_amd/go/bccsp/idemixgpu/nymverifier.go)
+    r2 = fabgpu.preverify_block2(csp, blk, block_seq=9, seed_memo=True)
+    assert (r2["tx_flags"] == want).all()
+    n_nym = 0
+    for i in np.nonzero(r2["tuple_kind"] == 0)[0]:
+        tx = int(r2["tuple_tx"][i])
+        if tx % 5 != 0 or r2["tuple_status"][i] not in (0, 1):
+            continue
+        sp = [int(x) for x in r2["tuple_spans"][i]]
+        msg, sig = r2["arena"][sp[4]:sp[4] + sp[5]], r2["arena"][sp[6]:sp[6] + sp[7]]
+        assert bytes(r2["tuple_digest"][i]) == hashlib.sha256(msg).digest() and r2["tuple_hashed"][i]
+        qxy = bytes(r2["tuple_qxy"][i])
+        assert fabgpu.memo_lookup(csp, qxy[:32], qxy[32:], sig, hashlib.sha256(msg).digest()) == int(r2["tuple_status"][i])
+        assert fabgpu.memo_lookup(csp, qxy[:32], qxy[32:], sig, hashlib.sha256(msg + b"!").digest()) is None
+        n_nym += 1
+    assert n_nym >= 15
+    assert fabgpu.memo_evict_block(csp, 9) == r2["memo_seeded"]
     csp.close()
 
 
