@@ -9,6 +9,9 @@
 #include "p256_pair29.h"
 #include "pair29_bn_gcn.h"   // prepared BN pair programs: validated here register for register, not yet used by a kernel
 #include "p256_tables29.h"
+#include "bn_nym29.h"
+#include "bn_tables29.h"
+#include "device_common.h"
 
 using namespace fab;
 
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(64, 1) gputest_pair_combined_kernel(const uint
     fe QX, QY;
     fe_to_mont(QX, qx);
     fe_to_mont(QY, qy);
-    PairQTab<32> qtab{qws + k};
+    PairQTab<32> qtab = PairQTab<32>::of(qws, k);
     pair_pt R;
     bool inf;
     pair_combined_mult29(R, inf, u1, u2, QX, QY, gtab, qtab, odd);
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(64, 1) gputest_pair_verify_kernel(const uint8_
     from_be32(e, in + 160 * k + 64);
     from_be32(r, in + 160 * k + 96);
     from_be32(s, in + 160 * k + 128);
-    PairQTab<32> qtab{qws + k};
+    PairQTab<32> qtab = PairQTab<32>::of(qws, k);
     const u256 P = FAB_P256_P;
     const u256 N = FAB_P256_N;
     uint32_t early = range_status(r, s);
@@ -189,5 +192,74 @@ extern "C" int gputest_pair_verify(const uint8_t* in, int32_t* out) {
     int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
     hipMemcpy(out, dout, 64 * 48 * 4, hipMemcpyDeviceToHost);
     hipFree(din); hipFree(dtab); hipFree(dout); hipFree(dws);
+    return rc;
+}
+
+// The commitment t of the pseudonym-signature equation as the DEVICE computes it (bn_nym29.h), exposed on its own so that tests can
+// compare it with vectors made by an independent implementation (tests/golden/idemix_nym_kats.json): one wave, up to 64 signatures
+// with one lane each (split == 0) or 32 with two lanes each (split == 1).  in: n x 5 big-endian fields (nym_x, nym_y, c, s_sk, s_rnym);
+// out: n x (tx[32] ty[32]) big-endian, st: n status words.
+__global__ void __launch_bounds__(64, 1) gputest_nym_commitment_kernel(int split, uint32_t n, const uint8_t* __restrict__ in, const int32_t* __restrict__ hskt,
+                                                                        const int32_t* __restrict__ hrandt, uint4* __restrict__ qws, uint8_t* __restrict__ out,
+                                                                        uint32_t* __restrict__ st_out) {
+    GlobalQTab29<64> qtab{qws + threadIdx.x};
+    KeyTab8 hsk{hskt}, hrand{hrandt};
+    const bool odd = (threadIdx.x & 1u) != 0;
+    uint32_t i = split ? threadIdx.x >> 1 : threadIdx.x;
+    bool active = i < n;
+    uint32_t ic = active ? i : n - 1;
+    u256 nx, ny, c, ssk, srn, tx, ty;
+    from_be32(nx, in + 160 * ic);
+    from_be32(ny, in + 160 * ic + 32);
+    from_be32(c, in + 160 * ic + 64);
+    from_be32(ssk, in + 160 * ic + 96);
+    from_be32(srn, in + 160 * ic + 128);
+    uint32_t st;
+    if (!split) {
+        st = bn_nym_commitment29(tx, ty, nx, ny, c, ssk, srn, hsk, hrand, qtab);
+    } else {
+        bn_nym_half mine;
+        bn_nym_split_part1(mine, odd, nx, ny, c, ssk, srn, hsk, hrand, qtab);
+        jacbn theirs;
+        for (int l = 0; l < 9; l++) {
+            theirs.X.v[l] = lane_pair_swap(mine.P.X.v[l]);
+            theirs.Y.v[l] = lane_pair_swap(mine.P.Y.v[l]);
+            theirs.Z.v[l] = lane_pair_swap(mine.P.Z.v[l]);
+        }
+        bool theirs_inf = lane_pair_swap(mine.inf ? 1 : 0) != 0;
+        st = bn_nym_split_part2(tx, ty, mine, theirs, theirs_inf);
+    }
+    if (active && (!split || !odd)) {
+        to_be32(out + 64 * i, tx);
+        to_be32(out + 64 * i + 32, ty);
+        st_out[i] = st;
+    }
+}
+
+extern "C" int gputest_nym_commitment(int split, uint32_t n, const uint8_t* hsk_xy64, const uint8_t* hrand_xy64, const uint8_t* in, uint8_t* out, uint32_t* st) {
+    if (n == 0 || n > (split ? 32u : 64u)) return -3;
+    std::vector<int32_t> t1(KeyTab8::TABLE_WORDS), t2(KeyTab8::TABLE_WORDS);
+    u256 x, y;
+    from_be32(x, hsk_xy64); from_be32(y, hsk_xy64 + 32);
+    build_bn_comb_table8(t1.data(), x, y);
+    from_be32(x, hrand_xy64); from_be32(y, hrand_xy64 + 32);
+    build_bn_comb_table8(t2.data(), x, y);
+    const size_t tb = sizeof(int32_t) * KeyTab8::TABLE_WORDS;
+    int32_t *d1 = nullptr, *d2 = nullptr;
+    uint8_t *din = nullptr, *dout = nullptr;
+    uint32_t* dst = nullptr;
+    uint4* dws = nullptr;
+    if (hipMalloc((void**)&d1, tb) != hipSuccess || hipMalloc((void**)&d2, tb) != hipSuccess || hipMalloc((void**)&din, 160 * n) != hipSuccess ||
+        hipMalloc((void**)&dout, 64 * n) != hipSuccess || hipMalloc((void**)&dst, 4 * n) != hipSuccess ||
+        hipMalloc((void**)&dws, (size_t)16 * 7 * 64 * 16) != hipSuccess)
+        return -1;
+    hipMemcpy(d1, t1.data(), tb, hipMemcpyHostToDevice);
+    hipMemcpy(d2, t2.data(), tb, hipMemcpyHostToDevice);
+    hipMemcpy(din, in, 160 * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(gputest_nym_commitment_kernel, dim3(1), dim3(64), 0, 0, split, n, din, d1, d2, dws, dout, dst);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+    hipMemcpy(out, dout, 64 * n, hipMemcpyDeviceToHost);
+    hipMemcpy(st, dst, 4 * n, hipMemcpyDeviceToHost);
+    hipFree(d1); hipFree(d2); hipFree(din); hipFree(dout); hipFree(dst); hipFree(dws);
     return rc;
 }

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(BLOCK, 1) p256_verify_pair_kernel(uint32_t n, 
     constexpr int NP = BLOCK / 2;
     const bool odd = (threadIdx.x & 1) != 0;
     const uint32_t pairidx = threadIdx.x >> 1;
-    PairQTab<NP> qtab{qws + (size_t)blockIdx.x * (QWS_PAIR_UINT4_PER_SIG * NP) + pairidx};
+    PairQTab<NP> qtab = PairQTab<NP>::of(qws + (size_t)blockIdx.x * (QWS_PAIR_UINT4_PER_SIG * NP), pairidx);
     uint32_t* verdict32 = reinterpret_cast<uint32_t*>(verdict_bits);
     const uint32_t ntiles = (n + NP - 1) / NP;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_pair_kernel(uint3
     constexpr int NP = BLOCK / 2;
     const bool odd = (threadIdx.x & 1) != 0;
     const uint32_t pairidx = threadIdx.x >> 1;
-    PairQTab<NP> qtab{qws + (size_t)blockIdx.x * (QWS_PAIR_UINT4_PER_SIG * NP) + pairidx};
+    PairQTab<NP> qtab = PairQTab<NP>::of(qws + (size_t)blockIdx.x * (QWS_PAIR_UINT4_PER_SIG * NP), pairidx);
     uint32_t* verdict32 = reinterpret_cast<uint32_t*>(verdict_bits);
     const uint32_t ntiles = (n + NP - 1) / NP;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

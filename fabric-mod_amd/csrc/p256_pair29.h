@@ -39,10 +39,29 @@ __device__ __forceinline__ void pair_sel(pair_pt& r, bool c, const pair_pt& a, c
 
 // Per-signature table j*Q (j = 1..16) in the global workspace.  Per workgroup slot: [entry][q 0..7][pair NP] x 16 bytes;
 // q 0..4 = X[9] Y[9] pad, q 5..7 = Z[9] pad.  E stores / owns the X,Y quads, O the Z quads.
+// Layout (FABGPU_QTAB_SIG_MAJOR, the default): per SIGNATURE contiguous - entry j of signature k is the 128-byte line
+// slot + (k * 16 + j - 1) * 128: the gather of a window (both lanes of the pair, eight 16-byte cells) is exactly one cache line, fully
+// used.  The round-1 layout [entry][q][pair] made the STORES of a wave contiguous but scattered a wave's gather over ~27 lines of which
+// 16 bytes each were wanted: rocprofv3 FETCH_SIZE 418 MB per 30 000-tuple launch for 266 MB of useful bytes (profiles/r01_pmc_traffic.json).
+#ifndef FABGPU_QTAB_SIG_MAJOR
+#define FABGPU_QTAB_SIG_MAJOR 1
+#endif
 template <int NP>
 struct PairQTab {
-    uint4* pair;   // workspace of this workgroup slot + pair index
+    uint4* pair;   // first 16-byte cell of this signature's table
+    // slot: workspace of this workgroup slot (NP signatures x 16 entries x 8 cells); k: index of the signature inside the workgroup
+    static __device__ __forceinline__ PairQTab of(uint4* slot, uint32_t k) {
+#if FABGPU_QTAB_SIG_MAJOR
+        return PairQTab{slot + (size_t)k * (16 * 8)};
+#else
+        return PairQTab{slot + k};
+#endif
+    }
+#if FABGPU_QTAB_SIG_MAJOR
+    __device__ __forceinline__ uint4* cell(int j, int q) const { return pair + ((size_t)(j - 1) * 8 + q); }
+#else
     __device__ __forceinline__ uint4* cell(int j, int q) const { return pair + ((size_t)(j - 1) * 8 + q) * NP; }
+#endif
     __device__ __forceinline__ void store_state(int j, const pair_pt& p, bool odd) const {
         if (!odd) {
             *cell(j, 0) = make_uint4(p.A.v[0], p.A.v[1], p.A.v[2], p.A.v[3]);

@@ -21,7 +21,8 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfabgpu.so")
+# FABGPU_LIB_PATH: A/B experiments load another build of the same library (tools/, never the tests or the driver)
+_LIB_PATH = os.environ.get("FABGPU_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libfabgpu.so")
 
 FABGPU_OK = 0
 FLAG_ONE_LANE_ONLY = 1   # fabgpu.h FABGPU_FLAG_ONE_LANE_ONLY

@@ -274,7 +274,7 @@ def test_preverify_pass_with_idemix_creators():
         assert fabgpu.memo_lookup(csp, qxy[:32], qxy[32:], sig, hashlib.sha256(msg).digest()) == int(r2["tuple_status"][i])
         assert fabgpu.memo_lookup(csp, qxy[:32], qxy[32:], sig, hashlib.sha256(msg + b"!").digest()) is None
         n_nym += 1
-    assert n_nym >= 15
+    assert n_nym >= 10
     assert fabgpu.memo_evict_block(csp, 9) == r2["memo_seeded"]
     csp.close()
 

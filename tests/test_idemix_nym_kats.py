@@ -1,0 +1,110 @@
+"""Pseudonym-signature known answers from a SECOND implementation (tests/golden/gen_idemix_nym_kats.py: affine big-integer G1 arithmetic,
+its own protobuf reader, its own HashModOrder - nothing imported from oracle/).  The reference stores no NymSignature anywhere
+(idemix/idemix_test.go:155-161 and bccsp/idemix/bridge/bridge_test.go sign and verify with fresh randomness; msp/testdata/idemix/* is key
+material only), so reference-produced signature BYTES do not exist to pin against; these vectors instead make three implementations
+of idemix/nymsignature.go:74-109 answer for each other: the generator, the oracle (oracle/idemix_oracle.py), and the kernels - on the host
+through the headers (CPU) and on the MI355X (GPU), in both lane geometries, down to the intermediate commitment t."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import idemix_oracle as io
+from idemix_common import be32, fixtures
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_nym_kats.json")))["vectors"]
+
+
+def sig_of(v):
+    return {k: bytes.fromhex(v[k]) for k in ("proof_c", "proof_s_sk", "proof_s_r_nym", "nonce")}
+
+
+def nym_of(v):
+    return int(v["nym_x"], 16), int(v["nym_y"], 16)
+
+
+def test_generator_is_independent_of_the_oracle_and_reproducible(tmp_path):
+    src = open(os.path.join(ROOT, "tests", "golden", "gen_idemix_nym_kats.py")).read()
+    imports = [l.strip() for l in src.splitlines() if l.strip().startswith(("import ", "from "))]
+    assert sorted(imports) == ["import hashlib", "import json", "import os", "import random"]      # nothing of oracle/, nothing of the product
+    import subprocess
+    import sys
+    gen = tmp_path / "gen.py"
+    gen.write_text(src.replace('os.path.join(HERE, "idemix_nym_kats.json")', repr(str(tmp_path / "out.json"))).replace(
+        "HERE = os.path.dirname(os.path.abspath(__file__))", "HERE = %r" % os.path.join(ROOT, "tests", "golden")))
+    subprocess.run([sys.executable, str(gen)], check=True, capture_output=True)
+    assert json.load(open(tmp_path / "out.json"))["vectors"] == KATS
+    assert len(KATS) == 24 and {v["msp"] for v in KATS} == {"MSP1OU1", "MSP1OU1Admin", "MSP1OU2", "MSP2OU1"}
+
+
+def test_oracle_agrees_with_the_second_implementation():
+    fx = fixtures()
+    for v in KATS:
+        ipk = fx[v["msp"]]["ipk"]
+        sig, nym, msg = sig_of(v), nym_of(v), bytes.fromhex(v["msg"])
+        assert io.nym_verify(sig, nym, ipk, msg) == io.NYM_VALID
+        assert io.nym_verify_t(sig, nym, ipk) == (int(v["t_x"], 16), int(v["t_y"], 16))
+        assert io.nym_verify(sig, nym, ipk, msg + b"\x00") == io.NYM_BAD_PROOF
+        bad = dict(sig, proof_s_sk=be32((int(v["proof_s_sk"], 16) + 1) % io.R))
+        assert io.nym_verify(bad, nym, ipk, msg) == io.NYM_BAD_PROOF
+        # and the nym is what MakeNym computes from the fixture's secret key (idemix/util.go:100-107): HSk^sk * HRand^r for some r -
+        # checked through the verification equation above; here only that it is a curve point
+        assert io.g1_on_curve(nym)
+
+
+def test_kernel_headers_on_the_host_reproduce_the_commitment():
+    L = ctypes.CDLL(os.path.join(ROOT, "fabric-mod_amd", "lib", "libfabgpu_hosttest.so"))
+    L.hosttest_bn_issuer_new.restype = ctypes.c_void_p
+    L.hosttest_bn_issuer_new.argtypes = [ctypes.c_char_p] * 4
+    L.hosttest_bn_issuer_free.argtypes = [ctypes.c_void_p]
+    L.hosttest_bn_nym_commitment.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 7
+    L.hosttest_bn_nym_commitment_split.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 7
+    fx = fixtures()
+    ox, oy = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    for name in sorted({v["msp"] for v in KATS}):
+        ipk = fx[name]["ipk"]
+        h = ctypes.c_void_p(L.hosttest_bn_issuer_new(be32(ipk.h_sk[0]), be32(ipk.h_sk[1]), be32(ipk.h_rand[0]), be32(ipk.h_rand[1])))
+        try:
+            for v in (v for v in KATS if v["msp"] == name):
+                args = (bytes.fromhex(v["nym_x"]), bytes.fromhex(v["nym_y"]), bytes.fromhex(v["proof_c"]), bytes.fromhex(v["proof_s_sk"]),
+                        bytes.fromhex(v["proof_s_r_nym"]))
+                for fn in (L.hosttest_bn_nym_commitment, L.hosttest_bn_nym_commitment_split):
+                    assert fn(h, *args, ox, oy) == 0
+                    assert (ox.raw.hex(), oy.raw.hex()) == (v["t_x"], v["t_y"])
+        finally:
+            L.hosttest_bn_issuer_free(h)
+
+
+@pytest.mark.gpu
+def test_device_commitment_and_verdicts_on_the_independent_vectors():
+    import fabgpu
+    G = ctypes.CDLL(os.path.join(ROOT, "fabric-mod_amd", "lib", "libfabgpu_gputest.so"))
+    fx = fixtures()
+    ctx = fabgpu.Context(device=0)
+    try:
+        for name in sorted({v["msp"] for v in KATS}):
+            ipk = fx[name]["ipk"]
+            vs = [v for v in KATS if v["msp"] == name]
+            n = len(vs)
+            rows = b"".join(bytes.fromhex(v["nym_x"] + v["nym_y"] + v["proof_c"] + v["proof_s_sk"] + v["proof_s_r_nym"]) for v in vs)
+            for split in (0, 1):                                   # the device's own t, one lane and two lanes per signature
+                out = ctypes.create_string_buffer(64 * n)
+                st = (ctypes.c_uint32 * n)()
+                rc = G.gputest_nym_commitment(split, n, be32(ipk.h_sk[0]) + be32(ipk.h_sk[1]), be32(ipk.h_rand[0]) + be32(ipk.h_rand[1]), rows, out, st)
+                assert rc == 0 and list(st) == [0] * n
+                for i, v in enumerate(vs):
+                    assert out.raw[64 * i:64 * i + 32].hex() == v["t_x"] and out.raw[64 * i + 32:64 * i + 64].hex() == v["t_y"], (name, split, i)
+            # the product entry point: accepts every vector, rejects every tampered twin
+            iid = ctx.idemix_issuer_register((be32(ipk.h_sk[0]), be32(ipk.h_sk[1])), (be32(ipk.h_rand[0]), be32(ipk.h_rand[1])), ipk.hash)
+            msgs = [bytes.fromhex(v["msg"]) for v in vs] + [bytes.fromhex(v["msg"]) + b"\x01" for v in vs]
+            off = np.concatenate([[0], np.cumsum([len(m) for m in msgs])]).astype(np.uint32)
+            arena = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8)
+            cols = [np.frombuffer(b"".join(bytes.fromhex(v[k]) for v in vs) * 2, dtype=np.uint8).reshape(2 * n, 32)
+                    for k in ("nym_x", "nym_y", "proof_c", "proof_s_sk", "proof_s_r_nym", "nonce")]
+            ok, stt = ctx.idemix_nym_verify_batch(arena, off, *cols, issuer_id=np.full(2 * n, iid, dtype=np.uint32))
+            assert list(stt) == [0] * n + [1] * n and list(ok) == [True] * n + [False] * n
+    finally:
+        ctx.close()
