@@ -416,6 +416,9 @@ Error GPUCSP::IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::v
 // block-level pre-verify pass (block_prepass.h)
 // ------------------------------------------------------------------------------------------------
 void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len) const {
+    // a launch is coming in a millisecond or three (walk + gates): start raising the clock now (fabgpu.h fabgpu_warm)
+    static const uint32_t warm_us = [] { const char* e = getenv("FABGPU_PASS_WARM_US"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();
+    if (warm_us) fabgpu_warm(ctx_, warm_us);
     size_t min_bytes = (size_t)4 << 20;                 // small blocks ride with the submission through pinned staging
     if (const char* e = getenv("FABGPU_PASS_STAGE_MIN_BYTES")) min_bytes = (size_t)strtoull(e, nullptr, 10);   // tests force the staged path
     if (!block || len < min_bytes) return;
@@ -506,54 +509,70 @@ Error GPUCSP::X509CheckSignatureBatch(size_t n, const uint8_t* cert_arena, const
 }
 
 // ---- verdict memo -------------------------------------------------------------------------------------------------------
-std::string GPUCSP::MemoKey(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) {
-    std::string k;
-    k.reserve(64 + 8 + siglen + dlen);
-    k.append((const char*)qx32, 32);
-    k.append((const char*)qy32, 32);
+void GPUCSP::MemoKeyWrite(uint8_t* k, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) {
+    memcpy(k, qx32, 32);
+    memcpy(k + 32, qy32, 32);
     const uint32_t sl = (uint32_t)siglen, dl = (uint32_t)dlen;      // length framing: (sig || d[:k], d[k:]) must not collide with (sig, d)
-    k.append((const char*)&sl, 4);
-    k.append((const char*)sig, siglen);
-    k.append((const char*)&dl, 4);
-    k.append((const char*)digest, dlen);
-    return k;
+    memcpy(k + 64, &sl, 4);
+    memcpy(k + 68, sig, siglen);
+    memcpy(k + 68 + siglen, &dl, 4);
+    memcpy(k + 72 + siglen, digest, dlen);
+}
+// Slot choice only (a hit is decided by comparing the whole key): the digest is SHA-256 output - uniformly distributed whatever the
+// sender of the block does - mixed with the tail of the signature.
+uint64_t GPUCSP::MemoHash(const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) {
+    uint64_t a = 0, b = 0;
+    memcpy(&a, digest, dlen < 8 ? dlen : 8);
+    memcpy(&b, sig + (siglen > 8 ? siglen - 8 : 0), siglen < 8 ? siglen : 8);
+    uint64_t h = (a ^ (b * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+    return h ^ (h >> 32);
 }
 int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen, uint8_t* status) const {
-    if (!qx32 || !qy32 || !sig || !digest || siglen > 0xFFFF || dlen > 0xFFFF) return 1;
-    const std::string k = MemoKey(qx32, qy32, sig, siglen, digest, dlen);
-    std::lock_guard<std::mutex> lk(memo_mu_);
-    auto it = memo_.find(k);
-    if (it == memo_.end()) {
-        memo_misses_++;
-        return 1;
+    if (!qx32 || !qy32 || !sig || !digest || siglen == 0 || dlen == 0 || siglen > 1024 || dlen > 1024) return 1;
+    uint8_t key[64 + 8 + 2048];
+    const size_t kl = MemoKeyBytes(siglen, dlen);
+    MemoKeyWrite(key, qx32, qy32, sig, siglen, digest, dlen);
+    const uint64_t h = MemoHash(sig, siglen, digest, dlen);
+    std::shared_lock<std::shared_timed_mutex> lk(memo_mu_);
+    for (auto it = memo_blocks_.rbegin(); it != memo_blocks_.rend(); ++it) {      // newest block first
+        const BlockMemo& bm = **it;
+        if (!bm.n) continue;
+        for (uint32_t probe = 0, at = (uint32_t)h & bm.mask; probe <= bm.mask && probe < 4096; probe++, at = (at + 1) & bm.mask) {
+            const uint32_t e = bm.slots[at].load(std::memory_order_acquire);
+            if (!e) break;
+            const uint32_t o = bm.key_off[e - 1], l = bm.key_off[e] - o;
+            if (l == kl && memcmp(&bm.keys[o], key, kl) == 0) {
+                if (status) *status = bm.status[e - 1];
+                memo_hits_.fetch_add(1, std::memory_order_relaxed);
+                return 0;
+            }
+        }
     }
-    memo_hits_++;
-    if (status) *status = it->second.status;
-    return 0;
+    memo_misses_.fetch_add(1, std::memory_order_relaxed);
+    return 1;
 }
 size_t GPUCSP::MemoEvictBlock(uint64_t block_seq) const {
-    std::lock_guard<std::mutex> lk(memo_mu_);
+    std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
     size_t gone = 0;
     for (auto b = memo_blocks_.begin(); b != memo_blocks_.end();) {
-        if (b->first != block_seq) { ++b; continue; }
-        for (const std::string& k : b->second) {
-            auto it = memo_.find(k);
-            if (it != memo_.end() && it->second.block_seq == block_seq) { memo_.erase(it); gone++; }
-        }
+        if ((*b)->seq != block_seq) { ++b; continue; }
+        gone += (*b)->n;
         b = memo_blocks_.erase(b);
     }
-    memo_evicted_ += gone;
+    memo_evicted_.fetch_add(gone, std::memory_order_relaxed);
     return gone;
 }
 void GPUCSP::MemoStats(uint64_t* entries, uint64_t* hits, uint64_t* misses, uint64_t* evicted) const {
-    std::lock_guard<std::mutex> lk(memo_mu_);
-    if (entries) *entries = memo_.size();
-    if (hits) *hits = memo_hits_;
-    if (misses) *misses = memo_misses_;
-    if (evicted) *evicted = memo_evicted_;
+    std::shared_lock<std::shared_timed_mutex> lk(memo_mu_);
+    uint64_t n = 0;
+    for (const auto& b : memo_blocks_) n += b->n;
+    if (entries) *entries = n;
+    if (hits) *hits = memo_hits_.load();
+    if (misses) *misses = memo_misses_.load();
+    if (evicted) *evicted = memo_evicted_.load();
 }
 void GPUCSP::MemoSetCapacity(size_t max_entries) const {
-    std::lock_guard<std::mutex> lk(memo_mu_);
+    std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
     memo_cap_ = max_entries ? max_entries : 1;
 }
 void GPUCSP::SetIdentityCacheLimits(size_t max_identities, size_t max_registered_keys, uint32_t register_after_hits) const {
@@ -989,32 +1008,70 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             if (!ok) id_registered_--;
         }
     }
-    // verdict memo: one entry per tuple the device hashed and decided, keyed on (key, signature bytes, device digest)
+    // verdict memo: one entry per tuple the device hashed and decided, keyed on (key, signature bytes, device digest).  The block's
+    // table is built here, outside the memo lock, by the pass's worker threads; publishing it is one push under the lock.
     if (opt.seed_memo) {
-        std::vector<std::string> keys;
-        keys.reserve(nt);
-        std::lock_guard<std::mutex> lk(memo_mu_);
+        std::shared_ptr<BlockMemo> bm(new BlockMemo);
+        bm->seq = opt.block_seq;
+        std::vector<uint32_t>& sel = ps_.sub;              // reuse: indices of the tuples that get an entry
+        if (sel.size() < nt) sel.resize(nt);
+        uint32_t m = 0;
+        bm->key_off.reserve(nt + 1);
+        bm->key_off.push_back(0);
         for (size_t i = 0; i < nt; i++) {
             if (!out.tuple_hashed[i]) continue;
             const uint8_t stt = out.tuple_status[i];
             if (stt > FABGPU_ST_RANGE) continue;           // 0 valid, 1 bad math, 2 high-S, 3 range: what bccsp.Verify decides itself
             // (pseudonym signatures: key = Nym.x || Nym.y, digest = SHA-256(message), status 0 valid / 1 proof invalid)
-            const BlockTuple& tp = pb.tuples[i];
-            std::string k = MemoKey(&out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], block + tp.sig.off, tp.sig.len, &out.tuple_digest[32 * i], 32);
-            MemoEntry& e = memo_[k];
-            e.status = stt;
-            e.block_seq = opt.block_seq;
-            keys.push_back(std::move(k));
+            if (pb.tuples[i].sig.len == 0 || pb.tuples[i].sig.len > 1024) continue;
+            sel[m++] = (uint32_t)i;
+            bm->key_off.push_back(bm->key_off.back() + (uint32_t)MemoKeyBytes(pb.tuples[i].sig.len, 32));
         }
-        out.memo_seeded = (uint32_t)keys.size();
-        if (!keys.empty()) memo_blocks_.emplace_back(opt.block_seq, std::move(keys));
-        while (memo_.size() > memo_cap_ && memo_blocks_.size() > 1) {     // bounded: the oldest block's entries go first
-            auto& b = memo_blocks_.front();
-            for (const std::string& k : b.second) {
-                auto it = memo_.find(k);
-                if (it != memo_.end() && it->second.block_seq == b.first) { memo_.erase(it); memo_evicted_++; }
+        bm->n = m;
+        if (m) {
+            uint32_t cap = 16;
+            while (cap < 2 * m) cap <<= 1;
+            bm->mask = cap - 1;
+            bm->slots.reset(new std::atomic<uint32_t>[cap]);
+            for (uint32_t k = 0; k < cap; k++) bm->slots[k].store(0, std::memory_order_relaxed);
+            bm->keys.resize(bm->key_off.back());
+            bm->status.resize(m);
+            BlockMemo* raw = bm.get();
+            auto fill = [&, raw](size_t lo, size_t hi) {
+                for (size_t e = lo; e < hi; e++) {
+                    const size_t i = sel[e];
+                    const BlockTuple& tp = pb.tuples[i];
+                    const uint8_t* sg = block + tp.sig.off;
+                    MemoKeyWrite(&raw->keys[raw->key_off[e]], &out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], sg, tp.sig.len, &out.tuple_digest[32 * i], 32);
+                    raw->status[e] = out.tuple_status[i];
+                    uint32_t at = (uint32_t)MemoHash(sg, tp.sig.len, &out.tuple_digest[32 * i], 32) & raw->mask;
+                    for (;;) {                             // lock-free linear probing: the table is at most half full
+                        uint32_t expect = 0;
+                        if (raw->slots[at].compare_exchange_strong(expect, (uint32_t)e + 1, std::memory_order_release, std::memory_order_relaxed)) break;
+                        at = (at + 1) & raw->mask;
+                    }
+                }
+            };
+            const int ft = m >= 8192 ? 8 : 1;
+            if (ft == 1) {
+                fill(0, m);
+            } else {
+                std::vector<std::thread> th;
+                for (int w = 0; w < ft; w++) th.emplace_back(fill, (size_t)m * w / ft, (size_t)m * (w + 1) / ft);
+                for (auto& x : th) x.join();
             }
-            memo_blocks_.pop_front();
+        }
+        out.memo_seeded = m;
+        if (m) {
+            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+            memo_blocks_.push_back(bm);
+            size_t total = 0;
+            for (const auto& b : memo_blocks_) total += b->n;
+            while (total > memo_cap_ && memo_blocks_.size() > 1) {        // bounded: the oldest block goes first
+                total -= memo_blocks_.front()->n;
+                memo_evicted_.fetch_add(memo_blocks_.front()->n, std::memory_order_relaxed);
+                memo_blocks_.pop_front();
+            }
         }
     }
     return Error();

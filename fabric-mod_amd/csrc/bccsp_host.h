@@ -13,7 +13,9 @@
 #include <deque>
 #include <list>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -186,16 +188,24 @@ class GPUCSP {
     mutable size_t id_max_ = 4096, id_max_registered_ = 256, id_registered_ = 0;
     mutable uint32_t id_register_after_ = 64;
     // verdict memo
-    struct MemoEntry {
-        uint8_t status;
-        uint64_t block_seq;
+    // One table per BLOCK (seeded once by the pass, dropped whole when the block's validation returns): an open-addressed index over
+    // length-framed keys stored back to back - no allocation per entry, filled by the pass's worker threads in parallel (a
+    // 10 000-transaction block seeds 40 000 entries; a node-per-entry map cost more than the device call).  Lookups take a shared lock.
+    struct BlockMemo {
+        uint64_t seq = 0;
+        uint32_t n = 0, mask = 0;
+        std::unique_ptr<std::atomic<uint32_t>[]> slots;   // entry index + 1; 0 = empty
+        std::vector<uint32_t> key_off;                    // n + 1 offsets into keys
+        std::vector<uint8_t> keys;                        // framed keys: X || Y || u32 len || sig || u32 len || digest
+        std::vector<uint8_t> status;                      // n
     };
-    mutable std::mutex memo_mu_;
-    mutable std::unordered_map<std::string, MemoEntry> memo_;
-    mutable std::deque<std::pair<uint64_t, std::vector<std::string>>> memo_blocks_;   // insertion order: oldest block first
+    mutable std::shared_timed_mutex memo_mu_;
+    mutable std::deque<std::shared_ptr<BlockMemo>> memo_blocks_;   // oldest first
     mutable size_t memo_cap_ = (size_t)1 << 18;
-    mutable uint64_t memo_hits_ = 0, memo_misses_ = 0, memo_evicted_ = 0;
-    static std::string MemoKey(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
+    mutable std::atomic<uint64_t> memo_hits_{0}, memo_misses_{0}, memo_evicted_{0};
+    static size_t MemoKeyBytes(size_t siglen, size_t dlen) { return 64 + 4 + siglen + 4 + dlen; }
+    static void MemoKeyWrite(uint8_t* out, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
+    static uint64_t MemoHash(const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
     mutable std::map<std::string, int64_t> idemix_msps_;   // mspid -> device issuer id (guarded by idmu_)
     // scratch of the pre-verify pass, reused from block to block (guarded by pass_mu_)
     struct PassScratch {

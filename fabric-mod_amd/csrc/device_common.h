@@ -218,28 +218,41 @@ __device__ __forceinline__ void emit_verdict(uint32_t i, bool active, uint32_t s
 
 // Per-lane table j*Q in a global-memory workspace (not private/scratch memory: the runtime caps a dispatch's scratch
 // at ~140 MiB, which at 1.8 KB per lane admitted only ~1270 wavefronts and held the kernel at one wave per SIMD).
-// Layout per workgroup slot: [entry j-1, j = 1..16][group 7][lane BLOCK] x 16 bytes - entry j of lane t is seven uint4 (27 limbs + pad),
-// consecutive lanes are consecutive 16-byte cells, so a store (all lanes the same j) is fully coalesced and a gather by
-// digit touches at most 15 distinct 4 KiB rows per group.
+// Layout (FABGPU_QTAB_LANE_MAJOR, the default): per LANE contiguous - entry j of lane t is the 128-byte line
+// slot + (t * 16 + j - 1) * 128 (seven 16-byte cells = 27 limbs + pad, the eighth cell unused): a gather by digit is ONE cache line
+// per lane, fully used.  The round-1 layout [entry][cell][lane] kept a wave's stores contiguous but scattered every gather over seven
+// 4 KiB rows in which a lane wanted 16 bytes each (see p256_pair29.h PairQTab for the measured effect on the pair kernel: FETCH_SIZE / 3.8).
+#ifndef FABGPU_QTAB_LANE_MAJOR
+#define FABGPU_QTAB_LANE_MAJOR 1
+#endif
 template <int BLOCK>
 struct GlobalQTab29 {
-    uint4* lane;   // workspace of this workgroup slot + threadIdx.x
+    uint4* lane;   // first 16-byte cell of this lane's table
+#if FABGPU_QTAB_LANE_MAJOR
+    static constexpr size_t STRIDE = 1;          // cell q of an entry at +q
+    static constexpr size_t ENTRY = 8;           // cells per entry
+    static __device__ __forceinline__ GlobalQTab29 of(uint4* slot, uint32_t t) { return GlobalQTab29{slot + (size_t)t * (16 * 8)}; }
+#else
+    static constexpr size_t STRIDE = BLOCK;
+    static constexpr size_t ENTRY = 7 * (size_t)BLOCK;
+    static __device__ __forceinline__ GlobalQTab29 of(uint4* slot, uint32_t t) { return GlobalQTab29{slot + t}; }
+#endif
     template <class J>
     __device__ __forceinline__ void store(int j, const J& p) {
-        uint4* e = lane + (size_t)(j - 1) * 7 * BLOCK;
-        e[0 * BLOCK] = make_uint4(p.X.v[0], p.X.v[1], p.X.v[2], p.X.v[3]);
-        e[1 * BLOCK] = make_uint4(p.X.v[4], p.X.v[5], p.X.v[6], p.X.v[7]);
-        e[2 * BLOCK] = make_uint4(p.X.v[8], p.Y.v[0], p.Y.v[1], p.Y.v[2]);
-        e[3 * BLOCK] = make_uint4(p.Y.v[3], p.Y.v[4], p.Y.v[5], p.Y.v[6]);
-        e[4 * BLOCK] = make_uint4(p.Y.v[7], p.Y.v[8], p.Z.v[0], p.Z.v[1]);
-        e[5 * BLOCK] = make_uint4(p.Z.v[2], p.Z.v[3], p.Z.v[4], p.Z.v[5]);
-        e[6 * BLOCK] = make_uint4(p.Z.v[6], p.Z.v[7], p.Z.v[8], 0);
+        uint4* e = lane + (size_t)(j - 1) * ENTRY;
+        e[0 * STRIDE] = make_uint4(p.X.v[0], p.X.v[1], p.X.v[2], p.X.v[3]);
+        e[1 * STRIDE] = make_uint4(p.X.v[4], p.X.v[5], p.X.v[6], p.X.v[7]);
+        e[2 * STRIDE] = make_uint4(p.X.v[8], p.Y.v[0], p.Y.v[1], p.Y.v[2]);
+        e[3 * STRIDE] = make_uint4(p.Y.v[3], p.Y.v[4], p.Y.v[5], p.Y.v[6]);
+        e[4 * STRIDE] = make_uint4(p.Y.v[7], p.Y.v[8], p.Z.v[0], p.Z.v[1]);
+        e[5 * STRIDE] = make_uint4(p.Z.v[2], p.Z.v[3], p.Z.v[4], p.Z.v[5]);
+        e[6 * STRIDE] = make_uint4(p.Z.v[6], p.Z.v[7], p.Z.v[8], 0);
     }
     template <class J>
     __device__ __forceinline__ void load(uint32_t d, J& p) const {
-        const uint4* e = lane + (size_t)(d - 1) * 7 * BLOCK;
-        uint4 a = e[0 * BLOCK], b = e[1 * BLOCK], c = e[2 * BLOCK], dd = e[3 * BLOCK];
-        uint4 f = e[4 * BLOCK], g = e[5 * BLOCK], h = e[6 * BLOCK];
+        const uint4* e = lane + (size_t)(d - 1) * ENTRY;
+        uint4 a = e[0 * STRIDE], b = e[1 * STRIDE], c = e[2 * STRIDE], dd = e[3 * STRIDE];
+        uint4 f = e[4 * STRIDE], g = e[5 * STRIDE], h = e[6 * STRIDE];
         p.X.v[0] = a.x; p.X.v[1] = a.y; p.X.v[2] = a.z; p.X.v[3] = a.w;
         p.X.v[4] = b.x; p.X.v[5] = b.y; p.X.v[6] = b.z; p.X.v[7] = b.w;
         p.X.v[8] = c.x; p.Y.v[0] = c.y; p.Y.v[1] = c.z; p.Y.v[2] = c.w;

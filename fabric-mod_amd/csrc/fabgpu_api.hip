@@ -47,6 +47,11 @@ struct fabgpu_ctx {
     int device = 0;
     bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
     hipStream_t stream = nullptr;
+    hipStream_t warm_stream = nullptr;   // fabgpu_warm: never the stream a batch runs on
+    void* d_warm_sink = nullptr;
+    // FABGPU_FAULT_INJECT (tests of the failure contract only): "launch" makes every kernel submission report hipErrorLaunchFailure,
+    // "oom" makes every workspace / staging allocation fail.  A non-zero return must then reach the caller and no verdict may be written.
+    int fault = 0;
     int32_t* d_gtab = nullptr;
     std::mutex mu;
     Buf fields;   // qx|qy|e|r|s
@@ -55,6 +60,8 @@ struct fabgpu_ctx {
     Buf out;      // verdict words | status bytes | digests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool time_kernels = false;   // FABGPU_FLAG_TIME_KERNELS: bracket every launch with two timing events (fabgpu_last_kernel_ms); off by
+                                 // default - two more packets per launch between back-to-back kernels are not free
     // Workspaces for the verify kernels' per-lane j*Q tables.  A launch borrows one: `reserved` from acquire until release has
     // recorded an event behind the kernel, `armed` from then until that event completes - two separate flags, because between
     // acquire and release the event is stale (or was never recorded) and hipEventQuery on it would answer "done".
@@ -65,6 +72,9 @@ struct fabgpu_ctx {
         hipEvent_t done = nullptr;
         bool reserved = false;   // handed to a launch that has not recorded `done` yet
         bool armed = false;      // `done` was recorded behind the launch that used it
+        hipStream_t last = nullptr;   // the stream of that launch: a later launch on the SAME stream runs behind it anyway and may
+                                      // take the workspace without waiting (20 queued steps of a bench loop used to mean 20 workspaces
+                                      // of 61 MB each, allocated inside the timed region)
     };
     std::vector<QWs> qws;
     // Registered public keys: one 640 KiB comb table each, resident on the device; d_ktabs mirrors the pointer array.
@@ -93,7 +103,7 @@ struct fabgpu_ctx {
     Buf pre;          // staging of prefixed batches: pre_off | pre_idx | mid-states
     Buf tailbuf;      // staging of an identity batch's tail when the arena itself bypasses the pinned buffer
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
-    int acquire_qws(size_t bytes, size_t* idx, void** p);
+    int acquire_qws(size_t bytes, size_t* idx, void** p, hipStream_t st);
     void release_qws(size_t idx, hipStream_t st) {
         std::lock_guard<std::mutex> lk(qmu);
         QWs& w = qws[idx];
@@ -101,24 +111,28 @@ struct fabgpu_ctx {
         if (hipEventRecord(w.done, st) == hipSuccess) {
             w.armed = true;
             w.reserved = false;
+            w.last = st;
         }
     }
 };
 
-int fabgpu_ctx::acquire_qws(size_t bytes, size_t* idx, void** p) {
+int fabgpu_ctx::acquire_qws(size_t bytes, size_t* idx, void** p, hipStream_t st) {
+    if (fault == 2) return FABGPU_ENOMEM;
     std::lock_guard<std::mutex> lk(qmu);
     for (size_t i = 0; i < qws.size(); i++) {
         QWs& w = qws[i];
         if (w.reserved) continue;                                          // somebody is between acquire and release
-        if (w.armed && hipEventQuery(w.done) != hipSuccess) continue;      // still in flight on some stream
-        w.armed = false;
+        const bool same_stream = w.armed && w.last == st;                  // stream order serialises the two launches
+        if (w.armed && !same_stream && hipEventQuery(w.done) != hipSuccess) continue;      // still in flight on another stream
         if (w.bytes < bytes) {
+            if (same_stream && hipEventQuery(w.done) != hipSuccess) continue;              // cannot free what a queued launch still reads
             if (w.p) hipFree(w.p);
             w.p = nullptr;
             w.bytes = 0;
             if (hipMalloc(&w.p, bytes) != hipSuccess) return FABGPU_ENOMEM;
             w.bytes = bytes;
         }
+        w.armed = false;
         w.reserved = true;
         *idx = i;
         *p = w.p;
@@ -153,6 +167,8 @@ struct DeviceGuard {
 };
 
 int hip_to_rc(hipError_t e) { return e == hipSuccess ? FABGPU_OK : (e == hipErrorOutOfMemory ? FABGPU_ENOMEM : FABGPU_ELAUNCH); }
+// the launch result an entry point reports: the real one, or the injected failure
+inline hipError_t launched(const fabgpu_ctx* ctx, hipError_t e) { return ctx->fault == 1 ? hipErrorLaunchFailure : e; }
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -183,7 +199,7 @@ int fabgpu_device_count(fabgpu_ctx*) {
 int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!out) return FABGPU_EINVAL;
     *out = nullptr;
-    if (cfg && (cfg->flags & ~(uint32_t)FABGPU_FLAG_ONE_LANE_ONLY) != 0) return FABGPU_EINVAL;
+    if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS)) != 0) return FABGPU_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
     int dev = cfg ? cfg->device : -1;
@@ -198,10 +214,14 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!ctx) return FABGPU_ENOMEM;
     ctx->device = dev;
     ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
+    ctx->time_kernels = cfg && (cfg->flags & FABGPU_FLAG_TIME_KERNELS);
     DeviceGuard g(dev);
     int rc = FABGPU_OK;
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        if (hipStreamCreateWithFlags(&ctx->warm_stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        if (hipMalloc(&ctx->d_warm_sink, 64) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
+        if (const char* fi = getenv("FABGPU_FAULT_INJECT")) ctx->fault = !strcmp(fi, "launch") ? 1 : (!strcmp(fi, "oom") ? 2 : 0);
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         std::vector<int32_t> tab(GTab16::TABLE_WORDS);   // 80 MiB, ~0.2 s on 16 host threads
         build_g_comb_table16(tab.data());
@@ -228,6 +248,8 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
     {
         DeviceGuard g(ctx->device);
         if (ctx->stream) hipStreamSynchronize(ctx->stream);
+        if (ctx->warm_stream) { hipStreamSynchronize(ctx->warm_stream); hipStreamDestroy(ctx->warm_stream); }
+        if (ctx->d_warm_sink) hipFree(ctx->d_warm_sink);
         ctx->fields.release();
         ctx->arena.release();
         ctx->offs.release();
@@ -256,6 +278,12 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
     delete ctx;
 }
 
+int fabgpu_warm(fabgpu_ctx* ctx, uint32_t usec) {
+    if (!ctx) return FABGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    return hip_to_rc(launch_warm(usec, ctx->d_warm_sink, ctx->warm_stream));
+}
+
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx) {
     if (!ctx || !ctx->timed) return -1.0f;
     DeviceGuard g(ctx->device);
@@ -275,14 +303,14 @@ int fabgpu_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* qx, cons
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
     void* wsp = nullptr;
-    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp);
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp, st);
     if (rc != FABGPU_OK) return rc;
-    hipEventRecord(ctx->ev0, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, wsp, verdict_bits, status, ctx->allow_pair, st);
-    hipEventRecord(ctx->ev1, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
-    ctx->timed = true;
-    return hip_to_rc(err);
+    ctx->timed = ctx->time_kernels;
+    return hip_to_rc(launched(ctx, err));
 }
 
 int fabgpu_sha256_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off, void* digests,
@@ -292,11 +320,11 @@ int fabgpu_sha256_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t
     if (n == 0) return FABGPU_OK;
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
-    hipEventRecord(ctx->ev0, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_sha256_batch((uint32_t)n, arena, arena_bytes, off, digests, st);
-    hipEventRecord(ctx->ev1, st);
-    ctx->timed = true;
-    return hip_to_rc(err);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
+    ctx->timed = ctx->time_kernels;
+    return hip_to_rc(launched(ctx, err));
 }
 
 int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
@@ -309,14 +337,14 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
     void* wsp = nullptr;
-    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp);
+    int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp, st);
     if (rc != FABGPU_OK) return rc;
-    hipEventRecord(ctx->ev0, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_sha256_p256_verify((uint32_t)n, arena, arena_bytes, off, qx, qy, r, s, ctx->d_gtab, wsp, verdict_bits, status, ctx->allow_pair, ShaPrefixArgs(), st);
-    hipEventRecord(ctx->ev1, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
-    ctx->timed = true;
-    return hip_to_rc(err);
+    ctx->timed = ctx->time_kernels;
+    return hip_to_rc(launched(ctx, err));
 }
 
 // ---- idemix pseudonym signatures --------------------------------------------------------------------
@@ -412,15 +440,15 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
     void* wsp = nullptr;
-    int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp);
+    int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp, st);
     if (rc != FABGPU_OK) return rc;
-    hipEventRecord(ctx->ev0, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
                                               proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, st);
-    hipEventRecord(ctx->ev1, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
-    ctx->timed = true;
-    return hip_to_rc(err);
+    ctx->timed = ctx->time_kernels;
+    return hip_to_rc(launched(ctx, err));
 }
 
 // ---- registered public keys -------------------------------------------------------------------------
@@ -504,11 +532,11 @@ int fabgpu_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* ke
     if (nkeys == 0) return FABGPU_EINVAL;
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
-    hipEventRecord(ctx->ev0, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_p256_verify_keyed((uint32_t)n, key_id, nkeys, (const void*)kt, e, r, s, ctx->d_gtab, verdict_bits, status, ctx->allow_pair, st);
-    hipEventRecord(ctx->ev1, st);
-    ctx->timed = true;
-    return hip_to_rc(err);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
+    ctx->timed = ctx->time_kernels;
+    return hip_to_rc(launched(ctx, err));
 }
 
 int fabgpu_sha256_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
@@ -526,12 +554,12 @@ int fabgpu_sha256_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const v
     if (nkeys == 0) return FABGPU_EINVAL;
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
-    hipEventRecord(ctx->ev0, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_sha256_p256_verify_keyed((uint32_t)n, arena, arena_bytes, off, key_id, nkeys, (const void*)kt, r, s, ctx->d_gtab, verdict_bits,
                                                      status, ctx->allow_pair, ShaPrefixArgs(), st);
-    hipEventRecord(ctx->ev1, st);
-    ctx->timed = true;
-    return hip_to_rc(err);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
+    ctx->timed = ctx->time_kernels;
+    return hip_to_rc(launched(ctx, err));
 }
 
 // ---- host-pointer entry points (what the cgo provider binds) -----------------------------------------
@@ -761,22 +789,23 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
             kt = ctx->d_ktabs;
         }
         if (nkeys == 0) return FABGPU_EINVAL;
-        hipEventRecord(ctx->ev0, st);
+        if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
         err = launch_sha256_p256_verify_keyed((uint32_t)n, b->arena, b->arena_bytes, b->off, b->key_id, nkeys, (const void*)kt, b->r, b->s, ctx->d_gtab,
                                               b->verdict_bits, b->status, ctx->allow_pair, pa, st);
-        hipEventRecord(ctx->ev1, st);
+        if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
     } else {
         size_t wi = 0;
         void* wsp = nullptr;
-        int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp);
+        int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp, st);
         if (rc != FABGPU_OK) return rc;
-        hipEventRecord(ctx->ev0, st);
+        if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
         err = launch_sha256_p256_verify((uint32_t)n, b->arena, b->arena_bytes, b->off, b->qx, b->qy, b->r, b->s, ctx->d_gtab, wsp,
                                         b->verdict_bits, b->status, ctx->allow_pair, pa, st);
-        hipEventRecord(ctx->ev1, st);
+        if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
         ctx->release_qws(wi, st);
     }
-    ctx->timed = true;
+    ctx->timed = ctx->time_kernels;
+    err = launched(ctx, err);
     if (err == hipSuccess && b->n_gather)   // behind the verification on the same stream; not part of fabgpu_last_kernel_ms
         err = launch_gather_sha256(b->n_gather, b->arena, b->arena_bytes, b->gather_spans, b->gather_off, b->gather_scratch, b->gather_scratch_bytes,
                                    b->gather_digests, st);

@@ -202,7 +202,7 @@ extern "C" int gputest_pair_verify(const uint8_t* in, int32_t* out) {
 __global__ void __launch_bounds__(64, 1) gputest_nym_commitment_kernel(int split, uint32_t n, const uint8_t* __restrict__ in, const int32_t* __restrict__ hskt,
                                                                         const int32_t* __restrict__ hrandt, uint4* __restrict__ qws, uint8_t* __restrict__ out,
                                                                         uint32_t* __restrict__ st_out) {
-    GlobalQTab29<64> qtab{qws + threadIdx.x};
+    GlobalQTab29<64> qtab = GlobalQTab29<64>::of(qws, threadIdx.x);
     KeyTab8 hsk{hskt}, hrand{hrandt};
     const bool odd = (threadIdx.x & 1u) != 0;
     uint32_t i = split ? threadIdx.x >> 1 : threadIdx.x;
@@ -251,7 +251,7 @@ extern "C" int gputest_nym_commitment(int split, uint32_t n, const uint8_t* hsk_
     uint4* dws = nullptr;
     if (hipMalloc((void**)&d1, tb) != hipSuccess || hipMalloc((void**)&d2, tb) != hipSuccess || hipMalloc((void**)&din, 160 * n) != hipSuccess ||
         hipMalloc((void**)&dout, 64 * n) != hipSuccess || hipMalloc((void**)&dst, 4 * n) != hipSuccess ||
-        hipMalloc((void**)&dws, (size_t)16 * 7 * 64 * 16) != hipSuccess)
+        hipMalloc((void**)&dws, (size_t)16 * 8 * 64 * 16) != hipSuccess)
         return -1;
     hipMemcpy(d1, t1.data(), tb, hipMemcpyHostToDevice);
     hipMemcpy(d2, t2.data(), tb, hipMemcpyHostToDevice);

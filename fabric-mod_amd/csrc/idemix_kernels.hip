@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(BLOCK, 2)
                              const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                              const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
                              uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
-    GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
+    GlobalQTab29<BLOCK> qtab = GlobalQTab29<BLOCK>::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK), threadIdx.x);
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(BLOCK, 2)
                                    const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                                    const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
                                    uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
-    GlobalQTab29<BLOCK> qtab{qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK) + threadIdx.x};
+    GlobalQTab29<BLOCK> qtab = GlobalQTab29<BLOCK>::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK), threadIdx.x);
     constexpr uint32_t PER_WG = BLOCK / 2;
     const uint32_t ntiles = (n + PER_WG - 1) / PER_WG;
     const bool odd = (threadIdx.x & 1u) != 0;

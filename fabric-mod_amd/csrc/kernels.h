@@ -8,8 +8,8 @@ namespace fab {
 constexpr int VERIFY_BLOCK = 256;         // 4 wavefronts per workgroup, one per SIMD
 constexpr int VERIFY_MAX_WGS = 256;       // persistent workgroup slots: one per CU (see kernels.hip for why not two)
 constexpr int VERIFY_PAIR_MAX = 32768;    // up to here two lanes per signature (one round of 256 workgroups x 128 signatures)
-// workspace of the per-lane j*Q tables: 16 entries x 7 uint4 per lane (one signature per lane), x 8 uint4 per signature (pairs)
-constexpr size_t QWS_UINT4_PER_LANE = (size_t)16 * 7;
+// workspace of the per-lane j*Q tables: 16 entries x 8 uint4 (one 128-byte line each; seven cells used) per lane or per signature
+constexpr size_t QWS_UINT4_PER_LANE = (size_t)16 * 8;
 constexpr size_t QWS_PAIR_UINT4_PER_SIG = (size_t)16 * 8;
 
 // Shared message prefixes of a fused batch (device pointers): prefix p = arena[pre_off[p], pre_off[p+1]), message i continues
@@ -27,6 +27,8 @@ struct VerifyGeom {
     uint32_t wgs;     // workgroups launched (= workspace slots)
     bool pair;        // two lanes per signature
 };
+// keeps every SIMD busy with integer multiply-adds for ~usec microseconds (<= 5000) on `st`; sink: any 4 writable device bytes
+hipError_t launch_warm(uint32_t usec, void* sink, hipStream_t st);
 VerifyGeom verify_geom(uint32_t n, bool allow_pair);
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair);
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);

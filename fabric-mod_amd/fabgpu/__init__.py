@@ -26,6 +26,7 @@ _LIB_PATH = os.environ.get("FABGPU_LIB_PATH") or os.path.join(os.path.dirname(_H
 
 FABGPU_OK = 0
 FLAG_ONE_LANE_ONLY = 1   # fabgpu.h FABGPU_FLAG_ONE_LANE_ONLY
+FLAG_TIME_KERNELS = 2    # fabgpu.h FABGPU_FLAG_TIME_KERNELS
 ST_VALID, ST_BAD_MATH, ST_HIGH_S, ST_RANGE, ST_OFF_CURVE = 0, 1, 2, 3, 4
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -89,7 +90,7 @@ ABI_SYMBOLS = [
     "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_evict_block",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
     "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",
-    "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
+    "fabgpu_warm", "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
     "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev",
 ]
 
@@ -168,6 +169,7 @@ def load():
     L.fabgpu_csp_identity_cache_size.argtypes = [_vp, _u64p]
     L.fabgpu_csp_x509_check_signature_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p, _u8p, _u8p]
     L.fabgpu_x509_signature_parts.argtypes = [ctypes.c_char_p, _sz, _u32p, _u32p, _u32p, _u32p, ctypes.POINTER(ctypes.c_int)]
+    L.fabgpu_warm.argtypes = [_vp, ctypes.c_uint32]
     L.fabgpu_multi_init.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(_vp)]
     L.fabgpu_multi_shutdown.argtypes = [_vp]
     L.fabgpu_multi_shutdown.restype = None
@@ -809,11 +811,27 @@ PASS_SEED_MEMO, PASS_NO_BLOCK_SIGS = 1, 2
 TUPLE_ST_SKIPPED = 8
 
 
-def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo: bool = False, block_sigs: bool = True):
+def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo: bool = False, block_sigs: bool = True, lean: bool = False):
     """fabgpu_csp_block_preverify2: the pass with verdicts tied to bytes.  Returns dict(tx_flags, tx_type, tuple_tx, tuple_kind,
     tuple_status, tuple_spans (n x 8), tuple_digest (n x 32), tuple_hashed, tuple_qxy (n x 64), n_block_sigs, block_sigs_understood,
-    memo_seeded, arena = block || padding || tail)."""
+    memo_seeded, arena = block || padding || tail).  lean: only what a memo-seeding caller needs (tx_flags and the counts) - no per-tuple
+    arrays are requested from the library and no arena copy is made (the timing benches use this)."""
     buf = np.frombuffer(block, dtype=np.uint8)
+    if lean:
+        cap_tx, cap_tu = getattr(csp, "_pass_caps", (1024, 4096))
+        while True:
+            flags = np.zeros(cap_tx, np.uint8)
+            ps = _BlockPass()
+            ps.block, ps.len, ps.block_seq = buf.ctypes.data, buf.size, block_seq
+            ps.flags = (PASS_SEED_MEMO if seed_memo else 0) | (0 if block_sigs else PASS_NO_BLOCK_SIGS)
+            ps.cap_tx, ps.cap_tuples, ps.tx_flags = cap_tx, cap_tu, flags.ctypes.data
+            rc = csp._L.fabgpu_csp_block_preverify2(csp._h, ctypes.byref(ps))
+            if rc == -5:
+                cap_tx, cap_tu = max(cap_tx, ps.n_tx), max(cap_tu, ps.n_tuples)
+                csp._pass_caps = (cap_tx, cap_tu)
+                continue
+            _check(rc, "fabgpu_csp_block_preverify2")
+            return dict(tx_flags=flags[:ps.n_tx], n_tuples=ps.n_tuples, n_block_sigs=ps.n_block_sigs, memo_seeded=ps.memo_seeded)
     cap_tx, cap_tu = getattr(csp, "_pass_caps", (1024, 4096))
     tail_cap = 1 << 16
     while True:

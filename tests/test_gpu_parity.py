@@ -36,7 +36,7 @@ def _arr(items):
 def ctx(request):
     """auto = the product default (two lanes per signature up to 32 768 tuples, one lane beyond);
     one-lane = FABGPU_FLAG_ONE_LANE_ONLY, so that every fixture and edge vector also goes through the one-lane kernel."""
-    c = fabgpu.Context(device=0, flags=fabgpu.FLAG_ONE_LANE_ONLY if request.param == "one-lane" else 0)
+    c = fabgpu.Context(device=0, flags=fabgpu.FLAG_TIME_KERNELS | (fabgpu.FLAG_ONE_LANE_ONLY if request.param == "one-lane" else 0))
     yield c
     c.close()
 
@@ -598,3 +598,53 @@ def test_concurrent_launches_on_two_streams_get_separate_workspaces(ctx):
     for th in ths:
         th.join()
     assert results == {"a": True, "b": True}
+
+
+# ---- the failure contract: a device fault is an infrastructure error, never a verdict (SURVEY section 5 "determinism under failure") ----
+_FAULT_SNIPPET = r"""
+import ctypes, sys, numpy as np
+sys.path[:0] = [%(root)r + "/fabric-mod_amd", %(root)r + "/oracle"]
+import fabgpu
+L = fabgpu.load()
+ctx = fabgpu.Context(device=0)
+n = 300
+b = fabgpu.synth_batch(n, seed=3, invalid_permille=100)
+u8 = ctypes.POINTER(ctypes.c_uint8)
+p = lambda a: a.ctypes.data_as(u8)
+bits = np.full((n + 63) // 64, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)          # sentinels: a failed call must not touch them
+st = np.full(n, 0xEE, dtype=np.uint8)
+rc = L.fabgpu_p256_verify_batch(ctx.handle, n, p(b["qx"]), p(b["qy"]), p(b["e"]), p(b["r"]), p(b["s"]), bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), p(st))
+assert rc == %(want)d, rc
+assert (bits == 0xA5A5A5A5A5A5A5A5).all() and (st == 0xEE).all(), "a failed call wrote verdicts"
+off = (np.arange(n + 1) * 40).astype(np.uint32)
+arena = np.zeros(n * 40 + 64, np.uint8)
+rc = L.fabgpu_sha256_p256_verify_batch(ctx.handle, n, p(arena), off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), p(b["qx"]), p(b["qy"]), p(b["r"]), p(b["s"]),
+                                       bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), p(st))
+assert rc == %(want)d, rc
+assert (bits == 0xA5A5A5A5A5A5A5A5).all() and (st == 0xEE).all()
+if %(mode)r == "launch":
+    # the provider surface: an infrastructure error, never "(false, nil)"
+    import bccsp_sw_oracle as po
+    csp = fabgpu.GPUCSP(device=0)
+    k = csp.key_import((int.from_bytes(b["qx"][0].tobytes(), "big"), int.from_bytes(b["qy"][0].tobytes(), "big")))
+    sig = po.marshal_ecdsa_signature(int.from_bytes(b["r"][0].tobytes(), "big"), int.from_bytes(b["s"][0].tobytes(), "big"))
+    try:
+        csp.verify(k, sig, b["e"][0].tobytes())
+        raise SystemExit("verify returned a verdict while the device was failing")
+    except fabgpu.FabgpuError:
+        pass
+print("FAULT_CONTRACT_OK")
+"""
+
+
+@pytest.mark.parametrize("mode,want", [("launch", -4), ("oom", -3)])
+def test_device_faults_surface_as_infrastructure_errors_never_as_verdicts(mode, want):
+    """FABGPU_FAULT_INJECT makes every kernel submission report hipErrorLaunchFailure ("launch") or every workspace allocation fail
+    ("oom"): the C ABI must return FABGPU_ELAUNCH / FABGPU_ENOMEM, leave the caller's verdict arrays untouched, and the provider must
+    raise an infrastructure error (the Go side then uses bccsp/sw) - never answer (false, nil)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FABGPU_FAULT_INJECT=mode)
+    r = subprocess.run([sys.executable, "-c", _FAULT_SNIPPET % {"root": root, "want": want, "mode": mode}], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "FAULT_CONTRACT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -17,7 +17,7 @@ def env(request):
     """auto: batches up to 32 768 run on the two-lanes-per-signature kernel, larger ones on the one-lane kernel;
     one-lane = FABGPU_FLAG_ONE_LANE_ONLY, so that every case also goes through the one-lane kernel."""
     fx = fixtures()
-    ctx = fabgpu.Context(device=0, flags=fabgpu.FLAG_ONE_LANE_ONLY if request.param == "one-lane" else 0)
+    ctx = fabgpu.Context(device=0, flags=fabgpu.FLAG_TIME_KERNELS | (fabgpu.FLAG_ONE_LANE_ONLY if request.param == "one-lane" else 0))
     issuers = []
     for name in ("MSP1OU1", "MSP2OU1"):
         ipk = fx[name]["ipk"]

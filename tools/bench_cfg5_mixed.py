@@ -34,7 +34,7 @@ def main():
     from idemix_common import NymBatch, be32, fixtures
 
     fx = fixtures()
-    ctx = fabgpu.Context(device=0, max_batch=args.n)
+    ctx = fabgpu.Context(device=0, max_batch=args.n, flags=fabgpu.FLAG_TIME_KERNELS)
     issuers = []
     t0 = time.perf_counter()
     for name in ("MSP1OU1", "MSP2OU1"):
