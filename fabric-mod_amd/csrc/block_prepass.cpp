@@ -75,21 +75,72 @@ struct Pick {
     int seen = 0;
     explicit Pick(uint32_t n) : num(n) {}
 };
-// false: malformed wire format, or one of the wanted fields repeated / not length-delimited
-bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
-    PbReader r(b, n);
-    PbField f;
-    while (r.next(f)) {
-        if (f.num == 0) return false;                                  // "illegal tag 0" in Go
-        for (int i = 0; i < k; i++)
-            if (want[i].num == f.num) {
-                if (f.wt != 2 || want[i].seen) return false;
-                want[i].seen = 1;
-                want[i].p = f.data;
-                want[i].len = f.len;
+// false: malformed wire format, or one of the wanted fields repeated / not length-delimited.
+// Hand-rolled scan (this is the walker's inner loop: ~25 messages per transaction): one-byte keys and one- or two-byte lengths - what
+// every field of these messages has - take the fast path; anything else goes through the general varint decoder.
+inline bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
+    const uint8_t* p = b;
+    const uint8_t* const end = b + n;
+    while (p < end) {
+        uint64_t key = *p++;
+        if (key & 0x80) {                                              // multi-byte key: field numbers >= 16
+            key &= 0x7F;
+            int shift = 7;
+            for (;;) {
+                if (p >= end || shift > 63) return false;
+                const uint8_t c = *p++;
+                key |= (uint64_t)(c & 0x7F) << shift;
+                if (!(c & 0x80)) break;
+                shift += 7;
             }
+        }
+        const uint32_t num = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+        if (num == 0) return false;                                    // "illegal tag 0" in Go
+        int hit = -1;
+        for (int i = 0; i < k; i++)
+            if (want[i].num == num) hit = i;
+        if (wt == 2) {
+            if (p >= end) return false;
+            uint64_t len = *p++;
+            if (len & 0x80) {
+                len &= 0x7F;
+                int shift = 7;
+                for (;;) {
+                    if (p >= end || shift > 63) return false;
+                    const uint8_t c = *p++;
+                    len |= (uint64_t)(c & 0x7F) << shift;
+                    if (!(c & 0x80)) break;
+                    shift += 7;
+                }
+            }
+            if (len > (uint64_t)(end - p)) return false;
+            if (hit >= 0) {
+                if (want[hit].seen) return false;
+                want[hit].seen = 1;
+                want[hit].p = p;
+                want[hit].len = (size_t)len;
+            }
+            p += len;
+            continue;
+        }
+        if (hit >= 0) return false;                                    // a wanted field with another wire type: Go rejects the message
+        if (wt == 0) {
+            int cnt = 0;
+            for (;;) {
+                if (p >= end || ++cnt > 10) return false;
+                if (!(*p++ & 0x80)) break;
+            }
+        } else if (wt == 1) {
+            if (end - p < 8) return false;
+            p += 8;
+        } else if (wt == 5) {
+            if (end - p < 4) return false;
+            p += 4;
+        } else {
+            return false;
+        }
     }
-    return r.ok;
+    return true;
 }
 // the one wanted field: 1 present once, 0 absent, -1 ambiguous / malformed
 int pb_one(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t& outlen) {
