@@ -13,7 +13,7 @@ int main() {
     size_t n = fread(base.data(), 1, base.size(), f);
     base.resize(n);
     std::mt19937_64 rng(7);
-    size_t parsed = 0, tuples = 0;
+    size_t parsed = 0, tuples = 0, blocksigs = 0;
     for (int it = 0; it < 20000; it++) {
         std::vector<uint8_t> b = base;
         int k = 1 + rng() % 8;
@@ -33,9 +33,16 @@ int main() {
         if (ParseBlock(heap, b.size(), pb, it % 2 ? 4 : 1)) {
             parsed++;
             tuples += pb.tuples.size();
+            if (pb.tail_base < b.size() || (pb.tail_base & 63u)) { printf("TAIL BASE\n"); return 1; }
             for (auto& t : pb.tuples) {
+                // the message of an orderer block signature lives in the walker's tail (block_prepass.h), everything else in the block
+                const bool in_tail = t.kind == TUPLE_BLOCK_SIG;
+                if (in_tail) {
+                    blocksigs++;
+                    if (t.suffix.off < pb.tail_base || (size_t)t.suffix.off - pb.tail_base + t.suffix.len > pb.tail.size() || t.tx != BLOCK_LEVEL_TX) { printf("TAIL SPAN OUT OF RANGE\n"); return 1; }
+                } else if ((size_t)t.suffix.off + t.suffix.len > b.size() || t.tx >= pb.n_tx) { printf("SPAN OUT OF RANGE\n"); return 1; }
                 if ((size_t)t.identity.off + t.identity.len > b.size() || (size_t)t.sig.off + t.sig.len > b.size() ||
-                    (size_t)t.suffix.off + t.suffix.len > b.size() || (size_t)t.prefix.off + t.prefix.len > b.size()) { printf("SPAN OUT OF RANGE\n"); return 1; }
+                    (size_t)t.prefix.off + t.prefix.len > b.size()) { printf("SPAN OUT OF RANGE\n"); return 1; }
                 uint8_t qx[32], qy[32], nx[32], ny[32];
                 std::string ms;
                 IdentityToP256(heap + t.identity.off, t.identity.len, qx, qy);
@@ -43,6 +50,8 @@ int main() {
                 NymSignatureFields sf;
                 UnmarshalNymSignature(heap + t.sig.off, t.sig.len, sf);
             }
+            if ((size_t)pb.data.off + pb.data.len > b.size() || (size_t)pb.previous_hash.off + pb.previous_hash.len > b.size() ||
+                (size_t)pb.data_hash.off + pb.data_hash.len > b.size()) { printf("HEADER SPAN OUT OF RANGE\n"); return 1; }
             for (auto& h : pb.hash_checks) {
                 for (int p = 0; p < 3; p++) if ((size_t)h.piece[p].off + h.piece[p].len > b.size()) { printf("PIECE OUT OF RANGE\n"); return 1; }
                 if ((size_t)h.expect.off + h.expect.len > b.size()) { printf("EXPECT OUT OF RANGE\n"); return 1; }
@@ -52,5 +61,5 @@ int main() {
         }
         free(heap);
     }
-    printf("fuzz ok: %zu of 20000 mutants parsed, %zu tuples\n", parsed, tuples);
+    printf("fuzz ok: %zu of 20000 mutants parsed, %zu tuples (%zu orderer block signatures)\n", parsed, tuples, blocksigs);
 }

@@ -4,7 +4,8 @@
 # UndefinedBehaviorSanitizer (ROCm's clang: fp256.h uses clang builtins).  Mutation fuzzing from valid inputs: bit flips, random
 # bytes, 0xFF / long-form length bytes, truncation; every mutant is copied to an exact-size heap block so that any read past its
 # end is caught, and every span the walker reports is checked to lie inside the buffer.  Host only, no GPU.
-#   tools/fuzz/run.sh        (about a minute; round 1: 20 000 block mutants and 200 000 certificate mutants, no finding)
+#   tools/fuzz/run.sh        (about a minute; 20 000 block mutants - orderer block signatures included since round 2 - and 200 000 certificate
+#                            mutants through the SPKI walker, the TBS / signature splitter of the x509 batch check and the DER gate: no finding)
 set -e
 cd "$(dirname "$0")/../.."
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
@@ -31,7 +32,12 @@ for t in range(40):
     payload, _ = bb.consistent_endorser_tx("mychannel", c, bytes(rng.integers(0, 256, size=24, dtype=np.uint8)), bytes(rng.integers(0, 256, size=60, dtype=np.uint8)),
                                            bytes(rng.integers(0, 256, size=90, dtype=np.uint8)), lambda prp: [(sid[j], fake) for j in (0, 1, 2)])
     envs.append(bb.envelope(payload, sig))
-open("/tmp/blk_small.bin", "wb").write(bb.block(1, envs))
+# a block with real SIGNATURES metadata (two orderer signatures over the block): common.Metadata{1 value, 2 MetadataSignature{1 signature_header, 2 signature}}
+hdr = bb.fvarint(1, 300) + bb.fbytes(2, b"\x11" * 32) + bb.fbytes(3, b"\x22" * 32)
+msig = lambda k: bb.fbytes(2, bb.fbytes(1, bb.signature_header(sid[k], b"n" * 24)) + bb.fbytes(2, fake))
+meta0 = bb.fbytes(1, b"\x0a\x02\x08\x05") + msig(0) + msig(1)
+blk = bb.fbytes(1, hdr) + bb.fbytes(2, b"".join(bb.fbytes(1, e) for e in envs)) + bb.fbytes(3, bb.fbytes(1, meta0) + bb.fbytes(1, b"") + bb.fbytes(1, b"\x00" * 40))
+open("/tmp/blk_small.bin", "wb").write(blk)
 open("/tmp/cert.pem", "w").write(ids[0]["pem"])
 PY
 $CXX $FLAGS tools/fuzz/fuzz_walk.cpp $SRC/block_prepass.cpp $SRC/idemix_host.cpp tools/fuzz/stubs.cpp -o /tmp/fuzz_walk -lpthread
