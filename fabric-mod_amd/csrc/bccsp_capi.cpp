@@ -130,7 +130,7 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
     GPUCSP::BlockUpload up;
     csp->csp->StartBlockUpload(up, block, len);            // the block travels while it is walked
     static thread_local ParsedBlock pb;                     // storage reused from block to block (a few MB: no page faults per block)
-    if (!ParseBlock(block, len, pb, 16)) return FABGPU_EINVAL;
+    if (!ParseBlock(block, len, pb, WalkThreads())) return FABGPU_EINVAL;
     auto t1 = std::chrono::steady_clock::now();
     *n_tx = pb.n_tx;
     *n_tuples = (uint32_t)pb.tuples.size();
@@ -161,7 +161,7 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     GPUCSP::BlockUpload up;
     csp->csp->StartBlockUpload(up, ps->block, ps->len);
     static thread_local ParsedBlock pb;
-    if (!ParseBlock(ps->block, ps->len, pb, 16)) return FABGPU_EINVAL;
+    if (!ParseBlock(ps->block, ps->len, pb, WalkThreads())) return FABGPU_EINVAL;
     ps->n_tx = pb.n_tx;
     ps->n_tuples = (uint32_t)pb.tuples.size();
     ps->n_block_sigs = pb.n_block_sigs;

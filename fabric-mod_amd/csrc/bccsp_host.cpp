@@ -12,6 +12,7 @@
 // There is no CPU implementation of the curve arithmetic or of SHA-256 in here: every verdict comes
 // from the HIP kernels through the C ABI; without a device fabgpu_init fails and so does this layer.
 #include "bccsp_host.h"
+#include "worker_pool.h"
 #include "idemix_host.h"
 
 #include <stdlib.h>
@@ -431,7 +432,7 @@ Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& ou
     BlockUpload up;
     StartBlockUpload(up, block, len);                     // the block travels while it is walked and its signatures are gated
     static thread_local ParsedBlock pb;                   // storage reused from block to block
-    if (!block || !ParseBlock(block, len, pb, 16)) return Error("block does not parse as common.Block");
+    if (!block || !ParseBlock(block, len, pb, WalkThreads())) return Error("block does not parse as common.Block");
     return PreVerifyParsed(block, pb, out, &up, opt);
 }
 
@@ -761,15 +762,15 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         }
     };
     auto clk0 = std::chrono::steady_clock::now();
-    const int nthreads = nt >= 16384 ? 16 : (nt >= 4096 ? 8 : 1);
+    static const int gate_max = [] { const char* e = getenv("FABGPU_PASS_GATE_THREADS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    const int nthreads = std::min(gate_max, nt >= 16384 ? 16 : (nt >= 4096 ? 8 : 1));
     auto in_threads = [&](const std::function<void(int, size_t, size_t)>& fn) {       // fn(worker, lo, hi) over contiguous tuple ranges
         if (nthreads == 1) {
             fn(0, 0, nt);
             return;
         }
-        std::vector<std::thread> th;
-        for (int w = 0; w < nthreads; w++) th.emplace_back([&, w] { fn(w, nt * w / nthreads, nt * (w + 1) / nthreads); });
-        for (auto& x : th) x.join();
+        // all nthreads run concurrently (they meet at a spin barrier): worker_pool.h keeps 15 parked threads + the caller
+        run_workers(nthreads, [&](int w) { fn(w, nt * w / nthreads, nt * (w + 1) / nthreads); });
     };
     new_ids.assign(nthreads, 0);
     // ONE round of workers (spawning 16 threads costs ~0.25 ms on the bench host, and there used to be three rounds): each gates
@@ -1056,9 +1057,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             if (ft == 1) {
                 fill(0, m);
             } else {
-                std::vector<std::thread> th;
-                for (int w = 0; w < ft; w++) th.emplace_back(fill, (size_t)m * w / ft, (size_t)m * (w + 1) / ft);
-                for (auto& x : th) x.join();
+                run_workers(ft, [&](int w) { fill((size_t)m * w / ft, (size_t)m * (w + 1) / ft); });
             }
         }
         out.memo_seeded = m;

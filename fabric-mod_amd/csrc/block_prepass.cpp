@@ -1,7 +1,9 @@
 // Block walker + identity decoding of the pre-verify pass (block_prepass.h).  Host only, no device code, no crypto:
 // protobuf wire format, PEM/base64, and just enough DER to reach SubjectPublicKeyInfo.
 #include "block_prepass.h"
+#include "worker_pool.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -501,6 +503,18 @@ struct EnvChunk {
 };
 }  // namespace
 
+int WalkThreads() {
+    static const int n = [] {
+        const char* e = getenv("FABGPU_PASS_WALK_THREADS");
+        // 8, not 16: the workers spin while the lister publishes chunks, and a peer's container is typically granted fewer CPUs than it
+        // sees (the GPU boxes here: 256 visible, cgroup quota 16) - measured on such a box with the upload thread running beside
+        // (tools/gpu_pass_probe.sh, 10 000-tx block): 16 workers 10.7 ms, 8 workers 1.9-2.2 ms, 4 workers 2.2-2.7 ms, 1 worker 5.9 ms
+        int v = e ? atoi(e) : 8;
+        return v < 1 ? 1 : (v > 16 ? 16 : v);
+    }();
+    return n;
+}
+
 bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_threads) {
     out.reset();
     if (len > 0xFFFFFFF0ull) return false;
@@ -546,11 +560,9 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
             parse_chunk(ci);
         }
     };
-    std::vector<std::thread> th;
-    for (int w = 0; w < nt; w++) th.emplace_back(worker);
-    // listing (this thread)
+    // listing (this thread) while the pool's workers parse the chunks it publishes
     uint32_t n = 0, nchunks = 0;
-    {
+    auto lister = [&] {
         PbReader r(data, dlen);
         PbField f;
         std::unique_ptr<EnvChunk> cur(new EnvChunk);
@@ -571,13 +583,16 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
             nchunks++;
             ready.store(nchunks, std::memory_order_release);
         }
-    }
-    listing_done.store(true, std::memory_order_release);
+        listing_done.store(true, std::memory_order_release);
+    };
     if (nt == 0) {
+        lister();
         for (uint32_t ci = 0; ci < nchunks; ci++) parse_chunk(ci);
     } else {
-        worker();                                                     // the lister helps with what is left
-        for (auto& x : th) x.join();
+        run_workers(nt + 1, [&](int w) {
+            if (w == 0) lister();                                     // ... and then helps with what is left
+            worker();
+        });
     }
     if (broken.load()) {
         out.reset();

@@ -108,6 +108,8 @@ struct ParsedBlock {
 // Pure parsing (no device): false only if the outer Block / BlockData framing is broken.
 // BlockData of 1 MiB and more is walked on up to max_threads (<= 16) worker threads while the calling thread lists the envelopes.
 bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_threads = 8);
+// worker threads the pass gives the walk: 8, or FABGPU_PASS_WALK_THREADS (experiments)
+int WalkThreads();
 // SerializedIdentity{mspid, id_bytes = PEM x509} -> uncompressed P-256 point.  false: not such an identity.
 bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy[32]);
 // DER x509 certificate -> P-256 SubjectPublicKeyInfo point (exposed for tests against the reference's certificate fixtures)
