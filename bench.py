@@ -10,7 +10,8 @@ step     : one pass of the hot path over one block: fabgpu_p256_verify_batch_dev
            i.e. N channels validating concurrently ("scaling": "weak"; DESIGN.md section 7 explains why a single
            30 000-tuple block cannot be made faster by more GPUs: its time is the length of one wavefront's
            instruction stream) - and one RCCL all-gather merges the per-rank verdict bitmaps over xGMI
-           (SURVEY.md 8(e)); no other data-path collective exists.
+           (SURVEY.md 8(e)); no other data-path collective exists.  The all-gather of block k runs on RCCL's stream while
+           block k + 1 is verified (two verdict buffers); every collective is complete before the closing synchronize.
 Timing   : W warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(); max over ranks.
 Same JSON line, outside that timed region (SURVEY.md 8(d) "Timing protocol"):
   dispersion      median / p95 of individually timed steps (HIP events), device-resident leg
@@ -271,13 +272,21 @@ def main():
     block = fabgpu.synth_batch(n, seed=SEED + rank, invalid_permille=10)
     dev = {k: torch.from_numpy(block[k]).cuda() for k in ("qx", "qy", "e", "r", "s")}
     words_n = (n + 63) // 64
-    words = torch.zeros(words_n, dtype=torch.int64, device="cuda")
-    merged = torch.zeros(words_n * world, dtype=torch.int64, device="cuda")
+    # Two verdict buffers: with N > 1 the all-gather of block k (RCCL's own stream) overlaps the verification of block k + 1 (this
+    # stream); a buffer is written again only after the collective that read it has finished (work.wait() = a stream-side wait).
+    words2 = [torch.zeros(words_n, dtype=torch.int64, device="cuda") for _ in range(2)]
+    merged2 = [torch.zeros(words_n * world, dtype=torch.int64, device="cuda") for _ in range(2)]
+    words, merged = words2[0], merged2[0]
+    pending = [None, None]
     stream = torch.cuda.current_stream()
+    state = {"k": 0}
+
+    def verify_into(w):
+        ctx.p256_verify_batch_dev(n, dev["qx"].data_ptr(), dev["qy"].data_ptr(), dev["e"].data_ptr(), dev["r"].data_ptr(),
+                                  dev["s"].data_ptr(), w.data_ptr(), 0, stream.cuda_stream)
 
     def verify_only():
-        ctx.p256_verify_batch_dev(n, dev["qx"].data_ptr(), dev["qy"].data_ptr(), dev["e"].data_ptr(), dev["r"].data_ptr(),
-                                  dev["s"].data_ptr(), words.data_ptr(), 0, stream.cuda_stream)
+        verify_into(words)
 
     def all_gather(dst, src):
         if not dry:
@@ -289,11 +298,28 @@ def main():
             dst.copy_(torch.cat(parts))
 
     def step():
-        verify_only()
-        if world > 1:
-            all_gather(merged, words)
+        if world == 1:
+            verify_only()
+            return
+        b = state["k"] & 1
+        state["k"] += 1
+        if pending[b] is not None:
+            pending[b].wait()                                         # the collective of two steps ago has released this buffer pair
+            pending[b] = None
+        verify_into(words2[b])
+        if dry:
+            all_gather(merged2[b], words2[b])
+        else:
+            pending[b] = dist.all_gather_into_tensor(merged2[b], words2[b], async_op=True)
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     def sync_all():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -327,8 +353,10 @@ def main():
     got = fabgpu.unpack_bits(words.cpu().numpy().view(np.uint64), n)
     assert (got == (block["kind"] == 0)).all(), "verdict bitmap differs from the generator's ground truth"
     if world > 1:
-        m = merged.cpu().numpy().view(np.uint64).reshape(world, words_n)
-        assert (fabgpu.unpack_bits(m[rank], n) == got).all(), "all-gathered bitmap differs from the local one"
+        for b in (0, 1):                                   # both buffer pairs of the pipelined loop
+            assert (fabgpu.unpack_bits(words2[b].cpu().numpy().view(np.uint64), n) == got).all()
+            m = merged2[b].cpu().numpy().view(np.uint64).reshape(world, words_n)
+            assert (fabgpu.unpack_bits(m[rank], n) == got).all(), "all-gathered bitmap differs from the local one"
 
     extras = not args.no_extras
     strong = None

@@ -135,7 +135,7 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
     *n_tx = pb.n_tx;
     *n_tuples = (uint32_t)pb.tuples.size();
     if (pb.n_tx > cap_tx || pb.tuples.size() > cap_tuples) return FABGPU_ETOOBIG;   // counts are set: retry with room (nothing was launched)
-    BlockVerdicts v;
+    static thread_local BlockVerdicts v;                    // answer arrays keep their capacity from block to block
     Error e = csp->csp->PreVerifyParsed(block, pb, v, &up);
     if (timing) {
         auto t2 = std::chrono::steady_clock::now();
@@ -175,7 +175,7 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     opt.want_digests = ps->tuple_digest != nullptr;
     opt.block_sigs = !(ps->flags & FABGPU_PASS_NO_BLOCK_SIGS);
     opt.block_seq = ps->block_seq;
-    BlockVerdicts v;
+    static thread_local BlockVerdicts v;                    // answer arrays keep their capacity from block to block
     Error e = csp->csp->PreVerifyParsed(ps->block, pb, v, &up, opt);
     if (!e.ok()) return FABGPU_ELAUNCH;
     const size_t nt = v.tuple_tx.size();

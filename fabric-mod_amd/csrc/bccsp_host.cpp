@@ -602,10 +602,14 @@ int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_r
 }
 
 Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, BlockUpload* up, const PassOptions& opt) const {
-    out = BlockVerdicts();
+    // `out` may come back from the previous block (the C entry points keep one per calling thread): its vectors keep their capacity -
+    // a fresh 3 MB of answer arrays per block is 700 page faults - and every element is (re)written below
     const bool want_digests = opt.want_digests || opt.seed_memo;
     const size_t nt = pb.tuples.size();
     out.n_tx = pb.n_tx;
+    out.distinct_identities = 0;
+    out.ms_gates = out.ms_upload_wait = out.ms_device = 0;
+    out.memo_seeded = 0;
     out.tx_type = pb.tx_type;
     out.tx_flags.assign(pb.n_tx, TX_ALL_SIGNATURES_VALID);
     for (uint32_t t = 0; t < pb.n_tx; t++)
@@ -613,9 +617,10 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     out.tuple_tx.resize(nt);
     out.tuple_kind.resize(nt);
     out.tuple_status.assign(nt, FABGPU_ST_VALID);
-    out.tuple_qxy.assign(nt * 64, 0);
+    out.tuple_qxy.resize(nt * 64);                       // written per tuple by the gates (key or zeros)
     out.tuple_hashed.assign(nt, 0);
     if (want_digests) out.tuple_digest.assign(nt * 32, 0);
+    else out.tuple_digest.clear();
     out.n_block_sigs = pb.n_block_sigs;
     out.block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
     // identities -> keys (cached across blocks), signatures -> (r, s) through the reference's gates.  Tuples are independent:
@@ -651,6 +656,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             g0.nym = false;
             out.tuple_tx[i] = tp.tx;
             out.tuple_kind[i] = tp.kind;
+            memset(&out.tuple_qxy[64 * i], 0, 64);
             if (tp.kind == TUPLE_BLOCK_SIG && !opt.block_sigs) {
                 out.tuple_status[i] = TUPLE_ST_SKIPPED;
                 continue;
@@ -827,16 +833,19 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     for (int w = 0; w < nthreads; w++) n += cnt[w + 1];
     bool all_keyed = true;
     for (uint8_t k : keyed_w) all_keyed = all_keyed && k;
-    std::vector<uint8_t> hash_digests;
+    std::vector<uint8_t>& hash_digests = ps_.hash_digests;   // (scratch of the pass: reused from block to block, like everything below)
     bool hashes_done = false;
     if (n) {
-        std::vector<uint32_t> pre_off(2 * pb.prefixes.size() + 2);
+        std::vector<uint32_t>& pre_off = ps_.pre_off;
+        pre_off.resize(2 * pb.prefixes.size() + 2);
         for (size_t p = 0; p < pb.prefixes.size(); p++) {
             pre_off[2 * p] = pb.prefixes[p].off;
             pre_off[2 * p + 1] = pb.prefixes[p].off + pb.prefixes[p].len;
         }
-        std::vector<uint64_t> bits((n + 63) / 64);
-        std::vector<uint8_t> st(n);
+        std::vector<uint64_t>& bits = ps_.bits;
+        std::vector<uint8_t>& st = ps_.st;
+        bits.assign((n + 63) / 64, 0);
+        st.assign(n, 0);
         fabgpu_identity_batch d;
         memset(&d, 0, sizeof(d));
         d.n = n;
@@ -868,7 +877,8 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         }
         // the TxID and proposal-hash digests of the endorser transactions ride along (one upload of the block, one submission)
         const size_t nh = getenv("FABGPU_PASS_SKIP_HASH_CHECKS") ? 0 : pb.hash_checks.size();   // the switch exists for A/B timing only
-        std::vector<uint32_t> gsp(nh * 6);
+        std::vector<uint32_t>& gsp = ps_.gsp;
+        gsp.resize(nh * 6);
         hash_digests.assign(nh * 32, 0);
         for (size_t j = 0; j < nh; j++)
             for (int p = 0; p < 3; p++) {

@@ -217,7 +217,9 @@ class GPUCSP {
         };
         std::vector<Gated> gt;
         std::vector<uint32_t> sub, ids, off, pre_idx;
-        std::vector<uint8_t> qx, qy, r, s, dig;
+        std::vector<uint8_t> qx, qy, r, s, dig, st, hash_digests;
+        std::vector<uint32_t> pre_off, gsp;
+        std::vector<uint64_t> bits;
     };
     mutable std::mutex pass_mu_;
     mutable PassScratch ps_;
