@@ -542,7 +542,7 @@ int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* 
             const uint32_t e = bm.slots[at].load(std::memory_order_acquire);
             if (!e) break;
             const uint32_t o = bm.key_off[e - 1], l = bm.key_off[e] - o;
-            if (l == kl && memcmp(&bm.keys[o], key, kl) == 0) {
+            if (l == kl && memcmp(bm.keys.get() + o, key, kl) == 0) {
                 if (status) *status = bm.status[e - 1];
                 memo_hits_.fetch_add(1, std::memory_order_relaxed);
                 return 0;
@@ -558,6 +558,7 @@ size_t GPUCSP::MemoEvictBlock(uint64_t block_seq) const {
     for (auto b = memo_blocks_.begin(); b != memo_blocks_.end();) {
         if ((*b)->seq != block_seq) { ++b; continue; }
         gone += (*b)->n;
+        if (memo_free_.size() < 4) memo_free_.push_back(*b);     // its buffers serve the next block (lookups hold the shared lock: none in flight here)
         b = memo_blocks_.erase(b);
     }
     memo_evicted_.fetch_add(gone, std::memory_order_relaxed);
@@ -1022,8 +1023,18 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     // verdict memo: one entry per tuple the device hashed and decided, keyed on (key, signature bytes, device digest).  The block's
     // table is built here, outside the memo lock, by the pass's worker threads; publishing it is one push under the lock.
     if (opt.seed_memo) {
-        std::shared_ptr<BlockMemo> bm(new BlockMemo);
+        std::shared_ptr<BlockMemo> bm;
+        {
+            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+            if (!memo_free_.empty()) {
+                bm = memo_free_.back();
+                memo_free_.pop_back();
+            }
+        }
+        if (!bm) bm.reset(new BlockMemo);
         bm->seq = opt.block_seq;
+        bm->n = 0;
+        bm->key_off.clear();
         std::vector<uint32_t>& sel = ps_.sub;              // reuse: indices of the tuples that get an entry
         if (sel.size() < nt) sel.resize(nt);
         uint32_t m = 0;
@@ -1043,9 +1054,15 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             uint32_t cap = 16;
             while (cap < 2 * m) cap <<= 1;
             bm->mask = cap - 1;
-            bm->slots.reset(new std::atomic<uint32_t>[cap]);
+            if (bm->slots_cap < cap) {
+                bm->slots.reset(new std::atomic<uint32_t>[cap]);
+                bm->slots_cap = cap;
+            }
             for (uint32_t k = 0; k < cap; k++) bm->slots[k].store(0, std::memory_order_relaxed);
-            bm->keys.resize(bm->key_off.back());
+            if (bm->keys_cap < bm->key_off.back()) {
+                bm->keys_cap = bm->key_off.back() + bm->key_off.back() / 8;
+                bm->keys.reset(new uint8_t[bm->keys_cap]);
+            }
             bm->status.resize(m);
             BlockMemo* raw = bm.get();
             auto fill = [&, raw](size_t lo, size_t hi) {
@@ -1053,7 +1070,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                     const size_t i = sel[e];
                     const BlockTuple& tp = pb.tuples[i];
                     const uint8_t* sg = block + tp.sig.off;
-                    MemoKeyWrite(&raw->keys[raw->key_off[e]], &out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], sg, tp.sig.len, &out.tuple_digest[32 * i], 32);
+                    MemoKeyWrite(raw->keys.get() + raw->key_off[e], &out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], sg, tp.sig.len, &out.tuple_digest[32 * i], 32);
                     raw->status[e] = out.tuple_status[i];
                     uint32_t at = (uint32_t)MemoHash(sg, tp.sig.len, &out.tuple_digest[32 * i], 32) & raw->mask;
                     for (;;) {                             // lock-free linear probing: the table is at most half full
@@ -1079,6 +1096,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             while (total > memo_cap_ && memo_blocks_.size() > 1) {        // bounded: the oldest block goes first
                 total -= memo_blocks_.front()->n;
                 memo_evicted_.fetch_add(memo_blocks_.front()->n, std::memory_order_relaxed);
+                if (memo_free_.size() < 4) memo_free_.push_back(memo_blocks_.front());
                 memo_blocks_.pop_front();
             }
         }

@@ -196,9 +196,11 @@ class GPUCSP {
         uint32_t n = 0, mask = 0;
         std::unique_ptr<std::atomic<uint32_t>[]> slots;   // entry index + 1; 0 = empty
         std::vector<uint32_t> key_off;                    // n + 1 offsets into keys
-        std::vector<uint8_t> keys;                        // framed keys: X || Y || u32 len || sig || u32 len || digest
+        std::unique_ptr<uint8_t[]> keys;                  // framed keys: X || Y || u32 len || sig || u32 len || digest (not zero-filled)
+        size_t keys_cap = 0, slots_cap = 0;
         std::vector<uint8_t> status;                      // n
     };
+    mutable std::vector<std::shared_ptr<BlockMemo>> memo_free_;    // evicted tables, recycled: 7 MB of fresh pages per block otherwise
     mutable std::shared_timed_mutex memo_mu_;
     mutable std::deque<std::shared_ptr<BlockMemo>> memo_blocks_;   // oldest first
     mutable size_t memo_cap_ = (size_t)1 << 18;
