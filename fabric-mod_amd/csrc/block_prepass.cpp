@@ -616,7 +616,7 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
         }
         out.has_header = ok && r.ok;
     }
-    if (out.has_header && top[2].seen) {
+    if (out.has_header && top[2].seen && len <= 0xFFFF0000ull) {       // (the tail must be addressable behind the block with 32-bit offsets)
         // common.BlockMetadata{1 repeated bytes metadata}; entry [BlockMetadataIndex_SIGNATURES = 0] is a marshalled
         // common.Metadata{1 value, 2 repeated MetadataSignature{1 signature_header, 2 signature}}
         PbReader r(top[2].p, top[2].len);
