@@ -323,6 +323,40 @@ def test_threaded_walk_on_a_multi_megabyte_block():
     assert bad == {(t, 0) for t in range(700) if t % 97 == 5} | {(t, 1) for t in range(700) if t % 89 == 7}
 
 
+def test_concurrent_walks_share_the_worker_pool_or_fall_back():
+    """Two channels validate at once: the walk's persistent worker pool (csrc/worker_pool.h) serves one job at a time, the second caller
+    runs on threads of its own.  Four Python threads (ctypes releases the GIL) walk multi-megabyte blocks concurrently, many times."""
+    import threading
+    rng = np.random.default_rng(5)
+    sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in IDS if i["curve"] == "prime256v1"]
+    fake = b"\x30\x44\x02\x20" + b"\x11" * 32 + b"\x02\x20" + b"\x22" * 32
+    blocks = []
+    for ntx in (300, 450, 600, 750):
+        envs = []
+        for t in range(ntx):
+            payload, _ = bb.consistent_endorser_tx("mychannel", sid[4 + t % 2], bytes(rng.integers(0, 256, size=24, dtype=np.uint8)),
+                                                   bytes(rng.integers(0, 256, size=300, dtype=np.uint8)), bytes(rng.integers(0, 256, size=900, dtype=np.uint8)),
+                                                   lambda prp: [(sid[j], fake) for j in (0, 1, 2)])
+            envs.append(bb.envelope(payload, fake))
+        blocks.append((ntx, bb.block(7, envs)))
+    assert all(len(b) > 1 << 20 for _, b in blocks)                    # the threaded walk
+    errors = []
+
+    def work(ntx, blk):
+        try:
+            for _ in range(25):
+                p = fabgpu.block_parse(blk)
+                assert p["n_tx"] == ntx and p["n_tuples"] == 4 * ntx and p["n_prefixes"] == ntx
+        except Exception as e:                                        # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=work, args=b) for b in blocks]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in th)
+
+
 def test_walkers_survive_mutated_input():
     """The host-side parsers read untrusted network bytes: a few thousand mutants of a valid block and of a valid certificate must
     neither crash the process nor report a span outside the buffer.  (The thorough version runs under ASan/UBSan: tools/fuzz/run.sh.)"""
