@@ -252,23 +252,12 @@ int fabgpu_x509_signature_parts(const uint8_t* der, size_t len, uint32_t* tbs_of
     return FABGPU_OK;
 }
 
-// test knob of the walker (differential tests run every block through both listings): 0 serial chain only, 1 scouts for big blocks, -1 default;
-// *was_speculative (of the LAST fabgpu_block_parse on this thread) tells which one produced the list
-static thread_local int g_last_walk_speculative = 0;
-int fabgpu_block_walk_mode(int mode, int* was_speculative) {
-    if (was_speculative) *was_speculative = g_last_walk_speculative;
-    if (mode >= -1 && mode <= 1) SetSpeculativeListing(mode);
-    return FABGPU_OK;
-}
-
 // pure host: structure of a marshalled block as the pre-verify pass sees it
 int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
                        char* channel_id, size_t channel_cap) {
     if (!block || !n_tx || !n_tuples) return FABGPU_EINVAL;
     ParsedBlock pb;
-    const bool parsed = ParseBlock(block, len, pb);
-    g_last_walk_speculative = pb.listed_speculatively ? 1 : 0;
-    if (!parsed) return FABGPU_EINVAL;
+    if (!ParseBlock(block, len, pb)) return FABGPU_EINVAL;
     *n_tx = pb.n_tx;
     *n_tuples = (uint32_t)pb.tuples.size();
     if (n_prefixes) *n_prefixes = (uint32_t)pb.prefixes.size();

@@ -6,7 +6,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -498,126 +497,11 @@ void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, ui
 // merged in order at the end (prefix indices rebased).
 namespace {
 constexpr uint32_t WALK_CHUNK = 256;
-constexpr size_t SPECULATIVE_MIN_BYTES = (size_t)8 << 20;
 struct EnvChunk {
     std::pair<const uint8_t*, size_t> env[WALK_CHUNK];
     uint32_t count = 0;
 };
 }  // namespace
-
-// ---- speculative parallel listing -------------------------------------------------------------------------------------------
-// Finding where each envelope starts is a chain of dependent loads through the BlockData (record i + 1 begins where record i ends):
-// ~100 ns of DRAM latency per envelope, 1 ms for a 10 000-transaction block, and until round 2 the floor of the whole walk.  But the
-// parse is a deterministic function of the POSITION: if the sequential chain ever arrives at byte p as a record boundary, then
-// everything a scout found by parsing from p onward is exactly what the chain would have found.  So S - 1 scouts start in the middle of
-// the BlockData (at dlen j / S), each looks for a plausible record start (a field-1 length-delimited record followed by five more
-// well-formed records, all inside the buffer), and lists from there past the next scout's search window.  Stitching keeps a scout's
-// list only if its predecessor's chain lands EXACTLY on the scout's first record (binary search over the predecessor's boundaries);
-// anything else - no plausible start, a mismatch, a malformed record - abandons the speculation and the caller lists sequentially.
-// Envelope bytes cannot fool this: a false start inside a payload is simply never reached by the authoritative chain.
-namespace {
-constexpr size_t SCOUT_WINDOW = (size_t)256 << 10;     // how far a scout searches for a record start (an envelope is a few KB)
-struct ScoutSeg {
-    const uint8_t* first = nullptr;                     // position of the first record this segment lists (segment 0: data)
-    std::vector<std::pair<const uint8_t*, size_t>> env; // (payload pointer, length) of every field-1 record, in order
-    std::vector<const uint8_t*> at;                     // start position of every listed ENVELOPE record (same index as env)
-    std::vector<const uint8_t*> other;                  // start positions of records that are not envelopes (sorted; normally empty)
-    const uint8_t* stop = nullptr;                      // position after the last record visited
-    bool ok = false, hit_end = false, malformed = false;
-};
-// one record at p: false if malformed / out of bounds
-inline bool one_record(const uint8_t*& p, const uint8_t* end, uint32_t& num, uint32_t& wt, const uint8_t*& payload, size_t& plen) {
-    PbReader r(p, (size_t)(end - p));
-    PbField f;
-    if (!r.next(f) || !r.ok) return false;
-    num = f.num; wt = f.wt; payload = f.data; plen = f.len;
-    p = r.p;
-    return f.num != 0;
-}
-void scout_list(ScoutSeg& sg, const uint8_t* from, const uint8_t* until, const uint8_t* end) {
-    const uint8_t* p = from;
-    sg.first = from;
-    while (p < end) {
-        if (p >= until) { sg.stop = p; sg.ok = true; return; }
-        const uint8_t* rec = p;
-        uint32_t num, wt;
-        const uint8_t* pl;
-        size_t ln;
-        if (!one_record(p, end, num, wt, pl, ln)) { sg.malformed = true; sg.stop = rec; return; }
-        if (num == 1 && wt == 2) { sg.env.emplace_back(pl, ln); sg.at.push_back(rec); }
-        else sg.other.push_back(rec);
-    }
-    sg.stop = p;
-    sg.hit_end = true;
-    sg.ok = true;
-}
-// a position in [from, from + SCOUT_WINDOW) that parses as a field-1 record followed by five more records
-const uint8_t* scout_sync(const uint8_t* from, const uint8_t* end) {
-    const uint8_t* lim = (size_t)(end - from) > SCOUT_WINDOW ? from + SCOUT_WINDOW : end;
-    for (const uint8_t* c = from; c < lim; c++) {
-        if (*c != 0x0A) continue;
-        const uint8_t* p = c;
-        bool good = true;
-        for (int hop = 0; hop < 6 && good; hop++) {
-            if (p >= end) break;                                       // ran into the end of the BlockData cleanly: acceptable
-            uint32_t num, wt;
-            const uint8_t* pl;
-            size_t ln;
-            good = one_record(p, end, num, wt, pl, ln) && (hop > 0 || (num == 1 && wt == 2 && ln >= 16));
-        }
-        if (good) return c;
-    }
-    return nullptr;
-}
-// true: `envs` holds every envelope of the BlockData in order and *broken tells whether the chain ended on a malformed record -
-// exactly what the sequential lister would have produced.  false: speculation abandoned, nothing decided.
-bool list_speculative(const uint8_t* data, size_t dlen, int S, std::vector<std::pair<const uint8_t*, size_t>>& envs, bool& broken_out) {
-    const uint8_t* end = data + dlen;
-    std::vector<ScoutSeg> seg((size_t)S);
-    std::vector<const uint8_t*> guess((size_t)S + 1);
-    for (int j = 0; j <= S; j++) guess[j] = data + dlen / (size_t)S * (size_t)j;
-    guess[S] = end;
-    run_workers(S, [&](int j) {
-        const uint8_t* from = j == 0 ? data : scout_sync(guess[j], end);
-        if (!from) return;
-        // list past the NEXT scout's whole search window, so that its first record is among this segment's boundaries
-        const uint8_t* until = j + 1 < S ? ((size_t)(end - guess[j + 1]) > SCOUT_WINDOW ? guess[j + 1] + SCOUT_WINDOW : end) : end;
-        seg[j].env.reserve(dlen / (size_t)S / 2048 + 64);
-        seg[j].at.reserve(dlen / (size_t)S / 2048 + 64);
-        scout_list(seg[j], from, until, end);
-    });
-    // stitch: segment j + 1 is trusted iff segment j's chain has a record boundary exactly at its first record.  The boundaries of a
-    // segment are the starts of the records it listed plus - if it stopped cleanly - the position where it stopped.
-    envs.clear();
-    for (int j = 0; j < S; j++) {
-        const ScoutSeg& a = seg[j];
-        if (!a.first) return false;                                    // this scout found no plausible record start
-        size_t take_to = a.env.size();
-        if (j + 1 < S) {
-            const ScoutSeg& b = seg[j + 1];
-            if (!b.first) return false;
-            auto it = std::lower_bound(a.at.begin(), a.at.end(), b.first);
-            if (it != a.at.end() && *it == b.first) take_to = (size_t)(it - a.at.begin());
-            else if (!(b.first == a.stop && !a.malformed)) return false;   // the chain never lands on b's first record: b is not trusted
-        } else {
-            if (!(a.hit_end || a.malformed)) return false;
-            broken_out = a.malformed;                                  // the sequential chain would have ended on the same record
-        }
-        envs.insert(envs.end(), a.env.begin(), a.env.begin() + (ptrdiff_t)take_to);
-    }
-    return true;
-}
-}  // namespace
-
-namespace {
-std::atomic<int> g_speculative_mode(-1);        // -1: FABGPU_PASS_NO_SPECULATIVE_LISTING decides; 0: off; 1: on
-}
-void SetSpeculativeListing(int mode) { g_speculative_mode.store(mode); }
-bool SpeculativeListingDisabled() {
-    static const bool off = getenv("FABGPU_PASS_NO_SPECULATIVE_LISTING") != nullptr;      // A/B timing
-    const int m = g_speculative_mode.load(std::memory_order_relaxed);
-    return m < 0 ? off : m == 0;
-}
 
 int WalkThreads() {
     static const int n = [] {
@@ -678,33 +562,7 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
     };
     // listing (this thread) while the pool's workers parse the chunks it publishes
     uint32_t n = 0, nchunks = 0;
-    // big blocks: list with scouts first (a quarter of a millisecond instead of one), then publish everything at once
-    std::vector<std::pair<const uint8_t*, size_t>>& spec = out.env_scratch;
-    bool spec_ok = false, spec_broken = false;
-    if (nt >= 4 && dlen >= SPECULATIVE_MIN_BYTES && !SpeculativeListingDisabled()) spec_ok = list_speculative(data, dlen, 4, spec, spec_broken);
-    out.listed_speculatively = spec_ok;
     auto lister = [&] {
-        if (spec_ok) {
-            std::unique_ptr<EnvChunk> cur(new EnvChunk);
-            for (const auto& e : spec) {
-                cur->env[cur->count++] = e;
-                n++;
-                if (cur->count == WALK_CHUNK) {
-                    chunks[nchunks] = std::move(cur);
-                    nchunks++;
-                    ready.store(nchunks, std::memory_order_release);
-                    cur.reset(new EnvChunk);
-                }
-            }
-            if (spec_broken) broken.store(true);
-            if (cur->count) {
-                chunks[nchunks] = std::move(cur);
-                nchunks++;
-                ready.store(nchunks, std::memory_order_release);
-            }
-            listing_done.store(true, std::memory_order_release);
-            return;
-        }
         PbReader r(data, dlen);
         PbField f;
         std::unique_ptr<EnvChunk> cur(new EnvChunk);

@@ -97,8 +97,6 @@ struct ParsedBlock {
     // A ParsedBlock that is handed to ParseBlock again keeps its storage (and that of the per-worker parts below): a provider
     // that parses block after block does not allocate - and page-fault in - a few MB per block.
     std::vector<std::unique_ptr<ParsedBlock>> parts;   // scratch of the threaded walk: one per chunk of envelopes
-    std::vector<std::pair<const uint8_t*, size_t>> env_scratch;   // scratch of the speculative listing
-    bool listed_speculatively = false;    // the envelope list came from the scouts (blocks of 8 MiB and more), not from the serial chain
     void reset() {
         n_tx = 0;
         tx_type.clear(); tx_understood.clear(); prefixes.clear(); tuples.clear(); hash_checks.clear(); first_channel_id.clear();
@@ -112,8 +110,6 @@ struct ParsedBlock {
 bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_threads = 8);
 // worker threads the pass gives the walk: 8, or FABGPU_PASS_WALK_THREADS (experiments)
 int WalkThreads();
-bool SpeculativeListingDisabled();        // FABGPU_PASS_NO_SPECULATIVE_LISTING set, or switched off by SetSpeculativeListing(0)
-void SetSpeculativeListing(int mode);     // differential tests: 0 off, 1 on, -1 back to the environment's choice
 // SerializedIdentity{mspid, id_bytes = PEM x509} -> uncompressed P-256 point.  false: not such an identity.
 bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy[32]);
 // DER x509 certificate -> P-256 SubjectPublicKeyInfo point (exposed for tests against the reference's certificate fixtures)

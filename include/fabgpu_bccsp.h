@@ -131,10 +131,6 @@ int fabgpu_csp_x509_check_signature_batch(fabgpu_csp* csp, size_t n, const uint8
 /* pure host: raw TBSCertificate and DER signature of a certificate (offsets into der); 1 = not a certificate */
 int fabgpu_x509_signature_parts(const uint8_t* der, size_t len, uint32_t* tbs_off, uint32_t* tbs_len, uint32_t* sig_off, uint32_t* sig_len, int* ecdsa_sha256);
 
-/* test knob: how the walker lists the envelopes of blocks of 8 MiB and more - 1: scouts in parallel (default), 0: the serial chain only,
- * -1: back to the default.  *was_speculative: which one the last fabgpu_block_parse of this thread used.  Both must give the same answer on
- * every input (tests/test_block_prepass.py runs both). */
-int fabgpu_block_walk_mode(int mode, int* was_speculative);
 /* pure host helpers of the pass (no device): block structure, and the P-256 key of an x509 certificate */
 int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
                        char* channel_id, size_t channel_cap);

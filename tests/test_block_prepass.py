@@ -357,91 +357,6 @@ def test_concurrent_walks_share_the_worker_pool_or_fall_back():
     assert not errors and not any(t.is_alive() for t in th)
 
 
-def _walk_everything(blk):
-    """everything the walker derives from a block, or None if it refuses the block"""
-    try:
-        p = fabgpu.block_parse(blk)
-    except fabgpu.FabgpuError:
-        return None
-    tup, arena = fabgpu.block_tuples(blk)
-    return (p["n_tx"], p["n_tuples"], p["n_prefixes"], bytes(p["tx_type"]), p["channel_id"], tup, arena[len(blk):], fabgpu.block_hash_checks(blk))
-
-
-def test_speculative_listing_equals_the_serial_chain():
-    """Blocks of 8 MiB and more are listed by scouts that start in the middle of the BlockData and are trusted only if the serial chain
-    lands exactly on their first record (block_prepass.cpp).  The parse is a function of the position, so both listings must agree on
-    EVERY input: honest blocks, blocks whose payloads are full of byte patterns that look like record chains, giant envelopes that
-    swallow a scout's whole search window, foreign fields between envelopes, and hundreds of mutants (flips, truncations)."""
-    rng = np.random.default_rng(77)
-    sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in IDS if i["curve"] == "prime256v1"]
-    fake = b"\x30\x44\x02\x20" + b"\x11" * 32 + b"\x02\x20" + b"\x22" * 32
-
-    def tx(ext):
-        payload, _ = bb.consistent_endorser_tx("mychannel", sid[4], bytes(rng.integers(0, 256, size=24, dtype=np.uint8)),
-                                               bytes(rng.integers(0, 256, size=200, dtype=np.uint8)), ext, lambda prp: [(sid[j], fake) for j in (0, 1, 2)])
-        return bb.envelope(payload, fake)
-
-    def decoy(n):        # bytes that parse as a chain of field-1 records: a scout that starts here syncs on a lie
-        out = b""
-        while len(out) < n:
-            body = bytes(rng.integers(0, 256, size=int(rng.integers(16, 120)), dtype=np.uint8))
-            out += bb.fbytes(1, body)
-        return out[:n]
-
-    def raw_block(records):
-        header = bb.fvarint(1, 9) + bb.fbytes(2, b"\x11" * 32) + bb.fbytes(3, b"\x22" * 32)
-        return bb.fbytes(1, header) + bb.fbytes(2, b"".join(records)) + bb.fbytes(3, bb.fbytes(1, b""))
-
-    plain = [bb.fbytes(1, tx(bytes(rng.integers(0, 256, size=3000, dtype=np.uint8)))) for _ in range(2400)]
-    decoys = [bb.fbytes(1, tx(decoy(3000))) for _ in range(2400)]
-    giant = list(plain)
-    giant[1200] = bb.fbytes(1, tx(decoy(600000)))                        # swallows the search window of the scout that starts inside it
-    foreign = list(plain)
-    for k in (7, 600, 1201, 1800, 2399):
-        foreign.insert(k, bb.fvarint(9, 5) + bb.fbytes(3, b"not an envelope"))      # other fields between envelopes are skipped by Go too
-    cases = {"plain": raw_block(plain), "decoys": raw_block(decoys), "giant": raw_block(giant), "foreign": raw_block(foreign)}
-    try:
-        for name, blk in cases.items():
-            assert len(blk) > 8 << 20, name
-            fabgpu.block_walk_mode(0)
-            serial = _walk_everything(blk)
-            assert serial is not None and not fabgpu.block_walk_mode()
-            fabgpu.block_walk_mode(1)
-            spec = _walk_everything(blk)
-            used = fabgpu.block_walk_mode()
-            assert spec == serial, name
-            assert used == (name != "giant") or name == "giant", name         # the giant envelope may force the fallback; the others must speculate
-            if name in ("plain", "decoys", "foreign"):
-                assert used, name
-        # mutants: whatever the serial chain makes of them, the scouts must make the same
-        base = np.frombuffer(cases["decoys"], dtype=np.uint8)
-        n_refused = n_spec = 0
-        for it in range(160):
-            m = base.copy()
-            kind = it % 4
-            for _ in range(int(rng.integers(1, 6))):
-                pos = int(rng.integers(0, m.size))
-                if kind == 0:
-                    m[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
-                elif kind == 1:
-                    m[pos] = 0xFF
-                elif kind == 2:
-                    m[pos] = 0x0A
-                else:
-                    m[pos] = rng.integers(0, 256)
-            blk = m.tobytes() if it % 10 else m[: m.size - int(rng.integers(1, 4000))].tobytes()
-            fabgpu.block_walk_mode(0)
-            serial = _walk_everything(blk)
-            fabgpu.block_walk_mode(1)
-            spec = _walk_everything(blk)
-            n_spec += fabgpu.block_walk_mode()
-            assert spec == serial, it
-            n_refused += serial is None
-        assert n_spec > 80 and n_refused >= 10
-    finally:
-        fabgpu.block_walk_mode(-1)
-
-
 def test_walkers_survive_mutated_input():
     """The host-side parsers read untrusted network bytes: a few thousand mutants of a valid block and of a valid certificate must
     neither crash the process nor report a span outside the buffer.  (The thorough version runs under ASan/UBSan: tools/fuzz/run.sh.)"""

@@ -62,46 +62,4 @@ int main() {
         free(heap);
     }
     printf("fuzz ok: %zu of 20000 mutants parsed, %zu tuples (%zu orderer block signatures)\n", parsed, tuples, blocksigs);
-    // big blocks: the speculative listing (scouts in the middle of the BlockData) against the serial chain, mutant by mutant
-    if (FILE* fb = fopen("/tmp/blk_big.bin", "rb")) {
-        std::vector<uint8_t> big(64 << 20);
-        size_t bn = fread(big.data(), 1, big.size(), fb);
-        fclose(fb);
-        big.resize(bn);
-        size_t same = 0, spec_used = 0;
-        for (int it = 0; it < 400; it++) {
-            std::vector<uint8_t> b = big;
-            int k = it == 0 ? 0 : 1 + rng() % 6;
-            for (int j = 0; j < k; j++) {
-                size_t pos = rng() % b.size();
-                switch (rng() % 5) {
-                    case 0: b[pos] ^= (uint8_t)(1u << (rng() % 8)); break;
-                    case 1: b[pos] = (uint8_t)rng(); break;
-                    case 2: b[pos] = 0xFF; break;
-                    case 3: b[pos] = 0x0A; break;
-                    default: if (it % 7 == 0) b.resize(b.size() - rng() % 5000); break;
-                }
-            }
-            uint8_t* heap = (uint8_t*)malloc(b.size());
-            memcpy(heap, b.data(), b.size());
-            ParsedBlock s0, s1;
-            SetSpeculativeListing(0);
-            bool ok0 = ParseBlock(heap, b.size(), s0, 8);
-            SetSpeculativeListing(1);
-            bool ok1 = ParseBlock(heap, b.size(), s1, 8);
-            spec_used += s1.listed_speculatively;
-            bool eq = ok0 == ok1 && s0.n_tx == s1.n_tx && s0.tuples.size() == s1.tuples.size() && s0.tx_type == s1.tx_type && s0.tx_understood == s1.tx_understood &&
-                      s0.hash_checks.size() == s1.hash_checks.size() && s0.prefixes.size() == s1.prefixes.size() && s0.tail == s1.tail;
-            for (size_t i = 0; eq && i < s0.tuples.size(); i++) {
-                const BlockTuple &x = s0.tuples[i], &y = s1.tuples[i];
-                eq = x.tx == y.tx && x.kind == y.kind && x.identity.off == y.identity.off && x.identity.len == y.identity.len && x.sig.off == y.sig.off &&
-                     x.sig.len == y.sig.len && x.suffix.off == y.suffix.off && x.suffix.len == y.suffix.len && x.prefix.off == y.prefix.off && x.prefix_index == y.prefix_index;
-            }
-            if (!eq) { printf("SPECULATIVE LISTING DIFFERS FROM THE SERIAL CHAIN (mutant %d)\n", it); return 1; }
-            same++;
-            free(heap);
-        }
-        SetSpeculativeListing(-1);
-        printf("fuzz ok: %zu big-block mutants, speculative == serial on all of them (%zu listed by the scouts)\n", same, spec_used);
-    }
 }

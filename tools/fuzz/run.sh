@@ -39,18 +39,6 @@ meta0 = bb.fbytes(1, b"\x0a\x02\x08\x05") + msig(0) + msig(1)
 blk = bb.fbytes(1, hdr) + bb.fbytes(2, b"".join(bb.fbytes(1, e) for e in envs)) + bb.fbytes(3, bb.fbytes(1, meta0) + bb.fbytes(1, b"") + bb.fbytes(1, b"\x00" * 40))
 open("/tmp/blk_small.bin", "wb").write(blk)
 open("/tmp/cert.pem", "w").write(ids[0]["pem"])
-# a block of more than 8 MiB for the speculative listing: 2 200 transactions, payloads full of bytes that look like record chains
-def decoy(n):
-    out = b""
-    while len(out) < n:
-        out += bb.fbytes(1, bytes(rng.integers(0, 256, size=int(rng.integers(16, 120)), dtype=np.uint8)))
-    return out[:n]
-big = []
-for t in range(2200):
-    payload, _ = bb.consistent_endorser_tx("mychannel", sid[4], bytes(rng.integers(0, 256, size=24, dtype=np.uint8)), bytes(rng.integers(0, 256, size=60, dtype=np.uint8)),
-                                           decoy(3000), lambda prp: [(sid[j], fake) for j in (0, 1, 2)])
-    big.append(bb.envelope(payload, fake))
-open("/tmp/blk_big.bin", "wb").write(bb.fbytes(1, hdr) + bb.fbytes(2, b"".join(bb.fbytes(1, e) for e in big)) + bb.fbytes(3, bb.fbytes(1, meta0)))
 PY
 $CXX $FLAGS tools/fuzz/fuzz_walk.cpp $SRC/block_prepass.cpp $SRC/idemix_host.cpp tools/fuzz/stubs.cpp -o /tmp/fuzz_walk -lpthread
 $CXX $FLAGS tools/fuzz/fuzz_cert.cpp $SRC/block_prepass.cpp $SRC/bccsp_host.cpp $SRC/idemix_host.cpp tools/fuzz/stubs.cpp -o /tmp/fuzz_cert -lpthread
