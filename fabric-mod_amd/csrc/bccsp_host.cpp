@@ -1044,7 +1044,10 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             if (!out.tuple_hashed[i]) continue;
             const uint8_t stt = out.tuple_status[i];
             if (stt > FABGPU_ST_RANGE) continue;           // 0 valid, 1 bad math, 2 high-S, 3 range: what bccsp.Verify decides itself
-            // (pseudonym signatures: key = Nym.x || Nym.y, digest = SHA-256(message), status 0 valid / 1 proof invalid)
+            // (pseudonym signatures: key = Nym.x || Nym.y, digest = SHA-256(message), status 0 valid / 1 proof invalid.  The issuer is
+            // not part of the key and need not be: the signed message is the envelope payload, which embeds the creator's serialized
+            // identity - MSP id included - so the same (Nym, signature, message) can only ever be presented under the MSP, hence the
+            // issuer key, it was verified under here.)
             if (pb.tuples[i].sig.len == 0 || pb.tuples[i].sig.len > 1024) continue;
             sel[m++] = (uint32_t)i;
             bm->key_off.push_back(bm->key_off.back() + (uint32_t)MemoKeyBytes(pb.tuples[i].sig.len, 32));
