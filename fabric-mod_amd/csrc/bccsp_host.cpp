@@ -417,9 +417,7 @@ Error GPUCSP::IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::v
 // block-level pre-verify pass (block_prepass.h)
 // ------------------------------------------------------------------------------------------------
 void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len) const {
-    // a launch is coming in a millisecond or three (walk + gates): start raising the clock now (fabgpu.h fabgpu_warm)
-    static const uint32_t warm_us = [] { const char* e = getenv("FABGPU_PASS_WARM_US"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();
-    if (warm_us) fabgpu_warm(ctx_, warm_us);
+
     size_t min_bytes = (size_t)4 << 20;                 // small blocks ride with the submission through pinned staging
     if (const char* e = getenv("FABGPU_PASS_STAGE_MIN_BYTES")) min_bytes = (size_t)strtoull(e, nullptr, 10);   // tests force the staged path
     if (!block || len < min_bytes) return;

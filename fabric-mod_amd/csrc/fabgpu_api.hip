@@ -47,8 +47,6 @@ struct fabgpu_ctx {
     int device = 0;
     bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
     hipStream_t stream = nullptr;
-    hipStream_t warm_stream = nullptr;   // fabgpu_warm: never the stream a batch runs on
-    void* d_warm_sink = nullptr;
     // FABGPU_FAULT_INJECT (tests of the failure contract only): "launch" makes every kernel submission report hipErrorLaunchFailure,
     // "oom" makes every workspace / staging allocation fail.  A non-zero return must then reach the caller and no verdict may be written.
     int fault = 0;
@@ -219,8 +217,6 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     int rc = FABGPU_OK;
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
-        if (hipStreamCreateWithFlags(&ctx->warm_stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
-        if (hipMalloc(&ctx->d_warm_sink, 64) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
         if (const char* fi = getenv("FABGPU_FAULT_INJECT")) ctx->fault = !strcmp(fi, "launch") ? 1 : (!strcmp(fi, "oom") ? 2 : 0);
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         std::vector<int32_t> tab(GTab16::TABLE_WORDS);   // 80 MiB, ~0.2 s on 16 host threads
@@ -248,8 +244,6 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
     {
         DeviceGuard g(ctx->device);
         if (ctx->stream) hipStreamSynchronize(ctx->stream);
-        if (ctx->warm_stream) { hipStreamSynchronize(ctx->warm_stream); hipStreamDestroy(ctx->warm_stream); }
-        if (ctx->d_warm_sink) hipFree(ctx->d_warm_sink);
         ctx->fields.release();
         ctx->arena.release();
         ctx->offs.release();
@@ -276,12 +270,6 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         if (ctx->stream) hipStreamDestroy(ctx->stream);
     }
     delete ctx;
-}
-
-int fabgpu_warm(fabgpu_ctx* ctx, uint32_t usec) {
-    if (!ctx) return FABGPU_EINVAL;
-    DeviceGuard g(ctx->device);
-    return hip_to_rc(launch_warm(usec, ctx->d_warm_sink, ctx->warm_stream));
 }
 
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx) {

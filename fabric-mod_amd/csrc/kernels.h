@@ -27,8 +27,6 @@ struct VerifyGeom {
     uint32_t wgs;     // workgroups launched (= workspace slots)
     bool pair;        // two lanes per signature
 };
-// keeps every SIMD busy with integer multiply-adds for ~usec microseconds (<= 5000) on `st`; sink: any 4 writable device bytes
-hipError_t launch_warm(uint32_t usec, void* sink, hipStream_t st);
 VerifyGeom verify_geom(uint32_t n, bool allow_pair);
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair);
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);

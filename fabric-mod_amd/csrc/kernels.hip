@@ -333,32 +333,6 @@ __global__ void __launch_bounds__(256) gather_spans_kernel(uint32_t n, const uin
     }
 }
 
-// Clock warm-up: a peer receives a block every few hundred milliseconds, and an idle MI355X answers the first launch at its idle
-// clock (the same 30 000-tuple launch: 2.8 ms instead of 0.8 ms).  The block pass knows a launch is coming
-// as soon as the block arrives - before it has walked and gated it - so it starts this kernel then: every SIMD executes integer
-// multiply-adds (the unit whose load the power manager reacts to) until `ticks` of the constant-rate wall clock have passed.
-__global__ void __launch_bounds__(256) warm_kernel(uint64_t ticks, uint32_t* __restrict__ sink) {
-    const long long t0 = wall_clock64();                      // the constant-rate counter (hipDeviceAttributeWallClockRate), not s_memtime
-    uint64_t a = threadIdx.x + 1, b = blockIdx.x + 3;
-    while ((uint64_t)(wall_clock64() - t0) < ticks) {
-#pragma unroll
-        for (int k = 0; k < 64; k++) a = a * b + (uint32_t)k;
-    }
-    if (a == 0x1234567887654321ull) sink[0] = (uint32_t)a;    // never true; keeps the loop alive
-}
-hipError_t launch_warm(uint32_t usec, void* sink, hipStream_t st) {
-    if (usec == 0) return hipSuccess;
-    if (usec > 5000) usec = 5000;
-    static int khz = 0;                                       // wall-clock rate of the current device (100 MHz on MI300-class parts)
-    if (khz == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, dev) != hipSuccess || v <= 0) v = 100000;
-        khz = v;
-    }
-    hipLaunchKernelGGL(warm_kernel, dim3(256), dim3(256), 0, st, (uint64_t)usec * (uint64_t)khz / 1000, (uint32_t*)sink);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------------------

@@ -90,7 +90,7 @@ ABI_SYMBOLS = [
     "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_evict_block",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
     "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",
-    "fabgpu_warm", "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
+    "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
     "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev",
 ]
 
@@ -169,7 +169,6 @@ def load():
     L.fabgpu_csp_identity_cache_size.argtypes = [_vp, _u64p]
     L.fabgpu_csp_x509_check_signature_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p, _u8p, _u8p]
     L.fabgpu_x509_signature_parts.argtypes = [ctypes.c_char_p, _sz, _u32p, _u32p, _u32p, _u32p, ctypes.POINTER(ctypes.c_int)]
-    L.fabgpu_warm.argtypes = [_vp, ctypes.c_uint32]
     L.fabgpu_multi_init.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(_vp)]
     L.fabgpu_multi_shutdown.argtypes = [_vp]
     L.fabgpu_multi_shutdown.restype = None

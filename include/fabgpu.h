@@ -249,12 +249,6 @@ int fabgpu_multi_sha256_p256_verify_batch(fabgpu_multi* m, size_t n, const uint8
 int fabgpu_multi_plan(size_t n, const uint32_t* off, uint32_t n_devices, uint64_t* lo, uint64_t* hi, uint64_t* words_per_rank);
 const void* fabgpu_multi_merged_bitmap_dev(fabgpu_multi* m, int g);
 
-/* Clock warm-up.  A peer validates a block every few hundred milliseconds; in between the GPU drops to its idle clock and the next
- * launch pays for it (the same 30 000-tuple launch: 2.8 ms idle, 0.8 ms warm).  fabgpu_warm keeps every SIMD busy with integer
- * multiply-adds for about `usec` microseconds (capped at 5000) on a stream of its own and returns at once: call it when a block ARRIVES,
- * before parsing it - the block pass does (FABGPU_PASS_WARM_US, fabgpu_csp_block_preverify*).  Never needed for correctness. */
-int fabgpu_warm(fabgpu_ctx* ctx, uint32_t usec);
-
 /* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
  * launch stream.  Only for contexts created with FABGPU_FLAG_TIME_KERNELS; <0 otherwise / if nothing was launched. */
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);

@@ -16,5 +16,4 @@ int fabgpu_p256_key_register(fabgpu_ctx*, const uint8_t*, const uint8_t*, uint32
 int fabgpu_p256_key_lookup(fabgpu_ctx*, const uint8_t*, const uint8_t*, uint32_t*) { return 1; }
 int fabgpu_identity_verify_batch(fabgpu_ctx*, const fabgpu_identity_batch*) { return -1; }
 int fabgpu_arena_stage(fabgpu_ctx*, const void*, size_t, uint64_t*) { return -1; }
-int fabgpu_warm(fabgpu_ctx*, uint32_t) { return -1; }
 }

@@ -1,12 +1,18 @@
 #!/bin/bash
-# where the block pass's HOST time goes: staging thread on/off, walk threads, memo on/off (FABGPU_PASS_TIMING prints the stages)
+# where the block pass's HOST time goes, in one gpurun call: the walker alone (hot, by thread count), then the pass with
+# FABGPU_PASS_TIMING for several thread settings, with and without the upload thread, with memo seeding, by block size
 R=$GRAFT_REPO_ROOT; cd $R
 python tools/make_walk_block.py /tmp/blk.bin
-echo "walker alone (hot): r01 / r02 / r02b, 16 threads then 1"; for b in walk_r01 walk_r02 walk_r02b; do fabric-mod_amd/lib/$b /tmp/blk.bin 16 | tail -1; fabric-mod_amd/lib/$b /tmp/blk.bin 1 | tail -1; done
-run() { echo "== $1"; shift; env "$@" FABGPU_PASS_TIMING=1 python tools/bench_block.py --steps 6 2>&1 | grep -E "fabgpu pass|ms_per_block" | tail -4 | cut -c1-260; }
-run "default" A=1
-run "no staging thread" FABGPU_PASS_STAGE_MIN_BYTES=999999999
-run "walk threads 8" FABGPU_PASS_WALK_THREADS=8
-run "walk threads 4" FABGPU_PASS_WALK_THREADS=4
-run "walk threads 1" FABGPU_PASS_WALK_THREADS=1
-run "walk threads 4, no staging" FABGPU_PASS_WALK_THREADS=4 FABGPU_PASS_STAGE_MIN_BYTES=999999999
+g++ -O3 -std=c++17 -Ifabric-mod_amd/csrc tools/walk_harness.cpp fabric-mod_amd/csrc/block_prepass.cpp -o /tmp/walk -lpthread 2>/dev/null
+for t in 16 8 4 1; do echo "walker alone, threads=$t"; /tmp/walk /tmp/blk.bin $t | tail -2; done
+run() { echo "== $1"; shift; env "$@" FABGPU_PASS_TIMING=1 python tools/bench_block.py --steps 8 $EXTRA 2>&1 | grep -E "fabgpu pass|ms_per_block" | tail -3 | cut -c1-230; }
+run "10k default (8 walk workers)" A=1
+run "10k walk threads 16" FABGPU_PASS_WALK_THREADS=16
+run "10k walk threads 4" FABGPU_PASS_WALK_THREADS=4
+run "10k walk threads 1" FABGPU_PASS_WALK_THREADS=1
+run "10k no staging thread" FABGPU_PASS_STAGE_MIN_BYTES=999999999
+run "10k gates 8" FABGPU_PASS_GATE_THREADS=8
+EXTRA=--memo run "10k memo" A=1
+EXTRA="--tx 3000" run "3k tx" A=1
+EXTRA="--tx 1000" run "1k tx" A=1
+EXTRA="--tx 100" run "100 tx" A=1

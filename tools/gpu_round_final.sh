@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-of-round evidence in one gpurun call: GPU test suite, the driver's bench command plain and under rocprofv3 (kernel trace + stats),
-# the block pass (flags only / memo seeding / idle gaps with and without warm-up), config 5, registered keys, the in-process multi
+# the block pass (flags only / memo seeding / idle gaps), config 5, registered keys, the in-process multi
 # dispatcher.  Summaries land in gpurun_out/ and are copied to profiles/ by hand.
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
@@ -16,8 +16,8 @@ cd $R
 for t in 10000 3000 1000 100; do python tools/bench_block.py --tx $t --steps 8 > $OUT/r02z_block_${t}_flags.json 2>/dev/null; python tools/bench_block.py --tx $t --steps 8 --memo > $OUT/r02z_block_${t}_memo.json 2>/dev/null; python -c "
 import json
 a=json.load(open('$OUT/r02z_block_${t}_flags.json')); b=json.load(open('$OUT/r02z_block_${t}_memo.json')); print('block', $t, 'flags', a['ms_per_block'], 'memo', b['ms_per_block'], b['memo_lookup_us_via_ctypes'])"; done
-for warm in 0 300 1000; do FABGPU_PASS_WARM_US=$warm python tools/bench_block.py --tx 1000 --steps 8 --idle-ms 250 --memo 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('idle250 1k warm', $warm, d['ms_per_block'], d['ms_min'], d['ms_max'])"; done
-for warm in 0 1500; do FABGPU_PASS_WARM_US=$warm python tools/bench_block.py --steps 8 --idle-ms 250 --memo 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('idle250 10k warm', $warm, d['ms_per_block'], d['ms_min'], d['ms_max'])"; done
+python tools/bench_block.py --tx 1000 --steps 10 --idle-ms 250 --memo 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('idle250 1k', d['ms_per_block'], d['ms_min'], d['ms_max'])"
+python tools/bench_block.py --steps 8 --idle-ms 250 --memo 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('idle250 10k', d['ms_per_block'], d['ms_min'], d['ms_max'])"
 python tools/bench_cfg5_mixed.py > $OUT/r02z_cfg5.json 2>/dev/null; cut -c1-300 $OUT/r02z_cfg5.json
 python tools/bench_keyed.py > $OUT/r02z_keyed.json 2>/dev/null; cut -c1-200 $OUT/r02z_keyed.json
 python tools/bench_multi.py --gpus 1 2>/dev/null | grep "^{" > $OUT/r02z_multi_g1.json; cut -c1-500 $OUT/r02z_multi_g1.json
