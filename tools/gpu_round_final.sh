@@ -8,7 +8,7 @@ cd $R
 python -m pytest tests -m gpu -q > $OUT/r02z_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/r02z_pytest.log
 python bench.py --steps 20 --warmup 5 > $OUT/r02z_bench.json 2> $OUT/r02z_bench.err; echo "bench rc=$?"
 python -c "
-import json; d=json.load(open('$OUT/r02z_bench.json')); print('bench', d['value'], d['ms_per_step'], d['dispersion']['median_ms'], d['pcie_inclusive']['value'], d['configs3_fused']['value'], d['two_blocks_in_flight']['value'], d['valu_roofline']['frac'], d['valu_roofline']['executed_frac'], d['cpu_baseline']['value'], d['cpu_baseline']['single_thread']['value'])"
+import json; d=json.load(open('$OUT/r02z_bench.json')); print('bench', d['value'], d['ms_per_step'], d['dispersion']['median_ms'], d['pcie_inclusive']['value'], d['configs3_fused']['value'], d['valu_roofline']['frac'], d['valu_roofline']['executed_frac'], d['cpu_baseline']['value'], d['cpu_baseline']['single_thread']['value'])"
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_final
 rocprofv3 --kernel-trace --stats -d /tmp/prof_final -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/r02z_bench_under_rocprof.json 2>/dev/null
 python $R/profiles/summarize_rocprof.py $(find /tmp/prof_final -name "*.db") > $OUT/r02z_rocprof_final.txt 2>&1; head -8 $OUT/r02z_rocprof_final.txt
