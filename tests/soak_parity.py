@@ -1,23 +1,22 @@
 #!/usr/bin/env python3
 """Randomised parity soak: for --seconds, draw batch sizes across both kernel geometries (two lanes per signature up to 32 768, one lane
 beyond), mutation mixes and entry points (verify-only, fused hash + verify with ragged messages, registered keys) and compare every
-status byte and verdict bit with the C oracle.  Prints one JSON line.  (The oracle is the checker here, as in the tests.)"""
+status byte and verdict bit with the C oracle.  Test infrastructure: tests/test_soak.py runs it for FABGPU_SOAK_SECONDS (default 15) under
+`pytest -m gpu`; `python tests/soak_parity.py --seconds 240` is the long run recorded in profiles/r02_soak_parity.json."""
 import argparse
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 for p in ("fabric-mod_amd", "oracle"):
     sys.path.insert(0, os.path.join(ROOT, p))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=120.0)
-    ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+def soak(seconds, seed):
+    import types
+    args = types.SimpleNamespace(seconds=seconds, seed=seed)
     import numpy as np
 
     import coracle
@@ -55,15 +54,24 @@ def main():
             stats["keyed"] += 1
         if not ((st == want).all() and (bits == (want == 0)).all()):
             bad = np.nonzero(st != want)[0][:5]
-            print(json.dumps({"soak": "MISMATCH", "iteration": it, "n": n, "mode": mode, "first_bad": bad.tolist()}))
-            sys.exit(1)
+            return {"soak": "MISMATCH", "iteration": it, "n": n, "mode": mode, "first_bad": bad.tolist()}
         stats["batches"] += 1
         stats["tuples"] += n
         stats["invalid"] += int((want != 0).sum())
         stats["pair_geometry" if n <= 32768 else "one_lane_geometry"] += 1
     ctx.close()
-    print(json.dumps({"soak": "ok", "seconds": args.seconds, "seed": args.seed, **stats,
-                      "parity": "every status byte and verdict bit equal to the C oracle (oracle/p256_oracle.c)"}))
+    return {"soak": "ok", "seconds": args.seconds, "seed": args.seed, **stats,
+            "parity": "every status byte and verdict bit equal to the C oracle (oracle/p256_oracle.c)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    r = soak(a.seconds, a.seed)
+    print(json.dumps(r))
+    sys.exit(0 if r["soak"] == "ok" else 1)
 
 
 if __name__ == "__main__":
