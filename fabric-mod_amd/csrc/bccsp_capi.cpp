@@ -169,6 +169,7 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     ps->tail_len = (uint32_t)pb.tail.size();
     ps->block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
     ps->memo_seeded = 0;
+    ps->n_keyed = 0;
     if (pb.n_tx > ps->cap_tx || pb.tuples.size() > ps->cap_tuples || (ps->tail && pb.tail.size() > ps->tail_cap)) return FABGPU_ETOOBIG;
     PassOptions opt;
     opt.seed_memo = (ps->flags & FABGPU_PASS_SEED_MEMO) != 0;
@@ -198,6 +199,7 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
         }
     if (ps->tail && !pb.tail.empty()) memcpy(ps->tail, pb.tail.data(), pb.tail.size());
     ps->memo_seeded = v.memo_seeded;
+    ps->n_keyed = (uint32_t)v.n_keyed;
     return FABGPU_OK;
 }
 

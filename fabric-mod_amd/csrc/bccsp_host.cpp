@@ -832,6 +832,11 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     for (int w = 0; w < nthreads; w++) n += cnt[w + 1];
     bool all_keyed = true;
     for (uint8_t k : keyed_w) all_keyed = all_keyed && k;
+    // One identity without a device table sends the whole block down the fresh-key kernel.  Splitting such a block into a table
+    // launch and a fresh-key launch was tried (round 2): submitted one after the other the two cost what the single launch costs,
+    // within +-0.3 ms on a 10 000-transaction block - the fresh-key kernel is latency-bound below 32 768 tuples, so
+    // taking tuples away from it does not shorten it.
+    out.n_keyed = all_keyed ? n : 0;
     std::vector<uint8_t>& hash_digests = ps_.hash_digests;   // (scratch of the pass: reused from block to block, like everything below)
     bool hashes_done = false;
     if (n) {

@@ -95,6 +95,7 @@ struct BlockVerdicts {
     uint32_t n_block_sigs = 0;            // TUPLE_BLOCK_SIG tuples (the last ones)
     uint8_t block_sigs_understood = 0;
     uint32_t memo_seeded = 0;             // entries this pass added to the verdict memo
+    size_t n_keyed = 0;                   // submitted tuples that went through per-key device tables (the rest carried their keys)
 };
 
 // Options of one pass.

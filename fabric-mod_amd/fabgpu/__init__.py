@@ -64,7 +64,8 @@ class _BlockPass(ctypes.Structure):
                 ("tail_base", ctypes.c_uint32), ("tail_len", ctypes.c_uint32), ("block_sigs_understood", ctypes.c_uint8),
                 ("tx_flags", ctypes.c_void_p), ("tx_type", ctypes.c_void_p), ("tuple_tx", ctypes.c_void_p), ("tuple_kind", ctypes.c_void_p),
                 ("tuple_status", ctypes.c_void_p), ("tuple_spans", ctypes.c_void_p), ("tuple_digest", ctypes.c_void_p),
-                ("tuple_hashed", ctypes.c_void_p), ("tuple_qxy", ctypes.c_void_p), ("tail", ctypes.c_void_p), ("tail_cap", ctypes.c_uint32)]
+                ("tuple_hashed", ctypes.c_void_p), ("tuple_qxy", ctypes.c_void_p), ("tail", ctypes.c_void_p), ("tail_cap", ctypes.c_uint32),
+                ("n_keyed", ctypes.c_uint32)]
 
 
 class _Cfg(ctypes.Structure):
@@ -830,7 +831,7 @@ def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo:
                 csp._pass_caps = (cap_tx, cap_tu)
                 continue
             _check(rc, "fabgpu_csp_block_preverify2")
-            return dict(tx_flags=flags[:ps.n_tx], n_tuples=ps.n_tuples, n_block_sigs=ps.n_block_sigs, memo_seeded=ps.memo_seeded)
+            return dict(tx_flags=flags[:ps.n_tx], n_tuples=ps.n_tuples, n_block_sigs=ps.n_block_sigs, memo_seeded=ps.memo_seeded, n_keyed=ps.n_keyed)
     cap_tx, cap_tu = getattr(csp, "_pass_caps", (1024, 4096))
     tail_cap = 1 << 16
     while True:
@@ -852,7 +853,7 @@ def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo:
         _check(rc, "fabgpu_csp_block_preverify2")
         nt, nu = ps.n_tx, ps.n_tuples
         out = {k: (v[:nt].copy() if k.startswith("tx_") else v[:nu].copy()) for k, v in a.items() if k != "tail"}
-        out.update(n_block_sigs=ps.n_block_sigs, block_sigs_understood=bool(ps.block_sigs_understood), memo_seeded=ps.memo_seeded,
+        out.update(n_block_sigs=ps.n_block_sigs, block_sigs_understood=bool(ps.block_sigs_understood), memo_seeded=ps.memo_seeded, n_keyed=ps.n_keyed,
                    arena=bytes(block) + b"\0" * (ps.tail_base - len(block)) + bytes(a["tail"][:ps.tail_len]))
         return out
 

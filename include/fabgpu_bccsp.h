@@ -103,6 +103,9 @@ typedef struct fabgpu_block_pass {
     uint8_t* tuple_qxy;          /* cap_tuples x 64 */
     uint8_t* tail;               /* tail_cap bytes: the block-signature messages (optional) */
     uint32_t tail_cap;
+    /* out: submitted tuples that went through per-key device tables (all of them, or none: one identity without a table sends the
+     * block down the fresh-key kernel) */
+    uint32_t n_keyed;
 } fabgpu_block_pass;
 int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* pass);
 /* 0: hit, *status = 0 valid / 1 arithmetic reject / 2 high-S / 3 r out of range (the reference rejects: ask bccsp/sw for its error

@@ -178,6 +178,31 @@ def test_preverify_pass_end_to_end():
     csp.close()
 
 
+@pytest.mark.gpu
+def test_preverify_pass_with_known_and_new_identities():
+    """A block signed by identities of which only some have a device table (newcomers among known ones): the answer does not depend
+    on which path - per-key tables or keys carried along - the tuples took."""
+    csp = fabgpu.GPUCSP(device=0)
+    L = csp._L
+    before = csp.key_count()
+    rng = np.random.default_rng(61)
+    blk, want = build_block(300, rng)
+    L.fabgpu_csp_identity_cache_limits(csp._h, 4096, 3, 1)               # three tables at most, earned at the first sight
+    first = fabgpu.preverify_block2(csp, blk, block_seq=1)                # nobody has a table yet
+    assert (first["tx_flags"] == want).all() and first["n_keyed"] == 0
+    assert csp.key_count() == before + 3
+    second = fabgpu.preverify_block2(csp, blk, block_seq=2)               # three of the six signers have one: still the fresh-key path
+    n_sub = int(second["tuple_hashed"].sum())
+    assert second["n_keyed"] == 0 and (second["tx_flags"] == want).all()
+    L.fabgpu_csp_identity_cache_limits(csp._h, 4096, 256, 1)              # room for everybody: this pass registers the rest ...
+    fabgpu.preverify_block2(csp, blk, block_seq=3)
+    fourth = fabgpu.preverify_block2(csp, blk, block_seq=4)               # ... and the next is all tables
+    assert fourth["n_keyed"] == n_sub and (fourth["tx_flags"] == want).all()
+    for k in ("tuple_status", "tuple_hashed", "tuple_digest", "tuple_tx", "tuple_kind"):
+        assert (second[k] == first[k]).all() and (fourth[k] == first[k]).all(), k
+    csp.close()
+
+
 # ---- blocks whose creators are idemix identities (BASELINE config 5 at the block level) -----------------------------------
 def build_mixed_block(n_tx, rng, idemix_every=5):
     """As build_block(corrupt=False), but every idemix_every-th transaction is created by an idemix identity of IdemixMSP1 whose
