@@ -624,9 +624,26 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     out.block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
     // identities -> keys (cached across blocks), signatures -> (r, s) through the reference's gates.  Tuples are independent:
     // blocks of 4096+ tuples are gated on worker threads (contiguous ranges), then compacted in order.
-    // One pass at a time per provider: the scratch below (8 MB for a 40 000-tuple block) is reused from block to block instead of
-    // being allocated - and page-faulted in - per call.
-    std::lock_guard<std::mutex> pass_lk(pass_mu_);
+    // The scratch below (8 MB for a 40 000-tuple block) is reused from block to block instead of being allocated - and page-faulted
+    // in - per call.  Passes of different callers run side by side, each on a set of its own (up to four are kept): one caller's gates
+    // and flags overlap another's device call (two callers, 10 000-tx blocks: 3.2 ms per block with one pass at a time).
+    struct Lease {
+        const GPUCSP* c;
+        std::unique_ptr<PassScratch> p;
+        explicit Lease(const GPUCSP* c_) : c(c_) {
+            std::lock_guard<std::mutex> lk(c->pass_mu_);
+            if (!c->scratch_free_.empty()) {
+                p = std::move(c->scratch_free_.back());
+                c->scratch_free_.pop_back();
+            }
+            if (!p) p.reset(new PassScratch);
+        }
+        ~Lease() {
+            std::lock_guard<std::mutex> lk(c->pass_mu_);
+            if (c->scratch_free_.size() < 4) c->scratch_free_.push_back(std::move(p));
+        }
+    } lease(this);
+    PassScratch& ps_ = *lease.p;
     typedef PassScratch::Gated Gated;
     std::map<std::string, int64_t> idemix_msps;
     {

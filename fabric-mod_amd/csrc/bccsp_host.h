@@ -210,7 +210,7 @@ class GPUCSP {
     static void MemoKeyWrite(uint8_t* out, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
     static uint64_t MemoHash(const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
     mutable std::map<std::string, int64_t> idemix_msps_;   // mspid -> device issuer id (guarded by idmu_)
-    // scratch of the pre-verify pass, reused from block to block (guarded by pass_mu_)
+    // scratch of the pre-verify pass, reused from block to block: a pass leases one set (a peer's channels run passes side by side)
     struct PassScratch {
         struct Gated {
             uint8_t qx[32], qy[32], r[32], s[32];   // idemix tuple: qx, qy = pseudonym; r, s = ProofC, ProofSSk
@@ -224,8 +224,8 @@ class GPUCSP {
         std::vector<uint32_t> pre_off, gsp;
         std::vector<uint64_t> bits;
     };
-    mutable std::mutex pass_mu_;
-    mutable PassScratch ps_;
+    mutable std::mutex pass_mu_;                                      // guards scratch_free_
+    mutable std::vector<std::unique_ptr<PassScratch>> scratch_free_;
 };
 
 }  // namespace bccsp

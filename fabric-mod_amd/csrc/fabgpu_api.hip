@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <map>
@@ -92,11 +94,20 @@ struct fabgpu_ctx {
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
     void* d_gscr = nullptr;   // device scratch the gather kernel stitches the messages into
     size_t gscr_cap = 0;
-    // fabgpu_arena_stage: an arena uploaded ahead of the batch that refers to it
+    // fabgpu_arena_stage: arenas uploaded ahead of the batches that refer to them.  A few slots, so that the channels of a peer
+    // validating at once do not throw each other's block out between "staged" and "submitted" (with one slot, two callers cost
+    // more per block than one: the loser uploaded its 50 MB a second time inside its device call).  A slot's mutex is held while
+    // it is being filled and while a batch reads it; smu only guards the choice of a slot.  Lock order: smu, slot, mu.
+    struct Staged {
+        std::mutex m;
+        void* d = nullptr;
+        size_t cap = 0, len = 0;
+        std::atomic<uint64_t> token{0};
+    };
+    static constexpr int N_STAGED = 3;
     std::mutex smu;
-    void* d_staged = nullptr;
-    size_t staged_cap = 0, staged_len = 0;
-    uint64_t staged_token = 0;
+    Staged staged_slots[N_STAGED];
+    uint64_t stage_seq = 0;
     Buf keyed;        // staging of the keyed host-pointer entry point: key_id | e | r | s
     Buf pre;          // staging of prefixed batches: pre_off | pre_idx | mid-states
     Buf tailbuf;      // staging of an identity batch's tail when the arena itself bypasses the pinned buffer
@@ -259,7 +270,8 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->keyed.release();
         ctx->pre.release();
         if (ctx->d_gscr) hipFree(ctx->d_gscr);
-        if (ctx->d_staged) hipFree(ctx->d_staged);
+        for (auto& sl : ctx->staged_slots)
+            if (sl.d) hipFree(sl.d);
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
@@ -803,26 +815,46 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
 int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token) {
     if (!ctx || !arena || !token || len == 0) return FABGPU_EINVAL;
     if (len > 0xFFFFFF00ull) return FABGPU_ETOOBIG;
-    std::lock_guard<std::mutex> lk(ctx->smu);
+    // the least recently filled slot nobody is using; all in use: wait for the oldest
+    fabgpu_ctx::Staged* sl = nullptr;
+    std::unique_lock<std::mutex> slot_lk;
+    {
+        std::lock_guard<std::mutex> lk(ctx->smu);
+        int order[fabgpu_ctx::N_STAGED];
+        for (int i = 0; i < fabgpu_ctx::N_STAGED; i++) order[i] = i;
+        std::sort(order, order + fabgpu_ctx::N_STAGED, [&](int x, int y) { return ctx->staged_slots[x].token.load() < ctx->staged_slots[y].token.load(); });
+        for (int i = 0; i < fabgpu_ctx::N_STAGED && !sl; i++) {
+            std::unique_lock<std::mutex> t(ctx->staged_slots[order[i]].m, std::try_to_lock);
+            if (t.owns_lock()) {
+                sl = &ctx->staged_slots[order[i]];
+                slot_lk = std::move(t);
+            }
+        }
+        if (!sl) sl = &ctx->staged_slots[order[0]];
+    }
+    if (!slot_lk.owns_lock()) slot_lk = std::unique_lock<std::mutex>(sl->m);
     DeviceGuard g(ctx->device);
     const size_t need = round_up(len, 64) + 128;          // + room for a batch's tail (fabgpu_identity_batch.tail) in the slack below
-    if (ctx->staged_cap < need + (64 << 10)) {
-        // a batch in flight may still read the old buffer: it was submitted under ctx->mu and synchronises before returning,
-        // and it holds no pointer past that; take mu to be sure nobody is between "token checked" and "kernels done"
-        std::lock_guard<std::mutex> lk2(ctx->mu);
-        if (ctx->d_staged) hipFree(ctx->d_staged);
-        ctx->d_staged = nullptr;
-        ctx->staged_cap = 0;
-        if (hipMalloc(&ctx->d_staged, need + need / 8 + (64 << 10)) != hipSuccess) return FABGPU_ENOMEM;
-        ctx->staged_cap = need + need / 8 + (64 << 10);
+    sl->token.store(0);                                    // the previous upload is gone from here on
+    sl->len = 0;
+    if (sl->cap < need + (64 << 10)) {                     // (a batch reading the old buffer would hold the slot's mutex)
+        if (sl->d) hipFree(sl->d);
+        sl->d = nullptr;
+        sl->cap = 0;
+        if (hipMalloc(&sl->d, need + need / 8 + (64 << 10)) != hipSuccess) return FABGPU_ENOMEM;
+        sl->cap = need + need / 8 + (64 << 10);
     }
-    ctx->staged_token++;                                   // the previous upload is gone from here on
-    ctx->staged_len = 0;
-    hipError_t err = hipMemcpy(ctx->d_staged, arena, len, hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = hipMemset((uint8_t*)ctx->d_staged + len, 0, need - len);
+    hipError_t err = hipMemcpy(sl->d, arena, len, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemset((uint8_t*)sl->d + len, 0, need - len);
     if (err != hipSuccess) return hip_to_rc(err);
-    ctx->staged_len = len;
-    *token = ctx->staged_token;
+    sl->len = len;
+    uint64_t t;
+    {
+        std::lock_guard<std::mutex> lk(ctx->smu);
+        t = ++ctx->stage_seq;
+    }
+    sl->token.store(t);
+    *token = t;
     return FABGPU_OK;
 }
 
@@ -838,11 +870,16 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     const bool spans = (b->flags & FABGPU_IDB_SPANS) != 0;
     const bool staged = (b->flags & FABGPU_IDB_ARENA_STAGED) != 0;
     if (b->flags & ~(uint32_t)(FABGPU_IDB_SPANS | FABGPU_IDB_ARENA_STAGED)) return FABGPU_EINVAL;
-    // a staged arena: the stager is kept out until this batch has run.  Lock order everywhere: smu, then mu.
-    std::unique_lock<std::mutex> slk(ctx->smu, std::defer_lock);
+    // a staged arena: its slot stays locked - the stager kept out of it - until this batch has run
+    fabgpu_ctx::Staged* sl = nullptr;
+    std::unique_lock<std::mutex> slk;
     if (staged) {
-        slk.lock();
-        if (b->stage_token == 0 || b->stage_token != ctx->staged_token || ctx->staged_len == 0) return FABGPU_EINVAL;   // replaced meanwhile
+        if (b->stage_token == 0) return FABGPU_EINVAL;
+        for (auto& c : ctx->staged_slots)
+            if (c.token.load() == b->stage_token) sl = &c;
+        if (!sl) return FABGPU_EINVAL;                                                          // replaced meanwhile
+        slk = std::unique_lock<std::mutex>(sl->m);
+        if (sl->token.load() != b->stage_token || sl->len == 0) return FABGPU_EINVAL;           // ... or just now
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
@@ -903,10 +940,10 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     if (spans && tail_used) lo = 0;                        // keeps tail_base an absolute offset of the device arena
     size_t span = hi >= lo ? (size_t)hi - lo : 0;          // bytes taken from the caller's arena
     if (staged) {
-        if (hi > ctx->staged_len) return FABGPU_EINVAL;
-        if (tail_used && ((size_t)tbase < round_up(ctx->staged_len, 64) || (size_t)tbase + b->tail_len + 128 > ctx->staged_cap)) return FABGPU_EINVAL;
+        if (hi > sl->len) return FABGPU_EINVAL;
+        if (tail_used && ((size_t)tbase < round_up(sl->len, 64) || (size_t)tbase + b->tail_len + 128 > sl->cap)) return FABGPU_EINVAL;
         lo = 0;                                           // offsets are offsets into the staged bytes
-        span = ctx->staged_len;
+        span = sl->len;
     } else if (span && !arena) {
         return FABGPU_EINVAL;
     }
@@ -966,8 +1003,8 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     if (staged) {
         err = hipSuccess;                                 // fabgpu_arena_stage put the bytes (and their zero tail) there
         if (tail_used) {
-            err = hipMemcpyAsync((uint8_t*)ctx->d_staged + tbase, ctx->tailbuf.h, b->tail_len, hipMemcpyHostToDevice, ctx->stream);
-            if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)ctx->d_staged + tbase + b->tail_len, 0, 128, ctx->stream);
+            err = hipMemcpyAsync((uint8_t*)sl->d + tbase, ctx->tailbuf.h, b->tail_len, hipMemcpyHostToDevice, ctx->stream);
+            if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)sl->d + tbase + b->tail_len, 0, 128, ctx->stream);
         }
     } else if (direct) {
         err = hipMemcpyAsync(ctx->arena.d, arena + lo, span, hipMemcpyHostToDevice, ctx->stream);
@@ -986,7 +1023,7 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     uint8_t* dout = (uint8_t*)ctx->out.d;
     fabgpu_identity_batch d = *b;
     d.flags = b->flags & FABGPU_IDB_SPANS;
-    d.arena = staged ? ctx->d_staged : ctx->arena.d;
+    d.arena = staged ? sl->d : ctx->arena.d;
     d.arena_bytes = staged ? round_up(tail_used ? (size_t)tbase + b->tail_len : span, 4) + 64 : ab;
     d.tail = nullptr;
     d.tail_base = d.tail_len = 0;

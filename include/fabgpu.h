@@ -188,7 +188,8 @@ typedef struct fabgpu_identity_batch {
 /* Uploads `len` bytes to a context-owned device buffer and returns when they are there; *token names the upload.  Meant to run on
  * a helper thread WHILE the caller still prepares the batch that refers to these bytes (the block pre-verify pass parses a
  * 50 MB block while it travels).  A later fabgpu_identity_verify_batch with FABGPU_IDB_ARENA_STAGED and this token uses the
- * staged bytes; if another upload replaced them meanwhile the call returns FABGPU_EINVAL and the caller resubmits unstaged. */
+ * staged bytes; if another upload replaced them meanwhile the call returns FABGPU_EINVAL and the caller resubmits unstaged.  A context
+ * keeps the three most recent uploads (channels validating at once), the least recent one that no batch is reading gives way. */
 int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token);
 int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch);
 int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batch* batch, void* mid_scratch, void* stream);

@@ -382,6 +382,48 @@ def test_concurrent_walks_share_the_worker_pool_or_fall_back():
     assert not errors and not any(t.is_alive() for t in th)
 
 
+@pytest.mark.gpu
+def test_concurrent_passes_on_one_provider():
+    """A peer with several channels validates their blocks at once through ONE BCCSP: three threads run the pass (with memo seeding and
+    eviction) over different blocks on the same provider, many times; every answer must be the block's own."""
+    import threading
+    csp = fabgpu.GPUCSP(device=0)
+    rng = np.random.default_rng(77)
+    blocks = [build_block(n, rng) for n in (90, 260, 1100)]            # the last one is big enough for the threaded walk and gates
+    solo = [fabgpu.preverify_block2(csp, blk, block_seq=10 + i) for i, (blk, _) in enumerate(blocks)]
+    for (blk, want), ref in zip(blocks, solo):
+        assert (ref["tx_flags"] == want).all()
+    errors = []
+
+    def work(i):
+        blk, want = blocks[i]
+        try:
+            for k in range(12):
+                seq = 1000 * (i + 1) + k
+                out = fabgpu.preverify_block2(csp, blk, block_seq=seq, seed_memo=True)
+                assert (out["tx_flags"] == want).all()
+                for f in ("tuple_status", "tuple_digest", "tuple_hashed", "tuple_tx"):
+                    assert (out[f] == solo[i][f]).all(), f
+                # one verdict of this block, looked up the way bccsp.Verify would
+                j = int(np.flatnonzero(out["tuple_hashed"])[k % int(out["tuple_hashed"].sum())])
+                sp = out["tuple_spans"][j]
+                sig = out["arena"][int(sp[6]):int(sp[6]) + int(sp[7])]
+                got = fabgpu.memo_lookup(csp, bytes(out["tuple_qxy"][j][:32]), bytes(out["tuple_qxy"][j][32:]), sig, bytes(out["tuple_digest"][j]))
+                assert got == int(out["tuple_status"][j]), (got, int(out["tuple_status"][j]))
+                fabgpu.memo_evict_block(csp, seq)
+        except Exception as e:                                        # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors[0]
+    assert not any(t.is_alive() for t in th)
+    csp.close()
+
+
 def test_walkers_survive_mutated_input():
     """The host-side parsers read untrusted network bytes: a few thousand mutants of a valid block and of a valid certificate must
     neither crash the process nor report a span outside the buffer.  (The thorough version runs under ASan/UBSan: tools/fuzz/run.sh.)"""

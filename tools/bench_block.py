@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--memo", action="store_true", help="fabgpu_csp_block_preverify2 with FABGPU_PASS_SEED_MEMO (digests back + memo seeding) and eviction per block")
     ap.add_argument("--idle-ms", type=float, default=0.0, help="sleep this long between blocks (a peer sees a block every few hundred ms: the GPU clocks down)")
+    ap.add_argument("--threads", type=int, default=1, help="callers validating blocks at once through the one provider (channels of a peer): aggregate rate")
     ap.add_argument("--tables", type=int, default=256, help="device comb tables the identity cache may build (6 signers: fewer than 6 leaves newcomers on the fresh-key path)")
     args = ap.parse_args()
     import numpy as np
@@ -75,6 +76,26 @@ def main():
             out = fabgpu.preverify_block(csp, blk)
             per.append(time.perf_counter() - t0)
     dt = statistics.median(per)
+    in_flight = None
+    if args.threads > 1:             # several channels: the walk of one block overlaps the gates + device call of another
+        import threading
+
+        def caller(t):
+            for k in range(args.steps):
+                if args.memo:
+                    fabgpu.preverify_block2(csp, blk, block_seq=10000 * (t + 1) + k, seed_memo=True, lean=True)
+                    fabgpu.memo_evict_block(csp, 10000 * (t + 1) + k)
+                else:
+                    fabgpu.preverify_block2(csp, blk, lean=True)
+        th = [threading.Thread(target=caller, args=(t,)) for t in range(args.threads)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        wall = time.perf_counter() - t0
+        in_flight = {"callers": args.threads, "blocks": args.threads * args.steps, "ms_per_block_aggregate": wall / (args.threads * args.steps) * 1e3,
+                     "validated_tx_per_s": args.tx * args.threads * args.steps / wall, "note": "memo eviction inside the timed loop" if args.memo else "flags only"}
     if args.memo:     # replay of the validators' bccsp.Verify lookups against a seeded block: all hits, timed
         out = fabgpu.preverify_block2(csp, blk, block_seq=7, seed_memo=True)
         nt = len(out["tuple_status"])
@@ -91,7 +112,7 @@ def main():
     data_hash_ms = (time.perf_counter() - t0) * 1e3
     print(json.dumps({"metric": "validated tx/sec per block (block-level pre-verify pass, marshalled block in, flags out)", "value": args.tx / dt,
                       "unit": "tx/s", "ms_per_block": dt * 1e3, "ms_min": min(per) * 1e3, "ms_max": max(per) * 1e3, "signatures_per_s": 4 * args.tx / dt,
-                      "tuples_through_key_tables": n_keyed,
+                      "tuples_through_key_tables": n_keyed, "callers_in_flight": in_flight,
                       "mode": ("preverify2 + memo seeding (eviction not timed)" if args.memo else "preverify (flags only)") + (", %.0f ms idle between blocks" % args.idle_ms if args.idle_ms else ", back to back"),
                       "memo_lookup_us_via_ctypes": (lookup_us if args.memo else None),
                       "host_block_data_hash_ms": data_hash_ms, "host_sha256_GB_per_s": len(b"".join(envs)) / data_hash_ms / 1e6,
