@@ -349,8 +349,17 @@ def test_identity_batch_with_shared_prefixes_vs_hashlib_and_oracle(ctx, keyed):
     bits6, st6, dig6 = ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True,
                                                  gather_spans=np.array(g, dtype=np.uint32), stage_token=tok, **kw2)
     assert (st6 == st4).all() and (bits6 == bits4).all() and [d.tobytes() for d in dig6] == want_g
+    # the context keeps its three most recent uploads (channels validating at once): one newer upload leaves the token good ...
     tok2 = ctx.arena_stage(arena[:100])
     assert tok2 != tok
+    bits7, st7, _ = ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True,
+                                              gather_spans=np.array(g, dtype=np.uint32), stage_token=tok, **kw2)
+    assert (st7 == st4).all() and (bits7 == bits4).all()
+    # ... and the short upload is refused for spans beyond its length; two more uploads push the first one out
+    with pytest.raises(fabgpu.FabgpuError):
+        ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True, stage_token=tok2, **kw2)
+    toks = {tok, tok2, ctx.arena_stage(arena[:200]), ctx.arena_stage(arena[:300])}
+    assert len(toks) == 4
     with pytest.raises(fabgpu.FabgpuError):
         ctx.identity_verify_batch(arena, spans, b["r"][perm], b["s"][perm], pre_off=pspans, pre_idx=pre_idx[perm], spans=True, stage_token=tok, **kw2)
 
