@@ -84,6 +84,53 @@ int fabgpu_csp_verify(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32,
     return FABGPU_OK;
 }
 
+int fabgpu_csp_verify_coalesced(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,
+                                const uint8_t* digest, size_t dlen, int* valid, int* flags, char* err, size_t errcap) {
+    if (!csp || !valid) return FABGPU_EINVAL;
+    ECDSAPublicKey k;
+    const ECDSAPublicKey* kp = nullptr;
+    if (qx32 && qy32) {
+        csp->csp->KeyImport(qx32, qy32, k);
+        kp = &k;
+    }
+    VerifyResult r = csp->csp->VerifyCoalesced(kp, sig, siglen, digest, dlen);
+    if (r.infrastructure) {
+        put_err(err, errcap, r.err.msg);
+        return FABGPU_ELAUNCH;
+    }
+    *valid = r.valid ? 1 : 0;
+    if (flags) *flags = r.needs_sw ? 1 : 0;
+    put_err(err, errcap, r.err.ok() ? "" : r.err.msg);
+    return FABGPU_OK;
+}
+
+int fabgpu_csp_identity_verify_coalesced(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* msg, size_t msglen,
+                                         const uint8_t* sig, size_t siglen, char* err, size_t errcap) {
+    if (!csp || (msglen && !msg)) return FABGPU_EINVAL;
+    ECDSAPublicKey k;
+    const ECDSAPublicKey* kp = nullptr;
+    if (qx32 && qy32) {
+        csp->csp->KeyImport(qx32, qy32, k);
+        kp = &k;
+    }
+    bool infra = false;
+    std::string out = csp->csp->IdentityVerifyCoalesced(kp, msg, msglen, sig, siglen, &infra);
+    put_err(err, errcap, out);
+    return infra ? FABGPU_ELAUNCH : FABGPU_OK;
+}
+
+int fabgpu_csp_coalescer_configure(fabgpu_csp* csp, uint32_t window_us, uint32_t max_batch) {
+    if (!csp) return FABGPU_EINVAL;
+    csp->csp->CoalescerConfigure(window_us, max_batch);
+    return FABGPU_OK;
+}
+
+int fabgpu_csp_coalescer_stats(fabgpu_csp* csp, uint64_t* calls, uint64_t* launches, uint64_t* largest_batch) {
+    if (!csp) return FABGPU_EINVAL;
+    csp->csp->CoalescerStats(calls, launches, largest_batch);
+    return FABGPU_OK;
+}
+
 int fabgpu_csp_verify_batch(fabgpu_csp* csp, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* sig_arena,
                             const uint32_t* sig_off, const uint8_t* dig_arena, const uint32_t* dig_off, uint8_t* valid,
                             char* errs, size_t errstride) {

@@ -414,6 +414,70 @@ Error GPUCSP::IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::v
 }
 
 // ------------------------------------------------------------------------------------------------
+// one-signature calls from many threads, sharing launches (coalescer.h)
+// ------------------------------------------------------------------------------------------------
+VerifyResult GPUCSP::VerifyCoalesced(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) const {
+    // the argument checks and the DER / low-S gates need no device: decided here, on the caller's thread, like Verify would
+    Gate g = gate_item(k, sig, siglen, digest, dlen);
+    if (!g.submit) return g.res;
+    CoReqV req;
+    req.item = {k, sig, siglen, digest, dlen};
+    co_verify_.submit(&req, [this](std::vector<CoReqV*>& batch) {
+        std::vector<VerifyItem> items(batch.size());
+        for (size_t i = 0; i < batch.size(); i++) items[i] = batch[i]->item;
+        std::vector<VerifyResult> res;
+        Error e = VerifyBatch(items, res);
+        for (size_t i = 0; i < batch.size(); i++) {
+            if (e.ok()) {
+                batch[i]->res = res[i];
+            } else {                                              // the device failed: an error for everybody, a verdict for nobody
+                batch[i]->res = VerifyResult();
+                batch[i]->res.err = e;
+                batch[i]->res.infrastructure = true;
+            }
+        }
+    });
+    return req.res;
+}
+
+std::string GPUCSP::IdentityVerifyCoalesced(const ECDSAPublicKey* k, const uint8_t* msg, size_t msglen, const uint8_t* sig, size_t siglen,
+                                            bool* infrastructure) const {
+    if (infrastructure) *infrastructure = false;
+    static const uint8_t one_digest[1] = {1};
+    Gate g = gate_item(k, sig, siglen, one_digest, 1);           // as in IdentityVerifyBatch: the digest is non-empty by construction
+    if (!g.submit) return g.res.err.ok() ? "The signature is invalid" : "could not determine the validity of the signature: " + g.res.err.msg;
+    CoReqI req;
+    req.item = {k, msg, msglen, sig, siglen};
+    req.infra = false;
+    co_identity_.submit(&req, [this](std::vector<CoReqI*>& batch) {
+        std::vector<IdentityItem> items(batch.size());
+        for (size_t i = 0; i < batch.size(); i++) items[i] = batch[i]->item;
+        std::vector<std::string> out;
+        Error e = IdentityVerifyBatch(items, out);
+        for (size_t i = 0; i < batch.size(); i++) {
+            batch[i]->infra = !e.ok();
+            batch[i]->out = e.ok() ? out[i] : e.msg;
+        }
+    });
+    if (infrastructure) *infrastructure = req.infra;
+    return req.out;
+}
+
+void GPUCSP::CoalescerConfigure(uint32_t window_us, uint32_t max_batch) const {
+    co_verify_.configure(window_us, max_batch);
+    co_identity_.configure(window_us, max_batch);
+}
+
+void GPUCSP::CoalescerStats(uint64_t* calls, uint64_t* launches, uint64_t* largest_batch) const {
+    uint64_t c[2], l[2], g[2];
+    co_verify_.stats(&c[0], &l[0], &g[0]);
+    co_identity_.stats(&c[1], &l[1], &g[1]);
+    if (calls) *calls = c[0] + c[1];
+    if (launches) *launches = l[0] + l[1];
+    if (largest_batch) *largest_batch = g[0] > g[1] ? g[0] : g[1];
+}
+
+// ------------------------------------------------------------------------------------------------
 // block-level pre-verify pass (block_prepass.h)
 // ------------------------------------------------------------------------------------------------
 void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len) const {

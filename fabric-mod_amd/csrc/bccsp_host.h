@@ -21,6 +21,7 @@
 
 #include "../../include/fabgpu.h"
 #include "block_prepass.h"
+#include "coalescer.h"
 
 namespace fab {
 namespace bccsp {
@@ -117,6 +118,14 @@ class GPUCSP {
     VerifyResult Verify(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) const;
     Error VerifyBatch(const std::vector<VerifyItem>& items, std::vector<VerifyResult>& results) const;
     Error IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::vector<std::string>& out) const;
+    // The same two one-signature verbs for callers that arrive MANY AT A TIME on their own threads (orderer Broadcast handlers behind
+    // SigFilter, validator goroutines on memo misses): blocking, same answers, calls in flight together share a launch (coalescer.h).
+    VerifyResult VerifyCoalesced(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) const;
+    // identity.Verify(msg, sig): "" (nil) or the error text; *infrastructure = true when the device failed (no verdict)
+    std::string IdentityVerifyCoalesced(const ECDSAPublicKey* k, const uint8_t* msg, size_t msglen, const uint8_t* sig, size_t siglen,
+                                        bool* infrastructure) const;
+    void CoalescerConfigure(uint32_t window_us, uint32_t max_batch) const;
+    void CoalescerStats(uint64_t* calls, uint64_t* launches, uint64_t* largest_batch) const;
     // Block-level pre-verify pass (block_prepass.h): one fused launch for every creator / endorsement signature of the block.
     Error PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out, const PassOptions& opt = PassOptions()) const;
     struct BlockUpload;
@@ -224,6 +233,17 @@ class GPUCSP {
         std::vector<uint32_t> pre_off, gsp;
         std::vector<uint64_t> bits;
     };
+    struct CoReqV : CoalescedBase {
+        VerifyItem item;
+        VerifyResult res;
+    };
+    struct CoReqI : CoalescedBase {
+        IdentityItem item;
+        std::string out;
+        bool infra = false;
+    };
+    mutable Coalescer<CoReqV> co_verify_;
+    mutable Coalescer<CoReqI> co_identity_;
     mutable std::mutex pass_mu_;                                      // guards scratch_free_
     mutable std::vector<std::unique_ptr<PassScratch>> scratch_free_;
 };

@@ -4,6 +4,8 @@
 // Nothing in the product path links or loads this file.
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -11,6 +13,7 @@
 #include "bn_tables29.h"
 #include "p256_tables29.h"
 #include "multi_plan.h"
+#include "coalescer.h"
 
 using namespace fab;
 
@@ -169,6 +172,47 @@ int hosttest_multi_verify(size_t n, uint32_t G, const uint32_t* off, const uint8
         memcpy(verdict_bits + p.word_at[g], merged[0].data() + (size_t)g * wpr, w * 8);
     }
     return 0;
+}
+
+// The coalescer of one-signature calls (coalescer.h) with a fake device: `threads` callers make `calls` calls each; a "launch" takes
+// launch_us and answers request x with 3 * x + 1.  Returns the number of wrong answers (0 expected); every caller must get its own.
+// Also reports how many launches served the calls and the largest batch - with callers arriving while a launch runs, far fewer
+// launches than calls.  fail_every > 0: every fail_every-th launch "fails" (answers -1 for the whole batch, as a device error would).
+int hosttest_coalescer(int threads, int calls, uint32_t launch_us, uint32_t window_us, uint32_t max_batch, int fail_every, uint64_t* launches,
+                       uint64_t* largest, uint64_t* failed_answers) {
+    struct Req : CoalescedBase {
+        int64_t x, y;
+    };
+    Coalescer<Req> co;
+    co.configure(window_us, max_batch);
+    std::atomic<int> wrong(0), failed(0), launch_no(0);
+    std::atomic<int> over(0);
+    auto runner = [&](std::vector<Req*>& batch) {
+        if (batch.size() > max_batch) over++;
+        const int k = ++launch_no;
+        if (launch_us) std::this_thread::sleep_for(std::chrono::microseconds(launch_us));
+        const bool fail = fail_every > 0 && k % fail_every == 0;
+        for (Req* q : batch) q->y = fail ? -1 : 3 * q->x + 1;
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            for (int c = 0; c < calls; c++) {
+                Req r;
+                r.x = (int64_t)t * 1000003 + c;
+                r.y = 0;
+                co.submit(&r, runner);
+                if (r.y == -1) failed++;
+                else if (r.y != 3 * r.x + 1) wrong++;
+            }
+        });
+    for (auto& t : th) t.join();
+    uint64_t c = 0;
+    co.stats(&c, launches, largest);
+    if (failed_answers) *failed_answers = (uint64_t)failed.load();
+    if (c != (uint64_t)threads * calls) return -1;
+    if (over.load()) return -2;
+    return wrong.load();
 }
 
 // op: 0 fp_mul 1 fp_sqr 2 fp_add 3 fp_sub 4 fp_to_mont 5 fp_from_mont 6 fn_mul 7 fn_sqr 8 fn_to_mont 9 fn_from_mont 10 fn_inv 11 fp_inv

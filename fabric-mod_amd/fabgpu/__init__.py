@@ -89,6 +89,7 @@ ABI_SYMBOLS = [
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
     "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_block_hash_checks",
     "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_evict_block",
+    "fabgpu_csp_verify_coalesced", "fabgpu_csp_identity_verify_coalesced", "fabgpu_csp_coalescer_configure", "fabgpu_csp_coalescer_stats",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
     "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",
     "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
@@ -154,6 +155,10 @@ def load():
     L.fabgpu_csp_verify.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz,
                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
     L.fabgpu_csp_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u32p, _u8p, _u32p, _u8p, ctypes.c_char_p, _sz]
+    L.fabgpu_csp_verify_coalesced.argtypes = L.fabgpu_csp_verify.argtypes
+    L.fabgpu_csp_identity_verify_coalesced.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz]
+    L.fabgpu_csp_coalescer_configure.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32]
+    L.fabgpu_csp_coalescer_stats.argtypes = [_vp, _u64p, _u64p, _u64p]
     L.fabgpu_csp_identity_verify_batch.argtypes = [_vp, _sz, _u8p, _u8p, _u8p, _u32p, _u8p, _u32p, ctypes.c_char_p, _sz]
     L.fabgpu_csp_block_preverify.argtypes = [_vp, _u8p, _sz, _u32p, _u8p, _u8p, ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_uint32]
     L.fabgpu_block_parse.argtypes = [_u8p, _sz, _u32p, _u32p, _u32p, _u8p, ctypes.c_uint32, ctypes.c_char_p, _sz]
@@ -595,6 +600,35 @@ class GPUCSP:
         if err.value:
             raise BCCSPError(err.value.decode())
         return bool(valid.value)
+
+    def verify_coalesced(self, k: Optional[ECDSAPublicKey], signature: bytes, digest: bytes) -> bool:
+        """CSP.Verify for callers arriving many at a time on their own threads (fabgpu_csp_verify_coalesced): blocking, same answers as
+        verify(); calls in flight together share a launch.  ctypes releases the GIL for the duration of the call."""
+        valid = ctypes.c_int(0)
+        flags = ctypes.c_int(0)
+        err = ctypes.create_string_buffer(1024)
+        qx, qy = (None, None) if k is None else k.xy_bytes()
+        _check(self._L.fabgpu_csp_verify_coalesced(self._h, qx, qy, signature, len(signature), digest, len(digest), ctypes.byref(valid),
+                                                   ctypes.byref(flags), err, 1024), "fabgpu_csp_verify_coalesced")
+        if err.value:
+            raise BCCSPError(err.value.decode())
+        return bool(valid.value)
+
+    def identity_verify_coalesced(self, k: Optional[ECDSAPublicKey], msg: bytes, signature: bytes) -> Optional[str]:
+        """identity.Verify(msg, sig) through the coalescer: None (nil) or the error text."""
+        err = ctypes.create_string_buffer(1024)
+        qx, qy = (None, None) if k is None else k.xy_bytes()
+        _check(self._L.fabgpu_csp_identity_verify_coalesced(self._h, qx, qy, msg, len(msg), signature, len(signature), err, 1024),
+               "fabgpu_csp_identity_verify_coalesced")
+        return err.value.decode() or None
+
+    def coalescer_configure(self, window_us: int = 50, max_batch: int = 32768) -> None:
+        _check(self._L.fabgpu_csp_coalescer_configure(self._h, window_us, max_batch), "fabgpu_csp_coalescer_configure")
+
+    def coalescer_stats(self):
+        v = [ctypes.c_uint64(0) for _ in range(3)]
+        _check(self._L.fabgpu_csp_coalescer_stats(self._h, *[ctypes.byref(x) for x in v]), "fabgpu_csp_coalescer_stats")
+        return dict(calls=v[0].value, launches=v[1].value, largest_batch=v[2].value)
 
     def verify_batch(self, keys: Sequence[ECDSAPublicKey], sigs: Sequence[bytes], digests: Sequence[bytes]):
         """n independent CSP.Verify calls in one launch: list of (valid, error-text-or-None)."""

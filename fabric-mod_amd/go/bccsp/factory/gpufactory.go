@@ -22,6 +22,10 @@ const (
 // GPUOpts is the `GPU:` section of the BCCSP configuration.
 type GPUOpts struct {
 	Device int `mapstructure:"device" json:"device" yaml:"Device"` // HIP device ordinal; -1 = the current device
+	// CoalesceVerify: Verify calls that miss the verdict memo share device launches with whatever other misses are in flight
+	// (fabgpu_csp_verify_coalesced).  For the orderer (General.BCCSP in orderer.yaml): its Broadcast handlers reach
+	// identity.Verify one message per goroutine behind SigFilter and no block pass precedes them.  Leave it off on peers.
+	CoalesceVerify bool `mapstructure:"coalesceverify" json:"coalesceverify" yaml:"CoalesceVerify"`
 }
 
 // GPUFactory is the factory of the GPU-accelerated BCCSP.
@@ -47,5 +51,14 @@ func (f *GPUFactory) Get(config *FactoryOpts) (bccsp.BCCSP, error) {
 	if config.GPUOpts != nil {
 		device = config.GPUOpts.Device
 	}
-	return gpu.New(swCSP, device)
+	csp, err := gpu.New(swCSP, device)
+	if err != nil {
+		return nil, err
+	}
+	if config.GPUOpts != nil && config.GPUOpts.CoalesceVerify {
+		if p, ok := csp.(*gpu.Provider); ok {
+			p.SetCoalesce(true)
+		}
+	}
+	return csp, nil
 }

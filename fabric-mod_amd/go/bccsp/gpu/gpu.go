@@ -74,7 +74,15 @@ type Provider struct {
 	bccsp.BCCSP // bccsp/sw: everything that is not overridden (pattern: bccsp/pkcs11/pkcs11.go:35-37)
 	csp         *C.fabgpu_csp
 	closeOnce   sync.Once
+	// coalesce: memo misses go to the device through fabgpu_csp_verify_coalesced instead of straight to bccsp/sw - for
+	// processes whose Verify calls arrive many at a time on their own goroutines and no block pass sees them first: the
+	// orderer (Broadcast handlers behind SigFilter, orderer/common/msgprocessor/sigfilter.go:50-80).  Off by default: a
+	// lone call costs a launch (0.7 ms) where bccsp/sw costs 0.1 ms; the break-even is about sixteen calls in flight.
+	coalesce bool
 }
+
+// SetCoalesce switches the coalesced device path for memo misses on or off (GPUOpts.CoalesceVerify in gpufactory.go).
+func (p *Provider) SetCoalesce(on bool) { p.coalesce = on }
 
 // BlockPreVerifier is what the validator wrapper needs from the default BCCSP.
 type BlockPreVerifier interface {
@@ -164,8 +172,9 @@ func swKey(k bccsp.Key) bccsp.Key {
 }
 
 // Verify: (true, nil) comes from the verdict memo; every other outcome - and every error text - from bccsp/sw
-// (bccsp/sw/impl.go:247-270, ecdsa.go:41-57).  There is deliberately no single-signature device call: one launch
-// costs more than one CPU verification.
+// (bccsp/sw/impl.go:247-270, ecdsa.go:41-57).  There is deliberately no single-signature device call of its own: one
+// launch costs more than one CPU verification.  With SetCoalesce(true) a miss joins whatever other misses are in flight
+// (fabgpu_csp_verify_coalesced): the orderer's case.
 func (p *Provider) Verify(k bccsp.Key, signature, digest []byte, opts bccsp.SignerOpts) (bool, error) {
 	gk, ok := k.(*gpuPublicKey)
 	if ok && gk != nil && len(signature) != 0 && len(digest) != 0 {
@@ -174,6 +183,18 @@ func (p *Provider) Verify(k bccsp.Key, signature, digest []byte, opts bccsp.Sign
 			(*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)),
 			(*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &st)
 		if hit == 0 && st == C.FABGPU_ST_VALID {
+			return true, nil
+		}
+	}
+	if ok && gk != nil && p.coalesce && len(signature) != 0 && len(digest) != 0 {
+		// calls in flight at the same moment share one launch; only "valid" is taken from the device - a reject, a key the
+		// device does not decide, or a device failure falls through to bccsp/sw for the reference's own answer and text
+		var valid, flags C.int
+		var errbuf [8]C.char
+		rc := C.fabgpu_csp_verify_coalesced(p.csp, (*C.uint8_t)(unsafe.Pointer(&gk.qx[0])), (*C.uint8_t)(unsafe.Pointer(&gk.qy[0])),
+			(*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)),
+			(*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &valid, &flags, &errbuf[0], C.size_t(len(errbuf)))
+		if rc == 0 && valid == 1 && errbuf[0] == 0 {
 			return true, nil
 		}
 	}

@@ -33,6 +33,20 @@ int fabgpu_csp_hash(fabgpu_csp* csp, const uint8_t* msg, size_t len, const char*
 int fabgpu_csp_verify(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,
                       const uint8_t* digest, size_t dlen, int* valid, int* flags, char* err, size_t errcap);
 
+/* The two one-signature verbs for callers that arrive MANY AT A TIME, each on its own thread: the orderer's Broadcast handlers behind
+ * SigFilter (orderer/common/msgprocessor/sigfilter.go:50-80 -> identity.Verify, msp/identities.go:169-196; one goroutine per client
+ * stream), the validator pool's bccsp.Verify calls that miss the verdict memo (core/committer/txvalidator/v20/validator.go:198-208).
+ * Blocking, same answers and error texts as fabgpu_csp_verify / fabgpu_csp_identity_verify_batch; calls that are in flight at the same
+ * moment share ONE launch (a caller that finds the device busy queues behind the running launch and travels with the next; a caller
+ * that finds it idle waits window_us - default 50 - for company).  A device failure is FABGPU_ELAUNCH for every caller of that launch,
+ * never a verdict.  err == "" means nil. */
+int fabgpu_csp_verify_coalesced(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,
+                                const uint8_t* digest, size_t dlen, int* valid, int* flags, char* err, size_t errcap);
+int fabgpu_csp_identity_verify_coalesced(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* msg, size_t msglen,
+                                         const uint8_t* sig, size_t siglen, char* err, size_t errcap);
+int fabgpu_csp_coalescer_configure(fabgpu_csp* csp, uint32_t window_us, uint32_t max_batch);
+int fabgpu_csp_coalescer_stats(fabgpu_csp* csp, uint64_t* calls, uint64_t* launches, uint64_t* largest_batch);
+
 /* n keys (n x 32), ragged signatures and digests; valid: n bytes; errs: n * errstride chars (NUL terminated, truncated). */
 int fabgpu_csp_verify_batch(fabgpu_csp* csp, size_t n, const uint8_t* qx, const uint8_t* qy, const uint8_t* sig_arena,
                             const uint32_t* sig_off, const uint8_t* dig_arena, const uint32_t* dig_off, uint8_t* valid,

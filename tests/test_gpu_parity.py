@@ -505,6 +505,79 @@ def test_csp_verify_equals_oracle_csp_verify_on_der_and_digest_shapes(csp):
                 assert ge == we
 
 
+def test_coalesced_one_signature_calls_from_many_threads(csp):
+    """bccsp.Verify / identity.Verify one signature at a time from 48 threads (orderer Broadcast handlers, validator goroutines):
+    fabgpu_csp_verify_coalesced / fabgpu_csp_identity_verify_coalesced give every caller the answer - and the error text - of the
+    batch entry points, which the tests above hold against the restated bccsp/sw; calls in flight together share launches."""
+    import threading
+    _, pk0 = _keypair(5)
+    keys, sigs, digs = [], [], []
+    for v in _load("der_kats.json"):
+        keys.append(pk0); sigs.append(bytes.fromhex(v["der"])); digs.append(b"\x01" * 32)
+    for v in _load("edge_kats.json"):
+        if po.on_curve(int(v["qx"], 16), int(v["qy"], 16)):
+            keys.append(fabgpu.ECDSAPublicKey(int(v["qx"], 16), int(v["qy"], 16)))
+            sigs.append(po.marshal_ecdsa_signature(int(v["r"], 16), int(v["s"], 16))); digs.append(bytes.fromhex(v["e"]))
+    rng = np.random.default_rng(21)
+    for t in range(400):                                   # fresh signatures, a third of them tampered
+        d, pk = _keypair(100 + t % 7)
+        dg = bytes(rng.integers(0, 256, size=32, dtype=np.uint8))
+        r, s_ = po.sign_raw(d, dg, int(rng.integers(1, 1 << 62)))
+        if t % 3 == 0:
+            dg = bytes([dg[0] ^ 1]) + dg[1:]
+        keys.append(pk); sigs.append(po.marshal_ecdsa_signature(r, s_)); digs.append(dg)
+    want = csp.verify_batch(keys, sigs, digs)
+    n = len(keys)
+    before = csp.coalescer_stats()
+    got = [None] * n
+    errors = []
+
+    def worker(w, nw):
+        try:
+            for i in range(w, n, nw):
+                try:
+                    got[i] = (csp.verify_coalesced(keys[i], sigs[i], digs[i]), None)
+                except fabgpu.BCCSPError as e:
+                    got[i] = (False, str(e))
+        except Exception:                                  # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+    th = [threading.Thread(target=worker, args=(w, 48)) for w in range(48)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors[0]
+    assert got == [(v, e) for v, e in want]
+    after = csp.coalescer_stats()
+    calls, launches = after["calls"] - before["calls"], after["launches"] - before["launches"]
+    assert 0 < launches < calls / 3 and after["largest_batch"] >= 4, (calls, launches, after)
+    # identity.Verify (hash fused on the device), messages of ragged lengths
+    d, pk = _keypair(6)
+    msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 3000)), dtype=np.uint8)) for _ in range(300)]
+    isigs = [po.marshal_ecdsa_signature(*po.sign_raw(d, hashlib.sha256(m).digest(), 1000 + j)) for j, m in enumerate(msgs)]
+    for j in range(0, 300, 4):
+        msgs[j] = msgs[j] + b"!"
+    iwant = csp.identity_verify_batch([pk] * 300, msgs, isigs)
+    igot = [None] * 300
+
+    def iworker(w, nw):
+        try:
+            for i in range(w, 300, nw):
+                igot[i] = csp.identity_verify_coalesced(pk, msgs[i], isigs[i])
+        except Exception:                                  # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+    th = [threading.Thread(target=iworker, args=(w, 32)) for w in range(32)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors[0]
+    assert igot == list(iwant) and sum(1 for e in igot if e is None) == 225
+    assert csp.identity_verify_coalesced(None, b"m", isigs[0]) == "could not determine the validity of the signature: Invalid Key. It must not be nil."
+
+
 def test_fullflow_every_single_byte_mutation_flips_the_verdict(csp):
     # core/common/validation/fullflow_test.go:240-250: for i := range payload { payload[i]++ ... must fail }
     d, pk = _keypair(6)

@@ -317,3 +317,25 @@ def test_synth_generator_is_checked_by_independent_implementations():
     e_in = np.random.default_rng(1).integers(0, 256, (50, 32), dtype=np.uint8)
     c = fabgpu.synth_batch(50, seed=7, e_in=e_in)
     assert (c["e"] == e_in).all() and (coracle.verify_batch(c["qx"], c["qy"], c["e"], c["r"], c["s"]) == 0).all()
+
+
+def test_coalescer_of_one_signature_calls(hosttest):
+    """coalescer.h with a fake device: every caller gets ITS answer, calls that are in flight together share launches, a batch never
+    exceeds max_batch, and a failed launch is a failure for exactly the callers it carried."""
+    import ctypes
+    f = hosttest.hosttest_coalescer
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int] + [ctypes.POINTER(ctypes.c_uint64)] * 3
+    f.restype = ctypes.c_int
+    launches, largest, failed = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    # 24 callers x 40 calls, a launch takes 300 us: callers pile up behind the running launch
+    assert f(24, 40, 300, 50, 32768, 0, ctypes.byref(launches), ctypes.byref(largest), ctypes.byref(failed)) == 0
+    assert launches.value < 24 * 40 / 4 and largest.value >= 8 and failed.value == 0
+    # one caller alone: one launch per call (the window only delays it)
+    assert f(1, 20, 0, 20, 32768, 0, ctypes.byref(launches), ctypes.byref(largest), ctypes.byref(failed)) == 0
+    assert launches.value == 20 and largest.value == 1
+    # max_batch 4: no launch carries more
+    assert f(16, 25, 200, 0, 4, 0, ctypes.byref(launches), ctypes.byref(largest), ctypes.byref(failed)) == 0
+    assert largest.value <= 4 and launches.value >= 16 * 25 / 4
+    # every third launch fails: its callers see the failure, nobody sees a wrong answer
+    assert f(12, 30, 100, 0, 32768, 3, ctypes.byref(launches), ctypes.byref(largest), ctypes.byref(failed)) == 0
+    assert 0 < failed.value < 12 * 30
