@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <exception>
 #include <functional>
 #include <thread>
 
@@ -423,10 +424,15 @@ VerifyResult GPUCSP::VerifyCoalesced(const ECDSAPublicKey* k, const uint8_t* sig
     CoReqV req;
     req.item = {k, sig, siglen, digest, dlen};
     co_verify_.submit(&req, [this](std::vector<CoReqV*>& batch) {
-        std::vector<VerifyItem> items(batch.size());
-        for (size_t i = 0; i < batch.size(); i++) items[i] = batch[i]->item;
         std::vector<VerifyResult> res;
-        Error e = VerifyBatch(items, res);
+        Error e;
+        try {                                                     // a runner must not throw: followers would sleep forever
+            std::vector<VerifyItem> items(batch.size());
+            for (size_t i = 0; i < batch.size(); i++) items[i] = batch[i]->item;
+            e = VerifyBatch(items, res);
+        } catch (const std::exception& x) {
+            e = Error(std::string("GPU verify failed: ") + x.what());
+        }
         for (size_t i = 0; i < batch.size(); i++) {
             if (e.ok()) {
                 batch[i]->res = res[i];
@@ -450,10 +456,15 @@ std::string GPUCSP::IdentityVerifyCoalesced(const ECDSAPublicKey* k, const uint8
     req.item = {k, msg, msglen, sig, siglen};
     req.infra = false;
     co_identity_.submit(&req, [this](std::vector<CoReqI*>& batch) {
-        std::vector<IdentityItem> items(batch.size());
-        for (size_t i = 0; i < batch.size(); i++) items[i] = batch[i]->item;
         std::vector<std::string> out;
-        Error e = IdentityVerifyBatch(items, out);
+        Error e;
+        try {
+            std::vector<IdentityItem> items(batch.size());
+            for (size_t i = 0; i < batch.size(); i++) items[i] = batch[i]->item;
+            e = IdentityVerifyBatch(items, out);
+        } catch (const std::exception& x) {
+            e = Error(std::string("GPU verify failed: ") + x.what());
+        }
         for (size_t i = 0; i < batch.size(); i++) {
             batch[i]->infra = !e.ok();
             batch[i]->out = e.ok() ? out[i] : e.msg;
