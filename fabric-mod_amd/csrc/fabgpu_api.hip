@@ -48,6 +48,7 @@ struct Buf {  // growable pinned-host + device pair
 struct fabgpu_ctx {
     int device = 0;
     bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
+    bool allow_quad = true;   // !FABGPU_FLAG_NO_QUAD (idemix: four lanes per signature for batches <= IDEMIX_QUAD_MAX)
     hipStream_t stream = nullptr;
     // FABGPU_FAULT_INJECT (tests of the failure contract only): "launch" makes every kernel submission report hipErrorLaunchFailure,
     // "oom" makes every workspace / staging allocation fail.  A non-zero return must then reach the caller and no verdict may be written.
@@ -208,7 +209,7 @@ int fabgpu_device_count(fabgpu_ctx*) {
 int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!out) return FABGPU_EINVAL;
     *out = nullptr;
-    if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS)) != 0) return FABGPU_EINVAL;
+    if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS | FABGPU_FLAG_NO_QUAD)) != 0) return FABGPU_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
     int dev = cfg ? cfg->device : -1;
@@ -223,6 +224,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!ctx) return FABGPU_ENOMEM;
     ctx->device = dev;
     ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
+    ctx->allow_quad = !(cfg && (cfg->flags & FABGPU_FLAG_NO_QUAD));
     ctx->time_kernels = cfg && (cfg->flags & FABGPU_FLAG_TIME_KERNELS);
     DeviceGuard g(dev);
     int rc = FABGPU_OK;
@@ -440,11 +442,11 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
     hipStream_t st = (hipStream_t)stream;
     size_t wi = 0;
     void* wsp = nullptr;
-    int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp, st);
+    int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair, ctx->allow_quad), &wi, &wsp, st);
     if (rc != FABGPU_OK) return rc;
     if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
-                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, st);
+                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, ctx->allow_quad, st);
     if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = ctx->time_kernels;

@@ -278,9 +278,9 @@ ALIGN_NOTE = """// Every instruction below is 8 bytes (VOP3, VOP2 + DPP, or VOP2
 def emit(path_kind):
     progs = {"field": FIELD_PROGRAMS, "bnfield": BN_FIELD_PROGRAMS, "bnpair": BN_PAIR_PROGRAMS}.get(path_kind, PROGRAMS)
     if path_kind == "bnpair":
-        print("// GENERATED by gen_pair_gcn.py bnpair - do not edit.  Two-lanes-per-point operations on FP256BN's G1 (a = 0): PREPARED for a")
-        print("// four-lanes-per-signature idemix kernel (DESIGN.md section 8, next steps); verified in the DSL interpreter against big integers")
-        print("// (tests/test_pair_programs.py), NOT yet included by any kernel.")
+        print("// GENERATED by gen_pair_gcn.py bnpair - do not edit.  Two-lanes-per-point operations on FP256BN's G1 (a = 0): the point")
+        print("// operations of the four-lanes-per-signature idemix kernel (bn_quad29.h); verified in the DSL interpreter against big integers")
+        print("// (tests/test_pair_programs.py) and register for register on the MI355X (gputest.hip ops 4-6).")
         print("#pragma once")
         print('#include "fe29_gcn.h"   // FE29_GCN_ALIGN')
         print()

@@ -7,9 +7,10 @@
 #include <vector>
 
 #include "p256_pair29.h"
-#include "pair29_bn_gcn.h"   // prepared BN pair programs: validated here register for register, not yet used by a kernel
+#include "pair29_bn_gcn.h"   // the BN pair programs of bn_quad29.h: validated here register for register
 #include "p256_tables29.h"
 #include "bn_nym29.h"
+#include "bn_quad29.h"
 #include "bn_tables29.h"
 #include "device_common.h"
 
@@ -197,7 +198,7 @@ extern "C" int gputest_pair_verify(const uint8_t* in, int32_t* out) {
 
 // The commitment t of the pseudonym-signature equation as the DEVICE computes it (bn_nym29.h), exposed on its own so that tests can
 // compare it with vectors made by an independent implementation (tests/golden/idemix_nym_kats.json): one wave, up to 64 signatures
-// with one lane each (split == 0) or 32 with two lanes each (split == 1).  in: n x 5 big-endian fields (nym_x, nym_y, c, s_sk, s_rnym);
+// with one lane each (split == 0), 32 with two lanes each (split == 1) or 16 with four lanes each (split == 2).  in: n x 5 big-endian fields (nym_x, nym_y, c, s_sk, s_rnym);
 // out: n x (tx[32] ty[32]) big-endian, st: n status words.
 __global__ void __launch_bounds__(64, 1) gputest_nym_commitment_kernel(int split, uint32_t n, const uint8_t* __restrict__ in, const int32_t* __restrict__ hskt,
                                                                         const int32_t* __restrict__ hrandt, uint4* __restrict__ qws, uint8_t* __restrict__ out,
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(64, 1) gputest_nym_commitment_kernel(int split
     GlobalQTab29<64> qtab = GlobalQTab29<64>::of(qws, threadIdx.x);
     KeyTab8 hsk{hskt}, hrand{hrandt};
     const bool odd = (threadIdx.x & 1u) != 0;
-    uint32_t i = split ? threadIdx.x >> 1 : threadIdx.x;
+    uint32_t i = split == 2 ? threadIdx.x >> 2 : (split ? threadIdx.x >> 1 : threadIdx.x);
     bool active = i < n;
     uint32_t ic = active ? i : n - 1;
     u256 nx, ny, c, ssk, srn, tx, ty;
@@ -215,6 +216,18 @@ __global__ void __launch_bounds__(64, 1) gputest_nym_commitment_kernel(int split
     from_be32(ssk, in + 160 * ic + 96);
     from_be32(srn, in + 160 * ic + 128);
     uint32_t st;
+    if (split == 2) {            // four lanes per signature (bn_quad29.h): 16 signatures on the wave, lane 4k reports
+        PairBNQTab pq = PairBNQTab::of(qws, threadIdx.x >> 1);
+        bn_nym_quad_half mine;
+        bn_nym_quad_part1(mine, odd, (threadIdx.x & 2u) != 0, nx, ny, c, ssk, srn, hskt, hrandt, pq);
+        st = bn_nym_quad_part2(tx, ty, mine, odd);
+        if (active && (threadIdx.x & 3u) == 0) {
+            to_be32(out + 64 * i, tx);
+            to_be32(out + 64 * i + 32, ty);
+            st_out[i] = st;
+        }
+        return;
+    }
     if (!split) {
         st = bn_nym_commitment29(tx, ty, nx, ny, c, ssk, srn, hsk, hrand, qtab);
     } else {
@@ -237,7 +250,7 @@ __global__ void __launch_bounds__(64, 1) gputest_nym_commitment_kernel(int split
 }
 
 extern "C" int gputest_nym_commitment(int split, uint32_t n, const uint8_t* hsk_xy64, const uint8_t* hrand_xy64, const uint8_t* in, uint8_t* out, uint32_t* st) {
-    if (n == 0 || n > (split ? 32u : 64u)) return -3;
+    if (n == 0 || n > (split == 2 ? 16u : (split ? 32u : 64u))) return -3;
     std::vector<int32_t> t1(KeyTab8::TABLE_WORDS), t2(KeyTab8::TABLE_WORDS);
     u256 x, y;
     from_be32(x, hsk_xy64); from_be32(y, hsk_xy64 + 32);

@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "bn_nym29.h"
+#include "bn_quad29.h"
 #include "device_common.h"
 #include "kernels.h"
 
@@ -189,6 +190,61 @@ __global__ void __launch_bounds__(BLOCK, 2)
     }
 }
 
+// Four lanes per signature (bn_quad29.h): 64 signatures per 256-thread workgroup = one verdict word per tile, for the batches the
+// idemix creators of one block make (a few thousand).  Lanes 4k .. 4k+3 of a wave own signature k: pair 0 computes
+// HSk s_sk - k1 Nym, pair 1 HRand s_rnym - k2 phi(Nym), every point operation on two lanes; lane 4k hashes and reports.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2)
+    idemix_nym_verify_quad_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
+                                  const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
+                                  const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
+                                  const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
+                                  uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+    // one table per PAIR: BLOCK / 2 of them in this workgroup's slot
+    PairBNQTab qtab = PairBNQTab::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * (BLOCK / 2)), threadIdx.x >> 1);
+    constexpr uint32_t PER_WG = BLOCK / 4;
+    const uint32_t ntiles = (n + PER_WG - 1) / PER_WG;
+    const uint32_t nwords = (n + 63) / 64;
+    const bool odd = (threadIdx.x & 1u) != 0;
+    const bool half = (threadIdx.x & 2u) != 0;
+    uint16_t* verdict16 = reinterpret_cast<uint16_t*>(verdict_bits);
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * PER_WG + (threadIdx.x >> 2);
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        uint32_t iss = issuer_id != nullptr ? issuer_id[ic] : 0u;
+        bool iss_ok = iss < n_issuers;
+        const IssuerDev* id = issuers + (iss_ok ? iss : 0u);
+        u256 nx, ny, c, ssk, srn, nn, tx, ty;
+        load_be_field(nx, nym_x, ic);
+        load_be_field(ny, nym_y, ic);
+        load_be_field(c, proof_c, ic);
+        load_be_field(ssk, s_sk, ic);
+        load_be_field(srn, s_rnym, ic);
+        load_be_field(nn, nonce, ic);
+        bn_nym_quad_half mine;
+        bn_nym_quad_part1(mine, odd, half, nx, ny, c, ssk, srn, id->hsk, id->hrand, qtab);
+        uint32_t st = bn_nym_quad_part2(tx, ty, mine, odd);
+        uint32_t ih[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) ih[k] = id->hash[k];
+        uint32_t start = off[ic], len = off[ic + 1] - start;
+        bool match = nym_challenge_matches(arena32, arena_words, start, len, active, tx, ty, nx, ny, ih, nn, c);
+        if (st == NYM_VALID) st = match ? NYM_VALID : NYM_BAD_PROOF;
+        if (!iss_ok) st = NYM_NEEDS_SW;
+        // 16 verdicts per wave sit on lanes 0, 4, 8, ...: squeeze every fourth bit of the ballot into 16 bits
+        const bool lead = (threadIdx.x & 3u) == 0;
+        uint64_t x = __ballot(active && lead && st == 0u) & 0x1111111111111111ull;
+        x = (x | (x >> 3)) & 0x0303030303030303ull;
+        x = (x | (x >> 6)) & 0x000f000f000f000full;
+        x = (x | (x >> 12)) & 0x000000ff000000ffull;
+        x = (x | (x >> 24)) & 0x000000000000ffffull;
+        const uint32_t i0 = tile * PER_WG + ((threadIdx.x & ~63u) >> 2);       // first signature of this wave: a multiple of 16
+        if ((threadIdx.x & 63u) == 0 && (i0 >> 6) < nwords) verdict16[i0 >> 4] = (uint16_t)x;   // every 16-bit part of every word has an owner
+        if (status != nullptr && active && lead) status[i] = (uint8_t)st;
+    }
+}
+
 size_t idemix_issuer_dev_bytes() { return sizeof(IssuerDev); }
 void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hrand, const uint8_t hash32[32]) {
     IssuerDev* s = (IssuerDev*)host_slot;
@@ -198,7 +254,13 @@ void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hr
         s->hash[k] = ((uint32_t)hash32[4 * k] << 24) | ((uint32_t)hash32[4 * k + 1] << 16) | ((uint32_t)hash32[4 * k + 2] << 8) | hash32[4 * k + 3];
 }
 
-size_t idemix_workspace_bytes(uint32_t n, bool allow_split) {
+static bool idemix_quad(uint32_t n, bool allow_split, bool allow_quad) { return allow_split && allow_quad && n <= (uint32_t)IDEMIX_QUAD_MAX; }
+static uint32_t idemix_quad_wgs(uint32_t n) {
+    const uint32_t tiles = (n + VERIFY_BLOCK / 4 - 1) / (VERIFY_BLOCK / 4);
+    return tiles < (uint32_t)VERIFY_MAX_WGS ? tiles : (uint32_t)VERIFY_MAX_WGS;
+}
+size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad) {
+    if (idemix_quad(n, allow_split, allow_quad)) return (size_t)idemix_quad_wgs(n) * (VERIFY_BLOCK / 2) * QWS_UINT4_PER_LANE * 16;
     VerifyGeom g = verify_geom(n, allow_split);
     return (size_t)g.wgs * g.block * QWS_UINT4_PER_LANE * 16;
 }
@@ -206,8 +268,16 @@ size_t idemix_workspace_bytes(uint32_t n, bool allow_split) {
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
-                                    hipStream_t st) {
+                                    bool allow_quad, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    if (idemix_quad(n, allow_split, allow_quad)) {                             // four lanes per signature: 64 signatures per workgroup
+        dim3 qgrid(idemix_quad_wgs(n)), qblock(VERIFY_BLOCK);
+        hipLaunchKernelGGL(idemix_nym_verify_quad_kernel<VERIFY_BLOCK>, qgrid, qblock, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                           (const uint32_t*)off, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
+                           (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
+                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+        return hipGetLastError();
+    }
     VerifyGeom g = verify_geom(n, allow_split);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair) {

@@ -49,10 +49,13 @@ hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t
 // with idemix_issuer_dev_fill (device pointers of the two comb tables + ipk.Hash) and copy it up.
 size_t idemix_issuer_dev_bytes();
 void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hrand, const uint8_t hash32[32]);
-// one signature per lane, or (allow_split and n <= VERIFY_PAIR_MAX) two lanes per signature; workspace: idemix_workspace_bytes
+// one signature per lane; (allow_split and n <= VERIFY_PAIR_MAX) two lanes per signature; (allow_split, allow_quad and
+// n <= IDEMIX_QUAD_MAX) four lanes per signature, every point operation on a lane pair; workspace: idemix_workspace_bytes
+constexpr int IDEMIX_QUAD_MAX = 16384;     // 256 workgroups x 64 signatures: one round of the chip
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
-                                    hipStream_t st);
-size_t idemix_workspace_bytes(uint32_t n, bool allow_split);   // every LANE owns a 16-entry table, in both geometries
+                                    bool allow_quad, hipStream_t st);
+// every LANE owns a 16-entry table in the one- and two-lane geometries, every lane PAIR in the four-lane one
+size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad);
 }  // namespace fab

@@ -27,6 +27,7 @@ _LIB_PATH = os.environ.get("FABGPU_LIB_PATH") or os.path.join(os.path.dirname(_H
 FABGPU_OK = 0
 FLAG_ONE_LANE_ONLY = 1   # fabgpu.h FABGPU_FLAG_ONE_LANE_ONLY
 FLAG_TIME_KERNELS = 2    # fabgpu.h FABGPU_FLAG_TIME_KERNELS
+FLAG_NO_QUAD = 4         # fabgpu.h FABGPU_FLAG_NO_QUAD (idemix: never the four-lanes-per-signature kernel)
 ST_VALID, ST_BAD_MATH, ST_HIGH_S, ST_RANGE, ST_OFF_CURVE = 0, 1, 2, 3, 4
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)

@@ -64,6 +64,7 @@ typedef struct fabgpu_ctx fabgpu_ctx;
 
 /* fabgpu_cfg.flags */
 #define FABGPU_FLAG_ONE_LANE_ONLY 1u /* never use the two-lanes-per-signature kernel (parity tests run both variants) */
+#define FABGPU_FLAG_NO_QUAD 4u       /* idemix: never use the four-lanes-per-signature kernel (parity tests run all three variants) */
 #define FABGPU_FLAG_TIME_KERNELS 2u  /* bracket every launch with timing events so that fabgpu_last_kernel_ms answers (tools only) */
 
 typedef struct fabgpu_cfg {

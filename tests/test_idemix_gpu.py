@@ -12,12 +12,13 @@ from idemix_common import be32, fixtures, make_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "one-lane"])
+@pytest.fixture(scope="module", params=["auto", "two-lanes", "one-lane"])
 def env(request):
-    """auto: batches up to 32 768 run on the two-lanes-per-signature kernel, larger ones on the one-lane kernel;
-    one-lane = FABGPU_FLAG_ONE_LANE_ONLY, so that every case also goes through the one-lane kernel."""
+    """auto: batches up to 16 384 run on the four-lanes-per-signature kernel (bn_quad29.h), up to 32 768 on the two-lanes one, larger
+    ones on the one-lane kernel; two-lanes = FABGPU_FLAG_NO_QUAD, one-lane = FABGPU_FLAG_ONE_LANE_ONLY: every case goes through all three."""
     fx = fixtures()
-    ctx = fabgpu.Context(device=0, flags=fabgpu.FLAG_TIME_KERNELS | (fabgpu.FLAG_ONE_LANE_ONLY if request.param == "one-lane" else 0))
+    extra = {"auto": 0, "two-lanes": fabgpu.FLAG_NO_QUAD, "one-lane": fabgpu.FLAG_ONE_LANE_ONLY}[request.param]
+    ctx = fabgpu.Context(device=0, flags=fabgpu.FLAG_TIME_KERNELS | extra)
     issuers = []
     for name in ("MSP1OU1", "MSP2OU1"):
         ipk = fx[name]["ipk"]
@@ -85,11 +86,11 @@ def test_every_message_length_class(env):
 
 
 def test_block_sized_batch_by_replication(env):
-    """30 000 (a block), the two-lane limit 32 768 and its neighbours, and a batch of several rounds"""
+    """the four-lane limit 16 384 and its neighbours, 30 000 (a block), the two-lane limit 32 768 and its neighbours, several rounds"""
     ctx, issuers = env
     base = make_batch(issuers, 300, 17)
     arena, off, iid, cols, expect = base.arrays()
-    for n in (30000, 32767, 32768, 32769, 70000):
+    for n in (5000, 16383, 16384, 16385, 30000, 32767, 32768, 32769, 70000):
         rng = np.random.default_rng(n)
         pick = rng.integers(0, 300, size=n)
         lens = (off[1:] - off[:-1])[pick]

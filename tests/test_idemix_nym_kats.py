@@ -90,13 +90,17 @@ def test_device_commitment_and_verdicts_on_the_independent_vectors():
             vs = [v for v in KATS if v["msp"] == name]
             n = len(vs)
             rows = b"".join(bytes.fromhex(v["nym_x"] + v["nym_y"] + v["proof_c"] + v["proof_s_sk"] + v["proof_s_r_nym"]) for v in vs)
-            for split in (0, 1):                                   # the device's own t, one lane and two lanes per signature
-                out = ctypes.create_string_buffer(64 * n)
-                st = (ctypes.c_uint32 * n)()
-                rc = G.gputest_nym_commitment(split, n, be32(ipk.h_sk[0]) + be32(ipk.h_sk[1]), be32(ipk.h_rand[0]) + be32(ipk.h_rand[1]), rows, out, st)
-                assert rc == 0 and list(st) == [0] * n
-                for i, v in enumerate(vs):
-                    assert out.raw[64 * i:64 * i + 32].hex() == v["t_x"] and out.raw[64 * i + 32:64 * i + 64].hex() == v["t_y"], (name, split, i)
+            for split in (0, 1, 2):                                # the device's own t: one, two and four lanes per signature
+                cap = {0: 64, 1: 32, 2: 16}[split]
+                for lo in range(0, n, cap):
+                    m = min(cap, n - lo)
+                    out = ctypes.create_string_buffer(64 * m)
+                    st = (ctypes.c_uint32 * m)()
+                    rc = G.gputest_nym_commitment(split, m, be32(ipk.h_sk[0]) + be32(ipk.h_sk[1]), be32(ipk.h_rand[0]) + be32(ipk.h_rand[1]),
+                                                  rows[160 * lo:160 * (lo + m)], out, st)
+                    assert rc == 0 and list(st) == [0] * m, (name, split, lo, list(st))
+                    for i, v in enumerate(vs[lo:lo + m]):
+                        assert out.raw[64 * i:64 * i + 32].hex() == v["t_x"] and out.raw[64 * i + 32:64 * i + 64].hex() == v["t_y"], (name, split, lo + i)
             # the product entry point: accepts every vector, rejects every tampered twin
             iid = ctx.idemix_issuer_register((be32(ipk.h_sk[0]), be32(ipk.h_sk[1])), (be32(ipk.h_rand[0]), be32(ipk.h_rand[1])), ipk.hash)
             msgs = [bytes.fromhex(v["msg"]) for v in vs] + [bytes.fromhex(v["msg"]) + b"\x01" for v in vs]

@@ -175,8 +175,8 @@ def test_pair_scalar_multiplication_chain(progs):
 
 
 def test_bn_pair_programs_scalar_multiplication_chain():
-    """PAIRBN_DBL / PAIRBN_ADD / PAIRBN_MADD (pair29_bn_gcn.h: prepared for a four-lanes-per-signature idemix kernel, not yet wired
-    into one): left-to-right double-and-add on FP256BN's G1 in the interpreter, against big-integer point arithmetic after
+    """PAIRBN_DBL / PAIRBN_ADD / PAIRBN_MADD (pair29_bn_gcn.h: the point operations of the four-lanes-per-signature idemix kernel,
+    bn_quad29.h): left-to-right double-and-add on FP256BN's G1 in the interpreter, against big-integer point arithmetic after
     every step, on a fixture base point of the reference."""
     import gen_bn_consts as bc
     import idemix_oracle as io
@@ -305,7 +305,7 @@ def test_generated_streams_on_gpu_match_the_interpreter_register_for_register(pr
 
 @pytest.mark.gpu
 def test_bn_pair_streams_on_gpu_match_the_interpreter_register_for_register():
-    """PAIRBN_DBL / ADD / MADD (prepared, not yet used by a kernel): one wavefront runs each generated asm statement, every output
+    """PAIRBN_DBL / ADD / MADD (the point operations of bn_quad29.h): one wavefront runs each generated asm statement, every output
     limb of every lane must equal the interpreter's."""
     import ctypes
 
