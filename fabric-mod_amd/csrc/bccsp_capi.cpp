@@ -189,8 +189,8 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        fprintf(stderr, "fabgpu pass: walk %.2f ms, gates + submission + flags %.2f ms (gates %.2f, wait for upload %.2f, device call %.2f)\n", ms(t0, t1),
-                ms(t1, t2), v.ms_gates, v.ms_upload_wait, v.ms_device);
+        fprintf(stderr, "fabgpu pass: walk %.2f ms, gates + submission + flags %.2f ms (gates %.2f, wait for upload %.2f, device call %.2f, idemix creators %.2f)\n", ms(t0, t1),
+                ms(t1, t2), v.ms_gates, v.ms_upload_wait, v.ms_device, v.ms_nym);
     }
     if (!e.ok()) return FABGPU_ELAUNCH;
     if (tx_flags && v.n_tx) memcpy(tx_flags, v.tx_flags.data(), v.n_tx);

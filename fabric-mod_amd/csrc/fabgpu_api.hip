@@ -91,7 +91,10 @@ struct fabgpu_ctx {
     void* d_issuers = nullptr;
     std::vector<int32_t*> itabs;                  // two comb tables per issuer
     std::map<std::string, uint32_t> issuer_ids;   // hsk || hrand || hash -> id
-    Buf nym;          // staging of the nym host-pointer entry point: issuer_id | six fields
+    Buf nym;          // staging of the nym host-pointer entry point: issuer_id | six fields (| spans, when they ride in an identity batch)
+    Buf nymout;       // results of the pseudonym signatures that ride in an identity batch: verdict words | status bytes
+    hipStream_t stream2 = nullptr;   // the pseudonym signatures of an identity batch run here, next to the ECDSA kernels on `stream`
+    hipEvent_t ev_up = nullptr;      // "the arena is on the device" (recorded on stream, awaited by stream2)
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
     void* d_gscr = nullptr;   // device scratch the gather kernel stitches the messages into
     size_t gscr_cap = 0;
@@ -230,6 +233,8 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     int rc = FABGPU_OK;
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        if (hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (const char* fi = getenv("FABGPU_FAULT_INJECT")) ctx->fault = !strcmp(fi, "launch") ? 1 : (!strcmp(fi, "oom") ? 2 : 0);
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         std::vector<int32_t> tab(GTab16::TABLE_WORDS);   // 80 MiB, ~0.2 s on 16 host threads
@@ -267,6 +272,9 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         for (auto* t : ctx->itabs) hipFree(t);
         if (ctx->d_issuers) hipFree(ctx->d_issuers);
         ctx->nym.release();
+        ctx->nymout.release();
+        if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+        if (ctx->ev_up) hipEventDestroy(ctx->ev_up);
         ctx->gath.release();
         ctx->tailbuf.release();
         ctx->keyed.release();
@@ -422,10 +430,10 @@ int fabgpu_idemix_issuer_count(fabgpu_ctx* ctx) {
     return (int)(ctx->itabs.size() / 2);
 }
 
-int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
-                                       const void* issuer_id, const void* nym_x, const void* nym_y, const void* proof_c,
-                                       const void* proof_s_sk, const void* proof_s_r_nym, const void* nonce, void* verdict_bits,
-                                       void* status, void* stream) {
+// spans: off holds n (start, end) pairs instead of n + 1 running offsets; timed: this launch is what fabgpu_last_kernel_ms reports
+static int nym_verify_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off, bool spans, const void* issuer_id,
+                          const void* nym_x, const void* nym_y, const void* proof_c, const void* proof_s_sk, const void* proof_s_r_nym,
+                          const void* nonce, void* verdict_bits, void* status, void* stream, bool timed) {
     if (!ctx || (n && (!arena || !off || !nym_x || !nym_y || !proof_c || !proof_s_sk || !proof_s_r_nym || !nonce || !verdict_bits)))
         return FABGPU_EINVAL;
     if (n > 0xFFFFFFF0ull || arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
@@ -444,13 +452,22 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
     void* wsp = nullptr;
     int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair, ctx->allow_quad), &wi, &wsp, st);
     if (rc != FABGPU_OK) return rc;
-    if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
+    timed = timed && ctx->time_kernels;
+    if (timed) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
-                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, ctx->allow_quad, st);
-    if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
+                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, ctx->allow_quad, spans, st);
+    if (timed) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
-    ctx->timed = ctx->time_kernels;
+    if (timed) ctx->timed = true;
     return hip_to_rc(launched(ctx, err));
+}
+
+int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off,
+                                       const void* issuer_id, const void* nym_x, const void* nym_y, const void* proof_c,
+                                       const void* proof_s_sk, const void* proof_s_r_nym, const void* nonce, void* verdict_bits,
+                                       void* status, void* stream) {
+    return nym_verify_dev(ctx, n, arena, arena_bytes, off, false, issuer_id, nym_x, nym_y, proof_c, proof_s_sk, proof_s_r_nym, nonce, verdict_bits,
+                          status, stream, true);
 }
 
 // ---- registered public keys -------------------------------------------------------------------------
@@ -872,6 +889,9 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
     const bool spans = (b->flags & FABGPU_IDB_SPANS) != 0;
     const bool staged = (b->flags & FABGPU_IDB_ARENA_STAGED) != 0;
     if (b->flags & ~(uint32_t)(FABGPU_IDB_SPANS | FABGPU_IDB_ARENA_STAGED)) return FABGPU_EINVAL;
+    const size_t nn = b->n_nym;            // pseudonym signatures over the same arena, on the second stream
+    if (nn && (!spans || !b->nym_off || !b->nym_issuer || !b->nym_fields || !b->nym_verdict_bits)) return FABGPU_EINVAL;
+    if (nn > 0x7FFFFFF0ull / 200) return FABGPU_ETOOBIG;
     // a staged arena: its slot stays locked - the stager kept out of it - until this batch has run
     fabgpu_ctx::Staged* sl = nullptr;
     std::unique_lock<std::mutex> slk;
@@ -914,6 +934,7 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
             see(s0, s1);
         }
     }
+    for (size_t i = 0; i < nn; i++) see(b->nym_off[2 * i], b->nym_off[2 * i + 1]);
     for (uint32_t p = 0; p < m; p++) {
         uint32_t s0 = b->pre_off[spans ? 2 * p : p], s1 = b->pre_off[spans ? 2 * p + 1 : p + 1];
         if (!spans) {
@@ -1075,17 +1096,60 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
         d.gather_scratch = ctx->d_gscr;
         d.gather_scratch_bytes = gscr;
     }
+    // the pseudonym signatures: staged and launched on the second stream BEFORE the ECDSA kernels are queued, so that the two run
+    // side by side (a block's idemix creators are a latency-bound launch of their own: bn_quad29.h)
+    const size_t nkb = round_up(nn * 4, 64), nfb = nn * 32, nwords = (nn + 63) / 64, nst_off = round_up(nwords * 8, 64);
+    if (nn) {
+        if ((rc = ctx->nym.ensure(nkb + 6 * nfb + nn * 8)) || (rc = ctx->nymout.ensure(nst_off + nn))) return rc;
+        uint8_t* nh = (uint8_t*)ctx->nym.h;
+        memcpy(nh, b->nym_issuer, nn * 4);
+        memcpy(nh + nkb, b->nym_fields, 6 * nfb);
+        uint32_t* no = (uint32_t*)(nh + nkb + 6 * nfb);
+        for (size_t i = 0; i < nn; i++) {
+            const uint32_t s0 = b->nym_off[2 * i], s1 = b->nym_off[2 * i + 1];
+            no[2 * i] = s1 > s0 ? s0 - lo : 0;
+            no[2 * i + 1] = s1 > s0 ? s1 - lo : 0;
+        }
+        err = hipEventRecord(ctx->ev_up, ctx->stream);                       // arena (and tail) uploads are queued on `stream`
+        if (err == hipSuccess) err = hipStreamWaitEvent(ctx->stream2, ctx->ev_up, 0);
+        if (err == hipSuccess) err = hipMemcpyAsync(ctx->nym.d, ctx->nym.h, nkb + 6 * nfb + nn * 8, hipMemcpyHostToDevice, ctx->stream2);
+        if (err != hipSuccess) return hip_to_rc(err);
+        uint8_t* nd = (uint8_t*)ctx->nym.d;
+        uint8_t* nout = (uint8_t*)ctx->nymout.d;
+        rc = nym_verify_dev(ctx, nn, d.arena, d.arena_bytes, nd + nkb + 6 * nfb, true, nd, nd + nkb, nd + nkb + nfb, nd + nkb + 2 * nfb, nd + nkb + 3 * nfb,
+                            nd + nkb + 4 * nfb, nd + nkb + 5 * nfb, nout, b->nym_status ? nout + nst_off : nullptr, ctx->stream2, false);
+        if (rc) {
+            hipStreamSynchronize(ctx->stream2);
+            return rc;
+        }
+        err = hipMemcpyAsync(ctx->nymout.h, nout, b->nym_status ? nst_off + nn : nwords * 8, hipMemcpyDeviceToHost, ctx->stream2);
+        if (err != hipSuccess) {
+            hipStreamSynchronize(ctx->stream2);
+            return hip_to_rc(err);
+        }
+    }
     rc = fabgpu_identity_verify_batch_dev(ctx, &d, m ? pd + pob + ib : nullptr, ctx->stream);
-    if (rc) return rc;
+    if (rc) {
+        if (nn) hipStreamSynchronize(ctx->stream2);                         // nothing of this call may still be running when it returns
+        return rc;
+    }
     err = hipMemcpyAsync(ctx->out.h, dout, b->digests ? dg_off + fb : (b->status ? st_off + n : words * 8), hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess && ng)
         err = hipMemcpyAsync((uint8_t*)ctx->gath.h + gsb + gob, (uint8_t*)ctx->gath.d + gsb + gob, (size_t)ng * 32, hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (nn) {
+        hipError_t e2 = hipStreamSynchronize(ctx->stream2);
+        if (err == hipSuccess) err = e2;
+    }
     if (err != hipSuccess) return hip_to_rc(err);
     memcpy(b->verdict_bits, ctx->out.h, words * 8);
     if (b->status) memcpy(b->status, (uint8_t*)ctx->out.h + st_off, n);
     if (b->digests) memcpy(b->digests, (uint8_t*)ctx->out.h + dg_off, fb);
     if (ng) memcpy(b->gather_digests, (uint8_t*)ctx->gath.h + gsb + gob, (size_t)ng * 32);
+    if (nn) {
+        memcpy(b->nym_verdict_bits, ctx->nymout.h, nwords * 8);
+        if (b->nym_status) memcpy(b->nym_status, (uint8_t*)ctx->nymout.h + nst_off, nn);
+    }
     return FABGPU_OK;
 }
 

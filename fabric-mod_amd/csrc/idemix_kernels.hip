@@ -105,7 +105,7 @@ struct IssuerDev {
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 2)
     idemix_nym_verify_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
-                             const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
+                             uint32_t spans, const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
                              const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                              const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
                              uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(BLOCK, 2)
         uint32_t ih[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) ih[k] = id->hash[k];
-        uint32_t start = off[ic], len = off[ic + 1] - start;
+        uint32_t start = spans ? off[2 * ic] : off[ic], len = (spans ? off[2 * ic + 1] : off[ic + 1]) - start;   // spans: (start, end) pairs
         bool match = nym_challenge_matches(arena32, arena_words, start, len, active, tx, ty, nx, ny, ih, nn, c);
         if (st == NYM_VALID) st = match ? NYM_VALID : NYM_BAD_PROOF;
         if (!iss_ok) st = NYM_NEEDS_SW;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(BLOCK, 2)
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 2)
     idemix_nym_verify_split_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
-                                   const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
+                                   uint32_t spans, const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
                                    const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                                    const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
                                    uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(BLOCK, 2)
         uint32_t ih[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) ih[k] = id->hash[k];
-        uint32_t start = off[ic], len = off[ic + 1] - start;
+        uint32_t start = spans ? off[2 * ic] : off[ic], len = (spans ? off[2 * ic + 1] : off[ic + 1]) - start;   // spans: (start, end) pairs
         bool match = nym_challenge_matches(arena32, arena_words, start, len, active, tx, ty, nx, ny, ih, nn, c);
         if (st == NYM_VALID) st = match ? NYM_VALID : NYM_BAD_PROOF;
         if (!iss_ok) st = NYM_NEEDS_SW;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(BLOCK, 2)
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 2)
     idemix_nym_verify_quad_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
-                                  const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
+                                  uint32_t spans, const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
                                   const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                                   const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
                                   uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(BLOCK, 2)
         uint32_t ih[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) ih[k] = id->hash[k];
-        uint32_t start = off[ic], len = off[ic + 1] - start;
+        uint32_t start = spans ? off[2 * ic] : off[ic], len = (spans ? off[2 * ic + 1] : off[ic + 1]) - start;   // spans: (start, end) pairs
         bool match = nym_challenge_matches(arena32, arena_words, start, len, active, tx, ty, nx, ny, ih, nn, c);
         if (st == NYM_VALID) st = match ? NYM_VALID : NYM_BAD_PROOF;
         if (!iss_ok) st = NYM_NEEDS_SW;
@@ -268,12 +268,12 @@ size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad) {
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
-                                    bool allow_quad, hipStream_t st) {
+                                    bool allow_quad, bool spans, hipStream_t st) {
     if (n == 0) return hipSuccess;
     if (idemix_quad(n, allow_split, allow_quad)) {                             // four lanes per signature: 64 signatures per workgroup
         dim3 qgrid(idemix_quad_wgs(n)), qblock(VERIFY_BLOCK);
         hipLaunchKernelGGL(idemix_nym_verify_quad_kernel<VERIFY_BLOCK>, qgrid, qblock, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                           (const uint32_t*)off, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
+                           (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                            (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
                            (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
         return hipGetLastError();
@@ -282,13 +282,13 @@ hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_
     dim3 grid(g.wgs), block(g.block);
     if (g.pair) {
         hipLaunchKernelGGL(idemix_nym_verify_split_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                           (const uint32_t*)off, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
+                           (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                            (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
                            (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(idemix_nym_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                       (const uint32_t*)off, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
+                       (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                        (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
                        (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();

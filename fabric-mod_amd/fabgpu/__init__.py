@@ -54,7 +54,9 @@ class _IdBatch(ctypes.Structure):
                 ("n_gather", ctypes.c_uint32), ("gather_spans", ctypes.c_void_p), ("gather_digests", ctypes.c_void_p),
                 ("gather_off", ctypes.c_void_p), ("gather_scratch", ctypes.c_void_p), ("gather_scratch_bytes", ctypes.c_size_t),
                 ("stage_token", ctypes.c_uint64), ("tail", ctypes.c_void_p), ("tail_base", ctypes.c_uint32), ("tail_len", ctypes.c_uint32),
-                ("digests", ctypes.c_void_p)]
+                ("digests", ctypes.c_void_p),
+                ("n_nym", ctypes.c_uint32), ("nym_off", ctypes.c_void_p), ("nym_issuer", ctypes.c_void_p), ("nym_fields", ctypes.c_void_p),
+                ("nym_verdict_bits", ctypes.c_void_p), ("nym_status", ctypes.c_void_p)]
 
 
 class _BlockPass(ctypes.Structure):
@@ -397,11 +399,12 @@ class Context:
         return int(tok.value)
 
     def identity_verify_batch(self, arena, off, r, s, qx=None, qy=None, key_id=None, pre_off=None, pre_idx=None, want_status=True, spans=False,
-                              gather_spans=None, stage_token=0, want_digests=False, tail=None, tail_base=0):
+                              gather_spans=None, stage_token=0, want_digests=False, tail=None, tail_base=0, nym=None):
         """fabgpu_identity_verify_batch: message i = [prefix pre_idx[i]] || arena[off[i], off[i+1]); keys by value or by id.
         gather_spans (m x 6 u32: three (start, end) pieces per gathered message): also returns their m x 32 digest bytes.
         want_digests: also returns (last) the n x 32 message digests as the fused kernel computed them.  tail / tail_base: bytes that
-        are not in the arena but addressed at offsets >= tail_base (spans mode)."""
+        are not in the arena but addressed at offsets >= tail_base (spans mode).  nym: pseudonym signatures over messages of the same
+        arena (spans mode), verified on a second stream in the same submission; returns (verdicts, statuses) of those last."""
         arena, r, s = map(_a8, (arena, r, s))
         off = np.ascontiguousarray(off, dtype=np.uint32)
         n = off.size // 2 if spans else off.size - 1
@@ -440,8 +443,20 @@ class Context:
             dig = np.zeros((gather_spans.shape[0], 32), dtype=np.uint8)
             keep += [gather_spans, dig]
             b.n_gather, b.gather_spans, b.gather_digests = gather_spans.shape[0], gather_spans.ctypes.data, dig.ctypes.data
+        nres = ()
+        if nym is not None:   # (spans m x 2, issuer ids m, [nym_x, nym_y, proof_c, proof_s_sk, proof_s_r_nym, nonce] each m x 32): pseudonym signatures riding along
+            nsp = np.ascontiguousarray(nym[0], dtype=np.uint32).reshape(-1, 2)
+            niss = np.ascontiguousarray(nym[1], dtype=np.uint32)
+            nf = np.ascontiguousarray(np.concatenate([_a8(c).reshape(-1, 32) for c in nym[2]], axis=0))
+            m = nsp.shape[0]
+            nbits, nst = np.zeros((m + 63) // 64, dtype=np.uint64), np.zeros(m, dtype=np.uint8)
+            keep += [nsp, niss, nf, nbits, nst]
+            b.n_nym, b.nym_off, b.nym_issuer, b.nym_fields = m, nsp.ctypes.data, niss.ctypes.data, nf.ctypes.data
+            b.nym_verdict_bits, b.nym_status = nbits.ctypes.data, nst.ctypes.data
         _check(self._L.fabgpu_identity_verify_batch(self._h, ctypes.byref(b)), "fabgpu_identity_verify_batch")
-        res = (unpack_bits(bits, n), st) + ((dig,) if dig is not None else ()) + ((mdig,) if mdig is not None else ())
+        if nym is not None:
+            nres = ((unpack_bits(nbits, m), nst),)
+        res = (unpack_bits(bits, n), st) + ((dig,) if dig is not None else ()) + ((mdig,) if mdig is not None else ()) + nres
         return res
 
     def identity_verify_batch_dev(self, desc: "_IdBatch", mid_scratch, stream=0):

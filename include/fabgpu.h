@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FABGPU_ABI_VERSION 3
+#define FABGPU_ABI_VERSION 4
 
 /* ---- return codes (infrastructure only) ---- */
 #define FABGPU_OK 0
@@ -181,6 +181,16 @@ typedef struct fabgpu_identity_batch {
      * bccsp.Verify(k, signature, digest) is the question the Go validators ask later (msp/identities.go:188), so a verdict memo
      * must be keyed on this digest, not on a second hash of bytes some other parser extracted.  NULL = digests stay on the chip. */
     void* digests;
+    /* ABI v4, host variant with FABGPU_IDB_SPANS: idemix pseudonym signatures over messages of the SAME arena ride in the submission - the
+     * idemix creators of a block (msp/idemixmsp.go:584-599 -> idemix/nymsignature.go:74-109).  They run on a stream of their own next to
+     * the ECDSA kernels: no second upload of their messages, no second blocking call.  Message i = arena[nym_off[2i], nym_off[2i+1]);
+     * statuses and verdicts as fabgpu_idemix_nym_verify_batch.  n_nym = 0: none.  (_dev callers use fabgpu_idemix_nym_verify_batch_dev.) */
+    uint32_t n_nym;
+    const uint32_t* nym_off;         /* n_nym x 2 */
+    const uint32_t* nym_issuer;      /* n_nym issuer ids (fabgpu_idemix_issuer_register) */
+    const void* nym_fields;          /* 6 x n_nym x 32 bytes, column after column: nym_x | nym_y | proof_c | proof_s_sk | proof_s_r_nym | nonce */
+    void* nym_verdict_bits;          /* ceil(n_nym / 64) x u64, out */
+    void* nym_status;                /* n_nym bytes, out (FABGPU_NYM_*), or NULL */
 } fabgpu_identity_batch;
 #define FABGPU_IDB_SPANS 1u /* off holds n (start, end) pairs and pre_off n_prefixes pairs: messages are arbitrary sub-slices of the arena
                              (a marshalled block), not consecutive */

@@ -103,6 +103,54 @@ def test_block_sized_batch_by_replication(env):
     assert ctx.last_kernel_ms() > 0
 
 
+def test_pseudonym_signatures_ride_in_an_identity_batch(env):
+    """fabgpu_identity_batch.n_nym (ABI v4): the idemix creators of a block in the same submission as its ECDSA signatures - messages
+    addressed as spans of the one arena, the nym kernel on a second stream.  Statuses must be those of the stand-alone entry point
+    (which the tests above hold against the oracle), the ECDSA answers must not notice the riders."""
+    import hashlib
+    import bccsp_sw_oracle as po
+    ctx, issuers = env
+    nb = make_batch(issuers, 150, 31)
+    narena, noff, iid, cols, expect = nb.arrays()
+    rng = np.random.default_rng(32)
+    d = 0x1234567
+    qx, qy = po.pt_mul(d, (po.GX, po.GY))
+    msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 900)), dtype=np.uint8)) for _ in range(90)]
+    sigs = [po.sign_raw(d, hashlib.sha256(m).digest(), 5000 + j) for j, m in enumerate(msgs)]
+    for j in range(0, 90, 7):
+        msgs[j] = msgs[j] + b"?"                                   # tampered after signing
+    # one arena: [pad][ECDSA messages][pad][pseudonym messages], everything addressed by (start, end)
+    pad = b"\xee" * 37
+    parts, espans = [pad], []
+    at = len(pad)
+    for m in msgs:
+        espans.append((at, at + len(m)))
+        parts.append(m)
+        at += len(m)
+    parts.append(pad)
+    at += len(pad)
+    base = at
+    nspans = np.stack([noff[:-1] + base, noff[1:] + base], axis=1).astype(np.uint32)
+    arena = np.frombuffer(b"".join(parts) + narena.tobytes() + b"\0" * 8, dtype=np.uint8)
+    col = lambda v: np.frombuffer(b"".join(x.to_bytes(32, "big") for x in v), dtype=np.uint8).reshape(-1, 32)
+    r, s_ = col([a for a, _ in sigs]), col([b for _, b in sigs])
+    kq = (col([qx] * 90), col([qy] * 90))
+    alone_bits, alone_st = ctx.identity_verify_batch(arena, np.array(espans, dtype=np.uint32), r, s_, qx=kq[0], qy=kq[1], spans=True)
+    bits, st, (nok, nst) = ctx.identity_verify_batch(arena, np.array(espans, dtype=np.uint32), r, s_, qx=kq[0], qy=kq[1], spans=True,
+                                                     nym=(nspans, iid, cols))
+    assert (bits == alone_bits).all() and (st == alone_st).all() and bits.sum() == 90 - len(range(0, 90, 7))
+    assert np.array_equal(nst, expect), [(int(i), nb.what[i], int(nst[i]), int(expect[i])) for i in np.nonzero(nst != expect)[0][:8]]
+    assert np.array_equal(nok, expect == 0)
+    # with the gathered digests in the same call, and with the arena staged ahead
+    g = np.zeros((150, 6), dtype=np.uint32)
+    g[:, 0:2] = nspans
+    tok = ctx.arena_stage(arena)
+    bits2, st2, dig, (nok2, nst2) = ctx.identity_verify_batch(arena, np.array(espans, dtype=np.uint32), r, s_, qx=kq[0], qy=kq[1], spans=True,
+                                                              gather_spans=g, stage_token=tok, nym=(nspans, iid, cols))
+    assert (bits2 == bits).all() and np.array_equal(nst2, expect)
+    assert [bytes(x) for x in dig] == [hashlib.sha256(m).digest() for m in nb.msgs]
+
+
 # ---- the host mirror of bccsp/idemix/handlers (NymVerifier.Verify), driven with the reference's vocabulary ------------------
 def test_nym_verifier_mirror_semantics():
     import json

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--memo", action="store_true", help="fabgpu_csp_block_preverify2 with FABGPU_PASS_SEED_MEMO (digests back + memo seeding) and eviction per block")
     ap.add_argument("--idle-ms", type=float, default=0.0, help="sleep this long between blocks (a peer sees a block every few hundred ms: the GPU clocks down)")
     ap.add_argument("--threads", type=int, default=1, help="callers validating blocks at once through the one provider (channels of a peer): aggregate rate")
+    ap.add_argument("--block-file", help="a marshalled block made by tools/make_bench_blocks.py (all signatures valid) instead of building one here")
+    ap.add_argument("--idemix", action="store_true", help="register the fixtures' IdemixMSP1 first (blocks of make_bench_blocks.py idemix ...)")
     ap.add_argument("--tables", type=int, default=256, help="device comb tables the identity cache may build (6 signers: fewer than 6 leaves newcomers on the fresh-key path)")
     args = ap.parse_args()
     import numpy as np
@@ -46,7 +48,7 @@ def main():
         assert L.oracle_p256_sign(d, e, nonce, 1, r, s) == 0
         return po.marshal_ecdsa_signature(int.from_bytes(r.raw, "big"), int.from_bytes(s.raw, "big"))
     envs = []
-    for t in range(args.tx):
+    for t in range(args.tx if not args.block_file else 0):
         picks = [int(j) for j in rng.choice(4, size=3, replace=False)]
         c = 4 + t % 2
         # TxID and proposal hash as the validators recompute them (the pass checks both: SURVEY 8(a) a12)
@@ -54,8 +56,13 @@ def main():
                                                bytes(rng.integers(0, 256, size=300, dtype=np.uint8)), bytes(rng.integers(0, 256, size=990, dtype=np.uint8)),
                                                lambda prp: [(sid[j], sign(j, prp + sid[j])) for j in picks])
         envs.append(bb.envelope(payload, sign(c, payload)))
-    blk = bb.block(1, envs)
+    blk = bb.block(1, envs) if not args.block_file else open(args.block_file, "rb").read()
     csp = fabgpu.GPUCSP(device=0)
+    if args.idemix:
+        raw_ipk = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_fixtures.json")))["msps"]["MSP1OU1"]["ipk"])
+        assert csp.idemix_msp_register("IdemixMSP1", raw_ipk) >= 0
+    if args.block_file:
+        args.tx = fabgpu.block_parse(blk)["n_tx"]
     csp._L.fabgpu_csp_identity_cache_limits(csp._h, 4096, args.tables, 1)
     out = fabgpu.preverify_block(csp, blk)
     n_keyed = fabgpu.preverify_block2(csp, blk, lean=True)["n_keyed"]
@@ -108,16 +115,16 @@ def main():
         fabgpu.memo_evict_block(csp, 7)
     # the one SHA-256 MCS.VerifyBlock needs that a GPU cannot parallelise: BlockDataHash over the concatenated envelopes, on this host
     t0 = time.perf_counter()
-    hashlib.sha256(b"".join(envs)).digest()
+    hashlib.sha256(b"".join(envs) if envs else blk).digest()
     data_hash_ms = (time.perf_counter() - t0) * 1e3
     print(json.dumps({"metric": "validated tx/sec per block (block-level pre-verify pass, marshalled block in, flags out)", "value": args.tx / dt,
                       "unit": "tx/s", "ms_per_block": dt * 1e3, "ms_min": min(per) * 1e3, "ms_max": max(per) * 1e3, "signatures_per_s": 4 * args.tx / dt,
                       "tuples_through_key_tables": n_keyed, "callers_in_flight": in_flight,
                       "mode": ("preverify2 + memo seeding (eviction not timed)" if args.memo else "preverify (flags only)") + (", %.0f ms idle between blocks" % args.idle_ms if args.idle_ms else ", back to back"),
                       "memo_lookup_us_via_ctypes": (lookup_us if args.memo else None),
-                      "host_block_data_hash_ms": data_hash_ms, "host_sha256_GB_per_s": len(b"".join(envs)) / data_hash_ms / 1e6,
-                      "config": {"workload": "%d endorser tx x (1 creator + 3 endorsement signatures), %.1f MB block, 6 signers, %d with a device table" % (
-                          args.tx, len(blk) / 1e6, min(6, args.tables))}, "checks": "creator signature, 3 endorsement signatures, TxID and proposal hash per transaction",
+                      "host_block_data_hash_ms": data_hash_ms, "host_sha256_GB_per_s": len(blk) / data_hash_ms / 1e6,
+                      "config": {"workload": "%d endorser tx x (1 creator + 3 endorsement signatures), %.1f MB block, 6 signers, %d with a device table%s" % (
+                          args.tx, len(blk) / 1e6, min(6, args.tables), (", block file " + os.path.basename(args.block_file)) if args.block_file else "")}, "checks": "creator signature, 3 endorsement signatures, TxID and proposal hash per transaction",
                       "parity": "every transaction flagged valid; corrupted blocks are covered by tests/test_block_prepass.py"}))
     csp.close()
 

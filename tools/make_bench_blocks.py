@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Pre-builds the blocks of the block-pass benches on the CPU (the signing is pure Python / C oracle and needs no GPU): written to
+.bench_blocks/ at the repo root - git-ignored, but it travels to the GPU box with the snapshot - so that GPU-minutes are not spent
+signing.      python tools/make_bench_blocks.py idemix 10000 5     -> .bench_blocks/idemix_10000_5.bin (every 5th creator idemix)"""
+import ctypes
+import hashlib
+import json
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "fabric-mod_amd"), os.path.join(ROOT, "oracle")]
+import numpy as np   # noqa: E402
+
+import bccsp_sw_oracle as po   # noqa: E402
+import blockbuilder as bb   # noqa: E402
+import coracle   # noqa: E402
+import idemix_oracle as io   # noqa: E402
+from idemix_common import be32, fixtures   # noqa: E402
+
+
+def main():
+    kind, ntx, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    assert kind == "idemix"
+    ids = [i for i in json.load(open(os.path.join(ROOT, "tests", "golden", "block_identities.json")))["identities"] if i["curve"] == "prime256v1"]
+    sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in ids]
+    L = coracle.lib()
+    rng = np.random.default_rng(1)
+    prng = random.Random(7)
+    fx = fixtures()
+    ipk, sk = fx["MSP1OU1"]["ipk"], fx["MSP1OU1"]["signer"].sk
+
+    def sign(k, msg):
+        d = int(ids[k]["d"], 16).to_bytes(32, "big")
+        e = hashlib.sha256(msg).digest()
+        nonce = b"\x00" + bytes(rng.integers(1, 255, size=31, dtype=np.uint8))
+        r, s = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        assert L.oracle_p256_sign(d, e, nonce, 1, r, s) == 0
+        return po.marshal_ecdsa_signature(int.from_bytes(r.raw, "big"), int.from_bytes(s.raw, "big"))
+    envs = []
+    for t in range(ntx):
+        picks = [int(j) for j in rng.choice(4, size=3, replace=False)]
+        ends = lambda prp: [(sid[j], sign(j, prp + sid[j])) for j in picks]   # noqa: E731
+        args = (bytes(rng.integers(0, 256, size=24, dtype=np.uint8)), bytes(rng.integers(0, 256, size=300, dtype=np.uint8)),
+                bytes(rng.integers(0, 256, size=990, dtype=np.uint8)))
+        if t % every == 0:
+            nym, r_nym = io.make_nym(sk, ipk, prng)
+            cbytes = bb.serialized_idemix_identity("IdemixMSP1", be32(nym[0]), be32(nym[1]))
+            payload, _ = bb.consistent_endorser_tx("mychannel", cbytes, *args, ends)
+            envs.append(bb.envelope(payload, io.nym_signature_marshal(io.nym_sign(sk, nym, r_nym, ipk, payload, prng))))
+        else:
+            c = 4 + t % 2
+            payload, _ = bb.consistent_endorser_tx("mychannel", sid[c], *args, ends)
+            envs.append(bb.envelope(payload, sign(c, payload)))
+        if t % 1000 == 999:
+            print(t + 1, file=sys.stderr)
+    os.makedirs(os.path.join(ROOT, ".bench_blocks"), exist_ok=True)
+    out = os.path.join(ROOT, ".bench_blocks", "idemix_%d_%d.bin" % (ntx, every))
+    open(out, "wb").write(bb.block(1, envs))
+    print(out, os.path.getsize(out))
+
+
+if __name__ == "__main__":
+    main()
