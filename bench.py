@@ -165,6 +165,68 @@ def inprocess_multi_leg(world):
         return {"error": repr(e)}
 
 
+def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
+    """SURVEY 8(f) rank 1 through the provider: a marshalled 10 000-transaction block in (built and signed here with the C oracle:
+    1 creator + 3 endorsement signatures, TxID and proposal hash per transaction), per-transaction flags out - walk, gates, one device
+    submission - timed around the blocking C-ABI call, flags-only and with digests + verdict-memo seeding (what the Go provider runs).
+    The tests hold the pass against the reference's ledgers and against corrupted blocks; here every transaction must come back valid
+    and one flipped payload byte must come back as a bad creator signature."""
+    import ctypes
+    import hashlib
+    import statistics
+    sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+    import bccsp_sw_oracle as po
+    import blockbuilder as bb
+    ids = [i for i in json.load(open(os.path.join(ROOT, "tests", "golden", "block_identities.json")))["identities"] if i["curve"] == "prime256v1"]
+    sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in ids]
+    L = coracle.lib()
+    rng = np.random.default_rng(1)
+
+    def sign(k, msg):
+        d = int(ids[k]["d"], 16).to_bytes(32, "big")
+        nonce = b"\x00" + bytes(rng.integers(1, 255, size=31, dtype=np.uint8))
+        r, s = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        assert L.oracle_p256_sign(d, hashlib.sha256(msg).digest(), nonce, 1, r, s) == 0
+        return po.marshal_ecdsa_signature(int.from_bytes(r.raw, "big"), int.from_bytes(s.raw, "big"))
+    envs = []
+    for t in range(n_tx):
+        picks = [int(j) for j in rng.choice(4, size=3, replace=False)]
+        c = 4 + t % 2
+        payload, _ = bb.consistent_endorser_tx("mychannel", sid[c], bytes(rng.integers(0, 256, size=24, dtype=np.uint8)),
+                                               bytes(rng.integers(0, 256, size=300, dtype=np.uint8)), bytes(rng.integers(0, 256, size=990, dtype=np.uint8)),
+                                               lambda prp: [(sid[j], sign(j, prp + sid[j])) for j in picks])
+        envs.append(bb.envelope(payload, sign(c, payload)))
+    blk = bb.block(1, envs)
+    csp = fabgpu.GPUCSP(device=0)
+    try:
+        for _ in range(3):                                     # identities earn their device tables on the first passes
+            first = fabgpu.preverify_block2(csp, blk, lean=True)
+        assert (first["tx_flags"] == 0).all() and first["n_tuples"] == 4 * n_tx and first["n_keyed"] == 4 * n_tx
+        legs = {}
+        for name, memo in (("flags_only", False), ("with_memo_seeding", True)):
+            per = []
+            for k in range(steps):
+                c0 = time.perf_counter()
+                r = fabgpu.preverify_block2(csp, blk, block_seq=100 + k, seed_memo=memo, lean=True)
+                per.append((time.perf_counter() - c0) * 1e3)
+                if memo:
+                    assert r["memo_seeded"] == 4 * n_tx
+                    fabgpu.memo_evict_block(csp, 100 + k)
+            med = statistics.median(per)
+            legs[name] = {"validated_tx_per_s": n_tx / (med * 1e-3), "median_ms_per_block": med, "min_ms": min(per), "max_ms": max(per), "blocks": steps}
+        bad = bytearray(blk)
+        at = blk.index(envs[7]) + len(envs[7]) // 2            # one byte inside transaction 7's payload
+        bad[at] ^= 1
+        flags = fabgpu.preverify_block2(csp, bytes(bad), lean=True)["tx_flags"]
+        assert flags[7] != 0 and (np.delete(flags, 7) == 0).all(), "a flipped payload byte must fail exactly its transaction"
+    finally:
+        csp.close()
+    return {"metric": "validated tx/s per block, marshalled block in, flags out (block-level pre-verify pass)", **legs,
+            "config": {"workload": "%d endorser tx x (1 creator + 3 endorsement signatures + TxID + proposal hash), %.1f MB block, 6 signers with device tables"
+                                   % (n_tx, len(blk) / 1e6)},
+            "parity": "every transaction valid; a flipped payload byte fails exactly its transaction (reference ledgers and corrupted blocks: tests/)"}
+
+
 def fused_cfg3_leg(ctx, torch, np, fabgpu, coracle, steps):
     """BASELINE.json configs[3]: 100 000 tx x 3 endorsements, SHA-256 fused ahead of the verify, 1 GPU."""
     import hashlib
@@ -480,6 +542,10 @@ def main():
             out["parity"] = "verdict bitmap bit-identical to the CPU oracle and to OpenSSL on the timed input"
             if n_tx == N_TX:
                 out["configs3_fused"] = fused_cfg3_leg(ctx, torch, np, fabgpu, coracle, steps=10)
+                try:
+                    out["block_pass"] = block_pass_leg(np, fabgpu, coracle)
+                except Exception as e:                                                                     # never let this leg cost the line
+                    out["block_pass"] = {"error": repr(e)[:300]}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(block, n, want)                                         # ... and OpenSSL is timed
         print(json.dumps(out))
