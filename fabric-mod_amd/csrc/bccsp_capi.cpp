@@ -189,8 +189,8 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        fprintf(stderr, "fabgpu pass: walk %.2f ms, gates + submission + flags %.2f ms (gates %.2f, wait for upload %.2f, device call %.2f, idemix creators %.2f)\n", ms(t0, t1),
-                ms(t1, t2), v.ms_gates, v.ms_upload_wait, v.ms_device, v.ms_nym);
+        fprintf(stderr, "fabgpu pass: walk %.2f ms, gates + submission + flags %.2f ms (gates %.2f, wait for upload %.2f, device call %.2f, idemix creators %.2f, memo %.2f)\n", ms(t0, t1),
+                ms(t1, t2), v.ms_gates, v.ms_upload_wait, v.ms_device, v.ms_nym, v.ms_memo);
     }
     if (!e.ok()) return FABGPU_ELAUNCH;
     if (tx_flags && v.n_tx) memcpy(tx_flags, v.tx_flags.data(), v.n_tx);
@@ -225,6 +225,9 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     opt.block_seq = ps->block_seq;
     static thread_local BlockVerdicts v;                    // answer arrays keep their capacity from block to block
     Error e = csp->csp->PreVerifyParsed(ps->block, pb, v, &up, opt);
+    if (getenv("FABGPU_PASS_TIMING"))
+        fprintf(stderr, "fabgpu pass2: gates %.2f ms, wait for upload %.2f, device call %.2f, idemix creators %.2f, memo %.2f\n", v.ms_gates, v.ms_upload_wait,
+                v.ms_device, v.ms_nym, v.ms_memo);
     if (!e.ok()) return FABGPU_ELAUNCH;
     const size_t nt = v.tuple_tx.size();
     if (ps->tx_flags && v.n_tx) memcpy(ps->tx_flags, v.tx_flags.data(), v.n_tx);

@@ -87,7 +87,7 @@ struct BlockVerdicts {
     std::vector<uint8_t> tuple_kind;      // TUPLE_CREATOR / TUPLE_ENDORSEMENT
     std::vector<uint8_t> tuple_status;    // device status 0..4 or TUPLE_ST_*
     uint32_t distinct_identities = 0;     // identities of this block that were not in the cache yet
-    double ms_gates = 0, ms_upload_wait = 0, ms_device = 0, ms_nym = 0;   // where the pass spent its time (host clock)
+    double ms_gates = 0, ms_upload_wait = 0, ms_device = 0, ms_nym = 0, ms_memo = 0;   // where the pass spent its time (host clock)
     // What a consumer needs to attach each verdict to the BYTES it was computed over (never to a position):
     std::vector<uint8_t> tuple_digest;    // 32 per tuple: SHA-256 of the signed message as the fused kernel computed it; zero unless the
                                           // device hashed the message (tuple_hashed[i] == 1)
