@@ -17,133 +17,12 @@ namespace bccsp {
 
 namespace {
 
-// ---- protobuf wire format ---------------------------------------------------------------------------------------
-struct PbField {
-    uint32_t num = 0, wt = 0;
-    uint64_t varint = 0;
-    const uint8_t* data = nullptr;   // wire type 2
-    size_t len = 0;
-};
-struct PbReader {
-    const uint8_t* p;
-    const uint8_t* end;
-    bool ok = true;
-    PbReader(const uint8_t* b, size_t n) : p(b), end(b + n) {}
-    bool varint(uint64_t& v) {
-        v = 0;
-        for (int shift = 0; shift < 64; shift += 7) {
-            if (p >= end) return false;
-            uint8_t c = *p++;
-            v |= (uint64_t)(c & 0x7F) << shift;
-            if (!(c & 0x80)) return true;
-        }
-        return false;
-    }
-    // next field; false at the end of the buffer or on malformed input (then ok == false)
-    bool next(PbField& f) {
-        if (p >= end) return false;
-        uint64_t key;
-        if (!varint(key)) return ok = false;
-        f.num = (uint32_t)(key >> 3);
-        f.wt = (uint32_t)(key & 7);
-        f.data = nullptr;
-        f.len = 0;
-        switch (f.wt) {
-            case 0: return varint(f.varint) ? true : (ok = false);
-            case 1: if (end - p < 8) return ok = false; p += 8; return true;
-            case 5: if (end - p < 4) return ok = false; p += 4; return true;
-            case 2: {
-                uint64_t n;
-                if (!varint(n) || n > (uint64_t)(end - p)) return ok = false;
-                f.data = p;
-                f.len = (size_t)n;
-                p += n;
-                return true;
-            }
-            default: return ok = false;
-        }
-    }
-};
-
-// Singular length-delimited fields.  golang/protobuf's proto.Unmarshal takes the LAST occurrence of a repeated singular bytes
-// field and MERGES repeated embedded messages; no marshaller ever writes a singular field twice.  A walker that picked "an"
-// occurrence could verify other bytes than the Go validators later see, so this one refuses the ambiguity instead of
-// resolving it: every message is scanned to its end, and a wanted field that repeats (or arrives with another wire type, which
-// Go rejects) makes the whole message "not understood" - the transaction then stays with the Go validators.
-struct Pick {
-    uint32_t num;
-    const uint8_t* p = nullptr;
-    size_t len = 0;
-    int seen = 0;
-    explicit Pick(uint32_t n) : num(n) {}
-};
-// false: malformed wire format, or one of the wanted fields repeated / not length-delimited.
-// Hand-rolled scan (this is the walker's inner loop: ~25 messages per transaction): one-byte keys and one- or two-byte lengths - what
-// every field of these messages has - take the fast path; anything else goes through the general varint decoder.
-inline bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
-    const uint8_t* p = b;
-    const uint8_t* const end = b + n;
-    while (p < end) {
-        uint64_t key = *p++;
-        if (key & 0x80) {                                              // multi-byte key: field numbers >= 16
-            key &= 0x7F;
-            int shift = 7;
-            for (;;) {
-                if (p >= end || shift > 63) return false;
-                const uint8_t c = *p++;
-                key |= (uint64_t)(c & 0x7F) << shift;
-                if (!(c & 0x80)) break;
-                shift += 7;
-            }
-        }
-        const uint32_t num = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
-        if (num == 0) return false;                                    // "illegal tag 0" in Go
-        int hit = -1;
-        for (int i = 0; i < k; i++)
-            if (want[i].num == num) hit = i;
-        if (wt == 2) {
-            if (p >= end) return false;
-            uint64_t len = *p++;
-            if (len & 0x80) {
-                len &= 0x7F;
-                int shift = 7;
-                for (;;) {
-                    if (p >= end || shift > 63) return false;
-                    const uint8_t c = *p++;
-                    len |= (uint64_t)(c & 0x7F) << shift;
-                    if (!(c & 0x80)) break;
-                    shift += 7;
-                }
-            }
-            if (len > (uint64_t)(end - p)) return false;
-            if (hit >= 0) {
-                if (want[hit].seen) return false;
-                want[hit].seen = 1;
-                want[hit].p = p;
-                want[hit].len = (size_t)len;
-            }
-            p += len;
-            continue;
-        }
-        if (hit >= 0) return false;                                    // a wanted field with another wire type: Go rejects the message
-        if (wt == 0) {
-            int cnt = 0;
-            for (;;) {
-                if (p >= end || ++cnt > 10) return false;
-                if (!(*p++ & 0x80)) break;
-            }
-        } else if (wt == 1) {
-            if (end - p < 8) return false;
-            p += 8;
-        } else if (wt == 5) {
-            if (end - p < 4) return false;
-            p += 4;
-        } else {
-            return false;
-        }
-    }
-    return true;
-}
+// ---- protobuf wire format: block_walk_core.h (shared with the device walker) ----------------------------------------------------
+using walk::PbField;
+using walk::PbReader;
+using walk::Pick;
+using walk::pb_pick;
+using walk::span_of;
 // the one wanted field: 1 present once, 0 absent, -1 ambiguous / malformed
 int pb_one(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t& outlen) {
     Pick w(num);
@@ -154,13 +33,6 @@ int pb_one(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t
 }
 // compatibility form for callers that only ask "is there exactly one": absent and ambiguous both answer false
 bool pb_bytes(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t& outlen) { return pb_one(b, n, num, out, outlen) == 1; }
-
-Span span_of(const uint8_t* base, const uint8_t* p, size_t n) {
-    Span s;
-    s.off = (uint32_t)(p - base);
-    s.len = (uint32_t)n;
-    return s;
-}
 
 // ---- DER ------------------------------------------------------------------------------------------------------------------
 struct Der {
@@ -358,135 +230,35 @@ bool IdentityToIdemixNym(const uint8_t* ident, size_t len, std::string& mspid, u
 }
 
 namespace {
-// one envelope -> its tuples (prefix indices local to `out`)
-void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, uint32_t tx, ParsedBlock& out, uint8_t& tx_type, uint8_t& understood) {
-    tx_type = 255;
-    understood = 0;
-    // common.Envelope{1 payload, 2 signature}
-    Pick e_[2] = {Pick(1), Pick(2)};
-    if (!pb_pick(env, env_len, e_, 2) || !e_[0].seen) return;
-    const uint8_t* payload = e_[0].p;
-    const size_t payload_l = e_[0].len;
-    const uint8_t* sig = e_[1].seen ? e_[1].p : payload;
-    const size_t sig_l = e_[1].seen ? e_[1].len : 0;
-    // common.Payload{1 header, 2 data}; common.Header{1 channel_header, 2 signature_header}
-    Pick p_[2] = {Pick(1), Pick(2)};
-    if (!pb_pick(payload, payload_l, p_, 2) || !p_[0].seen) return;
-    Pick h_[2] = {Pick(1), Pick(2)};
-    if (!pb_pick(p_[0].p, p_[0].len, h_, 2) || !h_[0].seen || !h_[1].seen) return;
-    const uint8_t *chdr = h_[0].p, *shdr = h_[1].p;
-    const size_t chdr_l = h_[0].len, shdr_l = h_[1].len;
-    // common.ChannelHeader{1 type (varint), ..., 4 channel_id, 5 tx_id}
-    uint8_t type = 0;   // proto3 default: MESSAGE
-    Span txid_span;     // ChannelHeader.tx_id (field 5)
-    {
-        PbReader r(chdr, chdr_l);
-        PbField g;
-        int n_type = 0, n_chan = 0, n_txid = 0;
-        while (r.next(g)) {
-            if (g.num == 0) return;
-            if (g.num == 1) {
-                if (g.wt != 0 || n_type++) return;
-                if (g.varint > 254) return;                            // no HeaderType is that large: leave it to Go
-                type = (uint8_t)g.varint;
-            }
-            if (g.num == 4) {
-                if (g.wt != 2 || n_chan++) return;
-                if (tx == 0) out.first_channel_id.assign((const char*)g.data, g.len);
-            }
-            if (g.num == 5) {
-                if (g.wt != 2 || n_txid++) return;
-                txid_span = span_of(block, g.data, g.len);
-            }
-        }
-        if (!r.ok) return;
+// the host's emitter of walk::walk_envelope: appends to the vectors of a ParsedBlock (prefix indices local to it)
+struct VectorEmitter {
+    ParsedBlock& out;
+    uint32_t tx;
+    size_t first_tuple = 0, first_check = 0, first_prefix = 0;
+    void mark() {
+        first_tuple = out.tuples.size();
+        first_check = out.hash_checks.size();
+        first_prefix = out.prefixes.size();
     }
-    tx_type = type;
-    // common.SignatureHeader{1 creator, 2 nonce}
-    Pick s_[2] = {Pick(1), Pick(2)};
-    if (!pb_pick(shdr, shdr_l, s_, 2) || !s_[0].seen) return;
-    BlockTuple ct;
-    ct.tx = tx;
-    ct.kind = TUPLE_CREATOR;
-    ct.identity = span_of(block, s_[0].p, s_[0].len);
-    ct.suffix = span_of(block, payload, payload_l);
-    ct.sig = span_of(block, sig, sig_l);
-    size_t first_tuple = out.tuples.size(), first_check = out.hash_checks.size(), first_prefix = out.prefixes.size();
-    out.tuples.push_back(ct);
-    if (type != 3) {                                               // only ENDORSER_TRANSACTION carries endorsements
-        understood = 1;
-        return;
-    }
-    {   // CheckTxID: endorser transactions only (msgvalidation.go:283-296)
-        BlockHashCheck hc;
-        hc.tx = tx;
-        hc.kind = HASH_TXID;
-        if (s_[1].seen) hc.piece[0] = span_of(block, s_[1].p, s_[1].len);
-        hc.piece[1] = ct.identity;
-        hc.expect = txid_span;
-        out.hash_checks.push_back(hc);
-    }
-    bool good = p_[1].seen != 0;
-    // peer.Transaction{1 repeated actions}; TransactionAction{1 header, 2 payload}
-    PbReader acts(good ? p_[1].p : payload, good ? p_[1].len : 0);
-    PbField a;
-    while (good && acts.next(a)) {
-        if (a.num == 0) { good = false; break; }
-        if (a.num != 1) continue;
-        if (a.wt != 2) { good = false; break; }
-        // ChaincodeActionPayload{1 chaincode_proposal_payload, 2 action}; ChaincodeEndorsedAction{1 proposal_response_payload, 2 endorsements}
-        Pick ta_[2] = {Pick(1), Pick(2)};
-        if (!pb_pick(a.data, a.len, ta_, 2) || !ta_[1].seen) { good = false; break; }
-        Pick cap_[2] = {Pick(1), Pick(2)};
-        if (!pb_pick(ta_[1].p, ta_[1].len, cap_, 2) || !cap_[1].seen) { good = false; break; }
-        const uint8_t* cea = cap_[1].p;
-        const size_t cea_l = cap_[1].len;
-        Pick prp_(1);
-        if (!pb_pick(cea, cea_l, &prp_, 1) || !prp_.seen) { good = false; break; }
-        const uint8_t* prp = prp_.p;
-        const size_t prp_l = prp_.len;
-        int32_t pidx = (int32_t)out.prefixes.size();
-        out.prefixes.push_back(span_of(block, prp, prp_l));
-        {   // GetProposalHash2 of this action
-            BlockHashCheck hc;
-            hc.tx = tx;
-            hc.kind = HASH_PROPOSAL;
-            hc.piece[0] = span_of(block, chdr, chdr_l);
-            if (ta_[0].seen) hc.piece[1] = span_of(block, ta_[0].p, ta_[0].len);
-            if (cap_[0].seen) hc.piece[2] = span_of(block, cap_[0].p, cap_[0].len);
-            Pick ph_(1);                                               // ProposalResponsePayload{1 proposal_hash, 2 extension}
-            if (!pb_pick(prp, prp_l, &ph_, 1)) { good = false; break; }
-            if (ph_.seen) hc.expect = span_of(block, ph_.p, ph_.len);
-            out.hash_checks.push_back(hc);
-        }
-        PbReader ends(cea, cea_l);
-        PbField e;
-        while (ends.next(e)) {
-            if (e.num != 2) continue;
-            if (e.wt != 2) { good = false; break; }
-            // peer.Endorsement{1 endorser, 2 signature}
-            Pick en_[2] = {Pick(1), Pick(2)};
-            if (!pb_pick(e.data, e.len, en_, 2) || !en_[0].seen) { good = false; break; }
-            BlockTuple et;
-            et.tx = tx;
-            et.kind = TUPLE_ENDORSEMENT;
-            et.identity = span_of(block, en_[0].p, en_[0].len);
-            et.prefix = span_of(block, prp, prp_l);
-            et.prefix_index = pidx;
-            et.suffix = et.identity;                               // message = prp || endorser
-            et.sig = en_[1].seen ? span_of(block, en_[1].p, en_[1].len) : span_of(block, en_[0].p, 0);
-            out.tuples.push_back(et);
-        }
-        if (!ends.ok) good = false;
-    }
-    if (!acts.ok) good = false;
-    if (!good) {
-        out.tuples.resize(first_tuple);                            // leave the whole transaction to the Go validators
+    void rollback() {
+        out.tuples.resize(first_tuple);
         out.hash_checks.resize(first_check);
         out.prefixes.resize(first_prefix);
-        return;
     }
-    understood = 1;
+    void add_tuple(const BlockTuple& t) { out.tuples.push_back(t); }
+    int32_t add_prefix(const Span& s) {
+        out.prefixes.push_back(s);
+        return (int32_t)out.prefixes.size() - 1;
+    }
+    void add_check(const BlockHashCheck& c) { out.hash_checks.push_back(c); }
+    void channel_id(const uint8_t* p, size_t n) {
+        if (tx == 0) out.first_channel_id.assign((const char*)p, n);
+    }
+};
+// one envelope -> its tuples (prefix indices local to `out`)
+void parse_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, uint32_t tx, ParsedBlock& out, uint8_t& tx_type, uint8_t& understood) {
+    VectorEmitter em{out, tx};
+    walk::walk_envelope(block, env, env_len, tx, em, tx_type, understood);
 }
 }  // namespace
 
@@ -513,6 +285,108 @@ int WalkThreads() {
         return v < 1 ? 1 : (v > 16 ? 16 : v);
     }();
     return n;
+}
+
+namespace {
+// block level: header fields and the orderer signatures over the block (TUPLE_BLOCK_SIG); `top` = the picked fields of common.Block
+void parse_block_level(const uint8_t* block, size_t len, const Pick* top, ParsedBlock& out, std::vector<BlockTuple>& block_sigs) {
+    const uint8_t* data = top[1].p;
+    const size_t dlen = top[1].len;
+    out.data = span_of(block, data, dlen);
+    out.tail_base = (uint32_t)((len + 63) / 64 * 64);
+    block_sigs.clear();
+    if (top[0].seen) {
+        // common.BlockHeader{1 number (varint), 2 previous_hash, 3 data_hash}
+        PbReader r(top[0].p, top[0].len);
+        PbField f;
+        int c1 = 0, c2 = 0, c3 = 0;
+        bool ok = true;
+        while (r.next(f)) {
+            if (f.num == 0) ok = false;
+            if (f.num == 1) { if (f.wt != 0 || c1++) ok = false; else out.number = f.varint; }
+            if (f.num == 2) { if (f.wt != 2 || c2++) ok = false; else out.previous_hash = span_of(block, f.data, f.len); }
+            if (f.num == 3) { if (f.wt != 2 || c3++) ok = false; else out.data_hash = span_of(block, f.data, f.len); }
+        }
+        out.has_header = ok && r.ok;
+    }
+    if (out.has_header && top[2].seen && len <= 0xFFFF0000ull) {       // (the tail must be addressable behind the block with 32-bit offsets)
+        // common.BlockMetadata{1 repeated bytes metadata}; entry [BlockMetadataIndex_SIGNATURES = 0] is a marshalled
+        // common.Metadata{1 value, 2 repeated MetadataSignature{1 signature_header, 2 signature}}
+        PbReader r(top[2].p, top[2].len);
+        PbField f;
+        const uint8_t* m0 = nullptr;
+        size_t m0_l = 0;
+        bool have = false, ok = true;
+        while (r.next(f)) {
+            if (f.num != 1) continue;
+            if (f.wt != 2) { ok = false; break; }
+            if (!have) { m0 = f.data; m0_l = f.len; have = true; }
+        }
+        ok = ok && r.ok && have;
+        Pick val(1);
+        if (ok && !pb_pick(m0, m0_l, &val, 1)) ok = false;
+        if (ok) {
+            std::vector<uint8_t> hb;
+            BlockHeaderBytes(out.number, block + out.previous_hash.off, out.previous_hash.len, block + out.data_hash.off, out.data_hash.len, hb);
+            PbReader sr(m0, m0_l);
+            PbField g;
+            while (sr.next(g)) {
+                if (g.num != 2) continue;
+                if (g.wt != 2) { ok = false; break; }
+                Pick ms[2] = {Pick(1), Pick(2)};
+                if (!pb_pick(g.data, g.len, ms, 2)) { ok = false; break; }
+                // protoutil.UnmarshalSignatureHeader(signature_header).Creator; an absent header unmarshals to an empty creator
+                Pick cr(1);
+                if (ms[0].seen && !pb_pick(ms[0].p, ms[0].len, &cr, 1)) { ok = false; break; }
+                BlockTuple bt;
+                bt.tx = BLOCK_LEVEL_TX;
+                bt.kind = TUPLE_BLOCK_SIG;
+                bt.identity = cr.seen ? span_of(block, cr.p, cr.len) : span_of(block, block, 0);
+                bt.sig = ms[1].seen ? span_of(block, ms[1].p, ms[1].len) : span_of(block, block, 0);
+                const size_t at = out.tail.size();
+                if (val.seen) out.tail.insert(out.tail.end(), val.p, val.p + val.len);
+                if (ms[0].seen) out.tail.insert(out.tail.end(), ms[0].p, ms[0].p + ms[0].len);
+                out.tail.insert(out.tail.end(), hb.begin(), hb.end());
+                if ((uint64_t)out.tail_base + out.tail.size() > 0xFFFFFFF0ull) { ok = false; break; }
+                bt.suffix.off = out.tail_base + (uint32_t)at;
+                bt.suffix.len = (uint32_t)(out.tail.size() - at);
+                block_sigs.push_back(bt);
+            }
+            if (!sr.ok) ok = false;
+        }
+        if (!ok) {
+            block_sigs.clear();
+            out.tail.clear();
+        }
+        out.block_sigs_understood = ok;
+    }
+    out.n_block_sigs = (uint32_t)block_sigs.size();
+}
+}  // namespace
+
+// The host's share of a DEVICE-side walk (block_walk_kernels.hip): the outer framing, where each envelope starts (a serial chain by
+// nature: envelope i + 1 begins where envelope i ends), the header fields and the orderers' block signatures with their tail.
+bool OutlineBlock(const uint8_t* block, size_t len, ParsedBlock& out, std::vector<uint32_t>& env_spans, std::vector<BlockTuple>& block_sigs) {
+    out.reset();
+    env_spans.clear();
+    block_sigs.clear();
+    if (len > 0xFFFFFFF0ull) return false;
+    Pick top[3] = {Pick(1), Pick(2), Pick(3)};                       // common.Block{1 header, 2 data, 3 metadata}
+    if (!pb_pick(block, len, top, 3) || !top[1].seen) return false;
+    PbReader r(top[1].p, top[1].len);
+    PbField f;
+    while (r.next(f)) {
+        if (f.num != 1 || f.wt != 2) continue;                        // common.BlockData{1 repeated bytes data}
+        env_spans.push_back((uint32_t)(f.data - block));
+        env_spans.push_back((uint32_t)f.len);
+    }
+    if (!r.ok) {
+        env_spans.clear();
+        return false;
+    }
+    out.n_tx = (uint32_t)(env_spans.size() / 2);
+    parse_block_level(block, len, top, out, block_sigs);
+    return true;
 }
 
 bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_threads) {
@@ -598,76 +472,8 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
         out.reset();
         return false;
     }
-    // block level: header fields and the orderer signatures over the block (TUPLE_BLOCK_SIG)
-    out.data = span_of(block, data, dlen);
-    out.tail_base = (uint32_t)((len + 63) / 64 * 64);
     std::vector<BlockTuple> block_sigs;
-    if (top[0].seen) {
-        // common.BlockHeader{1 number (varint), 2 previous_hash, 3 data_hash}
-        PbReader r(top[0].p, top[0].len);
-        PbField f;
-        int c1 = 0, c2 = 0, c3 = 0;
-        bool ok = true;
-        while (r.next(f)) {
-            if (f.num == 0) ok = false;
-            if (f.num == 1) { if (f.wt != 0 || c1++) ok = false; else out.number = f.varint; }
-            if (f.num == 2) { if (f.wt != 2 || c2++) ok = false; else out.previous_hash = span_of(block, f.data, f.len); }
-            if (f.num == 3) { if (f.wt != 2 || c3++) ok = false; else out.data_hash = span_of(block, f.data, f.len); }
-        }
-        out.has_header = ok && r.ok;
-    }
-    if (out.has_header && top[2].seen && len <= 0xFFFF0000ull) {       // (the tail must be addressable behind the block with 32-bit offsets)
-        // common.BlockMetadata{1 repeated bytes metadata}; entry [BlockMetadataIndex_SIGNATURES = 0] is a marshalled
-        // common.Metadata{1 value, 2 repeated MetadataSignature{1 signature_header, 2 signature}}
-        PbReader r(top[2].p, top[2].len);
-        PbField f;
-        const uint8_t* m0 = nullptr;
-        size_t m0_l = 0;
-        bool have = false, ok = true;
-        while (r.next(f)) {
-            if (f.num != 1) continue;
-            if (f.wt != 2) { ok = false; break; }
-            if (!have) { m0 = f.data; m0_l = f.len; have = true; }
-        }
-        ok = ok && r.ok && have;
-        Pick val(1);
-        if (ok && !pb_pick(m0, m0_l, &val, 1)) ok = false;
-        if (ok) {
-            std::vector<uint8_t> hb;
-            BlockHeaderBytes(out.number, block + out.previous_hash.off, out.previous_hash.len, block + out.data_hash.off, out.data_hash.len, hb);
-            PbReader sr(m0, m0_l);
-            PbField g;
-            while (sr.next(g)) {
-                if (g.num != 2) continue;
-                if (g.wt != 2) { ok = false; break; }
-                Pick ms[2] = {Pick(1), Pick(2)};
-                if (!pb_pick(g.data, g.len, ms, 2)) { ok = false; break; }
-                // protoutil.UnmarshalSignatureHeader(signature_header).Creator; an absent header unmarshals to an empty creator
-                Pick cr(1);
-                if (ms[0].seen && !pb_pick(ms[0].p, ms[0].len, &cr, 1)) { ok = false; break; }
-                BlockTuple bt;
-                bt.tx = BLOCK_LEVEL_TX;
-                bt.kind = TUPLE_BLOCK_SIG;
-                bt.identity = cr.seen ? span_of(block, cr.p, cr.len) : span_of(block, block, 0);
-                bt.sig = ms[1].seen ? span_of(block, ms[1].p, ms[1].len) : span_of(block, block, 0);
-                const size_t at = out.tail.size();
-                if (val.seen) out.tail.insert(out.tail.end(), val.p, val.p + val.len);
-                if (ms[0].seen) out.tail.insert(out.tail.end(), ms[0].p, ms[0].p + ms[0].len);
-                out.tail.insert(out.tail.end(), hb.begin(), hb.end());
-                if ((uint64_t)out.tail_base + out.tail.size() > 0xFFFFFFF0ull) { ok = false; break; }
-                bt.suffix.off = out.tail_base + (uint32_t)at;
-                bt.suffix.len = (uint32_t)(out.tail.size() - at);
-                block_sigs.push_back(bt);
-            }
-            if (!sr.ok) ok = false;
-        }
-        if (!ok) {
-            block_sigs.clear();
-            out.tail.clear();
-        }
-        out.block_sigs_understood = ok;
-    }
-    out.n_block_sigs = (uint32_t)block_sigs.size();
+    parse_block_level(block, len, top, out, block_sigs);
     // merge in chunk order
     out.n_tx = n;
     out.tx_type.resize(n);

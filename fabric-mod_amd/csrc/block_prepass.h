@@ -23,12 +23,10 @@
 #include <string>
 #include <vector>
 
+#include "block_walk_core.h"
+
 namespace fab {
 namespace bccsp {
-
-struct Span {
-    uint32_t off = 0, len = 0;   // into the block buffer
-};
 
 // TUPLE_BLOCK_SIG: an orderer's signature over the block (BlockMetadataIndex_SIGNATURES), the SignedData MCS.VerifyBlock hands to
 // the BlockValidation policy (internal/peer/gossip/mcs.go:166-193):
@@ -38,8 +36,7 @@ struct Span {
 // (protoutil/blockutils.go:38-58) - bytes that are NOT in the marshalled block.  The walker therefore writes each such message
 // into ParsedBlock::tail, and the tuple's suffix span addresses it at offset tail_base + k of a VIRTUAL arena
 // block || zero padding up to tail_base || tail  (fabgpu_identity_batch.tail).  tx = BLOCK_LEVEL_TX for these tuples.
-enum : uint8_t { TUPLE_CREATOR = 0, TUPLE_ENDORSEMENT = 1, TUPLE_BLOCK_SIG = 2 };
-constexpr uint32_t BLOCK_LEVEL_TX = 0xFFFFFFFFu;
+// (Span, BlockTuple, BlockHashCheck, TUPLE_* and HASH_*: block_walk_core.h - shared with the device walker.)
 // per-tuple outcome: 0..4 = the device status codes of include/fabgpu.h, plus
 enum : uint8_t {
     TUPLE_ST_BAD_DER = 5,        // UnmarshalECDSASignature fails / r,s <= 0: identity.Verify returns an error
@@ -63,20 +60,7 @@ enum : uint8_t {
 //   HASH_PROPOSAL       protoutil.GetProposalHash2 (protoutil/txutils.go:431-447, called at msgvalidation.go:233-241), per action:
 //                       SHA-256(Header.channel_header || TransactionAction.header || ChaincodeActionPayload.chaincode_proposal_payload),
 //                       compared with ProposalResponsePayload.proposal_hash
-enum : uint8_t { HASH_TXID = 0, HASH_PROPOSAL = 1 };
-struct BlockHashCheck {
-    uint32_t tx = 0;
-    uint8_t kind = HASH_TXID;
-    Span piece[3];                  // the message is their concatenation (unused pieces have len 0)
-    Span expect;                    // HASH_TXID: 64 hex characters; HASH_PROPOSAL: 32 raw bytes; anything else cannot match
-};
 
-struct BlockTuple {
-    uint32_t tx = 0;
-    uint8_t kind = TUPLE_CREATOR;
-    Span identity, prefix, suffix, sig;   // prefix.len == 0 for creator tuples
-    int32_t prefix_index = -1;
-};
 struct ParsedBlock {
     uint32_t n_tx = 0;
     std::vector<uint8_t> tx_type;         // ChannelHeader.type per envelope (-> 255 if not parsed)
@@ -108,6 +92,10 @@ struct ParsedBlock {
 // Pure parsing (no device): false only if the outer Block / BlockData framing is broken.
 // BlockData of 1 MiB and more is walked on up to max_threads (<= 16) worker threads while the calling thread lists the envelopes.
 bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_threads = 8);
+// The host's share of a DEVICE-side walk (block_walk_kernels.hip): outer framing, (offset, length) of every envelope in env_spans, and
+// the block-level fields of `out` (header, data span, tail, n_tx = envelopes listed) with the orderers' signature tuples in block_sigs.
+// out.tuples / prefixes / hash_checks / tx_type stay empty: the device fills its own copies.  false: as ParseBlock.
+bool OutlineBlock(const uint8_t* block, size_t len, ParsedBlock& out, std::vector<uint32_t>& env_spans, std::vector<BlockTuple>& block_sigs);
 // worker threads the pass gives the walk: 8, or FABGPU_PASS_WALK_THREADS (experiments)
 int WalkThreads();
 // SerializedIdentity{mspid, id_bytes = PEM x509} -> uncompressed P-256 point.  false: not such an identity.

@@ -1,0 +1,382 @@
+// The envelope walker of the pre-verify pass as ONE body of code for the host and for the device (block_prepass.h describes what it
+// extracts and which reference functions those tuples stand for).  block_prepass.cpp instantiates walk_envelope with an emitter that
+// appends to vectors; block_walk_kernels.hip instantiates the same template once with a counting emitter and once with an emitter that
+// writes at the offsets a prefix sum over those counts assigned - so the strictness rules (a repeated singular field, a wanted field with
+// another wire type, a tag 0 ... make the transaction "not understood") hold on the device because they are the same lines, and the CPU
+// tests of the host walker (ledger goldens, mutation fuzz under ASAN) cover the logic the kernels run.
+//
+// Also here, for the same reason: the signature gate of the common DER shape (gate_sig_fast) that the device applies per tuple; the
+// general parser with Go's error texts (bccsp_host.cpp, bccsp/utils/ecdsa.go:43-67) stays on the host and decides whatever this one
+// declines to.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define WALK_HD __host__ __device__
+#else
+#define WALK_HD
+#endif
+
+namespace fab {
+namespace bccsp {
+
+struct Span {
+    uint32_t off = 0, len = 0;   // into the block buffer
+};
+
+enum : uint8_t { TUPLE_CREATOR = 0, TUPLE_ENDORSEMENT = 1, TUPLE_BLOCK_SIG = 2 };
+constexpr uint32_t BLOCK_LEVEL_TX = 0xFFFFFFFFu;
+enum : uint8_t { HASH_TXID = 0, HASH_PROPOSAL = 1 };
+
+struct BlockHashCheck {
+    uint32_t tx = 0;
+    uint8_t kind = HASH_TXID;
+    Span piece[3];                  // the message is their concatenation (unused pieces have len 0)
+    Span expect;                    // HASH_TXID: 64 hex characters; HASH_PROPOSAL: 32 raw bytes; anything else cannot match
+};
+struct BlockTuple {
+    uint32_t tx = 0;
+    uint8_t kind = TUPLE_CREATOR;
+    Span identity, prefix, suffix, sig;   // prefix.len == 0 for creator tuples
+    int32_t prefix_index = -1;
+};
+static_assert(sizeof(BlockTuple) == 44 && sizeof(BlockHashCheck) == 40 && sizeof(Span) == 8, "records travel between host and device as raw bytes");
+
+namespace walk {
+
+// ---- protobuf wire format ---------------------------------------------------------------------------------------
+struct PbField {
+    uint32_t num = 0, wt = 0;
+    uint64_t varint = 0;
+    const uint8_t* data = nullptr;   // wire type 2
+    size_t len = 0;
+};
+struct PbReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool ok = true;
+    WALK_HD PbReader(const uint8_t* b, size_t n) : p(b), end(b + n) {}
+    WALK_HD bool varint(uint64_t& v) {
+        v = 0;
+        for (int shift = 0; shift < 64; shift += 7) {
+            if (p >= end) return false;
+            uint8_t c = *p++;
+            v |= (uint64_t)(c & 0x7F) << shift;
+            if (!(c & 0x80)) return true;
+        }
+        return false;
+    }
+    // next field; false at the end of the buffer or on malformed input (then ok == false)
+    WALK_HD bool next(PbField& f) {
+        if (p >= end) return false;
+        uint64_t key;
+        if (!varint(key)) return ok = false;
+        f.num = (uint32_t)(key >> 3);
+        f.wt = (uint32_t)(key & 7);
+        f.data = nullptr;
+        f.len = 0;
+        switch (f.wt) {
+            case 0: return varint(f.varint) ? true : (ok = false);
+            case 1: if (end - p < 8) return ok = false; p += 8; return true;
+            case 5: if (end - p < 4) return ok = false; p += 4; return true;
+            case 2: {
+                uint64_t n;
+                if (!varint(n) || n > (uint64_t)(end - p)) return ok = false;
+                f.data = p;
+                f.len = (size_t)n;
+                p += n;
+                return true;
+            }
+            default: return ok = false;
+        }
+    }
+};
+
+// Singular length-delimited fields.  golang/protobuf's proto.Unmarshal takes the LAST occurrence of a repeated singular bytes
+// field and MERGES repeated embedded messages; no marshaller ever writes a singular field twice.  A walker that picked "an"
+// occurrence could verify other bytes than the Go validators later see, so this one refuses the ambiguity instead of
+// resolving it: every message is scanned to its end, and a wanted field that repeats (or arrives with another wire type, which
+// Go rejects) makes the whole message "not understood" - the transaction then stays with the Go validators.
+struct Pick {
+    uint32_t num;
+    const uint8_t* p = nullptr;
+    size_t len = 0;
+    int seen = 0;
+    WALK_HD explicit Pick(uint32_t n) : num(n) {}
+};
+// false: malformed wire format, or one of the wanted fields repeated / not length-delimited.
+// Hand-rolled scan (this is the walker's inner loop: ~25 messages per transaction): one-byte keys and one- or two-byte lengths - what
+// every field of these messages has - take the fast path; anything else goes through the general varint decoder.
+WALK_HD inline bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
+    const uint8_t* p = b;
+    const uint8_t* const end = b + n;
+    while (p < end) {
+        uint64_t key = *p++;
+        if (key & 0x80) {                                              // multi-byte key: field numbers >= 16
+            key &= 0x7F;
+            int shift = 7;
+            for (;;) {
+                if (p >= end || shift > 63) return false;
+                const uint8_t c = *p++;
+                key |= (uint64_t)(c & 0x7F) << shift;
+                if (!(c & 0x80)) break;
+                shift += 7;
+            }
+        }
+        const uint32_t num = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+        if (num == 0) return false;                                    // "illegal tag 0" in Go
+        int hit = -1;
+        for (int i = 0; i < k; i++)
+            if (want[i].num == num) hit = i;
+        if (wt == 2) {
+            if (p >= end) return false;
+            uint64_t len = *p++;
+            if (len & 0x80) {
+                len &= 0x7F;
+                int shift = 7;
+                for (;;) {
+                    if (p >= end || shift > 63) return false;
+                    const uint8_t c = *p++;
+                    len |= (uint64_t)(c & 0x7F) << shift;
+                    if (!(c & 0x80)) break;
+                    shift += 7;
+                }
+            }
+            if (len > (uint64_t)(end - p)) return false;
+            if (hit >= 0) {
+                if (want[hit].seen) return false;
+                want[hit].seen = 1;
+                want[hit].p = p;
+                want[hit].len = (size_t)len;
+            }
+            p += len;
+            continue;
+        }
+        if (hit >= 0) return false;                                    // a wanted field with another wire type: Go rejects the message
+        if (wt == 0) {
+            int cnt = 0;
+            for (;;) {
+                if (p >= end || ++cnt > 10) return false;
+                if (!(*p++ & 0x80)) break;
+            }
+        } else if (wt == 1) {
+            if (end - p < 8) return false;
+            p += 8;
+        } else if (wt == 5) {
+            if (end - p < 4) return false;
+            p += 4;
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+
+WALK_HD inline Span span_of(const uint8_t* base, const uint8_t* p, size_t n) {
+    Span s;
+    s.off = (uint32_t)(p - base);
+    s.len = (uint32_t)n;
+    return s;
+}
+
+// One envelope -> its tuples, shared prefixes and hash checks, through an emitter:
+//     void    mark();                              the transaction starts here
+//     void    rollback();                          forget everything since mark() (the transaction is left to the Go validators)
+//     void    add_tuple(const BlockTuple&);
+//     int32_t add_prefix(const Span&);             returns the index tuples of this action carry as prefix_index
+//     void    add_check(const BlockHashCheck&);
+//     void    channel_id(const uint8_t*, size_t);  ChannelHeader.channel_id of the envelope (fixture pin; the device ignores it)
+template <class Em>
+WALK_HD inline void walk_envelope(const uint8_t* block, const uint8_t* env, size_t env_len, uint32_t tx, Em& em, uint8_t& tx_type, uint8_t& understood) {
+    tx_type = 255;
+    understood = 0;
+    // common.Envelope{1 payload, 2 signature}
+    Pick e_[2] = {Pick(1), Pick(2)};
+    if (!pb_pick(env, env_len, e_, 2) || !e_[0].seen) return;
+    const uint8_t* payload = e_[0].p;
+    const size_t payload_l = e_[0].len;
+    const uint8_t* sig = e_[1].seen ? e_[1].p : payload;
+    const size_t sig_l = e_[1].seen ? e_[1].len : 0;
+    // common.Payload{1 header, 2 data}; common.Header{1 channel_header, 2 signature_header}
+    Pick p_[2] = {Pick(1), Pick(2)};
+    if (!pb_pick(payload, payload_l, p_, 2) || !p_[0].seen) return;
+    Pick h_[2] = {Pick(1), Pick(2)};
+    if (!pb_pick(p_[0].p, p_[0].len, h_, 2) || !h_[0].seen || !h_[1].seen) return;
+    const uint8_t *chdr = h_[0].p, *shdr = h_[1].p;
+    const size_t chdr_l = h_[0].len, shdr_l = h_[1].len;
+    // common.ChannelHeader{1 type (varint), ..., 4 channel_id, 5 tx_id}
+    uint8_t type = 0;   // proto3 default: MESSAGE
+    Span txid_span;     // ChannelHeader.tx_id (field 5)
+    {
+        PbReader r(chdr, chdr_l);
+        PbField g;
+        int n_type = 0, n_chan = 0, n_txid = 0;
+        while (r.next(g)) {
+            if (g.num == 0) return;
+            if (g.num == 1) {
+                if (g.wt != 0 || n_type++) return;
+                if (g.varint > 254) return;                            // no HeaderType is that large: leave it to Go
+                type = (uint8_t)g.varint;
+            }
+            if (g.num == 4) {
+                if (g.wt != 2 || n_chan++) return;
+                em.channel_id(g.data, g.len);
+            }
+            if (g.num == 5) {
+                if (g.wt != 2 || n_txid++) return;
+                txid_span = span_of(block, g.data, g.len);
+            }
+        }
+        if (!r.ok) return;
+    }
+    tx_type = type;
+    // common.SignatureHeader{1 creator, 2 nonce}
+    Pick s_[2] = {Pick(1), Pick(2)};
+    if (!pb_pick(shdr, shdr_l, s_, 2) || !s_[0].seen) return;
+    BlockTuple ct;
+    ct.tx = tx;
+    ct.kind = TUPLE_CREATOR;
+    ct.identity = span_of(block, s_[0].p, s_[0].len);
+    ct.suffix = span_of(block, payload, payload_l);
+    ct.sig = span_of(block, sig, sig_l);
+    em.mark();
+    em.add_tuple(ct);
+    if (type != 3) {                                               // only ENDORSER_TRANSACTION carries endorsements
+        understood = 1;
+        return;
+    }
+    {   // CheckTxID: endorser transactions only (msgvalidation.go:283-296)
+        BlockHashCheck hc;
+        hc.tx = tx;
+        hc.kind = HASH_TXID;
+        if (s_[1].seen) hc.piece[0] = span_of(block, s_[1].p, s_[1].len);
+        hc.piece[1] = ct.identity;
+        hc.expect = txid_span;
+        em.add_check(hc);
+    }
+    bool good = p_[1].seen != 0;
+    // peer.Transaction{1 repeated actions}; TransactionAction{1 header, 2 payload}
+    PbReader acts(good ? p_[1].p : payload, good ? p_[1].len : 0);
+    PbField a;
+    while (good && acts.next(a)) {
+        if (a.num == 0) { good = false; break; }
+        if (a.num != 1) continue;
+        if (a.wt != 2) { good = false; break; }
+        // ChaincodeActionPayload{1 chaincode_proposal_payload, 2 action}; ChaincodeEndorsedAction{1 proposal_response_payload, 2 endorsements}
+        Pick ta_[2] = {Pick(1), Pick(2)};
+        if (!pb_pick(a.data, a.len, ta_, 2) || !ta_[1].seen) { good = false; break; }
+        Pick cap_[2] = {Pick(1), Pick(2)};
+        if (!pb_pick(ta_[1].p, ta_[1].len, cap_, 2) || !cap_[1].seen) { good = false; break; }
+        const uint8_t* cea = cap_[1].p;
+        const size_t cea_l = cap_[1].len;
+        Pick prp_(1);
+        if (!pb_pick(cea, cea_l, &prp_, 1) || !prp_.seen) { good = false; break; }
+        const uint8_t* prp = prp_.p;
+        const size_t prp_l = prp_.len;
+        const int32_t pidx = em.add_prefix(span_of(block, prp, prp_l));
+        {   // GetProposalHash2 of this action
+            BlockHashCheck hc;
+            hc.tx = tx;
+            hc.kind = HASH_PROPOSAL;
+            hc.piece[0] = span_of(block, chdr, chdr_l);
+            if (ta_[0].seen) hc.piece[1] = span_of(block, ta_[0].p, ta_[0].len);
+            if (cap_[0].seen) hc.piece[2] = span_of(block, cap_[0].p, cap_[0].len);
+            Pick ph_(1);                                               // ProposalResponsePayload{1 proposal_hash, 2 extension}
+            if (!pb_pick(prp, prp_l, &ph_, 1)) { good = false; break; }
+            if (ph_.seen) hc.expect = span_of(block, ph_.p, ph_.len);
+            em.add_check(hc);
+        }
+        PbReader ends(cea, cea_l);
+        PbField e;
+        while (ends.next(e)) {
+            if (e.num != 2) continue;
+            if (e.wt != 2) { good = false; break; }
+            // peer.Endorsement{1 endorser, 2 signature}
+            Pick en_[2] = {Pick(1), Pick(2)};
+            if (!pb_pick(e.data, e.len, en_, 2) || !en_[0].seen) { good = false; break; }
+            BlockTuple et;
+            et.tx = tx;
+            et.kind = TUPLE_ENDORSEMENT;
+            et.identity = span_of(block, en_[0].p, en_[0].len);
+            et.prefix = span_of(block, prp, prp_l);
+            et.prefix_index = pidx;
+            et.suffix = et.identity;                               // message = prp || endorser
+            et.sig = en_[1].seen ? span_of(block, en_[1].p, en_[1].len) : span_of(block, en_[0].p, 0);
+            em.add_tuple(et);
+        }
+        if (!ends.ok) good = false;
+    }
+    if (!acts.ok) good = false;
+    if (!good) {
+        em.rollback();                                             // leave the whole transaction to the Go validators
+        return;
+    }
+    understood = 1;
+}
+
+// ---- the signature gate of the common DER shape ----------------------------------------------------------------------------
+// bccsp/sw/ecdsa.go:41-57 before any arithmetic: UnmarshalECDSASignature (bccsp/utils/ecdsa.go:43-67: asn1.Unmarshal into
+// {R, S *big.Int}, R and S > 0) and IsLowS (bccsp/utils/ecdsa.go:84-92).  This decides the one shape every signer produces -
+// a minimal DER SEQUENCE { INTEGER r, INTEGER s }, short-form lengths, nothing behind it, r and s positive and below 2^256 - exactly
+// as the general parser would: GATE_SUBMIT (s <= n/2: r32 / s32 are set, the device decides, r >= n included) or GATE_HIGH_S.
+// Everything else (long-form lengths, trailing bytes, negative / zero / oversize integers, truncation ...) is GATE_DECLINED: the
+// caller takes the general parser and its error texts.
+enum : uint8_t { GATE_SUBMIT = 0, GATE_HIGH_S = 1, GATE_EMPTY = 2, GATE_DECLINED = 3 };
+WALK_HD inline bool der_minimal_positive(const uint8_t* p, uint32_t l) {
+    if (p[0] & 0x80) return false;                                  // negative
+    if (p[0] == 0) return l > 1 && (p[1] & 0x80) != 0 && l <= 33;   // a leading zero must be needed (also excludes zero)
+    return l <= 32;
+}
+WALK_HD inline uint8_t gate_sig_fast(const uint8_t* sig, uint32_t siglen, uint8_t* r32, uint8_t* s32) {
+    // n/2 of P-256 (bccsp/utils/ecdsa.go:30-37 curveHalfOrders)
+    const uint8_t HALF_N[32] = {0x7f, 0xff, 0xff, 0xff, 0x80, 0x00, 0x00, 0x00, 0x7f, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
+                                0xde, 0x73, 0x7d, 0x56, 0xd3, 0x8b, 0xcf, 0x42, 0x79, 0xdc, 0xe5, 0x61, 0x7e, 0x31, 0x92, 0xa8};
+    if (siglen == 0) return GATE_EMPTY;
+    if (siglen < 8 || siglen > 72 || sig[0] != 0x30 || sig[1] != siglen - 2 || sig[2] != 0x02) return GATE_DECLINED;
+    uint32_t lr = sig[3];
+    if (lr < 1 || lr > 33 || 4 + lr + 2 > siglen || sig[4 + lr] != 0x02) return GATE_DECLINED;
+    uint32_t ls = sig[5 + lr];
+    const uint8_t* pr = sig + 4;
+    const uint8_t* ps = sig + 6 + lr;
+    if (ls < 1 || ls > 33 || 6 + lr + ls != siglen || !der_minimal_positive(pr, lr) || !der_minimal_positive(ps, ls)) return GATE_DECLINED;
+    if (pr[0] == 0) { pr++; lr--; }
+    if (ps[0] == 0) { ps++; ls--; }
+    for (uint32_t k = 0; k < 32; k++) {
+        r32[k] = k + lr >= 32 ? pr[k + lr - 32] : 0;
+        s32[k] = k + ls >= 32 ? ps[k + ls - 32] : 0;
+    }
+    for (int k = 0; k < 32; k++) {
+        if (s32[k] < HALF_N[k]) return GATE_SUBMIT;
+        if (s32[k] > HALF_N[k]) return GATE_HIGH_S;
+    }
+    return GATE_SUBMIT;                                             // s == n/2 is low
+}
+
+// ---- identity bytes -> 64-bit table hash ---------------------------------------------------------------------------------
+// The device looks identities up in a table of the ones the provider has met (block_walk_kernels.hip); the hash only picks the slot,
+// equality is always decided on the bytes.  Defined over 64 interleaved byte streams so that a wavefront computes it with one
+// coalesced row per step: stream l folds bytes l, l + 64, ... ; the streams are mixed with per-stream odd constants and summed.
+WALK_HD inline uint64_t id_stream_const(uint32_t l) { return (0x9E3779B97F4A7C15ull * (uint64_t)(2 * l + 1)) | 1ull; }
+WALK_HD inline uint64_t id_stream_fold(uint64_t h, uint8_t b) { return (h ^ b) * 0x100000001B3ull; }
+WALK_HD inline uint64_t id_hash_finish(uint64_t sum, uint32_t len) {
+    uint64_t h = sum ^ ((uint64_t)len * 0xD6E8FEB86659FD93ull);
+    h ^= h >> 32;
+    h *= 0xD6E8FEB86659FD93ull;
+    h ^= h >> 29;
+    return h;
+}
+inline uint64_t id_hash_host(const uint8_t* p, uint32_t len) {
+    uint64_t sum = 0;
+    for (uint32_t l = 0; l < 64; l++) {
+        uint64_t h = 0xCBF29CE484222325ull;
+        for (uint32_t i = l; i < len; i += 64) h = id_stream_fold(h, p[i]);
+        sum += h * id_stream_const(l);
+    }
+    return id_hash_finish(sum, len);
+}
+
+}  // namespace walk
+}  // namespace bccsp
+}  // namespace fab
