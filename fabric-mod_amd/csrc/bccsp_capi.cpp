@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include <chrono>
 
 #include "../../include/fabgpu_bccsp.h"
@@ -14,6 +16,18 @@ using namespace fab::bccsp;
 
 struct fabgpu_csp {
     std::unique_ptr<GPUCSP> csp;
+    // which way the block passes went (fabgpu_csp_pass_routes)
+    std::mutex route_mu;
+    uint64_t device_walks = 0, host_walks = 0;
+    std::string last_decline;
+    void note_route(bool on_device, const char* why) {
+        std::lock_guard<std::mutex> lk(route_mu);
+        if (on_device) device_walks++;
+        else {
+            host_walks++;
+            last_decline = why ? why : "";
+        }
+    }
 };
 
 namespace {
@@ -174,28 +188,52 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
     if (!csp || !block || !n_tx || !n_tuples) return FABGPU_EINVAL;
     const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;          // stage breakdown on stderr (tools/bench_block.py --timing)
     auto t0 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
     GPUCSP::BlockUpload up;
     csp->csp->StartBlockUpload(up, block, len);            // the block travels while it is walked
     static thread_local ParsedBlock pb;                     // storage reused from block to block (a few MB: no page faults per block)
-    if (!ParseBlock(block, len, pb, WalkThreads())) return FABGPU_EINVAL;
-    auto t1 = std::chrono::steady_clock::now();
-    *n_tx = pb.n_tx;
-    *n_tuples = (uint32_t)pb.tuples.size();
-    if (pb.n_tx > cap_tx || pb.tuples.size() > cap_tuples) return FABGPU_ETOOBIG;   // counts are set: retry with room (nothing was launched)
     static thread_local BlockVerdicts v;                    // answer arrays keep their capacity from block to block
-    Error e = csp->csp->PreVerifyParsed(block, pb, v, &up);
-    if (timing) {
-        auto t2 = std::chrono::steady_clock::now();
-        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-            return std::chrono::duration<double, std::milli>(b - a).count();
-        };
-        fprintf(stderr, "fabgpu pass: walk %.2f ms, gates + submission + flags %.2f ms (gates %.2f, wait for upload %.2f, device call %.2f, idemix creators %.2f, memo %.2f)\n", ms(t0, t1),
-                ms(t1, t2), v.ms_gates, v.ms_upload_wait, v.ms_device, v.ms_nym, v.ms_memo);
+    bool done = false;
+    {   // the walk on the device (block_walk_dev.h); a block it declines takes the host walk below
+        const char* why = "";
+        uint32_t ntup = 0;
+        const int r = csp->csp->PreVerifyBlockOnDevice(block, len, pb, v, up, PassOptions(), tuple_tx != nullptr || tuple_kind != nullptr ? GPUCSP::WANT_TUPLES : 0u, cap_tx, cap_tuples,
+                                                       &ntup, &why);
+        csp->note_route(r == 0, why);
+        if (r == FABGPU_ETOOBIG) {
+            *n_tx = pb.n_tx;
+            *n_tuples = ntup;
+            return FABGPU_ETOOBIG;
+        }
+        if (r < 0) return r == FABGPU_EINVAL || r == FABGPU_ENOMEM ? r : FABGPU_ELAUNCH;
+        done = r == 0;
+        if (timing && done)
+            fprintf(stderr, "fabgpu pass (device walk): total %.2f ms (outline + identity table %.2f, wait for upload %.2f, device %.2f)\n", ms(t0, std::chrono::steady_clock::now()),
+                    v.ms_gates, v.ms_upload_wait, v.ms_device);
+        if (timing && !done) fprintf(stderr, "fabgpu pass: device walk declined (%s)\n", why);
     }
-    if (!e.ok()) return FABGPU_ELAUNCH;
+    if (done) {
+        *n_tx = pb.n_tx;
+        *n_tuples = (uint32_t)v.tuple_status.size();
+    } else {
+        if (!ParseBlock(block, len, pb, WalkThreads())) return FABGPU_EINVAL;
+        auto t1 = std::chrono::steady_clock::now();
+        *n_tx = pb.n_tx;
+        *n_tuples = (uint32_t)pb.tuples.size();
+        if (pb.n_tx > cap_tx || pb.tuples.size() > cap_tuples) return FABGPU_ETOOBIG;   // counts are set: retry with room (nothing was launched)
+        Error e = csp->csp->PreVerifyParsed(block, pb, v, &up);
+        if (timing) {
+            auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "fabgpu pass: walk %.2f ms, gates + submission + flags %.2f ms (gates %.2f, wait for upload %.2f, device call %.2f, idemix creators %.2f, memo %.2f)\n", ms(t0, t1),
+                    ms(t1, t2), v.ms_gates, v.ms_upload_wait, v.ms_device, v.ms_nym, v.ms_memo);
+        }
+        if (!e.ok()) return FABGPU_ELAUNCH;
+    }
     if (tx_flags && v.n_tx) memcpy(tx_flags, v.tx_flags.data(), v.n_tx);
     if (tx_type && v.n_tx) memcpy(tx_type, v.tx_type.data(), v.n_tx);
-    size_t nt = v.tuple_tx.size();
+    size_t nt = v.tuple_status.size();
     if (tuple_tx && nt) memcpy(tuple_tx, v.tuple_tx.data(), nt * 4);
     if (tuple_kind && nt) memcpy(tuple_kind, v.tuple_kind.data(), nt);
     if (tuple_status && nt) memcpy(tuple_status, v.tuple_status.data(), nt);
@@ -205,31 +243,61 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
 int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     if (!csp || !ps || !ps->block) return FABGPU_EINVAL;
     if (ps->flags & ~(uint32_t)(FABGPU_PASS_SEED_MEMO | FABGPU_PASS_NO_BLOCK_SIGS)) return FABGPU_EINVAL;
+    auto t0 = std::chrono::steady_clock::now();
     GPUCSP::BlockUpload up;
     csp->csp->StartBlockUpload(up, ps->block, ps->len);
     static thread_local ParsedBlock pb;
-    if (!ParseBlock(ps->block, ps->len, pb, WalkThreads())) return FABGPU_EINVAL;
-    ps->n_tx = pb.n_tx;
-    ps->n_tuples = (uint32_t)pb.tuples.size();
-    ps->n_block_sigs = pb.n_block_sigs;
-    ps->tail_base = pb.tail_base;
-    ps->tail_len = (uint32_t)pb.tail.size();
-    ps->block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
-    ps->memo_seeded = 0;
-    ps->n_keyed = 0;
-    if (pb.n_tx > ps->cap_tx || pb.tuples.size() > ps->cap_tuples || (ps->tail && pb.tail.size() > ps->tail_cap)) return FABGPU_ETOOBIG;
+    static thread_local BlockVerdicts v;                    // answer arrays keep their capacity from block to block
     PassOptions opt;
     opt.seed_memo = (ps->flags & FABGPU_PASS_SEED_MEMO) != 0;
     opt.want_digests = ps->tuple_digest != nullptr;
     opt.block_sigs = !(ps->flags & FABGPU_PASS_NO_BLOCK_SIGS);
     opt.block_seq = ps->block_seq;
-    static thread_local BlockVerdicts v;                    // answer arrays keep their capacity from block to block
-    Error e = csp->csp->PreVerifyParsed(ps->block, pb, v, &up, opt);
-    if (getenv("FABGPU_PASS_TIMING"))
-        fprintf(stderr, "fabgpu pass2: gates %.2f ms, wait for upload %.2f, device call %.2f, idemix creators %.2f, memo %.2f\n", v.ms_gates, v.ms_upload_wait,
-                v.ms_device, v.ms_nym, v.ms_memo);
-    if (!e.ok()) return FABGPU_ELAUNCH;
-    const size_t nt = v.tuple_tx.size();
+    ps->memo_seeded = 0;
+    ps->n_keyed = 0;
+    bool done = false;
+    {   // the walk on the device (block_walk_dev.h); a block it declines takes the host walk below
+        const char* why = "";
+        uint32_t ntup = 0;
+        const unsigned want = (ps->tuple_tx || ps->tuple_kind || ps->tuple_spans ? GPUCSP::WANT_TUPLES : 0u) | (ps->tuple_qxy ? GPUCSP::WANT_QXY : 0u);
+        const int r = csp->csp->PreVerifyBlockOnDevice(ps->block, ps->len, pb, v, up, opt, want, ps->cap_tx, ps->cap_tuples, &ntup, &why);
+        csp->note_route(r == 0, why);
+        if (r == 0 || r == FABGPU_ETOOBIG) {
+            ps->n_tx = pb.n_tx;
+            ps->n_tuples = r == 0 ? (uint32_t)v.tuple_status.size() : ntup;
+            ps->n_block_sigs = pb.n_block_sigs;
+            ps->tail_base = pb.tail_base;
+            ps->tail_len = (uint32_t)pb.tail.size();
+            ps->block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
+        }
+        if (r == FABGPU_ETOOBIG) return FABGPU_ETOOBIG;
+        if (r < 0) return r == FABGPU_EINVAL || r == FABGPU_ENOMEM ? r : FABGPU_ELAUNCH;
+        done = r == 0;
+        if (done && ps->tail && pb.tail.size() > ps->tail_cap) return FABGPU_ETOOBIG;
+        if (getenv("FABGPU_PASS_TIMING")) {
+            if (done)
+                fprintf(stderr, "fabgpu pass2 (device walk): total %.2f ms (outline + identity table %.2f, wait for upload %.2f, device %.2f, memo %.2f)\n",
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), v.ms_gates, v.ms_upload_wait, v.ms_device, v.ms_memo);
+            else
+                fprintf(stderr, "fabgpu pass2: device walk declined (%s)\n", why);
+        }
+    }
+    if (!done) {
+        if (!ParseBlock(ps->block, ps->len, pb, WalkThreads())) return FABGPU_EINVAL;
+        ps->n_tx = pb.n_tx;
+        ps->n_tuples = (uint32_t)pb.tuples.size();
+        ps->n_block_sigs = pb.n_block_sigs;
+        ps->tail_base = pb.tail_base;
+        ps->tail_len = (uint32_t)pb.tail.size();
+        ps->block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
+        if (pb.n_tx > ps->cap_tx || pb.tuples.size() > ps->cap_tuples || (ps->tail && pb.tail.size() > ps->tail_cap)) return FABGPU_ETOOBIG;
+        Error e = csp->csp->PreVerifyParsed(ps->block, pb, v, &up, opt);
+        if (getenv("FABGPU_PASS_TIMING"))
+            fprintf(stderr, "fabgpu pass2: gates %.2f ms, wait for upload %.2f, device call %.2f, idemix creators %.2f, memo %.2f\n", v.ms_gates, v.ms_upload_wait,
+                    v.ms_device, v.ms_nym, v.ms_memo);
+        if (!e.ok()) return FABGPU_ELAUNCH;
+    }
+    const size_t nt = v.tuple_status.size();
     if (ps->tx_flags && v.n_tx) memcpy(ps->tx_flags, v.tx_flags.data(), v.n_tx);
     if (ps->tx_type && v.n_tx) memcpy(ps->tx_type, v.tx_type.data(), v.n_tx);
     if (ps->tuple_tx && nt) memcpy(ps->tuple_tx, v.tuple_tx.data(), nt * 4);
@@ -251,6 +319,64 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     ps->memo_seeded = v.memo_seeded;
     ps->n_keyed = (uint32_t)v.n_keyed;
     return FABGPU_OK;
+}
+
+// Which way the passes of this provider went: walked on the device / walked on the host, and why the last block was declined.
+int fabgpu_csp_pass_routes(fabgpu_csp* csp, uint64_t* device_walks, uint64_t* host_walks, char* last_decline, size_t cap) {
+    if (!csp) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(csp->route_mu);
+    if (device_walks) *device_walks = csp->device_walks;
+    if (host_walks) *host_walks = csp->host_walks;
+    put_err(last_decline, cap, csp->last_decline);
+    return FABGPU_OK;
+}
+// TEST HOOK: the device walker against the host walker on one block.  0: identical (or *declined = 1: the device declined, nothing
+// compared); 1: they differ, `diff` says where.
+int fabgpu_csp_block_walk_compare(fabgpu_csp* csp, const uint8_t* block, size_t len, int* declined, char* diff, size_t cap) {
+    if (!csp || !block || !declined) return FABGPU_EINVAL;
+    *declined = 0;
+    put_err(diff, cap, "");
+    ParsedBlock host, dev;
+    const bool hok = ParseBlock(block, len, host, WalkThreads());
+    const char* why = "";
+    const int r = csp->csp->WalkBlockOnDevice(block, len, dev, &why);
+    if (r == 1) {
+        *declined = 1;
+        put_err(diff, cap, why);
+        return FABGPU_OK;
+    }
+    if (!hok || r == FABGPU_EINVAL) {
+        if (hok != (r != FABGPU_EINVAL)) { put_err(diff, cap, "one walker refuses the framing, the other does not"); return 1; }
+        return FABGPU_OK;
+    }
+    if (r < 0) return r;
+    std::string d;
+    auto span_eq = [](const Span& a, const Span& b) { return a.off == b.off && a.len == b.len; };
+    if (host.n_tx != dev.n_tx) d = "n_tx";
+    else if (host.tx_type != dev.tx_type) d = "tx_type";
+    else if (host.tx_understood != dev.tx_understood) d = "tx_understood";
+    else if (host.tuples.size() != dev.tuples.size()) d = "tuple count " + std::to_string(host.tuples.size()) + " vs " + std::to_string(dev.tuples.size());
+    else if (host.prefixes.size() != dev.prefixes.size()) d = "prefix count";
+    else if (host.hash_checks.size() != dev.hash_checks.size()) d = "hash check count";
+    for (size_t i = 0; d.empty() && i < host.tuples.size(); i++) {
+        const BlockTuple &a = host.tuples[i], &b = dev.tuples[i];
+        if (a.tx != b.tx || a.kind != b.kind || a.prefix_index != b.prefix_index || !span_eq(a.identity, b.identity) || !span_eq(a.prefix, b.prefix) ||
+            !span_eq(a.suffix, b.suffix) || !span_eq(a.sig, b.sig))
+            d = "tuple " + std::to_string(i);
+    }
+    for (size_t i = 0; d.empty() && i < host.prefixes.size(); i++) {
+        // (the device keeps (start, end) pairs and normalises an empty prefix to (0, 0))
+        const Span a = host.prefixes[i], b = dev.prefixes[i];
+        if (a.len != b.len || (a.len && a.off != b.off)) d = "prefix " + std::to_string(i);
+    }
+    for (size_t i = 0; d.empty() && i < host.hash_checks.size(); i++) {
+        const BlockHashCheck &a = host.hash_checks[i], &b = dev.hash_checks[i];
+        if (a.tx != b.tx || a.kind != b.kind || !span_eq(a.piece[0], b.piece[0]) || !span_eq(a.piece[1], b.piece[1]) || !span_eq(a.piece[2], b.piece[2]) ||
+            !span_eq(a.expect, b.expect))
+            d = "hash check " + std::to_string(i);
+    }
+    put_err(diff, cap, d);
+    return d.empty() ? FABGPU_OK : 1;
 }
 
 int fabgpu_csp_memo_lookup(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest,
@@ -383,6 +509,101 @@ int fabgpu_block_tuples(const uint8_t* block, size_t len, uint32_t cap, uint32_t
     if (tail && !pb.tail.empty()) memcpy(tail, pb.tail.data(), pb.tail.size());
     return FABGPU_OK;
 }
+
+// TEST HOOK (pure host): the device walk's two-run procedure - count per envelope, exclusive prefix sum, write at the assigned offsets
+// (block_walk_core.h CountEmitter / WriteEmitter, the code block_walk_kernels.hip runs) - carried out serially on the host and
+// compared, record for record, with ParseBlock.  0 identical, 1 different (`diff` says where), FABGPU_EINVAL: the framing is refused
+// (by both).
+int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* diff, size_t cap) {
+    if (!block) return FABGPU_EINVAL;
+    put_err(diff, cap, "");
+    ParsedBlock host, out;
+    std::vector<uint32_t> env;
+    std::vector<BlockTuple> sigs;
+    const bool hok = ParseBlock(block, len, host, 1);
+    const bool ook = OutlineBlock(block, len, out, env, sigs);
+    if (hok != ook) { put_err(diff, cap, "framing verdicts differ"); return 1; }
+    if (!hok) return FABGPU_EINVAL;
+    const uint32_t ne = (uint32_t)(env.size() / 2);
+    struct C { uint32_t t, p, c; uint64_t g; };
+    std::vector<C> cnt(ne), base(ne);
+    std::vector<uint8_t> type(ne), und(ne);
+    for (uint32_t e = 0; e < ne; e++) {
+        walk::CountEmitter em;
+        walk::walk_envelope(block, block + env[2 * e], env[2 * e + 1], e, em, type[e], und[e]);
+        cnt[e] = {em.nt, em.np, em.nc, em.gb};
+    }
+    C run = {0, 0, 0, 0};
+    for (uint32_t e = 0; e < ne; e++) {
+        base[e] = run;
+        run.t += cnt[e].t; run.p += cnt[e].p; run.c += cnt[e].c; run.g += cnt[e].g;
+    }
+    std::vector<BlockTuple> tuples(run.t + 1);
+    std::vector<uint32_t> pre_off2(2 * (size_t)run.p + 2), gsp(6 * (size_t)run.c + 6), goff(run.c + 1);
+    std::vector<BlockHashCheck> checks(run.c + 1);
+    // canaries: a record written outside its envelope's range would land on one
+    BlockTuple canary;
+    canary.tx = 0xDEADBEEF;
+    std::fill(tuples.begin(), tuples.end(), canary);
+    for (uint32_t e = 0; e < ne; e++) {
+        if (cnt[e].t == 0 && cnt[e].p == 0 && cnt[e].c == 0) continue;
+        walk::WriteEmitter em{tuples.data(), pre_off2.data(), checks.data(), gsp.data(), goff.data(), base[e].t, base[e].p, base[e].c, (uint32_t)base[e].g,
+                              cnt[e].t, cnt[e].p, cnt[e].c};
+        uint8_t t2, u2;
+        walk::walk_envelope(block, block + env[2 * e], env[2 * e + 1], e, em, t2, u2);
+        if (t2 != type[e] || u2 != und[e] || em.nt != cnt[e].t || em.np != cnt[e].p || em.nc != cnt[e].c) { put_err(diff, cap, "the two runs disagree on envelope " + std::to_string(e)); return 1; }
+    }
+    std::string d;
+    auto span_eq = [](const Span& a, const Span& b) { return a.off == b.off && a.len == b.len; };
+    const size_t host_env_tuples = host.tuples.size() - host.n_block_sigs;
+    if (host.n_tx != ne) d = "n_tx";
+    else if (memcmp(host.tx_type.data(), type.data(), ne) != 0) d = "tx_type";
+    else if (memcmp(host.tx_understood.data(), und.data(), ne) != 0) d = "tx_understood";
+    else if (host_env_tuples != run.t) d = "tuple count";
+    else if (host.prefixes.size() != run.p) d = "prefix count";
+    else if (host.hash_checks.size() != run.c) d = "hash check count";
+    else if (sigs.size() != host.n_block_sigs) d = "block signature count";
+    for (size_t i = 0; d.empty() && i < host.tuples.size(); i++) {
+        const BlockTuple& a = host.tuples[i];
+        const BlockTuple& b = i < host_env_tuples ? tuples[i] : sigs[i - host_env_tuples];
+        if (a.tx != b.tx || a.kind != b.kind || a.prefix_index != b.prefix_index || !span_eq(a.identity, b.identity) || !span_eq(a.prefix, b.prefix) ||
+            !span_eq(a.suffix, b.suffix) || !span_eq(a.sig, b.sig))
+            d = "tuple " + std::to_string(i);
+    }
+    if (d.empty() && tuples[run.t].tx != 0xDEADBEEF) d = "a tuple was written past the end";
+    for (size_t i = 0; d.empty() && i < host.prefixes.size(); i++) {
+        const Span a = host.prefixes[i];
+        if (pre_off2[2 * i + 1] - pre_off2[2 * i] != a.len || (a.len && pre_off2[2 * i] != a.off)) d = "prefix " + std::to_string(i);
+    }
+    uint64_t g = 0;
+    for (size_t i = 0; d.empty() && i < host.hash_checks.size(); i++) {
+        const BlockHashCheck &a = host.hash_checks[i], &b = checks[i];
+        if (a.tx != b.tx || a.kind != b.kind || !span_eq(a.piece[0], b.piece[0]) || !span_eq(a.piece[1], b.piece[1]) || !span_eq(a.piece[2], b.piece[2]) ||
+            !span_eq(a.expect, b.expect))
+            d = "hash check " + std::to_string(i);
+        if (d.empty() && goff[i] != (uint32_t)g) d = "gather offset " + std::to_string(i);
+        for (int p = 0; d.empty() && p < 3; p++) {
+            if (gsp[6 * i + 2 * p + 1] - gsp[6 * i + 2 * p] != a.piece[p].len || (a.piece[p].len && gsp[6 * i + 2 * p] != a.piece[p].off)) d = "gather span " + std::to_string(i);
+            g += a.piece[p].len;
+        }
+    }
+    if (d.empty() && g != run.g) d = "gathered bytes";
+    put_err(diff, cap, d);
+    return d.empty() ? FABGPU_OK : 1;
+}
+// TEST HOOK (pure host): the device's signature gate (block_walk_core.h gate_sig_fast): 0 submit (r32 / s32 set), 1 high-S, 2 empty, 3 declined
+int fabgpu_gate_sig_fast(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32) {
+    uint8_t r[32], s[32];
+    if (len > 0xFFFFFFFFull) return walk::GATE_DECLINED;
+    const uint8_t g = walk::gate_sig_fast(sig, (uint32_t)len, r, s);
+    if (g == walk::GATE_SUBMIT) {
+        if (r32) memcpy(r32, r, 32);
+        if (s32) memcpy(s32, s, 32);
+    }
+    return g;
+}
+// TEST HOOK (pure host): the table hash of identity bytes (block_walk_core.h id_hash_host)
+uint64_t fabgpu_identity_table_hash(const uint8_t* p, size_t len) { return walk::id_hash_host(p, (uint32_t)len); }
 
 // ---- idemix (idemix_host.h) ----
 int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id) {

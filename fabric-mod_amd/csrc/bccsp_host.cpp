@@ -14,6 +14,7 @@
 #include "bccsp_host.h"
 #include "worker_pool.h"
 #include "idemix_host.h"
+#include "block_walk_dev.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -659,6 +660,7 @@ void GPUCSP::SetIdentityCacheLimits(size_t max_identities, size_t max_registered
         idcache_.erase(idlru_.back().first);
         idlru_.pop_back();
     }
+    id_version_.fetch_add(1, std::memory_order_release);
 }
 size_t GPUCSP::IdentityCacheSize() const {
     std::lock_guard<std::mutex> lk(idmu_);
@@ -673,6 +675,448 @@ int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_r
     std::lock_guard<std::mutex> lk(idmu_);
     idemix_msps_[mspid] = k.issuer_id;
     return k.issuer_id;
+}
+
+// identities that earned a device comb table during a block: built and uploaded outside idmu_ (6 ms of host work each)
+void GPUCSP::RegisterQueued(const std::vector<std::string>& to_register) const {
+    if (to_register.empty()) return;
+    std::vector<std::pair<std::string, CachedIdentity>> todo;
+    {
+        std::lock_guard<std::mutex> lk(idmu_);
+        for (const std::string& k : to_register) {
+            auto it = idcache_.find(k);
+            if (it != idcache_.end()) todo.emplace_back(k, it->second->second);
+            else id_registered_--;                     // evicted meanwhile
+        }
+    }
+    for (auto& kv : todo) {
+        uint32_t id = 0;
+        const bool ok = fabgpu_p256_key_register(ctx_, kv.second.qx, kv.second.qy, &id) == FABGPU_OK;
+        std::lock_guard<std::mutex> lk(idmu_);
+        auto it = idcache_.find(kv.first);
+        if (it != idcache_.end()) {
+            it->second->second.registering = false;
+            if (ok) it->second->second.key_id = id;
+        }
+        if (!ok) id_registered_--;
+        id_version_.fetch_add(1, std::memory_order_release);
+    }
+}
+
+void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, const PassOptions& opt, std::vector<uint32_t>& sel_scratch,
+                      int gate_max) const {
+    const size_t nt = pb.tuples.size();
+    // verdict memo: one entry per tuple the device hashed and decided, keyed on (key, signature bytes, device digest).  The block's
+    // table is built here, outside the memo lock, by the pass's worker threads; publishing it is one push under the lock.
+    {
+        auto clk_memo = std::chrono::steady_clock::now();
+        struct MemoClock {
+            BlockVerdicts& o;
+            std::chrono::steady_clock::time_point t0;
+            ~MemoClock() { o.ms_memo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+        } memo_clock{out, clk_memo};
+        std::shared_ptr<BlockMemo> bm;
+        {
+            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+            if (!memo_free_.empty()) {
+                bm = memo_free_.back();
+                memo_free_.pop_back();
+            }
+        }
+        if (!bm) bm.reset(new BlockMemo);
+        bm->seq = opt.block_seq;
+        bm->n = 0;
+        // Which tuples get an entry: the ones the device hashed and decided with a status bccsp.Verify decides itself (0 valid, 1 bad math,
+        // 2 high-S, 3 range).  (Pseudonym signatures: key = Nym.x || Nym.y, digest = SHA-256(message), status 0 valid / 1 proof invalid.
+        // The issuer is not part of the key and need not be: the signed message is the envelope payload, which embeds the creator's
+        // serialized identity - MSP id included - so the same (Nym, signature, message) can only ever be presented under the MSP, hence
+        // the issuer key, it was verified under here.)
+        auto wanted = [&](size_t i) {
+            return out.tuple_hashed[i] && out.tuple_status[i] <= FABGPU_ST_RANGE && pb.tuples[i].sig.len != 0 && pb.tuples[i].sig.len <= 1024;
+        };
+        // Two phases on the pass's workers, like the gates: count (entries, key bytes) per range, meet, then every worker writes its
+        // entries - index, framed key, status - and inserts them into the block's table.  (Selecting and sizing on one thread first cost
+        // 0.3 ms of the 0.6 ms this stage took for a 40 000-tuple block.)
+        std::vector<uint32_t>& sel = sel_scratch;          // reuse: indices of the tuples that get an entry
+        if (sel.size() < nt) sel.resize(nt);
+        const int ft = nt >= 8192 ? std::min(gate_max, 16) : 1;
+        std::vector<uint32_t> cnt_e(ft + 1, 0), cnt_b(ft + 1, 0);
+        std::atomic<int> met(0), cleared(0);
+        BlockMemo* raw = bm.get();
+        uint32_t m = 0;
+        bool too_big = false;
+        auto work = [&](int w) {
+            const size_t lo = nt * w / ft, hi = nt * (w + 1) / ft;
+            uint32_t ce = 0, cb = 0;
+            for (size_t i = lo; i < hi; i++)
+                if (wanted(i)) {
+                    ce++;
+                    cb += (uint32_t)MemoKeyBytes(pb.tuples[i].sig.len, 32);
+                }
+            cnt_e[w + 1] = ce;
+            cnt_b[w + 1] = cb;
+            met.fetch_add(1, std::memory_order_acq_rel);
+            while (met.load(std::memory_order_acquire) < ft) std::this_thread::yield();
+            if (w == 0) {                                  // sizes are known: worker 0 makes room, the others wait for it
+                uint64_t tm = 0, tb = 0;
+                for (int v = 0; v < ft; v++) {
+                    tm += cnt_e[v + 1];
+                    tb += cnt_b[v + 1];
+                }
+                m = (uint32_t)tm;
+                too_big = tb > 0xFFFFFFF0ull;
+                if (m && !too_big) {
+                    uint32_t cap = 16;
+                    while (cap < 2 * m) cap <<= 1;
+                    raw->mask = cap - 1;
+                    if (raw->slots_cap < cap) {
+                        raw->slots.reset(new std::atomic<uint32_t>[cap]);
+                        raw->slots_cap = cap;
+                    }
+                    if (raw->keys_cap < tb) {
+                        raw->keys_cap = (size_t)tb + (size_t)tb / 8;
+                        raw->keys.reset(new uint8_t[raw->keys_cap]);
+                    }
+                    raw->key_off.resize((size_t)m + 1);
+                    raw->key_off[m] = (uint32_t)tb;
+                    raw->status.resize(m);
+                }
+                cleared.store(1, std::memory_order_release);
+            }
+            while (cleared.load(std::memory_order_acquire) < 1) std::this_thread::yield();
+            if (!m || too_big) return;
+            // every worker clears its share of the table, then all meet again before anybody inserts
+            const size_t cap = (size_t)raw->mask + 1;
+            for (size_t k = cap * w / ft; k < cap * (w + 1) / ft; k++) raw->slots[k].store(0, std::memory_order_relaxed);
+            cleared.fetch_add(1, std::memory_order_acq_rel);
+            while (cleared.load(std::memory_order_acquire) < 1 + ft) std::this_thread::yield();
+            uint32_t e = 0, off = 0;
+            for (int v = 0; v < w; v++) {
+                e += cnt_e[v + 1];
+                off += cnt_b[v + 1];
+            }
+            for (size_t i = lo; i < hi; i++) {
+                if (!wanted(i)) continue;
+                const BlockTuple& tp = pb.tuples[i];
+                const uint8_t* sg = block + tp.sig.off;
+                sel[e] = (uint32_t)i;
+                raw->key_off[e] = off;
+                MemoKeyWrite(raw->keys.get() + off, &out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], sg, tp.sig.len, &out.tuple_digest[32 * i], 32);
+                raw->status[e] = out.tuple_status[i];
+                uint32_t at = (uint32_t)MemoHash(sg, tp.sig.len, &out.tuple_digest[32 * i], 32) & raw->mask;
+                for (;;) {                                 // lock-free linear probing: the table is at most half full
+                    uint32_t expect = 0;
+                    if (raw->slots[at].compare_exchange_strong(expect, e + 1, std::memory_order_release, std::memory_order_relaxed)) break;
+                    at = (at + 1) & raw->mask;
+                }
+                off += (uint32_t)MemoKeyBytes(tp.sig.len, 32);
+                e++;
+            }
+        };
+        if (ft == 1) work(0);
+        else run_workers(ft, work);                       // all ft run at once (they meet at spin barriers): worker_pool.h
+        if (too_big) m = 0;
+        bm->n = m;
+        out.memo_seeded = m;
+        if (m) {
+            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+            memo_blocks_.push_back(bm);
+            size_t total = 0;
+            for (const auto& b : memo_blocks_) total += b->n;
+            while (total > memo_cap_ && memo_blocks_.size() > 1) {        // bounded: the oldest block goes first
+                total -= memo_blocks_.front()->n;
+                memo_evicted_.fetch_add(memo_blocks_.front()->n, std::memory_order_relaxed);
+                if (memo_free_.size() < 4) memo_free_.push_back(memo_blocks_.front());
+                memo_blocks_.pop_front();
+            }
+        }
+    }
+}
+
+// ---- the pass with the walk on the device (block_walk_dev.h) ----------------------------------------------------------------
+bool GPUCSP::DeviceWalkEnabled() {
+    static const bool on = [] {
+        const char* e = getenv("FABGPU_PASS_DEVICE_WALK");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// the provider's identity cache as the device sees it: every cached identity, most recently used first
+int GPUCSP::SyncDeviceIdentityTable() const {
+    if (idtab_version_ == id_version_.load(std::memory_order_acquire)) return FABGPU_OK;
+    std::unique_lock<std::shared_timed_mutex> wl(idtab_rw_);
+    std::vector<DevIdEntry> ents;
+    std::vector<uint8_t> bytes;
+    uint64_t ver;
+    {
+        std::lock_guard<std::mutex> lk(idmu_);
+        ver = id_version_.load(std::memory_order_acquire);
+        if (idtab_version_ == ver) return FABGPU_OK;
+        idtab_host_.clear();
+        idtab_host_.reserve(idlru_.size());
+        ents.reserve(idlru_.size());
+        for (const auto& kv : idlru_) {
+            DevIdEntry e;
+            memset(&e, 0, sizeof(e));
+            e.hash = walk::id_hash_host((const uint8_t*)kv.first.data(), (uint32_t)kv.first.size());
+            e.off = (uint32_t)bytes.size();
+            e.len = (uint32_t)kv.first.size();
+            e.key_id = kv.second.key_id >= 0 ? (int32_t)kv.second.key_id : -1;
+            e.p256 = kv.second.p256 ? 1 : 0;
+            if (kv.second.p256) {
+                memcpy(e.qx, kv.second.qx, 32);
+                memcpy(e.qy, kv.second.qy, 32);
+            }
+            bytes.insert(bytes.end(), kv.first.begin(), kv.first.end());
+            ents.push_back(e);
+            IdTabEntry he;
+            he.key = kv.first;
+            he.p256 = kv.second.p256;
+            memcpy(he.qx, e.qx, 32);
+            memcpy(he.qy, e.qy, 32);
+            idtab_host_.push_back(std::move(he));
+        }
+    }
+    int rc = walk_idtab_set(ctx_, (uint32_t)ents.size(), ents.data(), bytes.data(), bytes.size());
+    if (rc != FABGPU_OK) return rc;
+    idtab_version_ = ver;
+    return FABGPU_OK;
+}
+
+int GPUCSP::WalkBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock& pb, const char** why) const {
+    static const char* none = "";
+    const char* dummy;
+    if (!why) why = &dummy;
+    *why = none;
+    if (!block || len == 0) return FABGPU_EINVAL;
+    std::vector<uint32_t> env_spans;
+    std::vector<BlockTuple> block_sigs;
+    if (!OutlineBlock(block, len, pb, env_spans, block_sigs)) return FABGPU_EINVAL;
+    uint64_t tok = 0;
+    int rc = fabgpu_arena_stage(ctx_, block, len, &tok);
+    if (rc != FABGPU_OK) return rc;
+    struct Sizer {
+        ParsedBlock& pb;
+    } sz{pb};
+    WalkRequest rq;
+    rq.stage_token = tok;
+    rq.block_len = len;
+    rq.env_spans = env_spans.data();
+    rq.n_env = (uint32_t)(env_spans.size() / 2);
+    rq.block_sigs = block_sigs.data();
+    rq.n_block_sigs = (uint32_t)block_sigs.size();
+    if (!block_sigs.empty()) {
+        rq.tail = pb.tail.data();
+        rq.tail_base = pb.tail_base;
+        rq.tail_len = (uint32_t)pb.tail.size();
+    }
+    rq.walk_only = true;
+    rq.user = &sz;
+    rq.sizes = [](void* user, const WalkCounts& c, WalkOut& o) {
+        ParsedBlock& p = ((Sizer*)user)->pb;
+        p.tx_type.resize(c.n_tx);
+        p.tx_understood.resize(c.n_tx);
+        p.tuples.resize(c.n_tuples);
+        p.prefixes.resize(c.n_prefixes);
+        p.hash_checks.resize(c.n_checks);
+        o.tx_type = p.tx_type.data();
+        o.tx_understood = p.tx_understood.data();
+        o.tuples = p.tuples.data();
+        o.prefixes = p.prefixes.data();
+        o.checks = p.hash_checks.data();
+        return true;
+    };
+    rc = walk_block_pass(ctx_, rq);
+    if (rc == WALK_DECLINED) {
+        *why = rq.declined_why;
+        return 1;
+    }
+    return rc;
+}
+
+int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock& pb, BlockVerdicts& out, BlockUpload& up, const PassOptions& opt,
+                                   unsigned want, uint32_t cap_tx, uint32_t cap_tuples, uint32_t* n_tuples_out, const char** why) const {
+    static const char* none = "";
+    const char* dummy;
+    if (!why) why = &dummy;
+    *why = none;
+    auto declined = [&](const char* w) {
+        *why = w;
+        return 1;
+    };
+    if (!DeviceWalkEnabled()) return declined("FABGPU_PASS_DEVICE_WALK=0");
+    if (!block || !up.th.joinable()) return declined("the block was not staged ahead (small block)");
+    if (getenv("FABGPU_PASS_SKIP_HASH_CHECKS")) return declined("FABGPU_PASS_SKIP_HASH_CHECKS");
+    {
+        std::lock_guard<std::mutex> lk(idmu_);
+        if (!idemix_msps_.empty()) return declined("idemix MSPs are registered (their creators are recognised on the host)");
+        if (idcache_.empty()) return declined("no identity is known yet");
+    }
+    struct Lease {
+        const GPUCSP* c;
+        std::unique_ptr<PassScratch> p;
+        explicit Lease(const GPUCSP* c_) : c(c_) {
+            std::lock_guard<std::mutex> lk(c->pass_mu_);
+            if (!c->scratch_free_.empty()) {
+                p = std::move(c->scratch_free_.back());
+                c->scratch_free_.pop_back();
+            }
+            if (!p) p.reset(new PassScratch);
+        }
+        ~Lease() {
+            std::lock_guard<std::mutex> lk(c->pass_mu_);
+            if (c->scratch_free_.size() < 4) c->scratch_free_.push_back(std::move(p));
+        }
+    } lease(this);
+    PassScratch& ps = *lease.p;
+    auto clk0 = std::chrono::steady_clock::now();
+    if (!OutlineBlock(block, len, pb, ps.env_spans, ps.block_sigs)) return FABGPU_EINVAL;
+    const bool want_digests = opt.want_digests || opt.seed_memo;
+    const bool want_tuples = (want & WANT_TUPLES) || opt.seed_memo, want_qxy = (want & WANT_QXY) || opt.seed_memo;
+    const uint32_t n_skipped = opt.block_sigs ? 0 : (uint32_t)ps.block_sigs.size();   // reported (TUPLE_ST_SKIPPED), not submitted
+    int rc = SyncDeviceIdentityTable();
+    if (rc != FABGPU_OK) return rc;
+    std::shared_lock<std::shared_timed_mutex> rl(idtab_rw_);
+    if (idtab_version_ != id_version_.load(std::memory_order_acquire)) return declined("the identity cache changed under the pass");
+    out.ms_gates = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk0).count();   // (outline + table sync)
+    auto clk1 = std::chrono::steady_clock::now();
+    const uint64_t tok = up.join();
+    out.ms_upload_wait = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk1).count();
+    if (!tok) return declined("the upload failed");
+    struct Sizer {
+        ParsedBlock& pb;
+        BlockVerdicts& out;
+        PassScratch& ps;
+        bool want_tuples, want_digests;
+        uint32_t cap_tx, cap_tuples, n_skipped;
+        uint32_t n_tuples = 0;
+        bool too_big = false;
+    } sz{pb, out, ps, want_tuples, want_digests, cap_tx, cap_tuples, n_skipped};
+    WalkRequest rq;
+    rq.stage_token = tok;
+    rq.block_len = len;
+    rq.env_spans = ps.env_spans.data();
+    rq.n_env = (uint32_t)(ps.env_spans.size() / 2);
+    if (opt.block_sigs && !ps.block_sigs.empty()) {
+        rq.block_sigs = ps.block_sigs.data();
+        rq.n_block_sigs = (uint32_t)ps.block_sigs.size();
+        rq.tail = pb.tail.data();
+        rq.tail_base = pb.tail_base;
+        rq.tail_len = (uint32_t)pb.tail.size();
+    }
+    rq.user = &sz;
+    rq.sizes = [](void* user, const WalkCounts& c, WalkOut& o) {
+        Sizer& z = *(Sizer*)user;
+        const size_t nt = (size_t)c.n_tuples + z.n_skipped;
+        z.n_tuples = (uint32_t)nt;
+        if (c.n_tx > z.cap_tx || nt > z.cap_tuples) {
+            z.too_big = true;
+            return false;
+        }
+        z.out.tx_flags.resize(c.n_tx);
+        z.out.tx_type.resize(c.n_tx);
+        z.pb.tx_type.resize(c.n_tx);
+        z.pb.tx_understood.resize(c.n_tx);
+        z.out.tuple_status.resize(nt);
+        z.out.tuple_hashed.resize(nt);
+        o.tx_flags = z.out.tx_flags.data();
+        o.tx_type = z.out.tx_type.data();
+        o.tx_understood = z.pb.tx_understood.data();
+        o.tuple_status = z.out.tuple_status.data();
+        o.tuple_hashed = z.out.tuple_hashed.data();
+        z.ps.id_idx.resize(nt);                                          // (4 bytes per tuple: who was named, for the cache's bookkeeping)
+        o.id_idx = z.ps.id_idx.data();
+        if (z.want_tuples) {
+            z.pb.tuples.resize(nt);
+            o.tuples = z.pb.tuples.data();
+        }
+        if (z.want_digests) {
+            z.out.tuple_digest.resize(nt * 32);
+            o.tuple_digest = z.out.tuple_digest.data();
+        } else {
+            z.out.tuple_digest.clear();
+        }
+        return true;
+    };
+    auto clk2 = std::chrono::steady_clock::now();
+    rc = walk_block_pass(ctx_, rq);
+    out.ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk2).count();
+    if (n_tuples_out) *n_tuples_out = sz.n_tuples;
+    if (rc == WALK_DECLINED) return declined(rq.declined_why);
+    if (rc == FABGPU_ETOOBIG && sz.too_big) return FABGPU_ETOOBIG;     // pb.n_tx / *n_tuples_out say what to make room for
+    if (rc != FABGPU_OK) return rc;
+    const size_t nt = sz.n_tuples, nd = nt - n_skipped;
+    out.n_tx = pb.n_tx;
+    memcpy(pb.tx_type.data(), out.tx_type.data(), pb.n_tx);
+    out.distinct_identities = 0;
+    out.ms_nym = out.ms_memo = 0;
+    out.memo_seeded = 0;
+    out.n_block_sigs = pb.n_block_sigs;
+    out.block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
+    out.n_keyed = rq.all_keyed ? rq.summary.n_submitted : 0;
+    for (size_t i = nd; i < nt; i++) {                                   // block signatures the caller asked not to verify
+        out.tuple_status[i] = TUPLE_ST_SKIPPED;
+        out.tuple_hashed[i] = 0;
+        ps.id_idx[i] = 0xFFFFFFFFu;
+        if (want_tuples) pb.tuples[i] = ps.block_sigs[i - nd];
+        if (want_digests) memset(&out.tuple_digest[32 * i], 0, 32);
+    }
+    if (want_tuples) {
+        out.tuple_tx.resize(nt);
+        out.tuple_kind.resize(nt);
+        for (size_t i = 0; i < nt; i++) {
+            out.tuple_tx[i] = pb.tuples[i].tx;
+            out.tuple_kind[i] = pb.tuples[i].kind;
+        }
+    } else {
+        out.tuple_tx.clear();
+        out.tuple_kind.clear();
+    }
+    if (want_qxy) {                                                      // the key of tuple i = the key of the cache entry the device matched
+        out.tuple_qxy.resize(nt * 64);
+        for (size_t i = 0; i < nt; i++) {
+            const uint32_t ix = ps.id_idx[i];
+            if (ix < idtab_host_.size() && idtab_host_[ix].p256) {
+                memcpy(&out.tuple_qxy[64 * i], idtab_host_[ix].qx, 32);
+                memcpy(&out.tuple_qxy[64 * i + 32], idtab_host_[ix].qy, 32);
+            } else {
+                memset(&out.tuple_qxy[64 * i], 0, 64);
+            }
+        }
+    } else {
+        out.tuple_qxy.clear();
+    }
+    if (want_digests)
+        for (size_t i = 0; i < nt; i++)
+            if (!out.tuple_hashed[i]) memset(&out.tuple_digest[32 * i], 0, 32);   // as the host pass reports them
+    // What the host pass does per tuple for the cache - count who was named (a device comb table is earned by being named
+    // id_register_after_ times) and keep the LRU order fresh - from the identity indices, when they came back.
+    std::vector<std::string> to_register;
+    if (!idtab_host_.empty()) {
+        std::vector<uint32_t> hits(idtab_host_.size(), 0);
+        for (size_t i = 0; i < nd; i++)
+            if (ps.id_idx[i] < hits.size()) hits[ps.id_idx[i]]++;
+        std::lock_guard<std::mutex> lk(idmu_);
+        for (size_t k = 0; k < hits.size(); k++) {
+            if (!hits[k]) continue;
+            auto it = idcache_.find(idtab_host_[k].key);
+            if (it == idcache_.end()) continue;
+            idlru_.splice(idlru_.begin(), idlru_, it->second);
+            CachedIdentity& c = it->second->second;
+            c.hits += hits[k];
+            if (c.p256 && c.key_id < 0 && !c.registering && c.hits >= id_register_after_ && id_registered_ < id_max_registered_) {
+                c.registering = true;
+                id_registered_++;
+                to_register.push_back(it->first);
+            }
+        }
+    }
+    rl.unlock();
+    RegisterQueued(to_register);
+    static const int gate_max = [] { const char* e = getenv("FABGPU_PASS_GATE_THREADS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    if (opt.seed_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max);
+    return 0;
 }
 
 Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, BlockUpload* up, const PassOptions& opt) const {
@@ -815,6 +1259,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                                 idcache_.erase(idlru_.back().first);             // registered: tables are bounded by id_max_registered_)
                                 idlru_.pop_back();
                             }
+                            id_version_.fetch_add(1, std::memory_order_release);   // (the device's copy of the cache is stale now)
                         } else {
                             ci = it->second->second;
                         }
@@ -1157,154 +1602,8 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                           : sw[t]        ? TX_NEEDS_SW
                                          : TX_ALL_SIGNATURES_VALID;
     }
-    // identities that earned a device comb table during this block: built and uploaded outside idmu_ (6 ms of host work each)
-    {
-        std::vector<std::pair<std::string, CachedIdentity>> todo;
-        {
-            std::lock_guard<std::mutex> lk(idmu_);
-            for (const std::string& k : to_register) {
-                auto it = idcache_.find(k);
-                if (it != idcache_.end()) todo.emplace_back(k, it->second->second);
-                else id_registered_--;                     // evicted meanwhile
-            }
-        }
-        for (auto& kv : todo) {
-            uint32_t id = 0;
-            const bool ok = fabgpu_p256_key_register(ctx_, kv.second.qx, kv.second.qy, &id) == FABGPU_OK;
-            std::lock_guard<std::mutex> lk(idmu_);
-            auto it = idcache_.find(kv.first);
-            if (it != idcache_.end()) {
-                it->second->second.registering = false;
-                if (ok) it->second->second.key_id = id;
-            }
-            if (!ok) id_registered_--;
-        }
-    }
-    // verdict memo: one entry per tuple the device hashed and decided, keyed on (key, signature bytes, device digest).  The block's
-    // table is built here, outside the memo lock, by the pass's worker threads; publishing it is one push under the lock.
-    if (opt.seed_memo) {
-        auto clk_memo = std::chrono::steady_clock::now();
-        struct MemoClock {
-            BlockVerdicts& o;
-            std::chrono::steady_clock::time_point t0;
-            ~MemoClock() { o.ms_memo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
-        } memo_clock{out, clk_memo};
-        std::shared_ptr<BlockMemo> bm;
-        {
-            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
-            if (!memo_free_.empty()) {
-                bm = memo_free_.back();
-                memo_free_.pop_back();
-            }
-        }
-        if (!bm) bm.reset(new BlockMemo);
-        bm->seq = opt.block_seq;
-        bm->n = 0;
-        // Which tuples get an entry: the ones the device hashed and decided with a status bccsp.Verify decides itself (0 valid, 1 bad math,
-        // 2 high-S, 3 range).  (Pseudonym signatures: key = Nym.x || Nym.y, digest = SHA-256(message), status 0 valid / 1 proof invalid.
-        // The issuer is not part of the key and need not be: the signed message is the envelope payload, which embeds the creator's
-        // serialized identity - MSP id included - so the same (Nym, signature, message) can only ever be presented under the MSP, hence
-        // the issuer key, it was verified under here.)
-        auto wanted = [&](size_t i) {
-            return out.tuple_hashed[i] && out.tuple_status[i] <= FABGPU_ST_RANGE && pb.tuples[i].sig.len != 0 && pb.tuples[i].sig.len <= 1024;
-        };
-        // Two phases on the pass's workers, like the gates: count (entries, key bytes) per range, meet, then every worker writes its
-        // entries - index, framed key, status - and inserts them into the block's table.  (Selecting and sizing on one thread first cost
-        // 0.3 ms of the 0.6 ms this stage took for a 40 000-tuple block.)
-        std::vector<uint32_t>& sel = ps_.sub;              // reuse: indices of the tuples that get an entry
-        if (sel.size() < nt) sel.resize(nt);
-        const int ft = nt >= 8192 ? std::min(gate_max, 16) : 1;
-        std::vector<uint32_t> cnt_e(ft + 1, 0), cnt_b(ft + 1, 0);
-        std::atomic<int> met(0), cleared(0);
-        BlockMemo* raw = bm.get();
-        uint32_t m = 0;
-        bool too_big = false;
-        auto work = [&](int w) {
-            const size_t lo = nt * w / ft, hi = nt * (w + 1) / ft;
-            uint32_t ce = 0, cb = 0;
-            for (size_t i = lo; i < hi; i++)
-                if (wanted(i)) {
-                    ce++;
-                    cb += (uint32_t)MemoKeyBytes(pb.tuples[i].sig.len, 32);
-                }
-            cnt_e[w + 1] = ce;
-            cnt_b[w + 1] = cb;
-            met.fetch_add(1, std::memory_order_acq_rel);
-            while (met.load(std::memory_order_acquire) < ft) std::this_thread::yield();
-            if (w == 0) {                                  // sizes are known: worker 0 makes room, the others wait for it
-                uint64_t tm = 0, tb = 0;
-                for (int v = 0; v < ft; v++) {
-                    tm += cnt_e[v + 1];
-                    tb += cnt_b[v + 1];
-                }
-                m = (uint32_t)tm;
-                too_big = tb > 0xFFFFFFF0ull;
-                if (m && !too_big) {
-                    uint32_t cap = 16;
-                    while (cap < 2 * m) cap <<= 1;
-                    raw->mask = cap - 1;
-                    if (raw->slots_cap < cap) {
-                        raw->slots.reset(new std::atomic<uint32_t>[cap]);
-                        raw->slots_cap = cap;
-                    }
-                    if (raw->keys_cap < tb) {
-                        raw->keys_cap = (size_t)tb + (size_t)tb / 8;
-                        raw->keys.reset(new uint8_t[raw->keys_cap]);
-                    }
-                    raw->key_off.resize((size_t)m + 1);
-                    raw->key_off[m] = (uint32_t)tb;
-                    raw->status.resize(m);
-                }
-                cleared.store(1, std::memory_order_release);
-            }
-            while (cleared.load(std::memory_order_acquire) < 1) std::this_thread::yield();
-            if (!m || too_big) return;
-            // every worker clears its share of the table, then all meet again before anybody inserts
-            const size_t cap = (size_t)raw->mask + 1;
-            for (size_t k = cap * w / ft; k < cap * (w + 1) / ft; k++) raw->slots[k].store(0, std::memory_order_relaxed);
-            cleared.fetch_add(1, std::memory_order_acq_rel);
-            while (cleared.load(std::memory_order_acquire) < 1 + ft) std::this_thread::yield();
-            uint32_t e = 0, off = 0;
-            for (int v = 0; v < w; v++) {
-                e += cnt_e[v + 1];
-                off += cnt_b[v + 1];
-            }
-            for (size_t i = lo; i < hi; i++) {
-                if (!wanted(i)) continue;
-                const BlockTuple& tp = pb.tuples[i];
-                const uint8_t* sg = block + tp.sig.off;
-                sel[e] = (uint32_t)i;
-                raw->key_off[e] = off;
-                MemoKeyWrite(raw->keys.get() + off, &out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], sg, tp.sig.len, &out.tuple_digest[32 * i], 32);
-                raw->status[e] = out.tuple_status[i];
-                uint32_t at = (uint32_t)MemoHash(sg, tp.sig.len, &out.tuple_digest[32 * i], 32) & raw->mask;
-                for (;;) {                                 // lock-free linear probing: the table is at most half full
-                    uint32_t expect = 0;
-                    if (raw->slots[at].compare_exchange_strong(expect, e + 1, std::memory_order_release, std::memory_order_relaxed)) break;
-                    at = (at + 1) & raw->mask;
-                }
-                off += (uint32_t)MemoKeyBytes(tp.sig.len, 32);
-                e++;
-            }
-        };
-        if (ft == 1) work(0);
-        else run_workers(ft, work);                       // all ft run at once (they meet at spin barriers): worker_pool.h
-        if (too_big) m = 0;
-        bm->n = m;
-        out.memo_seeded = m;
-        if (m) {
-            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
-            memo_blocks_.push_back(bm);
-            size_t total = 0;
-            for (const auto& b : memo_blocks_) total += b->n;
-            while (total > memo_cap_ && memo_blocks_.size() > 1) {        // bounded: the oldest block goes first
-                total -= memo_blocks_.front()->n;
-                memo_evicted_.fetch_add(memo_blocks_.front()->n, std::memory_order_relaxed);
-                if (memo_free_.size() < 4) memo_free_.push_back(memo_blocks_.front());
-                memo_blocks_.pop_front();
-            }
-        }
-    }
+    RegisterQueued(to_register);
+    if (opt.seed_memo) SeedMemo(block, pb, out, opt, ps_.sub, gate_max);
     return Error();
 }
 

@@ -133,6 +133,20 @@ class GPUCSP {
     // travels with the submission.
     Error PreVerifyParsed(const uint8_t* block, const ParsedBlock& parsed, BlockVerdicts& out, BlockUpload* up = nullptr,
                           const PassOptions& opt = PassOptions()) const;
+    // The same pass with the envelope walk, the signature gates and the identity lookup ON THE DEVICE (block_walk_dev.h): the host lists
+    // the envelopes, the block is read where StartBlockUpload put it, only flags (and, when asked for, tuple records / digests) come
+    // back.  Serves blocks whose identities the provider has already met and whose signatures have the common DER shape; anything else
+    // is DECLINED (returns 1, *why says why, nothing was written) and the caller takes ParseBlock + PreVerifyParsed, which also learns
+    // the new identities.  0: done (`out` as PreVerifyParsed fills it; parsed.tuples too with WANT_TUPLES); < 0: FABGPU_E* - with
+    // FABGPU_ETOOBIG parsed.n_tx / *n_tuples hold what the caller must make room for.
+    enum : unsigned { WANT_TUPLES = 1, WANT_QXY = 2 };   // what the caller reads besides flags and statuses: tuple records; keys
+    int PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock& parsed, BlockVerdicts& out, BlockUpload& up, const PassOptions& opt,
+                               unsigned want, uint32_t cap_tx, uint32_t cap_tuples, uint32_t* n_tuples, const char** why) const;
+    // The device walker alone (tests: it must produce what ParseBlock produces, record for record): fills `parsed` like ParseBlock does,
+    // except first_channel_id.  0 done, 1 declined, < 0 FABGPU_E*.
+    int WalkBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock& parsed, const char** why) const;
+    // FABGPU_PASS_DEVICE_WALK=0 keeps every block on the host walk (A/B runs); default on
+    static bool DeviceWalkEnabled();
     // ---- x509 certificate signatures ----
     // The arithmetic of crypto/x509 Certificate.CheckSignatureFrom(parent) for ecdsa-with-SHA256 certificates under P-256 issuer keys -
     // what msp identity validation runs per chain link on an msp-cache miss (msp/mspimplvalidate.go:21-52 -> msp/mspimpl.go:721-739 ->
@@ -197,6 +211,20 @@ class GPUCSP {
     mutable std::unordered_map<std::string, IdList::iterator> idcache_;
     mutable size_t id_max_ = 4096, id_max_registered_ = 256, id_registered_ = 0;
     mutable uint32_t id_register_after_ = 64;
+    // The device's copy of this cache (block_walk_dev.h walk_idtab_set): rebuilt whenever id_version_ moved.  Passes hold idtab_rw_
+    // shared from the version check until they have translated the device's identity indices back; a rebuild holds it exclusively.
+    mutable std::atomic<uint64_t> id_version_{1};
+    mutable std::shared_timed_mutex idtab_rw_;
+    mutable std::atomic<uint64_t> idtab_version_{0};
+    struct IdTabEntry {
+        std::string key;                    // the SerializedIdentity bytes
+        bool p256;
+        uint8_t qx[32], qy[32];
+    };
+    mutable std::vector<IdTabEntry> idtab_host_;
+    int SyncDeviceIdentityTable() const;
+    void RegisterQueued(const std::vector<std::string>& to_register) const;
+    void SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, const PassOptions& opt, std::vector<uint32_t>& sel_scratch, int gate_max) const;
     // verdict memo
     // One table per BLOCK (seeded once by the pass, dropped whole when the block's validation returns): an open-addressed index over
     // length-framed keys stored back to back - no allocation per entry, filled by the pass's worker threads in parallel (a
@@ -236,6 +264,9 @@ class GPUCSP {
         std::vector<uint32_t> nym_idx, nym_sp, nym_iss;
         std::vector<uint8_t> nym_fields, nym_st;
         std::vector<uint64_t> nym_bits;
+        // the device walk: envelope list, block-signature tuples, identity indices per tuple
+        std::vector<uint32_t> env_spans, id_idx;
+        std::vector<BlockTuple> block_sigs;
     };
     struct CoReqV : CoalescedBase {
         VerifyItem item;

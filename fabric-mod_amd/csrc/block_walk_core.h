@@ -316,6 +316,64 @@ WALK_HD inline void walk_envelope(const uint8_t* block, const uint8_t* env, size
     understood = 1;
 }
 
+// ---- the two emitters of the device walk (block_walk_kernels.hip; the host runs them in tests) ---------------------------------
+// First run: count.  Then an exclusive prefix sum over the envelopes assigns every envelope its ranges.  Second run: write.
+struct CountEmitter {
+    uint32_t nt = 0, np = 0, nc = 0;
+    uint64_t gb = 0;
+    uint32_t m_nt = 0, m_np = 0, m_nc = 0;
+    uint64_t m_gb = 0;
+    WALK_HD void mark() { m_nt = nt; m_np = np; m_nc = nc; m_gb = gb; }
+    WALK_HD void rollback() { nt = m_nt; np = m_np; nc = m_nc; gb = m_gb; }
+    WALK_HD void add_tuple(const BlockTuple&) { nt++; }
+    WALK_HD int32_t add_prefix(const Span&) { return (int32_t)np++; }
+    WALK_HD void add_check(const BlockHashCheck& c) {
+        nc++;
+        gb += (uint64_t)c.piece[0].len + c.piece[1].len + c.piece[2].len;
+    }
+    WALK_HD void channel_id(const uint8_t*, size_t) {}
+};
+
+// Writes at base + k while k is below what the counting run reserved for this envelope: a transaction that is rolled back reserved
+// nothing, so its transient records never land in a neighbour's range.
+struct WriteEmitter {
+    BlockTuple* tuples;
+    uint32_t* pre_off2;
+    BlockHashCheck* checks;
+    uint32_t* gather_spans;
+    uint32_t* gather_off;
+    uint32_t base_t, base_p, base_c, base_g;
+    uint32_t lim_t, lim_p, lim_c;
+    uint32_t nt = 0, np = 0, nc = 0, g = 0;
+    WALK_HD void mark() {}
+    WALK_HD void rollback() { nt = np = nc = g = 0; }    // (mark() precedes the first record of an envelope)
+    WALK_HD void add_tuple(const BlockTuple& t) {
+        if (nt < lim_t) tuples[base_t + nt] = t;
+        nt++;
+    }
+    WALK_HD int32_t add_prefix(const Span& s) {
+        if (np < lim_p) {
+            pre_off2[2 * (size_t)(base_p + np)] = s.len ? s.off : 0;
+            pre_off2[2 * (size_t)(base_p + np) + 1] = s.len ? s.off + s.len : 0;
+        }
+        return (int32_t)(base_p + np++);
+    }
+    WALK_HD void add_check(const BlockHashCheck& c) {
+        if (nc < lim_c) {
+            const size_t j = base_c + nc;
+            checks[j] = c;
+            gather_off[j] = base_g + g;
+            for (int p = 0; p < 3; p++) {
+                gather_spans[6 * j + 2 * p] = c.piece[p].len ? c.piece[p].off : 0;
+                gather_spans[6 * j + 2 * p + 1] = c.piece[p].len ? c.piece[p].off + c.piece[p].len : 0;
+            }
+        }
+        g += c.piece[0].len + c.piece[1].len + c.piece[2].len;
+        nc++;
+    }
+    WALK_HD void channel_id(const uint8_t*, size_t) {}
+};
+
 // ---- the signature gate of the common DER shape ----------------------------------------------------------------------------
 // bccsp/sw/ecdsa.go:41-57 before any arithmetic: UnmarshalECDSASignature (bccsp/utils/ecdsa.go:43-67: asn1.Unmarshal into
 // {R, S *big.Int}, R and S > 0) and IsLowS (bccsp/utils/ecdsa.go:84-92).  This decides the one shape every signer produces -

@@ -1,0 +1,145 @@
+// The block-level pre-verify pass ON THE DEVICE (private interface between bccsp_host.cpp, fabgpu_api.hip and block_walk_kernels.hip;
+// the C ABI above it is unchanged: fabgpu_csp_block_preverify / _preverify2 of include/fabgpu_bccsp.h take this route for blocks it
+// can serve and the host walk for the rest).
+//
+// What moved: the envelope walk (core/common/validation/msgvalidation.go:258-298, statebased/validator_keylevel.go:246-258 tuples;
+// protoutil CheckTxID / GetProposalHash2 inputs), the signature gates of the common DER shape (bccsp/utils/ecdsa.go:43-92), the
+// identity -> key lookup (the msp identity cache, msp/cache/cache.go), the submission arrays of the fused launch, the comparison of the
+// TxID / proposal-hash digests and the per-transaction flags.  What the host keeps: the outer framing and the serial list of envelope
+// starts (block_prepass.h OutlineBlock), the orderers' block-signature tuples with their tail, the identity cache itself (decoding a
+// certificate nobody has seen yet), the verdict memo.
+//
+// Data layout in HBM for one pass (all sized by the counts of the first kernel):
+//     block bytes              as uploaded by fabgpu_arena_stage (read-only; tail behind it at tail_base)
+//     env_spans   u32[2 n_env]      (offset, length) of every envelope                                   H2D  8 B / tx
+//     counts      uint4[n_env]      tuples, prefixes, hash checks, gathered bytes per envelope            device only
+//     bases       uint4[n_env]      exclusive prefix sums of the above                                    device only
+//     tuples      BlockTuple[n]     44 B records                                                          D2H only when the caller wants spans / memo
+//     off2 u32[2n]  pre_idx u32[n]  key_id u32[n]  qx qy r s u8[32 n]  gate_st u8[n]                       device only (the fused launch reads them)
+//     pre_off2    u32[2 n_pre]      checks BlockHashCheck[n_chk]  gather_spans u32[6 n_chk]  gather_off u32[n_chk + 1]
+//     verdict words, status bytes, digests 32 n, gather digests 32 n_chk                                   digests D2H only when wanted
+//     tx_mask u32[n_tx] -> tx_flags u8[n_tx], tx_type u8[n_tx]                                             D2H  2 B / tx
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "block_walk_core.h"
+
+struct fabgpu_ctx;
+
+namespace fab {
+
+// One identity the provider has met: the host's cache entry as the device sees it.
+struct DevIdEntry {
+    uint64_t hash;        // walk::id_hash_host of the SerializedIdentity bytes
+    uint32_t off, len;    // those bytes in the table's byte arena
+    int32_t key_id;       // >= 0: a registered comb table (fabgpu_p256_key_register)
+    uint32_t p256;        // 1: (qx, qy) is an on-curve P-256 key; 0: identity.Verify needs bccsp/sw (TUPLE_ST_NEEDS_SW)
+    uint8_t qx[32], qy[32];
+};
+static_assert(sizeof(DevIdEntry) == 88, "uploaded as raw bytes");
+
+// summary words the gate kernel accumulates (device -> host, one small copy)
+struct WalkSummary {
+    uint32_t n_unknown_identity;   // tuples whose identity is not in the device table: the host walk takes the block (and learns them)
+    uint32_t n_declined;           // signatures the fast gate declines: the host's general parser decides
+    uint32_t n_submitted;          // tuples the device decides
+    uint32_t n_unkeyed;            // ... of which without a registered comb table (any: the fresh-key kernel serves the block)
+};
+
+struct WalkTotals {
+    uint32_t tuples, prefixes, checks, pad;
+    uint64_t gather_bytes;
+};
+
+// device pointers of one pass (block_walk_kernels.hip launchers; every pointer is device memory)
+struct WalkArrays {
+    const uint8_t* block = nullptr;
+    uint32_t block_len = 0;          // bytes of the marshalled block
+    uint32_t arena_len = 0;          // block + tail extent (spans of block-signature tuples reach into the tail)
+    const uint32_t* env_spans = nullptr;
+    uint32_t n_env = 0;
+    uint4* counts = nullptr;
+    uint4* bases = nullptr;
+    WalkTotals* totals = nullptr;
+    uint8_t* tx_type = nullptr;
+    uint8_t* tx_understood = nullptr;
+    // sized after the totals are known
+    bccsp::BlockTuple* tuples = nullptr;
+    uint32_t n_tuples = 0;           // device-emitted + appended block signatures
+    uint32_t* pre_off2 = nullptr;
+    bccsp::BlockHashCheck* checks = nullptr;
+    uint32_t* gather_spans = nullptr;
+    uint32_t* gather_off = nullptr;
+    uint32_t* id_idx = nullptr;
+    uint32_t* off2 = nullptr;
+    uint32_t* pre_idx = nullptr;
+    uint32_t* key_id = nullptr;
+    uint8_t *qx = nullptr, *qy = nullptr, *r = nullptr, *s = nullptr;
+    uint8_t* gate_st = nullptr;
+    WalkSummary* summary = nullptr;
+    // identity table
+    const uint32_t* id_slots = nullptr;
+    uint32_t id_mask = 0;
+    const DevIdEntry* id_entries = nullptr;
+    const uint8_t* id_bytes = nullptr;
+    // results
+    const uint64_t* verdict_bits = nullptr;
+    const uint8_t* dev_status = nullptr;
+    uint8_t* tuple_status = nullptr;
+    uint8_t* tuple_hashed = nullptr;
+    const uint8_t* gather_digests = nullptr;
+    uint32_t* tx_mask = nullptr;
+    uint8_t* tx_flags = nullptr;
+};
+
+hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st);                       // counts, tx_type, tx_understood; then the scan
+hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st);   // tuples, prefixes, checks, gather spans / offsets
+hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);                        // identity lookup + gates + submission arrays + summary
+hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st);    // statuses, digest comparisons, per-transaction flags
+
+// ---- host side (fabgpu_api.hip) ----
+// Replace the device's identity table (entries + their bytes); the table is rebuilt by the provider whenever its cache changes.
+int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const uint8_t* bytes, size_t nbytes);
+
+constexpr int WALK_DECLINED = 100;   // not an error: this block is for the host walk (why: WalkRequest::declined_why)
+
+struct WalkCounts {
+    uint32_t n_tx = 0, n_tuples = 0, n_prefixes = 0, n_checks = 0;
+};
+// host arrays the pass fills; asked for through WalkRequest::sizes once the counts are known (null = not wanted)
+struct WalkOut {
+    uint8_t* tx_flags = nullptr;          // n_tx
+    uint8_t* tx_type = nullptr;           // n_tx
+    uint8_t* tx_understood = nullptr;     // n_tx
+    uint8_t* tuple_status = nullptr;      // n_tuples
+    uint8_t* tuple_hashed = nullptr;      // n_tuples
+    bccsp::BlockTuple* tuples = nullptr;  // n_tuples
+    uint32_t* id_idx = nullptr;           // n_tuples: index into the entries of walk_idtab_set (the key of the tuple's identity)
+    uint8_t* tuple_digest = nullptr;      // 32 n_tuples
+    bccsp::Span* prefixes = nullptr;      // n_prefixes            (tests)
+    bccsp::BlockHashCheck* checks = nullptr;   // n_checks         (tests)
+};
+struct WalkRequest {
+    uint64_t stage_token = 0;             // the block, uploaded with fabgpu_arena_stage
+    size_t block_len = 0;
+    const uint32_t* env_spans = nullptr;  // host
+    uint32_t n_env = 0;
+    const bccsp::BlockTuple* block_sigs = nullptr;   // appended behind the device's tuples
+    uint32_t n_block_sigs = 0;
+    const uint8_t* tail = nullptr;
+    uint32_t tail_base = 0, tail_len = 0;
+    bool walk_only = false;               // stop after the walk (tests: the device walker against the host walker)
+    void* user = nullptr;
+    bool (*sizes)(void* user, const WalkCounts& c, WalkOut& out) = nullptr;   // false: the caller has no room (FABGPU_ETOOBIG)
+    // out
+    WalkSummary summary = {0, 0, 0, 0};
+    bool all_keyed = false;
+    const char* declined_why = "";
+    double ms_walk = 0, ms_gate = 0, ms_verify = 0;
+};
+// FABGPU_OK, WALK_DECLINED, or a negative FABGPU_E*
+int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq);
+
+}  // namespace fab

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <map>
@@ -15,6 +16,7 @@
 
 #include "../../include/fabgpu.h"
 #include "kernels.h"
+#include "block_walk_dev.h"
 #include "bn_tables29.h"
 #include "p256_tables29.h"
 
@@ -39,6 +41,41 @@ struct Buf {  // growable pinned-host + device pair
         if (h) hipHostFree(h);
         if (d) hipFree(d);
         h = d = nullptr;
+        cap = 0;
+    }
+};
+
+struct DevBuf {  // growable device-only buffer
+    void* d = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return FABGPU_OK;
+        release();
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&d, want) != hipSuccess) { d = nullptr; return FABGPU_ENOMEM; }
+        cap = want;
+        return FABGPU_OK;
+    }
+    void release() {
+        if (d) hipFree(d);
+        d = nullptr;
+        cap = 0;
+    }
+};
+struct PinBuf {  // growable pinned host buffer
+    void* h = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return FABGPU_OK;
+        release();
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipHostMalloc(&h, want, hipHostMallocDefault) != hipSuccess) { h = nullptr; return FABGPU_ENOMEM; }
+        cap = want;
+        return FABGPU_OK;
+    }
+    void release() {
+        if (h) hipHostFree(h);
+        h = nullptr;
         cap = 0;
     }
 };
@@ -115,6 +152,13 @@ struct fabgpu_ctx {
     Buf keyed;        // staging of the keyed host-pointer entry point: key_id | e | r | s
     Buf pre;          // staging of prefixed batches: pre_off | pre_idx | mid-states
     Buf tailbuf;      // staging of an identity batch's tail when the arena itself bypasses the pinned buffer
+    // the block pass on the device (block_walk_dev.h): per-envelope arrays, per-tuple arrays, pinned staging for what travels, and
+    // the table of identities the provider has met (slots | entries | bytes in one allocation, swapped whole under mu)
+    DevBuf walk_env, walk_tup;
+    PinBuf walk_pin;
+    void* d_idtab = nullptr;
+    uint32_t idtab_n = 0, idtab_mask = 0;
+    size_t idtab_entries_off = 0, idtab_bytes_off = 0;
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
     int acquire_qws(size_t bytes, size_t* idx, void** p, hipStream_t st);
     void release_qws(size_t idx, hipStream_t st) {
@@ -280,6 +324,10 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->keyed.release();
         ctx->pre.release();
         if (ctx->d_gscr) hipFree(ctx->d_gscr);
+        ctx->walk_env.release();
+        ctx->walk_tup.release();
+        ctx->walk_pin.release();
+        if (ctx->d_idtab) hipFree(ctx->d_idtab);
         for (auto& sl : ctx->staged_slots)
             if (sl.d) hipFree(sl.d);
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
@@ -1154,3 +1202,278 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// the block pass on the device (block_walk_dev.h)
+// ------------------------------------------------------------------------------------------------
+namespace fab {
+
+int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const uint8_t* bytes, size_t nbytes) {
+    if (!ctx || (n && (!entries || !bytes))) return FABGPU_EINVAL;
+    if (n > (1u << 20) || nbytes > 0x7FFFFFF0ull) return FABGPU_ETOOBIG;
+    uint32_t cap = 16;
+    while (cap < 2 * n) cap <<= 1;
+    std::vector<uint32_t> slots(cap, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        if ((uint64_t)entries[i].off + entries[i].len > nbytes) return FABGPU_EINVAL;
+        uint32_t at = (uint32_t)entries[i].hash & (cap - 1);
+        while (slots[at]) at = (at + 1) & (cap - 1);
+        slots[at] = i + 1;
+    }
+    const size_t eo = round_up((size_t)cap * 4, 256), bo = round_up(eo + (size_t)n * sizeof(DevIdEntry), 256), total = bo + round_up(nbytes, 64) + 64;
+    DeviceGuard g(ctx->device);
+    void* d = nullptr;
+    if (ctx->fault == 2 || hipMalloc(&d, total) != hipSuccess) return FABGPU_ENOMEM;
+    hipError_t err = hipMemcpy(d, slots.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
+    if (err == hipSuccess && n) err = hipMemcpy((uint8_t*)d + eo, entries, (size_t)n * sizeof(DevIdEntry), hipMemcpyHostToDevice);
+    if (err == hipSuccess && nbytes) err = hipMemcpy((uint8_t*)d + bo, bytes, nbytes, hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        hipFree(d);
+        return hip_to_rc(err);
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);             // no pass is in flight while mu is held (a pass synchronises before it returns)
+    if (ctx->d_idtab) hipFree(ctx->d_idtab);
+    ctx->d_idtab = d;
+    ctx->idtab_n = n;
+    ctx->idtab_mask = cap - 1;
+    ctx->idtab_entries_off = eo;
+    ctx->idtab_bytes_off = bo;
+    return FABGPU_OK;
+}
+
+int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
+    if (!ctx || !rq.sizes || !rq.env_spans || rq.stage_token == 0) return FABGPU_EINVAL;
+    if (rq.n_block_sigs && !rq.block_sigs) return FABGPU_EINVAL;
+    const bool has_tail = rq.tail != nullptr && rq.tail_len != 0;
+    if (has_tail && ((rq.tail_base & 63u) || (uint64_t)rq.tail_base + rq.tail_len > 0xFFFFFFF0ull)) return FABGPU_EINVAL;
+    auto decline = [&](const char* why) {
+        rq.declined_why = why;
+        return WALK_DECLINED;
+    };
+    if (rq.n_env == 0) return decline("no envelopes");
+    if (rq.n_env > 0x7FFFFFF0u / 64) return FABGPU_ETOOBIG;
+    // the staged block: its slot stays locked - the stager kept out of it - until this pass has run
+    fabgpu_ctx::Staged* sl = nullptr;
+    for (auto& c : ctx->staged_slots)
+        if (c.token.load() == rq.stage_token) sl = &c;
+    if (!sl) return decline("the staged block was replaced");
+    std::unique_lock<std::mutex> slk(sl->m);
+    if (sl->token.load() != rq.stage_token || sl->len == 0 || sl->len != rq.block_len) return decline("the staged block was replaced");
+    if (has_tail && ((size_t)rq.tail_base < round_up(sl->len, 64) || (size_t)rq.tail_base + rq.tail_len + 128 > sl->cap)) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->fault) return ctx->fault == 2 ? FABGPU_ENOMEM : FABGPU_ELAUNCH;
+    if (!rq.walk_only && (!ctx->d_idtab || ctx->idtab_n == 0)) return decline("no identity is known to the device yet");
+    DeviceGuard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const auto t_start = now();
+    const uint32_t ne = rq.n_env;
+    // ---- per-envelope arrays ----
+    size_t o = 0;
+    auto carve = [&](size_t bytes) { size_t at = o; o = round_up(o + bytes, 256); return at; };
+    const size_t o_env = carve((size_t)ne * 8), o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_tot = carve(sizeof(WalkTotals)),
+                 o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary));
+    int rc;
+    if ((rc = ctx->walk_env.ensure(o))) return rc;
+    // pinned staging: env spans up, totals / summary down (the result arrays are sized further down)
+    const size_t p_env = 0, p_tot = round_up((size_t)ne * 8, 64), p_sum = p_tot + 64, p_first = p_sum + 64;
+    if ((rc = ctx->walk_pin.ensure(p_first))) return rc;
+    uint8_t* de = (uint8_t*)ctx->walk_env.d;
+    WalkArrays a;
+    a.block = (const uint8_t*)sl->d;
+    a.block_len = (uint32_t)sl->len;
+    a.arena_len = has_tail ? rq.tail_base + rq.tail_len : (uint32_t)sl->len;
+    a.env_spans = (const uint32_t*)(de + o_env);
+    a.n_env = ne;
+    a.counts = (uint4*)(de + o_cnt);
+    a.bases = (uint4*)(de + o_base);
+    a.totals = (WalkTotals*)(de + o_tot);
+    a.tx_type = de + o_type;
+    a.tx_understood = de + o_und;
+    a.tx_mask = (uint32_t*)(de + o_mask);
+    a.tx_flags = de + o_flags;
+    a.summary = (WalkSummary*)(de + o_sum);
+    memcpy((uint8_t*)ctx->walk_pin.h + p_env, rq.env_spans, (size_t)ne * 8);
+    hipError_t err = hipMemcpyAsync(de + o_env, (uint8_t*)ctx->walk_pin.h + p_env, (size_t)ne * 8, hipMemcpyHostToDevice, st);
+    if (err == hipSuccess && has_tail) {
+        if ((rc = ctx->tailbuf.ensure(rq.tail_len))) return rc;
+        memcpy(ctx->tailbuf.h, rq.tail, rq.tail_len);
+        err = hipMemcpyAsync((uint8_t*)sl->d + rq.tail_base, ctx->tailbuf.h, rq.tail_len, hipMemcpyHostToDevice, st);
+        if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)sl->d + rq.tail_base + rq.tail_len, 0, 128, st);
+    }
+    if (err == hipSuccess) err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
+    if (err == hipSuccess) err = hipMemsetAsync(de + o_sum, 0, sizeof(WalkSummary), st);
+    if (err == hipSuccess) err = launch_walk_count(a, st);
+    if (err == hipSuccess) err = hipMemcpyAsync((uint8_t*)ctx->walk_pin.h + p_tot, de + o_tot, sizeof(WalkTotals), hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err != hipSuccess) return hip_to_rc(err);
+    const WalkTotals tot = *(const WalkTotals*)((uint8_t*)ctx->walk_pin.h + p_tot);
+    if (tot.gather_bytes > 0x7FFFFFF0ull) return decline("gathered hash inputs exceed 2 GiB");
+    const uint64_t nt64 = (uint64_t)tot.tuples + rq.n_block_sigs;
+    if (nt64 > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
+    const uint32_t nt = (uint32_t)nt64, np = tot.prefixes, nc = tot.checks;
+    if (nt == 0) return decline("no signature in the block");
+    WalkCounts cnts;
+    cnts.n_tx = ne; cnts.n_tuples = nt; cnts.n_prefixes = np; cnts.n_checks = nc;
+    WalkOut out;
+    if (!rq.sizes(rq.user, cnts, out)) return FABGPU_ETOOBIG;
+    // ---- per-tuple arrays ----
+    o = 0;
+    const size_t words = (nt + 63) / 64;
+    const size_t o_tup = carve((size_t)nt * sizeof(bccsp::BlockTuple)), o_pre = carve(((size_t)np + 1) * 8), o_chk = carve(((size_t)nc + 1) * sizeof(bccsp::BlockHashCheck)),
+                 o_gsp = carve(((size_t)nc + 1) * 24), o_gof = carve(((size_t)nc + 1) * 4), o_gdg = carve(((size_t)nc + 1) * 32), o_idx = carve((size_t)nt * 4),
+                 o_off = carve((size_t)nt * 8), o_pix = carve((size_t)nt * 4), o_kid = carve((size_t)nt * 4), o_qx = carve((size_t)nt * 32),
+                 o_qy = carve((size_t)nt * 32), o_r = carve((size_t)nt * 32), o_s = carve((size_t)nt * 32), o_gst = carve(nt), o_bits = carve(words * 8),
+                 o_dst = carve(nt), o_tst = carve(nt), o_hsh = carve(nt), o_dig = carve((size_t)nt * 32), o_mid = carve(((size_t)np + 1) * 32);
+    if ((rc = ctx->walk_tup.ensure(o))) return rc;
+    uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
+    a.tuples = (bccsp::BlockTuple*)(dt + o_tup);
+    a.n_tuples = nt;
+    a.pre_off2 = (uint32_t*)(dt + o_pre);
+    a.checks = (bccsp::BlockHashCheck*)(dt + o_chk);
+    a.gather_spans = (uint32_t*)(dt + o_gsp);
+    a.gather_off = (uint32_t*)(dt + o_gof);
+    a.gather_digests = dt + o_gdg;
+    a.id_idx = (uint32_t*)(dt + o_idx);
+    a.off2 = (uint32_t*)(dt + o_off);
+    a.pre_idx = (uint32_t*)(dt + o_pix);
+    a.key_id = (uint32_t*)(dt + o_kid);
+    a.qx = dt + o_qx; a.qy = dt + o_qy; a.r = dt + o_r; a.s = dt + o_s;
+    a.gate_st = dt + o_gst;
+    a.verdict_bits = (const uint64_t*)(dt + o_bits);
+    a.dev_status = dt + o_dst;
+    a.tuple_status = dt + o_tst;
+    a.tuple_hashed = dt + o_hsh;
+    if (ctx->d_idtab) {
+        a.id_slots = (const uint32_t*)ctx->d_idtab;
+        a.id_mask = ctx->idtab_mask;
+        a.id_entries = (const DevIdEntry*)((uint8_t*)ctx->d_idtab + ctx->idtab_entries_off);
+        a.id_bytes = (uint8_t*)ctx->d_idtab + ctx->idtab_bytes_off;
+    }
+    // pinned room for everything that comes back
+    size_t po = p_first;
+    auto pin = [&](size_t bytes) { size_t at = po; po = round_up(po + bytes, 64); return at; };
+    const size_t p_flags = pin(ne), p_type = pin(ne), p_und = pin(ne), p_tst = pin(nt), p_hsh = pin(nt), p_tup = pin((size_t)nt * sizeof(bccsp::BlockTuple)),
+                 p_idx = pin((size_t)nt * 4), p_dig = pin((size_t)nt * 32), p_pre = pin(((size_t)np + 1) * 8), p_chk = pin(((size_t)nc + 1) * sizeof(bccsp::BlockHashCheck)),
+                 p_sigs = pin((size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple) + 64);
+    {
+        // (growing the pinned buffer moves it: nothing above is still needed from the old one)
+        if ((rc = ctx->walk_pin.ensure(po))) return rc;
+    }
+    uint8_t* ph = (uint8_t*)ctx->walk_pin.h;
+    err = launch_walk_emit(a, tot, st);
+    if (err == hipSuccess && rq.n_block_sigs) {
+        memcpy(ph + p_sigs, rq.block_sigs, (size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple));
+        err = hipMemcpyAsync(a.tuples + tot.tuples, ph + p_sigs, (size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple), hipMemcpyHostToDevice, st);
+    }
+    if (err != hipSuccess) return hip_to_rc(err);
+    auto fetch = [&](void* host_dst, size_t pin_off, const void* dev_src, size_t bytes) {
+        if (!host_dst || bytes == 0 || err != hipSuccess) return;
+        err = hipMemcpyAsync(ph + pin_off, dev_src, bytes, hipMemcpyDeviceToHost, st);
+    };
+    auto deliver = [&](void* host_dst, size_t pin_off, size_t bytes) {
+        if (host_dst && bytes) memcpy(host_dst, ph + pin_off, bytes);
+    };
+    if (rq.walk_only) {
+        fetch(out.tx_type, p_type, a.tx_type, ne);
+        fetch(out.tx_understood, p_und, a.tx_understood, ne);
+        fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
+        fetch(out.prefixes, p_pre, a.pre_off2, (size_t)np * 8);
+        fetch(out.checks, p_chk, a.checks, (size_t)nc * sizeof(bccsp::BlockHashCheck));
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        if (err != hipSuccess) return hip_to_rc(err);
+        deliver(out.tx_type, p_type, ne);
+        deliver(out.tx_understood, p_und, ne);
+        deliver(out.tuples, p_tup, (size_t)nt * sizeof(bccsp::BlockTuple));
+        deliver(out.checks, p_chk, (size_t)nc * sizeof(bccsp::BlockHashCheck));
+        if (out.prefixes)                                          // (start, end) pairs on the device, (offset, length) for the caller
+            for (uint32_t p = 0; p < np; p++) {
+                const uint32_t s0 = ((const uint32_t*)(ph + p_pre))[2 * p], s1 = ((const uint32_t*)(ph + p_pre))[2 * p + 1];
+                out.prefixes[p].off = s0;
+                out.prefixes[p].len = s1 - s0;
+            }
+        rq.ms_walk = ms_since(t_start);
+        return FABGPU_OK;
+    }
+    err = launch_walk_gate(a, st);
+    if (err == hipSuccess) err = hipMemcpyAsync(ph + p_sum, de + o_sum, sizeof(WalkSummary), hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err != hipSuccess) return hip_to_rc(err);
+    rq.summary = *(const WalkSummary*)(ph + p_sum);
+    rq.ms_walk = ms_since(t_start);
+    if (rq.summary.n_unknown_identity) return decline("an identity the device has not met");
+    if (rq.summary.n_declined) return decline("a signature outside the common DER shape");
+    if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
+    rq.all_keyed = rq.summary.n_unkeyed == 0;
+    // ---- the fused launch over device-resident submission arrays ----
+    const auto t_verify = now();
+    if (nc && ctx->gscr_cap < round_up((size_t)tot.gather_bytes, 4) + 64) {
+        const size_t gscr = round_up((size_t)tot.gather_bytes, 4) + 64;
+        if (ctx->d_gscr) hipFree(ctx->d_gscr);
+        ctx->d_gscr = nullptr;
+        ctx->gscr_cap = 0;
+        if (hipMalloc(&ctx->d_gscr, gscr + gscr / 4) != hipSuccess) return FABGPU_ENOMEM;
+        ctx->gscr_cap = gscr + gscr / 4;
+    }
+    fabgpu_identity_batch d;
+    memset(&d, 0, sizeof(d));
+    d.n = nt;
+    d.arena = sl->d;
+    d.arena_bytes = round_up(has_tail ? (size_t)rq.tail_base + rq.tail_len : sl->len, 4) + 64;
+    d.off = a.off2;
+    d.flags = FABGPU_IDB_SPANS;
+    d.n_prefixes = np;
+    d.pre_off = np ? a.pre_off2 : nullptr;
+    d.pre_idx = np ? a.pre_idx : nullptr;
+    if (rq.all_keyed) {
+        d.key_id = a.key_id;
+    } else {
+        d.qx = a.qx;
+        d.qy = a.qy;
+    }
+    d.r = a.r;
+    d.s = a.s;
+    d.verdict_bits = (uint64_t*)(dt + o_bits);
+    d.status = dt + o_dst;
+    d.digests = out.tuple_digest ? dt + o_dig : nullptr;
+    if (nc) {
+        d.n_gather = nc;
+        d.gather_spans = a.gather_spans;
+        d.gather_off = a.gather_off;
+        d.gather_digests = dt + o_gdg;
+        d.gather_scratch = ctx->d_gscr;
+        d.gather_scratch_bytes = round_up((size_t)tot.gather_bytes, 4) + 64;
+    }
+    rc = fabgpu_identity_verify_batch_dev(ctx, &d, np ? dt + o_mid : nullptr, st);
+    if (rc != FABGPU_OK) {
+        hipStreamSynchronize(st);
+        return rc;
+    }
+    err = launch_walk_flags(a, nc, st);
+    fetch(out.tx_flags, p_flags, a.tx_flags, ne);
+    fetch(out.tx_type, p_type, a.tx_type, ne);
+    fetch(out.tx_understood, p_und, a.tx_understood, ne);
+    fetch(out.tuple_status, p_tst, a.tuple_status, nt);
+    fetch(out.tuple_hashed, p_hsh, a.tuple_hashed, nt);
+    fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
+    fetch(out.id_idx, p_idx, a.id_idx, (size_t)nt * 4);
+    fetch(out.tuple_digest, p_dig, dt + o_dig, (size_t)nt * 32);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err != hipSuccess) {
+        hipStreamSynchronize(st);
+        return hip_to_rc(err);
+    }
+    rq.ms_verify = ms_since(t_verify);
+    deliver(out.tx_flags, p_flags, ne);
+    deliver(out.tx_type, p_type, ne);
+    deliver(out.tx_understood, p_und, ne);
+    deliver(out.tuple_status, p_tst, nt);
+    deliver(out.tuple_hashed, p_hsh, nt);
+    deliver(out.tuples, p_tup, (size_t)nt * sizeof(bccsp::BlockTuple));
+    deliver(out.id_idx, p_idx, (size_t)nt * 4);
+    deliver(out.tuple_digest, p_dig, (size_t)nt * 32);
+    return FABGPU_OK;
+}
+
+}  // namespace fab

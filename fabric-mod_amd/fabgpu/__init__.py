@@ -25,6 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("FABGPU_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libfabgpu.so")
 
 FABGPU_OK = 0
+FABGPU_EINVAL = -1
 FLAG_ONE_LANE_ONLY = 1   # fabgpu.h FABGPU_FLAG_ONE_LANE_ONLY
 FLAG_TIME_KERNELS = 2    # fabgpu.h FABGPU_FLAG_TIME_KERNELS
 FLAG_NO_QUAD = 4         # fabgpu.h FABGPU_FLAG_NO_QUAD (idemix: never the four-lanes-per-signature kernel)
@@ -97,6 +98,7 @@ ABI_SYMBOLS = [
     "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",
     "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
     "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev",
+    "fabgpu_csp_pass_routes", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast", "fabgpu_identity_table_hash",
 ]
 
 _lib = None
@@ -176,6 +178,12 @@ def load():
     L.fabgpu_csp_memo_set_capacity.argtypes = [_vp, ctypes.c_uint64]
     L.fabgpu_csp_identity_cache_limits.argtypes = [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
     L.fabgpu_csp_identity_cache_size.argtypes = [_vp, _u64p]
+    L.fabgpu_csp_pass_routes.argtypes = [_vp, _u64p, _u64p, ctypes.c_char_p, _sz]
+    L.fabgpu_csp_block_walk_compare.argtypes = [_vp, _u8p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
+    L.fabgpu_block_walk_twopass_compare.argtypes = [_u8p, _sz, ctypes.c_char_p, _sz]
+    L.fabgpu_gate_sig_fast.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
+    L.fabgpu_identity_table_hash.argtypes = [ctypes.c_char_p, _sz]
+    L.fabgpu_identity_table_hash.restype = ctypes.c_uint64
     L.fabgpu_csp_x509_check_signature_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p, _u8p, _u8p]
     L.fabgpu_x509_signature_parts.argtypes = [ctypes.c_char_p, _sz, _u32p, _u32p, _u32p, _u32p, ctypes.POINTER(ctypes.c_int)]
     L.fabgpu_multi_init.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(_vp)]
@@ -832,6 +840,47 @@ def preverify_block(csp: "GPUCSP", block: bytes):
         a, b = n_tx.value, n_tu.value
         return dict(tx_flags=tx_flags[:a].copy(), tx_type=tx_type[:a].copy(), tuple_tx=t_tx[:b].copy(), tuple_kind=t_kind[:b].copy(),
                     tuple_status=t_st[:b].copy())
+
+
+def pass_routes(csp: "GPUCSP"):
+    """How the block passes of this provider went: dict(device_walks, host_walks, last_decline)."""
+    d, h = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    why = ctypes.create_string_buffer(256)
+    _check(csp._L.fabgpu_csp_pass_routes(csp._h, ctypes.byref(d), ctypes.byref(h), why, 256), "fabgpu_csp_pass_routes")
+    return dict(device_walks=d.value, host_walks=h.value, last_decline=why.value.decode(errors="replace"))
+
+
+def block_walk_compare(csp: "GPUCSP", block: bytes):
+    """TEST HOOK: the device walker against the host walker on one block -> (identical, declined, text)."""
+    buf = np.frombuffer(block, dtype=np.uint8)
+    declined = ctypes.c_int(0)
+    diff = ctypes.create_string_buffer(256)
+    rc = csp._L.fabgpu_csp_block_walk_compare(csp._h, _p8(buf), buf.size, ctypes.byref(declined), diff, 256)
+    if rc < 0:
+        raise FabgpuError("fabgpu_csp_block_walk_compare failed: %s (%d)" % (strerror(rc), rc))
+    return rc == 0, bool(declined.value), diff.value.decode(errors="replace")
+
+
+def block_walk_twopass_compare(block: bytes):
+    """TEST HOOK (pure host): the device walk's count / prefix-sum / write procedure on the host against ParseBlock ->
+    (identical, text); None when both refuse the framing."""
+    buf = np.frombuffer(block, dtype=np.uint8)
+    diff = ctypes.create_string_buffer(256)
+    rc = load().fabgpu_block_walk_twopass_compare(_p8(buf), buf.size, diff, 256)
+    if rc == FABGPU_EINVAL:
+        return None
+    return rc == 0, diff.value.decode(errors="replace")
+
+
+def gate_sig_fast(sig: bytes):
+    """TEST HOOK (pure host): the device's signature gate -> (code, r32, s32); code 0 submit, 1 high-S, 2 empty, 3 declined."""
+    r, s2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    code = load().fabgpu_gate_sig_fast(sig, len(sig), r, s2)
+    return code, r.raw, s2.raw
+
+
+def identity_table_hash(b: bytes) -> int:
+    return load().fabgpu_identity_table_hash(b, len(b))
 
 
 def x509_signature_parts(der: bytes):

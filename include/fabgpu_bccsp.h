@@ -133,6 +133,21 @@ int fabgpu_csp_memo_set_capacity(fabgpu_csp* csp, uint64_t max_entries);
  * msp/cache), a device comb table only for an identity named register_after_hits times, at most max_registered_keys tables. */
 int fabgpu_csp_identity_cache_limits(fabgpu_csp* csp, uint64_t max_identities, uint64_t max_registered_keys, uint32_t register_after_hits);
 int fabgpu_csp_identity_cache_size(fabgpu_csp* csp, uint64_t* identities);
+/* Both forms of the pass walk a staged block (4 MiB and more) ON THE DEVICE when every identity it names is already in the provider's
+ * cache and every signature has the common DER shape (envelope walk, signature gates, identity lookup, submission arrays, digest
+ * comparisons and flags as kernels; block_walk_dev.h) and on the host otherwise (which is also how new identities are learned): same
+ * answers either way.  FABGPU_PASS_DEVICE_WALK=0 keeps every block on the host walk.  This reports how many passes went which way and
+ * why the last block was declined by the device walk. */
+int fabgpu_csp_pass_routes(fabgpu_csp* csp, uint64_t* device_walks, uint64_t* host_walks, char* last_decline, size_t cap);
+/* TEST HOOK: the device walker against the host walker on one block, record for record.  0 identical (*declined = 1: the device walk
+ * declined the block, `diff` says why), 1 they differ (`diff` says where). */
+int fabgpu_csp_block_walk_compare(fabgpu_csp* csp, const uint8_t* block, size_t len, int* declined, char* diff, size_t cap);
+/* TEST HOOKS (pure host, no device): the device walk's two-run procedure (count, prefix sum, write) carried out serially on the host
+ * and compared with the host walker (0 identical, 1 different, FABGPU_EINVAL framing refused); the device's signature gate (0 submit,
+ * 1 high-S, 2 empty, 3 declined: the general parser decides); the identity-table hash. */
+int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* diff, size_t cap);
+int fabgpu_gate_sig_fast(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32);
+uint64_t fabgpu_identity_table_hash(const uint8_t* p, size_t len);
 
 /* ---- x509 certificate signatures in batch ----
  * crypto/x509 Certificate.CheckSignatureFrom(parent) - the ECDSA part - for n DER certificates (cert i = cert_arena[cert_off[i], cert_off[i+1]))

@@ -113,13 +113,14 @@ def main():
         lookup_us = (time.perf_counter() - t0) / len(keys) * 1e6
         assert hits == len(keys) and out["memo_seeded"] == nt
         fabgpu.memo_evict_block(csp, 7)
+    routes = fabgpu.pass_routes(csp)    # walked on the device / on the host (FABGPU_PASS_DEVICE_WALK=0 keeps every block on the host walk)
     # the one SHA-256 MCS.VerifyBlock needs that a GPU cannot parallelise: BlockDataHash over the concatenated envelopes, on this host
     t0 = time.perf_counter()
     hashlib.sha256(b"".join(envs) if envs else blk).digest()
     data_hash_ms = (time.perf_counter() - t0) * 1e3
     print(json.dumps({"metric": "validated tx/sec per block (block-level pre-verify pass, marshalled block in, flags out)", "value": args.tx / dt,
                       "unit": "tx/s", "ms_per_block": dt * 1e3, "ms_min": min(per) * 1e3, "ms_max": max(per) * 1e3, "signatures_per_s": 4 * args.tx / dt,
-                      "tuples_through_key_tables": n_keyed, "callers_in_flight": in_flight,
+                      "tuples_through_key_tables": n_keyed, "callers_in_flight": in_flight, "routes": routes,
                       "mode": ("preverify2 + memo seeding (eviction not timed)" if args.memo else "preverify (flags only)") + (", %.0f ms idle between blocks" % args.idle_ms if args.idle_ms else ", back to back"),
                       "memo_lookup_us_via_ctypes": (lookup_us if args.memo else None),
                       "host_block_data_hash_ms": data_hash_ms, "host_sha256_GB_per_s": len(blk) / data_hash_ms / 1e6,
