@@ -337,7 +337,7 @@ def test_device_route_on_the_reference_ledgers(csp, monkeypatch):
             assert (nb["tuple_status"][-k:] == fabgpu.TUPLE_ST_SKIPPED).all() and (nb["tuple_kind"][-k:] == 2).all()
             assert np.array_equal(nb["tuple_status"][:-k], dev["tuple_status"][:-k])
     walked = fabgpu.pass_routes(csp)["device_walks"] - before
-    assert walked >= len(LEDGER_RAW)                                          # most blocks took the device route in both forms
+    assert walked >= 40                                                       # the 20 blocks of the Fabric 2.0 ledger, in both forms (the ledger-harness blocks name no certificate: nothing for the device to decide)
     valid_block_sigs = sum(int(((h["tuple_kind"] == 2) & (h["tuple_status"] == 0)).sum()) for h in host)
     assert valid_block_sigs >= 19
 

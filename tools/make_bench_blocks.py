@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Pre-builds the blocks of the block-pass benches on the CPU (the signing is pure Python / C oracle and needs no GPU): written to
 .bench_blocks/ at the repo root - git-ignored, but it travels to the GPU box with the snapshot - so that GPU-minutes are not spent
-signing.      python tools/make_bench_blocks.py idemix 10000 5     -> .bench_blocks/idemix_10000_5.bin (every 5th creator idemix)"""
+signing.      python tools/make_bench_blocks.py idemix 10000 5     -> .bench_blocks/idemix_10000_5.bin (every 5th creator idemix)
+              python tools/make_bench_blocks.py ecdsa 10000 0      -> .bench_blocks/ecdsa_10000_0.bin  (x509 creators only)"""
 import ctypes
 import hashlib
 import json
@@ -22,7 +23,7 @@ from idemix_common import be32, fixtures   # noqa: E402
 
 def main():
     kind, ntx, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    assert kind == "idemix"
+    assert kind in ("idemix", "ecdsa")
     ids = [i for i in json.load(open(os.path.join(ROOT, "tests", "golden", "block_identities.json")))["identities"] if i["curve"] == "prime256v1"]
     sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in ids]
     L = coracle.lib()
@@ -44,7 +45,7 @@ def main():
         ends = lambda prp: [(sid[j], sign(j, prp + sid[j])) for j in picks]   # noqa: E731
         args = (bytes(rng.integers(0, 256, size=24, dtype=np.uint8)), bytes(rng.integers(0, 256, size=300, dtype=np.uint8)),
                 bytes(rng.integers(0, 256, size=990, dtype=np.uint8)))
-        if t % every == 0:
+        if kind == "idemix" and t % every == 0:
             nym, r_nym = io.make_nym(sk, ipk, prng)
             cbytes = bb.serialized_idemix_identity("IdemixMSP1", be32(nym[0]), be32(nym[1]))
             payload, _ = bb.consistent_endorser_tx("mychannel", cbytes, *args, ends)
@@ -56,7 +57,7 @@ def main():
         if t % 1000 == 999:
             print(t + 1, file=sys.stderr)
     os.makedirs(os.path.join(ROOT, ".bench_blocks"), exist_ok=True)
-    out = os.path.join(ROOT, ".bench_blocks", "idemix_%d_%d.bin" % (ntx, every))
+    out = os.path.join(ROOT, ".bench_blocks", "%s_%d_%d.bin" % (kind, ntx, every))
     open(out, "wb").write(bb.block(1, envs))
     print(out, os.path.getsize(out))
 
