@@ -49,7 +49,7 @@ struct WalkSummary {
 };
 
 struct WalkTotals {
-    uint32_t tuples, prefixes, checks, pad;
+    uint32_t tuples, prefixes, checks, creators;   // creators: envelopes that yield tuples (each yields exactly one creator tuple, its first)
     uint64_t gather_bytes;
 };
 
@@ -62,6 +62,7 @@ struct WalkArrays {
     uint32_t n_env = 0;
     uint4* counts = nullptr;
     uint4* bases = nullptr;
+    uint32_t* cbase = nullptr;       // per envelope: creator tuples of the envelopes before it
     WalkTotals* totals = nullptr;
     uint8_t* tx_type = nullptr;
     uint8_t* tx_understood = nullptr;
@@ -78,6 +79,13 @@ struct WalkArrays {
     uint32_t* key_id = nullptr;
     uint8_t *qx = nullptr, *qy = nullptr, *r = nullptr, *s = nullptr;
     uint8_t* gate_st = nullptr;
+    // Row of tuple i in the submission arrays.  Plain: row = i.  Split (a block of 32 769 .. 65 536 tuples): the creator tuples - long
+    // messages (the whole envelope payload), no shared prefix - take rows [0, n_creators) and run as a launch of their own with two
+    // lanes per signature, next to the endorsements' launch (rows n_creators ..) with one: the chip's 1024 SIMDs hold both.
+    uint32_t* row_of = nullptr;
+    uint32_t n_dev_tuples = 0;       // tuples the walk emitted (the appended block signatures follow)
+    uint32_t n_creators = 0;
+    uint32_t split = 0;
     WalkSummary* summary = nullptr;
     // identity table
     const uint32_t* id_slots = nullptr;
@@ -85,8 +93,11 @@ struct WalkArrays {
     const DevIdEntry* id_entries = nullptr;
     const uint8_t* id_bytes = nullptr;
     // results
-    const uint64_t* verdict_bits = nullptr;
-    const uint8_t* dev_status = nullptr;
+    const uint64_t* verdict_bits = nullptr;    // of the launch over rows [split ? n_creators : 0, n)
+    const uint64_t* verdict_bits_c = nullptr;  // split: of the creators' launch
+    const uint8_t* dev_status = nullptr;       // by row
+    const uint8_t* row_digests = nullptr;      // by row (null: not wanted)
+    uint8_t* tuple_digests = nullptr;          // by tuple
     uint8_t* tuple_status = nullptr;
     uint8_t* tuple_hashed = nullptr;
     const uint8_t* gather_digests = nullptr;

@@ -41,40 +41,44 @@ __global__ void __launch_bounds__(64) walk_count_kernel(WalkArrays a) {
 
 // Exclusive prefix sums of the per-envelope counts: ONE workgroup (10 000 envelopes are ten per thread; the block-wide part is a
 // 1024-entry Hillis-Steele scan in LDS).
-__global__ void __launch_bounds__(1024) walk_scan_kernel(uint32_t n, const uint4* __restrict__ counts, uint4* __restrict__ bases, WalkTotals* __restrict__ totals) {
-    __shared__ uint32_t st[1024], sp[1024], sc[1024];
+__global__ void __launch_bounds__(1024) walk_scan_kernel(uint32_t n, const uint4* __restrict__ counts, uint4* __restrict__ bases, uint32_t* __restrict__ cbase,
+                                                         WalkTotals* __restrict__ totals) {
+    __shared__ uint32_t st[1024], sp[1024], sc[1024], sk[1024];
     __shared__ uint64_t sg[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023) / 1024;
     const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    uint32_t t = 0, p = 0, c = 0;
+    uint32_t t = 0, p = 0, c = 0, k = 0;
     uint64_t g = 0;
     for (uint32_t i = lo; i < hi; i++) {
         const uint4 v = counts[i];
         t += v.x; p += v.y; c += v.z; g += v.w;
+        k += v.x ? 1u : 0u;
     }
-    st[tid] = t; sp[tid] = p; sc[tid] = c; sg[tid] = g;
+    st[tid] = t; sp[tid] = p; sc[tid] = c; sg[tid] = g; sk[tid] = k;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint32_t vt = 0, vp = 0, vc = 0;
+        uint32_t vt = 0, vp = 0, vc = 0, vk = 0;
         uint64_t vg = 0;
-        if (tid >= o) { vt = st[tid - o]; vp = sp[tid - o]; vc = sc[tid - o]; vg = sg[tid - o]; }
+        if (tid >= o) { vt = st[tid - o]; vp = sp[tid - o]; vc = sc[tid - o]; vg = sg[tid - o]; vk = sk[tid - o]; }
         __syncthreads();
-        st[tid] += vt; sp[tid] += vp; sc[tid] += vc; sg[tid] += vg;
+        st[tid] += vt; sp[tid] += vp; sc[tid] += vc; sg[tid] += vg; sk[tid] += vk;
         __syncthreads();
     }
-    uint32_t bt = st[tid] - t, bp = sp[tid] - p, bc = sc[tid] - c;
+    uint32_t bt = st[tid] - t, bp = sp[tid] - p, bc = sc[tid] - c, bk = sk[tid] - k;
     uint64_t bg = sg[tid] - g;
     for (uint32_t i = lo; i < hi; i++) {
         const uint4 v = counts[i];
         bases[i] = make_uint4(bt, bp, bc, (uint32_t)bg);
+        cbase[i] = bk;
         bt += v.x; bp += v.y; bc += v.z; bg += v.w;
+        bk += v.x ? 1u : 0u;
     }
     if (tid == 1023) {
         totals->tuples = st[1023];
         totals->prefixes = sp[1023];
         totals->checks = sc[1023];
-        totals->pad = 0;
+        totals->creators = sk[1023];
         totals->gather_bytes = sg[1023];
     }
 }
@@ -143,9 +147,18 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     const uint8_t GY[32] = {0x4f, 0xe3, 0x42, 0xe2, 0xfe, 0x1a, 0x7f, 0x9b, 0x8e, 0xe7, 0xeb, 0x4a, 0x7c, 0x0f, 0x9e, 0x16,
                             0x2b, 0xce, 0x33, 0x57, 0x6b, 0x31, 0x5e, 0xce, 0xcb, 0xb6, 0x40, 0x68, 0x37, 0xbf, 0x51, 0xf5};
     const BlockTuple t = a.tuples[i];
-    a.off2[2 * (size_t)i] = t.suffix.len ? t.suffix.off : 0;
-    a.off2[2 * (size_t)i + 1] = t.suffix.len ? t.suffix.off + t.suffix.len : 0;
-    a.pre_idx[i] = t.prefix_index >= 0 ? (uint32_t)t.prefix_index : 0xFFFFFFFFu;
+    // the row of this tuple (WalkArrays::row_of): creators first when the submission is split
+    uint32_t row = i;
+    if (a.split) {
+        // creator tuples at indices <= i: those of the envelopes before this one, plus this envelope's (its first tuple)
+        const uint32_t before = i < a.n_dev_tuples ? a.cbase[t.tx] : a.n_creators;
+        const bool creator = i < a.n_dev_tuples && i == a.bases[t.tx].x;
+        row = creator ? before : a.n_creators + (i - before - (i < a.n_dev_tuples ? 1u : 0u));
+    }
+    a.row_of[i] = row;
+    a.off2[2 * (size_t)row] = t.suffix.len ? t.suffix.off : 0;
+    a.off2[2 * (size_t)row + 1] = t.suffix.len ? t.suffix.off + t.suffix.len : 0;
+    a.pre_idx[row] = t.prefix_index >= 0 ? (uint32_t)t.prefix_index : 0xFFFFFFFFu;
     uint8_t r32[32], s32[32];
     for (int k = 0; k < 32; k++) r32[k] = s32[k] = 0;
     r32[31] = s32[31] = 1;
@@ -182,11 +195,11 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         atomicAdd(&a.summary->n_submitted, 1u);
         if (!keyed) atomicAdd(&a.summary->n_unkeyed, 1u);
     }
-    a.key_id[i] = keyed ? (uint32_t)ent->key_id : 0u;
-    uint8_t* qx = a.qx + 32 * (size_t)i;
-    uint8_t* qy = a.qy + 32 * (size_t)i;
-    uint8_t* r = a.r + 32 * (size_t)i;
-    uint8_t* s = a.s + 32 * (size_t)i;
+    a.key_id[row] = keyed ? (uint32_t)ent->key_id : 0u;
+    uint8_t* qx = a.qx + 32 * (size_t)row;
+    uint8_t* qy = a.qy + 32 * (size_t)row;
+    uint8_t* r = a.r + 32 * (size_t)row;
+    uint8_t* s = a.s + 32 * (size_t)row;
     for (int k = 0; k < 32; k++) {
         qx[k] = submit ? ent->qx[k] : GX[k];
         qy[k] = submit ? ent->qy[k] : GY[k];
@@ -206,9 +219,18 @@ __global__ void __launch_bounds__(256) walk_status_kernel(WalkArrays a) {
     const BlockTuple t = a.tuples[i];
     uint8_t st = gst;
     uint8_t hashed = 0;
+    const uint32_t row = a.row_of[i];
+    if (a.row_digests) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.row_digests + 32 * (size_t)row);
+        uint4* dst = reinterpret_cast<uint4*>(a.tuple_digests + 32 * (size_t)i);
+        dst[0] = src[0];
+        dst[1] = src[1];
+    }
     if (gst == FABGPU_ST_VALID) {                                    // the device decided: exactly PreVerifyParsed's mapping
-        const bool bit = (a.verdict_bits[i >> 6] >> (i & 63)) & 1;
-        const uint8_t ds = a.dev_status[i];
+        const bool in_c = a.split && row < a.n_creators;
+        const uint32_t j = in_c ? row : row - (a.split ? a.n_creators : 0u);
+        const bool bit = ((in_c ? a.verdict_bits_c : a.verdict_bits)[j >> 6] >> (j & 63)) & 1;
+        const uint8_t ds = a.dev_status[row];
         st = (bit && ds == FABGPU_ST_VALID) ? FABGPU_ST_VALID : (ds == FABGPU_ST_VALID ? FABGPU_ST_BAD_MATH : ds);
         hashed = 1;
     }
@@ -264,7 +286,7 @@ hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, st, a.n_env, (const uint4*)a.counts, a.bases, a.totals);
+    hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, st, a.n_env, (const uint4*)a.counts, a.bases, a.cbase, a.totals);
     return hipGetLastError();
 }
 hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st) {

@@ -132,6 +132,10 @@ struct fabgpu_ctx {
     Buf nymout;       // results of the pseudonym signatures that ride in an identity batch: verdict words | status bytes
     hipStream_t stream2 = nullptr;   // the pseudonym signatures of an identity batch run here, next to the ECDSA kernels on `stream`
     hipEvent_t ev_up = nullptr;      // "the arena is on the device" (recorded on stream, awaited by stream2)
+    // the device block pass runs on three streams: walk / gates / endorsements on `stream`, mid-states and the creators' launch on
+    // stream2, the TxID / proposal-hash digests on stream3
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
     void* d_gscr = nullptr;   // device scratch the gather kernel stitches the messages into
     size_t gscr_cap = 0;
@@ -279,6 +283,12 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        {
+            bool ok = true;
+            for (auto& e : ctx->ev_w) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { rc = FABGPU_ENODEV; break; }
+        }
         if (const char* fi = getenv("FABGPU_FAULT_INJECT")) ctx->fault = !strcmp(fi, "launch") ? 1 : (!strcmp(fi, "oom") ? 2 : 0);
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         std::vector<int32_t> tab(GTab16::TABLE_WORDS);   // 80 MiB, ~0.2 s on 16 host threads
@@ -319,6 +329,9 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->nymout.release();
         if (ctx->stream2) hipStreamDestroy(ctx->stream2);
         if (ctx->ev_up) hipEventDestroy(ctx->ev_up);
+        if (ctx->stream3) hipStreamDestroy(ctx->stream3);
+        for (auto& e : ctx->ev_w)
+            if (e) hipEventDestroy(e);
         ctx->gath.release();
         ctx->tailbuf.release();
         ctx->keyed.release();
@@ -1273,7 +1286,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     size_t o = 0;
     auto carve = [&](size_t bytes) { size_t at = o; o = round_up(o + bytes, 256); return at; };
     const size_t o_env = carve((size_t)ne * 8), o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_tot = carve(sizeof(WalkTotals)),
-                 o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary));
+                 o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
+                 o_cbase = carve((size_t)ne * 4);
     int rc;
     if ((rc = ctx->walk_env.ensure(o))) return rc;
     // pinned staging: env spans up, totals / summary down (the result arrays are sized further down)
@@ -1288,6 +1302,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.n_env = ne;
     a.counts = (uint4*)(de + o_cnt);
     a.bases = (uint4*)(de + o_base);
+    a.cbase = (uint32_t*)(de + o_cbase);
     a.totals = (WalkTotals*)(de + o_tot);
     a.tx_type = de + o_type;
     a.tx_understood = de + o_und;
@@ -1325,7 +1340,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_gsp = carve(((size_t)nc + 1) * 24), o_gof = carve(((size_t)nc + 1) * 4), o_gdg = carve(((size_t)nc + 1) * 32), o_idx = carve((size_t)nt * 4),
                  o_off = carve((size_t)nt * 8), o_pix = carve((size_t)nt * 4), o_kid = carve((size_t)nt * 4), o_qx = carve((size_t)nt * 32),
                  o_qy = carve((size_t)nt * 32), o_r = carve((size_t)nt * 32), o_s = carve((size_t)nt * 32), o_gst = carve(nt), o_bits = carve(words * 8),
-                 o_dst = carve(nt), o_tst = carve(nt), o_hsh = carve(nt), o_dig = carve((size_t)nt * 32), o_mid = carve(((size_t)np + 1) * 32);
+                 o_dst = carve(nt), o_tst = carve(nt), o_hsh = carve(nt), o_dig = carve((size_t)nt * 32), o_mid = carve(((size_t)np + 1) * 32),
+                 o_row = carve((size_t)nt * 4), o_bitc = carve(words * 8), o_tdig = carve((size_t)nt * 32);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
     a.tuples = (bccsp::BlockTuple*)(dt + o_tup);
@@ -1341,7 +1357,18 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.key_id = (uint32_t*)(dt + o_kid);
     a.qx = dt + o_qx; a.qy = dt + o_qy; a.r = dt + o_r; a.s = dt + o_s;
     a.gate_st = dt + o_gst;
+    a.row_of = (uint32_t*)(dt + o_row);
+    a.n_dev_tuples = tot.tuples;
+    a.n_creators = tot.creators;
+    // Split the submission (WalkArrays::row_of) when one launch would have to run one lane per signature (more than VERIFY_PAIR_MAX
+    // tuples) although creators on two lanes + everybody else on one still fit the chip's 65 536 lanes: the creators hash the longest
+    // messages (whole payloads), so they get the shorter arithmetic.
+    a.split = (ctx->allow_pair && nt > (uint32_t)VERIFY_PAIR_MAX && tot.creators != 0 && tot.creators <= (uint32_t)VERIFY_PAIR_MAX &&
+               (uint64_t)2 * tot.creators + (nt - tot.creators) <= 65536u) ? 1u : 0u;
     a.verdict_bits = (const uint64_t*)(dt + o_bits);
+    a.verdict_bits_c = (const uint64_t*)(dt + o_bitc);
+    a.row_digests = out.tuple_digest ? dt + o_dig : nullptr;
+    a.tuple_digests = dt + o_tdig;
     a.dev_status = dt + o_dst;
     a.tuple_status = dt + o_tst;
     a.tuple_hashed = dt + o_hsh;
@@ -1396,7 +1423,48 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         rq.ms_walk = ms_since(t_start);
         return FABGPU_OK;
     }
-    err = launch_walk_gate(a, st);
+    // From here on three streams work side by side; whatever happens, none of them may still be running when this call returns
+    // (the next pass reuses every buffer).
+    hipStream_t s2 = ctx->stream2, s3 = ctx->stream3;
+    struct Drain {
+        hipStream_t a, b, c;
+        ~Drain() {
+            hipStreamSynchronize(a);
+            hipStreamSynchronize(b);
+            hipStreamSynchronize(c);
+        }
+    } drain{s2, s3, st};
+    const size_t arena_bytes = round_up(has_tail ? (size_t)rq.tail_base + rq.tail_len : sl->len, 4) + 64;
+    ShaPrefixArgs pa;
+    pa.spans = true;
+    if (np) {
+        pa.m = np;
+        pa.pre_off = a.pre_off2;
+        pa.pre_idx = a.pre_idx;
+        pa.mid_scratch = dt + o_mid;
+    }
+    const size_t gscr = round_up((size_t)tot.gather_bytes, 4) + 64;
+    if (nc && ctx->gscr_cap < gscr) {
+        if (ctx->d_gscr) hipFree(ctx->d_gscr);
+        ctx->d_gscr = nullptr;
+        ctx->gscr_cap = 0;
+        if (hipMalloc(&ctx->d_gscr, gscr + gscr / 4) != hipSuccess) return FABGPU_ENOMEM;
+        ctx->gscr_cap = gscr + gscr / 4;
+    }
+    // the emitted prefixes / hash checks are all stream2 and stream3 need: mid-states and the TxID / proposal-hash digests run while
+    // the main stream looks identities up and gates signatures
+    err = hipEventRecord(ctx->ev_w[0], st);
+    if (err == hipSuccess && np) {
+        err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pa, s2);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s2);
+    }
+    if (err == hipSuccess && nc) {
+        err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s3);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s3);
+    }
+    if (err == hipSuccess) err = launch_walk_gate(a, st);
     if (err == hipSuccess) err = hipMemcpyAsync(ph + p_sum, de + o_sum, sizeof(WalkSummary), hipMemcpyDeviceToHost, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err != hipSuccess) return hip_to_rc(err);
@@ -1406,51 +1474,61 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (rq.summary.n_declined) return decline("a signature outside the common DER shape");
     if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
     rq.all_keyed = rq.summary.n_unkeyed == 0;
-    // ---- the fused launch over device-resident submission arrays ----
+    // ---- the fused launches over device-resident submission arrays ----
     const auto t_verify = now();
-    if (nc && ctx->gscr_cap < round_up((size_t)tot.gather_bytes, 4) + 64) {
-        const size_t gscr = round_up((size_t)tot.gather_bytes, 4) + 64;
-        if (ctx->d_gscr) hipFree(ctx->d_gscr);
-        ctx->d_gscr = nullptr;
-        ctx->gscr_cap = 0;
-        if (hipMalloc(&ctx->d_gscr, gscr + gscr / 4) != hipSuccess) return FABGPU_ENOMEM;
-        ctx->gscr_cap = gscr + gscr / 4;
-    }
-    fabgpu_identity_batch d;
-    memset(&d, 0, sizeof(d));
-    d.n = nt;
-    d.arena = sl->d;
-    d.arena_bytes = round_up(has_tail ? (size_t)rq.tail_base + rq.tail_len : sl->len, 4) + 64;
-    d.off = a.off2;
-    d.flags = FABGPU_IDB_SPANS;
-    d.n_prefixes = np;
-    d.pre_off = np ? a.pre_off2 : nullptr;
-    d.pre_idx = np ? a.pre_idx : nullptr;
+    pa.mid_ready = true;
+    pa.digests = out.tuple_digest ? dt + o_dig : nullptr;
+    uint32_t nkeys = 0;
+    const int32_t** kt = nullptr;
     if (rq.all_keyed) {
-        d.key_id = a.key_id;
+        std::lock_guard<std::mutex> klk(ctx->kmu);
+        nkeys = (uint32_t)ctx->ktabs.size();
+        kt = ctx->d_ktabs;
+        if (nkeys == 0) return FABGPU_EINVAL;
+    }
+    // rows [row0, row0 + n) as one launch on stream `ls`
+    auto verify_rows = [&](uint32_t row0, uint32_t n, bool prefixed, bool pair, void* bits, hipStream_t ls) -> int {
+        ShaPrefixArgs p = pa;
+        if (!prefixed) {
+            p.m = 0;
+            p.pre_off = p.pre_idx = nullptr;
+            p.mid_scratch = nullptr;
+        } else {
+            p.pre_idx = a.pre_idx + row0;
+        }
+        if (p.digests) p.digests = dt + o_dig + 32 * (size_t)row0;
+        hipError_t e;
+        if (rq.all_keyed) {
+            e = launch_sha256_p256_verify_keyed(n, sl->d, arena_bytes, a.off2 + 2 * (size_t)row0, a.key_id + row0, nkeys, (const void*)kt, a.r + 32 * (size_t)row0,
+                                                a.s + 32 * (size_t)row0, ctx->d_gtab, bits, dt + o_dst + row0, pair, p, ls);
+        } else {
+            size_t wi = 0;
+            void* wsp = nullptr;
+            int r2 = ctx->acquire_qws(verify_workspace_bytes(n, pair), &wi, &wsp, ls);
+            if (r2 != FABGPU_OK) return r2;
+            e = launch_sha256_p256_verify(n, sl->d, arena_bytes, a.off2 + 2 * (size_t)row0, a.qx + 32 * (size_t)row0, a.qy + 32 * (size_t)row0,
+                                          a.r + 32 * (size_t)row0, a.s + 32 * (size_t)row0, ctx->d_gtab, wsp, bits, dt + o_dst + row0, pair, p, ls);
+            ctx->release_qws(wi, ls);
+        }
+        return hip_to_rc(e);
+    };
+    if (np) err = hipStreamWaitEvent(st, ctx->ev_w[1], 0);               // the mid-states (long done: they ran beside the gates)
+    if (err != hipSuccess) return hip_to_rc(err);
+    if (a.split) {
+        // creators on stream2 (two lanes per signature), everybody else on the main stream (one lane): side by side
+        err = hipEventRecord(ctx->ev_w[3], st);                            // the submission arrays are complete
+        if (err == hipSuccess) err = hipStreamWaitEvent(s2, ctx->ev_w[3], 0);
+        if (err != hipSuccess) return hip_to_rc(err);
+        if ((rc = verify_rows(0, tot.creators, false, true, dt + o_bitc, s2))) return rc;
+        err = hipEventRecord(ctx->ev_w[4], s2);
+        if (err != hipSuccess) return hip_to_rc(err);
+        if ((rc = verify_rows(tot.creators, nt - tot.creators, np != 0, false, dt + o_bits, st))) return rc;
+        err = hipStreamWaitEvent(st, ctx->ev_w[4], 0);
     } else {
-        d.qx = a.qx;
-        d.qy = a.qy;
+        if ((rc = verify_rows(0, nt, np != 0, ctx->allow_pair, dt + o_bits, st))) return rc;
     }
-    d.r = a.r;
-    d.s = a.s;
-    d.verdict_bits = (uint64_t*)(dt + o_bits);
-    d.status = dt + o_dst;
-    d.digests = out.tuple_digest ? dt + o_dig : nullptr;
-    if (nc) {
-        d.n_gather = nc;
-        d.gather_spans = a.gather_spans;
-        d.gather_off = a.gather_off;
-        d.gather_digests = dt + o_gdg;
-        d.gather_scratch = ctx->d_gscr;
-        d.gather_scratch_bytes = round_up((size_t)tot.gather_bytes, 4) + 64;
-    }
-    rc = fabgpu_identity_verify_batch_dev(ctx, &d, np ? dt + o_mid : nullptr, st);
-    if (rc != FABGPU_OK) {
-        hipStreamSynchronize(st);
-        return rc;
-    }
-    err = launch_walk_flags(a, nc, st);
+    if (err == hipSuccess && nc) err = hipStreamWaitEvent(st, ctx->ev_w[2], 0);
+    if (err == hipSuccess) err = launch_walk_flags(a, nc, st);
     fetch(out.tx_flags, p_flags, a.tx_flags, ne);
     fetch(out.tx_type, p_type, a.tx_type, ne);
     fetch(out.tx_understood, p_und, a.tx_understood, ne);
@@ -1458,12 +1536,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     fetch(out.tuple_hashed, p_hsh, a.tuple_hashed, nt);
     fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
     fetch(out.id_idx, p_idx, a.id_idx, (size_t)nt * 4);
-    fetch(out.tuple_digest, p_dig, dt + o_dig, (size_t)nt * 32);
+    fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
-    if (err != hipSuccess) {
-        hipStreamSynchronize(st);
-        return hip_to_rc(err);
-    }
+    if (err != hipSuccess) return hip_to_rc(err);
     rq.ms_verify = ms_since(t_verify);
     deliver(out.tx_flags, p_flags, ne);
     deliver(out.tx_type, p_type, ne);

@@ -21,6 +21,7 @@ struct ShaPrefixArgs {
     void* mid_scratch = nullptr;
     bool spans = false;   // off / pre_off hold (start, end) pairs
     void* digests = nullptr;   // optional out (device): n x 32 bytes, the digest of every message
+    bool mid_ready = false;    // the mid-states are already in mid_scratch (launch_sha256_midstates ran, e.g. on another stream)
 };
 struct VerifyGeom {
     uint32_t block;   // threads per workgroup
@@ -29,6 +30,8 @@ struct VerifyGeom {
 };
 VerifyGeom verify_geom(uint32_t n, bool allow_pair);
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair);
+// the mid-state kernel of a prefixed batch alone (the fused launchers run it themselves unless pa.mid_ready)
+hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st);
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);
 // gathered messages (pieces of the arena stitched into `scratch` at out_off[j] .. out_off[j+1]) -> n x 32 digest bytes
 hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,

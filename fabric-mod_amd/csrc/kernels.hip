@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(BLOCK, 2) p256_verify_keyed_kernel(uint32_t n,
     }
 }
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 1) p256_verify_keyed_pair_kernel(uint32_t n, const uint32_t* __restrict__ key_id, uint32_t nkeys,
+__global__ void __launch_bounds__(BLOCK, 2) p256_verify_keyed_pair_kernel(uint32_t n, const uint32_t* __restrict__ key_id, uint32_t nkeys,
                                                                                const int32_t* const* __restrict__ ktabs, const uint8_t* __restrict__ e,
                                                                                const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                                                                                const int32_t* __restrict__ gtab, uint64_t* __restrict__ verdict_bits,
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_kernel(uint
     }
 }
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 1) sha256_p256_verify_keyed_pair_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+__global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_pair_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
                                                                                       const uint32_t* __restrict__ off, const uint32_t* __restrict__ key_id,
                                                                                       uint32_t nkeys, const int32_t* const* __restrict__ ktabs,
                                                                                       const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
@@ -340,14 +340,23 @@ __global__ void __launch_bounds__(256) gather_spans_kernel(uint32_t n, const uin
 static sha_prefixes launch_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st) {
     sha_prefixes pre{nullptr, nullptr, nullptr, 0, pa.spans ? 1u : 0u, (uint32_t*)pa.digests};
     if (pa.m == 0 || pa.pre_idx == nullptr) return pre;
-    dim3 grid((pa.m + 255) / 256), block(256);
-    hipLaunchKernelGGL(sha256_midstate_kernel, grid, block, 0, st, pa.m, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                       (const uint32_t*)pa.pre_off, pre.spans, (uint32_t*)pa.mid_scratch);
+    if (!pa.mid_ready) {
+        dim3 grid((pa.m + 255) / 256), block(256);
+        hipLaunchKernelGGL(sha256_midstate_kernel, grid, block, 0, st, pa.m, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                           (const uint32_t*)pa.pre_off, pre.spans, (uint32_t*)pa.mid_scratch);
+    }
     pre.pre_idx = (const uint32_t*)pa.pre_idx;
     pre.pre_off = (const uint32_t*)pa.pre_off;
     pre.mid = (const uint32_t*)pa.mid_scratch;
     pre.m = pa.m;
     return pre;
+}
+hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st) {
+    if (pa.m == 0) return hipSuccess;
+    dim3 grid((pa.m + 255) / 256), block(256);
+    hipLaunchKernelGGL(sha256_midstate_kernel, grid, block, 0, st, pa.m, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                       (const uint32_t*)pa.pre_off, pa.spans ? 1u : 0u, (uint32_t*)pa.mid_scratch);
+    return hipGetLastError();
 }
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st) {
     if (n == 0) return hipSuccess;

@@ -374,3 +374,64 @@ def test_device_route_big_block_caps_and_concurrency(csp, monkeypatch):
     for t in th:
         t.join(timeout=300)
     assert not errors, errors[0]
+
+
+def _bench_block(n_tx):
+    """a block of n_tx endorser transactions with VALID signatures: the pre-built bench block when it travelled along
+    (tools/make_bench_blocks.py ecdsa 10000 0), else signed here with the C oracle"""
+    path = os.path.join(ROOT, ".bench_blocks", "ecdsa_10000_0.bin")
+    if n_tx == 10000 and os.path.exists(path):
+        return open(path, "rb").read()
+    import ctypes
+
+    import coracle
+    L = coracle.lib()
+    rng = np.random.default_rng(1)
+    ids = [i for i in IDS if i["curve"] == "prime256v1"]
+    sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in ids]
+
+    def sign(k, msg):
+        d = int(ids[k]["d"], 16).to_bytes(32, "big")
+        nonce = b"\x00" + bytes(rng.integers(1, 255, size=31, dtype=np.uint8))
+        r, s = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        assert L.oracle_p256_sign(d, hashlib.sha256(msg).digest(), nonce, 1, r, s) == 0
+        return po.marshal_ecdsa_signature(int.from_bytes(r.raw, "big"), int.from_bytes(s.raw, "big"))
+    envs = []
+    for t in range(n_tx):
+        picks = [int(j) for j in rng.choice(4, size=3, replace=False)]
+        c = 4 + t % 2
+        payload, _ = bb.consistent_endorser_tx("mychannel", sid[c], bytes(rng.integers(0, 256, size=24, dtype=np.uint8)),
+                                               bytes(rng.integers(0, 256, size=300, dtype=np.uint8)), bytes(rng.integers(0, 256, size=990, dtype=np.uint8)),
+                                               lambda prp: [(sid[j], sign(j, prp + sid[j])) for j in picks])
+        envs.append(bb.envelope(payload, sign(c, payload)))
+    return bb.block(1, envs)
+
+
+@pytest.mark.gpu
+def test_split_submission_equals_the_host_route(csp, monkeypatch):
+    """More than 32 768 tuples: the device route submits the creators as a launch of their own (two lanes per signature) beside the
+    endorsements (one lane), rows permuted - statuses, digests and keys must still land on the right tuples.  The block's signatures are
+    valid; a few dozen are then broken in place (creators and endorsers), so that a wrong row would show."""
+    blk = _bench_block(10000)
+    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+    host = fabgpu.preverify_block2(csp, blk, block_seq=1)
+    assert (host["tx_flags"] == 0).all() and len(host["tuple_status"]) == 40000
+    rng = np.random.default_rng(12)
+    broken = bytearray(blk)
+    victims = sorted(int(v) for v in rng.choice(40000, size=60, replace=False))
+    for i in victims:
+        sp = [int(x) for x in host["tuple_spans"][i]]
+        broken[sp[6] + sp[7] - 1 - int(rng.integers(0, 6))] ^= 0x04            # low bytes of s: still the common DER shape
+    broken = bytes(broken)
+    host_b = fabgpu.preverify_block2(csp, broken, block_seq=2)
+    assert sorted(int(i) for i in np.nonzero(host_b["tuple_status"])[0]) == victims
+    monkeypatch.delenv("FABGPU_PASS_STAGE_MIN_BYTES")
+    before = fabgpu.pass_routes(csp)["device_walks"]
+    keys = ["tx_flags", "tx_type", "tuple_tx", "tuple_kind", "tuple_status", "tuple_spans", "tuple_digest", "tuple_hashed", "tuple_qxy"]
+    _same(host, fabgpu.preverify_block2(csp, blk, block_seq=3), keys)
+    dev_b = fabgpu.preverify_block2(csp, broken, block_seq=4, seed_memo=True)
+    _same(host_b, dev_b, keys)
+    assert fabgpu.pass_routes(csp)["device_walks"] == before + 2
+    assert dev_b["memo_seeded"] == 40000
+    flags_only = fabgpu.preverify_block(csp, broken)
+    _same(host_b, flags_only, ["tx_flags", "tuple_status"])
