@@ -545,10 +545,13 @@ int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* di
     BlockTuple canary;
     canary.tx = 0xDEADBEEF;
     std::fill(tuples.begin(), tuples.end(), canary);
+    std::vector<uint32_t> cspans(2 * (size_t)ne + 2, 0xDEADBEEFu);     // the creators' message spans, in creator order
+    uint32_t ncre = 0;
     for (uint32_t e = 0; e < ne; e++) {
         if (cnt[e].t == 0 && cnt[e].p == 0 && cnt[e].c == 0) continue;
         walk::WriteEmitter em{tuples.data(), pre_off2.data(), checks.data(), gsp.data(), goff.data(), base[e].t, base[e].p, base[e].c, (uint32_t)base[e].g,
-                              cnt[e].t, cnt[e].p, cnt[e].c};
+                              cnt[e].t, cnt[e].p, cnt[e].c, cspans.data(), ncre};
+        if (cnt[e].t) ncre++;
         uint8_t t2, u2;
         walk::walk_envelope(block, block + env[2 * e], env[2 * e + 1], e, em, t2, u2);
         if (t2 != type[e] || u2 != und[e] || em.nt != cnt[e].t || em.np != cnt[e].p || em.nc != cnt[e].c) { put_err(diff, cap, "the two runs disagree on envelope " + std::to_string(e)); return 1; }
@@ -571,6 +574,16 @@ int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* di
             d = "tuple " + std::to_string(i);
     }
     if (d.empty() && tuples[run.t].tx != 0xDEADBEEF) d = "a tuple was written past the end";
+    {   // creator spans: one per envelope that yields tuples, equal to the suffix of that envelope's first tuple
+        uint32_t k = 0;
+        for (size_t i = 0; d.empty() && i < host_env_tuples; i++) {
+            if (host.tuples[i].kind != TUPLE_CREATOR) continue;
+            const Span sx = host.tuples[i].suffix;
+            if (cspans[2 * (size_t)k + 1] - cspans[2 * (size_t)k] != sx.len || (sx.len && cspans[2 * (size_t)k] != sx.off)) d = "creator span " + std::to_string(k);
+            k++;
+        }
+        if (d.empty() && (k != ncre || cspans[2 * (size_t)k] != 0xDEADBEEFu)) d = "creator span count";
+    }
     for (size_t i = 0; d.empty() && i < host.prefixes.size(); i++) {
         const Span a = host.prefixes[i];
         if (pre_off2[2 * i + 1] - pre_off2[2 * i] != a.len || (a.len && pre_off2[2 * i] != a.off)) d = "prefix " + std::to_string(i);

@@ -344,11 +344,19 @@ struct WriteEmitter {
     uint32_t* gather_off;
     uint32_t base_t, base_p, base_c, base_g;
     uint32_t lim_t, lim_p, lim_c;
+    uint32_t* creator_spans;          // optional: (start, end) of the creator tuple's message at index creator_index (its hash can start early)
+    uint32_t creator_index;
     uint32_t nt = 0, np = 0, nc = 0, g = 0;
     WALK_HD void mark() {}
     WALK_HD void rollback() { nt = np = nc = g = 0; }    // (mark() precedes the first record of an envelope)
     WALK_HD void add_tuple(const BlockTuple& t) {
-        if (nt < lim_t) tuples[base_t + nt] = t;
+        if (nt < lim_t) {
+            tuples[base_t + nt] = t;
+            if (nt == 0 && creator_spans) {                          // an envelope's first tuple is its creator's
+                creator_spans[2 * (size_t)creator_index] = t.suffix.len ? t.suffix.off : 0;
+                creator_spans[2 * (size_t)creator_index + 1] = t.suffix.len ? t.suffix.off + t.suffix.len : 0;
+            }
+        }
         nt++;
     }
     WALK_HD int32_t add_prefix(const Span& s) {

@@ -73,6 +73,7 @@ struct WalkArrays {
     bccsp::BlockHashCheck* checks = nullptr;
     uint32_t* gather_spans = nullptr;
     uint32_t* gather_off = nullptr;
+    uint32_t* creator_spans = nullptr;   // (start, end) of every creator tuple's message, in creator order (split submissions hash them early)
     uint32_t* id_idx = nullptr;
     uint32_t* off2 = nullptr;
     uint32_t* pre_idx = nullptr;

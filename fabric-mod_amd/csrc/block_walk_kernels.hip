@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64) walk_emit_kernel(WalkArrays a, uint32_t n_
     const uint4 base = a.bases[e];
     uint32_t off = a.env_spans[2 * e], len = a.env_spans[2 * e + 1];
     if (off > a.block_len || len > a.block_len - off) off = len = 0;
-    WriteEmitter em{a.tuples, a.pre_off2, a.checks, a.gather_spans, a.gather_off, base.x, base.y, base.z, base.w, cnt.x, cnt.y, cnt.z};
+    WriteEmitter em{a.tuples, a.pre_off2, a.checks, a.gather_spans, a.gather_off, base.x, base.y, base.z, base.w, cnt.x, cnt.y, cnt.z, a.creator_spans, a.cbase[e]};
     uint8_t type = 255, understood = 0;
     bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
 }

@@ -162,6 +162,7 @@ struct fabgpu_ctx {
     PinBuf walk_pin;
     void* d_idtab = nullptr;
     uint32_t idtab_n = 0, idtab_mask = 0;
+    bool idtab_all_keyed = false;    // every P-256 identity of the table has a comb table: whoever the device recognises is keyed
     size_t idtab_entries_off = 0, idtab_bytes_off = 0;
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
     int acquire_qws(size_t bytes, size_t* idx, void** p, hipStream_t st);
@@ -1248,6 +1249,9 @@ int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const
     if (ctx->d_idtab) hipFree(ctx->d_idtab);
     ctx->d_idtab = d;
     ctx->idtab_n = n;
+    ctx->idtab_all_keyed = n != 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (entries[i].p256 && entries[i].key_id < 0) ctx->idtab_all_keyed = false;
     ctx->idtab_mask = cap - 1;
     ctx->idtab_entries_off = eo;
     ctx->idtab_bytes_off = bo;
@@ -1341,7 +1345,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_off = carve((size_t)nt * 8), o_pix = carve((size_t)nt * 4), o_kid = carve((size_t)nt * 4), o_qx = carve((size_t)nt * 32),
                  o_qy = carve((size_t)nt * 32), o_r = carve((size_t)nt * 32), o_s = carve((size_t)nt * 32), o_gst = carve(nt), o_bits = carve(words * 8),
                  o_dst = carve(nt), o_tst = carve(nt), o_hsh = carve(nt), o_dig = carve((size_t)nt * 32), o_mid = carve(((size_t)np + 1) * 32),
-                 o_row = carve((size_t)nt * 4), o_bitc = carve(words * 8), o_tdig = carve((size_t)nt * 32);
+                 o_row = carve((size_t)nt * 4), o_bitc = carve(words * 8), o_tdig = carve((size_t)nt * 32), o_cspan = carve(((size_t)tot.creators + 1) * 8);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
     a.tuples = (bccsp::BlockTuple*)(dt + o_tup);
@@ -1358,6 +1362,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.qx = dt + o_qx; a.qy = dt + o_qy; a.r = dt + o_r; a.s = dt + o_s;
     a.gate_st = dt + o_gst;
     a.row_of = (uint32_t*)(dt + o_row);
+    a.creator_spans = (uint32_t*)(dt + o_cspan);
     a.n_dev_tuples = tot.tuples;
     a.n_creators = tot.creators;
     // Split the submission (WalkArrays::row_of) when one launch would have to run one lane per signature (more than VERIFY_PAIR_MAX
@@ -1459,6 +1464,12 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pa, s2);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s2);
     }
+    if (err == hipSuccess && a.split) {
+        // the creators' messages are whole envelope payloads - the longest hashes of the block by far: they start now, beside the
+        // identity lookup and the gates, and their launch then only has the arithmetic left (digest rows [0, n_creators))
+        if (!np) err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2);
+    }
     if (err == hipSuccess && nc) {
         err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
         if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s3);
@@ -1466,14 +1477,26 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     }
     if (err == hipSuccess) err = launch_walk_gate(a, st);
     if (err == hipSuccess) err = hipMemcpyAsync(ph + p_sum, de + o_sum, sizeof(WalkSummary), hipMemcpyDeviceToHost, st);
-    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    // What the gates found decides whether this pass may answer at all (an unknown identity, an odd signature: the host walk takes the
+    // block) and which kernels run (registered keys or keys carried along).  When every identity the device can recognise HAS a comb
+    // table the second question is settled in advance, and the first is asked after the fact: the launches are queued without waiting
+    // for the summary (one host round trip less) and their results are dropped if the summary says so.
+    const bool speculate = ctx->idtab_all_keyed;
+    auto judge = [&]() -> int {
+        rq.summary = *(const WalkSummary*)(ph + p_sum);
+        if (rq.summary.n_unknown_identity) return decline("an identity the device has not met");
+        if (rq.summary.n_declined) return decline("a signature outside the common DER shape");
+        if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
+        return FABGPU_OK;
+    };
+    if (!speculate) {
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        if (err != hipSuccess) return hip_to_rc(err);
+        if ((rc = judge())) return rc;
+    }
     if (err != hipSuccess) return hip_to_rc(err);
-    rq.summary = *(const WalkSummary*)(ph + p_sum);
     rq.ms_walk = ms_since(t_start);
-    if (rq.summary.n_unknown_identity) return decline("an identity the device has not met");
-    if (rq.summary.n_declined) return decline("a signature outside the common DER shape");
-    if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
-    rq.all_keyed = rq.summary.n_unkeyed == 0;
+    rq.all_keyed = speculate || rq.summary.n_unkeyed == 0;
     // ---- the fused launches over device-resident submission arrays ----
     const auto t_verify = now();
     pa.mid_ready = true;
@@ -1489,6 +1512,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // rows [row0, row0 + n) as one launch on stream `ls`
     auto verify_rows = [&](uint32_t row0, uint32_t n, bool prefixed, bool pair, void* bits, hipStream_t ls) -> int {
         ShaPrefixArgs p = pa;
+        if (a.split) p.lds_reserve = 84u << 10;                            // the two launches of a split submission on disjoint CUs (kernels.h)
         if (!prefixed) {
             p.m = 0;
             p.pre_off = p.pre_idx = nullptr;
@@ -1519,7 +1543,19 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipEventRecord(ctx->ev_w[3], st);                            // the submission arrays are complete
         if (err == hipSuccess) err = hipStreamWaitEvent(s2, ctx->ev_w[3], 0);
         if (err != hipSuccess) return hip_to_rc(err);
-        if ((rc = verify_rows(0, tot.creators, false, true, dt + o_bitc, s2))) return rc;
+        {   // rows [0, n_creators): digests are there (or about to be: same stream), keys by id or carried along
+            hipError_t e;
+            if (rq.all_keyed) {
+                e = launch_p256_verify_keyed(tot.creators, a.key_id, nkeys, (const void*)kt, dt + o_dig, a.r, a.s, ctx->d_gtab, dt + o_bitc, dt + o_dst, true, s2, 84u << 10);
+            } else {
+                size_t wi = 0;
+                void* wsp = nullptr;
+                if ((rc = ctx->acquire_qws(verify_workspace_bytes(tot.creators, true), &wi, &wsp, s2))) return rc;
+                e = launch_p256_verify(tot.creators, a.qx, a.qy, dt + o_dig, a.r, a.s, ctx->d_gtab, wsp, dt + o_bitc, dt + o_dst, true, s2, 84u << 10);
+                ctx->release_qws(wi, s2);
+            }
+            if (e != hipSuccess) return hip_to_rc(e);
+        }
         err = hipEventRecord(ctx->ev_w[4], s2);
         if (err != hipSuccess) return hip_to_rc(err);
         if ((rc = verify_rows(tot.creators, nt - tot.creators, np != 0, false, dt + o_bits, st))) return rc;
@@ -1539,6 +1575,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err != hipSuccess) return hip_to_rc(err);
+    if (speculate && (rc = judge())) return rc;                             // (nothing was delivered)
     rq.ms_verify = ms_since(t_verify);
     deliver(out.tx_flags, p_flags, ne);
     deliver(out.tx_type, p_type, ne);

@@ -22,6 +22,10 @@ struct ShaPrefixArgs {
     bool spans = false;   // off / pre_off hold (start, end) pairs
     void* digests = nullptr;   // optional out (device): n x 32 bytes, the digest of every message
     bool mid_ready = false;    // the mid-states are already in mid_scratch (launch_sha256_midstates ran, e.g. on another stream)
+    // Bytes of (unused) dynamic LDS to request with the launch.  More than half a CU's 160 KB keeps a second workgroup - of this or of
+    // any other kernel - off the CU: two launches that run side by side on two streams then land on DISJOINT CUs instead of sharing
+    // SIMDs (two waves on a SIMD take 1.5x the time each; the dispatcher fills a CU that still has room before it moves on).
+    uint32_t lds_reserve = 0;
 };
 struct VerifyGeom {
     uint32_t block;   // threads per workgroup
@@ -33,16 +37,19 @@ size_t verify_workspace_bytes(uint32_t n, bool allow_pair);
 // the mid-state kernel of a prefixed batch alone (the fused launchers run it themselves unless pa.mid_ready)
 hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st);
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);
+// n messages given as (start, end) pairs -> n x 32 digest bytes
+hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st);
 // gathered messages (pieces of the arena stitched into `scratch` at out_off[j] .. out_off[j+1]) -> n x 32 digest bytes
 hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,
                                 size_t scratch_bytes, void* digests, hipStream_t st);
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
-                              const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
+                              const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st,
+                              uint32_t lds_reserve = 0);   // lds_reserve: see ShaPrefixArgs
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
                                      const void* qy, const void* r, const void* s, const void* gtab, void* qws,
                                      void* verdict_bits, void* status, bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st);
 hipError_t launch_p256_verify_keyed(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* e, const void* r, const void* s,
-                                    const void* gtab, void* verdict_bits, void* status, bool allow_pair, hipStream_t st);
+                                    const void* gtab, void* verdict_bits, void* status, bool allow_pair, hipStream_t st, uint32_t lds_reserve = 0);
 hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* key_id, uint32_t nkeys,
                                            const void* ktabs, const void* r, const void* s, const void* gtab, void* verdict_bits, void* status,
                                            bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st);

@@ -68,6 +68,22 @@ __global__ void __launch_bounds__(256) sha256_batch_kernel(uint32_t n, const uin
     }
 }
 
+// the same over (start, end) pairs: message i = arena[spans[2i], spans[2i + 1])
+__global__ void __launch_bounds__(256) sha256_spans_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                            const uint32_t* __restrict__ spans, uint32_t* __restrict__ digests) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < n;
+    uint32_t ic = active ? i : (n - 1);
+    uint32_t start = spans[2 * ic], end = spans[2 * ic + 1];
+    uint32_t h[8];
+    sha256_lane(arena32, arena_words, start, end >= start ? end - start : 0, active, h);
+    if (active) {
+        uint4* out = reinterpret_cast<uint4*>(digests + 8 * (size_t)i);
+        out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+        out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ECDSA P-256 verify
 // ------------------------------------------------------------------------------------------------
@@ -365,6 +381,13 @@ hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes
                        (const uint32_t*)off, (uint32_t*)digests);
     return hipGetLastError();
 }
+hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((n + 63) / 64), block(64);      // one wavefront per workgroup: a few thousand long messages spread over every CU
+    hipLaunchKernelGGL(sha256_spans_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)spans,
+                       (uint32_t*)digests);
+    return hipGetLastError();
+}
 hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,
                                 size_t scratch_bytes, void* digests, hipStream_t st) {
     if (n == 0) return hipSuccess;
@@ -391,16 +414,16 @@ size_t verify_workspace_bytes(uint32_t n, bool allow_pair) {
     return (size_t)g.wgs * g.block * QWS_UINT4_PER_LANE * 16;
 }
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
-                              const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st) {
+                              const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st, uint32_t lds_reserve) {
     if (n == 0) return hipSuccess;
     VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair) {
-        hipLaunchKernelGGL(p256_verify_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
+        hipLaunchKernelGGL(p256_verify_pair_kernel<VERIFY_BLOCK>, grid, block, lds_reserve, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
                            (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(p256_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
+    hipLaunchKernelGGL(p256_verify_kernel<VERIFY_BLOCK>, grid, block, lds_reserve, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
                        (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
@@ -412,27 +435,27 @@ hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena
     VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair) {
-        hipLaunchKernelGGL(sha256_p256_verify_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+        hipLaunchKernelGGL(sha256_p256_verify_pair_kernel<VERIFY_BLOCK>, grid, block, pa.lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                            (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
                            (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, pre);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(sha256_p256_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+    hipLaunchKernelGGL(sha256_p256_verify_kernel<VERIFY_BLOCK>, grid, block, pa.lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                        (const uint32_t*)off, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)r, (const uint8_t*)s,
                        (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, pre);
     return hipGetLastError();
 }
 
 hipError_t launch_p256_verify_keyed(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* e, const void* r, const void* s,
-                                    const void* gtab, void* verdict_bits, void* status, bool allow_pair, hipStream_t st) {
+                                    const void* gtab, void* verdict_bits, void* status, bool allow_pair, hipStream_t st, uint32_t lds_reserve) {
     if (n == 0) return hipSuccess;
     VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair)
-        hipLaunchKernelGGL(p256_verify_keyed_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
+        hipLaunchKernelGGL(p256_verify_keyed_pair_kernel<VERIFY_BLOCK>, grid, block, lds_reserve, st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
                            (const uint8_t*)e, (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
     else
-        hipLaunchKernelGGL(p256_verify_keyed_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
+        hipLaunchKernelGGL(p256_verify_keyed_kernel<VERIFY_BLOCK>, grid, block, lds_reserve, st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
                            (const uint8_t*)e, (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
@@ -445,11 +468,11 @@ hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t
     VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair)
-        hipLaunchKernelGGL(sha256_p256_verify_keyed_pair_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena,
+        hipLaunchKernelGGL(sha256_p256_verify_keyed_pair_kernel<VERIFY_BLOCK>, grid, block, pa.lds_reserve, st, n, (const uint32_t*)arena,
                            (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
                            (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status, pre);
     else
-        hipLaunchKernelGGL(sha256_p256_verify_keyed_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena,
+        hipLaunchKernelGGL(sha256_p256_verify_keyed_kernel<VERIFY_BLOCK>, grid, block, pa.lds_reserve, st, n, (const uint32_t*)arena,
                            (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs,
                            (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status, pre);
     return hipGetLastError();
