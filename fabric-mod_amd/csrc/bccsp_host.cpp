@@ -860,6 +860,7 @@ int GPUCSP::SyncDeviceIdentityTable() const {
             DevIdEntry e;
             memset(&e, 0, sizeof(e));
             e.hash = walk::id_hash_host((const uint8_t*)kv.first.data(), (uint32_t)kv.first.size());
+            bytes.resize((bytes.size() + 3) & ~(size_t)3);                  // dword-aligned: the device compares a dword per lane
             e.off = (uint32_t)bytes.size();
             e.len = (uint32_t)kv.first.size();
             e.key_id = kv.second.key_id >= 0 ? (int32_t)kv.second.key_id : -1;

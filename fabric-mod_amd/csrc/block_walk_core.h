@@ -422,8 +422,9 @@ WALK_HD inline uint8_t gate_sig_fast(const uint8_t* sig, uint32_t siglen, uint8_
 
 // ---- identity bytes -> 64-bit table hash ---------------------------------------------------------------------------------
 // The device looks identities up in a table of the ones the provider has met (block_walk_kernels.hip); the hash only picks the slot,
-// equality is always decided on the bytes.  Defined over 64 interleaved byte streams so that a wavefront computes it with one
-// coalesced row per step: stream l folds bytes l, l + 64, ... ; the streams are mixed with per-stream odd constants and summed.
+// equality is always decided on ALL the bytes.  It covers the length and the last 64 bytes - for a certificate the end of its
+// signature, which no two certificates share - so that a wavefront computes it from one coalesced row: lane l folds byte l of that
+// row, the lanes are mixed with per-lane odd constants and summed.  (Identities crafted to collide only lengthen a probe sequence.)
 WALK_HD inline uint64_t id_stream_const(uint32_t l) { return (0x9E3779B97F4A7C15ull * (uint64_t)(2 * l + 1)) | 1ull; }
 WALK_HD inline uint64_t id_stream_fold(uint64_t h, uint8_t b) { return (h ^ b) * 0x100000001B3ull; }
 WALK_HD inline uint64_t id_hash_finish(uint64_t sum, uint32_t len) {
@@ -434,10 +435,12 @@ WALK_HD inline uint64_t id_hash_finish(uint64_t sum, uint32_t len) {
     return h;
 }
 inline uint64_t id_hash_host(const uint8_t* p, uint32_t len) {
+    const uint32_t m = len < 64 ? len : 64;
+    const uint8_t* q = p + (len - m);
     uint64_t sum = 0;
     for (uint32_t l = 0; l < 64; l++) {
         uint64_t h = 0xCBF29CE484222325ull;
-        for (uint32_t i = l; i < len; i += 64) h = id_stream_fold(h, p[i]);
+        if (l < m) h = id_stream_fold(h, q[l]);
         sum += h * id_stream_const(l);
     }
     return id_hash_finish(sum, len);

@@ -97,8 +97,10 @@ __global__ void __launch_bounds__(64) walk_emit_kernel(WalkArrays a, uint32_t n_
     bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
 }
 
-// identity bytes -> index of the provider's cache entry (0xFFFFFFFF: not in the table).  One wavefront per tuple: the ~800 bytes of
-// a SerializedIdentity are hashed and compared in 64-byte rows.
+// identity bytes -> index of the provider's cache entry (0xFFFFFFFF: not in the table).  One wavefront per tuple: one coalesced row
+// for the hash (length + last 64 bytes), then the ~800 bytes of the SerializedIdentity against the candidate's in 256-byte rows
+// (a dword per lane; the block side sits at an arbitrary byte offset: unaligned dword loads, which global memory serves).
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __global__ void __launch_bounds__(256) walk_identity_kernel(WalkArrays a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -107,23 +109,27 @@ __global__ void __launch_bounds__(256) walk_identity_kernel(WalkArrays a) {
     uint32_t found = 0xFFFFFFFFu;
     if (a.id_mask != 0 && id.off <= a.arena_len && id.len <= a.arena_len - id.off) {
         const uint8_t* p = a.block + id.off;
+        const uint32_t m = id.len < 64 ? id.len : 64;
         uint64_t h = 0xCBF29CE484222325ull;
-        for (uint32_t b = lane; b < id.len; b += 64) h = bccsp::walk::id_stream_fold(h, p[b]);
+        if (lane < m) h = bccsp::walk::id_stream_fold(h, p[id.len - m + lane]);
         uint64_t term = h * bccsp::walk::id_stream_const(lane);
         for (int o = 32; o >= 1; o >>= 1) {
             const uint32_t lo32 = __shfl_xor((uint32_t)term, o, 64), hi32 = __shfl_xor((uint32_t)(term >> 32), o, 64);
             term += ((uint64_t)hi32 << 32) | lo32;
         }
         const uint64_t hash = bccsp::walk::id_hash_finish(term, id.len);
+        const uint32_t ndw = id.len >> 2, rest = id.len & 3u;
         uint32_t slot = (uint32_t)hash & a.id_mask;
         for (uint32_t probes = 0; probes <= a.id_mask; probes++) {
             const uint32_t e = a.id_slots[slot];
             if (e == 0) break;
             const DevIdEntry* ent = a.id_entries + (e - 1);
             if (ent->hash == hash && ent->len == id.len) {
-                const uint8_t* q = a.id_bytes + ent->off;
+                const uint8_t* q = a.id_bytes + ent->off;                  // (4-byte aligned: walk_idtab_set's callers lay the bytes out so)
                 bool differs = false;
-                for (uint32_t b = lane; b < id.len; b += 64) differs |= q[b] != p[b];
+                for (uint32_t w = lane; w < ndw; w += 64)
+                    differs |= *reinterpret_cast<const u32_unaligned*>(p + 4 * (size_t)w) != *reinterpret_cast<const u32_unaligned*>(q + 4 * (size_t)w);
+                if (lane < rest) differs |= p[4 * (size_t)ndw + lane] != q[4 * (size_t)ndw + lane];
                 if (__ballot(differs) == 0) {
                     found = e - 1;
                     break;
@@ -166,8 +172,9 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     bool submit = false;
     const uint32_t idx = a.id_idx[i];
     const DevIdEntry* ent = idx != 0xFFFFFFFFu ? a.id_entries + idx : nullptr;
+    bool unknown = false, declined = false;
     if (!ent) {
-        atomicAdd(&a.summary->n_unknown_identity, 1u);
+        unknown = true;
         gst = bccsp::TUPLE_ST_NEEDS_SW;                             // (the host walk takes the whole block when this count is not zero)
     } else if (!ent->p256) {
         gst = bccsp::TUPLE_ST_NEEDS_SW;
@@ -182,7 +189,7 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         } else if (g == bccsp::walk::GATE_HIGH_S) {
             gst = FABGPU_ST_HIGH_S;
         } else {
-            atomicAdd(&a.summary->n_declined, 1u);
+            declined = true;
             gst = bccsp::TUPLE_ST_BAD_DER;                          // (never reported: a declined signature sends the block to the host walk)
         }
         if (!submit) {
@@ -191,9 +198,16 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         }
     }
     const bool keyed = submit && ent->key_id >= 0;
-    if (submit) {
-        atomicAdd(&a.summary->n_submitted, 1u);
-        if (!keyed) atomicAdd(&a.summary->n_unkeyed, 1u);
+    {   // the summary: one atomic per wavefront and counter, not one per tuple
+        const uint64_t live = __ballot(true);
+        const bool first = (uint32_t)(__ffsll((unsigned long long)live) - 1) == (threadIdx.x & 63u);
+        const uint32_t nu = __popcll(__ballot(unknown)), nd = __popcll(__ballot(declined)), ns = __popcll(__ballot(submit)), nk = __popcll(__ballot(submit && !keyed));
+        if (first) {
+            if (nu) atomicAdd(&a.summary->n_unknown_identity, nu);
+            if (nd) atomicAdd(&a.summary->n_declined, nd);
+            if (ns) atomicAdd(&a.summary->n_submitted, ns);
+            if (nk) atomicAdd(&a.summary->n_unkeyed, nk);
+        }
     }
     a.key_id[row] = keyed ? (uint32_t)ent->key_id : 0u;
     uint8_t* qx = a.qx + 32 * (size_t)row;

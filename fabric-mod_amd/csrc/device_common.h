@@ -76,7 +76,11 @@ struct ShaTailRegs {
         for (int k = 0; k < 16; k++) va[k] = w[k];
     }
 };
-template <class Tail>
+// PREFETCH: the 17 dwords of block k + 1 are requested before block k is compressed (17 more VGPRs).  A lane reads its own message,
+// so one load instruction of a wave touches 64 different cache lines and a block's loads take 2-3 us to come back - as long as the
+// ~2 600 instructions of the compression itself when nothing hides them.  The pure hash kernels turn it on (a 2.6 KB message per
+// lane: 8.1 -> us per block); the fused verify kernels are at their register budget and keep the plain loop.
+template <class Tail, bool PREFETCH = false>
 __device__ __forceinline__ void sha256_stream_t(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t h[8], const Tail& tail,
                                                 uint32_t a, uint32_t sb, uint32_t b, uint32_t base, bool active, bool any_prefix) {
     const uint32_t len = a + b;                        // stream bytes still to absorb
@@ -91,17 +95,28 @@ __device__ __forceinline__ void sha256_stream_t(const uint32_t* __restrict__ are
     const int32_t vstart = (int32_t)sb - (int32_t)a;   // B's bytes sit at stream position a: virtual start of the B stream
     const uint32_t shift = (uint32_t)vstart & 3u;      // byte misalignment of the B stream
     const int32_t last_word = arena_words ? (int32_t)arena_words - 1 : 0;
+    uint32_t nxt[17];
+    auto fetch = [&](uint32_t blk_, uint32_t (&dst)[17]) {
+        const int32_t wi_ = (vstart + (int32_t)(blk_ << 6)) >> 2;     // first aligned dword (may be negative in block 0 of a prefixed lane)
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            int32_t idx = wi_ + k;
+            idx = idx < last_word ? idx : last_word;
+            idx = idx > 0 ? idx : 0;
+            dst[k] = arena32[idx];
+        }
+    };
+    if (PREFETCH && maxblk) fetch(0, nxt);
     for (uint32_t blk = 0; blk < maxblk; blk++) {
         uint32_t w[16];
         uint32_t pos = blk << 6;                       // byte position of this block inside the stream
-        int32_t wi = (vstart + (int32_t)pos) >> 2;     // first aligned dword (may be negative in block 0 of a prefixed lane)
         uint32_t raw[17];
+        if (PREFETCH) {
 #pragma unroll
-        for (int k = 0; k < 17; k++) {
-            int32_t idx = wi + k;
-            idx = idx < last_word ? idx : last_word;
-            idx = idx > 0 ? idx : 0;
-            raw[k] = arena32[idx];
+            for (int k = 0; k < 17; k++) raw[k] = nxt[k];
+            if (blk + 1 < maxblk) fetch(blk + 1, nxt);
+        } else {
+            fetch(blk, raw);
         }
         bool full = pos + 64 <= len;
 #pragma unroll
@@ -140,10 +155,11 @@ __device__ __forceinline__ void sha256_stream_t(const uint32_t* __restrict__ are
     }
 }
 
+template <bool PREFETCH = false>
 __device__ __forceinline__ void sha256_stream(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t h[8], uint32_t sa, uint32_t a,
                                               uint32_t sb, uint32_t b, uint32_t base, bool active, bool any_prefix) {
     ShaTailArena tail{arena32, arena_words ? (int32_t)arena_words - 1 : 0, sa};
-    sha256_stream_t(arena32, arena_words, h, tail, a, sb, b, base, active, any_prefix);
+    sha256_stream_t<ShaTailArena, PREFETCH>(arena32, arena_words, h, tail, a, sb, b, base, active, any_prefix);
 }
 
 __device__ __forceinline__ void sha256_iv(uint32_t h[8]) {
@@ -151,10 +167,11 @@ __device__ __forceinline__ void sha256_iv(uint32_t h[8]) {
     h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
 }
 // Hash message [start, start+len) of the arena.
+template <bool PREFETCH = false>
 __device__ __forceinline__ void sha256_lane(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t start,
                                             uint32_t len, bool active, uint32_t h[8]) {
     sha256_iv(h);
-    sha256_stream(arena32, arena_words, h, 0, 0, start, len, 0, active, false);
+    sha256_stream<PREFETCH>(arena32, arena_words, h, 0, 0, start, len, 0, active, false);
 }
 
 // Shared prefixes (the endorsements of one transaction all sign  prp || endorser_i,

@@ -1468,7 +1468,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         // the creators' messages are whole envelope payloads - the longest hashes of the block by far: they start now, beside the
         // identity lookup and the gates, and their launch then only has the arithmetic left (digest rows [0, n_creators))
         if (!np) err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2);
+        if (err == hipSuccess) err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2, 84u << 10);
     }
     if (err == hipSuccess && nc) {
         err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);

@@ -34,15 +34,22 @@ __global__ void __launch_bounds__(256) sha256_midstate_kernel(uint32_t m, const 
     sha256_iv(h);
     const uint32_t shift = start & 3u;
     const uint32_t last_word = arena_words ? arena_words - 1 : 0;
-    for (uint32_t blk = 0; blk < maxfull; blk++) {
-        uint32_t w[16], raw[17];
-        uint32_t wi = (start + (blk << 6)) >> 2;
+    uint32_t nxt[17];
+    auto fetch = [&](uint32_t blk_, uint32_t (&dst)[17]) {
+        const uint32_t wi = (start + (blk_ << 6)) >> 2;
 #pragma unroll
         for (int k = 0; k < 17; k++) {
             uint32_t idx = wi + k;
             idx = idx < last_word ? idx : last_word;
-            raw[k] = arena32[idx];
+            dst[k] = arena32[idx];
         }
+    };
+    if (maxfull) fetch(0, nxt);
+    for (uint32_t blk = 0; blk < maxfull; blk++) {             // (the next block's loads are in flight while this one is compressed)
+        uint32_t w[16], raw[17];
+#pragma unroll
+        for (int k = 0; k < 17; k++) raw[k] = nxt[k];
+        if (blk + 1 < maxfull) fetch(blk + 1, nxt);
 #pragma unroll
         for (int k = 0; k < 16; k++) w[k] = __builtin_bswap32(__builtin_amdgcn_alignbyte(raw[k + 1], raw[k], shift));
         if (blk < nfull) sha256_compress(h, w);
@@ -60,7 +67,7 @@ __global__ void __launch_bounds__(256) sha256_batch_kernel(uint32_t n, const uin
     uint32_t ic = active ? i : (n - 1);
     uint32_t start = off[ic], end = off[ic + 1];
     uint32_t h[8];
-    sha256_lane(arena32, arena_words, start, end - start, active, h);
+    sha256_lane<true>(arena32, arena_words, start, end - start, active, h);
     if (active) {
         uint4* out = reinterpret_cast<uint4*>(digests + 8 * (size_t)i);
         out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
@@ -76,7 +83,7 @@ __global__ void __launch_bounds__(256) sha256_spans_kernel(uint32_t n, const uin
     uint32_t ic = active ? i : (n - 1);
     uint32_t start = spans[2 * ic], end = spans[2 * ic + 1];
     uint32_t h[8];
-    sha256_lane(arena32, arena_words, start, end >= start ? end - start : 0, active, h);
+    sha256_lane<true>(arena32, arena_words, start, end >= start ? end - start : 0, active, h);
     if (active) {
         uint4* out = reinterpret_cast<uint4*>(digests + 8 * (size_t)i);
         out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
@@ -381,10 +388,12 @@ hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes
                        (const uint32_t*)off, (uint32_t*)digests);
     return hipGetLastError();
 }
-hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st) {
+hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st, uint32_t lds_reserve) {
     if (n == 0) return hipSuccess;
-    dim3 grid((n + 63) / 64), block(64);      // one wavefront per workgroup: a few thousand long messages spread over every CU
-    hipLaunchKernelGGL(sha256_spans_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)spans,
+    // small workgroups: a few thousand long messages spread over many CUs (two wavefronts each when the launch keeps its CUs to itself)
+    const uint32_t per = lds_reserve ? 128 : 64;
+    dim3 grid((n + per - 1) / per), block(per);
+    hipLaunchKernelGGL(sha256_spans_kernel, grid, block, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)spans,
                        (uint32_t*)digests);
     return hipGetLastError();
 }
