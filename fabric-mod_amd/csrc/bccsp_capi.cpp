@@ -6,6 +6,8 @@
 
 #include <mutex>
 
+#include "block_walk_dev.h"
+
 #include <chrono>
 
 #include "../../include/fabgpu_bccsp.h"
@@ -614,6 +616,11 @@ int fabgpu_gate_sig_fast(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* 
         if (s32) memcpy(s32, s, 32);
     }
     return g;
+}
+// TEST HOOK (device): the wavefront form of the same gate, as block_walk_kernels.hip runs it, over n signatures
+int fabgpu_csp_gate_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s) {
+    if (!csp) return FABGPU_EINVAL;
+    return fab::walk_gate_probe(csp->csp->ctx(), n, arena, arena_len, spans, code, r, s);
 }
 // TEST HOOK (pure host): the table hash of identity bytes (block_walk_core.h id_hash_host)
 uint64_t fabgpu_identity_table_hash(const uint8_t* p, size_t len) { return walk::id_hash_host(p, (uint32_t)len); }

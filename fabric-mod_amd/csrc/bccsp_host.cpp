@@ -1055,7 +1055,11 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     out.memo_seeded = 0;
     out.n_block_sigs = pb.n_block_sigs;
     out.block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
-    out.n_keyed = rq.all_keyed ? rq.summary.n_submitted : 0;
+    {   // tuples the device decided = tuples it hashed
+        size_t submitted = 0;
+        for (size_t i = 0; i < out.tuple_hashed.size(); i++) submitted += out.tuple_hashed[i];
+        out.n_keyed = rq.all_keyed ? submitted : 0;
+    }
     for (size_t i = nd; i < nt; i++) {                                   // block signatures the caller asked not to verify
         out.tuple_status[i] = TUPLE_ST_SKIPPED;
         out.tuple_hashed[i] = 0;

@@ -44,7 +44,7 @@ static_assert(sizeof(DevIdEntry) == 88, "uploaded as raw bytes");
 struct WalkSummary {
     uint32_t n_unknown_identity;   // tuples whose identity is not in the device table: the host walk takes the block (and learns them)
     uint32_t n_declined;           // signatures the fast gate declines: the host's general parser decides
-    uint32_t n_submitted;          // tuples the device decides
+    uint32_t n_submitted;          // non-zero: some tuple is for the device to decide (a flag, not a count)
     uint32_t n_unkeyed;            // ... of which without a registered comb table (any: the fresh-key kernel serves the block)
 };
 
@@ -109,7 +109,9 @@ struct WalkArrays {
 hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st);                       // counts, tx_type, tx_understood; then the scan
 hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st);   // tuples, prefixes, checks, gather spans / offsets
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);                        // identity lookup + gates + submission arrays + summary
-hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st);    // statuses, digest comparisons, per-transaction flags
+hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st);
+// TEST HOOK: the wavefront form of the signature gate over n signatures (device pointers; spans = (start, end) pairs into arena)
+hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spans, void* code, void* r, void* s, hipStream_t st);    // statuses, digest comparisons, per-transaction flags
 
 // ---- host side (fabgpu_api.hip) ----
 // Replace the device's identity table (entries + their bytes); the table is rebuilt by the provider whenever its cache changes.
@@ -153,5 +155,8 @@ struct WalkRequest {
 };
 // FABGPU_OK, WALK_DECLINED, or a negative FABGPU_E*
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq);
+// TEST HOOK: the device's (wavefront) signature gate over n signatures = arena[spans[2i], spans[2i+1]) in host memory -> code (as
+// walk::gate_sig_fast), r, s (32 bytes each; zero unless code == GATE_SUBMIT)
+int walk_gate_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s);
 
 }  // namespace fab

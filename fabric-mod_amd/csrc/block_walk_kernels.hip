@@ -97,62 +97,106 @@ __global__ void __launch_bounds__(64) walk_emit_kernel(WalkArrays a, uint32_t n_
     bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
 }
 
-// identity bytes -> index of the provider's cache entry (0xFFFFFFFF: not in the table).  One wavefront per tuple: one coalesced row
-// for the hash (length + last 64 bytes), then the ~800 bytes of the SerializedIdentity against the candidate's in 256-byte rows
-// (a dword per lane; the block side sits at an arbitrary byte offset: unaligned dword loads, which global memory serves).
+// ---- one wavefront per tuple: identity lookup, signature gate, submission row -----------------------------------------------------
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-__global__ void __launch_bounds__(256) walk_identity_kernel(WalkArrays a) {
+// n/2 of P-256 (bccsp/utils/ecdsa.go:30-37 curveHalfOrders) and the generator (key of the filler rows), big-endian bytes
+__constant__ uint8_t C_HALF_N[32] = {0x7f, 0xff, 0xff, 0xff, 0x80, 0x00, 0x00, 0x00, 0x7f, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
+                                     0xde, 0x73, 0x7d, 0x56, 0xd3, 0x8b, 0xcf, 0x42, 0x79, 0xdc, 0xe5, 0x61, 0x7e, 0x31, 0x92, 0xa8};
+__constant__ uint8_t C_GXY[64] = {0x6b, 0x17, 0xd1, 0xf2, 0xe1, 0x2c, 0x42, 0x47, 0xf8, 0xbc, 0xe6, 0xe5, 0x63, 0xa4, 0x40, 0xf2,
+                                  0x77, 0x03, 0x7d, 0x81, 0x2d, 0xeb, 0x33, 0xa0, 0xf4, 0xa1, 0x39, 0x45, 0xd8, 0x98, 0xc2, 0x96,
+                                  0x4f, 0xe3, 0x42, 0xe2, 0xfe, 0x1a, 0x7f, 0x9b, 0x8e, 0xe7, 0xeb, 0x4a, 0x7c, 0x0f, 0x9e, 0x16,
+                                  0x2b, 0xce, 0x33, 0x57, 0x6b, 0x31, 0x5e, 0xce, 0xcb, 0xb6, 0x40, 0x68, 0x37, 0xbf, 0x51, 0xf5};
+
+// identity bytes -> index of the provider's cache entry (0xFFFFFFFF: not in the table): one coalesced row for the hash (length + last
+// 64 bytes), then the ~800 bytes of the SerializedIdentity against the candidate's in 256-byte rows (a dword per lane; the block side
+// sits at an arbitrary byte offset: unaligned dword loads, which global memory serves).  Wave-uniform in, wave-uniform out.
+__device__ __forceinline__ uint32_t wave_identity_lookup(const WalkArrays& a, const Span id, uint32_t lane) {
+    uint32_t found = 0xFFFFFFFFu;
+    if (a.id_mask == 0 || id.off > a.arena_len || id.len > a.arena_len - id.off) return found;
+    const uint8_t* p = a.block + id.off;
+    const uint32_t m = id.len < 64 ? id.len : 64;
+    uint64_t h = 0xCBF29CE484222325ull;
+    if (lane < m) h = bccsp::walk::id_stream_fold(h, p[id.len - m + lane]);
+    uint64_t term = h * bccsp::walk::id_stream_const(lane);
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t lo32 = __shfl_xor((uint32_t)term, o, 64), hi32 = __shfl_xor((uint32_t)(term >> 32), o, 64);
+        term += ((uint64_t)hi32 << 32) | lo32;
+    }
+    const uint64_t hash = bccsp::walk::id_hash_finish(term, id.len);
+    const uint32_t ndw = id.len >> 2, rest = id.len & 3u;
+    uint32_t slot = (uint32_t)hash & a.id_mask;
+    for (uint32_t probes = 0; probes <= a.id_mask; probes++) {
+        const uint32_t e = a.id_slots[slot];
+        if (e == 0) break;
+        const DevIdEntry* ent = a.id_entries + (e - 1);
+        if (ent->hash == hash && ent->len == id.len) {
+            const uint8_t* q = a.id_bytes + ent->off;                  // (4-byte aligned: walk_idtab_set's callers lay the bytes out so)
+            bool differs = false;
+            for (uint32_t w = lane; w < ndw; w += 64)
+                differs |= *reinterpret_cast<const u32_unaligned*>(p + 4 * (size_t)w) != *reinterpret_cast<const u32_unaligned*>(q + 4 * (size_t)w);
+            if (lane < rest) differs |= p[4 * (size_t)ndw + lane] != q[4 * (size_t)ndw + lane];
+            if (__ballot(differs) == 0) {
+                found = e - 1;
+                break;
+            }
+        }
+        slot = (slot + 1) & a.id_mask;
+    }
+    return found;
+}
+
+// walk::gate_sig_fast (block_walk_core.h) by a whole wavefront: the signature's bytes sit one per lane (two coalesced loads), every
+// byte the parse looks at travels by a lane permute, lanes 0..31 assemble r and lanes 32..63 assemble s (one byte each), the
+// comparison with n/2 is two ballots.  Returns the same code; `field_byte` is this lane's byte of r (lanes 0..31) or s (32..63) when
+// the code is GATE_SUBMIT.  Must be called by all 64 lanes; sig / siglen wave-uniform.
+__device__ __forceinline__ uint8_t wave_gate_sig(const uint8_t* sig, uint32_t siglen, uint32_t lane, uint32_t& field_byte) {
+    using namespace bccsp::walk;
+    field_byte = 0;
+    if (siglen == 0) return GATE_EMPTY;
+    if (siglen < 8 || siglen > 72) return GATE_DECLINED;
+    const uint32_t b0 = lane < siglen ? sig[lane] : 0u, b1 = lane + 64 < siglen ? sig[lane + 64] : 0u;
+    auto at = [&](uint32_t pos) -> uint32_t {                          // byte `pos` of the signature (0 beyond its end); pos <= 79
+        const uint32_t v0 = __shfl(b0, (int)(pos & 63u), 64), v1 = __shfl(b1, (int)(pos & 63u), 64);
+        return pos < 64 ? v0 : v1;
+    };
+    if (at(0) != 0x30 || at(1) != siglen - 2 || at(2) != 0x02) return GATE_DECLINED;
+    uint32_t lr = at(3);
+    if (lr < 1 || lr > 33 || 4 + lr + 2 > siglen || at(4 + lr) != 0x02) return GATE_DECLINED;
+    uint32_t ls = at(5 + lr);
+    uint32_t pr = 4, ps = 6 + lr;
+    if (ls < 1 || ls > 33 || 6 + lr + ls != siglen) return GATE_DECLINED;
+    const uint32_t r0 = at(pr), r1 = at(pr + 1), s0 = at(ps), s1 = at(ps + 1);
+    auto minimal_positive = [](uint32_t p0, uint32_t p1, uint32_t l) {
+        if (p0 & 0x80) return false;                                    // negative
+        if (p0 == 0) return l > 1 && (p1 & 0x80) != 0 && l <= 33;       // a leading zero must be needed (also excludes zero)
+        return l <= 32;
+    };
+    if (!minimal_positive(r0, r1, lr) || !minimal_positive(s0, s1, ls)) return GATE_DECLINED;
+    if (r0 == 0) { pr++; lr--; }
+    if (s0 == 0) { ps++; ls--; }
+    const uint32_t k = lane & 31u;
+    const bool is_s = lane >= 32;
+    const uint32_t base = is_s ? ps : pr, L = is_s ? ls : lr;
+    const bool inside = k + L >= 32;                                    // leading zero bytes of a short integer otherwise
+    const uint32_t v = at(inside ? base + k + L - 32 : 0u);
+    field_byte = inside ? v : 0u;
+    const uint32_t hn = C_HALF_N[k];
+    const uint64_t gt = __ballot(is_s && field_byte > hn), lt = __ballot(is_s && field_byte < hn);
+    const uint64_t d = gt | lt;
+    if (d == 0) return GATE_SUBMIT;                                     // s == n/2 is low
+    const uint64_t first = d & (~d + 1);                                // the most significant differing byte sits in the lowest lane
+    return (gt & first) ? GATE_HIGH_S : GATE_SUBMIT;
+}
+
+// The identity, the gates of one tuple and its row of the submission arrays.  A tuple the device does not decide still gets a
+// well-formed row (r = s = 1 under the generator as key, like the host's fillers): there is no compaction and its verdict is ignored
+// in favour of gate_st.
+__global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= a.n_tuples) return;
-    const Span id = a.tuples[i].identity;
-    uint32_t found = 0xFFFFFFFFu;
-    if (a.id_mask != 0 && id.off <= a.arena_len && id.len <= a.arena_len - id.off) {
-        const uint8_t* p = a.block + id.off;
-        const uint32_t m = id.len < 64 ? id.len : 64;
-        uint64_t h = 0xCBF29CE484222325ull;
-        if (lane < m) h = bccsp::walk::id_stream_fold(h, p[id.len - m + lane]);
-        uint64_t term = h * bccsp::walk::id_stream_const(lane);
-        for (int o = 32; o >= 1; o >>= 1) {
-            const uint32_t lo32 = __shfl_xor((uint32_t)term, o, 64), hi32 = __shfl_xor((uint32_t)(term >> 32), o, 64);
-            term += ((uint64_t)hi32 << 32) | lo32;
-        }
-        const uint64_t hash = bccsp::walk::id_hash_finish(term, id.len);
-        const uint32_t ndw = id.len >> 2, rest = id.len & 3u;
-        uint32_t slot = (uint32_t)hash & a.id_mask;
-        for (uint32_t probes = 0; probes <= a.id_mask; probes++) {
-            const uint32_t e = a.id_slots[slot];
-            if (e == 0) break;
-            const DevIdEntry* ent = a.id_entries + (e - 1);
-            if (ent->hash == hash && ent->len == id.len) {
-                const uint8_t* q = a.id_bytes + ent->off;                  // (4-byte aligned: walk_idtab_set's callers lay the bytes out so)
-                bool differs = false;
-                for (uint32_t w = lane; w < ndw; w += 64)
-                    differs |= *reinterpret_cast<const u32_unaligned*>(p + 4 * (size_t)w) != *reinterpret_cast<const u32_unaligned*>(q + 4 * (size_t)w);
-                if (lane < rest) differs |= p[4 * (size_t)ndw + lane] != q[4 * (size_t)ndw + lane];
-                if (__ballot(differs) == 0) {
-                    found = e - 1;
-                    break;
-                }
-            }
-            slot = (slot + 1) & a.id_mask;
-        }
-    }
-    if (lane == 0) a.id_idx[i] = found;
-}
-
-// The gates of one tuple and its row of the submission arrays.  A tuple the device does not decide still gets a well-formed row
-// (r = s = 1 under the generator as key, like the host's fillers): there is no compaction - tuple i is submission i - and its
-// verdict is ignored in favour of gate_st.
-__global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_tuples) return;
-    // the generator of P-256: key of the filler rows
-    const uint8_t GX[32] = {0x6b, 0x17, 0xd1, 0xf2, 0xe1, 0x2c, 0x42, 0x47, 0xf8, 0xbc, 0xe6, 0xe5, 0x63, 0xa4, 0x40, 0xf2,
-                            0x77, 0x03, 0x7d, 0x81, 0x2d, 0xeb, 0x33, 0xa0, 0xf4, 0xa1, 0x39, 0x45, 0xd8, 0x98, 0xc2, 0x96};
-    const uint8_t GY[32] = {0x4f, 0xe3, 0x42, 0xe2, 0xfe, 0x1a, 0x7f, 0x9b, 0x8e, 0xe7, 0xeb, 0x4a, 0x7c, 0x0f, 0x9e, 0x16,
-                            0x2b, 0xce, 0x33, 0x57, 0x6b, 0x31, 0x5e, 0xce, 0xcb, 0xb6, 0x40, 0x68, 0x37, 0xbf, 0x51, 0xf5};
     const BlockTuple t = a.tuples[i];
+    const uint32_t idx = wave_identity_lookup(a, t.identity, lane);
     // the row of this tuple (WalkArrays::row_of): creators first when the submission is split
     uint32_t row = i;
     if (a.split) {
@@ -161,28 +205,20 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         const bool creator = i < a.n_dev_tuples && i == a.bases[t.tx].x;
         row = creator ? before : a.n_creators + (i - before - (i < a.n_dev_tuples ? 1u : 0u));
     }
-    a.row_of[i] = row;
-    a.off2[2 * (size_t)row] = t.suffix.len ? t.suffix.off : 0;
-    a.off2[2 * (size_t)row + 1] = t.suffix.len ? t.suffix.off + t.suffix.len : 0;
-    a.pre_idx[row] = t.prefix_index >= 0 ? (uint32_t)t.prefix_index : 0xFFFFFFFFu;
-    uint8_t r32[32], s32[32];
-    for (int k = 0; k < 32; k++) r32[k] = s32[k] = 0;
-    r32[31] = s32[31] = 1;
-    uint8_t gst;
-    bool submit = false;
-    const uint32_t idx = a.id_idx[i];
     const DevIdEntry* ent = idx != 0xFFFFFFFFu ? a.id_entries + idx : nullptr;
-    bool unknown = false, declined = false;
+    uint8_t gst;
+    bool submit = false, unknown = false, declined = false;
+    uint32_t field_byte = 0;
     if (!ent) {
         unknown = true;
-        gst = bccsp::TUPLE_ST_NEEDS_SW;                             // (the host walk takes the whole block when this count is not zero)
+        gst = bccsp::TUPLE_ST_NEEDS_SW;                             // (the host walk takes the whole block when any tuple says this)
     } else if (!ent->p256) {
         gst = bccsp::TUPLE_ST_NEEDS_SW;
     } else if (t.sig.len == 0) {
         gst = bccsp::TUPLE_ST_EMPTY_SIG;
     } else {
         uint8_t g = bccsp::walk::GATE_DECLINED;
-        if (t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off) g = bccsp::walk::gate_sig_fast(a.block + t.sig.off, t.sig.len, r32, s32);
+        if (t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off) g = wave_gate_sig(a.block + t.sig.off, t.sig.len, lane, field_byte);
         if (g == bccsp::walk::GATE_SUBMIT) {
             gst = FABGPU_ST_VALID;
             submit = true;
@@ -192,35 +228,40 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
             declined = true;
             gst = bccsp::TUPLE_ST_BAD_DER;                          // (never reported: a declined signature sends the block to the host walk)
         }
-        if (!submit) {
-            for (int k = 0; k < 32; k++) r32[k] = s32[k] = 0;
-            r32[31] = s32[31] = 1;
-        }
     }
     const bool keyed = submit && ent->key_id >= 0;
-    {   // the summary: one atomic per wavefront and counter, not one per tuple
-        const uint64_t live = __ballot(true);
-        const bool first = (uint32_t)(__ffsll((unsigned long long)live) - 1) == (threadIdx.x & 63u);
-        const uint32_t nu = __popcll(__ballot(unknown)), nd = __popcll(__ballot(declined)), ns = __popcll(__ballot(submit)), nk = __popcll(__ballot(submit && !keyed));
-        if (first) {
-            if (nu) atomicAdd(&a.summary->n_unknown_identity, nu);
-            if (nd) atomicAdd(&a.summary->n_declined, nd);
-            if (ns) atomicAdd(&a.summary->n_submitted, ns);
-            if (nk) atomicAdd(&a.summary->n_unkeyed, nk);
-        }
+    // r | s and qx | qy: one byte per lane, 64-byte coalesced rows
+    const uint32_t k = lane & 31u;
+    const uint8_t rs = submit ? (uint8_t)field_byte : (uint8_t)(k == 31 ? 1 : 0);
+    const uint8_t q = submit ? (lane < 32 ? ent->qx[k] : ent->qy[k]) : C_GXY[lane];
+    (lane < 32 ? a.r : a.s)[32 * (size_t)row + k] = rs;
+    (lane < 32 ? a.qx : a.qy)[32 * (size_t)row + k] = q;
+    if (lane == 0) {
+        a.id_idx[i] = idx;
+        a.row_of[i] = row;
+        a.off2[2 * (size_t)row] = t.suffix.len ? t.suffix.off : 0;
+        a.off2[2 * (size_t)row + 1] = t.suffix.len ? t.suffix.off + t.suffix.len : 0;
+        a.pre_idx[row] = t.prefix_index >= 0 ? (uint32_t)t.prefix_index : 0xFFFFFFFFu;
+        a.key_id[row] = keyed ? (uint32_t)ent->key_id : 0u;
+        a.gate_st[i] = gst;
+        // the summary: the rare events are counted, "somebody was submitted" is a flag (most waves find it set already)
+        if (unknown) atomicAdd(&a.summary->n_unknown_identity, 1u);
+        if (declined) atomicAdd(&a.summary->n_declined, 1u);
+        if (submit && !keyed) atomicAdd(&a.summary->n_unkeyed, 1u);
+        if (submit && __builtin_nontemporal_load(&a.summary->n_submitted) == 0) atomicOr(&a.summary->n_submitted, 1u);
     }
-    a.key_id[row] = keyed ? (uint32_t)ent->key_id : 0u;
-    uint8_t* qx = a.qx + 32 * (size_t)row;
-    uint8_t* qy = a.qy + 32 * (size_t)row;
-    uint8_t* r = a.r + 32 * (size_t)row;
-    uint8_t* s = a.s + 32 * (size_t)row;
-    for (int k = 0; k < 32; k++) {
-        qx[k] = submit ? ent->qx[k] : GX[k];
-        qy[k] = submit ? ent->qy[k] : GY[k];
-        r[k] = r32[k];
-        s[k] = s32[k];
-    }
-    a.gate_st[i] = gst;
+}
+
+// TEST HOOK: the wavefront gate alone over n signatures (spans into arena) -> code, r, s per signature
+__global__ void __launch_bounds__(256) walk_gate_probe_kernel(uint32_t n, const uint8_t* __restrict__ arena, const uint32_t* __restrict__ spans,
+                                                               uint8_t* __restrict__ code, uint8_t* __restrict__ r, uint8_t* __restrict__ s) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n) return;
+    uint32_t fb = 0;
+    const uint8_t g = wave_gate_sig(arena + spans[2 * i], spans[2 * i + 1] - spans[2 * i], lane, fb);
+    (lane < 32 ? r : s)[32 * (size_t)i + (lane & 31u)] = g == bccsp::walk::GATE_SUBMIT ? (uint8_t)fb : 0;
+    if (lane == 0) code[i] = g;
 }
 
 // per-transaction evidence bits
@@ -310,10 +351,13 @@ hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_
 }
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st) {
     if (a.n_tuples == 0) return hipSuccess;
-    hipLaunchKernelGGL(walk_identity_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);   // four wavefronts = four tuples per workgroup
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(walk_gate_kernel, dim3((a.n_tuples + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(walk_gate_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);   // four wavefronts = four tuples per workgroup
+    return hipGetLastError();
+}
+hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spans, void* code, void* r, void* s, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(walk_gate_probe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, (const uint8_t*)arena, (const uint32_t*)spans, (uint8_t*)code, (uint8_t*)r,
+                       (uint8_t*)s);
     return hipGetLastError();
 }
 hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st) {

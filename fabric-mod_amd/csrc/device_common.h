@@ -79,7 +79,7 @@ struct ShaTailRegs {
 // PREFETCH: the 17 dwords of block k + 1 are requested before block k is compressed (17 more VGPRs).  A lane reads its own message,
 // so one load instruction of a wave touches 64 different cache lines and a block's loads take 2-3 us to come back - as long as the
 // ~2 600 instructions of the compression itself when nothing hides them.  The pure hash kernels turn it on (a 2.6 KB message per
-// lane: 8.1 -> us per block); the fused verify kernels are at their register budget and keep the plain loop.
+// lane: a few per cent on the 2.6 KB creator payloads of a block, 15 % on the short mid-state and hash-check messages); the fused verify kernels are at their register budget and keep the plain loop.
 template <class Tail, bool PREFETCH = false>
 __device__ __forceinline__ void sha256_stream_t(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t h[8], const Tail& tail,
                                                 uint32_t a, uint32_t sb, uint32_t b, uint32_t base, bool active, bool any_prefix) {

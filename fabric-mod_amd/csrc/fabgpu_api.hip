@@ -132,9 +132,9 @@ struct fabgpu_ctx {
     Buf nymout;       // results of the pseudonym signatures that ride in an identity batch: verdict words | status bytes
     hipStream_t stream2 = nullptr;   // the pseudonym signatures of an identity batch run here, next to the ECDSA kernels on `stream`
     hipEvent_t ev_up = nullptr;      // "the arena is on the device" (recorded on stream, awaited by stream2)
-    // the device block pass runs on three streams: walk / gates / endorsements on `stream`, mid-states and the creators' launch on
-    // stream2, the TxID / proposal-hash digests on stream3
-    hipStream_t stream3 = nullptr;
+    // the device block pass runs on four streams: walk / gates / endorsements on `stream`, the creators' hashes and launch on
+    // stream2, the mid-states on stream3, the TxID / proposal-hash digests on stream4
+    hipStream_t stream3 = nullptr, stream4 = nullptr;
     hipEvent_t ev_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
     void* d_gscr = nullptr;   // device scratch the gather kernel stitches the messages into
@@ -285,6 +285,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
         if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        if (hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         {
             bool ok = true;
             for (auto& e : ctx->ev_w) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -331,6 +332,7 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         if (ctx->stream2) hipStreamDestroy(ctx->stream2);
         if (ctx->ev_up) hipEventDestroy(ctx->ev_up);
         if (ctx->stream3) hipStreamDestroy(ctx->stream3);
+        if (ctx->stream4) hipStreamDestroy(ctx->stream4);
         for (auto& e : ctx->ev_w)
             if (e) hipEventDestroy(e);
         ctx->gath.release();
@@ -1258,6 +1260,32 @@ int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const
     return FABGPU_OK;
 }
 
+// TEST HOOK: the wavefront signature gate of the device walk over n signatures held in host memory
+int walk_gate_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s_out) {
+    if (!ctx || (n && (!arena || !spans || !code || !r || !s_out))) return FABGPU_EINVAL;
+    if (n == 0) return FABGPU_OK;
+    for (uint32_t i = 0; i < n; i++)
+        if (spans[2 * i + 1] < spans[2 * i] || spans[2 * i + 1] > arena_len) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    void *da = nullptr, *ds = nullptr, *dout = nullptr;
+    int rc = FABGPU_ENOMEM;
+    if (hipMalloc(&da, arena_len + 256) == hipSuccess && hipMalloc(&ds, (size_t)n * 8) == hipSuccess && hipMalloc(&dout, (size_t)n * 65) == hipSuccess) {
+        hipError_t e = hipMemcpy(da, arena, arena_len, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ds, spans, (size_t)n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_walk_gate_probe(n, da, ds, (uint8_t*)dout + (size_t)n * 64, dout, (uint8_t*)dout + (size_t)n * 32, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(r, dout, (size_t)n * 32, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s_out, (uint8_t*)dout + (size_t)n * 32, (size_t)n * 32, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(code, (uint8_t*)dout + (size_t)n * 64, n, hipMemcpyDeviceToHost);
+        rc = hip_to_rc(e);
+    }
+    if (da) hipFree(da);
+    if (ds) hipFree(ds);
+    if (dout) hipFree(dout);
+    return rc;
+}
+
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (!ctx || !rq.sizes || !rq.env_spans || rq.stage_token == 0) return FABGPU_EINVAL;
     if (rq.n_block_sigs && !rq.block_sigs) return FABGPU_EINVAL;
@@ -1430,15 +1458,16 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     }
     // From here on three streams work side by side; whatever happens, none of them may still be running when this call returns
     // (the next pass reuses every buffer).
-    hipStream_t s2 = ctx->stream2, s3 = ctx->stream3;
+    hipStream_t s2 = ctx->stream2, s3 = ctx->stream3, s4 = ctx->stream4;
     struct Drain {
-        hipStream_t a, b, c;
+        hipStream_t a, b, c, d;
         ~Drain() {
             hipStreamSynchronize(a);
             hipStreamSynchronize(b);
             hipStreamSynchronize(c);
+            hipStreamSynchronize(d);
         }
-    } drain{s2, s3, st};
+    } drain{s2, s3, s4, st};
     const size_t arena_bytes = round_up(has_tail ? (size_t)rq.tail_base + rq.tail_len : sl->len, 4) + 64;
     ShaPrefixArgs pa;
     pa.spans = true;
@@ -1459,21 +1488,22 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // the emitted prefixes / hash checks are all stream2 and stream3 need: mid-states and the TxID / proposal-hash digests run while
     // the main stream looks identities up and gates signatures
     err = hipEventRecord(ctx->ev_w[0], st);
-    if (err == hipSuccess && np) {
-        err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pa, s2);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s2);
-    }
     if (err == hipSuccess && a.split) {
-        // the creators' messages are whole envelope payloads - the longest hashes of the block by far: they start now, beside the
-        // identity lookup and the gates, and their launch then only has the arithmetic left (digest rows [0, n_creators))
-        if (!np) err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
+        // stream2: the creators' messages are whole envelope payloads - the longest hashes of the block by far (and a serial chain per
+        // message): they start now, beside the identity lookup and the gates, and their launch then only has the arithmetic left
+        // (digest rows [0, n_creators))
+        err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
         if (err == hipSuccess) err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2, 84u << 10);
     }
-    if (err == hipSuccess && nc) {
+    if (err == hipSuccess && np) {       // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them)
         err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s3);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s3);
+        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pa, s3);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s3);
+    }
+    if (err == hipSuccess && nc) {       // stream4: the TxID / proposal-hash digests (only the flags at the very end wait for them)
+        err = hipStreamWaitEvent(s4, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s4);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
     }
     if (err == hipSuccess) err = launch_walk_gate(a, st);
     if (err == hipSuccess) err = hipMemcpyAsync(ph + p_sum, de + o_sum, sizeof(WalkSummary), hipMemcpyDeviceToHost, st);

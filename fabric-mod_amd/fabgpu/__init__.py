@@ -182,6 +182,7 @@ def load():
     L.fabgpu_csp_block_walk_compare.argtypes = [_vp, _u8p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
     L.fabgpu_block_walk_twopass_compare.argtypes = [_u8p, _sz, ctypes.c_char_p, _sz]
     L.fabgpu_gate_sig_fast.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
+    L.fabgpu_csp_gate_probe.argtypes = [_vp, ctypes.c_uint32, _u8p, _sz, _u32p, _u8p, _u8p, _u8p]
     L.fabgpu_identity_table_hash.argtypes = [ctypes.c_char_p, _sz]
     L.fabgpu_identity_table_hash.restype = ctypes.c_uint64
     L.fabgpu_csp_x509_check_signature_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p, _u8p, _u8p]
@@ -877,6 +878,19 @@ def gate_sig_fast(sig: bytes):
     r, s2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
     code = load().fabgpu_gate_sig_fast(sig, len(sig), r, s2)
     return code, r.raw, s2.raw
+
+
+def gate_probe(csp: "GPUCSP", sigs: Sequence[bytes]):
+    """TEST HOOK (device): the wavefront form of the signature gate over many signatures -> (codes, r (n x 32), s (n x 32))."""
+    n = len(sigs)
+    arena = np.frombuffer(b"".join(sigs) + b"\0" * 8, dtype=np.uint8)
+    ends = np.cumsum([len(x) for x in sigs], dtype=np.int64)
+    spans = np.zeros((n, 2), dtype=np.uint32)
+    spans[:, 1] = ends
+    spans[1:, 0] = ends[:-1]
+    code, r, s2 = np.zeros(n, np.uint8), np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
+    _check(csp._L.fabgpu_csp_gate_probe(csp._h, n, _p8(arena), arena.size, spans.ctypes.data_as(_u32p), _p8(code), _p8(r), _p8(s2)), "fabgpu_csp_gate_probe")
+    return code, r, s2
 
 
 def identity_table_hash(b: bytes) -> int:

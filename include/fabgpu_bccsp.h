@@ -147,6 +147,8 @@ int fabgpu_csp_block_walk_compare(fabgpu_csp* csp, const uint8_t* block, size_t 
  * 1 high-S, 2 empty, 3 declined: the general parser decides); the identity-table hash. */
 int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* diff, size_t cap);
 int fabgpu_gate_sig_fast(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32);
+/* TEST HOOK (device): the same gate in the wavefront form the kernels run, over n signatures = arena[spans[2i], spans[2i+1]) */
+int fabgpu_csp_gate_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s);
 uint64_t fabgpu_identity_table_hash(const uint8_t* p, size_t len);
 
 /* ---- x509 certificate signatures in batch ----

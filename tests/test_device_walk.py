@@ -84,9 +84,8 @@ def _der_int(v: bytes) -> bytes:
     return b"\x02" + bytes([len(v)]) + v
 
 
-def test_device_signature_gate_equals_the_general_parser():
-    """gate_sig_fast decides only what UnmarshalECDSASignature + IsLowS (bccsp/utils/ecdsa.go:43-92) would decide the same way, and
-    declines nothing a signer produces."""
+def _gate_cases():
+    """signatures for the gate tests: (bytes, produced_by_a_signer)"""
     rng = np.random.default_rng(3)
     half = po.N >> 1
     cases = []
@@ -101,22 +100,36 @@ def test_device_signature_gate_equals_the_general_parser():
     for s in (1, half - 1, half, half + 1, po.N - 1, po.N, (1 << 256) - 1):
         for r in (1, po.N - 1, po.N, (1 << 256) - 1):
             cases.append((po.marshal_ecdsa_signature(r, s), True))
+    for k in range(1, 32):                                  # s differing from n/2 in one byte only, on either side
+        for delta in (-1, 1):
+            cases.append((po.marshal_ecdsa_signature(7, half + delta * (1 << (8 * k))), True))
     good = po.marshal_ecdsa_signature(0x1234 << 200, 0x77 << 100)
     odd = [b"", b"\x30", b"\x30\x00", good + b"\x00", good[:-1], b"\x30\x81" + bytes([len(good) - 2]) + good[2:],
            b"\x30\x06" + _der_int(b"\x00") + _der_int(b"\x01"), b"\x30\x06" + _der_int(b"\x01") + _der_int(b"\x00"),
            b"\x30\x06" + _der_int(b"\x80") + _der_int(b"\x01"), b"\x30\x08" + _der_int(b"\x00\x01") + _der_int(b"\x01"),
            b"\x30\x08" + _der_int(b"\x00\x80") + _der_int(b"\x7f"), b"\x31" + good[1:], b"\x30\x03\x02\x01",
            b"\x30" + bytes([2 + 34 + 3]) + _der_int(b"\x01" + b"\x00" * 33) + _der_int(b"\x01"),       # r of 34 bytes
-           b"\x30" + bytes([2 + 33 + 3]) + _der_int(b"\x00" + b"\xff" * 32) + _der_int(b"\x01")]       # r = 2^256 - 1 with its sign byte
+           b"\x30" + bytes([2 + 33 + 3]) + _der_int(b"\x00" + b"\xff" * 32) + _der_int(b"\x01"),       # r = 2^256 - 1 with its sign byte
+           b"\x30\x46" + _der_int(b"\x00" + b"\xff" * 32) + _der_int(b"\x00" + b"\xff" * 32),        # the longest common shape: 72 bytes
+           b"\x30\x47" + _der_int(b"\x00" + b"\xff" * 32) + _der_int(b"\x00" + b"\xff" * 32) + b"\x00", b"\x30" * 80, bytes(73), bytes(200)]
     cases += [(c, False) for c in odd]
-    base = np.frombuffer(good, dtype=np.uint8)
-    for _ in range(3000):                                   # mutants of a good signature
-        m = base.copy()
-        for _ in range(int(rng.integers(1, 4))):
-            m[int(rng.integers(0, m.size))] = np.uint8(rng.integers(0, 256))
-        cases.append((m.tobytes(), False))
+    for base_sig in (good, po.marshal_ecdsa_signature((1 << 255) + 12345, half - 99)):
+        base = np.frombuffer(base_sig, dtype=np.uint8)
+        for _ in range(1500):                               # mutants of a good signature
+            m = base.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, m.size))] = np.uint8(rng.integers(0, 256))
+            if rng.integers(0, 8) == 0:
+                m = m[: m.size - int(rng.integers(1, 5))]
+            cases.append((m.tobytes(), False))
+    return cases
+
+
+def test_device_signature_gate_equals_the_general_parser():
+    """gate_sig_fast decides only what UnmarshalECDSASignature + IsLowS (bccsp/utils/ecdsa.go:43-92) would decide the same way, and
+    declines nothing a signer produces."""
     n_submit = n_high = n_declined = 0
-    for sig, from_signer in cases:
+    for sig, from_signer in _gate_cases():
         code, r32, s32 = fabgpu.gate_sig_fast(sig)
         if not sig:
             assert code == 2
@@ -171,6 +184,22 @@ def csp():
     c = fabgpu.GPUCSP(device=0)
     yield c
     c.close()
+
+
+@pytest.mark.gpu
+def test_wavefront_signature_gate_equals_the_lane_form(csp):
+    """The kernels run the gate with a signature's bytes spread over a wavefront (lane permutes, ballots); it must give the code and
+    the (r, s) of walk::gate_sig_fast - which the CPU test above holds against the general parser - on every case."""
+    cases = [c for c, _ in _gate_cases()]
+    code, r, s = fabgpu.gate_probe(csp, cases)
+    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    for i, sig in enumerate(cases):
+        want, wr, ws = fabgpu.gate_sig_fast(sig)
+        assert int(code[i]) == want, (i, sig.hex(), int(code[i]), want)
+        if want == 0:
+            assert bytes(r[i]) == wr and bytes(s[i]) == ws, sig.hex()
+        seen[want] += 1
+    assert min(seen.values()) > 0 and seen[0] > 1500 and seen[1] > 300
 
 
 @pytest.mark.gpu
