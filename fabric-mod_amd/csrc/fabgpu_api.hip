@@ -1495,9 +1495,14 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
         if (err == hipSuccess) err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2, 84u << 10);
     }
-    if (err == hipSuccess && np) {       // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them)
+    if (err == hipSuccess && np) {
+        // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them), on CUs of their own: 40
+        // workgroups that would otherwise share SIMDs with the 40 000 short-lived wavefronts of the gate kernel and take 4x as long,
+        // with the endorsements' launch waiting for them (measured, tools/gpu_dw_sched.sh: device phase 1.04 -> 0.90 ms)
+        ShaPrefixArgs pm = pa;
+        pm.lds_reserve = 84u << 10;
         err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pa, s3);
+        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pm, s3);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s3);
     }
     if (err == hipSuccess && nc) {       // stream4: the TxID / proposal-hash digests (only the flags at the very end wait for them)

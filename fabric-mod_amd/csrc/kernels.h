@@ -35,14 +35,14 @@ struct VerifyGeom {
 VerifyGeom verify_geom(uint32_t n, bool allow_pair);
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair);
 // the mid-state kernel of a prefixed batch alone (the fused launchers run it themselves unless pa.mid_ready)
-hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st);
+hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st);   // honours pa.lds_reserve
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);
 // n messages given as (start, end) pairs -> n x 32 digest bytes
 hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st,
                                uint32_t lds_reserve = 0);
 // gathered messages (pieces of the arena stitched into `scratch` at out_off[j] .. out_off[j+1]) -> n x 32 digest bytes
 hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,
-                                size_t scratch_bytes, void* digests, hipStream_t st);
+                                size_t scratch_bytes, void* digests, hipStream_t st, uint32_t lds_reserve = 0);
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
                               const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st,
                               uint32_t lds_reserve = 0);   // lds_reserve: see ShaPrefixArgs

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) sha256_midstate_kernel(uint32_t m, const 
         o[1] = make_uint4(h[4], h[5], h[6], h[7]);
     }
 }
-__global__ void __launch_bounds__(256) sha256_batch_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+__global__ void __launch_bounds__(512) sha256_batch_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
                                                             const uint32_t* __restrict__ off, uint32_t* __restrict__ digests) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n;
@@ -377,7 +377,7 @@ static sha_prefixes launch_midstates(const void* arena, size_t arena_bytes, cons
 hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st) {
     if (pa.m == 0) return hipSuccess;
     dim3 grid((pa.m + 255) / 256), block(256);
-    hipLaunchKernelGGL(sha256_midstate_kernel, grid, block, 0, st, pa.m, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+    hipLaunchKernelGGL(sha256_midstate_kernel, grid, block, pa.lds_reserve, st, pa.m, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                        (const uint32_t*)pa.pre_off, pa.spans ? 1u : 0u, (uint32_t*)pa.mid_scratch);
     return hipGetLastError();
 }
@@ -398,13 +398,19 @@ hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes
     return hipGetLastError();
 }
 hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,
-                                size_t scratch_bytes, void* digests, hipStream_t st) {
+                                size_t scratch_bytes, void* digests, hipStream_t st, uint32_t lds_reserve) {
     if (n == 0) return hipSuccess;
     dim3 grid((n + 3) / 4), block(256);   // four wavefronts = four messages per workgroup
-    hipLaunchKernelGGL(gather_spans_kernel, grid, block, 0, st, n, (const uint8_t*)arena, (uint32_t)arena_bytes, (const uint32_t*)spans,
+    hipLaunchKernelGGL(gather_spans_kernel, grid, block, lds_reserve, st, n, (const uint8_t*)arena, (uint32_t)arena_bytes, (const uint32_t*)spans,
                        (const uint32_t*)out_off, (uint8_t*)scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (lds_reserve) {                    // keeping to its own CUs: 512-thread workgroups, so that the hashes need half as many of them
+        dim3 g2((n + 511) / 512), b2(512);
+        hipLaunchKernelGGL(sha256_batch_kernel, g2, b2, lds_reserve, st, n, (const uint32_t*)scratch, (uint32_t)((scratch_bytes + 3) / 4),
+                           (const uint32_t*)out_off, (uint32_t*)digests);
+        return hipGetLastError();
+    }
     return launch_sha256_batch(n, scratch, scratch_bytes, out_off, digests, st);
 }
 

@@ -98,7 +98,7 @@ ABI_SYMBOLS = [
     "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",
     "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
     "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev",
-    "fabgpu_csp_pass_routes", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast", "fabgpu_identity_table_hash",
+    "fabgpu_csp_pass_routes", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast", "fabgpu_identity_table_hash", "fabgpu_csp_gate_probe",
 ]
 
 _lib = None
