@@ -168,7 +168,9 @@ def inprocess_multi_leg(world):
 def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
     """SURVEY 8(f) rank 1 through the provider: a marshalled 10 000-transaction block in (built and signed here with the C oracle:
     1 creator + 3 endorsement signatures, TxID and proposal hash per transaction), per-transaction flags out - walk, gates, one device
-    submission - timed around the blocking C-ABI call, flags-only and with digests + verdict-memo seeding (what the Go provider runs).
+    submission - timed around the blocking C-ABI call, flags-only and with digests + verdict-memo seeding (what the Go provider runs),
+    with the walk / gates / identity lookup on the device (block_walk_dev.h: the route a staged block of known identities takes) and,
+    for comparison, on the host.
     The tests hold the pass against the reference's ledgers and against corrupted blocks; here every transaction must come back valid
     and one flipped payload byte must come back as a bad creator signature."""
     import ctypes
@@ -203,7 +205,14 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
             first = fabgpu.preverify_block2(csp, blk, lean=True)
         assert (first["tx_flags"] == 0).all() and first["n_tuples"] == 4 * n_tx and first["n_keyed"] == 4 * n_tx
         legs = {}
-        for name, memo in (("flags_only", False), ("with_memo_seeding", True)):
+        # (the device walk takes blocks that were staged ahead: lifting the staging threshold sends the same block down the host walk)
+        for name, memo, host_walk in (("flags_only", False, False), ("with_memo_seeding", True, False), ("flags_only_host_walk", False, True),
+                                      ("with_memo_seeding_host_walk", True, True)):
+            if host_walk:
+                os.environ["FABGPU_PASS_STAGE_MIN_BYTES"] = str(1 << 40)
+            else:
+                os.environ.pop("FABGPU_PASS_STAGE_MIN_BYTES", None)
+            before = fabgpu.pass_routes(csp)
             per = []
             for k in range(steps):
                 c0 = time.perf_counter()
@@ -213,7 +222,10 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
                     assert r["memo_seeded"] == 4 * n_tx
                     fabgpu.memo_evict_block(csp, 100 + k)
             med = statistics.median(per)
-            legs[name] = {"validated_tx_per_s": n_tx / (med * 1e-3), "median_ms_per_block": med, "min_ms": min(per), "max_ms": max(per), "blocks": steps}
+            after = fabgpu.pass_routes(csp)
+            legs[name] = {"validated_tx_per_s": n_tx / (med * 1e-3), "median_ms_per_block": med, "min_ms": min(per), "max_ms": max(per), "blocks": steps,
+                          "walked_on_device": after["device_walks"] - before["device_walks"], "walked_on_host": after["host_walks"] - before["host_walks"]}
+        os.environ.pop("FABGPU_PASS_STAGE_MIN_BYTES", None)
         bad = bytearray(blk)
         at = blk.index(envs[7]) + len(envs[7]) // 2            # one byte inside transaction 7's payload
         bad[at] ^= 1
