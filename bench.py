@@ -556,6 +556,8 @@ def main():
                 out["configs3_fused"] = fused_cfg3_leg(ctx, torch, np, fabgpu, coracle, steps=10)
                 try:
                     out["block_pass"] = block_pass_leg(np, fabgpu, coracle)
+                    # BASELINE's second metric ("validated tx/sec per block") as the provider delivers it: marshalled block in, flags out
+                    out["validated_tx_per_s_block_pass"] = out["block_pass"]["flags_only"]["validated_tx_per_s"]
                 except Exception as e:                                                                     # never let this leg cost the line
                     out["block_pass"] = {"error": repr(e)[:300]}
             if not args.no_cpu_baseline:

@@ -264,6 +264,19 @@ func (p *Provider) RegisterIdemixMSP(mspID string, ipkBytes []byte) bool {
 	return rc == 0 && id >= 0
 }
 
+// PassRoutes: how the block passes of this provider went - walked on the device (DESIGN 4.4b) or on the host - and why the last
+// block was declined by the device walk (a new endorser, a signature outside the common DER shape, ...).  For metrics.
+func (p *Provider) PassRoutes() (deviceWalks, hostWalks uint64, lastDecline string) {
+	var d, h C.uint64_t
+	why := make([]byte, 256)
+	C.fabgpu_csp_pass_routes(p.csp, &d, &h, (*C.char)(unsafe.Pointer(&why[0])), C.size_t(len(why)))
+	n := 0
+	for n < len(why) && why[n] != 0 {
+		n++
+	}
+	return uint64(d), uint64(h), string(why[:n])
+}
+
 // MemoStats is for metrics / tests.
 func (p *Provider) MemoStats() (entries, hits, misses, evicted uint64) {
 	var e, h, m, v C.uint64_t
