@@ -1,3 +1,8 @@
+#!/bin/bash
+# Which kernels of the device-side block walk get CUs of their own, and who waits for whom: eleven combinations in one gpurun call.
+# The knob (FABGPU_WALK_SCHED: 1 hash checks after the gates, 2 hash checks on CUs of their own, 4 mid-states on CUs of their own,
+# 8 mid-states on the main stream ahead of the gates) existed in fabgpu_api.hip::walk_block_pass for this measurement only; variant 4
+# won (device phase 1.04 -> 0.90 ms) and is what the code now does unconditionally.  Kept as the record of the experiment.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 B=.bench_blocks/ecdsa_10000_0.bin
 for s in 0 1 2 3 4 5 7 8 9 11 0; do
