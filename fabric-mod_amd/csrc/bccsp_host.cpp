@@ -499,11 +499,7 @@ void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len)
     if (!block || len < min_bytes) return;
     fabgpu_ctx* c = ctx_;
     BlockUpload* u = &up;
-    // the slot is chosen and locked HERE, by the calling thread (it may walk the block on the device itself while the bytes arrive);
-    // the copy runs on a helper thread
-    if (stage_acquire(c, len, &up.ticket, &up.slot) != FABGPU_OK) return;
-    up.started = true;
-    up.th = std::thread([c, u, block] { u->rc = stage_fill(c, &u->ticket, block); });
+    up.th = std::thread([c, u, block, len] { u->rc = fabgpu_arena_stage(c, block, len, &u->token); });
 }
 
 Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out, const PassOptions& opt) const {
@@ -951,7 +947,7 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         return 1;
     };
     if (!DeviceWalkEnabled()) return declined("FABGPU_PASS_DEVICE_WALK=0");
-    if (!block || !up.started) return declined("the block was not staged ahead (small block)");
+    if (!block || !up.th.joinable()) return declined("the block was not staged ahead (small block)");
     if (getenv("FABGPU_PASS_SKIP_HASH_CHECKS")) return declined("FABGPU_PASS_SKIP_HASH_CHECKS");
     {
         std::lock_guard<std::mutex> lk(idmu_);
@@ -976,7 +972,7 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     } lease(this);
     PassScratch& ps = *lease.p;
     auto clk0 = std::chrono::steady_clock::now();
-    if (!OutlineBlock(block, len, pb, ps.env_spans, ps.block_sigs, &ps.payload_spans)) return FABGPU_EINVAL;
+    if (!OutlineBlock(block, len, pb, ps.env_spans, ps.block_sigs)) return FABGPU_EINVAL;
     const bool want_digests = opt.want_digests || opt.seed_memo;
     const bool want_tuples = (want & WANT_TUPLES) || opt.seed_memo, want_qxy = (want & WANT_QXY) || opt.seed_memo;
     const uint32_t n_skipped = opt.block_sigs ? 0 : (uint32_t)ps.block_sigs.size();   // reported (TUPLE_ST_SKIPPED), not submitted
@@ -985,7 +981,10 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     std::shared_lock<std::shared_timed_mutex> rl(idtab_rw_);
     if (idtab_version_ != id_version_.load(std::memory_order_acquire)) return declined("the identity cache changed under the pass");
     out.ms_gates = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk0).count();   // (outline + table sync)
-    out.ms_upload_wait = 0;                                   // (nobody waits for the upload: the pass starts on the pieces that have arrived)
+    auto clk1 = std::chrono::steady_clock::now();
+    const uint64_t tok = up.join();
+    out.ms_upload_wait = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk1).count();
+    if (!tok) return declined("the upload failed");
     struct Sizer {
         ParsedBlock& pb;
         BlockVerdicts& out;
@@ -996,10 +995,9 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         bool too_big = false;
     } sz{pb, out, ps, want_tuples, want_digests, cap_tx, cap_tuples, n_skipped};
     WalkRequest rq;
-    rq.ticket = &up.ticket;                                   // still arriving: this thread locked the slot in StartBlockUpload
+    rq.stage_token = tok;
     rq.block_len = len;
     rq.env_spans = ps.env_spans.data();
-    rq.payload_spans = ps.payload_spans.data();
     rq.n_env = (uint32_t)(ps.env_spans.size() / 2);
     if (opt.block_sigs && !ps.block_sigs.empty()) {
         rq.block_sigs = ps.block_sigs.data();
@@ -1047,7 +1045,6 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     out.ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk2).count();
     if (n_tuples_out) *n_tuples_out = sz.n_tuples;
     if (rc == WALK_DECLINED) return declined(rq.declined_why);
-    if (rc == FABGPU_OK && up.join() == 0) return declined("the upload failed");   // (the kernels read what had arrived: nothing of it counts)
     if (rc == FABGPU_ETOOBIG && sz.too_big) return FABGPU_ETOOBIG;     // pb.n_tx / *n_tuples_out say what to make room for
     if (rc != FABGPU_OK) return rc;
     const size_t nt = sz.n_tuples, nd = nt - n_skipped;

@@ -21,7 +21,6 @@
 
 #include "../../include/fabgpu.h"
 #include "block_prepass.h"
-#include "block_walk_dev.h"
 #include "coalescer.h"
 
 namespace fab {
@@ -177,17 +176,13 @@ class GPUCSP {
     // and gates; join() returns the token for PreVerifyParsed (0 if nothing was staged).
     struct BlockUpload {
         std::thread th;
-        StageTicket ticket;                       // the staging slot this block travels into (locked by the thread that started the upload)
-        std::unique_lock<std::mutex> slot;
+        uint64_t token = 0;
         int rc = -1;
-        bool started = false;
-        // waits for the last byte, gives the slot back, returns the token a staged submission names (0: nothing was staged)
         uint64_t join() {
             if (th.joinable()) th.join();
-            if (slot.owns_lock()) slot.unlock();
-            return rc == 0 ? ticket.token : 0;
+            return rc == 0 ? token : 0;
         }
-        ~BlockUpload() { join(); }
+        ~BlockUpload() { if (th.joinable()) th.join(); }
     };
     void StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len) const;
     // An idemix MSP of the channel (msp/idemixmsp.go:99-173 Setup): its creators' pseudonym signatures are then verified by the
@@ -270,7 +265,7 @@ class GPUCSP {
         std::vector<uint8_t> nym_fields, nym_st;
         std::vector<uint64_t> nym_bits;
         // the device walk: envelope list, block-signature tuples, identity indices per tuple
-        std::vector<uint32_t> env_spans, payload_spans, id_idx;
+        std::vector<uint32_t> env_spans, id_idx;
         std::vector<BlockTuple> block_sigs;
     };
     struct CoReqV : CoalescedBase {

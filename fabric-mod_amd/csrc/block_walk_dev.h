@@ -24,9 +24,6 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include <atomic>
-#include <mutex>
-
 #include "block_walk_core.h"
 
 struct fabgpu_ctx;
@@ -76,9 +73,6 @@ struct WalkArrays {
     bccsp::BlockHashCheck* checks = nullptr;
     uint32_t* gather_spans = nullptr;
     uint32_t* gather_off = nullptr;
-    const uint32_t* payload_spans = nullptr;   // per envelope, from the host's outline: (start, end) of Envelope.payload
-    uint8_t* digest_env = nullptr;       // per envelope: SHA-256 of that payload, computed while the block was still arriving
-    uint32_t early_creator_hash = 0;     // the creators' launch reads digests that came from digest_env (the gate kernel cross-checks the spans)
     uint32_t* creator_spans = nullptr;   // (start, end) of every creator tuple's message, in creator order (split submissions hash them early)
     uint32_t* id_idx = nullptr;
     uint32_t* off2 = nullptr;
@@ -112,9 +106,7 @@ struct WalkArrays {
     uint8_t* tx_flags = nullptr;
 };
 
-hipError_t launch_walk_count(const WalkArrays& a, uint32_t env0, uint32_t env1, hipStream_t st);   // counts, tx_type, tx_understood of envelopes [env0, env1)
-hipError_t launch_walk_scan(const WalkArrays& a, hipStream_t st);                        // exclusive prefix sums over all envelopes, totals
-hipError_t launch_walk_creator_digests(const WalkArrays& a, void* row_digests, hipStream_t st);   // digest_env -> the creators' digest rows
+hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st);                       // counts, tx_type, tx_understood; then the scan
 hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st);   // tuples, prefixes, checks, gather spans / offsets
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);                        // identity lookup + gates + submission arrays + summary
 hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st);
@@ -122,19 +114,6 @@ hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t
 hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spans, void* code, void* r, void* s, hipStream_t st);    // statuses, digest comparisons, per-transaction flags
 
 // ---- host side (fabgpu_api.hip) ----
-// A block on its way into one of the context's staging slots (fabgpu_arena_stage in two steps, for callers that want to start on
-// the first bytes while the last are still on the bus).
-struct StageTicket {
-    void* slot = nullptr;        // fabgpu_ctx::Staged*
-    size_t len = 0, chunk_bytes = 0;
-    int n_chunks = 0;            // piece k = bytes [k * chunk_bytes, ...); the slot carries one event per piece
-    uint64_t token = 0;          // set by stage_fill when everything has arrived (what fabgpu_identity_batch.stage_token names)
-    // stage_fill -> a pass that started early: events 0 .. recorded - 1 have been RECORDED (a stream may only be told to wait for an
-    // event after that: waiting for an event that has not been recorded yet means waiting for its previous use); failed: give up
-    std::atomic<int> recorded{0}, failed{0};
-};
-int stage_acquire(fabgpu_ctx* ctx, size_t len, StageTicket* t, std::unique_lock<std::mutex>* lk);   // the CALLER's thread owns the slot's lock from here
-int stage_fill(fabgpu_ctx* ctx, StageTicket* t, const void* arena);                                  // any thread; blocks until the bytes are there
 // Replace the device's identity table (entries + their bytes); the table is rebuilt by the provider whenever its cache changes.
 int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const uint8_t* bytes, size_t nbytes);
 
@@ -157,10 +136,7 @@ struct WalkOut {
     bccsp::BlockHashCheck* checks = nullptr;   // n_checks         (tests)
 };
 struct WalkRequest {
-    uint64_t stage_token = 0;             // the block, uploaded with fabgpu_arena_stage ...
-    const StageTicket* ticket = nullptr;  // ... or still on its way (stage_acquire / stage_fill): the caller holds the slot's lock, the pass
-                                          // starts on the pieces that have arrived
-    const uint32_t* payload_spans = nullptr;   // host, optional (with ticket): OutlineBlock's payload spans, 2 per envelope
+    uint64_t stage_token = 0;             // the block, uploaded with fabgpu_arena_stage
     size_t block_len = 0;
     const uint32_t* env_spans = nullptr;  // host
     uint32_t n_env = 0;

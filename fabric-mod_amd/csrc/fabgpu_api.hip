@@ -12,7 +12,6 @@
 #include <new>
 #include <map>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/fabgpu.h"
@@ -149,12 +148,7 @@ struct fabgpu_ctx {
         void* d = nullptr;
         size_t cap = 0, len = 0;
         std::atomic<uint64_t> token{0};
-        // the upload travels in up to STAGE_CHUNKS pieces on a stream of the slot's own; ev[k] = "piece k is on the device", so that a
-        // pass can start on the first bytes while the last are still on the bus (walk_block_pass)
-        hipStream_t up = nullptr;
-        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     };
-    static constexpr int STAGE_CHUNKS = 4;
     static constexpr int N_STAGED = 3;
     std::mutex smu;
     Staged staged_slots[N_STAGED];
@@ -294,14 +288,6 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
         if (hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         {
             bool ok = true;
-            for (auto& sl : ctx->staged_slots) {
-                ok = ok && hipStreamCreateWithFlags(&sl.up, hipStreamNonBlocking) == hipSuccess;
-                for (auto& e : sl.ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-            }
-            if (!ok) { rc = FABGPU_ENODEV; break; }
-        }
-        {
-            bool ok = true;
             for (auto& e : ctx->ev_w) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
             if (!ok) { rc = FABGPU_ENODEV; break; }
         }
@@ -358,12 +344,8 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->walk_tup.release();
         ctx->walk_pin.release();
         if (ctx->d_idtab) hipFree(ctx->d_idtab);
-        for (auto& sl : ctx->staged_slots) {
+        for (auto& sl : ctx->staged_slots)
             if (sl.d) hipFree(sl.d);
-            if (sl.up) hipStreamDestroy(sl.up);
-            for (auto& e : sl.ev)
-                if (e) hipEventDestroy(e);
-        }
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
@@ -913,27 +895,22 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
     return hip_to_rc(err);
 }
 
-}  // extern "C"
-
-namespace fab {
-// Choose and lock a staging slot for `len` bytes - the least recently filled one nobody is using; all in use: wait for the oldest -
-// and make room in it.  The lock is taken by the CALLING thread and handed back in `lk`: the caller keeps it while the slot is
-// filled (stage_fill, on any thread) and, if it walks the block on the device itself, until its pass has run.
-int stage_acquire(fabgpu_ctx* ctx, size_t len, StageTicket* t, std::unique_lock<std::mutex>* lk) {
-    if (!ctx || !t || !lk || len == 0) return FABGPU_EINVAL;
+int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token) {
+    if (!ctx || !arena || !token || len == 0) return FABGPU_EINVAL;
     if (len > 0xFFFFFF00ull) return FABGPU_ETOOBIG;
+    // the least recently filled slot nobody is using; all in use: wait for the oldest
     fabgpu_ctx::Staged* sl = nullptr;
     std::unique_lock<std::mutex> slot_lk;
     {
-        std::lock_guard<std::mutex> g(ctx->smu);
+        std::lock_guard<std::mutex> lk(ctx->smu);
         int order[fabgpu_ctx::N_STAGED];
         for (int i = 0; i < fabgpu_ctx::N_STAGED; i++) order[i] = i;
         std::sort(order, order + fabgpu_ctx::N_STAGED, [&](int x, int y) { return ctx->staged_slots[x].token.load() < ctx->staged_slots[y].token.load(); });
         for (int i = 0; i < fabgpu_ctx::N_STAGED && !sl; i++) {
-            std::unique_lock<std::mutex> tl(ctx->staged_slots[order[i]].m, std::try_to_lock);
-            if (tl.owns_lock()) {
+            std::unique_lock<std::mutex> t(ctx->staged_slots[order[i]].m, std::try_to_lock);
+            if (t.owns_lock()) {
                 sl = &ctx->staged_slots[order[i]];
-                slot_lk = std::move(tl);
+                slot_lk = std::move(t);
             }
         }
         if (!sl) sl = &ctx->staged_slots[order[0]];
@@ -944,67 +921,23 @@ int stage_acquire(fabgpu_ctx* ctx, size_t len, StageTicket* t, std::unique_lock<
     sl->token.store(0);                                    // the previous upload is gone from here on
     sl->len = 0;
     if (sl->cap < need + (64 << 10)) {                     // (a batch reading the old buffer would hold the slot's mutex)
-        if (ctx->fault == 2) return FABGPU_ENOMEM;
         if (sl->d) hipFree(sl->d);
         sl->d = nullptr;
         sl->cap = 0;
         if (hipMalloc(&sl->d, need + need / 8 + (64 << 10)) != hipSuccess) return FABGPU_ENOMEM;
         sl->cap = need + need / 8 + (64 << 10);
     }
-    t->slot = sl;
-    t->len = len;
-    // pieces of at least 4 MiB, 64-byte multiples, at most STAGE_CHUNKS of them
-    int k = (int)(len / ((size_t)4 << 20));
-    k = k < 1 ? 1 : (k > fabgpu_ctx::STAGE_CHUNKS ? fabgpu_ctx::STAGE_CHUNKS : k);
-    t->n_chunks = k;
-    t->chunk_bytes = round_up((len + k - 1) / k, 64);
-    t->token = 0;
-    t->recorded.store(0);
-    t->failed.store(0);
-    *lk = std::move(slot_lk);
-    return FABGPU_OK;
-}
-// The bytes, piece by piece, then the zero padding behind them; returns when everything is on the device and publishes the token.
-int stage_fill(fabgpu_ctx* ctx, StageTicket* t, const void* arena) {
-    if (!ctx || !t || !t->slot || !arena) return FABGPU_EINVAL;
-    fabgpu_ctx::Staged* sl = (fabgpu_ctx::Staged*)t->slot;
-    DeviceGuard g(ctx->device);
-    const size_t len = t->len, need = round_up(len, 64) + 128;
-    hipError_t err = hipSuccess;
-    for (int k = 0; k < t->n_chunks && err == hipSuccess; k++) {
-        const size_t o = (size_t)k * t->chunk_bytes, n = o >= len ? 0 : (len - o < t->chunk_bytes ? len - o : t->chunk_bytes);
-        if (n) err = hipMemcpyAsync((uint8_t*)sl->d + o, (const uint8_t*)arena + o, n, hipMemcpyHostToDevice, sl->up);
-        if (err == hipSuccess && k == t->n_chunks - 1) err = hipMemsetAsync((uint8_t*)sl->d + len, 0, need - len, sl->up);
-        if (err == hipSuccess) err = hipEventRecord(sl->ev[k], sl->up);
-        if (err == hipSuccess) t->recorded.store(k + 1, std::memory_order_release);
-    }
-    if (err == hipSuccess) err = hipStreamSynchronize(sl->up);
-    if (err != hipSuccess) {
-        t->failed.store(1, std::memory_order_release);
-        return hip_to_rc(err);
-    }
+    hipError_t err = hipMemcpy(sl->d, arena, len, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemset((uint8_t*)sl->d + len, 0, need - len);
+    if (err != hipSuccess) return hip_to_rc(err);
     sl->len = len;
-    uint64_t tok;
+    uint64_t t;
     {
         std::lock_guard<std::mutex> lk(ctx->smu);
-        tok = ++ctx->stage_seq;
+        t = ++ctx->stage_seq;
     }
-    sl->token.store(tok);
-    t->token = tok;
-    return FABGPU_OK;
-}
-}  // namespace fab
-
-extern "C" {
-
-int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token) {
-    if (!ctx || !arena || !token || len == 0) return FABGPU_EINVAL;
-    fab::StageTicket t;
-    std::unique_lock<std::mutex> lk;
-    int rc = fab::stage_acquire(ctx, len, &t, &lk);
-    if (rc == FABGPU_OK) rc = fab::stage_fill(ctx, &t, arena);
-    if (rc != FABGPU_OK) return rc;
-    *token = t.token;
+    sl->token.store(t);
+    *token = t;
     return FABGPU_OK;
 }
 
@@ -1354,7 +1287,7 @@ int walk_gate_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t ar
 }
 
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
-    if (!ctx || !rq.sizes || !rq.env_spans || (rq.stage_token == 0 && !rq.ticket)) return FABGPU_EINVAL;
+    if (!ctx || !rq.sizes || !rq.env_spans || rq.stage_token == 0) return FABGPU_EINVAL;
     if (rq.n_block_sigs && !rq.block_sigs) return FABGPU_EINVAL;
     const bool has_tail = rq.tail != nullptr && rq.tail_len != 0;
     if (has_tail && ((rq.tail_base & 63u) || (uint64_t)rq.tail_base + rq.tail_len > 0xFFFFFFF0ull)) return FABGPU_EINVAL;
@@ -1364,28 +1297,14 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     };
     if (rq.n_env == 0) return decline("no envelopes");
     if (rq.n_env > 0x7FFFFFF0u / 64) return FABGPU_ETOOBIG;
-    // The block: either staged (by token: its slot is locked here - the stager kept out of it - until this pass has run) or still
-    // ARRIVING piece by piece (ticket: the caller locked the slot when it started the upload and keeps it; the kernels wait for the
-    // pieces they read: the walk's first run and the creators' payload hashes start on piece 0 while piece 3 is on the bus).
+    // the staged block: its slot stays locked - the stager kept out of it - until this pass has run
     fabgpu_ctx::Staged* sl = nullptr;
-    std::unique_lock<std::mutex> slk;
-    int n_chunks = 0;
-    size_t chunk_bytes = 0, block_len = 0;
-    if (rq.ticket) {
-        sl = (fabgpu_ctx::Staged*)rq.ticket->slot;
-        if (!sl || rq.ticket->len != rq.block_len) return FABGPU_EINVAL;
-        n_chunks = rq.ticket->n_chunks;
-        chunk_bytes = rq.ticket->chunk_bytes;
-        block_len = rq.ticket->len;
-    } else {
-        for (auto& c : ctx->staged_slots)
-            if (c.token.load() == rq.stage_token) sl = &c;
-        if (!sl) return decline("the staged block was replaced");
-        slk = std::unique_lock<std::mutex>(sl->m);
-        if (sl->token.load() != rq.stage_token || sl->len == 0 || sl->len != rq.block_len) return decline("the staged block was replaced");
-        block_len = sl->len;
-    }
-    if (has_tail && ((size_t)rq.tail_base < round_up(block_len, 64) || (size_t)rq.tail_base + rq.tail_len + 128 > sl->cap)) return FABGPU_EINVAL;
+    for (auto& c : ctx->staged_slots)
+        if (c.token.load() == rq.stage_token) sl = &c;
+    if (!sl) return decline("the staged block was replaced");
+    std::unique_lock<std::mutex> slk(sl->m);
+    if (sl->token.load() != rq.stage_token || sl->len == 0 || sl->len != rq.block_len) return decline("the staged block was replaced");
+    if (has_tail && ((size_t)rq.tail_base < round_up(sl->len, 64) || (size_t)rq.tail_base + rq.tail_len + 128 > sl->cap)) return FABGPU_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->fault) return ctx->fault == 2 ? FABGPU_ENOMEM : FABGPU_ELAUNCH;
     if (!rq.walk_only && (!ctx->d_idtab || ctx->idtab_n == 0)) return decline("no identity is known to the device yet");
@@ -1395,40 +1314,22 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     const auto t_start = now();
     const uint32_t ne = rq.n_env;
-    // Whatever happens from here on, nothing of this pass may still be queued or running when the call returns: the next pass reuses
-    // every buffer, and the caller gives the staging slot back.
-    hipStream_t s2 = ctx->stream2, s3 = ctx->stream3, s4 = ctx->stream4;
-    struct Drain {
-        hipStream_t a, b, c, d;
-        ~Drain() {
-            hipStreamSynchronize(a);
-            hipStreamSynchronize(b);
-            hipStreamSynchronize(c);
-            hipStreamSynchronize(d);
-        }
-    } drain{s2, s3, s4, st};
-    // The creators' messages are whole envelope payloads - by far the longest hashes of a block, and a serial chain per message.  With
-    // the host's outline of where they are they can start the moment their bytes arrive, before anything is walked - worth it when the
-    // submission is going to be split (a creators' launch of its own: blocks of more than 32 768 tuples; four tuples per
-    // transaction is the estimate), otherwise the fused kernel hashes them anyway.
-    const bool early_hash = rq.ticket && rq.payload_spans && !rq.walk_only && ctx->allow_pair && (uint64_t)ne * 4 > (uint64_t)VERIFY_PAIR_MAX;
     // ---- per-envelope arrays ----
     size_t o = 0;
     auto carve = [&](size_t bytes) { size_t at = o; o = round_up(o + bytes, 256); return at; };
     const size_t o_env = carve((size_t)ne * 8), o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_tot = carve(sizeof(WalkTotals)),
                  o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
-                 o_cbase = carve((size_t)ne * 4), o_pay = carve(early_hash ? (size_t)ne * 8 : 0), o_denv = carve(early_hash ? (size_t)ne * 32 : 0);
+                 o_cbase = carve((size_t)ne * 4);
     int rc;
     if ((rc = ctx->walk_env.ensure(o))) return rc;
-    // pinned staging: env (and payload) spans up, totals / summary down (the result arrays are sized further down)
-    const size_t p_env = 0, p_pay = round_up((size_t)ne * 8, 64), p_tot = p_pay + round_up(early_hash ? (size_t)ne * 8 : 0, 64), p_sum = p_tot + 64, p_first = p_sum + 64;
+    // pinned staging: env spans up, totals / summary down (the result arrays are sized further down)
+    const size_t p_env = 0, p_tot = round_up((size_t)ne * 8, 64), p_sum = p_tot + 64, p_first = p_sum + 64;
     if ((rc = ctx->walk_pin.ensure(p_first))) return rc;
     uint8_t* de = (uint8_t*)ctx->walk_env.d;
-    const size_t arena_bytes = round_up(has_tail ? (size_t)rq.tail_base + rq.tail_len : block_len, 4) + 64;
     WalkArrays a;
     a.block = (const uint8_t*)sl->d;
-    a.block_len = (uint32_t)block_len;
-    a.arena_len = has_tail ? rq.tail_base + rq.tail_len : (uint32_t)block_len;
+    a.block_len = (uint32_t)sl->len;
+    a.arena_len = has_tail ? rq.tail_base + rq.tail_len : (uint32_t)sl->len;
     a.env_spans = (const uint32_t*)(de + o_env);
     a.n_env = ne;
     a.counts = (uint4*)(de + o_cnt);
@@ -1440,58 +1341,17 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.tx_mask = (uint32_t*)(de + o_mask);
     a.tx_flags = de + o_flags;
     a.summary = (WalkSummary*)(de + o_sum);
-    if (early_hash) {
-        a.payload_spans = (const uint32_t*)(de + o_pay);
-        a.digest_env = de + o_denv;
-    }
     memcpy((uint8_t*)ctx->walk_pin.h + p_env, rq.env_spans, (size_t)ne * 8);
     hipError_t err = hipMemcpyAsync(de + o_env, (uint8_t*)ctx->walk_pin.h + p_env, (size_t)ne * 8, hipMemcpyHostToDevice, st);
-    if (err == hipSuccess && early_hash) {
-        memcpy((uint8_t*)ctx->walk_pin.h + p_pay, rq.payload_spans, (size_t)ne * 8);
-        err = hipMemcpyAsync(de + o_pay, (uint8_t*)ctx->walk_pin.h + p_pay, (size_t)ne * 8, hipMemcpyHostToDevice, st);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[3], st);     // "the span lists are on the device"
-        if (err == hipSuccess) err = hipStreamWaitEvent(s2, ctx->ev_w[3], 0);
-    }
-    if (err == hipSuccess) err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
-    if (err == hipSuccess) err = hipMemsetAsync(de + o_sum, 0, sizeof(WalkSummary), st);
-    // the walk's first run (and the early hashes), piece by piece: envelopes [e0, e1) end inside the pieces that have arrived
-    {
-        uint32_t e0 = 0;
-        const int pieces = rq.ticket ? n_chunks : 1;
-        for (int k = 0; k < pieces && err == hipSuccess; k++) {
-            uint32_t e1 = ne;
-            if (k + 1 < pieces) {
-                const uint64_t arrived = (uint64_t)(k + 1) * chunk_bytes;
-                uint32_t lo = e0, hi = ne;                                // first envelope that does not end inside the arrived bytes
-                while (lo < hi) {
-                    const uint32_t mid = lo + (hi - lo) / 2;
-                    if ((uint64_t)rq.env_spans[2 * mid] + rq.env_spans[2 * mid + 1] <= arrived) lo = mid + 1;
-                    else hi = mid;
-                }
-                e1 = lo;
-            }
-            if (rq.ticket) {
-                // (the event must have been recorded by the upload thread before a stream is told to wait for it)
-                while (rq.ticket->recorded.load(std::memory_order_acquire) <= k && !rq.ticket->failed.load(std::memory_order_acquire)) std::this_thread::yield();
-                if (rq.ticket->failed.load(std::memory_order_acquire)) return decline("the upload failed");
-                err = hipStreamWaitEvent(st, sl->ev[k], 0);
-            }
-            if (err == hipSuccess) err = launch_walk_count(a, e0, e1, st);
-            if (err == hipSuccess && early_hash && e1 > e0) {
-                err = hipStreamWaitEvent(s2, sl->ev[k], 0);
-                if (err == hipSuccess)
-                    err = launch_sha256_spans(e1 - e0, sl->d, arena_bytes, a.payload_spans + 2 * (size_t)e0, a.digest_env + 32 * (size_t)e0, s2, 84u << 10);
-            }
-            e0 = e1;
-        }
-    }
-    if (err == hipSuccess && has_tail) {       // (behind the last piece: the upload ends by zeroing the padding the tail sits in)
+    if (err == hipSuccess && has_tail) {
         if ((rc = ctx->tailbuf.ensure(rq.tail_len))) return rc;
         memcpy(ctx->tailbuf.h, rq.tail, rq.tail_len);
         err = hipMemcpyAsync((uint8_t*)sl->d + rq.tail_base, ctx->tailbuf.h, rq.tail_len, hipMemcpyHostToDevice, st);
         if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)sl->d + rq.tail_base + rq.tail_len, 0, 128, st);
     }
-    if (err == hipSuccess) err = launch_walk_scan(a, st);
+    if (err == hipSuccess) err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
+    if (err == hipSuccess) err = hipMemsetAsync(de + o_sum, 0, sizeof(WalkSummary), st);
+    if (err == hipSuccess) err = launch_walk_count(a, st);
     if (err == hipSuccess) err = hipMemcpyAsync((uint8_t*)ctx->walk_pin.h + p_tot, de + o_tot, sizeof(WalkTotals), hipMemcpyDeviceToHost, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err != hipSuccess) return hip_to_rc(err);
@@ -1596,6 +1456,19 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         rq.ms_walk = ms_since(t_start);
         return FABGPU_OK;
     }
+    // From here on three streams work side by side; whatever happens, none of them may still be running when this call returns
+    // (the next pass reuses every buffer).
+    hipStream_t s2 = ctx->stream2, s3 = ctx->stream3, s4 = ctx->stream4;
+    struct Drain {
+        hipStream_t a, b, c, d;
+        ~Drain() {
+            hipStreamSynchronize(a);
+            hipStreamSynchronize(b);
+            hipStreamSynchronize(c);
+            hipStreamSynchronize(d);
+        }
+    } drain{s2, s3, s4, st};
+    const size_t arena_bytes = round_up(has_tail ? (size_t)rq.tail_base + rq.tail_len : sl->len, 4) + 64;
     ShaPrefixArgs pa;
     pa.spans = true;
     if (np) {
@@ -1616,16 +1489,11 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // the main stream looks identities up and gates signatures
     err = hipEventRecord(ctx->ev_w[0], st);
     if (err == hipSuccess && a.split) {
-        // stream2: the creators' digests into rows [0, n_creators), so that their launch only has the arithmetic left.  Either they
-        // were hashed per envelope while the block arrived (early_hash: a scatter by the scan's creator ranks is all that is left), or
-        // they are hashed now, beside the identity lookup and the gates.
-        if (early_hash) {
-            a.early_creator_hash = 1;
-            err = launch_walk_creator_digests(a, dt + o_dig, s2);
-        } else {
-            err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
-            if (err == hipSuccess) err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2, 84u << 10);
-        }
+        // stream2: the creators' messages are whole envelope payloads - the longest hashes of the block by far (and a serial chain per
+        // message): they start now, beside the identity lookup and the gates, and their launch then only has the arithmetic left
+        // (digest rows [0, n_creators))
+        err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2, 84u << 10);
     }
     if (err == hipSuccess && np) {
         // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them), on CUs of their own: 40
