@@ -466,3 +466,33 @@ def test_split_submission_equals_the_host_route(csp, monkeypatch):
     assert dev_b["memo_seeded"] == 40000
     flags_only = fabgpu.preverify_block(csp, broken)
     _same(host_b, flags_only, ["tx_flags", "tuple_status"])
+
+
+@pytest.mark.gpu
+def test_device_route_with_keys_carried_along(monkeypatch):
+    """Identities that are known but have NOT earned a comb table (or only some of them have): the device route then runs the
+    fresh-key kernels over its own rows - keys copied out of the identity table, per-launch j*Q workspaces, the blind launch replaced
+    by a wait for the gate summary - on a small block (one fused launch) and on a 40 000-tuple block (split: creators' verify-only
+    pair launch beside the endorsements' one-lane launch, two workspaces on two streams).  Same answers as the host route."""
+    keys = ["tx_flags", "tx_type", "tuple_tx", "tuple_kind", "tuple_status", "tuple_spans", "tuple_digest", "tuple_hashed", "tuple_qxy"]
+    rng = np.random.default_rng(55)
+    small, want = clean_modes_block(150, rng)
+    big = _bench_block(10000)
+    for tables in (0, 3):
+        csp = fabgpu.GPUCSP(device=0)
+        try:
+            csp._L.fabgpu_csp_identity_cache_limits(csp._h, 4096, tables, 1)
+            monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+            host_small = fabgpu.preverify_block2(csp, small, block_seq=1)
+            host_big = fabgpu.preverify_block2(csp, big, block_seq=2)
+            assert (host_small["tx_flags"] == want).all() and (host_big["tx_flags"] == 0).all()
+            monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+            before = fabgpu.pass_routes(csp)["device_walks"]
+            dev_small = fabgpu.preverify_block2(csp, small, block_seq=3)
+            dev_big = fabgpu.preverify_block2(csp, big, block_seq=4, seed_memo=True)
+            assert fabgpu.pass_routes(csp)["device_walks"] == before + 2, fabgpu.pass_routes(csp)
+            _same(host_small, dev_small, keys)
+            _same(host_big, dev_big, keys)
+            assert dev_big["n_keyed"] == 0 and dev_small["n_keyed"] == 0 and dev_big["memo_seeded"] == 40000
+        finally:
+            csp.close()
