@@ -715,6 +715,17 @@ if %(mode)r == "launch":
         raise SystemExit("verify returned a verdict while the device was failing")
     except fabgpu.FabgpuError:
         pass
+# the block pass, on both routes (the second call finds the identities cached and takes the device walk): an error, never flags
+import base64, json, os
+os.environ["FABGPU_PASS_STAGE_MIN_BYTES"] = "1"
+blk = next(base64.b64decode(b_["block_b64"]) for b_ in json.load(open(%(root)r + "/tests/golden/ledger_blocks.json"))["blocks"] if b_["source"] == "v20" and b_["number"] == 6)
+csp2 = fabgpu.GPUCSP(device=0)
+for attempt in range(3):
+    try:
+        fabgpu.preverify_block(csp2, blk)
+        raise SystemExit("the block pass answered while the device was failing")
+    except fabgpu.FabgpuError:
+        pass
 print("FAULT_CONTRACT_OK")
 """
 
