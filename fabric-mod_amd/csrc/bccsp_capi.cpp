@@ -255,6 +255,7 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     opt.want_digests = ps->tuple_digest != nullptr;
     opt.block_sigs = !(ps->flags & FABGPU_PASS_NO_BLOCK_SIGS);
     opt.block_seq = ps->block_seq;
+    if (ps->tail) opt.tail_cap = ps->tail_cap;
     ps->memo_seeded = 0;
     ps->n_keyed = 0;
     bool done = false;
@@ -266,7 +267,7 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
         csp->note_route(r == 0, why);
         if (r == 0 || r == FABGPU_ETOOBIG) {
             ps->n_tx = pb.n_tx;
-            ps->n_tuples = r == 0 ? (uint32_t)v.tuple_status.size() : ntup;
+            ps->n_tuples = r == 0 ? (uint32_t)v.tuple_status.size() : (ntup ? ntup : ps->cap_tuples);   // (0: only the tail was too big)
             ps->n_block_sigs = pb.n_block_sigs;
             ps->tail_base = pb.tail_base;
             ps->tail_len = (uint32_t)pb.tail.size();
@@ -275,7 +276,6 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
         if (r == FABGPU_ETOOBIG) return FABGPU_ETOOBIG;
         if (r < 0) return r == FABGPU_EINVAL || r == FABGPU_ENOMEM ? r : FABGPU_ELAUNCH;
         done = r == 0;
-        if (done && ps->tail && pb.tail.size() > ps->tail_cap) return FABGPU_ETOOBIG;
         if (getenv("FABGPU_PASS_TIMING")) {
             if (done)
                 fprintf(stderr, "fabgpu pass2 (device walk): total %.2f ms (outline + identity table %.2f, wait for upload %.2f, device %.2f, memo %.2f)\n",

@@ -976,8 +976,12 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     const bool want_digests = opt.want_digests || opt.seed_memo;
     const bool want_tuples = (want & WANT_TUPLES) || opt.seed_memo, want_qxy = (want & WANT_QXY) || opt.seed_memo;
     const uint32_t n_skipped = opt.block_sigs ? 0 : (uint32_t)ps.block_sigs.size();   // reported (TUPLE_ST_SKIPPED), not submitted
+    if (pb.tail.size() > opt.tail_cap) {                             // the caller wants the tail and has no room for it: say so before anything runs
+        if (n_tuples_out) *n_tuples_out = 0;
+        return FABGPU_ETOOBIG;
+    }
     int rc = SyncDeviceIdentityTable();
-    if (rc != FABGPU_OK) return rc;
+    if (rc != FABGPU_OK) return declined("the identity cache could not be copied to the device");   // (the host walk will say what is wrong, if anything is)
     std::shared_lock<std::shared_timed_mutex> rl(idtab_rw_);
     if (idtab_version_ != id_version_.load(std::memory_order_acquire)) return declined("the identity cache changed under the pass");
     out.ms_gates = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk0).count();   // (outline + table sync)

@@ -105,6 +105,7 @@ struct PassOptions {
     bool seed_memo = false;               // remember (key, signature, digest) -> status under `block_seq` (implies want_digests)
     bool block_sigs = true;               // verify the orderers' block signatures too (MCS.VerifyBlock's SignedData)
     uint64_t block_seq = 0;
+    size_t tail_cap = (size_t)-1;         // room the caller has for the block-signature tail (device route: checked before anything is launched)
 };
 
 class GPUCSP {
