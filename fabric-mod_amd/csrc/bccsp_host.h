@@ -266,7 +266,7 @@ class GPUCSP {
         std::vector<uint8_t> nym_fields, nym_st;
         std::vector<uint64_t> nym_bits;
         // the device walk: envelope list, block-signature tuples, identity indices per tuple
-        std::vector<uint32_t> env_spans, id_idx;
+        std::vector<uint32_t> env_spans, payload_spans, id_idx;
         std::vector<BlockTuple> block_sigs;
     };
     struct CoReqV : CoalescedBase {

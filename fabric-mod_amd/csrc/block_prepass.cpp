@@ -366,10 +366,12 @@ void parse_block_level(const uint8_t* block, size_t len, const Pick* top, Parsed
 
 // The host's share of a DEVICE-side walk (block_walk_kernels.hip): the outer framing, where each envelope starts (a serial chain by
 // nature: envelope i + 1 begins where envelope i ends), the header fields and the orderers' block signatures with their tail.
-bool OutlineBlock(const uint8_t* block, size_t len, ParsedBlock& out, std::vector<uint32_t>& env_spans, std::vector<BlockTuple>& block_sigs) {
+bool OutlineBlock(const uint8_t* block, size_t len, ParsedBlock& out, std::vector<uint32_t>& env_spans, std::vector<BlockTuple>& block_sigs,
+                  std::vector<uint32_t>* payload_spans) {
     out.reset();
     env_spans.clear();
     block_sigs.clear();
+    if (payload_spans) payload_spans->clear();
     if (len > 0xFFFFFFF0ull) return false;
     Pick top[3] = {Pick(1), Pick(2), Pick(3)};                       // common.Block{1 header, 2 data, 3 metadata}
     if (!pb_pick(block, len, top, 3) || !top[1].seen) return false;
@@ -379,9 +381,17 @@ bool OutlineBlock(const uint8_t* block, size_t len, ParsedBlock& out, std::vecto
         if (f.num != 1 || f.wt != 2) continue;                        // common.BlockData{1 repeated bytes data}
         env_spans.push_back((uint32_t)(f.data - block));
         env_spans.push_back((uint32_t)f.len);
+        if (payload_spans) {
+            // common.Envelope{1 payload, 2 signature}, by the walker's own rule (walk_envelope's first step): what a creator signed
+            Pick e_[2] = {Pick(1), Pick(2)};
+            const bool ok = pb_pick(f.data, f.len, e_, 2) && e_[0].seen && e_[0].len != 0;
+            payload_spans->push_back(ok ? (uint32_t)(e_[0].p - block) : 0u);
+            payload_spans->push_back(ok ? (uint32_t)(e_[0].p - block + e_[0].len) : 0u);
+        }
     }
     if (!r.ok) {
         env_spans.clear();
+        if (payload_spans) payload_spans->clear();
         return false;
     }
     out.n_tx = (uint32_t)(env_spans.size() / 2);

@@ -95,7 +95,10 @@ bool ParseBlock(const uint8_t* block, size_t len, ParsedBlock& out, int max_thre
 // The host's share of a DEVICE-side walk (block_walk_kernels.hip): outer framing, (offset, length) of every envelope in env_spans, and
 // the block-level fields of `out` (header, data span, tail, n_tx = envelopes listed) with the orderers' signature tuples in block_sigs.
 // out.tuples / prefixes / hash_checks / tx_type stay empty: the device fills its own copies.  false: as ParseBlock.
-bool OutlineBlock(const uint8_t* block, size_t len, ParsedBlock& out, std::vector<uint32_t>& env_spans, std::vector<BlockTuple>& block_sigs);
+// payload_spans (optional): (start, end) of every envelope's Envelope.payload - what its creator signed - so that the device can start
+// hashing it before it has walked anything ((0, 0) where the envelope does not yield one).
+bool OutlineBlock(const uint8_t* block, size_t len, ParsedBlock& out, std::vector<uint32_t>& env_spans, std::vector<BlockTuple>& block_sigs,
+                  std::vector<uint32_t>* payload_spans = nullptr);
 // worker threads the pass gives the walk: 8, or FABGPU_PASS_WALK_THREADS (experiments)
 int WalkThreads();
 // SerializedIdentity{mspid, id_bytes = PEM x509} -> uncompressed P-256 point.  false: not such an identity.

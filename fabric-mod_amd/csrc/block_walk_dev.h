@@ -73,6 +73,9 @@ struct WalkArrays {
     bccsp::BlockHashCheck* checks = nullptr;
     uint32_t* gather_spans = nullptr;
     uint32_t* gather_off = nullptr;
+    const uint32_t* payload_spans = nullptr;   // per envelope, from the host's outline: (start, end) of Envelope.payload
+    uint8_t* digest_env = nullptr;       // per envelope: SHA-256 of that payload, started before anything was walked
+    uint32_t early_creator_hash = 0;     // the creators' launch reads digests that came from digest_env (the gate kernel cross-checks the spans)
     uint32_t* creator_spans = nullptr;   // (start, end) of every creator tuple's message, in creator order (split submissions hash them early)
     uint32_t* id_idx = nullptr;
     uint32_t* off2 = nullptr;
@@ -110,6 +113,7 @@ hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st);              
 hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st);   // tuples, prefixes, checks, gather spans / offsets
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);                        // identity lookup + gates + submission arrays + summary
 hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st);
+hipError_t launch_walk_creator_digests(const WalkArrays& a, void* row_digests, hipStream_t st);   // digest_env -> the creators' digest rows
 // TEST HOOK: the wavefront form of the signature gate over n signatures (device pointers; spans = (start, end) pairs into arena)
 hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spans, void* code, void* r, void* s, hipStream_t st);    // statuses, digest comparisons, per-transaction flags
 
@@ -137,6 +141,7 @@ struct WalkOut {
 };
 struct WalkRequest {
     uint64_t stage_token = 0;             // the block, uploaded with fabgpu_arena_stage
+    const uint32_t* payload_spans = nullptr;   // host, optional: OutlineBlock's payload spans, 2 per envelope (the creators' hashes start on them)
     size_t block_len = 0;
     const uint32_t* env_spans = nullptr;  // host
     uint32_t n_env = 0;

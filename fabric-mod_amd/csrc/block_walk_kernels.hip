@@ -209,7 +209,17 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     uint8_t gst;
     bool submit = false, unknown = false, declined = false;
     uint32_t field_byte = 0;
-    if (!ent) {
+    // a creator's digest may have been computed from the host's outline of the envelope (WalkArrays::early_creator_hash): the
+    // walker's own idea of that message must be the same bytes, or this pass does not answer
+    bool outline_differs = false;
+    if (a.early_creator_hash && i < a.n_dev_tuples && i == a.bases[t.tx].x) {
+        const uint32_t p0 = a.payload_spans[2 * (size_t)t.tx], p1 = a.payload_spans[2 * (size_t)t.tx + 1];
+        outline_differs = (t.suffix.len ? t.suffix.off : 0u) != p0 || (t.suffix.len ? t.suffix.off + t.suffix.len : 0u) != p1;
+    }
+    if (outline_differs) {
+        declined = true;
+        gst = bccsp::TUPLE_ST_BAD_DER;
+    } else if (!ent) {
         unknown = true;
         gst = bccsp::TUPLE_ST_NEEDS_SW;                             // (the host walk takes the whole block when any tuple says this)
     } else if (!ent->p256) {
@@ -262,6 +272,17 @@ __global__ void __launch_bounds__(256) walk_gate_probe_kernel(uint32_t n, const 
     const uint8_t g = wave_gate_sig(arena + spans[2 * i], spans[2 * i + 1] - spans[2 * i], lane, fb);
     (lane < 32 ? r : s)[32 * (size_t)i + (lane & 31u)] = g == bccsp::walk::GATE_SUBMIT ? (uint8_t)fb : 0;
     if (lane == 0) code[i] = g;
+}
+
+// The creators' payload digests were computed per ENVELOPE (from the host's outline, before anything was walked); the creators' launch
+// reads them per ROW: row = the number of tuple-yielding envelopes before this one.
+__global__ void __launch_bounds__(256) walk_creator_digest_kernel(WalkArrays a, uint8_t* __restrict__ row_digests) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n_env || a.counts[e].x == 0) return;
+    const uint4* src = reinterpret_cast<const uint4*>(a.digest_env + 32 * (size_t)e);
+    uint4* dst = reinterpret_cast<uint4*>(row_digests + 32 * (size_t)a.cbase[e]);
+    dst[0] = src[0];
+    dst[1] = src[1];
 }
 
 // per-transaction evidence bits
@@ -352,6 +373,11 @@ hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st) {
     if (a.n_tuples == 0) return hipSuccess;
     hipLaunchKernelGGL(walk_gate_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);   // four wavefronts = four tuples per workgroup
+    return hipGetLastError();
+}
+hipError_t launch_walk_creator_digests(const WalkArrays& a, void* row_digests, hipStream_t st) {
+    if (a.n_env == 0) return hipSuccess;
+    hipLaunchKernelGGL(walk_creator_digest_kernel, dim3((a.n_env + 255) / 256), dim3(256), 0, st, a, (uint8_t*)row_digests);
     return hipGetLastError();
 }
 hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spans, void* code, void* r, void* s, hipStream_t st) {

@@ -1320,10 +1320,15 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     const size_t o_env = carve((size_t)ne * 8), o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_tot = carve(sizeof(WalkTotals)),
                  o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
                  o_cbase = carve((size_t)ne * 4);
+    // The creators' messages are whole envelope payloads - the longest hashes of a block, a serial chain per message, and for a
+    // block of a few hundred transactions THE critical path (300 tx: the chain is 240 us of a 600 us device phase).  With the host's
+    // outline of where they are they start before anything is walked, beside the walk's two runs and the gates.
+    const bool early_hash = rq.payload_spans && !rq.walk_only && ctx->allow_pair && (uint64_t)ne * 2 <= 65536u;
+    const size_t o_pay = carve(early_hash ? (size_t)ne * 8 : 0), o_denv = carve(early_hash ? (size_t)ne * 32 : 0);
     int rc;
     if ((rc = ctx->walk_env.ensure(o))) return rc;
-    // pinned staging: env spans up, totals / summary down (the result arrays are sized further down)
-    const size_t p_env = 0, p_tot = round_up((size_t)ne * 8, 64), p_sum = p_tot + 64, p_first = p_sum + 64;
+    // pinned staging: env (and payload) spans up, totals / summary down (the result arrays are sized further down)
+    const size_t p_env = 0, p_pay = round_up((size_t)ne * 8, 64), p_tot = p_pay + round_up(early_hash ? (size_t)ne * 8 : 0, 64), p_sum = p_tot + 64, p_first = p_sum + 64;
     if ((rc = ctx->walk_pin.ensure(p_first))) return rc;
     uint8_t* de = (uint8_t*)ctx->walk_env.d;
     WalkArrays a;
@@ -1343,6 +1348,25 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.summary = (WalkSummary*)(de + o_sum);
     memcpy((uint8_t*)ctx->walk_pin.h + p_env, rq.env_spans, (size_t)ne * 8);
     hipError_t err = hipMemcpyAsync(de + o_env, (uint8_t*)ctx->walk_pin.h + p_env, (size_t)ne * 8, hipMemcpyHostToDevice, st);
+    bool s2_busy = false;
+    struct Drain2 {                                                         // (an early exit must not leave the hashes running)
+        hipStream_t s;
+        bool* busy;
+        ~Drain2() { if (*busy) hipStreamSynchronize(s); }
+    } drain2{ctx->stream2, &s2_busy};
+    if (err == hipSuccess && early_hash) {
+        a.payload_spans = (const uint32_t*)(de + o_pay);
+        a.digest_env = de + o_denv;
+        memcpy((uint8_t*)ctx->walk_pin.h + p_pay, rq.payload_spans, (size_t)ne * 8);
+        err = hipMemcpyAsync(de + o_pay, (uint8_t*)ctx->walk_pin.h + p_pay, (size_t)ne * 8, hipMemcpyHostToDevice, st);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[3], st);     // "the span lists are on the device"
+        if (err == hipSuccess) err = hipStreamWaitEvent(ctx->stream2, ctx->ev_w[3], 0);
+        if (err == hipSuccess) {
+            s2_busy = true;
+            // (thousands of them: on CUs of their own, like every long-running launch of a big block)
+            err = launch_sha256_spans(ne, sl->d, round_up(sl->len, 4) + 64, a.payload_spans, a.digest_env, ctx->stream2, ne > 2048 ? 84u << 10 : 0u);
+        }
+    }
     if (err == hipSuccess && has_tail) {
         if ((rc = ctx->tailbuf.ensure(rq.tail_len))) return rc;
         memcpy(ctx->tailbuf.h, rq.tail, rq.tail_len);
@@ -1398,6 +1422,15 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // messages (whole payloads), so they get the shorter arithmetic.
     a.split = (ctx->allow_pair && nt > (uint32_t)VERIFY_PAIR_MAX && tot.creators != 0 && tot.creators <= (uint32_t)VERIFY_PAIR_MAX &&
                (uint64_t)2 * tot.creators + (nt - tot.creators) <= 65536u) ? 1u : 0u;
+    // Smaller blocks split too - both launches with two lanes per signature, sharing the chip: what counts there is that the creators'
+    // 40-block hashes start behind the emit kernel instead of inside the one fused launch (300 tx: 0.92 -> 0.82 ms, 1 000 tx:
+    // 1.09 -> 0.99 ms; tools/gpu_dw_small.sh)
+    bool both_pair = false;
+    if (!a.split && ctx->allow_pair && tot.creators != 0 && nt > tot.creators && (uint64_t)2 * nt <= 65536u) {
+        a.split = 1;
+        both_pair = true;
+    }
+    const bool exclusive = a.split && !both_pair;
     a.verdict_bits = (const uint64_t*)(dt + o_bits);
     a.verdict_bits_c = (const uint64_t*)(dt + o_bitc);
     a.row_digests = out.tuple_digest ? dt + o_dig : nullptr;
@@ -1489,11 +1522,16 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // the main stream looks identities up and gates signatures
     err = hipEventRecord(ctx->ev_w[0], st);
     if (err == hipSuccess && a.split) {
-        // stream2: the creators' messages are whole envelope payloads - the longest hashes of the block by far (and a serial chain per
-        // message): they start now, beside the identity lookup and the gates, and their launch then only has the arithmetic left
-        // (digest rows [0, n_creators))
+        // stream2: the creators' digests into rows [0, n_creators), so that their launch only has the arithmetic left.  Either they
+        // were hashed per envelope from the host's outline (early_hash, queued before the walk: a scatter by the scan's creator ranks
+        // is all that is left), or they are hashed now, beside the identity lookup and the gates.
         err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2, 84u << 10);
+        if (err == hipSuccess && early_hash) {
+            a.early_creator_hash = 1;
+            err = launch_walk_creator_digests(a, dt + o_dig, s2);
+        } else if (err == hipSuccess) {
+            err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2, exclusive ? 84u << 10 : 0u);
+        }
     }
     if (err == hipSuccess && np) {
         // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them), on CUs of their own: 40
@@ -1547,7 +1585,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // rows [row0, row0 + n) as one launch on stream `ls`
     auto verify_rows = [&](uint32_t row0, uint32_t n, bool prefixed, bool pair, void* bits, hipStream_t ls) -> int {
         ShaPrefixArgs p = pa;
-        if (a.split) p.lds_reserve = 84u << 10;                            // the two launches of a split submission on disjoint CUs (kernels.h)
+        if (exclusive) p.lds_reserve = 84u << 10;                          // the two launches of a split submission on disjoint CUs (kernels.h)
         if (!prefixed) {
             p.m = 0;
             p.pre_off = p.pre_idx = nullptr;
@@ -1581,19 +1619,19 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         {   // rows [0, n_creators): digests are there (or about to be: same stream), keys by id or carried along
             hipError_t e;
             if (rq.all_keyed) {
-                e = launch_p256_verify_keyed(tot.creators, a.key_id, nkeys, (const void*)kt, dt + o_dig, a.r, a.s, ctx->d_gtab, dt + o_bitc, dt + o_dst, true, s2, 84u << 10);
+                e = launch_p256_verify_keyed(tot.creators, a.key_id, nkeys, (const void*)kt, dt + o_dig, a.r, a.s, ctx->d_gtab, dt + o_bitc, dt + o_dst, true, s2, exclusive ? 84u << 10 : 0u);
             } else {
                 size_t wi = 0;
                 void* wsp = nullptr;
                 if ((rc = ctx->acquire_qws(verify_workspace_bytes(tot.creators, true), &wi, &wsp, s2))) return rc;
-                e = launch_p256_verify(tot.creators, a.qx, a.qy, dt + o_dig, a.r, a.s, ctx->d_gtab, wsp, dt + o_bitc, dt + o_dst, true, s2, 84u << 10);
+                e = launch_p256_verify(tot.creators, a.qx, a.qy, dt + o_dig, a.r, a.s, ctx->d_gtab, wsp, dt + o_bitc, dt + o_dst, true, s2, exclusive ? 84u << 10 : 0u);
                 ctx->release_qws(wi, s2);
             }
             if (e != hipSuccess) return hip_to_rc(e);
         }
         err = hipEventRecord(ctx->ev_w[4], s2);
         if (err != hipSuccess) return hip_to_rc(err);
-        if ((rc = verify_rows(tot.creators, nt - tot.creators, np != 0, false, dt + o_bits, st))) return rc;
+        if ((rc = verify_rows(tot.creators, nt - tot.creators, np != 0, both_pair, dt + o_bits, st))) return rc;
         err = hipStreamWaitEvent(st, ctx->ev_w[4], 0);
     } else {
         if ((rc = verify_rows(0, nt, np != 0, ctx->allow_pair, dt + o_bits, st))) return rc;
