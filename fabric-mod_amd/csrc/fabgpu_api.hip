@@ -1580,8 +1580,10 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         std::lock_guard<std::mutex> klk(ctx->kmu);
         nkeys = (uint32_t)ctx->ktabs.size();
         kt = ctx->d_ktabs;
-        if (nkeys == 0) return FABGPU_EINVAL;
     }
+    // (a table without a single P-256 identity - ledger-harness identities, other curves - is "all keyed" vacuously and there is no
+    // comb table at all: the rows are fillers then, carried keys serve them, and the pass ends with "no tuple for the device to decide")
+    if (rq.all_keyed && nkeys == 0) rq.all_keyed = false;
     // rows [row0, row0 + n) as one launch on stream `ls`
     auto verify_rows = [&](uint32_t row0, uint32_t n, bool prefixed, bool pair, void* bits, hipStream_t ls) -> int {
         ShaPrefixArgs p = pa;
