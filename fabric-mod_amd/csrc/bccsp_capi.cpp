@@ -520,10 +520,10 @@ int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* di
     if (!block) return FABGPU_EINVAL;
     put_err(diff, cap, "");
     ParsedBlock host, out;
-    std::vector<uint32_t> env;
+    std::vector<uint32_t> env, pay;
     std::vector<BlockTuple> sigs;
     const bool hok = ParseBlock(block, len, host, 1);
-    const bool ook = OutlineBlock(block, len, out, env, sigs);
+    const bool ook = OutlineBlock(block, len, out, env, sigs, &pay);
     if (hok != ook) { put_err(diff, cap, "framing verdicts differ"); return 1; }
     if (!hok) return FABGPU_EINVAL;
     const uint32_t ne = (uint32_t)(env.size() / 2);
@@ -585,6 +585,15 @@ int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* di
             k++;
         }
         if (d.empty() && (k != ncre || cspans[2 * (size_t)k] != 0xDEADBEEFu)) d = "creator span count";
+        // the outline's payload span of an envelope that yields tuples IS its creator's message (the device hashes it before it has
+        // walked anything, and its gate kernel insists on exactly this equality)
+        if (d.empty() && pay.size() != 2 * (size_t)ne) d = "payload span list";
+        uint32_t c = 0;
+        for (uint32_t e = 0; d.empty() && e < ne; e++) {
+            if (!cnt[e].t) continue;
+            if (pay[2 * (size_t)e] != cspans[2 * (size_t)c] || pay[2 * (size_t)e + 1] != cspans[2 * (size_t)c + 1]) d = "payload span of envelope " + std::to_string(e);
+            c++;
+        }
     }
     for (size_t i = 0; d.empty() && i < host.prefixes.size(); i++) {
         const Span a = host.prefixes[i];
