@@ -226,6 +226,24 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
             legs[name] = {"validated_tx_per_s": n_tx / (med * 1e-3), "median_ms_per_block": med, "min_ms": min(per), "max_ms": max(per), "blocks": steps,
                           "walked_on_device": after["device_walks"] - before["device_walks"], "walked_on_host": after["host_walks"] - before["host_walks"]}
         os.environ.pop("FABGPU_PASS_STAGE_MIN_BYTES", None)
+        try:                                                   # several channels of a peer at once: three callers on the one provider
+            import threading
+            n_callers, per_caller = 3, 8
+
+            def caller(t):
+                for k in range(per_caller):
+                    fabgpu.preverify_block2(csp, blk, block_seq=10000 * (t + 1) + k, lean=True)
+            th = [threading.Thread(target=caller, args=(t,)) for t in range(n_callers)]
+            c0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            wall = time.perf_counter() - c0
+            legs["three_callers_flags_only"] = {"validated_tx_per_s": n_tx * n_callers * per_caller / wall, "ms_per_block_aggregate": wall / (n_callers * per_caller) * 1e3,
+                                                "blocks": n_callers * per_caller}
+        except Exception as e:                                 # noqa: BLE001
+            legs["three_callers_flags_only"] = {"error": repr(e)[:200]}
         bad = bytearray(blk)
         at = blk.index(envs[7]) + len(envs[7]) // 2            # one byte inside transaction 7's payload
         bad[at] ^= 1
