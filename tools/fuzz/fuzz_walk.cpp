@@ -7,6 +7,71 @@
 #include "block_prepass.h"
 #include "idemix_host.h"
 using namespace fab::bccsp;
+
+// The device walk's two-run procedure (block_walk_core.h: CountEmitter, exclusive prefix sum, WriteEmitter) on the host, into arrays of
+// EXACTLY the counted sizes (a record written outside its envelope's range is a heap overflow ASAN sees), compared with ParseBlock;
+// the outline's payload spans against the creator messages; the device's signature gate on every signature of the mutant.
+static bool two_run(const uint8_t* block, size_t len, const ParsedBlock& host) {
+    ParsedBlock out;
+    std::vector<uint32_t> env, pay;
+    std::vector<BlockTuple> sigs;
+    if (!OutlineBlock(block, len, out, env, sigs, &pay)) { printf("OUTLINE REFUSES WHAT PARSEBLOCK TAKES\n"); return false; }
+    const uint32_t ne = (uint32_t)(env.size() / 2);
+    struct C { uint32_t t, p, c; uint64_t g; };
+    std::vector<C> cnt(ne), base(ne);
+    std::vector<uint32_t> cb(ne);
+    C run = {0, 0, 0, 0};
+    uint32_t ncre = 0;
+    for (uint32_t e = 0; e < ne; e++) {
+        if ((size_t)env[2 * e] + env[2 * e + 1] > len) { printf("ENVELOPE SPAN OUT OF RANGE\n"); return false; }
+        walk::CountEmitter em;
+        uint8_t ty, un;
+        walk::walk_envelope(block, block + env[2 * e], env[2 * e + 1], e, em, ty, un);
+        if (ty != host.tx_type[e] || un != host.tx_understood[e]) { printf("COUNT RUN DISAGREES WITH PARSEBLOCK\n"); return false; }
+        cnt[e] = {em.nt, em.np, em.nc, em.gb};
+        base[e] = run;
+        cb[e] = ncre;
+        run.t += em.nt; run.p += em.np; run.c += em.nc; run.g += em.gb;
+        if (em.nt) ncre++;
+    }
+    if (run.t + sigs.size() != host.tuples.size() || run.p != host.prefixes.size() || run.c != host.hash_checks.size()) { printf("TOTALS DIFFER\n"); return false; }
+    // exact-size heap arrays (malloc, not vectors: no slack)
+    BlockTuple* tuples = (BlockTuple*)malloc(sizeof(BlockTuple) * run.t + 1);
+    uint32_t* pre = (uint32_t*)malloc(8 * (size_t)run.p + 1);
+    BlockHashCheck* chk = (BlockHashCheck*)malloc(sizeof(BlockHashCheck) * run.c + 1);
+    uint32_t* gsp = (uint32_t*)malloc(24 * (size_t)run.c + 1);
+    uint32_t* gof = (uint32_t*)malloc(4 * (size_t)run.c + 4);
+    uint32_t* csp = (uint32_t*)malloc(8 * (size_t)ncre + 1);
+    bool ok = true;
+    for (uint32_t e = 0; e < ne && ok; e++) {
+        if (!cnt[e].t && !cnt[e].p && !cnt[e].c) continue;
+        walk::WriteEmitter em{tuples, pre, chk, gsp, gof, base[e].t, base[e].p, base[e].c, (uint32_t)base[e].g, cnt[e].t, cnt[e].p, cnt[e].c, csp, cb[e]};
+        uint8_t ty, un;
+        walk::walk_envelope(block, block + env[2 * e], env[2 * e + 1], e, em, ty, un);
+        if (em.nt != cnt[e].t || em.np != cnt[e].p || em.nc != cnt[e].c) { printf("THE TWO RUNS DISAGREE\n"); ok = false; }
+    }
+    for (size_t i = 0; ok && i < run.t; i++)
+        if (memcmp(&tuples[i], &host.tuples[i], sizeof(BlockTuple)) != 0) { printf("TUPLE %zu DIFFERS\n", i); ok = false; }
+    for (uint32_t e = 0, c = 0; ok && e < ne; e++) {
+        if (!cnt[e].t) continue;
+        if (pay[2 * e] != csp[2 * c] || pay[2 * e + 1] != csp[2 * c + 1]) { printf("PAYLOAD SPAN OF ENVELOPE %u DIFFERS\n", e); ok = false; }
+        c++;
+    }
+    for (size_t i = 0; ok && i < host.tuples.size(); i++) {
+        const BlockTuple& t = host.tuples[i];
+        uint8_t r[32], s2[32];
+        if ((size_t)t.sig.off + t.sig.len <= len) {
+            uint8_t* sig = (uint8_t*)malloc(t.sig.len ? t.sig.len : 1);          // exact-size copy: the gate must not read past the signature
+            memcpy(sig, block + t.sig.off, t.sig.len);
+            (void)walk::gate_sig_fast(sig, t.sig.len, r, s2);
+            free(sig);
+        }
+        (void)walk::id_hash_host(block + t.identity.off, t.identity.len);
+    }
+    free(tuples); free(pre); free(chk); free(gsp); free(gof); free(csp);
+    return ok;
+}
+
 int main() {
     FILE* f = fopen("/tmp/blk_small.bin", "rb");
     std::vector<uint8_t> base(8 << 20);
@@ -32,6 +97,7 @@ int main() {
         ParsedBlock pb;
         if (ParseBlock(heap, b.size(), pb, it % 2 ? 4 : 1)) {
             parsed++;
+            if (!two_run(heap, b.size(), pb)) return 1;
             tuples += pb.tuples.size();
             if (pb.tail_base < b.size() || (pb.tail_base & 63u)) { printf("TAIL BASE\n"); return 1; }
             for (auto& t : pb.tuples) {
@@ -61,5 +127,6 @@ int main() {
         }
         free(heap);
     }
-    printf("fuzz ok: %zu of 20000 mutants parsed, %zu tuples (%zu orderer block signatures)\n", parsed, tuples, blocksigs);
+    printf("fuzz ok: %zu of 20000 mutants parsed, %zu tuples (%zu orderer block signatures); the device walk's two-run procedure, the outline and the\n"
+           "signature gate ran on every parsed mutant with exact-size arrays and agreed with ParseBlock\n", parsed, tuples, blocksigs);
 }

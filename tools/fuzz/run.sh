@@ -6,11 +6,14 @@
 # end is caught, and every span the walker reports is checked to lie inside the buffer.  Host only, no GPU.
 #   tools/fuzz/run.sh        (about a minute; 20 000 block mutants - orderer block signatures included since round 2 - and 200 000 certificate
 #                            mutants through the SPKI walker, the TBS / signature splitter of the x509 batch check and the DER gate: no finding)
+# The block mutants also go through the code the DEVICE walk is compiled from (block_walk_core.h): the count / prefix sum / write
+# procedure into exact-size arrays, the host's outline with its payload spans, the signature gate of the common DER shape - each
+# compared with what ParseBlock says.
 set -e
 cd "$(dirname "$0")/../.."
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
 SRC=fabric-mod_amd/csrc
-FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -I$SRC -Iinclude"
+FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -I$SRC -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__"
 python3 - <<'PY'
 import json, os, sys
 ROOT = os.getcwd()

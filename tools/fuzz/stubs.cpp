@@ -17,3 +17,8 @@ int fabgpu_p256_key_lookup(fabgpu_ctx*, const uint8_t*, const uint8_t*, uint32_t
 int fabgpu_identity_verify_batch(fabgpu_ctx*, const fabgpu_identity_batch*) { return -1; }
 int fabgpu_arena_stage(fabgpu_ctx*, const void*, size_t, uint64_t*) { return -1; }
 }
+#include "block_walk_dev.h"
+namespace fab {
+int walk_idtab_set(fabgpu_ctx*, uint32_t, const DevIdEntry*, const uint8_t*, size_t) { return -1; }
+int walk_block_pass(fabgpu_ctx*, WalkRequest&) { return -1; }
+}
