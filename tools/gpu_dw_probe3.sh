@@ -1,3 +1,5 @@
+#!/bin/bash
+# the device-walk GPU tests, the 10 000-tx pass from one and from three callers, and a rocprofv3 kernel trace of it (one gpurun call)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 300 python -m pytest tests/test_device_walk.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/dw_tests.log; tail -3 gpurun_out/dw_tests.log
 B=.bench_blocks/ecdsa_10000_0.bin

@@ -1,3 +1,5 @@
+#!/bin/bash
+# as gpu_dw_probe3.sh, the bench twice (box noise), trace without the stats table: the timelines in profiles/r02_device_walk_timeline.txt
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 300 python -m pytest tests/test_device_walk.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/dw_tests.log; tail -1 gpurun_out/dw_tests.log
 B=.bench_blocks/ecdsa_10000_0.bin

@@ -1,3 +1,5 @@
+#!/bin/bash
+# blocks of 5 .. 100 transactions on both routes (staging forced): where the device walk starts to win
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for t in 5 20 50 100; do
   for route in device host; do
