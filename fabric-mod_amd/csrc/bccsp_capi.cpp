@@ -258,6 +258,7 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     if (ps->tail) opt.tail_cap = ps->tail_cap;
     ps->memo_seeded = 0;
     ps->n_keyed = 0;
+    ps->n_device_decoded = 0;
     bool done = false;
     {   // the walk on the device (block_walk_dev.h); a block it declines takes the host walk below
         const char* why = "";
@@ -320,6 +321,7 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     if (ps->tail && !pb.tail.empty()) memcpy(ps->tail, pb.tail.data(), pb.tail.size());
     ps->memo_seeded = v.memo_seeded;
     ps->n_keyed = (uint32_t)v.n_keyed;
+    ps->n_device_decoded = done ? v.n_device_decoded : 0;
     return FABGPU_OK;
 }
 
@@ -330,6 +332,13 @@ int fabgpu_csp_pass_routes(fabgpu_csp* csp, uint64_t* device_walks, uint64_t* ho
     if (device_walks) *device_walks = csp->device_walks;
     if (host_walks) *host_walks = csp->host_walks;
     put_err(last_decline, cap, csp->last_decline);
+    return FABGPU_OK;
+}
+// device-route statistics of this provider (GPUCSP::PassStats): out[0] relaunches, [1] tuples whose certificate the device decoded,
+// [2] identities learned that way, [3] signatures that took the general DER parser
+int fabgpu_csp_pass_stats(fabgpu_csp* csp, uint64_t* out4) {
+    if (!csp || !out4) return FABGPU_EINVAL;
+    csp->csp->PassStats(out4);
     return FABGPU_OK;
 }
 // TEST HOOK: the device walker against the host walker on one block.  0: identical (or *declined = 1: the device declined, nothing
@@ -625,6 +634,34 @@ int fabgpu_gate_sig_fast(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* 
         if (s32) memcpy(s32, s, 32);
     }
     return g;
+}
+// TEST HOOK (pure host): the gate the device route applies to EVERY signature (block_walk_core.h gate_sig_any = the fast gate, then the
+// general parser for what it declines): 0 submit (r32 / s32 set), 1 high-S, 2 empty, 4 does not unmarshal / r, s <= 0, 5 r beyond 256 bits
+int fabgpu_gate_sig_any(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32) {
+    uint8_t r[32], s[32];
+    if (len > 0xFFFFFFFFull) return walk::GATE_BAD_DER;
+    const uint8_t g = walk::gate_sig_any(sig, (uint32_t)len, r, s);
+    if (g == walk::GATE_SUBMIT) {
+        if (r32) memcpy(r32, r, 32);
+        if (s32) memcpy(s32, s, 32);
+    }
+    return g;
+}
+// TEST HOOK (pure host): what the host route makes of an identity: 0 = a PEM x509 certificate with an on-curve P-256 key (qxy set),
+// 1 = anything else (identity.Verify needs bccsp/sw)
+int fabgpu_identity_to_p256(const uint8_t* ident, size_t len, uint8_t* qxy64) {
+    uint8_t qx[32], qy[32];
+    if (!ident || !IdentityToP256(ident, len, qx, qy) || !PublicKeyOnCurve(qx, qy)) return 1;
+    if (qxy64) {
+        memcpy(qxy64, qx, 32);
+        memcpy(qxy64 + 32, qy, 32);
+    }
+    return 0;
+}
+// TEST HOOK (device): the identity decoder of the device route (certificate -> key by one wavefront) over n identities
+int fabgpu_csp_idfix_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* key) {
+    if (!csp) return FABGPU_EINVAL;
+    return fab::walk_idfix_probe(csp->csp->ctx(), n, arena, arena_len, spans, code, key);
 }
 // TEST HOOK (device): the wavefront form of the same gate, as block_walk_kernels.hip runs it, over n signatures
 int fabgpu_csp_gate_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s) {

@@ -659,11 +659,26 @@ void GPUCSP::SetIdentityCacheLimits(size_t max_identities, size_t max_registered
     id_max_ = max_identities ? max_identities : 1;
     id_max_registered_ = max_registered_keys;
     id_register_after_ = register_after_hits ? register_after_hits : 1;
+    EvictIdentitiesLocked();
+    id_version_.fetch_add(1, std::memory_order_release);
+}
+// (idmu_ held) the LRU bound.  An identity that owned a device comb table gives its place in the table budget back: the table itself
+// stays registered with the context (launches in flight may still name it; fabgpu_p256_key_register finds it again by key should the
+// identity return), but id_registered_ counts the tables of CACHED identities - otherwise a provider that churned through more than
+// id_max_registered_ registered identities could never register another one and stayed on the fresh-key kernels for good.
+void GPUCSP::EvictIdentitiesLocked() const {
     while (idcache_.size() > id_max_) {
+        const CachedIdentity& c = idlru_.back().second;
+        if ((c.key_id >= 0 || c.registering) && id_registered_ > 0) id_registered_--;
         idcache_.erase(idlru_.back().first);
         idlru_.pop_back();
     }
-    id_version_.fetch_add(1, std::memory_order_release);
+}
+void GPUCSP::PassStats(uint64_t out[4]) const {
+    out[0] = pass_relaunches_.load(std::memory_order_relaxed);
+    out[1] = pass_decoded_.load(std::memory_order_relaxed);
+    out[2] = pass_learned_.load(std::memory_order_relaxed);
+    out[3] = pass_general_der_.load(std::memory_order_relaxed);
 }
 size_t GPUCSP::IdentityCacheSize() const {
     std::lock_guard<std::mutex> lk(idmu_);
@@ -689,7 +704,7 @@ void GPUCSP::RegisterQueued(const std::vector<std::string>& to_register) const {
         for (const std::string& k : to_register) {
             auto it = idcache_.find(k);
             if (it != idcache_.end()) todo.emplace_back(k, it->second->second);
-            else id_registered_--;                     // evicted meanwhile
+            // (evicted meanwhile: EvictIdentitiesLocked gave its place in the table budget back)
         }
     }
     for (auto& kv : todo) {
@@ -700,8 +715,8 @@ void GPUCSP::RegisterQueued(const std::vector<std::string>& to_register) const {
         if (it != idcache_.end()) {
             it->second->second.registering = false;
             if (ok) it->second->second.key_id = id;
+            else if (id_registered_ > 0) id_registered_--;
         }
-        if (!ok) id_registered_--;
         id_version_.fetch_add(1, std::memory_order_release);
     }
 }
@@ -955,7 +970,6 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     {
         std::lock_guard<std::mutex> lk(idmu_);
         if (!idemix_msps_.empty()) return declined("idemix MSPs are registered (their creators are recognised on the host)");
-        if (idcache_.empty()) return declined("no identity is known yet");
     }
     struct Lease {
         const GPUCSP* c;
@@ -996,11 +1010,11 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         ParsedBlock& pb;
         BlockVerdicts& out;
         PassScratch& ps;
-        bool want_tuples, want_digests;
+        bool want_tuples, want_digests, want_qxy;
         uint32_t cap_tx, cap_tuples, n_skipped;
         uint32_t n_tuples = 0;
         bool too_big = false;
-    } sz{pb, out, ps, want_tuples, want_digests, cap_tx, cap_tuples, n_skipped};
+    } sz{pb, out, ps, want_tuples, want_digests, want_qxy, cap_tx, cap_tuples, n_skipped};
     WalkRequest rq;
     rq.stage_token = tok;
     rq.block_len = len;
@@ -1046,15 +1060,27 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         } else {
             z.out.tuple_digest.clear();
         }
+        if (z.want_qxy) {                                                // the key of every tuple's identity, as the device matched or decoded it
+            z.out.tuple_qxy.resize(nt * 64);
+            o.tuple_qxy = z.out.tuple_qxy.data();
+        } else {
+            z.out.tuple_qxy.clear();
+        }
         return true;
     };
+    ps.learn.resize(WALK_LEARN_SLOTS);
+    rq.learn_out = ps.learn.data();
     auto clk2 = std::chrono::steady_clock::now();
     rc = walk_block_pass(ctx_, rq);
     out.ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk2).count();
     if (n_tuples_out) *n_tuples_out = sz.n_tuples;
     if (rc == WALK_DECLINED) return declined(rq.declined_why);
     if (rc == FABGPU_ETOOBIG && sz.too_big) return FABGPU_ETOOBIG;     // pb.n_tx / *n_tuples_out say what to make room for
+    if (rc == FABGPU_ETOOBIG) return declined("the block exceeds the device walk's limits");   // (not the caller's arrays: the host walk takes it)
     if (rc != FABGPU_OK) return rc;
+    pass_relaunches_.fetch_add(rq.relaunched, std::memory_order_relaxed);
+    pass_decoded_.fetch_add(rq.summary.n_unknown_identity, std::memory_order_relaxed);
+    pass_general_der_.fetch_add(rq.summary.n_general_der, std::memory_order_relaxed);
     const size_t nt = sz.n_tuples, nd = nt - n_skipped;
     out.n_tx = pb.n_tx;
     memcpy(pb.tx_type.data(), out.tx_type.data(), pb.n_tx);
@@ -1063,11 +1089,9 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     out.memo_seeded = 0;
     out.n_block_sigs = pb.n_block_sigs;
     out.block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
-    {   // tuples the device decided = tuples it hashed
-        size_t submitted = 0;
-        for (size_t i = 0; i < out.tuple_hashed.size(); i++) submitted += out.tuple_hashed[i];
-        out.n_keyed = rq.all_keyed ? submitted : 0;
-    }
+    // tuples that went through registered comb tables, by launch class (the status kernel counted what each class decided)
+    out.n_keyed = (rq.keyed_creators ? rq.summary.n_hashed_creator : 0u) + (rq.keyed_others ? rq.summary.n_hashed_other : 0u);
+    out.n_device_decoded = rq.summary.n_unknown_identity;
     for (size_t i = nd; i < nt; i++) {                                   // block signatures the caller asked not to verify
         out.tuple_status[i] = TUPLE_ST_SKIPPED;
         out.tuple_hashed[i] = 0;
@@ -1086,20 +1110,8 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         out.tuple_tx.clear();
         out.tuple_kind.clear();
     }
-    if (want_qxy) {                                                      // the key of tuple i = the key of the cache entry the device matched
-        out.tuple_qxy.resize(nt * 64);
-        for (size_t i = 0; i < nt; i++) {
-            const uint32_t ix = ps.id_idx[i];
-            if (ix < idtab_host_.size() && idtab_host_[ix].p256) {
-                memcpy(&out.tuple_qxy[64 * i], idtab_host_[ix].qx, 32);
-                memcpy(&out.tuple_qxy[64 * i + 32], idtab_host_[ix].qy, 32);
-            } else {
-                memset(&out.tuple_qxy[64 * i], 0, 64);
-            }
-        }
-    } else {
-        out.tuple_qxy.clear();
-    }
+    if (want_qxy)
+        for (size_t i = nd; i < nt; i++) memset(&out.tuple_qxy[64 * i], 0, 64);   // (skipped block signatures: as the host pass reports them)
     if (want_digests)
         for (size_t i = 0; i < nt; i++)
             if (!out.tuple_hashed[i]) memset(&out.tuple_digest[32 * i], 0, 32);   // as the host pass reports them
@@ -1126,6 +1138,34 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         }
     }
     rl.unlock();
+    // Identities the device decoded itself (nobody had met them) enter the cache here, with the key the device read out of the
+    // certificate - the host route's "new identity" branch without decoding anything again.  At most WALK_LEARN_SLOTS per block; the
+    // LRU bounds what unvalidated blocks can make the provider remember, and a comb table is still only earned by being named often.
+    if (rq.summary.n_learn) {
+        std::lock_guard<std::mutex> lk(idmu_);
+        bool grew = false;
+        for (const WalkLearn& l : ps.learn) {
+            if (!l.tag || !l.ready || (uint64_t)l.off + l.len > len) continue;
+            std::string key((const char*)block + l.off, l.len);
+            if (idcache_.find(key) != idcache_.end()) continue;
+            CachedIdentity ci;
+            ci.p256 = l.ready == 1;
+            memcpy(ci.qx, l.qx, 32);
+            memcpy(ci.qy, l.qy, 32);
+            ci.hits = l.hits ? l.hits : 1;
+            if (ci.p256 && ci.hits >= id_register_after_ && id_registered_ < id_max_registered_) {
+                ci.registering = true;
+                id_registered_++;
+                to_register.push_back(key);
+            }
+            idlru_.emplace_front(std::move(key), ci);
+            idcache_[idlru_.front().first] = idlru_.begin();
+            EvictIdentitiesLocked();
+            pass_learned_.fetch_add(1, std::memory_order_relaxed);
+            grew = true;
+        }
+        if (grew) id_version_.fetch_add(1, std::memory_order_release);
+    }
     RegisterQueued(to_register);
     static const int gate_max = [] { const char* e = getenv("FABGPU_PASS_GATE_THREADS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     if (opt.seed_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max);
@@ -1268,10 +1308,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                         if (it == idcache_.end()) {
                             idlru_.emplace_front(key, ci);
                             idcache_[key] = idlru_.begin();
-                            while (idcache_.size() > id_max_) {                  // least recently used goes (its device table, if any, stays
-                                idcache_.erase(idlru_.back().first);             // registered: tables are bounded by id_max_registered_)
-                                idlru_.pop_back();
-                            }
+                            EvictIdentitiesLocked();                             // least recently used goes
                             id_version_.fetch_add(1, std::memory_order_release);   // (the device's copy of the cache is stale now)
                         } else {
                             ci = it->second->second;
@@ -1342,10 +1379,15 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     std::vector<uint8_t> keyed_w(nthreads, 1);
     std::vector<uint32_t>&sub = ps_.sub, &ids = ps_.ids, &off = ps_.off, &pre_idx = ps_.pre_idx;
     std::vector<uint8_t>&qx = ps_.qx, &qy = ps_.qy, &r = ps_.r, &s = ps_.s;
-    if (sub.size() < nt) {
-        sub.resize(nt); ids.resize(nt); off.resize(2 * nt); pre_idx.resize(nt);
-        qx.resize(nt * 32); qy.resize(nt * 32); r.resize(nt * 32); s.resize(nt * 32);
-    }
+    // (each on its own: the device route borrows `sub` alone - SeedMemo's selection scratch - so its size says nothing about the others)
+    if (sub.size() < nt) sub.resize(nt);
+    if (ids.size() < nt) ids.resize(nt);
+    if (off.size() < 2 * nt) off.resize(2 * nt);
+    if (pre_idx.size() < nt) pre_idx.resize(nt);
+    if (qx.size() < nt * 32) qx.resize(nt * 32);
+    if (qy.size() < nt * 32) qy.resize(nt * 32);
+    if (r.size() < nt * 32) r.resize(nt * 32);
+    if (s.size() < nt * 32) s.resize(nt * 32);
     std::atomic<int> arrived(0);
     double ms_gates_max = 0;
     std::mutex gm;

@@ -21,6 +21,7 @@
 
 #include "../../include/fabgpu.h"
 #include "block_prepass.h"
+#include "block_walk_dev.h"
 #include "coalescer.h"
 
 namespace fab {
@@ -97,6 +98,7 @@ struct BlockVerdicts {
     uint8_t block_sigs_understood = 0;
     uint32_t memo_seeded = 0;             // entries this pass added to the verdict memo
     size_t n_keyed = 0;                   // submitted tuples that went through per-key device tables (the rest carried their keys)
+    uint32_t n_device_decoded = 0;        // device route: tuples whose identity was not in the device's table (certificate decoded on the device)
 };
 
 // Options of one pass.
@@ -173,6 +175,9 @@ class GPUCSP {
     // identity cache bounds (msp/cache/cache.go keeps 100 deserialized identities; the pass sees every client certificate too)
     void SetIdentityCacheLimits(size_t max_identities, size_t max_registered_keys, uint32_t register_after_hits) const;
     size_t IdentityCacheSize() const;
+    // device-route statistics since construction: launches repeated after a wrong "everybody is registered" prediction, tuples whose
+    // certificate the device decoded itself, identities that entered the cache that way, signatures that took the general DER parser
+    void PassStats(uint64_t out[4]) const;
     // Starts the upload of a block on a helper thread (blocks of 4 MiB and more) so that it travels while the caller parses
     // and gates; join() returns the token for PreVerifyParsed (0 if nothing was staged).
     struct BlockUpload {
@@ -224,6 +229,8 @@ class GPUCSP {
     };
     mutable std::vector<IdTabEntry> idtab_host_;
     int SyncDeviceIdentityTable() const;
+    mutable std::atomic<uint64_t> pass_relaunches_{0}, pass_decoded_{0}, pass_learned_{0}, pass_general_der_{0};
+    void EvictIdentitiesLocked() const;
     void RegisterQueued(const std::vector<std::string>& to_register) const;
     void SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, const PassOptions& opt, std::vector<uint32_t>& sel_scratch, int gate_max) const;
     // verdict memo
@@ -268,6 +275,7 @@ class GPUCSP {
         // the device walk: envelope list, block-signature tuples, identity indices per tuple
         std::vector<uint32_t> env_spans, payload_spans, id_idx;
         std::vector<BlockTuple> block_sigs;
+        std::vector<WalkLearn> learn;              // identities the device decoded and offers to the cache
     };
     struct CoReqV : CoalescedBase {
         VerifyItem item;

@@ -34,40 +34,8 @@ int pb_one(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t
 // compatibility form for callers that only ask "is there exactly one": absent and ambiguous both answer false
 bool pb_bytes(const uint8_t* b, size_t n, uint32_t num, const uint8_t*& out, size_t& outlen) { return pb_one(b, n, num, out, outlen) == 1; }
 
-// ---- DER ------------------------------------------------------------------------------------------------------------------
-struct Der {
-    const uint8_t* p;
-    const uint8_t* end;
-    // reads one TLV header; on success tag / content / len describe it and p is advanced past the whole element
-    bool tlv(uint8_t& tag, const uint8_t*& content, size_t& len) {
-        if (end - p < 2) return false;
-        tag = *p++;
-        size_t l = *p++;
-        if (l & 0x80) {
-            int nb = (int)(l & 0x7F);
-            if (nb == 0 || nb > 4 || end - p < nb) return false;
-            l = 0;
-            for (int i = 0; i < nb; i++) l = (l << 8) | *p++;
-        }
-        if ((size_t)(end - p) < l) return false;
-        content = p;
-        len = l;
-        p += l;
-        return true;
-    }
-};
-
-const uint8_t OID_EC_PUBLIC_KEY[] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x02, 0x01};          // 1.2.840.10045.2.1
-const uint8_t OID_PRIME256V1[] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x03, 0x01, 0x07};       // 1.2.840.10045.3.1.7
-
-int b64val(uint8_t c) {
-    if (c >= 'A' && c <= 'Z') return c - 'A';
-    if (c >= 'a' && c <= 'z') return c - 'a' + 26;
-    if (c >= '0' && c <= '9') return c - '0' + 52;
-    if (c == '+') return 62;
-    if (c == '/') return 63;
-    return -1;
-}
+// ---- DER: block_walk_core.h (DerCursor, cert_der_p256_key_offset, pem_char_class - shared with the device's identity decoder) ----
+typedef walk::DerCursor Der;
 
 }  // namespace
 
@@ -83,11 +51,10 @@ bool PemToDer(const uint8_t* pem, size_t len, std::vector<uint8_t>& der) {
     uint32_t acc = 0;
     int bits = 0;
     for (; i < len; i++) {
-        uint8_t c = pem[i];
-        if (c == '-') break;
-        if (c == '=' || c == '\n' || c == '\r' || c == ' ' || c == '\t') continue;
-        int v = b64val(c);
-        if (v < 0) return false;
+        const int v = walk::pem_char_class(pem[i]);
+        if (v == walk::PEM_DASH) break;
+        if (v == walk::PEM_SKIP) continue;
+        if (v == walk::PEM_INVALID) return false;
         acc = (acc << 6) | (uint32_t)v;
         bits += 6;
         if (bits >= 8) {
@@ -100,31 +67,10 @@ bool PemToDer(const uint8_t* pem, size_t len, std::vector<uint8_t>& der) {
 }
 
 bool CertDerToP256(const uint8_t* der, size_t len, uint8_t qx[32], uint8_t qy[32]) {
-    Der top{der, der + len};
-    uint8_t tag;
-    const uint8_t* c;
-    size_t l;
-    if (!top.tlv(tag, c, l) || tag != 0x30) return false;             // Certificate
-    Der cert{c, c + l};
-    if (!cert.tlv(tag, c, l) || tag != 0x30) return false;            // TBSCertificate
-    Der tbs{c, c + l};
-    if (!tbs.tlv(tag, c, l)) return false;
-    if (tag == 0xA0) {                                                // [0] version (absent in v1 certificates)
-        if (!tbs.tlv(tag, c, l)) return false;
-    }
-    if (tag != 0x02) return false;                                    // serialNumber
-    for (int k = 0; k < 4; k++)                                       // signature, issuer, validity, subject
-        if (!tbs.tlv(tag, c, l) || tag != 0x30) return false;
-    if (!tbs.tlv(tag, c, l) || tag != 0x30) return false;             // subjectPublicKeyInfo
-    Der spki{c, c + l};
-    if (!spki.tlv(tag, c, l) || tag != 0x30) return false;            // AlgorithmIdentifier
-    Der alg{c, c + l};
-    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != sizeof(OID_EC_PUBLIC_KEY) || memcmp(c, OID_EC_PUBLIC_KEY, l) != 0) return false;
-    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != sizeof(OID_PRIME256V1) || memcmp(c, OID_PRIME256V1, l) != 0) return false;
-    if (!spki.tlv(tag, c, l) || tag != 0x03) return false;            // BIT STRING: 00 04 X Y
-    if (l != 66 || c[0] != 0x00 || c[1] != 0x04) return false;
-    memcpy(qx, c + 2, 32);
-    memcpy(qy, c + 34, 32);
+    const int32_t at = walk::cert_der_p256_key_offset(der, len);
+    if (at < 0) return false;
+    memcpy(qx, der + at, 32);
+    memcpy(qy, der + at + 32, 32);
     return true;
 }
 

@@ -420,6 +420,184 @@ WALK_HD inline uint8_t gate_sig_fast(const uint8_t* sig, uint32_t siglen, uint8_
     return GATE_SUBMIT;                                             // s == n/2 is low
 }
 
+// ---- the signature gate in general ---------------------------------------------------------------------------------------------
+// Everything gate_sig_fast declines, decided the way the reference decides it - so that no signature, however it is encoded, takes a
+// block off the device route (one crafted signature used to send a 10 000-transaction block to the host walk).  Restates, outcome
+// for outcome, bccsp/sw/ecdsa.go:41-57 up to the arithmetic:
+//   utils.UnmarshalECDSASignature (bccsp/utils/ecdsa.go:43-67): Go's asn1.Unmarshal into struct{R, S *big.Int} - identifier octet
+//     0x30 (a high-tag-number form never matches), DER length (short form, or long form that is minimal, without leading zero, below
+//     2^23 at every step, and present), content inside the input; two INTEGERs (identifier 0x02, same length rules, not empty,
+//     minimally encoded); bytes behind the second INTEGER inside the SEQUENCE and bytes behind the SEQUENCE are ignored (asn1's struct
+//     parser / the discarded `rest`); then R > 0 and S > 0                                              -> GATE_BAD_DER otherwise
+//   utils.IsLowS (bccsp/utils/ecdsa.go:84-92): S <= n/2                                                  -> GATE_HIGH_S otherwise
+//   ecdsa.Verify's range check: an R of more than 256 bits is >= n, (false, nil)                         -> GATE_RANGE
+//   else GATE_SUBMIT: R and S are the magnitudes at sig[pr, pr + lr) and sig[ps, ps + ls), lr, ls <= 32 (R < n is the device's check).
+// The host's general parser with Go's error TEXTS (bccsp_host.cpp UnmarshalECDSASignature) stays what single-signature callers get;
+// tests hold the two against each other on every shape (tests/test_device_walk.py).
+enum : uint8_t { GATE_BAD_DER = 4, GATE_RANGE = 5 };
+struct DerTL {
+    uint32_t len;
+    bool ok;
+};
+// Go asn1.go parseTagAndLength + parseField's identifier comparison for one expected identifier octet; off moves past the header
+WALK_HD inline DerTL gate_parse_tl(const uint8_t* b, uint32_t n, uint32_t& off, uint8_t want) {
+    DerTL r{0, false};
+    if (off >= n) return r;
+    const uint8_t id = b[off++];
+    if ((id & 0x1F) == 0x1F) return r;
+    if (off >= n) return r;
+    const uint8_t l0 = b[off++];
+    uint32_t L = l0;
+    if (l0 & 0x80) {
+        const uint32_t nb = l0 & 0x7F;
+        if (nb == 0) return r;                                       // indefinite length
+        L = 0;
+        for (uint32_t i = 0; i < nb; i++) {
+            if (off >= n) return r;
+            if (L >= (1u << 23)) return r;                           // "length too large"
+            L = (L << 8) | b[off++];
+            if (L == 0) return r;                                    // "superfluous leading zeros in length"
+        }
+        if (L < 0x80) return r;                                      // "non-minimal length"
+    }
+    if (id != want) return r;
+    if (L > n - off) return r;
+    r.len = L;
+    r.ok = true;
+    return r;
+}
+// one INTEGER of the SEQUENCE content b[0, n): sign (-1, 0, 1) and where its magnitude lies (positive values only)
+WALK_HD inline bool gate_parse_int(const uint8_t* b, uint32_t n, uint32_t& off, int& sign, uint32_t& mag_off, uint32_t& mag_len) {
+    if (off == n) return false;                                      // "sequence truncated"
+    const DerTL tl = gate_parse_tl(b, n, off, 0x02);
+    if (!tl.ok) return false;
+    const uint32_t p = off, L = tl.len;
+    off += L;
+    if (L == 0) return false;                                        // "empty integer"
+    if (L > 1 && ((b[p] == 0x00 && !(b[p + 1] & 0x80)) || (b[p] == 0xFF && (b[p + 1] & 0x80)))) return false;   // "not minimally-encoded"
+    if (b[p] & 0x80) {
+        sign = -1;
+        return true;
+    }
+    uint32_t z = 0;                                                  // a minimal non-negative INTEGER has at most one leading zero octet
+    while (z < L && b[p + z] == 0) z++;
+    sign = z == L ? 0 : 1;
+    mag_off = p + z;
+    mag_len = L - z;
+    return true;
+}
+WALK_HD inline uint8_t gate_sig_general(const uint8_t* sig, uint32_t siglen, uint32_t& pr, uint32_t& lr, uint32_t& ps, uint32_t& ls) {
+    const uint8_t HALF_N[32] = {0x7f, 0xff, 0xff, 0xff, 0x80, 0x00, 0x00, 0x00, 0x7f, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
+                                0xde, 0x73, 0x7d, 0x56, 0xd3, 0x8b, 0xcf, 0x42, 0x79, 0xdc, 0xe5, 0x61, 0x7e, 0x31, 0x92, 0xa8};
+    pr = lr = ps = ls = 0;
+    if (siglen == 0) return GATE_EMPTY;
+    uint32_t off = 0;
+    const DerTL seq = gate_parse_tl(sig, siglen, off, 0x30);
+    if (!seq.ok) return GATE_BAD_DER;
+    const uint8_t* in = sig + off;
+    uint32_t io = 0, ro = 0, rl = 0, so = 0, sl = 0;
+    int rsign = 0, ssign = 0;
+    if (!gate_parse_int(in, seq.len, io, rsign, ro, rl)) return GATE_BAD_DER;
+    if (!gate_parse_int(in, seq.len, io, ssign, so, sl)) return GATE_BAD_DER;
+    if (rsign != 1 || ssign != 1) return GATE_BAD_DER;               // "R / S must be larger than zero"
+    if (sl > 32) return GATE_HIGH_S;
+    for (uint32_t k = 0; k < 32; k++) {
+        const uint8_t v = k + sl >= 32 ? in[so + k + sl - 32] : 0;
+        if (v < HALF_N[k]) break;
+        if (v > HALF_N[k]) return GATE_HIGH_S;
+    }
+    if (rl > 32) return GATE_RANGE;
+    pr = off + ro; lr = rl; ps = off + so; ls = sl;
+    return GATE_SUBMIT;
+}
+// both gates as one answer (never GATE_DECLINED): what the device route's gate kernel computes per tuple, in lane form
+WALK_HD inline uint8_t gate_sig_any(const uint8_t* sig, uint32_t siglen, uint8_t* r32, uint8_t* s32) {
+    uint8_t g = gate_sig_fast(sig, siglen, r32, s32);
+    if (g != GATE_DECLINED) return g;
+    uint32_t pr, lr, ps, ls;
+    g = gate_sig_general(sig, siglen, pr, lr, ps, ls);
+    if (g == GATE_SUBMIT)
+        for (uint32_t k = 0; k < 32; k++) {
+            r32[k] = k + lr >= 32 ? sig[pr + k + lr - 32] : 0;
+            s32[k] = k + ls >= 32 ? sig[ps + k + ls - 32] : 0;
+        }
+    return g;
+}
+
+// ---- x509 certificate (DER) -> where its P-256 public key lies ---------------------------------------------------------------
+// Just enough DER to reach SubjectPublicKeyInfo (what msp/mspimpl.go:408-421 takes from x509.ParseCertificate): Certificate ->
+// TBSCertificate -> [0] version (optional), serialNumber, signature, issuer, validity, subject, subjectPublicKeyInfo{algorithm{
+// id-ecPublicKey, prime256v1}, BIT STRING 00 04 X Y}.  Returns the offset of X (Y follows) or -1.  One body of code for the host's
+// identity decoder (block_prepass.cpp CertDerToP256) and the device's (block_walk_kernels.hip, over the bytes a wavefront decoded
+// from the PEM into LDS).
+struct DerCursor {
+    const uint8_t* p;
+    const uint8_t* end;
+    // reads one TLV header; on success tag / content / len describe it and p is advanced past the whole element
+    WALK_HD bool tlv(uint8_t& tag, const uint8_t*& content, size_t& len) {
+        if (end - p < 2) return false;
+        tag = *p++;
+        size_t l = *p++;
+        if (l & 0x80) {
+            const int nb = (int)(l & 0x7F);
+            if (nb == 0 || nb > 4 || end - p < nb) return false;
+            l = 0;
+            for (int i = 0; i < nb; i++) l = (l << 8) | *p++;
+        }
+        if ((size_t)(end - p) < l) return false;
+        content = p;
+        len = l;
+        p += l;
+        return true;
+    }
+};
+WALK_HD inline bool der_bytes_equal(const uint8_t* a, const uint8_t* b, size_t n) {
+    bool same = true;
+    for (size_t i = 0; i < n; i++) same = same && a[i] == b[i];
+    return same;
+}
+WALK_HD inline int32_t cert_der_p256_key_offset(const uint8_t* der, size_t len) {
+    const uint8_t OID_EC_PUBLIC_KEY[7] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x02, 0x01};          // 1.2.840.10045.2.1
+    const uint8_t OID_PRIME256V1[8] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x03, 0x01, 0x07};       // 1.2.840.10045.3.1.7
+    DerCursor top{der, der + len};
+    uint8_t tag;
+    const uint8_t* c;
+    size_t l;
+    if (!top.tlv(tag, c, l) || tag != 0x30) return -1;             // Certificate
+    DerCursor cert{c, c + l};
+    if (!cert.tlv(tag, c, l) || tag != 0x30) return -1;            // TBSCertificate
+    DerCursor tbs{c, c + l};
+    if (!tbs.tlv(tag, c, l)) return -1;
+    if (tag == 0xA0) {                                             // [0] version (absent in v1 certificates)
+        if (!tbs.tlv(tag, c, l)) return -1;
+    }
+    if (tag != 0x02) return -1;                                    // serialNumber
+    for (int k = 0; k < 4; k++)                                    // signature, issuer, validity, subject
+        if (!tbs.tlv(tag, c, l) || tag != 0x30) return -1;
+    if (!tbs.tlv(tag, c, l) || tag != 0x30) return -1;             // subjectPublicKeyInfo
+    DerCursor spki{c, c + l};
+    if (!spki.tlv(tag, c, l) || tag != 0x30) return -1;            // AlgorithmIdentifier
+    DerCursor alg{c, c + l};
+    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != 7 || !der_bytes_equal(c, OID_EC_PUBLIC_KEY, 7)) return -1;
+    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != 8 || !der_bytes_equal(c, OID_PRIME256V1, 8)) return -1;
+    if (!spki.tlv(tag, c, l) || tag != 0x03) return -1;            // BIT STRING: 00 04 X Y
+    if (l != 66 || c[0] != 0x00 || c[1] != 0x04) return -1;
+    return (int32_t)(c + 2 - der);
+}
+// PEM text -> the class of one character, as PemToDer (block_prepass.cpp) reads the body of a certificate block: a base64 digit (its
+// value), something it skips ('=', line ends, blanks), the dash that ends the body, or a character that makes the block invalid
+enum : int { PEM_SKIP = 64, PEM_DASH = 65, PEM_INVALID = 66 };
+WALK_HD inline int pem_char_class(uint8_t c) {
+    if (c >= 'A' && c <= 'Z') return c - 'A';
+    if (c >= 'a' && c <= 'z') return c - 'a' + 26;
+    if (c >= '0' && c <= '9') return c - '0' + 52;
+    if (c == '+') return 62;
+    if (c == '/') return 63;
+    if (c == '-') return PEM_DASH;
+    if (c == '=' || c == '\n' || c == '\r' || c == ' ' || c == '\t') return PEM_SKIP;
+    return PEM_INVALID;
+}
+
 // ---- identity bytes -> 64-bit table hash ---------------------------------------------------------------------------------
 // The device looks identities up in a table of the ones the provider has met (block_walk_kernels.hip); the hash only picks the slot,
 // equality is always decided on ALL the bytes.  It covers the length and the last 64 bytes - for a certificate the end of its

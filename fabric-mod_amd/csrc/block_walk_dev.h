@@ -40,13 +40,32 @@ struct DevIdEntry {
 };
 static_assert(sizeof(DevIdEntry) == 88, "uploaded as raw bytes");
 
-// summary words the gate kernel accumulates (device -> host, one small copy)
+// summary words of one pass (gate, identity-decode and status kernels accumulate them; one small copy device -> host at the end)
 struct WalkSummary {
-    uint32_t n_unknown_identity;   // tuples whose identity is not in the device table: the host walk takes the block (and learns them)
-    uint32_t n_declined;           // signatures the fast gate declines: the host's general parser decides
+    uint32_t n_unknown_identity;   // tuples whose identity is not in the device table: the device decodes their certificates itself
+    uint32_t n_undecided;          // ... of which it could not decide (a PEM body beyond its buffer): the one case the host repairs
+    uint32_t n_outline_differs;    // creator messages that are not the span the host's outline named: this pass does not answer
     uint32_t n_submitted;          // non-zero: some tuple is for the device to decide (a flag, not a count)
-    uint32_t n_unkeyed;            // ... of which without a registered comb table (any: the fresh-key kernel serves the block)
+    uint32_t n_unkeyed_creator;    // submitted creator tuples without a registered comb table (any: the fresh-key kernel serves that launch)
+    uint32_t n_unkeyed_other;      // the same for endorsements and block signatures
+    uint32_t n_hashed_creator;     // tuples the device hashed and decided, by launch class (status kernel)
+    uint32_t n_hashed_other;
+    uint32_t n_learn;              // identities offered to the provider's cache in learn[] (distinct by table hash; may exceed WALK_LEARN_SLOTS)
+    uint32_t n_general_der;        // signatures that took the general DER parser (statistics)
+    uint32_t pad[2];
 };
+// An identity the device decoded and the provider may want in its cache (and, once it has been named often enough, with a comb table):
+// one slot per table hash, first come first served - a block offers at most WALK_LEARN_SLOTS new identities, whoever is left shows up
+// again in the next block if it matters.
+constexpr uint32_t WALK_LEARN_SLOTS = 128;
+struct WalkLearn {
+    uint64_t tag;                  // 0: empty; else the identity's table hash | 1
+    uint32_t off, len;             // the SerializedIdentity bytes in the block (valid once `ready` is set)
+    uint32_t ready;                // 1: qx, qy = its P-256 key; 2: a certificate without a P-256 key (identity.Verify needs bccsp/sw)
+    uint32_t hits;                 // tuples of this block that named it
+    uint8_t qx[32], qy[32];
+};
+static_assert(sizeof(WalkSummary) == 48 && sizeof(WalkLearn) == 88, "copied as raw bytes");
 
 struct WalkTotals {
     uint32_t tuples, prefixes, checks, creators;   // creators: envelopes that yield tuples (each yields exactly one creator tuple, its first)
@@ -83,6 +102,7 @@ struct WalkArrays {
     uint32_t* key_id = nullptr;
     uint8_t *qx = nullptr, *qy = nullptr, *r = nullptr, *s = nullptr;
     uint8_t* gate_st = nullptr;
+    WalkLearn* learn = nullptr;          // WALK_LEARN_SLOTS slots, zeroed per pass
     // Row of tuple i in the submission arrays.  Plain: row = i.  Split (a block of 32 769 .. 65 536 tuples): the creator tuples - long
     // messages (the whole envelope payload), no shared prefix - take rows [0, n_creators) and run as a launch of their own with two
     // lanes per signature, next to the endorsements' launch (rows n_creators ..) with one: the chip's 1024 SIMDs hold both.
@@ -102,6 +122,7 @@ struct WalkArrays {
     const uint8_t* dev_status = nullptr;       // by row
     const uint8_t* row_digests = nullptr;      // by row (null: not wanted)
     uint8_t* tuple_digests = nullptr;          // by tuple
+    uint8_t* tuple_qxy = nullptr;              // by tuple, 64 bytes: the key of a P-256 identity, zeros otherwise (null: not wanted)
     uint8_t* tuple_status = nullptr;
     uint8_t* tuple_hashed = nullptr;
     const uint8_t* gather_digests = nullptr;
@@ -112,6 +133,10 @@ struct WalkArrays {
 hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st);                       // counts, tx_type, tx_understood; then the scan
 hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st);   // tuples, prefixes, checks, gather spans / offsets
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);                        // identity lookup + gates + submission arrays + summary
+hipError_t launch_walk_idfix(const WalkArrays& a, hipStream_t st);                       // certificates of identities the table lacks -> keys
+// TEST HOOK: the device's identity decoder over n SerializedIdentity byte strings (spans = (start, end) pairs into arena) -> code
+// (0 P-256 key, 1 not such an identity, 2 undecided), key (64 bytes each, zero unless code == 0)
+hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st);
 hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st);
 hipError_t launch_walk_creator_digests(const WalkArrays& a, void* row_digests, hipStream_t st);   // digest_env -> the creators' digest rows
 // TEST HOOK: the wavefront form of the signature gate over n signatures (device pointers; spans = (start, end) pairs into arena)
@@ -134,7 +159,8 @@ struct WalkOut {
     uint8_t* tuple_status = nullptr;      // n_tuples
     uint8_t* tuple_hashed = nullptr;      // n_tuples
     bccsp::BlockTuple* tuples = nullptr;  // n_tuples
-    uint32_t* id_idx = nullptr;           // n_tuples: index into the entries of walk_idtab_set (the key of the tuple's identity)
+    uint32_t* id_idx = nullptr;           // n_tuples: index into the entries of walk_idtab_set; 0xFFFFFFFE: decoded by the device, 0xFFFFFFFF: none
+    uint8_t* tuple_qxy = nullptr;         // 64 n_tuples: key of a P-256 identity, zeros otherwise
     uint8_t* tuple_digest = nullptr;      // 32 n_tuples
     bccsp::Span* prefixes = nullptr;      // n_prefixes            (tests)
     bccsp::BlockHashCheck* checks = nullptr;   // n_checks         (tests)
@@ -153,15 +179,19 @@ struct WalkRequest {
     void* user = nullptr;
     bool (*sizes)(void* user, const WalkCounts& c, WalkOut& out) = nullptr;   // false: the caller has no room (FABGPU_ETOOBIG)
     // out
-    WalkSummary summary = {0, 0, 0, 0};
-    bool all_keyed = false;
+    WalkSummary summary = {};
+    bool keyed_creators = false, keyed_others = false;   // which launch classes ran on registered comb tables
+    uint32_t relaunched = 0;              // launches repeated because the prediction "everybody is registered" did not hold
+    WalkLearn* learn_out = nullptr;       // host, optional: WALK_LEARN_SLOTS records (tag == 0 or ready == 0: empty)
     const char* declined_why = "";
     double ms_walk = 0, ms_gate = 0, ms_verify = 0;
 };
 // FABGPU_OK, WALK_DECLINED, or a negative FABGPU_E*
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq);
 // TEST HOOK: the device's (wavefront) signature gate over n signatures = arena[spans[2i], spans[2i+1]) in host memory -> code (as
-// walk::gate_sig_fast), r, s (32 bytes each; zero unless code == GATE_SUBMIT)
+// walk::gate_sig_any), r, s (32 bytes each; zero unless code == GATE_SUBMIT)
 int walk_gate_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s);
+// TEST HOOK: the device's identity decoder over n identities in host memory -> code, key (64 bytes each)
+int walk_idfix_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* key);
 
 }  // namespace fab

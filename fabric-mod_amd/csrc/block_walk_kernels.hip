@@ -14,6 +14,7 @@
 #include "../../include/fabgpu.h"
 #include "block_prepass.h"
 #include "block_walk_dev.h"
+#include "p256_verify29.h"   // on_curve29: the curve-membership gate of a certificate key the device decodes itself
 
 namespace fab {
 
@@ -112,7 +113,7 @@ __constant__ uint8_t C_GXY[64] = {0x6b, 0x17, 0xd1, 0xf2, 0xe1, 0x2c, 0x42, 0x47
 // sits at an arbitrary byte offset: unaligned dword loads, which global memory serves).  Wave-uniform in, wave-uniform out.
 __device__ __forceinline__ uint32_t wave_identity_lookup(const WalkArrays& a, const Span id, uint32_t lane) {
     uint32_t found = 0xFFFFFFFFu;
-    if (a.id_mask == 0 || id.off > a.arena_len || id.len > a.arena_len - id.off) return found;
+    if (a.id_mask == 0 || a.id_slots == nullptr || id.off > a.arena_len || id.len > a.arena_len - id.off) return found;
     const uint8_t* p = a.block + id.off;
     const uint32_t m = id.len < 64 ? id.len : 64;
     uint64_t h = 0xCBF29CE484222325ull;
@@ -188,9 +189,116 @@ __device__ __forceinline__ uint8_t wave_gate_sig(const uint8_t* sig, uint32_t si
     return (gt & first) ? GATE_HIGH_S : GATE_SUBMIT;
 }
 
+// The gate for EVERY signature (block_walk_core.h gate_sig_any): the wavefront form above for the shape every signer produces, and -
+// for whatever it declines - the general parser, run identically by all lanes over the signature's bytes (rare, so its cost does not
+// matter; what matters is that no encoding takes the block off the device route).  Never returns GATE_DECLINED.
+__device__ __forceinline__ uint8_t wave_gate_sig_any(const uint8_t* sig, uint32_t siglen, uint32_t lane, uint32_t& field_byte) {
+    using namespace bccsp::walk;
+    uint8_t g = wave_gate_sig(sig, siglen, lane, field_byte);
+    if (g != GATE_DECLINED) return g;
+    uint32_t pr, lr, ps, ls;
+    g = gate_sig_general(sig, siglen, pr, lr, ps, ls);
+    field_byte = 0;
+    if (g == GATE_SUBMIT) {
+        const uint32_t k = lane & 31u, base = lane >= 32 ? ps : pr, L = lane >= 32 ? ls : lr;
+        field_byte = k + L >= 32 ? sig[base + k + L - 32] : 0u;
+    }
+    return g;
+}
+
+// ---- an identity nobody has met: SerializedIdentity -> PEM -> DER -> P-256 key, by one wavefront -----------------------------------
+// What the host's IdentityToP256 + PublicKeyOnCurve do (block_prepass.cpp; the reference: msp/mspimpl.go:408-421 getIdentityFromConf ->
+// pem.Decode, x509.ParseCertificate, the ECDSA public key), so that a block naming identities the provider has never seen - a busy
+// network has thousands of client certificates, msp/cache/cache.go keeps 100 - stays on the device route:
+//   1. msp.SerializedIdentity{1 mspid, 2 id_bytes}: exactly one field 2 (walk::pb_pick, the host's rule);
+//   2. the first "-----BEGIN CERTIFICATE-----" of id_bytes; every character behind it up to the next '-' is a base64 digit, skipped
+//      ('=', line ends, blanks) or fatal (PemToDer's classes, walk::pem_char_class) - a character per lane, 64-byte coalesced rows,
+//      digits compacted into LDS by ballot ranks; "-----END CERTIFICATE-----" must follow;
+//   3. 6-bit digits -> bytes, in place (byte j needs digits 4j/3 and 4j/3 + 1, which lie at or above j);
+//   4. walk::cert_der_p256_key_offset over those bytes - the host decoder's own lines;
+//   5. x, y < p and y^2 = x^3 - 3x + b (on_curve29).
+// IDC_P256: key_byte = this lane's byte of X || Y.  IDC_NOT / IDC_NOT_CERT: the host says "not a P-256 certificate identity" too
+// (bccsp/sw decides: other curves / no certificate block at all - idemix, garbage).  IDC_UNDECIDED: more base64 digits than the LDS buffer holds - the only case the host must repair.
+// Called by the 64 lanes of a one-wavefront workgroup (the __syncthreads are wave-local).
+constexpr uint32_t IDFIX_MAX_DIGITS = 4096;                             // 3 KiB of DER
+enum : uint8_t { IDC_P256 = 0, IDC_NOT = 1, IDC_UNDECIDED = 2, IDC_NOT_CERT = 3 };   // NOT_CERT: no PEM certificate block at all (idemix, garbage)
+__constant__ char C_PEM_BEGIN[28] = "-----BEGIN CERTIFICATE-----";
+__constant__ char C_PEM_END[26] = "-----END CERTIFICATE-----";
+
+__device__ uint8_t wave_identity_to_p256(const uint8_t* ident, uint32_t len, uint32_t lane, uint8_t* lds, uint32_t& key_byte) {
+    using namespace bccsp::walk;
+    key_byte = 0;
+    Pick w(2);
+    if (!pb_pick(ident, len, &w, 1) || w.seen != 1) return IDC_NOT_CERT;
+    const uint8_t* pem = w.p;
+    const uint32_t pl = (uint32_t)w.len;
+    // the first BEGIN marker (PemToDer scans for it)
+    uint32_t start = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base + 27 <= pl && start == 0xFFFFFFFFu; base += 64) {
+        const uint32_t pos = base + lane;
+        bool hit = pos + 27 <= pl && pem[pos] == '-';
+        if (hit)
+            for (uint32_t k = 1; k < 27; k++) hit = hit && pem[pos + k] == (uint8_t)C_PEM_BEGIN[k];
+        const uint64_t m = __ballot(hit);
+        if (m) start = base + (uint32_t)__builtin_ctzll(m) + 27;
+    }
+    if (start == 0xFFFFFFFFu) return IDC_NOT_CERT;
+    uint32_t total = 0, end_pos = 0xFFFFFFFFu;
+    for (uint32_t base = start; base < pl; base += 64) {
+        const uint32_t pos = base + lane;
+        const int cls = pos < pl ? pem_char_class(pem[pos]) : (int)PEM_SKIP;
+        const uint64_t dash = __ballot(cls == PEM_DASH);
+        const uint32_t limit = dash ? (uint32_t)__builtin_ctzll(dash) : 64u;
+        const bool act = lane < limit;
+        if (__ballot(act && cls == PEM_INVALID)) return IDC_NOT;
+        const bool digit = act && cls < 64;
+        const uint64_t dig = __ballot(digit);
+        const uint32_t rank = total + (uint32_t)__builtin_popcountll(dig & ((1ull << lane) - 1ull));
+        if (__ballot(digit && rank >= IDFIX_MAX_DIGITS)) return IDC_UNDECIDED;
+        if (digit) lds[rank] = (uint8_t)cls;
+        total += (uint32_t)__builtin_popcountll(dig);
+        if (dash) {
+            end_pos = base + limit;
+            break;
+        }
+    }
+    if (end_pos == 0xFFFFFFFFu || end_pos + 25 > pl) return IDC_NOT;
+    if (__ballot(lane < 25 && pem[end_pos + (lane < 25 ? lane : 0)] != (uint8_t)C_PEM_END[lane < 25 ? lane : 0])) return IDC_NOT;
+    const uint32_t nder = total * 6 / 8;
+    if (nder == 0) return IDC_NOT;
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < nder; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        uint32_t byte = 0;
+        if (j < nder) {
+            const uint32_t q = 4 * j / 3, sh = 4 - 2 * ((4 * j) % 3);       // bit 8j of the digit stream = bit (8j mod 6) of digit q
+            byte = ((((uint32_t)lds[q] << 6) | lds[q + 1]) >> sh) & 0xFFu;
+        }
+        __syncthreads();                                                 // (all of this row's digits are read before its bytes land on them)
+        if (j < nder) lds[j] = (uint8_t)byte;
+    }
+    __syncthreads();
+    const int32_t at = cert_der_p256_key_offset(lds, nder);
+    if (at < 0) return IDC_NOT;
+    u256 x, y;
+    from_be32(x, lds + at);
+    from_be32(y, lds + at + 32);
+    const u256 P = FAB_P256_P;
+    bool ok = lt256(x, P) & lt256(y, P);
+    fe mx, my;
+    fe_to_mont(mx, x);
+    fe_to_mont(my, y);
+    ok = ok & on_curve29(mx, my);
+    if (!ok) return IDC_NOT;
+    key_byte = lds[at + lane];
+    return IDC_P256;
+}
+
 // The identity, the gates of one tuple and its row of the submission arrays.  A tuple the device does not decide still gets a
-// well-formed row (r = s = 1 under the generator as key, like the host's fillers): there is no compaction and its verdict is ignored
-// in favour of gate_st.
+// well-formed row (r = s = 1; its identity's key, or the generator when there is none): there is no compaction and its verdict is
+// ignored in favour of gate_st.  An identity the table does not hold is NOT a reason to give the block up: the tuple is gated as if its
+// identity carried a P-256 key, and walk_idfix_kernel - next on the stream - decodes the certificate and fills the key in (or sets
+// TUPLE_ST_NEEDS_SW when there is none).
 __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -198,52 +306,53 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     const BlockTuple t = a.tuples[i];
     const uint32_t idx = wave_identity_lookup(a, t.identity, lane);
     // the row of this tuple (WalkArrays::row_of): creators first when the submission is split
+    const bool creator = i < a.n_dev_tuples && i == a.bases[t.tx].x;
     uint32_t row = i;
     if (a.split) {
         // creator tuples at indices <= i: those of the envelopes before this one, plus this envelope's (its first tuple)
         const uint32_t before = i < a.n_dev_tuples ? a.cbase[t.tx] : a.n_creators;
-        const bool creator = i < a.n_dev_tuples && i == a.bases[t.tx].x;
         row = creator ? before : a.n_creators + (i - before - (i < a.n_dev_tuples ? 1u : 0u));
     }
     const DevIdEntry* ent = idx != 0xFFFFFFFFu ? a.id_entries + idx : nullptr;
     uint8_t gst;
-    bool submit = false, unknown = false, declined = false;
+    bool submit = false, general = false;
     uint32_t field_byte = 0;
     // a creator's digest may have been computed from the host's outline of the envelope (WalkArrays::early_creator_hash): the
     // walker's own idea of that message must be the same bytes, or this pass does not answer
     bool outline_differs = false;
-    if (a.early_creator_hash && i < a.n_dev_tuples && i == a.bases[t.tx].x) {
+    if (a.early_creator_hash && creator) {
         const uint32_t p0 = a.payload_spans[2 * (size_t)t.tx], p1 = a.payload_spans[2 * (size_t)t.tx + 1];
         outline_differs = (t.suffix.len ? t.suffix.off : 0u) != p0 || (t.suffix.len ? t.suffix.off + t.suffix.len : 0u) != p1;
     }
-    if (outline_differs) {
-        declined = true;
-        gst = bccsp::TUPLE_ST_BAD_DER;
-    } else if (!ent) {
-        unknown = true;
-        gst = bccsp::TUPLE_ST_NEEDS_SW;                             // (the host walk takes the whole block when any tuple says this)
-    } else if (!ent->p256) {
+    if (ent && !ent->p256) {
         gst = bccsp::TUPLE_ST_NEEDS_SW;
     } else if (t.sig.len == 0) {
         gst = bccsp::TUPLE_ST_EMPTY_SIG;
     } else {
-        uint8_t g = bccsp::walk::GATE_DECLINED;
-        if (t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off) g = wave_gate_sig(a.block + t.sig.off, t.sig.len, lane, field_byte);
+        uint8_t g = bccsp::walk::GATE_BAD_DER;
+        if (t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off) {
+            g = wave_gate_sig(a.block + t.sig.off, t.sig.len, lane, field_byte);
+            if (g == bccsp::walk::GATE_DECLINED) {
+                general = true;
+                g = wave_gate_sig_any(a.block + t.sig.off, t.sig.len, lane, field_byte);
+            }
+        }
         if (g == bccsp::walk::GATE_SUBMIT) {
             gst = FABGPU_ST_VALID;
             submit = true;
         } else if (g == bccsp::walk::GATE_HIGH_S) {
             gst = FABGPU_ST_HIGH_S;
+        } else if (g == bccsp::walk::GATE_RANGE) {
+            gst = FABGPU_ST_RANGE;                                  // r of more than 256 bits: ecdsa.Verify's (false, nil)
         } else {
-            declined = true;
-            gst = bccsp::TUPLE_ST_BAD_DER;                          // (never reported: a declined signature sends the block to the host walk)
+            gst = bccsp::TUPLE_ST_BAD_DER;
         }
     }
-    const bool keyed = submit && ent->key_id >= 0;
+    const bool keyed = submit && ent && ent->key_id >= 0;
     // r | s and qx | qy: one byte per lane, 64-byte coalesced rows
     const uint32_t k = lane & 31u;
     const uint8_t rs = submit ? (uint8_t)field_byte : (uint8_t)(k == 31 ? 1 : 0);
-    const uint8_t q = submit ? (lane < 32 ? ent->qx[k] : ent->qy[k]) : C_GXY[lane];
+    const uint8_t q = (ent && ent->p256) ? (lane < 32 ? ent->qx[k] : ent->qy[k]) : C_GXY[lane];
     (lane < 32 ? a.r : a.s)[32 * (size_t)row + k] = rs;
     (lane < 32 ? a.qx : a.qy)[32 * (size_t)row + k] = q;
     if (lane == 0) {
@@ -255,11 +364,84 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         a.key_id[row] = keyed ? (uint32_t)ent->key_id : 0u;
         a.gate_st[i] = gst;
         // the summary: the rare events are counted, "somebody was submitted" is a flag (most waves find it set already)
-        if (unknown) atomicAdd(&a.summary->n_unknown_identity, 1u);
-        if (declined) atomicAdd(&a.summary->n_declined, 1u);
-        if (submit && !keyed) atomicAdd(&a.summary->n_unkeyed, 1u);
+        if (!ent) atomicAdd(&a.summary->n_unknown_identity, 1u);
+        if (outline_differs) atomicAdd(&a.summary->n_outline_differs, 1u);
+        if (general) atomicAdd(&a.summary->n_general_der, 1u);
+        if (submit && !keyed) {
+            // ("somebody of this class has no comb table" is all the host asks: one atomic per class is enough once it is known)
+            uint32_t* c = creator ? &a.summary->n_unkeyed_creator : &a.summary->n_unkeyed_other;
+            if (__builtin_nontemporal_load(c) == 0) atomicAdd(c, 1u);
+        }
         if (submit && __builtin_nontemporal_load(&a.summary->n_submitted) == 0) atomicOr(&a.summary->n_submitted, 1u);
     }
+}
+
+// One wavefront per tuple whose identity the table did not hold (everybody else leaves at once): decode the certificate, put the key
+// into the tuple's row, offer the identity to the provider's cache.
+__global__ void __launch_bounds__(64) walk_idfix_kernel(WalkArrays a) {
+    __shared__ uint8_t lds[IDFIX_MAX_DIGITS];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x;
+    if (i >= a.n_tuples || a.id_idx[i] != 0xFFFFFFFFu) return;
+    const BlockTuple t = a.tuples[i];
+    uint32_t key_byte = 0;
+    uint8_t code = IDC_NOT;
+    if (t.identity.off <= a.arena_len && t.identity.len <= a.arena_len - t.identity.off)
+        code = wave_identity_to_p256(a.block + t.identity.off, t.identity.len, lane, lds, key_byte);
+    if (code == IDC_P256) {
+        const uint32_t row = a.row_of[i];
+        (lane < 32 ? a.qx : a.qy)[32 * (size_t)row + (lane & 31u)] = (uint8_t)key_byte;
+        if (lane == 0) a.id_idx[i] = 0xFFFFFFFEu;
+    } else if (lane == 0) {
+        if (code == IDC_UNDECIDED) atomicAdd(&a.summary->n_undecided, 1u);
+        a.gate_st[i] = bccsp::TUPLE_ST_NEEDS_SW;
+    }
+    if (code == IDC_P256 || code == IDC_NOT) {
+        // Offer it to the provider's cache (the host route caches what it decodes, keys and "this certificate has no P-256 key" alike;
+        // identities without a certificate block - a fresh idemix pseudonym per transaction - would only churn it): one slot per table
+        // hash (the lookup's hash, recomputed from the same row of bytes); whoever names the same identity after the slot's owner counts
+        // as a hit - a comb table is earned by being named often.
+        const uint32_t m = t.identity.len < 64 ? t.identity.len : 64;
+        uint64_t h = 0xCBF29CE484222325ull;
+        if (lane < m) h = bccsp::walk::id_stream_fold(h, a.block[t.identity.off + t.identity.len - m + lane]);
+        uint64_t term = h * bccsp::walk::id_stream_const(lane);
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t lo32 = __shfl_xor((uint32_t)term, o, 64), hi32 = __shfl_xor((uint32_t)(term >> 32), o, 64);
+            term += ((uint64_t)hi32 << 32) | lo32;
+        }
+        const uint64_t tag = bccsp::walk::id_hash_finish(term, t.identity.len) | 1ull;
+        WalkLearn* slot = a.learn + ((uint32_t)(tag >> 17) & (WALK_LEARN_SLOTS - 1));
+        uint32_t mine = 0;
+        if (lane == 0) {
+            const unsigned long long old = atomicCAS((unsigned long long*)&slot->tag, 0ull, (unsigned long long)tag);
+            mine = old == 0ull ? 1u : 0u;
+            if (old == (unsigned long long)tag) atomicAdd(&slot->hits, 1u);
+        }
+        mine = __shfl(mine, 0, 64);
+        if (mine) {
+            (lane < 32 ? slot->qx : slot->qy)[lane & 31u] = (uint8_t)key_byte;
+            if (lane == 0) {
+                slot->off = t.identity.off;
+                slot->len = t.identity.len;
+                atomicAdd(&slot->hits, 1u);
+                __threadfence();
+                slot->ready = code == IDC_P256 ? 1u : 2u;
+                atomicAdd(&a.summary->n_learn, 1u);
+            }
+        }
+    }
+}
+
+// TEST HOOK: the identity decoder alone over n identities (spans into arena) -> code, key per identity
+__global__ void __launch_bounds__(64) walk_idfix_probe_kernel(uint32_t n, const uint8_t* __restrict__ arena, const uint32_t* __restrict__ spans,
+                                                              uint8_t* __restrict__ code, uint8_t* __restrict__ key) {
+    __shared__ uint8_t lds[IDFIX_MAX_DIGITS];
+    const uint32_t lane = threadIdx.x, i = blockIdx.x;
+    if (i >= n) return;
+    uint32_t kb = 0;
+    const uint8_t c = wave_identity_to_p256(arena + spans[2 * i], spans[2 * i + 1] - spans[2 * i], lane, lds, kb);
+    key[64 * (size_t)i + lane] = c == IDC_P256 ? (uint8_t)kb : 0;
+    if (lane == 0) code[i] = c == IDC_NOT_CERT ? (uint8_t)IDC_NOT : c;
 }
 
 // TEST HOOK: the wavefront gate alone over n signatures (spans into arena) -> code, r, s per signature
@@ -269,7 +451,7 @@ __global__ void __launch_bounds__(256) walk_gate_probe_kernel(uint32_t n, const 
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n) return;
     uint32_t fb = 0;
-    const uint8_t g = wave_gate_sig(arena + spans[2 * i], spans[2 * i + 1] - spans[2 * i], lane, fb);
+    const uint8_t g = wave_gate_sig_any(arena + spans[2 * i], spans[2 * i + 1] - spans[2 * i], lane, fb);
     (lane < 32 ? r : s)[32 * (size_t)i + (lane & 31u)] = g == bccsp::walk::GATE_SUBMIT ? (uint8_t)fb : 0;
     if (lane == 0) code[i] = g;
 }
@@ -290,30 +472,51 @@ enum : uint32_t { M_BAD_CREATOR = 1, M_BAD_END = 2, M_SW = 4, M_BAD_TXID = 8, M_
 
 __global__ void __launch_bounds__(256) walk_status_kernel(WalkArrays a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_tuples) return;
-    const uint8_t gst = a.gate_st[i];
-    const BlockTuple t = a.tuples[i];
-    uint8_t st = gst;
+    const bool live = i < a.n_tuples;
     uint8_t hashed = 0;
-    const uint32_t row = a.row_of[i];
-    if (a.row_digests) {
-        const uint4* src = reinterpret_cast<const uint4*>(a.row_digests + 32 * (size_t)row);
-        uint4* dst = reinterpret_cast<uint4*>(a.tuple_digests + 32 * (size_t)i);
-        dst[0] = src[0];
-        dst[1] = src[1];
+    bool creator = false;
+    if (live) {
+        const uint8_t gst = a.gate_st[i];
+        const BlockTuple t = a.tuples[i];
+        uint8_t st = gst;
+        const uint32_t row = a.row_of[i];
+        creator = i < a.n_dev_tuples && i == a.bases[t.tx].x;
+        if (a.row_digests) {
+            const uint4* src = reinterpret_cast<const uint4*>(a.row_digests + 32 * (size_t)row);
+            uint4* dst = reinterpret_cast<uint4*>(a.tuple_digests + 32 * (size_t)i);
+            dst[0] = src[0];
+            dst[1] = src[1];
+        }
+        if (a.tuple_qxy) {                                           // the key of the tuple's identity (zeros when it has no P-256 key)
+            const bool p256 = gst != bccsp::TUPLE_ST_NEEDS_SW;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const uint4* sx = reinterpret_cast<const uint4*>(a.qx + 32 * (size_t)row);
+            const uint4* sy = reinterpret_cast<const uint4*>(a.qy + 32 * (size_t)row);
+            uint4* dst = reinterpret_cast<uint4*>(a.tuple_qxy + 64 * (size_t)i);
+            dst[0] = p256 ? sx[0] : z;
+            dst[1] = p256 ? sx[1] : z;
+            dst[2] = p256 ? sy[0] : z;
+            dst[3] = p256 ? sy[1] : z;
+        }
+        if (gst == FABGPU_ST_VALID) {                                    // the device decided: exactly PreVerifyParsed's mapping
+            const bool in_c = a.split && row < a.n_creators;
+            const uint32_t j = in_c ? row : row - (a.split ? a.n_creators : 0u);
+            const bool bit = ((in_c ? a.verdict_bits_c : a.verdict_bits)[j >> 6] >> (j & 63)) & 1;
+            const uint8_t ds = a.dev_status[row];
+            st = (bit && ds == FABGPU_ST_VALID) ? FABGPU_ST_VALID : (ds == FABGPU_ST_VALID ? FABGPU_ST_BAD_MATH : ds);
+            hashed = 1;
+        }
+        a.tuple_status[i] = st;
+        a.tuple_hashed[i] = hashed;
+        if (st != FABGPU_ST_VALID && t.tx < a.n_env)                     // block-level tuples (orderer signatures) do not flag a transaction
+            atomicOr(&a.tx_mask[t.tx], st == bccsp::TUPLE_ST_NEEDS_SW ? M_SW : (t.kind == bccsp::TUPLE_CREATOR ? M_BAD_CREATOR : M_BAD_END));
     }
-    if (gst == FABGPU_ST_VALID) {                                    // the device decided: exactly PreVerifyParsed's mapping
-        const bool in_c = a.split && row < a.n_creators;
-        const uint32_t j = in_c ? row : row - (a.split ? a.n_creators : 0u);
-        const bool bit = ((in_c ? a.verdict_bits_c : a.verdict_bits)[j >> 6] >> (j & 63)) & 1;
-        const uint8_t ds = a.dev_status[row];
-        st = (bit && ds == FABGPU_ST_VALID) ? FABGPU_ST_VALID : (ds == FABGPU_ST_VALID ? FABGPU_ST_BAD_MATH : ds);
-        hashed = 1;
+    // how many tuples each launch class decided (the provider reports how many went through registered comb tables)
+    const uint64_t hc = __ballot(hashed && creator), ho = __ballot(hashed && !creator);
+    if ((threadIdx.x & 63u) == 0) {
+        if (hc) atomicAdd(&a.summary->n_hashed_creator, (uint32_t)__builtin_popcountll(hc));
+        if (ho) atomicAdd(&a.summary->n_hashed_other, (uint32_t)__builtin_popcountll(ho));
     }
-    a.tuple_status[i] = st;
-    a.tuple_hashed[i] = hashed;
-    if (st != FABGPU_ST_VALID && t.tx < a.n_env)                     // block-level tuples (orderer signatures) do not flag a transaction
-        atomicOr(&a.tx_mask[t.tx], st == bccsp::TUPLE_ST_NEEDS_SW ? M_SW : (t.kind == bccsp::TUPLE_CREATOR ? M_BAD_CREATOR : M_BAD_END));
 }
 
 // does the digest equal what the block says (block_prepass.cpp HashCheckMatches: lowercase hex for the TxID, raw bytes for the proposal hash)
@@ -373,6 +576,16 @@ hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st) {
     if (a.n_tuples == 0) return hipSuccess;
     hipLaunchKernelGGL(walk_gate_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);   // four wavefronts = four tuples per workgroup
+    return hipGetLastError();
+}
+hipError_t launch_walk_idfix(const WalkArrays& a, hipStream_t st) {
+    if (a.n_tuples == 0) return hipSuccess;
+    hipLaunchKernelGGL(walk_idfix_kernel, dim3(a.n_tuples), dim3(64), 0, st, a);                // one wavefront = one workgroup = one tuple
+    return hipGetLastError();
+}
+hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(walk_idfix_probe_kernel, dim3(n), dim3(64), 0, st, n, (const uint8_t*)arena, (const uint32_t*)spans, (uint8_t*)code, (uint8_t*)key);
     return hipGetLastError();
 }
 hipError_t launch_walk_creator_digests(const WalkArrays& a, void* row_digests, hipStream_t st) {

@@ -162,7 +162,10 @@ struct fabgpu_ctx {
     PinBuf walk_pin;
     void* d_idtab = nullptr;
     uint32_t idtab_n = 0, idtab_mask = 0;
-    bool idtab_all_keyed = false;    // every P-256 identity of the table has a comb table: whoever the device recognises is keyed
+    // Which verify kernels the pass queues BEFORE it knows what the gates found (one host round trip less): the keyed ones for a launch
+    // class (creators / everybody else) whose tuples all had comb tables in the previous pass, the fresh-key ones - always correct, the
+    // key travels in the row - otherwise.  A wrong "keyed" guess is repaired by launching that class again (walk_block_pass).
+    bool pred_keyed_creators = false, pred_keyed_others = false;
     size_t idtab_entries_off = 0, idtab_bytes_off = 0;
     std::mutex qmu;   // guards qws only (the host-pointer entry points call the _dev ones while holding mu)
     int acquire_qws(size_t bytes, size_t* idx, void** p, hipStream_t st);
@@ -1251,9 +1254,6 @@ int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const
     if (ctx->d_idtab) hipFree(ctx->d_idtab);
     ctx->d_idtab = d;
     ctx->idtab_n = n;
-    ctx->idtab_all_keyed = n != 0;
-    for (uint32_t i = 0; i < n; i++)
-        if (entries[i].p256 && entries[i].key_id < 0) ctx->idtab_all_keyed = false;
     ctx->idtab_mask = cap - 1;
     ctx->idtab_entries_off = eo;
     ctx->idtab_bytes_off = bo;
@@ -1286,6 +1286,31 @@ int walk_gate_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t ar
     return rc;
 }
 
+// TEST HOOK: the device's identity decoder (certificate -> P-256 key) over n identities held in host memory
+int walk_idfix_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* key) {
+    if (!ctx || (n && (!arena || !spans || !code || !key))) return FABGPU_EINVAL;
+    if (n == 0) return FABGPU_OK;
+    for (uint32_t i = 0; i < n; i++)
+        if (spans[2 * i + 1] < spans[2 * i] || spans[2 * i + 1] > arena_len) return FABGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    void *da = nullptr, *ds = nullptr, *dout = nullptr;
+    int rc = FABGPU_ENOMEM;
+    if (hipMalloc(&da, arena_len + 256) == hipSuccess && hipMalloc(&ds, (size_t)n * 8) == hipSuccess && hipMalloc(&dout, (size_t)n * 65) == hipSuccess) {
+        hipError_t e = hipMemcpy(da, arena, arena_len, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ds, spans, (size_t)n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_walk_idfix_probe(n, da, ds, (uint8_t*)dout + (size_t)n * 64, dout, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(key, dout, (size_t)n * 64, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(code, (uint8_t*)dout + (size_t)n * 64, n, hipMemcpyDeviceToHost);
+        rc = hip_to_rc(e);
+    }
+    if (da) hipFree(da);
+    if (ds) hipFree(ds);
+    if (dout) hipFree(dout);
+    return rc;
+}
+
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (!ctx || !rq.sizes || !rq.env_spans || rq.stage_token == 0) return FABGPU_EINVAL;
     if (rq.n_block_sigs && !rq.block_sigs) return FABGPU_EINVAL;
@@ -1307,7 +1332,6 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (has_tail && ((size_t)rq.tail_base < round_up(sl->len, 64) || (size_t)rq.tail_base + rq.tail_len + 128 > sl->cap)) return FABGPU_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->fault) return ctx->fault == 2 ? FABGPU_ENOMEM : FABGPU_ELAUNCH;
-    if (!rq.walk_only && (!ctx->d_idtab || ctx->idtab_n == 0)) return decline("no identity is known to the device yet");
     DeviceGuard g(ctx->device);
     hipStream_t st = ctx->stream;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1319,7 +1343,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     auto carve = [&](size_t bytes) { size_t at = o; o = round_up(o + bytes, 256); return at; };
     const size_t o_env = carve((size_t)ne * 8), o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_tot = carve(sizeof(WalkTotals)),
                  o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
-                 o_cbase = carve((size_t)ne * 4);
+                 o_cbase = carve((size_t)ne * 4), o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS);
     // The creators' messages are whole envelope payloads - the longest hashes of a block, a serial chain per message, and for a
     // block of a few hundred transactions THE critical path (300 tx: the chain is 240 us of a 600 us device phase).  With the host's
     // outline of where they are they start before anything is walked, beside the walk's two runs and the gates.
@@ -1346,6 +1370,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.tx_mask = (uint32_t*)(de + o_mask);
     a.tx_flags = de + o_flags;
     a.summary = (WalkSummary*)(de + o_sum);
+    a.learn = (WalkLearn*)(de + o_learn);
     memcpy((uint8_t*)ctx->walk_pin.h + p_env, rq.env_spans, (size_t)ne * 8);
     hipError_t err = hipMemcpyAsync(de + o_env, (uint8_t*)ctx->walk_pin.h + p_env, (size_t)ne * 8, hipMemcpyHostToDevice, st);
     bool s2_busy = false;
@@ -1375,6 +1400,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     }
     if (err == hipSuccess) err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
     if (err == hipSuccess) err = hipMemsetAsync(de + o_sum, 0, sizeof(WalkSummary), st);
+    if (err == hipSuccess) err = hipMemsetAsync(de + o_learn, 0, sizeof(WalkLearn) * WALK_LEARN_SLOTS, st);
     if (err == hipSuccess) err = launch_walk_count(a, st);
     if (err == hipSuccess) err = hipMemcpyAsync((uint8_t*)ctx->walk_pin.h + p_tot, de + o_tot, sizeof(WalkTotals), hipMemcpyDeviceToHost, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
@@ -1397,7 +1423,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_off = carve((size_t)nt * 8), o_pix = carve((size_t)nt * 4), o_kid = carve((size_t)nt * 4), o_qx = carve((size_t)nt * 32),
                  o_qy = carve((size_t)nt * 32), o_r = carve((size_t)nt * 32), o_s = carve((size_t)nt * 32), o_gst = carve(nt), o_bits = carve(words * 8),
                  o_dst = carve(nt), o_tst = carve(nt), o_hsh = carve(nt), o_dig = carve((size_t)nt * 32), o_mid = carve(((size_t)np + 1) * 32),
-                 o_row = carve((size_t)nt * 4), o_bitc = carve(words * 8), o_tdig = carve((size_t)nt * 32), o_cspan = carve(((size_t)tot.creators + 1) * 8);
+                 o_row = carve((size_t)nt * 4), o_bitc = carve(words * 8), o_tdig = carve((size_t)nt * 32), o_cspan = carve(((size_t)tot.creators + 1) * 8),
+                 o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
     a.tuples = (bccsp::BlockTuple*)(dt + o_tup);
@@ -1435,6 +1462,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.verdict_bits_c = (const uint64_t*)(dt + o_bitc);
     a.row_digests = out.tuple_digest ? dt + o_dig : nullptr;
     a.tuple_digests = dt + o_tdig;
+    a.tuple_qxy = out.tuple_qxy ? dt + o_tqxy : nullptr;
     a.dev_status = dt + o_dst;
     a.tuple_status = dt + o_tst;
     a.tuple_hashed = dt + o_hsh;
@@ -1449,7 +1477,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     auto pin = [&](size_t bytes) { size_t at = po; po = round_up(po + bytes, 64); return at; };
     const size_t p_flags = pin(ne), p_type = pin(ne), p_und = pin(ne), p_tst = pin(nt), p_hsh = pin(nt), p_tup = pin((size_t)nt * sizeof(bccsp::BlockTuple)),
                  p_idx = pin((size_t)nt * 4), p_dig = pin((size_t)nt * 32), p_pre = pin(((size_t)np + 1) * 8), p_chk = pin(((size_t)nc + 1) * sizeof(bccsp::BlockHashCheck)),
-                 p_sigs = pin((size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple) + 64);
+                 p_sigs = pin((size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple) + 64), p_qxy = pin(out.tuple_qxy ? (size_t)nt * 64 : 0),
+                 p_learn = pin(sizeof(WalkLearn) * WALK_LEARN_SLOTS);
     {
         // (growing the pinned buffer moves it: nothing above is still needed from the old one)
         if ((rc = ctx->walk_pin.ensure(po))) return rc;
@@ -1549,43 +1578,25 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
     }
     if (err == hipSuccess) err = launch_walk_gate(a, st);
-    if (err == hipSuccess) err = hipMemcpyAsync(ph + p_sum, de + o_sum, sizeof(WalkSummary), hipMemcpyDeviceToHost, st);
-    // What the gates found decides whether this pass may answer at all (an unknown identity, an odd signature: the host walk takes the
-    // block) and which kernels run (registered keys or keys carried along).  When every identity the device can recognise HAS a comb
-    // table the second question is settled in advance, and the first is asked after the fact: the launches are queued without waiting
-    // for the summary (one host round trip less) and their results are dropped if the summary says so.
-    const bool speculate = ctx->idtab_all_keyed;
-    auto judge = [&]() -> int {
-        rq.summary = *(const WalkSummary*)(ph + p_sum);
-        if (rq.summary.n_unknown_identity) return decline("an identity the device has not met");
-        if (rq.summary.n_declined) return decline("a signature outside the common DER shape");
-        if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
-        return FABGPU_OK;
-    };
-    if (!speculate) {
-        if (err == hipSuccess) err = hipStreamSynchronize(st);
-        if (err != hipSuccess) return hip_to_rc(err);
-        if ((rc = judge())) return rc;
-    }
+    if (err == hipSuccess) err = launch_walk_idfix(a, st);             // identities the table lacks: certificate -> key, on the device
     if (err != hipSuccess) return hip_to_rc(err);
+    // What the gates found decides which kernels SHOULD run per launch class - registered comb tables when every submitted tuple of the
+    // class has one, keys carried in the rows otherwise - and whether this pass may answer at all.  Neither is waited for: the launches
+    // are queued on a prediction (fabgpu_ctx::pred_keyed_*: what held for the previous block; "fresh keys" is always correct) and the
+    // summary is read once, at the very end; a class that was predicted "keyed" and was not is launched again.
     rq.ms_walk = ms_since(t_start);
-    rq.all_keyed = speculate || rq.summary.n_unkeyed == 0;
-    // ---- the fused launches over device-resident submission arrays ----
     const auto t_verify = now();
     pa.mid_ready = true;
     pa.digests = out.tuple_digest ? dt + o_dig : nullptr;
     uint32_t nkeys = 0;
     const int32_t** kt = nullptr;
-    if (rq.all_keyed) {
+    {
         std::lock_guard<std::mutex> klk(ctx->kmu);
         nkeys = (uint32_t)ctx->ktabs.size();
         kt = ctx->d_ktabs;
     }
-    // (a table without a single P-256 identity - ledger-harness identities, other curves - is "all keyed" vacuously and there is no
-    // comb table at all: the rows are fillers then, carried keys serve them, and the pass ends with "no tuple for the device to decide")
-    if (rq.all_keyed && nkeys == 0) rq.all_keyed = false;
-    // rows [row0, row0 + n) as one launch on stream `ls`
-    auto verify_rows = [&](uint32_t row0, uint32_t n, bool prefixed, bool pair, void* bits, hipStream_t ls) -> int {
+    // rows [row0, row0 + n) as one fused (hash + verify) launch on stream `ls`
+    auto verify_rows = [&](uint32_t row0, uint32_t n, bool prefixed, bool pair, bool keyed, void* bits, hipStream_t ls) -> int {
         ShaPrefixArgs p = pa;
         if (exclusive) p.lds_reserve = 84u << 10;                          // the two launches of a split submission on disjoint CUs (kernels.h)
         if (!prefixed) {
@@ -1597,7 +1608,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         }
         if (p.digests) p.digests = dt + o_dig + 32 * (size_t)row0;
         hipError_t e;
-        if (rq.all_keyed) {
+        if (keyed) {
             e = launch_sha256_p256_verify_keyed(n, sl->d, arena_bytes, a.off2 + 2 * (size_t)row0, a.key_id + row0, nkeys, (const void*)kt, a.r + 32 * (size_t)row0,
                                                 a.s + 32 * (size_t)row0, ctx->d_gtab, bits, dt + o_dst + row0, pair, p, ls);
         } else {
@@ -1611,46 +1622,94 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         }
         return hip_to_rc(e);
     };
+    // the creators of a split submission: rows [0, n_creators), digests ready (or about to be: same stream), arithmetic only
+    auto verify_creators = [&](bool keyed) -> int {
+        hipError_t e;
+        if (keyed) {
+            e = launch_p256_verify_keyed(tot.creators, a.key_id, nkeys, (const void*)kt, dt + o_dig, a.r, a.s, ctx->d_gtab, dt + o_bitc, dt + o_dst, true, s2, exclusive ? 84u << 10 : 0u);
+        } else {
+            size_t wi = 0;
+            void* wsp = nullptr;
+            int r2 = ctx->acquire_qws(verify_workspace_bytes(tot.creators, true), &wi, &wsp, s2);
+            if (r2 != FABGPU_OK) return r2;
+            e = launch_p256_verify(tot.creators, a.qx, a.qy, dt + o_dig, a.r, a.s, ctx->d_gtab, wsp, dt + o_bitc, dt + o_dst, true, s2, exclusive ? 84u << 10 : 0u);
+            ctx->release_qws(wi, s2);
+        }
+        return hip_to_rc(e);
+    };
+    bool keyed_c = ctx->pred_keyed_creators && nkeys != 0, keyed_o = ctx->pred_keyed_others && nkeys != 0;
+    if (!a.split) keyed_c = keyed_o = keyed_c && keyed_o;                  // one launch serves both classes
+    auto fetch_all = [&] {
+        fetch(out.tx_flags, p_flags, a.tx_flags, ne);
+        fetch(out.tx_type, p_type, a.tx_type, ne);
+        fetch(out.tx_understood, p_und, a.tx_understood, ne);
+        fetch(out.tuple_status, p_tst, a.tuple_status, nt);
+        fetch(out.tuple_hashed, p_hsh, a.tuple_hashed, nt);
+        fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
+        fetch(out.id_idx, p_idx, a.id_idx, (size_t)nt * 4);
+        fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
+        fetch(out.tuple_qxy, p_qxy, dt + o_tqxy, (size_t)nt * 64);
+        fetch(ph, p_learn, de + o_learn, sizeof(WalkLearn) * WALK_LEARN_SLOTS);
+        fetch(ph, p_sum, de + o_sum, sizeof(WalkSummary));
+    };
     if (np) err = hipStreamWaitEvent(st, ctx->ev_w[1], 0);               // the mid-states (long done: they ran beside the gates)
     if (err != hipSuccess) return hip_to_rc(err);
     if (a.split) {
-        // creators on stream2 (two lanes per signature), everybody else on the main stream (one lane): side by side
+        // creators on stream2 (two lanes per signature), everybody else on the main stream: side by side
         err = hipEventRecord(ctx->ev_w[3], st);                            // the submission arrays are complete
         if (err == hipSuccess) err = hipStreamWaitEvent(s2, ctx->ev_w[3], 0);
         if (err != hipSuccess) return hip_to_rc(err);
-        {   // rows [0, n_creators): digests are there (or about to be: same stream), keys by id or carried along
-            hipError_t e;
-            if (rq.all_keyed) {
-                e = launch_p256_verify_keyed(tot.creators, a.key_id, nkeys, (const void*)kt, dt + o_dig, a.r, a.s, ctx->d_gtab, dt + o_bitc, dt + o_dst, true, s2, exclusive ? 84u << 10 : 0u);
-            } else {
-                size_t wi = 0;
-                void* wsp = nullptr;
-                if ((rc = ctx->acquire_qws(verify_workspace_bytes(tot.creators, true), &wi, &wsp, s2))) return rc;
-                e = launch_p256_verify(tot.creators, a.qx, a.qy, dt + o_dig, a.r, a.s, ctx->d_gtab, wsp, dt + o_bitc, dt + o_dst, true, s2, exclusive ? 84u << 10 : 0u);
-                ctx->release_qws(wi, s2);
-            }
-            if (e != hipSuccess) return hip_to_rc(e);
-        }
+        if ((rc = verify_creators(keyed_c))) return rc;
         err = hipEventRecord(ctx->ev_w[4], s2);
         if (err != hipSuccess) return hip_to_rc(err);
-        if ((rc = verify_rows(tot.creators, nt - tot.creators, np != 0, both_pair, dt + o_bits, st))) return rc;
+        if ((rc = verify_rows(tot.creators, nt - tot.creators, np != 0, both_pair, keyed_o, dt + o_bits, st))) return rc;
         err = hipStreamWaitEvent(st, ctx->ev_w[4], 0);
     } else {
-        if ((rc = verify_rows(0, nt, np != 0, ctx->allow_pair, dt + o_bits, st))) return rc;
+        if ((rc = verify_rows(0, nt, np != 0, ctx->allow_pair, keyed_o, dt + o_bits, st))) return rc;
     }
     if (err == hipSuccess && nc) err = hipStreamWaitEvent(st, ctx->ev_w[2], 0);
     if (err == hipSuccess) err = launch_walk_flags(a, nc, st);
-    fetch(out.tx_flags, p_flags, a.tx_flags, ne);
-    fetch(out.tx_type, p_type, a.tx_type, ne);
-    fetch(out.tx_understood, p_und, a.tx_understood, ne);
-    fetch(out.tuple_status, p_tst, a.tuple_status, nt);
-    fetch(out.tuple_hashed, p_hsh, a.tuple_hashed, nt);
-    fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
-    fetch(out.id_idx, p_idx, a.id_idx, (size_t)nt * 4);
-    fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
+    fetch_all();
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err != hipSuccess) return hip_to_rc(err);
-    if (speculate && (rc = judge())) return rc;                             // (nothing was delivered)
+    rq.summary = *(const WalkSummary*)(ph + p_sum);
+    if (rq.summary.n_outline_differs) return decline("the walker's creator message is not the span the outline named");
+    if (rq.summary.n_undecided) return decline("a certificate beyond the device decoder's buffer");
+    if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
+    {
+        // Was "keyed" a wrong guess for a class?  Then its rows ran against filler tables: launch it again with the keys carried along
+        // (a new client's first block, an endorser's first 64 signatures: once per change of regime), and redo the flags.
+        const bool unk_c = rq.summary.n_unkeyed_creator != 0, unk_o = rq.summary.n_unkeyed_other != 0;
+        const bool redo_c = a.split ? (keyed_c && unk_c) : false, redo_o = a.split ? (keyed_o && unk_o) : (keyed_o && (unk_c || unk_o));
+        ctx->pred_keyed_creators = !unk_c;
+        ctx->pred_keyed_others = !unk_o;
+        if (redo_c || redo_o) {
+            rq.relaunched = (redo_c ? 1u : 0u) + (redo_o ? 1u : 0u);
+            if (redo_c) {
+                keyed_c = false;
+                if ((rc = verify_creators(false))) return rc;
+                err = hipEventRecord(ctx->ev_w[4], s2);
+                if (err == hipSuccess) err = hipStreamWaitEvent(st, ctx->ev_w[4], 0);
+                if (err != hipSuccess) return hip_to_rc(err);
+            }
+            if (redo_o) {
+                keyed_o = false;
+                if (!a.split) keyed_c = false;
+                if ((rc = a.split ? verify_rows(tot.creators, nt - tot.creators, np != 0, both_pair, false, dt + o_bits, st)
+                                  : verify_rows(0, nt, np != 0, ctx->allow_pair, false, dt + o_bits, st)))
+                    return rc;
+            }
+            err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
+            if (err == hipSuccess) err = hipMemsetAsync(&a.summary->n_hashed_creator, 0, 8, st);
+            if (err == hipSuccess) err = launch_walk_flags(a, nc, st);
+            fetch_all();
+            if (err == hipSuccess) err = hipStreamSynchronize(st);
+            if (err != hipSuccess) return hip_to_rc(err);
+            rq.summary = *(const WalkSummary*)(ph + p_sum);
+        }
+    }
+    rq.keyed_creators = keyed_c;
+    rq.keyed_others = keyed_o;
     rq.ms_verify = ms_since(t_verify);
     deliver(out.tx_flags, p_flags, ne);
     deliver(out.tx_type, p_type, ne);
@@ -1660,6 +1719,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     deliver(out.tuples, p_tup, (size_t)nt * sizeof(bccsp::BlockTuple));
     deliver(out.id_idx, p_idx, (size_t)nt * 4);
     deliver(out.tuple_digest, p_dig, (size_t)nt * 32);
+    deliver(out.tuple_qxy, p_qxy, (size_t)nt * 64);
+    deliver(rq.learn_out, p_learn, sizeof(WalkLearn) * WALK_LEARN_SLOTS);
     return FABGPU_OK;
 }
 

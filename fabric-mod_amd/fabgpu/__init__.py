@@ -69,7 +69,7 @@ class _BlockPass(ctypes.Structure):
                 ("tx_flags", ctypes.c_void_p), ("tx_type", ctypes.c_void_p), ("tuple_tx", ctypes.c_void_p), ("tuple_kind", ctypes.c_void_p),
                 ("tuple_status", ctypes.c_void_p), ("tuple_spans", ctypes.c_void_p), ("tuple_digest", ctypes.c_void_p),
                 ("tuple_hashed", ctypes.c_void_p), ("tuple_qxy", ctypes.c_void_p), ("tail", ctypes.c_void_p), ("tail_cap", ctypes.c_uint32),
-                ("n_keyed", ctypes.c_uint32)]
+                ("n_keyed", ctypes.c_uint32), ("n_device_decoded", ctypes.c_uint32)]
 
 
 class _Cfg(ctypes.Structure):
@@ -99,6 +99,7 @@ ABI_SYMBOLS = [
     "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
     "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev",
     "fabgpu_csp_pass_routes", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast", "fabgpu_identity_table_hash", "fabgpu_csp_gate_probe",
+    "fabgpu_gate_sig_any", "fabgpu_identity_to_p256", "fabgpu_csp_idfix_probe", "fabgpu_csp_pass_stats",
 ]
 
 _lib = None
@@ -183,6 +184,10 @@ def load():
     L.fabgpu_block_walk_twopass_compare.argtypes = [_u8p, _sz, ctypes.c_char_p, _sz]
     L.fabgpu_gate_sig_fast.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_csp_gate_probe.argtypes = [_vp, ctypes.c_uint32, _u8p, _sz, _u32p, _u8p, _u8p, _u8p]
+    L.fabgpu_gate_sig_any.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
+    L.fabgpu_identity_to_p256.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p]
+    L.fabgpu_csp_pass_stats.argtypes = [_vp, _u64p]
+    L.fabgpu_csp_idfix_probe.argtypes = [_vp, ctypes.c_uint32, _u8p, _sz, _u32p, _u8p, _u8p]
     L.fabgpu_identity_table_hash.argtypes = [ctypes.c_char_p, _sz]
     L.fabgpu_identity_table_hash.restype = ctypes.c_uint64
     L.fabgpu_csp_x509_check_signature_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p, _u8p, _u8p]
@@ -848,7 +853,16 @@ def pass_routes(csp: "GPUCSP"):
     d, h = ctypes.c_uint64(0), ctypes.c_uint64(0)
     why = ctypes.create_string_buffer(256)
     _check(csp._L.fabgpu_csp_pass_routes(csp._h, ctypes.byref(d), ctypes.byref(h), why, 256), "fabgpu_csp_pass_routes")
-    return dict(device_walks=d.value, host_walks=h.value, last_decline=why.value.decode(errors="replace"))
+    st = (ctypes.c_uint64 * 4)()
+    _check(csp._L.fabgpu_csp_pass_stats(csp._h, st), "fabgpu_csp_pass_stats")
+    return dict(device_walks=d.value, host_walks=h.value, last_decline=why.value.decode(errors="replace"), relaunches=st[0], device_decoded=st[1],
+                learned=st[2], general_der=st[3])
+
+
+def identity_cache_size(csp: "GPUCSP") -> int:
+    n = ctypes.c_uint64(0)
+    _check(csp._L.fabgpu_csp_identity_cache_size(csp._h, ctypes.byref(n)), "fabgpu_csp_identity_cache_size")
+    return n.value
 
 
 def block_walk_compare(csp: "GPUCSP", block: bytes):
@@ -878,6 +892,33 @@ def gate_sig_fast(sig: bytes):
     r, s2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
     code = load().fabgpu_gate_sig_fast(sig, len(sig), r, s2)
     return code, r.raw, s2.raw
+
+
+def gate_sig_any(sig: bytes):
+    """TEST HOOK (pure host): the gate the device route applies to every signature -> (code, r32, s32); code 0 submit, 1 high-S, 2 empty,
+    4 does not unmarshal / r, s <= 0, 5 r of more than 256 bits."""
+    r, s2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    code = load().fabgpu_gate_sig_any(sig, len(sig), r, s2)
+    return code, r.raw, s2.raw
+
+
+def identity_to_p256(ident: bytes):
+    """Pure host: the P-256 key (64 bytes) the host route reads out of a SerializedIdentity, or None."""
+    q = ctypes.create_string_buffer(64)
+    return q.raw if load().fabgpu_identity_to_p256(ident, len(ident), q) == 0 else None
+
+
+def idfix_probe(csp: "GPUCSP", idents: Sequence[bytes]):
+    """TEST HOOK (device): the device route's identity decoder over many identities -> (codes, keys (n x 64))."""
+    n = len(idents)
+    arena = np.frombuffer(b"".join(idents) + b"\0" * 8, dtype=np.uint8)
+    ends = np.cumsum([len(x) for x in idents], dtype=np.int64)
+    spans = np.zeros((n, 2), dtype=np.uint32)
+    spans[:, 1] = ends
+    spans[1:, 0] = ends[:-1]
+    code, key = np.zeros(n, np.uint8), np.zeros((n, 64), np.uint8)
+    _check(csp._L.fabgpu_csp_idfix_probe(csp._h, n, _p8(arena), arena.size, spans.ctypes.data_as(_u32p), _p8(code), _p8(key)), "fabgpu_csp_idfix_probe")
+    return code, key
 
 
 def gate_probe(csp: "GPUCSP", sigs: Sequence[bytes]):
@@ -944,7 +985,8 @@ def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo:
                 csp._pass_caps = (cap_tx, cap_tu)
                 continue
             _check(rc, "fabgpu_csp_block_preverify2")
-            return dict(tx_flags=flags[:ps.n_tx], n_tuples=ps.n_tuples, n_block_sigs=ps.n_block_sigs, memo_seeded=ps.memo_seeded, n_keyed=ps.n_keyed)
+            return dict(tx_flags=flags[:ps.n_tx], n_tuples=ps.n_tuples, n_block_sigs=ps.n_block_sigs, memo_seeded=ps.memo_seeded, n_keyed=ps.n_keyed,
+                        n_device_decoded=ps.n_device_decoded)
     cap_tx, cap_tu = getattr(csp, "_pass_caps", (1024, 4096))
     tail_cap = 1 << 16
     while True:
@@ -967,7 +1009,7 @@ def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo:
         nt, nu = ps.n_tx, ps.n_tuples
         out = {k: (v[:nt].copy() if k.startswith("tx_") else v[:nu].copy()) for k, v in a.items() if k != "tail"}
         out.update(n_block_sigs=ps.n_block_sigs, block_sigs_understood=bool(ps.block_sigs_understood), memo_seeded=ps.memo_seeded, n_keyed=ps.n_keyed,
-                   arena=bytes(block) + b"\0" * (ps.tail_base - len(block)) + bytes(a["tail"][:ps.tail_len]))
+                   n_device_decoded=ps.n_device_decoded, arena=bytes(block) + b"\0" * (ps.tail_base - len(block)) + bytes(a["tail"][:ps.tail_len]))
         return out
 
 

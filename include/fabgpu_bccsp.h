@@ -117,9 +117,13 @@ typedef struct fabgpu_block_pass {
     uint8_t* tuple_qxy;          /* cap_tuples x 64 */
     uint8_t* tail;               /* tail_cap bytes: the block-signature messages (optional) */
     uint32_t tail_cap;
-    /* out: submitted tuples that went through per-key device tables (all of them, or none: one identity without a table sends the
-     * block down the fresh-key kernel) */
+    /* out: submitted tuples that went through per-key device tables.  Host walk: all of them, or none (one identity without a table
+     * sends the block down the fresh-key kernel).  Device walk: per launch class - the creators' launch and the launch of everybody
+     * else each take the tables when every one of their submitted tuples has one. */
     uint32_t n_keyed;
+    /* out (ABI v5), device walk: tuples whose identity the provider had never met - their certificates were decoded on the device
+     * (msp/mspimpl.go:408-421 deserialization: PEM, x509 SubjectPublicKeyInfo, curve membership) and offered to its identity cache */
+    uint32_t n_device_decoded;
 } fabgpu_block_pass;
 int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* pass);
 /* 0: hit, *status = 0 valid / 1 arithmetic reject / 2 high-S / 3 r out of range (the reference rejects: ask bccsp/sw for its error
@@ -133,12 +137,18 @@ int fabgpu_csp_memo_set_capacity(fabgpu_csp* csp, uint64_t max_entries);
  * msp/cache), a device comb table only for an identity named register_after_hits times, at most max_registered_keys tables. */
 int fabgpu_csp_identity_cache_limits(fabgpu_csp* csp, uint64_t max_identities, uint64_t max_registered_keys, uint32_t register_after_hits);
 int fabgpu_csp_identity_cache_size(fabgpu_csp* csp, uint64_t* identities);
-/* Both forms of the pass walk a staged block (4 MiB and more) ON THE DEVICE when every identity it names is already in the provider's
- * cache and every signature has the common DER shape (envelope walk, signature gates, identity lookup, submission arrays, digest
- * comparisons and flags as kernels; block_walk_dev.h) and on the host otherwise (which is also how new identities are learned): same
- * answers either way.  FABGPU_PASS_DEVICE_WALK=0 keeps every block on the host walk.  This reports how many passes went which way and
- * why the last block was declined by the device walk. */
+/* Both forms of the pass walk a staged block ON THE DEVICE (envelope walk, signature gates - every DER encoding, decided as
+ * bccsp/utils/ecdsa.go:43-92 decides it -, identity lookup, certificates of identities nobody has met decoded by a wavefront each,
+ * submission arrays, digest comparisons and flags as kernels; block_walk_dev.h).  The host walk answers what is left: blocks that were
+ * not staged, blocks on a provider with idemix MSPs, a certificate longer than the device decoder's buffer (3 KiB of DER), a block
+ * without any signature for the device to decide.  Same answers either way.  FABGPU_PASS_DEVICE_WALK=0 keeps every block on the host
+ * walk.  This reports how many passes went which way and why the last block was declined by the device walk. */
 int fabgpu_csp_pass_routes(fabgpu_csp* csp, uint64_t* device_walks, uint64_t* host_walks, char* last_decline, size_t cap);
+/* Device-route statistics since the provider was made: out4[0] verify launches repeated because the prediction "every signer of this
+ * launch class has a comb table" (taken from the previous block, so that nothing waits for the gates) did not hold, [1] tuples whose
+ * identity was not in the device's table (certificate decoded on the device), [2] identities that entered the cache that way,
+ * [3] signatures outside the common DER shape (decided by the general parser, on the device). */
+int fabgpu_csp_pass_stats(fabgpu_csp* csp, uint64_t* out4);
 /* TEST HOOK: the device walker against the host walker on one block, record for record.  0 identical (*declined = 1: the device walk
  * declined the block, `diff` says why), 1 they differ (`diff` says where). */
 int fabgpu_csp_block_walk_compare(fabgpu_csp* csp, const uint8_t* block, size_t len, int* declined, char* diff, size_t cap);
@@ -147,6 +157,14 @@ int fabgpu_csp_block_walk_compare(fabgpu_csp* csp, const uint8_t* block, size_t 
  * 1 high-S, 2 empty, 3 declined: the general parser decides); the identity-table hash. */
 int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* diff, size_t cap);
 int fabgpu_gate_sig_fast(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32);
+/* ... and the gate the device route applies to every signature (the fast gate, then the general parser for what that declines):
+ * 0 submit (r32 / s32 set), 1 high-S, 2 empty, 4 does not unmarshal or r, s <= 0, 5 r of more than 256 bits ((false, nil)) */
+int fabgpu_gate_sig_any(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32);
+/* what the host route makes of a SerializedIdentity: 0 = PEM x509 certificate with an on-curve P-256 key (qxy64 = X || Y), 1 = anything else */
+int fabgpu_identity_to_p256(const uint8_t* ident, size_t len, uint8_t* qxy64);
+/* TEST HOOK (device): the device route's identity decoder (one wavefront per identity) over n identities = arena[spans[2i], spans[2i+1]):
+ * code 0 P-256 key (key[64 i ..] = X || Y), 1 not such an identity, 2 undecided (left to the host) */
+int fabgpu_csp_idfix_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* key);
 /* TEST HOOK (device): the same gate in the wavefront form the kernels run, over n signatures = arena[spans[2i], spans[2i+1]) */
 int fabgpu_csp_gate_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s);
 uint64_t fabgpu_identity_table_hash(const uint8_t* p, size_t len);

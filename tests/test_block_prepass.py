@@ -154,7 +154,8 @@ def test_block_walker_on_synthetic_blocks():
 
 
 @pytest.mark.gpu
-def test_preverify_pass_end_to_end():
+def test_preverify_pass_end_to_end(monkeypatch):
+    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))         # the pass with the walk on the HOST (the device route: test_device_walk.py)
     csp = fabgpu.GPUCSP(device=0)
     rng = np.random.default_rng(6)
     blk, want = build_block(220, rng)
@@ -179,9 +180,11 @@ def test_preverify_pass_end_to_end():
 
 
 @pytest.mark.gpu
-def test_preverify_pass_with_known_and_new_identities():
+def test_preverify_pass_with_known_and_new_identities(monkeypatch):
     """A block signed by identities of which only some have a device table (newcomers among known ones): the answer does not depend
-    on which path - per-key tables or keys carried along - the tuples took."""
+    on which path - per-key tables or keys carried along - the tuples took.  (Host walk: one launch for the whole block, so "some" means
+    the fresh-key kernel for everybody; the device route decides per launch class, test_device_walk.py.)"""
+    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
     csp = fabgpu.GPUCSP(device=0)
     L = csp._L
     before = csp.key_count()

@@ -149,6 +149,147 @@ def test_device_signature_gate_equals_the_general_parser():
     assert n_submit > 1500 and n_high > 300 and n_declined > 100, (n_submit, n_high, n_declined)
 
 
+def _long_len(n: int) -> bytes:
+    if n < 128:
+        return bytes([n])
+    b = n.to_bytes((n.bit_length() + 7) // 8, "big")
+    return bytes([0x80 | len(b)]) + b
+
+
+def _der(tag: int, content: bytes) -> bytes:
+    return bytes([tag]) + _long_len(len(content)) + content
+
+
+def _general_gate_cases():
+    """encodings only the general parser decides: long-form lengths where DER demands them (integers of 128+ bytes), trailing bytes
+    inside and behind the SEQUENCE, negative / zero / non-minimal integers, non-minimal and indefinite lengths, foreign tags,
+    truncations - and what a signer produces, for good measure"""
+    rng = np.random.default_rng(17)
+    half = po.N >> 1
+    out = [c for c, _ in _gate_cases()]
+    ints = [b"\x01", b"\x7f", b"\x00\x80", b"\x00" + b"\xff" * 32, b"\x01" + b"\x00" * 32, b"\x7f" * 40, b"\x00" + b"\x80" * 127, b"\x01" * 128,
+            b"\x01" * 200, b"\x00" + b"\xff" * 300, b"\x80", b"\xff\x7f", b"\x00", b"\x00\x01", b"\xff\xff", b"", half.to_bytes(32, "big"),
+            (half + 1).to_bytes(32, "big"), b"\x00" + (po.N - 1).to_bytes(32, "big"), b"\x00" * 2 + b"\x80"]
+    for r in ints:
+        for s_ in ints:
+            body = _der(2, r) + _der(2, s_)
+            out.append(_der(0x30, body))
+            out.append(_der(0x30, body) + b"\x05\x00")                       # behind the SEQUENCE: `rest`, discarded
+            out.append(_der(0x30, body + b"\x02\x01\x07"))                   # a third element inside: allowed by asn1's struct parser
+    good = po.marshal_ecdsa_signature(0x1234 << 200, 0x77 << 100)
+    body = good[2:]
+    out += [b"\x30\x81" + bytes([len(body)]) + body,                         # non-minimal long form
+            b"\x30\x82\x00" + bytes([len(body)]) + body,                      # leading zero in the length
+            b"\x30\x80" + body + b"\x00\x00",                                # indefinite
+            b"\x30\x84\x00\x00\x00" + bytes([len(body)]) + body,
+            b"\x30\x85\x01\x00\x00\x00\x00" + body,                         # length too large
+            b"\x3f\x30" + bytes([len(body)]) + body,                          # high-tag-number form
+            b"\x10" + bytes([len(body)]) + body,                              # SEQUENCE without the constructed bit
+            b"\x30" + bytes([len(body) + 1]) + body,                          # content beyond the input
+            b"\x30\x04\x02\x02\x00\x01", b"\x30\x02\x02\x00", b"\x30\x03\x02\x81\x00", b"\x30\x04\x02\x01\x01\x02", b"\x30\x05\x02\x01\x01\x02\x01",
+            b"\x30\x06\x02\x01\x01\x04\x01\x01", b"\x30\x06\x04\x01\x01\x02\x01\x01"]
+    big = _der(0x30, _der(2, b"\x01" * 200) + _der(2, b"\x01"))
+    base = np.frombuffer(big, dtype=np.uint8)
+    for _ in range(1500):                                                    # mutants of a long-form signature
+        m = base.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            m[int(rng.integers(0, min(m.size, 12) if rng.integers(0, 2) else m.size))] = np.uint8(rng.integers(0, 256))
+        if rng.integers(0, 8) == 0:
+            m = m[: m.size - int(rng.integers(1, 5))]
+        out.append(m.tobytes())
+    return out
+
+
+def _reference_gate(sig: bytes):
+    """the any-gate's answer derived from the PYTHON oracle (oracle/bccsp_sw_oracle.py: Go's asn1 + bccsp/utils restated independently of
+    the C++ in this tree): (code, r, s)"""
+    if not sig:
+        return 2, None, None
+    try:
+        r, s_ = po.unmarshal_ecdsa_signature(sig)
+    except Exception:   # noqa: BLE001  (ASN1Error / BCCSPError: does not unmarshal, or r, s <= 0)
+        return 4, None, None
+    if not po.is_low_s(s_):
+        return 1, None, None
+    if r >> 256:
+        return 5, None, None
+    return 0, r, s_
+
+
+def test_general_signature_gate_equals_both_general_parsers():
+    """gate_sig_any - what the device route applies to EVERY signature, so that no encoding takes a block off the device - against
+    the C++ general parser (UnmarshalECDSASignature + IsLowS, Go's error texts) and against the independent Python oracle, on every
+    shape: nothing is declined any more, and every outcome (submit with these r, s / high-S / does not unmarshal / r beyond 256 bits)
+    is the reference's (bccsp/sw/ecdsa.go:41-57 up to the arithmetic)."""
+    seen = {0: 0, 1: 0, 2: 0, 4: 0, 5: 0}
+    for sig in _general_gate_cases():
+        code, r32, s32 = fabgpu.gate_sig_any(sig)
+        want, wr, ws = _reference_gate(sig)
+        assert code == want, (sig.hex(), code, want)
+        if code == 0:
+            assert int.from_bytes(r32, "big") == wr and int.from_bytes(s32, "big") == ws, sig.hex()
+        if sig:
+            rc, gr, gs, flags = fabgpu.unmarshal_ecdsa_signature(sig)
+            mine = 4 if rc != 0 else (1 if (flags & 2) or not fabgpu.is_low_s(gs) else (5 if flags & 1 else 0))
+            assert code == mine, (sig.hex(), code, mine)
+            if code == 0:
+                assert (gr, gs) == (r32, s32)
+        seen[code] += 1
+    assert seen[0] > 1500 and seen[1] > 300 and seen[4] > 500 and seen[5] > 20 and seen[2] >= 1, seen
+
+
+def _identity_cases():
+    """SerializedIdentity byte strings for the identity decoder: every certificate fixture of the reference (P-256, P-384, RSA ...),
+    their PEM re-wrapped in other layouts, mutants, and things that are not certificates at all"""
+    rng = np.random.default_rng(23)
+    chains = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_cert_chains.json")))
+    ders = [base64.b64decode(v) for _, v in sorted(chains["certs"].items())]
+    out = []
+
+    def pem(der, width=64, eol=b"\n", head=b"-----BEGIN CERTIFICATE-----", tail=b"-----END CERTIFICATE-----", trailer=b"\n"):
+        b = base64.b64encode(der)
+        lines = [b[i:i + width] for i in range(0, len(b), width)]
+        return head + eol + eol.join(lines) + eol + tail + trailer
+    class _B:   # blockbuilder.serialized_identity takes text; these armours are bytes (and not always text)
+        @staticmethod
+        def serialized_identity(mspid, pem_bytes):
+            return bb.fbytes(1, mspid.encode()) + bb.fbytes(2, pem_bytes)
+    sid = _B.serialized_identity
+    for d in ders:
+        out.append(sid("Org1MSP", pem(d)))
+    for d in ders[:25]:
+        out.append(sid("Org1MSP", pem(d, width=76, eol=b"\r\n")))
+        out.append(sid("Org2MSP", pem(d, width=1 << 20, trailer=b"")))
+        out.append(sid("Org2MSP", b"junk before\n" + pem(d)))                # PemToDer scans for the marker
+        out.append(sid("Org2MSP", pem(d, width=61, eol=b" \t\n")))
+        out.append(sid("Org1MSP", pem(d, tail=b"-----END CERTIFICATE----")))   # broken END marker
+        out.append(sid("Org1MSP", pem(d, head=b"-----BEGIN CERTIFICATE----")))
+        out.append(sid("Org1MSP", pem(d)[:-30]))
+        out.append(sid("Org1MSP", pem(d).replace(b"A", b"*", 1)))
+        out.append(bb.fbytes(1, b"Org1MSP") + bb.fbytes(2, pem(d)) + bb.fbytes(2, pem(d)))        # id_bytes twice: ambiguous
+        out.append(bb.fbytes(1, b"Org1MSP"))                                                       # no id_bytes
+    out += [b"", b"\x00", b"\x12\x00", sid("X", b""), sid("X", b"-----BEGIN CERTIFICATE-----"),
+            sid("X", b"-----BEGIN CERTIFICATE-----\n-----END CERTIFICATE-----\n"),
+            sid("X", b"-----BEGIN CERTIFICATE-----\nAAAA\n-----END CERTIFICATE-----\n"), bytes(rng.integers(0, 256, size=700, dtype=np.uint8))]
+    for i in IDS:
+        out.append(sid("Org1MSP", i["pem"].encode()))
+    base = np.frombuffer(out[0], dtype=np.uint8)
+    for _ in range(1200):                                                    # mutants of a good identity: text and (through it) DER
+        m = base.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            m[int(rng.integers(0, m.size))] = np.uint8(rng.integers(0, 256))
+        out.append(m.tobytes())
+    d0 = ders[0]
+    for _ in range(800):                                                     # mutants of the DER under intact PEM armour
+        m = np.frombuffer(d0, dtype=np.uint8).copy()
+        for _ in range(int(rng.integers(1, 3))):
+            m[int(rng.integers(0, m.size))] = np.uint8(rng.integers(0, 256))
+        out.append(sid("Org1MSP", pem(m.tobytes())))
+    # a certificate beyond the device decoder's buffer (4096 base64 digits): the one thing it leaves to the host
+    out.append(sid("Org1MSP", pem(d0[:4] + d0[4:] + bytes(3100))))
+    return out
+
+
 def test_identity_table_hash_restated():
     """The table hash covers the length and the last 64 bytes (one coalesced row for a wavefront: lane l folds byte l); equality is
     always decided on all the bytes, so the hash only has to spread the identities a provider meets."""
@@ -190,16 +331,38 @@ def csp():
 def test_wavefront_signature_gate_equals_the_lane_form(csp):
     """The kernels run the gate with a signature's bytes spread over a wavefront (lane permutes, ballots); it must give the code and
     the (r, s) of walk::gate_sig_fast - which the CPU test above holds against the general parser - on every case."""
-    cases = [c for c, _ in _gate_cases()]
+    cases = _general_gate_cases()
     code, r, s = fabgpu.gate_probe(csp, cases)
-    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    seen = {0: 0, 1: 0, 2: 0, 4: 0, 5: 0}
     for i, sig in enumerate(cases):
-        want, wr, ws = fabgpu.gate_sig_fast(sig)
+        want, wr, ws = fabgpu.gate_sig_any(sig)
         assert int(code[i]) == want, (i, sig.hex(), int(code[i]), want)
         if want == 0:
             assert bytes(r[i]) == wr and bytes(s[i]) == ws, sig.hex()
         seen[want] += 1
-    assert min(seen.values()) > 0 and seen[0] > 1500 and seen[1] > 300
+    assert min(seen.values()) > 0 and seen[0] > 1500 and seen[1] > 300 and seen[4] > 500
+
+
+@pytest.mark.gpu
+def test_device_identity_decoder_equals_the_host_decoder(csp):
+    """A wavefront per identity: SerializedIdentity -> PEM (any line layout) -> DER -> SubjectPublicKeyInfo -> curve membership.  Same
+    answer as the host route's IdentityToP256 + PublicKeyOnCurve on the reference's 102 certificate fixtures (P-256, P-384 ...), on
+    re-wrapped / broken armour, on 2 000 mutants of text and DER, on non-certificates; only a certificate beyond its buffer is left
+    undecided."""
+    cases = _identity_cases()
+    code, key = fabgpu.idfix_probe(csp, cases)
+    n_key = n_not = 0
+    for i, ident in enumerate(cases[:-1]):
+        want = fabgpu.identity_to_p256(ident)
+        if want is None:
+            assert int(code[i]) == 1, (i, ident[:80])
+            assert not key[i].any()
+            n_not += 1
+        else:
+            assert int(code[i]) == 0 and bytes(key[i]) == want, (i, ident[:80])
+            n_key += 1
+    assert int(code[-1]) == 2 and fabgpu.identity_to_p256(cases[-1]) is not None
+    assert n_key > 300 and n_not > 300, (n_key, n_not)
 
 
 @pytest.mark.gpu
@@ -326,25 +489,139 @@ def test_pass_on_the_device_route_equals_the_host_route(csp, monkeypatch):
     assert fabgpu.pass_routes(csp)["device_walks"] == 3
 
 
+KEYS_ALL = ["tx_flags", "tx_type", "tuple_tx", "tuple_kind", "tuple_status", "tuple_spans", "tuple_digest", "tuple_hashed", "tuple_qxy"]
+
+
+def _both_routes(csp, monkeypatch, blk, seq, device_first=True, **kw):
+    """the same block through the device route and through the host route of ONE provider -> (device answer, host answer)"""
+    def run(device):
+        monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1" if device else str(1 << 40))
+        before = fabgpu.pass_routes(csp)
+        out = fabgpu.preverify_block2(csp, blk, block_seq=seq + (0 if device else 1), **kw)
+        after = fabgpu.pass_routes(csp)
+        assert after["device_walks"] - before["device_walks"] == (1 if device else 0), after
+        return out
+    if device_first:
+        dev = run(True)
+        return dev, run(False)
+    host = run(False)
+    return run(True), host
+
+
 @pytest.mark.gpu
-def test_device_route_declines_what_it_must(csp, monkeypatch):
-    """A signature outside the common DER shape, an identity nobody has met, a block that was not staged: the host walk answers (and
-    learns), the answers are the reference's, and the next block of known shape is walked on the device again."""
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+def test_device_route_serves_what_it_used_to_decline(csp, monkeypatch):
+    """Identities nobody has met (the device decodes their certificates itself), garbage DER, a provider that knows nobody at all:
+    none of it takes a block to the host walk any more, and the answers are the host route's - which learns nothing the device route
+    does not learn too."""
     rng = np.random.default_rng(5)
     first, want1 = clean_modes_block(40, rng)
-    out = fabgpu.preverify_block(csp, first)                                # nobody is known yet
+    dev, host = _both_routes(csp, monkeypatch, first, 10)                   # nobody is known yet: every tuple's certificate is decoded
+    assert (dev["tx_flags"] == want1).all() and dev["n_device_decoded"] == len(dev["tuple_status"]) > 100
+    _same(host, dev, KEYS_ALL)
     r = fabgpu.pass_routes(csp)
-    assert (out["tx_flags"] == want1).all() and r["device_walks"] == 0 and "identity" in r["last_decline"]
-    out = fabgpu.preverify_block(csp, first)
-    assert (out["tx_flags"] == want1).all() and fabgpu.pass_routes(csp)["device_walks"] == 1
+    assert r["learned"] == 7 and r["device_decoded"] == len(dev["tuple_status"])          # 6 P-256 signers + the P-384 certificate
+    dev2, _ = _both_routes(csp, monkeypatch, first, 20)
+    assert dev2["n_device_decoded"] == 0 and (dev2["tx_flags"] == want1).all()             # ... and are known from then on
+    _same(dev, dev2, KEYS_ALL)
     garbage, want2 = build_block(60, rng)                                   # carries garbage DER (and everything else)
-    out = fabgpu.preverify_block(csp, garbage)
+    dev3, host3 = _both_routes(csp, monkeypatch, garbage, 30)
+    assert (dev3["tx_flags"] == want2).all()
+    assert (dev3["tuple_status"] == fabgpu.TUPLE_ST_BAD_DER).sum() == sum(1 for t in range(60) if t % 13 == 5)
+    _same(host3, dev3, KEYS_ALL)
+    assert fabgpu.pass_routes(csp)["general_der"] >= sum(1 for t in range(60) if t % 13 == 5)
+
+
+@pytest.mark.gpu
+def test_crafted_signature_encodings_stay_on_the_device_route(csp, monkeypatch):
+    """Every way of writing a signature that Go's asn1 package accepts or rejects (long-form lengths, trailing bytes, a third element,
+    oversize / negative integers, non-minimal lengths) inside an otherwise valid block: decided on the device exactly as
+    bccsp/sw/ecdsa.go:41-57 decides - two of them are VALID signatures in the reference - and the block stays on the device route
+    (one such signature used to cost a peer the whole block's host walk)."""
+    import blockgen
+    hows = {(3, 0): "trailing", (5, 1): "third", (8, 2): "long_r", (11, 0): "long_s", (14, 1): "neg_r", (17, 2): "nonminimal"}
+    want_st = {"trailing": 0, "third": 0, "long_r": 3, "long_s": 2, "neg_r": 5, "nonminimal": 5}
+    blk, envs = blockgen.endorser_block(24, 41, craft=lambda t, j, sig: blockgen.crafted(sig, hows[(t, j)]) if (t, j) in hows else sig)
+    _learn(csp, blk)
+    dev, host = _both_routes(csp, monkeypatch, blk, 10)
+    _same(host, dev, KEYS_ALL)
+    st = dev["tuple_status"].reshape(24, 4)
+    for (t, j), how in hows.items():
+        assert int(st[t, 1 + j]) == want_st[how], (t, j, how, int(st[t, 1 + j]))
+        # the oracle's bccsp.Verify on that tuple: valid exactly when the status says so
+        sp = [int(x) for x in dev["tuple_spans"][4 * t + 1 + j]]
+        q = bytes(dev["tuple_qxy"][4 * t + 1 + j])
+        msg = dev["arena"][sp[2]:sp[2] + sp[3]] + dev["arena"][sp[4]:sp[4] + sp[5]]
+        try:
+            ok = po.verify_ecdsa(int.from_bytes(q[:32], "big"), int.from_bytes(q[32:], "big"), dev["arena"][sp[6]:sp[6] + sp[7]], hashlib.sha256(msg).digest())
+        except po.BCCSPError:
+            ok = False
+        assert ok == (want_st[how] == 0), how
+    bad_tx = {t for (t, j), how in hows.items() if want_st[how] != 0}
+    assert {int(t) for t in np.nonzero(dev["tx_flags"])[0]} == bad_tx and (st.reshape(-1) != 0).sum() == len(bad_tx)
+    assert fabgpu.pass_routes(csp)["general_der"] >= 6
+
+
+@pytest.mark.gpu
+def test_blocks_full_of_new_clients_stay_on_the_device_route(monkeypatch):
+    """A busy network: every creator of a block is a certificate the provider has never seen (and there are more of them than its
+    identity cache holds), while the endorsers are the channel's few peers with comb tables.  The device decodes the newcomers'
+    certificates, their launch carries the keys along, the endorsements' launch stays on the registered tables; the prediction that
+    was right for the previous (friendly) block is repaired by one relaunch; statuses, keys, digests and memo equal the host route's."""
+    import blockgen
+    csp = fabgpu.GPUCSP(device=0)
+    try:
+        csp._L.fabgpu_csp_identity_cache_limits(csp._h, 128, 64, 1)         # a small cache: 300 newcomers overflow it
+        friendly, _ = blockgen.endorser_block(300, 7)
+        monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+        for k in range(3):                                                  # the six fixture signers are learned and earn their tables
+            out = fabgpu.preverify_block2(csp, friendly, block_seq=k)
+        assert (out["tx_flags"] == 0).all() and out["n_keyed"] == 1200 and out["n_device_decoded"] == 0
+        fresh = blockgen.fresh_identities(300, 99)
+        crowd, _ = blockgen.endorser_block(300, 8, creators=fresh)
+        before = fabgpu.pass_routes(csp)
+        dev = fabgpu.preverify_block2(csp, crowd, block_seq=10, seed_memo=True)
+        after = fabgpu.pass_routes(csp)
+        assert after["device_walks"] == before["device_walks"] + 1 and after["relaunches"] == before["relaunches"] + 1
+        assert (dev["tx_flags"] == 0).all() and (dev["tuple_status"] == 0).all()
+        assert dev["n_device_decoded"] == 300 and dev["n_keyed"] == 900 and dev["memo_seeded"] == 1200
+        # every creator's key is the one the certificate carries
+        for t in (0, 17, 299):
+            assert bytes(dev["tuple_qxy"][4 * t]) == blockgen._pubkey(fresh[t][1])
+        # the same kind of block again: the prediction now says "creators carry their keys" - no relaunch
+        crowd2, _ = blockgen.endorser_block(300, 9, creators=blockgen.fresh_identities(300, 100))
+        dev2 = fabgpu.preverify_block2(csp, crowd2, block_seq=11)
+        assert fabgpu.pass_routes(csp)["relaunches"] == after["relaunches"] and (dev2["tx_flags"] == 0).all() and dev2["n_keyed"] == 900
+        # one broken creator signature and one broken endorsement among the newcomers
+        sp = dev2["tuple_spans"]
+        broken = bytearray(crowd2)
+        for i in (4 * 100, 4 * 200 + 2):
+            broken[int(sp[i][6]) + int(sp[i][7]) - 2] ^= 0x10
+        dev3 = fabgpu.preverify_block2(csp, bytes(broken), block_seq=12)
+        assert {int(i) for i in np.nonzero(dev3["tuple_status"])[0]} == {400, 800, 802}     # (the endorsement sits inside what creator 200 signed)
+        assert fabgpu.identity_cache_size(csp) <= 128
+        # the host route on the same blocks: same answers
+        monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+        host = fabgpu.preverify_block2(csp, crowd, block_seq=20, seed_memo=True)
+        _same(host, dev, KEYS_ALL)
+        _same(fabgpu.preverify_block2(csp, bytes(broken), block_seq=21), dev3, KEYS_ALL)
+    finally:
+        csp.close()
+
+
+@pytest.mark.gpu
+def test_a_certificate_beyond_the_device_decoder_is_left_to_the_host_walk(csp, monkeypatch):
+    """The one thing the device route still declines: an identity whose PEM body exceeds the decoder's buffer (4096 base64 digits) -
+    the host walk answers, with the reference's answer."""
+    import blockgen
+    fx = blockgen.fixture_signers()
+    d = blockgen._IDS[4]["d"]
+    big = bb.serialized_identity("Org1MSP", blockgen._pem_wrap(blockgen._pem_der(blockgen._IDS[4]["pem"]) + bytes(3100)))   # (bytes behind the Certificate: ignored)
+    blk, _ = blockgen.endorser_block(12, 3, creators=[(big, int(d, 16).to_bytes(32, "big")), fx[5]])
+    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    out = fabgpu.preverify_block2(csp, blk, block_seq=1)
     r = fabgpu.pass_routes(csp)
-    assert (out["tx_flags"] == want2).all() and r["device_walks"] == 1 and "DER" in r["last_decline"]
-    assert (out["tuple_status"] == fabgpu.TUPLE_ST_BAD_DER).sum() == sum(1 for t in range(60) if t % 13 == 5)
-    out = fabgpu.preverify_block(csp, first)
-    assert (out["tx_flags"] == want1).all() and fabgpu.pass_routes(csp)["device_walks"] == 2
+    assert r["device_walks"] == 0 and "decoder" in r["last_decline"], r
+    assert (out["tx_flags"] == 0).all() and (out["tuple_status"] == 0).all()
 
 
 @pytest.mark.gpu
@@ -493,6 +770,8 @@ def test_device_route_with_keys_carried_along(monkeypatch):
             assert fabgpu.pass_routes(csp)["device_walks"] == before + 2, fabgpu.pass_routes(csp)
             _same(host_small, dev_small, keys)
             _same(host_big, dev_big, keys)
-            assert dev_big["n_keyed"] == 0 and dev_small["n_keyed"] == 0 and dev_big["memo_seeded"] == 40000
+            assert dev_big["memo_seeded"] == 40000
+            if tables == 0:
+                assert dev_big["n_keyed"] == 0 and dev_small["n_keyed"] == 0
         finally:
             csp.close()

@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(fabgpu.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.fabgpu_abi_version() == 4      # 4: pseudonym signatures ride in fabgpu_identity_batch (3: tail / digests; 2: the gather_* fields)
+    assert L.fabgpu_abi_version() == 5      # 4: pseudonym signatures ride in fabgpu_identity_batch (3: tail / digests; 2: the gather_* fields)
     assert fabgpu.strerror(0) == "ok" and "bccsp/sw" in fabgpu.strerror(-2)
 
 
