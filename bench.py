@@ -166,66 +166,69 @@ def inprocess_multi_leg(world):
 
 
 def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
-    """SURVEY 8(f) rank 1 through the provider: a marshalled 10 000-transaction block in (built and signed here with the C oracle:
-    1 creator + 3 endorsement signatures, TxID and proposal hash per transaction), per-transaction flags out - walk, gates, one device
-    submission - timed around the blocking C-ABI call, flags-only and with digests + verdict-memo seeding (what the Go provider runs),
-    with the walk / gates / identity lookup on the device (block_walk_dev.h: the route a staged block of known identities takes) and,
-    for comparison, on the host.
-    The tests hold the pass against the reference's ledgers and against corrupted blocks; here every transaction must come back valid
-    and one flipped payload byte must come back as a bad creator signature."""
-    import ctypes
-    import hashlib
+    """BASELINE.json's second metric - validated tx/sec per block - as the provider delivers it: a marshalled
+    block of n_tx endorser transactions (1 creator + 3 endorsement signatures + TxID + proposal hash each, real certificates,
+    tests/blockgen.py) in, per-transaction flags out.  Legs:
+      flags_only / with_memo_seeding (+ _host_walk): the friendly block - six signers, all with device comb tables - on both routes;
+      distinct_creators: every creator of the block is a certificate the provider has not met (and its identity cache is kept too
+        small to remember them): 10 000 certificates decoded on the device per pass, the creators' launch carries the keys along;
+      one_percent_new_creators: ten consecutive blocks, each with 1 % never-seen creators among known ones;
+      one_crafted_der_signature: the friendly block with one endorsement signature in long-form DER (r of 200 bytes);
+      three_callers_flags_only: three callers on the one provider.
+    Every transaction of every timed block must come back valid (the crafted one: exactly its transaction flagged), and one flipped
+    payload byte must come back as a bad creator signature."""
     import statistics
     sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
-    import bccsp_sw_oracle as po
     import blockbuilder as bb
-    ids = [i for i in json.load(open(os.path.join(ROOT, "tests", "golden", "block_identities.json")))["identities"] if i["curve"] == "prime256v1"]
-    sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in ids]
-    L = coracle.lib()
-    rng = np.random.default_rng(1)
+    import blockgen
+    cache_dir = os.path.join(ROOT, ".bench_blocks")
 
-    def sign(k, msg):
-        d = int(ids[k]["d"], 16).to_bytes(32, "big")
-        nonce = b"\x00" + bytes(rng.integers(1, 255, size=31, dtype=np.uint8))
-        r, s = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
-        assert L.oracle_p256_sign(d, hashlib.sha256(msg).digest(), nonce, 1, r, s) == 0
-        return po.marshal_ecdsa_signature(int.from_bytes(r.raw, "big"), int.from_bytes(s.raw, "big"))
-    envs = []
-    for t in range(n_tx):
-        picks = [int(j) for j in rng.choice(4, size=3, replace=False)]
-        c = 4 + t % 2
-        payload, _ = bb.consistent_endorser_tx("mychannel", sid[c], bytes(rng.integers(0, 256, size=24, dtype=np.uint8)),
-                                               bytes(rng.integers(0, 256, size=300, dtype=np.uint8)), bytes(rng.integers(0, 256, size=990, dtype=np.uint8)),
-                                               lambda prp: [(sid[j], sign(j, prp + sid[j])) for j in picks])
-        envs.append(bb.envelope(payload, sign(c, payload)))
-    blk = bb.block(1, envs)
+    def cached(name, build):
+        """blocks pre-built by tools/make_bench_blocks.py travel with the snapshot; otherwise they are signed here (CPU oracle, ~15 s each)"""
+        path = os.path.join(cache_dir, name)
+        if os.path.exists(path):
+            return open(path, "rb").read()
+        return build()
+    blk = cached("friendly_%d.bin" % n_tx, lambda: blockgen.endorser_block(n_tx, 1)[0])
+    _, envs = blockgen.split_envelopes(blk)
+    assert len(envs) == n_tx
     csp = fabgpu.GPUCSP(device=0)
+
+    def timed(name, blocks, memo=False, host_walk=False, expect_bad=()):
+        """one pass per entry of `blocks`, each timed on its own -> a leg"""
+        if host_walk:
+            os.environ["FABGPU_PASS_STAGE_MIN_BYTES"] = str(1 << 40)
+        else:
+            os.environ.pop("FABGPU_PASS_STAGE_MIN_BYTES", None)
+        before = fabgpu.pass_routes(csp)
+        per, decoded = [], []
+        for k, b in enumerate(blocks):
+            c0 = time.perf_counter()
+            r = fabgpu.preverify_block2(csp, b, block_seq=1000 + k, seed_memo=memo, lean=True)
+            per.append((time.perf_counter() - c0) * 1e3)
+            bad = sorted(int(t) for t in np.nonzero(r["tx_flags"])[0])
+            assert bad == sorted(expect_bad), "%s: transactions %r flagged" % (name, bad[:8])
+            decoded.append(int(r["n_device_decoded"]))
+            if memo:
+                assert r["memo_seeded"] == 4 * n_tx
+                fabgpu.memo_evict_block(csp, 1000 + k)
+        os.environ.pop("FABGPU_PASS_STAGE_MIN_BYTES", None)
+        med = statistics.median(per)
+        after = fabgpu.pass_routes(csp)
+        return {"validated_tx_per_s": n_tx / (med * 1e-3), "median_ms_per_block": med, "min_ms": min(per), "max_ms": max(per), "blocks": len(per),
+                "walked_on_device": after["device_walks"] - before["device_walks"], "walked_on_host": after["host_walks"] - before["host_walks"],
+                "certificates_decoded_on_device_per_block": statistics.median(decoded), "relaunches": after["relaunches"] - before["relaunches"]}
     try:
-        for _ in range(3):                                     # identities earn their device tables on the first passes
+        for _ in range(3):                                     # identities are learned and earn their device tables on the first passes
             first = fabgpu.preverify_block2(csp, blk, lean=True)
         assert (first["tx_flags"] == 0).all() and first["n_tuples"] == 4 * n_tx and first["n_keyed"] == 4 * n_tx
         legs = {}
         # (the device walk takes blocks that were staged ahead: lifting the staging threshold sends the same block down the host walk)
-        for name, memo, host_walk in (("flags_only", False, False), ("with_memo_seeding", True, False), ("flags_only_host_walk", False, True),
-                                      ("with_memo_seeding_host_walk", True, True)):
-            if host_walk:
-                os.environ["FABGPU_PASS_STAGE_MIN_BYTES"] = str(1 << 40)
-            else:
-                os.environ.pop("FABGPU_PASS_STAGE_MIN_BYTES", None)
-            before = fabgpu.pass_routes(csp)
-            per = []
-            for k in range(steps):
-                c0 = time.perf_counter()
-                r = fabgpu.preverify_block2(csp, blk, block_seq=100 + k, seed_memo=memo, lean=True)
-                per.append((time.perf_counter() - c0) * 1e3)
-                if memo:
-                    assert r["memo_seeded"] == 4 * n_tx
-                    fabgpu.memo_evict_block(csp, 100 + k)
-            med = statistics.median(per)
-            after = fabgpu.pass_routes(csp)
-            legs[name] = {"validated_tx_per_s": n_tx / (med * 1e-3), "median_ms_per_block": med, "min_ms": min(per), "max_ms": max(per), "blocks": steps,
-                          "walked_on_device": after["device_walks"] - before["device_walks"], "walked_on_host": after["host_walks"] - before["host_walks"]}
-        os.environ.pop("FABGPU_PASS_STAGE_MIN_BYTES", None)
+        legs["flags_only"] = timed("flags_only", [blk] * steps)
+        legs["with_memo_seeding"] = timed("with_memo_seeding", [blk] * steps, memo=True)
+        legs["flags_only_host_walk"] = timed("flags_only_host_walk", [blk] * steps, host_walk=True)
+        legs["with_memo_seeding_host_walk"] = timed("with_memo_seeding_host_walk", [blk] * steps, memo=True, host_walk=True)
+        friendly_ms = legs["flags_only"]["median_ms_per_block"]
         try:                                                   # several channels of a peer at once: three callers on the one provider
             import threading
             n_callers, per_caller = 3, 8
@@ -249,12 +252,46 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
         bad[at] ^= 1
         flags = fabgpu.preverify_block2(csp, bytes(bad), lean=True)["tx_flags"]
         assert flags[7] != 0 and (np.delete(flags, 7) == 0).all(), "a flipped payload byte must fail exactly its transaction"
+        del bad
+        # ---- the unfriendly blocks (what a busy network and an adversary send): all on the device route ----
+        try:
+            # (c) one endorsement signature of transaction 11 re-encoded with a 200-byte r in long-form DER: parses, r >= n, (false, nil)
+            fx = blockgen.fixture_signers()
+            rng = np.random.default_rng(77)
+            env11 = blockgen.endorser_tx(11, rng, fx[5], [fx[0], fx[1], fx[2]], blockgen.make_signer(78),
+                                         craft=lambda t, j, sig: blockgen.crafted(sig, "long_r") if j == 1 else sig)
+            crafted_blk = bb.block(1, envs[:11] + [env11] + envs[12:])
+            legs["one_crafted_der_signature"] = timed("one_crafted_der_signature", [crafted_blk] * steps, expect_bad=(11,))
+            del crafted_blk
+            # (b) ten consecutive blocks, 1 % of the creators of each never seen before
+            per_block = max(1, n_tx // 100)
+            new_envs = cached("fresh1pct_%d.bin" % n_tx, lambda: blockgen.pack_envelopes(
+                blockgen.endorser_block(10 * per_block, 5, creators=blockgen.fresh_identities(10 * per_block, 6))[1]))
+            new_envs = blockgen.unpack_envelopes(new_envs)
+            assert len(new_envs) == 10 * per_block
+
+            def with_newcomers(k):
+                e = list(envs)
+                for q in range(per_block):
+                    e[(97 * q + k) % n_tx] = new_envs[k * per_block + q]
+                return bb.block(1, e)
+            legs["one_percent_new_creators"] = timed("one_percent_new_creators", [with_newcomers(k) for k in range(10)])
+            # (a) every creator a certificate nobody has met, more of them than the identity cache is allowed to remember
+            distinct = cached("distinct_%d.bin" % n_tx, lambda: blockgen.endorser_block(n_tx, 3, creators=blockgen.fresh_identities(n_tx, 4))[0])
+            csp._L.fabgpu_csp_identity_cache_limits(csp._h, 256, 256, 64)
+            legs["distinct_creators"] = timed("distinct_creators", [distinct] * steps)
+            csp._L.fabgpu_csp_identity_cache_limits(csp._h, 4096, 256, 64)
+            for name in ("one_crafted_der_signature", "one_percent_new_creators", "distinct_creators"):
+                legs[name]["vs_friendly_device_route"] = legs[name]["median_ms_per_block"] / friendly_ms
+        except Exception as e:                                 # noqa: BLE001
+            legs["unfriendly_blocks_error"] = repr(e)[:300]
     finally:
         csp.close()
     return {"metric": "validated tx/s per block, marshalled block in, flags out (block-level pre-verify pass)", **legs,
-            "config": {"workload": "%d endorser tx x (1 creator + 3 endorsement signatures + TxID + proposal hash), %.1f MB block, 6 signers with device tables"
-                                   % (n_tx, len(blk) / 1e6)},
-            "parity": "every transaction valid; a flipped payload byte fails exactly its transaction (reference ledgers and corrupted blocks: tests/)"}
+            "config": {"workload": "%d endorser tx x (1 creator + 3 endorsement signatures + TxID + proposal hash), %.1f MB block; friendly legs: 6 signers with device "
+                                   "tables; unfriendly legs: see block_pass_leg" % (n_tx, len(blk) / 1e6)},
+            "parity": "every transaction valid (crafted leg: exactly the crafted one flagged); a flipped payload byte fails exactly its transaction "
+                      "(reference ledgers, corrupted blocks, route equality: tests/)"}
 
 
 def fused_cfg3_leg(ctx, torch, np, fabgpu, coracle, steps):

@@ -212,8 +212,8 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
         if (r < 0) return r == FABGPU_EINVAL || r == FABGPU_ENOMEM ? r : FABGPU_ELAUNCH;
         done = r == 0;
         if (timing && done)
-            fprintf(stderr, "fabgpu pass (device walk): total %.2f ms (outline + identity table %.2f, wait for upload %.2f, device %.2f)\n", ms(t0, std::chrono::steady_clock::now()),
-                    v.ms_gates, v.ms_upload_wait, v.ms_device);
+            fprintf(stderr, "fabgpu pass (device walk): total %.2f ms (outline + identity table %.2f, wait for upload %.2f, device %.2f, bookkeeping %.2f)\n",
+                    ms(t0, std::chrono::steady_clock::now()), v.ms_gates, v.ms_upload_wait, v.ms_device, v.ms_post);
         if (timing && !done) fprintf(stderr, "fabgpu pass: device walk declined (%s)\n", why);
     }
     if (done) {

@@ -89,6 +89,7 @@ struct BlockVerdicts {
     std::vector<uint8_t> tuple_status;    // device status 0..4 or TUPLE_ST_*
     uint32_t distinct_identities = 0;     // identities of this block that were not in the cache yet
     double ms_gates = 0, ms_upload_wait = 0, ms_device = 0, ms_nym = 0, ms_memo = 0;   // where the pass spent its time (host clock)
+    double ms_post = 0;                   // device route: bookkeeping behind the device phase (cache hits, learned identities, comb tables, memo)
     // What a consumer needs to attach each verdict to the BYTES it was computed over (never to a position):
     std::vector<uint8_t> tuple_digest;    // 32 per tuple: SHA-256 of the signed message as the fused kernel computed it; zero unless the
                                           // device hashed the message (tuple_hashed[i] == 1)
@@ -206,6 +207,8 @@ class GPUCSP {
         int64_t key_id = -1;
         uint32_t hits = 0;              // tuples that named this identity (drives device-table registration)
         bool registering = false;       // some thread is building the device table right now
+        uint64_t table_hash = 0;        // walk::id_hash_host of the identity bytes under idtab_seed_ (computed once, when it enters the cache)
+        uint64_t serial = 0;            // unique per cache entry: how the device table's indices find their way back (idserial_)
     };
     // Bounded LRU (the reference's msp cache is one: msp/cache/cache.go:14-18, second_chance.go).  Identities come out of
     // UNVALIDATED blocks, so neither host memory nor device tables may grow with what a block names: at most id_max_ cached
@@ -215,6 +218,10 @@ class GPUCSP {
     mutable std::mutex idmu_;
     mutable IdList idlru_;
     mutable std::unordered_map<std::string, IdList::iterator> idcache_;
+    mutable std::unordered_map<uint64_t, IdList::iterator> idserial_;
+    mutable uint64_t id_next_serial_ = 1;
+    // (idmu_ held) a new cache entry at the front of the LRU list; evicts what no longer fits
+    void InsertIdentityLocked(std::string&& key, CachedIdentity ci) const;
     mutable size_t id_max_ = 4096, id_max_registered_ = 256, id_registered_ = 0;
     mutable uint32_t id_register_after_ = 64;
     // The device's copy of this cache (block_walk_dev.h walk_idtab_set): rebuilt whenever id_version_ moved.  Passes hold idtab_rw_
@@ -222,12 +229,11 @@ class GPUCSP {
     mutable std::atomic<uint64_t> id_version_{1};
     mutable std::shared_timed_mutex idtab_rw_;
     mutable std::atomic<uint64_t> idtab_version_{0};
-    struct IdTabEntry {
-        std::string key;                    // the SerializedIdentity bytes
-        bool p256;
-        uint8_t qx[32], qy[32];
-    };
-    mutable std::vector<IdTabEntry> idtab_host_;
+    mutable std::vector<uint64_t> idtab_host_;         // serial of the cache entry behind index k of the device table
+    mutable std::vector<uint8_t> idtab_bytes_;         // scratch of the rebuild (3 MB when the cache is full: not reallocated per version)
+    mutable std::vector<DevIdEntry> idtab_ents_;
+    const uint64_t idtab_seed_ = MakeSeed();      // the device table's hash is keyed per provider (block_walk_core.h id_hash_host)
+    static uint64_t MakeSeed();
     int SyncDeviceIdentityTable() const;
     mutable std::atomic<uint64_t> pass_relaunches_{0}, pass_decoded_{0}, pass_learned_{0}, pass_general_der_{0};
     void EvictIdentitiesLocked() const;

@@ -600,11 +600,18 @@ WALK_HD inline int pem_char_class(uint8_t c) {
 
 // ---- identity bytes -> 64-bit table hash ---------------------------------------------------------------------------------
 // The device looks identities up in a table of the ones the provider has met (block_walk_kernels.hip); the hash only picks the slot,
-// equality is always decided on ALL the bytes.  It covers the length and the last 64 bytes - for a certificate the end of its
-// signature, which no two certificates share - so that a wavefront computes it from one coalesced row: lane l folds byte l of that
-// row, the lanes are mixed with per-lane odd constants and summed.  (Identities crafted to collide only lengthen a probe sequence.)
+// equality is always decided on ALL the bytes.  It covers the length and two rows of 64 bytes that a wavefront loads with one
+// instruction each - the LAST 64 bytes (for a certificate the end of its signature) and 64 bytes SPREAD over the whole string (byte
+// l * len / 64 for lane l: the subject, the public key ...) - folded per lane, mixed with per-lane odd constants and summed.  A
+// per-provider random seed enters every lane, and a lookup gives up after WALK_ID_PROBE_MAX probes (the table builder never places an
+// entry further from its home slot): identities crafted to collide cost a bounded number of comparisons and are then simply treated
+// as unknown - the device decodes their certificates itself, which is always correct.  (Round 2's hash covered the last 64 bytes
+// only: ten thousand certificates that shared them - re-keyed copies of one certificate - made every lookup walk 4 096 entries.)
+constexpr uint32_t WALK_ID_PROBE_MAX = 16;
 WALK_HD inline uint64_t id_stream_const(uint32_t l) { return (0x9E3779B97F4A7C15ull * (uint64_t)(2 * l + 1)) | 1ull; }
 WALK_HD inline uint64_t id_stream_fold(uint64_t h, uint8_t b) { return (h ^ b) * 0x100000001B3ull; }
+WALK_HD inline uint64_t id_stream_basis(uint64_t seed) { return 0xCBF29CE484222325ull ^ seed; }
+WALK_HD inline uint32_t id_spread_pos(uint32_t l, uint32_t len) { return (uint32_t)(((uint64_t)l * len) >> 6); }   // < len for len > 0
 WALK_HD inline uint64_t id_hash_finish(uint64_t sum, uint32_t len) {
     uint64_t h = sum ^ ((uint64_t)len * 0xD6E8FEB86659FD93ull);
     h ^= h >> 32;
@@ -612,15 +619,22 @@ WALK_HD inline uint64_t id_hash_finish(uint64_t sum, uint32_t len) {
     h ^= h >> 29;
     return h;
 }
-inline uint64_t id_hash_host(const uint8_t* p, uint32_t len) {
+// one lane's term of the sum (lane l of 64)
+WALK_HD inline uint64_t id_lane_term(const uint8_t* p, uint32_t len, uint32_t l, uint64_t seed) {
     const uint32_t m = len < 64 ? len : 64;
-    const uint8_t* q = p + (len - m);
+    uint64_t h = id_stream_basis(seed);
+    if (l < m) h = id_stream_fold(h, p[len - m + l]);
+    if (len) h = id_stream_fold(h, p[id_spread_pos(l, len)]);
+    // (xor-shifts around the per-lane multiplication: without them the sum is LINEAR in the small differences two bytes make - the
+    // per-lane constants are multiples of one number - and strings that differ in a few sampled bytes collide in droves)
+    h ^= h >> 31;
+    h *= id_stream_const(l);
+    h ^= h >> 29;
+    return h;
+}
+inline uint64_t id_hash_host(const uint8_t* p, uint32_t len, uint64_t seed = 0) {
     uint64_t sum = 0;
-    for (uint32_t l = 0; l < 64; l++) {
-        uint64_t h = 0xCBF29CE484222325ull;
-        if (l < m) h = id_stream_fold(h, q[l]);
-        sum += h * id_stream_const(l);
-    }
+    for (uint32_t l = 0; l < 64; l++) sum += id_lane_term(p, len, l, seed);
     return id_hash_finish(sum, len);
 }
 

@@ -40,18 +40,19 @@ struct DevIdEntry {
 };
 static_assert(sizeof(DevIdEntry) == 88, "uploaded as raw bytes");
 
-// summary words of one pass (gate, identity-decode and status kernels accumulate them; one small copy device -> host at the end)
+// summary words of one pass (the status kernel adds up what the gate and identity-decode kernels noted per tuple, one atomic per
+// wavefront; one small copy device -> host at the end)
 struct WalkSummary {
     uint32_t n_unknown_identity;   // tuples whose identity is not in the device table: the device decodes their certificates itself
     uint32_t n_undecided;          // ... of which it could not decide (a PEM body beyond its buffer): the one case the host repairs
     uint32_t n_outline_differs;    // creator messages that are not the span the host's outline named: this pass does not answer
-    uint32_t n_submitted;          // non-zero: some tuple is for the device to decide (a flag, not a count)
+    uint32_t n_submitted;          // tuples for the device to decide
     uint32_t n_unkeyed_creator;    // submitted creator tuples without a registered comb table (any: the fresh-key kernel serves that launch)
     uint32_t n_unkeyed_other;      // the same for endorsements and block signatures
     uint32_t n_hashed_creator;     // tuples the device hashed and decided, by launch class (status kernel)
     uint32_t n_hashed_other;
-    uint32_t n_learn;              // identities offered to the provider's cache in learn[] (distinct by table hash; may exceed WALK_LEARN_SLOTS)
     uint32_t n_general_der;        // signatures that took the general DER parser (statistics)
+    uint32_t n_learn;              // (identity kernel) identities offered to the provider's cache in learn[] (distinct by table hash)
     uint32_t pad[2];
 };
 // An identity the device decoded and the provider may want in its cache (and, once it has been named often enough, with a comb table):
@@ -102,6 +103,7 @@ struct WalkArrays {
     uint32_t* key_id = nullptr;
     uint8_t *qx = nullptr, *qy = nullptr, *r = nullptr, *s = nullptr;
     uint8_t* gate_st = nullptr;
+    uint8_t* tflags = nullptr;           // per tuple: what the gate / identity kernels note for the summary (the status kernel adds them up)
     WalkLearn* learn = nullptr;          // WALK_LEARN_SLOTS slots, zeroed per pass
     // Row of tuple i in the submission arrays.  Plain: row = i.  Split (a block of 32 769 .. 65 536 tuples): the creator tuples - long
     // messages (the whole envelope payload), no shared prefix - take rows [0, n_creators) and run as a launch of their own with two
@@ -116,6 +118,7 @@ struct WalkArrays {
     uint32_t id_mask = 0;
     const DevIdEntry* id_entries = nullptr;
     const uint8_t* id_bytes = nullptr;
+    uint64_t id_seed = 0;            // the provider's table-hash seed (walk::id_hash_host)
     // results
     const uint64_t* verdict_bits = nullptr;    // of the launch over rows [split ? n_creators : 0, n)
     const uint64_t* verdict_bits_c = nullptr;  // split: of the creators' launch
@@ -132,8 +135,7 @@ struct WalkArrays {
 
 hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st);                       // counts, tx_type, tx_understood; then the scan
 hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st);   // tuples, prefixes, checks, gather spans / offsets
-hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);                        // identity lookup + gates + submission arrays + summary
-hipError_t launch_walk_idfix(const WalkArrays& a, hipStream_t st);                       // certificates of identities the table lacks -> keys
+hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);                        // identity lookup / certificate decode + gates + submission arrays
 // TEST HOOK: the device's identity decoder over n SerializedIdentity byte strings (spans = (start, end) pairs into arena) -> code
 // (0 P-256 key, 1 not such an identity, 2 undecided), key (64 bytes each, zero unless code == 0)
 hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st);
@@ -144,7 +146,9 @@ hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spa
 
 // ---- host side (fabgpu_api.hip) ----
 // Replace the device's identity table (entries + their bytes); the table is rebuilt by the provider whenever its cache changes.
-int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const uint8_t* bytes, size_t nbytes);
+// Entries are placed in the order given (put the ones that matter most first); one that would land WALK_ID_PROBE_MAX or more slots from
+// its home is left out (the device then decodes that identity itself: slower, never wrong).  `seed`: what the entries' hashes were made with.
+int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const uint8_t* bytes, size_t nbytes, uint64_t seed);
 
 constexpr int WALK_DECLINED = 100;   // not an error: this block is for the host walk (why: WalkRequest::declined_why)
 

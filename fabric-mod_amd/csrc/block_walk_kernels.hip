@@ -98,6 +98,9 @@ __global__ void __launch_bounds__(64) walk_emit_kernel(WalkArrays a, uint32_t n_
     bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
 }
 
+// per-tuple notes of the gate kernel for the summary (WalkArrays::tflags)
+enum : uint8_t { TF_SUBMIT = 1, TF_KEYED = 2, TF_UNKNOWN = 4, TF_GENERAL = 8, TF_OUTLINE = 16, TF_UNDECIDED = 32 };
+
 // ---- one wavefront per tuple: identity lookup, signature gate, submission row -----------------------------------------------------
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 // n/2 of P-256 (bccsp/utils/ecdsa.go:30-37 curveHalfOrders) and the generator (key of the filler rows), big-endian bytes
@@ -115,10 +118,7 @@ __device__ __forceinline__ uint32_t wave_identity_lookup(const WalkArrays& a, co
     uint32_t found = 0xFFFFFFFFu;
     if (a.id_mask == 0 || a.id_slots == nullptr || id.off > a.arena_len || id.len > a.arena_len - id.off) return found;
     const uint8_t* p = a.block + id.off;
-    const uint32_t m = id.len < 64 ? id.len : 64;
-    uint64_t h = 0xCBF29CE484222325ull;
-    if (lane < m) h = bccsp::walk::id_stream_fold(h, p[id.len - m + lane]);
-    uint64_t term = h * bccsp::walk::id_stream_const(lane);
+    uint64_t term = bccsp::walk::id_lane_term(p, id.len, lane, a.id_seed);
     for (int o = 32; o >= 1; o >>= 1) {
         const uint32_t lo32 = __shfl_xor((uint32_t)term, o, 64), hi32 = __shfl_xor((uint32_t)(term >> 32), o, 64);
         term += ((uint64_t)hi32 << 32) | lo32;
@@ -126,7 +126,7 @@ __device__ __forceinline__ uint32_t wave_identity_lookup(const WalkArrays& a, co
     const uint64_t hash = bccsp::walk::id_hash_finish(term, id.len);
     const uint32_t ndw = id.len >> 2, rest = id.len & 3u;
     uint32_t slot = (uint32_t)hash & a.id_mask;
-    for (uint32_t probes = 0; probes <= a.id_mask; probes++) {
+    for (uint32_t probes = 0; probes < bccsp::walk::WALK_ID_PROBE_MAX; probes++) {
         const uint32_t e = a.id_slots[slot];
         if (e == 0) break;
         const DevIdEntry* ent = a.id_entries + (e - 1);
@@ -219,8 +219,15 @@ __device__ __forceinline__ uint8_t wave_gate_sig_any(const uint8_t* sig, uint32_
 //   5. x, y < p and y^2 = x^3 - 3x + b (on_curve29).
 // IDC_P256: key_byte = this lane's byte of X || Y.  IDC_NOT / IDC_NOT_CERT: the host says "not a P-256 certificate identity" too
 // (bccsp/sw decides: other curves / no certificate block at all - idemix, garbage).  IDC_UNDECIDED: more base64 digits than the LDS buffer holds - the only case the host must repair.
-// Called by the 64 lanes of a one-wavefront workgroup (the __syncthreads are wave-local).
+// Called by all 64 lanes of a wavefront, with an LDS buffer of its own.
 constexpr uint32_t IDFIX_MAX_DIGITS = 4096;                             // 3 KiB of DER
+// One wavefront owns its LDS buffer: its LDS instructions execute in order, so all that is needed between "these lanes wrote" and
+// "those lanes read" is that the compiler keeps the order (no workgroup barrier: the other wavefronts of the workgroup are elsewhere).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 enum : uint8_t { IDC_P256 = 0, IDC_NOT = 1, IDC_UNDECIDED = 2, IDC_NOT_CERT = 3 };   // NOT_CERT: no PEM certificate block at all (idemix, garbage)
 __constant__ char C_PEM_BEGIN[28] = "-----BEGIN CERTIFICATE-----";
 __constant__ char C_PEM_END[26] = "-----END CERTIFICATE-----";
@@ -232,41 +239,52 @@ __device__ uint8_t wave_identity_to_p256(const uint8_t* ident, uint32_t len, uin
     if (!pb_pick(ident, len, &w, 1) || w.seen != 1) return IDC_NOT_CERT;
     const uint8_t* pem = w.p;
     const uint32_t pl = (uint32_t)w.len;
-    // the first BEGIN marker (PemToDer scans for it)
+    // the first BEGIN marker (PemToDer scans for it): candidates are the dashes of a 64-byte row, each checked by 27 lanes at once
     uint32_t start = 0xFFFFFFFFu;
     for (uint32_t base = 0; base + 27 <= pl && start == 0xFFFFFFFFu; base += 64) {
         const uint32_t pos = base + lane;
-        bool hit = pos + 27 <= pl && pem[pos] == '-';
-        if (hit)
-            for (uint32_t k = 1; k < 27; k++) hit = hit && pem[pos + k] == (uint8_t)C_PEM_BEGIN[k];
-        const uint64_t m = __ballot(hit);
-        if (m) start = base + (uint32_t)__builtin_ctzll(m) + 27;
+        uint64_t cand = __ballot(pos + 27 <= pl && pem[pos] == '-');
+        while (cand) {
+            const uint32_t at = base + (uint32_t)__builtin_ctzll(cand);
+            cand &= cand - 1;
+            if (__ballot(lane < 27 && pem[at + (lane < 27 ? lane : 0)] != (uint8_t)C_PEM_BEGIN[lane < 27 ? lane : 0]) == 0) {
+                start = at + 27;
+                break;
+            }
+        }
     }
     if (start == 0xFFFFFFFFu) return IDC_NOT_CERT;
+    // The body, four 64-byte rows per step: their loads are issued together (a row's rank needs the digit count of the rows before
+    // it, its load does not), then the rows are classified and compacted one after the other.
     uint32_t total = 0, end_pos = 0xFFFFFFFFu;
-    for (uint32_t base = start; base < pl; base += 64) {
-        const uint32_t pos = base + lane;
-        const int cls = pos < pl ? pem_char_class(pem[pos]) : (int)PEM_SKIP;
-        const uint64_t dash = __ballot(cls == PEM_DASH);
-        const uint32_t limit = dash ? (uint32_t)__builtin_ctzll(dash) : 64u;
-        const bool act = lane < limit;
-        if (__ballot(act && cls == PEM_INVALID)) return IDC_NOT;
-        const bool digit = act && cls < 64;
-        const uint64_t dig = __ballot(digit);
-        const uint32_t rank = total + (uint32_t)__builtin_popcountll(dig & ((1ull << lane) - 1ull));
-        if (__ballot(digit && rank >= IDFIX_MAX_DIGITS)) return IDC_UNDECIDED;
-        if (digit) lds[rank] = (uint8_t)cls;
-        total += (uint32_t)__builtin_popcountll(dig);
-        if (dash) {
-            end_pos = base + limit;
-            break;
+    for (uint32_t base = start; base < pl && end_pos == 0xFFFFFFFFu; base += 256) {
+        int cls[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t pos = base + 64 * r + lane;
+            cls[r] = pos < pl ? pem_char_class(pem[pos]) : (int)PEM_SKIP;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (end_pos != 0xFFFFFFFFu || base + 64 * r >= pl) break;
+            const uint64_t dash = __ballot(cls[r] == PEM_DASH);
+            const uint32_t limit = dash ? (uint32_t)__builtin_ctzll(dash) : 64u;
+            const bool act = lane < limit;
+            if (__ballot(act && cls[r] == PEM_INVALID)) return IDC_NOT;
+            const bool digit = act && cls[r] < 64;
+            const uint64_t dig = __ballot(digit);
+            const uint32_t rank = total + (uint32_t)__builtin_popcountll(dig & ((1ull << lane) - 1ull));
+            if (__ballot(digit && rank >= IDFIX_MAX_DIGITS)) return IDC_UNDECIDED;
+            if (digit) lds[rank] = (uint8_t)cls[r];
+            total += (uint32_t)__builtin_popcountll(dig);
+            if (dash) end_pos = base + 64 * r + limit;
         }
     }
     if (end_pos == 0xFFFFFFFFu || end_pos + 25 > pl) return IDC_NOT;
     if (__ballot(lane < 25 && pem[end_pos + (lane < 25 ? lane : 0)] != (uint8_t)C_PEM_END[lane < 25 ? lane : 0])) return IDC_NOT;
     const uint32_t nder = total * 6 / 8;
     if (nder == 0) return IDC_NOT;
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t j0 = 0; j0 < nder; j0 += 64) {
         const uint32_t j = j0 + lane;
         uint32_t byte = 0;
@@ -274,10 +292,10 @@ __device__ uint8_t wave_identity_to_p256(const uint8_t* ident, uint32_t len, uin
             const uint32_t q = 4 * j / 3, sh = 4 - 2 * ((4 * j) % 3);       // bit 8j of the digit stream = bit (8j mod 6) of digit q
             byte = ((((uint32_t)lds[q] << 6) | lds[q + 1]) >> sh) & 0xFFu;
         }
-        __syncthreads();                                                 // (all of this row's digits are read before its bytes land on them)
+        wave_lds_sync();                                                 // (all of this row's digits are read before its bytes land on them)
         if (j < nder) lds[j] = (uint8_t)byte;
     }
-    __syncthreads();
+    wave_lds_sync();
     const int32_t at = cert_der_p256_key_offset(lds, nder);
     if (at < 0) return IDC_NOT;
     u256 x, y;
@@ -296,15 +314,17 @@ __device__ uint8_t wave_identity_to_p256(const uint8_t* ident, uint32_t len, uin
 
 // The identity, the gates of one tuple and its row of the submission arrays.  A tuple the device does not decide still gets a
 // well-formed row (r = s = 1; its identity's key, or the generator when there is none): there is no compaction and its verdict is
-// ignored in favour of gate_st.  An identity the table does not hold is NOT a reason to give the block up: the tuple is gated as if its
-// identity carried a P-256 key, and walk_idfix_kernel - next on the stream - decodes the certificate and fills the key in (or sets
-// TUPLE_ST_NEEDS_SW when there is none).
+// ignored in favour of gate_st.  An identity the table does not hold is NOT a reason to give the block up: its certificate is decoded
+// right here (wave_identity_to_p256: the wavefront's own 4 KiB of LDS - 16 KiB per workgroup, which does not cost an occupancy slot)
+// and the identity is offered to the provider's cache; waves that looked their identity up are long gone meanwhile.
 __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
+    __shared__ uint8_t lds_all[4 * IDFIX_MAX_DIGITS];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= a.n_tuples) return;
+    uint8_t* lds = lds_all + (threadIdx.x >> 6) * IDFIX_MAX_DIGITS;
     const BlockTuple t = a.tuples[i];
-    const uint32_t idx = wave_identity_lookup(a, t.identity, lane);
+    uint32_t idx = wave_identity_lookup(a, t.identity, lane);
     // the row of this tuple (WalkArrays::row_of): creators first when the submission is split
     const bool creator = i < a.n_dev_tuples && i == a.bases[t.tx].x;
     uint32_t row = i;
@@ -314,6 +334,56 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         row = creator ? before : a.n_creators + (i - before - (i < a.n_dev_tuples ? 1u : 0u));
     }
     const DevIdEntry* ent = idx != 0xFFFFFFFFu ? a.id_entries + idx : nullptr;
+    // ---- whose key? ----
+    const bool unknown = ent == nullptr;
+    bool p256 = ent && ent->p256, undecided = false;
+    uint32_t key_byte = p256 ? (lane < 32 ? ent->qx[lane & 31u] : ent->qy[lane & 31u]) : C_GXY[lane];
+    if (unknown) {
+        uint8_t code = IDC_NOT_CERT;
+        uint32_t kb = 0;
+        if (t.identity.off <= a.arena_len && t.identity.len <= a.arena_len - t.identity.off)
+            code = wave_identity_to_p256(a.block + t.identity.off, t.identity.len, lane, lds, kb);
+        undecided = code == IDC_UNDECIDED;
+        if (code == IDC_P256) {
+            p256 = true;
+            key_byte = kb;
+            idx = 0xFFFFFFFEu;                                           // "decoded here"
+        }
+        if (code == IDC_P256 || code == IDC_NOT) {
+            // Offer it to the provider's cache (the host route caches what it decodes, keys and "this certificate has no P-256 key"
+            // alike; identities without a certificate block - a fresh idemix pseudonym per transaction - would only churn it): one
+            // slot per table hash; whoever names the same identity after the slot's owner counts as a hit - a comb table is earned by
+            // being named often.
+            uint64_t term = bccsp::walk::id_lane_term(a.block + t.identity.off, t.identity.len, lane, a.id_seed);
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint32_t lo32 = __shfl_xor((uint32_t)term, o, 64), hi32 = __shfl_xor((uint32_t)(term >> 32), o, 64);
+                term += ((uint64_t)hi32 << 32) | lo32;
+            }
+            const uint64_t tag = bccsp::walk::id_hash_finish(term, t.identity.len) | 1ull;
+            WalkLearn* slot = a.learn + ((uint32_t)(tag >> 17) & (WALK_LEARN_SLOTS - 1));
+            uint32_t mine = 0;
+            if (lane == 0) {
+                unsigned long long old = __builtin_nontemporal_load((const unsigned long long*)&slot->tag);
+                if (old == 0ull) old = atomicCAS((unsigned long long*)&slot->tag, 0ull, (unsigned long long)tag);
+                mine = old == 0ull ? 1u : 0u;
+                // (hits only matter up to the registration threshold: a block naming one new identity thousands of times stops counting early)
+                if (old == (unsigned long long)tag && __builtin_nontemporal_load(&slot->hits) < 256u) atomicAdd(&slot->hits, 1u);
+            }
+            mine = __shfl(mine, 0, 64);
+            if (mine) {
+                (lane < 32 ? slot->qx : slot->qy)[lane & 31u] = (uint8_t)key_byte;
+                if (lane == 0) {
+                    slot->off = t.identity.off;
+                    slot->len = t.identity.len;
+                    atomicAdd(&slot->hits, 1u);
+                    __threadfence();
+                    slot->ready = code == IDC_P256 ? 1u : 2u;
+                    atomicAdd(&a.summary->n_learn, 1u);
+                }
+            }
+        }
+    }
+    // ---- the signature ----
     uint8_t gst;
     bool submit = false, general = false;
     uint32_t field_byte = 0;
@@ -324,7 +394,7 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         const uint32_t p0 = a.payload_spans[2 * (size_t)t.tx], p1 = a.payload_spans[2 * (size_t)t.tx + 1];
         outline_differs = (t.suffix.len ? t.suffix.off : 0u) != p0 || (t.suffix.len ? t.suffix.off + t.suffix.len : 0u) != p1;
     }
-    if (ent && !ent->p256) {
+    if (!p256) {
         gst = bccsp::TUPLE_ST_NEEDS_SW;
     } else if (t.sig.len == 0) {
         gst = bccsp::TUPLE_ST_EMPTY_SIG;
@@ -352,9 +422,8 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     // r | s and qx | qy: one byte per lane, 64-byte coalesced rows
     const uint32_t k = lane & 31u;
     const uint8_t rs = submit ? (uint8_t)field_byte : (uint8_t)(k == 31 ? 1 : 0);
-    const uint8_t q = (ent && ent->p256) ? (lane < 32 ? ent->qx[k] : ent->qy[k]) : C_GXY[lane];
     (lane < 32 ? a.r : a.s)[32 * (size_t)row + k] = rs;
-    (lane < 32 ? a.qx : a.qy)[32 * (size_t)row + k] = q;
+    (lane < 32 ? a.qx : a.qy)[32 * (size_t)row + k] = (uint8_t)key_byte;
     if (lane == 0) {
         a.id_idx[i] = idx;
         a.row_of[i] = row;
@@ -363,72 +432,11 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         a.pre_idx[row] = t.prefix_index >= 0 ? (uint32_t)t.prefix_index : 0xFFFFFFFFu;
         a.key_id[row] = keyed ? (uint32_t)ent->key_id : 0u;
         a.gate_st[i] = gst;
-        // the summary: the rare events are counted, "somebody was submitted" is a flag (most waves find it set already)
-        if (!ent) atomicAdd(&a.summary->n_unknown_identity, 1u);
-        if (outline_differs) atomicAdd(&a.summary->n_outline_differs, 1u);
-        if (general) atomicAdd(&a.summary->n_general_der, 1u);
-        if (submit && !keyed) {
-            // ("somebody of this class has no comb table" is all the host asks: one atomic per class is enough once it is known)
-            uint32_t* c = creator ? &a.summary->n_unkeyed_creator : &a.summary->n_unkeyed_other;
-            if (__builtin_nontemporal_load(c) == 0) atomicAdd(c, 1u);
-        }
-        if (submit && __builtin_nontemporal_load(&a.summary->n_submitted) == 0) atomicOr(&a.summary->n_submitted, 1u);
-    }
-}
-
-// One wavefront per tuple whose identity the table did not hold (everybody else leaves at once): decode the certificate, put the key
-// into the tuple's row, offer the identity to the provider's cache.
-__global__ void __launch_bounds__(64) walk_idfix_kernel(WalkArrays a) {
-    __shared__ uint8_t lds[IDFIX_MAX_DIGITS];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t i = blockIdx.x;
-    if (i >= a.n_tuples || a.id_idx[i] != 0xFFFFFFFFu) return;
-    const BlockTuple t = a.tuples[i];
-    uint32_t key_byte = 0;
-    uint8_t code = IDC_NOT;
-    if (t.identity.off <= a.arena_len && t.identity.len <= a.arena_len - t.identity.off)
-        code = wave_identity_to_p256(a.block + t.identity.off, t.identity.len, lane, lds, key_byte);
-    if (code == IDC_P256) {
-        const uint32_t row = a.row_of[i];
-        (lane < 32 ? a.qx : a.qy)[32 * (size_t)row + (lane & 31u)] = (uint8_t)key_byte;
-        if (lane == 0) a.id_idx[i] = 0xFFFFFFFEu;
-    } else if (lane == 0) {
-        if (code == IDC_UNDECIDED) atomicAdd(&a.summary->n_undecided, 1u);
-        a.gate_st[i] = bccsp::TUPLE_ST_NEEDS_SW;
-    }
-    if (code == IDC_P256 || code == IDC_NOT) {
-        // Offer it to the provider's cache (the host route caches what it decodes, keys and "this certificate has no P-256 key" alike;
-        // identities without a certificate block - a fresh idemix pseudonym per transaction - would only churn it): one slot per table
-        // hash (the lookup's hash, recomputed from the same row of bytes); whoever names the same identity after the slot's owner counts
-        // as a hit - a comb table is earned by being named often.
-        const uint32_t m = t.identity.len < 64 ? t.identity.len : 64;
-        uint64_t h = 0xCBF29CE484222325ull;
-        if (lane < m) h = bccsp::walk::id_stream_fold(h, a.block[t.identity.off + t.identity.len - m + lane]);
-        uint64_t term = h * bccsp::walk::id_stream_const(lane);
-        for (int o = 32; o >= 1; o >>= 1) {
-            const uint32_t lo32 = __shfl_xor((uint32_t)term, o, 64), hi32 = __shfl_xor((uint32_t)(term >> 32), o, 64);
-            term += ((uint64_t)hi32 << 32) | lo32;
-        }
-        const uint64_t tag = bccsp::walk::id_hash_finish(term, t.identity.len) | 1ull;
-        WalkLearn* slot = a.learn + ((uint32_t)(tag >> 17) & (WALK_LEARN_SLOTS - 1));
-        uint32_t mine = 0;
-        if (lane == 0) {
-            const unsigned long long old = atomicCAS((unsigned long long*)&slot->tag, 0ull, (unsigned long long)tag);
-            mine = old == 0ull ? 1u : 0u;
-            if (old == (unsigned long long)tag) atomicAdd(&slot->hits, 1u);
-        }
-        mine = __shfl(mine, 0, 64);
-        if (mine) {
-            (lane < 32 ? slot->qx : slot->qy)[lane & 31u] = (uint8_t)key_byte;
-            if (lane == 0) {
-                slot->off = t.identity.off;
-                slot->len = t.identity.len;
-                atomicAdd(&slot->hits, 1u);
-                __threadfence();
-                slot->ready = code == IDC_P256 ? 1u : 2u;
-                atomicAdd(&a.summary->n_learn, 1u);
-            }
-        }
+        // What the summary wants to know about this tuple travels as a byte; walk_status_kernel turns the bytes into one atomic per
+        // WAVEFRONT.  (An atomic per tuple on the summary's words - ten thousand unknown creators, ten thousand increments of one
+        // address - serialises at the memory side: the gate kernel took 1.6 ms instead of 0.15, and the hash kernels beside it 1 ms.)
+        a.tflags[i] = (uint8_t)((submit ? TF_SUBMIT : 0) | (keyed ? TF_KEYED : 0) | (unknown ? TF_UNKNOWN : 0) | (general ? TF_GENERAL : 0) |
+                                (outline_differs ? TF_OUTLINE : 0) | (undecided ? TF_UNDECIDED : 0));
     }
 }
 
@@ -511,11 +519,26 @@ __global__ void __launch_bounds__(256) walk_status_kernel(WalkArrays a) {
         if (st != FABGPU_ST_VALID && t.tx < a.n_env)                     // block-level tuples (orderer signatures) do not flag a transaction
             atomicOr(&a.tx_mask[t.tx], st == bccsp::TUPLE_ST_NEEDS_SW ? M_SW : (t.kind == bccsp::TUPLE_CREATOR ? M_BAD_CREATOR : M_BAD_END));
     }
-    // how many tuples each launch class decided (the provider reports how many went through registered comb tables)
+    // The summary, one atomic per wavefront and word: how many tuples each launch class decided (the provider reports how many went
+    // through registered comb tables), and what the gate and identity kernels noted per tuple.
+    const uint8_t tf = live ? a.tflags[i] : 0;
     const uint64_t hc = __ballot(hashed && creator), ho = __ballot(hashed && !creator);
+    const uint64_t unk = __ballot((tf & TF_UNKNOWN) != 0), und = __ballot((tf & TF_UNDECIDED) != 0), gen = __ballot((tf & TF_GENERAL) != 0),
+                   outl = __ballot((tf & TF_OUTLINE) != 0), sub = __ballot((tf & TF_SUBMIT) != 0),
+                   ukc = __ballot((tf & (TF_SUBMIT | TF_KEYED)) == TF_SUBMIT && creator), uko = __ballot((tf & (TF_SUBMIT | TF_KEYED)) == TF_SUBMIT && !creator);
     if ((threadIdx.x & 63u) == 0) {
-        if (hc) atomicAdd(&a.summary->n_hashed_creator, (uint32_t)__builtin_popcountll(hc));
-        if (ho) atomicAdd(&a.summary->n_hashed_other, (uint32_t)__builtin_popcountll(ho));
+        auto add = [](uint32_t* w, uint64_t m) {
+            if (m) atomicAdd(w, (uint32_t)__builtin_popcountll(m));
+        };
+        add(&a.summary->n_hashed_creator, hc);
+        add(&a.summary->n_hashed_other, ho);
+        add(&a.summary->n_unknown_identity, unk);
+        add(&a.summary->n_undecided, und);
+        add(&a.summary->n_general_der, gen);
+        add(&a.summary->n_outline_differs, outl);
+        add(&a.summary->n_submitted, sub);
+        add(&a.summary->n_unkeyed_creator, ukc);
+        add(&a.summary->n_unkeyed_other, uko);
     }
 }
 
@@ -576,11 +599,6 @@ hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st) {
     if (a.n_tuples == 0) return hipSuccess;
     hipLaunchKernelGGL(walk_gate_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);   // four wavefronts = four tuples per workgroup
-    return hipGetLastError();
-}
-hipError_t launch_walk_idfix(const WalkArrays& a, hipStream_t st) {
-    if (a.n_tuples == 0) return hipSuccess;
-    hipLaunchKernelGGL(walk_idfix_kernel, dim3(a.n_tuples), dim3(64), 0, st, a);                // one wavefront = one workgroup = one tuple
     return hipGetLastError();
 }
 hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st) {

@@ -158,10 +158,11 @@ struct fabgpu_ctx {
     Buf tailbuf;      // staging of an identity batch's tail when the arena itself bypasses the pinned buffer
     // the block pass on the device (block_walk_dev.h): per-envelope arrays, per-tuple arrays, pinned staging for what travels, and
     // the table of identities the provider has met (slots | entries | bytes in one allocation, swapped whole under mu)
-    DevBuf walk_env, walk_tup;
+    DevBuf walk_env, walk_tup, idtab_buf;
     PinBuf walk_pin;
     void* d_idtab = nullptr;
     uint32_t idtab_n = 0, idtab_mask = 0;
+    uint64_t idtab_seed = 0;
     // Which verify kernels the pass queues BEFORE it knows what the gates found (one host round trip less): the keyed ones for a launch
     // class (creators / everybody else) whose tuples all had comb tables in the previous pass, the fresh-key ones - always correct, the
     // key travels in the row - otherwise.  A wrong "keyed" guess is repaired by launching that class again (walk_block_pass).
@@ -346,7 +347,7 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->walk_env.release();
         ctx->walk_tup.release();
         ctx->walk_pin.release();
-        if (ctx->d_idtab) hipFree(ctx->d_idtab);
+        ctx->idtab_buf.release();
         for (auto& sl : ctx->staged_slots)
             if (sl.d) hipFree(sl.d);
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
@@ -1227,7 +1228,7 @@ int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b
 // ------------------------------------------------------------------------------------------------
 namespace fab {
 
-int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const uint8_t* bytes, size_t nbytes) {
+int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const uint8_t* bytes, size_t nbytes, uint64_t seed) {
     if (!ctx || (n && (!entries || !bytes))) return FABGPU_EINVAL;
     if (n > (1u << 20) || nbytes > 0x7FFFFFF0ull) return FABGPU_ETOOBIG;
     uint32_t cap = 16;
@@ -1235,26 +1236,35 @@ int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const
     std::vector<uint32_t> slots(cap, 0);
     for (uint32_t i = 0; i < n; i++) {
         if ((uint64_t)entries[i].off + entries[i].len > nbytes) return FABGPU_EINVAL;
-        uint32_t at = (uint32_t)entries[i].hash & (cap - 1);
-        while (slots[at]) at = (at + 1) & (cap - 1);
-        slots[at] = i + 1;
+        uint32_t at = (uint32_t)entries[i].hash & (cap - 1), d = 0;
+        while (slots[at] && d < bccsp::walk::WALK_ID_PROBE_MAX) {
+            at = (at + 1) & (cap - 1);
+            d++;
+        }
+        if (d < bccsp::walk::WALK_ID_PROBE_MAX) slots[at] = i + 1;     // (else: left out - the lookup would not walk that far either)
     }
     const size_t eo = round_up((size_t)cap * 4, 256), bo = round_up(eo + (size_t)n * sizeof(DevIdEntry), 256), total = bo + round_up(nbytes, 64) + 64;
+    // The table lives in ONE grow-only allocation that is overwritten in place (it used to be a fresh hipMalloc per version with a
+    // hipFree of the old one: a provider whose cache changes with every block - new clients - paid both before every pass).
+    std::lock_guard<std::mutex> lk(ctx->mu);             // no pass is in flight while mu is held (a pass synchronises before it returns)
     DeviceGuard g(ctx->device);
-    void* d = nullptr;
-    if (ctx->fault == 2 || hipMalloc(&d, total) != hipSuccess) return FABGPU_ENOMEM;
+    if (ctx->fault == 2) return FABGPU_ENOMEM;
+    int rc = ctx->idtab_buf.ensure(total);
+    if (rc != FABGPU_OK) return rc;
+    void* d = ctx->idtab_buf.d;
     hipError_t err = hipMemcpy(d, slots.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
     if (err == hipSuccess && n) err = hipMemcpy((uint8_t*)d + eo, entries, (size_t)n * sizeof(DevIdEntry), hipMemcpyHostToDevice);
     if (err == hipSuccess && nbytes) err = hipMemcpy((uint8_t*)d + bo, bytes, nbytes, hipMemcpyHostToDevice);
     if (err != hipSuccess) {
-        hipFree(d);
+        ctx->d_idtab = nullptr;                          // (half-written: the device treats everybody as unknown until the next table)
+        ctx->idtab_n = 0;
+        ctx->idtab_mask = 0;
         return hip_to_rc(err);
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);             // no pass is in flight while mu is held (a pass synchronises before it returns)
-    if (ctx->d_idtab) hipFree(ctx->d_idtab);
     ctx->d_idtab = d;
     ctx->idtab_n = n;
     ctx->idtab_mask = cap - 1;
+    ctx->idtab_seed = seed;
     ctx->idtab_entries_off = eo;
     ctx->idtab_bytes_off = bo;
     return FABGPU_OK;
@@ -1423,7 +1433,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_off = carve((size_t)nt * 8), o_pix = carve((size_t)nt * 4), o_kid = carve((size_t)nt * 4), o_qx = carve((size_t)nt * 32),
                  o_qy = carve((size_t)nt * 32), o_r = carve((size_t)nt * 32), o_s = carve((size_t)nt * 32), o_gst = carve(nt), o_bits = carve(words * 8),
                  o_dst = carve(nt), o_tst = carve(nt), o_hsh = carve(nt), o_dig = carve((size_t)nt * 32), o_mid = carve(((size_t)np + 1) * 32),
-                 o_row = carve((size_t)nt * 4), o_bitc = carve(words * 8), o_tdig = carve((size_t)nt * 32), o_cspan = carve(((size_t)tot.creators + 1) * 8),
+                 o_row = carve((size_t)nt * 4), o_bitc = carve(words * 8), o_tdig = carve((size_t)nt * 32), o_cspan = carve(((size_t)tot.creators + 1) * 8), o_tfl = carve(nt),
                  o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
@@ -1440,6 +1450,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.key_id = (uint32_t*)(dt + o_kid);
     a.qx = dt + o_qx; a.qy = dt + o_qy; a.r = dt + o_r; a.s = dt + o_s;
     a.gate_st = dt + o_gst;
+    a.tflags = dt + o_tfl;
     a.row_of = (uint32_t*)(dt + o_row);
     a.creator_spans = (uint32_t*)(dt + o_cspan);
     a.n_dev_tuples = tot.tuples;
@@ -1469,6 +1480,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (ctx->d_idtab) {
         a.id_slots = (const uint32_t*)ctx->d_idtab;
         a.id_mask = ctx->idtab_mask;
+        a.id_seed = ctx->idtab_seed;
         a.id_entries = (const DevIdEntry*)((uint8_t*)ctx->d_idtab + ctx->idtab_entries_off);
         a.id_bytes = (uint8_t*)ctx->d_idtab + ctx->idtab_bytes_off;
     }
@@ -1578,7 +1590,6 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
     }
     if (err == hipSuccess) err = launch_walk_gate(a, st);
-    if (err == hipSuccess) err = launch_walk_idfix(a, st);             // identities the table lacks: certificate -> key, on the device
     if (err != hipSuccess) return hip_to_rc(err);
     // What the gates found decides which kernels SHOULD run per launch class - registered comb tables when every submitted tuple of the
     // class has one, keys carried in the rows otherwise - and whether this pass may answer at all.  Neither is waited for: the launches
@@ -1700,7 +1711,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                     return rc;
             }
             err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
-            if (err == hipSuccess) err = hipMemsetAsync(&a.summary->n_hashed_creator, 0, 8, st);
+            if (err == hipSuccess) err = hipMemsetAsync(a.summary, 0, offsetof(WalkSummary, n_learn), st);   // (the status kernel adds them up again)
             if (err == hipSuccess) err = launch_walk_flags(a, nc, st);
             fetch_all();
             if (err == hipSuccess) err = hipStreamSynchronize(st);

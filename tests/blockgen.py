@@ -67,7 +67,8 @@ def fresh_identities(n: int, seed: int, mspid: str = "Org1MSP"):
     out = []
     for _ in range(n):
         d32 = b"\x00" + bytes(rng.integers(1, 255, size=31, dtype=np.uint8))
-        out.append((bb.serialized_identity(mspid, _pem_wrap(der[:at] + _pubkey(d32) + der[at + 64:])), d32))
+        # (another key, and - as a certificate a CA really issued would have - another signature value: its last 20 bytes)
+        out.append((bb.serialized_identity(mspid, _pem_wrap(der[:at] + _pubkey(d32) + der[at + 64:-20] + bytes(rng.integers(1, 255, size=20, dtype=np.uint8)))), d32))
     return out
 
 
@@ -135,6 +136,20 @@ def split_envelopes(block: bytes):
         if num == 2:
             envs = [v2 for n2, v2 in fields(v) if n2 == 1]
     return number, envs
+
+
+def pack_envelopes(envs) -> bytes:
+    """a list of envelopes as one byte string (u32 length prefixes): what tools/make_bench_blocks.py stores for the blocks it patches together"""
+    return b"".join(len(e).to_bytes(4, "little") + e for e in envs)
+
+
+def unpack_envelopes(b: bytes):
+    out, i = [], 0
+    while i < len(b):
+        n = int.from_bytes(b[i:i + 4], "little")
+        out.append(b[i + 4:i + 4 + n])
+        i += 4 + n
+    return out
 
 
 # ---- signature encodings only Go's asn1 package and the general parser agree on (bccsp/utils/ecdsa.go:43-67) -----------------------

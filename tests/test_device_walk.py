@@ -291,18 +291,23 @@ def _identity_cases():
 
 
 def test_identity_table_hash_restated():
-    """The table hash covers the length and the last 64 bytes (one coalesced row for a wavefront: lane l folds byte l); equality is
-    always decided on all the bytes, so the hash only has to spread the identities a provider meets."""
+    """The table hash covers the length, the last 64 bytes and 64 bytes spread over the whole string (two coalesced rows for a
+    wavefront: lane l folds byte l of the tail and byte l * len / 64); equality is always decided on all the bytes, so the hash only has
+    to spread the identities a provider meets - including ones that share their last 64 bytes."""
     M = (1 << 64) - 1
 
     def restated(b):
-        tail = b[-64:] if len(b) >= 64 else b
+        m = min(len(b), 64)
         total = 0
         for lane in range(64):
             h = 0xCBF29CE484222325
-            if lane < len(tail):
-                h = ((h ^ tail[lane]) * 0x100000001B3) & M
-            total = (total + h * (((0x9E3779B97F4A7C15 * (2 * lane + 1)) & M) | 1)) & M
+            if lane < m:
+                h = ((h ^ b[len(b) - m + lane]) * 0x100000001B3) & M
+            if len(b):
+                h = ((h ^ b[(lane * len(b)) >> 6]) * 0x100000001B3) & M
+            h ^= h >> 31
+            h = (h * (((0x9E3779B97F4A7C15 * (2 * lane + 1)) & M) | 1)) & M
+            total = (total + (h ^ (h >> 29))) & M
         h = total ^ ((len(b) * 0xD6E8FEB86659FD93) & M)
         h ^= h >> 32
         h = (h * 0xD6E8FEB86659FD93) & M
@@ -314,9 +319,16 @@ def test_identity_table_hash_restated():
         assert fabgpu.identity_table_hash(b) == restated(b)
         seen.add(fabgpu.identity_table_hash(b))
     assert len(seen) == 10
-    # the identities of the fixtures (certificates: their signatures end differently) all hash apart
+    # the identities of the fixtures all hash apart, and so do re-keyed copies of ONE certificate that share their last 64 bytes
     ids = [bb.serialized_identity("Org1MSP", i["pem"]) for i in IDS]
     assert len({fabgpu.identity_table_hash(i) for i in ids}) == len(ids)
+    base = bytearray(ids[0])
+    twins = set()
+    for k in range(500):
+        t = bytearray(base)
+        t[300:386] = bytes(rng.integers(65, 91, size=86, dtype=np.uint8))      # the 86 base64 characters a 64-byte public key takes
+        twins.add(fabgpu.identity_table_hash(bytes(t)))
+    assert len(twins) == 500                                               # (half a dozen of them are among the spread bytes)
 
 
 # ---- GPU -----------------------------------------------------------------------------------------------------------------------
@@ -685,8 +697,8 @@ def test_device_route_big_block_caps_and_concurrency(csp, monkeypatch):
 
 def _bench_block(n_tx):
     """a block of n_tx endorser transactions with VALID signatures: the pre-built bench block when it travelled along
-    (tools/make_bench_blocks.py ecdsa 10000 0), else signed here with the C oracle"""
-    path = os.path.join(ROOT, ".bench_blocks", "ecdsa_10000_0.bin")
+    (tools/make_bench_blocks.py passlegs 10000 0), else signed here with the C oracle"""
+    path = os.path.join(ROOT, ".bench_blocks", "friendly_10000.bin")
     if n_tx == 10000 and os.path.exists(path):
         return open(path, "rb").read()
     import ctypes

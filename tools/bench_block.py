@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--block-file", help="a marshalled block made by tools/make_bench_blocks.py (all signatures valid) instead of building one here")
     ap.add_argument("--idemix", action="store_true", help="register the fixtures' IdemixMSP1 first (blocks of make_bench_blocks.py idemix ...)")
     ap.add_argument("--tables", type=int, default=256, help="device comb tables the identity cache may build (6 signers: fewer than 6 leaves newcomers on the fresh-key path)")
+    ap.add_argument("--register-after", type=int, default=1, help="an identity earns its comb table after being named this often (the provider's default: 64)")
     args = ap.parse_args()
     import numpy as np
 
@@ -63,7 +64,7 @@ def main():
         assert csp.idemix_msp_register("IdemixMSP1", raw_ipk) >= 0
     if args.block_file:
         args.tx = fabgpu.block_parse(blk)["n_tx"]
-    csp._L.fabgpu_csp_identity_cache_limits(csp._h, 4096, args.tables, 1)
+    csp._L.fabgpu_csp_identity_cache_limits(csp._h, 4096, args.tables, args.register_after)
     out = fabgpu.preverify_block(csp, blk)
     n_keyed = fabgpu.preverify_block2(csp, blk, lean=True)["n_keyed"]
     assert (out["tx_flags"] == 0).all() and len(out["tuple_status"]) == 4 * args.tx

@@ -2,7 +2,10 @@
 """Pre-builds the blocks of the block-pass benches on the CPU (the signing is pure Python / C oracle and needs no GPU): written to
 .bench_blocks/ at the repo root - git-ignored, but it travels to the GPU box with the snapshot - so that GPU-minutes are not spent
 signing.      python tools/make_bench_blocks.py idemix 10000 5     -> .bench_blocks/idemix_10000_5.bin (every 5th creator idemix)
-              python tools/make_bench_blocks.py ecdsa 10000 0      -> .bench_blocks/ecdsa_10000_0.bin  (x509 creators only)"""
+              python tools/make_bench_blocks.py ecdsa 10000 0      -> .bench_blocks/ecdsa_10000_0.bin  (x509 creators only)
+              python tools/make_bench_blocks.py passlegs 10000 0   -> the blocks of bench.py's block_pass legs (tests/blockgen.py):
+                  friendly_10000.bin (six signers), distinct_10000.bin (every creator a certificate nobody has met),
+                  fresh1pct_10000.bin (10 x 1 % envelopes by never-seen creators, patched into the friendly block at bench time)"""
 import ctypes
 import hashlib
 import json
@@ -23,7 +26,19 @@ from idemix_common import be32, fixtures   # noqa: E402
 
 def main():
     kind, ntx, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    assert kind in ("idemix", "ecdsa")
+    assert kind in ("idemix", "ecdsa", "passlegs")
+    if kind == "passlegs":
+        import blockgen
+        os.makedirs(os.path.join(ROOT, ".bench_blocks"), exist_ok=True)
+        per_block = max(1, ntx // 100)
+        for name, build in (("friendly_%d.bin" % ntx, lambda: blockgen.endorser_block(ntx, 1)[0]),
+                            ("distinct_%d.bin" % ntx, lambda: blockgen.endorser_block(ntx, 3, creators=blockgen.fresh_identities(ntx, 4))[0]),
+                            ("fresh1pct_%d.bin" % ntx, lambda: blockgen.pack_envelopes(
+                                blockgen.endorser_block(10 * per_block, 5, creators=blockgen.fresh_identities(10 * per_block, 6))[1]))):
+            out = os.path.join(ROOT, ".bench_blocks", name)
+            open(out, "wb").write(build())
+            print(out, os.path.getsize(out))
+        return
     ids = [i for i in json.load(open(os.path.join(ROOT, "tests", "golden", "block_identities.json")))["identities"] if i["curve"] == "prime256v1"]
     sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in ids]
     L = coracle.lib()
