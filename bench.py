@@ -203,6 +203,7 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
         before = fabgpu.pass_routes(csp)
         per, decoded = [], []
         for k, b in enumerate(blocks):
+            b = bytes(bytearray(b))                            # a peer's blocks arrive in memory the runtime has not seen: never re-send a buffer
             c0 = time.perf_counter()
             r = fabgpu.preverify_block2(csp, b, block_seq=1000 + k, seed_memo=memo, lean=True)
             per.append((time.perf_counter() - c0) * 1e3)
@@ -233,9 +234,11 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
             import threading
             n_callers, per_caller = 3, 8
 
+            copies = [[bytes(bytearray(blk)) for _ in range(per_caller)] for _ in range(n_callers)]
+
             def caller(t):
                 for k in range(per_caller):
-                    fabgpu.preverify_block2(csp, blk, block_seq=10000 * (t + 1) + k, lean=True)
+                    fabgpu.preverify_block2(csp, copies[t][k], block_seq=10000 * (t + 1) + k, lean=True)
             th = [threading.Thread(target=caller, args=(t,)) for t in range(n_callers)]
             c0 = time.perf_counter()
             for t in th:
@@ -290,6 +293,8 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
     return {"metric": "validated tx/s per block, marshalled block in, flags out (block-level pre-verify pass)", **legs,
             "config": {"workload": "%d endorser tx x (1 creator + 3 endorsement signatures + TxID + proposal hash), %.1f MB block; friendly legs: 6 signers with device "
                                    "tables; unfriendly legs: see block_pass_leg" % (n_tx, len(blk) / 1e6)},
+            "buffers": "every timed pass gets a fresh copy of its block (a block a peer receives sits in memory the HIP runtime has never seen; re-sending one "
+                       "buffer, as earlier rounds' benches did, lets the runtime reuse its pinning and flatters a pageable upload by ~1 ms per 50 MB)",
             "parity": "every transaction valid (crafted leg: exactly the crafted one flagged); a flipped payload byte fails exactly its transaction "
                       "(reference ledgers, corrupted blocks, route equality: tests/)"}
 

@@ -325,6 +325,19 @@ bool OutlineBlock(const uint8_t* block, size_t len, ParsedBlock& out, std::vecto
     PbField f;
     while (r.next(f)) {
         if (f.num != 1 || f.wt != 2) continue;                        // common.BlockData{1 repeated bytes data}
+        // This loop is a chain of dependent cache misses (where envelope i + 1 starts is written at the start of envelope i), and a
+        // block that has just arrived is in nobody's cache: ~100 ns per envelope, 1 ms for 10 000.  Transactions of one block tend to
+        // be of similar size, so the lines where the NEXT few envelopes would start if they were as long as this one are requested
+        // now (a wrong guess costs nothing but the request): 0.75-1.3 ms -> the chain runs out of the cache.
+        {
+            const uint8_t* guess = f.data + f.len;
+            const size_t step = f.len + 3;
+            for (int k = 0; k < 6; k++, guess += step)
+                if (guess + 128 < block + len) {
+                    __builtin_prefetch(guess);
+                    __builtin_prefetch(guess + 64);
+                }
+        }
         env_spans.push_back((uint32_t)(f.data - block));
         env_spans.push_back((uint32_t)f.len);
         if (payload_spans) {

@@ -8,15 +8,18 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fabgpu.h"
 #include "kernels.h"
 #include "block_walk_dev.h"
+#include "worker_pool.h"
 #include "bn_tables29.h"
 #include "p256_tables29.h"
 
@@ -159,6 +162,9 @@ struct fabgpu_ctx {
     // the block pass on the device (block_walk_dev.h): per-envelope arrays, per-tuple arrays, pinned staging for what travels, and
     // the table of identities the provider has met (slots | entries | bytes in one allocation, swapped whole under mu)
     DevBuf walk_env, walk_tup, idtab_buf;
+    PinBuf stage_pin;                // fabgpu_arena_stage: pinned staging of arenas that arrive in pageable memory
+    std::mutex stage_pin_mu;
+    hipStream_t stream_copy = nullptr;
     PinBuf walk_pin;
     void* d_idtab = nullptr;
     uint32_t idtab_n = 0, idtab_mask = 0;
@@ -290,6 +296,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
         if (hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         if (hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
+        if (hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         {
             bool ok = true;
             for (auto& e : ctx->ev_w) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -337,6 +344,8 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         if (ctx->ev_up) hipEventDestroy(ctx->ev_up);
         if (ctx->stream3) hipStreamDestroy(ctx->stream3);
         if (ctx->stream4) hipStreamDestroy(ctx->stream4);
+        if (ctx->stream_copy) hipStreamDestroy(ctx->stream_copy);
+        ctx->stage_pin.release();
         for (auto& e : ctx->ev_w)
             if (e) hipEventDestroy(e);
         ctx->gath.release();
@@ -931,9 +940,67 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
         if (hipMalloc(&sl->d, need + need / 8 + (64 << 10)) != hipSuccess) return FABGPU_ENOMEM;
         sl->cap = need + need / 8 + (64 << 10);
     }
-    hipError_t err = hipMemcpy(sl->d, arena, len, hipMemcpyHostToDevice);
+    // A block arrives in memory the runtime has never seen (a peer's blocks are fresh allocations): a pageable hipMemcpy of such
+    // memory spends more time making the pages DMA-able than moving them - 50 MB took 2.0-2.5 ms against 0.9 ms for a buffer that was
+    // sent before, which the runtime keeps pinned (tools/gpu_probe_fresh_buffers.py).  Arenas of 4 MiB and more therefore travel
+    // through a pinned staging buffer the context owns: a few threads copy 2 MiB pieces into it and queue each piece's DMA as soon as
+    // it is there (FABGPU_STAGE_THREADS, default 4; 0 = the runtime's pageable path): 2.2 ms per 10 000-transaction pass whatever the
+    // buffer's history, against 2.9-3.9 ms (fresh) / 1.85 ms (re-sent, which a peer never does) on the pageable path.  Splitting the pageable copy itself over threads
+    // was measured too: slower than one call (the pinning serialises in the driver).
+    static const bool stage_timing = getenv("FABGPU_PASS_TIMING") != nullptr;
+    const auto stage_t0 = std::chrono::steady_clock::now();
+    static const int stage_threads = [] { const char* e = getenv("FABGPU_STAGE_THREADS"); int v = e ? atoi(e) : 4; return v < 0 ? 0 : (v > 16 ? 16 : v); }();
+    hipError_t err = hipSuccess;
+    if (stage_threads == 0 || len < ((size_t)4 << 20)) {
+        err = hipMemcpy(sl->d, arena, len, hipMemcpyHostToDevice);
+    } else {
+        std::lock_guard<std::mutex> plk(ctx->stage_pin_mu);              // one staging buffer: uploads share the bus anyway
+        if (ctx->fault == 2 || ctx->stage_pin.ensure(len) != FABGPU_OK) return FABGPU_ENOMEM;
+        // pieces: 256 KiB, 512 KiB, 1 MiB, then 2 MiB each - the first DMA starts after 25 us of copying instead of 200
+        std::vector<size_t> cut;
+        static const size_t max_piece = [] { const char* e = getenv("FABGPU_STAGE_PIECE_KB"); size_t v = e ? (size_t)atoi(e) : 2048; return (v < 256 ? 256 : v) << 10; }();
+        for (size_t at = 0, sz = (size_t)256 << 10; at < len; at += sz, sz = std::min(sz * 2, max_piece)) cut.push_back(at);
+        cut.push_back(len);
+        const size_t n_pieces = cut.size() - 1;
+        std::atomic<size_t> next(0);
+        std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[n_pieces]);
+        for (size_t k = 0; k < n_pieces; k++) done[k].store(0, std::memory_order_relaxed);
+        int failed = 0;
+        uint8_t* dst = (uint8_t*)sl->d;
+        uint8_t* pin = (uint8_t*)ctx->stage_pin.h;
+        const uint8_t* src = (const uint8_t*)arena;
+        hipStream_t cs = ctx->stream_copy;
+        const int dev = ctx->device;
+        // The copiers (the host side's worker pool: idle while a block travels) claim pieces in order; this thread queues a piece's DMA
+        // as soon as it is in the staging buffer - it alone talks to the runtime (several threads queueing on one stream spend their
+        // time on its lock) - and copies pieces itself while it has nothing to queue.
+        auto copy_one = [&]() -> bool {
+            const size_t k = next.fetch_add(1, std::memory_order_relaxed);
+            if (k >= n_pieces) return false;
+            memcpy(pin + cut[k], src + cut[k], cut[k + 1] - cut[k]);
+            done[k].store(1, std::memory_order_release);
+            return true;
+        };
+        const int nth = (int)std::min<size_t>((size_t)stage_threads, n_pieces);
+        run_workers(nth + 1, [&](int w) {
+            if (w != 0) {
+                while (copy_one()) {}
+                return;
+            }
+            hipSetDevice(dev);
+            for (size_t k = 0; k < n_pieces; k++) {
+                while (!done[k].load(std::memory_order_acquire))
+                    if (!copy_one()) std::this_thread::yield();
+                if (hipMemcpyAsync(dst + cut[k], pin + cut[k], cut[k + 1] - cut[k], hipMemcpyHostToDevice, cs) != hipSuccess) failed = 1;
+            }
+        });
+        err = hipStreamSynchronize(cs);
+        if (err == hipSuccess && failed) err = hipErrorUnknown;
+    }
     if (err == hipSuccess) err = hipMemset((uint8_t*)sl->d + len, 0, need - len);
     if (err != hipSuccess) return hip_to_rc(err);
+    if (stage_timing)
+        fprintf(stderr, "fabgpu arena stage: %.1f MB in %.2f ms\n", len / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - stage_t0).count());
     sl->len = len;
     uint64_t t;
     {

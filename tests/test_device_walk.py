@@ -531,10 +531,16 @@ def test_device_route_serves_what_it_used_to_decline(csp, monkeypatch):
     assert (dev["tx_flags"] == want1).all() and dev["n_device_decoded"] == len(dev["tuple_status"]) > 100
     _same(host, dev, KEYS_ALL)
     r = fabgpu.pass_routes(csp)
-    assert r["learned"] == 7 and r["device_decoded"] == len(dev["tuple_status"])          # 6 P-256 signers + the P-384 certificate
-    dev2, _ = _both_routes(csp, monkeypatch, first, 20)
-    assert dev2["n_device_decoded"] == 0 and (dev2["tx_flags"] == want1).all()             # ... and are known from then on
-    _same(dev, dev2, KEYS_ALL)
+    # 6 P-256 signers + the P-384 certificate enter the cache (one slot per table hash - keyed per provider - so two of them may meet
+    # in a slot and the loser is learned from the next block)
+    assert 5 <= r["learned"] <= 7 and r["device_decoded"] == len(dev["tuple_status"])
+    for k in range(3):
+        dev2, _ = _both_routes(csp, monkeypatch, first, 20 + 2 * k)
+        assert (dev2["tx_flags"] == want1).all()
+        _same(dev, dev2, KEYS_ALL)
+        if dev2["n_device_decoded"] == 0:
+            break
+    assert dev2["n_device_decoded"] == 0 and fabgpu.pass_routes(csp)["learned"] == 7        # ... and are known from then on
     garbage, want2 = build_block(60, rng)                                   # carries garbage DER (and everything else)
     dev3, host3 = _both_routes(csp, monkeypatch, garbage, 30)
     assert (dev3["tx_flags"] == want2).all()
