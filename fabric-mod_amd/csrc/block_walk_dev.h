@@ -133,13 +133,30 @@ struct WalkArrays {
     uint8_t* tx_flags = nullptr;
 };
 
-hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st);                       // counts, tx_type, tx_understood; then the scan
+// Where the kernels write what the HOST waits for: pinned, host-mapped memory (device pointers to it), each block of results closed by a
+// 32-bit flag that takes the pass's sequence number once everything before it is visible to the host.  The host polls the flag instead
+// of queueing device-to-host copies and synchronising the stream: a copy command plus a stream wake-up is ~40 us per round trip and
+// a pass used to end with six of them (profiles/r02_device_walk_timeline.txt: 652 -> 714 us, and 81 -> 119 us for the totals).
+struct WalkHostOut {
+    uint32_t* flag = nullptr;             // <- seq when the arrays below are complete
+    uint32_t seq = 0;
+    uint32_t* done = nullptr;             // DEVICE memory: workgroups of the last kernel that have finished (zeroed per pass)
+    WalkSummary* summary = nullptr;
+    WalkLearn* learn = nullptr;           // WALK_LEARN_SLOTS
+    uint8_t *tx_flags = nullptr, *tx_type = nullptr, *tx_understood = nullptr;   // n_env each
+    uint8_t *tuple_status = nullptr, *tuple_hashed = nullptr;                    // n_tuples each
+    uint32_t* id_idx = nullptr;                                                  // n_tuples
+};
+// counts, tx_type, tx_understood; then the scan, which also writes the totals to host_totals and then seq to host_flag (host-mapped)
+hipError_t launch_walk_count(const WalkArrays& a, WalkTotals* host_totals, uint32_t* host_flag, uint32_t seq, hipStream_t st);
 hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st);   // tuples, prefixes, checks, gather spans / offsets
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);                        // identity lookup / certificate decode + gates + submission arrays
 // TEST HOOK: the device's identity decoder over n SerializedIdentity byte strings (spans = (start, end) pairs into arena) -> code
 // (0 P-256 key, 1 not such an identity, 2 undecided), key (64 bytes each, zero unless code == 0)
 hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st);
-hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st);
+hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st);   // tuple statuses + digest comparisons (one launch)
+// per-transaction flags and everything the host reads, written to host-mapped memory; the last workgroup raises h.flag
+hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStream_t st);
 hipError_t launch_walk_creator_digests(const WalkArrays& a, void* row_digests, hipStream_t st);   // digest_env -> the creators' digest rows
 // TEST HOOK: the wavefront form of the signature gate over n signatures (device pointers; spans = (start, end) pairs into arena)
 hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spans, void* code, void* r, void* s, hipStream_t st);    // statuses, digest comparisons, per-transaction flags

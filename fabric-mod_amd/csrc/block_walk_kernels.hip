@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(64) walk_count_kernel(WalkArrays a) {
 // Exclusive prefix sums of the per-envelope counts: ONE workgroup (10 000 envelopes are ten per thread; the block-wide part is a
 // 1024-entry Hillis-Steele scan in LDS).
 __global__ void __launch_bounds__(1024) walk_scan_kernel(uint32_t n, const uint4* __restrict__ counts, uint4* __restrict__ bases, uint32_t* __restrict__ cbase,
-                                                         WalkTotals* __restrict__ totals) {
+                                                         WalkTotals* __restrict__ totals, WalkTotals* __restrict__ host_totals, uint32_t* __restrict__ host_flag,
+                                                         uint32_t seq) {
     __shared__ uint32_t st[1024], sp[1024], sc[1024], sk[1024];
     __shared__ uint64_t sg[1024];
     const uint32_t tid = threadIdx.x;
@@ -81,6 +82,15 @@ __global__ void __launch_bounds__(1024) walk_scan_kernel(uint32_t n, const uint4
         totals->checks = sc[1023];
         totals->creators = sk[1023];
         totals->gather_bytes = sg[1023];
+        if (host_totals) {                                         // the host sizes everything else from these: it polls host_flag
+            host_totals->tuples = st[1023];
+            host_totals->prefixes = sp[1023];
+            host_totals->checks = sc[1023];
+            host_totals->creators = sk[1023];
+            host_totals->gather_bytes = sg[1023];
+            __threadfence_system();
+            __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -478,8 +488,7 @@ __global__ void __launch_bounds__(256) walk_creator_digest_kernel(WalkArrays a, 
 // per-transaction evidence bits
 enum : uint32_t { M_BAD_CREATOR = 1, M_BAD_END = 2, M_SW = 4, M_BAD_TXID = 8, M_BAD_PHASH = 16 };
 
-__global__ void __launch_bounds__(256) walk_status_kernel(WalkArrays a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i) {
     const bool live = i < a.n_tuples;
     uint8_t hashed = 0;
     bool creator = false;
@@ -543,8 +552,7 @@ __global__ void __launch_bounds__(256) walk_status_kernel(WalkArrays a) {
 }
 
 // does the digest equal what the block says (block_prepass.cpp HashCheckMatches: lowercase hex for the TxID, raw bytes for the proposal hash)
-__global__ void __launch_bounds__(256) walk_checks_kernel(WalkArrays a, uint32_t n_checks) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void walk_checks_part(const WalkArrays& a, uint32_t n_checks, uint32_t j) {
     if (j >= n_checks) return;
     const BlockHashCheck hc = a.checks[j];
     const uint8_t* d = a.gather_digests + 32 * (size_t)j;
@@ -563,32 +571,74 @@ __global__ void __launch_bounds__(256) walk_checks_kernel(WalkArrays a, uint32_t
     if (!ok && hc.tx < a.n_env) atomicOr(&a.tx_mask[hc.tx], hc.kind == bccsp::HASH_TXID ? M_BAD_TXID : M_BAD_PHASH);
 }
 
-// in the order ValidateTransaction and then VSCC would reject (PreVerifyParsed): not understood > bad creator signature > bad TxID >
-// bad proposal hash > bad endorsement > "ask bccsp/sw" > all valid
-__global__ void __launch_bounds__(256) walk_txflags_kernel(WalkArrays a) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.n_env) return;
-    const uint32_t m = a.tx_mask[t];
-    uint8_t f;
-    if (!a.tx_understood[t]) f = bccsp::TX_NOT_UNDERSTOOD;
-    else if (m & M_BAD_CREATOR) f = bccsp::TX_BAD_CREATOR_SIGNATURE;
-    else if (m & M_BAD_TXID) f = bccsp::TX_BAD_TXID;
-    else if (m & M_BAD_PHASH) f = bccsp::TX_BAD_PROPOSAL_HASH;
-    else if (m & M_BAD_END) f = bccsp::TX_BAD_ENDORSEMENT;
-    else if (m & M_SW) f = bccsp::TX_NEEDS_SW;
-    else f = bccsp::TX_ALL_SIGNATURES_VALID;
-    a.tx_flags[t] = f;
+// statuses (workgroups [0, ceil(n_tuples / 256))) and digest comparisons (the workgroups behind them) as ONE launch: both only feed tx_mask
+__global__ void __launch_bounds__(256) walk_status_checks_kernel(WalkArrays a, uint32_t n_checks, uint32_t status_blocks) {
+    if (blockIdx.x < status_blocks) walk_status_part(a, blockIdx.x * blockDim.x + threadIdx.x);
+    else walk_checks_part(a, n_checks, (blockIdx.x - status_blocks) * blockDim.x + threadIdx.x);
+}
+
+// The last kernel of a pass: the flag of every transaction - in the order ValidateTransaction and then VSCC would reject
+// (PreVerifyParsed): not understood > bad creator signature > bad TxID > bad proposal hash > bad endorsement > "ask bccsp/sw" > all
+// valid - and everything the host reads, stored straight into host-mapped memory (WalkHostOut: four bytes per lane, coalesced rows
+// over PCIe); the workgroup that finishes last raises the flag the host polls.
+__global__ void __launch_bounds__(256) walk_finish_kernel(WalkArrays a, WalkHostOut h) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t0 = 4 * j;
+    if (t0 < a.n_env) {
+        uint32_t packed = 0;
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t t = t0 + k;
+            uint8_t f = 0;
+            if (t < a.n_env) {
+                const uint32_t m = a.tx_mask[t];
+                if (!a.tx_understood[t]) f = bccsp::TX_NOT_UNDERSTOOD;
+                else if (m & M_BAD_CREATOR) f = bccsp::TX_BAD_CREATOR_SIGNATURE;
+                else if (m & M_BAD_TXID) f = bccsp::TX_BAD_TXID;
+                else if (m & M_BAD_PHASH) f = bccsp::TX_BAD_PROPOSAL_HASH;
+                else if (m & M_BAD_END) f = bccsp::TX_BAD_ENDORSEMENT;
+                else if (m & M_SW) f = bccsp::TX_NEEDS_SW;
+                else f = bccsp::TX_ALL_SIGNATURES_VALID;
+                a.tx_flags[t] = f;
+            }
+            packed |= (uint32_t)f << (8 * k);
+        }
+        // (the byte arrays are padded to 256 bytes on both sides: whole dwords may be read and written)
+        reinterpret_cast<uint32_t*>(h.tx_flags)[j] = packed;
+        reinterpret_cast<uint32_t*>(h.tx_type)[j] = reinterpret_cast<const uint32_t*>(a.tx_type)[j];
+        reinterpret_cast<uint32_t*>(h.tx_understood)[j] = reinterpret_cast<const uint32_t*>(a.tx_understood)[j];
+    }
+    if (t0 < a.n_tuples) {
+        reinterpret_cast<uint32_t*>(h.tuple_status)[j] = reinterpret_cast<const uint32_t*>(a.tuple_status)[j];
+        reinterpret_cast<uint32_t*>(h.tuple_hashed)[j] = reinterpret_cast<const uint32_t*>(a.tuple_hashed)[j];
+        for (uint32_t k = 0; k < 4; k++)
+            if (t0 + k < a.n_tuples) h.id_idx[t0 + k] = a.id_idx[t0 + k];
+    }
+    if (blockIdx.x == 0) {
+        const uint32_t* ls = reinterpret_cast<const uint32_t*>(a.learn);
+        uint32_t* ld = reinterpret_cast<uint32_t*>(h.learn);
+        for (uint32_t w = threadIdx.x; w < sizeof(WalkLearn) * WALK_LEARN_SLOTS / 4; w += blockDim.x) ld[w] = ls[w];
+        if (threadIdx.x < sizeof(WalkSummary) / 4) reinterpret_cast<uint32_t*>(h.summary)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.summary)[threadIdx.x];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t before = atomicAdd(h.done, 1u);
+        if (before == gridDim.x - 1) {
+            __threadfence_system();
+            __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace
 
-hipError_t launch_walk_count(const WalkArrays& a, hipStream_t st) {
+hipError_t launch_walk_count(const WalkArrays& a, WalkTotals* host_totals, uint32_t* host_flag, uint32_t seq, hipStream_t st) {
     if (a.n_env) {
         hipLaunchKernelGGL(walk_count_kernel, dim3((a.n_env + 63) / 64), dim3(64), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, st, a.n_env, (const uint4*)a.counts, a.bases, a.cbase, a.totals);
+    hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, st, a.n_env, (const uint4*)a.counts, a.bases, a.cbase, a.totals, host_totals, host_flag, seq);
     return hipGetLastError();
 }
 hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_t st) {
@@ -617,21 +667,16 @@ hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spa
                        (uint8_t*)s);
     return hipGetLastError();
 }
-hipError_t launch_walk_flags(const WalkArrays& a, uint32_t n_checks, hipStream_t st) {
-    hipError_t e = hipSuccess;
-    if (a.n_tuples) {
-        hipLaunchKernelGGL(walk_status_kernel, dim3((a.n_tuples + 255) / 256), dim3(256), 0, st, a);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess && n_checks) {
-        hipLaunchKernelGGL(walk_checks_kernel, dim3((n_checks + 255) / 256), dim3(256), 0, st, a, n_checks);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess && a.n_env) {
-        hipLaunchKernelGGL(walk_txflags_kernel, dim3((a.n_env + 255) / 256), dim3(256), 0, st, a);
-        e = hipGetLastError();
-    }
-    return e;
+hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st) {
+    const uint32_t sb = (a.n_tuples + 255) / 256, cb = (n_checks + 255) / 256;
+    if (sb + cb == 0) return hipSuccess;
+    hipLaunchKernelGGL(walk_status_checks_kernel, dim3(sb + cb), dim3(256), 0, st, a, n_checks, sb);
+    return hipGetLastError();
+}
+hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStream_t st) {
+    const uint32_t most = a.n_env > a.n_tuples ? a.n_env : a.n_tuples;
+    hipLaunchKernelGGL(walk_finish_kernel, dim3(most ? (most + 1023) / 1024 : 1), dim3(256), 0, st, a, h);
+    return hipGetLastError();
 }
 
 }  // namespace fab

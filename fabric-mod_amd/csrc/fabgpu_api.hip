@@ -68,11 +68,12 @@ struct DevBuf {  // growable device-only buffer
 struct PinBuf {  // growable pinned host buffer
     void* h = nullptr;
     size_t cap = 0;
+    unsigned flags = hipHostMallocDefault;
     int ensure(size_t bytes) {
         if (bytes <= cap) return FABGPU_OK;
         release();
         size_t want = bytes + bytes / 4 + 256;
-        if (hipHostMalloc(&h, want, hipHostMallocDefault) != hipSuccess) { h = nullptr; return FABGPU_ENOMEM; }
+        if (hipHostMalloc(&h, want, flags) != hipSuccess) { h = nullptr; return FABGPU_ENOMEM; }
         cap = want;
         return FABGPU_OK;
     }
@@ -166,6 +167,9 @@ struct fabgpu_ctx {
     std::mutex stage_pin_mu;
     hipStream_t stream_copy = nullptr;
     PinBuf walk_pin;
+    // what the pass's kernels write for the HOST (block_walk_dev.h WalkHostOut): pinned, mapped, coherent - the host polls flags in it
+    PinBuf walk_map;
+    uint32_t walk_seq = 0;
     void* d_idtab = nullptr;
     uint32_t idtab_n = 0, idtab_mask = 0;
     uint64_t idtab_seed = 0;
@@ -285,6 +289,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     fabgpu_ctx* ctx = new (std::nothrow) fabgpu_ctx();
     if (!ctx) return FABGPU_ENOMEM;
     ctx->device = dev;
+    ctx->walk_map.flags = hipHostMallocMapped | hipHostMallocCoherent;
     ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
     ctx->allow_quad = !(cfg && (cfg->flags & FABGPU_FLAG_NO_QUAD));
     ctx->time_kernels = cfg && (cfg->flags & FABGPU_FLAG_TIME_KERNELS);
@@ -356,6 +361,7 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->walk_env.release();
         ctx->walk_tup.release();
         ctx->walk_pin.release();
+        ctx->walk_map.release();
         ctx->idtab_buf.release();
         for (auto& sl : ctx->staged_slots)
             if (sl.d) hipFree(sl.d);
@@ -1388,6 +1394,22 @@ int walk_idfix_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t a
     return rc;
 }
 
+namespace {
+// The host's side of a WalkHostOut flag: poll the mapped word until the kernel has stored `seq` (everything it wrote before is then
+// visible).  Every ~50 us the stream is asked whether it has drained: a drained stream without the flag is a launch that failed.
+int wait_host_flag(const uint32_t* flag, uint32_t seq, hipStream_t st) {
+    for (uint32_t spin = 1;; spin++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return FABGPU_OK;
+        if ((spin & 0x3FFu) == 0) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq ? FABGPU_OK : FABGPU_ELAUNCH;
+            if (q != hipErrorNotReady) return hip_to_rc(q);
+        }
+        __builtin_ia32_pause();
+    }
+}
+}  // namespace
+
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (!ctx || !rq.sizes || !rq.env_spans || rq.stage_token == 0) return FABGPU_EINVAL;
     if (rq.n_block_sigs && !rq.block_sigs) return FABGPU_EINVAL;
@@ -1420,7 +1442,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     auto carve = [&](size_t bytes) { size_t at = o; o = round_up(o + bytes, 256); return at; };
     const size_t o_env = carve((size_t)ne * 8), o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_tot = carve(sizeof(WalkTotals)),
                  o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
-                 o_cbase = carve((size_t)ne * 4), o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS);
+                 o_cbase = carve((size_t)ne * 4), o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS), o_done = carve(64);
     // The creators' messages are whole envelope payloads - the longest hashes of a block, a serial chain per message, and for a
     // block of a few hundred transactions THE critical path (300 tx: the chain is 240 us of a 600 us device phase).  With the host's
     // outline of where they are they start before anything is walked, beside the walk's two runs and the gates.
@@ -1429,8 +1451,13 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     int rc;
     if ((rc = ctx->walk_env.ensure(o))) return rc;
     // pinned staging: env (and payload) spans up, totals / summary down (the result arrays are sized further down)
-    const size_t p_env = 0, p_pay = round_up((size_t)ne * 8, 64), p_tot = p_pay + round_up(early_hash ? (size_t)ne * 8 : 0, 64), p_sum = p_tot + 64, p_first = p_sum + 64;
+    const size_t p_env = 0, p_pay = round_up((size_t)ne * 8, 64), p_first = p_pay + round_up(early_hash ? (size_t)ne * 8 : 0, 64);
     if ((rc = ctx->walk_pin.ensure(p_first))) return rc;
+    // host-mapped results: [0, 64) the totals' flag, [64, 128) the totals, [128, 192) the final flag, [192, 256) the summary; the arrays follow
+    constexpr size_t m_totflag = 0, m_tot = 64, m_finflag = 128, m_sum = 192, m_arrays = 256;
+    if ((rc = ctx->walk_map.ensure(m_arrays + sizeof(WalkLearn) * WALK_LEARN_SLOTS + 3 * round_up(ne, 64) + ((size_t)8 << 10)))) return rc;
+    if (++ctx->walk_seq == 0) ++ctx->walk_seq;
+    const uint32_t seq_tot = ctx->walk_seq;
     uint8_t* de = (uint8_t*)ctx->walk_env.d;
     WalkArrays a;
     a.block = (const uint8_t*)sl->d;
@@ -1454,7 +1481,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     struct Drain2 {                                                         // (an early exit must not leave the hashes running)
         hipStream_t s;
         bool* busy;
-        ~Drain2() { if (*busy) hipStreamSynchronize(s); }
+        bool armed = true;
+        ~Drain2() { if (armed && *busy) hipStreamSynchronize(s); }
     } drain2{ctx->stream2, &s2_busy};
     if (err == hipSuccess && early_hash) {
         a.payload_spans = (const uint32_t*)(de + o_pay);
@@ -1478,11 +1506,17 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (err == hipSuccess) err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
     if (err == hipSuccess) err = hipMemsetAsync(de + o_sum, 0, sizeof(WalkSummary), st);
     if (err == hipSuccess) err = hipMemsetAsync(de + o_learn, 0, sizeof(WalkLearn) * WALK_LEARN_SLOTS, st);
-    if (err == hipSuccess) err = launch_walk_count(a, st);
-    if (err == hipSuccess) err = hipMemcpyAsync((uint8_t*)ctx->walk_pin.h + p_tot, de + o_tot, sizeof(WalkTotals), hipMemcpyDeviceToHost, st);
-    if (err == hipSuccess) err = hipStreamSynchronize(st);
-    if (err != hipSuccess) return hip_to_rc(err);
-    const WalkTotals tot = *(const WalkTotals*)((uint8_t*)ctx->walk_pin.h + p_tot);
+    if (err == hipSuccess) err = hipMemsetAsync(de + o_done, 0, 64, st);
+    {
+        uint8_t* mh = (uint8_t*)ctx->walk_map.h;
+        void* md = nullptr;
+        if (err == hipSuccess) err = hipHostGetDevicePointer(&md, mh, 0);
+        if (err == hipSuccess) err = launch_walk_count(a, (WalkTotals*)((uint8_t*)md + m_tot), (uint32_t*)((uint8_t*)md + m_totflag), seq_tot, st);
+        if (err != hipSuccess) return hip_to_rc(err);
+        // the one thing the host must know before it can go on - how many tuples, prefixes, checks - arrives in mapped memory
+        if ((rc = wait_host_flag((const uint32_t*)(mh + m_totflag), seq_tot, st))) return rc;
+    }
+    const WalkTotals tot = *(const WalkTotals*)((uint8_t*)ctx->walk_map.h + m_tot);
     if (tot.gather_bytes > 0x7FFFFFF0ull) return decline("gathered hash inputs exceed 2 GiB");
     const uint64_t nt64 = (uint64_t)tot.tuples + rq.n_block_sigs;
     if (nt64 > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
@@ -1554,15 +1588,34 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // pinned room for everything that comes back
     size_t po = p_first;
     auto pin = [&](size_t bytes) { size_t at = po; po = round_up(po + bytes, 64); return at; };
-    const size_t p_flags = pin(ne), p_type = pin(ne), p_und = pin(ne), p_tst = pin(nt), p_hsh = pin(nt), p_tup = pin((size_t)nt * sizeof(bccsp::BlockTuple)),
-                 p_idx = pin((size_t)nt * 4), p_dig = pin((size_t)nt * 32), p_pre = pin(((size_t)np + 1) * 8), p_chk = pin(((size_t)nc + 1) * sizeof(bccsp::BlockHashCheck)),
-                 p_sigs = pin((size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple) + 64), p_qxy = pin(out.tuple_qxy ? (size_t)nt * 64 : 0),
-                 p_learn = pin(sizeof(WalkLearn) * WALK_LEARN_SLOTS);
+    const size_t p_type = pin(ne), p_und = pin(ne), p_tup = pin((size_t)nt * sizeof(bccsp::BlockTuple)), p_dig = pin((size_t)nt * 32),
+                 p_pre = pin(((size_t)np + 1) * 8), p_chk = pin(((size_t)nc + 1) * sizeof(bccsp::BlockHashCheck)),
+                 p_sigs = pin((size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple) + 64), p_qxy = pin(out.tuple_qxy ? (size_t)nt * 64 : 0);
     {
         // (growing the pinned buffer moves it: nothing above is still needed from the old one)
         if ((rc = ctx->walk_pin.ensure(po))) return rc;
     }
     uint8_t* ph = (uint8_t*)ctx->walk_pin.h;
+    // ... and mapped room for what the last kernel writes itself (flags, statuses, identity indices, learn records, summary)
+    size_t mo = m_arrays;
+    auto mapped = [&](size_t bytes) { size_t at = mo; mo = round_up(mo + bytes, 64); return at; };
+    const size_t m_learn = mapped(sizeof(WalkLearn) * WALK_LEARN_SLOTS), m_flags = mapped(ne), m_type = mapped(ne), m_und = mapped(ne), m_tst = mapped(nt),
+                 m_hsh = mapped(nt), m_idx = mapped((size_t)nt * 4);
+    if ((rc = ctx->walk_map.ensure(mo))) return rc;                        // (may move it: the totals above have been read)
+    uint8_t* mh = (uint8_t*)ctx->walk_map.h;
+    WalkHostOut ho;
+    {
+        void* md = nullptr;
+        if (hipHostGetDevicePointer(&md, mh, 0) != hipSuccess) return FABGPU_ELAUNCH;
+        uint8_t* m8 = (uint8_t*)md;
+        ho.flag = (uint32_t*)(m8 + m_finflag);
+        ho.done = (uint32_t*)(de + o_done);
+        ho.summary = (WalkSummary*)(m8 + m_sum);
+        ho.learn = (WalkLearn*)(m8 + m_learn);
+        ho.tx_flags = m8 + m_flags; ho.tx_type = m8 + m_type; ho.tx_understood = m8 + m_und;
+        ho.tuple_status = m8 + m_tst; ho.tuple_hashed = m8 + m_hsh;
+        ho.id_idx = (uint32_t*)(m8 + m_idx);
+    }
     err = launch_walk_emit(a, tot, st);
     if (err == hipSuccess && rq.n_block_sigs) {
         memcpy(ph + p_sigs, rq.block_sigs, (size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple));
@@ -1602,7 +1655,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     hipStream_t s2 = ctx->stream2, s3 = ctx->stream3, s4 = ctx->stream4;
     struct Drain {
         hipStream_t a, b, c, d;
+        bool armed = true;
         ~Drain() {
+            if (!armed) return;
             hipStreamSynchronize(a);
             hipStreamSynchronize(b);
             hipStreamSynchronize(c);
@@ -1717,18 +1772,22 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     };
     bool keyed_c = ctx->pred_keyed_creators && nkeys != 0, keyed_o = ctx->pred_keyed_others && nkeys != 0;
     if (!a.split) keyed_c = keyed_o = keyed_c && keyed_o;                  // one launch serves both classes
-    auto fetch_all = [&] {
-        fetch(out.tx_flags, p_flags, a.tx_flags, ne);
-        fetch(out.tx_type, p_type, a.tx_type, ne);
-        fetch(out.tx_understood, p_und, a.tx_understood, ne);
-        fetch(out.tuple_status, p_tst, a.tuple_status, nt);
-        fetch(out.tuple_hashed, p_hsh, a.tuple_hashed, nt);
+    // the end of a pass on the main stream: statuses and digest comparisons, the big optional arrays as copies (tuple records, digests,
+    // keys: only a caller that seeds the memo or wants spans asks for them), then the kernel that writes the small results into mapped
+    // memory and raises the flag - behind the copies, so the flag covers them too
+    auto finish = [&]() -> int {
+        if (++ctx->walk_seq == 0) ++ctx->walk_seq;
+        ho.seq = ctx->walk_seq;
+        if (err == hipSuccess) err = launch_walk_status_checks(a, nc, st);
         fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
-        fetch(out.id_idx, p_idx, a.id_idx, (size_t)nt * 4);
         fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
         fetch(out.tuple_qxy, p_qxy, dt + o_tqxy, (size_t)nt * 64);
-        fetch(ph, p_learn, de + o_learn, sizeof(WalkLearn) * WALK_LEARN_SLOTS);
-        fetch(ph, p_sum, de + o_sum, sizeof(WalkSummary));
+        if (err == hipSuccess) err = launch_walk_finish(a, ho, st);
+        if (err != hipSuccess) return hip_to_rc(err);
+        int r2 = wait_host_flag((const uint32_t*)(mh + m_finflag), ho.seq, st);
+        if (r2 != FABGPU_OK) return r2;
+        rq.summary = *(const WalkSummary*)(mh + m_sum);
+        return FABGPU_OK;
     };
     if (np) err = hipStreamWaitEvent(st, ctx->ev_w[1], 0);               // the mid-states (long done: they ran beside the gates)
     if (err != hipSuccess) return hip_to_rc(err);
@@ -1746,11 +1805,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if ((rc = verify_rows(0, nt, np != 0, ctx->allow_pair, keyed_o, dt + o_bits, st))) return rc;
     }
     if (err == hipSuccess && nc) err = hipStreamWaitEvent(st, ctx->ev_w[2], 0);
-    if (err == hipSuccess) err = launch_walk_flags(a, nc, st);
-    fetch_all();
-    if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err != hipSuccess) return hip_to_rc(err);
-    rq.summary = *(const WalkSummary*)(ph + p_sum);
+    if ((rc = finish())) return rc;
     if (rq.summary.n_outline_differs) return decline("the walker's creator message is not the span the outline named");
     if (rq.summary.n_undecided) return decline("a certificate beyond the device decoder's buffer");
     if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
@@ -1779,26 +1835,29 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             }
             err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
             if (err == hipSuccess) err = hipMemsetAsync(a.summary, 0, offsetof(WalkSummary, n_learn), st);   // (the status kernel adds them up again)
-            if (err == hipSuccess) err = launch_walk_flags(a, nc, st);
-            fetch_all();
-            if (err == hipSuccess) err = hipStreamSynchronize(st);
+            if (err == hipSuccess) err = hipMemsetAsync(de + o_done, 0, 64, st);
             if (err != hipSuccess) return hip_to_rc(err);
-            rq.summary = *(const WalkSummary*)(ph + p_sum);
+            if ((rc = finish())) return rc;
         }
     }
     rq.keyed_creators = keyed_c;
     rq.keyed_others = keyed_o;
     rq.ms_verify = ms_since(t_verify);
-    deliver(out.tx_flags, p_flags, ne);
-    deliver(out.tx_type, p_type, ne);
-    deliver(out.tx_understood, p_und, ne);
-    deliver(out.tuple_status, p_tst, nt);
-    deliver(out.tuple_hashed, p_hsh, nt);
+    auto from_map = [&](void* host_dst, size_t map_off, size_t bytes) {
+        if (host_dst && bytes) memcpy(host_dst, mh + map_off, bytes);
+    };
+    from_map(out.tx_flags, m_flags, ne);
+    from_map(out.tx_type, m_type, ne);
+    from_map(out.tx_understood, m_und, ne);
+    from_map(out.tuple_status, m_tst, nt);
+    from_map(out.tuple_hashed, m_hsh, nt);
+    from_map(out.id_idx, m_idx, (size_t)nt * 4);
+    from_map(rq.learn_out, m_learn, sizeof(WalkLearn) * WALK_LEARN_SLOTS);
     deliver(out.tuples, p_tup, (size_t)nt * sizeof(bccsp::BlockTuple));
-    deliver(out.id_idx, p_idx, (size_t)nt * 4);
     deliver(out.tuple_digest, p_dig, (size_t)nt * 32);
     deliver(out.tuple_qxy, p_qxy, (size_t)nt * 64);
-    deliver(rq.learn_out, p_learn, sizeof(WalkLearn) * WALK_LEARN_SLOTS);
+    drain.armed = false;                                                    // (the flag was raised behind everything: all four streams are idle)
+    drain2.armed = false;
     return FABGPU_OK;
 }
 
