@@ -23,7 +23,12 @@ Same JSON line, outside that timed region (SURVEY.md 8(d) "Timing protocol", VER
                   SHA-256 + verify (fabgpu_sha256_p256_verify_batch_dev), with its own roofline
   cpu_baseline    N = 1 only: OpenSSL 3 libcrypto driven like bccsp/sw (the reference's Go path cannot be built here):
                   single thread (BASELINE configs[0]) and the best of a thread sweep up to all host cores
-  roofline / valu_roofline   HBM view as the contract asks, and the integer-ALU fraction north_star asks for
+  configs4_mixed  N = 1 only: BASELINE.json configs[4] on one GPU - 24 000 P-256 tuples + 6 000 idemix pseudonym signatures
+                  (FP256BN, creators only), two streams, both verdict bitmaps checked against the oracles
+  roofline        the bound that governs this path: integer multiply-accumulate issue ("integer VALU throughput, not HBM
+                  and not MFMA"), priced against a ceiling MEASURED IN THIS RUN - every SIMD issuing independent v_mad_i64_i32
+                  for >= 5 ms (sustained: the power budget decides the clock), with the 40-130 us burst ceiling of earlier rounds
+                  beside it; the HBM view the contract's format names is the sub-object roofline.hbm
 The oracle (oracle/) is used only as the checker and as the cpu_baseline leg, never inside a timed region.
 """
 import argparse
@@ -163,6 +168,108 @@ def inprocess_multi_leg(world):
         return {"error": "timeout after 240 s"}
     except Exception as e:                                          # never let this leg cost the line
         return {"error": repr(e)}
+
+
+def mac_ceiling_leg():
+    """The integer multiply-accumulate ceiling of THIS box, sustained: gputest_mac_ceiling (csrc/gputest.hip) keeps every SIMD issuing
+    independent v_mad_i64_i32 for >= 5 ms at 1, 2 and 4 wavefronts per SIMD; the shader clock it ran at = s_memtime ticks / wall."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "fabric-mod_amd", "lib", "libfabgpu_gputest.so"))
+    lib.gputest_mac_ceiling.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
+    legs = {}
+    for wps, iters in ((1, 40000), (2, 26000), (4, 15000)):
+        out = (ctypes.c_double * 4)()
+        rc = lib.gputest_mac_ceiling(wps, iters, out)
+        if rc != 0:
+            raise RuntimeError("gputest_mac_ceiling rc=%d" % rc)
+        ms, ticks, macs, waves = out[0], out[1], out[2], out[3]
+        legs["%d_waves_per_simd" % wps] = {"mac_per_s": macs / (ms * 1e-3), "kernel_ms": ms, "shader_clock_ghz": ticks / (ms * 1e-3) / 1e9,
+                                            "cycles_per_instruction_per_wave": ticks / (iters * 64.0), "wavefronts": int(waves)}
+    best = max(v["mac_per_s"] for v in legs.values())
+    return {"peak_mac_per_s": best, **legs,
+            "what": "every SIMD issuing 4-8 independent v_mad_i64_i32 chains (64 lanes x 32x32->64 MAC each) for >= 5 ms; wall clock by HIP events"}
+
+
+def mixed_cfg4_leg(torch, np, fabgpu, coracle, steps=20, n=30000, msg_len=4608, base=192):
+    """BASELINE.json configs[4] on ONE GPU: a mixed batch, 80 % ECDSA P-256 tuples (fresh keys, as the headline) and 20 % idemix
+    pseudonym signatures (FP256BN NymSignature.Ver, idemix/nymsignature.go:74-109; idemix identities are creators only), inputs
+    resident in HBM, the two kernels on two HIP streams per step.  Every timed input's verdicts are compared with the oracles'."""
+    import random
+    sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+    import idemix_oracle as io
+    from idemix_common import NymBatch, be32, fixtures
+    fx = fixtures()
+    ctx = fabgpu.Context(device=0, max_batch=n)
+    try:
+        issuers = []
+        for name in ("MSP1OU1", "MSP2OU1"):
+            ipk = fx[name]["ipk"]
+            ctx.idemix_issuer_register((be32(ipk.h_sk[0]), be32(ipk.h_sk[1])), (be32(ipk.h_rand[0]), be32(ipk.h_rand[1])), ipk.hash)
+            issuers.append((ipk, fx[name]["signer"].sk))
+        n_nym = n // 5
+        n_ec = n - n_nym
+        rng = random.Random(SEED)
+        nb = NymBatch()
+        for i in range(base):                                  # `base` signatures signed by the oracle (1 % tampered), replicated to n_nym
+            k = i % 2
+            ipk, sk = issuers[k]
+            nym, r_nym = io.make_nym(sk, ipk, rng)
+            msg = bytes(rng.getrandbits(8) for _ in range(msg_len))
+            sig = io.nym_sign(sk, nym, r_nym, ipk, msg, rng)
+            if i % 100 == 99:
+                msg = msg[:-1] + bytes([msg[-1] ^ 1])
+            nb.add(k, ipk, nym, sig, msg)
+        arena, off, iid, cols, expect = nb.arrays()
+        pick = np.random.default_rng(1).integers(0, base, size=n_nym)
+        lens = (off[1:] - off[:-1])[pick]
+        off2 = np.zeros(n_nym + 1, dtype=np.uint32)
+        off2[1:] = np.cumsum(lens)
+        arena2 = np.concatenate([arena[off[i]:off[i + 1]] for i in pick])
+        d_arena = torch.from_numpy(arena2).cuda()
+        d_off = torch.from_numpy(off2.view(np.int32)).cuda()
+        d_iid = torch.from_numpy(iid[pick].view(np.int32)).cuda()
+        d_cols = [torch.from_numpy(c[pick]).cuda() for c in cols]
+        d_words_nym = torch.zeros((n_nym + 63) // 64, dtype=torch.int64, device="cuda")
+        want_nym = expect[pick] == 0
+        b = fabgpu.synth_batch(n_ec, seed=SEED, invalid_permille=10)
+        d_ec = {k: torch.from_numpy(b[k]).cuda() for k in ("qx", "qy", "e", "r", "s")}
+        d_words_ec = torch.zeros((n_ec + 63) // 64, dtype=torch.int64, device="cuda")
+        want_ec = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"]) == 0
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+        def step_nym(st):
+            ctx.idemix_nym_verify_batch_dev(n_nym, d_arena.data_ptr(), d_arena.numel(), d_off.data_ptr(), d_iid.data_ptr(), *[c.data_ptr() for c in d_cols],
+                                            d_words_nym.data_ptr(), 0, st.cuda_stream)
+
+        def step_ec(st):
+            ctx.p256_verify_batch_dev(n_ec, d_ec["qx"].data_ptr(), d_ec["qy"].data_ptr(), d_ec["e"].data_ptr(), d_ec["r"].data_ptr(), d_ec["s"].data_ptr(),
+                                      d_words_ec.data_ptr(), 0, st.cuda_stream)
+
+        def timed(fn):
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
+        dt_nym = timed(lambda: step_nym(s1))
+        dt_ec = timed(lambda: step_ec(s1))
+        dt_mix = timed(lambda: (step_ec(s1), step_nym(s2)))
+        got_nym = fabgpu.unpack_bits(d_words_nym.cpu().numpy().view(np.uint64), n_nym)
+        got_ec = fabgpu.unpack_bits(d_words_ec.cpu().numpy().view(np.uint64), n_ec)
+        assert (got_nym == want_nym).all(), "idemix verdicts differ from the oracle"
+        assert (got_ec == want_ec).all(), "ECDSA verdicts differ from the oracle"
+    finally:
+        ctx.close()
+    return {"workload": "BASELINE.json configs[4] on one GPU: %d ECDSA P-256 tuples (fresh keypair per signature) + %d idemix pseudonym signatures (FP256BN, %d-byte creator "
+                        "messages, 2 issuers), 1 %% invalid, inputs resident in HBM, the two kernels on two HIP streams per step" % (n_ec, n_nym, msg_len),
+            "value": n / dt_mix, "unit": "verifies/s", "ms_per_step": dt_mix * 1e3, "steps": steps,
+            "idemix_alone": {"n": n_nym, "verifies_per_s": n_nym / dt_nym, "ms_per_step": dt_nym * 1e3},
+            "ecdsa_alone": {"n": n_ec, "verifies_per_s": n_ec / dt_ec, "ms_per_step": dt_ec * 1e3},
+            "parity": "both verdict bitmaps bit-identical to the CPU oracles (oracle/idemix_oracle.py, oracle/p256_oracle.c) on the timed inputs",
+            "note": "the 8-GPU form shards both sub-batches by contiguous ranges exactly as configs2_strong does for P-256"}
 
 
 def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
@@ -536,6 +643,14 @@ def main():
             if n_tx == N_TX and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("traffic_gb_per_launch") * 1e9   # bytes per launch
                 break
+        mac_ceiling, mac_peak, mac_peak_what = None, VALU_PEAK_MAC, "the burst v_mad ceiling of earlier rounds (the sustained measurement was not taken)"
+        if extras:
+            try:
+                mac_ceiling = mac_ceiling_leg()
+                mac_peak = mac_ceiling["peak_mac_per_s"]
+                mac_peak_what = "MAC/s of every SIMD issuing independent v_mad_i64_i32 for >= 5 ms, the best of 1 / 2 / 4 wavefronts per SIMD, measured in this run on this box"
+            except Exception as e:                                                                     # noqa: BLE001
+                mac_ceiling = {"error": repr(e)[:200]}
         ms_per_step = dt / args.steps * 1e3
         total = n * world
         value = total / (dt / args.steps)
@@ -554,20 +669,32 @@ def main():
             "validated_tx_per_s": n_tx * world / (dt / args.steps),
             "dispersion": {"median_ms": statistics.median(each), "p95_ms": pctl(each, 0.95), "min_ms": min(each), "iters": len(each),
                            "what": "fabgpu_p256_verify_batch_dev, inputs resident in HBM, one HIP event pair per launch"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (algorithmic: %d)" % int(ALGO_BYTES_PER_VERIFY * n),
+            "roofline": {"bound": "valu-mac", "achieved": n / kernel_s * MAC_PER_VERIFY, "peak": mac_peak, "unit": "MAC/s",
+                         "frac": n / kernel_s * MAC_PER_VERIFY / mac_peak,
+                         "traffic": traffic, "traffic_unit": "HBM bytes/launch from the PMC passes (algorithmic: %d)" % int(ALGO_BYTES_PER_VERIFY * n),
                          "kernel": "p256_verify_pair_kernel<256> (two lanes per signature)" if n <= 32768 else "p256_verify_kernel<256>", "kernel_ms": kernel_s * 1e3,
                          "kernel_ms_per_launch_events": kernel_ms,
-                         "note": "integer-VALU-bound, not HBM-bound (SURVEY 8(d)): see valu_roofline"},
+                         "model": "achieved = verifies/s x 3.1e5 u32 MACs per verify (SURVEY 8(d) canonical count: 4 512 field products x 64 + the mod-n reductions); "
+                                  "peak = " + mac_peak_what,
+                         "executed_mac_per_verify": EXECUTED_MAC_PER_VERIFY, "executed_frac": n / kernel_s * EXECUTED_MAC_PER_VERIFY / mac_peak,
+                         "frac_vs_burst_ceiling": n / kernel_s * MAC_PER_VERIFY / VALU_PEAK_MAC, "burst_ceiling_mac_per_s": VALU_PEAK_MAC,
+                         "sustained_ceiling": mac_ceiling,
+                         "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "note": "the contract's HBM view: 160.125 B per verify / kernel time; three orders of magnitude below the bound because the path "
+                                         "is integer-issue bound (SURVEY 8(d))"}},
             "valu_roofline": {"bound": "u32-mac", "achieved": n / kernel_s * MAC_PER_VERIFY, "peak": VALU_PEAK_MAC, "unit": "MAC/s",
                               "frac": n / kernel_s * MAC_PER_VERIFY / VALU_PEAK_MAC,
-                              "model": "3.1e5 u32 MACs per verify (SURVEY 8(d) canonical count); peak = measured v_mad_u64_u32 ceiling of csrc/ubench.hip",
+                              "model": "as rounds 1-2 reported it: 3.1e5 u32 MACs per verify against the BURST v_mad_u64_u32 ceiling of csrc/ubench.hip (kept for continuity; "
+                                       "roofline carries the sustained ceiling measured in this run)",
                               "executed_mac_per_verify": EXECUTED_MAC_PER_VERIFY,
                               "executed_frac": n / kernel_s * EXECUTED_MAC_PER_VERIFY / VALU_PEAK_MAC},
             "parity": "verdict bitmap bit-identical to generator ground truth on the timed input",
         }
         if strong is not None:
             out["configs2_strong"] = strong
+            # one block cut into N shards, beside the blocks-in-flight `value` (north_star: "the batch is split across the 8 GPUs")
+            out["value_one_block_sharded"] = strong["value"]
+            out["rccl_ranks"] = world if not dry else 0
             out["configs2_inprocess"] = inprocess_multi_leg(world)
         if extras:
             # PCIe-inclusive: the host-pointer ABI exactly as the cgo provider calls it (never `value`)
@@ -579,6 +706,7 @@ def main():
                 wall.append((time.perf_counter() - c0) * 1e3)
             assert (hb == got).all(), "host-pointer ABI verdicts differ"
             med = statistics.median(wall)
+            out["value_pcie_inclusive"] = n / (med * 1e-3)       # the host-pointer ABI a cgo provider calls (SURVEY 8(d) "Timing protocol": both are reported)
             out["pcie_inclusive"] = {"value": n / (med * 1e-3), "unit": "verifies/s", "median_ms": med, "p95_ms": pctl(wall, 0.95), "min_ms": min(wall), "iters": len(wall),
                                      "what": "fabgpu_p256_verify_batch (host pointers): 5 field copies into pinned staging + H2D 4.8 MB + kernel + D2H bitmap, "
                                              "wall clock around the blocking C-ABI call (through ctypes)"}
@@ -614,6 +742,10 @@ def main():
             out["parity"] = "verdict bitmap bit-identical to the CPU oracle and to OpenSSL on the timed input"
             if n_tx == N_TX:
                 out["configs3_fused"] = fused_cfg3_leg(ctx, torch, np, fabgpu, coracle, steps=10)
+                try:
+                    out["configs4_mixed"] = mixed_cfg4_leg(torch, np, fabgpu, coracle)
+                except Exception as e:                                                                     # noqa: BLE001
+                    out["configs4_mixed"] = {"error": repr(e)[:300]}
                 try:
                     out["block_pass"] = block_pass_leg(np, fabgpu, coracle)
                     # BASELINE's second metric ("validated tx/sec per block") as the provider delivers it: marshalled block in, flags out

@@ -276,3 +276,62 @@ extern "C" int gputest_nym_commitment(int split, uint32_t n, const uint8_t* hsk_
     hipFree(d1); hipFree(d2); hipFree(din); hipFree(dout); hipFree(dst); hipFree(dws);
     return rc;
 }
+
+// ---- the integer multiply-accumulate ceiling of this chip, SUSTAINED ---------------------------------------------------------------
+// What roofline.frac of the verify kernels is priced against (bench.py): every SIMD of the chip issuing nothing but independent
+// v_mad_i64_i32 - the instruction the field products are made of - for several milliseconds, at 1, 2 or 4 wavefronts per SIMD.  Short
+// bursts (ubench.hip: 40-130 us) run at the boost clock; a kernel that keeps the multiplier array busy for milliseconds runs at
+// whatever clock the power budget leaves, and that is the ceiling a 0.7 ms verify launch actually lives under.
+// Reports wall time (HIP events), the shader-clock ticks one wavefront counted (s_memtime) and the MACs retired.
+__global__ void __launch_bounds__(1024) gputest_mac_ceiling_kernel(uint32_t iters, uint32_t seed, uint64_t* __restrict__ ticks) {
+    int32_t a = (int32_t)(seed + threadIdx.x), b = (int32_t)(seed * 3 + 1);
+    int64_t x0 = a, x1 = b, x2 = a ^ 77, x3 = threadIdx.x, x4 = a + 1, x5 = b + 2, x6 = a + 3, x7 = b + 4;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (uint32_t it = 0; it < iters; it++) {
+#define MAC8 "v_mad_i64_i32 %0, s[10:11], %8, %9, %0\n v_mad_i64_i32 %1, s[10:11], %8, %9, %1\n v_mad_i64_i32 %2, s[10:11], %8, %9, %2\n v_mad_i64_i32 %3, s[10:11], %8, %9, %3\n" \
+             "v_mad_i64_i32 %4, s[10:11], %8, %9, %4\n v_mad_i64_i32 %5, s[10:11], %8, %9, %5\n v_mad_i64_i32 %6, s[10:11], %8, %9, %6\n v_mad_i64_i32 %7, s[10:11], %8, %9, %7\n"
+        asm volatile(MAC8 MAC8 MAC8 MAC8 MAC8 MAC8 MAC8 MAC8
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                     : "v"(a), "v"(b)
+                     : "s10", "s11");
+#undef MAC8
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    const uint64_t sink = (uint64_t)(x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7);
+    if ((threadIdx.x & 63) == 0) ticks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = (t1 - t0) + (sink == 0x1234567 ? 1 : 0);
+}
+
+// waves_per_simd in {1, 2, 4}; iters x 64 MAC instructions per wavefront.  out: [0] wall ms, [1] mean s_memtime ticks per wavefront,
+// [2] MACs retired (lanes x instructions), [3] wavefronts.  0 ok.
+extern "C" int gputest_mac_ceiling(int waves_per_simd, uint32_t iters, double* out4) {
+    if (!out4 || (waves_per_simd != 1 && waves_per_simd != 2 && waves_per_simd != 4)) return 1;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2;
+    const int cus = prop.multiProcessorCount, threads = 256 * waves_per_simd, waves = cus * 4 * waves_per_simd;
+    uint64_t* d = nullptr;
+    if (hipMalloc(&d, sizeof(uint64_t) * waves) != hipSuccess) return 3;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(gputest_mac_ceiling_kernel, dim3(cus), dim3(threads), 0, 0, iters / 16 + 1, 12345u, d);     // warm-up
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(gputest_mac_ceiling_kernel, dim3(cus), dim3(threads), 0, 0, iters, 12345u, d);
+    hipEventRecord(e1, 0);
+    int rc = hipEventSynchronize(e1) == hipSuccess ? 0 : 4;
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<uint64_t> h(waves);
+    if (rc == 0 && hipMemcpy(h.data(), d, sizeof(uint64_t) * waves, hipMemcpyDeviceToHost) != hipSuccess) rc = 5;
+    double sum = 0;
+    for (uint64_t v : h) sum += (double)v;
+    out4[0] = ms;
+    out4[1] = sum / waves;
+    out4[2] = (double)waves * 64.0 * 64.0 * (double)iters;
+    out4[3] = waves;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(d);
+    return rc;
+}
