@@ -395,6 +395,17 @@ int fabgpu_csp_memo_lookup(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* 
     if (!csp) return 1;
     return csp->csp->MemoLookup(qx32, qy32, sig, siglen, digest, dlen, status);
 }
+// the entry of an idemix pseudonym signature: bound to the issuer key (ipk.Hash, 32 bytes) the caller verifies under
+int fabgpu_csp_memo_lookup_nym(fabgpu_csp* csp, const uint8_t* issuer_hash32, const uint8_t* nym_x32, const uint8_t* nym_y32, const uint8_t* sig, size_t siglen,
+                               const uint8_t* digest, size_t dlen, uint8_t* status) {
+    if (!csp || !issuer_hash32) return 1;
+    return csp->csp->MemoLookup(nym_x32, nym_y32, sig, siglen, digest, dlen, status, issuer_hash32);
+}
+int fabgpu_csp_memo_has_block(fabgpu_csp* csp, uint64_t block_seq, uint64_t* entries) {
+    if (!csp || !entries) return FABGPU_EINVAL;
+    *entries = csp->csp->MemoHasBlock(block_seq);
+    return FABGPU_OK;
+}
 int fabgpu_csp_memo_evict_block(fabgpu_csp* csp, uint64_t block_seq, uint64_t* evicted) {
     if (!csp) return FABGPU_EINVAL;
     size_t g = csp->csp->MemoEvictBlock(block_seq);

@@ -589,7 +589,16 @@ Error GPUCSP::X509CheckSignatureBatch(size_t n, const uint8_t* cert_arena, const
 }
 
 // ---- verdict memo -------------------------------------------------------------------------------------------------------
-void GPUCSP::MemoKeyWrite(uint8_t* k, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) {
+void GPUCSP::MemoKeyWrite(uint8_t* k, const uint8_t* issuer_hash32, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,
+                          const uint8_t* digest, size_t dlen) {
+    // Domain first: 1 = ECDSA under the key (X, Y); 2 = idemix pseudonym signature under the ISSUER KEY whose ipk.Hash follows - a
+    // verdict about (Nym, signature, message) is only ever found again by a caller who names the same issuer (two channels may define
+    // one idemix MSP id with different issuer keys, and provider and memo are shared by all channels).
+    *k++ = issuer_hash32 ? 2 : 1;
+    if (issuer_hash32) {
+        memcpy(k, issuer_hash32, 32);
+        k += 32;
+    }
     memcpy(k, qx32, 32);
     memcpy(k + 32, qy32, 32);
     const uint32_t sl = (uint32_t)siglen, dl = (uint32_t)dlen;      // length framing: (sig || d[:k], d[k:]) must not collide with (sig, d)
@@ -607,11 +616,12 @@ uint64_t GPUCSP::MemoHash(const uint8_t* sig, size_t siglen, const uint8_t* dige
     uint64_t h = (a ^ (b * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
     return h ^ (h >> 32);
 }
-int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen, uint8_t* status) const {
+int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen, uint8_t* status,
+                       const uint8_t* issuer_hash32) const {
     if (!qx32 || !qy32 || !sig || !digest || siglen == 0 || dlen == 0 || siglen > 1024 || dlen > 1024) return 1;
-    uint8_t key[64 + 8 + 2048];
-    const size_t kl = MemoKeyBytes(siglen, dlen);
-    MemoKeyWrite(key, qx32, qy32, sig, siglen, digest, dlen);
+    uint8_t key[1 + 32 + 64 + 8 + 2048];
+    const size_t kl = MemoKeyBytes(siglen, dlen, issuer_hash32 != nullptr);
+    MemoKeyWrite(key, issuer_hash32, qx32, qy32, sig, siglen, digest, dlen);
     const uint64_t h = MemoHash(sig, siglen, digest, dlen);
     std::shared_lock<std::shared_timed_mutex> lk(memo_mu_);
     for (auto it = memo_blocks_.rbegin(); it != memo_blocks_.rend(); ++it) {      // newest block first
@@ -630,6 +640,13 @@ int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* 
     }
     memo_misses_.fetch_add(1, std::memory_order_relaxed);
     return 1;
+}
+size_t GPUCSP::MemoHasBlock(uint64_t block_seq) const {
+    std::shared_lock<std::shared_timed_mutex> lk(memo_mu_);
+    size_t n = 0;
+    for (const auto& b : memo_blocks_)
+        if (b->seq == block_seq) n += b->n;
+    return n;
 }
 size_t GPUCSP::MemoEvictBlock(uint64_t block_seq) const {
     std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
@@ -702,7 +719,16 @@ int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_r
     Error e = ic.IssuerKeyImport(ipk_raw, len, k);
     if (!e.ok()) return -1;
     std::lock_guard<std::mutex> lk(idmu_);
-    idemix_msps_[mspid] = k.issuer_id;
+    if (k.issuer_id >= 0) {
+        std::array<uint8_t, 32> h;
+        memcpy(h.data(), k.hash, 32);
+        idemix_issuer_hash_[k.issuer_id] = h;
+    }
+    // One MSP id, two issuer keys (two channels that both call their idemix MSP "IdemixMSP1"): the pass sees a creator's MSP id, not its
+    // channel, so it can no longer tell under which key to verify - creators of that MSP id stay with bccsp/idemix from then on.
+    auto it = idemix_msps_.find(mspid);
+    if (it != idemix_msps_.end() && it->second != k.issuer_id) it->second = -2;
+    else idemix_msps_[mspid] = k.issuer_id;
     return k.issuer_id;
 }
 
@@ -756,11 +782,23 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
         bm->seq = opt.block_seq;
         bm->n = 0;
         // Which tuples get an entry: the ones the device hashed and decided with a status bccsp.Verify decides itself (0 valid, 1 bad math,
-        // 2 high-S, 3 range).  (Pseudonym signatures: key = Nym.x || Nym.y, digest = SHA-256(message), status 0 valid / 1 proof invalid.
-        // The issuer is not part of the key and need not be: the signed message is the envelope payload, which embeds the creator's
-        // serialized identity - MSP id included - so the same (Nym, signature, message) can only ever be presented under the MSP, hence
-        // the issuer key, it was verified under here.)
+        // 2 high-S, 3 range).  (Pseudonym signatures: key = domain 2 || ipk.Hash of the issuer it was verified under || Nym.x || Nym.y,
+        // digest = SHA-256(message), status 0 valid / 1 proof invalid.)
+        // a pseudonym signature's entry is bound to the issuer key it was verified under (BlockVerdicts::tuple_nym_issuer, filled by the pass);
+        // a nym tuple whose issuer hash is not at hand gets no entry at all
+        std::map<int64_t, std::array<uint8_t, 32>> issuer_hash;
+        {
+            std::lock_guard<std::mutex> lk(idmu_);
+            issuer_hash = idemix_issuer_hash_;
+        }
+        const bool any_nym = !out.tuple_nym_issuer.empty();
+        auto issuer_of = [&](size_t i) -> const uint8_t* {
+            if (!any_nym || out.tuple_nym_issuer[i] < 0) return nullptr;
+            auto it = issuer_hash.find(out.tuple_nym_issuer[i]);
+            return it == issuer_hash.end() ? nullptr : it->second.data();
+        };
         auto wanted = [&](size_t i) {
+            if (any_nym && out.tuple_nym_issuer[i] >= 0 && !issuer_of(i)) return false;
             return out.tuple_hashed[i] && out.tuple_status[i] <= FABGPU_ST_RANGE && pb.tuples[i].sig.len != 0 && pb.tuples[i].sig.len <= 1024;
         };
         // Two phases on the pass's workers, like the gates: count (entries, key bytes) per range, meet, then every worker writes its
@@ -780,7 +818,7 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
             for (size_t i = lo; i < hi; i++)
                 if (wanted(i)) {
                     ce++;
-                    cb += (uint32_t)MemoKeyBytes(pb.tuples[i].sig.len, 32);
+                    cb += (uint32_t)MemoKeyBytes(pb.tuples[i].sig.len, 32, issuer_of(i) != nullptr);
                 }
             cnt_e[w + 1] = ce;
             cnt_b[w + 1] = cb;
@@ -830,7 +868,8 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
                 const uint8_t* sg = block + tp.sig.off;
                 sel[e] = (uint32_t)i;
                 raw->key_off[e] = off;
-                MemoKeyWrite(raw->keys.get() + off, &out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], sg, tp.sig.len, &out.tuple_digest[32 * i], 32);
+                const uint8_t* issuer = issuer_of(i);
+                MemoKeyWrite(raw->keys.get() + off, issuer, &out.tuple_qxy[64 * i], &out.tuple_qxy[64 * i + 32], sg, tp.sig.len, &out.tuple_digest[32 * i], 32);
                 raw->status[e] = out.tuple_status[i];
                 uint32_t at = (uint32_t)MemoHash(sg, tp.sig.len, &out.tuple_digest[32 * i], 32) & raw->mask;
                 for (;;) {                                 // lock-free linear probing: the table is at most half full
@@ -838,7 +877,7 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
                     if (raw->slots[at].compare_exchange_strong(expect, e + 1, std::memory_order_release, std::memory_order_relaxed)) break;
                     at = (at + 1) & raw->mask;
                 }
-                off += (uint32_t)MemoKeyBytes(tp.sig.len, 32);
+                off += (uint32_t)MemoKeyBytes(tp.sig.len, 32, issuer != nullptr);
                 e++;
             }
         };
@@ -1114,6 +1153,7 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     // tuples that went through registered comb tables, by launch class (the status kernel counted what each class decided)
     out.n_keyed = (rq.keyed_creators ? rq.summary.n_hashed_creator : 0u) + (rq.keyed_others ? rq.summary.n_hashed_other : 0u);
     out.n_device_decoded = rq.summary.n_unknown_identity;
+    out.tuple_nym_issuer.clear();
     for (size_t i = nd; i < nt; i++) {                                   // block signatures the caller asked not to verify
         out.tuple_status[i] = TUPLE_ST_SKIPPED;
         out.tuple_hashed[i] = 0;
@@ -1467,6 +1507,11 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     for (size_t i = 0; i < nt; i++)
         if (gt[i].nym) ns.push_back((uint32_t)i);
     const size_t mn = ns.size();
+    out.tuple_nym_issuer.clear();                            // (the memo binds a pseudonym signature's entry to the issuer it was verified under)
+    if (mn) {
+        out.tuple_nym_issuer.assign(nt, -1);
+        for (uint32_t i : ns) out.tuple_nym_issuer[i] = gt[i].key_id;
+    }
     bool nym_rode = false;
     if (mn && n) {
         nsp.resize(2 * mn);

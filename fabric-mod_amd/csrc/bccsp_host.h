@@ -13,6 +13,7 @@
 #include <deque>
 #include <list>
 #include <map>
+#include <array>
 #include <atomic>
 #include <mutex>
 #include <shared_mutex>
@@ -95,6 +96,7 @@ struct BlockVerdicts {
                                           // device hashed the message (tuple_hashed[i] == 1)
     std::vector<uint8_t> tuple_hashed;
     std::vector<uint8_t> tuple_qxy;       // 64 per tuple: the P-256 key the identity carries (zero: none / not P-256)
+    std::vector<int64_t> tuple_nym_issuer;   // empty, or per tuple: the device issuer id an idemix pseudonym signature was verified under (-1: not one)
     uint32_t n_block_sigs = 0;            // TUPLE_BLOCK_SIG tuples (the last ones)
     uint8_t block_sigs_understood = 0;
     uint32_t memo_seeded = 0;             // entries this pass added to the verdict memo
@@ -169,8 +171,11 @@ class GPUCSP {
     // length-framed, so a verdict can only ever be found again by a caller holding the same key, signature and digest.
     // Lookup: 0 = hit (*status = tuple status: 0 valid; 1 / 2 / 3 / 5 = the reference rejects, its exact error text comes from
     // bccsp/sw on that one tuple), 1 = miss (ask bccsp/sw).  Bounded: at most memo_capacity entries; the oldest BLOCK goes first.
-    int MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen, uint8_t* status) const;
+    // issuer_hash32 != nullptr: the entry of an idemix pseudonym signature (qx, qy = Nym) verified under the issuer key with that ipk.Hash
+    int MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen, uint8_t* status,
+                   const uint8_t* issuer_hash32 = nullptr) const;
     size_t MemoEvictBlock(uint64_t block_seq) const;          // the validator wrapper calls this when Validate(block) returned
+    size_t MemoHasBlock(uint64_t block_seq) const;            // entries still held under block_seq (0: never seeded, evicted, or aged out)
     void MemoStats(uint64_t* entries, uint64_t* hits, uint64_t* misses, uint64_t* evicted) const;
     void MemoSetCapacity(size_t max_entries) const;
     // identity cache bounds (msp/cache/cache.go keeps 100 deserialized identities; the pass sees every client certificate too)
@@ -257,8 +262,10 @@ class GPUCSP {
     mutable std::deque<std::shared_ptr<BlockMemo>> memo_blocks_;   // oldest first
     mutable size_t memo_cap_ = (size_t)1 << 18;
     mutable std::atomic<uint64_t> memo_hits_{0}, memo_misses_{0}, memo_evicted_{0};
-    static size_t MemoKeyBytes(size_t siglen, size_t dlen) { return 64 + 4 + siglen + 4 + dlen; }
-    static void MemoKeyWrite(uint8_t* out, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
+    static size_t MemoKeyBytes(size_t siglen, size_t dlen, bool nym) { return 1 + (nym ? 32 : 0) + 64 + 4 + siglen + 4 + dlen; }
+    static void MemoKeyWrite(uint8_t* out, const uint8_t* issuer_hash32, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,
+                             const uint8_t* digest, size_t dlen);
+    mutable std::map<int64_t, std::array<uint8_t, 32>> idemix_issuer_hash_;   // device issuer id -> ipk.Hash (guarded by idmu_)
     static uint64_t MemoHash(const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
     mutable std::map<std::string, int64_t> idemix_msps_;   // mspid -> device issuer id (guarded by idmu_)
     // scratch of the pre-verify pass, reused from block to block: a pass leases one set (a peer's channels run passes side by side)

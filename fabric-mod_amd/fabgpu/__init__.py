@@ -92,7 +92,7 @@ ABI_SYMBOLS = [
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
     "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_block_hash_checks",
-    "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_evict_block",
+    "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_lookup_nym", "fabgpu_csp_memo_has_block", "fabgpu_csp_memo_evict_block",
     "fabgpu_csp_verify_coalesced", "fabgpu_csp_identity_verify_coalesced", "fabgpu_csp_coalescer_configure", "fabgpu_csp_coalescer_stats",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
     "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",
@@ -174,6 +174,8 @@ def load():
     L.fabgpu_block_hash_checks.argtypes = [_u8p, _sz, ctypes.c_uint32, _u32p, _u32p, _u8p, _u32p, _u32p]
     L.fabgpu_csp_block_preverify2.argtypes = [_vp, ctypes.POINTER(_BlockPass)]
     L.fabgpu_csp_memo_lookup.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz, _u8p]
+    L.fabgpu_csp_memo_has_block.argtypes = [_vp, ctypes.c_uint64, _u64p]
+    L.fabgpu_csp_memo_lookup_nym.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz, _u8p]
     L.fabgpu_csp_memo_evict_block.argtypes = [_vp, ctypes.c_uint64, _u64p]
     L.fabgpu_csp_memo_stats.argtypes = [_vp, _u64p, _u64p, _u64p, _u64p]
     L.fabgpu_csp_memo_set_capacity.argtypes = [_vp, ctypes.c_uint64]
@@ -1018,6 +1020,20 @@ def memo_lookup(csp: "GPUCSP", qx32: bytes, qy32: bytes, sig: bytes, digest: byt
     st = ctypes.c_uint8(255)
     rc = csp._L.fabgpu_csp_memo_lookup(csp._h, qx32, qy32, sig, len(sig), digest, len(digest), ctypes.byref(st))
     return int(st.value) if rc == 0 else None
+
+
+def memo_has_block(csp: "GPUCSP", block_seq: int) -> int:
+    """Entries the verdict memo still holds under block_seq."""
+    n = ctypes.c_uint64(0)
+    _check(csp._L.fabgpu_csp_memo_has_block(csp._h, block_seq, ctypes.byref(n)), "fabgpu_csp_memo_has_block")
+    return n.value
+
+
+def memo_lookup_nym(csp: "GPUCSP", issuer_hash32: bytes, nym_x32: bytes, nym_y32: bytes, sig: bytes, digest: bytes) -> Optional[int]:
+    """The verdict memo's entry for an idemix pseudonym signature verified under the issuer key with that ipk.Hash: status, or None."""
+    st = ctypes.c_uint8(0)
+    rc = csp._L.fabgpu_csp_memo_lookup_nym(csp._h, issuer_hash32, nym_x32, nym_y32, sig, len(sig), digest, len(digest), ctypes.byref(st))
+    return st.value if rc == 0 else None
 
 
 def memo_evict_block(csp: "GPUCSP", block_seq: int) -> int:

@@ -1,7 +1,11 @@
 // +build fabgpu
 
 // Package gpu is the reference-side binding of libfabgpu.so: a bccsp.BCCSP that embeds bccsp/sw exactly the
-// way bccsp/pkcs11/pkcs11.go:35-52 does and overrides KeyImport (to hold X, Y) and Verify.
+// way bccsp/pkcs11/pkcs11.go:35-52 does and overrides KeyImport (to REMEMBER X, Y under the key's SKI) and Verify.
+// Every key it hands out is bccsp/sw's own key object: bccsp/sw dispatches on reflect.TypeOf(key) (bccsp/sw/impl.go:110
+// KeyDeriv, :232 Sign, :259 Verify, :296 Decrypt; the registrations are bccsp/sw/new.go:60-96), so a wrapper type around a
+// public key would make every verb this provider does not override fail with "Unsupported 'Key' provided" - round 2's
+// *gpuPublicKey did exactly that to KeyDeriv (a KeyDeriver IS registered for *ecdsaPublicKey, new.go:86).
 //
 // Drop this directory into the reference tree as bccsp/gpu and build the peer with GO_TAGS=fabgpu
 // (same mechanism as the pkcs11 tag, Makefile:80,209).  Written for the reference's Go 1.14.4 (Makefile:79):
@@ -74,6 +78,8 @@ type Provider struct {
 	bccsp.BCCSP // bccsp/sw: everything that is not overridden (pattern: bccsp/pkcs11/pkcs11.go:35-37)
 	csp         *C.fabgpu_csp
 	closeOnce   sync.Once
+	keys        keyXY
+	inflight    sync.Map // blockSeq -> chan struct{}: passes that are running right now (arrival hook / validator wrapper)
 	// coalesce: memo misses go to the device through fabgpu_csp_verify_coalesced instead of straight to bccsp/sw - for
 	// processes whose Verify calls arrive many at a time on their own goroutines and no block pass sees them first: the
 	// orderer (Broadcast handlers behind SigFilter, orderer/common/msgprocessor/sigfilter.go:50-80).  Off by default: a
@@ -91,6 +97,8 @@ type BlockPreVerifier interface {
 	PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSummary, error)
 	// EvictBlock drops the memo entries seeded under blockSeq.
 	EvictBlock(blockSeq uint64)
+	// HasBlock: a pass under blockSeq has already seeded the memo (the arrival hook ran) and nothing evicted it since.
+	HasBlock(blockSeq uint64) bool
 }
 
 // PassSummary is the per-transaction advice of one pass (never consensus input: the validators decide).
@@ -101,10 +109,43 @@ type PassSummary struct {
 	MemoSeeded int
 }
 
-// gpuPublicKey carries X, Y so that Verify never needs the unexported sw key type (bccsp/sw/ecdsakey.go:72-74).
-type gpuPublicKey struct {
-	bccsp.Key        // the sw key (SKI, Bytes, Symmetric, Private, PublicKey)
-	qx, qy    [32]byte
+// keyXY remembers the affine coordinates of every on-curve P-256 public key this provider imported, under the key's SKI
+// (bccsp/sw/ecdsakey.go:87-99: SHA-256 of the uncompressed point - the same for a private key and its public half), so that
+// Verify never needs the unexported sw key type (bccsp/sw/ecdsakey.go:72-74) and never has to wrap it either.  Two generations:
+// when the young one is full it becomes the old one and the old one is dropped; a key that is still in use is found in the old
+// generation and moves back.  A key that fell out (imported long ago, never verified with since) just verifies on bccsp/sw.
+type keyXY struct {
+	mu         sync.RWMutex
+	young, old map[string][64]byte
+}
+
+const keyXYGeneration = 1 << 16 // entries per generation (an entry: 32-byte SKI + 64 bytes)
+
+func (s *keyXY) put(ski []byte, xy *[64]byte) {
+	s.mu.Lock()
+	if s.young == nil {
+		s.young = make(map[string][64]byte)
+	}
+	if len(s.young) >= keyXYGeneration {
+		s.old, s.young = s.young, make(map[string][64]byte)
+	}
+	s.young[string(ski)] = *xy
+	s.mu.Unlock()
+}
+
+func (s *keyXY) get(ski []byte) (xy [64]byte, ok bool) {
+	s.mu.RLock()
+	xy, ok = s.young[string(ski)]
+	inOld := false
+	if !ok {
+		xy, inOld = s.old[string(ski)]
+	}
+	s.mu.RUnlock()
+	if inOld {
+		s.put(ski, &xy)
+		return xy, true
+	}
+	return xy, ok
 }
 
 // New is what bccsp/factory calls for ProviderName "GPU" (gpufactory.go).  device < 0: the current HIP device.
@@ -157,18 +198,27 @@ func (p *Provider) KeyImport(raw interface{}, opts bccsp.KeyImportOpts) (bccsp.K
 	if pub.X.Sign() < 0 || pub.Y.Sign() < 0 || pub.X.BitLen() > 256 || pub.Y.BitLen() > 256 || !pub.Curve.IsOnCurve(pub.X, pub.Y) {
 		return k, nil // ECDSAGoPublicKeyImportOpts does not check the point (bccsp/sw/keyimport.go:103-112): such keys stay with sw
 	}
-	gk := &gpuPublicKey{Key: k}
-	be32(pub.X, &gk.qx)
-	be32(pub.Y, &gk.qy)
-	return gk, nil
+	var xy [64]byte
+	var x, y [32]byte
+	be32(pub.X, &x)
+	be32(pub.Y, &y)
+	copy(xy[:32], x[:])
+	copy(xy[32:], y[:])
+	p.keys.put(k.SKI(), &xy)
+	return k, nil // bccsp/sw's own key: every other verb of bccsp/sw keeps working on it
 }
 
-// swKey unwraps a key of this provider so that bccsp/sw sees its own type.
-func swKey(k bccsp.Key) bccsp.Key {
-	if gk, ok := k.(*gpuPublicKey); ok && gk != nil {
-		return gk.Key
+// xyOf: the coordinates this provider remembered for k's SKI (public and private ECDSA keys share it; bccsp/sw verifies with a
+// private key's public half, bccsp/sw/ecdsa.go:59-69, and so does the memo).
+func (p *Provider) xyOf(k bccsp.Key) (xy [64]byte, ok bool) {
+	if k == nil || k.Symmetric() {
+		return xy, false
 	}
-	return k
+	ski := k.SKI()
+	if len(ski) == 0 {
+		return xy, false
+	}
+	return p.keys.get(ski)
 }
 
 // Verify: (true, nil) comes from the verdict memo; every other outcome - and every error text - from bccsp/sw
@@ -176,36 +226,34 @@ func swKey(k bccsp.Key) bccsp.Key {
 // launch costs more than one CPU verification.  With SetCoalesce(true) a miss joins whatever other misses are in flight
 // (fabgpu_csp_verify_coalesced): the orderer's case.
 func (p *Provider) Verify(k bccsp.Key, signature, digest []byte, opts bccsp.SignerOpts) (bool, error) {
-	gk, ok := k.(*gpuPublicKey)
-	if ok && gk != nil && len(signature) != 0 && len(digest) != 0 {
-		var st C.uint8_t
-		hit := C.fabgpu_csp_memo_lookup(p.csp, (*C.uint8_t)(unsafe.Pointer(&gk.qx[0])), (*C.uint8_t)(unsafe.Pointer(&gk.qy[0])),
-			(*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)),
-			(*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &st)
-		if hit == 0 && st == C.FABGPU_ST_VALID {
-			return true, nil
+	if len(signature) != 0 && len(digest) != 0 {
+		if xy, ok := p.xyOf(k); ok {
+			var st C.uint8_t
+			hit := C.fabgpu_csp_memo_lookup(p.csp, (*C.uint8_t)(unsafe.Pointer(&xy[0])), (*C.uint8_t)(unsafe.Pointer(&xy[32])),
+				(*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)),
+				(*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &st)
+			if hit == 0 && st == C.FABGPU_ST_VALID {
+				return true, nil
+			}
+			if p.coalesce {
+				// calls in flight at the same moment share one launch; only "valid" is taken from the device - a reject, a key the
+				// device does not decide, or a device failure falls through to bccsp/sw for the reference's own answer and text
+				var valid, flags C.int
+				var errbuf [8]C.char
+				rc := C.fabgpu_csp_verify_coalesced(p.csp, (*C.uint8_t)(unsafe.Pointer(&xy[0])), (*C.uint8_t)(unsafe.Pointer(&xy[32])),
+					(*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)),
+					(*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &valid, &flags, &errbuf[0], C.size_t(len(errbuf)))
+				if rc == 0 && valid == 1 && errbuf[0] == 0 {
+					return true, nil
+				}
+			}
 		}
 	}
-	if ok && gk != nil && p.coalesce && len(signature) != 0 && len(digest) != 0 {
-		// calls in flight at the same moment share one launch; only "valid" is taken from the device - a reject, a key the
-		// device does not decide, or a device failure falls through to bccsp/sw for the reference's own answer and text
-		var valid, flags C.int
-		var errbuf [8]C.char
-		rc := C.fabgpu_csp_verify_coalesced(p.csp, (*C.uint8_t)(unsafe.Pointer(&gk.qx[0])), (*C.uint8_t)(unsafe.Pointer(&gk.qy[0])),
-			(*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)),
-			(*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &valid, &flags, &errbuf[0], C.size_t(len(errbuf)))
-		if rc == 0 && valid == 1 && errbuf[0] == 0 {
-			return true, nil
-		}
-	}
-	return p.BCCSP.Verify(swKey(k), signature, digest, opts) // nil key, foreign key types, misses, rejects: the reference's own answer
+	return p.BCCSP.Verify(k, signature, digest, opts) // nil key, foreign key types, misses, rejects: the reference's own answer
 }
 
-// Sign, Encrypt, Decrypt, KeyDeriv, GetKey reach sw with sw's key type (a gpuPublicKey is only ever a public key, but
-// callers may hand it back, e.g. to Encrypt: unwrap for symmetry with Verify).
-func (p *Provider) Encrypt(k bccsp.Key, plaintext []byte, opts bccsp.EncrypterOpts) ([]byte, error) {
-	return p.BCCSP.Encrypt(swKey(k), plaintext, opts)
-}
+// (Sign, Encrypt, Decrypt, KeyDeriv, KeyGen, GetKey, GetHashOpt, GetHash are bccsp/sw's, reached through the embedded interface with
+// bccsp/sw's own key objects: nothing to unwrap.  INTEGRATION.md lists every bccsp.BCCSP method x key type with who answers.)
 
 // Hash stays on the CPU on purpose: a PCIe round trip costs more than SHA-256 of a few KB, and - more important -
 // the digest the validator computes over ITS bytes is what binds those bytes to a memo entry.
@@ -216,6 +264,20 @@ func (p *Provider) PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSumm
 	if len(blockBytes) == 0 {
 		return nil, errors.New("empty block")
 	}
+	// one pass per block name at a time: whoever comes second (the validator wrapper while the arrival hook's pass is still
+	// running, a gossiped duplicate) waits for the first and finds the memo seeded
+	done := make(chan struct{})
+	if other, running := p.inflight.LoadOrStore(blockSeq, done); running {
+		<-other.(chan struct{})
+		if p.HasBlock(blockSeq) {
+			return &PassSummary{}, nil
+		}
+		return nil, errors.New("fabgpu: the pass this call waited for failed")
+	}
+	defer func() {
+		p.inflight.Delete(blockSeq)
+		close(done)
+	}()
 	capTx, capTuples := C.uint32_t(1024), C.uint32_t(8192)
 	for attempt := 0; attempt < 3; attempt++ {
 		flags := make([]uint8, capTx) // the only array this caller wants back; the memo lives behind the ABI
@@ -251,6 +313,30 @@ func (p *Provider) MemoLookup(qx, qy *[32]byte, signature, digest []byte) (statu
 	return uint8(st), rc == 0
 }
 
+// MemoLookupNym is MemoLookup for an idemix pseudonym signature: the entry is bound to the issuer key the caller verifies under
+// (issuerHash = idemix.IssuerPublicKey.Hash of bccsp.IdemixNymSignerOpts.IssuerPK) - two channels may define one idemix MSP id with
+// different issuer keys, and provider and memo are shared by all channels.
+func (p *Provider) MemoLookupNym(issuerHash, nymX, nymY *[32]byte, signature, digest []byte) (status uint8, hit bool) {
+	if len(signature) == 0 || len(digest) == 0 {
+		return 0, false
+	}
+	var st C.uint8_t
+	rc := C.fabgpu_csp_memo_lookup_nym(p.csp, (*C.uint8_t)(unsafe.Pointer(&issuerHash[0])), (*C.uint8_t)(unsafe.Pointer(&nymX[0])),
+		(*C.uint8_t)(unsafe.Pointer(&nymY[0])), (*C.uint8_t)(unsafe.Pointer(&signature[0])), C.size_t(len(signature)),
+		(*C.uint8_t)(unsafe.Pointer(&digest[0])), C.size_t(len(digest)), &st)
+	return uint8(st), rc == 0
+}
+
+// HasBlock: are memo entries seeded under blockSeq still there?  (extensions/gossip/state pre-verifies a block when it ARRIVES;
+// the validator wrapper asks this before it would marshal and submit the block a second time.)
+func (p *Provider) HasBlock(blockSeq uint64) bool {
+	if running, ok := p.inflight.Load(blockSeq); ok {
+		<-running.(chan struct{}) // a pass under this name is in flight: its verdicts are a few hundred microseconds away
+	}
+	var n C.uint64_t
+	return C.fabgpu_csp_memo_has_block(p.csp, C.uint64_t(blockSeq), &n) == 0 && n > 0
+}
+
 // RegisterIdemixMSP makes the block pass verify the pseudonym signatures of creators serialized under mspID
 // (msp/idemixmsp.go:99-173 Setup calls this with the marshalled idemix.IssuerPublicKey).  false: not accelerated.
 func (p *Provider) RegisterIdemixMSP(mspID string, ipkBytes []byte) bool {
@@ -265,7 +351,7 @@ func (p *Provider) RegisterIdemixMSP(mspID string, ipkBytes []byte) bool {
 }
 
 // PassRoutes: how the block passes of this provider went - walked on the device (DESIGN 4.4b) or on the host - and why the last
-// block was declined by the device walk (a new endorser, a signature outside the common DER shape, ...).  For metrics.
+// block was declined by the device walk (not staged, idemix MSPs registered, a certificate beyond the device decoder).  For metrics.
 func (p *Provider) PassRoutes() (deviceWalks, hostWalks uint64, lastDecline string) {
 	var d, h C.uint64_t
 	why := make([]byte, 256)

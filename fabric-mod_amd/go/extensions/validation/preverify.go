@@ -9,6 +9,11 @@
 // provider's verdict memo.  The validators then run exactly as before; their bccsp.Verify calls hit the memo.  When Validate
 // returns the block's memo entries are evicted.
 //
+// Since round 3 the pass normally ran long before: extensions/gossip/state/preverify_on_arrival.go submits the block when it ARRIVES
+// (its marshalled bytes are in hand there).  Validate asks the provider whether the block's verdicts are waiting (HasBlock) and only
+// marshals and submits the block itself when they are not (a block that came in while the arrival hook's slots were taken, a peer
+// built without that hook).
+//
 // Nothing here is consensus input: the pass only pre-answers bccsp.Verify for byte strings the validators themselves present
 // (see bccsp/gpu/gpu.go); if the provider is not the GPU one, or the pass fails, validation proceeds on bccsp/sw unchanged.
 //
@@ -43,7 +48,8 @@ func newPreVerifying(next txvalidator.Validator, cryptoProvider bccsp.BCCSP, cha
 	return &preVerifying{next: next, pre: pre, channelID: channelID}
 }
 
-// memoSeq names the block in the memo: channels share one provider, block numbers repeat across channels.
+// memoSeq names the block in the memo: channels share one provider, block numbers repeat across channels.  (Same function as
+// extensions/gossip/state.MemoSeq - repeated here so that this file stands alone in a build without the arrival hook.)
 func memoSeq(channelID string, number uint64) uint64 {
 	h := uint64(14695981039346656037) // FNV-1a of the channel id, folded over the block number: a name, not a security boundary
 	for i := 0; i < len(channelID); i++ {
@@ -58,11 +64,15 @@ func (v *preVerifying) Validate(block *common.Block) error {
 	if block == nil || block.Header == nil || block.Data == nil || len(block.Data.Data) == 0 {
 		return v.next.Validate(block)
 	}
+	seq := memoSeq(v.channelID, block.Header.Number)
+	if v.pre.HasBlock(seq) { // pre-verified when it arrived: nothing to marshal, nothing to submit
+		defer v.pre.EvictBlock(seq)
+		return v.next.Validate(block)
+	}
 	raw, err := proto.Marshal(block) // one pass over the block's bytes; the pass walks them in place
 	if err != nil {
 		return v.next.Validate(block)
 	}
-	seq := memoSeq(v.channelID, block.Header.Number)
 	sum, err := v.pre.PreVerifyBlock(raw, seq)
 	if err != nil {
 		preLogger.Warningf("[%s] block %d: GPU pre-verify pass failed (%s); validating on bccsp/sw", v.channelID, block.Header.Number, err)

@@ -130,6 +130,16 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* pass);
  * text); 1: miss -> bccsp/sw.  Never an infrastructure error: a miss is always a correct answer. */
 int fabgpu_csp_memo_lookup(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest,
                            size_t dlen, uint8_t* status);
+/* The same for an idemix pseudonym signature (key = Nym.x, Nym.y; digest = SHA-256(message)): entries are bound to the issuer key they
+ * were verified under - issuer_hash32 = idemix.IssuerPublicKey.Hash of the key the CALLER verifies under (bccsp.IdemixNymSignerOpts.IssuerPK) -
+ * so a verdict reached under one channel's issuer can never answer for another's (two channels may give their idemix MSPs the same id).
+ * ECDSA entries and pseudonym entries live in separate key domains. */
+int fabgpu_csp_memo_lookup_nym(fabgpu_csp* csp, const uint8_t* issuer_hash32, const uint8_t* nym_x32, const uint8_t* nym_y32, const uint8_t* sig, size_t siglen,
+                               const uint8_t* digest, size_t dlen, uint8_t* status);
+/* *entries = memo entries still held under block_seq (0: never seeded, evicted, or pushed out by newer blocks).  The pass may run when
+ * a block ARRIVES (extensions/gossip/state AddPayload: the marshalled bytes are in hand, gossip/state/state.go:592,785-787) and the
+ * validator wrapper asks this before it would marshal and submit the same block again at Validate. */
+int fabgpu_csp_memo_has_block(fabgpu_csp* csp, uint64_t block_seq, uint64_t* entries);
 int fabgpu_csp_memo_evict_block(fabgpu_csp* csp, uint64_t block_seq, uint64_t* evicted);
 int fabgpu_csp_memo_stats(fabgpu_csp* csp, uint64_t* entries, uint64_t* hits, uint64_t* misses, uint64_t* evicted);
 int fabgpu_csp_memo_set_capacity(fabgpu_csp* csp, uint64_t max_entries);
@@ -208,7 +218,9 @@ int fabgpu_block_tuples(const uint8_t* block, size_t len, uint32_t cap, uint32_t
  * issuer: nym public keys as NymPublicKeyImporter.KeyImport receives them (x || y), marshalled idemix.NymSignature bytes,
  * messages.  valid[i] 0/1; flags[i] bit0: tuple left to bccsp/idemix; errs[i] = Go error text ("" == nil). */
 /* An idemix MSP of the channel (msp/idemixmsp.go:99-173): after this call fabgpu_csp_block_preverify also verifies the pseudonym
- * signatures of creators serialized under `mspid` (tuple_status 0 valid / 1 invalid / 6 left to bccsp/idemix). */
+ * signatures of creators serialized under `mspid` (tuple_status 0 valid / 1 invalid / 6 left to bccsp/idemix).  Registering one MSP id
+ * with a SECOND, different issuer key (another channel's MSP of the same name) makes the pass leave that MSP id's creators to
+ * bccsp/idemix (status 6): it sees MSP ids, not channels. */
 int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id);
 int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap);
 int fabgpu_csp_idemix_nym_verify_batch(fabgpu_csp* csp, int64_t issuer_id, size_t n, const uint8_t* nym_arena, const uint32_t* nym_off,

@@ -290,6 +290,9 @@ def test_preverify_pass_with_idemix_creators():
     # NymVerifier wrapper recomputes from ITS arguments (fabric-mod_amd/go/bccsp/idemixgpu/nymverifier.go)
     r2 = fabgpu.preverify_block2(csp, blk, block_seq=9, seed_memo=True)
     assert (r2["tx_flags"] == want).all()
+    from idemix_common import fixtures
+    ipk_hash, other_hash = bytes(fixtures()["MSP1OU1"]["ipk"].hash), bytes(fixtures()["MSP2OU1"]["ipk"].hash)
+    assert len(ipk_hash) == 32 and ipk_hash != other_hash
     n_nym = 0
     for i in np.nonzero(r2["tuple_kind"] == 0)[0]:
         tx = int(r2["tuple_tx"][i])
@@ -299,11 +302,21 @@ def test_preverify_pass_with_idemix_creators():
         msg, sig = r2["arena"][sp[4]:sp[4] + sp[5]], r2["arena"][sp[6]:sp[6] + sp[7]]
         assert bytes(r2["tuple_digest"][i]) == hashlib.sha256(msg).digest() and r2["tuple_hashed"][i]
         qxy = bytes(r2["tuple_qxy"][i])
-        assert fabgpu.memo_lookup(csp, qxy[:32], qxy[32:], sig, hashlib.sha256(msg).digest()) == int(r2["tuple_status"][i])
-        assert fabgpu.memo_lookup(csp, qxy[:32], qxy[32:], sig, hashlib.sha256(msg + b"!").digest()) is None
+        # ... bound to the issuer key it was verified under (ipk.Hash), and in a key domain of its own: the ECDSA lookup with the same
+        # bytes misses, another issuer's hash misses (two channels may name their idemix MSPs alike - ADVICE r2)
+        assert fabgpu.memo_lookup_nym(csp, ipk_hash, qxy[:32], qxy[32:], sig, hashlib.sha256(msg).digest()) == int(r2["tuple_status"][i])
+        assert fabgpu.memo_lookup_nym(csp, ipk_hash, qxy[:32], qxy[32:], sig, hashlib.sha256(msg + b"!").digest()) is None
+        assert fabgpu.memo_lookup_nym(csp, other_hash, qxy[:32], qxy[32:], sig, hashlib.sha256(msg).digest()) is None
+        assert fabgpu.memo_lookup(csp, qxy[:32], qxy[32:], sig, hashlib.sha256(msg).digest()) is None
         n_nym += 1
     assert n_nym >= 10
     assert fabgpu.memo_evict_block(csp, 9) == r2["memo_seeded"]
+    # the same MSP id registered with ANOTHER issuer key (a second channel's "IdemixMSP1"): the pass can no longer know under which key a
+    # creator of that MSP id verifies - it leaves them to bccsp/idemix
+    raw_ipk2 = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_fixtures.json")))["msps"]["MSP2OU1"]["ipk"])
+    assert csp.idemix_msp_register("IdemixMSP1", raw_ipk2) >= 0
+    amb = fabgpu.preverify_block(csp, blk)
+    assert (amb["tx_flags"][idemix_tx] == fabgpu.TX_NEEDS_SW).all() and (amb["tx_flags"][~idemix_tx] == 0).all()
     csp.close()
 
 

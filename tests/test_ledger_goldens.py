@@ -322,6 +322,48 @@ def test_verdict_memo_replays_bccsp_verify_lookups(csp):
 
 
 @pytest.mark.gpu
+def test_pass_at_block_arrival_then_mcs_then_validators_then_evict(csp):
+    """The sequence the Go side runs since round 3 (fabric-mod_amd/go/extensions/gossip/state/preverify_on_arrival.go + extensions/validation/
+    preverify.go), replayed through the C ABI on the reference's own Fabric 2.0 blocks: several blocks ARRIVE (AddPayload: the marshalled
+    bytes go through the pass, memo seeded under a per-block name) before the committer reaches the first; then, block by block, the
+    validator wrapper finds the block's verdicts waiting (no second pass), the BlockValidation policy's lookups for the orderers'
+    signatures hit, every creator / endorsement lookup of the validators hits, and the block's entries are evicted.  Hit counts are the
+    reference's signature counts: 20 creator + 21 endorsement + 19 orderer."""
+    seqs = {}
+    before = fabgpu.memo_stats(csp)
+    routes0 = fabgpu.pass_routes(csp)
+    for b, raw in V20:                                                   # arrival: gossip hands over proto.Marshal(block) (gossip/state/state.go:592)
+        seq = 0xA11CE000 + b["number"]
+        assert fabgpu.memo_has_block(csp, seq) == 0
+        r = fabgpu.preverify_block2(csp, raw, block_seq=seq, seed_memo=True, lean=True)
+        seqs[b["number"]] = (seq, r["memo_seeded"])
+        assert fabgpu.memo_has_block(csp, seq) == r["memo_seeded"] > 0
+    passes = fabgpu.pass_routes(csp)
+    assert passes["device_walks"] + passes["host_walks"] - routes0["device_walks"] - routes0["host_walks"] == len(V20)
+    hits = {0: 0, 1: 0, 2: 0}
+    for b, raw in V20:                                                   # the committer reaches the blocks, in order
+        seq, seeded = seqs[b["number"]]
+        assert fabgpu.memo_has_block(csp, seq) == seeded                 # Validate: HasBlock(seq) -> no marshal, no second pass
+        blk = fd.decode_block(raw)
+        want = expected_tuples(blk)
+        assert len(want) == seeded
+        h0 = fabgpu.memo_stats(csp)["hits"]
+        for kind_wanted in (2, 0, 1):                                    # orderer signatures (block validation policy) first, then the validators
+            for tx, kind, ident, msg, sig in want:
+                if kind != kind_wanted:
+                    continue
+                _, pub = fd.identity_pubkey(ident)
+                assert fabgpu.memo_lookup(csp, pub[0].to_bytes(32, "big"), pub[1].to_bytes(32, "big"), sig, hashlib.sha256(msg).digest()) == 0
+                hits[kind] += 1
+        assert fabgpu.memo_stats(csp)["hits"] - h0 == len(want)
+        assert fabgpu.memo_evict_block(csp, seq) == seeded               # Validate returned
+        assert fabgpu.memo_has_block(csp, seq) == 0
+    assert (hits[0], hits[1], hits[2]) == (20, 21, 19)
+    assert fabgpu.memo_stats(csp)["entries"] == before["entries"]
+    assert fabgpu.pass_routes(csp)["device_walks"] + fabgpu.pass_routes(csp)["host_walks"] == passes["device_walks"] + passes["host_walks"]   # no pass since arrival
+
+
+@pytest.mark.gpu
 def test_memo_and_identity_cache_are_bounded(csp):
     L = fabgpu.load()
     L.fabgpu_csp_memo_set_capacity(csp._h, 8)

@@ -360,3 +360,14 @@ def test_bn_pair_streams_on_gpu_match_the_interpreter_register_for_register():
                     if got != exp:
                         bad.add((nm, "odd" if lane & 1 else "even", tuple(i for i in range(9) if got[i] != exp[i])))
         assert not bad, (name, sorted(bad))
+
+
+def test_tracked_generated_headers_are_what_the_generators_produce():
+    """pair29_gcn.h, pair29_bn_gcn.h, fe29_gcn.h, bn29_gcn.h and bn29_consts.h are tracked AND have Makefile rules: a header that is
+    older than its generator by content (not by timestamp) would compile silently.  Regenerate each and compare byte for byte."""
+    import subprocess
+    csrc = os.path.join(ROOT, "fabric-mod_amd", "csrc")
+    for args, header in ((["gen_pair_gcn.py", "field"], "fe29_gcn.h"), (["gen_pair_gcn.py"], "pair29_gcn.h"), (["gen_pair_gcn.py", "bnfield"], "bn29_gcn.h"),
+                         (["gen_pair_gcn.py", "bnpair"], "pair29_bn_gcn.h"), (["gen_bn_consts.py"], "bn29_consts.h")):
+        fresh = subprocess.run([sys.executable] + args, cwd=csrc, check=True, capture_output=True).stdout
+        assert fresh == open(os.path.join(csrc, header), "rb").read(), "%s is stale: run make -C fabric-mod_amd/csrc %s" % (header, header)
