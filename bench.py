@@ -643,7 +643,7 @@ def main():
         # HBM/fabric bytes per launch from the rocprofv3 PMC passes of this same command (profiles/*_pmc_traffic.json:
         # 2 x FETCH_SIZE per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), only valid for the BASELINE workload
         traffic = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if n_tx == N_TX and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("traffic_gb_per_launch") * 1e9   # bytes per launch
@@ -677,7 +677,7 @@ def main():
             "roofline": {"bound": "valu-mac", "achieved": n / kernel_s * MAC_PER_VERIFY, "peak": mac_peak, "unit": "MAC/s",
                          "frac": n / kernel_s * MAC_PER_VERIFY / mac_peak,
                          "traffic": traffic, "traffic_unit": "HBM bytes/launch from the PMC passes (algorithmic: %d)" % int(ALGO_BYTES_PER_VERIFY * n),
-                         "kernel": "p256_verify_pair_kernel<256> (two lanes per signature)" if n <= 32768 else "p256_verify_kernel<256>", "kernel_ms": kernel_s * 1e3,
+                         "kernel": ("p256_verify_pair_lds_kernel<256> (two lanes per signature, per-signature table in LDS)" if n > 16384 else "p256_verify_pair_kernel<256> (two lanes per signature)") if n <= 32768 else "p256_verify_kernel<256>", "kernel_ms": kernel_s * 1e3,
                          "kernel_ms_per_launch_events": kernel_ms,
                          "model": "achieved = verifies/s x 3.1e5 u32 MACs per verify (SURVEY 8(d) canonical count: 4 512 field products x 64 + the mod-n reductions); "
                                   "peak = " + mac_peak_what,

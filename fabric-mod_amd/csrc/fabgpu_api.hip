@@ -90,6 +90,7 @@ struct fabgpu_ctx {
     int device = 0;
     bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
     bool allow_quad = true;   // !FABGPU_FLAG_NO_QUAD (idemix: four lanes per signature for batches <= IDEMIX_QUAD_MAX)
+    int pair_table_lds = -1;       // the verify-only pair kernel's per-signature table: 1 in LDS, 0 in the global workspace, -1 by batch size (kernels.h)
     hipStream_t stream = nullptr;
     // FABGPU_FAULT_INJECT (tests of the failure contract only): "launch" makes every kernel submission report hipErrorLaunchFailure,
     // "oom" makes every workspace / staging allocation fail.  A non-zero return must then reach the caller and no verdict may be written.
@@ -275,7 +276,9 @@ int fabgpu_device_count(fabgpu_ctx*) {
 int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!out) return FABGPU_EINVAL;
     *out = nullptr;
-    if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS | FABGPU_FLAG_NO_QUAD)) != 0) return FABGPU_EINVAL;
+    if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS | FABGPU_FLAG_NO_QUAD | FABGPU_FLAG_PAIR_TABLE_LDS |
+                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL)) != 0) return FABGPU_EINVAL;
+    if (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL)) return FABGPU_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
     int dev = cfg ? cfg->device : -1;
@@ -292,6 +295,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     ctx->walk_map.flags = hipHostMallocMapped | hipHostMallocCoherent;
     ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
     ctx->allow_quad = !(cfg && (cfg->flags & FABGPU_FLAG_NO_QUAD));
+    ctx->pair_table_lds = cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) ? 1 : (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL) ? 0 : pair_table_default());
     ctx->time_kernels = cfg && (cfg->flags & FABGPU_FLAG_TIME_KERNELS);
     DeviceGuard g(dev);
     int rc = FABGPU_OK;
@@ -399,7 +403,7 @@ int fabgpu_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* qx, cons
     int rc = ctx->acquire_qws(verify_workspace_bytes((uint32_t)n, ctx->allow_pair), &wi, &wsp, st);
     if (rc != FABGPU_OK) return rc;
     if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
-    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, wsp, verdict_bits, status, ctx->allow_pair, st);
+    hipError_t err = launch_p256_verify((uint32_t)n, qx, qy, e, r, s, ctx->d_gtab, wsp, verdict_bits, status, ctx->allow_pair, st, 0, ctx->pair_table_lds);
     if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     ctx->timed = ctx->time_kernels;
@@ -1765,7 +1769,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             void* wsp = nullptr;
             int r2 = ctx->acquire_qws(verify_workspace_bytes(tot.creators, true), &wi, &wsp, s2);
             if (r2 != FABGPU_OK) return r2;
-            e = launch_p256_verify(tot.creators, a.qx, a.qy, dt + o_dig, a.r, a.s, ctx->d_gtab, wsp, dt + o_bitc, dt + o_dst, true, s2, exclusive ? 84u << 10 : 0u);
+            e = launch_p256_verify(tot.creators, a.qx, a.qy, dt + o_dig, a.r, a.s, ctx->d_gtab, wsp, dt + o_bitc, dt + o_dst, true, s2, exclusive ? 84u << 10 : 0u, ctx->pair_table_lds);
             ctx->release_qws(wi, s2);
         }
         return hip_to_rc(e);

@@ -34,6 +34,8 @@ struct VerifyGeom {
 };
 VerifyGeom verify_geom(uint32_t n, bool allow_pair);
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair);
+int pair_table_default();
+constexpr int PAIR_TABLE_LDS_FROM = 16384;   // launches of more tuples than this keep the pair kernel's per-signature table in LDS
 // the mid-state kernel of a prefixed batch alone (the fused launchers run it themselves unless pa.mid_ready)
 hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st);   // honours pa.lds_reserve
 hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);
@@ -45,7 +47,7 @@ hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_byte
                                 size_t scratch_bytes, void* digests, hipStream_t st, uint32_t lds_reserve = 0);
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
                               const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st,
-                              uint32_t lds_reserve = 0);   // lds_reserve: see ShaPrefixArgs
+                              uint32_t lds_reserve = 0, int table_lds = 0);   // lds_reserve: see ShaPrefixArgs; table_lds: 1 PairQTabLds, 0 global, -1 by size
 hipError_t launch_sha256_p256_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* qx,
                                      const void* qy, const void* r, const void* s, const void* gtab, void* qws,
                                      void* verdict_bits, void* status, bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st);

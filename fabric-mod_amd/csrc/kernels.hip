@@ -7,6 +7,7 @@
 // Replaces (reference, all CPU): bccsp/sw/hash.go:29-33, bccsp/sw/ecdsa.go:41-57 -> crypto/ecdsa.Verify,
 // called per signature from msp/identities.go:169-196.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "device_common.h"
@@ -148,6 +149,35 @@ __global__ void __launch_bounds__(BLOCK, 1) p256_verify_pair_kernel(uint32_t n, 
         load_be_field(vr, r, ic);
         load_be_field(vs, s, ic);
         uint32_t st = p256_verify_pair29(vqx, vqy, ve, vr, vs, gtab, qtab, odd);
+        pair_emit_verdict(i, n, active, odd, st, verdict32, status);
+    }
+}
+
+// The same with the per-signature table in LDS (PairQTabLds: 8 entries, signed 4-bit windows) instead of the global workspace: no
+// table traffic at all (p256_pair29.h says what that is worth).  Dynamic LDS: 128 signatures x 1040 bytes.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 1) p256_verify_pair_lds_kernel(uint32_t n, const uint8_t* __restrict__ qx, const uint8_t* __restrict__ qy,
+                                                                             const uint8_t* __restrict__ e, const uint8_t* __restrict__ r,
+                                                                             const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
+                                                                             uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+    extern __shared__ uint4 pair_lds[];
+    constexpr int NP = BLOCK / 2;
+    const bool odd = (threadIdx.x & 1) != 0;
+    const uint32_t pairidx = threadIdx.x >> 1;
+    PairQTabLds qtab = PairQTabLds::of(pair_lds, pairidx);
+    uint32_t* verdict32 = reinterpret_cast<uint32_t*>(verdict_bits);
+    const uint32_t ntiles = (n + NP - 1) / NP;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * NP + pairidx;
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        u256 vqx, vqy, ve, vr, vs;
+        load_be_field(vqx, qx, ic);
+        load_be_field(vqy, qy, ic);
+        load_be_field(ve, e, ic);
+        load_be_field(vr, r, ic);
+        load_be_field(vs, s, ic);
+        uint32_t st = p256_verify_pair29<PairQTabLds, 4>(vqx, vqy, ve, vr, vs, gtab, qtab, odd);
         pair_emit_verdict(i, n, active, odd, st, verdict32, status);
     }
 }
@@ -423,16 +453,35 @@ VerifyGeom verify_geom(uint32_t n, bool allow_pair) {
     g.wgs = tiles < (uint32_t)VERIFY_MAX_WGS ? tiles : (uint32_t)VERIFY_MAX_WGS;
     return g;
 }
+// Where the two-lanes-per-signature verify-only kernel keeps its per-signature table when the context does not say
+// (FABGPU_FLAG_PAIR_TABLE_*): FABGPU_PAIR_TABLE=lds / global force one (A/B runs), otherwise -1 = by batch size (launch_p256_verify).
+int pair_table_default() {
+    static const int v = [] {
+        const char* e = getenv("FABGPU_PAIR_TABLE");
+        return !e ? -1 : (e[0] == 'l' ? 1 : (e[0] == 'g' ? 0 : -1));
+    }();
+    return v;
+}
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair) {
     VerifyGeom g = verify_geom(n, allow_pair);
     if (g.pair) return (size_t)g.wgs * (g.block / 2) * QWS_PAIR_UINT4_PER_SIG * 16;
     return (size_t)g.wgs * g.block * QWS_UINT4_PER_LANE * 16;
 }
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
-                              const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st, uint32_t lds_reserve) {
+                              const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st, uint32_t lds_reserve, int table_lds) {
     if (n == 0) return hipSuccess;
     VerifyGeom g = verify_geom(n, allow_pair);
     dim3 grid(g.wgs), block(g.block);
+    // The per-signature table of the pair kernel: in LDS when the launch is large (measured on MI355X, tools/gpu_pair_table_ab.py and
+    // tools/gpu_pmc_traffic.sh: at 30 000 tuples the two forms take the same time - 0.631 / 0.629 ms back to back - and the LDS form
+    // moves 94 MB through the memory system per launch instead of 279 MB); in the global workspace for smaller ones, where the LDS
+    // form's 13 extra additions show as latency (10 000 tuples: 0.624 against 0.614 ms; 1 000: 0.618 against 0.603 ms).
+    if (table_lds < 0) table_lds = n > (uint32_t)PAIR_TABLE_LDS_FROM ? 1 : 0;
+    if (g.pair && table_lds) {
+        hipLaunchKernelGGL(p256_verify_pair_lds_kernel<VERIFY_BLOCK>, grid, block, (size_t)(VERIFY_BLOCK / 2) * PAIR_LDS_CELLS_PER_SIG * 16, st, n, (const uint8_t*)qx,
+                           (const uint8_t*)qy, (const uint8_t*)e, (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint64_t*)verdict_bits, (uint8_t*)status);
+        return hipGetLastError();
+    }
     if (g.pair) {
         hipLaunchKernelGGL(p256_verify_pair_kernel<VERIFY_BLOCK>, grid, block, lds_reserve, st, n, (const uint8_t*)qx, (const uint8_t*)qy, (const uint8_t*)e,
                            (const uint8_t*)r, (const uint8_t*)s, (const int32_t*)gtab, (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);

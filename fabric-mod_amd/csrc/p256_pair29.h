@@ -109,6 +109,68 @@ struct PairQTab {
     }
 };
 
+// The same table in LDS, EIGHT entries per signature (j*Q, j = 1..8, for signed 4-bit windows): 128 signatures x 8 x 128 B = 128 KiB of
+// the CU's 160 KiB - the pair kernel runs one workgroup per CU anyway.  Costs 13 more additions per verification than the 16-entry
+// table with 5-bit windows (65 windows instead of 52) and saves eight table-building operations; in exchange NOTHING of the
+// per-signature table touches the memory system: the global-workspace form writes 60 MB and fetches 2 x 110 MB per 30 000-tuple
+// launch (58x the algorithmic bytes), which is free on an idle chip and costs 4-17 % beside a tenant that streams 1.5-5 TB/s
+// (tools/gpu_hbm_tenant_probe.py).  A signature's entries are 65 cells apart (one cell of padding per signature): a wave's 32 pairs
+// gather from 32 different signatures, and a 1 KiB stride would put them all on the same banks.
+constexpr int PAIR_LDS_ENTRIES = 8;
+constexpr int PAIR_LDS_CELLS_PER_SIG = PAIR_LDS_ENTRIES * 8 + 1;
+struct PairQTabLds {
+    uint4* pair;   // (LDS) first cell of this signature's table
+    static __device__ __forceinline__ PairQTabLds of(uint4* lds, uint32_t k) { return PairQTabLds{lds + (size_t)k * PAIR_LDS_CELLS_PER_SIG}; }
+    __device__ __forceinline__ uint4* cell(int j, int q) const { return pair + ((j - 1) * 8 + q); }
+    __device__ __forceinline__ void store_state(int j, const pair_pt& p, bool odd) const {
+        if (!odd) {
+            *cell(j, 0) = make_uint4(p.A.v[0], p.A.v[1], p.A.v[2], p.A.v[3]);
+            *cell(j, 1) = make_uint4(p.A.v[4], p.A.v[5], p.A.v[6], p.A.v[7]);
+            *cell(j, 2) = make_uint4(p.A.v[8], p.B.v[0], p.B.v[1], p.B.v[2]);
+            *cell(j, 3) = make_uint4(p.B.v[3], p.B.v[4], p.B.v[5], p.B.v[6]);
+            *cell(j, 4) = make_uint4(p.B.v[7], p.B.v[8], 0, 0);
+        } else {
+            *cell(j, 5) = make_uint4(p.B.v[0], p.B.v[1], p.B.v[2], p.B.v[3]);
+            *cell(j, 6) = make_uint4(p.B.v[4], p.B.v[5], p.B.v[6], p.B.v[7]);
+            *cell(j, 7) = make_uint4(p.B.v[8], 0, 0, 0);
+        }
+        // the partner lane reads what this lane wrote (and the other way round): same wavefront, in-order LDS - only the compiler
+        // must not move accesses across
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void load5(uint32_t j, int q0, uint4 (&l)[5]) const {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int q = q0 + k;
+            l[k] = *cell((int)j, q > 7 ? 7 : q);
+        }
+    }
+    __device__ __forceinline__ void load_state(uint32_t j, pair_pt& p, bool odd) const {
+        uint4 l[5];
+        load5(j, odd ? 5 : 0, l);
+        p.A.v[0] = l[0].x; p.A.v[1] = l[0].y; p.A.v[2] = l[0].z; p.A.v[3] = l[0].w;
+        p.A.v[4] = l[1].x; p.A.v[5] = l[1].y; p.A.v[6] = l[1].z; p.A.v[7] = l[1].w;
+        p.A.v[8] = l[2].x;
+        fe y;
+        y.v[0] = l[2].y; y.v[1] = l[2].z; y.v[2] = l[2].w;
+        y.v[3] = l[3].x; y.v[4] = l[3].y; y.v[5] = l[3].z; y.v[6] = l[3].w;
+        y.v[7] = l[4].x; y.v[8] = l[4].y;
+        fe_sel(p.B, odd, p.A, y);
+    }
+    __device__ __forceinline__ void load_crossed(uint32_t j, fe& C, fe& D, bool odd) const {
+        uint4 l[5];
+        load5(j, odd ? 0 : 5, l);
+        C.v[0] = l[0].x; C.v[1] = l[0].y; C.v[2] = l[0].z; C.v[3] = l[0].w;
+        C.v[4] = l[1].x; C.v[5] = l[1].y; C.v[6] = l[1].z; C.v[7] = l[1].w;
+        C.v[8] = l[2].x;
+        D.v[0] = l[2].y; D.v[1] = l[2].z; D.v[2] = l[2].w;
+        D.v[3] = l[3].x; D.v[4] = l[3].y; D.v[5] = l[3].z; D.v[6] = l[3].w;
+        D.v[7] = l[4].x; D.v[8] = l[4].y;
+    }
+};
+
 // E gets x2, O gets y2 of comb entry (window, digit) in the SAME nine registers (they are passed as both C and D of PAIR_MADD)
 template <class Tab>
 __device__ __forceinline__ void pair_comb_load(const int32_t* __restrict__ tab, int window, uint32_t digit, bool odd, fe& xy) {
@@ -256,31 +318,42 @@ __device__ __forceinline__ void pair_final_add29(pair_pt& Rr, bool& r_inf, const
 }
 
 // R = u1*G + u2*Q on a lane pair.  Q: affine Montgomery (both lanes hold both coordinates).  Returns the pair state of R;
-// r_inf as in p256_combined_mult29.
-template <class QTab>
+// r_inf as in p256_combined_mult29.  W = width of the signed (Booth) windows over u2: 5 (a 16-entry table j*Q, 52 windows: the
+// global-workspace table) or 4 (8 entries, 65 windows: the LDS table).
+//
+// No addition inside the loop may meet P == +-Q (the addition formulas do not handle it).  Before window i is added T = M Q with M a
+// non-zero multiple of 2^W and the addend is d Q, |d| <= 2^(W-1).  M == +-d (mod n) needs M = n +- |d| (M >= 2^W > |d|), possible
+// only at the last window, where M = u2 - d: M = n - d gives u2 = n, impossible; M = n + d with d < 0 gives u2 = n - 2|d| and needs
+// |d| == n (mod 2^W).  n mod 32 = 17 > 16: never for W = 5.  n mod 16 = 1: for W = 4 EXACTLY ONE scalar, u2 = n - 2
+// (digit -1 on top of M = n - 1: T = -Q, addend -Q).  That scalar is recognised up front and its product, -2Q, is taken from the
+// table (entry 2, negated) instead of from the loop.
+template <class QTab, int W = 5>
 __device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, const u256& u1, const u256& u2, const fe& QX, const fe& QY,
                                                      const int32_t* __restrict__ gtab, const QTab& qtab, bool odd) {
+    static_assert(W == 4 || W == 5, "signed 4- or 5-bit windows");
+    constexpr int TAB = 1 << (W - 1);                 // entries j*Q, j = 1..TAB
+    constexpr int NWIN = (257 + W - 1) / W;           // windows over bits -1 .. 256 of a scalar below n
     const fe ONE = {FE29_R1};
     PAIR_TMPS;
     pair_pt Qp;
     Qp.A = QX;
     fe_sel(Qp.B, odd, ONE, QY);
 
-    // --- per-signature table j*Q, j = 1..16 ---
+    // --- per-signature table j*Q, j = 1..TAB ---
     qtab.store_state(1, Qp, odd);
 #pragma unroll 1
-    for (int j = 2; j <= 16; j += 2) {
+    for (int j = 2; j <= TAB; j += 2) {
         pair_pt d;
         qtab.load_state((uint32_t)(j >> 1), d, odd);
         PAIR_DBL(d);
         qtab.store_state(j, d, odd);
-        if (j < 16) {
+        if (j < TAB) {
             PAIR_MADD(d, QX, QY);
             qtab.store_state(j + 1, d, odd);
         }
     }
 
-    // --- T = u2 * Q : 52 signed 5-bit windows (same recoding as p256_combined_mult29) ---
+    // --- T = u2 * Q : NWIN signed W-bit windows (same recoding as p256_combined_mult29 for W = 5) ---
     uint32_t kw[9];
 #pragma unroll
     for (int i = 0; i < 8; i++) kw[i] = u2.w[i];
@@ -288,23 +361,23 @@ __device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, c
     pair_pt T = Qp;
     bool t_inf = true;
 #pragma unroll 1
-    for (int i = Q5_WINDOWS - 1; i >= 0; i--) {
-        uint32_t six;
+    for (int i = NWIN - 1; i >= 0; i--) {
+        uint32_t field;                               // bits W i - 1 .. W i + W - 1 of the scalar (bit -1 = 0)
         if (i == 0) {
-            six = (kw[0] << 1) & 63u;
+            field = (kw[0] << 1) & ((2u << W) - 1u);
         } else {
-            int p = 5 * i - 1;
+            int p = W * i - 1;
             uint64_t two = ((uint64_t)kw[(p >> 5) + 1] << 32) | kw[p >> 5];
-            six = (uint32_t)(two >> (p & 31)) & 63u;
+            field = (uint32_t)(two >> (p & 31)) & ((2u << W) - 1u);
         }
-        int32_t digit = (int32_t)((six >> 1) & 15u) + (int32_t)(six & 1u) - (int32_t)((six >> 5) << 4);
+        int32_t digit = (int32_t)((field >> 1) & (uint32_t)(TAB - 1)) + (int32_t)(field & 1u) - (int32_t)((field >> W) << (W - 1));
         bool neg = digit < 0;
         uint32_t mag = (uint32_t)(neg ? -digit : digit);
         fe C, D;
         qtab.load_crossed(mag ? mag : 1u, C, D, odd);   // issued ahead of the doublings
-        if (i != Q5_WINDOWS - 1) {
+        if (i != NWIN - 1) {
 #pragma unroll 1
-            for (int k = 0; k < 5; k++) PAIR_DBL(T);
+            for (int k = 0; k < W; k++) PAIR_DBL(T);
         }
 #pragma unroll
         for (int l = 0; l < 9; l++) D.v[l] = neg ? -D.v[l] : D.v[l];   // -Y2 (lives on O)
@@ -323,6 +396,22 @@ __device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, c
             pair_sel(T, take_ent, ent, T);
         }
         t_inf = t_inf & (mag == 0);
+    }
+    if (W == 4) {
+        // u2 = n - 2: the one scalar whose last addition is a doubling (see above).  (n - 2) Q = -2Q: entry 2, Y negated.
+        const u256 NM2 = {{0xFC63254Fu, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu}};
+        bool special = true;
+#pragma unroll
+        for (int l = 0; l < 8; l++) special = special & (u2.w[l] == NM2.w[l]);
+        if (__any(special)) {
+            pair_pt two;
+            qtab.load_state(2u, two, odd);
+            fe ny;
+#pragma unroll
+            for (int l = 0; l < 9; l++) ny.v[l] = -two.B.v[l];
+            fe_sel(two.B, odd, two.B, ny);        // E holds Y in B (negate it), O holds Z in B (keep it)
+            pair_sel(T, special, two, T);
+        }
     }
 
     // --- S = u1 * G (16-bit comb), then R = S + T ---
@@ -373,7 +462,7 @@ __device__ __forceinline__ bool pair_x_equals_r29(const pair_pt& Rr, bool r_inf,
 }
 
 // Status of one tuple, valid on the EVEN lane of the pair.
-template <class QTab>
+template <class QTab, int W = 5>
 __device__ __forceinline__ uint32_t p256_verify_pair29(const u256& qx, const u256& qy, const u256& e, const u256& r, const u256& s,
                                                         const int32_t* __restrict__ gtab, const QTab& qtab, bool odd) {
     const u256 P = FAB_P256_P;
@@ -391,7 +480,7 @@ __device__ __forceinline__ uint32_t p256_verify_pair29(const u256& qx, const u25
 
     pair_pt Rr;
     bool r_inf;
-    pair_combined_mult29(Rr, r_inf, u1, u2, QX, QY, gtab, qtab, odd);
+    pair_combined_mult29<QTab, W>(Rr, r_inf, u1, u2, QX, QY, gtab, qtab, odd);
     bool ok = pair_x_equals_r29(Rr, r_inf, r);
     uint32_t st = ok ? ST_VALID : ST_BAD_MATH;
     return early != ST_VALID ? early : st;

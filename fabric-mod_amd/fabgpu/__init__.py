@@ -29,6 +29,8 @@ FABGPU_EINVAL = -1
 FLAG_ONE_LANE_ONLY = 1   # fabgpu.h FABGPU_FLAG_ONE_LANE_ONLY
 FLAG_TIME_KERNELS = 2    # fabgpu.h FABGPU_FLAG_TIME_KERNELS
 FLAG_NO_QUAD = 4         # fabgpu.h FABGPU_FLAG_NO_QUAD (idemix: never the four-lanes-per-signature kernel)
+FLAG_PAIR_TABLE_LDS = 8      # fabgpu.h: the verify-only pair kernel keeps its per-signature table in LDS
+FLAG_PAIR_TABLE_GLOBAL = 16  # ... in the global workspace
 ST_VALID, ST_BAD_MATH, ST_HIGH_S, ST_RANGE, ST_OFF_CURVE = 0, 1, 2, 3, 4
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)

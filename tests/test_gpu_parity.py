@@ -32,13 +32,57 @@ def _arr(items):
     return np.frombuffer(b"".join(items), dtype=np.uint8).reshape(-1, 32).copy()
 
 
-@pytest.fixture(scope="module", params=["auto", "one-lane"])
+@pytest.fixture(scope="module", params=["auto", "one-lane", "pair-table-lds", "pair-table-global"])
 def ctx(request):
     """auto = the product default (two lanes per signature up to 32 768 tuples, one lane beyond);
-    one-lane = FABGPU_FLAG_ONE_LANE_ONLY, so that every fixture and edge vector also goes through the one-lane kernel."""
-    c = fabgpu.Context(device=0, flags=fabgpu.FLAG_TIME_KERNELS | (fabgpu.FLAG_ONE_LANE_ONLY if request.param == "one-lane" else 0))
+    one-lane = FABGPU_FLAG_ONE_LANE_ONLY, so that every fixture and edge vector also goes through the one-lane kernel;
+    pair-table-lds / -global = the two homes of the pair kernel's per-signature table (8 entries + signed 4-bit windows in LDS / 16
+    entries + 5-bit windows in the global workspace): every fixture and edge vector through both, whichever is the default."""
+    extra = {"auto": 0, "one-lane": fabgpu.FLAG_ONE_LANE_ONLY, "pair-table-lds": fabgpu.FLAG_PAIR_TABLE_LDS, "pair-table-global": fabgpu.FLAG_PAIR_TABLE_GLOBAL}
+    c = fabgpu.Context(device=0, flags=fabgpu.FLAG_TIME_KERNELS | extra[request.param])
     yield c
     c.close()
+
+
+def test_scalars_at_the_window_recodings_edges(ctx):
+    """VALID signatures whose u2 = r / s (the scalar that multiplies the public key) sits where a signed-window recoding can go wrong:
+    n - 2 (with 4-bit windows the ONE scalar whose last addition is a doubling, T = -Q plus -Q: p256_pair29.h takes -2Q from the table
+    instead), n - 1, small values, all-ones digits, the values around every power of 16 and 32 at the top.  A signer can hit any u2 it
+    likes by choosing its private key after the fact: for a digest e and a nonce k, r = x(kG), s = r / u2, d = (s k - e) / r."""
+    rng = np.random.default_rng(4)
+    targets = [po.N - 2, po.N - 1, po.N - 3, po.N - 16, po.N - 17, po.N - 18, po.N - 32, po.N - 34, 1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33,
+               (1 << 255) - 1, 1 << 255, (1 << 255) + 8, (1 << 256) % po.N, int("8" * 64, 16) % po.N, int("7" * 64, 16), int("f" * 63, 16),
+               int("1" * 64, 16), po.N >> 1, (po.N >> 1) + 1]
+    rows, want = [], []
+    for u2 in targets:
+        for _ in range(200):
+            k = int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) + 1
+            R = po.pt_mul(k, (po.GX, po.GY))
+            r = R[0] % po.N
+            s = r * pow(u2, -1, po.N) % po.N
+            if r == 0 or not po.is_low_s(s):
+                continue
+            digest = bytes(rng.integers(0, 256, size=32, dtype=np.uint8))
+            e = int.from_bytes(digest, "big")
+            d = (s * k - e) * pow(r, -1, po.N) % po.N
+            if d == 0:
+                continue
+            Q = po.pt_mul(d, (po.GX, po.GY))
+            assert po.ecdsa_verify_raw(Q[0], Q[1], digest, r, s)
+            rows.append((_h32("%064x" % Q[0]), _h32("%064x" % Q[1]), digest, _h32("%064x" % r), _h32("%064x" % s)))
+            want.append(0)
+            rows.append((_h32("%064x" % Q[0]), _h32("%064x" % Q[1]), digest, _h32("%064x" % r), _h32("%064x" % ((s + 1) % po.N or 1))))   # same key, another s
+            want.append(None)
+            break
+        else:
+            raise AssertionError("no low-S signature found for u2 = %x" % u2)
+    cols = [_arr([row[c] for row in rows]) for c in range(5)]
+    bits, st = ctx.p256_verify_batch(*cols)
+    oracle = coracle.verify_batch(*cols)
+    assert (st == oracle).all()
+    for i, w in enumerate(want):
+        if w is not None:
+            assert st[i] == 0 and bits[i], (i, hex(targets[i // 2]))
 
 
 @pytest.fixture(scope="module")
