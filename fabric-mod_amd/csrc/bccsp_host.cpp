@@ -809,10 +809,13 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
         const int ft = nt >= 8192 ? std::min(gate_max, 16) : 1;
         std::vector<uint32_t> cnt_e(ft + 1, 0), cnt_b(ft + 1, 0);
         std::atomic<int> met(0), cleared(0);
+        // (the workers meet at spin barriers; one that cannot go on - worker 0 allocates between two of them - raises `aborted`, which
+        // every barrier watches: nobody spins for a worker that is gone, the block simply gets no memo entries)
+        std::atomic<bool> aborted(false);
         BlockMemo* raw = bm.get();
         uint32_t m = 0;
         bool too_big = false;
-        auto work = [&](int w) {
+        auto work_body = [&](int w) {
             const size_t lo = nt * w / ft, hi = nt * (w + 1) / ft;
             uint32_t ce = 0, cb = 0;
             for (size_t i = lo; i < hi; i++)
@@ -823,7 +826,8 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
             cnt_e[w + 1] = ce;
             cnt_b[w + 1] = cb;
             met.fetch_add(1, std::memory_order_acq_rel);
-            while (met.load(std::memory_order_acquire) < ft) std::this_thread::yield();
+            while (met.load(std::memory_order_acquire) < ft && !aborted.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (aborted.load(std::memory_order_acquire)) return;
             if (w == 0) {                                  // sizes are known: worker 0 makes room, the others wait for it
                 uint64_t tm = 0, tb = 0;
                 for (int v = 0; v < ft; v++) {
@@ -850,13 +854,14 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
                 }
                 cleared.store(1, std::memory_order_release);
             }
-            while (cleared.load(std::memory_order_acquire) < 1) std::this_thread::yield();
-            if (!m || too_big) return;
+            while (cleared.load(std::memory_order_acquire) < 1 && !aborted.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (aborted.load(std::memory_order_acquire) || !m || too_big) return;
             // every worker clears its share of the table, then all meet again before anybody inserts
             const size_t cap = (size_t)raw->mask + 1;
             for (size_t k = cap * w / ft; k < cap * (w + 1) / ft; k++) raw->slots[k].store(0, std::memory_order_relaxed);
             cleared.fetch_add(1, std::memory_order_acq_rel);
-            while (cleared.load(std::memory_order_acquire) < 1 + ft) std::this_thread::yield();
+            while (cleared.load(std::memory_order_acquire) < 1 + ft && !aborted.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (aborted.load(std::memory_order_acquire)) return;
             uint32_t e = 0, off = 0;
             for (int v = 0; v < w; v++) {
                 e += cnt_e[v + 1];
@@ -881,9 +886,16 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
                 e++;
             }
         };
+        auto work = [&](int w) {
+            try {
+                work_body(w);
+            } catch (...) {                                // bad_alloc: no entries for this block, never a stuck pool or a terminate()
+                aborted.store(true, std::memory_order_release);
+            }
+        };
         if (ft == 1) work(0);
         else run_workers(ft, work);                       // all ft run at once (they meet at spin barriers): worker_pool.h
-        if (too_big) m = 0;
+        if (too_big || aborted.load()) m = 0;
         bm->n = m;
         out.memo_seeded = m;
         if (m) {
@@ -1420,7 +1432,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     };
     auto clk0 = std::chrono::steady_clock::now();
     static const int gate_max = [] { const char* e = getenv("FABGPU_PASS_GATE_THREADS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
-    const int nthreads = std::min(gate_max, nt >= 16384 ? 16 : (nt >= 4096 ? 8 : 1));
+    const int nthreads = std::min(gate_max, nt >= 16384 ? 16 : (nt >= 4096 ? 8 : 1));     // <= 16 = the pool + the caller: all of them run at once (they meet at a barrier)
     auto in_threads = [&](const std::function<void(int, size_t, size_t)>& fn) {       // fn(worker, lo, hi) over contiguous tuple ranges
         if (nthreads == 1) {
             fn(0, 0, nt);
@@ -1447,10 +1459,17 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
     if (r.size() < nt * 32) r.resize(nt * 32);
     if (s.size() < nt * 32) s.resize(nt * 32);
     std::atomic<int> arrived(0);
+    std::atomic<bool> gate_failed(false);      // a worker that threw (bad_alloc while decoding an identity): the others do not wait for it
     double ms_gates_max = 0;
     std::mutex gm;
     in_threads([&](int w, size_t lo, size_t hi) {
-        gate_range(lo, hi, &new_ids[w]);
+        try {
+            gate_range(lo, hi, &new_ids[w]);
+        } catch (...) {
+            gate_failed.store(true, std::memory_order_release);
+            arrived.fetch_add(1, std::memory_order_acq_rel);
+            return;
+        }
         size_t c = 0;
         for (size_t i = lo; i < hi; i++)
             if (gt[i].submit) {
@@ -1465,6 +1484,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         }
         arrived.fetch_add(1, std::memory_order_acq_rel);
         while (arrived.load(std::memory_order_acquire) < nthreads) std::this_thread::yield();
+        if (gate_failed.load(std::memory_order_acquire)) return;
         size_t j = 0;
         for (int v = 0; v < w; v++) j += cnt[v + 1];
         for (size_t i = lo; i < hi; i++) {
@@ -1483,6 +1503,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
             j++;
         }
     });
+    if (gate_failed.load()) return Error("out of memory in the signature gates");     // an infrastructure error: never a verdict
     for (uint32_t v : new_ids) out.distinct_identities += v;
     out.ms_gates = ms_gates_max;
     size_t n = 0;

@@ -199,6 +199,21 @@ static int multi_verify(fabgpu_multi* m, size_t n, const uint8_t* arena, const u
     const size_t wpr = p.words_per_rank;
     const int nf = hash ? 4 : 5;
     int rc = FABGPU_OK;
+    // Whatever way this function is left, nothing it queued may still be in flight (the next call may free or regrow the staging
+    // buffers a copy or a kernel still reads) and the caller's current device is what it was: every early return below runs this.
+    struct Quiesce {
+        fabgpu_multi* m;
+        int prev = -1;
+        bool clean = false;               // the normal path has synchronised every stream itself
+        explicit Quiesce(fabgpu_multi* m_) : m(m_) { hipGetDevice(&prev); }
+        ~Quiesce() {
+            if (!clean)
+                for (auto& d : m->dev) {
+                    if (hipSetDevice(d.ordinal) == hipSuccess && d.stream) hipStreamSynchronize(d.stream);
+                }
+            if (prev >= 0) hipSetDevice(prev);
+        }
+    } quiesce(m);
     // 1. per device: stage the shard, upload, launch - everything asynchronous on the device's own stream
     for (uint32_t g = 0; g < G; g++) {
         Dev& d = m->dev[g];
@@ -285,6 +300,7 @@ static int multi_verify(fabgpu_multi* m, size_t n, const uint8_t* arena, const u
         memcpy(verdict_bits + p.word_at[g], srcw, w * 8);
         if (status) memcpy(status + p.lo[g], (const uint8_t*)m->dev[g].h_out + round_up((size_t)G * wpr * 8, 64), cnt);
     }
+    quiesce.clean = true;
     return FABGPU_OK;
 }
 
