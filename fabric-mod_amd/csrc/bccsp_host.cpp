@@ -1034,9 +1034,22 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     if (!DeviceWalkEnabled()) return declined("FABGPU_PASS_DEVICE_WALK=0");
     if (!block || !up.th.joinable()) return declined("the block was not staged ahead (small block)");
     if (getenv("FABGPU_PASS_SKIP_HASH_CHECKS")) return declined("FABGPU_PASS_SKIP_HASH_CHECKS");
+    // the idemix MSPs whose creators the pass verifies (an MSP id registered with two different issuer keys is not among them: its
+    // creators stay with bccsp/idemix, as on the host route)
+    std::vector<DevIdemixMsp> msps;
     {
         std::lock_guard<std::mutex> lk(idmu_);
-        if (!idemix_msps_.empty()) return declined("idemix MSPs are registered (their creators are recognised on the host)");
+        for (const auto& kv : idemix_msps_) {
+            if (kv.second < 0) continue;
+            if (kv.first.size() > WALK_IDEMIX_MSPID_MAX || msps.size() >= WALK_IDEMIX_MSPS_MAX)
+                return declined("more idemix MSPs (or a longer MSP id) than the device route carries");
+            DevIdemixMsp m;
+            memset(&m, 0, sizeof(m));
+            m.len = (uint32_t)kv.first.size();
+            m.issuer = (int32_t)kv.second;
+            memcpy(m.id, kv.first.data(), kv.first.size());
+            msps.push_back(m);
+        }
     }
     struct Lease {
         const GPUCSP* c;
@@ -1077,11 +1090,11 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         ParsedBlock& pb;
         BlockVerdicts& out;
         PassScratch& ps;
-        bool want_tuples, want_digests, want_qxy;
+        bool want_tuples, want_digests, want_qxy, want_nym_issuer;
         uint32_t cap_tx, cap_tuples, n_skipped;
         uint32_t n_tuples = 0;
         bool too_big = false;
-    } sz{pb, out, ps, want_tuples, want_digests, want_qxy, cap_tx, cap_tuples, n_skipped};
+    } sz{pb, out, ps, want_tuples, want_digests, want_qxy, opt.seed_memo && !msps.empty(), cap_tx, cap_tuples, n_skipped};
     WalkRequest rq;
     rq.stage_token = tok;
     rq.block_len = len;
@@ -1127,6 +1140,10 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         } else {
             z.out.tuple_digest.clear();
         }
+        if (z.want_nym_issuer) {                                         // which issuer an idemix creator's row was verified under (memo binding)
+            z.ps.nym_issuer_rank.resize(c.n_creators);
+            o.nym_issuer = z.ps.nym_issuer_rank.data();
+        }
         if (z.want_qxy) {                                                // the key of every tuple's identity, as the device matched or decoded it
             z.out.tuple_qxy.resize(nt * 64);
             o.tuple_qxy = z.out.tuple_qxy.data();
@@ -1137,6 +1154,8 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     };
     ps.learn.resize(WALK_LEARN_SLOTS);
     rq.learn_out = ps.learn.data();
+    rq.idemix_msps = msps.data();
+    rq.n_idemix_msps = (uint32_t)msps.size();
     auto clk2 = std::chrono::steady_clock::now();
     rc = walk_block_pass(ctx_, rq);
     out.ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk2).count();
@@ -1166,6 +1185,17 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     out.n_keyed = (rq.keyed_creators ? rq.summary.n_hashed_creator : 0u) + (rq.keyed_others ? rq.summary.n_hashed_other : 0u);
     out.n_device_decoded = rq.summary.n_unknown_identity;
     out.tuple_nym_issuer.clear();
+    if (sz.want_nym_issuer && rq.summary.n_nym != 0 && want_tuples) {
+        // the memo binds a pseudonym signature's entry to the issuer it was verified under: issuer ids come back by creator rank, and
+        // creator tuples appear in rank order (every tuple-yielding envelope yields exactly one, its first)
+        out.tuple_nym_issuer.assign(nt, -1);
+        size_t rank = 0;
+        for (size_t i = 0; i < nd; i++)
+            if (pb.tuples[i].kind == TUPLE_CREATOR) {
+                if (rank < ps.nym_issuer_rank.size()) out.tuple_nym_issuer[i] = ps.nym_issuer_rank[rank];
+                rank++;
+            }
+    }
     for (size_t i = nd; i < nt; i++) {                                   // block signatures the caller asked not to verify
         out.tuple_status[i] = TUPLE_ST_SKIPPED;
         out.tuple_hashed[i] = 0;

@@ -289,6 +289,7 @@ class GPUCSP {
         std::vector<uint32_t> env_spans, payload_spans, id_idx;
         std::vector<BlockTuple> block_sigs;
         std::vector<WalkLearn> learn;              // identities the device decoded and offers to the cache
+        std::vector<int32_t> nym_issuer_rank;      // device route: issuer id of an idemix creator's row, by creator rank (-1: not one)
     };
     struct CoReqV : CoalescedBase {
         VerifyItem item;

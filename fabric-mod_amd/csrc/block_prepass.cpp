@@ -158,20 +158,11 @@ bool HashCheckMatches(const uint8_t* block, const BlockHashCheck& hc, const uint
 }
 
 bool IdentityToIdemixNym(const uint8_t* ident, size_t len, std::string& mspid, uint8_t nx[32], uint8_t ny[32]) {
-    const uint8_t *idb, *ms;
-    size_t idl, msl;
-    if (!pb_bytes(ident, len, 2, idb, idl) || !pb_bytes(ident, len, 1, ms, msl)) return false;
-    PbReader r(idb, idl);
-    PbField f;
-    bool hx = false, hy = false, proof = false;
-    while (r.next(f)) {
-        if (f.wt != 2) continue;
-        if (f.num == 1 && f.len == 32) { memcpy(nx, f.data, 32); hx = true; }
-        if (f.num == 2 && f.len == 32) { memcpy(ny, f.data, 32); hy = true; }
-        if (f.num == 5) proof = true;
-    }
-    if (!r.ok || !hx || !hy || !proof) return false;
-    mspid.assign((const char*)ms, msl);
+    walk::IdemixNymRef ref;
+    if (!walk::identity_to_idemix_nym(ident, len, ref)) return false;       // (block_walk_core.h: shared with the gate kernel)
+    memcpy(nx, ref.nx, 32);
+    memcpy(ny, ref.ny, 32);
+    mspid.assign((const char*)ref.mspid, ref.mspid_len);
     return true;
 }
 

@@ -598,6 +598,53 @@ WALK_HD inline int pem_char_class(uint8_t c) {
     return PEM_INVALID;
 }
 
+// ---- idemix creators ---------------------------------------------------------------------------------------------------------------
+// msp.SerializedIdentity{1 mspid, 2 id_bytes = msp.SerializedIdemixIdentity{1 nym_x, 2 nym_y, 3 ou, 4 role, 5 proof}} (what
+// idemixidentity.Serialize writes, msp/idemixmsp.go:605-640) -> where the MSP id and the two 32-byte pseudonym coordinates lie.
+// false: not such an identity (or coordinates of another size: those stay with bccsp/idemix).  One body of code for the host's
+// IdentityToIdemixNym (block_prepass.cpp) and the gate kernel.
+struct IdemixNymRef {
+    const uint8_t* mspid = nullptr;
+    uint32_t mspid_len = 0;
+    const uint8_t* nx = nullptr;
+    const uint8_t* ny = nullptr;
+};
+WALK_HD inline bool identity_to_idemix_nym(const uint8_t* ident, size_t len, IdemixNymRef& out) {
+    Pick idb(2), ms(1);
+    if (!pb_pick(ident, len, &idb, 1) || idb.seen != 1) return false;
+    if (!pb_pick(ident, len, &ms, 1) || ms.seen != 1) return false;
+    PbReader r(idb.p, idb.len);
+    PbField f;
+    bool proof = false;
+    out.nx = out.ny = nullptr;
+    while (r.next(f)) {
+        if (f.wt != 2) continue;
+        if (f.num == 1 && f.len == 32) out.nx = f.data;
+        if (f.num == 2 && f.len == 32) out.ny = f.data;
+        if (f.num == 5) proof = true;
+    }
+    if (!r.ok || !out.nx || !out.ny || !proof) return false;
+    out.mspid = ms.p;
+    out.mspid_len = (uint32_t)ms.len;
+    return true;
+}
+// idemix.NymSignature{1 proof_c, 2 proof_s_sk, 3 proof_s_r_nym, 4 nonce} (last occurrence wins, as proto.Unmarshal): true when the bytes
+// are a protobuf message AND all four fields are 32 bytes (what the nym kernels take; anything else stays with bccsp/idemix)
+WALK_HD inline bool unmarshal_nym_signature32(const uint8_t* raw, size_t len, const uint8_t* (&field)[4]) {
+    size_t flen[4] = {0, 0, 0, 0};
+    field[0] = field[1] = field[2] = field[3] = nullptr;
+    PbReader r(raw, len);
+    PbField f;
+    while (r.next(f)) {
+        if (f.num == 0) return false;                                  // "illegal tag 0"
+        if (f.wt == 2 && f.num >= 1 && f.num <= 4) {
+            field[f.num - 1] = f.data;
+            flen[f.num - 1] = f.len;
+        }
+    }
+    return r.ok && flen[0] == 32 && flen[1] == 32 && flen[2] == 32 && flen[3] == 32;
+}
+
 // ---- identity bytes -> 64-bit table hash ---------------------------------------------------------------------------------
 // The device looks identities up in a table of the ones the provider has met (block_walk_kernels.hip); the hash only picks the slot,
 // equality is always decided on ALL the bytes.  It covers the length and two rows of 64 bytes that a wavefront loads with one

@@ -51,10 +51,23 @@ struct WalkSummary {
     uint32_t n_unkeyed_other;      // the same for endorsements and block signatures
     uint32_t n_hashed_creator;     // tuples the device hashed and decided, by launch class (status kernel)
     uint32_t n_hashed_other;
+    uint32_t n_nym;                // idemix creators whose pseudonym signature went to the nym kernel
     uint32_t n_general_der;        // signatures that took the general DER parser (statistics)
     uint32_t n_learn;              // (identity kernel) identities offered to the provider's cache in learn[] (distinct by table hash)
-    uint32_t pad[2];
+    uint32_t pad[1];
 };
+// An idemix MSP the provider knows (GPUCSP::RegisterIdemixMSP): creators serialized under this MSP id sign with pseudonym signatures, which
+// the device route verifies itself since round 3 (the gate kernel recognises msp.SerializedIdemixIdentity and unmarshals the
+// idemix.NymSignature; the nym kernels of idemix_kernels.hip run beside the ECDSA launches over rows indexed by creator rank).
+constexpr uint32_t WALK_IDEMIX_MSPS_MAX = 16;
+constexpr uint32_t WALK_IDEMIX_MSPID_MAX = 120;
+struct DevIdemixMsp {
+    uint32_t len;                  // of the MSP id
+    int32_t issuer;                // device issuer id (fabgpu_idemix_issuer_register)
+    uint8_t id[WALK_IDEMIX_MSPID_MAX];
+};
+static_assert(sizeof(DevIdemixMsp) == 128, "uploaded as raw bytes");
+
 // An identity the device decoded and the provider may want in its cache (and, once it has been named often enough, with a comb table):
 // one slot per table hash, first come first served - a block offers at most WALK_LEARN_SLOTS new identities, whoever is left shows up
 // again in the next block if it matters.
@@ -104,6 +117,16 @@ struct WalkArrays {
     uint8_t *qx = nullptr, *qy = nullptr, *r = nullptr, *s = nullptr;
     uint8_t* gate_st = nullptr;
     uint8_t* tflags = nullptr;           // per tuple: what the gate / identity kernels note for the summary (the status kernel adds them up)
+    // idemix creators (null / 0: no idemix MSP is registered).  Rows by CREATOR RANK (cbase): six 32-byte columns, issuer, message span;
+    // creators that are not idemix keep an all-zero row the nym kernel answers "not decided" for, and nobody reads.
+    const DevIdemixMsp* idemix_msps = nullptr;
+    uint32_t n_idemix_msps = 0;
+    uint8_t* nym_fields = nullptr;       // 6 columns x 32 n_creators: nym_x, nym_y, proof_c, proof_s_sk, proof_s_r_nym, nonce
+    uint32_t* nym_issuer = nullptr;      // n_creators
+    int32_t* nym_issuer_out = nullptr;   // n_creators: the issuer id of an ACTIVE row, -1 otherwise (the memo binds entries to the issuer)
+    uint32_t* nym_spans = nullptr;       // 2 n_creators: (start, end) of the signed message = the envelope payload
+    const uint64_t* nym_bits = nullptr;  // results of the nym launch, by creator rank
+    const uint8_t* nym_status = nullptr;
     WalkLearn* learn = nullptr;          // WALK_LEARN_SLOTS slots, zeroed per pass
     // Row of tuple i in the submission arrays.  Plain: row = i.  Split (a block of 32 769 .. 65 536 tuples): the creator tuples - long
     // messages (the whole envelope payload), no shared prefix - take rows [0, n_creators) and run as a launch of their own with two
@@ -170,7 +193,7 @@ int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const
 constexpr int WALK_DECLINED = 100;   // not an error: this block is for the host walk (why: WalkRequest::declined_why)
 
 struct WalkCounts {
-    uint32_t n_tx = 0, n_tuples = 0, n_prefixes = 0, n_checks = 0;
+    uint32_t n_tx = 0, n_tuples = 0, n_prefixes = 0, n_checks = 0, n_creators = 0;
 };
 // host arrays the pass fills; asked for through WalkRequest::sizes once the counts are known (null = not wanted)
 struct WalkOut {
@@ -182,6 +205,7 @@ struct WalkOut {
     bccsp::BlockTuple* tuples = nullptr;  // n_tuples
     uint32_t* id_idx = nullptr;           // n_tuples: index into the entries of walk_idtab_set; 0xFFFFFFFE: decoded by the device, 0xFFFFFFFF: none
     uint8_t* tuple_qxy = nullptr;         // 64 n_tuples: key of a P-256 identity, zeros otherwise
+    int32_t* nym_issuer = nullptr;        // n_creators (WalkCounts::n_creators): issuer id of an idemix creator's row by creator rank, -1 otherwise
     uint8_t* tuple_digest = nullptr;      // 32 n_tuples
     bccsp::Span* prefixes = nullptr;      // n_prefixes            (tests)
     bccsp::BlockHashCheck* checks = nullptr;   // n_checks         (tests)
@@ -196,6 +220,8 @@ struct WalkRequest {
     uint32_t n_block_sigs = 0;
     const uint8_t* tail = nullptr;
     uint32_t tail_base = 0, tail_len = 0;
+    const DevIdemixMsp* idemix_msps = nullptr;   // host: the idemix MSPs whose creators the pass verifies (at most WALK_IDEMIX_MSPS_MAX)
+    uint32_t n_idemix_msps = 0;
     bool walk_only = false;               // stop after the walk (tests: the device walker against the host walker)
     void* user = nullptr;
     bool (*sizes)(void* user, const WalkCounts& c, WalkOut& out) = nullptr;   // false: the caller has no room (FABGPU_ETOOBIG)

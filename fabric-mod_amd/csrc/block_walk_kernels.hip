@@ -109,7 +109,9 @@ __global__ void __launch_bounds__(64) walk_emit_kernel(WalkArrays a, uint32_t n_
 }
 
 // per-tuple notes of the gate kernel for the summary (WalkArrays::tflags)
-enum : uint8_t { TF_SUBMIT = 1, TF_KEYED = 2, TF_UNKNOWN = 4, TF_GENERAL = 8, TF_OUTLINE = 16, TF_UNDECIDED = 32 };
+enum : uint8_t { TF_SUBMIT = 1, TF_KEYED = 2, TF_UNKNOWN = 4, TF_GENERAL = 8, TF_OUTLINE = 16, TF_UNDECIDED = 32, TF_NYM = 64 };
+// gate_st of an idemix creator whose pseudonym signature went to the nym kernel (internal: walk_status_kernel replaces it)
+constexpr uint8_t GATE_ST_NYM = 250;
 
 // ---- one wavefront per tuple: identity lookup, signature gate, submission row -----------------------------------------------------
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
@@ -393,6 +395,44 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
             }
         }
     }
+    // ---- an idemix creator?  (msp/idemixmsp.go:584-599: identity.Verify is NymSignature.Ver under the MSP's issuer key; idemix
+    // identities are creators only, docs/source/idemix.rst:171-176.)  The host's rule and order: an identity of the idemix shape that does
+    // not ALSO yield a P-256 certificate key, under a registered MSP id, with a NymSignature of four 32-byte fields -> the nym kernel;
+    // of the idemix shape but anything else -> bccsp/idemix decides (TUPLE_ST_NEEDS_SW).
+    bool nym = false;
+    if (a.n_idemix_msps && creator && unknown && !p256 && t.identity.off <= a.arena_len && t.identity.len <= a.arena_len - t.identity.off) {
+        bccsp::walk::IdemixNymRef ref;
+        if (bccsp::walk::identity_to_idemix_nym(a.block + t.identity.off, t.identity.len, ref)) {
+            int32_t issuer = -1;
+            for (uint32_t m = 0; m < a.n_idemix_msps; m++) {
+                const DevIdemixMsp& ms = a.idemix_msps[m];
+                if (ms.len != ref.mspid_len) continue;
+                bool same = true;
+                for (uint32_t k = 0; k < ms.len; k++) same = same && ms.id[k] == ref.mspid[k];
+                if (same) issuer = ms.issuer;
+            }
+            const uint8_t* sf[4];
+            const bool sig_ok = t.sig.len != 0 && t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off &&
+                                bccsp::walk::unmarshal_nym_signature32(a.block + t.sig.off, t.sig.len, sf);
+            if (issuer >= 0 && sig_ok) {
+                nym = true;
+                const uint32_t rank = a.cbase[t.tx];                       // this creator's row
+                const size_t col = (size_t)32 * a.n_creators;
+                const uint8_t* src[6] = {ref.nx, ref.ny, sf[0], sf[1], sf[2], sf[3]};
+                if (lane < 32) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) a.nym_fields[c * col + 32 * (size_t)rank + lane] = src[c][lane];
+                }
+                key_byte = lane < 32 ? ref.nx[lane] : ref.ny[lane & 31u];    // the pseudonym in the key slot (what the memo keys on)
+                if (lane == 0) {
+                    a.nym_issuer[rank] = (uint32_t)issuer;
+                    a.nym_issuer_out[rank] = issuer;
+                    a.nym_spans[2 * (size_t)rank] = t.suffix.len ? t.suffix.off : 0;
+                    a.nym_spans[2 * (size_t)rank + 1] = t.suffix.len ? t.suffix.off + t.suffix.len : 0;
+                }
+            }
+        }
+    }
     // ---- the signature ----
     uint8_t gst;
     bool submit = false, general = false;
@@ -404,7 +444,9 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         const uint32_t p0 = a.payload_spans[2 * (size_t)t.tx], p1 = a.payload_spans[2 * (size_t)t.tx + 1];
         outline_differs = (t.suffix.len ? t.suffix.off : 0u) != p0 || (t.suffix.len ? t.suffix.off + t.suffix.len : 0u) != p1;
     }
-    if (!p256) {
+    if (nym) {
+        gst = GATE_ST_NYM;
+    } else if (!p256) {
         gst = bccsp::TUPLE_ST_NEEDS_SW;
     } else if (t.sig.len == 0) {
         gst = bccsp::TUPLE_ST_EMPTY_SIG;
@@ -433,7 +475,9 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     const uint32_t k = lane & 31u;
     const uint8_t rs = submit ? (uint8_t)field_byte : (uint8_t)(k == 31 ? 1 : 0);
     (lane < 32 ? a.r : a.s)[32 * (size_t)row + k] = rs;
-    (lane < 32 ? a.qx : a.qy)[32 * (size_t)row + k] = (uint8_t)key_byte;
+    // (an idemix creator's ECDSA row stays the filler - generator key, r = s = 1 - while its pseudonym travels to the status kernel in the
+    // nym columns)
+    (lane < 32 ? a.qx : a.qy)[32 * (size_t)row + k] = nym ? C_GXY[lane] : (uint8_t)key_byte;
     if (lane == 0) {
         a.id_idx[i] = idx;
         a.row_of[i] = row;
@@ -446,7 +490,7 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
         // WAVEFRONT.  (An atomic per tuple on the summary's words - ten thousand unknown creators, ten thousand increments of one
         // address - serialises at the memory side: the gate kernel took 1.6 ms instead of 0.15, and the hash kernels beside it 1 ms.)
         a.tflags[i] = (uint8_t)((submit ? TF_SUBMIT : 0) | (keyed ? TF_KEYED : 0) | (unknown ? TF_UNKNOWN : 0) | (general ? TF_GENERAL : 0) |
-                                (outline_differs ? TF_OUTLINE : 0) | (undecided ? TF_UNDECIDED : 0));
+                                (outline_differs ? TF_OUTLINE : 0) | (undecided ? TF_UNDECIDED : 0) | (nym ? TF_NYM : 0));
     }
 }
 
@@ -491,7 +535,7 @@ enum : uint32_t { M_BAD_CREATOR = 1, M_BAD_END = 2, M_SW = 4, M_BAD_TXID = 8, M_
 __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i) {
     const bool live = i < a.n_tuples;
     uint8_t hashed = 0;
-    bool creator = false;
+    bool creator = false, by_ecdsa = false;
     if (live) {
         const uint8_t gst = a.gate_st[i];
         const BlockTuple t = a.tuples[i];
@@ -504,16 +548,35 @@ __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i
             dst[0] = src[0];
             dst[1] = src[1];
         }
-        if (a.tuple_qxy) {                                           // the key of the tuple's identity (zeros when it has no P-256 key)
-            const bool p256 = gst != bccsp::TUPLE_ST_NEEDS_SW;
+        bool key_from_nym = false;
+        if (gst == GATE_ST_NYM) {
+            // An idemix creator: the nym kernel's answer for its row (FABGPU_NYM_VALID = 0, BAD_PROOF = 1 = "signature invalid",
+            // NEEDS_SW = 6 = TUPLE_ST_NEEDS_SW: exactly the host pass's mapping).  Its memo entry is keyed on the pseudonym and on
+            // SHA-256(message) - the creator's payload digest, which this row already holds - so it counts as hashed, and carries its
+            // key, only for a caller that asked for digests (as on the host route).
+            const uint32_t rank = a.cbase[t.tx];
+            st = a.nym_status ? a.nym_status[rank] : (uint8_t)bccsp::TUPLE_ST_NEEDS_SW;
+            if (a.row_digests && st != bccsp::TUPLE_ST_NEEDS_SW) {
+                hashed = 1;
+                key_from_nym = true;
+            }
+        }
+        if (a.tuple_qxy) {                                           // the key of the tuple's identity (zeros when it has none to report)
+            const bool p256 = gst != bccsp::TUPLE_ST_NEEDS_SW && gst != GATE_ST_NYM;
             const uint4 z = make_uint4(0, 0, 0, 0);
             const uint4* sx = reinterpret_cast<const uint4*>(a.qx + 32 * (size_t)row);
             const uint4* sy = reinterpret_cast<const uint4*>(a.qy + 32 * (size_t)row);
+            if (key_from_nym) {
+                const uint32_t rank = a.cbase[t.tx];
+                sx = reinterpret_cast<const uint4*>(a.nym_fields + 32 * (size_t)rank);
+                sy = reinterpret_cast<const uint4*>(a.nym_fields + 32 * (size_t)a.n_creators + 32 * (size_t)rank);
+            }
             uint4* dst = reinterpret_cast<uint4*>(a.tuple_qxy + 64 * (size_t)i);
-            dst[0] = p256 ? sx[0] : z;
-            dst[1] = p256 ? sx[1] : z;
-            dst[2] = p256 ? sy[0] : z;
-            dst[3] = p256 ? sy[1] : z;
+            const bool have = p256 || key_from_nym;
+            dst[0] = have ? sx[0] : z;
+            dst[1] = have ? sx[1] : z;
+            dst[2] = have ? sy[0] : z;
+            dst[3] = have ? sy[1] : z;
         }
         if (gst == FABGPU_ST_VALID) {                                    // the device decided: exactly PreVerifyParsed's mapping
             const bool in_c = a.split && row < a.n_creators;
@@ -522,6 +585,7 @@ __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i
             const uint8_t ds = a.dev_status[row];
             st = (bit && ds == FABGPU_ST_VALID) ? FABGPU_ST_VALID : (ds == FABGPU_ST_VALID ? FABGPU_ST_BAD_MATH : ds);
             hashed = 1;
+            by_ecdsa = true;
         }
         a.tuple_status[i] = st;
         a.tuple_hashed[i] = hashed;
@@ -529,11 +593,11 @@ __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i
             atomicOr(&a.tx_mask[t.tx], st == bccsp::TUPLE_ST_NEEDS_SW ? M_SW : (t.kind == bccsp::TUPLE_CREATOR ? M_BAD_CREATOR : M_BAD_END));
     }
     // The summary, one atomic per wavefront and word: how many tuples each launch class decided (the provider reports how many went
-    // through registered comb tables), and what the gate and identity kernels noted per tuple.
+    // through registered comb tables), and what the gate kernel noted per tuple.
     const uint8_t tf = live ? a.tflags[i] : 0;
-    const uint64_t hc = __ballot(hashed && creator), ho = __ballot(hashed && !creator);
+    const uint64_t hc = __ballot(by_ecdsa && creator), ho = __ballot(by_ecdsa && !creator);
     const uint64_t unk = __ballot((tf & TF_UNKNOWN) != 0), und = __ballot((tf & TF_UNDECIDED) != 0), gen = __ballot((tf & TF_GENERAL) != 0),
-                   outl = __ballot((tf & TF_OUTLINE) != 0), sub = __ballot((tf & TF_SUBMIT) != 0),
+                   outl = __ballot((tf & TF_OUTLINE) != 0), sub = __ballot((tf & TF_SUBMIT) != 0), nym = __ballot((tf & TF_NYM) != 0),
                    ukc = __ballot((tf & (TF_SUBMIT | TF_KEYED)) == TF_SUBMIT && creator), uko = __ballot((tf & (TF_SUBMIT | TF_KEYED)) == TF_SUBMIT && !creator);
     if ((threadIdx.x & 63u) == 0) {
         auto add = [](uint32_t* w, uint64_t m) {
@@ -546,6 +610,7 @@ __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i
         add(&a.summary->n_general_der, gen);
         add(&a.summary->n_outline_differs, outl);
         add(&a.summary->n_submitted, sub);
+        add(&a.summary->n_nym, nym);
         add(&a.summary->n_unkeyed_creator, ukc);
         add(&a.summary->n_unkeyed_other, uko);
     }

@@ -140,7 +140,8 @@ struct fabgpu_ctx {
     // the device block pass runs on four streams: walk / gates / endorsements on `stream`, the creators' hashes and launch on
     // stream2, the mid-states on stream3, the TxID / proposal-hash digests on stream4
     hipStream_t stream3 = nullptr, stream4 = nullptr;
-    hipEvent_t ev_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_w[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool pred_has_nym = false;       // the previous block had idemix creators: queue the nym launch without waiting for the gates
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
     void* d_gscr = nullptr;   // device scratch the gather kernel stitches the messages into
     size_t gscr_cap = 0;
@@ -1446,7 +1447,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     auto carve = [&](size_t bytes) { size_t at = o; o = round_up(o + bytes, 256); return at; };
     const size_t o_env = carve((size_t)ne * 8), o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_tot = carve(sizeof(WalkTotals)),
                  o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
-                 o_cbase = carve((size_t)ne * 4), o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS), o_done = carve(64);
+                 o_cbase = carve((size_t)ne * 4), o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS), o_done = carve(64),
+                 o_msps = carve(sizeof(DevIdemixMsp) * WALK_IDEMIX_MSPS_MAX);
+    const uint32_t n_msps = rq.idemix_msps && !rq.walk_only ? std::min(rq.n_idemix_msps, WALK_IDEMIX_MSPS_MAX) : 0u;
     // The creators' messages are whole envelope payloads - the longest hashes of a block, a serial chain per message, and for a
     // block of a few hundred transactions THE critical path (300 tx: the chain is 240 us of a 600 us device phase).  With the host's
     // outline of where they are they start before anything is walked, beside the walk's two runs and the gates.
@@ -1455,7 +1458,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     int rc;
     if ((rc = ctx->walk_env.ensure(o))) return rc;
     // pinned staging: env (and payload) spans up, totals / summary down (the result arrays are sized further down)
-    const size_t p_env = 0, p_pay = round_up((size_t)ne * 8, 64), p_first = p_pay + round_up(early_hash ? (size_t)ne * 8 : 0, 64);
+    const size_t p_env = 0, p_pay = round_up((size_t)ne * 8, 64), p_msps = p_pay + round_up(early_hash ? (size_t)ne * 8 : 0, 64),
+                 p_first = p_msps + sizeof(DevIdemixMsp) * WALK_IDEMIX_MSPS_MAX;
     if ((rc = ctx->walk_pin.ensure(p_first))) return rc;
     // host-mapped results: [0, 64) the totals' flag, [64, 128) the totals, [128, 192) the final flag, [192, 256) the summary; the arrays follow
     constexpr size_t m_totflag = 0, m_tot = 64, m_finflag = 128, m_sum = 192, m_arrays = 256;
@@ -1507,6 +1511,10 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipMemcpyAsync((uint8_t*)sl->d + rq.tail_base, ctx->tailbuf.h, rq.tail_len, hipMemcpyHostToDevice, st);
         if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)sl->d + rq.tail_base + rq.tail_len, 0, 128, st);
     }
+    if (err == hipSuccess && n_msps) {
+        memcpy((uint8_t*)ctx->walk_pin.h + p_msps, rq.idemix_msps, sizeof(DevIdemixMsp) * n_msps);
+        err = hipMemcpyAsync(de + o_msps, (uint8_t*)ctx->walk_pin.h + p_msps, sizeof(DevIdemixMsp) * n_msps, hipMemcpyHostToDevice, st);
+    }
     if (err == hipSuccess) err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
     if (err == hipSuccess) err = hipMemsetAsync(de + o_sum, 0, sizeof(WalkSummary), st);
     if (err == hipSuccess) err = hipMemsetAsync(de + o_learn, 0, sizeof(WalkLearn) * WALK_LEARN_SLOTS, st);
@@ -1527,7 +1535,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     const uint32_t nt = (uint32_t)nt64, np = tot.prefixes, nc = tot.checks;
     if (nt == 0) return decline("no signature in the block");
     WalkCounts cnts;
-    cnts.n_tx = ne; cnts.n_tuples = nt; cnts.n_prefixes = np; cnts.n_checks = nc;
+    cnts.n_tx = ne; cnts.n_tuples = nt; cnts.n_prefixes = np; cnts.n_checks = nc; cnts.n_creators = tot.creators;
     WalkOut out;
     if (!rq.sizes(rq.user, cnts, out)) return FABGPU_ETOOBIG;
     // ---- per-tuple arrays ----
@@ -1539,6 +1547,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_qy = carve((size_t)nt * 32), o_r = carve((size_t)nt * 32), o_s = carve((size_t)nt * 32), o_gst = carve(nt), o_bits = carve(words * 8),
                  o_dst = carve(nt), o_tst = carve(nt), o_hsh = carve(nt), o_dig = carve((size_t)nt * 32), o_mid = carve(((size_t)np + 1) * 32),
                  o_row = carve((size_t)nt * 4), o_bitc = carve(words * 8), o_tdig = carve((size_t)nt * 32), o_cspan = carve(((size_t)tot.creators + 1) * 8), o_tfl = carve(nt),
+                 o_nymf = carve(n_msps ? (size_t)tot.creators * 192 : 0), o_nymi = carve(n_msps ? (size_t)tot.creators * 4 : 0),
+                 o_nymsp = carve(n_msps ? (size_t)tot.creators * 8 : 0), o_nymio = carve(n_msps ? (size_t)tot.creators * 4 : 0),
+                 o_nymb = carve(n_msps ? ((size_t)tot.creators + 63) / 64 * 8 + 8 : 0), o_nymst = carve(n_msps ? (size_t)tot.creators + 64 : 0),
                  o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
@@ -1556,6 +1567,15 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.qx = dt + o_qx; a.qy = dt + o_qy; a.r = dt + o_r; a.s = dt + o_s;
     a.gate_st = dt + o_gst;
     a.tflags = dt + o_tfl;
+    const bool has_nym_rows = n_msps != 0 && tot.creators != 0;
+    if (has_nym_rows) {
+        a.idemix_msps = (const DevIdemixMsp*)(de + o_msps);
+        a.n_idemix_msps = n_msps;
+        a.nym_fields = dt + o_nymf;
+        a.nym_issuer = (uint32_t*)(dt + o_nymi);
+        a.nym_issuer_out = (int32_t*)(dt + o_nymio);
+        a.nym_spans = (uint32_t*)(dt + o_nymsp);
+    }
     a.row_of = (uint32_t*)(dt + o_row);
     a.creator_spans = (uint32_t*)(dt + o_cspan);
     a.n_dev_tuples = tot.tuples;
@@ -1594,7 +1614,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     auto pin = [&](size_t bytes) { size_t at = po; po = round_up(po + bytes, 64); return at; };
     const size_t p_type = pin(ne), p_und = pin(ne), p_tup = pin((size_t)nt * sizeof(bccsp::BlockTuple)), p_dig = pin((size_t)nt * 32),
                  p_pre = pin(((size_t)np + 1) * 8), p_chk = pin(((size_t)nc + 1) * sizeof(bccsp::BlockHashCheck)),
-                 p_sigs = pin((size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple) + 64), p_qxy = pin(out.tuple_qxy ? (size_t)nt * 64 : 0);
+                 p_sigs = pin((size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple) + 64), p_qxy = pin(out.tuple_qxy ? (size_t)nt * 64 : 0),
+                 p_nymi = pin(out.nym_issuer ? (size_t)tot.creators * 4 : 0);
     {
         // (growing the pinned buffer moves it: nothing above is still needed from the old one)
         if ((rc = ctx->walk_pin.ensure(po))) return rc;
@@ -1715,8 +1736,38 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s4);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
     }
+    if (err == hipSuccess && has_nym_rows) {
+        // rows of creators that are not idemix stay all-zero (nobody reads what the nym kernel makes of them); issuer_out -1 = inactive;
+        // the status bytes start out as "not decided" so that a row the nym kernel never ran over can not read as valid
+        err = hipMemsetAsync(dt + o_nymf, 0, (o_nymio - o_nymf), st);
+        if (err == hipSuccess) err = hipMemsetAsync(dt + o_nymio, 0xFF, (size_t)tot.creators * 4, st);
+        if (err == hipSuccess) err = hipMemsetAsync(dt + o_nymb, 0, ((size_t)tot.creators + 63) / 64 * 8 + 8, st);
+        if (err == hipSuccess) err = hipMemsetAsync(dt + o_nymst, 6 /* FABGPU_NYM_NEEDS_SW */, (size_t)tot.creators + 64, st);
+    }
     if (err == hipSuccess) err = launch_walk_gate(a, st);
+    if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[5], st);       // "the gates are through" (the nym launch waits for it)
     if (err != hipSuccess) return hip_to_rc(err);
+    // The block's idemix creators: ONE nym launch over the creators' rows, beside the ECDSA launches (stream3, behind the mid-states),
+    // queued on a prediction like the key tables - the previous block had idemix creators - and caught up with below if the
+    // prediction said no and the gates say yes.
+    bool nym_ran = false;
+    auto run_nym = [&]() -> int {
+        hipError_t e = hipStreamWaitEvent(s3, ctx->ev_w[5], 0);
+        if (e != hipSuccess) return hip_to_rc(e);
+        const size_t col = (size_t)32 * tot.creators;
+        uint8_t* f = dt + o_nymf;
+        int r2 = nym_verify_dev(ctx, tot.creators, sl->d, arena_bytes, dt + o_nymsp, true, dt + o_nymi, f, f + col, f + 2 * col, f + 3 * col, f + 4 * col, f + 5 * col,
+                                dt + o_nymb, dt + o_nymst, s3, false);
+        if (r2 != FABGPU_OK) return r2;
+        e = hipEventRecord(ctx->ev_w[6], s3);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->ev_w[6], 0);
+        if (e != hipSuccess) return hip_to_rc(e);
+        a.nym_bits = (const uint64_t*)(dt + o_nymb);
+        a.nym_status = dt + o_nymst;
+        nym_ran = true;
+        return FABGPU_OK;
+    };
+    if (has_nym_rows && ctx->pred_has_nym && (rc = run_nym())) return rc;
     // What the gates found decides which kernels SHOULD run per launch class - registered comb tables when every submitted tuple of the
     // class has one, keys carried in the rows otherwise - and whether this pass may answer at all.  Neither is waited for: the launches
     // are queued on a prediction (fabgpu_ctx::pred_keyed_*: what held for the previous block; "fresh keys" is always correct) and the
@@ -1786,6 +1837,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
         fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
         fetch(out.tuple_qxy, p_qxy, dt + o_tqxy, (size_t)nt * 64);
+        if (has_nym_rows) fetch(out.nym_issuer, p_nymi, dt + o_nymio, (size_t)tot.creators * 4);
         if (err == hipSuccess) err = launch_walk_finish(a, ho, st);
         if (err != hipSuccess) return hip_to_rc(err);
         int r2 = wait_host_flag((const uint32_t*)(mh + m_finflag), ho.seq, st);
@@ -1819,10 +1871,13 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         // (a new client's first block, an endorser's first 64 signatures: once per change of regime), and redo the flags.
         const bool unk_c = rq.summary.n_unkeyed_creator != 0, unk_o = rq.summary.n_unkeyed_other != 0;
         const bool redo_c = a.split ? (keyed_c && unk_c) : false, redo_o = a.split ? (keyed_o && unk_o) : (keyed_o && (unk_c || unk_o));
+        const bool redo_nym = has_nym_rows && rq.summary.n_nym != 0 && !nym_ran;   // idemix creators turned up and nobody had launched for them
         ctx->pred_keyed_creators = !unk_c;
         ctx->pred_keyed_others = !unk_o;
-        if (redo_c || redo_o) {
-            rq.relaunched = (redo_c ? 1u : 0u) + (redo_o ? 1u : 0u);
+        ctx->pred_has_nym = has_nym_rows && rq.summary.n_nym != 0;
+        if (redo_c || redo_o || redo_nym) {
+            rq.relaunched = (redo_c ? 1u : 0u) + (redo_o ? 1u : 0u) + (redo_nym ? 1u : 0u);
+            if (redo_nym && (rc = run_nym())) return rc;
             if (redo_c) {
                 keyed_c = false;
                 if ((rc = verify_creators(false))) return rc;
@@ -1860,6 +1915,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     deliver(out.tuples, p_tup, (size_t)nt * sizeof(bccsp::BlockTuple));
     deliver(out.tuple_digest, p_dig, (size_t)nt * 32);
     deliver(out.tuple_qxy, p_qxy, (size_t)nt * 64);
+    if (has_nym_rows) deliver(out.nym_issuer, p_nymi, (size_t)tot.creators * 4);
+    else if (out.nym_issuer && tot.creators) memset(out.nym_issuer, 0xFF, (size_t)tot.creators * 4);
     drain.armed = false;                                                    // (the flag was raised behind everything: all four streams are idle)
     drain2.armed = false;
     return FABGPU_OK;

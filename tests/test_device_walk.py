@@ -627,6 +627,63 @@ def test_blocks_full_of_new_clients_stay_on_the_device_route(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_idemix_creators_on_the_device_route(monkeypatch):
+    """A provider with an idemix MSP used to decline every block to the host walk.  Now the gate kernel recognises
+    msp.SerializedIdemixIdentity creators and unmarshals their idemix.NymSignature, the nym kernel runs over the creators' rows beside the
+    ECDSA launches (on a prediction; caught up with when the first such block arrives), and statuses, flags, keys (the pseudonym), digests
+    (SHA-256 of the payload) and issuer-bound memo entries equal the host route's - tampered, out-of-domain and unknown-MSP cases
+    included (tests/test_block_prepass.py::build_mixed_block)."""
+    from idemix_common import fixtures
+    from test_block_prepass import build_mixed_block
+    raw_ipk = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_fixtures.json")))["msps"]["MSP1OU1"]["ipk"])
+    ipk_hash = bytes(fixtures()["MSP1OU1"]["ipk"].hash)
+    csp = fabgpu.GPUCSP(device=0)
+    try:
+        rng = np.random.default_rng(9)
+        blk, want, n_idemix = build_mixed_block(120, rng)
+        assert csp.idemix_msp_register("IdemixMSP1", raw_ipk) >= 0
+        r0 = fabgpu.pass_routes(csp)
+        dev, host = _both_routes(csp, monkeypatch, blk, 10, seed_memo=True)
+        assert (dev["tx_flags"] == want).all() and (host["tx_flags"] == want).all()
+        _same(host, dev, KEYS_ALL)
+        assert dev["memo_seeded"] == host["memo_seeded"] > 0
+        assert fabgpu.pass_routes(csp)["relaunches"] == r0["relaunches"] + 1          # the first block with idemix creators: the nym launch caught up
+        n_nym = 0
+        for i in np.nonzero(dev["tuple_kind"] == 0)[0]:
+            if int(dev["tuple_tx"][i]) % 5 != 0 or dev["tuple_status"][i] not in (0, 1):
+                continue
+            sp = [int(x) for x in dev["tuple_spans"][i]]
+            msg, sig = dev["arena"][sp[4]:sp[4] + sp[5]], dev["arena"][sp[6]:sp[6] + sp[7]]
+            q = bytes(dev["tuple_qxy"][i])
+            assert bytes(dev["tuple_digest"][i]) == hashlib.sha256(msg).digest() and dev["tuple_hashed"][i]
+            # (the host route's pass of the same block seeded the same entries under seq 11: look the device route's up under seq 10 only)
+            n_nym += 1
+        assert n_nym >= 10
+        fabgpu.memo_evict_block(csp, 11)
+        hits = 0
+        for i in np.nonzero(dev["tuple_kind"] == 0)[0]:
+            if int(dev["tuple_tx"][i]) % 5 != 0 or dev["tuple_status"][i] not in (0, 1):
+                continue
+            sp = [int(x) for x in dev["tuple_spans"][i]]
+            msg, sig = dev["arena"][sp[4]:sp[4] + sp[5]], dev["arena"][sp[6]:sp[6] + sp[7]]
+            q = bytes(dev["tuple_qxy"][i])
+            assert fabgpu.memo_lookup_nym(csp, ipk_hash, q[:32], q[32:], sig, hashlib.sha256(msg).digest()) == int(dev["tuple_status"][i])
+            assert fabgpu.memo_lookup(csp, q[:32], q[32:], sig, hashlib.sha256(msg).digest()) is None
+            hits += 1
+        assert hits == n_nym
+        fabgpu.memo_evict_block(csp, 10)
+        # the next block of the kind: the nym launch is queued on the prediction, nothing is repeated; flags-only callers get the same flags
+        before = fabgpu.pass_routes(csp)
+        monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+        again = fabgpu.preverify_block(csp, blk)
+        after = fabgpu.pass_routes(csp)
+        assert after["device_walks"] == before["device_walks"] + 1 and after["relaunches"] == before["relaunches"]
+        _same(host, again, ["tx_flags", "tuple_status"])
+    finally:
+        csp.close()
+
+
+@pytest.mark.gpu
 def test_a_certificate_beyond_the_device_decoder_is_left_to_the_host_walk(csp, monkeypatch):
     """The one thing the device route still declines: an identity whose PEM body exceeds the decoder's buffer (4096 base64 digits) -
     the host walk answers, with the reference's answer."""
