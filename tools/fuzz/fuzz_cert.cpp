@@ -32,6 +32,10 @@ int main() {
         memcpy(heap, d.data(), d.size());
         uint8_t qx[32], qy[32];
         ok += CertDerToP256(heap, d.size(), qx, qy);
+        {   // the walk the device's certificate decoder shares with the host (block_walk_core.h): the key must lie inside the certificate
+            const int32_t at = walk::cert_der_p256_key_offset(heap, d.size());
+            if (at >= 0 && (size_t)at + 64 > d.size()) { printf("KEY OFFSET OUT OF RANGE\n"); return 1; }
+        }
         {   // the parts crypto/x509 checkSignature looks at (x509 batch entry point): spans must stay inside the certificate
             Span tbs, sg;
             bool alg = false;
@@ -46,6 +50,17 @@ int main() {
         BigInt R, S;
         size_t off = d.size() > 80 ? d.size() - 72 - rng() % 8 : 0;
         sigok += UnmarshalECDSASignature(heap + off, d.size() - off, R, S).ok();
+        {   // the device route's general gate on the same slice: agrees with the host's parser on "unmarshals with r, s > 0"
+            uint8_t* sl = (uint8_t*)malloc(d.size() - off ? d.size() - off : 1);
+            memcpy(sl, heap + off, d.size() - off);
+            uint32_t pr, lr, ps, ls;
+            const uint8_t g = walk::gate_sig_general(sl, (uint32_t)(d.size() - off), pr, lr, ps, ls);
+            BigInt R3, S3;
+            const bool host_ok = d.size() != off && UnmarshalECDSASignature(sl, d.size() - off, R3, S3).ok();
+            const bool dev_ok = g == walk::GATE_SUBMIT || g == walk::GATE_HIGH_S || g == walk::GATE_RANGE;
+            if (d.size() != off && host_ok != dev_ok) { printf("GENERAL GATE DISAGREES WITH THE HOST PARSER\n"); return 1; }
+            free(sl);
+        }
         free(heap);
         // PEM layer: mutate the text
         if (it % 8 == 0) {

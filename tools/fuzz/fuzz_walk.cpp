@@ -64,9 +64,35 @@ static bool two_run(const uint8_t* block, size_t len, const ParsedBlock& host) {
             uint8_t* sig = (uint8_t*)malloc(t.sig.len ? t.sig.len : 1);          // exact-size copy: the gate must not read past the signature
             memcpy(sig, block + t.sig.off, t.sig.len);
             (void)walk::gate_sig_fast(sig, t.sig.len, r, s2);
+            // ... and the gate the device route applies to EVERY signature (round 3): the general parser for what the fast gate declines,
+            // on the same exact-size copy; a submit must come with magnitudes inside the signature
+            uint32_t pr, lr, ps, ls;
+            const uint8_t g = walk::gate_sig_general(sig, t.sig.len, pr, lr, ps, ls);
+            if (g == walk::GATE_SUBMIT && ((size_t)pr + lr > t.sig.len || (size_t)ps + ls > t.sig.len || lr > 32 || ls > 32 || !lr || !ls)) { printf("GENERAL GATE SPAN\n"); ok = false; }
+            (void)walk::gate_sig_any(sig, t.sig.len, r, s2);
+            // the idemix parsers the gate kernel shares with the host: same answer as the host's own
+            {
+                const uint8_t* sf4[4];
+                const bool dev_ok = walk::unmarshal_nym_signature32(sig, t.sig.len, sf4);
+                NymSignatureFields hf;
+                const bool host_ok = UnmarshalNymSignature(sig, t.sig.len, hf) && hf.len[0] == 32 && hf.len[1] == 32 && hf.len[2] == 32 && hf.len[3] == 32;
+                if (dev_ok != host_ok) { printf("NYM SIGNATURE PARSERS DISAGREE\n"); ok = false; }
+                for (int q = 0; ok && dev_ok && q < 4; q++)
+                    if (sf4[q] != hf.f[q]) { printf("NYM SIGNATURE FIELD %d DIFFERS\n", q); ok = false; }
+            }
             free(sig);
         }
         (void)walk::id_hash_host(block + t.identity.off, t.identity.len);
+        if ((size_t)t.identity.off + t.identity.len <= len) {
+            uint8_t* idc = (uint8_t*)malloc(t.identity.len ? t.identity.len : 1);   // exact-size copy of the identity
+            memcpy(idc, block + t.identity.off, t.identity.len);
+            walk::IdemixNymRef ref;
+            const bool is_nym = walk::identity_to_idemix_nym(idc, t.identity.len, ref);
+            if (is_nym && (ref.mspid < idc || ref.mspid + ref.mspid_len > idc + t.identity.len || ref.nx < idc || ref.nx + 32 > idc + t.identity.len ||
+                           ref.ny < idc || ref.ny + 32 > idc + t.identity.len)) { printf("IDEMIX IDENTITY SPAN\n"); ok = false; }
+            (void)walk::id_hash_host(idc, t.identity.len, 0x1234567ull);
+            free(idc);
+        }
     }
     free(tuples); free(pre); free(chk); free(gsp); free(gof); free(csp);
     return ok;

@@ -19,6 +19,6 @@ int fabgpu_arena_stage(fabgpu_ctx*, const void*, size_t, uint64_t*) { return -1;
 }
 #include "block_walk_dev.h"
 namespace fab {
-int walk_idtab_set(fabgpu_ctx*, uint32_t, const DevIdEntry*, const uint8_t*, size_t) { return -1; }
+int walk_idtab_set(fabgpu_ctx*, uint32_t, const DevIdEntry*, const uint8_t*, size_t, uint64_t) { return -1; }
 int walk_block_pass(fabgpu_ctx*, WalkRequest&) { return -1; }
 }
