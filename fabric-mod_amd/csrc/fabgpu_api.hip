@@ -1759,9 +1759,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         int r2 = nym_verify_dev(ctx, tot.creators, sl->d, arena_bytes, dt + o_nymsp, true, dt + o_nymi, f, f + col, f + 2 * col, f + 3 * col, f + 4 * col, f + 5 * col,
                                 dt + o_nymb, dt + o_nymst, s3, false);
         if (r2 != FABGPU_OK) return r2;
-        e = hipEventRecord(ctx->ev_w[6], s3);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->ev_w[6], 0);
-        if (e != hipSuccess) return hip_to_rc(e);
+        e = hipEventRecord(ctx->ev_w[6], s3);                              // (the main stream waits for it in front of the status kernel, not here:
+        if (e != hipSuccess) return hip_to_rc(e);                          // the ECDSA launches queued next must run BESIDE the nym kernel)
         a.nym_bits = (const uint64_t*)(dt + o_nymb);
         a.nym_status = dt + o_nymst;
         nym_ran = true;
@@ -1833,6 +1832,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     auto finish = [&]() -> int {
         if (++ctx->walk_seq == 0) ++ctx->walk_seq;
         ho.seq = ctx->walk_seq;
+        if (err == hipSuccess && nym_ran) err = hipStreamWaitEvent(st, ctx->ev_w[6], 0);     // the nym kernel's answers
         if (err == hipSuccess) err = launch_walk_status_checks(a, nc, st);
         fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
         fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
