@@ -281,7 +281,8 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
         small to remember them): 10 000 certificates decoded on the device per pass, the creators' launch carries the keys along;
       one_percent_new_creators: ten consecutive blocks, each with 1 % never-seen creators among known ones;
       one_crafted_der_signature: the friendly block with one endorsement signature in long-form DER (r of 200 bytes);
-      two_in_flight_arrival_pipeline / three_callers_flags_only: two / three passes in flight on the one provider.
+      two_in_flight_arrival_pipeline / three_callers_flags_only: two / three passes in flight on the one provider;
+      idemix_every_5th_creator (+ _host_walk): 2 000 of the 10 000 creators are idemix pseudonyms (nym signatures), both routes.
     Every transaction of every timed block must come back valid (the crafted one: exactly its transaction flagged), and one flipped
     payload byte must come back as a bad creator signature."""
     import statistics
@@ -400,6 +401,27 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
                 legs[name]["vs_friendly_device_route"] = legs[name]["median_ms_per_block"] / friendly_ms
         except Exception as e:                                 # noqa: BLE001
             legs["unfriendly_blocks_error"] = repr(e)[:300]
+        # ---- idemix creators (BASELINE.json configs[5]'s kind of traffic): every 5th creator an idemix pseudonym with its nym signature, the
+        #      other creators and all endorsements ECDSA; the nym rows go to the nym kernel beside the ECDSA launches, on both routes ----
+        try:
+            import json as _json
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+            def build_idemix():
+                import make_bench_blocks
+                return make_bench_blocks.mixed_block("idemix", n_tx, 5)
+            iblk = cached("idemix_%d_5.bin" % n_tx, build_idemix)
+            raw_ipk = bytes.fromhex(_json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_fixtures.json")))["msps"]["MSP1OU1"]["ipk"])
+            assert csp.idemix_msp_register("IdemixMSP1", raw_ipk) >= 0
+            for _ in range(3):
+                r = fabgpu.preverify_block2(csp, iblk, lean=True)
+            assert (r["tx_flags"] == 0).all() and r["n_tuples"] == 4 * n_tx
+            legs["idemix_every_5th_creator"] = timed("idemix_every_5th_creator", [iblk] * steps)
+            legs["idemix_every_5th_creator_host_walk"] = timed("idemix_every_5th_creator_host_walk", [iblk] * steps, host_walk=True)
+            legs["idemix_every_5th_creator"]["nym_signatures_per_block"] = (n_tx + 4) // 5
+            del iblk
+        except Exception as e:                                 # noqa: BLE001
+            legs["idemix_block_error"] = repr(e)[:300]
     finally:
         csp.close()
     return {"metric": "validated tx/s per block, marshalled block in, flags out (block-level pre-verify pass)", **legs,

@@ -125,8 +125,13 @@ struct WalkArrays {
     uint32_t* nym_issuer = nullptr;      // n_creators
     int32_t* nym_issuer_out = nullptr;   // n_creators: the issuer id of an ACTIVE row, -1 otherwise (the memo binds entries to the issuer)
     uint32_t* nym_spans = nullptr;       // 2 n_creators: (start, end) of the signed message = the envelope payload
-    const uint64_t* nym_bits = nullptr;  // results of the nym launch, by creator rank
-    const uint8_t* nym_status = nullptr;
+    // The nym launch runs over the idemix creators' rows only, through a row -> rank list (walk_nym_pack_kernel): a block's 10 000 creator
+    // rows with 2 000 idemix ones among them would otherwise occupy every SIMD beside the ECDSA launches.  nym_slot[rank] = the launch's row
+    // for that creator, nym_cap = rows launched.
+    uint32_t* nym_slot = nullptr;        // n_creators
+    uint32_t nym_cap = 0;
+    uint32_t gate_mode = 0;              // walk_gate_kernel: 0 every tuple, 1 the creators' tuples only, 2 the others only
+    const uint8_t* nym_status = nullptr; // results of the nym launch, by the LAUNCH's row (nym_cap + 64 bytes)
     WalkLearn* learn = nullptr;          // WALK_LEARN_SLOTS slots, zeroed per pass
     // Row of tuple i in the submission arrays.  Plain: row = i.  Split (a block of 32 769 .. 65 536 tuples): the creator tuples - long
     // messages (the whole envelope payload), no shared prefix - take rows [0, n_creators) and run as a launch of their own with two
@@ -177,6 +182,8 @@ hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);               
 // TEST HOOK: the device's identity decoder over n SerializedIdentity byte strings (spans = (start, end) pairs into arena) -> code
 // (0 P-256 key, 1 not such an identity, 2 undecided), key (64 bytes each, zero unless code == 0)
 hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st);
+// the idemix creators among [0, n_creators), counted off: nym_slot[rank] = its row in the nym launch, gather[row] = rank for row < cap
+hipError_t launch_walk_nym_pack(const WalkArrays& a, uint32_t* gather, uint32_t cap, hipStream_t st);
 hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st);   // tuple statuses + digest comparisons (one launch)
 // per-transaction flags and everything the host reads, written to host-mapped memory; the last workgroup raises h.flag
 hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStream_t st);

@@ -332,10 +332,17 @@ __device__ uint8_t wave_identity_to_p256(const uint8_t* ident, uint32_t len, uin
 __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
     __shared__ uint8_t lds_all[4 * IDFIX_MAX_DIGITS];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // (gate_mode 1: one wavefront per ENVELOPE, its creator tuple only - what the nym launch and the creators' launch wait for; 2: all
+    //  tuples but those; 0: everything in one launch)
+    uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (a.gate_mode == 1) {
+        if (i >= a.n_env || a.counts[i].x == 0) return;
+        i = a.bases[i].x;
+    }
     if (i >= a.n_tuples) return;
     uint8_t* lds = lds_all + (threadIdx.x >> 6) * IDFIX_MAX_DIGITS;
     const BlockTuple t = a.tuples[i];
+    if (a.gate_mode == 2 && i < a.n_dev_tuples && i == a.bases[t.tx].x) return;
     uint32_t idx = wave_identity_lookup(a, t.identity, lane);
     // the row of this tuple (WalkArrays::row_of): creators first when the submission is split
     const bool creator = i < a.n_dev_tuples && i == a.bases[t.tx].x;
@@ -554,8 +561,8 @@ __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i
             // NEEDS_SW = 6 = TUPLE_ST_NEEDS_SW: exactly the host pass's mapping).  Its memo entry is keyed on the pseudonym and on
             // SHA-256(message) - the creator's payload digest, which this row already holds - so it counts as hashed, and carries its
             // key, only for a caller that asked for digests (as on the host route).
-            const uint32_t rank = a.cbase[t.tx];
-            st = a.nym_status ? a.nym_status[rank] : (uint8_t)bccsp::TUPLE_ST_NEEDS_SW;
+            const uint32_t slot = a.nym_status ? a.nym_slot[a.cbase[t.tx]] : 0xFFFFFFFFu;   // (a row past the launch's capacity: not decided -
+            st = slot < a.nym_cap ? a.nym_status[slot] : (uint8_t)bccsp::TUPLE_ST_NEEDS_SW;    //  the host sees n_nym > capacity and launches again)
             if (a.row_digests && st != bccsp::TUPLE_ST_NEEDS_SW) {
                 hashed = 1;
                 key_from_nym = true;
@@ -697,6 +704,35 @@ __global__ void __launch_bounds__(256) walk_finish_kernel(WalkArrays a, WalkHost
 
 }  // namespace
 
+
+// The idemix creators, counted off for the nym launch: rank -> row = the number of active ranks below it (one workgroup, the scan of
+// walk_scan_kernel), and the launch's list row -> rank.  Creators whose row is past `cap` stay out (the host launches again with the
+// capacity the summary names).
+__global__ void __launch_bounds__(1024) walk_nym_pack_kernel(WalkArrays a, uint32_t* __restrict__ gather, uint32_t cap) {
+    __shared__ uint32_t sk[1024];
+    const uint32_t tid = threadIdx.x, n = a.n_creators;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    uint32_t k = 0;
+    for (uint32_t i = lo; i < hi; i++) k += a.nym_issuer_out[i] >= 0 ? 1u : 0u;
+    sk[tid] = k;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t v = 0;
+        if (tid >= o) v = sk[tid - o];
+        __syncthreads();
+        sk[tid] += v;
+        __syncthreads();
+    }
+    uint32_t slot = sk[tid] - k;
+    for (uint32_t i = lo; i < hi; i++) {
+        const bool on = a.nym_issuer_out[i] >= 0;
+        a.nym_slot[i] = on ? slot : 0xFFFFFFFFu;
+        if (on && slot < cap) gather[slot] = i;
+        slot += on ? 1u : 0u;
+    }
+}
+
 hipError_t launch_walk_count(const WalkArrays& a, WalkTotals* host_totals, uint32_t* host_flag, uint32_t seq, hipStream_t st) {
     if (a.n_env) {
         hipLaunchKernelGGL(walk_count_kernel, dim3((a.n_env + 63) / 64), dim3(64), 0, st, a);
@@ -712,8 +748,9 @@ hipError_t launch_walk_emit(const WalkArrays& a, const WalkTotals& t, hipStream_
     return hipGetLastError();
 }
 hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st) {
-    if (a.n_tuples == 0) return hipSuccess;
-    hipLaunchKernelGGL(walk_gate_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);   // four wavefronts = four tuples per workgroup
+    const uint32_t n = a.gate_mode == 1 ? a.n_env : a.n_tuples;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(walk_gate_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);   // four wavefronts = four tuples per workgroup
     return hipGetLastError();
 }
 hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st) {
@@ -730,6 +767,11 @@ hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spa
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(walk_gate_probe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, (const uint8_t*)arena, (const uint32_t*)spans, (uint8_t*)code, (uint8_t*)r,
                        (uint8_t*)s);
+    return hipGetLastError();
+}
+hipError_t launch_walk_nym_pack(const WalkArrays& a, uint32_t* gather, uint32_t cap, hipStream_t st) {
+    if (a.n_creators == 0) return hipSuccess;
+    hipLaunchKernelGGL(walk_nym_pack_kernel, dim3(1), dim3(1024), 0, st, a, gather, cap);
     return hipGetLastError();
 }
 hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st) {

@@ -142,6 +142,7 @@ struct fabgpu_ctx {
     hipStream_t stream3 = nullptr, stream4 = nullptr;
     hipEvent_t ev_w[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool pred_has_nym = false;       // the previous block had idemix creators: queue the nym launch without waiting for the gates
+    uint32_t pred_nym_rows = 0;      // ... and how many: the launch runs over that many packed rows plus a margin
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
     void* d_gscr = nullptr;   // device scratch the gather kernel stitches the messages into
     size_t gscr_cap = 0;
@@ -521,7 +522,7 @@ int fabgpu_idemix_issuer_count(fabgpu_ctx* ctx) {
 // spans: off holds n (start, end) pairs instead of n + 1 running offsets; timed: this launch is what fabgpu_last_kernel_ms reports
 static int nym_verify_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t arena_bytes, const void* off, bool spans, const void* issuer_id,
                           const void* nym_x, const void* nym_y, const void* proof_c, const void* proof_s_sk, const void* proof_s_r_nym,
-                          const void* nonce, void* verdict_bits, void* status, void* stream, bool timed) {
+                          const void* nonce, void* verdict_bits, void* status, void* stream, bool timed, const void* gather = nullptr, uint32_t lds_reserve = 0) {
     if (!ctx || (n && (!arena || !off || !nym_x || !nym_y || !proof_c || !proof_s_sk || !proof_s_r_nym || !nonce || !verdict_bits)))
         return FABGPU_EINVAL;
     if (n > 0xFFFFFFF0ull || arena_bytes > 0xFFFFFFFFull) return FABGPU_ETOOBIG;
@@ -543,7 +544,7 @@ static int nym_verify_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t a
     timed = timed && ctx->time_kernels;
     if (timed) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
-                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, ctx->allow_quad, spans, st);
+                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, ctx->allow_quad, spans, st, gather, lds_reserve);
     if (timed) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     if (timed) ctx->timed = true;
@@ -1550,6 +1551,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_nymf = carve(n_msps ? (size_t)tot.creators * 192 : 0), o_nymi = carve(n_msps ? (size_t)tot.creators * 4 : 0),
                  o_nymsp = carve(n_msps ? (size_t)tot.creators * 8 : 0), o_nymio = carve(n_msps ? (size_t)tot.creators * 4 : 0),
                  o_nymb = carve(n_msps ? ((size_t)tot.creators + 63) / 64 * 8 + 8 : 0), o_nymst = carve(n_msps ? (size_t)tot.creators + 64 : 0),
+                 o_nymga = carve(n_msps ? (size_t)tot.creators * 4 + 256 : 0), o_nymsl = carve(n_msps ? (size_t)tot.creators * 4 : 0),
                  o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
@@ -1737,36 +1739,58 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
     }
     if (err == hipSuccess && has_nym_rows) {
-        // rows of creators that are not idemix stay all-zero (nobody reads what the nym kernel makes of them); issuer_out -1 = inactive;
-        // the status bytes start out as "not decided" so that a row the nym kernel never ran over can not read as valid
+        // rows of creators that are not idemix stay all-zero; issuer_out -1 = inactive
         err = hipMemsetAsync(dt + o_nymf, 0, (o_nymio - o_nymf), st);
         if (err == hipSuccess) err = hipMemsetAsync(dt + o_nymio, 0xFF, (size_t)tot.creators * 4, st);
-        if (err == hipSuccess) err = hipMemsetAsync(dt + o_nymb, 0, ((size_t)tot.creators + 63) / 64 * 8 + 8, st);
-        if (err == hipSuccess) err = hipMemsetAsync(dt + o_nymst, 6 /* FABGPU_NYM_NEEDS_SW */, (size_t)tot.creators + 64, st);
     }
-    if (err == hipSuccess) err = launch_walk_gate(a, st);
-    if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[5], st);       // "the gates are through" (the nym launch waits for it)
+    // With idemix creators expected the creators' tuples are gated in a launch of their own, first: the nym launch (a long kernel: the
+    // pass's critical path on such a block) waits for that one only.
+    const bool creators_first = has_nym_rows && ctx->pred_has_nym;
+    if (creators_first) {
+        a.gate_mode = 1;
+        if (err == hipSuccess) err = launch_walk_gate(a, st);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[5], st);   // "the creators' gates are through"
+        a.gate_mode = 2;
+        if (err == hipSuccess) err = launch_walk_gate(a, st);
+        a.gate_mode = 0;
+    } else {
+        if (err == hipSuccess) err = launch_walk_gate(a, st);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[5], st);   // "the gates are through" (a nym launch waits for it)
+    }
     if (err != hipSuccess) return hip_to_rc(err);
-    // The block's idemix creators: ONE nym launch over the creators' rows, beside the ECDSA launches (stream3, behind the mid-states),
-    // queued on a prediction like the key tables - the previous block had idemix creators - and caught up with below if the
-    // prediction said no and the gates say yes.
+    // The block's idemix creators: ONE nym launch over their rows, packed (walk_nym_pack_kernel: 2 000 idemix creators among 10 000 are
+    // 125 wavefronts of the four-lane kernel, not 625 - the ECDSA launches beside it keep their SIMDs), on stream3 behind the mid-states.
+    // Queued on a prediction like the key tables - the previous block had idemix creators, about so many - and caught up with below if
+    // the gates say there are some and nobody launched, or more than the launch had rows for.
     bool nym_ran = false;
-    auto run_nym = [&]() -> int {
-        hipError_t e = hipStreamWaitEvent(s3, ctx->ev_w[5], 0);
+    uint32_t nym_cap = 0;
+    auto run_nym = [&](uint32_t cap) -> int {
+        cap = std::min<uint32_t>(tot.creators, (cap + 63u) & ~63u);
+        // The launch's rows take their inputs through the pack kernel's list (row -> creator rank); rows nobody claims stay idle (~0).
+        // The status bytes start out as "not decided" so that a row the nym kernel never ran over can not read as valid.  (All of that
+        // ahead of the wait for the gates.)
+        hipError_t e = hipMemsetAsync(dt + o_nymga, 0xFF, (size_t)cap * 4, s3);
+        if (e == hipSuccess) e = hipMemsetAsync(dt + o_nymb, 0, ((size_t)cap + 63) / 64 * 8 + 8, s3);
+        if (e == hipSuccess) e = hipMemsetAsync(dt + o_nymst, 6 /* FABGPU_NYM_NEEDS_SW */, (size_t)cap + 64, s3);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s3, ctx->ev_w[5], 0);
+        a.nym_slot = (uint32_t*)(dt + o_nymsl);
+        if (e == hipSuccess) e = launch_walk_nym_pack(a, (uint32_t*)(dt + o_nymga), cap, s3);
         if (e != hipSuccess) return hip_to_rc(e);
         const size_t col = (size_t)32 * tot.creators;
         uint8_t* f = dt + o_nymf;
-        int r2 = nym_verify_dev(ctx, tot.creators, sl->d, arena_bytes, dt + o_nymsp, true, dt + o_nymi, f, f + col, f + 2 * col, f + 3 * col, f + 4 * col, f + 5 * col,
-                                dt + o_nymb, dt + o_nymst, s3, false);
+        int r2 = nym_verify_dev(ctx, cap, sl->d, arena_bytes, dt + o_nymsp, true, dt + o_nymi, f, f + col, f + 2 * col, f + 3 * col, f + 4 * col, f + 5 * col,
+                                dt + o_nymb, dt + o_nymst, s3, false, dt + o_nymga,
+                                exclusive ? 84u << 10 : 0u);   // on CUs of its own, like the two ECDSA launches (kernels.h)
         if (r2 != FABGPU_OK) return r2;
         e = hipEventRecord(ctx->ev_w[6], s3);                              // (the main stream waits for it in front of the status kernel, not here:
         if (e != hipSuccess) return hip_to_rc(e);                          // the ECDSA launches queued next must run BESIDE the nym kernel)
-        a.nym_bits = (const uint64_t*)(dt + o_nymb);
+        a.nym_cap = cap;
         a.nym_status = dt + o_nymst;
         nym_ran = true;
+        nym_cap = cap;
         return FABGPU_OK;
     };
-    if (has_nym_rows && ctx->pred_has_nym && (rc = run_nym())) return rc;
+    if (has_nym_rows && ctx->pred_has_nym && (rc = run_nym(ctx->pred_nym_rows + ctx->pred_nym_rows / 4 + 64))) return rc;
     // What the gates found decides which kernels SHOULD run per launch class - registered comb tables when every submitted tuple of the
     // class has one, keys carried in the rows otherwise - and whether this pass may answer at all.  Neither is waited for: the launches
     // are queued on a prediction (fabgpu_ctx::pred_keyed_*: what held for the previous block; "fresh keys" is always correct) and the
@@ -1871,13 +1895,15 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         // (a new client's first block, an endorser's first 64 signatures: once per change of regime), and redo the flags.
         const bool unk_c = rq.summary.n_unkeyed_creator != 0, unk_o = rq.summary.n_unkeyed_other != 0;
         const bool redo_c = a.split ? (keyed_c && unk_c) : false, redo_o = a.split ? (keyed_o && unk_o) : (keyed_o && (unk_c || unk_o));
-        const bool redo_nym = has_nym_rows && rq.summary.n_nym != 0 && !nym_ran;   // idemix creators turned up and nobody had launched for them
+        // idemix creators turned up and nobody had launched for them, or for fewer
+        const bool redo_nym = has_nym_rows && rq.summary.n_nym != 0 && (!nym_ran || rq.summary.n_nym > nym_cap);
         ctx->pred_keyed_creators = !unk_c;
         ctx->pred_keyed_others = !unk_o;
         ctx->pred_has_nym = has_nym_rows && rq.summary.n_nym != 0;
+        ctx->pred_nym_rows = rq.summary.n_nym;
         if (redo_c || redo_o || redo_nym) {
             rq.relaunched = (redo_c ? 1u : 0u) + (redo_o ? 1u : 0u) + (redo_nym ? 1u : 0u);
-            if (redo_nym && (rc = run_nym())) return rc;
+            if (redo_nym && (rc = run_nym(rq.summary.n_nym))) return rc;
             if (redo_c) {
                 keyed_c = false;
                 if ((rc = verify_creators(false))) return rc;

@@ -108,13 +108,19 @@ __global__ void __launch_bounds__(BLOCK, 2)
                              uint32_t spans, const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
                              const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                              const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
-                             uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+                             uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status,
+                             const uint32_t* __restrict__ gather) {
     GlobalQTab29<BLOCK> qtab = GlobalQTab29<BLOCK>::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK), threadIdx.x);
     const uint32_t ntiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t i = tile * BLOCK + threadIdx.x;
         bool active = i < n;
         uint32_t ic = active ? i : (n - 1);
+        if (gather != nullptr) {                                           // row i reads the inputs of row gather[i] (~0: nobody's)
+            const uint32_t g = gather[ic];
+            active = active && g != 0xFFFFFFFFu;
+            ic = g != 0xFFFFFFFFu ? g : 0u;
+        }
         uint32_t iss = issuer_id != nullptr ? issuer_id[ic] : 0u;
         bool iss_ok = iss < n_issuers;
         const IssuerDev* id = issuers + (iss_ok ? iss : 0u);
@@ -147,7 +153,8 @@ __global__ void __launch_bounds__(BLOCK, 2)
                                    uint32_t spans, const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
                                    const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                                    const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
-                                   uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+                                   uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status,
+                             const uint32_t* __restrict__ gather) {
     GlobalQTab29<BLOCK> qtab = GlobalQTab29<BLOCK>::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * BLOCK), threadIdx.x);
     constexpr uint32_t PER_WG = BLOCK / 2;
     const uint32_t ntiles = (n + PER_WG - 1) / PER_WG;
@@ -157,6 +164,11 @@ __global__ void __launch_bounds__(BLOCK, 2)
         uint32_t i = tile * PER_WG + (threadIdx.x >> 1);
         bool active = i < n;
         uint32_t ic = active ? i : (n - 1);
+        if (gather != nullptr) {                                           // row i reads the inputs of row gather[i] (~0: nobody's)
+            const uint32_t g = gather[ic];
+            active = active && g != 0xFFFFFFFFu;
+            ic = g != 0xFFFFFFFFu ? g : 0u;
+        }
         uint32_t iss = issuer_id != nullptr ? issuer_id[ic] : 0u;
         bool iss_ok = iss < n_issuers;
         const IssuerDev* id = issuers + (iss_ok ? iss : 0u);
@@ -199,7 +211,8 @@ __global__ void __launch_bounds__(BLOCK, 2)
                                   uint32_t spans, const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
                                   const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                                   const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
-                                  uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status) {
+                                  uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status,
+                             const uint32_t* __restrict__ gather) {
     // one table per PAIR: BLOCK / 2 of them in this workgroup's slot
     PairBNQTab qtab = PairBNQTab::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * (BLOCK / 2)), threadIdx.x >> 1);
     constexpr uint32_t PER_WG = BLOCK / 4;
@@ -212,6 +225,11 @@ __global__ void __launch_bounds__(BLOCK, 2)
         uint32_t i = tile * PER_WG + (threadIdx.x >> 2);
         bool active = i < n;
         uint32_t ic = active ? i : (n - 1);
+        if (gather != nullptr) {                                           // row i reads the inputs of row gather[i] (~0: nobody's)
+            const uint32_t g = gather[ic];
+            active = active && g != 0xFFFFFFFFu;
+            ic = g != 0xFFFFFFFFu ? g : 0u;
+        }
         uint32_t iss = issuer_id != nullptr ? issuer_id[ic] : 0u;
         bool iss_ok = iss < n_issuers;
         const IssuerDev* id = issuers + (iss_ok ? iss : 0u);
@@ -268,29 +286,29 @@ size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad) {
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
-                                    bool allow_quad, bool spans, hipStream_t st) {
+                                    bool allow_quad, bool spans, hipStream_t st, const void* gather, uint32_t lds_reserve) {
     if (n == 0) return hipSuccess;
     if (idemix_quad(n, allow_split, allow_quad)) {                             // four lanes per signature: 64 signatures per workgroup
         dim3 qgrid(idemix_quad_wgs(n)), qblock(VERIFY_BLOCK);
-        hipLaunchKernelGGL(idemix_nym_verify_quad_kernel<VERIFY_BLOCK>, qgrid, qblock, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+        hipLaunchKernelGGL(idemix_nym_verify_quad_kernel<VERIFY_BLOCK>, qgrid, qblock, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                            (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                            (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
-                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather);
         return hipGetLastError();
     }
     VerifyGeom g = verify_geom(n, allow_split);
     dim3 grid(g.wgs), block(g.block);
     if (g.pair) {
-        hipLaunchKernelGGL(idemix_nym_verify_split_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+        hipLaunchKernelGGL(idemix_nym_verify_split_kernel<VERIFY_BLOCK>, grid, block, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                            (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                            (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
-                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(idemix_nym_verify_kernel<VERIFY_BLOCK>, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+    hipLaunchKernelGGL(idemix_nym_verify_kernel<VERIFY_BLOCK>, grid, block, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                        (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                        (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
-                       (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status);
+                       (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather);
     return hipGetLastError();
 }
 

@@ -68,7 +68,9 @@ constexpr int IDEMIX_QUAD_MAX = 16384;     // 256 workgroups x 64 signatures: on
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
-                                    bool allow_quad, bool spans, hipStream_t st);   // spans: off = n x (start, end) instead of n + 1 running offsets
+                                    bool allow_quad, bool spans, hipStream_t st,    // spans: off = n x (start, end) instead of n + 1 running offsets
+                                    const void* gather = nullptr,                 // gather: row i takes its inputs from row gather[i] (uint32; ~0 = an idle row)
+                                    uint32_t lds_reserve = 0);                    // unused LDS asked for: keeps other reserving kernels off this one's CUs
 // every LANE owns a 16-entry table in the one- and two-lane geometries, every lane PAIR in the four-lane one
 size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad);
 }  // namespace fab

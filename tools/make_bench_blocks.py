@@ -24,21 +24,9 @@ import idemix_oracle as io   # noqa: E402
 from idemix_common import be32, fixtures   # noqa: E402
 
 
-def main():
-    kind, ntx, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    assert kind in ("idemix", "ecdsa", "passlegs")
-    if kind == "passlegs":
-        import blockgen
-        os.makedirs(os.path.join(ROOT, ".bench_blocks"), exist_ok=True)
-        per_block = max(1, ntx // 100)
-        for name, build in (("friendly_%d.bin" % ntx, lambda: blockgen.endorser_block(ntx, 1)[0]),
-                            ("distinct_%d.bin" % ntx, lambda: blockgen.endorser_block(ntx, 3, creators=blockgen.fresh_identities(ntx, 4))[0]),
-                            ("fresh1pct_%d.bin" % ntx, lambda: blockgen.pack_envelopes(
-                                blockgen.endorser_block(10 * per_block, 5, creators=blockgen.fresh_identities(10 * per_block, 6))[1]))):
-            out = os.path.join(ROOT, ".bench_blocks", name)
-            open(out, "wb").write(build())
-            print(out, os.path.getsize(out))
-        return
+def mixed_block(kind, ntx, every, progress=False):
+    """ntx endorser transactions (1 creator + 3 endorsements); kind 'idemix': every `every`-th creator is an idemix pseudonym of the
+    fixtures' IdemixMSP1 with its nym signature"""
     ids = [i for i in json.load(open(os.path.join(ROOT, "tests", "golden", "block_identities.json")))["identities"] if i["curve"] == "prime256v1"]
     sid = [bb.serialized_identity("Org1MSP", i["pem"]) for i in ids]
     L = coracle.lib()
@@ -69,11 +57,30 @@ def main():
             c = 4 + t % 2
             payload, _ = bb.consistent_endorser_tx("mychannel", sid[c], *args, ends)
             envs.append(bb.envelope(payload, sign(c, payload)))
-        if t % 1000 == 999:
+        if progress and t % 1000 == 999:
             print(t + 1, file=sys.stderr)
+    return bb.block(1, envs)
+
+
+def main():
+    kind, ntx, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    assert kind in ("idemix", "ecdsa", "passlegs")
+    if kind == "passlegs":
+        import blockgen
+        os.makedirs(os.path.join(ROOT, ".bench_blocks"), exist_ok=True)
+        per_block = max(1, ntx // 100)
+        for name, build in (("friendly_%d.bin" % ntx, lambda: blockgen.endorser_block(ntx, 1)[0]),
+                            ("distinct_%d.bin" % ntx, lambda: blockgen.endorser_block(ntx, 3, creators=blockgen.fresh_identities(ntx, 4))[0]),
+                            ("fresh1pct_%d.bin" % ntx, lambda: blockgen.pack_envelopes(
+                                blockgen.endorser_block(10 * per_block, 5, creators=blockgen.fresh_identities(10 * per_block, 6))[1]))):
+            out = os.path.join(ROOT, ".bench_blocks", name)
+            open(out, "wb").write(build())
+            print(out, os.path.getsize(out))
+        return
+    blk = mixed_block(kind, ntx, every, progress=True)
     os.makedirs(os.path.join(ROOT, ".bench_blocks"), exist_ok=True)
     out = os.path.join(ROOT, ".bench_blocks", "%s_%d_%d.bin" % (kind, ntx, every))
-    open(out, "wb").write(bb.block(1, envs))
+    open(out, "wb").write(blk)
     print(out, os.path.getsize(out))
 
 
