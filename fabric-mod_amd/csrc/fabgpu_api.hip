@@ -169,6 +169,7 @@ struct fabgpu_ctx {
     PinBuf stage_pin;                // fabgpu_arena_stage: pinned staging of arenas that arrive in pageable memory
     std::mutex stage_pin_mu;
     hipStream_t stream_copy = nullptr;
+    hipStream_t stream_copy_more[3] = {nullptr, nullptr, nullptr};   // further upload queues: pieces alternate between DMA engines
     PinBuf walk_pin;
     // what the pass's kernels write for the HOST (block_walk_dev.h WalkHostOut): pinned, mapped, coherent - the host polls flags in it
     PinBuf walk_map;
@@ -310,6 +311,11 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
         if (hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess) { rc = FABGPU_ENODEV; break; }
         {
             bool ok = true;
+            for (auto& sc : ctx->stream_copy_more) ok = ok && hipStreamCreateWithFlags(&sc, hipStreamNonBlocking) == hipSuccess;
+            if (!ok) { rc = FABGPU_ENODEV; break; }
+        }
+        {
+            bool ok = true;
             for (auto& e : ctx->ev_w) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
             if (!ok) { rc = FABGPU_ENODEV; break; }
         }
@@ -356,6 +362,8 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         if (ctx->stream3) hipStreamDestroy(ctx->stream3);
         if (ctx->stream4) hipStreamDestroy(ctx->stream4);
         if (ctx->stream_copy) hipStreamDestroy(ctx->stream_copy);
+        for (auto sc : ctx->stream_copy_more)
+            if (sc) hipStreamDestroy(sc);
         ctx->stage_pin.release();
         for (auto& e : ctx->ev_w)
             if (e) hipEventDestroy(e);
@@ -981,7 +989,11 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
         uint8_t* dst = (uint8_t*)sl->d;
         uint8_t* pin = (uint8_t*)ctx->stage_pin.h;
         const uint8_t* src = (const uint8_t*)arena;
-        hipStream_t cs = ctx->stream_copy;
+        // Pieces go round-robin over FABGPU_STAGE_QUEUES upload queues (default 4) so that one piece's set-up overlaps another's transfer:
+        // measured (tools/gpu_probe_stage_threads.sh, 48.6 MB) 1.33 ms with one queue, 1.23 with two, 1.13 with four - 43 GB/s; the
+        // number of copier threads makes no difference from two up.
+        static const int n_queues = [] { const char* e = getenv("FABGPU_STAGE_QUEUES"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+        hipStream_t cs[4] = {ctx->stream_copy, ctx->stream_copy_more[0], ctx->stream_copy_more[1], ctx->stream_copy_more[2]};
         const int dev = ctx->device;
         // The copiers (the host side's worker pool: idle while a block travels) claim pieces in order; this thread queues a piece's DMA
         // as soon as it is in the staging buffer - it alone talks to the runtime (several threads queueing on one stream spend their
@@ -1003,10 +1015,13 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
             for (size_t k = 0; k < n_pieces; k++) {
                 while (!done[k].load(std::memory_order_acquire))
                     if (!copy_one()) std::this_thread::yield();
-                if (hipMemcpyAsync(dst + cut[k], pin + cut[k], cut[k + 1] - cut[k], hipMemcpyHostToDevice, cs) != hipSuccess) failed = 1;
+                if (hipMemcpyAsync(dst + cut[k], pin + cut[k], cut[k + 1] - cut[k], hipMemcpyHostToDevice, cs[k % (size_t)n_queues]) != hipSuccess) failed = 1;
             }
         });
-        err = hipStreamSynchronize(cs);
+        for (int q = 0; q < n_queues; q++) {
+            const hipError_t e = hipStreamSynchronize(cs[q]);
+            if (err == hipSuccess) err = e;
+        }
         if (err == hipSuccess && failed) err = hipErrorUnknown;
     }
     if (err == hipSuccess) err = hipMemset((uint8_t*)sl->d + len, 0, need - len);
