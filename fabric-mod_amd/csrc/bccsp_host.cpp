@@ -1077,6 +1077,45 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         if (n_tuples_out) *n_tuples_out = 0;
         return FABGPU_ETOOBIG;
     }
+    // OPTIONAL (FABGPU_PASS_HOST_COUNTS=1; off by default): while the block is on its way up, the per-envelope counts the device walk
+    // starts from (tuples, prefixes, hash checks, gathered bytes - walk::walk_envelope with the counting emitter, the code
+    // walk_count_kernel runs) taken here, on a few threads; the device then needs neither that kernel, nor the scan behind it, nor the
+    // wait for the totals in between.  Measured (round 3, 10 000 tx, tools/host_walk_probe.cpp + tools/gpu_probe_sizes.sh): the device
+    // phase drops 0.92 -> 0.85 ms, but the host's walk is a chain of DRAM misses per envelope - 8.2 ms on one thread, 1.2-1.7 ms on
+    // 8-12, about the whole upload - against 0.10 ms for the count kernel: 4 % off the pass for 8 ms of the peer's CPU per block.
+    // Not a trade a peer wants by default; the entry stays for hosts with idle cores (and as the second source the emit kernel's
+    // count check is tested against).
+    const char* hc_env = getenv("FABGPU_PASS_HOST_COUNTS");                // (read per pass: tests run both ways in one process)
+    const bool host_counts = hc_env && atoi(hc_env) != 0;
+    const uint32_t n_env = (uint32_t)(ps.env_spans.size() / 2);
+    if (host_counts && n_env) {
+        ps.env_counts.resize(4 * (size_t)n_env);
+        ps.env_type.resize(n_env);
+        ps.env_understood.resize(n_env);
+        std::atomic<uint32_t> next(0);
+        auto count_some = [&](int) {
+            for (;;) {
+                const uint32_t lo = next.fetch_add(64, std::memory_order_relaxed);
+                if (lo >= n_env) return;
+                const uint32_t hi = std::min(n_env, lo + 64);
+                for (uint32_t e = lo; e < hi; e++) {
+                    uint32_t off = ps.env_spans[2 * (size_t)e], elen = ps.env_spans[2 * (size_t)e + 1];
+                    if (off > len || elen > len - off) off = elen = 0;
+                    walk::CountEmitter em;
+                    uint8_t type = 255, understood = 0;
+                    walk::walk_envelope(block, block + off, elen, e, em, type, understood);
+                    uint32_t* c = &ps.env_counts[4 * (size_t)e];
+                    c[0] = em.nt; c[1] = em.np; c[2] = em.nc;
+                    c[3] = em.gb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)em.gb;
+                    ps.env_type[e] = type;
+                    ps.env_understood[e] = understood;
+                }
+            }
+        };
+        const int nth = n_env >= 2048 ? std::min(WalkThreads(), 8) : 1;
+        if (nth == 1) count_some(0);
+        else run_workers(nth, count_some);
+    }
     int rc = SyncDeviceIdentityTable();
     if (rc != FABGPU_OK) return declined("the identity cache could not be copied to the device");   // (the host walk will say what is wrong, if anything is)
     std::shared_lock<std::shared_timed_mutex> rl(idtab_rw_);
@@ -1101,6 +1140,11 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     rq.env_spans = ps.env_spans.data();
     rq.payload_spans = ps.payload_spans.data();
     rq.n_env = (uint32_t)(ps.env_spans.size() / 2);
+    if (host_counts && n_env) {
+        rq.host_counts = ps.env_counts.data();
+        rq.host_tx_type = ps.env_type.data();
+        rq.host_tx_understood = ps.env_understood.data();
+    }
     if (opt.block_sigs && !ps.block_sigs.empty()) {
         rq.block_sigs = ps.block_sigs.data();
         rq.n_block_sigs = (uint32_t)ps.block_sigs.size();

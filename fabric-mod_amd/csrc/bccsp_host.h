@@ -287,6 +287,8 @@ class GPUCSP {
         std::vector<uint64_t> nym_bits;
         // the device walk: envelope list, block-signature tuples, identity indices per tuple
         std::vector<uint32_t> env_spans, payload_spans, id_idx;
+        std::vector<uint32_t> env_counts;          // 4 per envelope: what walk_count_kernel would find (counted here while the block travels)
+        std::vector<uint8_t> env_type, env_understood;
         std::vector<BlockTuple> block_sigs;
         std::vector<WalkLearn> learn;              // identities the device decoded and offers to the cache
         std::vector<int32_t> nym_issuer_rank;      // device route: issuer id of an idemix creator's row, by creator rank (-1: not one)

@@ -223,6 +223,13 @@ struct WalkRequest {
     size_t block_len = 0;
     const uint32_t* env_spans = nullptr;  // host
     uint32_t n_env = 0;
+    // host, optional: what walk_count_kernel would find - 4 per envelope (tuples, prefixes, hash checks, gathered bytes clamped to 2^32 - 1)
+    // and the two per-envelope bytes - counted by the caller with the same walk_envelope<CountEmitter> while the block was still on its
+    // way up.  The pass then starts at the emit kernel: no count kernel, no scan, no wait for totals.  (The emit kernel checks every
+    // envelope's counts against its own walk: WalkSummary::n_outline_differs.)
+    const uint32_t* host_counts = nullptr;
+    const uint8_t* host_tx_type = nullptr;
+    const uint8_t* host_tx_understood = nullptr;
     const bccsp::BlockTuple* block_sigs = nullptr;   // appended behind the device's tuples
     uint32_t n_block_sigs = 0;
     const uint8_t* tail = nullptr;

@@ -99,13 +99,16 @@ __global__ void __launch_bounds__(64) walk_emit_kernel(WalkArrays a, uint32_t n_
     if (e == 0) a.gather_off[n_checks] = gather_total;
     if (e >= a.n_env) return;
     const uint4 cnt = a.counts[e];
-    if (cnt.x == 0 && cnt.y == 0 && cnt.z == 0) return;
     const uint4 base = a.bases[e];
     uint32_t off = a.env_spans[2 * e], len = a.env_spans[2 * e + 1];
     if (off > a.block_len || len > a.block_len - off) off = len = 0;
     WriteEmitter em{a.tuples, a.pre_off2, a.checks, a.gather_spans, a.gather_off, base.x, base.y, base.z, base.w, cnt.x, cnt.y, cnt.z, a.creator_spans, a.cbase[e]};
     uint8_t type = 255, understood = 0;
     bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
+    // the counts this envelope's slots were sized from (the count kernel's, or the host's - WalkRequest::host_counts) against this walk
+    if (em.nt != cnt.x || em.np != cnt.y || em.nc != cnt.z || (cnt.w != 0xFFFFFFFFu && em.g != cnt.w) || type != a.tx_type[e] ||
+        understood != a.tx_understood[e])
+        atomicAdd(&a.summary->n_outline_differs, 1u);
 }
 
 // per-tuple notes of the gate kernel for the summary (WalkArrays::tflags)

@@ -1461,21 +1461,24 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // ---- per-envelope arrays ----
     size_t o = 0;
     auto carve = [&](size_t bytes) { size_t at = o; o = round_up(o + bytes, 256); return at; };
-    const size_t o_env = carve((size_t)ne * 8), o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_tot = carve(sizeof(WalkTotals)),
-                 o_type = carve(ne), o_und = carve(ne), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
-                 o_cbase = carve((size_t)ne * 4), o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS), o_done = carve(64),
-                 o_msps = carve(sizeof(DevIdemixMsp) * WALK_IDEMIX_MSPS_MAX);
+    // (what the host sends up sits together - envelope spans, payload spans, idemix MSPs and, when the host counted, the count kernel's
+    //  and the scan's arrays - mirrored at the same offsets in the pinned staging buffer: ONE copy)
+    const bool host_counted = rq.host_counts && rq.host_tx_type && rq.host_tx_understood;
     const uint32_t n_msps = rq.idemix_msps && !rq.walk_only ? std::min(rq.n_idemix_msps, WALK_IDEMIX_MSPS_MAX) : 0u;
     // The creators' messages are whole envelope payloads - the longest hashes of a block, a serial chain per message, and for a
     // block of a few hundred transactions THE critical path (300 tx: the chain is 240 us of a 600 us device phase).  With the host's
     // outline of where they are they start before anything is walked, beside the walk's two runs and the gates.
     const bool early_hash = rq.payload_spans && !rq.walk_only && ctx->allow_pair && (uint64_t)ne * 2 <= 65536u;
-    const size_t o_pay = carve(early_hash ? (size_t)ne * 8 : 0), o_denv = carve(early_hash ? (size_t)ne * 32 : 0);
+    const size_t o_env = carve((size_t)ne * 8), o_pay = carve(early_hash ? (size_t)ne * 8 : 0), o_msps = carve(sizeof(DevIdemixMsp) * n_msps),
+                 o_up_small = o,                                                // ... the copy ends here unless the host counted
+                 o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_cbase = carve((size_t)ne * 4), o_type = carve(ne), o_und = carve(ne),
+                 o_up_all = o,
+                 o_tot = carve(sizeof(WalkTotals)), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
+                 o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS), o_done = carve(64), o_denv = carve(early_hash ? (size_t)ne * 32 : 0);
     int rc;
     if ((rc = ctx->walk_env.ensure(o))) return rc;
-    // pinned staging: env (and payload) spans up, totals / summary down (the result arrays are sized further down)
-    const size_t p_env = 0, p_pay = round_up((size_t)ne * 8, 64), p_msps = p_pay + round_up(early_hash ? (size_t)ne * 8 : 0, 64),
-                 p_first = p_msps + sizeof(DevIdemixMsp) * WALK_IDEMIX_MSPS_MAX;
+    // pinned staging: the region above as it goes up (the result arrays are sized further down)
+    const size_t up_bytes = host_counted ? o_up_all : o_up_small, p_first = round_up(o_up_all, 256);
     if ((rc = ctx->walk_pin.ensure(p_first))) return rc;
     // host-mapped results: [0, 64) the totals' flag, [64, 128) the totals, [128, 192) the final flag, [192, 256) the summary; the arrays follow
     constexpr size_t m_totflag = 0, m_tot = 64, m_finflag = 128, m_sum = 192, m_arrays = 256;
@@ -1499,8 +1502,32 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.tx_flags = de + o_flags;
     a.summary = (WalkSummary*)(de + o_sum);
     a.learn = (WalkLearn*)(de + o_learn);
-    memcpy((uint8_t*)ctx->walk_pin.h + p_env, rq.env_spans, (size_t)ne * 8);
-    hipError_t err = hipMemcpyAsync(de + o_env, (uint8_t*)ctx->walk_pin.h + p_env, (size_t)ne * 8, hipMemcpyHostToDevice, st);
+    uint8_t* up = (uint8_t*)ctx->walk_pin.h;
+    memcpy(up + o_env, rq.env_spans, (size_t)ne * 8);
+    if (early_hash) memcpy(up + o_pay, rq.payload_spans, (size_t)ne * 8);
+    if (n_msps) memcpy(up + o_msps, rq.idemix_msps, sizeof(DevIdemixMsp) * n_msps);
+    WalkTotals host_tot = {};
+    if (host_counted) {
+        // the scan, here: exclusive prefix sums per envelope (walk_scan_kernel's outputs), and the totals the host would otherwise wait for
+        memcpy(up + o_cnt, rq.host_counts, (size_t)ne * 16);
+        memcpy(up + o_type, rq.host_tx_type, ne);
+        memcpy(up + o_und, rq.host_tx_understood, ne);
+        uint32_t* bases = (uint32_t*)(up + o_base);
+        uint32_t* cb = (uint32_t*)(up + o_cbase);
+        uint64_t bt = 0, bp = 0, bc = 0, bg = 0;
+        uint32_t bk = 0;
+        for (uint32_t e = 0; e < ne; e++) {
+            const uint32_t* c = rq.host_counts + 4 * (size_t)e;
+            bases[4 * (size_t)e] = (uint32_t)bt; bases[4 * (size_t)e + 1] = (uint32_t)bp; bases[4 * (size_t)e + 2] = (uint32_t)bc; bases[4 * (size_t)e + 3] = (uint32_t)bg;
+            cb[e] = bk;
+            bt += c[0]; bp += c[1]; bc += c[2]; bg += c[3];
+            bk += c[0] ? 1u : 0u;
+        }
+        if (bt > 0x7FFFFFF0ull || bp > 0x7FFFFFF0ull || bc > 0x7FFFFFF0ull) return FABGPU_ETOOBIG;
+        host_tot.tuples = (uint32_t)bt; host_tot.prefixes = (uint32_t)bp; host_tot.checks = (uint32_t)bc; host_tot.creators = bk;
+        host_tot.gather_bytes = bg;
+    }
+    hipError_t err = hipMemcpyAsync(de + o_env, up + o_env, up_bytes, hipMemcpyHostToDevice, st);
     bool s2_busy = false;
     struct Drain2 {                                                         // (an early exit must not leave the hashes running)
         hipStream_t s;
@@ -1511,9 +1538,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (err == hipSuccess && early_hash) {
         a.payload_spans = (const uint32_t*)(de + o_pay);
         a.digest_env = de + o_denv;
-        memcpy((uint8_t*)ctx->walk_pin.h + p_pay, rq.payload_spans, (size_t)ne * 8);
-        err = hipMemcpyAsync(de + o_pay, (uint8_t*)ctx->walk_pin.h + p_pay, (size_t)ne * 8, hipMemcpyHostToDevice, st);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[3], st);     // "the span lists are on the device"
+        err = hipEventRecord(ctx->ev_w[3], st);                            // "the span lists are on the device"
         if (err == hipSuccess) err = hipStreamWaitEvent(ctx->stream2, ctx->ev_w[3], 0);
         if (err == hipSuccess) {
             s2_busy = true;
@@ -1527,15 +1552,11 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipMemcpyAsync((uint8_t*)sl->d + rq.tail_base, ctx->tailbuf.h, rq.tail_len, hipMemcpyHostToDevice, st);
         if (err == hipSuccess) err = hipMemsetAsync((uint8_t*)sl->d + rq.tail_base + rq.tail_len, 0, 128, st);
     }
-    if (err == hipSuccess && n_msps) {
-        memcpy((uint8_t*)ctx->walk_pin.h + p_msps, rq.idemix_msps, sizeof(DevIdemixMsp) * n_msps);
-        err = hipMemcpyAsync(de + o_msps, (uint8_t*)ctx->walk_pin.h + p_msps, sizeof(DevIdemixMsp) * n_msps, hipMemcpyHostToDevice, st);
-    }
     if (err == hipSuccess) err = hipMemsetAsync(de + o_mask, 0, (size_t)ne * 4, st);
     if (err == hipSuccess) err = hipMemsetAsync(de + o_sum, 0, sizeof(WalkSummary), st);
     if (err == hipSuccess) err = hipMemsetAsync(de + o_learn, 0, sizeof(WalkLearn) * WALK_LEARN_SLOTS, st);
     if (err == hipSuccess) err = hipMemsetAsync(de + o_done, 0, 64, st);
-    {
+    if (!host_counted) {
         uint8_t* mh = (uint8_t*)ctx->walk_map.h;
         void* md = nullptr;
         if (err == hipSuccess) err = hipHostGetDevicePointer(&md, mh, 0);
@@ -1544,7 +1565,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         // the one thing the host must know before it can go on - how many tuples, prefixes, checks - arrives in mapped memory
         if ((rc = wait_host_flag((const uint32_t*)(mh + m_totflag), seq_tot, st))) return rc;
     }
-    const WalkTotals tot = *(const WalkTotals*)((uint8_t*)ctx->walk_map.h + m_tot);
+    if (err != hipSuccess) return hip_to_rc(err);
+    const WalkTotals tot = host_counted ? host_tot : *(const WalkTotals*)((uint8_t*)ctx->walk_map.h + m_tot);
     if (tot.gather_bytes > 0x7FFFFFF0ull) return decline("gathered hash inputs exceed 2 GiB");
     const uint64_t nt64 = (uint64_t)tot.tuples + rq.n_block_sigs;
     if (nt64 > 0x7FFFFFF0ull / 160) return FABGPU_ETOOBIG;
@@ -1725,34 +1747,11 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     }
     // the emitted prefixes / hash checks are all stream2 and stream3 need: mid-states and the TxID / proposal-hash digests run while
     // the main stream looks identities up and gates signatures
+    hipStream_t sc = s2;                                                   // the creators' stream
     err = hipEventRecord(ctx->ev_w[0], st);
-    if (err == hipSuccess && a.split) {
-        // stream2: the creators' digests into rows [0, n_creators), so that their launch only has the arithmetic left.  Either they
-        // were hashed per envelope from the host's outline (early_hash, queued before the walk: a scatter by the scan's creator ranks
-        // is all that is left), or they are hashed now, beside the identity lookup and the gates.
-        err = hipStreamWaitEvent(s2, ctx->ev_w[0], 0);
-        if (err == hipSuccess && early_hash) {
-            a.early_creator_hash = 1;
-            err = launch_walk_creator_digests(a, dt + o_dig, s2);
-        } else if (err == hipSuccess) {
-            err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, s2, exclusive ? 84u << 10 : 0u);
-        }
-    }
-    if (err == hipSuccess && np) {
-        // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them), on CUs of their own: 40
-        // workgroups that would otherwise share SIMDs with the 40 000 short-lived wavefronts of the gate kernel and take 4x as long,
-        // with the endorsements' launch waiting for them (measured, tools/gpu_dw_sched.sh: device phase 1.04 -> 0.90 ms)
-        ShaPrefixArgs pm = pa;
-        pm.lds_reserve = 84u << 10;
-        err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pm, s3);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s3);
-    }
-    if (err == hipSuccess && nc) {       // stream4: the TxID / proposal-hash digests (only the flags at the very end wait for them)
-        err = hipStreamWaitEvent(s4, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s4);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
-    }
+    // (The gates are queued right here, ahead of the side streams' work: on a small block the host's calls, not the kernels, set the pace,
+    //  and the gate kernel is the main stream's critical path.)
+    if (a.split && early_hash) a.early_creator_hash = 1;
     if (err == hipSuccess && has_nym_rows) {
         // rows of creators that are not idemix stay all-zero; issuer_out -1 = inactive
         err = hipMemsetAsync(dt + o_nymf, 0, (o_nymio - o_nymf), st);
@@ -1772,7 +1771,32 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess) err = launch_walk_gate(a, st);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[5], st);   // "the gates are through" (a nym launch waits for it)
     }
-    if (err != hipSuccess) return hip_to_rc(err);
+    if (err == hipSuccess && a.split) {
+        // stream2: the creators' digests into rows [0, n_creators), so that their launch only has the arithmetic left.  Either they
+        // were hashed per envelope from the host's outline (early_hash, queued before the walk: a scatter by the scan's creator ranks
+        // is all that is left), or they are hashed now, beside the identity lookup and the gates.
+        err = hipStreamWaitEvent(sc, ctx->ev_w[0], 0);
+        if (err == hipSuccess && early_hash) {
+            err = launch_walk_creator_digests(a, dt + o_dig, sc);
+        } else if (err == hipSuccess) {
+            err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, sc, exclusive ? 84u << 10 : 0u);
+        }
+    }
+    if (err == hipSuccess && np) {
+        // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them), on CUs of their own: 40
+        // workgroups that would otherwise share SIMDs with the 40 000 short-lived wavefronts of the gate kernel and take 4x as long,
+        // with the endorsements' launch waiting for them (measured, tools/gpu_dw_sched.sh: device phase 1.04 -> 0.90 ms)
+        ShaPrefixArgs pm = pa;
+        pm.lds_reserve = 84u << 10;
+        err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pm, s3);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s3);
+    }
+    if (err == hipSuccess && nc) {       // stream4: the TxID / proposal-hash digests (only the flags at the very end wait for them)
+        err = hipStreamWaitEvent(s4, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s4);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
+    }
     // The block's idemix creators: ONE nym launch over their rows, packed (walk_nym_pack_kernel: 2 000 idemix creators among 10 000 are
     // 125 wavefronts of the four-lane kernel, not 625 - the ECDSA launches beside it keep their SIMDs), on stream3 behind the mid-states.
     // Queued on a prediction like the key tables - the previous block had idemix creators, about so many - and caught up with below if
@@ -1902,7 +1926,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (err == hipSuccess && nc) err = hipStreamWaitEvent(st, ctx->ev_w[2], 0);
     if (err != hipSuccess) return hip_to_rc(err);
     if ((rc = finish())) return rc;
-    if (rq.summary.n_outline_differs) return decline("the walker's creator message is not the span the outline named");
+    if (rq.summary.n_outline_differs) return decline("the device's walk of an envelope differs from the host's outline of it (creator message span, or the counts)");
     if (rq.summary.n_undecided) return decline("a certificate beyond the device decoder's buffer");
     if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
     {

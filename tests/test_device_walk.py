@@ -521,6 +521,26 @@ def _both_routes(csp, monkeypatch, blk, seq, device_first=True, **kw):
 
 
 @pytest.mark.gpu
+def test_counts_from_the_host_and_counts_from_the_device_give_one_answer(csp, monkeypatch):
+    """The device route can start from per-envelope counts the host took while the block travelled (the count kernel's own code,
+    WalkRequest::host_counts, FABGPU_PASS_HOST_COUNTS=1) instead of running the count kernel and the scan.  Same block, same answers -
+    spans, digests, statuses, flags - on a block that carries every kind of envelope the generator knows (config envelopes without
+    tuples, garbage, oversize fields)."""
+    rng = np.random.default_rng(23)
+    blk, want = build_block(90, rng)
+    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    answers = []
+    for mode in ("0", "1", "0"):
+        monkeypatch.setenv("FABGPU_PASS_HOST_COUNTS", mode)
+        before = fabgpu.pass_routes(csp)
+        answers.append(fabgpu.preverify_block2(csp, blk, block_seq=70 + len(answers)))
+        assert fabgpu.pass_routes(csp)["device_walks"] - before["device_walks"] == 1
+    assert (answers[0]["tx_flags"] == want).all()
+    _same(answers[0], answers[1], KEYS_ALL)
+    _same(answers[1], answers[2], KEYS_ALL)
+
+
+@pytest.mark.gpu
 def test_device_route_serves_what_it_used_to_decline(csp, monkeypatch):
     """Identities nobody has met (the device decodes their certificates itself), garbage DER, a provider that knows nobody at all:
     none of it takes a block to the host walk any more, and the answers are the host route's - which learns nothing the device route
@@ -591,8 +611,10 @@ def test_blocks_full_of_new_clients_stay_on_the_device_route(monkeypatch):
         csp._L.fabgpu_csp_identity_cache_limits(csp._h, 128, 64, 1)         # a small cache: 300 newcomers overflow it
         friendly, _ = blockgen.endorser_block(300, 7)
         monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
-        for k in range(3):                                                  # the six fixture signers are learned and earn their tables
-            out = fabgpu.preverify_block2(csp, friendly, block_seq=k)
+        for k in range(6):                                                  # the six fixture signers are learned and earn their tables
+            out = fabgpu.preverify_block2(csp, friendly, block_seq=k)       # (one learn slot per table hash, keyed per provider: two signers
+            if k >= 2 and out["n_keyed"] == 1200 and out["n_device_decoded"] == 0:   #  that meet in a slot take a block longer)
+                break
         assert (out["tx_flags"] == 0).all() and out["n_keyed"] == 1200 and out["n_device_decoded"] == 0
         fresh = blockgen.fresh_identities(300, 99)
         crowd, _ = blockgen.endorser_block(300, 8, creators=fresh)
