@@ -701,10 +701,11 @@ def test_idemix_creators_on_the_device_route(monkeypatch):
         after = fabgpu.pass_routes(csp)
         assert after["device_walks"] == before["device_walks"] + 1 and after["relaunches"] == before["relaunches"]
         _same(host, again, ["tx_flags", "tuple_status"])
-        # a block with MORE idemix creators than the prediction left rows for (24 last time: the launch gets 128 rows, this block has 140):
-        # the creators past the launch's rows read "not decided", the summary says so, and a second phase runs over all of them
-        big, want_big, n_big = build_mixed_block(700, np.random.default_rng(10))
-        assert n_big == 140
+        # a block with MORE pseudonym signatures than the prediction left rows for (16 of the 24 idemix creators were the nym kernel's last
+        # time: the launch gets 128 rows; of this block's 220, 147 are): the creators past the launch's rows read "not decided", the
+        # summary says so, and a second phase runs over all of them
+        big, want_big, n_big = build_mixed_block(1100, np.random.default_rng(10))
+        assert n_big == 220
         before = fabgpu.pass_routes(csp)
         dev_big, host_big = _both_routes(csp, monkeypatch, big, 40, seed_memo=True)
         assert fabgpu.pass_routes(csp)["relaunches"] == before["relaunches"] + 1
