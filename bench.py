@@ -281,7 +281,8 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
         small to remember them): 10 000 certificates decoded on the device per pass, the creators' launch carries the keys along;
       one_percent_new_creators: ten consecutive blocks, each with 1 % never-seen creators among known ones;
       one_crafted_der_signature: the friendly block with one endorsement signature in long-form DER (r of 200 bytes);
-      two_in_flight_arrival_pipeline / three_callers_flags_only: two / three passes in flight on the one provider;
+      two_in_flight_arrival_pipeline (+ _with_memo_seeding: what the Go arrival hook runs) / three_callers_flags_only: two / three passes
+        in flight on the one provider;
       idemix_every_5th_creator (+ _host_walk): 2 000 of the 10 000 creators are idemix pseudonyms (nym signatures), both routes.
     Every transaction of every timed block must come back valid (the crafted one: exactly its transaction flagged), and one flipped
     payload byte must come back as a bad creator signature."""
@@ -343,12 +344,16 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
         # pass costs its aggregate time per block, not its latency).  Three: three channels of a peer at once.
         import threading
 
-        def in_flight(n_callers, per_caller):
+        def in_flight(n_callers, per_caller, memo=False):
             copies = [[bytes(bytearray(blk)) for _ in range(per_caller)] for _ in range(n_callers)]
 
             def caller(t):
                 for k in range(per_caller):
-                    fabgpu.preverify_block2(csp, copies[t][k], block_seq=10000 * (t + 1) + k, lean=True)
+                    seq = 10000 * (t + 1) + k
+                    r = fabgpu.preverify_block2(csp, copies[t][k], block_seq=seq, seed_memo=memo, lean=True)
+                    if memo:                                   # (what Validate does when it returns: the memo never grows with the chain)
+                        assert r["memo_seeded"] == 4 * n_tx
+                        fabgpu.memo_evict_block(csp, seq)
             th = [threading.Thread(target=caller, args=(t,)) for t in range(n_callers)]
             c0 = time.perf_counter()
             for t in th:
@@ -358,9 +363,10 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
             wall = time.perf_counter() - c0
             return {"validated_tx_per_s": n_tx * n_callers * per_caller / wall, "ms_per_block_aggregate": wall / (n_callers * per_caller) * 1e3,
                     "blocks": n_callers * per_caller, "callers": n_callers}
-        for name, nc_ in (("two_in_flight_arrival_pipeline", 2), ("three_callers_flags_only", 3)):
+        for name, nc_, memo_ in (("two_in_flight_arrival_pipeline", 2, False), ("two_in_flight_arrival_pipeline_with_memo_seeding", 2, True),
+                                 ("three_callers_flags_only", 3, False)):
             try:
-                legs[name] = in_flight(nc_, 8)
+                legs[name] = in_flight(nc_, 8, memo_)
             except Exception as e:                             # noqa: BLE001
                 legs[name] = {"error": repr(e)[:200]}
         bad = bytearray(blk)
@@ -779,6 +785,7 @@ def main():
                     out["validated_tx_per_s_block_pass"] = out["block_pass"]["flags_only"]["validated_tx_per_s"]
                     # ... and in steady state, with the pass run when a block arrives (overlapped behind the previous block)
                     out["validated_tx_per_s_block_pass_pipelined"] = out["block_pass"]["two_in_flight_arrival_pipeline"].get("validated_tx_per_s")
+                    out["validated_tx_per_s_block_pass_pipelined_with_memo"] = out["block_pass"]["two_in_flight_arrival_pipeline_with_memo_seeding"].get("validated_tx_per_s")
                 except Exception as e:                                                                     # never let this leg cost the line
                     out["block_pass"] = {"error": repr(e)[:300]}
             if not args.no_cpu_baseline:
