@@ -203,7 +203,14 @@ Error GPUCSP::New(const fabgpu_cfg* cfg, std::unique_ptr<GPUCSP>& out) {
     out.reset(new GPUCSP(ctx));
     return Error();
 }
-GPUCSP::~GPUCSP() { fabgpu_shutdown(ctx_); }
+GPUCSP::~GPUCSP() {
+    memo_blocks_.clear();                                   // (tables the device built live in pinned memory of the context)
+    memo_free_.clear();
+    fabgpu_shutdown(ctx_);
+}
+GPUCSP::BlockMemo::~BlockMemo() {
+    if (pin) walk_pinned_free(pin_ctx, pin);
+}
 
 // bccsp/sw/keyimport.go:103-112 (ECDSAGoPublicKeyImportOpts) with the curve check x509 parsing implies
 Error GPUCSP::KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out, bool device_table) const {
@@ -628,11 +635,12 @@ int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* 
         const BlockMemo& bm = **it;
         if (!bm.n) continue;
         for (uint32_t probe = 0, at = (uint32_t)h & bm.mask; probe <= bm.mask && probe < 4096; probe++, at = (at + 1) & bm.mask) {
-            const uint32_t e = bm.slots[at].load(std::memory_order_acquire);
+            const uint32_t e = bm.slots_v[at];                             // (published under the lock: complete)
             if (!e) break;
-            const uint32_t o = bm.key_off[e - 1], l = bm.key_off[e] - o;
-            if (l == kl && memcmp(bm.keys.get() + o, key, kl) == 0) {
-                if (status) *status = bm.status[e - 1];
+            if (e > bm.n) break;                                            // (never: an index past the entries)
+            const uint32_t o = bm.key_off_v[e - 1], l = bm.key_off_v[e] - o;
+            if (l == kl && memcmp(bm.keys_v + o, key, kl) == 0) {
+                if (status) *status = bm.status_v[e - 1];
                 memo_hits_.fetch_add(1, std::memory_order_relaxed);
                 return 0;
             }
@@ -899,17 +907,25 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
         bm->n = m;
         out.memo_seeded = m;
         if (m) {
-            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
-            memo_blocks_.push_back(bm);
-            size_t total = 0;
-            for (const auto& b : memo_blocks_) total += b->n;
-            while (total > memo_cap_ && memo_blocks_.size() > 1) {        // bounded: the oldest block goes first
-                total -= memo_blocks_.front()->n;
-                memo_evicted_.fetch_add(memo_blocks_.front()->n, std::memory_order_relaxed);
-                if (memo_free_.size() < 4) memo_free_.push_back(memo_blocks_.front());
-                memo_blocks_.pop_front();
-            }
+            static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the slot table is read as plain words once it is published");
+            bm->slots_v = reinterpret_cast<const uint32_t*>(bm->slots.get());
+            bm->key_off_v = bm->key_off.data();
+            bm->keys_v = bm->keys.get();
+            bm->status_v = bm->status.data();
+            PublishMemo(bm);
         }
+    }
+}
+void GPUCSP::PublishMemo(const std::shared_ptr<BlockMemo>& bm) const {
+    std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+    memo_blocks_.push_back(bm);
+    size_t total = 0;
+    for (const auto& b : memo_blocks_) total += b->n;
+    while (total > memo_cap_ && memo_blocks_.size() > 1) {        // bounded: the oldest block goes first
+        total -= memo_blocks_.front()->n;
+        memo_evicted_.fetch_add(memo_blocks_.front()->n, std::memory_order_relaxed);
+        if (memo_free_.size() < 4) memo_free_.push_back(memo_blocks_.front());
+        memo_blocks_.pop_front();
     }
 }
 
@@ -1070,8 +1086,14 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     PassScratch& ps = *lease.p;
     auto clk0 = std::chrono::steady_clock::now();
     if (!OutlineBlock(block, len, pb, ps.env_spans, ps.block_sigs, &ps.payload_spans)) return FABGPU_EINVAL;
-    const bool want_digests = opt.want_digests || opt.seed_memo;
-    const bool want_tuples = (want & WANT_TUPLES) || opt.seed_memo, want_qxy = (want & WANT_QXY) || opt.seed_memo;
+    // The verdict memo of a device-route pass is built by the device (round 3: block_walk_dev.h WalkOut::memo_*) into pinned memory of a
+    // BlockMemo: keys, offsets, statuses and the slot table come back as they are looked up - no tuple records, digests and keys to bring
+    // back, copy out and read 40 000 signatures out of the host's copy of the block for.  FABGPU_PASS_DEVICE_MEMO=0: SeedMemo, as before.
+    const char* dm_env = getenv("FABGPU_PASS_DEVICE_MEMO");
+    const bool dev_memo = opt.seed_memo && !(dm_env && dm_env[0] == '0');
+    const bool host_memo = opt.seed_memo && !dev_memo;
+    const bool want_digests = opt.want_digests || host_memo;
+    const bool want_tuples = (want & WANT_TUPLES) || host_memo, want_qxy = (want & WANT_QXY) || host_memo;
     const uint32_t n_skipped = opt.block_sigs ? 0 : (uint32_t)ps.block_sigs.size();   // reported (TUPLE_ST_SKIPPED), not submitted
     if (pb.tail.size() > opt.tail_cap) {                             // the caller wants the tail and has no room for it: say so before anything runs
         if (n_tuples_out) *n_tuples_out = 0;
@@ -1133,7 +1155,31 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         uint32_t cap_tx, cap_tuples, n_skipped;
         uint32_t n_tuples = 0;
         bool too_big = false;
-    } sz{pb, out, ps, want_tuples, want_digests, want_qxy, opt.seed_memo && !msps.empty(), cap_tx, cap_tuples, n_skipped};
+        // the memo the device fills: a table out of the free list (its pinned room is reused), sized once the tuple count is known
+        fabgpu_ctx* ctx = nullptr;
+        BlockMemo* bm = nullptr;
+        uint32_t n_creators_hint = 0;
+    } sz{pb, out, ps, want_tuples, want_digests, want_qxy, host_memo && !msps.empty(), cap_tx, cap_tuples, n_skipped};
+    std::shared_ptr<BlockMemo> dev_bm;
+    if (dev_memo) {
+        {
+            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+            // (prefer a recycled table that already owns pinned room)
+            for (auto it = memo_free_.begin(); it != memo_free_.end(); ++it)
+                if ((*it)->pin) {
+                    dev_bm = *it;
+                    memo_free_.erase(it);
+                    break;
+                }
+            if (!dev_bm && !memo_free_.empty()) {
+                dev_bm = memo_free_.back();
+                memo_free_.pop_back();
+            }
+        }
+        if (!dev_bm) dev_bm.reset(new BlockMemo);
+        sz.ctx = ctx_;
+        sz.bm = dev_bm.get();
+    }
     WalkRequest rq;
     rq.stage_token = tok;
     rq.block_len = len;
@@ -1194,12 +1240,68 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         } else {
             z.out.tuple_qxy.clear();
         }
+        if (z.bm && c.n_tuples) {
+            // room for the memo: a slot table of at least twice the tuples, offsets, statuses, and keys of 141 (173 for a pseudonym
+            // signature) + signature bytes each - 96 bytes of signature on average are allowed for (an ECDSA signature has <= 72; a
+            // block whose keys do not fit simply gets no memo)
+            uint32_t cap = 16;
+            while (cap < 2 * (uint64_t)c.n_tuples && cap < (1u << 30)) cap <<= 1;
+            const size_t keys_cap = (size_t)c.n_tuples * (141 + 96) + (size_t)c.n_creators * 32 + 256;
+            auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t a_slots = 0, a_off = up256((size_t)cap * 4), a_st = a_off + up256(((size_t)c.n_tuples + 1) * 4), a_keys = a_st + up256(c.n_tuples),
+                         total = a_keys + up256(keys_cap);
+            if (cap >= 2 * (uint64_t)c.n_tuples && keys_cap < 0xFFFFFFF0ull) {
+                if (z.bm->pin_cap < total) {
+                    if (z.bm->pin) walk_pinned_free(z.bm->pin_ctx, z.bm->pin);
+                    z.bm->pin = walk_pinned_alloc(z.ctx, total + total / 4);
+                    z.bm->pin_ctx = z.ctx;
+                    z.bm->pin_cap = z.bm->pin ? total + total / 4 : 0;
+                }
+                if (z.bm->pin) {
+                    uint8_t* p = (uint8_t*)z.bm->pin;
+                    o.memo_slots = (uint32_t*)(p + a_slots);
+                    o.memo_slot_cap = cap;
+                    o.memo_key_off = (uint32_t*)(p + a_off);
+                    o.memo_status = p + a_st;
+                    o.memo_keys = p + a_keys;
+                    o.memo_keys_cap = keys_cap;
+                    z.bm->mask = cap - 1;
+                    z.bm->slots_v = o.memo_slots;
+                    z.bm->key_off_v = o.memo_key_off;
+                    z.bm->status_v = o.memo_status;
+                    z.bm->keys_v = o.memo_keys;
+                }
+            }
+        }
         return true;
     };
     ps.learn.resize(WALK_LEARN_SLOTS);
     rq.learn_out = ps.learn.data();
     rq.idemix_msps = msps.data();
     rq.n_idemix_msps = (uint32_t)msps.size();
+    // (a pseudonym signature's memo entry is bound to the hash of the issuer key it was verified under: without every MSP's hash at hand
+    //  the device makes no entries for pseudonym signatures at all)
+    std::vector<uint8_t> issuer_hashes;
+    if (dev_memo && !msps.empty()) {
+        std::lock_guard<std::mutex> lk(idmu_);
+        issuer_hashes.resize(32 * msps.size());
+        bool all = true;
+        for (size_t m = 0; m < msps.size(); m++) {
+            auto it = idemix_issuer_hash_.find(msps[m].issuer);
+            if (it == idemix_issuer_hash_.end()) all = false;
+            else memcpy(&issuer_hashes[32 * m], it->second.data(), 32);
+        }
+        if (all) rq.idemix_issuer_hashes = issuer_hashes.data();
+    }
+    struct MemoBack {                                                       // a table that was not published goes back to the free list
+        const GPUCSP* c;
+        std::shared_ptr<BlockMemo>& bm;
+        ~MemoBack() {
+            if (!bm) return;
+            std::unique_lock<std::shared_timed_mutex> lk(c->memo_mu_);
+            if (c->memo_free_.size() < 4) c->memo_free_.push_back(bm);
+        }
+    } memo_back{this, dev_bm};
     auto clk2 = std::chrono::steady_clock::now();
     rc = walk_block_pass(ctx_, rq);
     out.ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk2).count();
@@ -1314,7 +1416,16 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     }
     RegisterQueued(to_register);
     static const int gate_max = [] { const char* e = getenv("FABGPU_PASS_GATE_THREADS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
-    if (opt.seed_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max);
+    if (host_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max);
+    if (dev_memo && dev_bm && rq.memo_n && dev_bm->slots_v) {
+        auto clk_memo = std::chrono::steady_clock::now();
+        dev_bm->seq = opt.block_seq;
+        dev_bm->n = rq.memo_n;
+        out.memo_seeded = rq.memo_n;
+        PublishMemo(dev_bm);
+        dev_bm.reset();                                                    // (published: not for the free list)
+        out.ms_memo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk_memo).count();
+    }
     return 0;
 }
 

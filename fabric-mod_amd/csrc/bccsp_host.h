@@ -256,7 +256,18 @@ class GPUCSP {
         std::unique_ptr<uint8_t[]> keys;                  // framed keys: X || Y || u32 len || sig || u32 len || digest (not zero-filled)
         size_t keys_cap = 0, slots_cap = 0;
         std::vector<uint8_t> status;                      // n
+        // What a lookup reads: the arrays above (a table SeedMemo built on the host) or - a table the DEVICE built, block_walk_dev.h
+        // WalkOut::memo_* - the same four arrays inside `pin`, pinned host memory the pass copied them into.
+        const uint32_t* slots_v = nullptr;
+        const uint32_t* key_off_v = nullptr;
+        const uint8_t* keys_v = nullptr;
+        const uint8_t* status_v = nullptr;
+        void* pin = nullptr;
+        size_t pin_cap = 0;
+        fabgpu_ctx* pin_ctx = nullptr;
+        ~BlockMemo();
     };
+    void PublishMemo(const std::shared_ptr<BlockMemo>& bm) const;   // push under the lock, oldest blocks out while over capacity
     mutable std::vector<std::shared_ptr<BlockMemo>> memo_free_;    // evicted tables, recycled: 7 MB of fresh pages per block otherwise
     mutable std::shared_timed_mutex memo_mu_;
     mutable std::deque<std::shared_ptr<BlockMemo>> memo_blocks_;   // oldest first

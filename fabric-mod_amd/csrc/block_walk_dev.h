@@ -81,6 +81,11 @@ struct WalkLearn {
 };
 static_assert(sizeof(WalkSummary) == 48 && sizeof(WalkLearn) == 88, "copied as raw bytes");
 
+// what the memo kernels made: entries, key bytes, and whether the keys outgrew the room the caller gave (then there is no memo for this block)
+struct WalkMemoTotals {
+    uint32_t n, overflow;
+    uint64_t bytes;
+};
 struct WalkTotals {
     uint32_t tuples, prefixes, checks, creators;   // creators: envelopes that yield tuples (each yields exactly one creator tuple, its first)
     uint64_t gather_bytes;
@@ -153,6 +158,17 @@ struct WalkArrays {
     const uint8_t* dev_status = nullptr;       // by row
     const uint8_t* row_digests = nullptr;      // by row (null: not wanted)
     uint8_t* tuple_digests = nullptr;          // by tuple
+    // The block's verdict memo, built on the device (walk_memo_*_kernel) in the layout of bccsp_host.h's BlockMemo: framed keys back to
+    // back, their offsets, a status byte per entry and an open-addressed slot table (entry index + 1; the slot hash is GPUCSP::MemoHash).
+    uint32_t* memo_slots = nullptr;
+    uint32_t memo_mask = 0;
+    uint32_t* memo_key_off = nullptr;          // entries + 1
+    uint8_t* memo_keys = nullptr;
+    uint32_t memo_keys_cap = 0;
+    uint8_t* memo_status = nullptr;            // by entry
+    uint32_t* memo_ent = nullptr;              // by tuple: its entry, ~0 = none
+    struct WalkMemoTotals* memo_totals = nullptr;
+    const uint8_t* issuer_hashes = nullptr;    // 32 bytes per idemix MSP of idemix_msps: ipk.Hash of its issuer (a pseudonym entry is bound to it)
     uint8_t* tuple_qxy = nullptr;              // by tuple, 64 bytes: the key of a P-256 identity, zeros otherwise (null: not wanted)
     uint8_t* tuple_status = nullptr;
     uint8_t* tuple_hashed = nullptr;
@@ -174,6 +190,7 @@ struct WalkHostOut {
     uint8_t *tx_flags = nullptr, *tx_type = nullptr, *tx_understood = nullptr;   // n_env each
     uint8_t *tuple_status = nullptr, *tuple_hashed = nullptr;                    // n_tuples each
     uint32_t* id_idx = nullptr;                                                  // n_tuples
+    WalkMemoTotals* memo_totals = nullptr;                                       // optional
 };
 // counts, tx_type, tx_understood; then the scan, which also writes the totals to host_totals and then seq to host_flag (host-mapped)
 hipError_t launch_walk_count(const WalkArrays& a, WalkTotals* host_totals, uint32_t* host_flag, uint32_t seq, hipStream_t st);
@@ -184,6 +201,8 @@ hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);               
 hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st);
 // the idemix creators among [0, n_creators), counted off: nym_slot[rank] = its row in the nym launch, gather[row] = rank for row < cap
 hipError_t launch_walk_nym_pack(const WalkArrays& a, uint32_t* gather, uint32_t cap, hipStream_t st);
+// the verdict memo of the pass (after the status kernel): entries counted off by ONE workgroup, then a wavefront per tuple writes its key
+hipError_t launch_walk_memo(const WalkArrays& a, hipStream_t st);
 hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st);   // tuple statuses + digest comparisons (one launch)
 // per-transaction flags and everything the host reads, written to host-mapped memory; the last workgroup raises h.flag
 hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStream_t st);
@@ -216,6 +235,15 @@ struct WalkOut {
     uint8_t* tuple_digest = nullptr;      // 32 n_tuples
     bccsp::Span* prefixes = nullptr;      // n_prefixes            (tests)
     bccsp::BlockHashCheck* checks = nullptr;   // n_checks         (tests)
+    // The block's verdict memo as the DEVICE builds it (round 3), into PINNED host memory of the caller (walk_pinned_alloc), in the layout
+    // GPUCSP::MemoLookup reads; all null = not wanted.  Afterwards WalkRequest::memo_n entries are in place (0: none - nothing to remember,
+    // or the keys did not fit memo_keys_cap: that block simply has no memo, its signatures are verified by bccsp/sw).
+    uint32_t* memo_slots = nullptr;       // memo_slot_cap entries, a power of two >= 2 n_tuples
+    uint32_t memo_slot_cap = 0;
+    uint32_t* memo_key_off = nullptr;     // n_tuples + 1
+    uint8_t* memo_keys = nullptr;         // memo_keys_cap bytes (< 2^32)
+    size_t memo_keys_cap = 0;
+    uint8_t* memo_status = nullptr;       // n_tuples
 };
 struct WalkRequest {
     uint64_t stage_token = 0;             // the block, uploaded with fabgpu_arena_stage
@@ -236,6 +264,7 @@ struct WalkRequest {
     uint32_t tail_base = 0, tail_len = 0;
     const DevIdemixMsp* idemix_msps = nullptr;   // host: the idemix MSPs whose creators the pass verifies (at most WALK_IDEMIX_MSPS_MAX)
     uint32_t n_idemix_msps = 0;
+    const uint8_t* idemix_issuer_hashes = nullptr;   // host, 32 bytes per entry of idemix_msps: ipk.Hash (memo entries of pseudonym signatures)
     bool walk_only = false;               // stop after the walk (tests: the device walker against the host walker)
     void* user = nullptr;
     bool (*sizes)(void* user, const WalkCounts& c, WalkOut& out) = nullptr;   // false: the caller has no room (FABGPU_ETOOBIG)
@@ -244,11 +273,16 @@ struct WalkRequest {
     bool keyed_creators = false, keyed_others = false;   // which launch classes ran on registered comb tables
     uint32_t relaunched = 0;              // launches repeated because the prediction "everybody is registered" did not hold
     WalkLearn* learn_out = nullptr;       // host, optional: WALK_LEARN_SLOTS records (tag == 0 or ready == 0: empty)
+    uint32_t memo_n = 0;                  // entries of the memo the device built into WalkOut::memo_* (0: none)
+    uint64_t memo_bytes = 0;
     const char* declined_why = "";
     double ms_walk = 0, ms_gate = 0, ms_verify = 0;
 };
 // FABGPU_OK, WALK_DECLINED, or a negative FABGPU_E*
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq);
+// pinned host memory for WalkOut::memo_* (hipHostMalloc / hipHostFree; nullptr when there is none to be had)
+void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes);
+void walk_pinned_free(fabgpu_ctx* ctx, void* p);
 // TEST HOOK: the device's (wavefront) signature gate over n signatures = arena[spans[2i], spans[2i+1]) in host memory -> code (as
 // walk::gate_sig_any), r, s (32 bytes each; zero unless code == GATE_SUBMIT)
 int walk_gate_probe(fabgpu_ctx* ctx, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s);

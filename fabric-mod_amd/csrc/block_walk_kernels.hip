@@ -599,6 +599,23 @@ __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i
         }
         a.tuple_status[i] = st;
         a.tuple_hashed[i] = hashed;
+        if (a.memo_ent) {
+            // The memo entry this tuple will get (GPUCSP::SeedMemo's rule): hashed and decided with a status bccsp.Verify decides itself, a
+            // signature of 1 .. 1024 bytes; a pseudonym signature only with the hash of the issuer key it was verified under at hand.
+            // Stored as the length of its framed key (GPUCSP::MemoKeyBytes); walk_memo_scan_kernel turns the lengths into entries.
+            uint32_t klen = 0;
+            int32_t ih = -1;
+            if (key_from_nym && a.issuer_hashes) {
+                const int32_t issuer = a.nym_issuer_out[a.cbase[t.tx]];
+                for (uint32_t m = 0; m < a.n_idemix_msps; m++)
+                    if (a.idemix_msps[m].issuer == issuer) ih = (int32_t)m;
+            }
+            const bool nym_t = gst == GATE_ST_NYM;
+            if (hashed && st <= FABGPU_ST_RANGE && t.sig.len >= 1 && t.sig.len <= 1024 && t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off &&
+                (!nym_t || ih >= 0))
+                klen = 1u + (nym_t ? 32u : 0u) + 64u + 4u + t.sig.len + 4u + 32u;
+            a.memo_ent[i] = klen;
+        }
         if (st != FABGPU_ST_VALID && t.tx < a.n_env)                     // block-level tuples (orderer signatures) do not flag a transaction
             atomicOr(&a.tx_mask[t.tx], st == bccsp::TUPLE_ST_NEEDS_SW ? M_SW : (t.kind == bccsp::TUPLE_CREATOR ? M_BAD_CREATOR : M_BAD_END));
     }
@@ -693,6 +710,8 @@ __global__ void __launch_bounds__(256) walk_finish_kernel(WalkArrays a, WalkHost
         uint32_t* ld = reinterpret_cast<uint32_t*>(h.learn);
         for (uint32_t w = threadIdx.x; w < sizeof(WalkLearn) * WALK_LEARN_SLOTS / 4; w += blockDim.x) ld[w] = ls[w];
         if (threadIdx.x < sizeof(WalkSummary) / 4) reinterpret_cast<uint32_t*>(h.summary)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.summary)[threadIdx.x];
+        if (h.memo_totals && a.memo_totals && threadIdx.x < sizeof(WalkMemoTotals) / 4)
+            reinterpret_cast<uint32_t*>(h.memo_totals)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.memo_totals)[threadIdx.x];
     }
     __threadfence_system();
     __syncthreads();
@@ -736,6 +755,113 @@ __global__ void __launch_bounds__(1024) walk_nym_pack_kernel(WalkArrays a, uint3
     }
 }
 
+
+// ---- the block's verdict memo, built where the verdicts are (bccsp_host.h BlockMemo; GPUCSP::SeedMemo is the host's version) -------------
+// Entries counted off: the status kernel left the length of every tuple's framed key (0 = no entry) in memo_ent; ONE workgroup turns the
+// lengths into entry indices and key offsets (the scan of walk_scan_kernel) and says whether the keys fit the room the caller gave.
+__global__ void __launch_bounds__(1024) walk_memo_scan_kernel(WalkArrays a) {
+    __shared__ uint32_t sn[1024];
+    __shared__ uint64_t sb[1024];
+    const uint32_t tid = threadIdx.x, n = a.n_tuples;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    uint32_t k = 0;
+    uint64_t b = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t l = a.memo_ent[i];
+        k += l ? 1u : 0u;
+        b += l;
+    }
+    sn[tid] = k;
+    sb[tid] = b;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t vn = 0;
+        uint64_t vb = 0;
+        if (tid >= o) { vn = sn[tid - o]; vb = sb[tid - o]; }
+        __syncthreads();
+        sn[tid] += vn;
+        sb[tid] += vb;
+        __syncthreads();
+    }
+    const bool fits = sb[1023] <= (uint64_t)a.memo_keys_cap;
+    uint32_t e = sn[tid] - k;
+    uint64_t off = sb[tid] - b;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t l = a.memo_ent[i];
+        if (l && fits) {
+            a.memo_key_off[e] = (uint32_t)off;
+            a.memo_ent[i] = e;
+            e++;
+            off += l;
+        } else {
+            a.memo_ent[i] = 0xFFFFFFFFu;
+        }
+    }
+    if (tid == 1023) {
+        a.memo_key_off[fits ? sn[1023] : 0u] = fits ? (uint32_t)sb[1023] : 0u;
+        a.memo_totals->n = fits ? sn[1023] : 0u;
+        a.memo_totals->overflow = fits ? 0u : 1u;
+        a.memo_totals->bytes = fits ? sb[1023] : 0u;
+    }
+}
+// One wavefront per tuple: its framed key - [1 | 2 || issuer hash] || X || Y || u32 len || signature || u32 32 || digest, exactly
+// GPUCSP::MemoKeyWrite - its status byte, and its place in the slot table (GPUCSP::MemoHash, linear probing, entry index + 1).
+__global__ void __launch_bounds__(256) walk_memo_write_kernel(WalkArrays a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= a.n_tuples) return;
+    const uint32_t e = a.memo_ent[i];
+    if (e == 0xFFFFFFFFu) return;
+    const BlockTuple t = a.tuples[i];
+    const uint32_t off = a.memo_key_off[e];
+    const bool nym = a.gate_st[i] == GATE_ST_NYM;
+    const uint32_t klen = 1u + (nym ? 32u : 0u) + 64u + 4u + t.sig.len + 4u + 32u;
+    if ((uint64_t)off + klen > (uint64_t)a.memo_keys_cap) return;            // (the scan said it fits: defensive)
+    uint8_t* k = a.memo_keys + off;
+    const uint8_t* sig = a.block + t.sig.off;
+    const uint8_t* dig = a.tuple_digests + 32 * (size_t)i;
+    uint32_t pos = 1;
+    if (lane == 0) k[0] = nym ? 2 : 1;
+    const uint8_t *kx, *ky;
+    if (nym) {
+        const uint32_t rank = a.cbase[t.tx];
+        const int32_t issuer = a.nym_issuer_out[rank];
+        uint32_t m_at = 0;
+        for (uint32_t m = 0; m < a.n_idemix_msps; m++)
+            if (a.idemix_msps[m].issuer == issuer) m_at = m;
+        if (lane < 32) k[1 + lane] = a.issuer_hashes[32 * (size_t)m_at + lane];
+        pos = 33;
+        kx = a.nym_fields + 32 * (size_t)rank;
+        ky = a.nym_fields + 32 * (size_t)a.n_creators + 32 * (size_t)rank;
+    } else {
+        const uint32_t row = a.row_of[i];
+        kx = a.qx + 32 * (size_t)row;
+        ky = a.qy + 32 * (size_t)row;
+    }
+    k[pos + lane] = lane < 32 ? kx[lane] : ky[lane & 31u];
+    pos += 64;
+    if (lane < 4) k[pos + lane] = (uint8_t)(t.sig.len >> (8 * lane));
+    pos += 4;
+    for (uint32_t b = lane; b < t.sig.len; b += 64) k[pos + b] = sig[b];
+    pos += t.sig.len;
+    if (lane < 4) k[pos + lane] = lane == 0 ? 32 : 0;
+    pos += 4;
+    if (lane < 32) k[pos + lane] = dig[lane];
+    if (lane == 0) {
+        a.memo_status[e] = a.tuple_status[i];
+        uint64_t ha = 0, hb = 0;
+        for (int q = 0; q < 8; q++) ha |= (uint64_t)dig[q] << (8 * q);
+        const uint32_t nb = t.sig.len < 8 ? t.sig.len : 8u, s0 = t.sig.len > 8 ? t.sig.len - 8 : 0u;
+        for (uint32_t q = 0; q < nb; q++) hb |= (uint64_t)sig[s0 + q] << (8 * q);
+        uint64_t h = (ha ^ (hb * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+        h ^= h >> 32;
+        uint32_t at = (uint32_t)h & a.memo_mask;
+        for (uint32_t probe = 0; probe <= a.memo_mask; probe++, at = (at + 1) & a.memo_mask)
+            if (atomicCAS(&a.memo_slots[at], 0u, e + 1) == 0u) break;
+    }
+}
+
 hipError_t launch_walk_count(const WalkArrays& a, WalkTotals* host_totals, uint32_t* host_flag, uint32_t seq, hipStream_t st) {
     if (a.n_env) {
         hipLaunchKernelGGL(walk_count_kernel, dim3((a.n_env + 63) / 64), dim3(64), 0, st, a);
@@ -775,6 +901,14 @@ hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spa
 hipError_t launch_walk_nym_pack(const WalkArrays& a, uint32_t* gather, uint32_t cap, hipStream_t st) {
     if (a.n_creators == 0) return hipSuccess;
     hipLaunchKernelGGL(walk_nym_pack_kernel, dim3(1), dim3(1024), 0, st, a, gather, cap);
+    return hipGetLastError();
+}
+hipError_t launch_walk_memo(const WalkArrays& a, hipStream_t st) {
+    if (a.n_tuples == 0 || !a.memo_ent) return hipSuccess;
+    hipLaunchKernelGGL(walk_memo_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(walk_memo_write_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st) {

@@ -1470,6 +1470,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // outline of where they are they start before anything is walked, beside the walk's two runs and the gates.
     const bool early_hash = rq.payload_spans && !rq.walk_only && ctx->allow_pair && (uint64_t)ne * 2 <= 65536u;
     const size_t o_env = carve((size_t)ne * 8), o_pay = carve(early_hash ? (size_t)ne * 8 : 0), o_msps = carve(sizeof(DevIdemixMsp) * n_msps),
+                 o_ihash = carve(rq.idemix_issuer_hashes ? (size_t)32 * n_msps : 0),
                  o_up_small = o,                                                // ... the copy ends here unless the host counted
                  o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_cbase = carve((size_t)ne * 4), o_type = carve(ne), o_und = carve(ne),
                  o_up_all = o,
@@ -1481,7 +1482,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     const size_t up_bytes = host_counted ? o_up_all : o_up_small, p_first = round_up(o_up_all, 256);
     if ((rc = ctx->walk_pin.ensure(p_first))) return rc;
     // host-mapped results: [0, 64) the totals' flag, [64, 128) the totals, [128, 192) the final flag, [192, 256) the summary; the arrays follow
-    constexpr size_t m_totflag = 0, m_tot = 64, m_finflag = 128, m_sum = 192, m_arrays = 256;
+    constexpr size_t m_totflag = 0, m_tot = 64, m_finflag = 128, m_sum = 192, m_mtot = 240, m_arrays = 256;   // (the summary is 48 bytes, the memo's totals 16)
     if ((rc = ctx->walk_map.ensure(m_arrays + sizeof(WalkLearn) * WALK_LEARN_SLOTS + 3 * round_up(ne, 64) + ((size_t)8 << 10)))) return rc;
     if (++ctx->walk_seq == 0) ++ctx->walk_seq;
     const uint32_t seq_tot = ctx->walk_seq;
@@ -1506,6 +1507,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     memcpy(up + o_env, rq.env_spans, (size_t)ne * 8);
     if (early_hash) memcpy(up + o_pay, rq.payload_spans, (size_t)ne * 8);
     if (n_msps) memcpy(up + o_msps, rq.idemix_msps, sizeof(DevIdemixMsp) * n_msps);
+    if (n_msps && rq.idemix_issuer_hashes) memcpy(up + o_ihash, rq.idemix_issuer_hashes, (size_t)32 * n_msps);
     WalkTotals host_tot = {};
     if (host_counted) {
         // the scan, here: exclusive prefix sums per envelope (walk_scan_kernel's outputs), and the totals the host would otherwise wait for
@@ -1590,6 +1592,13 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_nymb = carve(n_msps ? ((size_t)tot.creators + 63) / 64 * 8 + 8 : 0), o_nymst = carve(n_msps ? (size_t)tot.creators + 64 : 0),
                  o_nymga = carve(n_msps ? (size_t)tot.creators * 4 + 256 : 0), o_nymsl = carve(n_msps ? (size_t)tot.creators * 4 : 0),
                  o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0);
+    // the verdict memo, if the caller gave room for it (WalkOut::memo_*): built behind the status kernel, copied straight into that room
+    const bool memo = out.memo_slots && out.memo_key_off && out.memo_keys && out.memo_status && out.memo_slot_cap >= 16 &&
+                      (out.memo_slot_cap & (out.memo_slot_cap - 1)) == 0 && out.memo_slot_cap >= 2 * (uint64_t)nt && out.memo_keys_cap != 0 &&
+                      out.memo_keys_cap < 0xFFFFFFF0ull;
+    const size_t o_ment = carve(memo ? (size_t)nt * 4 : 0), o_mslots = carve(memo ? (size_t)out.memo_slot_cap * 4 : 0),
+                 o_mkoff = carve(memo ? ((size_t)nt + 1) * 4 : 0), o_mkeys = carve(memo ? out.memo_keys_cap : 0), o_mst = carve(memo ? nt : 0),
+                 o_mtot = carve(memo ? sizeof(WalkMemoTotals) : 0);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
     a.tuples = (bccsp::BlockTuple*)(dt + o_tup);
@@ -1635,9 +1644,20 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     const bool exclusive = a.split && !both_pair;
     a.verdict_bits = (const uint64_t*)(dt + o_bits);
     a.verdict_bits_c = (const uint64_t*)(dt + o_bitc);
-    a.row_digests = out.tuple_digest ? dt + o_dig : nullptr;
+    a.row_digests = (out.tuple_digest || memo) ? dt + o_dig : nullptr;    // (the memo's keys hold the digests)
     a.tuple_digests = dt + o_tdig;
     a.tuple_qxy = out.tuple_qxy ? dt + o_tqxy : nullptr;
+    if (memo) {
+        a.memo_ent = (uint32_t*)(dt + o_ment);
+        a.memo_slots = (uint32_t*)(dt + o_mslots);
+        a.memo_mask = out.memo_slot_cap - 1;
+        a.memo_key_off = (uint32_t*)(dt + o_mkoff);
+        a.memo_keys = dt + o_mkeys;
+        a.memo_keys_cap = (uint32_t)out.memo_keys_cap;
+        a.memo_status = dt + o_mst;
+        a.memo_totals = (WalkMemoTotals*)(dt + o_mtot);
+        if (n_msps && rq.idemix_issuer_hashes) a.issuer_hashes = de + o_ihash;
+    }
     a.dev_status = dt + o_dst;
     a.tuple_status = dt + o_tst;
     a.tuple_hashed = dt + o_hsh;
@@ -1675,6 +1695,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         ho.flag = (uint32_t*)(m8 + m_finflag);
         ho.done = (uint32_t*)(de + o_done);
         ho.summary = (WalkSummary*)(m8 + m_sum);
+        ho.memo_totals = memo ? (WalkMemoTotals*)(m8 + m_mtot) : nullptr;
         ho.learn = (WalkLearn*)(m8 + m_learn);
         ho.tx_flags = m8 + m_flags; ho.tx_type = m8 + m_type; ho.tx_understood = m8 + m_und;
         ho.tuple_status = m8 + m_tst; ho.tuple_hashed = m8 + m_hsh;
@@ -1837,7 +1858,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     rq.ms_walk = ms_since(t_start);
     const auto t_verify = now();
     pa.mid_ready = true;
-    pa.digests = out.tuple_digest ? dt + o_dig : nullptr;
+    pa.digests = (out.tuple_digest || memo) ? dt + o_dig : nullptr;
     uint32_t nkeys = 0;
     const int32_t** kt = nullptr;
     {
@@ -1896,7 +1917,16 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (++ctx->walk_seq == 0) ++ctx->walk_seq;
         ho.seq = ctx->walk_seq;
         if (err == hipSuccess && nym_ran) err = hipStreamWaitEvent(st, ctx->ev_w[6], 0);     // the nym kernel's answers
+        if (err == hipSuccess && memo) err = hipMemsetAsync(dt + o_mslots, 0, (size_t)out.memo_slot_cap * 4, st);
         if (err == hipSuccess) err = launch_walk_status_checks(a, nc, st);
+        if (memo) {
+            // the memo: entries counted off, keys written, slots filled - and copied into the caller's (pinned) room as it stands
+            if (err == hipSuccess) err = launch_walk_memo(a, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(out.memo_slots, dt + o_mslots, (size_t)out.memo_slot_cap * 4, hipMemcpyDeviceToHost, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(out.memo_key_off, dt + o_mkoff, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(out.memo_keys, dt + o_mkeys, out.memo_keys_cap, hipMemcpyDeviceToHost, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(out.memo_status, dt + o_mst, nt, hipMemcpyDeviceToHost, st);
+        }
         fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
         fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
         fetch(out.tuple_qxy, p_qxy, dt + o_tqxy, (size_t)nt * 64);
@@ -1906,6 +1936,11 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         int r2 = wait_host_flag((const uint32_t*)(mh + m_finflag), ho.seq, st);
         if (r2 != FABGPU_OK) return r2;
         rq.summary = *(const WalkSummary*)(mh + m_sum);
+        if (memo) {
+            const WalkMemoTotals mt = *(const WalkMemoTotals*)(mh + m_mtot);
+            rq.memo_n = mt.overflow ? 0 : mt.n;
+            rq.memo_bytes = mt.overflow ? 0 : mt.bytes;
+        }
         return FABGPU_OK;
     };
     if (np) err = hipStreamWaitEvent(st, ctx->ev_w[1], 0);               // the mid-states (long done: they ran beside the gates)
@@ -1985,6 +2020,19 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     drain.armed = false;                                                    // (the flag was raised behind everything: all four streams are idle)
     drain2.armed = false;
     return FABGPU_OK;
+}
+
+void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes) {
+    if (!ctx || bytes == 0) return nullptr;
+    DeviceGuard g(ctx->device);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void walk_pinned_free(fabgpu_ctx* ctx, void* p) {
+    if (!ctx || !p) return;
+    DeviceGuard g(ctx->device);
+    (void)hipHostFree(p);
 }
 
 }  // namespace fab

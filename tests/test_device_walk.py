@@ -541,6 +541,43 @@ def test_counts_from_the_host_and_counts_from_the_device_give_one_answer(csp, mo
 
 
 @pytest.mark.gpu
+def test_memo_built_by_the_device_equals_the_memo_seeded_on_the_host(csp, monkeypatch):
+    """The verdict memo of a device-route pass is built by the device (keys, offsets, statuses, slot table copied into pinned memory of the
+    provider's table: block_walk_dev.h WalkOut::memo_*); FABGPU_PASS_DEVICE_MEMO=0 brings the arrays back and lets GPUCSP::SeedMemo build it
+    as before.  Same block - every kind of corruption the generator knows - same entries: every tuple's (key, signature, digest) finds the
+    same status or the same miss, the same number of entries, and nothing is left after eviction."""
+    rng = np.random.default_rng(31)
+    blk, want = build_block(120, rng)
+    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    answers = []
+    for k, mode in enumerate(("1", "0")):
+        monkeypatch.setenv("FABGPU_PASS_DEVICE_MEMO", mode)
+        before = fabgpu.pass_routes(csp)
+        out = fabgpu.preverify_block2(csp, blk, block_seq=90 + k, seed_memo=True)
+        assert fabgpu.pass_routes(csp)["device_walks"] - before["device_walks"] == 1
+        assert (out["tx_flags"] == want).all()
+        found = []
+        for i in range(len(out["tuple_status"])):
+            sp = [int(x) for x in out["tuple_spans"][i]]
+            sig, q = out["arena"][sp[6]:sp[6] + sp[7]], bytes(out["tuple_qxy"][i])
+            if not sig:
+                found.append(None)
+                continue
+            found.append(fabgpu.memo_lookup(csp, q[:32], q[32:], sig, bytes(out["tuple_digest"][i])))
+        hashed = [i for i in range(len(found)) if out["tuple_hashed"][i] and out["tuple_status"][i] <= 3 and 0 < int(out["tuple_spans"][i][7]) <= 1024]
+        assert out["memo_seeded"] == len(hashed) > 100
+        for i in hashed:
+            assert found[i] == int(out["tuple_status"][i])
+        assert all(found[i] is None for i in range(len(found)) if i not in set(hashed))
+        assert fabgpu.memo_has_block(csp, 90 + k) == out["memo_seeded"]
+        fabgpu.memo_evict_block(csp, 90 + k)
+        assert fabgpu.memo_has_block(csp, 90 + k) == 0
+        answers.append((out, found))
+    _same(answers[0][0], answers[1][0], KEYS_ALL)
+    assert answers[0][1] == answers[1][1]
+
+
+@pytest.mark.gpu
 def test_device_route_serves_what_it_used_to_decline(csp, monkeypatch):
     """Identities nobody has met (the device decodes their certificates itself), garbage DER, a provider that knows nobody at all:
     none of it takes a block to the host walk any more, and the answers are the host route's - which learns nothing the device route

@@ -21,4 +21,6 @@ int fabgpu_arena_stage(fabgpu_ctx*, const void*, size_t, uint64_t*) { return -1;
 namespace fab {
 int walk_idtab_set(fabgpu_ctx*, uint32_t, const DevIdEntry*, const uint8_t*, size_t, uint64_t) { return -1; }
 int walk_block_pass(fabgpu_ctx*, WalkRequest&) { return -1; }
+void* walk_pinned_alloc(fabgpu_ctx*, size_t) { return nullptr; }
+void walk_pinned_free(fabgpu_ctx*, void*) {}
 }
