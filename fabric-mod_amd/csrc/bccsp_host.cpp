@@ -637,9 +637,12 @@ int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* 
         for (uint32_t probe = 0, at = (uint32_t)h & bm.mask; probe <= bm.mask && probe < 4096; probe++, at = (at + 1) & bm.mask) {
             const uint32_t e = bm.slots_v[at];                             // (published under the lock: complete)
             if (!e) break;
-            if (e > bm.n) break;                                            // (never: an index past the entries)
+            if (e > bm.n_entries) break;                                    // (never: an index past the entries)
             const uint32_t o = bm.key_off_v[e - 1], l = bm.key_off_v[e] - o;
-            if (l == kl && memcmp(bm.keys_v + o, key, kl) == 0) {
+            const bool same = bm.digests_v ? (dlen == 32 && l == kl - 32 && memcmp(bm.keys_v + o, key, l) == 0 &&
+                                              memcmp(bm.digests_v + 32 * (size_t)(e - 1), digest, 32) == 0)
+                                           : (l == kl && memcmp(bm.keys_v + o, key, kl) == 0);
+            if (same) {
                 if (status) *status = bm.status_v[e - 1];
                 memo_hits_.fetch_add(1, std::memory_order_relaxed);
                 return 0;
@@ -912,6 +915,8 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
             bm->key_off_v = bm->key_off.data();
             bm->keys_v = bm->keys.get();
             bm->status_v = bm->status.data();
+            bm->digests_v = nullptr;
+            bm->n_entries = m;
             PublishMemo(bm);
         }
     }
@@ -1241,15 +1246,15 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
             z.out.tuple_qxy.clear();
         }
         if (z.bm && c.n_tuples) {
-            // room for the memo: a slot table of at least twice the tuples, offsets, statuses, and keys of 141 (173 for a pseudonym
-            // signature) + signature bytes each - 96 bytes of signature on average are allowed for (an ECDSA signature has <= 72; a
-            // block whose keys do not fit simply gets no memo)
+            // room for the memo: a slot table of at least twice the tuples, offsets, statuses, digests, and keys of 109 (141 for a
+            // pseudonym signature) + signature bytes each - 96 bytes of signature on average are allowed for (an ECDSA signature has
+            // <= 72; a block whose keys do not fit simply gets no memo)
             uint32_t cap = 16;
             while (cap < 2 * (uint64_t)c.n_tuples && cap < (1u << 30)) cap <<= 1;
-            const size_t keys_cap = (size_t)c.n_tuples * (141 + 96) + (size_t)c.n_creators * 32 + 256;
+            const size_t keys_cap = (size_t)c.n_tuples * (109 + 96) + (size_t)c.n_creators * 32 + 256;
             auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-            const size_t a_slots = 0, a_off = up256((size_t)cap * 4), a_st = a_off + up256(((size_t)c.n_tuples + 1) * 4), a_keys = a_st + up256(c.n_tuples),
-                         total = a_keys + up256(keys_cap);
+            const size_t a_slots = 0, a_off = up256((size_t)cap * 4), a_st = a_off + up256(((size_t)c.n_tuples + 1) * 4), a_dig = a_st + up256(c.n_tuples),
+                         a_keys = a_dig + up256((size_t)c.n_tuples * 32), total = a_keys + up256(keys_cap);
             if (cap >= 2 * (uint64_t)c.n_tuples && keys_cap < 0xFFFFFFF0ull) {
                 if (z.bm->pin_cap < total) {
                     if (z.bm->pin) walk_pinned_free(z.bm->pin_ctx, z.bm->pin);
@@ -1263,12 +1268,14 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
                     o.memo_slot_cap = cap;
                     o.memo_key_off = (uint32_t*)(p + a_off);
                     o.memo_status = p + a_st;
+                    o.memo_digests = p + a_dig;
                     o.memo_keys = p + a_keys;
                     o.memo_keys_cap = keys_cap;
                     z.bm->mask = cap - 1;
                     z.bm->slots_v = o.memo_slots;
                     z.bm->key_off_v = o.memo_key_off;
                     z.bm->status_v = o.memo_status;
+                    z.bm->digests_v = o.memo_digests;
                     z.bm->keys_v = o.memo_keys;
                 }
             }
@@ -1417,11 +1424,12 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     RegisterQueued(to_register);
     static const int gate_max = [] { const char* e = getenv("FABGPU_PASS_GATE_THREADS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     if (host_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max);
-    if (dev_memo && dev_bm && rq.memo_n && dev_bm->slots_v) {
+    if (dev_memo && dev_bm && rq.memo_live && dev_bm->slots_v) {
         auto clk_memo = std::chrono::steady_clock::now();
         dev_bm->seq = opt.block_seq;
-        dev_bm->n = rq.memo_n;
-        out.memo_seeded = rq.memo_n;
+        dev_bm->n = rq.memo_live;
+        dev_bm->n_entries = rq.memo_n;
+        out.memo_seeded = rq.memo_live;
         PublishMemo(dev_bm);
         dev_bm.reset();                                                    // (published: not for the free list)
         out.ms_memo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk_memo).count();

@@ -262,6 +262,11 @@ class GPUCSP {
         const uint32_t* key_off_v = nullptr;
         const uint8_t* keys_v = nullptr;
         const uint8_t* status_v = nullptr;
+        // a table the device built: its keys end with the digest's LENGTH field and the 32-byte digests sit in an array of their own, by
+        // entry (they are the one part of a key that only exists once the verify launches are through; everything else travels beside
+        // them); it may hold entries without a slot (candidates that were not decided: status 255) - n counts the ones with a slot
+        const uint8_t* digests_v = nullptr;
+        uint32_t n_entries = 0;
         void* pin = nullptr;
         size_t pin_cap = 0;
         fabgpu_ctx* pin_ctx = nullptr;

@@ -83,8 +83,9 @@ static_assert(sizeof(WalkSummary) == 48 && sizeof(WalkLearn) == 88, "copied as r
 
 // what the memo kernels made: entries, key bytes, and whether the keys outgrew the room the caller gave (then there is no memo for this block)
 struct WalkMemoTotals {
-    uint32_t n, overflow;
-    uint64_t bytes;
+    uint32_t n, overflow;       // entries written (candidates), 1: the keys did not fit
+    uint64_t bytes;             // of keys
+    uint32_t live, pad;         // entries that got a slot (hashed and decided)
 };
 struct WalkTotals {
     uint32_t tuples, prefixes, checks, creators;   // creators: envelopes that yield tuples (each yields exactly one creator tuple, its first)
@@ -165,7 +166,8 @@ struct WalkArrays {
     uint32_t* memo_key_off = nullptr;          // entries + 1
     uint8_t* memo_keys = nullptr;
     uint32_t memo_keys_cap = 0;
-    uint8_t* memo_status = nullptr;            // by entry
+    uint8_t* memo_status = nullptr;            // by entry (255: a candidate that was not decided - it has no slot)
+    uint8_t* memo_digests = nullptr;           // 32 bytes by entry
     uint32_t* memo_ent = nullptr;              // by tuple: its entry, ~0 = none
     struct WalkMemoTotals* memo_totals = nullptr;
     const uint8_t* issuer_hashes = nullptr;    // 32 bytes per idemix MSP of idemix_msps: ipk.Hash of its issuer (a pseudonym entry is bound to it)
@@ -201,8 +203,9 @@ hipError_t launch_walk_gate(const WalkArrays& a, hipStream_t st);               
 hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* spans, void* code, void* key, hipStream_t st);
 // the idemix creators among [0, n_creators), counted off: nym_slot[rank] = its row in the nym launch, gather[row] = rank for row < cap
 hipError_t launch_walk_nym_pack(const WalkArrays& a, uint32_t* gather, uint32_t cap, hipStream_t st);
-// the verdict memo of the pass (after the status kernel): entries counted off by ONE workgroup, then a wavefront per tuple writes its key
-hipError_t launch_walk_memo(const WalkArrays& a, hipStream_t st);
+// the verdict memo of the pass: keys, entry indices and offsets as soon as the gates are through; digests, statuses and slots behind the status kernel
+hipError_t launch_walk_memo_early(const WalkArrays& a, hipStream_t st);
+hipError_t launch_walk_memo_late(const WalkArrays& a, hipStream_t st);
 hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st);   // tuple statuses + digest comparisons (one launch)
 // per-transaction flags and everything the host reads, written to host-mapped memory; the last workgroup raises h.flag
 hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStream_t st);
@@ -244,6 +247,7 @@ struct WalkOut {
     uint8_t* memo_keys = nullptr;         // memo_keys_cap bytes (< 2^32)
     size_t memo_keys_cap = 0;
     uint8_t* memo_status = nullptr;       // n_tuples
+    uint8_t* memo_digests = nullptr;      // 32 n_tuples: the digest of entry e (the keys end with the digest's length field)
 };
 struct WalkRequest {
     uint64_t stage_token = 0;             // the block, uploaded with fabgpu_arena_stage
@@ -273,7 +277,8 @@ struct WalkRequest {
     bool keyed_creators = false, keyed_others = false;   // which launch classes ran on registered comb tables
     uint32_t relaunched = 0;              // launches repeated because the prediction "everybody is registered" did not hold
     WalkLearn* learn_out = nullptr;       // host, optional: WALK_LEARN_SLOTS records (tag == 0 or ready == 0: empty)
-    uint32_t memo_n = 0;                  // entries of the memo the device built into WalkOut::memo_* (0: none)
+    uint32_t memo_n = 0;                  // entries the device wrote into WalkOut::memo_* (0: none) ...
+    uint32_t memo_live = 0;               // ... of which so many have a slot (were hashed and decided)
     uint64_t memo_bytes = 0;
     const char* declined_why = "";
     double ms_walk = 0, ms_gate = 0, ms_verify = 0;

@@ -599,23 +599,6 @@ __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i
         }
         a.tuple_status[i] = st;
         a.tuple_hashed[i] = hashed;
-        if (a.memo_ent) {
-            // The memo entry this tuple will get (GPUCSP::SeedMemo's rule): hashed and decided with a status bccsp.Verify decides itself, a
-            // signature of 1 .. 1024 bytes; a pseudonym signature only with the hash of the issuer key it was verified under at hand.
-            // Stored as the length of its framed key (GPUCSP::MemoKeyBytes); walk_memo_scan_kernel turns the lengths into entries.
-            uint32_t klen = 0;
-            int32_t ih = -1;
-            if (key_from_nym && a.issuer_hashes) {
-                const int32_t issuer = a.nym_issuer_out[a.cbase[t.tx]];
-                for (uint32_t m = 0; m < a.n_idemix_msps; m++)
-                    if (a.idemix_msps[m].issuer == issuer) ih = (int32_t)m;
-            }
-            const bool nym_t = gst == GATE_ST_NYM;
-            if (hashed && st <= FABGPU_ST_RANGE && t.sig.len >= 1 && t.sig.len <= 1024 && t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off &&
-                (!nym_t || ih >= 0))
-                klen = 1u + (nym_t ? 32u : 0u) + 64u + 4u + t.sig.len + 4u + 32u;
-            a.memo_ent[i] = klen;
-        }
         if (st != FABGPU_ST_VALID && t.tx < a.n_env)                     // block-level tuples (orderer signatures) do not flag a transaction
             atomicOr(&a.tx_mask[t.tx], st == bccsp::TUPLE_ST_NEEDS_SW ? M_SW : (t.kind == bccsp::TUPLE_CREATOR ? M_BAD_CREATOR : M_BAD_END));
     }
@@ -757,8 +740,30 @@ __global__ void __launch_bounds__(1024) walk_nym_pack_kernel(WalkArrays a, uint3
 
 
 // ---- the block's verdict memo, built where the verdicts are (bccsp_host.h BlockMemo; GPUCSP::SeedMemo is the host's version) -------------
-// Entries counted off: the status kernel left the length of every tuple's framed key (0 = no entry) in memo_ent; ONE workgroup turns the
-// lengths into entry indices and key offsets (the scan of walk_scan_kernel) and says whether the keys fit the room the caller gave.
+// In two halves.  EARLY, beside the verify launches: everything of an entry that is known once the gates are through - which tuples are
+// candidates (submitted to the device, or a pseudonym signature with its issuer's hash at hand; a signature of 1 .. 1024 bytes), their
+// framed keys WITHOUT the digest ([1 | 2 || issuer hash] || X || Y || u32 len || signature || u32 32: GPUCSP::MemoKeyWrite up to the digest),
+// entry indices and offsets - and its copy to the host.  LATE, behind the status kernel: digest, status byte and slot of the candidates that
+// were hashed and decided with a status bccsp.Verify decides itself (GPUCSP::SeedMemo's rule); a candidate that was not simply gets no slot.
+__device__ __forceinline__ int32_t memo_issuer_slot(const WalkArrays& a, const BlockTuple& t) {
+    if (!a.issuer_hashes || !a.nym_issuer_out) return -1;
+    const int32_t issuer = a.nym_issuer_out[a.cbase[t.tx]];
+    int32_t at = -1;
+    for (uint32_t m = 0; m < a.n_idemix_msps; m++)
+        if (issuer >= 0 && a.idemix_msps[m].issuer == issuer) at = (int32_t)m;
+    return at;
+}
+__global__ void __launch_bounds__(256) walk_memo_len_kernel(WalkArrays a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_tuples) return;
+    const uint8_t gst = a.gate_st[i];
+    const BlockTuple t = a.tuples[i];
+    const bool nym = gst == GATE_ST_NYM;
+    const bool cand = (gst == FABGPU_ST_VALID || (nym && memo_issuer_slot(a, t) >= 0)) && t.sig.len >= 1 && t.sig.len <= 1024 &&
+                      t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off;
+    a.memo_ent[i] = cand ? 1u + (nym ? 32u : 0u) + 64u + 4u + t.sig.len + 4u : 0u;
+}
+// key lengths -> entry indices and offsets: ONE workgroup (the scan of walk_scan_kernel); says whether the keys fit the caller's room
 __global__ void __launch_bounds__(1024) walk_memo_scan_kernel(WalkArrays a) {
     __shared__ uint32_t sn[1024];
     __shared__ uint64_t sb[1024];
@@ -805,8 +810,7 @@ __global__ void __launch_bounds__(1024) walk_memo_scan_kernel(WalkArrays a) {
         a.memo_totals->bytes = fits ? sb[1023] : 0u;
     }
 }
-// One wavefront per tuple: its framed key - [1 | 2 || issuer hash] || X || Y || u32 len || signature || u32 32 || digest, exactly
-// GPUCSP::MemoKeyWrite - its status byte, and its place in the slot table (GPUCSP::MemoHash, linear probing, entry index + 1).
+// one wavefront per candidate: its framed key up to the digest
 __global__ void __launch_bounds__(256) walk_memo_write_kernel(WalkArrays a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -816,21 +820,17 @@ __global__ void __launch_bounds__(256) walk_memo_write_kernel(WalkArrays a) {
     const BlockTuple t = a.tuples[i];
     const uint32_t off = a.memo_key_off[e];
     const bool nym = a.gate_st[i] == GATE_ST_NYM;
-    const uint32_t klen = 1u + (nym ? 32u : 0u) + 64u + 4u + t.sig.len + 4u + 32u;
+    const uint32_t klen = 1u + (nym ? 32u : 0u) + 64u + 4u + t.sig.len + 4u;
     if ((uint64_t)off + klen > (uint64_t)a.memo_keys_cap) return;            // (the scan said it fits: defensive)
     uint8_t* k = a.memo_keys + off;
     const uint8_t* sig = a.block + t.sig.off;
-    const uint8_t* dig = a.tuple_digests + 32 * (size_t)i;
     uint32_t pos = 1;
     if (lane == 0) k[0] = nym ? 2 : 1;
     const uint8_t *kx, *ky;
     if (nym) {
         const uint32_t rank = a.cbase[t.tx];
-        const int32_t issuer = a.nym_issuer_out[rank];
-        uint32_t m_at = 0;
-        for (uint32_t m = 0; m < a.n_idemix_msps; m++)
-            if (a.idemix_msps[m].issuer == issuer) m_at = m;
-        if (lane < 32) k[1 + lane] = a.issuer_hashes[32 * (size_t)m_at + lane];
+        const int32_t m_at = memo_issuer_slot(a, t);
+        if (lane < 32) k[1 + lane] = a.issuer_hashes[32 * (size_t)(m_at < 0 ? 0 : m_at) + lane];
         pos = 33;
         kx = a.nym_fields + 32 * (size_t)rank;
         ky = a.nym_fields + 32 * (size_t)a.n_creators + 32 * (size_t)rank;
@@ -846,20 +846,40 @@ __global__ void __launch_bounds__(256) walk_memo_write_kernel(WalkArrays a) {
     for (uint32_t b = lane; b < t.sig.len; b += 64) k[pos + b] = sig[b];
     pos += t.sig.len;
     if (lane < 4) k[pos + lane] = lane == 0 ? 32 : 0;
-    pos += 4;
-    if (lane < 32) k[pos + lane] = dig[lane];
-    if (lane == 0) {
-        a.memo_status[e] = a.tuple_status[i];
-        uint64_t ha = 0, hb = 0;
-        for (int q = 0; q < 8; q++) ha |= (uint64_t)dig[q] << (8 * q);
-        const uint32_t nb = t.sig.len < 8 ? t.sig.len : 8u, s0 = t.sig.len > 8 ? t.sig.len - 8 : 0u;
-        for (uint32_t q = 0; q < nb; q++) hb |= (uint64_t)sig[s0 + q] << (8 * q);
-        uint64_t h = (ha ^ (hb * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
-        h ^= h >> 32;
-        uint32_t at = (uint32_t)h & a.memo_mask;
-        for (uint32_t probe = 0; probe <= a.memo_mask; probe++, at = (at + 1) & a.memo_mask)
-            if (atomicCAS(&a.memo_slots[at], 0u, e + 1) == 0u) break;
+}
+// LATE: one lane per tuple - a candidate that was hashed and decided gets its digest, its status byte and its place in the slot table
+// (GPUCSP::MemoHash, linear probing, entry index + 1); the others get status 255 and no slot.
+__global__ void __launch_bounds__(256) walk_memo_late_kernel(WalkArrays a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    if (i < a.n_tuples) {
+        const uint32_t e = a.memo_ent[i];
+        if (e != 0xFFFFFFFFu) {
+            const uint8_t st = a.tuple_status[i];
+            live = a.tuple_hashed[i] && st <= FABGPU_ST_RANGE;
+            a.memo_status[e] = live ? st : (uint8_t)255;
+            if (live) {
+                const BlockTuple t = a.tuples[i];
+                const uint8_t* sig = a.block + t.sig.off;
+                const uint4* src = reinterpret_cast<const uint4*>(a.tuple_digests + 32 * (size_t)i);
+                uint4* dst = reinterpret_cast<uint4*>(a.memo_digests + 32 * (size_t)e);
+                const uint4 d0 = src[0];
+                dst[0] = d0;
+                dst[1] = src[1];
+                const uint64_t ha = ((uint64_t)d0.y << 32) | d0.x;             // the first eight digest bytes, little-endian
+                uint64_t hb = 0;
+                const uint32_t nb = t.sig.len < 8 ? t.sig.len : 8u, s0 = t.sig.len > 8 ? t.sig.len - 8 : 0u;
+                for (uint32_t q = 0; q < nb; q++) hb |= (uint64_t)sig[s0 + q] << (8 * q);
+                uint64_t h = (ha ^ (hb * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+                h ^= h >> 32;
+                uint32_t at = (uint32_t)h & a.memo_mask;
+                for (uint32_t probe = 0; probe <= a.memo_mask; probe++, at = (at + 1) & a.memo_mask)
+                    if (atomicCAS(&a.memo_slots[at], 0u, e + 1) == 0u) break;
+            }
+        }
     }
+    const uint64_t lv = __ballot(live);
+    if ((threadIdx.x & 63u) == 0 && lv) atomicAdd(&a.memo_totals->live, (uint32_t)__popcll(lv));
 }
 
 hipError_t launch_walk_count(const WalkArrays& a, WalkTotals* host_totals, uint32_t* host_flag, uint32_t seq, hipStream_t st) {
@@ -903,12 +923,20 @@ hipError_t launch_walk_nym_pack(const WalkArrays& a, uint32_t* gather, uint32_t 
     hipLaunchKernelGGL(walk_nym_pack_kernel, dim3(1), dim3(1024), 0, st, a, gather, cap);
     return hipGetLastError();
 }
-hipError_t launch_walk_memo(const WalkArrays& a, hipStream_t st) {
+hipError_t launch_walk_memo_early(const WalkArrays& a, hipStream_t st) {
     if (a.n_tuples == 0 || !a.memo_ent) return hipSuccess;
-    hipLaunchKernelGGL(walk_memo_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(walk_memo_len_kernel, dim3((a.n_tuples + 255) / 256), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(walk_memo_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(walk_memo_write_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_walk_memo_late(const WalkArrays& a, hipStream_t st) {
+    if (a.n_tuples == 0 || !a.memo_ent) return hipSuccess;
+    hipLaunchKernelGGL(walk_memo_late_kernel, dim3((a.n_tuples + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st) {

@@ -140,7 +140,7 @@ struct fabgpu_ctx {
     // the device block pass runs on four streams: walk / gates / endorsements on `stream`, the creators' hashes and launch on
     // stream2, the mid-states on stream3, the TxID / proposal-hash digests on stream4
     hipStream_t stream3 = nullptr, stream4 = nullptr;
-    hipEvent_t ev_w[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_w[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool pred_has_nym = false;       // the previous block had idemix creators: queue the nym launch without waiting for the gates
     uint32_t pred_nym_rows = 0;      // ... and how many: the launch runs over that many packed rows plus a margin
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
@@ -1482,7 +1482,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     const size_t up_bytes = host_counted ? o_up_all : o_up_small, p_first = round_up(o_up_all, 256);
     if ((rc = ctx->walk_pin.ensure(p_first))) return rc;
     // host-mapped results: [0, 64) the totals' flag, [64, 128) the totals, [128, 192) the final flag, [192, 256) the summary; the arrays follow
-    constexpr size_t m_totflag = 0, m_tot = 64, m_finflag = 128, m_sum = 192, m_mtot = 240, m_arrays = 256;   // (the summary is 48 bytes, the memo's totals 16)
+    constexpr size_t m_totflag = 0, m_tot = 64, m_finflag = 128, m_sum = 192, m_mtot = 256, m_arrays = 320;   // (the summary is 48 bytes, the memo's totals 24)
     if ((rc = ctx->walk_map.ensure(m_arrays + sizeof(WalkLearn) * WALK_LEARN_SLOTS + 3 * round_up(ne, 64) + ((size_t)8 << 10)))) return rc;
     if (++ctx->walk_seq == 0) ++ctx->walk_seq;
     const uint32_t seq_tot = ctx->walk_seq;
@@ -1593,12 +1593,12 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_nymga = carve(n_msps ? (size_t)tot.creators * 4 + 256 : 0), o_nymsl = carve(n_msps ? (size_t)tot.creators * 4 : 0),
                  o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0);
     // the verdict memo, if the caller gave room for it (WalkOut::memo_*): built behind the status kernel, copied straight into that room
-    const bool memo = out.memo_slots && out.memo_key_off && out.memo_keys && out.memo_status && out.memo_slot_cap >= 16 &&
+    const bool memo = out.memo_slots && out.memo_key_off && out.memo_keys && out.memo_status && out.memo_digests && out.memo_slot_cap >= 16 &&
                       (out.memo_slot_cap & (out.memo_slot_cap - 1)) == 0 && out.memo_slot_cap >= 2 * (uint64_t)nt && out.memo_keys_cap != 0 &&
                       out.memo_keys_cap < 0xFFFFFFF0ull;
     const size_t o_ment = carve(memo ? (size_t)nt * 4 : 0), o_mslots = carve(memo ? (size_t)out.memo_slot_cap * 4 : 0),
                  o_mkoff = carve(memo ? ((size_t)nt + 1) * 4 : 0), o_mkeys = carve(memo ? out.memo_keys_cap : 0), o_mst = carve(memo ? nt : 0),
-                 o_mtot = carve(memo ? sizeof(WalkMemoTotals) : 0);
+                 o_mtot = carve(memo ? sizeof(WalkMemoTotals) : 0), o_mdig = carve(memo ? (size_t)nt * 32 : 0);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
     a.tuples = (bccsp::BlockTuple*)(dt + o_tup);
@@ -1656,6 +1656,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         a.memo_keys_cap = (uint32_t)out.memo_keys_cap;
         a.memo_status = dt + o_mst;
         a.memo_totals = (WalkMemoTotals*)(dt + o_mtot);
+        a.memo_digests = dt + o_mdig;
         if (n_msps && rq.idemix_issuer_hashes) a.issuer_hashes = de + o_ihash;
     }
     a.dev_status = dt + o_dst;
@@ -1769,6 +1770,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // the emitted prefixes / hash checks are all stream2 and stream3 need: mid-states and the TxID / proposal-hash digests run while
     // the main stream looks identities up and gates signatures
     hipStream_t sc = s2;                                                   // the creators' stream
+    bool memo_early_pending = false;
     err = hipEventRecord(ctx->ev_w[0], st);
     // (The gates are queued right here, ahead of the side streams' work: on a small block the host's calls, not the kernels, set the pace,
     //  and the gate kernel is the main stream's critical path.)
@@ -1791,6 +1793,12 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     } else {
         if (err == hipSuccess) err = launch_walk_gate(a, st);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[5], st);   // "the gates are through" (a nym launch waits for it)
+    }
+    if (err == hipSuccess && memo) {
+        // stream4, behind its digests: the EARLY half of the verdict memo - candidates, keys up to the digest, offsets - and its copy into
+        // the caller's table, all of it beside the verify launches (block_walk_kernels.hip "the block's verdict memo")
+        err = hipEventRecord(ctx->ev_w[7], st);                            // "every gate is through"
+        memo_early_pending = true;
     }
     if (err == hipSuccess && a.split) {
         // stream2: the creators' digests into rows [0, n_creators), so that their launch only has the arithmetic left.  Either they
@@ -1817,6 +1825,13 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipStreamWaitEvent(s4, ctx->ev_w[0], 0);
         if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s4);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
+    }
+    if (err == hipSuccess && memo_early_pending) {
+        err = hipStreamWaitEvent(s4, ctx->ev_w[7], 0);
+        if (err == hipSuccess) err = launch_walk_memo_early(a, s4);
+        if (err == hipSuccess) err = hipMemcpyAsync(out.memo_key_off, dt + o_mkoff, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, s4);
+        if (err == hipSuccess) err = hipMemcpyAsync(out.memo_keys, dt + o_mkeys, out.memo_keys_cap, hipMemcpyDeviceToHost, s4);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[8], s4);
     }
     // The block's idemix creators: ONE nym launch over their rows, packed (walk_nym_pack_kernel: 2 000 idemix creators among 10 000 are
     // 125 wavefronts of the four-lane kernel, not 625 - the ECDSA launches beside it keep their SIMDs), on stream3 behind the mid-states.
@@ -1918,13 +1933,14 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         ho.seq = ctx->walk_seq;
         if (err == hipSuccess && nym_ran) err = hipStreamWaitEvent(st, ctx->ev_w[6], 0);     // the nym kernel's answers
         if (err == hipSuccess && memo) err = hipMemsetAsync(dt + o_mslots, 0, (size_t)out.memo_slot_cap * 4, st);
+        if (err == hipSuccess && memo) err = hipStreamWaitEvent(st, ctx->ev_w[8], 0);        // the early half (long done: it ran beside the verify launches)
+        if (err == hipSuccess && memo) err = hipMemsetAsync(&((WalkMemoTotals*)(dt + o_mtot))->live, 0, 4, st);
         if (err == hipSuccess) err = launch_walk_status_checks(a, nc, st);
         if (memo) {
-            // the memo: entries counted off, keys written, slots filled - and copied into the caller's (pinned) room as it stands
-            if (err == hipSuccess) err = launch_walk_memo(a, st);
+            // the LATE half of the memo: digests, status bytes and slots of the candidates that were hashed and decided
+            if (err == hipSuccess) err = launch_walk_memo_late(a, st);
             if (err == hipSuccess) err = hipMemcpyAsync(out.memo_slots, dt + o_mslots, (size_t)out.memo_slot_cap * 4, hipMemcpyDeviceToHost, st);
-            if (err == hipSuccess) err = hipMemcpyAsync(out.memo_key_off, dt + o_mkoff, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st);
-            if (err == hipSuccess) err = hipMemcpyAsync(out.memo_keys, dt + o_mkeys, out.memo_keys_cap, hipMemcpyDeviceToHost, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(out.memo_digests, dt + o_mdig, (size_t)nt * 32, hipMemcpyDeviceToHost, st);
             if (err == hipSuccess) err = hipMemcpyAsync(out.memo_status, dt + o_mst, nt, hipMemcpyDeviceToHost, st);
         }
         fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
@@ -1939,6 +1955,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (memo) {
             const WalkMemoTotals mt = *(const WalkMemoTotals*)(mh + m_mtot);
             rq.memo_n = mt.overflow ? 0 : mt.n;
+            rq.memo_live = mt.overflow ? 0 : mt.live;
             rq.memo_bytes = mt.overflow ? 0 : mt.bytes;
         }
         return FABGPU_OK;
@@ -2025,14 +2042,20 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes) {
     if (!ctx || bytes == 0) return nullptr;
     DeviceGuard g(ctx->device);
+    static const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (timing) fprintf(stderr, "fabgpu: %.1f MB of pinned memory for a memo table in %.2f ms\n", bytes / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return p;
 }
 void walk_pinned_free(fabgpu_ctx* ctx, void* p) {
     if (!ctx || !p) return;
+    static const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     DeviceGuard g(ctx->device);
     (void)hipHostFree(p);
+    if (timing) fprintf(stderr, "fabgpu: a memo table's pinned memory freed in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
 
 }  // namespace fab
