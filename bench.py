@@ -345,7 +345,7 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
         import threading
 
         def in_flight(n_callers, per_caller, memo=False):
-            copies = [[bytes(bytearray(blk)) for _ in range(max(per_caller, 4))] for _ in range(n_callers)]
+            copies = [[bytes(bytearray(blk)) for _ in range(max(per_caller, 8))] for _ in range(n_callers)]
 
             def caller(t):
                 for k in range(per_caller):
@@ -355,10 +355,10 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
                         assert r["memo_seeded"] == 4 * n_tx
                         fabgpu.memo_evict_block(csp, seq)
             # (untimed rounds first: the first concurrent passes of a configuration grow device buffers and - with memo seeding - create
-            #  the provider's pool of memo tables in pinned memory, up to four of them: three or four passes of 5-10 ms per caller, once
-            #  (tools/gpu_probe_memo_pipeline.py), which would weigh on a 16-block window)
+            #  the provider's memo tables in pinned memory: the first three or four passes of each caller take 5-10 ms, once per
+            #  provider (tools/gpu_probe_memo_pipeline.py prints every pass), which would weigh on a 16-block window)
             def warm_up(t):
-                for k in range(4 if memo else 2):
+                for k in range(8 if memo else 2):
                     fabgpu.preverify_block2(csp, copies[t][k], block_seq=900000 + 10 * t + k, seed_memo=memo, lean=True)
                     fabgpu.memo_evict_block(csp, 900000 + 10 * t + k)
             warm = [threading.Thread(target=warm_up, args=(t,)) for t in range(n_callers)]

@@ -7,6 +7,12 @@ blk = open(os.path.join(ROOT, ".bench_blocks", "friendly_10000.bin"), "rb").read
 csp = fabgpu.GPUCSP(device=0)
 for _ in range(3):
     fabgpu.preverify_block2(csp, blk, lean=True)
+if len(sys.argv) > 3 and sys.argv[3] == "hostfirst":      # as bench.py's legs come: memo tables built on the HOST first (they end up in the free list)
+    os.environ["FABGPU_PASS_STAGE_MIN_BYTES"] = str(1 << 40)
+    for k in range(10):
+        fabgpu.preverify_block2(csp, bytes(bytearray(blk)), block_seq=50 + k, seed_memo=True, lean=True)
+        fabgpu.memo_evict_block(csp, 50 + k)
+    os.environ.pop("FABGPU_PASS_STAGE_MIN_BYTES")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 memo = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
 copies = [[bytes(bytearray(blk)) for _ in range(N)] for _ in range(2)]
