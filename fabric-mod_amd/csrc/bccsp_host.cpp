@@ -210,6 +210,7 @@ GPUCSP::~GPUCSP() {
 }
 GPUCSP::BlockMemo::~BlockMemo() {
     if (pin) walk_pinned_free(pin_ctx, pin);
+    if (pin_keys) walk_pinned_free(pin_ctx, pin_keys);
 }
 
 // bccsp/sw/keyimport.go:103-112 (ECDSAGoPublicKeyImportOpts) with the curve check x509 parsing implies
@@ -1281,6 +1282,19 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
             }
         }
         return true;
+    };
+    rq.memo_grow = [](void* user, size_t bytes) -> uint8_t* {
+        Sizer& z = *(Sizer*)user;
+        if (!z.bm || bytes >= 0xFFFFFFF0ull) return nullptr;
+        if (z.bm->pin_keys_cap < bytes) {
+            if (z.bm->pin_keys) walk_pinned_free(z.bm->pin_ctx, z.bm->pin_keys);
+            z.bm->pin_keys = walk_pinned_alloc(z.ctx, bytes + bytes / 4);
+            z.bm->pin_ctx = z.ctx;
+            z.bm->pin_keys_cap = z.bm->pin_keys ? bytes + bytes / 4 : 0;
+        }
+        if (!z.bm->pin_keys) return nullptr;
+        z.bm->keys_v = (const uint8_t*)z.bm->pin_keys;
+        return (uint8_t*)z.bm->pin_keys;
     };
     ps.learn.resize(WALK_LEARN_SLOTS);
     rq.learn_out = ps.learn.data();

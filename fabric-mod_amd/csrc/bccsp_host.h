@@ -269,6 +269,8 @@ class GPUCSP {
         uint32_t n_entries = 0;
         void* pin = nullptr;
         size_t pin_cap = 0;
+        void* pin_keys = nullptr;                         // room of its own for the keys of a block whose signatures are far longer than usual
+        size_t pin_keys_cap = 0;
         fabgpu_ctx* pin_ctx = nullptr;
         ~BlockMemo();
     };

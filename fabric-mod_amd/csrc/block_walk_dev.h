@@ -244,7 +244,7 @@ struct WalkOut {
     uint32_t* memo_slots = nullptr;       // memo_slot_cap entries, a power of two >= 2 n_tuples
     uint32_t memo_slot_cap = 0;
     uint32_t* memo_key_off = nullptr;     // n_tuples + 1
-    uint8_t* memo_keys = nullptr;         // memo_keys_cap bytes (< 2^32)
+    uint8_t* memo_keys = nullptr;         // memo_keys_cap bytes (< 2^32): copied ahead; keys that need more arrive through WalkRequest::memo_grow
     size_t memo_keys_cap = 0;
     uint8_t* memo_status = nullptr;       // n_tuples
     uint8_t* memo_digests = nullptr;      // 32 n_tuples: the digest of entry e (the keys end with the digest's length field)
@@ -272,6 +272,8 @@ struct WalkRequest {
     bool walk_only = false;               // stop after the walk (tests: the device walker against the host walker)
     void* user = nullptr;
     bool (*sizes)(void* user, const WalkCounts& c, WalkOut& out) = nullptr;   // false: the caller has no room (FABGPU_ETOOBIG)
+    // the memo's keys need `bytes` > WalkOut::memo_keys_cap: pinned room for all of them (they are copied there whole), or null: no memo
+    uint8_t* (*memo_grow)(void* user, size_t bytes) = nullptr;
     // out
     WalkSummary summary = {};
     bool keyed_creators = false, keyed_others = false;   // which launch classes ran on registered comb tables

@@ -1596,8 +1596,11 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     const bool memo = out.memo_slots && out.memo_key_off && out.memo_keys && out.memo_status && out.memo_digests && out.memo_slot_cap >= 16 &&
                       (out.memo_slot_cap & (out.memo_slot_cap - 1)) == 0 && out.memo_slot_cap >= 2 * (uint64_t)nt && out.memo_keys_cap != 0 &&
                       out.memo_keys_cap < 0xFFFFFFF0ull;
+    // (on the device the keys have room for the longest signatures the memo takes - 1 024 bytes each; what is copied ahead is the room
+    //  the caller gave, sized for ordinary signatures; a block that needs more gets the rest through WalkRequest::memo_grow at the end)
+    const size_t dev_keys_cap = memo ? (size_t)std::min<uint64_t>(0xFFFFFFE0ull, std::max<uint64_t>(out.memo_keys_cap, (uint64_t)nt * (141 + 1024) + 256)) : 0;
     const size_t o_ment = carve(memo ? (size_t)nt * 4 : 0), o_mslots = carve(memo ? (size_t)out.memo_slot_cap * 4 : 0),
-                 o_mkoff = carve(memo ? ((size_t)nt + 1) * 4 : 0), o_mkeys = carve(memo ? out.memo_keys_cap : 0), o_mst = carve(memo ? nt : 0),
+                 o_mkoff = carve(memo ? ((size_t)nt + 1) * 4 : 0), o_mkeys = carve(memo ? dev_keys_cap : 0), o_mst = carve(memo ? nt : 0),
                  o_mtot = carve(memo ? sizeof(WalkMemoTotals) : 0), o_mdig = carve(memo ? (size_t)nt * 32 : 0);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
@@ -1653,7 +1656,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         a.memo_mask = out.memo_slot_cap - 1;
         a.memo_key_off = (uint32_t*)(dt + o_mkoff);
         a.memo_keys = dt + o_mkeys;
-        a.memo_keys_cap = (uint32_t)out.memo_keys_cap;
+        a.memo_keys_cap = (uint32_t)dev_keys_cap;
         a.memo_status = dt + o_mst;
         a.memo_totals = (WalkMemoTotals*)(dt + o_mtot);
         a.memo_digests = dt + o_mdig;
@@ -1933,7 +1936,6 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         ho.seq = ctx->walk_seq;
         if (err == hipSuccess && nym_ran) err = hipStreamWaitEvent(st, ctx->ev_w[6], 0);     // the nym kernel's answers
         if (err == hipSuccess && memo) err = hipMemsetAsync(dt + o_mslots, 0, (size_t)out.memo_slot_cap * 4, st);
-        if (err == hipSuccess && memo) err = hipStreamWaitEvent(st, ctx->ev_w[8], 0);        // the early half (long done: it ran beside the verify launches)
         if (err == hipSuccess && memo) err = hipMemsetAsync(&((WalkMemoTotals*)(dt + o_mtot))->live, 0, 4, st);
         if (err == hipSuccess) err = launch_walk_status_checks(a, nc, st);
         if (memo) {
@@ -1947,6 +1949,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
         fetch(out.tuple_qxy, p_qxy, dt + o_tqxy, (size_t)nt * 64);
         if (has_nym_rows) fetch(out.nym_issuer, p_nymi, dt + o_nymio, (size_t)tot.creators * 4);
+        if (err == hipSuccess && memo) err = hipStreamWaitEvent(st, ctx->ev_w[8], 0);        // the memo's early half (long done: it ran beside the verify launches)
         if (err == hipSuccess) err = launch_walk_finish(a, ho, st);
         if (err != hipSuccess) return hip_to_rc(err);
         int r2 = wait_host_flag((const uint32_t*)(mh + m_finflag), ho.seq, st);
@@ -1957,6 +1960,12 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             rq.memo_n = mt.overflow ? 0 : mt.n;
             rq.memo_live = mt.overflow ? 0 : mt.live;
             rq.memo_bytes = mt.overflow ? 0 : mt.bytes;
+            if (rq.memo_n && mt.bytes > out.memo_keys_cap) {
+                // more key bytes than the room that was copied ahead (signatures far longer than an ECDSA signature's 72 bytes): the caller
+                // makes room, the keys are copied again - whole - and the pass answers a little later; no room: no memo for this block
+                uint8_t* big = rq.memo_grow ? rq.memo_grow(rq.user, (size_t)mt.bytes) : nullptr;
+                if (!big || hipMemcpy(big, dt + o_mkeys, (size_t)mt.bytes, hipMemcpyDeviceToHost) != hipSuccess) rq.memo_n = rq.memo_live = 0;
+            }
         }
         return FABGPU_OK;
     };

@@ -578,6 +578,39 @@ def test_memo_built_by_the_device_equals_the_memo_seeded_on_the_host(csp, monkey
 
 
 @pytest.mark.gpu
+def test_memo_of_a_block_whose_signatures_are_far_longer_than_usual(csp, monkeypatch):
+    """The memo's keys travel to the host ahead of the verdicts into room sized for ordinary signatures (96 bytes each on average).  A
+    block whose every signature drags 600 bytes behind its SEQUENCE - accepted by the reference, still VALID (bccsp/utils/ecdsa.go:43-67:
+    asn1.Unmarshal's rest is ignored) - needs four times that: the pass asks for more room at the end and copies the keys again, whole.
+    Nobody can switch a block's memo off by padding signatures (up to the 1 024 bytes the memo takes at all; beyond: bccsp/sw decides)."""
+    import blockgen
+    fx = blockgen.fixture_signers()
+    rng = np.random.default_rng(41)
+    pad = lambda t, j, sig: sig + b"\x05\x82\x02\x54" + bytes(596)    # noqa: E731   (every creator and endorsement signature)
+    envs = [blockgen.endorser_tx(t, rng, fx[4 + t % 2], [fx[0], fx[1], fx[2]], blockgen.make_signer(100 + t), craft=pad) for t in range(48)]
+    envs[7] = blockgen.endorser_tx(7, rng, fx[4], [fx[0], fx[1], fx[2]], blockgen.make_signer(999),
+                                   craft=lambda t, j, sig: sig + bytes(1100) if j == 0 else pad(t, j, sig))   # one beyond 1 024 bytes: no entry
+    blk = bb.block(1, envs)
+    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    seeded = []
+    for k, mode in enumerate(("1", "0")):
+        monkeypatch.setenv("FABGPU_PASS_DEVICE_MEMO", mode)
+        out = fabgpu.preverify_block2(csp, blk, block_seq=300 + k, seed_memo=True)
+        assert (out["tx_flags"] == 0).all() and (out["tuple_status"] == 0).all()
+        hits = 0
+        for i in range(len(out["tuple_status"])):
+            sp = [int(x) for x in out["tuple_spans"][i]]
+            sig, q = out["arena"][sp[6]:sp[6] + sp[7]], bytes(out["tuple_qxy"][i])
+            got = fabgpu.memo_lookup(csp, q[:32], q[32:], sig, bytes(out["tuple_digest"][i])) if len(sig) <= 1024 else None
+            assert got == (0 if len(sig) <= 1024 else None)
+            hits += got is not None
+        assert hits == out["memo_seeded"] == 4 * 48 - 1
+        seeded.append(out["memo_seeded"])
+        fabgpu.memo_evict_block(csp, 300 + k)
+    assert seeded[0] == seeded[1]
+
+
+@pytest.mark.gpu
 def test_device_route_serves_what_it_used_to_decline(csp, monkeypatch):
     """Identities nobody has met (the device decodes their certificates itself), garbage DER, a provider that knows nobody at all:
     none of it takes a block to the host walk any more, and the answers are the host route's - which learns nothing the device route
