@@ -505,7 +505,7 @@ void GPUCSP::CoalescerStats(uint64_t* calls, uint64_t* launches, uint64_t* large
 void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len) const {
 
     // With the walk on the device every block is staged ahead - the device route answers a 5-transaction block in 0.63 ms against
-    // 0.70 ms on the host walk, a 1 000-transaction block in 0.75 against 1.4 (tools/gpu_dw_tiny.sh, gpu_dw_small.sh).  Without it
+    // 0.70 ms on the host walk, a 1 000-transaction block in 0.75 against 1.4 (round-2 probe gpu_dw_tiny.sh, since removed, gpu_dw_small.sh).  Without it
     // (FABGPU_PASS_DEVICE_WALK=0) small blocks ride with the submission through pinned staging, as before.
     size_t min_bytes = DeviceWalkEnabled() ? 1 : (size_t)4 << 20;
     if (const char* e = getenv("FABGPU_PASS_STAGE_MIN_BYTES")) min_bytes = (size_t)strtoull(e, nullptr, 10);   // tests choose the route with it

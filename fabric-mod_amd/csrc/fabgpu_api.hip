@@ -1638,7 +1638,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                (uint64_t)2 * tot.creators + (nt - tot.creators) <= 65536u) ? 1u : 0u;
     // Smaller blocks split too - both launches with two lanes per signature, sharing the chip: what counts there is that the creators'
     // 40-block hashes start behind the emit kernel instead of inside the one fused launch (300 tx: 0.92 -> 0.82 ms, 1 000 tx:
-    // 1.09 -> 0.99 ms; tools/gpu_dw_small.sh)
+    // 1.09 -> 0.99 ms; round-2 probe gpu_dw_small.sh, since removed)
     bool both_pair = false;
     if (!a.split && ctx->allow_pair && tot.creators != 0 && nt > tot.creators && (uint64_t)2 * nt <= 65536u) {
         a.split = 1;
@@ -1817,7 +1817,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (err == hipSuccess && np) {
         // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them), on CUs of their own: 40
         // workgroups that would otherwise share SIMDs with the 40 000 short-lived wavefronts of the gate kernel and take 4x as long,
-        // with the endorsements' launch waiting for them (measured, tools/gpu_dw_sched.sh: device phase 1.04 -> 0.90 ms)
+        // with the endorsements' launch waiting for them (measured, round-2 probe gpu_dw_sched.sh, since removed: device phase 1.04 -> 0.90 ms)
         ShaPrefixArgs pm = pa;
         pm.lds_reserve = 84u << 10;
         err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
