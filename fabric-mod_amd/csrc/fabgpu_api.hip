@@ -187,12 +187,16 @@ struct fabgpu_ctx {
     void release_qws(size_t idx, hipStream_t st) {
         std::lock_guard<std::mutex> lk(qmu);
         QWs& w = qws[idx];
-        // if the record fails the workspace stays reserved forever (never reused): a leak, not a shared table
         if (hipEventRecord(w.done, st) == hipSuccess) {
             w.armed = true;
             w.reserved = false;
             w.last = st;
+        } else if (hipStreamSynchronize(st) == hipSuccess) {
+            // no event to watch: wait the launch out, then the workspace is simply free again (a flapping device must not eat one per failure)
+            w.armed = false;
+            w.reserved = false;
         }
+        // (neither worked: the workspace stays reserved - never shared with a launch that may still be reading it)
     }
 };
 
