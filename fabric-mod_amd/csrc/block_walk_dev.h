@@ -159,6 +159,7 @@ struct WalkArrays {
     const uint8_t* dev_status = nullptr;       // by row
     const uint8_t* row_digests = nullptr;      // by row (null: not wanted)
     uint8_t* tuple_digests = nullptr;          // by tuple
+    uint32_t* summary_parts = nullptr;         // ceil(n_tuples / 256) rows of WalkSummary's words: the status kernel's workgroups, summed by the finish kernel
     // The block's verdict memo, built on the device (walk_memo_*_kernel) in the layout of bccsp_host.h's BlockMemo: framed keys back to
     // back, their offsets, a status byte per entry and an open-addressed slot table (entry index + 1; the slot hash is GPUCSP::MemoHash).
     uint32_t* memo_slots = nullptr;

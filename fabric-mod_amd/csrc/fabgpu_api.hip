@@ -1595,7 +1595,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_nymsp = carve(n_msps ? (size_t)tot.creators * 8 : 0), o_nymio = carve(n_msps ? (size_t)tot.creators * 4 : 0),
                  o_nymb = carve(n_msps ? ((size_t)tot.creators + 63) / 64 * 8 + 8 : 0), o_nymst = carve(n_msps ? (size_t)tot.creators + 64 : 0),
                  o_nymga = carve(n_msps ? (size_t)tot.creators * 4 + 256 : 0), o_nymsl = carve(n_msps ? (size_t)tot.creators * 4 : 0),
-                 o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0);
+                 o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0), o_sparts = carve(((size_t)nt + 255) / 256 * sizeof(WalkSummary));
     // the verdict memo, if the caller gave room for it (WalkOut::memo_*): built behind the status kernel, copied straight into that room
     const bool memo = out.memo_slots && out.memo_key_off && out.memo_keys && out.memo_status && out.memo_digests && out.memo_slot_cap >= 16 &&
                       (out.memo_slot_cap & (out.memo_slot_cap - 1)) == 0 && out.memo_slot_cap >= 2 * (uint64_t)nt && out.memo_keys_cap != 0 &&
@@ -1654,6 +1654,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.row_digests = (out.tuple_digest || memo) ? dt + o_dig : nullptr;    // (the memo's keys hold the digests)
     a.tuple_digests = dt + o_tdig;
     a.tuple_qxy = out.tuple_qxy ? dt + o_tqxy : nullptr;
+    a.summary_parts = (uint32_t*)(dt + o_sparts);
     if (memo) {
         a.memo_ent = (uint32_t*)(dt + o_ment);
         a.memo_slots = (uint32_t*)(dt + o_mslots);
