@@ -18,6 +18,35 @@ using namespace fab::bccsp;
 
 struct fabgpu_csp {
     std::unique_ptr<GPUCSP> csp;
+    // An upload whose pass ended with FABGPU_ETOOBIG (the caller's arrays were too small): kept for the retry - the same buffer, length
+    // and block_seq - so that making room costs the caller no second upload.  One slot; a retry that never comes is dropped by the next
+    // pass that finds it older than a second (its device counts as busy until then: GPUCSP::RouteBlock).
+    std::mutex orphan_mu;
+    std::unique_ptr<GPUCSP::BlockUpload> orphan;
+    std::chrono::steady_clock::time_point orphan_at;
+    std::unique_ptr<GPUCSP::BlockUpload> upload_for(const uint8_t* block, size_t len, uint64_t seq) {
+        std::unique_ptr<GPUCSP::BlockUpload> up, stale;
+        {
+            std::lock_guard<std::mutex> lk(orphan_mu);
+            if (orphan && orphan->block == block && orphan->len == len && orphan->seq == seq) up = std::move(orphan);
+            else if (orphan && std::chrono::steady_clock::now() - orphan_at > std::chrono::seconds(1)) stale = std::move(orphan);
+        }
+        stale.reset();                                       // (joins its thread: outside the lock)
+        if (!up) {
+            up.reset(new GPUCSP::BlockUpload);
+            csp->StartBlockUpload(*up, block, len, seq);     // the block travels while it is walked
+        }
+        return up;
+    }
+    void park(std::unique_ptr<GPUCSP::BlockUpload> up) {
+        std::unique_ptr<GPUCSP::BlockUpload> old;
+        {
+            std::lock_guard<std::mutex> lk(orphan_mu);
+            old = std::move(orphan);
+            orphan = std::move(up);
+            orphan_at = std::chrono::steady_clock::now();
+        }
+    }
     // which way the block passes went (fabgpu_csp_pass_routes)
     std::mutex route_mu;
     uint64_t device_walks = 0, host_walks = 0;
@@ -57,8 +86,65 @@ int fabgpu_csp_new(const fabgpu_cfg* cfg, fabgpu_csp** out, char* err, size_t er
     *out = h;
     return FABGPU_OK;
 }
-void fabgpu_csp_free(fabgpu_csp* csp) { delete csp; }
+// One provider over several devices: what bccsp/factory builds from the `GPU:` section (go/bccsp/factory/gpufactory.go GPUOpts).
+int fabgpu_csp_new2(const fabgpu_csp_opts* o, fabgpu_csp** out, char* err, size_t errcap) {
+    if (!out) return FABGPU_EINVAL;
+    *out = nullptr;
+    ProviderOptions po;
+    if (o) {
+        if (o->size < sizeof(uint32_t) * 2 || o->n_devices < 0 || o->n_devices > kMaxProviderDevices) return FABGPU_EINVAL;
+        fabgpu_csp_opts v;
+        memset(&v, 0, sizeof(v));                                      // (0 = the default of every switch)
+        memcpy(&v, o, o->size < sizeof(v) ? o->size : sizeof(v));     // (a caller built against an older, shorter struct)
+        for (int i = 0; i < v.n_devices; i++) po.devices.push_back(v.devices ? v.devices[i] : i);
+        po.ctx_flags = v.ctx_flags;
+        po.concurrent_passes = v.concurrent_passes;
+        po.expect_block_bytes = v.expect_block_bytes;
+        po.expect_tuples = v.expect_tuples;
+        po.pass_stage_min_bytes = v.pass_stage_min_bytes;
+        po.pass_device_walk = v.pass_device_walk;
+        po.pass_device_memo = v.pass_device_memo;
+        po.pass_host_counts = v.pass_host_counts;
+        po.pass_timing = v.pass_timing;
+    }
+    fabgpu_csp* h = new fabgpu_csp();
+    Error e = GPUCSP::New(po, h->csp);
+    if (!e.ok()) {
+        put_err(err, errcap, e.msg);
+        delete h;
+        return FABGPU_ENODEV;
+    }
+    put_err(err, errcap, "");
+    *out = h;
+    return FABGPU_OK;
+}
+void fabgpu_csp_free(fabgpu_csp* csp) {
+    if (csp) csp->orphan.reset();                            // (an upload refers to the provider: it goes first)
+    delete csp;
+}
 fabgpu_ctx* fabgpu_csp_ctx(fabgpu_csp* csp) { return csp ? csp->csp->ctx() : nullptr; }
+int fabgpu_csp_device_count(fabgpu_csp* csp) { return csp ? csp->csp->n_devices() : FABGPU_EINVAL; }
+fabgpu_ctx* fabgpu_csp_ctx_of(fabgpu_csp* csp, int d) { return csp && d >= 0 && d < csp->csp->n_devices() ? csp->csp->ctx_of(d) : nullptr; }
+int fabgpu_csp_passes_per_device(fabgpu_csp* csp, uint64_t* passes, int cap) {
+    if (!csp || !passes || cap < csp->csp->n_devices()) return FABGPU_EINVAL;
+    csp->csp->PassesPerDevice(passes);
+    return csp->csp->n_devices();
+}
+int fabgpu_csp_route_block(fabgpu_csp* csp, uint64_t block_seq) { return csp ? csp->csp->RouteBlock(block_seq) : FABGPU_EINVAL; }
+int fabgpu_csp_set_option(fabgpu_csp* csp, const char* name, int64_t value, int64_t* previous) {
+    if (!csp || !name) return FABGPU_EINVAL;
+    const int64_t prev = csp->csp->SetOption(name, value);
+    if (prev == INT64_MIN) return FABGPU_EINVAL;
+    if (previous) *previous = prev;
+    return FABGPU_OK;
+}
+int fabgpu_csp_get_option(fabgpu_csp* csp, const char* name, int64_t* value) {
+    if (!csp || !name || !value) return FABGPU_EINVAL;
+    const int64_t v = csp->csp->GetOption(name);
+    if (v == INT64_MIN) return FABGPU_EINVAL;
+    *value = v;
+    return FABGPU_OK;
+}
 
 int fabgpu_csp_key_import(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, int* on_curve, char* err, size_t errcap) {
     if (!csp) return FABGPU_EINVAL;
@@ -188,25 +274,28 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
                                uint32_t cap_tx, uint32_t* n_tuples, uint32_t* tuple_tx, uint8_t* tuple_kind, uint8_t* tuple_status,
                                uint32_t cap_tuples) {
     if (!csp || !block || !n_tx || !n_tuples) return FABGPU_EINVAL;
-    const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;          // stage breakdown on stderr (tools/bench_block.py --timing)
+    const bool timing = csp->csp->GetOption("pass_timing") > 0;           // stage breakdown on stderr (tools/bench_block.py --timing)
     auto t0 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
-    GPUCSP::BlockUpload up;
-    csp->csp->StartBlockUpload(up, block, len);            // the block travels while it is walked
+    std::unique_ptr<GPUCSP::BlockUpload> up_p = csp->upload_for(block, len, 0);   // the block travels while it is walked
+    GPUCSP::BlockUpload& up = *up_p;
+    const bool per_tuple = tuple_tx != nullptr || tuple_kind != nullptr || tuple_status != nullptr;
     static thread_local ParsedBlock pb;                     // storage reused from block to block (a few MB: no page faults per block)
     static thread_local BlockVerdicts v;                    // answer arrays keep their capacity from block to block
     bool done = false;
     {   // the walk on the device (block_walk_dev.h); a block it declines takes the host walk below
         const char* why = "";
         uint32_t ntup = 0;
-        const int r = csp->csp->PreVerifyBlockOnDevice(block, len, pb, v, up, PassOptions(), tuple_tx != nullptr || tuple_kind != nullptr ? GPUCSP::WANT_TUPLES : 0u, cap_tx, cap_tuples,
-                                                       &ntup, &why);
-        csp->note_route(r == 0, why);
+        // (room for per-tuple answers only matters to a caller that asked for some)
+        const int r = csp->csp->PreVerifyBlockOnDevice(block, len, pb, v, up, PassOptions(), tuple_tx != nullptr || tuple_kind != nullptr ? GPUCSP::WANT_TUPLES : 0u, cap_tx,
+                                                       per_tuple ? cap_tuples : 0xFFFFFFFFu, &ntup, &why);
+        if (r != FABGPU_ETOOBIG) csp->note_route(r == 0, why);
         if (r == FABGPU_ETOOBIG) {
             *n_tx = pb.n_tx;
             *n_tuples = ntup;
+            csp->park(std::move(up_p));                      // the retry finds its upload again
             return FABGPU_ETOOBIG;
         }
         if (r < 0) return r == FABGPU_EINVAL || r == FABGPU_ENOMEM ? r : FABGPU_ELAUNCH;
@@ -224,7 +313,10 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
         auto t1 = std::chrono::steady_clock::now();
         *n_tx = pb.n_tx;
         *n_tuples = (uint32_t)pb.tuples.size();
-        if (pb.n_tx > cap_tx || pb.tuples.size() > cap_tuples) return FABGPU_ETOOBIG;   // counts are set: retry with room (nothing was launched)
+        if (pb.n_tx > cap_tx || (per_tuple && pb.tuples.size() > cap_tuples)) {          // counts are set: retry with room (nothing was launched)
+            csp->park(std::move(up_p));
+            return FABGPU_ETOOBIG;
+        }
         Error e = csp->csp->PreVerifyParsed(block, pb, v, &up);
         if (timing) {
             auto t2 = std::chrono::steady_clock::now();
@@ -246,8 +338,12 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     if (!csp || !ps || !ps->block) return FABGPU_EINVAL;
     if (ps->flags & ~(uint32_t)(FABGPU_PASS_SEED_MEMO | FABGPU_PASS_NO_BLOCK_SIGS)) return FABGPU_EINVAL;
     auto t0 = std::chrono::steady_clock::now();
-    GPUCSP::BlockUpload up;
-    csp->csp->StartBlockUpload(up, ps->block, ps->len);
+    const bool timing = csp->csp->GetOption("pass_timing") > 0;
+    std::unique_ptr<GPUCSP::BlockUpload> up_p = csp->upload_for(ps->block, ps->len, ps->block_seq);
+    GPUCSP::BlockUpload& up = *up_p;
+    // room for per-tuple answers only matters to a caller that asked for some (the Go binding asks for flags alone)
+    const bool per_tuple = ps->tuple_tx || ps->tuple_kind || ps->tuple_status || ps->tuple_spans || ps->tuple_digest || ps->tuple_hashed || ps->tuple_qxy;
+    const uint32_t cap_tuples = per_tuple ? ps->cap_tuples : 0xFFFFFFFFu;
     static thread_local ParsedBlock pb;
     static thread_local BlockVerdicts v;                    // answer arrays keep their capacity from block to block
     PassOptions opt;
@@ -264,20 +360,23 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
         const char* why = "";
         uint32_t ntup = 0;
         const unsigned want = (ps->tuple_tx || ps->tuple_kind || ps->tuple_spans ? GPUCSP::WANT_TUPLES : 0u) | (ps->tuple_qxy ? GPUCSP::WANT_QXY : 0u);
-        const int r = csp->csp->PreVerifyBlockOnDevice(ps->block, ps->len, pb, v, up, opt, want, ps->cap_tx, ps->cap_tuples, &ntup, &why);
-        csp->note_route(r == 0, why);
+        const int r = csp->csp->PreVerifyBlockOnDevice(ps->block, ps->len, pb, v, up, opt, want, ps->cap_tx, cap_tuples, &ntup, &why);
+        if (r != FABGPU_ETOOBIG) csp->note_route(r == 0, why);
         if (r == 0 || r == FABGPU_ETOOBIG) {
             ps->n_tx = pb.n_tx;
-            ps->n_tuples = r == 0 ? (uint32_t)v.tuple_status.size() : (ntup ? ntup : ps->cap_tuples);   // (0: only the tail was too big)
+            ps->n_tuples = r == 0 ? (uint32_t)v.tuple_status.size() : (ntup ? ntup : ps->cap_tuples);   // (0: not counted yet - the transactions or the tail did not fit)
             ps->n_block_sigs = pb.n_block_sigs;
             ps->tail_base = pb.tail_base;
             ps->tail_len = (uint32_t)pb.tail.size();
             ps->block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
         }
-        if (r == FABGPU_ETOOBIG) return FABGPU_ETOOBIG;
+        if (r == FABGPU_ETOOBIG) {
+            csp->park(std::move(up_p));                      // the retry - same buffer, length and block_seq - finds its upload again
+            return FABGPU_ETOOBIG;
+        }
         if (r < 0) return r == FABGPU_EINVAL || r == FABGPU_ENOMEM ? r : FABGPU_ELAUNCH;
         done = r == 0;
-        if (getenv("FABGPU_PASS_TIMING")) {
+        if (timing) {
             if (done)
                 fprintf(stderr, "fabgpu pass2 (device walk): total %.2f ms (outline + identity table %.2f, wait for upload %.2f, device %.2f, memo %.2f)\n",
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), v.ms_gates, v.ms_upload_wait, v.ms_device, v.ms_memo);
@@ -293,9 +392,12 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
         ps->tail_base = pb.tail_base;
         ps->tail_len = (uint32_t)pb.tail.size();
         ps->block_sigs_understood = pb.block_sigs_understood ? 1 : 0;
-        if (pb.n_tx > ps->cap_tx || pb.tuples.size() > ps->cap_tuples || (ps->tail && pb.tail.size() > ps->tail_cap)) return FABGPU_ETOOBIG;
+        if (pb.n_tx > ps->cap_tx || pb.tuples.size() > cap_tuples || (ps->tail && pb.tail.size() > ps->tail_cap)) {
+            csp->park(std::move(up_p));
+            return FABGPU_ETOOBIG;
+        }
         Error e = csp->csp->PreVerifyParsed(ps->block, pb, v, &up, opt);
-        if (getenv("FABGPU_PASS_TIMING"))
+        if (timing)
             fprintf(stderr, "fabgpu pass2: gates %.2f ms, wait for upload %.2f, device call %.2f, idemix creators %.2f, memo %.2f\n", v.ms_gates, v.ms_upload_wait,
                     v.ms_device, v.ms_nym, v.ms_memo);
         if (!e.ok()) return FABGPU_ELAUNCH;
@@ -691,11 +793,10 @@ int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uin
 
 int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap) {
     if (!csp || !issuer_id) return FABGPU_EINVAL;
-    IdemixCSP ic(csp->csp->ctx());
-    IdemixIssuerPublicKey k;
-    Error e = ic.IssuerKeyImport(ipk_raw, len, k);
-    put_err(err, errcap, e.ok() ? "" : e.msg);
-    *issuer_id = e.ok() ? k.issuer_id : -1;
+    // (every device of the provider gets the issuer's tables, under one id)
+    std::string msg;
+    *issuer_id = csp->csp->ImportIdemixIssuer(ipk_raw, len, &msg);
+    put_err(err, errcap, msg);
     return FABGPU_OK;
 }
 
@@ -706,7 +807,7 @@ int fabgpu_csp_idemix_nym_verify_batch(fabgpu_csp* csp, int64_t issuer_id, size_
                                        const uint8_t* sig_arena, const uint32_t* sig_off, const uint8_t* msg_arena, const uint32_t* msg_off,
                                        uint8_t* valid, uint8_t* flags, char* errs, size_t errstride) {
     if (!csp || (n && (!nym_off || !sig_off || !msg_off || !valid || !flags || !errs || !errstride))) return FABGPU_EINVAL;
-    IdemixCSP ic(csp->csp->ctx());
+    IdemixCSP ic(csp->csp->flat_ctx());
     IdemixIssuerPublicKey ipk;
     ipk.issuer_id = issuer_id;
     std::vector<NymPublicKey> keys(n);

@@ -113,10 +113,44 @@ struct PassOptions {
     size_t tail_cap = (size_t)-1;         // room the caller has for the block-signature tail (device route: checked before anything is launched)
 };
 
+// What the `GPU:` section of the BCCSP configuration carries (go/bccsp/factory/gpufactory.go GPUOpts -> include/fabgpu_bccsp.h
+// fabgpu_csp_opts; pattern: bccsp/pkcs11/conf.go:70-84).  The reference has ONE process-global BCCSP (bccsp/factory/factory.go:41-55,
+// handed to every channel's validator at core/peer/peer.go:337-355), so one provider owns every device of the node.
+struct ProviderOptions {
+    std::vector<int32_t> devices;      // HIP ordinals, one device context each; an ordinal may repeat (several contexts on one GPU).
+                                       // empty: every visible device
+    uint32_t ctx_flags = 0;            // FABGPU_FLAG_* for every context
+    uint32_t concurrent_passes = 0;    // per device: what that many overlapping block passes need (staging slots, pinned memo tables,
+                                       // per-pass scratch) is allocated when the provider is made; 0 = when passes first overlap
+    size_t expect_block_bytes = 0;     // sizes the pre-allocation (0: 64 MiB)
+    uint32_t expect_tuples = 0;        // (0: 65 536)
+    // switches that used to be environment variables.  0 = the default, > 0 on, < 0 off - a zeroed struct is all defaults.
+    int64_t pass_stage_min_bytes = 0;  // > 0: blocks of at least this many bytes are uploaded ahead of the pass (default: every block, with the device walk)
+    int pass_device_walk = 0;          // < 0: every block takes the host walk (default on)
+    int pass_device_memo = 0;          // < 0: the verdict memo is seeded on the host (SeedMemo) also on the device route (default on)
+    int pass_host_counts = 0;          // > 0: count the envelopes' tuples on the host while the block travels (default off)
+    int pass_skip_hash_checks = 0;     // > 0: no TxID / proposal-hash digests (A/B timing only; default off)
+    int pass_timing = 0;               // > 0: stage breakdown of every pass on stderr (default off)
+};
+constexpr int kMaxProviderDevices = 64;   // contexts per provider (8 GPUs x up to 8 contexts each)
+
 class GPUCSP {
    public:
-    static Error New(const fabgpu_cfg* cfg, std::unique_ptr<GPUCSP>& out);
+    static Error New(const fabgpu_cfg* cfg, std::unique_ptr<GPUCSP>& out);              // one context on cfg->device
+    static Error New(const ProviderOptions& opts, std::unique_ptr<GPUCSP>& out);        // one context per entry of opts.devices
     ~GPUCSP();
+    // ---- the device pool ----
+    int n_devices() const { return (int)devs_.size(); }
+    fabgpu_ctx* ctx_of(int d) const { return devs_[(size_t)d]->ctx; }
+    int device_ordinal(int d) const { return devs_[(size_t)d]->ordinal; }
+    // Which context a block pass named `block_seq` runs on: the one with the fewest passes in flight, ties broken round the ring
+    // starting at block_seq mod G (pass_route.h) - consecutive blocks and the channels of a peer spread over the node.
+    int RouteBlock(uint64_t block_seq) const;
+    // passes[d] = block passes context d has served since construction (n_devices() entries)
+    void PassesPerDevice(uint64_t* passes) const;
+    // options that may change while the provider lives (tests, A/B runs); returns the previous value, INT64_MIN for an unknown name
+    int64_t SetOption(const std::string& name, int64_t value) const;
+    int64_t GetOption(const std::string& name) const;
     // device_table: also build the key's comb table on the device (fabgpu_p256_key_register) - what the provider does for a
     // key imported through BCCSP.KeyImport; false for keys merely unmarshalled from a flat batch.
     Error KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out, bool device_table = false) const;
@@ -151,8 +185,8 @@ class GPUCSP {
     // The device walker alone (tests: it must produce what ParseBlock produces, record for record): fills `parsed` like ParseBlock does,
     // except first_channel_id.  0 done, 1 declined, < 0 FABGPU_E*.
     int WalkBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock& parsed, const char** why) const;
-    // FABGPU_PASS_DEVICE_WALK=0 keeps every block on the host walk (A/B runs); default on
-    static bool DeviceWalkEnabled();
+    // option pass_device_walk = 0 keeps every block on the host walk (A/B runs); default on
+    bool DeviceWalkEnabled() const;
     // ---- x509 certificate signatures ----
     // The arithmetic of crypto/x509 Certificate.CheckSignatureFrom(parent) for ecdsa-with-SHA256 certificates under P-256 issuer keys -
     // what msp identity validation runs per chain link on an msp-cache miss (msp/mspimplvalidate.go:21-52 -> msp/mspimpl.go:721-739 ->
@@ -190,21 +224,60 @@ class GPUCSP {
         std::thread th;
         uint64_t token = 0;
         int rc = -1;
+        int dev = 0;                 // the context (index into the provider's pool) the block travels to: the pass runs there
+        bool started = false;        // an upload was started (join() may already have been called)
+        bool routed = false;         // dev was chosen by RouteBlock and counts as a pass in flight on it until the upload object dies
+        const GPUCSP* owner = nullptr;
+        const uint8_t* block = nullptr;   // what was uploaded (a retry of the same call finds its upload again: bccsp_capi.cpp)
+        size_t len = 0;
+        uint64_t seq = 0;
         uint64_t join() {
             if (th.joinable()) th.join();
             return rc == 0 ? token : 0;
         }
-        ~BlockUpload() { if (th.joinable()) th.join(); }
+        BlockUpload() {}
+        BlockUpload(const BlockUpload&) = delete;
+        BlockUpload& operator=(const BlockUpload&) = delete;
+        ~BlockUpload();
     };
-    void StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len) const;
+    // Chooses the pass's device (RouteBlock) and, for blocks of pass_stage_min_bytes and more, starts the upload to it.
+    void StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len, uint64_t block_seq = 0) const;
     // An idemix MSP of the channel (msp/idemixmsp.go:99-173 Setup): its creators' pseudonym signatures are then verified by the
     // pre-verify pass too.  ipk_raw: marshalled idemix.IssuerPublicKey.  Returns the device issuer id, or -1 (not accelerated).
     int64_t RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len) const;
-    fabgpu_ctx* ctx() const { return ctx_; }
+    // Registers an idemix issuer on EVERY device of the pool, under one lock, so that its id is the same everywhere (ids are handed
+    // out in order of registration per context); -1: not accelerated.  ipk_raw: marshalled idemix.IssuerPublicKey.
+    int64_t ImportIdemixIssuer(const uint8_t* ipk_raw, size_t len, std::string* err = nullptr) const;
+    fabgpu_ctx* ctx() const { return devs_[0]->ctx; }          // the first context (tests, single-device callers)
+    // the context a flat batch (Verify / VerifyBatch / IdentityVerifyBatch / a coalesced launch) runs on: round the ring
+    fabgpu_ctx* flat_ctx() const { return devs_[flat_rr_.fetch_add(1, std::memory_order_relaxed) % devs_.size()]->ctx; }
+    const ProviderOptions& options() const { return opts_; }
 
    private:
-    explicit GPUCSP(fabgpu_ctx* c) : ctx_(c) {}
-    fabgpu_ctx* ctx_;
+    GPUCSP() {}
+    // One device context of the pool and the provider's per-device state: the device's copy of the identity cache and its version.
+    struct Dev {
+        fabgpu_ctx* ctx = nullptr;
+        int ordinal = 0;
+        std::atomic<uint32_t> in_flight{0};                 // passes routed here that have not finished
+        std::atomic<uint64_t> passes{0};                    // passes served
+        // The device's copy of the identity cache (block_walk_dev.h walk_idtab_set): rebuilt whenever id_version_ moved.  Passes hold
+        // idtab_rw shared from the version check until they have translated the device's identity indices back; a rebuild holds it exclusively.
+        std::shared_timed_mutex idtab_rw;
+        std::atomic<uint64_t> idtab_version{0};
+        std::vector<uint64_t> idtab_host;                   // serial of the cache entry behind index k of the device table
+        std::vector<uint8_t> idtab_bytes;                   // scratch of the rebuild (3 MB when the cache is full: not reallocated per version)
+        std::vector<DevIdEntry> idtab_ents;
+    };
+    std::vector<std::unique_ptr<Dev>> devs_;
+    mutable std::atomic<uint64_t> flat_rr_{0};
+    mutable ProviderOptions opts_;
+    mutable std::mutex opt_mu_;
+    // A P-256 key's comb table on every device of the pool (the table is built once, fabgpu_p256_key_register_many): the common key id,
+    // or -1 when the devices disagree about it / a device failed (the fresh-key kernels then serve that key: always correct).
+    int64_t RegisterKeyOnAllDevices(const uint8_t* qx32, const uint8_t* qy32) const;
+    mutable std::mutex reg_mu_;                             // registrations take turns: ids stay the same on every device
+    void Preallocate() const;
     // identity cache of the pre-verify pass (msp/cache/cache.go): SerializedIdentity bytes -> P-256 key + device key id
     struct CachedIdentity {
         bool p256 = false;
@@ -229,17 +302,11 @@ class GPUCSP {
     void InsertIdentityLocked(std::string&& key, CachedIdentity ci) const;
     mutable size_t id_max_ = 4096, id_max_registered_ = 256, id_registered_ = 0;
     mutable uint32_t id_register_after_ = 64;
-    // The device's copy of this cache (block_walk_dev.h walk_idtab_set): rebuilt whenever id_version_ moved.  Passes hold idtab_rw_
-    // shared from the version check until they have translated the device's identity indices back; a rebuild holds it exclusively.
+    // Every device of the pool holds a copy of this cache (Dev::idtab_*), rebuilt before a pass on that device whenever id_version_ moved.
     mutable std::atomic<uint64_t> id_version_{1};
-    mutable std::shared_timed_mutex idtab_rw_;
-    mutable std::atomic<uint64_t> idtab_version_{0};
-    mutable std::vector<uint64_t> idtab_host_;         // serial of the cache entry behind index k of the device table
-    mutable std::vector<uint8_t> idtab_bytes_;         // scratch of the rebuild (3 MB when the cache is full: not reallocated per version)
-    mutable std::vector<DevIdEntry> idtab_ents_;
     const uint64_t idtab_seed_ = MakeSeed();      // the device table's hash is keyed per provider (block_walk_core.h id_hash_host)
     static uint64_t MakeSeed();
-    int SyncDeviceIdentityTable() const;
+    int SyncDeviceIdentityTable(Dev& dv) const;
     mutable std::atomic<uint64_t> pass_relaunches_{0}, pass_decoded_{0}, pass_learned_{0}, pass_general_der_{0};
     void EvictIdentitiesLocked() const;
     void RegisterQueued(const std::vector<std::string>& to_register) const;
@@ -276,10 +343,12 @@ class GPUCSP {
     };
     void PublishMemo(const std::shared_ptr<BlockMemo>& bm) const;   // push under the lock, oldest blocks out while over capacity
     mutable std::vector<std::shared_ptr<BlockMemo>> memo_free_;    // evicted tables, recycled: 7 MB of fresh pages per block otherwise
+    mutable size_t memo_free_max_ = 4, scratch_free_max_ = 4;      // (both grow with the pool and with ProviderOptions::concurrent_passes)
     mutable std::shared_timed_mutex memo_mu_;
     mutable std::deque<std::shared_ptr<BlockMemo>> memo_blocks_;   // oldest first
     mutable size_t memo_cap_ = (size_t)1 << 18;
     mutable std::atomic<uint64_t> memo_hits_{0}, memo_misses_{0}, memo_evicted_{0};
+    static size_t MemoPinLayout(uint32_t n_tuples, uint32_t n_creators, uint32_t* slot_cap, size_t* keys_cap, size_t* total, size_t* offs5 = nullptr);
     static size_t MemoKeyBytes(size_t siglen, size_t dlen, bool nym) { return 1 + (nym ? 32 : 0) + 64 + 4 + siglen + 4 + dlen; }
     static void MemoKeyWrite(uint8_t* out, const uint8_t* issuer_hash32, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,
                              const uint8_t* digest, size_t dlen);

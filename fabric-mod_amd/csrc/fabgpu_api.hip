@@ -168,6 +168,9 @@ struct fabgpu_ctx {
     DevBuf walk_env, walk_tup, idtab_buf;
     PinBuf stage_pin;                // fabgpu_arena_stage: pinned staging of arenas that arrive in pageable memory
     std::mutex stage_pin_mu;
+    // The copiers of this context's uploads: threads of its own (made with the first big upload), so that the uploads of a provider's G
+    // devices - each behind its own PCIe link - run side by side instead of taking turns on the process-wide pool of the host passes.
+    std::unique_ptr<WorkerPool> stage_pool;
     hipStream_t stream_copy = nullptr;
     hipStream_t stream_copy_more[3] = {nullptr, nullptr, nullptr};   // further upload queues: pieces alternate between DMA engines
     PinBuf walk_pin;
@@ -347,6 +350,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
 
 void fabgpu_shutdown(fabgpu_ctx* ctx) {
     if (!ctx) return;
+    ctx->stage_pool.reset();
     {
         DeviceGuard g(ctx->device);
         if (ctx->stream) hipStreamSynchronize(ctx->stream);
@@ -572,11 +576,8 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
 }
 
 // ---- registered public keys -------------------------------------------------------------------------
-int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
-    if (!ctx || !qx32 || !qy32 || !key_id) return FABGPU_EINVAL;
-    if (!fabgpu_p256_pubkey_on_curve(qx32, qy32)) return FABGPU_EINVAL;   // KeyImport gate: such keys stay with bccsp/sw
-    std::string k((const char*)qx32, 32);
-    k.append((const char*)qy32, 32);
+// one key's comb table into one context: id of the key there (idempotent per (qx, qy)); `tab` = the table, built by the caller
+static int key_install(fabgpu_ctx* ctx, const std::string& k, const std::vector<int32_t>* tab_in, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
     std::lock_guard<std::mutex> lk(ctx->kmu);
     auto it = ctx->key_ids.find(k);
     if (it != ctx->key_ids.end()) {
@@ -585,11 +586,16 @@ int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t
     }
     if (ctx->ktabs.size() >= FABGPU_MAX_KEYS) return FABGPU_ENOMEM;
     DeviceGuard g(ctx->device);
-    u256 qx, qy;
-    from_be32(qx, qx32);
-    from_be32(qy, qy32);
-    std::vector<int32_t> tab(KeyTab8::TABLE_WORDS);
-    build_key_comb_table8(tab.data(), qx, qy);
+    std::vector<int32_t> own;
+    if (!tab_in) {
+        u256 qx, qy;
+        from_be32(qx, qx32);
+        from_be32(qy, qy32);
+        own.resize(KeyTab8::TABLE_WORDS);
+        build_key_comb_table8(own.data(), qx, qy);
+        tab_in = &own;
+    }
+    const std::vector<int32_t>& tab = *tab_in;
     int32_t* d = nullptr;
     if (hipMalloc((void**)&d, sizeof(int32_t) * KeyTab8::TABLE_WORDS) != hipSuccess) return FABGPU_ENOMEM;
     if (hipMemcpy(d, tab.data(), sizeof(int32_t) * KeyTab8::TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) {
@@ -617,6 +623,47 @@ int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t
     ctx->ktabs.push_back(d);
     *key_id = (uint32_t)(ctx->ktabs.size() - 1);
     ctx->key_ids[k] = *key_id;
+    return FABGPU_OK;
+}
+
+int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
+    if (!ctx || !qx32 || !qy32 || !key_id) return FABGPU_EINVAL;
+    if (!fabgpu_p256_pubkey_on_curve(qx32, qy32)) return FABGPU_EINVAL;   // KeyImport gate: such keys stay with bccsp/sw
+    std::string k((const char*)qx32, 32);
+    k.append((const char*)qy32, 32);
+    return key_install(ctx, k, nullptr, qx32, qy32, key_id);
+}
+
+// The same key on n contexts (a provider that owns every GPU of the node): the 640 KiB comb table is built ONCE on the host (~6 ms)
+// and uploaded to each context that does not have the key yet.  key_ids[g] = the key's id on ctxs[g].  The first failure is returned
+// (contexts before it keep the key: registration is idempotent).
+int fabgpu_p256_key_register_many(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_ids) {
+    if (!ctxs || n <= 0 || !qx32 || !qy32 || !key_ids) return FABGPU_EINVAL;
+    for (int g = 0; g < n; g++)
+        if (!ctxs[g]) return FABGPU_EINVAL;
+    if (!fabgpu_p256_pubkey_on_curve(qx32, qy32)) return FABGPU_EINVAL;
+    std::string k((const char*)qx32, 32);
+    k.append((const char*)qy32, 32);
+    std::vector<int32_t> tab;                              // built when the first context turns out to need it
+    for (int g = 0; g < n; g++) {
+        bool have;
+        {
+            std::lock_guard<std::mutex> lk(ctxs[g]->kmu);
+            auto it = ctxs[g]->key_ids.find(k);
+            have = it != ctxs[g]->key_ids.end();
+            if (have) key_ids[g] = it->second;
+        }
+        if (have) continue;
+        if (tab.empty()) {
+            u256 qx, qy;
+            from_be32(qx, qx32);
+            from_be32(qy, qy32);
+            tab.resize(KeyTab8::TABLE_WORDS);
+            build_key_comb_table8(tab.data(), qx, qy);
+        }
+        const int rc = key_install(ctxs[g], k, &tab, qx32, qy32, &key_ids[g]);
+        if (rc != FABGPU_OK) return rc;
+    }
     return FABGPU_OK;
 }
 
@@ -1010,6 +1057,7 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
             return true;
         };
         const int nth = (int)std::min<size_t>((size_t)stage_threads, n_pieces);
+        if (!ctx->stage_pool) ctx->stage_pool.reset(new (std::nothrow) WorkerPool(stage_threads));   // (stage_pin_mu is held)
         run_workers(nth + 1, [&](int w) {
             if (w != 0) {
                 while (copy_one()) {}
@@ -1021,7 +1069,7 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
                     if (!copy_one()) std::this_thread::yield();
                 if (hipMemcpyAsync(dst + cut[k], pin + cut[k], cut[k + 1] - cut[k], hipMemcpyHostToDevice, cs[k % (size_t)n_queues]) != hipSuccess) failed = 1;
             }
-        });
+        }, ctx->stage_pool.get());
         for (int q = 0; q < n_queues; q++) {
             const hipError_t e = hipStreamSynchronize(cs[q]);
             if (err == hipSuccess) err = e;
@@ -2053,13 +2101,65 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     return FABGPU_OK;
 }
 
+// What `slots` overlapping passes over blocks of up to block_bytes / n_tx transactions / n_tuples signatures need on this device, made
+// NOW (provider construction: ProviderOptions::concurrent_passes) instead of when passes first overlap - the staging slots for uploaded
+// blocks, the pinned staging buffer, the pass's device / pinned / host-mapped arrays at generous upper bounds, the gather scratch.  A peer
+// that joins a channel gets no untimed rounds: measured in round 3, the first overlapping passes of a provider took 5-16 ms (a second
+// and third 63 MB staging slot, the arrays of the first memo-seeding pass).  Best effort: a failed allocation is simply made later.
+int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_t n_tuples, int slots) {
+    if (!ctx) return FABGPU_EINVAL;
+    if (block_bytes > 0xFFFFFF00ull) return FABGPU_ETOOBIG;
+    DeviceGuard g(ctx->device);
+    int rc = FABGPU_OK;
+    const size_t need = round_up(block_bytes, 64) + 128;
+    for (int i = 0; i < fabgpu_ctx::N_STAGED && i < slots; i++) {
+        fabgpu_ctx::Staged& sl = ctx->staged_slots[i];
+        std::lock_guard<std::mutex> lk(sl.m);
+        if (sl.cap >= need + (64 << 10)) continue;
+        if (sl.d) hipFree(sl.d);
+        sl.d = nullptr;
+        sl.cap = 0;
+        sl.token.store(0);
+        sl.len = 0;
+        if (hipMalloc(&sl.d, need + need / 8 + (64 << 10)) != hipSuccess) {
+            sl.d = nullptr;
+            rc = FABGPU_ENOMEM;
+            continue;
+        }
+        sl.cap = need + need / 8 + (64 << 10);
+    }
+    {
+        std::lock_guard<std::mutex> plk(ctx->stage_pin_mu);
+        if (block_bytes >= ((size_t)4 << 20) && ctx->stage_pin.ensure(block_bytes) != FABGPU_OK) rc = FABGPU_ENOMEM;
+        if (!ctx->stage_pool) ctx->stage_pool.reset(new (std::nothrow) WorkerPool(4));
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t ne = n_tx, nt = n_tuples;
+    // upper bounds of walk_block_pass's carves: per envelope 91 bytes of arrays, per tuple ~1.9 KB with the memo's key room (1 165 bytes)
+    if (ctx->walk_env.ensure(ne * 128 + ((size_t)256 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
+    if (ctx->walk_tup.ensure(nt * 2048 + ne * 256 + ((size_t)1 << 20)) != FABGPU_OK) rc = FABGPU_ENOMEM;
+    if (ctx->walk_pin.ensure(nt * 256 + ne * 160 + ((size_t)256 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
+    if (ctx->walk_map.ensure(nt * 8 + ne * 8 + sizeof(WalkLearn) * WALK_LEARN_SLOTS + ((size_t)64 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
+    const size_t gscr = ne * 4096 + ((size_t)64 << 10);                         // TxID + proposal-hash inputs: a few KB per transaction
+    if (ctx->gscr_cap < gscr) {
+        if (ctx->d_gscr) hipFree(ctx->d_gscr);
+        ctx->d_gscr = nullptr;
+        ctx->gscr_cap = 0;
+        if (hipMalloc(&ctx->d_gscr, gscr) == hipSuccess) ctx->gscr_cap = gscr;
+        else rc = FABGPU_ENOMEM;
+    }
+    if (ctx->tailbuf.ensure((size_t)64 << 10) != FABGPU_OK) rc = FABGPU_ENOMEM;
+    return rc;
+}
+
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes) {
     if (!ctx || bytes == 0) return nullptr;
     DeviceGuard g(ctx->device);
     static const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    // (portable: a memo table is recycled by whichever device of the provider's pool runs the next pass)
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
     if (timing) fprintf(stderr, "fabgpu: %.1f MB of pinned memory for a memo table in %.2f ms\n", bytes / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return p;
 }

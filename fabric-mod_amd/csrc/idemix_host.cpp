@@ -80,8 +80,8 @@ bool UnmarshalNymSignature(const uint8_t* raw, size_t len, NymSignatureFields& o
     return w.ok;
 }
 
-Error IdemixCSP::IssuerKeyImport(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out) const {
-    if (!raw || len == 0) return Error("invalid raw, it must not be nil");                      // handlers/issuer.go KeyImport
+// 0: the bytes do not parse; 1: parsed, but a field the device needs is missing or has another size; 2: HSk, HRand, Hash in place
+static int issuer_key_fields(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out) {
     Walker w(raw, len);
     Field f;
     bool hsk = false, hrand = false, hash = false;
@@ -91,9 +91,20 @@ Error IdemixCSP::IssuerKeyImport(const uint8_t* raw, size_t len, IdemixIssuerPub
         if (f.num == 3) hrand = ecp32(f.data, f.len, out.hrand_x, out.hrand_y);
         if (f.num == 10 && f.len == 32) { memcpy(out.hash, f.data, 32); hash = true; }
     }
-    if (!w.ok) return Error("failed to unmarshal issuer public key");
+    if (!w.ok) return 0;
+    return hsk && hrand && hash ? 2 : 1;
+}
+bool IdemixCSP::IssuerKeyFields(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out) {
     out.issuer_id = -1;
-    if (!hsk || !hrand || !hash) return Error();   // a key the device cannot take (odd field sizes): valid for bccsp/idemix, not accelerated
+    return raw && len && issuer_key_fields(raw, len, out) == 2;
+}
+
+Error IdemixCSP::IssuerKeyImport(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out) const {
+    if (!raw || len == 0) return Error("invalid raw, it must not be nil");                      // handlers/issuer.go KeyImport
+    const int got = issuer_key_fields(raw, len, out);
+    if (got == 0) return Error("failed to unmarshal issuer public key");
+    out.issuer_id = -1;
+    if (got != 2) return Error();   // a key the device cannot take (odd field sizes): valid for bccsp/idemix, not accelerated
     uint32_t id = 0;
     int rc = fabgpu_idemix_issuer_register(ctx_, out.hsk_x, out.hsk_y, out.hrand_x, out.hrand_y, out.hash, &id);
     if (rc == FABGPU_OK) out.issuer_id = id;

@@ -41,6 +41,8 @@ class IdemixCSP {
     // device.  The proof of knowledge inside the key (IssuerPublicKey.Check, idemix/issuerkey.go:114-172: G2 arithmetic) is NOT
     // re-checked here - key import stays with bccsp/idemix, which calls this after its own checks passed.
     Error IssuerKeyImport(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out) const;
+    // the fields alone (HSk, HRand, Hash as 32-byte halves), no device: false when the bytes do not parse or a field has another size
+    static bool IssuerKeyFields(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out);
     // raw: x || y (bccsp/idemix/bridge/user.go:72-86 splits at len/2)
     Error NymKeyImport(const uint8_t* raw, size_t len, NymPublicKey& out) const;
     Error NymVerifyBatch(const std::vector<NymVerifyItem>& items, std::vector<VerifyResult>& results) const;

@@ -75,10 +75,12 @@ class WorkerPool {
         for (auto& t : threads_) t.join();
     }
 
-   private:
+    // a pool of its own (a device context keeps four copier threads for its uploads: fabgpu_api.hip fabgpu_arena_stage)
     explicit WorkerPool(int n) {
         for (int i = 0; i < n; i++) threads_.emplace_back([this, i] { loop(i); });
     }
+
+   private:
     void drain(const std::function<void(int)>& fn) {
         for (;;) {
             int idx = next_index_.fetch_add(1, std::memory_order_relaxed);
@@ -124,8 +126,8 @@ class WorkerPool {
 };
 
 // k workers (worker 0 = the caller) through the pool, or - pool busy - on threads of their own
-inline void run_workers(int k, const std::function<void(int)>& fn) {
-    if (WorkerPool::instance().run(k, fn)) return;
+inline void run_workers(int k, const std::function<void(int)>& fn, WorkerPool* pool = nullptr) {
+    if ((pool ? *pool : WorkerPool::instance()).run(k, fn)) return;
     std::vector<std::thread> th;
     for (int w = 1; w < k; w++) th.emplace_back(fn, w);
     fn(0);

@@ -74,6 +74,14 @@ class _BlockPass(ctypes.Structure):
                 ("n_keyed", ctypes.c_uint32), ("n_device_decoded", ctypes.c_uint32)]
 
 
+class _CspOpts(ctypes.Structure):
+    """fabgpu_csp_opts (include/fabgpu_bccsp.h): the `GPU:` section of the BCCSP configuration."""
+    _fields_ = [("size", ctypes.c_uint32), ("n_devices", ctypes.c_int32), ("devices", ctypes.POINTER(ctypes.c_int32)), ("ctx_flags", ctypes.c_uint32),
+                ("concurrent_passes", ctypes.c_uint32), ("expect_block_bytes", ctypes.c_uint64), ("expect_tuples", ctypes.c_uint32),
+                ("pass_device_walk", ctypes.c_int32), ("pass_stage_min_bytes", ctypes.c_int64), ("pass_device_memo", ctypes.c_int32),
+                ("pass_host_counts", ctypes.c_int32), ("pass_timing", ctypes.c_int32)]
+
+
 class _Cfg(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("max_batch", ctypes.c_uint32), ("max_arena", ctypes.c_uint32),
                 ("flags", ctypes.c_uint32)]
@@ -102,6 +110,8 @@ ABI_SYMBOLS = [
     "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev",
     "fabgpu_csp_pass_routes", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast", "fabgpu_identity_table_hash", "fabgpu_csp_gate_probe",
     "fabgpu_gate_sig_any", "fabgpu_identity_to_p256", "fabgpu_csp_idfix_probe", "fabgpu_csp_pass_stats",
+    "fabgpu_p256_key_register_many", "fabgpu_csp_new2", "fabgpu_csp_device_count", "fabgpu_csp_ctx_of", "fabgpu_csp_passes_per_device",
+    "fabgpu_csp_route_block", "fabgpu_csp_set_option", "fabgpu_csp_get_option",
 ]
 
 _lib = None
@@ -154,6 +164,15 @@ def load():
     L.fabgpu_hash_to_int.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p]
     L.fabgpu_hash_to_int.restype = None
     L.fabgpu_csp_new.argtypes = [ctypes.POINTER(_Cfg), ctypes.POINTER(_vp), ctypes.c_char_p, _sz]
+    L.fabgpu_csp_new2.argtypes = [ctypes.POINTER(_CspOpts), ctypes.POINTER(_vp), ctypes.c_char_p, _sz]
+    L.fabgpu_csp_device_count.argtypes = [_vp]
+    L.fabgpu_csp_ctx_of.argtypes = [_vp, ctypes.c_int]
+    L.fabgpu_csp_ctx_of.restype = _vp
+    L.fabgpu_csp_passes_per_device.argtypes = [_vp, _u64p, ctypes.c_int]
+    L.fabgpu_csp_route_block.argtypes = [_vp, ctypes.c_uint64]
+    L.fabgpu_csp_set_option.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+    L.fabgpu_csp_get_option.argtypes = [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
+    L.fabgpu_p256_key_register_many.argtypes = [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, _u32p]
     L.fabgpu_csp_free.argtypes = [_vp]
     L.fabgpu_csp_free.restype = None
     L.fabgpu_csp_ctx.argtypes = [_vp]
@@ -577,15 +596,57 @@ class SHA3_256Opts:
 class GPUCSP:
     """The accelerated verbs of bccsp.BCCSP (bccsp/bccsp.go:90-134); everything else the Go provider delegates to bccsp/sw."""
 
-    def __init__(self, device: int = -1):
+    def __init__(self, device: int = -1, devices: Optional[Sequence[int]] = None, flags: int = 0, concurrent_passes: int = 0,
+                 expect_block_bytes: int = 0, expect_tuples: int = 0, **switches):
+        """device: ONE context on that HIP ordinal (fabgpu_csp_new).  devices: one context per entry - an ordinal may repeat; an empty
+        list means every visible device - behind ONE provider (fabgpu_csp_new2: what bccsp/factory builds from the `GPU:` section).
+        switches: pass_device_walk / pass_stage_min_bytes / pass_device_memo / pass_host_counts / pass_timing (0 default, > 0 on, < 0 off)."""
         L = load()
-        cfg = _Cfg(device, 0, 0, 0)
         h = _vp()
         err = ctypes.create_string_buffer(512)
-        rc = L.fabgpu_csp_new(ctypes.byref(cfg), ctypes.byref(h), err, 512)
+        if devices is None and not (flags or concurrent_passes or switches):
+            cfg = _Cfg(device, 0, 0, 0)
+            rc = L.fabgpu_csp_new(ctypes.byref(cfg), ctypes.byref(h), err, 512)
+        else:
+            devs = [device] if devices is None else list(devices)
+            arr = (ctypes.c_int32 * max(1, len(devs)))(*devs)
+            o = _CspOpts()
+            o.size, o.n_devices, o.devices = ctypes.sizeof(_CspOpts), len(devs), arr
+            o.ctx_flags, o.concurrent_passes, o.expect_block_bytes, o.expect_tuples = flags, concurrent_passes, expect_block_bytes, expect_tuples
+            for k, v in switches.items():
+                if not hasattr(o, k):
+                    raise TypeError("unknown provider switch %r" % k)
+                setattr(o, k, v)
+            rc = L.fabgpu_csp_new2(ctypes.byref(o), ctypes.byref(h), err, 512)
         if rc != FABGPU_OK:
             raise FabgpuError(err.value.decode() or strerror(rc))
         self._h, self._L = h, L
+
+    def device_count(self) -> int:
+        """Device contexts behind this provider."""
+        return self._L.fabgpu_csp_device_count(self._h)
+
+    def passes_per_device(self) -> List[int]:
+        """Block passes each context of the pool has served."""
+        v = (ctypes.c_uint64 * 64)()
+        n = self._L.fabgpu_csp_passes_per_device(self._h, v, 64)
+        if n < 0:
+            raise FabgpuError("fabgpu_csp_passes_per_device: %s" % strerror(n))
+        return [int(v[i]) for i in range(n)]
+
+    def route_block(self, block_seq: int) -> int:
+        return self._L.fabgpu_csp_route_block(self._h, block_seq)
+
+    def set_option(self, name: str, value: int) -> int:
+        """A switch of the living provider (0 default, > 0 on / threshold, < 0 off); returns the previous value."""
+        prev = ctypes.c_int64(0)
+        _check(self._L.fabgpu_csp_set_option(self._h, name.encode(), int(value), ctypes.byref(prev)), "fabgpu_csp_set_option(%s)" % name)
+        return int(prev.value)
+
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_int64(0)
+        _check(self._L.fabgpu_csp_get_option(self._h, name.encode(), ctypes.byref(v)), "fabgpu_csp_get_option(%s)" % name)
+        return int(v.value)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -598,9 +659,9 @@ class GPUCSP:
         except Exception:
             pass
 
-    def key_count(self) -> int:
-        """Number of public keys whose comb table is resident on the device."""
-        return self._L.fabgpu_p256_key_count(self._L.fabgpu_csp_ctx(self._h))
+    def key_count(self, d: int = 0) -> int:
+        """Number of public keys whose comb table is resident on device context d of the pool."""
+        return self._L.fabgpu_p256_key_count(self._L.fabgpu_csp_ctx_of(self._h, d))
 
     def key_import(self, raw, opts=None) -> ECDSAPublicKey:
         """KeyImport(raw, &bccsp.ECDSAGoPublicKeyImportOpts{}) (bccsp/sw/keyimport.go:103-112): raw = (X, Y)."""

@@ -119,6 +119,9 @@ int fabgpu_sha256_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* a
  * yields status 4 for that tuple. */
 #define FABGPU_MAX_KEYS 4096
 int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id);
+/* The same key on n contexts - a provider that drives every GPU of the node (fabgpu_csp_new2) keeps each registered key's table on
+ * each of them: built once on the host, uploaded n times.  key_ids[g] = the key's id on ctxs[g]. */
+int fabgpu_p256_key_register_many(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_ids);
 int fabgpu_p256_key_lookup(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id); /* 0 found, 1 not registered */
 int fabgpu_p256_key_count(fabgpu_ctx* ctx);
 int fabgpu_p256_verify_batch_keyed(fabgpu_ctx* ctx, size_t n, const uint32_t* key_id, const uint8_t* e, const uint8_t* r,

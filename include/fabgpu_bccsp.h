@@ -18,8 +18,44 @@ extern "C" {
 typedef struct fabgpu_csp fabgpu_csp;
 
 int fabgpu_csp_new(const fabgpu_cfg* cfg, fabgpu_csp** out, char* err, size_t errcap);
+/* ONE provider over SEVERAL devices.  The reference has one process-global BCCSP (bccsp/factory/factory.go:41-55: GetDefault), handed to
+ * every channel's validator (core/peer/peer.go:337-355), and validates its channels side by side (core/committer/txvalidator/v20/
+ * validator.go:194-210): whatever drives more than one GPU has to sit BEHIND that one object.  fabgpu_csp_new2 makes one device context
+ * per entry of `devices` (an ordinal may repeat: several contexts on one GPU); every block pass is routed to the context with the fewest
+ * passes in flight (ties: round the ring from block_seq mod G), the identity cache and the verdict memo stay ONE on the host -
+ * fabgpu_csp_memo_lookup does not care which device verified - and registered keys / idemix issuers get their tables on every device
+ * under the same id.  Flat batches (verify_batch, identity_verify_batch, coalesced launches) take turns round the pool.
+ * This struct is what `GPU:` of the BCCSP configuration carries (go/bccsp/factory/gpufactory.go GPUOpts; pattern bccsp/pkcs11/conf.go:70-84);
+ * `size` = sizeof(fabgpu_csp_opts) as the caller compiled it (the struct may grow at its end). */
+typedef struct fabgpu_csp_opts {
+    uint32_t size;
+    int32_t n_devices;             /* 0: every visible gfx950 device */
+    const int32_t* devices;        /* n_devices HIP ordinals, or NULL = 0 .. n_devices-1 */
+    uint32_t ctx_flags;            /* FABGPU_FLAG_* for every context */
+    uint32_t concurrent_passes;    /* per device: what this many overlapping block passes need - staging slots, pinned memo tables, pass
+                                      arrays - is allocated NOW, not when passes first overlap (0: on demand) */
+    uint64_t expect_block_bytes;   /* sizes that pre-allocation (0: 64 MiB) */
+    uint32_t expect_tuples;        /* (0: 65 536) */
+    /* switches that were environment variables through round 3: 0 = the default, > 0 on, < 0 off (a zeroed struct is all defaults) */
+    int32_t pass_device_walk;      /* < 0: every block takes the host walk (default: the walk runs on the device) */
+    int64_t pass_stage_min_bytes;  /* > 0: only blocks of at least this many bytes are uploaded ahead of their pass (default: every block) */
+    int32_t pass_device_memo;      /* < 0: the verdict memo is seeded on the host also on the device route (default: built by the device) */
+    int32_t pass_host_counts;      /* > 0: the envelopes' tuples are counted on the host while the block travels (default off) */
+    int32_t pass_timing;           /* > 0: stage breakdown of every pass on stderr (default off) */
+} fabgpu_csp_opts;
+int fabgpu_csp_new2(const fabgpu_csp_opts* opts, fabgpu_csp** out, char* err, size_t errcap);
 void fabgpu_csp_free(fabgpu_csp* csp);
-fabgpu_ctx* fabgpu_csp_ctx(fabgpu_csp* csp);
+fabgpu_ctx* fabgpu_csp_ctx(fabgpu_csp* csp);            /* the first device's context */
+int fabgpu_csp_device_count(fabgpu_csp* csp);            /* contexts in the pool */
+fabgpu_ctx* fabgpu_csp_ctx_of(fabgpu_csp* csp, int d);
+/* passes[d] = block passes context d has served; returns the number of contexts (cap must be at least that) */
+int fabgpu_csp_passes_per_device(fabgpu_csp* csp, uint64_t* passes, int cap);
+int fabgpu_csp_route_block(fabgpu_csp* csp, uint64_t block_seq);   /* where a pass named block_seq would go right now */
+/* the switches above on a living provider (tests, A/B runs): "pass_device_walk", "pass_stage_min_bytes", "pass_device_memo",
+ * "pass_host_counts", "pass_skip_hash_checks", "pass_timing" - same convention: 0 the default, > 0 on / the threshold, < 0 off; get also
+ * answers "n_devices".  FABGPU_EINVAL: no such option. */
+int fabgpu_csp_set_option(fabgpu_csp* csp, const char* name, int64_t value, int64_t* previous);
+int fabgpu_csp_get_option(fabgpu_csp* csp, const char* name, int64_t* value);
 
 /* BCCSP.KeyImport for a P-256 public key (bccsp/sw/keyimport.go:103-134; pattern bccsp/pkcs11/pkcs11.go:148-179): checks
  * curve membership and registers the key's comb table on the device (fabgpu_p256_key_register), so that batches whose

@@ -155,8 +155,8 @@ def test_block_walker_on_synthetic_blocks():
 
 @pytest.mark.gpu
 def test_preverify_pass_end_to_end(monkeypatch):
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))         # the pass with the walk on the HOST (the device route: test_device_walk.py)
     csp = fabgpu.GPUCSP(device=0)
+    csp.set_option("pass_stage_min_bytes", 1 << 40)         # the pass with the walk on the HOST (the device route: test_device_walk.py)
     rng = np.random.default_rng(6)
     blk, want = build_block(220, rng)
     before = csp.key_count()
@@ -184,8 +184,8 @@ def test_preverify_pass_with_known_and_new_identities(monkeypatch):
     """A block signed by identities of which only some have a device table (newcomers among known ones): the answer does not depend
     on which path - per-key tables or keys carried along - the tuples took.  (Host walk: one launch for the whole block, so "some" means
     the fresh-key kernel for everybody; the device route decides per launch class, test_device_walk.py.)"""
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
     csp = fabgpu.GPUCSP(device=0)
+    csp.set_option("pass_stage_min_bytes", 1 << 40)
     L = csp._L
     before = csp.key_count()
     rng = np.random.default_rng(61)
@@ -328,7 +328,7 @@ def test_preverify_pass_with_the_block_uploaded_ahead(monkeypatch):
     rng = np.random.default_rng(16)
     blk, want = build_block(130, rng)
     plain = fabgpu.preverify_block(csp, blk)
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    csp.set_option("pass_stage_min_bytes", 1)
     staged = fabgpu.preverify_block(csp, blk)
     assert (plain["tx_flags"] == want).all() and (staged["tx_flags"] == want).all()
     assert (staged["tuple_status"] == plain["tuple_status"]).all()

@@ -463,11 +463,11 @@ def test_pass_on_the_device_route_equals_the_host_route(csp, monkeypatch):
     digests and memo; every corruption the device decides itself is in the block."""
     rng = np.random.default_rng(101)
     blk, want = clean_modes_block(220, rng)
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+    csp.set_option("pass_stage_min_bytes", 1 << 40)
     host = fabgpu.preverify_block(csp, blk)                                # host route; learns the identities
     host2 = fabgpu.preverify_block2(csp, blk, block_seq=1, seed_memo=True)
     assert (host["tx_flags"] == want).all() and fabgpu.pass_routes(csp)["device_walks"] == 0
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    csp.set_option("pass_stage_min_bytes", 1)
     dev = fabgpu.preverify_block(csp, blk)
     routes = fabgpu.pass_routes(csp)
     assert routes["device_walks"] == 1, routes
@@ -507,7 +507,7 @@ KEYS_ALL = ["tx_flags", "tx_type", "tuple_tx", "tuple_kind", "tuple_status", "tu
 def _both_routes(csp, monkeypatch, blk, seq, device_first=True, **kw):
     """the same block through the device route and through the host route of ONE provider -> (device answer, host answer)"""
     def run(device):
-        monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1" if device else str(1 << 40))
+        csp.set_option("pass_stage_min_bytes", 1 if device else 1 << 40)
         before = fabgpu.pass_routes(csp)
         out = fabgpu.preverify_block2(csp, blk, block_seq=seq + (0 if device else 1), **kw)
         after = fabgpu.pass_routes(csp)
@@ -528,10 +528,10 @@ def test_counts_from_the_host_and_counts_from_the_device_give_one_answer(csp, mo
     tuples, garbage, oversize fields)."""
     rng = np.random.default_rng(23)
     blk, want = build_block(90, rng)
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    csp.set_option("pass_stage_min_bytes", 1)
     answers = []
     for mode in ("0", "1", "0"):
-        monkeypatch.setenv("FABGPU_PASS_HOST_COUNTS", mode)
+        csp.set_option("pass_host_counts", 1 if mode == "1" else -1)
         before = fabgpu.pass_routes(csp)
         answers.append(fabgpu.preverify_block2(csp, blk, block_seq=70 + len(answers)))
         assert fabgpu.pass_routes(csp)["device_walks"] - before["device_walks"] == 1
@@ -548,10 +548,10 @@ def test_memo_built_by_the_device_equals_the_memo_seeded_on_the_host(csp, monkey
     same status or the same miss, the same number of entries, and nothing is left after eviction."""
     rng = np.random.default_rng(31)
     blk, want = build_block(120, rng)
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    csp.set_option("pass_stage_min_bytes", 1)
     answers = []
     for k, mode in enumerate(("1", "0")):
-        monkeypatch.setenv("FABGPU_PASS_DEVICE_MEMO", mode)
+        csp.set_option("pass_device_memo", 1 if mode == "1" else -1)
         before = fabgpu.pass_routes(csp)
         out = fabgpu.preverify_block2(csp, blk, block_seq=90 + k, seed_memo=True)
         assert fabgpu.pass_routes(csp)["device_walks"] - before["device_walks"] == 1
@@ -591,10 +591,10 @@ def test_memo_of_a_block_whose_signatures_are_far_longer_than_usual(csp, monkeyp
     envs[7] = blockgen.endorser_tx(7, rng, fx[4], [fx[0], fx[1], fx[2]], blockgen.make_signer(999),
                                    craft=lambda t, j, sig: sig + bytes(1100) if j == 0 else pad(t, j, sig))   # one beyond 1 024 bytes: no entry
     blk = bb.block(1, envs)
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    csp.set_option("pass_stage_min_bytes", 1)
     seeded = []
     for k, mode in enumerate(("1", "0")):
-        monkeypatch.setenv("FABGPU_PASS_DEVICE_MEMO", mode)
+        csp.set_option("pass_device_memo", 1 if mode == "1" else -1)
         out = fabgpu.preverify_block2(csp, blk, block_seq=300 + k, seed_memo=True)
         assert (out["tx_flags"] == 0).all() and (out["tuple_status"] == 0).all()
         hits = 0
@@ -680,7 +680,7 @@ def test_blocks_full_of_new_clients_stay_on_the_device_route(monkeypatch):
     try:
         csp._L.fabgpu_csp_identity_cache_limits(csp._h, 128, 64, 1)         # a small cache: 300 newcomers overflow it
         friendly, _ = blockgen.endorser_block(300, 7)
-        monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+        csp.set_option("pass_stage_min_bytes", 1)
         for k in range(6):                                                  # the six fixture signers are learned and earn their tables
             out = fabgpu.preverify_block2(csp, friendly, block_seq=k)       # (one learn slot per table hash, keyed per provider: two signers
             if k >= 2 and out["n_keyed"] == 1200 and out["n_device_decoded"] == 0:   #  that meet in a slot take a block longer)
@@ -710,7 +710,7 @@ def test_blocks_full_of_new_clients_stay_on_the_device_route(monkeypatch):
         assert {int(i) for i in np.nonzero(dev3["tuple_status"])[0]} == {400, 800, 802}     # (the endorsement sits inside what creator 200 signed)
         assert fabgpu.identity_cache_size(csp) <= 128
         # the host route on the same blocks: same answers
-        monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+        csp.set_option("pass_stage_min_bytes", 1 << 40)
         host = fabgpu.preverify_block2(csp, crowd, block_seq=20, seed_memo=True)
         _same(host, dev, KEYS_ALL)
         _same(fabgpu.preverify_block2(csp, bytes(broken), block_seq=21), dev3, KEYS_ALL)
@@ -766,7 +766,7 @@ def test_idemix_creators_on_the_device_route(monkeypatch):
         fabgpu.memo_evict_block(csp, 10)
         # the next block of the kind: the nym launch is queued on the prediction, nothing is repeated; flags-only callers get the same flags
         before = fabgpu.pass_routes(csp)
-        monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+        csp.set_option("pass_stage_min_bytes", 1)
         again = fabgpu.preverify_block(csp, blk)
         after = fabgpu.pass_routes(csp)
         assert after["device_walks"] == before["device_walks"] + 1 and after["relaunches"] == before["relaunches"]
@@ -794,7 +794,7 @@ def test_a_certificate_beyond_the_device_decoder_is_left_to_the_host_walk(csp, m
     d = blockgen._IDS[4]["d"]
     big = bb.serialized_identity("Org1MSP", blockgen._pem_wrap(blockgen._pem_der(blockgen._IDS[4]["pem"]) + bytes(3100)))   # (bytes behind the Certificate: ignored)
     blk, _ = blockgen.endorser_block(12, 3, creators=[(big, int(d, 16).to_bytes(32, "big")), fx[5]])
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    csp.set_option("pass_stage_min_bytes", 1)
     out = fabgpu.preverify_block2(csp, blk, block_seq=1)
     r = fabgpu.pass_routes(csp)
     assert r["device_walks"] == 0 and "decoder" in r["last_decline"], r
@@ -805,9 +805,9 @@ def test_a_certificate_beyond_the_device_decoder_is_left_to_the_host_walk(csp, m
 def test_device_route_on_the_reference_ledgers(csp, monkeypatch):
     """The reference's own blocks - orderer block signatures with their tail, identities that are not certificates (bccsp/sw
     decides), creator-less genesis envelopes, UUID TxIDs - through both routes: identical answers, reference signatures valid."""
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+    csp.set_option("pass_stage_min_bytes", 1 << 40)
     host = [fabgpu.preverify_block2(csp, raw, block_seq=i) for i, raw in enumerate(LEDGER_RAW)]
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+    csp.set_option("pass_stage_min_bytes", 1)
     before = fabgpu.pass_routes(csp)["device_walks"]
     walked = 0
     for i, raw in enumerate(LEDGER_RAW):
@@ -833,9 +833,9 @@ def test_device_route_big_block_caps_and_concurrency(csp, monkeypatch):
     rng = np.random.default_rng(31)
     blk = big_block(2600, rng, bad_every=97)                                # 13 MB: staged by default
     assert len(blk) > 8 << 20
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+    csp.set_option("pass_stage_min_bytes", 1 << 40)
     host = fabgpu.preverify_block(csp, blk)
-    monkeypatch.delenv("FABGPU_PASS_STAGE_MIN_BYTES")
+    csp.set_option("pass_stage_min_bytes", 0)
     csp._pass_caps = (16, 16)                                               # forces the ETOOBIG round trip on the device route
     before = fabgpu.pass_routes(csp)["device_walks"]
     dev = fabgpu.preverify_block(csp, blk)
@@ -897,7 +897,7 @@ def test_split_submission_equals_the_host_route(csp, monkeypatch):
     endorsements (one lane), rows permuted - statuses, digests and keys must still land on the right tuples.  The block's signatures are
     valid; a few dozen are then broken in place (creators and endorsers), so that a wrong row would show."""
     blk = _bench_block(10000)
-    monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+    csp.set_option("pass_stage_min_bytes", 1 << 40)
     host = fabgpu.preverify_block2(csp, blk, block_seq=1)
     assert (host["tx_flags"] == 0).all() and len(host["tuple_status"]) == 40000
     rng = np.random.default_rng(12)
@@ -910,7 +910,7 @@ def test_split_submission_equals_the_host_route(csp, monkeypatch):
     host_b = fabgpu.preverify_block2(csp, broken, block_seq=2)
     # (an endorsement sits inside the payload its transaction's creator signed: breaking it breaks that creator signature too)
     assert sorted(int(i) for i in np.nonzero(host_b["tuple_status"])[0]) == sorted(set(victims) | {4 * (i // 4) for i in victims})
-    monkeypatch.delenv("FABGPU_PASS_STAGE_MIN_BYTES")
+    csp.set_option("pass_stage_min_bytes", 0)
     before = fabgpu.pass_routes(csp)["device_walks"]
     keys = ["tx_flags", "tx_type", "tuple_tx", "tuple_kind", "tuple_status", "tuple_spans", "tuple_digest", "tuple_hashed", "tuple_qxy"]
     _same(host, fabgpu.preverify_block2(csp, blk, block_seq=3), keys)
@@ -936,11 +936,11 @@ def test_device_route_with_keys_carried_along(monkeypatch):
         csp = fabgpu.GPUCSP(device=0)
         try:
             csp._L.fabgpu_csp_identity_cache_limits(csp._h, 4096, tables, 1)
-            monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", str(1 << 40))
+            csp.set_option("pass_stage_min_bytes", 1 << 40)
             host_small = fabgpu.preverify_block2(csp, small, block_seq=1)
             host_big = fabgpu.preverify_block2(csp, big, block_seq=2)
             assert (host_small["tx_flags"] == want).all() and (host_big["tx_flags"] == 0).all()
-            monkeypatch.setenv("FABGPU_PASS_STAGE_MIN_BYTES", "1")
+            csp.set_option("pass_stage_min_bytes", 1)
             before = fabgpu.pass_routes(csp)["device_walks"]
             dev_small = fabgpu.preverify_block2(csp, small, block_seq=3)
             dev_big = fabgpu.preverify_block2(csp, big, block_seq=4, seed_memo=True)

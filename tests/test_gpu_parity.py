@@ -761,9 +761,9 @@ if %(mode)r == "launch":
         pass
 # the block pass, on both routes (the second call finds the identities cached and takes the device walk): an error, never flags
 import base64, json, os
-os.environ["FABGPU_PASS_STAGE_MIN_BYTES"] = "1"
 blk = next(base64.b64decode(b_["block_b64"]) for b_ in json.load(open(%(root)r + "/tests/golden/ledger_blocks.json"))["blocks"] if b_["source"] == "v20" and b_["number"] == 6)
 csp2 = fabgpu.GPUCSP(device=0)
+csp2.set_option("pass_stage_min_bytes", 1)
 for attempt in range(3):
     try:
         fabgpu.preverify_block(csp2, blk)
