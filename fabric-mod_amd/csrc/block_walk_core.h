@@ -533,14 +533,28 @@ WALK_HD inline uint8_t gate_sig_any(const uint8_t* sig, uint32_t siglen, uint8_t
 struct DerCursor {
     const uint8_t* p;
     const uint8_t* end;
+    // A WINDOW on a longer encoding (the device's certificate decoder keeps the first 3 KiB of a certificate in LDS, whatever its
+    // length): bytes from `limit` on are not there.  Lengths are still checked against `end` - the real extent - and a header that
+    // would have to be READ beyond the window sets *beyond and fails.  limit == nullptr: everything up to `end` is there.
+    const uint8_t* limit = nullptr;
+    bool* beyond = nullptr;
+    WALK_HD bool missing(const uint8_t* upto) const {      // true: bytes below `upto` lie outside the window
+        if (limit && upto > limit) {
+            if (beyond) *beyond = true;
+            return true;
+        }
+        return false;
+    }
     // reads one TLV header; on success tag / content / len describe it and p is advanced past the whole element
     WALK_HD bool tlv(uint8_t& tag, const uint8_t*& content, size_t& len) {
         if (end - p < 2) return false;
+        if (missing(p + 2)) return false;
         tag = *p++;
         size_t l = *p++;
         if (l & 0x80) {
             const int nb = (int)(l & 0x7F);
             if (nb == 0 || nb > 4 || end - p < nb) return false;
+            if (missing(p + nb)) return false;
             l = 0;
             for (int i = 0; i < nb; i++) l = (l << 8) | *p++;
         }
@@ -556,34 +570,47 @@ WALK_HD inline bool der_bytes_equal(const uint8_t* a, const uint8_t* b, size_t n
     for (size_t i = 0; i < n; i++) same = same && a[i] == b[i];
     return same;
 }
-WALK_HD inline int32_t cert_der_p256_key_offset(const uint8_t* der, size_t len) {
+// `avail` <= len: how many of the certificate's `len` bytes are at `der` (a window, see DerCursor).  Returns the offset of X, -1
+// (not a certificate with a P-256 key), or -2: the answer depends on bytes beyond the window.
+WALK_HD inline int32_t cert_der_p256_key_offset_window(const uint8_t* der, size_t avail, size_t len) {
     const uint8_t OID_EC_PUBLIC_KEY[7] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x02, 0x01};          // 1.2.840.10045.2.1
     const uint8_t OID_PRIME256V1[8] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x03, 0x01, 0x07};       // 1.2.840.10045.3.1.7
-    DerCursor top{der, der + len};
+    bool beyond = false;
+    const uint8_t* const lim = avail < len ? der + avail : nullptr;
+#define FAB_DER_FAIL return beyond ? -2 : -1
+    DerCursor top{der, der + len, lim, &beyond};
     uint8_t tag;
     const uint8_t* c;
     size_t l;
-    if (!top.tlv(tag, c, l) || tag != 0x30) return -1;             // Certificate
-    DerCursor cert{c, c + l};
-    if (!cert.tlv(tag, c, l) || tag != 0x30) return -1;            // TBSCertificate
-    DerCursor tbs{c, c + l};
-    if (!tbs.tlv(tag, c, l)) return -1;
+    if (!top.tlv(tag, c, l) || tag != 0x30) FAB_DER_FAIL;          // Certificate
+    DerCursor cert{c, c + l, lim, &beyond};
+    if (!cert.tlv(tag, c, l) || tag != 0x30) FAB_DER_FAIL;         // TBSCertificate
+    DerCursor tbs{c, c + l, lim, &beyond};
+    if (!tbs.tlv(tag, c, l)) FAB_DER_FAIL;
     if (tag == 0xA0) {                                             // [0] version (absent in v1 certificates)
-        if (!tbs.tlv(tag, c, l)) return -1;
+        if (!tbs.tlv(tag, c, l)) FAB_DER_FAIL;
     }
-    if (tag != 0x02) return -1;                                    // serialNumber
+    if (tag != 0x02) FAB_DER_FAIL;                                 // serialNumber
     for (int k = 0; k < 4; k++)                                    // signature, issuer, validity, subject
-        if (!tbs.tlv(tag, c, l) || tag != 0x30) return -1;
-    if (!tbs.tlv(tag, c, l) || tag != 0x30) return -1;             // subjectPublicKeyInfo
-    DerCursor spki{c, c + l};
-    if (!spki.tlv(tag, c, l) || tag != 0x30) return -1;            // AlgorithmIdentifier
-    DerCursor alg{c, c + l};
-    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != 7 || !der_bytes_equal(c, OID_EC_PUBLIC_KEY, 7)) return -1;
-    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != 8 || !der_bytes_equal(c, OID_PRIME256V1, 8)) return -1;
-    if (!spki.tlv(tag, c, l) || tag != 0x03) return -1;            // BIT STRING: 00 04 X Y
-    if (l != 66 || c[0] != 0x00 || c[1] != 0x04) return -1;
+        if (!tbs.tlv(tag, c, l) || tag != 0x30) FAB_DER_FAIL;
+    if (!tbs.tlv(tag, c, l) || tag != 0x30) FAB_DER_FAIL;          // subjectPublicKeyInfo
+    DerCursor spki{c, c + l, lim, &beyond};
+    if (!spki.tlv(tag, c, l) || tag != 0x30) FAB_DER_FAIL;         // AlgorithmIdentifier
+    DerCursor alg{c, c + l, lim, &beyond};
+    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != 7) FAB_DER_FAIL;
+    if (alg.missing(c + 7)) return -2;
+    if (!der_bytes_equal(c, OID_EC_PUBLIC_KEY, 7)) return -1;
+    if (!alg.tlv(tag, c, l) || tag != 0x06 || l != 8) FAB_DER_FAIL;
+    if (alg.missing(c + 8)) return -2;
+    if (!der_bytes_equal(c, OID_PRIME256V1, 8)) return -1;
+    if (!spki.tlv(tag, c, l) || tag != 0x03) FAB_DER_FAIL;         // BIT STRING: 00 04 X Y
+    if (l != 66) return -1;
+    if (spki.missing(c + 66)) return -2;
+    if (c[0] != 0x00 || c[1] != 0x04) return -1;
     return (int32_t)(c + 2 - der);
+#undef FAB_DER_FAIL
 }
+WALK_HD inline int32_t cert_der_p256_key_offset(const uint8_t* der, size_t len) { return cert_der_p256_key_offset_window(der, len, len); }
 // PEM text -> the class of one character, as PemToDer (block_prepass.cpp) reads the body of a certificate block: a base64 digit (its
 // value), something it skips ('=', line ends, blanks), the dash that ends the body, or a character that makes the block invalid
 enum : int { PEM_SKIP = 64, PEM_DASH = 65, PEM_INVALID = 66 };

@@ -233,7 +233,11 @@ __device__ __forceinline__ uint8_t wave_gate_sig_any(const uint8_t* sig, uint32_
 //   4. walk::cert_der_p256_key_offset over those bytes - the host decoder's own lines;
 //   5. x, y < p and y^2 = x^3 - 3x + b (on_curve29).
 // IDC_P256: key_byte = this lane's byte of X || Y.  IDC_NOT / IDC_NOT_CERT: the host says "not a P-256 certificate identity" too
-// (bccsp/sw decides: other curves / no certificate block at all - idemix, garbage).  IDC_UNDECIDED: more base64 digits than the LDS buffer holds - the only case the host must repair.
+// (bccsp/sw decides: other curves / no certificate block at all - idemix, garbage).  A certificate of ANY length is decided from its
+// first 3 KiB of DER (the digits behind them are classified and counted, not kept); IDC_UNDECIDED is left for a certificate whose
+// SubjectPublicKeyInfo starts beyond that window (kilobytes of issuer / subject names): that one tuple is TUPLE_ST_NEEDS_SW - its
+// transaction flag 4, no memo entry - and the block stays on the device route (round 3 sent the whole block to the host walk:
+// core/common/validation/msgvalidation.go:258-298 treats a creator per transaction, and so must the pass).
 // Called by all 64 lanes of a wavefront, with an LDS buffer of its own.
 constexpr uint32_t IDFIX_MAX_DIGITS = 4096;                             // 3 KiB of DER
 // One wavefront owns its LDS buffer: its LDS instructions execute in order, so all that is needed between "these lanes wrote" and
@@ -289,16 +293,21 @@ __device__ uint8_t wave_identity_to_p256(const uint8_t* ident, uint32_t len, uin
             const bool digit = act && cls[r] < 64;
             const uint64_t dig = __ballot(digit);
             const uint32_t rank = total + (uint32_t)__builtin_popcountll(dig & ((1ull << lane) - 1ull));
-            if (__ballot(digit && rank >= IDFIX_MAX_DIGITS)) return IDC_UNDECIDED;
-            if (digit) lds[rank] = (uint8_t)cls[r];
+            // (digits beyond the buffer are classified and counted - the certificate's length enters the DER walk - but not kept: what
+            //  the walk needs, everything up to SubjectPublicKeyInfo, lies at the front)
+            if (digit && rank < IDFIX_MAX_DIGITS) lds[rank] = (uint8_t)cls[r];
             total += (uint32_t)__builtin_popcountll(dig);
+            // (a lone wavefront reading on through megabytes of PEM would hold the whole gate kernel up: beyond four windows - 12 KiB of
+            //  DER, several times any real certificate - the tuple is left to bccsp/sw)
+            if (total > 4 * IDFIX_MAX_DIGITS) return IDC_UNDECIDED;
             if (dash) end_pos = base + 64 * r + limit;
         }
     }
     if (end_pos == 0xFFFFFFFFu || end_pos + 25 > pl) return IDC_NOT;
     if (__ballot(lane < 25 && pem[end_pos + (lane < 25 ? lane : 0)] != (uint8_t)C_PEM_END[lane < 25 ? lane : 0])) return IDC_NOT;
-    const uint32_t nder = total * 6 / 8;
-    if (nder == 0) return IDC_NOT;
+    const uint32_t nder_all = total * 6 / 8;                             // bytes of the whole certificate
+    const uint32_t nder = (total < IDFIX_MAX_DIGITS ? total : IDFIX_MAX_DIGITS) * 6 / 8;   // ... of which so many are decoded into LDS
+    if (nder_all == 0) return IDC_NOT;
     wave_lds_sync();
     for (uint32_t j0 = 0; j0 < nder; j0 += 64) {
         const uint32_t j = j0 + lane;
@@ -311,7 +320,8 @@ __device__ uint8_t wave_identity_to_p256(const uint8_t* ident, uint32_t len, uin
         if (j < nder) lds[j] = (uint8_t)byte;
     }
     wave_lds_sync();
-    const int32_t at = cert_der_p256_key_offset(lds, nder);
+    const int32_t at = cert_der_p256_key_offset_window(lds, nder, nder_all);
+    if (at == -2) return IDC_UNDECIDED;                                  // SubjectPublicKeyInfo beyond the first 3 KiB of DER: bccsp/sw decides THIS tuple
     if (at < 0) return IDC_NOT;
     u256 x, y;
     from_be32(x, lds + at);

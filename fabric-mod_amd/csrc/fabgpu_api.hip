@@ -2041,7 +2041,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (err != hipSuccess) return hip_to_rc(err);
     if ((rc = finish())) return rc;
     if (rq.summary.n_outline_differs) return decline("the device's walk of an envelope differs from the host's outline of it (creator message span, or the counts)");
-    if (rq.summary.n_undecided) return decline("a certificate beyond the device decoder's buffer");
+    // (summary.n_undecided - certificates whose key lies beyond the decoder's window - are TUPLE_ST_NEEDS_SW tuples of their own
+    //  transactions, not a reason to give the block up)
     if (rq.summary.n_submitted == 0) return decline("no tuple for the device to decide");
     {
         // Was "keyed" a wrong guess for a class?  Then its rows ran against filler tables: launch it again with the keys carried along

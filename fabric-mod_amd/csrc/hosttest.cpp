@@ -14,6 +14,8 @@
 #include "p256_tables29.h"
 #include "multi_plan.h"
 #include "coalescer.h"
+#include "pass_route.h"
+#include "block_walk_core.h"
 
 using namespace fab;
 
@@ -411,5 +413,12 @@ void hosttest_bn_tab16_entry(const uint8_t* bx32, const uint8_t* by32, int windo
     fe_from_mont(py, y);
     to_be32(x32, px);
     to_be32(y32, py);
+}
+// the provider's pass routing (pass_route.h): which of n_devices contexts a block pass named block_seq goes to
+int hosttest_route_block(uint64_t block_seq, const uint32_t* in_flight, int n_devices) { return route_block(block_seq, in_flight, n_devices); }
+// The certificate walk of the device route over a WINDOW of the DER (block_walk_core.h cert_der_p256_key_offset_window): `avail` of the
+// certificate's `len` bytes are readable.  Offset of X, -1 not a P-256 certificate, -2 the answer needs bytes beyond the window.
+int hosttest_cert_key_offset_window(const uint8_t* der, size_t avail, size_t len) {
+    return (int)bccsp::walk::cert_der_p256_key_offset_window(der, avail, len);
 }
 }

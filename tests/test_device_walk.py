@@ -285,9 +285,49 @@ def _identity_cases():
         for _ in range(int(rng.integers(1, 3))):
             m[int(rng.integers(0, m.size))] = np.uint8(rng.integers(0, 256))
         out.append(sid("Org1MSP", pem(m.tobytes())))
-    # a certificate beyond the device decoder's buffer (4096 base64 digits): the one thing it leaves to the host
-    out.append(sid("Org1MSP", pem(d0[:4] + d0[4:] + bytes(3100))))
+    # certificates longer than the device decoder's window (4096 base64 digits = 3 KiB of DER): decided all the same when the key lies
+    # inside the window (here: bytes behind the Certificate) ...
+    out.append(sid("Org1MSP", pem(d0 + bytes(3100))))
+    out.append(sid("Org1MSP", pem(_cert_with_long_issuer(d0, 1500))))         # (a long issuer name that still fits)
+    # ... and the one thing it leaves to bccsp/sw: SubjectPublicKeyInfo BEYOND the window (kilobytes of issuer name in front of it)
+    out.append(sid("Org1MSP", pem(_cert_with_long_issuer(d0, 3300))))
     return out
+
+
+def _der_tlv(b, at):
+    """(tag, header length, content length) of the DER element at b[at:]"""
+    l = b[at + 1]
+    if l < 0x80:
+        return b[at], 2, l
+    nb = l & 0x7F
+    return b[at], 2 + nb, int.from_bytes(b[at + 2:at + 2 + nb], "big")
+
+
+def _der_wrap(tag, content):
+    n = len(content)
+    if n < 0x80:
+        return bytes([tag, n]) + content
+    k = (n.bit_length() + 7) // 8
+    return bytes([tag, 0x80 | k]) + n.to_bytes(k, "big") + content
+
+
+def _cert_with_long_issuer(der, pad):
+    """the certificate with `pad` more bytes (an extra RDN set full of zeros) inside its issuer Name: what stands behind the issuer -
+    validity, subject, SubjectPublicKeyInfo - moves back by about that much.  The signature no longer matches, which no key
+    extraction looks at."""
+    _, h0, _ = _der_tlv(der, 0)
+    _, h1, l1 = _der_tlv(der, h0)
+    tbs = der[h0 + h1:h0 + h1 + l1]
+    rest = der[h0 + h1 + l1:]
+    at, parts = 0, []
+    while at < len(tbs):
+        t, h, l = _der_tlv(tbs, at)
+        parts.append(tbs[at:at + h + l])
+        at += h + l
+    k = 3 if parts[0][0] == 0xA0 else 2                                      # [0] version, serial, signature, ISSUER
+    _, h, l = _der_tlv(parts[k], 0)
+    parts[k] = _der_wrap(0x30, parts[k][h:h + l] + _der_wrap(0x31, bytes(pad)))
+    return _der_wrap(0x30, _der_wrap(0x30, b"".join(parts)) + rest)
 
 
 def test_identity_table_hash_restated():
@@ -359,11 +399,12 @@ def test_wavefront_signature_gate_equals_the_lane_form(csp):
 def test_device_identity_decoder_equals_the_host_decoder(csp):
     """A wavefront per identity: SerializedIdentity -> PEM (any line layout) -> DER -> SubjectPublicKeyInfo -> curve membership.  Same
     answer as the host route's IdentityToP256 + PublicKeyOnCurve on the reference's 102 certificate fixtures (P-256, P-384 ...), on
-    re-wrapped / broken armour, on 2 000 mutants of text and DER, on non-certificates; only a certificate beyond its buffer is left
-    undecided."""
+    re-wrapped / broken armour, on 2 000 mutants of text and DER, on non-certificates, on certificates longer than its 3 KiB window; only
+    a certificate whose key lies beyond that window is left undecided."""
     cases = _identity_cases()
     code, key = fabgpu.idfix_probe(csp, cases)
     n_key = n_not = 0
+    assert fabgpu.identity_to_p256(cases[-2]) is not None and fabgpu.identity_to_p256(cases[-3]) is not None
     for i, ident in enumerate(cases[:-1]):
         want = fabgpu.identity_to_p256(ident)
         if want is None:
@@ -786,19 +827,40 @@ def test_idemix_creators_on_the_device_route(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_a_certificate_beyond_the_device_decoder_is_left_to_the_host_walk(csp, monkeypatch):
-    """The one thing the device route still declines: an identity whose PEM body exceeds the decoder's buffer (4096 base64 digits) -
-    the host walk answers, with the reference's answer."""
+def test_a_certificate_beyond_the_device_decoders_window_costs_its_own_transactions_only(csp, monkeypatch):
+    """Round 3 declined the whole block for ONE identity whose PEM body exceeded the decoder's buffer (4 096 base64 digits): anybody who
+    can submit a transaction could send every block down the 3.3x slower host walk.  Now the device decodes a certificate of any length
+    from its first 3 KiB of DER, and the one case it cannot decide - SubjectPublicKeyInfo beyond that window - is that TUPLE's
+    TUPLE_ST_NEEDS_SW (its transaction: flag 4, no memo entry; bccsp/sw decides, as core/common/validation/msgvalidation.go:258-298
+    treats a creator per transaction): the block stays on the device route either way."""
     import blockgen
     fx = blockgen.fixture_signers()
-    d = blockgen._IDS[4]["d"]
-    big = bb.serialized_identity("Org1MSP", blockgen._pem_wrap(blockgen._pem_der(blockgen._IDS[4]["pem"]) + bytes(3100)))   # (bytes behind the Certificate: ignored)
-    blk, _ = blockgen.endorser_block(12, 3, creators=[(big, int(d, 16).to_bytes(32, "big")), fx[5]])
+    d32 = int(blockgen._IDS[4]["d"], 16).to_bytes(32, "big")
+    der = blockgen._pem_der(blockgen._IDS[4]["pem"])
     csp.set_option("pass_stage_min_bytes", 1)
+    # (a) bytes behind the Certificate (ignored by every decoder): longer than the window, decided all the same
+    padded = bb.serialized_identity("Org1MSP", blockgen._pem_wrap(der + bytes(3100)))
+    blk, _ = blockgen.endorser_block(12, 3, creators=[(padded, d32), fx[5]])
     out = fabgpu.preverify_block2(csp, blk, block_seq=1)
     r = fabgpu.pass_routes(csp)
-    assert r["device_walks"] == 0 and "decoder" in r["last_decline"], r
+    assert r["device_walks"] == 1 and r["host_walks"] == 0, r
     assert (out["tx_flags"] == 0).all() and (out["tuple_status"] == 0).all()
+    # (b) the key beyond the window: transactions 0, 2, 4 ... (that creator's) are left to bccsp/sw, everything else is decided
+    far = bb.serialized_identity("Org1MSP", blockgen._pem_wrap(_cert_with_long_issuer(der, 3300)))
+    assert fabgpu.identity_to_p256(far) is not None                          # (the host decoder reads it)
+    blk2, _ = blockgen.endorser_block(12, 4, creators=[(far, d32), fx[5]])
+    out2 = fabgpu.preverify_block2(csp, blk2, block_seq=2, seed_memo=True)
+    r = fabgpu.pass_routes(csp)
+    assert r["device_walks"] == 2 and r["host_walks"] == 0, r
+    assert list(out2["tx_flags"]) == [fabgpu.TX_NEEDS_SW if t % 2 == 0 else 0 for t in range(12)]
+    creators = out2["tuple_kind"] == 0
+    assert (out2["tuple_status"][creators & (out2["tuple_tx"] % 2 == 0)] == fabgpu.TUPLE_ST_NEEDS_SW).all()
+    assert (out2["tuple_status"][~(creators & (out2["tuple_tx"] % 2 == 0))] == 0).all()
+    assert out2["memo_seeded"] == int((out2["tuple_status"] == 0).sum())    # no memo entry for what was not decided
+    # the host route reads the whole certificate and verifies those creators itself: every transaction valid
+    csp.set_option("pass_stage_min_bytes", 1 << 40)
+    host = fabgpu.preverify_block2(csp, blk2, block_seq=3)
+    assert (host["tx_flags"] == 0).all() and (host["tuple_status"] == 0).all()
 
 
 @pytest.mark.gpu

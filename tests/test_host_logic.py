@@ -347,3 +347,86 @@ def test_coalescer_of_one_signature_calls(hosttest):
     # every third launch fails: its callers see the failure, nobody sees a wrong answer
     assert f(12, 30, 100, 0, 32768, 3, ctypes.byref(launches), ctypes.byref(largest), ctypes.byref(failed)) == 0
     assert 0 < failed.value < 12 * 30
+
+
+def test_pass_routing_spreads_blocks_over_the_pool(hosttest):
+    """pass_route.h (GPUCSP::RouteBlock): the device with the fewest passes in flight, ties broken round the ring from block_seq mod G.
+    The reference has ONE process-global BCCSP (bccsp/factory/factory.go:41-55) whose callers - the channels of a peer - arrive side by
+    side (core/committer/txvalidator/v20/validator.go:194-210): the provider, not its callers, spreads them over the node's GPUs."""
+    route = hosttest.hosttest_route_block
+    route.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+
+    def r(seq, fl):
+        return route(seq, (ctypes.c_uint32 * len(fl))(*fl), len(fl))
+    assert r(12345, [7]) == 0                                                  # one device: always it
+    for G in (2, 3, 8):
+        assert [r(s, [0] * G) for s in range(2 * G)] == [s % G for s in range(2 * G)]           # idle pool: round the ring by name
+        for busy in range(G):                                                  # one idle device among busy ones always wins
+            fl = [2] * G
+            fl[busy] = 0
+            assert all(r(s, fl) == busy for s in range(3 * G))
+        # ties among the least busy: the first one round the ring from seq mod G
+        fl = [1, 0] + [1] * (G - 2) if G > 2 else [1, 1]
+        if G > 2:
+            fl[-1] = 0
+            assert r(2, fl) == G - 1 and r(0, fl) == 1 and r(1, fl) == 1
+    # a long run of arrivals that each stay in flight: every device ends up with the same load
+    G, fl = 8, [0] * 8
+    rng = np.random.default_rng(5)
+    for _ in range(800):
+        fl[r(int(rng.integers(0, 1 << 62)), fl)] += 1
+    assert fl == [100] * 8
+    # passes come and go (each arrival finds the previous arrivals' devices busy, a random one finishes): never more than one apart
+    fl = [0] * 8
+    for k in range(4000):
+        fl[r(int(rng.integers(0, 1 << 62)), fl)] += 1
+        if k >= 8:
+            busy = [g for g in range(8) if fl[g]]
+            fl[busy[int(rng.integers(0, len(busy)))]] -= 1
+        assert max(fl) - min(fl) <= 2, fl
+
+
+def test_certificate_walk_over_a_window_of_the_der(hosttest):
+    """The device's certificate decoder keeps the first 3 KiB of a certificate's DER and walks it with the real length in hand
+    (block_walk_core.h cert_der_p256_key_offset_window).  Over every certificate fixture of the reference and every window size: the
+    answer is the whole-certificate answer, or -2 ("needs bytes beyond the window") - never a different key offset, never a wrong
+    "no key"; and once the window reaches the end of SubjectPublicKeyInfo it IS the whole-certificate answer."""
+    import base64
+    fn = hosttest.hosttest_cert_key_offset_window
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t]
+    chains = json.load(open(os.path.join(G, "ref_cert_chains.json")))
+    ders = [base64.b64decode(v) for _, v in sorted(chains["certs"].items())]
+    n_key = n_not = 0
+    for der in ders:
+        full = fn(der, len(der), len(der))
+        assert full >= -1
+        n_key += full >= 0
+        n_not += full < 0
+        padded = der + bytes(5000)                                             # bytes behind the Certificate change nothing
+        assert fn(padded, len(padded), len(padded)) == full
+        seen_decided = False
+        for avail in list(range(0, min(len(der), 700))) + [len(der) - 1, len(der)]:
+            got = fn(der, avail, len(der))
+            assert got in (full, -2), (avail, got, full)
+            if full >= 0:
+                assert (got == full) == (avail >= full + 64), (avail, got, full)   # decided exactly when X || Y is inside the window
+            if got != -2:
+                seen_decided = True
+            elif seen_decided:
+                raise AssertionError("a larger window must not take a decided answer back")
+        # truncated certificates (len < the real length): a length that does not cover the encoding is "no key", window or not
+        for cut in (1, 10, len(der) // 2):
+            assert fn(der, len(der) - cut, len(der) - cut) == -1
+    assert n_key > 60, (n_key, n_not)
+    # certificates WITHOUT a P-256 key (another curve's OID, a broken BIT STRING header): "no key" or "needs more", never a key
+    for der in ders[:20]:
+        at = fn(der, len(der), len(der))
+        for delta, val in ((-4, 0x22), (-1, 0x05), (-2, 0x01), (-11, 0x2B)):   # inside prime256v1's OID / the 00 04 prefix / the lengths in front
+            m = bytearray(der)
+            m[at + delta] = val
+            full = fn(bytes(m), len(m), len(m))
+            assert full == -1, (delta, full)
+            for avail in range(0, at + 80, 7):
+                assert fn(bytes(m), avail, len(m)) in (-1, -2)
+            n_not += 1
+    assert n_not >= 80
