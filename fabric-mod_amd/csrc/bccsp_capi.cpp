@@ -424,6 +424,11 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     ps->memo_seeded = v.memo_seeded;
     ps->n_keyed = (uint32_t)v.n_keyed;
     ps->n_device_decoded = done ? v.n_device_decoded : 0;
+    ps->ms_stage[0] = (float)v.ms_gates;
+    ps->ms_stage[1] = (float)v.ms_upload_wait;
+    ps->ms_stage[2] = (float)v.ms_device;
+    ps->ms_stage[3] = (float)(done ? v.ms_post : v.ms_memo);
+    ps->device_context = up.dev;
     return FABGPU_OK;
 }
 

@@ -71,7 +71,7 @@ class _BlockPass(ctypes.Structure):
                 ("tx_flags", ctypes.c_void_p), ("tx_type", ctypes.c_void_p), ("tuple_tx", ctypes.c_void_p), ("tuple_kind", ctypes.c_void_p),
                 ("tuple_status", ctypes.c_void_p), ("tuple_spans", ctypes.c_void_p), ("tuple_digest", ctypes.c_void_p),
                 ("tuple_hashed", ctypes.c_void_p), ("tuple_qxy", ctypes.c_void_p), ("tail", ctypes.c_void_p), ("tail_cap", ctypes.c_uint32),
-                ("n_keyed", ctypes.c_uint32), ("n_device_decoded", ctypes.c_uint32)]
+                ("n_keyed", ctypes.c_uint32), ("n_device_decoded", ctypes.c_uint32), ("ms_stage", ctypes.c_float * 4), ("device_context", ctypes.c_int32)]
 
 
 class _CspOpts(ctypes.Structure):
@@ -1051,7 +1051,7 @@ def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo:
                 continue
             _check(rc, "fabgpu_csp_block_preverify2")
             return dict(tx_flags=flags[:ps.n_tx], n_tuples=ps.n_tuples, n_block_sigs=ps.n_block_sigs, memo_seeded=ps.memo_seeded, n_keyed=ps.n_keyed,
-                        n_device_decoded=ps.n_device_decoded)
+                        n_device_decoded=ps.n_device_decoded, ms_stage=[float(x) for x in ps.ms_stage], device_context=int(ps.device_context))
     cap_tx, cap_tu = getattr(csp, "_pass_caps", (1024, 4096))
     tail_cap = 1 << 16
     while True:
@@ -1074,7 +1074,7 @@ def preverify_block2(csp: "GPUCSP", block: bytes, block_seq: int = 0, seed_memo:
         nt, nu = ps.n_tx, ps.n_tuples
         out = {k: (v[:nt].copy() if k.startswith("tx_") else v[:nu].copy()) for k, v in a.items() if k != "tail"}
         out.update(n_block_sigs=ps.n_block_sigs, block_sigs_understood=bool(ps.block_sigs_understood), memo_seeded=ps.memo_seeded, n_keyed=ps.n_keyed,
-                   n_device_decoded=ps.n_device_decoded, arena=bytes(block) + b"\0" * (ps.tail_base - len(block)) + bytes(a["tail"][:ps.tail_len]))
+                   n_device_decoded=ps.n_device_decoded, ms_stage=[float(x) for x in ps.ms_stage], device_context=int(ps.device_context), arena=bytes(block) + b"\0" * (ps.tail_base - len(block)) + bytes(a["tail"][:ps.tail_len]))
         return out
 
 

@@ -21,7 +21,21 @@ const (
 
 // GPUOpts is the `GPU:` section of the BCCSP configuration.
 type GPUOpts struct {
-	Device int `mapstructure:"device" json:"device" yaml:"Device"` // HIP device ordinal; -1 = the current device
+	// Devices: the HIP ordinals this node's ONE provider drives, one device context each (an ordinal may repeat: several contexts on
+	// one GPU).  Empty = every visible device.  factory.GetDefault() is process-global (bccsp/factory/factory.go:41-55) and every
+	// channel's validator receives it (core/peer/peer.go:337-355), so "one provider per device" cannot be configured - one provider
+	// owns them all and routes each block pass to the least busy device (fabgpu_csp_new2, include/fabgpu_bccsp.h).
+	Devices []int `mapstructure:"devices" json:"devices" yaml:"Devices"`
+	// ConcurrentPasses: per device, how many overlapping block passes to allocate for when the provider is made (staging slots, pinned
+	// memo tables, pass arrays) instead of when passes first overlap.  2 suits the arrival pipeline of one channel per device.
+	ConcurrentPasses int `mapstructure:"concurrentpasses" json:"concurrentpasses" yaml:"ConcurrentPasses"`
+	// ExpectBlockBytes / ExpectTuples size that pre-allocation; 0 = 64 MiB / 65 536 signatures (configtx.yaml AbsoluteMaxBytes and
+	// MaxMessageCount x (1 + endorsements) are the numbers to put here).
+	ExpectBlockBytes int `mapstructure:"expectblockbytes" json:"expectblockbytes" yaml:"ExpectBlockBytes"`
+	ExpectTuples     int `mapstructure:"expecttuples" json:"expecttuples" yaml:"ExpectTuples"`
+	// HostWalk keeps the envelope walk of the block pass on the host (A/B runs); PassTiming prints every pass's stage breakdown.
+	HostWalk   bool `mapstructure:"hostwalk" json:"hostwalk" yaml:"HostWalk"`
+	PassTiming bool `mapstructure:"passtiming" json:"passtiming" yaml:"PassTiming"`
 	// CoalesceVerify: Verify calls that miss the verdict memo share device launches with whatever other misses are in flight
 	// (fabgpu_csp_verify_coalesced).  For the orderer (General.BCCSP in orderer.yaml): its Broadcast handlers reach
 	// identity.Verify one message per goroutine behind SigFilter and no block pass precedes them.  Leave it off on peers.
@@ -47,11 +61,12 @@ func (f *GPUFactory) Get(config *FactoryOpts) (bccsp.BCCSP, error) {
 	if err != nil {
 		return nil, errors.Wrapf(err, "Failed initializing the software BCCSP behind the GPU provider")
 	}
-	device := -1
-	if config.GPUOpts != nil {
-		device = config.GPUOpts.Device
+	var opts gpu.Options
+	if g := config.GPUOpts; g != nil {
+		opts = gpu.Options{Devices: g.Devices, ConcurrentPasses: g.ConcurrentPasses, ExpectBlockBytes: g.ExpectBlockBytes,
+			ExpectTuples: g.ExpectTuples, HostWalk: g.HostWalk, PassTiming: g.PassTiming}
 	}
-	csp, err := gpu.New(swCSP, device)
+	csp, err := gpu.New(swCSP, opts)
 	if err != nil {
 		return nil, err
 	}

@@ -65,10 +65,14 @@ import (
 	"crypto/elliptic"
 	"crypto/x509"
 	"math/big"
+	"strconv"
 	"sync"
+	"sync/atomic"
+	"time"
 	"unsafe"
 
 	"github.com/hyperledger/fabric/bccsp"
+	"github.com/hyperledger/fabric/common/metrics"
 	"github.com/pkg/errors"
 )
 
@@ -85,6 +89,22 @@ type Provider struct {
 	// orderer (Broadcast handlers behind SigFilter, orderer/common/msgprocessor/sigfilter.go:50-80).  Off by default: a
 	// lone call costs a launch (0.7 ms) where bccsp/sw costs 0.1 ms; the break-even is about sixteen calls in flight.
 	coalesce bool
+	// room for per-transaction flags, remembered from block to block (atomic max): the library answers FABGPU_ETOOBIG - before it has
+	// waited for the upload or launched anything, and the retry finds its upload again - only when a block outgrows every block before it
+	capTx uint32
+	m     *passMetrics // nil until RegisterMetrics
+}
+
+// Options is what GPUFactory reads from the `GPU:` section of the BCCSP configuration (bccsp/factory/gpufactory.go GPUOpts) - the
+// fabgpu_csp_opts of include/fabgpu_bccsp.h.  The reference has ONE process-global BCCSP (bccsp/factory/factory.go:41-55) that every
+// channel's validator shares (core/peer/peer.go:337-355): it owns every device listed here and spreads the block passes over them.
+type Options struct {
+	Devices          []int // HIP ordinals, one device context each (an ordinal may repeat); empty: every visible device
+	ConcurrentPasses int   // per device: staging slots, pinned memo tables and pass arrays for that many overlapping passes are allocated now
+	ExpectBlockBytes int   // sizes that pre-allocation (0: 64 MiB) ...
+	ExpectTuples     int   // ... (0: 65 536 signatures per block)
+	HostWalk         bool  // keep the envelope walk on the host (A/B runs)
+	PassTiming       bool  // stage breakdown of every pass on stderr
 }
 
 // SetCoalesce switches the coalesced device path for memo misses on or off (GPUOpts.CoalesceVerify in gpufactory.go).
@@ -148,18 +168,59 @@ func (s *keyXY) get(ski []byte) (xy [64]byte, ok bool) {
 	return xy, ok
 }
 
-// New is what bccsp/factory calls for ProviderName "GPU" (gpufactory.go).  device < 0: the current HIP device.
-func New(swCSP bccsp.BCCSP, device int) (bccsp.BCCSP, error) {
+// New is what bccsp/factory calls for ProviderName "GPU" (gpufactory.go): ONE provider over every device of opts.Devices.
+func New(swCSP bccsp.BCCSP, opts Options) (bccsp.BCCSP, error) {
 	if swCSP == nil {
 		return nil, errors.New("Invalid software BCCSP. It must not be nil.")
 	}
-	cfg := C.fabgpu_cfg{device: C.int32_t(device)}
+	var o C.fabgpu_csp_opts // zeroed: every switch at its default
+	o.size = C.uint32_t(unsafe.Sizeof(o))
+	o.n_devices = C.int32_t(len(opts.Devices))
+	var devs *C.int32_t
+	if len(opts.Devices) != 0 { // the ordinals live in C memory for the call (cgo: no Go pointer inside a struct handed to C)
+		devs = (*C.int32_t)(C.malloc(C.size_t(4 * len(opts.Devices))))
+		defer C.free(unsafe.Pointer(devs))
+		arr := (*[1 << 16]C.int32_t)(unsafe.Pointer(devs))
+		for i, d := range opts.Devices {
+			arr[i] = C.int32_t(d)
+		}
+		o.devices = devs
+	}
+	o.concurrent_passes = C.uint32_t(opts.ConcurrentPasses)
+	o.expect_block_bytes = C.uint64_t(opts.ExpectBlockBytes)
+	o.expect_tuples = C.uint32_t(opts.ExpectTuples)
+	if opts.HostWalk {
+		o.pass_device_walk = -1
+	}
+	if opts.PassTiming {
+		o.pass_timing = 1
+	}
 	var csp *C.fabgpu_csp
 	errbuf := make([]byte, 256)
-	if rc := C.fabgpu_csp_new(&cfg, &csp, (*C.char)(unsafe.Pointer(&errbuf[0])), C.size_t(len(errbuf))); rc != 0 {
-		return nil, errors.Errorf("Failed initializing GPU BCCSP: %s", C.GoString(C.fabgpu_strerror(rc)))
+	if rc := C.fabgpu_csp_new2(&o, &csp, (*C.char)(unsafe.Pointer(&errbuf[0])), C.size_t(len(errbuf))); rc != 0 {
+		return nil, errors.Errorf("Failed initializing GPU BCCSP: %s (%s)", C.GoString(C.fabgpu_strerror(rc)), C.GoString((*C.char)(unsafe.Pointer(&errbuf[0]))))
 	}
-	return &Provider{BCCSP: swCSP, csp: csp}, nil
+	return &Provider{BCCSP: swCSP, csp: csp, capTx: 1024}, nil
+}
+
+// Devices: how many device contexts this provider drives.
+func (p *Provider) Devices() int { return int(C.fabgpu_csp_device_count(p.csp)) }
+
+// PassesPerDevice: block passes each device context has served (metrics).
+func (p *Provider) PassesPerDevice() []uint64 {
+	n := p.Devices()
+	if n <= 0 {
+		return nil
+	}
+	v := make([]C.uint64_t, n)
+	if int(C.fabgpu_csp_passes_per_device(p.csp, &v[0], C.int(n))) != n {
+		return nil
+	}
+	out := make([]uint64, n)
+	for i := range v {
+		out[i] = uint64(v[i])
+	}
+	return out
 }
 
 // Close releases the device context (tests; a peer keeps its BCCSP for life).
@@ -278,21 +339,35 @@ func (p *Provider) PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSumm
 		p.inflight.Delete(blockSeq)
 		close(done)
 	}()
-	capTx, capTuples := C.uint32_t(1024), C.uint32_t(8192)
+	// Room for the flags: what the largest block so far needed (atomic max).  No per-tuple array is asked for, so the tuple capacity is
+	// not checked at all; FABGPU_ETOOBIG can only mean "more transactions than any block before" - it is answered from the host's outline
+	// of the block, before the upload is waited for or anything is launched, and the retry below (same buffer, length and name) finds
+	// its upload again inside the library: growing costs the outline (0.15 ms per 10 000 transactions), once.
+	start := time.Now()
 	for attempt := 0; attempt < 3; attempt++ {
+		capTx := atomic.LoadUint32(&p.capTx)
 		flags := make([]uint8, capTx) // the only array this caller wants back; the memo lives behind the ABI
 		var nTx, nTuples, nBlockSigs, seeded C.uint32_t
 		rc := C.fabgpu_go_block_pass(p.csp, (*C.uint8_t)(unsafe.Pointer(&blockBytes[0])), C.size_t(len(blockBytes)), C.uint64_t(blockSeq),
-			C.FABGPU_PASS_SEED_MEMO, (*C.uint8_t)(unsafe.Pointer(&flags[0])), capTx, capTuples, &nTx, &nTuples, &nBlockSigs, &seeded)
-		if rc == C.FABGPU_ETOOBIG { // counts are set, nothing was launched
-			capTx, capTuples = nTx+16, nTuples+64
+			C.FABGPU_PASS_SEED_MEMO, (*C.uint8_t)(unsafe.Pointer(&flags[0])), C.uint32_t(capTx), 0, &nTx, &nTuples, &nBlockSigs, &seeded)
+		if rc == C.FABGPU_ETOOBIG { // n_tx is set; nothing was launched, the upload is kept for the retry
+			want := uint32(nTx) + uint32(nTx)/8 + 16
+			for {
+				cur := atomic.LoadUint32(&p.capTx)
+				if cur >= want || atomic.CompareAndSwapUint32(&p.capTx, cur, want) {
+					break
+				}
+			}
 			continue
 		}
 		if rc != 0 {
+			p.m.passFailed()
 			return nil, errors.Errorf("fabgpu: %s", C.GoString(C.fabgpu_strerror(rc)))
 		}
+		p.m.passDone(time.Since(start), int(nTx), int(nTuples), int(seeded))
 		return &PassSummary{TxFlags: flags[:nTx], Tuples: int(nTuples), BlockSigs: int(nBlockSigs), MemoSeeded: int(seeded)}, nil
 	}
+	p.m.passFailed()
 	return nil, errors.New("fabgpu: block shape changed between attempts")
 }
 
@@ -368,4 +443,87 @@ func (p *Provider) MemoStats() (entries, hits, misses, evicted uint64) {
 	var e, h, m, v C.uint64_t
 	C.fabgpu_csp_memo_stats(p.csp, &e, &h, &m, &v)
 	return uint64(e), uint64(h), uint64(m), uint64(v)
+}
+
+// ---- metrics (SURVEY.md section 5: next to gossip_privdata_validation_duration, gossip/metrics/metrics.go:161-187) ----
+
+var (
+	passDurationOpts = metrics.HistogramOpts{
+		Namespace: "bccsp", Subsystem: "gpu", Name: "block_pass_duration",
+		Help: "Time it takes to pre-verify every signature of a block on the GPU (in seconds): marshalled block in, verdict memo seeded",
+	}
+	passTxOpts = metrics.CounterOpts{
+		Namespace: "bccsp", Subsystem: "gpu", Name: "block_pass_transactions",
+		Help: "Transactions that went through the block pre-verify pass",
+	}
+	passSigOpts = metrics.CounterOpts{
+		Namespace: "bccsp", Subsystem: "gpu", Name: "block_pass_signatures",
+		Help: "Creator, endorsement and orderer signatures the block pre-verify pass derived from blocks",
+	}
+	passFailedOpts = metrics.CounterOpts{
+		Namespace: "bccsp", Subsystem: "gpu", Name: "block_pass_failures",
+		Help: "Block pre-verify passes that ended in an infrastructure error (validation then ran on bccsp/sw)",
+	}
+	passRouteOpts = metrics.GaugeOpts{
+		Namespace: "bccsp", Subsystem: "gpu", Name: "block_passes",
+		Help: "Block pre-verify passes by route: walked on the device, walked on the host, and per device context",
+		LabelNames: []string{"route"}, StatsdFormat: "%{#fqname}.%{route}",
+	}
+	memoOpts = metrics.GaugeOpts{
+		Namespace: "bccsp", Subsystem: "gpu", Name: "verdict_memo",
+		Help: "Verdict memo: entries held, bccsp.Verify lookups answered (hits), lookups left to bccsp/sw (misses), entries evicted",
+		LabelNames: []string{"what"}, StatsdFormat: "%{#fqname}.%{what}",
+	}
+)
+
+type passMetrics struct {
+	duration         metrics.Histogram
+	tx, sigs, failed metrics.Counter
+	routes, memo     metrics.Gauge
+}
+
+func (m *passMetrics) passDone(d time.Duration, nTx, nSig, seeded int) {
+	if m == nil {
+		return
+	}
+	m.duration.Observe(d.Seconds())
+	m.tx.Add(float64(nTx))
+	m.sigs.Add(float64(nSig))
+}
+
+func (m *passMetrics) passFailed() {
+	if m != nil {
+		m.failed.Add(1)
+	}
+}
+
+// RegisterMetrics wires the provider's counters into the peer's metrics provider.  Call once where the peer creates its other
+// metrics (internal/peer/node/start.go:243: metricsProvider := opsSystem.Provider - the patch line is in gpufactory_patch.txt); the
+// route and memo gauges are refreshed every refresh interval from the library's own counters (PassRoutes, PassesPerDevice, MemoStats).
+func (p *Provider) RegisterMetrics(mp metrics.Provider, refresh time.Duration) {
+	if mp == nil || p.m != nil {
+		return
+	}
+	p.m = &passMetrics{
+		duration: mp.NewHistogram(passDurationOpts), tx: mp.NewCounter(passTxOpts), sigs: mp.NewCounter(passSigOpts),
+		failed: mp.NewCounter(passFailedOpts), routes: mp.NewGauge(passRouteOpts), memo: mp.NewGauge(memoOpts),
+	}
+	if refresh <= 0 {
+		refresh = 5 * time.Second
+	}
+	go func() {
+		for range time.Tick(refresh) {
+			d, h, _ := p.PassRoutes()
+			p.m.routes.With("route", "device_walk").Set(float64(d))
+			p.m.routes.With("route", "host_walk").Set(float64(h))
+			for i, n := range p.PassesPerDevice() {
+				p.m.routes.With("route", "context_"+strconv.Itoa(i)).Set(float64(n))
+			}
+			e, hit, miss, ev := p.MemoStats()
+			p.m.memo.With("what", "entries").Set(float64(e))
+			p.m.memo.With("what", "hits").Set(float64(hit))
+			p.m.memo.With("what", "misses").Set(float64(miss))
+			p.m.memo.With("what", "evicted").Set(float64(ev))
+		}
+	}()
 }

@@ -23,7 +23,7 @@ import (
 func providers(t *testing.T) (bccsp.BCCSP, bccsp.BCCSP) {
 	ref, err := sw.NewDefaultSecurityLevelWithKeystore(sw.NewDummyKeyStore())
 	require.NoError(t, err)
-	g, err := New(ref, 0)
+	g, err := New(ref, Options{Devices: []int{0}})
 	if err != nil {
 		t.Skipf("no MI355X here: %s", err)
 	}
@@ -137,7 +137,7 @@ func TestImportedKeysKeepEveryVerbOfBCCSPSW(t *testing.T) {
 	require.NoError(t, err)
 	ref2, err := sw.NewDefaultSecurityLevelWithKeystore(ks)
 	require.NoError(t, err)
-	g2, err := New(ref2, 0)
+	g2, err := New(ref2, Options{Devices: []int{0, 0}}) // two contexts on the one device: the pool behind one provider
 	require.NoError(t, err)
 	k, err := g2.KeyGen(&bccsp.ECDSAP256KeyGenOpts{Temporary: false})
 	require.NoError(t, err)

@@ -25,10 +25,14 @@
 // than the CPU's SHA extensions (DESIGN.md section 9).  The orderers' signatures are still tuples of the pass (kind 2): the
 // BlockValidation policy evaluated again at commit time (core/committer/txvalidator, config blocks) finds them in the memo.
 //
-// Apply in extensions/gossip/state/state.go:75-77:
+// Apply in extensions/gossip/state/state.go:
+//	:58-60   NewGossipStateProviderExtension keeps  arrival: newArrivalPasses(chainID)  in gossipStateProviderExtension
+//	:75-77   AddPayload:
 //	-	return handle
-//	+	return preVerifyOnArrival(s.chainID, handle)
-// (and keep chainID in gossipStateProviderExtension: NewGossipStateProviderExtension receives it, :58-60).
+//	+	return s.arrival.wrap(handle)
+// The reference builds the AddPayload wrapper anew for EVERY payload (gossip/state/state.go:328 and :787 call
+// s.extension.AddPayload(s.addPayload)(payload, ...)), so whatever must outlive one payload - the limiter on passes in flight, the
+// provider lookup - lives in arrivalPasses, made once per channel (ADVICE r3: a limiter created inside the wrapper limited nothing).
 // NOT compiled in this repository (no Go toolchain in the build image); Go 1.14 compatible.
 package state
 
@@ -55,30 +59,47 @@ func MemoSeq(channelID string, number uint64) uint64 {
 // at most this many passes in flight per channel: a burst of arriving blocks (state transfer) must not queue device work without bound
 const maxArrivalPasses = 4
 
-func preVerifyOnArrival(channelID string, handle func(payload *proto.Payload, blockingMode bool) error) func(payload *proto.Payload, blockingMode bool) error {
+// arrivalPasses is the per-channel state of the hook: ONE limiter and ONE provider lookup for the life of the channel.
+type arrivalPasses struct {
+	channelID string
+	pre       gpu.BlockPreVerifier // nil: the default BCCSP cannot pre-verify
+	slots     chan struct{}        // at most maxArrivalPasses passes in flight for this channel
+}
+
+func newArrivalPasses(channelID string) *arrivalPasses {
 	pre, _ := factory.GetDefault().(gpu.BlockPreVerifier)
-	if pre == nil {
+	return &arrivalPasses{channelID: channelID, pre: pre, slots: make(chan struct{}, maxArrivalPasses)}
+}
+
+// wrap is what AddPayload returns: handle first - it decides whether the block is kept at all (gossip/state/state.go:804 drops blocks
+// below the ledger height or beyond the buffer window, payloads.Push drops duplicates) - and only a block that was KEPT is pre-verified:
+// a pass for a block that never reaches Validate would seed memo entries nobody evicts, and the bounded memo drops its OLDEST block
+// first - the one the committer needs next (ADVICE r3).
+func (a *arrivalPasses) wrap(handle func(payload *proto.Payload, blockingMode bool) error) func(payload *proto.Payload, blockingMode bool) error {
+	if a == nil || a.pre == nil {
 		return handle
 	}
-	slots := make(chan struct{}, maxArrivalPasses)
 	return func(payload *proto.Payload, blockingMode bool) error {
-		if payload != nil && len(payload.Data) != 0 {
-			seq := MemoSeq(channelID, payload.SeqNum)
-			select {
-			case slots <- struct{}{}:
-				data := payload.Data // not retained past the call: the provider copies what it keeps (cgo pointer rules)
-				go func() {
-					defer func() { <-slots }()
-					if pre.HasBlock(seq) {
-						return // a duplicate of a block that is already waiting
-					}
-					if _, err := pre.PreVerifyBlock(data, seq); err != nil {
-						arrivalLogger.Debugf("[%s] block %d: pre-verify at arrival failed (%s); the validators will use bccsp/sw", channelID, payload.SeqNum, err)
-					}
-				}()
-			default: // enough passes in flight: this block is pre-verified at Validate (or not at all: bccsp/sw is always right)
-			}
+		err := handle(payload, blockingMode)
+		if err != nil || payload == nil || len(payload.Data) == 0 {
+			return err
 		}
-		return handle(payload, blockingMode)
+		seq := MemoSeq(a.channelID, payload.SeqNum)
+		select {
+		case a.slots <- struct{}{}:
+			data := payload.Data // not retained past the pass: the provider copies what it keeps (cgo pointer rules)
+			num := payload.SeqNum
+			go func() {
+				defer func() { <-a.slots }()
+				if a.pre.HasBlock(seq) {
+					return // a duplicate of a block that is already waiting
+				}
+				if _, err := a.pre.PreVerifyBlock(data, seq); err != nil {
+					arrivalLogger.Debugf("[%s] block %d: pre-verify at arrival failed (%s); the validators will use bccsp/sw", a.channelID, num, err)
+				}
+			}()
+		default: // enough passes in flight: this block is pre-verified at Validate (or not at all: bccsp/sw is always right)
+		}
+		return nil
 	}
 }

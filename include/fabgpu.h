@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FABGPU_ABI_VERSION 5
+#define FABGPU_ABI_VERSION 6
 
 /* ---- return codes (infrastructure only) ---- */
 #define FABGPU_OK 0

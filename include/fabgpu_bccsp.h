@@ -160,6 +160,11 @@ typedef struct fabgpu_block_pass {
     /* out (ABI v5), device walk: tuples whose identity the provider had never met - their certificates were decoded on the device
      * (msp/mspimpl.go:408-421 deserialization: PEM, x509 SubjectPublicKeyInfo, curve membership) and offered to its identity cache */
     uint32_t n_device_decoded;
+    /* out (ABI v6): where this pass spent its time, host clock, milliseconds - [0] the outline of the block and the identity table's
+     * sync (host walk: the gates), [1] waiting for the block's upload to finish, [2] the device phase (count .. finish, the verify
+     * launches inside), [3] bookkeeping behind it (cache, learned identities, memo publication); [4] the device context that served it */
+    float ms_stage[4];
+    int32_t device_context;
 } fabgpu_block_pass;
 int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* pass);
 /* 0: hit, *status = 0 valid / 1 arithmetic reject / 2 high-S / 3 r out of range (the reference rejects: ask bccsp/sw for its error

@@ -133,3 +133,58 @@ void ossl_sha256_p256_verify_batch(size_t n, const uint8_t *arena, const uint32_
         worker_free(&w);
     }
 }
+
+/* The CPU side of BASELINE's SECOND metric (validated tx/s per block): identity.Verify (msp/identities.go:169-196) for every tuple of
+ * a marshalled block, as validatorPoolSize goroutines would drain it - per tuple  digest = SHA-256(prefix || suffix)  (an endorsement
+ * signs prp || endorser, a creator the envelope payload), the DER signature unmarshalled (bccsp/utils/ecdsa.go:43-67), the low-S gate,
+ * ECDSA_do_verify.  spans6[6 i ..] = (prefix off, len, suffix off, len, signature off, len) into `arena`; qxy = X || Y per tuple.
+ * `reps` passes on exactly `threads` workers inside one parallel region; returns the wall seconds between the earliest start and the
+ * latest finish.  status: 0 valid, 1 reject, 2 high-S, 3 range, 4 off-curve, 5 signature does not unmarshal. */
+double ossl_identity_verify_spans_timed(size_t n, const uint8_t *arena, const uint32_t *spans6, const uint8_t *qxy, uint8_t *status,
+                                        int threads, int reps) {
+    double t_first = 1e300, t_last = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        worker w;
+        worker_init(&w);
+#pragma omp barrier
+        double t0 = omp_get_wtime();
+        for (int rep = 0; rep < reps; rep++) {
+#pragma omp for schedule(dynamic, 16) nowait
+            for (long i = 0; i < (long)n; i++) {
+                const uint32_t *sp = spans6 + 6 * i;
+                uint8_t d[32], r32[32], s32[32];
+                SHA256_CTX c;
+                SHA256_Init(&c);
+                if (sp[1]) SHA256_Update(&c, arena + sp[0], sp[1]);
+                if (sp[3]) SHA256_Update(&c, arena + sp[2], sp[3]);
+                SHA256_Final(d, &c);
+                const unsigned char *p = arena + sp[4];
+                ECDSA_SIG *sg = d2i_ECDSA_SIG(NULL, &p, (long)sp[5]);
+                int st = 5;
+                if (sg) {
+                    const BIGNUM *r = NULL, *s = NULL;
+                    ECDSA_SIG_get0(sg, &r, &s);
+                    if (BN_num_bytes(r) <= 32 && BN_num_bytes(s) <= 32 && !BN_is_negative(r) && !BN_is_negative(s)) {
+                        BN_bn2binpad(r, r32, 32);
+                        BN_bn2binpad(s, s32, 32);
+                        st = one(&w, qxy + 64 * i, qxy + 64 * i + 32, d, r32, s32);
+                    } else {
+                        st = BN_num_bytes(s) > 32 ? 2 : 3;
+                    }
+                    ECDSA_SIG_free(sg);
+                }
+                status[i] = (uint8_t)st;
+            }
+        }
+        double t1 = omp_get_wtime();
+#pragma omp critical
+        {
+            if (t0 < t_first) t_first = t0;
+            if (t1 > t_last) t_last = t1;
+        }
+        worker_free(&w);
+    }
+    return t_last - t_first;
+}

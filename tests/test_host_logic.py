@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(fabgpu.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.fabgpu_abi_version() == 5      # 4: pseudonym signatures ride in fabgpu_identity_batch (3: tail / digests; 2: the gather_* fields)
+    assert L.fabgpu_abi_version() == 6      # 6: fabgpu_block_pass.ms_stage / device_context, fabgpu_csp_new2 (5: n_device_decoded; 4: pseudonym signatures ride along)
     assert fabgpu.strerror(0) == "ok" and "bccsp/sw" in fabgpu.strerror(-2)
 
 
