@@ -984,7 +984,9 @@ def main():
                 out["configs4_mixed"] = mixed_n
             # BASELINE's second metric on N GPUs: ONE provider (the process-global BCCSP) over all N devices, 2 N callers submitting blocks
             if extras and n_tx == N_TX:
-                out["block_pass_inprocess"] = inprocess_multi_leg(world, tool="bench_pool.py")
+                # (a dry run has fewer GPUs than ranks: the pool is then `world` contexts on the devices that exist)
+                pool_devs = ",".join(str(i % torch.cuda.device_count()) for i in range(world))
+                out["block_pass_inprocess"] = inprocess_multi_leg(world, tool="bench_pool.py", extra=("--devices", pool_devs))
                 if isinstance(out["block_pass_inprocess"], dict) and "validated_tx_per_s" in out["block_pass_inprocess"]:
                     out["validated_tx_per_s_block_pass_all_gpus"] = out["block_pass_inprocess"]["validated_tx_per_s"]
         if extras:

@@ -355,6 +355,32 @@ void GPUCSP::Preallocate() const {
             bm->pin_cap = total + total / 4;
             made.push_back(bm);
         }
+        for (auto& t : th) t.join();
+        th.clear();
+        // The copies of a memo-seeding pass, rehearsed: device -> each table's pinned room, WHILE a block-sized upload travels the other
+        // way - the situation in which the runtime was seen to create further DMA queues inside hipMemcpyAsync (10-14 ms each, three or
+        // four times per provider: walk_preallocate).  Until the calls return at once, at most six rounds per device.
+        if (!made.empty()) {
+            std::vector<uint8_t> dummy(std::min<size_t>(block_bytes, (size_t)32 << 20), 0x5a);
+            std::vector<void*> pins;
+            std::vector<size_t> sizes;
+            for (auto& bm : made) {
+                pins.push_back(bm->pin);
+                sizes.push_back(bm->pin_cap);
+            }
+            for (int g = 0; g < G; g++) {
+                fabgpu_ctx* c = devs_[(size_t)g]->ctx;
+                int calm = 0;
+                for (int round = 0; round < 6 && calm < 2; round++) {
+                    uint64_t tok = 0;
+                    std::thread up([&] { (void)fabgpu_arena_stage(c, dummy.data(), dummy.size(), &tok); });
+                    const double worst = walk_warm_copies(c, pins.data(), sizes.data(), (int)pins.size());
+                    up.join();
+                    if (worst < 0) break;
+                    calm = worst < 1.0 ? calm + 1 : 0;
+                }
+            }
+        }
         std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
         for (auto& bm : made) memo_free_.push_back(bm);
     }

@@ -290,6 +290,7 @@ struct WalkRequest {
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq);
 // allocate now what `slots` overlapping passes over blocks of up to these sizes will need on this device (best effort)
 int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_t n_tuples, int slots);
+double walk_warm_copies(fabgpu_ctx* ctx, void* const* pinned, const size_t* bytes, int n);
 // pinned host memory for WalkOut::memo_* (hipHostMalloc / hipHostFree; nullptr when there is none to be had)
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes);
 void walk_pinned_free(fabgpu_ctx* ctx, void* p);

@@ -1509,6 +1509,11 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     const auto t_start = now();
+    // (developer aid: FABGPU_WALK_TRACE=1 prints where the HOST side of a pass spends its time, checkpoint by checkpoint)
+    static const bool walk_trace = getenv("FABGPU_WALK_TRACE") != nullptr;
+    auto mark = [&](const char* what) {
+        if (walk_trace) fprintf(stderr, "fabgpu walk %p %-28s %8.3f ms\n", (void*)&rq, what, ms_since(t_start));
+    };
     const uint32_t ne = rq.n_env;
     // ---- per-envelope arrays ----
     size_t o = 0;
@@ -1629,7 +1634,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     WalkCounts cnts;
     cnts.n_tx = ne; cnts.n_tuples = nt; cnts.n_prefixes = np; cnts.n_checks = nc; cnts.n_creators = tot.creators;
     WalkOut out;
+    mark("totals known");
     if (!rq.sizes(rq.user, cnts, out)) return FABGPU_ETOOBIG;
+    mark("sizes callback");
     // ---- per-tuple arrays ----
     o = 0;
     const size_t words = (nt + 63) / 64;
@@ -1758,6 +1765,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         ho.tuple_status = m8 + m_tst; ho.tuple_hashed = m8 + m_hsh;
         ho.id_idx = (uint32_t*)(m8 + m_idx);
     }
+    mark("buffers ensured");
     err = launch_walk_emit(a, tot, st);
     if (err == hipSuccess && rq.n_block_sigs) {
         memcpy(ph + p_sigs, rq.block_sigs, (size_t)rq.n_block_sigs * sizeof(bccsp::BlockTuple));
@@ -1882,11 +1890,15 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s4);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
     }
+    mark("side streams queued");
     if (err == hipSuccess && memo_early_pending) {
         err = hipStreamWaitEvent(s4, ctx->ev_w[7], 0);
         if (err == hipSuccess) err = launch_walk_memo_early(a, s4);
+        mark("memo early launched");
         if (err == hipSuccess) err = hipMemcpyAsync(out.memo_key_off, dt + o_mkoff, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, s4);
+        mark("memo key_off copy queued");
         if (err == hipSuccess) err = hipMemcpyAsync(out.memo_keys, dt + o_mkeys, out.memo_keys_cap, hipMemcpyDeviceToHost, s4);
+        mark("memo keys copy queued");
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[8], s4);
     }
     // The block's idemix creators: ONE nym launch over their rows, packed (walk_nym_pack_kernel: 2 000 idemix creators among 10 000 are
@@ -1990,6 +2002,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess && nym_ran) err = hipStreamWaitEvent(st, ctx->ev_w[6], 0);     // the nym kernel's answers
         if (err == hipSuccess && memo) err = hipMemsetAsync(dt + o_mslots, 0, (size_t)out.memo_slot_cap * 4, st);
         if (err == hipSuccess && memo) err = hipMemsetAsync(&((WalkMemoTotals*)(dt + o_mtot))->live, 0, 4, st);
+        mark("finish: memsets queued");
         if (err == hipSuccess) err = launch_walk_status_checks(a, nc, st);
         if (memo) {
             // the LATE half of the memo: digests, status bytes and slots of the candidates that were hashed and decided
@@ -1997,6 +2010,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             if (err == hipSuccess) err = hipMemcpyAsync(out.memo_slots, dt + o_mslots, (size_t)out.memo_slot_cap * 4, hipMemcpyDeviceToHost, st);
             if (err == hipSuccess) err = hipMemcpyAsync(out.memo_digests, dt + o_mdig, (size_t)nt * 32, hipMemcpyDeviceToHost, st);
             if (err == hipSuccess) err = hipMemcpyAsync(out.memo_status, dt + o_mst, nt, hipMemcpyDeviceToHost, st);
+            mark("finish: late memo copies queued");
         }
         fetch(out.tuples, p_tup, a.tuples, (size_t)nt * sizeof(bccsp::BlockTuple));
         fetch(out.tuple_digest, p_dig, dt + o_tdig, (size_t)nt * 32);
@@ -2004,6 +2018,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (has_nym_rows) fetch(out.nym_issuer, p_nymi, dt + o_nymio, (size_t)tot.creators * 4);
         if (err == hipSuccess && memo) err = hipStreamWaitEvent(st, ctx->ev_w[8], 0);        // the memo's early half (long done: it ran beside the verify launches)
         if (err == hipSuccess) err = launch_walk_finish(a, ho, st);
+        mark("finish: last kernel queued");
         if (err != hipSuccess) return hip_to_rc(err);
         int r2 = wait_host_flag((const uint32_t*)(mh + m_finflag), ho.seq, st);
         if (r2 != FABGPU_OK) return r2;
@@ -2039,7 +2054,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     }
     if (err == hipSuccess && nc) err = hipStreamWaitEvent(st, ctx->ev_w[2], 0);
     if (err != hipSuccess) return hip_to_rc(err);
+    mark("verify launches queued");
     if ((rc = finish())) return rc;
+    mark("finish flag seen");
     if (rq.summary.n_outline_differs) return decline("the device's walk of an envelope differs from the host's outline of it (creator message span, or the counts)");
     // (summary.n_undecided - certificates whose key lies beyond the decoder's window - are TUPLE_ST_NEEDS_SW tuples of their own
     //  transactions, not a reason to give the block up)
@@ -2150,7 +2167,67 @@ int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_
         else rc = FABGPU_ENOMEM;
     }
     if (ctx->tailbuf.ensure((size_t)64 << 10) != FABGPU_OK) rc = FABGPU_ENOMEM;
+    // The copy ENGINES, too.  The runtime creates a DMA queue the first time a copy of a direction needs one more of them - ~10 ms each,
+    // on the calling thread, inside hipMemcpyAsync: measured (rocprofv3 --memory-copy-trace, profiles/r04_trace_first_memo_passes.txt) as
+    // 11 ms of nothing on the device in front of the first memo-seeding passes' key copies (device -> pinned host, 8.5 MB, beside the
+    // uploads of the other pass), four passes in a row - what round 3 booked as "pinned memo tables allocated on first overlap".  Copies
+    // of both directions on all four pass streams at once, twice, make the runtime create them now.
+    {
+        const size_t piece = (size_t)4 << 20;
+        void *d = nullptr, *h = nullptr;
+        if (hipMalloc(&d, 4 * piece) == hipSuccess && hipHostMalloc(&h, 4 * piece, hipHostMallocPortable) == hipSuccess) {
+            hipStream_t ss[4] = {ctx->stream, ctx->stream2, ctx->stream3, ctx->stream4};
+            for (int rep = 0; rep < 2; rep++) {
+                for (int k = 0; k < 4; k++) (void)hipMemcpyAsync((uint8_t*)h + k * piece, (uint8_t*)d + k * piece, piece, hipMemcpyDeviceToHost, ss[k]);
+                for (int k = 0; k < 4; k++) (void)hipMemcpyAsync((uint8_t*)d + k * piece, (uint8_t*)h + k * piece, piece, hipMemcpyHostToDevice, ss[3 - k]);
+                for (int k = 0; k < 4; k++) (void)hipStreamSynchronize(ss[k]);
+            }
+        }
+        if (d) hipFree(d);
+        if (h) hipHostFree(h);
+    }
     return rc;
+}
+
+// Device -> pinned-host copies into the given buffers on the pass's streams, as a memo-seeding pass issues them; returns the longest
+// time one hipMemcpyAsync call kept the calling thread (ms; < 0: a copy failed).  GPUCSP::Preallocate runs this beside an upload until
+// the calls return at once: see walk_preallocate on the runtime's lazily created DMA queues.
+double walk_warm_copies(fabgpu_ctx* ctx, void* const* pinned, const size_t* bytes, int n) {
+    if (!ctx || !pinned || !bytes || n <= 0) return -1;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    if (!ctx->walk_tup.d || !ctx->walk_pin.h || ctx->walk_tup.cap < ((size_t)8 << 20)) return -1;
+    hipStream_t ss[4] = {ctx->stream4, ctx->stream, ctx->stream2, ctx->stream3};
+    uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
+    double worst = 0;
+    auto timed = [&](hipError_t e, const std::chrono::steady_clock::time_point& t0) {
+        worst = std::max(worst, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        return e == hipSuccess;
+    };
+    for (int i = 0; i < n; i++) {
+        const size_t b = std::min(bytes[i], (size_t)8 << 20);
+        // every kind of command a pass queues, on every stream it queues them on: fills (large, small), copies both ways (large, small),
+        // an event recorded on one stream and awaited on the next
+        for (int k = 0; k < 4; k++) {
+            auto t0 = std::chrono::steady_clock::now();
+            if (!timed(hipMemsetAsync(dt + ((size_t)k << 20), 0, (size_t)512 << 10, ss[k]), t0)) return -1;
+            t0 = std::chrono::steady_clock::now();
+            if (!timed(hipMemsetAsync(dt + ((size_t)k << 20), 0, 4, ss[k]), t0)) return -1;
+            t0 = std::chrono::steady_clock::now();
+            if (!timed(hipMemcpyAsync(dt + ((size_t)(4 + k) << 20), ctx->walk_pin.h, std::min<size_t>(ctx->walk_pin.cap, 80000), hipMemcpyHostToDevice, ss[k]), t0)) return -1;
+            t0 = std::chrono::steady_clock::now();
+            if (!timed(hipEventRecord(ctx->ev_w[k], ss[k]), t0)) return -1;
+            t0 = std::chrono::steady_clock::now();
+            if (!timed(hipStreamWaitEvent(ss[(k + 1) & 3], ctx->ev_w[k], 0), t0)) return -1;
+        }
+        auto t0 = std::chrono::steady_clock::now();
+        if (!timed(hipMemcpyAsync(pinned[i], dt, b, hipMemcpyDeviceToHost, ss[i & 1]), t0)) return -1;
+        t0 = std::chrono::steady_clock::now();
+        // (the small ones that follow the keys in a pass: offsets, statuses)
+        if (!timed(hipMemcpyAsync(pinned[i], dt, std::min<size_t>(b, 160000), hipMemcpyDeviceToHost, ss[(i + 1) & 1]), t0)) return -1;
+    }
+    for (int k = 0; k < 4; k++) (void)hipStreamSynchronize(ss[k]);
+    return worst;
 }
 
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes) {

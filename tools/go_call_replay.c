@@ -108,8 +108,12 @@ static void* validator(void* arg) {
             uint8_t digest[32];
             /* msp/identities.go:173-181: digest = bccsp.Hash(msg).  A creator signs Envelope.payload; an endorser prp || endorser
              * (validator_keylevel.go:246-258 builds that concatenation: append(prp, endorser...) - a copy, then one hash) */
+            /* (SHA256_Init / Update / Final, not the one-shot SHA256(): OpenSSL 3 routes that through an EVP fetch per call, whose locks
+             *  sixteen threads fight over - 42 ms per block instead of 6) */
+            SHA256_CTX c;
+            SHA256_Init(&c);
             if (tp->pre_len == 0) {
-                SHA256(j->blk + tp->suf_off, tp->suf_len, digest);
+                SHA256_Update(&c, j->blk + tp->suf_off, tp->suf_len);
             } else {
                 size_t n = (size_t)tp->pre_len + tp->suf_len;
                 if (cat_cap < n) {
@@ -119,8 +123,9 @@ static void* validator(void* arg) {
                 }
                 memcpy(cat, j->blk + tp->pre_off, tp->pre_len);
                 memcpy(cat + tp->pre_len, j->blk + tp->suf_off, tp->suf_len);
-                SHA256(cat, n, digest);
+                SHA256_Update(&c, cat, n);
             }
+            SHA256_Final(digest, &c);
             bytes += (uint64_t)tp->pre_len + tp->suf_len;
             uint8_t st = 255;
             /* gpu.go Verify: xyOf(k) -> fabgpu_csp_memo_lookup; (true, nil) only on a valid hit */
@@ -252,8 +257,27 @@ int main(int argc, char** argv) {
     uint64_t hits = 0, misses = 0, hashed = 0;
     pthread_t* pool = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_thr);
 
-    /* block 0 arrives alone (a peer that has just joined: the provider's caps are the initial 1 024 transactions) */
+    /* The first blocks of a fresh process, one after the other.  Block 0 pays what a process pays once - code objects loaded at their
+     * first launch, the signers' certificates decoded and their comb tables built - AND finds the provider's caps at the initial 1 024
+     * transactions (FABGPU_ETOOBIG, grow, retry).  To price the over-caps retry ALONE the caps are put back to 1 024 once the provider
+     * is warm (what a provider whose earlier blocks were all small looks like) and one more block is sent: `over_caps_on_a_warm_provider`. */
     for (int k = 0; k < n_blocks; k++) { arr[k].blk = copies[k]; arr[k].len = len; arr[k].seq = 0x9E3779B97F4A7C15ull * (uint64_t)(k + 1); }
+    arrival_job warmup[6];
+    memset(warmup, 0, sizeof(warmup));
+    double warm_ms[6];
+    for (int k = 0; k < 6; k++) {
+        warmup[k].blk = (uint8_t*)malloc(len);
+        memcpy((void*)warmup[k].blk, blk, len);
+        warmup[k].len = len;
+        warmup[k].seq = 0xD6E8FEB86659FD93ull * (uint64_t)(k + 1);
+        if (k == 5) __atomic_store_n(&g_cap_tx, 1024, __ATOMIC_RELAXED);
+        arrival(&warmup[k]);
+        warm_ms[k] = warmup[k].ms;
+        uint64_t ev = 0;
+        fabgpu_csp_memo_evict_block(g_csp, warmup[k].seq, &ev);
+        if (warmup[k].rc != 0) { printf("{\"error\": \"warm-up pass %d: %s\"}\n", k, fabgpu_strerror(warmup[k].rc)); return 1; }
+    }
+    double warm4 = warm_ms[3] < warm_ms[4] ? warm_ms[3] : warm_ms[4];
     arrival(&arr[0]);
     double wall0 = now_ms();
     for (int k = 0; k < n_blocks; k++) {
@@ -295,12 +319,16 @@ int main(int argc, char** argv) {
     char why[128];
     fabgpu_csp_pass_routes(g_csp, &dw, &hw, why, sizeof(why));
     printf("{\"block_bytes\": %zu, \"n_tx\": %u, \"signatures_per_block\": %u, \"blocks\": %d, \"validator_threads\": %d, \"device_contexts\": %d, "
-           "\"provider_new_ms\": %.3f, \"first_block_over_caps\": {\"ms\": %.3f, \"etoobig_retries\": %d, \"cap_tx_before\": 1024, \"cap_tx_after\": %u}, "
-           "\"second_block_ms\": %.3f, \"warm_pass_ms_median\": %.3f, \"first_over_warm\": %.3f, "
+           "\"provider_new_ms\": %.3f, \"first_block_of_a_fresh_process\": {\"ms\": %.3f, \"etoobig_retries\": %d, \"cap_tx_before\": 1024, \"cap_tx_after\": %u, "
+           "\"what\": \"code objects loaded at first launch, six certificates decoded, caps grown: once per process\"}, "
+           "\"lone_passes_ms\": [%.3f, %.3f, %.3f, %.3f, %.3f], "
+           "\"over_caps_on_a_warm_provider\": {\"ms\": %.3f, \"etoobig_retries\": %d, \"warm_lone_pass_ms\": %.3f, \"over_warm\": %.3f}, "
+           "\"pipelined_pass_ms_median\": %.3f, "
            "\"validators_ms_per_block_median\": %.3f, \"has_block_ms\": %.4f, \"cpu_sha256_MB_per_block\": %.2f, \"memo_hits\": %llu, \"memo_misses\": %llu, "
            "\"pipeline_wall_ms\": %.3f, \"ms_per_block_end_to_end\": %.3f, \"validated_tx_per_s_end_to_end\": %.1f, "
            "\"passes_on_device_route\": %llu, \"passes_on_host_route\": %llu, \"passes_per_context\": [",
-           len, n_tx, n_env_tuples, n_blocks, n_thr, n_dev, t_new, arr[0].ms, arr[0].retries, g_cap_tx, arr[1].ms, warm_med, warm_med > 0 ? arr[0].ms / warm_med : 0,
+           len, n_tx, n_env_tuples, n_blocks, n_thr, n_dev, t_new, warm_ms[0], warmup[0].retries, g_cap_tx, warm_ms[0], warm_ms[1], warm_ms[2], warm_ms[3], warm_ms[4],
+           warm_ms[5], warmup[5].retries, warm4, warm4 > 0 ? warm_ms[5] / warm4 : 0, warm_med,
            val_med, has_ms[n_blocks / 2], hashed / 1e6 / n_blocks, (unsigned long long)hits, (unsigned long long)misses, wall, wall / n_blocks,
            (double)n_tx * n_blocks / (wall * 1e-3), (unsigned long long)dw, (unsigned long long)hw);
     for (int d = 0; d < nd; d++) printf("%s%llu", d ? ", " : "", (unsigned long long)per_dev[d]);
