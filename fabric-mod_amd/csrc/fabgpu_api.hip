@@ -306,6 +306,10 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
     ctx->allow_quad = !(cfg && (cfg->flags & FABGPU_FLAG_NO_QUAD));
     ctx->pair_table_lds = cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) ? 1 : (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL) ? 0 : pair_table_default());
+    // The LDS form of the pair kernel asks for 130 KiB of dynamic LDS per workgroup (p256_pair29.h PAIR_LDS_CELLS_PER_SIG): a device that
+    // grants less keeps the table in the global workspace instead of failing every large launch.  (That allocation is also
+    // what keeps other kernels off the launch's CUs - more than the 84 KiB the pass reserves for that purpose.)
+    if (std::max<size_t>(prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor) < pair_table_lds_bytes()) ctx->pair_table_lds = 0;
     ctx->time_kernels = cfg && (cfg->flags & FABGPU_FLAG_TIME_KERNELS);
     DeviceGuard g(dev);
     int rc = FABGPU_OK;

@@ -35,6 +35,7 @@ struct VerifyGeom {
 VerifyGeom verify_geom(uint32_t n, bool allow_pair);
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair);
 int pair_table_default();
+size_t pair_table_lds_bytes();   // dynamic LDS one workgroup of the LDS-table pair kernel asks for
 constexpr int PAIR_TABLE_LDS_FROM = 16384;   // launches of more tuples than this keep the pair kernel's per-signature table in LDS
 // the mid-state kernel of a prefixed batch alone (the fused launchers run it themselves unless pa.mid_ready)
 hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st);   // honours pa.lds_reserve

@@ -456,6 +456,7 @@ VerifyGeom verify_geom(uint32_t n, bool allow_pair) {
 // Where the two-lanes-per-signature verify-only kernel keeps its per-signature table when the context does not say
 // (FABGPU_FLAG_PAIR_TABLE_LDS / _GLOBAL in fabgpu_cfg.flags force one; bench.py --pair-table for A/B runs): -1 = by batch size (launch_p256_verify).
 int pair_table_default() { return -1; }
+size_t pair_table_lds_bytes() { return (size_t)(VERIFY_BLOCK / 2) * PAIR_LDS_CELLS_PER_SIG * 16; }
 size_t verify_workspace_bytes(uint32_t n, bool allow_pair) {
     VerifyGeom g = verify_geom(n, allow_pair);
     if (g.pair) return (size_t)g.wgs * (g.block / 2) * QWS_PAIR_UINT4_PER_SIG * 16;
