@@ -90,6 +90,7 @@ struct fabgpu_ctx {
     int device = 0;
     bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
     bool allow_quad = true;   // !FABGPU_FLAG_NO_QUAD (idemix: four lanes per signature for batches <= IDEMIX_QUAD_MAX)
+    bool allow_wide = true;   // !FABGPU_FLAG_NO_WIDE (registered keys: eight lanes per signature in two phases for launches <= WIDE_LAUNCH_MAX)
     int pair_table_lds = -1;       // the verify-only pair kernel's per-signature table: 1 in LDS, 0 in the global workspace, -1 by batch size (kernels.h)
     hipStream_t stream = nullptr;
     // FABGPU_FAULT_INJECT (tests of the failure contract only): "launch" makes every kernel submission report hipErrorLaunchFailure,
@@ -140,7 +141,7 @@ struct fabgpu_ctx {
     // the device block pass runs on four streams: walk / gates / endorsements on `stream`, the creators' hashes and launch on
     // stream2, the mid-states on stream3, the TxID / proposal-hash digests on stream4
     hipStream_t stream3 = nullptr, stream4 = nullptr;
-    hipEvent_t ev_w[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_w[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool pred_has_nym = false;       // the previous block had idemix creators: queue the nym launch without waiting for the gates
     uint32_t pred_nym_rows = 0;      // ... and how many: the launch runs over that many packed rows plus a margin
     Buf gath;         // gathered hashes of an identity batch: spans | running offsets | digests
@@ -287,7 +288,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!out) return FABGPU_EINVAL;
     *out = nullptr;
     if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS | FABGPU_FLAG_NO_QUAD | FABGPU_FLAG_PAIR_TABLE_LDS |
-                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL)) != 0) return FABGPU_EINVAL;
+                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL | FABGPU_FLAG_NO_WIDE)) != 0) return FABGPU_EINVAL;
     if (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL)) return FABGPU_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
@@ -305,6 +306,8 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     ctx->walk_map.flags = hipHostMallocMapped | hipHostMallocCoherent;
     ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
     ctx->allow_quad = !(cfg && (cfg->flags & FABGPU_FLAG_NO_QUAD));
+    // (the wide form is built from the two-lane form's reasons: a context that may not use two lanes per signature does not use eight)
+    ctx->allow_wide = ctx->allow_pair && !(cfg && (cfg->flags & FABGPU_FLAG_NO_WIDE));
     ctx->pair_table_lds = cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) ? 1 : (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL) ? 0 : pair_table_default());
     // The LDS form of the pair kernel asks for 130 KiB of dynamic LDS per workgroup (p256_pair29.h PAIR_LDS_CELLS_PER_SIG): a device that
     // grants less keeps the table in the global workspace instead of failing every large launch.  (That allocation is also
@@ -703,9 +706,45 @@ int fabgpu_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const void* ke
     if (nkeys == 0) return FABGPU_EINVAL;
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
+    if (ctx->allow_wide && n <= (size_t)WIDE_LAUNCH_MAX) {
+        // a launch that cannot fill the chip: eight lanes per signature, the digest-independent half first (kernels.h, p256_wide29.h)
+        size_t wi = 0;
+        void* wsp = nullptr;
+        int rc = ctx->acquire_qws(n * WIDE_SCRATCH_BYTES, &wi, &wsp, st);
+        if (rc != FABGPU_OK) return rc;
+        if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
+        hipError_t err = launch_p256_wide_pre((uint32_t)n, key_id, nkeys, (const void*)kt, r, s, ctx->d_gtab, wsp, st);
+        if (err == hipSuccess) err = launch_p256_wide_post((uint32_t)n, e, r, ctx->d_gtab, wsp, verdict_bits, status, st);
+        if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
+        ctx->release_qws(wi, st);
+        ctx->timed = ctx->time_kernels;
+        return hip_to_rc(launched(ctx, err));
+    }
     if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_p256_verify_keyed((uint32_t)n, key_id, nkeys, (const void*)kt, e, r, s, ctx->d_gtab, verdict_bits, status, ctx->allow_pair, st);
     if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
+    ctx->timed = ctx->time_kernels;
+    return hip_to_rc(launched(ctx, err));
+}
+
+// identity.Verify for registered keys on a launch that cannot fill the chip: the digest-independent half of the verification, the
+// hashes (mid-states of shared prefixes first, unless the caller has them), then the half behind the digest.  One stream here - the
+// block pass runs the first two side by side (walk_block_pass).  digests_out: the caller's n x 32 bytes, or nullptr (scratch is used).
+static int keyed_wide_identity_dev(fabgpu_ctx* ctx, uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* key_id, uint32_t nkeys,
+                                   const void* kt, const void* r, const void* s, void* verdict_bits, void* status, ShaPrefixArgs pa, hipStream_t st) {
+    size_t wi = 0;
+    void* wsp = nullptr;
+    int rc = ctx->acquire_qws((size_t)n * (WIDE_SCRATCH_BYTES + 32), &wi, &wsp, st);
+    if (rc != FABGPU_OK) return rc;
+    void* dig = pa.digests ? pa.digests : (void*)((uint8_t*)wsp + (size_t)n * WIDE_SCRATCH_BYTES);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
+    hipError_t err = launch_p256_wide_pre(n, key_id, nkeys, kt, r, s, ctx->d_gtab, wsp, st);
+    if (err == hipSuccess && pa.m && pa.pre_idx && !pa.mid_ready) err = launch_sha256_midstates(arena, arena_bytes, pa, st);
+    pa.digests = dig;
+    if (err == hipSuccess) err = launch_sha256_messages(n, arena, arena_bytes, off, pa, st);
+    if (err == hipSuccess) err = launch_p256_wide_post(n, dig, r, ctx->d_gtab, wsp, verdict_bits, status, st);
+    if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
+    ctx->release_qws(wi, st);
     ctx->timed = ctx->time_kernels;
     return hip_to_rc(launched(ctx, err));
 }
@@ -725,6 +764,8 @@ int fabgpu_sha256_p256_verify_batch_keyed_dev(fabgpu_ctx* ctx, size_t n, const v
     if (nkeys == 0) return FABGPU_EINVAL;
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
+    if (ctx->allow_wide && n <= (size_t)WIDE_LAUNCH_MAX)
+        return keyed_wide_identity_dev(ctx, (uint32_t)n, arena, arena_bytes, off, key_id, nkeys, (const void*)kt, r, s, verdict_bits, status, ShaPrefixArgs(), st);
     if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_sha256_p256_verify_keyed((uint32_t)n, arena, arena_bytes, off, key_id, nkeys, (const void*)kt, r, s, ctx->d_gtab, verdict_bits,
                                                      status, ctx->allow_pair, ShaPrefixArgs(), st);
@@ -960,6 +1001,16 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
             kt = ctx->d_ktabs;
         }
         if (nkeys == 0) return FABGPU_EINVAL;
+        if (ctx->allow_wide && n <= (size_t)WIDE_LAUNCH_MAX) {
+            int rc = keyed_wide_identity_dev(ctx, (uint32_t)n, b->arena, b->arena_bytes, b->off, b->key_id, nkeys, (const void*)kt, b->r, b->s, b->verdict_bits,
+                                             b->status, pa, st);
+            if (rc != FABGPU_OK) return rc;
+            err = hipSuccess;
+            if (b->n_gather)
+                err = launch_gather_sha256(b->n_gather, b->arena, b->arena_bytes, b->gather_spans, b->gather_off, b->gather_scratch, b->gather_scratch_bytes,
+                                           b->gather_digests, st);
+            return hip_to_rc(err);
+        }
         if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
         err = launch_sha256_p256_verify_keyed((uint32_t)n, b->arena, b->arena_bytes, b->off, b->key_id, nkeys, (const void*)kt, b->r, b->s, ctx->d_gtab,
                                               b->verdict_bits, b->status, ctx->allow_pair, pa, st);
@@ -1654,7 +1705,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_nymsp = carve(n_msps ? (size_t)tot.creators * 8 : 0), o_nymio = carve(n_msps ? (size_t)tot.creators * 4 : 0),
                  o_nymb = carve(n_msps ? ((size_t)tot.creators + 63) / 64 * 8 + 8 : 0), o_nymst = carve(n_msps ? (size_t)tot.creators + 64 : 0),
                  o_nymga = carve(n_msps ? (size_t)tot.creators * 4 + 256 : 0), o_nymsl = carve(n_msps ? (size_t)tot.creators * 4 : 0),
-                 o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0), o_sparts = carve(((size_t)nt + 255) / 256 * sizeof(WalkSummary));
+                 o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0), o_sparts = carve(((size_t)nt + 255) / 256 * sizeof(WalkSummary)),
+                 o_wide = carve(nt <= (uint32_t)WIDE_LAUNCH_MAX ? (size_t)nt * WIDE_SCRATCH_BYTES : 0);   // w and u2 Q of every row between the two phases of the wide kernels
     // the verdict memo, if the caller gave room for it (WalkOut::memo_*): built behind the status kernel, copied straight into that room
     const bool memo = out.memo_slots && out.memo_key_off && out.memo_keys && out.memo_status && out.memo_digests && out.memo_slot_cap >= 16 &&
                       (out.memo_slot_cap & (out.memo_slot_cap - 1)) == 0 && out.memo_slot_cap >= 2 * (uint64_t)nt && out.memo_keys_cap != 0 &&
@@ -1839,6 +1891,21 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // the main stream looks identities up and gates signatures
     hipStream_t sc = s2;                                                   // the creators' stream
     bool memo_early_pending = false;
+    uint32_t nkeys = 0;
+    const int32_t** kt = nullptr;
+    {
+        std::lock_guard<std::mutex> klk(ctx->kmu);
+        nkeys = (uint32_t)ctx->ktabs.size();
+        kt = ctx->d_ktabs;
+    }
+    bool keyed_c = ctx->pred_keyed_creators && nkeys != 0, keyed_o = ctx->pred_keyed_others && nkeys != 0;
+    if (!a.split) keyed_c = keyed_o = keyed_c && keyed_o;                  // one launch serves both classes
+    // A block of a few hundred transactions (what a default network cuts: sampleconfig/configtx.yaml:284 MaxMessageCount 500) cannot
+    // fill the chip, and its device phase is a chain of LATENCIES: the creators' payload hashes (76 serial SHA-256 blocks), then a
+    // keyed verification (78 000 instructions per wavefront on two lanes).  The wide kernels (p256_wide29.h) put eight lanes on a
+    // signature and cut the verification in two: `pre` - s^-1, u2, u2 Q: everything but the digest - runs right behind the gates,
+    // BESIDE the hashes; `post` (e w, u1 G, the final addition and comparison: 18 000 instructions) is all that is left behind them.
+    const bool wide = ctx->allow_wide && both_pair && keyed_c && keyed_o && nt <= (uint32_t)WIDE_LAUNCH_MAX && !has_nym_rows;
     err = hipEventRecord(ctx->ev_w[0], st);
     // (The gates are queued right here, ahead of the side streams' work: on a small block the host's calls, not the kernels, set the pace,
     //  and the gate kernel is the main stream's critical path.)
@@ -1868,6 +1935,11 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipEventRecord(ctx->ev_w[7], st);                            // "every gate is through"
         memo_early_pending = true;
     }
+    if (err == hipSuccess && wide) {
+        err = hipEventRecord(ctx->ev_w[3], st);                            // the submission arrays are complete (the endorsements' hashes read them)
+        if (err == hipSuccess) err = launch_p256_wide_pre(nt, a.key_id, nkeys, (const void*)kt, a.r, a.s, ctx->d_gtab, dt + o_wide, st);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[9], st);   // "w and u2 Q of every row are in the scratch"
+    }
     if (err == hipSuccess && a.split) {
         // stream2: the creators' digests into rows [0, n_creators), so that their launch only has the arithmetic left.  Either they
         // were hashed per envelope from the host's outline (early_hash, queued before the walk: a scatter by the scan's creator ranks
@@ -1877,6 +1949,12 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             err = launch_walk_creator_digests(a, dt + o_dig, sc);
         } else if (err == hipSuccess) {
             err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, sc, exclusive ? 84u << 10 : 0u);
+        }
+        if (err == hipSuccess && wide) {
+            // ... and behind their digests the second phase of the creators' verification, on this stream: rows [0, n_creators)
+            err = hipStreamWaitEvent(sc, ctx->ev_w[9], 0);
+            if (err == hipSuccess) err = launch_p256_wide_post(tot.creators, dt + o_dig, a.r, ctx->d_gtab, dt + o_wide, dt + o_bitc, dt + o_dst, sc);
+            if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[4], sc);
         }
     }
     if (err == hipSuccess && np) {
@@ -1888,6 +1966,17 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
         if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pm, s3);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s3);
+    }
+    if (err == hipSuccess && wide) {
+        // stream3, behind the mid-states: the endorsements' (and block signatures') digests, rows [n_creators, nt) - hash only, beside `pre`
+        ShaPrefixArgs ph = pa;
+        ph.mid_ready = true;
+        ph.digests = dt + o_dig + 32 * (size_t)tot.creators;
+        if (np) ph.pre_idx = a.pre_idx + tot.creators;
+        if (!np) err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = hipStreamWaitEvent(s3, ctx->ev_w[3], 0);
+        if (err == hipSuccess) err = launch_sha256_messages(nt - tot.creators, sl->d, arena_bytes, a.off2 + 2 * (size_t)tot.creators, ph, s3);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[10], s3);
     }
     if (err == hipSuccess && nc) {       // stream4: the TxID / proposal-hash digests (only the flags at the very end wait for them)
         err = hipStreamWaitEvent(s4, ctx->ev_w[0], 0);
@@ -1946,13 +2035,6 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     const auto t_verify = now();
     pa.mid_ready = true;
     pa.digests = (out.tuple_digest || memo) ? dt + o_dig : nullptr;
-    uint32_t nkeys = 0;
-    const int32_t** kt = nullptr;
-    {
-        std::lock_guard<std::mutex> klk(ctx->kmu);
-        nkeys = (uint32_t)ctx->ktabs.size();
-        kt = ctx->d_ktabs;
-    }
     // rows [row0, row0 + n) as one fused (hash + verify) launch on stream `ls`
     auto verify_rows = [&](uint32_t row0, uint32_t n, bool prefixed, bool pair, bool keyed, void* bits, hipStream_t ls) -> int {
         ShaPrefixArgs p = pa;
@@ -1995,8 +2077,6 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         }
         return hip_to_rc(e);
     };
-    bool keyed_c = ctx->pred_keyed_creators && nkeys != 0, keyed_o = ctx->pred_keyed_others && nkeys != 0;
-    if (!a.split) keyed_c = keyed_o = keyed_c && keyed_o;                  // one launch serves both classes
     // the end of a pass on the main stream: statuses and digest comparisons, the big optional arrays as copies (tuple records, digests,
     // keys: only a caller that seeds the memo or wants spans asks for them), then the kernel that writes the small results into mapped
     // memory and raises the flag - behind the copies, so the flag covers them too
@@ -2041,9 +2121,16 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         }
         return FABGPU_OK;
     };
-    if (np) err = hipStreamWaitEvent(st, ctx->ev_w[1], 0);               // the mid-states (long done: they ran beside the gates)
+    if (np && !wide) err = hipStreamWaitEvent(st, ctx->ev_w[1], 0);      // the mid-states (long done: they ran beside the gates)
     if (err != hipSuccess) return hip_to_rc(err);
-    if (a.split) {
+    if (wide) {
+        // the second phase of everybody else's verification, behind their digests; the creators' runs on stream2 behind theirs
+        err = hipStreamWaitEvent(st, ctx->ev_w[10], 0);
+        if (err == hipSuccess)
+            err = launch_p256_wide_post(nt - tot.creators, dt + o_dig + 32 * (size_t)tot.creators, a.r + 32 * (size_t)tot.creators, ctx->d_gtab,
+                                        dt + o_wide + WIDE_SCRATCH_BYTES * (size_t)tot.creators, dt + o_bits, dt + o_dst + tot.creators, st);
+        if (err == hipSuccess) err = hipStreamWaitEvent(st, ctx->ev_w[4], 0);
+    } else if (a.split) {
         // creators on stream2 (two lanes per signature), everybody else on the main stream: side by side
         err = hipEventRecord(ctx->ev_w[3], st);                            // the submission arrays are complete
         if (err == hipSuccess) err = hipStreamWaitEvent(s2, ctx->ev_w[3], 0);

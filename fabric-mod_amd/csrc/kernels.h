@@ -58,6 +58,19 @@ hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t
                                            const void* ktabs, const void* r, const void* s, const void* gtab, void* verdict_bits, void* status,
                                            bool allow_pair, const ShaPrefixArgs& pa, hipStream_t st);
 
+// ---- wide_kernels.hip: a registered key's verification on eight lanes per signature, in two phases (p256_wide29.h) ----
+// For launches of at most WIDE_LAUNCH_MAX signatures (they cannot fill the chip: their time is one wavefront's instruction stream).
+// pre: everything that does not need the digest (w = s^-1, u2 = r w, T = u2 Q) -> 144 bytes of scratch per signature; it can run while the
+// messages are still being hashed.  post: e = the 32-byte digests by row -> verdict bits (ceil(n / 64) words, written bytewise) and status.
+constexpr int WIDE_LAUNCH_MAX = 8192;
+constexpr size_t WIDE_SCRATCH_BYTES = 144;
+hipError_t launch_p256_wide_pre(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* r, const void* s, const void* gtab,
+                                void* scratch, hipStream_t st);
+hipError_t launch_p256_wide_post(uint32_t n, const void* e, const void* r, const void* gtab, const void* scratch, void* verdict_bits, void* status,
+                                 hipStream_t st);
+// SHA-256 of n (possibly prefixed: pa.mid_scratch must hold the mid-states) messages -> pa.digests (n x 32 bytes), one message per lane
+hipError_t launch_sha256_messages(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const ShaPrefixArgs& pa, hipStream_t st);
+
 // ---- idemix_kernels.hip: idemix pseudonym signatures on FP256BN ----
 // A registered issuer occupies one slot of idemix_issuer_dev_bytes() bytes in a device array; fill a host copy of the slot
 // with idemix_issuer_dev_fill (device pointers of the two comb tables + ipk.Hash) and copy it up.

@@ -1,0 +1,116 @@
+// Kernels of the eight-lanes-per-signature keyed verification (p256_wide29.h) and the hash-only kernel that feeds its second phase.
+// A TU of its own: the point arithmetic is inlined generated asm, and kernels.hip is large enough.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.h"
+#include "kernels.h"
+#include "p256_wide29.h"
+
+namespace fab {
+
+// One wavefront per workgroup: a 100-transaction block is 50 wavefronts - each gets a CU's SIMD to itself wherever the dispatcher
+// puts it; 8 192 signatures are 1 024, one per SIMD.
+constexpr int WIDE_BLOCK = 64;
+
+__global__ void __launch_bounds__(WIDE_BLOCK, 1) p256_wide_pre_kernel(uint32_t n, const uint32_t* __restrict__ key_id, uint32_t nkeys,
+                                                                      const int32_t* const* __restrict__ ktabs, const uint8_t* __restrict__ r,
+                                                                      const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
+                                                                      int32_t* __restrict__ scratch) {
+    GTab16 gt{gtab};
+    constexpr uint32_t PER = WIDE_BLOCK / WIDE_LANES;
+    const uint32_t sub = threadIdx.x & (WIDE_LANES - 1);
+    const uint32_t ntiles = (n + PER - 1) / PER;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t i = tile * PER + (threadIdx.x >> 3);
+        const bool active = i < n;
+        const uint32_t ic = active ? i : (n - 1);
+        const uint32_t kid = key_id[ic];
+        const bool kok = kid < nkeys;
+        KeyTab8 kt{ktabs[kok ? kid : 0]};
+        u256 vr, vs;
+        load_be_field(vr, r, ic);
+        load_be_field(vs, s, ic);
+        p256_wide_pre29(vr, vs, gt, kt, sub, kok, active && sub == 0, scratch + (size_t)WIDE_SCRATCH_WORDS * ic);
+    }
+}
+
+// e: 32-byte big-endian digests by row.  verdict8: one byte per eight signatures (bit k of byte j = signature 8 j + k), i.e. the byte
+// view of the usual verdict words.
+__global__ void __launch_bounds__(WIDE_BLOCK, 1) p256_wide_post_kernel(uint32_t n, const uint8_t* __restrict__ e, const uint8_t* __restrict__ r,
+                                                                       const int32_t* __restrict__ gtab, const int32_t* __restrict__ scratch,
+                                                                       uint8_t* __restrict__ verdict8, uint8_t* __restrict__ status) {
+    GTab16 gt{gtab};
+    constexpr uint32_t PER = WIDE_BLOCK / WIDE_LANES;
+    const uint32_t sub = threadIdx.x & (WIDE_LANES - 1);
+    const uint32_t ntiles = (n + PER - 1) / PER;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t i = tile * PER + (threadIdx.x >> 3);
+        const bool active = i < n;
+        const uint32_t ic = active ? i : (n - 1);
+        u256 ve, vr;
+        load_be_field(ve, e, ic);
+        load_be_field(vr, r, ic);
+        const uint32_t st = p256_wide_post29(ve, vr, gt, sub, scratch + (size_t)WIDE_SCRATCH_WORDS * ic);
+        // eight verdicts per wavefront, on lanes 0, 8, .. 56: squeeze them into one byte
+        uint64_t x = __ballot(active && sub == 0 && st == 0u) & 0x0101010101010101ull;
+        x = (x | (x >> 7)) & 0x0003000300030003ull;
+        x = (x | (x >> 14)) & 0x0000000f0000000full;
+        x = (x | (x >> 28)) & 0xffull;
+        if (threadIdx.x == 0) {
+            verdict8[tile] = (uint8_t)x;       // (PER == 8: tile j covers signatures 8 j .. 8 j + 7)
+            if (tile == ntiles - 1)            // the rest of the last 64-bit verdict word: nobody's signatures
+                for (uint32_t b = ntiles; b < ((n + 63) / 64) * 8; b++) verdict8[b] = 0;
+        }
+        if (status != nullptr && active && sub == 0) status[i] = (uint8_t)st;
+    }
+}
+
+// SHA-256 of n (possibly prefixed) messages -> n x 32 digest bytes (pre.digests): the hash half of the fused kernels alone, one
+// message per lane; the wide verification takes digests from memory because its first phase runs beside this kernel, not behind it.
+__global__ void __launch_bounds__(64) sha256_messages_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                             const uint32_t* __restrict__ off, sha_prefixes pre) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    const uint32_t ic = active ? i : (n - 1);
+    uint32_t h[8];
+    sha256_message(arena32, arena_words, off, pre, ic, active, h);
+    emit_digest(pre, i, active, h);
+}
+
+static_assert(WIDE_BLOCK / WIDE_LANES == 8, "one verdict byte per tile");
+static_assert(WIDE_LAUNCH_MAX == WIDE_MAX && WIDE_SCRATCH_BYTES == 4 * WIDE_SCRATCH_WORDS, "kernels.h restates p256_wide29.h for the host");
+
+hipError_t launch_p256_wide_pre(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* r, const void* s, const void* gtab,
+                                void* scratch, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint32_t tiles = (n + 7) / 8;
+    dim3 grid(tiles < 4096u ? tiles : 4096u), block(WIDE_BLOCK);
+    hipLaunchKernelGGL(p256_wide_pre_kernel, grid, block, 0, st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
+                       (const uint8_t*)s, (const int32_t*)gtab, (int32_t*)scratch);
+    return hipGetLastError();
+}
+hipError_t launch_p256_wide_post(uint32_t n, const void* e, const void* r, const void* gtab, const void* scratch, void* verdict_bits, void* status,
+                                 hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint32_t tiles = (n + 7) / 8;
+    dim3 grid(tiles < 4096u ? tiles : 4096u), block(WIDE_BLOCK);
+    hipLaunchKernelGGL(p256_wide_post_kernel, grid, block, 0, st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
+                       (uint8_t*)verdict_bits, (uint8_t*)status);
+    return hipGetLastError();
+}
+hipError_t launch_sha256_messages(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const ShaPrefixArgs& pa, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    sha_prefixes pre;
+    pre.pre_idx = (pa.m && pa.pre_idx) ? (const uint32_t*)pa.pre_idx : nullptr;
+    pre.pre_off = (const uint32_t*)pa.pre_off;
+    pre.mid = (const uint32_t*)pa.mid_scratch;
+    pre.m = pre.pre_idx ? pa.m : 0;
+    pre.spans = pa.spans ? 1u : 0u;
+    pre.digests = (uint32_t*)pa.digests;
+    dim3 grid((n + 63) / 64), block(64);
+    hipLaunchKernelGGL(sha256_messages_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, pre);
+    return hipGetLastError();
+}
+
+}  // namespace fab

@@ -31,6 +31,7 @@ FLAG_TIME_KERNELS = 2    # fabgpu.h FABGPU_FLAG_TIME_KERNELS
 FLAG_NO_QUAD = 4         # fabgpu.h FABGPU_FLAG_NO_QUAD (idemix: never the four-lanes-per-signature kernel)
 FLAG_PAIR_TABLE_LDS = 8      # fabgpu.h: the verify-only pair kernel keeps its per-signature table in LDS
 FLAG_PAIR_TABLE_GLOBAL = 16  # ... in the global workspace
+FLAG_NO_WIDE = 32            # fabgpu.h: registered keys never on the eight-lanes-per-signature two-phase kernels (launches <= 8 192 signatures)
 ST_VALID, ST_BAD_MATH, ST_HIGH_S, ST_RANGE, ST_OFF_CURVE = 0, 1, 2, 3, 4
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)

@@ -68,6 +68,8 @@ typedef struct fabgpu_ctx fabgpu_ctx;
 #define FABGPU_FLAG_TIME_KERNELS 2u  /* bracket every launch with timing events so that fabgpu_last_kernel_ms answers (tools only) */
 #define FABGPU_FLAG_PAIR_TABLE_LDS 8u    /* two-lanes-per-signature verify kernel: per-signature table in LDS (8 entries, 65 signed 4-bit windows) */
 #define FABGPU_FLAG_PAIR_TABLE_GLOBAL 16u /* ... in the global workspace (16 entries, 52 signed 5-bit windows).  Neither: the default */
+#define FABGPU_FLAG_NO_WIDE 32u          /* registered keys: never use the eight-lanes-per-signature, two-phase kernels that serve launches of up to
+                                            8 192 signatures (parity tests run both forms) */
 
 typedef struct fabgpu_cfg {
     int32_t device;      /* HIP device ordinal; -1 = the current device */

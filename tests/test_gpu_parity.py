@@ -32,13 +32,16 @@ def _arr(items):
     return np.frombuffer(b"".join(items), dtype=np.uint8).reshape(-1, 32).copy()
 
 
-@pytest.fixture(scope="module", params=["auto", "one-lane", "pair-table-lds", "pair-table-global"])
+@pytest.fixture(scope="module", params=["auto", "one-lane", "pair-table-lds", "pair-table-global", "no-wide"])
 def ctx(request):
-    """auto = the product default (two lanes per signature up to 32 768 tuples, one lane beyond);
+    """auto = the product default (two lanes per signature up to 32 768 tuples, one lane beyond; registered keys: eight lanes per
+    signature in two phases up to 8 192 signatures - p256_wide29.h); no-wide = FABGPU_FLAG_NO_WIDE: registered keys on the two-lane /
+    one-lane keyed kernels at every size, so that every keyed fixture runs through both forms;
     one-lane = FABGPU_FLAG_ONE_LANE_ONLY, so that every fixture and edge vector also goes through the one-lane kernel;
     pair-table-lds / -global = the two homes of the pair kernel's per-signature table (8 entries + signed 4-bit windows in LDS / 16
     entries + 5-bit windows in the global workspace): every fixture and edge vector through both, whichever is the default."""
-    extra = {"auto": 0, "one-lane": fabgpu.FLAG_ONE_LANE_ONLY, "pair-table-lds": fabgpu.FLAG_PAIR_TABLE_LDS, "pair-table-global": fabgpu.FLAG_PAIR_TABLE_GLOBAL}
+    extra = {"auto": 0, "one-lane": fabgpu.FLAG_ONE_LANE_ONLY, "pair-table-lds": fabgpu.FLAG_PAIR_TABLE_LDS, "pair-table-global": fabgpu.FLAG_PAIR_TABLE_GLOBAL,
+             "no-wide": fabgpu.FLAG_NO_WIDE}
     c = fabgpu.Context(device=0, flags=fabgpu.FLAG_TIME_KERNELS | extra[request.param])
     yield c
     c.close()
@@ -295,6 +298,65 @@ def test_registered_keys_every_signer_its_own_key_edge_vectors_and_bad_ids(ctx):
     kid = ctx.key_register(b["qx"][0].tobytes(), b["qy"][0].tobytes())
     bits, st = ctx.p256_verify_batch_keyed(np.array([kid, 0xFFFFFFF0, kid + 100000], dtype=np.uint32), b["e"][:3], b["r"][:3], b["s"][:3])
     assert list(st) == [0, 4, 4] and list(bits) == [True, False, False]
+
+
+_EMPTY_LANE_ROWS = ([], [])
+
+
+def test_registered_keys_scalars_whose_digits_leave_lanes_empty(ctx):
+    """The eight-lanes-per-signature kernels (p256_wide29.h) add a comb's table entries up lane by lane - u2's 32 eight-bit windows
+    four to a lane, u1's 16 sixteen-bit windows two to a lane - and then across lanes.  VALID signatures whose scalars make whole
+    lanes (or all but one, or every lane) contribute NOTHING - partial sums at infinity at every level of the tree - and scalars at
+    the top of the range; every one with a registered key of its own, each beside a broken twin.  A signer can hit any (u1, u2): for a
+    nonce k, r = x(kG), s = r / u2, e = u1 s, d = (s k - e) / r.  (Run by every context configuration: the two-lane and one-lane keyed
+    kernels must say the same.)"""
+    rng = np.random.default_rng(44)
+    N = po.N
+
+    def lane_mask(lanes, bits, per):                                          # all-ones digits in the windows of the given lanes
+        v = 0
+        for ln in lanes:
+            for w in range(per * ln, per * ln + per):
+                v |= ((1 << bits) - 1) << (bits * w)
+        return v % N or 1
+    u2s = [1, 0xFF, 1 << 8, 1 << 31, 1 << 32, 1 << 248, (1 << 248) | 1, lane_mask([0], 8, 4), lane_mask([7], 8, 4), lane_mask([0, 7], 8, 4),
+           lane_mask([1, 2], 8, 4), lane_mask([3], 8, 4), lane_mask([0, 2, 4, 6], 8, 4), lane_mask([1, 3, 5, 7], 8, 4), N - 1, N - 2, N >> 1, (N >> 1) + 1,
+           int("01" * 32, 16), int("0100" * 16, 16), int("00000001" * 8, 16), int("ff000000" * 8, 16) % N]
+    u1s = [0, 1, 0xFFFF, 1 << 16, 1 << 240, (1 << 240) | 1, lane_mask([0], 16, 2), lane_mask([7], 16, 2), lane_mask([3, 4], 16, 2),
+           lane_mask([0, 2, 4, 6], 16, 2), N - 1, N - 2, int("0001" * 16, 16), int("00010000" * 8, 16), int("ffff0000" * 8, 16) % N]
+    rows, want = _EMPTY_LANE_ROWS
+    for u2 in ([] if rows else u2s):                                         # (built once: every context configuration runs the same rows)
+        for u1 in u1s + [int(rng.integers(1, 1 << 62)) ** 4 % N]:
+            for _ in range(400):
+                k = int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) + 1
+                R = po.pt_mul(k, (po.GX, po.GY))
+                r = R[0] % N
+                s = r * pow(u2, -1, N) % N
+                if r == 0 or s == 0 or not po.is_low_s(s):
+                    continue
+                e = u1 * s % N
+                d = (s * k - e) * pow(r, -1, N) % N
+                if d == 0:
+                    continue
+                Q = po.pt_mul(d, (po.GX, po.GY))
+                digest = e.to_bytes(32, "big")
+                assert po.ecdsa_verify_raw(Q[0], Q[1], digest, r, s), (hex(u1), hex(u2))
+                rows.append((Q, digest, r, s))
+                want.append(0)
+                rows.append((Q, digest, r, (s + 1) % N if po.is_low_s((s + 1) % N) and (s + 1) % N else s - 1))
+                want.append(None)
+                break
+            else:
+                raise AssertionError("no signature for u1 = %x, u2 = %x" % (u1, u2))
+    ids = np.array([ctx.key_register(_h32("%064x" % Q[0]), _h32("%064x" % Q[1])) for Q, _, _, _ in rows], dtype=np.uint32)
+    cols = [_arr([dg for _, dg, _, _ in rows]), _arr([_h32("%064x" % r) for _, _, r, _ in rows]), _arr([_h32("%064x" % s) for _, _, _, s in rows])]
+    oracle = coracle.verify_batch(_arr([_h32("%064x" % Q[0]) for Q, _, _, _ in rows]), _arr([_h32("%064x" % Q[1]) for Q, _, _, _ in rows]), *cols)
+    for w, o in zip(want, oracle):
+        assert w is None or o == w
+    for lo in (0, 5):                                                        # (a batch that starts inside a wavefront's eight signatures, too)
+        bits, st = ctx.p256_verify_batch_keyed(ids[lo:], *[c[lo:] for c in cols])
+        assert (st == oracle[lo:]).all() and (bits == (oracle[lo:] == 0)).all(), np.nonzero(st != oracle[lo:])[0][:8]
+    assert int((oracle == 0).sum()) >= len(u2s) * (len(u1s) + 1) and int((oracle != 0).sum()) >= len(u2s) * len(u1s)
 
 
 def test_registered_keys_fused_hash_verify_vs_oracle(ctx):
