@@ -78,6 +78,17 @@ __global__ void __launch_bounds__(64) sha256_messages_kernel(uint32_t n, const u
     emit_digest(pre, i, active, h);
 }
 
+// Unused dynamic LDS asked for with a wide launch so that its one-wavefront workgroups SPREAD over the chip: the dispatcher fills a CU
+// as long as a workgroup fits, and 250 workgroups (a 500-transaction block) that land four to a CU share that CU's instruction cache,
+// L1 and SIMDs with each other and with the hash kernels running beside them - measured (500-transaction block): `post` 84 us without,
+// 53 us with; the pass as a whole did not move (its critical path is the walk chain and `pre`), so this is tidiness, not a result.
+// 160 KB of LDS per CU / the workgroups a CU must take = the reservation; 8 192 signatures (1 024 workgroups, four per CU) get none.
+static uint32_t wide_lds_reserve(uint32_t workgroups) {
+    const uint32_t per_cu = (workgroups + 255) / 256;
+    if (per_cu >= 4) return 0;
+    return ((160u << 10) / per_cu) - (4u << 10);          // 1 per CU: 156 KB, 2: 76 KB, 3: 49 KB
+}
+
 static_assert(WIDE_BLOCK / WIDE_LANES == 8, "one verdict byte per tile");
 static_assert(WIDE_LAUNCH_MAX == WIDE_MAX && WIDE_SCRATCH_BYTES == 4 * WIDE_SCRATCH_WORDS, "kernels.h restates p256_wide29.h for the host");
 
@@ -86,7 +97,7 @@ hipError_t launch_p256_wide_pre(uint32_t n, const void* key_id, uint32_t nkeys, 
     if (n == 0) return hipSuccess;
     const uint32_t tiles = (n + 7) / 8;
     dim3 grid(tiles < 4096u ? tiles : 4096u), block(WIDE_BLOCK);
-    hipLaunchKernelGGL(p256_wide_pre_kernel, grid, block, 0, st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
+    hipLaunchKernelGGL(p256_wide_pre_kernel, grid, block, wide_lds_reserve(grid.x), st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
                        (const uint8_t*)s, (const int32_t*)gtab, (int32_t*)scratch);
     return hipGetLastError();
 }
@@ -95,7 +106,7 @@ hipError_t launch_p256_wide_post(uint32_t n, const void* e, const void* r, const
     if (n == 0) return hipSuccess;
     const uint32_t tiles = (n + 7) / 8;
     dim3 grid(tiles < 4096u ? tiles : 4096u), block(WIDE_BLOCK);
-    hipLaunchKernelGGL(p256_wide_post_kernel, grid, block, 0, st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
+    hipLaunchKernelGGL(p256_wide_post_kernel, grid, block, wide_lds_reserve(grid.x), st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
                        (uint8_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
