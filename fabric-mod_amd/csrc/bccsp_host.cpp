@@ -1671,7 +1671,7 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         if (grew) id_version_.fetch_add(1, std::memory_order_release);
     }
     RegisterQueued(to_register);
-    static const int gate_max = [] { const char* e = getenv("FABGPU_PASS_GATE_THREADS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    constexpr int gate_max = 16;
     if (host_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max);
     if (dev_memo && dev_bm && rq.memo_live && dev_bm->slots_v) {
         auto clk_memo = std::chrono::steady_clock::now();
@@ -1881,7 +1881,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
         }
     };
     auto clk0 = std::chrono::steady_clock::now();
-    static const int gate_max = [] { const char* e = getenv("FABGPU_PASS_GATE_THREADS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    constexpr int gate_max = 16;
     const int nthreads = std::min(gate_max, nt >= 16384 ? 16 : (nt >= 4096 ? 8 : 1));     // <= 16 = the pool + the caller: all of them run at once (they meet at a barrier)
     auto in_threads = [&](const std::function<void(int, size_t, size_t)>& fn) {       // fn(worker, lo, hi) over contiguous tuple ranges
         if (nthreads == 1) {

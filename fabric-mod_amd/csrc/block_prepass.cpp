@@ -213,15 +213,11 @@ struct EnvChunk {
 }  // namespace
 
 int WalkThreads() {
-    static const int n = [] {
-        const char* e = getenv("FABGPU_PASS_WALK_THREADS");
-        // 8, not 16: the workers spin while the lister publishes chunks, and a peer's container is typically granted fewer CPUs than it
-        // sees (the GPU boxes here: 256 visible, cgroup quota 16) - measured on such a box with the upload thread running beside
-        // (tools/gpu_pass_probe.sh, 10 000-tx block): 16 workers 10.7 ms, 8 workers 1.9-2.2 ms, 4 workers 2.2-2.7 ms, 1 worker 5.9 ms
-        int v = e ? atoi(e) : 8;
-        return v < 1 ? 1 : (v > 16 ? 16 : v);
-    }();
-    return n;
+    // 8, not 16: the workers spin while the lister publishes chunks, and a peer's container is typically granted fewer CPUs than it
+    // sees (the GPU boxes here: 256 visible, cgroup quota 16) - measured on such a box with the upload thread running beside
+    // (round 2, 10 000-tx block): 16 workers 10.7 ms, 8 workers 1.9-2.2 ms, 4 workers 2.2-2.7 ms, 1 worker 5.9 ms.  A constant since
+    // round 4 (it was FABGPU_PASS_WALK_THREADS while it was being measured).
+    return 8;
 }
 
 namespace {

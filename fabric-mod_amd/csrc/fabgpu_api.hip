@@ -1070,12 +1070,12 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
     // memory spends more time making the pages DMA-able than moving them - 50 MB took 2.0-2.5 ms against 0.9 ms for a buffer that was
     // sent before, which the runtime keeps pinned (tools/gpu_probe_fresh_buffers.py).  Arenas of 4 MiB and more therefore travel
     // through a pinned staging buffer the context owns: a few threads copy 2 MiB pieces into it and queue each piece's DMA as soon as
-    // it is there (FABGPU_STAGE_THREADS, default 4; 0 = the runtime's pageable path): 2.2 ms per 10 000-transaction pass whatever the
+    // it is there (four copiers): 2.2 ms per 10 000-transaction pass whatever the
     // buffer's history, against 2.9-3.9 ms (fresh) / 1.85 ms (re-sent, which a peer never does) on the pageable path.  Splitting the pageable copy itself over threads
     // was measured too: slower than one call (the pinning serialises in the driver).
     static const bool stage_timing = getenv("FABGPU_PASS_TIMING") != nullptr;
     const auto stage_t0 = std::chrono::steady_clock::now();
-    static const int stage_threads = [] { const char* e = getenv("FABGPU_STAGE_THREADS"); int v = e ? atoi(e) : 4; return v < 0 ? 0 : (v > 16 ? 16 : v); }();
+    constexpr int stage_threads = 4;             // measured from 0 (the runtime's pageable path) to 16 in rounds 2-3; no difference from two up
     hipError_t err = hipSuccess;
     if (stage_threads == 0 || len < ((size_t)4 << 20)) {
         err = hipMemcpy(sl->d, arena, len, hipMemcpyHostToDevice);
@@ -1084,7 +1084,7 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
         if (ctx->fault == 2 || ctx->stage_pin.ensure(len) != FABGPU_OK) return FABGPU_ENOMEM;
         // pieces: 256 KiB, 512 KiB, 1 MiB, then 2 MiB each - the first DMA starts after 25 us of copying instead of 200
         std::vector<size_t> cut;
-        static const size_t max_piece = [] { const char* e = getenv("FABGPU_STAGE_PIECE_KB"); size_t v = e ? (size_t)atoi(e) : 2048; return (v < 256 ? 256 : v) << 10; }();
+        constexpr size_t max_piece = (size_t)2048 << 10;
         for (size_t at = 0, sz = (size_t)256 << 10; at < len; at += sz, sz = std::min(sz * 2, max_piece)) cut.push_back(at);
         cut.push_back(len);
         const size_t n_pieces = cut.size() - 1;
@@ -1095,10 +1095,10 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
         uint8_t* dst = (uint8_t*)sl->d;
         uint8_t* pin = (uint8_t*)ctx->stage_pin.h;
         const uint8_t* src = (const uint8_t*)arena;
-        // Pieces go round-robin over FABGPU_STAGE_QUEUES upload queues (default 4) so that one piece's set-up overlaps another's transfer:
-        // measured (tools/gpu_probe_stage_threads.sh, 48.6 MB) 1.33 ms with one queue, 1.23 with two, 1.13 with four - 43 GB/s; the
+        // Pieces go round-robin over four upload queues so that one piece's set-up overlaps another's transfer:
+        // measured (round 3, 48.6 MB) 1.33 ms with one queue, 1.23 with two, 1.13 with four - 43 GB/s; the
         // number of copier threads makes no difference from two up.
-        static const int n_queues = [] { const char* e = getenv("FABGPU_STAGE_QUEUES"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+        constexpr int n_queues = 4;
         hipStream_t cs[4] = {ctx->stream_copy, ctx->stream_copy_more[0], ctx->stream_copy_more[1], ctx->stream_copy_more[2]};
         const int dev = ctx->device;
         // The copiers (the host side's worker pool: idle while a block travels) claim pieces in order; this thread queues a piece's DMA

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--block-file", help="a marshalled block made by tools/make_bench_blocks.py (all signatures valid) instead of building one here")
     ap.add_argument("--idemix", action="store_true", help="register the fixtures' IdemixMSP1 first (blocks of make_bench_blocks.py idemix ...)")
     ap.add_argument("--tables", type=int, default=256, help="device comb tables the identity cache may build (6 signers: fewer than 6 leaves newcomers on the fresh-key path)")
+    ap.add_argument("--host-walk", action="store_true", help="provider option pass_device_walk off: the block is walked on the host (the round-2 route)")
+    ap.add_argument("--timing", action="store_true", help="provider option pass_timing: per-stage times of every pass on stderr")
     ap.add_argument("--register-after", type=int, default=1, help="an identity earns its comb table after being named this often (the provider's default: 64)")
     args = ap.parse_args()
     import numpy as np
@@ -58,7 +60,12 @@ def main():
                                                lambda prp: [(sid[j], sign(j, prp + sid[j])) for j in picks])
         envs.append(bb.envelope(payload, sign(c, payload)))
     blk = bb.block(1, envs) if not args.block_file else open(args.block_file, "rb").read()
-    csp = fabgpu.GPUCSP(device=0)
+    switches = {}
+    if args.host_walk:
+        switches["pass_device_walk"] = -1
+    if args.timing:
+        switches["pass_timing"] = 1
+    csp = fabgpu.GPUCSP(devices=[0], **switches)
     if args.idemix:
         raw_ipk = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_fixtures.json")))["msps"]["MSP1OU1"]["ipk"])
         assert csp.idemix_msp_register("IdemixMSP1", raw_ipk) >= 0
@@ -114,7 +121,7 @@ def main():
         lookup_us = (time.perf_counter() - t0) / len(keys) * 1e6
         assert hits == len(keys) and out["memo_seeded"] == nt
         fabgpu.memo_evict_block(csp, 7)
-    routes = fabgpu.pass_routes(csp)    # walked on the device / on the host (FABGPU_PASS_DEVICE_WALK=0 keeps every block on the host walk)
+    routes = fabgpu.pass_routes(csp)    # walked on the device / on the host (--host-walk keeps every block on the host walk)
     # the one SHA-256 MCS.VerifyBlock needs that a GPU cannot parallelise: BlockDataHash over the concatenated envelopes, on this host
     t0 = time.perf_counter()
     hashlib.sha256(b"".join(envs) if envs else blk).digest()

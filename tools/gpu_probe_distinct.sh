@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 B=${1:-.bench_blocks/distinct_10000.bin}
 T=${2:-distinct}
 cd $R
-FABGPU_PASS_TIMING=1 timeout 120 python tools/bench_block.py --block-file $B --steps 6 --register-after 64 > gpurun_out/probe_$T.json 2> gpurun_out/probe_$T.err
+timeout 120 python tools/bench_block.py --timing --block-file $B --steps 6 --register-after 64 > gpurun_out/probe_$T.json 2> gpurun_out/probe_$T.err
 tail -3 gpurun_out/probe_$T.err | cut -c1-250
 cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_$T -- python $R/tools/bench_block.py --block-file $R/$B --steps 6 --register-after 64 > /dev/null 2>&1
 f=$(find /tmp/prof_$T -name "*.db" 2>/dev/null | head -1)
