@@ -210,6 +210,9 @@ hipError_t launch_walk_memo_late(const WalkArrays& a, hipStream_t st);
 hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st);   // tuple statuses + digest comparisons (one launch)
 // per-transaction flags and everything the host reads, written to host-mapped memory; the last workgroup raises h.flag
 hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStream_t st);
+// the two above as ONE single-workgroup launch, for a block of a few hundred transactions whose caller wants no arrays copied between them
+bool walk_small_finish_fits(const WalkArrays& a, uint32_t n_checks);
+hipError_t launch_walk_status_finish_small(const WalkArrays& a, uint32_t n_checks, const WalkHostOut& h, hipStream_t st);
 hipError_t launch_walk_creator_digests(const WalkArrays& a, void* row_digests, hipStream_t st);   // digest_env -> the creators' digest rows
 // TEST HOOK: the wavefront form of the signature gate over n signatures (device pointers; spans = (start, end) pairs into arena)
 hipError_t launch_walk_gate_probe(uint32_t n, const void* arena, const void* spans, void* code, void* r, void* s, hipStream_t st);    // statuses, digest comparisons, per-transaction flags

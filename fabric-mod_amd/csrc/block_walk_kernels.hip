@@ -677,8 +677,8 @@ __global__ void __launch_bounds__(256) walk_status_checks_kernel(WalkArrays a, u
 // (PreVerifyParsed): not understood > bad creator signature > bad TxID > bad proposal hash > bad endorsement > "ask bccsp/sw" > all
 // valid - and everything the host reads, stored straight into host-mapped memory (WalkHostOut: four bytes per lane, coalesced rows
 // over PCIe); the workgroup that finishes last raises the flag the host polls.
-__global__ void __launch_bounds__(256) walk_finish_kernel(WalkArrays a, WalkHostOut h) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+// rows 4 j .. 4 j + 3 of everything the host reads
+__device__ __forceinline__ void walk_finish_rows(const WalkArrays& a, const WalkHostOut& h, uint32_t j) {
     const uint32_t t0 = 4 * j;
     if (t0 < a.n_env) {
         uint32_t packed = 0;
@@ -709,27 +709,29 @@ __global__ void __launch_bounds__(256) walk_finish_kernel(WalkArrays a, WalkHost
         for (uint32_t k = 0; k < 4; k++)
             if (t0 + k < a.n_tuples) h.id_idx[t0 + k] = a.id_idx[t0 + k];
     }
-    if (blockIdx.x == 0) {
-        const uint32_t* ls = reinterpret_cast<const uint32_t*>(a.learn);
-        uint32_t* ld = reinterpret_cast<uint32_t*>(h.learn);
-        for (uint32_t w = threadIdx.x; w < sizeof(WalkLearn) * WALK_LEARN_SLOTS / 4; w += blockDim.x) ld[w] = ls[w];
-        // the summary = what single kernels added to it (emit: count checks; gate: learn slots) + the status workgroups' rows, summed here by
-        // 252 threads (word w, every 21st row) through LDS
-        constexpr uint32_t W = sizeof(WalkSummary) / 4;
-        __shared__ uint32_t tot[W];
-        if (threadIdx.x < W) tot[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.summary)[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x < W * 21) {
-            const uint32_t w = threadIdx.x % W, c = threadIdx.x / W, rows = (a.n_tuples + 255) / 256;
-            uint32_t v = 0;
-            for (uint32_t r = c; r < rows; r += 21) v += a.summary_parts[(size_t)r * W + w];
-            if (v) atomicAdd(&tot[w], v);
-        }
-        __syncthreads();
-        if (threadIdx.x < W) reinterpret_cast<uint32_t*>(h.summary)[threadIdx.x] = tot[threadIdx.x];
-        if (h.memo_totals && a.memo_totals && threadIdx.x < sizeof(WalkMemoTotals) / 4)
-            reinterpret_cast<uint32_t*>(h.memo_totals)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.memo_totals)[threadIdx.x];
+}
+// one workgroup's job: the learn records, the summary, the memo's totals.  tot: sizeof(WalkSummary) / 4 words of LDS; at least 252 threads.
+__device__ __forceinline__ void walk_finish_summary(const WalkArrays& a, const WalkHostOut& h, uint32_t* tot) {
+    const uint32_t* ls = reinterpret_cast<const uint32_t*>(a.learn);
+    uint32_t* ld = reinterpret_cast<uint32_t*>(h.learn);
+    for (uint32_t w = threadIdx.x; w < sizeof(WalkLearn) * WALK_LEARN_SLOTS / 4; w += blockDim.x) ld[w] = ls[w];
+    // the summary = what single kernels added to it (emit: count checks; gate: learn slots) + the status workgroups' rows, summed here by
+    // 252 threads (word w, every 21st row) through LDS
+    constexpr uint32_t W = sizeof(WalkSummary) / 4;
+    if (threadIdx.x < W) tot[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.summary)[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < W * 21) {
+        const uint32_t w = threadIdx.x % W, c = threadIdx.x / W, rows = (a.n_tuples + 255) / 256;
+        uint32_t v = 0;
+        for (uint32_t r = c; r < rows; r += 21) v += a.summary_parts[(size_t)r * W + w];
+        if (v) atomicAdd(&tot[w], v);
     }
+    __syncthreads();
+    if (threadIdx.x < W) reinterpret_cast<uint32_t*>(h.summary)[threadIdx.x] = tot[threadIdx.x];
+    if (h.memo_totals && a.memo_totals && threadIdx.x < sizeof(WalkMemoTotals) / 4)
+        reinterpret_cast<uint32_t*>(h.memo_totals)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.memo_totals)[threadIdx.x];
+}
+__device__ __forceinline__ void walk_finish_raise(const WalkHostOut& h) {
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -739,6 +741,46 @@ __global__ void __launch_bounds__(256) walk_finish_kernel(WalkArrays a, WalkHost
             __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+__global__ void __launch_bounds__(256) walk_finish_kernel(WalkArrays a, WalkHostOut h) {
+    walk_finish_rows(a, h, blockIdx.x * blockDim.x + threadIdx.x);
+    if (blockIdx.x == 0) {
+        __shared__ uint32_t tot[sizeof(WalkSummary) / 4];
+        walk_finish_summary(a, h, tot);
+    }
+    walk_finish_raise(h);
+}
+
+// A block of a few hundred transactions: statuses, digest comparisons AND the finish in ONE launch - the two launches above are 15 and
+// 10 us of work with a launch gap between them that is as long, at the very end of a pass's critical path.  The workgroups do what
+// walk_status_checks_kernel's do; the one that is through LAST (a counter: h.done[1]) goes on and does the finish for the whole block -
+// at most WALK_SMALL_FINISH_MAX rows, four rounds of its 256 threads.  (No memo: its late half sits between the two.)
+constexpr uint32_t WALK_SMALL_FINISH_MAX = 4096;                           // tuples, transactions
+__global__ void __launch_bounds__(256) walk_status_finish_small_kernel(WalkArrays a, uint32_t n_checks, uint32_t status_blocks, WalkHostOut h) {
+    constexpr uint32_t W = sizeof(WalkSummary) / 4;
+    __shared__ uint32_t part[W], tot[W];
+    __shared__ uint32_t am_last;
+    if (blockIdx.x < status_blocks) {
+        if (threadIdx.x < W) part[threadIdx.x] = 0;
+        __syncthreads();
+        walk_status_part(a, blockIdx.x * blockDim.x + threadIdx.x, part);
+        __syncthreads();
+        if (threadIdx.x < W) a.summary_parts[(size_t)blockIdx.x * W + threadIdx.x] = part[threadIdx.x];
+    } else {
+        walk_checks_part(a, n_checks, (blockIdx.x - status_blocks) * blockDim.x + threadIdx.x);
+    }
+    __threadfence();                                                       // this workgroup's tx_mask bits, statuses, summary row: out
+    __syncthreads();
+    if (threadIdx.x == 0) am_last = atomicAdd(h.done + 1, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!am_last) return;
+    __threadfence();                                                       // ... and everybody else's: in
+    const uint32_t most = a.n_env > a.n_tuples ? a.n_env : a.n_tuples;
+    for (uint32_t j = threadIdx.x; 4 * j < most; j += blockDim.x) walk_finish_rows(a, h, j);
+    walk_finish_summary(a, h, tot);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -977,6 +1019,15 @@ hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hip
     const uint32_t sb = (a.n_tuples + 255) / 256, cb = (n_checks + 255) / 256;
     if (sb + cb == 0) return hipSuccess;
     hipLaunchKernelGGL(walk_status_checks_kernel, dim3(sb + cb), dim3(256), 0, st, a, n_checks, sb);
+    return hipGetLastError();
+}
+bool walk_small_finish_fits(const WalkArrays& a, uint32_t n_checks) {
+    (void)n_checks;
+    return a.n_tuples != 0 && a.n_tuples <= WALK_SMALL_FINISH_MAX && a.n_env <= WALK_SMALL_FINISH_MAX;
+}
+hipError_t launch_walk_status_finish_small(const WalkArrays& a, uint32_t n_checks, const WalkHostOut& h, hipStream_t st) {
+    const uint32_t sb = (a.n_tuples + 255) / 256, cb = (n_checks + 255) / 256;
+    hipLaunchKernelGGL(walk_status_finish_small_kernel, dim3(sb + cb), dim3(256), 0, st, a, n_checks, sb, h);
     return hipGetLastError();
 }
 hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStream_t st) {

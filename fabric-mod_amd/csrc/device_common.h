@@ -26,6 +26,10 @@ __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_a
 // a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96): left alone, hipcc emits two v_xor_b32 for every Sigma / sigma
 // (476 of the ~1700 instructions of a compressed block)
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+// Ch and Maj likewise (table bit (x << 2 | y << 1 | z) = f(x, y, z)): hipcc finds the one instruction for Ch by itself but spends
+// v_xor + v_and + v_bitop3 on Maj - 128 of a block's 1 512 instructions
+__device__ __forceinline__ uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
+__device__ __forceinline__ uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
 
 __device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
     uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
@@ -37,8 +41,8 @@ __device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
             uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
             w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         }
-        uint32_t t1 = hh + xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i & 15];
-        uint32_t t2 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        uint32_t t1 = hh + xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25)) + sha_ch(e, f, g) + K256[i] + w[i & 15];
+        uint32_t t2 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22)) + sha_maj(a, b, c);
         hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;

@@ -739,9 +739,10 @@ static int keyed_wide_identity_dev(fabgpu_ctx* ctx, uint32_t n, const void* aren
     void* dig = pa.digests ? pa.digests : (void*)((uint8_t*)wsp + (size_t)n * WIDE_SCRATCH_BYTES);
     if (ctx->time_kernels) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_p256_wide_pre(n, key_id, nkeys, kt, r, s, ctx->d_gtab, wsp, st);
-    if (err == hipSuccess && pa.m && pa.pre_idx && !pa.mid_ready) err = launch_sha256_midstates(arena, arena_bytes, pa, st);
+    const bool coop = n <= SHA_COOP_MAX;                 // eight lanes per message, prefixed ones hashed whole: no mid-states (sha256_coop.h)
+    if (err == hipSuccess && !coop && pa.m && pa.pre_idx && !pa.mid_ready) err = launch_sha256_midstates(arena, arena_bytes, pa, st);
     pa.digests = dig;
-    if (err == hipSuccess) err = launch_sha256_messages(n, arena, arena_bytes, off, pa, st);
+    if (err == hipSuccess) err = coop ? launch_sha256_messages_coop(n, arena, arena_bytes, off, pa, st) : launch_sha256_messages(n, arena, arena_bytes, off, pa, st);
     if (err == hipSuccess) err = launch_p256_wide_post(n, dig, r, ctx->d_gtab, wsp, verdict_bits, status, st);
     if (ctx->time_kernels) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
@@ -1657,7 +1658,10 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess) {
             s2_busy = true;
             // (thousands of them: on CUs of their own, like every long-running launch of a big block)
-            err = launch_sha256_spans(ne, sl->d, round_up(sl->len, 4) + 64, a.payload_spans, a.digest_env, ctx->stream2, ne > 2048 ? 84u << 10 : 0u);
+            // (up to SHA_COOP_MAX of them: eight lanes on a message, the workgroups spread by what a block of ne transactions with four
+            //  signatures each will run beside them - `pre` and the endorsements' hashes, nt / 8 workgroups each, the hash checks' ne / 4)
+            err = launch_sha256_spans(ne, sl->d, round_up(sl->len, 4) + 64, a.payload_spans, a.digest_env, ctx->stream2, ne > 2048 ? 84u << 10 : 0u,
+                                      spread_lds_bytes(ne / 8 + ne + ne / 4 + 3));
         }
     }
     if (err == hipSuccess && has_tail) {
@@ -1906,6 +1910,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // signature and cut the verification in two: `pre` - s^-1, u2, u2 Q: everything but the digest - runs right behind the gates,
     // BESIDE the hashes; `post` (e w, u1 G, the final addition and comparison: 18 000 instructions) is all that is left behind them.
     const bool wide = ctx->allow_wide && both_pair && keyed_c && keyed_o && nt <= (uint32_t)WIDE_LAUNCH_MAX && !has_nym_rows;
+    // The one-wavefront workgroups of a small block's launches - `pre` (nt / 8), the endorsements' hashes (nt / 8), the hash checks'
+    // (nc / 8), the creators' early hashes still running - spread over the chip together (kernels.h spread_lds_bytes).
+    const uint32_t spread = spread_lds_bytes(nt / 8 + nt / 8 + nc / 8 + 3);
     err = hipEventRecord(ctx->ev_w[0], st);
     // (The gates are queued right here, ahead of the side streams' work: on a small block the host's calls, not the kernels, set the pace,
     //  and the gate kernel is the main stream's critical path.)
@@ -1927,7 +1934,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         a.gate_mode = 0;
     } else {
         if (err == hipSuccess) err = launch_walk_gate(a, st);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[5], st);   // "the gates are through" (a nym launch waits for it)
+        if (err == hipSuccess && has_nym_rows) err = hipEventRecord(ctx->ev_w[5], st);   // "the gates are through" (a nym launch waits for it)
     }
     if (err == hipSuccess && memo) {
         // stream4, behind its digests: the EARLY half of the verdict memo - candidates, keys up to the digest, offsets - and its copy into
@@ -1935,9 +1942,40 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipEventRecord(ctx->ev_w[7], st);                            // "every gate is through"
         memo_early_pending = true;
     }
+    // A block of a few hundred transactions: the endorsements' messages are hashed WHOLE, eight lanes on each (sha256_coop.h) - no
+    // mid-state launch in front of them; the mid-states follow on the same stream, off the critical path, for the relaunch below that
+    // continues from them should "keyed" have been a wrong guess.
+    const bool coop_messages = wide && nt - tot.creators <= SHA_COOP_MAX;
+    auto queue_midstates = [&]() {
+        // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them), on CUs of their own: 40
+        // workgroups that would otherwise share SIMDs with the 40 000 short-lived wavefronts of the gate kernel and take 4x as long,
+        // with the endorsements' launch waiting for them (measured, round-2 probe gpu_dw_sched.sh, since removed: device phase 1.04 -> 0.90 ms)
+        ShaPrefixArgs pm = pa;
+        pm.lds_reserve = coop_messages ? 0u : 84u << 10;
+        if (!coop_messages) err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pm, s3);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s3);
+    };
+    auto queue_messages = [&]() {
+        // stream3 (behind the mid-states unless the messages are hashed whole): the endorsements' (and block signatures') digests, rows
+        // [n_creators, nt) - hash only, beside `pre`
+        ShaPrefixArgs ph = pa;
+        ph.mid_ready = true;
+        ph.digests = dt + o_dig + 32 * (size_t)tot.creators;
+        if (np) ph.pre_idx = a.pre_idx + tot.creators;
+        if (!np || coop_messages) err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
+        if (err == hipSuccess) err = hipStreamWaitEvent(s3, ctx->ev_w[3], 0);
+        if (err == hipSuccess)
+            err = coop_messages ? launch_sha256_messages_coop(nt - tot.creators, sl->d, arena_bytes, a.off2 + 2 * (size_t)tot.creators, ph, s3, spread)
+                                : launch_sha256_messages(nt - tot.creators, sl->d, arena_bytes, a.off2 + 2 * (size_t)tot.creators, ph, s3);
+        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[10], s3);
+    };
     if (err == hipSuccess && wide) {
         err = hipEventRecord(ctx->ev_w[3], st);                            // the submission arrays are complete (the endorsements' hashes read them)
-        if (err == hipSuccess) err = launch_p256_wide_pre(nt, a.key_id, nkeys, (const void*)kt, a.r, a.s, ctx->d_gtab, dt + o_wide, st);
+        // (the order of these calls is the order the kernels start in - the host's calls, 3 us each, set the pace of a small block - and
+        //  the hashes are the longer leg of what `post` waits for)
+        if (err == hipSuccess && coop_messages) queue_messages();
+        if (err == hipSuccess) err = launch_p256_wide_pre(nt, a.key_id, nkeys, (const void*)kt, a.r, a.s, ctx->d_gtab, dt + o_wide, st, spread);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[9], st);   // "w and u2 Q of every row are in the scratch"
     }
     if (err == hipSuccess && a.split) {
@@ -1953,34 +1991,16 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess && wide) {
             // ... and behind their digests the second phase of the creators' verification, on this stream: rows [0, n_creators)
             err = hipStreamWaitEvent(sc, ctx->ev_w[9], 0);
-            if (err == hipSuccess) err = launch_p256_wide_post(tot.creators, dt + o_dig, a.r, ctx->d_gtab, dt + o_wide, dt + o_bitc, dt + o_dst, sc);
+            if (err == hipSuccess) err = launch_p256_wide_post(tot.creators, dt + o_dig, a.r, ctx->d_gtab, dt + o_wide, dt + o_bitc, dt + o_dst, sc, spread);
             if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[4], sc);
         }
     }
-    if (err == hipSuccess && np) {
-        // stream3: the mid-states of the shared prefixes (the endorsements' launch continues from them), on CUs of their own: 40
-        // workgroups that would otherwise share SIMDs with the 40 000 short-lived wavefronts of the gate kernel and take 4x as long,
-        // with the endorsements' launch waiting for them (measured, round-2 probe gpu_dw_sched.sh, since removed: device phase 1.04 -> 0.90 ms)
-        ShaPrefixArgs pm = pa;
-        pm.lds_reserve = 84u << 10;
-        err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_sha256_midstates(sl->d, arena_bytes, pm, s3);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[1], s3);
-    }
-    if (err == hipSuccess && wide) {
-        // stream3, behind the mid-states: the endorsements' (and block signatures') digests, rows [n_creators, nt) - hash only, beside `pre`
-        ShaPrefixArgs ph = pa;
-        ph.mid_ready = true;
-        ph.digests = dt + o_dig + 32 * (size_t)tot.creators;
-        if (np) ph.pre_idx = a.pre_idx + tot.creators;
-        if (!np) err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = hipStreamWaitEvent(s3, ctx->ev_w[3], 0);
-        if (err == hipSuccess) err = launch_sha256_messages(nt - tot.creators, sl->d, arena_bytes, a.off2 + 2 * (size_t)tot.creators, ph, s3);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[10], s3);
-    }
+    if (err == hipSuccess && np && !coop_messages) queue_midstates();
+    if (err == hipSuccess && wide && !coop_messages) queue_messages();
+    if (err == hipSuccess && np && coop_messages) queue_midstates();
     if (err == hipSuccess && nc) {       // stream4: the TxID / proposal-hash digests (only the flags at the very end wait for them)
         err = hipStreamWaitEvent(s4, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s4);
+        if (err == hipSuccess) err = launch_gather_sha256(nc, sl->d, arena_bytes, a.gather_spans, a.gather_off, ctx->d_gscr, gscr, dt + o_gdg, s4, 0, spread);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[2], s4);
     }
     mark("side streams queued");
@@ -2087,6 +2107,16 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         if (err == hipSuccess && memo) err = hipMemsetAsync(dt + o_mslots, 0, (size_t)out.memo_slot_cap * 4, st);
         if (err == hipSuccess && memo) err = hipMemsetAsync(&((WalkMemoTotals*)(dt + o_mtot))->live, 0, 4, st);
         mark("finish: memsets queued");
+        if (!memo && !out.tuples && !out.tuple_digest && !out.tuple_qxy && !(has_nym_rows && out.nym_issuer) && walk_small_finish_fits(a, nc)) {
+            // a small block, flags only: statuses, digest comparisons and the finish in one launch
+            if (err == hipSuccess) err = launch_walk_status_finish_small(a, nc, ho, st);
+            mark("finish: last kernel queued");
+            if (err != hipSuccess) return hip_to_rc(err);
+            int r2 = wait_host_flag((const uint32_t*)(mh + m_finflag), ho.seq, st);
+            if (r2 != FABGPU_OK) return r2;
+            rq.summary = *(const WalkSummary*)(mh + m_sum);
+            return FABGPU_OK;
+        }
         if (err == hipSuccess) err = launch_walk_status_checks(a, nc, st);
         if (memo) {
             // the LATE half of the memo: digests, status bytes and slots of the candidates that were hashed and decided
@@ -2128,7 +2158,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         err = hipStreamWaitEvent(st, ctx->ev_w[10], 0);
         if (err == hipSuccess)
             err = launch_p256_wide_post(nt - tot.creators, dt + o_dig + 32 * (size_t)tot.creators, a.r + 32 * (size_t)tot.creators, ctx->d_gtab,
-                                        dt + o_wide + WIDE_SCRATCH_BYTES * (size_t)tot.creators, dt + o_bits, dt + o_dst + tot.creators, st);
+                                        dt + o_wide + WIDE_SCRATCH_BYTES * (size_t)tot.creators, dt + o_bits, dt + o_dst + tot.creators, st, spread);
         if (err == hipSuccess) err = hipStreamWaitEvent(st, ctx->ev_w[4], 0);
     } else if (a.split) {
         // creators on stream2 (two lanes per signature), everybody else on the main stream: side by side
@@ -2176,6 +2206,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             if (redo_o) {
                 keyed_o = false;
                 if (!a.split) keyed_c = false;
+                if (wide && np && (err = hipStreamWaitEvent(st, ctx->ev_w[1], 0)) != hipSuccess) return hip_to_rc(err);   // (wide: nobody waited for the mid-states yet)
                 if ((rc = a.split ? verify_rows(tot.creators, nt - tot.creators, np != 0, both_pair, false, dt + o_bits, st)
                                   : verify_rows(0, nt, np != 0, ctx->allow_pair, false, dt + o_bits, st)))
                     return rc;

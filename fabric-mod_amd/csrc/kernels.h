@@ -39,13 +39,13 @@ size_t pair_table_lds_bytes();   // dynamic LDS one workgroup of the LDS-table p
 constexpr int PAIR_TABLE_LDS_FROM = 16384;   // launches of more tuples than this keep the pair kernel's per-signature table in LDS
 // the mid-state kernel of a prefixed batch alone (the fused launchers run it themselves unless pa.mid_ready)
 hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const ShaPrefixArgs& pa, hipStream_t st);   // honours pa.lds_reserve
-hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st);
+hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st, uint32_t lds_spread = 0);
 // n messages given as (start, end) pairs -> n x 32 digest bytes
 hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st,
-                               uint32_t lds_reserve = 0);
+                               uint32_t lds_reserve = 0, uint32_t lds_spread = 0);   // lds_spread: for the eight-lane road (n <= SHA_COOP_MAX, no lds_reserve)
 // gathered messages (pieces of the arena stitched into `scratch` at out_off[j] .. out_off[j+1]) -> n x 32 digest bytes
 hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,
-                                size_t scratch_bytes, void* digests, hipStream_t st, uint32_t lds_reserve = 0);
+                                size_t scratch_bytes, void* digests, hipStream_t st, uint32_t lds_reserve = 0, uint32_t lds_spread = 0);
 hipError_t launch_p256_verify(uint32_t n, const void* qx, const void* qy, const void* e, const void* r, const void* s,
                               const void* gtab, void* qws, void* verdict_bits, void* status, bool allow_pair, hipStream_t st,
                               uint32_t lds_reserve = 0, int table_lds = 0);   // lds_reserve: see ShaPrefixArgs; table_lds: 1 PairQTabLds, 0 global, -1 by size
@@ -64,12 +64,22 @@ hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t
 // messages are still being hashed.  post: e = the 32-byte digests by row -> verdict bits (ceil(n / 64) words, written bytewise) and status.
 constexpr int WIDE_LAUNCH_MAX = 8192;
 constexpr size_t WIDE_SCRATCH_BYTES = 144;
+// lds_spread: bytes of LDS to ask for so that the one-wavefront workgroups spread over the chip - spread_lds_bytes(the workgroups that run
+// at the same time, over all launches that do); 0 = this launch's own count
+constexpr uint32_t SPREAD_NONE = 1;                 // "no reservation" (0 = decide by the launch's own workgroup count)
+uint32_t spread_lds_bytes(uint32_t workgroups);
 hipError_t launch_p256_wide_pre(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* r, const void* s, const void* gtab,
-                                void* scratch, hipStream_t st);
+                                void* scratch, hipStream_t st, uint32_t lds_spread = 0);
 hipError_t launch_p256_wide_post(uint32_t n, const void* e, const void* r, const void* gtab, const void* scratch, void* verdict_bits, void* status,
-                                 hipStream_t st);
+                                 hipStream_t st, uint32_t lds_spread = 0);
 // SHA-256 of n (possibly prefixed: pa.mid_scratch must hold the mid-states) messages -> pa.digests (n x 32 bytes), one message per lane
 hipError_t launch_sha256_messages(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const ShaPrefixArgs& pa, hipStream_t st);
+// The same digests with eight lanes on a message (sha256_coop.h) and NO mid-states: a prefixed message is hashed whole.  For launches that
+// cannot fill the chip - SHA_COOP_MAX messages are 256 wavefronts; launch_sha256_batch / _spans (without an LDS reservation) take this road
+// by themselves up to that size.
+constexpr uint32_t SHA_COOP_MAX = 2048;
+hipError_t launch_sha256_messages_coop(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const ShaPrefixArgs& pa, hipStream_t st,
+                                       uint32_t lds_spread = 0);
 
 // ---- idemix_kernels.hip: idemix pseudonym signatures on FP256BN ----
 // A registered issuer occupies one slot of idemix_issuer_dev_bytes() bytes in a device array; fill a host copy of the slot

@@ -411,15 +411,27 @@ hipError_t launch_sha256_midstates(const void* arena, size_t arena_bytes, const 
                        (const uint32_t*)pa.pre_off, pa.spans ? 1u : 0u, (uint32_t*)pa.mid_scratch);
     return hipGetLastError();
 }
-hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st) {
+hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes, const void* off, void* digests, hipStream_t st, uint32_t lds_spread) {
     if (n == 0) return hipSuccess;
+    if (n <= SHA_COOP_MAX) {                    // a launch that cannot fill the chip: eight lanes per message (sha256_coop.h)
+        ShaPrefixArgs pa;
+        pa.digests = digests;
+        return launch_sha256_messages_coop(n, arena, arena_bytes, off, pa, st, lds_spread);
+    }
     dim3 grid((n + 255) / 256), block(256);
     hipLaunchKernelGGL(sha256_batch_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                        (const uint32_t*)off, (uint32_t*)digests);
     return hipGetLastError();
 }
-hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st, uint32_t lds_reserve) {
+hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st, uint32_t lds_reserve,
+                               uint32_t lds_spread) {
     if (n == 0) return hipSuccess;
+    if (n <= SHA_COOP_MAX && lds_reserve == 0) {
+        ShaPrefixArgs pa;
+        pa.spans = true;
+        pa.digests = digests;
+        return launch_sha256_messages_coop(n, arena, arena_bytes, spans, pa, st, lds_spread);
+    }
     // small workgroups: a few thousand long messages spread over many CUs (two wavefronts each when the launch keeps its CUs to itself)
     const uint32_t per = lds_reserve ? 128 : 64;
     dim3 grid((n + per - 1) / per), block(per);
@@ -428,7 +440,7 @@ hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes
     return hipGetLastError();
 }
 hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,
-                                size_t scratch_bytes, void* digests, hipStream_t st, uint32_t lds_reserve) {
+                                size_t scratch_bytes, void* digests, hipStream_t st, uint32_t lds_reserve, uint32_t lds_spread) {
     if (n == 0) return hipSuccess;
     dim3 grid((n + 3) / 4), block(256);   // four wavefronts = four messages per workgroup
     hipLaunchKernelGGL(gather_spans_kernel, grid, block, lds_reserve, st, n, (const uint8_t*)arena, (uint32_t)arena_bytes, (const uint32_t*)spans,
@@ -441,7 +453,7 @@ hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_byte
                            (const uint32_t*)out_off, (uint32_t*)digests);
         return hipGetLastError();
     }
-    return launch_sha256_batch(n, scratch, scratch_bytes, out_off, digests, st);
+    return launch_sha256_batch(n, scratch, scratch_bytes, out_off, digests, st, lds_spread);
 }
 
 VerifyGeom verify_geom(uint32_t n, bool allow_pair) {

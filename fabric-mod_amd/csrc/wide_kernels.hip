@@ -6,6 +6,7 @@
 #include "device_common.h"
 #include "kernels.h"
 #include "p256_wide29.h"
+#include "sha256_coop.h"
 
 namespace fab {
 
@@ -78,35 +79,68 @@ __global__ void __launch_bounds__(64) sha256_messages_kernel(uint32_t n, const u
     emit_digest(pre, i, active, h);
 }
 
-// Unused dynamic LDS asked for with a wide launch so that its one-wavefront workgroups SPREAD over the chip: the dispatcher fills a CU
-// as long as a workgroup fits, and 250 workgroups (a 500-transaction block) that land four to a CU share that CU's instruction cache,
-// L1 and SIMDs with each other and with the hash kernels running beside them - measured (500-transaction block): `post` 84 us without,
-// 53 us with; the pass as a whole did not move (its critical path is the walk chain and `pre`), so this is tidiness, not a result.
-// 160 KB of LDS per CU / the workgroups a CU must take = the reservation; 8 192 signatures (1 024 workgroups, four per CU) get none.
-static uint32_t wide_lds_reserve(uint32_t workgroups) {
+// The same digests with eight lanes on a message (sha256_coop.h): no mid-states - a prefixed message is hashed whole, prefix first.
+__global__ void __launch_bounds__(64) sha256_messages_coop_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                                  const uint32_t* __restrict__ off, sha_prefixes pre) {
+    extern __shared__ uint32_t lds[];                                      // SHAC_LDS_WORDS, or more (spread_lds_bytes: placement)
+    const uint32_t i = blockIdx.x * SHAC_PER_WAVE + (threadIdx.x >> 3);
+    const bool active = i < n;
+    const uint32_t ic = active ? i : (n - 1);
+    const uint32_t sb = off[pre.spans ? 2 * ic : ic], se = off[pre.spans ? 2 * ic + 1 : ic + 1];
+    uint32_t ps = 0, pl = 0;
+    if (pre.pre_idx != nullptr) {
+        const uint32_t pi = pre.pre_idx[ic];
+        if (pi < pre.m) {
+            ps = pre.pre_off[pre.spans ? 2 * pi : pi];
+            const uint32_t pe = pre.pre_off[pre.spans ? 2 * pi + 1 : pi + 1];
+            pl = pe >= ps ? pe - ps : 0;
+        }
+    }
+    uint32_t h[8];
+    sha256_coop(arena32, arena_words, ps, pl, sb, se >= sb ? se - sb : 0, active, lds, threadIdx.x, h);
+    if (active && (threadIdx.x & (SHAC_LANES - 1)) == 0 && pre.digests != nullptr) sha256_coop_store(pre.digests, i, h);
+}
+
+// Unused dynamic LDS asked for with the launches of one-wavefront workgroups (the wide kernels, the eight-lane hashes) so that they SPREAD
+// over the chip: the dispatcher fills a CU as long as a workgroup fits - nine of the hash kernel's, dozens of `pre`'s - and wavefronts
+// that share a SIMD take turns.  workgroups = how many of them run at the same time, over all the launches that do (a pass tells: its
+// `pre`, its hashes and its hash checks run side by side); 160 KB of LDS per CU / the workgroups a CU must take = the reservation.
+// Measured, device phase of a pass by block size and workgroups allowed per CU (tools/gpu_probe_small2.py; none = no reservation):
+//      100 tx (125 workgroups at a time):  1: 0.304 ms   2: 0.355   3: 0.350   8: 0.340   none: 0.350
+//      500 tx (625):                       1: 0.454      2: 0.466   3: 0.437   8: 0.458   none: 0.451
+//    1 000 tx (1 250):                     1: 0.539      2: 0.543   3: 0.488   8: 0.469
+// - it pays while every workgroup can have a CU to itself and does nothing (500) or harm (1 000) beyond: up to three per CU by count,
+// none after that (SPREAD_NONE).
+uint32_t spread_lds_bytes(uint32_t workgroups) {
     const uint32_t per_cu = (workgroups + 255) / 256;
-    if (per_cu >= 4) return 0;
-    return ((160u << 10) / per_cu) - (4u << 10);          // 1 per CU: 156 KB, 2: 76 KB, 3: 49 KB
+    if (per_cu > 3) return SPREAD_NONE;
+    return ((160u << 10) / (per_cu ? per_cu : 1u)) - (4u << 10);          // 1 per CU: 156 KB, 2: 76 KB, 3: 49 KB
+}
+
+// what a launch asks for: the caller's figure, or (0) one from its own workgroup count; SPREAD_NONE = nothing
+static uint32_t spread_or_own(uint32_t lds_spread, uint32_t workgroups) {
+    if (lds_spread == 0) lds_spread = spread_lds_bytes(workgroups);
+    return lds_spread == SPREAD_NONE ? 0u : lds_spread;
 }
 
 static_assert(WIDE_BLOCK / WIDE_LANES == 8, "one verdict byte per tile");
 static_assert(WIDE_LAUNCH_MAX == WIDE_MAX && WIDE_SCRATCH_BYTES == 4 * WIDE_SCRATCH_WORDS, "kernels.h restates p256_wide29.h for the host");
 
 hipError_t launch_p256_wide_pre(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* r, const void* s, const void* gtab,
-                                void* scratch, hipStream_t st) {
+                                void* scratch, hipStream_t st, uint32_t lds_spread) {
     if (n == 0) return hipSuccess;
     const uint32_t tiles = (n + 7) / 8;
     dim3 grid(tiles < 4096u ? tiles : 4096u), block(WIDE_BLOCK);
-    hipLaunchKernelGGL(p256_wide_pre_kernel, grid, block, wide_lds_reserve(grid.x), st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
+    hipLaunchKernelGGL(p256_wide_pre_kernel, grid, block, spread_or_own(lds_spread, grid.x), st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
                        (const uint8_t*)s, (const int32_t*)gtab, (int32_t*)scratch);
     return hipGetLastError();
 }
 hipError_t launch_p256_wide_post(uint32_t n, const void* e, const void* r, const void* gtab, const void* scratch, void* verdict_bits, void* status,
-                                 hipStream_t st) {
+                                 hipStream_t st, uint32_t lds_spread) {
     if (n == 0) return hipSuccess;
     const uint32_t tiles = (n + 7) / 8;
     dim3 grid(tiles < 4096u ? tiles : 4096u), block(WIDE_BLOCK);
-    hipLaunchKernelGGL(p256_wide_post_kernel, grid, block, wide_lds_reserve(grid.x), st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
+    hipLaunchKernelGGL(p256_wide_post_kernel, grid, block, spread_or_own(lds_spread, grid.x), st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
                        (uint8_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
@@ -121,6 +155,22 @@ hipError_t launch_sha256_messages(uint32_t n, const void* arena, size_t arena_by
     pre.digests = (uint32_t*)pa.digests;
     dim3 grid((n + 63) / 64), block(64);
     hipLaunchKernelGGL(sha256_messages_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, pre);
+    return hipGetLastError();
+}
+hipError_t launch_sha256_messages_coop(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const ShaPrefixArgs& pa, hipStream_t st,
+                                       uint32_t lds_spread) {
+    if (n == 0) return hipSuccess;
+    sha_prefixes pre;
+    pre.pre_idx = (pa.m && pa.pre_idx) ? (const uint32_t*)pa.pre_idx : nullptr;
+    pre.pre_off = (const uint32_t*)pa.pre_off;
+    pre.mid = nullptr;
+    pre.m = pre.pre_idx ? pa.m : 0;
+    pre.spans = pa.spans ? 1u : 0u;
+    pre.digests = (uint32_t*)pa.digests;
+    dim3 grid((n + SHAC_PER_WAVE - 1) / SHAC_PER_WAVE), block(64);
+    lds_spread = spread_or_own(lds_spread, grid.x);
+    const uint32_t lds = lds_spread > (uint32_t)SHAC_LDS_WORDS * 4 ? lds_spread : (uint32_t)SHAC_LDS_WORDS * 4;
+    hipLaunchKernelGGL(sha256_messages_coop_kernel, grid, block, lds, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, pre);
     return hipGetLastError();
 }
 

@@ -374,8 +374,9 @@ def test_registered_keys_fused_hash_verify_vs_oracle(ctx):
     assert (st2 == st).all() and (bits2 == bits).all()
 
 
+@pytest.mark.parametrize("n", [1500, 2600])        # (keyed: eight lanes per message and whole-message hashing up to 2 048; mid-states beyond)
 @pytest.mark.parametrize("keyed", [False, True])
-def test_identity_batch_with_shared_prefixes_vs_hashlib_and_oracle(ctx, keyed):
+def test_identity_batch_with_shared_prefixes_vs_hashlib_and_oracle(ctx, keyed, n):
     """fabgpu_identity_verify_batch: message = prefix || suffix with the prefix hashed once (mid-state).  Prefix lengths
     around every multiple of 64 (so the re-read tail is 0..63 bytes), arbitrary alignments, empty suffixes, messages without
     a prefix, prefixes nobody uses.  The digests are pinned by hashlib on the concatenation, the verdicts by the oracle and by
@@ -383,7 +384,6 @@ def test_identity_batch_with_shared_prefixes_vs_hashlib_and_oracle(ctx, keyed):
     rng = np.random.default_rng(64)
     plens = [0, 1, 55, 56, 63, 64, 65, 119, 120, 127, 128, 129, 191, 192, 1023, 1024, 1025, 1856] + [int(x) for x in rng.integers(0, 300, size=12)]
     m = len(plens)
-    n = 1500
     pre_idx = rng.integers(0, m, size=n).astype(np.uint32)
     pre_idx[rng.random(n) < 0.1] = 0xFFFFFFFF
     slens = rng.integers(0, 200, size=n)
@@ -481,6 +481,43 @@ def test_sha256_like_reference_TestSHA(ctx):
     for i, m in enumerate(msgs):
         assert d[i].tobytes() == hashlib.sha256(m).digest(), lens[i]
     assert (d == coracle.sha256_batch(arena, off)).all()
+
+
+def test_sha256_both_roads_agree_on_every_length_and_alignment(ctx):
+    """Up to 2 048 messages a launch puts eight lanes on a message (sha256_coop.h: lengths that end a block, spill the length field into
+    a block of its own, span several eight-block chunks, start at every byte alignment); beyond, one lane per message.  The same
+    messages both ways, against hashlib."""
+    rng = np.random.default_rng(55)
+    lens = [0, 1, 3, 4, 54, 55, 56, 57, 63, 64, 65, 119, 120, 121, 127, 128, 447, 448, 449, 503, 504, 511, 512, 513, 1023, 1024, 1087, 3391, 3392, 3400, 4608]
+    parts, off, pos = [], [], 0
+    for k, L in enumerate(lens * 4):
+        pad = k % 4                                       # every alignment for every length
+        parts.append(b"\x55" * pad); pos += pad
+        off.append(pos)
+        parts.append(rng.integers(0, 256, size=L, dtype=np.uint8).tobytes()); pos += L
+        off.append(pos)
+    arena = np.frombuffer(b"".join(parts) + b"\0" * 8, dtype=np.uint8)
+    spans = np.array(off, dtype=np.uint32).reshape(-1, 2)
+    want = [hashlib.sha256(arena[a:b].tobytes()).digest() for a, b in spans]
+    # n + 1 consecutive offsets are what the flat entry point takes: hash the gaps too and ignore them
+    flat = np.array(sorted(set(off)), dtype=np.uint32)
+    idx = {int(a): i for i, a in enumerate(flat[:-1])}
+    small = ctx.sha256_batch(arena, flat)
+    assert len(flat) - 1 <= 2048
+    for (a, b), w in zip(spans, want):
+        if b > a:
+            assert small[idx[int(a)]].tobytes() == w, (a, b)
+    # the same list in disjoint copies of the arena (each copy's last message - the arena's tail and the next copy's padding - is a dummy)
+    per = len(flat)
+    reps = 2048 // per + 1
+    big_arena = np.tile(arena, reps)
+    big_off = np.concatenate([flat.astype(np.uint64) + r * len(arena) for r in range(reps)] + [np.array([reps * len(arena)], dtype=np.uint64)]).astype(np.uint32)
+    assert len(big_off) - 1 > 2048
+    big = ctx.sha256_batch(big_arena, big_off)
+    for r in (0, reps - 1):
+        for (a, b), w in zip(spans, want):
+            if b > a:
+                assert big[r * per + idx[int(a)]].tobytes() == w, (r, a, b)
 
 
 def test_sha256_misaligned_overlapping_and_offset_base(ctx):
