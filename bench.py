@@ -477,6 +477,24 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
         flags = fabgpu.preverify_block2(csp, bytes(bad), lean=True)["tx_flags"]
         assert flags[7] != 0 and (np.delete(flags, 7) == 0).all(), "a flipped payload byte must fail exactly its transaction"
         del bad
+        # ---- one identity the device decoder cannot decide (its key lies beyond the decoder's 3 KiB window): round 3 sent the WHOLE block
+        #      to the 3.3x slower host walk for it; now that tuple alone is left to bccsp/sw (tx flag 4) and the block stays on the device.
+        #      (Measured before the legs below churn the identity cache.) ----
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from test_device_walk import _cert_with_long_issuer
+            fx = blockgen.fixture_signers()
+            der = blockgen._pem_der(blockgen._IDS[4]["pem"])
+            far = bb.serialized_identity("Org1MSP", blockgen._pem_wrap(_cert_with_long_issuer(der, 3300)))
+            env_far = blockgen.endorser_tx(13, np.random.default_rng(79), (far, fx[4][1]), [fx[0], fx[1], fx[2]], blockgen.make_signer(80))
+            far_blk = bb.block(1, envs[:13] + [env_far] + envs[14:])
+            want_far = np.zeros(n_tx, np.uint8)
+            want_far[13] = fabgpu.TX_NEEDS_SW
+            legs["one_oversize_identity"] = timed("one_oversize_identity", [far_blk] * steps, expect_flags=want_far)
+            legs["one_oversize_identity"]["vs_friendly_device_route"] = legs["one_oversize_identity"]["median_ms_per_block"] / friendly_ms
+            del far_blk
+        except Exception as e:                                 # noqa: BLE001
+            legs["one_oversize_identity"] = {"error": repr(e)[:300]}
         # ---- the unfriendly blocks (what a busy network and an adversary send): all on the device route ----
         try:
             # (c) one endorsement signature of transaction 11 re-encoded with a 200-byte r in long-form DER: parses, r >= n, (false, nil)
@@ -510,23 +528,6 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
         except Exception as e:                                 # noqa: BLE001
             import traceback
             legs["unfriendly_blocks_error"] = (repr(e) + " | " + traceback.format_exc().strip().splitlines()[-3].strip())[:400]
-        # ---- one identity the device decoder cannot decide (its key lies beyond the decoder's 3 KiB window): round 3 sent the WHOLE block
-        #      to the 3.3x slower host walk for it; now that tuple alone is left to bccsp/sw (tx flag 4) and the block stays on the device ----
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from test_device_walk import _cert_with_long_issuer
-            fx = blockgen.fixture_signers()
-            der = blockgen._pem_der(blockgen._IDS[4]["pem"])
-            far = bb.serialized_identity("Org1MSP", blockgen._pem_wrap(_cert_with_long_issuer(der, 3300)))
-            env_far = blockgen.endorser_tx(13, np.random.default_rng(79), (far, fx[4][1]), [fx[0], fx[1], fx[2]], blockgen.make_signer(80))
-            far_blk = bb.block(1, envs[:13] + [env_far] + envs[14:])
-            want_far = np.zeros(n_tx, np.uint8)
-            want_far[13] = fabgpu.TX_NEEDS_SW
-            legs["one_oversize_identity"] = timed("one_oversize_identity", [far_blk] * steps, expect_flags=want_far)
-            legs["one_oversize_identity"]["vs_friendly_device_route"] = legs["one_oversize_identity"]["median_ms_per_block"] / friendly_ms
-            del far_blk
-        except Exception as e:                                 # noqa: BLE001
-            legs["one_oversize_identity"] = {"error": repr(e)[:300]}
         # ---- roofline of the pass: it is PCIe-bound when pipelined (the block has to reach the device), so the bound is a pinned
         #      hipMemcpy of the same bytes, measured here ----
         try:

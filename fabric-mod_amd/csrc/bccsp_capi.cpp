@@ -791,8 +791,11 @@ uint64_t fabgpu_identity_table_hash(const uint8_t* p, size_t len) { return walk:
 
 // ---- idemix (idemix_host.h) ----
 int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id) {
-    if (!csp || !mspid || !ipk_raw || !issuer_id) return FABGPU_EINVAL;
-    *issuer_id = csp->csp->RegisterIdemixMSP(mspid, ipk_raw, len);
+    return fabgpu_csp_idemix_msp_register2(csp, "", mspid, ipk_raw, len, issuer_id);
+}
+int fabgpu_csp_idemix_msp_register2(fabgpu_csp* csp, const char* channel, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id) {
+    if (!csp || !channel || !mspid || !ipk_raw || !issuer_id) return FABGPU_EINVAL;
+    *issuer_id = csp->csp->RegisterIdemixMSP(mspid, ipk_raw, len, channel);
     return FABGPU_OK;
 }
 

@@ -948,7 +948,7 @@ size_t GPUCSP::IdentityCacheSize() const {
     return idcache_.size();
 }
 
-int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len) const {
+int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len, const std::string& channel) const {
     IdemixIssuerPublicKey k;
     // (what the key holds - its bases and its hash - read once, without a device; the registration itself goes to every device)
     if (!IdemixCSP::IssuerKeyFields(ipk_raw, len, k)) return -1;
@@ -959,11 +959,17 @@ int64_t GPUCSP::RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_r
         memcpy(h.data(), k.hash, 32);
         idemix_issuer_hash_[k.issuer_id] = h;
     }
-    // One MSP id, two issuer keys (two channels that both call their idemix MSP "IdemixMSP1"): the pass sees a creator's MSP id, not its
-    // channel, so it can no longer tell under which key to verify - creators of that MSP id stay with bccsp/idemix from then on.
-    auto it = idemix_msps_.find(mspid);
-    if (it != idemix_msps_.end() && it->second != k.issuer_id) it->second = -2;
-    else idemix_msps_[mspid] = k.issuer_id;
+    // The pass sees a creator's MSP id, not its channel.  Each channel's LATEST key for the MSP id is remembered (a config update that
+    // rotates the issuer key replaces that channel's entry); while all channels that name the MSP id agree on one key the pass verifies
+    // under it, and while two of them differ (two channels that both call their idemix MSP "IdemixMSP1") it cannot tell under which
+    // key a creator verifies: creators of that MSP id stay with bccsp/idemix (-2) - until the channels agree again.
+    // (a caller that names no channel cannot rotate: every distinct key counts as a channel of its own)
+    std::map<std::string, int64_t>& by_channel = idemix_msp_channels_[mspid];
+    by_channel[channel.empty() ? "#" + std::to_string(k.issuer_id) : channel] = k.issuer_id;
+    int64_t resolved = k.issuer_id;
+    for (const auto& kv : by_channel)
+        if (kv.second != k.issuer_id) resolved = -2;
+    idemix_msps_[mspid] = resolved;
     return k.issuer_id;
 }
 

@@ -244,7 +244,7 @@ class GPUCSP {
     void StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len, uint64_t block_seq = 0) const;
     // An idemix MSP of the channel (msp/idemixmsp.go:99-173 Setup): its creators' pseudonym signatures are then verified by the
     // pre-verify pass too.  ipk_raw: marshalled idemix.IssuerPublicKey.  Returns the device issuer id, or -1 (not accelerated).
-    int64_t RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len) const;
+    int64_t RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len, const std::string& channel = std::string()) const;
     // Registers an idemix issuer on EVERY device of the pool, under one lock, so that its id is the same everywhere (ids are handed
     // out in order of registration per context); -1: not accelerated.  ipk_raw: marshalled idemix.IssuerPublicKey.
     int64_t ImportIdemixIssuer(const uint8_t* ipk_raw, size_t len, std::string* err = nullptr) const;
@@ -354,7 +354,8 @@ class GPUCSP {
                              const uint8_t* digest, size_t dlen);
     mutable std::map<int64_t, std::array<uint8_t, 32>> idemix_issuer_hash_;   // device issuer id -> ipk.Hash (guarded by idmu_)
     static uint64_t MemoHash(const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen);
-    mutable std::map<std::string, int64_t> idemix_msps_;   // mspid -> device issuer id (guarded by idmu_)
+    mutable std::map<std::string, int64_t> idemix_msps_;   // mspid -> device issuer id, or -2 while channels disagree (guarded by idmu_)
+    mutable std::map<std::string, std::map<std::string, int64_t>> idemix_msp_channels_;   // mspid -> channel -> that channel's latest issuer id (idmu_)
     // scratch of the pre-verify pass, reused from block to block: a pass leases one set (a peer's channels run passes side by side)
     struct PassScratch {
         struct Gated {

@@ -12,12 +12,14 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <vector>
 
 #include "../../include/fabgpu.h"
 #include "multi_plan.h"
+#include "worker_pool.h"
 
 using namespace fab;
 
@@ -214,15 +216,14 @@ static int multi_verify(fabgpu_multi* m, size_t n, const uint8_t* arena, const u
             if (prev >= 0) hipSetDevice(prev);
         }
     } quiesce(m);
-    // 1. per device: stage the shard, upload, launch - everything asynchronous on the device's own stream
+    // 1a. per device: room (rare: only when a batch is larger than anything before)
     for (uint32_t g = 0; g < G; g++) {
         Dev& d = m->dev[g];
         const size_t cnt = p.hi[g] - p.lo[g], fb = cnt * 32;
         if (hipSetDevice(d.ordinal) != hipSuccess) return FABGPU_ENODEV;
-        size_t msg_bytes = 0, msg_pad = 0, off_bytes = 0;
+        size_t msg_pad = 0, off_bytes = 0;
         if (hash && cnt) {
-            msg_bytes = (size_t)off[p.hi[g]] - off[p.lo[g]];
-            msg_pad = round_up(msg_bytes, 4) + 128;
+            msg_pad = round_up((size_t)off[p.hi[g]] - off[p.lo[g]], 4) + 128;
             off_bytes = round_up((cnt + 1) * 4, 64);
         }
         const size_t in_need = round_up((size_t)nf * fb, 64) + off_bytes + msg_pad + 64;
@@ -232,34 +233,73 @@ static int multi_verify(fabgpu_multi* m, size_t n, const uint8_t* arena, const u
             (rc = grow(&d.h_out, &d.out_cap, (size_t)G * wpr * 8 + 64 + (status ? cnt : 0) + 64, true)) ||
             (status && (rc = grow(&d.d_status, &d.status_cap, cnt + 64, false))))
             return rc;
+    }
+    // 1b. per device, ALL DEVICES AT ONCE (one worker each: the host side's pool, or threads of its own when that is busy): stage the
+    // shard into the device's pinned buffer, upload, launch - asynchronous on the device's own stream.  The staging is a memcpy of the
+    // shard (a configs[3]-sized batch: 557 MB over the node) and was a loop on the calling thread in round 3 - the last of eight
+    // devices got its first byte 50 ms after the first.  Inside a worker the copy and the upload overlap too: every STAGE_PIECE bytes
+    // that are in the pinned buffer go up while the next are being copied.
+    std::vector<int> rcs(G, FABGPU_OK);
+    run_workers((int)G, [&](int gi) {
+        const uint32_t g = (uint32_t)gi;
+        Dev& d = m->dev[g];
+        int& out = rcs[g];
+        const size_t cnt = p.hi[g] - p.lo[g], fb = cnt * 32;
+        if (hipSetDevice(d.ordinal) != hipSuccess) { out = FABGPU_ENODEV; return; }      // (the current device is per thread)
+        size_t msg_bytes = 0, msg_pad = 0, off_bytes = 0;
+        if (hash && cnt) {
+            msg_bytes = (size_t)off[p.hi[g]] - off[p.lo[g]];
+            msg_pad = round_up(msg_bytes, 4) + 128;
+            off_bytes = round_up((cnt + 1) * 4, 64);
+        }
         hipError_t err = hipMemsetAsync(d.d_words, 0, wpr * 8, d.stream);      // tail ranks contribute zero words
-        if (err != hipSuccess) return hip_rc(err);
-        if (!cnt) continue;
+        if (err != hipSuccess) { out = hip_rc(err); return; }
+        if (!cnt) return;
         uint8_t* h = (uint8_t*)d.h_in;
+        uint8_t* dd = (uint8_t*)d.d_in;
+        constexpr size_t STAGE_PIECE = (size_t)4 << 20;
+        size_t sent = 0;
+        auto staged_upto = [&](size_t end_, bool last) {                       // [sent, end_) of the pinned buffer is final: send what is worth a DMA
+            if (err != hipSuccess || end_ <= sent || (!last && end_ - sent < STAGE_PIECE)) return;
+            err = hipMemcpyAsync(dd + sent, h + sent, end_ - sent, hipMemcpyHostToDevice, d.stream);
+            sent = end_;
+        };
+        auto stage = [&](size_t at, const uint8_t* from, size_t bytes) {       // h[at, at + bytes) <- from, in pieces
+            for (size_t k = 0; k < bytes; k += STAGE_PIECE) {
+                const size_t c = std::min(STAGE_PIECE, bytes - k);
+                memcpy(h + at + k, from + k, c);
+                staged_upto(at + k + c, false);
+            }
+        };
         const uint8_t* src[5] = {qx, qy, hash ? r : e, hash ? s : r, s};
-        for (int f = 0; f < nf; f++) memcpy(h + (size_t)f * fb, src[f] + 32 * p.lo[g], fb);
+        for (int f = 0; f < nf; f++) stage((size_t)f * fb, src[f] + 32 * p.lo[g], fb);
         const size_t o_off = round_up((size_t)nf * fb, 64), m_off = o_off + off_bytes;
+        memset(h + (size_t)nf * fb, 0, o_off - (size_t)nf * fb);
         if (hash) {
             uint32_t* ho = (uint32_t*)(h + o_off);
             const uint32_t base = off[p.lo[g]];
             for (size_t i = 0; i <= cnt; i++) ho[i] = off[p.lo[g] + i] - base;
-            if (msg_bytes) memcpy(h + m_off, arena + base, msg_bytes);
+            memset(h + o_off + (cnt + 1) * 4, 0, off_bytes - (cnt + 1) * 4);
+            staged_upto(m_off, false);
+            if (msg_bytes) stage(m_off, arena + base, msg_bytes);
             memset(h + m_off + msg_bytes, 0, msg_pad - msg_bytes);
         }
-        err = hipMemcpyAsync(d.d_in, h, m_off + msg_pad, hipMemcpyHostToDevice, d.stream);
-        if (err != hipSuccess) return hip_rc(err);
-        uint8_t* dd = (uint8_t*)d.d_in;
+        staged_upto(m_off + msg_pad, true);
+        if (err != hipSuccess) { out = hip_rc(err); return; }
+        int r2;
         if (hash)
-            rc = fabgpu_sha256_p256_verify_batch_dev(d.ctx, cnt, dd + m_off, msg_pad, dd + o_off, dd, dd + fb, dd + 2 * fb, dd + 3 * fb, d.d_words,
+            r2 = fabgpu_sha256_p256_verify_batch_dev(d.ctx, cnt, dd + m_off, msg_pad, dd + o_off, dd, dd + fb, dd + 2 * fb, dd + 3 * fb, d.d_words,
                                                      status ? d.d_status : nullptr, d.stream);
         else
-            rc = fabgpu_p256_verify_batch_dev(d.ctx, cnt, dd, dd + fb, dd + 2 * fb, dd + 3 * fb, dd + 4 * fb, d.d_words, status ? d.d_status : nullptr, d.stream);
-        if (rc) return rc;
+            r2 = fabgpu_p256_verify_batch_dev(d.ctx, cnt, dd, dd + fb, dd + 2 * fb, dd + 3 * fb, dd + 4 * fb, d.d_words, status ? d.d_status : nullptr, d.stream);
+        if (r2) { out = r2; return; }
         if (status) {
             err = hipMemcpyAsync((uint8_t*)d.h_out + round_up((size_t)G * wpr * 8, 64), d.d_status, cnt, hipMemcpyDeviceToHost, d.stream);
-            if (err != hipSuccess) return hip_rc(err);
+            if (err != hipSuccess) out = hip_rc(err);
         }
-    }
+    });
+    for (uint32_t g = 0; g < G; g++)
+        if (rcs[g] != FABGPU_OK) return rcs[g];
     // 2. the verdict bitmaps: one all-gather over RCCL / xGMI (every device ends up with the merged bitmap), or G small D2H copies
     if (!m->host_merge) {
         if (m->rccl.GroupStart() != 0) return FABGPU_ELAUNCH;

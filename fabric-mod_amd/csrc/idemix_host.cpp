@@ -4,6 +4,9 @@
 
 #include <string.h>
 
+#include "bn29_consts.h"
+#include "fp256.h"
+
 namespace fab {
 namespace bccsp {
 
@@ -105,6 +108,33 @@ Error IdemixCSP::IssuerKeyImport(const uint8_t* raw, size_t len, IdemixIssuerPub
     if (got == 0) return Error("failed to unmarshal issuer public key");
     out.issuer_id = -1;
     if (got != 2) return Error();   // a key the device cannot take (odd field sizes): valid for bccsp/idemix, not accelerated
+    // The reference never trusts field 10: IssuerPublicKey.Check ends in SetHash (idemix/issuerkey.go:171-182) - Hash = HashModOrder of the
+    // key marshalled with Hash cleared - and the Go side's lookups carry THAT value.  The challenge of every pseudonym signature and
+    // the memo's issuer binding hang on it, so the same is recomputed here (the marshalled key minus its field 10; SHA-256 on the device,
+    // once per registration) and a key whose field 10 says something else is not accelerated.
+    {
+        std::vector<uint8_t> cleared;
+        cleared.reserve(len);
+        Walker w(raw, len);
+        Field f;
+        const uint8_t* at = raw;
+        while (w.next(f)) {
+            if (f.num != 10) cleared.insert(cleared.end(), at, w.p);
+            at = w.p;
+        }
+        const uint32_t off[2] = {0u, (uint32_t)cleared.size()};
+        uint8_t dig[32];
+        if (cleared.empty() || fabgpu_sha256_batch(ctx_, 1, cleared.data(), off, dig) != FABGPU_OK) return Error();
+        // HashModOrder (idemix/util.go:46-51): the digest as a big-endian number, mod the group order (r > 2^255: one subtraction)
+        const u256 R = FAB_BN_R;
+        u256 x, t, red;
+        from_be32(x, dig);
+        const uint32_t borrow = sub256(t, x, R);
+        sel256(red, borrow == 0, t, x);
+        uint8_t want[32];
+        to_be32(want, red);
+        if (memcmp(want, out.hash, 32) != 0) return Error();
+    }
     uint32_t id = 0;
     int rc = fabgpu_idemix_issuer_register(ctx_, out.hsk_x, out.hsk_y, out.hrand_x, out.hrand_y, out.hash, &id);
     if (rc == FABGPU_OK) out.issuer_id = id;

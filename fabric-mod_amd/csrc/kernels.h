@@ -78,6 +78,12 @@ hipError_t launch_sha256_messages(uint32_t n, const void* arena, size_t arena_by
 // cannot fill the chip - SHA_COOP_MAX messages are 256 wavefronts; launch_sha256_batch / _spans (without an LDS reservation) take this road
 // by themselves up to that size.
 constexpr uint32_t SHA_COOP_MAX = 2048;
+// Larger launches: one lane per message, except that messages well above the launch's average length (a quarter above arena_bytes / n,
+// at least 2 KiB) are hashed on eight lanes each - at most eight per 64 messages - by wavefronts of their own inside the same launch
+// (wide_kernels.hip sha256_mixed_kernel).  pairs: off holds (start, end) pairs instead of n + 1 consecutive offsets.  lds_reserve: see
+// ShaPrefixArgs.
+hipError_t launch_sha256_mixed(uint32_t n, const void* arena, size_t arena_bytes, const void* off, bool pairs, void* digests, hipStream_t st,
+                               uint32_t lds_reserve = 0);
 hipError_t launch_sha256_messages_coop(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const ShaPrefixArgs& pa, hipStream_t st,
                                        uint32_t lds_spread = 0);
 

@@ -61,36 +61,7 @@ __global__ void __launch_bounds__(256) sha256_midstate_kernel(uint32_t m, const 
         o[1] = make_uint4(h[4], h[5], h[6], h[7]);
     }
 }
-__global__ void __launch_bounds__(512) sha256_batch_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
-                                                            const uint32_t* __restrict__ off, uint32_t* __restrict__ digests) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < n;
-    uint32_t ic = active ? i : (n - 1);
-    uint32_t start = off[ic], end = off[ic + 1];
-    uint32_t h[8];
-    sha256_lane<true>(arena32, arena_words, start, end - start, active, h);
-    if (active) {
-        uint4* out = reinterpret_cast<uint4*>(digests + 8 * (size_t)i);
-        out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
-        out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
-    }
-}
-
-// the same over (start, end) pairs: message i = arena[spans[2i], spans[2i + 1])
-__global__ void __launch_bounds__(256) sha256_spans_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
-                                                            const uint32_t* __restrict__ spans, uint32_t* __restrict__ digests) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < n;
-    uint32_t ic = active ? i : (n - 1);
-    uint32_t start = spans[2 * ic], end = spans[2 * ic + 1];
-    uint32_t h[8];
-    sha256_lane<true>(arena32, arena_words, start, end >= start ? end - start : 0, active, h);
-    if (active) {
-        uint4* out = reinterpret_cast<uint4*>(digests + 8 * (size_t)i);
-        out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
-        out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
-    }
-}
+// (hash-only launches: wide_kernels.hip - eight lanes per message for small ones, sha256_mixed_kernel beyond)
 
 // ------------------------------------------------------------------------------------------------
 // ECDSA P-256 verify
@@ -418,10 +389,7 @@ hipError_t launch_sha256_batch(uint32_t n, const void* arena, size_t arena_bytes
         pa.digests = digests;
         return launch_sha256_messages_coop(n, arena, arena_bytes, off, pa, st, lds_spread);
     }
-    dim3 grid((n + 255) / 256), block(256);
-    hipLaunchKernelGGL(sha256_batch_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                       (const uint32_t*)off, (uint32_t*)digests);
-    return hipGetLastError();
+    return launch_sha256_mixed(n, arena, arena_bytes, off, false, digests, st);
 }
 hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, void* digests, hipStream_t st, uint32_t lds_reserve,
                                uint32_t lds_spread) {
@@ -432,12 +400,7 @@ hipError_t launch_sha256_spans(uint32_t n, const void* arena, size_t arena_bytes
         pa.digests = digests;
         return launch_sha256_messages_coop(n, arena, arena_bytes, spans, pa, st, lds_spread);
     }
-    // small workgroups: a few thousand long messages spread over many CUs (two wavefronts each when the launch keeps its CUs to itself)
-    const uint32_t per = lds_reserve ? 128 : 64;
-    dim3 grid((n + per - 1) / per), block(per);
-    hipLaunchKernelGGL(sha256_spans_kernel, grid, block, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)spans,
-                       (uint32_t*)digests);
-    return hipGetLastError();
+    return launch_sha256_mixed(n, arena, arena_bytes, spans, true, digests, st, lds_reserve);
 }
 hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_bytes, const void* spans, const void* out_off, void* scratch,
                                 size_t scratch_bytes, void* digests, hipStream_t st, uint32_t lds_reserve, uint32_t lds_spread) {
@@ -447,12 +410,7 @@ hipError_t launch_gather_sha256(uint32_t n, const void* arena, size_t arena_byte
                        (const uint32_t*)out_off, (uint8_t*)scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (lds_reserve) {                    // keeping to its own CUs: 512-thread workgroups, so that the hashes need half as many of them
-        dim3 g2((n + 511) / 512), b2(512);
-        hipLaunchKernelGGL(sha256_batch_kernel, g2, b2, lds_reserve, st, n, (const uint32_t*)scratch, (uint32_t)((scratch_bytes + 3) / 4),
-                           (const uint32_t*)out_off, (uint32_t*)digests);
-        return hipGetLastError();
-    }
+    if (lds_reserve) return launch_sha256_mixed(n, scratch, scratch_bytes, out_off, false, digests, st, lds_reserve);   // keeping to its own CUs
     return launch_sha256_batch(n, scratch, scratch_bytes, out_off, digests, st, lds_spread);
 }
 

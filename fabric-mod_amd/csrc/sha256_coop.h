@@ -15,7 +15,9 @@
 // in front: three endorsements hash their transaction's prp three times, which on idle SIMDs is free, and one launch (and one
 // cross-stream wait) leaves the chain.  pl = 0: a plain message.
 //
-// One wavefront per workgroup (the loop bounds are per wavefront; __syncthreads is the wavefront's own barrier).  LDS: 16 640 bytes.
+// Everything is per WAVEFRONT (loop bounds, the LDS buffer - 16 640 bytes -, the ordering of its LDS accesses: a wavefront's LDS
+// instructions execute in order, so between "these lanes wrote" and "those lanes read" only the compiler has to be held: no workgroup
+// barrier, the other wavefronts of a workgroup are elsewhere in their own messages).
 #pragma once
 #include "device_common.h"
 
@@ -26,7 +28,13 @@ constexpr int SHAC_PER_WAVE = 64 / SHAC_LANES;                       // messages
 constexpr int SHAC_GROUP_WORDS = 64 * SHAC_LANES + 8;                // [t][block of the chunk]; + 8: the eight groups read from different banks
 constexpr int SHAC_LDS_WORDS = SHAC_PER_WAVE * SHAC_GROUP_WORDS;
 
-// h: the digest's eight words in every lane of the group.  lane = threadIdx.x of a 64-thread workgroup.
+__device__ __forceinline__ void shac_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// h: the digest's eight words in every lane of the group.  lane = the lane in its wavefront, lds = that wavefront's SHAC_LDS_WORDS.
 __device__ __forceinline__ void sha256_coop(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t ps, uint32_t pl, uint32_t sb, uint32_t b,
                                             bool active, uint32_t* __restrict__ lds, uint32_t lane, uint32_t h[8]) {
     const uint32_t sub = lane & (SHAC_LANES - 1);
@@ -99,7 +107,7 @@ __device__ __forceinline__ void sha256_coop(const uint32_t* __restrict__ arena32
                 wk[t * SHAC_LANES + sub] = w[t & 15] + K256[t];
             }
         }
-        __syncthreads();
+        shac_wave_sync();
         // ---- phase 2: the rounds of the chunk's blocks, one after the other, in all eight lanes alike ----
         const uint32_t cnt = maxblk - c0 < (uint32_t)SHAC_LANES ? maxblk - c0 : (uint32_t)SHAC_LANES;
         for (uint32_t j = 0; j < cnt; j++) {
@@ -113,7 +121,7 @@ __device__ __forceinline__ void sha256_coop(const uint32_t* __restrict__ arena32
             const uint32_t m = c0 + j < nblk ? 0xFFFFFFFFu : 0u;           // (a shorter message of the wavefront is through already)
             h[0] += a & m; h[1] += bb & m; h[2] += c & m; h[3] += d & m; h[4] += e & m; h[5] += f & m; h[6] += g & m; h[7] += hh & m;
         }
-        __syncthreads();
+        shac_wave_sync();
     }
 }
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "device_common.h"
 #include "kernels.h"
 #include "p256_wide29.h"
@@ -101,6 +103,59 @@ __global__ void __launch_bounds__(64) sha256_messages_coop_kernel(uint32_t n, co
     if (active && (threadIdx.x & (SHAC_LANES - 1)) == 0 && pre.digests != nullptr) sha256_coop_store(pre.digests, i, h);
 }
 
+// A launch too large for eight lanes per message: one lane per message - but not for its LONG messages.  The launch lasts as long as
+// its longest message (a wavefront runs until its last lane is through), and one creator with a 5 KB certificate makes three of a
+// block's messages that long - its payload, its TxID check (nonce || creator), an endorsement if it endorses - which held a
+// 10 000-transaction block's hash checks for 310 us instead of 115 (round 4: the `one_oversize_identity` leg, 1.09x a friendly block).
+// So the messages of more than `long_over` bytes are taken out and hashed on eight lanes each: the first `scan_wgs` workgroups look at
+// 64 messages per wavefront - a lane each - and hash the first EIGHT long ones among them (none, nearly always: they leave after one
+// ballot; one round at most, so that a launch whose messages are all "long" by the launcher's guess loses nothing); the workgroups
+// behind them are the ordinary lane-per-message ones, cut into the same groups of 64, and skip exactly those.  One launch: the long
+// ones start first.
+__global__ void __launch_bounds__(256) sha256_mixed_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+                                                           const uint32_t* __restrict__ off, uint32_t pairs, uint32_t long_over, uint32_t scan_wgs,
+                                                           uint32_t* __restrict__ digests) {
+    extern __shared__ uint32_t lds_all[];                                  // SHAC_LDS_WORDS per wavefront of the workgroup
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    auto span = [&](uint32_t i, uint32_t& start, uint32_t& len) {
+        start = off[pairs ? 2 * i : i];
+        const uint32_t end = off[pairs ? 2 * i + 1 : i + 1];
+        len = end >= start ? end - start : 0;
+    };
+    if (blockIdx.x < scan_wgs) {
+        uint32_t* lds = lds_all + wave * SHAC_LDS_WORDS;
+        const uint32_t i0 = (blockIdx.x * waves + wave) * 64u, mine = i0 + lane;
+        uint32_t st0 = 0, ln0 = 0;
+        if (mine < n) span(mine, st0, ln0);
+        uint64_t longs = __ballot(mine < n && ln0 > long_over);
+        if (longs == 0ull) return;
+        uint32_t pick = 64;
+        for (uint32_t g = 0; g < (uint32_t)SHAC_PER_WAVE && longs; g++) {    // (wavefront-uniform) the first eight, one per lane group
+            const uint32_t b = (uint32_t)__builtin_ctzll(longs);
+            longs &= longs - 1;
+            if ((lane >> 3) == g) pick = b;
+        }
+        const bool active = pick < 64;
+        const uint32_t i = i0 + (active ? pick : 0u);
+        uint32_t start = 0, len = 0;
+        if (active) span(i, start, len);
+        uint32_t h[8];
+        sha256_coop(arena32, arena_words, 0, 0, start, len, active, lds, lane, h);
+        if (active && (lane & (SHAC_LANES - 1)) == 0) sha256_coop_store(digests, i, h);
+        return;
+    }
+    const uint32_t i = (blockIdx.x - scan_wgs) * blockDim.x + threadIdx.x;
+    uint32_t start = 0, len = 0;
+    if (i < n) span(i, start, len);
+    // (this wavefront's 64 messages are the 64 a scan wavefront looked at: the first eight long ones are that one's)
+    const uint64_t longs = __ballot(i < n && len > long_over);
+    const bool taken = i < n && len > long_over && __builtin_popcountll(longs & ((1ull << lane) - 1ull)) < SHAC_PER_WAVE;
+    const bool active = i < n && !taken;
+    uint32_t h[8];
+    sha256_lane<true>(arena32, arena_words, start, len, active, h);
+    if (active) sha256_coop_store(digests, i, h);
+}
+
 // Unused dynamic LDS asked for with the launches of one-wavefront workgroups (the wide kernels, the eight-lane hashes) so that they SPREAD
 // over the chip: the dispatcher fills a CU as long as a workgroup fits - nine of the hash kernel's, dozens of `pre`'s - and wavefronts
 // that share a SIMD take turns.  workgroups = how many of them run at the same time, over all the launches that do (a pass tells: its
@@ -155,6 +210,20 @@ hipError_t launch_sha256_messages(uint32_t n, const void* arena, size_t arena_by
     pre.digests = (uint32_t*)pa.digests;
     dim3 grid((n + 63) / 64), block(64);
     hipLaunchKernelGGL(sha256_messages_kernel, grid, block, 0, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, pre);
+    return hipGetLastError();
+}
+hipError_t launch_sha256_mixed(uint32_t n, const void* arena, size_t arena_bytes, const void* off, bool pairs, void* digests, hipStream_t st,
+                               uint32_t lds_reserve) {
+    if (n == 0) return hipSuccess;
+    // (a launch that keeps CUs to itself - lds_reserve, ShaPrefixArgs - brings four wavefronts per workgroup, one per SIMD of its CU)
+    const uint32_t block = lds_reserve ? 256u : 64u, wgs = (n + block - 1) / block;
+    const uint32_t own = (block / 64u) * (uint32_t)SHAC_LDS_WORDS * 4u;
+    // "long": a quarter above what the messages average if they fill their arena (they do: a block's payloads, a gather scratch), and at
+    // least 2 KiB.  A friendly 10 000-transaction block: payloads of 5.0 KB, threshold 6.3 KB; its hash checks: 1.3 KB, threshold 2 KiB.
+    const uint64_t mean = arena_bytes / n;
+    const uint32_t long_over = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(2048, mean + mean / 4));
+    hipLaunchKernelGGL(sha256_mixed_kernel, dim3(2 * wgs), dim3(block), lds_reserve > own ? lds_reserve : own, st, n, (const uint32_t*)arena,
+                       (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, pairs ? 1u : 0u, long_over, wgs, (uint32_t*)digests);
     return hipGetLastError();
 }
 hipError_t launch_sha256_messages_coop(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const ShaPrefixArgs& pa, hipStream_t st,

@@ -102,7 +102,7 @@ ABI_SYMBOLS = [
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
-    "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_block_hash_checks",
+    "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_csp_idemix_msp_register2", "fabgpu_block_hash_checks",
     "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_lookup_nym", "fabgpu_csp_memo_has_block", "fabgpu_csp_memo_evict_block",
     "fabgpu_csp_verify_coalesced", "fabgpu_csp_identity_verify_coalesced", "fabgpu_csp_coalescer_configure", "fabgpu_csp_coalescer_stats",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
@@ -191,6 +191,7 @@ def load():
     L.fabgpu_csp_block_preverify.argtypes = [_vp, _u8p, _sz, _u32p, _u8p, _u8p, ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_uint32]
     L.fabgpu_block_parse.argtypes = [_u8p, _sz, _u32p, _u32p, _u32p, _u8p, ctypes.c_uint32, ctypes.c_char_p, _sz]
     L.fabgpu_csp_idemix_msp_register.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64)]
+    L.fabgpu_csp_idemix_msp_register2.argtypes = [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64)]
     L.fabgpu_csp_idemix_issuer_import.argtypes = [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, _sz]
     L.fabgpu_csp_idemix_nym_verify_batch.argtypes = [_vp, ctypes.c_int64, _sz, _u8p, _u32p, _u8p, _u32p, _u8p, _u32p, _u8p, _u8p, ctypes.c_char_p, _sz]
     L.fabgpu_block_hash_checks.argtypes = [_u8p, _sz, ctypes.c_uint32, _u32p, _u32p, _u8p, _u32p, _u32p]
@@ -768,11 +769,17 @@ class GPUCSP:
             raise BCCSPError(err.value.decode())
         return int(iid.value)
 
-    def idemix_msp_register(self, mspid: str, ipk_raw: bytes) -> int:
-        """An idemix MSP of the channel: preverify_block then verifies its creators' pseudonym signatures too."""
+    def idemix_msp_register(self, mspid: str, ipk_raw: bytes, channel: Optional[str] = None) -> int:
+        """An idemix MSP of the channel: preverify_block then verifies its creators' pseudonym signatures too.  With a channel name the
+        channel's latest key for the MSP id replaces its earlier one (rotation); the MSP id is ambiguous only while two channels disagree.
+        -1: not accelerated (a key the device does not take, or one whose Hash field is not the hash of the rest of the key)."""
         iid = ctypes.c_int64(-1)
-        _check(self._L.fabgpu_csp_idemix_msp_register(self._h, mspid.encode(), bytes(ipk_raw), len(ipk_raw), ctypes.byref(iid)),
-               "fabgpu_csp_idemix_msp_register")
+        if channel is None:
+            _check(self._L.fabgpu_csp_idemix_msp_register(self._h, mspid.encode(), bytes(ipk_raw), len(ipk_raw), ctypes.byref(iid)),
+                   "fabgpu_csp_idemix_msp_register")
+        else:
+            _check(self._L.fabgpu_csp_idemix_msp_register2(self._h, channel.encode(), mspid.encode(), bytes(ipk_raw), len(ipk_raw), ctypes.byref(iid)),
+                   "fabgpu_csp_idemix_msp_register2")
         return int(iid.value)
 
     def idemix_nym_verify_batch(self, issuer_id: int, nym_keys: Sequence[bytes], sigs: Sequence[bytes], msgs: Sequence[bytes]):

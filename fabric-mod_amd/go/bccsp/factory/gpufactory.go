@@ -33,6 +33,11 @@ type GPUOpts struct {
 	// MaxMessageCount x (1 + endorsements) are the numbers to put here).
 	ExpectBlockBytes int `mapstructure:"expectblockbytes" json:"expectblockbytes" yaml:"ExpectBlockBytes"`
 	ExpectTuples     int `mapstructure:"expecttuples" json:"expecttuples" yaml:"ExpectTuples"`
+	// MemoBlocks: how many pre-verified blocks the verdict memo may hold while they wait for their validators - MemoBlocks x ExpectTuples
+	// entries.  The bounded memo drops its OLDEST block first, which during a state transfer is the one the committer needs next, so this
+	// must not be smaller than what the payload buffer accepts ahead: peer.gossip.state.blockBufferSize (core.yaml, default 20; the
+	// arrival hook only pre-verifies blocks the buffer kept).  0 = the library's 2^18 entries (six 10 000-transaction blocks).
+	MemoBlocks int `mapstructure:"memoblocks" json:"memoblocks" yaml:"MemoBlocks"`
 	// HostWalk keeps the envelope walk of the block pass on the host (A/B runs); PassTiming prints every pass's stage breakdown.
 	HostWalk   bool `mapstructure:"hostwalk" json:"hostwalk" yaml:"HostWalk"`
 	PassTiming bool `mapstructure:"passtiming" json:"passtiming" yaml:"PassTiming"`
@@ -64,7 +69,7 @@ func (f *GPUFactory) Get(config *FactoryOpts) (bccsp.BCCSP, error) {
 	var opts gpu.Options
 	if g := config.GPUOpts; g != nil {
 		opts = gpu.Options{Devices: g.Devices, ConcurrentPasses: g.ConcurrentPasses, ExpectBlockBytes: g.ExpectBlockBytes,
-			ExpectTuples: g.ExpectTuples, HostWalk: g.HostWalk, PassTiming: g.PassTiming}
+			ExpectTuples: g.ExpectTuples, MemoBlocks: g.MemoBlocks, HostWalk: g.HostWalk, PassTiming: g.PassTiming}
 	}
 	csp, err := gpu.New(swCSP, opts)
 	if err != nil {

@@ -103,6 +103,7 @@ type Options struct {
 	ConcurrentPasses int   // per device: staging slots, pinned memo tables and pass arrays for that many overlapping passes are allocated now
 	ExpectBlockBytes int   // sizes that pre-allocation (0: 64 MiB) ...
 	ExpectTuples     int   // ... (0: 65 536 signatures per block)
+	MemoBlocks       int   // the verdict memo holds this many blocks' worth of entries (x ExpectTuples); 0: the library's 2^18 entries
 	HostWalk         bool  // keep the envelope walk on the host (A/B runs)
 	PassTiming       bool  // stage breakdown of every pass on stderr
 }
@@ -199,6 +200,15 @@ func New(swCSP bccsp.BCCSP, opts Options) (bccsp.BCCSP, error) {
 	errbuf := make([]byte, 256)
 	if rc := C.fabgpu_csp_new2(&o, &csp, (*C.char)(unsafe.Pointer(&errbuf[0])), C.size_t(len(errbuf))); rc != 0 {
 		return nil, errors.Errorf("Failed initializing GPU BCCSP: %s (%s)", C.GoString(C.fabgpu_strerror(rc)), C.GoString((*C.char)(unsafe.Pointer(&errbuf[0]))))
+	}
+	if opts.MemoBlocks > 0 {
+		// (peer.gossip.state.blockBufferSize blocks may be waiting for their validators: the memo must hold them all, or it drops the
+		// oldest - the block the committer needs next - and every block of a catch-up is passed twice)
+		tuples := opts.ExpectTuples
+		if tuples <= 0 {
+			tuples = 65536
+		}
+		C.fabgpu_csp_memo_set_capacity(csp, C.uint64_t(opts.MemoBlocks)*C.uint64_t(tuples))
 	}
 	return &Provider{BCCSP: swCSP, csp: csp, capTx: 1024}, nil
 }
@@ -413,15 +423,22 @@ func (p *Provider) HasBlock(blockSeq uint64) bool {
 }
 
 // RegisterIdemixMSP makes the block pass verify the pseudonym signatures of creators serialized under mspID
-// (msp/idemixmsp.go:99-173 Setup calls this with the marshalled idemix.IssuerPublicKey).  false: not accelerated.
-func (p *Provider) RegisterIdemixMSP(mspID string, ipkBytes []byte) bool {
+// (RegisterIdemixMSPsOfConfig, idemix_config.go, calls this for every idemix MSP of a channel's committed configuration with the
+// marshalled idemix.IssuerPublicKey its msp/idemixmsp.go:99-173 Setup imports).
+// The pass sees MSP ids, not channels: a channel's latest key for an MSP id replaces its earlier one (a config update that rotates the
+// issuer key), and while two channels' current keys for one MSP id differ that MSP id's creators stay with bccsp/idemix.
+// false: not accelerated (a key the device does not take, or one whose Hash field is not the hash of the rest of the key - the
+// reference recomputes it, idemix/issuerkey.go:171-182, and so does the library).
+func (p *Provider) RegisterIdemixMSP(channelID, mspID string, ipkBytes []byte) bool {
 	if len(ipkBytes) == 0 {
 		return false
 	}
+	cc := C.CString(channelID)
+	defer C.free(unsafe.Pointer(cc))
 	cs := C.CString(mspID)
 	defer C.free(unsafe.Pointer(cs))
 	var id C.int64_t
-	rc := C.fabgpu_csp_idemix_msp_register(p.csp, cs, (*C.uint8_t)(unsafe.Pointer(&ipkBytes[0])), C.size_t(len(ipkBytes)), &id)
+	rc := C.fabgpu_csp_idemix_msp_register2(p.csp, cc, cs, (*C.uint8_t)(unsafe.Pointer(&ipkBytes[0])), C.size_t(len(ipkBytes)), &id)
 	return rc == 0 && id >= 0
 }
 

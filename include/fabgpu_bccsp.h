@@ -261,8 +261,13 @@ int fabgpu_block_tuples(const uint8_t* block, size_t len, uint32_t cap, uint32_t
 /* An idemix MSP of the channel (msp/idemixmsp.go:99-173): after this call fabgpu_csp_block_preverify also verifies the pseudonym
  * signatures of creators serialized under `mspid` (tuple_status 0 valid / 1 invalid / 6 left to bccsp/idemix).  Registering one MSP id
  * with a SECOND, different issuer key (another channel's MSP of the same name) makes the pass leave that MSP id's creators to
- * bccsp/idemix (status 6): it sees MSP ids, not channels. */
+ * bccsp/idemix (status 6): it sees MSP ids, not channels.
+ * fabgpu_csp_idemix_msp_register2 names the channel whose config carries the MSP: a channel's LATEST key for an MSP id replaces its earlier
+ * one (issuer-key rotation), and the MSP id is ambiguous only while two channels' current keys for it differ.  (..._register = channel "".)
+ * A key whose field 10 (Hash) is not HashModOrder of the rest of the key - which is what the reference recomputes and uses,
+ * idemix/issuerkey.go:171-182 - is not accelerated (*issuer_id = -1). */
 int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id);
+int fabgpu_csp_idemix_msp_register2(fabgpu_csp* csp, const char* channel, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id);
 int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap);
 int fabgpu_csp_idemix_nym_verify_batch(fabgpu_csp* csp, int64_t issuer_id, size_t n, const uint8_t* nym_arena, const uint32_t* nym_off,
                                        const uint8_t* sig_arena, const uint32_t* sig_off, const uint8_t* msg_arena, const uint32_t* msg_off,

@@ -318,6 +318,28 @@ def test_preverify_pass_with_idemix_creators():
     amb = fabgpu.preverify_block(csp, blk)
     assert (amb["tx_flags"][idemix_tx] == fabgpu.TX_NEEDS_SW).all() and (amb["tx_flags"][~idemix_tx] == 0).all()
     csp.close()
+    # With channels named, a channel's latest key replaces its earlier one: a second channel that disagrees makes the MSP id ambiguous,
+    # and the ambiguity ends when that channel's config moves to the same key (or the first channel rotates to the other's)
+    csp = fabgpu.GPUCSP(device=0)
+    assert csp.idemix_msp_register("IdemixMSP1", raw_ipk, channel="ch1") >= 0
+    assert (fabgpu.preverify_block(csp, blk)["tx_flags"] == want).all()
+    assert csp.idemix_msp_register("IdemixMSP1", raw_ipk2, channel="ch2") >= 0
+    amb = fabgpu.preverify_block(csp, blk)
+    assert (amb["tx_flags"][idemix_tx] == fabgpu.TX_NEEDS_SW).all() and (amb["tx_flags"][~idemix_tx] == 0).all()
+    assert csp.idemix_msp_register("IdemixMSP1", raw_ipk, channel="ch2") >= 0
+    assert (fabgpu.preverify_block(csp, blk)["tx_flags"] == want).all()
+    # rotation inside the one channel left: its creators now verify under the NEW key - these, signed under the old one, fail
+    assert csp.idemix_msp_register("IdemixMSP1", raw_ipk2, channel="ch1") >= 0 and csp.idemix_msp_register("IdemixMSP1", raw_ipk2, channel="ch2") >= 0
+    rot = fabgpu.preverify_block(csp, blk)
+    # (... those the nym kernel decides; the ones the block leaves to bccsp/idemix stay there)
+    assert (rot["tx_flags"][idemix_tx] == np.where(want[idemix_tx] == fabgpu.TX_NEEDS_SW, fabgpu.TX_NEEDS_SW, fabgpu.TX_BAD_CREATOR_SIGNATURE)).all()
+    assert (rot["tx_flags"][~idemix_tx] == 0).all()
+    # The Hash field of a marshalled issuer key is not trusted (the reference recomputes it: idemix/issuerkey.go:171-182): a key whose
+    # field 10 says something else is not accelerated
+    assert raw_ipk[-34] == 0x52 and raw_ipk[-33] == 0x20
+    forged = raw_ipk[:-1] + bytes([raw_ipk[-1] ^ 1])
+    assert csp.idemix_msp_register("IdemixMSP9", forged, channel="ch1") == -1
+    csp.close()
 
 
 @pytest.mark.gpu

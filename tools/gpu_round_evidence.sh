@@ -13,7 +13,7 @@ timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 ( time timeout 600 python bench.py ) > $O/r04_final_bench.json 2> $O/r04_final_bench.err; tail -3 $O/r04_final_bench.err | cut -c1-200; wc -c $O/r04_final_bench.json
 rm -rf /tmp/prof_bench
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python $R/bench.py > $O/r04_final_bench_under_rocprof.json 2> $O/r04_final_bench_under_rocprof.err )
-f=$(find /tmp/prof_bench -name "*.db" 2>/dev/null | head -1)
+f=$(find /tmp/prof_bench -name "*.db" -printf "%s %p\n" 2>/dev/null | sort -n | tail -1 | cut -d" " -f2)   # (bench.py starts helper processes: theirs are the small ones)
 if [ -n "$f" ]; then python $R/profiles/summarize_rocprof.py "$f" > $O/r04_final_rocprof_stats.txt 2>&1; head -12 $O/r04_final_rocprof_stats.txt | cut -c1-160; else echo "no rocprof db"; fi
 FABGPU_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 > $O/r04_final_bench_n2_gloo.json 2> $O/r04_final_bench_n2_gloo.err
 echo "n2 rc=$?"; cut -c1-300 $O/r04_final_bench_n2_gloo.json | tail -2
