@@ -1661,7 +1661,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             // (up to SHA_COOP_MAX of them: eight lanes on a message, the workgroups spread by what a block of ne transactions with four
             //  signatures each will run beside them - `pre` and the endorsements' hashes, nt / 8 workgroups each, the hash checks' ne / 4)
             err = launch_sha256_spans(ne, sl->d, round_up(sl->len, 4) + 64, a.payload_spans, a.digest_env, ctx->stream2, ne > 2048 ? 84u << 10 : 0u,
-                                      spread_lds_bytes(ne / 8 + ne + ne / 4 + 3));
+                                      spread_waves_per_cu(ne / 8 + ne + ne / 4 + 3));
         }
     }
     if (err == hipSuccess && has_tail) {
@@ -1911,8 +1911,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // BESIDE the hashes; `post` (e w, u1 G, the final addition and comparison: 18 000 instructions) is all that is left behind them.
     const bool wide = ctx->allow_wide && both_pair && keyed_c && keyed_o && nt <= (uint32_t)WIDE_LAUNCH_MAX && !has_nym_rows;
     // The one-wavefront workgroups of a small block's launches - `pre` (nt / 8), the endorsements' hashes (nt / 8), the hash checks'
-    // (nc / 8), the creators' early hashes still running - spread over the chip together (kernels.h spread_lds_bytes).
-    const uint32_t spread = spread_lds_bytes(nt / 8 + nt / 8 + nc / 8 + 3);
+    // (nc / 8), the creators' early hashes still running - are placed together (kernels.h spread_waves_per_cu).
+    const uint32_t spread = spread_waves_per_cu(nt / 8 + nt / 8 + nc / 8 + 3);
     err = hipEventRecord(ctx->ev_w[0], st);
     // (The gates are queued right here, ahead of the side streams' work: on a small block the host's calls, not the kernels, set the pace,
     //  and the gate kernel is the main stream's critical path.)

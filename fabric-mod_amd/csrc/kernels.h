@@ -64,10 +64,11 @@ hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t
 // messages are still being hashed.  post: e = the 32-byte digests by row -> verdict bits (ceil(n / 64) words, written bytewise) and status.
 constexpr int WIDE_LAUNCH_MAX = 8192;
 constexpr size_t WIDE_SCRATCH_BYTES = 144;
-// lds_spread: bytes of LDS to ask for so that the one-wavefront workgroups spread over the chip - spread_lds_bytes(the workgroups that run
-// at the same time, over all launches that do); 0 = this launch's own count
-constexpr uint32_t SPREAD_NONE = 1;                 // "no reservation" (0 = decide by the launch's own workgroup count)
-uint32_t spread_lds_bytes(uint32_t workgroups);
+// lds_spread: how many wavefronts of the small launches a CU should take at most - spread_waves_per_cu(the wavefronts that run at the same
+// time, over all launches that do) = 1, 2, 4, 8 or SPREAD_NONE; a launch turns it into unused dynamic LDS per workgroup
+// (wide_kernels.hip "PLACEMENT").  0 = from this launch's own wavefront count.
+constexpr uint32_t SPREAD_NONE = 0xFFFFFFFFu;
+uint32_t spread_waves_per_cu(uint32_t wavefronts);
 hipError_t launch_p256_wide_pre(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* r, const void* s, const void* gtab,
                                 void* scratch, hipStream_t st, uint32_t lds_spread = 0);
 hipError_t launch_p256_wide_post(uint32_t n, const void* e, const void* r, const void* gtab, const void* scratch, void* verdict_bits, void* status,

@@ -16,16 +16,18 @@ namespace fab {
 // puts it; 8 192 signatures are 1 024, one per SIMD.
 constexpr int WIDE_BLOCK = 64;
 
-__global__ void __launch_bounds__(WIDE_BLOCK, 1) p256_wide_pre_kernel(uint32_t n, const uint32_t* __restrict__ key_id, uint32_t nkeys,
+template <int W>
+__global__ void __launch_bounds__(64 * W, 1) p256_wide_pre_kernel(uint32_t n, const uint32_t* __restrict__ key_id, uint32_t nkeys,
                                                                       const int32_t* const* __restrict__ ktabs, const uint8_t* __restrict__ r,
                                                                       const uint8_t* __restrict__ s, const int32_t* __restrict__ gtab,
                                                                       int32_t* __restrict__ scratch) {
     GTab16 gt{gtab};
     constexpr uint32_t PER = WIDE_BLOCK / WIDE_LANES;
-    const uint32_t sub = threadIdx.x & (WIDE_LANES - 1);
+    const uint32_t lane = threadIdx.x & 63u, waves = blockDim.x >> 6;      // a tile = one wavefront's eight signatures
+    const uint32_t sub = lane & (WIDE_LANES - 1);
     const uint32_t ntiles = (n + PER - 1) / PER;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t i = tile * PER + (threadIdx.x >> 3);
+    for (uint32_t tile = blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * waves) {
+        const uint32_t i = tile * PER + (lane >> 3);
         const bool active = i < n;
         const uint32_t ic = active ? i : (n - 1);
         const uint32_t kid = key_id[ic];
@@ -40,15 +42,17 @@ __global__ void __launch_bounds__(WIDE_BLOCK, 1) p256_wide_pre_kernel(uint32_t n
 
 // e: 32-byte big-endian digests by row.  verdict8: one byte per eight signatures (bit k of byte j = signature 8 j + k), i.e. the byte
 // view of the usual verdict words.
-__global__ void __launch_bounds__(WIDE_BLOCK, 1) p256_wide_post_kernel(uint32_t n, const uint8_t* __restrict__ e, const uint8_t* __restrict__ r,
+template <int W>
+__global__ void __launch_bounds__(64 * W, 1) p256_wide_post_kernel(uint32_t n, const uint8_t* __restrict__ e, const uint8_t* __restrict__ r,
                                                                        const int32_t* __restrict__ gtab, const int32_t* __restrict__ scratch,
                                                                        uint8_t* __restrict__ verdict8, uint8_t* __restrict__ status) {
     GTab16 gt{gtab};
     constexpr uint32_t PER = WIDE_BLOCK / WIDE_LANES;
-    const uint32_t sub = threadIdx.x & (WIDE_LANES - 1);
+    const uint32_t lane = threadIdx.x & 63u, waves = blockDim.x >> 6;
+    const uint32_t sub = lane & (WIDE_LANES - 1);
     const uint32_t ntiles = (n + PER - 1) / PER;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t i = tile * PER + (threadIdx.x >> 3);
+    for (uint32_t tile = blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * waves) {
+        const uint32_t i = tile * PER + (lane >> 3);
         const bool active = i < n;
         const uint32_t ic = active ? i : (n - 1);
         u256 ve, vr;
@@ -60,7 +64,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK, 1) p256_wide_post_kernel(uint32_t 
         x = (x | (x >> 7)) & 0x0003000300030003ull;
         x = (x | (x >> 14)) & 0x0000000f0000000full;
         x = (x | (x >> 28)) & 0xffull;
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             verdict8[tile] = (uint8_t)x;       // (PER == 8: tile j covers signatures 8 j .. 8 j + 7)
             if (tile == ntiles - 1)            // the rest of the last 64-bit verdict word: nobody's signatures
                 for (uint32_t b = ntiles; b < ((n + 63) / 64) * 8; b++) verdict8[b] = 0;
@@ -82,10 +86,13 @@ __global__ void __launch_bounds__(64) sha256_messages_kernel(uint32_t n, const u
 }
 
 // The same digests with eight lanes on a message (sha256_coop.h): no mid-states - a prefixed message is hashed whole, prefix first.
-__global__ void __launch_bounds__(64) sha256_messages_coop_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
+template <int W>
+__global__ void __launch_bounds__(64 * W) sha256_messages_coop_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words,
                                                                   const uint32_t* __restrict__ off, sha_prefixes pre) {
-    extern __shared__ uint32_t lds[];                                      // SHAC_LDS_WORDS, or more (spread_lds_bytes: placement)
-    const uint32_t i = blockIdx.x * SHAC_PER_WAVE + (threadIdx.x >> 3);
+    extern __shared__ uint32_t lds_all[];                                  // SHAC_LDS_WORDS per wavefront, or more (placement: see PLACEMENT below)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* lds = lds_all + wave * SHAC_LDS_WORDS;
+    const uint32_t i = (blockIdx.x * (blockDim.x >> 6) + wave) * SHAC_PER_WAVE + (lane >> 3);
     const bool active = i < n;
     const uint32_t ic = active ? i : (n - 1);
     const uint32_t sb = off[pre.spans ? 2 * ic : ic], se = off[pre.spans ? 2 * ic + 1 : ic + 1];
@@ -99,8 +106,8 @@ __global__ void __launch_bounds__(64) sha256_messages_coop_kernel(uint32_t n, co
         }
     }
     uint32_t h[8];
-    sha256_coop(arena32, arena_words, ps, pl, sb, se >= sb ? se - sb : 0, active, lds, threadIdx.x, h);
-    if (active && (threadIdx.x & (SHAC_LANES - 1)) == 0 && pre.digests != nullptr) sha256_coop_store(pre.digests, i, h);
+    sha256_coop(arena32, arena_words, ps, pl, sb, se >= sb ? se - sb : 0, active, lds, lane, h);
+    if (active && (lane & (SHAC_LANES - 1)) == 0 && pre.digests != nullptr) sha256_coop_store(pre.digests, i, h);
 }
 
 // A launch too large for eight lanes per message: one lane per message - but not for its LONG messages.  The launch lasts as long as
@@ -156,27 +163,29 @@ __global__ void __launch_bounds__(256) sha256_mixed_kernel(uint32_t n, const uin
     if (active) sha256_coop_store(digests, i, h);
 }
 
-// Unused dynamic LDS asked for with the launches of one-wavefront workgroups (the wide kernels, the eight-lane hashes) so that they SPREAD
-// over the chip: the dispatcher fills a CU as long as a workgroup fits - nine of the hash kernel's, dozens of `pre`'s - and wavefronts
-// that share a SIMD take turns.  workgroups = how many of them run at the same time, over all the launches that do (a pass tells: its
-// `pre`, its hashes and its hash checks run side by side); 160 KB of LDS per CU / the workgroups a CU must take = the reservation.
-// Measured, device phase of a pass by block size and workgroups allowed per CU (tools/gpu_probe_small2.py; none = no reservation):
-//      100 tx (125 workgroups at a time):  1: 0.304 ms   2: 0.355   3: 0.350   8: 0.340   none: 0.350
-//      500 tx (625):                       1: 0.454      2: 0.466   3: 0.437   8: 0.458   none: 0.451
-//    1 000 tx (1 250):                     1: 0.539      2: 0.543   3: 0.488   8: 0.469
-// - it pays while every workgroup can have a CU to itself and does nothing (500) or harm (1 000) beyond: up to three per CU by count,
-// none after that (SPREAD_NONE).
-uint32_t spread_lds_bytes(uint32_t workgroups) {
-    const uint32_t per_cu = (workgroups + 255) / 256;
-    if (per_cu > 3) return SPREAD_NONE;
-    return ((160u << 10) / (per_cu ? per_cu : 1u)) - (4u << 10);          // 1 per CU: 156 KB, 2: 76 KB, 3: 49 KB
+// PLACEMENT of the small launches (the wide kernels, the eight-lane hashes): their wavefronts are long serial instruction streams, a
+// SIMD runs one such stream at full speed and two at half each, and the dispatcher fills a CU as long as a workgroup fits - dozens of
+// one-wavefront workgroups, on whichever SIMDs.  Two levers, both measured (tools/gpu_probe_small2.py, device phase of a pass):
+//   * workgroups of SEVERAL wavefronts - a workgroup's wavefronts go to different SIMDs of its CU: two per workgroup for the wide
+//     kernels (four do not launch: HSA_STATUS_ERROR_INVALID_ALLOCATION), four for the hashes: 500 tx 0.498 -> 0.406 ms, 1 000 tx
+//     0.599 -> 0.562 (same box, same call; 100 tx 0.345 -> 0.328);
+//   * unused dynamic LDS, so that a CU takes no more wavefronts of these launches than it should: `cap` wavefronts per CU = what
+//     runs at the same time over all the launches that do (a pass tells: its `pre`, its hashes and its hash checks run side by side)
+//     / 256 CUs, rounded up to 1, 2, 4 or 8; a workgroup of W wavefronts asks for W / cap of the CU's 160 KB.  One workgroup per CU
+//     while that is possible (100 tx: 0.35 -> 0.30 ms against four one-wavefront workgroups per CU), one wavefront per SIMD up to
+//     1 024 of them, two up to 2 048, nothing beyond.
+uint32_t spread_waves_per_cu(uint32_t wavefronts) {
+    const uint32_t per_cu = (wavefronts + 255) / 256;
+    return per_cu <= 1 ? 1u : (per_cu <= 2 ? 2u : (per_cu <= 4 ? 4u : (per_cu <= 8 ? 8u : SPREAD_NONE)));
 }
-
-// what a launch asks for: the caller's figure, or (0) one from its own workgroup count; SPREAD_NONE = nothing
-static uint32_t spread_or_own(uint32_t lds_spread, uint32_t workgroups) {
-    if (lds_spread == 0) lds_spread = spread_lds_bytes(workgroups);
-    return lds_spread == SPREAD_NONE ? 0u : lds_spread;
+// the dynamic LDS a launch of W-wavefront workgroups asks for under `cap` (0: from its own wavefront count)
+static uint32_t spread_bytes(uint32_t cap, uint32_t own_wavefronts, uint32_t W) {
+    if (cap == 0) cap = spread_waves_per_cu(own_wavefronts);
+    if (cap == SPREAD_NONE) return 0;
+    const uint32_t wgs_per_cu = cap > W ? cap / W : 1u;
+    return ((160u << 10) / wgs_per_cu) - (4u << 10);                      // 1 per CU: 156 KB, 2: 76 KB, 4: 36 KB, 8: 16 KB
 }
+constexpr uint32_t WIDE_WG_WAVES = 2, COOP_WG_WAVES = 4;
 
 static_assert(WIDE_BLOCK / WIDE_LANES == 8, "one verdict byte per tile");
 static_assert(WIDE_LAUNCH_MAX == WIDE_MAX && WIDE_SCRATCH_BYTES == 4 * WIDE_SCRATCH_WORDS, "kernels.h restates p256_wide29.h for the host");
@@ -184,18 +193,20 @@ static_assert(WIDE_LAUNCH_MAX == WIDE_MAX && WIDE_SCRATCH_BYTES == 4 * WIDE_SCRA
 hipError_t launch_p256_wide_pre(uint32_t n, const void* key_id, uint32_t nkeys, const void* ktabs, const void* r, const void* s, const void* gtab,
                                 void* scratch, hipStream_t st, uint32_t lds_spread) {
     if (n == 0) return hipSuccess;
-    const uint32_t tiles = (n + 7) / 8;
-    dim3 grid(tiles < 4096u ? tiles : 4096u), block(WIDE_BLOCK);
-    hipLaunchKernelGGL(p256_wide_pre_kernel, grid, block, spread_or_own(lds_spread, grid.x), st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
+    const uint32_t tiles = (n + 7) / 8, W = tiles >= WIDE_WG_WAVES ? WIDE_WG_WAVES : 1u, wgs = (tiles + W - 1) / W;
+    dim3 grid(wgs < 4096u ? wgs : 4096u), block(64 * W);
+    auto k = W == 2 ? p256_wide_pre_kernel<2> : p256_wide_pre_kernel<1>;
+    hipLaunchKernelGGL(k, grid, block, spread_bytes(lds_spread, tiles, W), st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
                        (const uint8_t*)s, (const int32_t*)gtab, (int32_t*)scratch);
     return hipGetLastError();
 }
 hipError_t launch_p256_wide_post(uint32_t n, const void* e, const void* r, const void* gtab, const void* scratch, void* verdict_bits, void* status,
                                  hipStream_t st, uint32_t lds_spread) {
     if (n == 0) return hipSuccess;
-    const uint32_t tiles = (n + 7) / 8;
-    dim3 grid(tiles < 4096u ? tiles : 4096u), block(WIDE_BLOCK);
-    hipLaunchKernelGGL(p256_wide_post_kernel, grid, block, spread_or_own(lds_spread, grid.x), st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
+    const uint32_t tiles = (n + 7) / 8, W = tiles >= WIDE_WG_WAVES ? WIDE_WG_WAVES : 1u, wgs = (tiles + W - 1) / W;
+    dim3 grid(wgs < 4096u ? wgs : 4096u), block(64 * W);
+    auto k = W == 2 ? p256_wide_post_kernel<2> : p256_wide_post_kernel<1>;
+    hipLaunchKernelGGL(k, grid, block, spread_bytes(lds_spread, tiles, W), st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
                        (uint8_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
@@ -236,10 +247,12 @@ hipError_t launch_sha256_messages_coop(uint32_t n, const void* arena, size_t are
     pre.m = pre.pre_idx ? pa.m : 0;
     pre.spans = pa.spans ? 1u : 0u;
     pre.digests = (uint32_t*)pa.digests;
-    dim3 grid((n + SHAC_PER_WAVE - 1) / SHAC_PER_WAVE), block(64);
-    lds_spread = spread_or_own(lds_spread, grid.x);
-    const uint32_t lds = lds_spread > (uint32_t)SHAC_LDS_WORDS * 4 ? lds_spread : (uint32_t)SHAC_LDS_WORDS * 4;
-    hipLaunchKernelGGL(sha256_messages_coop_kernel, grid, block, lds, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, pre);
+    const uint32_t nwaves = (n + SHAC_PER_WAVE - 1) / SHAC_PER_WAVE, W = nwaves >= COOP_WG_WAVES ? COOP_WG_WAVES : 1u;
+    dim3 grid((nwaves + W - 1) / W), block(64 * W);
+    const uint32_t want = spread_bytes(lds_spread, nwaves, W), own = W * (uint32_t)SHAC_LDS_WORDS * 4;
+    const uint32_t lds = want > own ? want : own;
+    auto k = W == 4 ? sha256_messages_coop_kernel<4> : sha256_messages_coop_kernel<1>;
+    hipLaunchKernelGGL(k, grid, block, lds, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, pre);
     return hipGetLastError();
 }
 
