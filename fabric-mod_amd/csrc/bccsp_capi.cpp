@@ -657,10 +657,14 @@ int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* di
     struct C { uint32_t t, p, c; uint64_t g; };
     std::vector<C> cnt(ne), base(ne);
     std::vector<uint8_t> type(ne), und(ne);
+    // (as the kernels: the counting run keeps each envelope's records in its slot, the second run copies them - or, for an envelope with
+    //  more records than a slot holds, walks again)
+    std::vector<walk::EnvStash> stash(ne);
     for (uint32_t e = 0; e < ne; e++) {
-        walk::CountEmitter em;
+        walk::StashEmitter em{&stash[e]};
         walk::walk_envelope(block, block + env[2 * e], env[2 * e + 1], e, em, type[e], und[e]);
         cnt[e] = {em.nt, em.np, em.nc, em.gb};
+        stash[e].over = em.fits() ? 0u : 1u;
     }
     C run = {0, 0, 0, 0};
     for (uint32_t e = 0; e < ne; e++) {
@@ -681,6 +685,16 @@ int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* di
         walk::WriteEmitter em{tuples.data(), pre_off2.data(), checks.data(), gsp.data(), goff.data(), base[e].t, base[e].p, base[e].c, (uint32_t)base[e].g,
                               cnt[e].t, cnt[e].p, cnt[e].c, cspans.data(), ncre};
         if (cnt[e].t) ncre++;
+        if (stash[e].over == 0) {
+            for (uint32_t k = 0; k < cnt[e].p; k++) em.add_prefix(stash[e].p[k]);
+            for (uint32_t k = 0; k < cnt[e].t; k++) {
+                BlockTuple t = stash[e].t[k];
+                if (t.prefix_index >= 0) t.prefix_index += (int32_t)base[e].p;
+                em.add_tuple(t);
+            }
+            for (uint32_t k = 0; k < cnt[e].c; k++) em.add_check(stash[e].c[k]);
+            continue;
+        }
         uint8_t t2, u2;
         walk::walk_envelope(block, block + env[2 * e], env[2 * e + 1], e, em, t2, u2);
         if (t2 != type[e] || u2 != und[e] || em.nt != cnt[e].t || em.np != cnt[e].p || em.nc != cnt[e].c) { put_err(diff, cap, "the two runs disagree on envelope " + std::to_string(e)); return 1; }

@@ -100,6 +100,7 @@ struct WalkArrays {
     const uint32_t* env_spans = nullptr;
     uint32_t n_env = 0;
     uint4* counts = nullptr;
+    bccsp::walk::EnvStash* stash = nullptr;   // optional, n_env slots: the count kernel keeps what it found, the emit kernel copies it (block_walk_core.h)
     uint4* bases = nullptr;
     uint32_t* cbase = nullptr;       // per envelope: creator tuples of the envelopes before it
     WalkTotals* totals = nullptr;

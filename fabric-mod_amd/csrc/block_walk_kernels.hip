@@ -25,6 +25,7 @@ using bccsp::Span;
 namespace {
 
 using bccsp::walk::CountEmitter;
+using bccsp::walk::StashEmitter;
 using bccsp::walk::WriteEmitter;
 
 __global__ void __launch_bounds__(64) walk_count_kernel(WalkArrays a) {
@@ -32,10 +33,20 @@ __global__ void __launch_bounds__(64) walk_count_kernel(WalkArrays a) {
     if (e >= a.n_env) return;
     uint32_t off = a.env_spans[2 * e], len = a.env_spans[2 * e + 1];
     if (off > a.block_len || len > a.block_len - off) off = len = 0;       // (the list comes from the host's lister)
-    CountEmitter em;
     uint8_t type = 255, understood = 0;
-    bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
-    a.counts[e] = make_uint4(em.nt, em.np, em.nc, em.gb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)em.gb);
+    uint32_t nt, np, nc;
+    uint64_t gb;
+    if (a.stash) {
+        bccsp::walk::StashEmitter em{a.stash + e};
+        bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
+        nt = em.nt; np = em.np; nc = em.nc; gb = em.gb;
+        a.stash[e].over = em.fits() ? 0u : 1u;
+    } else {
+        CountEmitter em;
+        bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
+        nt = em.nt; np = em.np; nc = em.nc; gb = em.gb;
+    }
+    a.counts[e] = make_uint4(nt, np, nc, gb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)gb);
     a.tx_type[e] = type;
     a.tx_understood[e] = understood;
 }
@@ -103,6 +114,19 @@ __global__ void __launch_bounds__(64) walk_emit_kernel(WalkArrays a, uint32_t n_
     uint32_t off = a.env_spans[2 * e], len = a.env_spans[2 * e + 1];
     if (off > a.block_len || len > a.block_len - off) off = len = 0;
     WriteEmitter em{a.tuples, a.pre_off2, a.checks, a.gather_spans, a.gather_off, base.x, base.y, base.z, base.w, cnt.x, cnt.y, cnt.z, a.creator_spans, a.cbase[e]};
+    if (a.stash && a.stash[e].over == 0) {
+        // what the count kernel kept for this envelope, to the places the scan assigned (the emitter's own stores: one body of code
+        // for "where a record goes"); the prefix indices become global here
+        const bccsp::walk::EnvStash& st = a.stash[e];
+        for (uint32_t k = 0; k < cnt.y; k++) em.add_prefix(st.p[k]);
+        for (uint32_t k = 0; k < cnt.x; k++) {
+            BlockTuple t = st.t[k];
+            if (t.prefix_index >= 0) t.prefix_index += (int32_t)base.y;
+            em.add_tuple(t);
+        }
+        for (uint32_t k = 0; k < cnt.z; k++) em.add_check(st.c[k]);
+        return;
+    }
     uint8_t type = 255, understood = 0;
     bccsp::walk::walk_envelope(a.block, a.block + off, len, e, em, type, understood);
     // the counts this envelope's slots were sized from (the count kernel's, or the host's - WalkRequest::host_counts) against this walk

@@ -1588,7 +1588,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_cnt = carve((size_t)ne * 16), o_base = carve((size_t)ne * 16), o_cbase = carve((size_t)ne * 4), o_type = carve(ne), o_und = carve(ne),
                  o_up_all = o,
                  o_tot = carve(sizeof(WalkTotals)), o_mask = carve((size_t)ne * 4), o_flags = carve(ne), o_sum = carve(sizeof(WalkSummary)),
-                 o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS), o_done = carve(64), o_denv = carve(early_hash ? (size_t)ne * 32 : 0);
+                 o_learn = carve(sizeof(WalkLearn) * WALK_LEARN_SLOTS), o_done = carve(64), o_denv = carve(early_hash ? (size_t)ne * 32 : 0),
+                 o_stash = carve(host_counted ? 0 : (size_t)ne * sizeof(bccsp::walk::EnvStash));   // what the count kernel keeps for the emit kernel
     int rc;
     if ((rc = ctx->walk_env.ensure(o))) return rc;
     // pinned staging: the region above as it goes up (the result arrays are sized further down)
@@ -1607,6 +1608,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     a.env_spans = (const uint32_t*)(de + o_env);
     a.n_env = ne;
     a.counts = (uint4*)(de + o_cnt);
+    a.stash = host_counted ? nullptr : (bccsp::walk::EnvStash*)(de + o_stash);
     a.bases = (uint4*)(de + o_base);
     a.cbase = (uint32_t*)(de + o_cbase);
     a.totals = (WalkTotals*)(de + o_tot);
@@ -2275,8 +2277,8 @@ int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t ne = n_tx, nt = n_tuples;
-    // upper bounds of walk_block_pass's carves: per envelope 91 bytes of arrays, per tuple ~1.9 KB with the memo's key room (1 165 bytes)
-    if (ctx->walk_env.ensure(ne * 128 + ((size_t)256 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
+    // upper bounds of walk_block_pass's carves: per envelope 91 bytes of arrays + the count kernel's record slot, per tuple ~1.9 KB with the memo's key room (1 165 bytes)
+    if (ctx->walk_env.ensure(ne * (128 + sizeof(bccsp::walk::EnvStash)) + ((size_t)256 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
     if (ctx->walk_tup.ensure(nt * 2048 + ne * 256 + ((size_t)1 << 20)) != FABGPU_OK) rc = FABGPU_ENOMEM;
     if (ctx->walk_pin.ensure(nt * 256 + ne * 160 + ((size_t)256 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
     if (ctx->walk_map.ensure(nt * 8 + ne * 8 + sizeof(WalkLearn) * WALK_LEARN_SLOTS + ((size_t)64 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;

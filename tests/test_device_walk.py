@@ -75,6 +75,11 @@ def test_two_run_procedure_equals_the_host_walker():
         assert got == (True, ""), got
         understood += 1
     assert understood > 1000 and refused > 10
+    # envelopes with more records than the counting run's slot holds (8 tuples: block_walk_core.h EnvStash) beside ones that fit
+    import blockgen
+    fx, sign = blockgen.fixture_signers(), blockgen.make_signer(991)
+    many = [blockgen.endorser_tx(t, rng, fx[4 + t % 2], [fx[int(j)] for j in rng.integers(0, 4, size=3 + 3 * (t % 4))], sign) for t in range(24)]
+    assert fabgpu.block_walk_twopass_compare(bb.block(2, many)) == (True, "")
     # an envelope list of one, and a block without transactions
     assert fabgpu.block_walk_twopass_compare(bb.block(1, [bb.envelope(b"\x0a\x02\x0a\x00", b"")])) == (True, "")
     assert fabgpu.block_walk_twopass_compare(bb.block(1, [])) == (True, "")
@@ -432,6 +437,27 @@ def test_device_walker_equals_host_walker(csp):
         else:
             assert text in ("no envelopes", "no signature in the block"), text
     assert compared > 200
+
+
+@pytest.mark.gpu
+def test_envelopes_with_more_records_than_the_count_kernels_slot_are_walked_again(csp):
+    """The count kernel keeps an envelope's records in a fixed slot (8 tuples, 2 prefixes, 4 hash checks: block_walk_core.h EnvStash) and
+    the emit kernel copies them; an envelope with more - here 3, 6, 9 and 12 endorsements per transaction, side by side in one block -
+    is walked a second time as before.  Same records as the host walker either way, and the pass decides every signature."""
+    import blockgen
+    fx = blockgen.fixture_signers()
+    rng = np.random.default_rng(4242)
+    sign = blockgen.make_signer(4243)
+    envs = []
+    for t in range(48):
+        k = 3 + 3 * (t % 4)
+        envs.append(blockgen.endorser_tx(t, rng, fx[4 + t % 2], [fx[int(j)] for j in rng.integers(0, 4, size=k)], sign))
+    blk = bb.block(3, envs)
+    same, declined, text = fabgpu.block_walk_compare(csp, blk)
+    assert same and not declined, text
+    out = fabgpu.preverify_block(csp, blk)
+    assert (out["tx_flags"] == 0).all() and len(out["tuple_status"]) == sum(1 + 3 + 3 * (t % 4) for t in range(48))
+    assert (out["tuple_status"] == 0).all()
 
 
 def _learn(csp, blk):
