@@ -15,8 +15,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define WALK_HD __host__ __device__
+#define WALK_FORCEINLINE __forceinline__
 #else
 #define WALK_HD
+#define WALK_FORCEINLINE inline __attribute__((always_inline))
 #endif
 
 namespace fab {
@@ -109,7 +111,12 @@ struct Pick {
 // false: malformed wire format, or one of the wanted fields repeated / not length-delimited.
 // Hand-rolled scan (this is the walker's inner loop: ~25 messages per transaction): one-byte keys and one- or two-byte lengths - what
 // every field of these messages has - take the fast path; anything else goes through the general varint decoder.
-WALK_HD inline bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
+// K wanted fields with DISTINCT numbers.  Every access to want[] has a compile-time index (the loops over K are unrolled and the hit is
+// applied per index, not through a computed one): on the device the picks then live in registers - with `want[hit]` they lived in
+// scratch memory, and the count kernel spent its time waiting for its own spills (walk_count_kernel: 496 bytes of scratch per lane,
+// 40 us for 100 envelopes).
+template <int K>
+WALK_HD WALK_FORCEINLINE bool pb_pick_n(const uint8_t* b, size_t n, Pick* want) {
     const uint8_t* p = b;
     const uint8_t* const end = b + n;
     while (p < end) {
@@ -127,9 +134,9 @@ WALK_HD inline bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
         }
         const uint32_t num = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
         if (num == 0) return false;                                    // "illegal tag 0" in Go
-        int hit = -1;
-        for (int i = 0; i < k; i++)
-            if (want[i].num == num) hit = i;
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < K; i++) hit = hit || want[i].num == num;
         if (wt == 2) {
             if (p >= end) return false;
             uint64_t len = *p++;
@@ -145,16 +152,21 @@ WALK_HD inline bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
                 }
             }
             if (len > (uint64_t)(end - p)) return false;
-            if (hit >= 0) {
-                if (want[hit].seen) return false;
-                want[hit].seen = 1;
-                want[hit].p = p;
-                want[hit].len = (size_t)len;
+            bool again = false;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                if (want[i].num == num) {
+                    again = again || want[i].seen != 0;
+                    want[i].seen = 1;
+                    want[i].p = p;
+                    want[i].len = (size_t)len;
+                }
             }
+            if (again) return false;
             p += len;
             continue;
         }
-        if (hit >= 0) return false;                                    // a wanted field with another wire type: Go rejects the message
+        if (hit) return false;                                         // a wanted field with another wire type: Go rejects the message
         if (wt == 0) {
             int cnt = 0;
             for (;;) {
@@ -172,6 +184,14 @@ WALK_HD inline bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
         }
     }
     return true;
+}
+WALK_HD WALK_FORCEINLINE bool pb_pick(const uint8_t* b, size_t n, Pick* want, int k) {
+    switch (k) {                                                       // (k is a literal at every call site: the switch folds away)
+        case 1: return pb_pick_n<1>(b, n, want);
+        case 2: return pb_pick_n<2>(b, n, want);
+        case 3: return pb_pick_n<3>(b, n, want);
+        default: return false;
+    }
 }
 
 WALK_HD inline Span span_of(const uint8_t* base, const uint8_t* p, size_t n) {
