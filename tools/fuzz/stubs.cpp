@@ -16,6 +16,8 @@ int fabgpu_p256_key_register(fabgpu_ctx*, const uint8_t*, const uint8_t*, uint32
 int fabgpu_p256_key_lookup(fabgpu_ctx*, const uint8_t*, const uint8_t*, uint32_t*) { return 1; }
 int fabgpu_identity_verify_batch(fabgpu_ctx*, const fabgpu_identity_batch*) { return -1; }
 int fabgpu_arena_stage(fabgpu_ctx*, const void*, size_t, uint64_t*) { return -1; }
+int fabgpu_device_count(fabgpu_ctx*) { return 0; }
+int fabgpu_p256_key_register_many(fabgpu_ctx* const*, int, const uint8_t*, const uint8_t*, uint32_t*) { return -1; }
 }
 #include "block_walk_dev.h"
 namespace fab {
@@ -23,4 +25,6 @@ int walk_idtab_set(fabgpu_ctx*, uint32_t, const DevIdEntry*, const uint8_t*, siz
 int walk_block_pass(fabgpu_ctx*, WalkRequest&) { return -1; }
 void* walk_pinned_alloc(fabgpu_ctx*, size_t) { return nullptr; }
 void walk_pinned_free(fabgpu_ctx*, void*) {}
+int walk_preallocate(fabgpu_ctx*, size_t, uint32_t, uint32_t, int) { return -1; }
+double walk_warm_copies(fabgpu_ctx*, void* const*, const size_t*, int) { return -1; }
 }
