@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) sha256_mixed_kernel(uint32_t n, const uin
 // SIMD runs one such stream at full speed and two at half each, and the dispatcher fills a CU as long as a workgroup fits - dozens of
 // one-wavefront workgroups, on whichever SIMDs.  Two levers, both measured (tools/gpu_probe_small2.py, device phase of a pass):
 //   * workgroups of SEVERAL wavefronts - a workgroup's wavefronts go to different SIMDs of its CU: two per workgroup for the wide
-//     kernels (four do not launch: HSA_STATUS_ERROR_INVALID_ALLOCATION), four for the hashes: 500 tx 0.498 -> 0.406 ms, 1 000 tx
+//     kernels (four measured the same, within noise), four for the hashes: 500 tx 0.498 -> 0.406 ms, 1 000 tx
 //     0.599 -> 0.562 (same box, same call; 100 tx 0.345 -> 0.328);
 //   * unused dynamic LDS, so that a CU takes no more wavefronts of these launches than it should: `cap` wavefronts per CU = what
 //     runs at the same time over all the launches that do (a pass tells: its `pre`, its hashes and its hash checks run side by side)
@@ -179,13 +179,15 @@ uint32_t spread_waves_per_cu(uint32_t wavefronts) {
     return per_cu <= 1 ? 1u : (per_cu <= 2 ? 2u : (per_cu <= 4 ? 4u : (per_cu <= 8 ? 8u : SPREAD_NONE)));
 }
 // the dynamic LDS a launch of W-wavefront workgroups asks for under `cap` (0: from its own wavefront count)
-static uint32_t spread_bytes(uint32_t cap, uint32_t own_wavefronts, uint32_t W) {
+// (static_lds: what the kernel's workgroup holds anyway - the wide kernels keep 2 KB per wavefront - so that the sum stays inside a CU)
+static uint32_t spread_bytes(uint32_t cap, uint32_t own_wavefronts, uint32_t W, uint32_t static_lds) {
     if (cap == 0) cap = spread_waves_per_cu(own_wavefronts);
     if (cap == SPREAD_NONE) return 0;
     const uint32_t wgs_per_cu = cap > W ? cap / W : 1u;
-    return ((160u << 10) / wgs_per_cu) - (4u << 10);                      // 1 per CU: 156 KB, 2: 76 KB, 4: 36 KB, 8: 16 KB
+    const uint32_t room = ((160u << 10) / wgs_per_cu) - (4u << 10);       // 1 per CU: 156 KB, 2: 76 KB, 4: 36 KB, 8: 16 KB
+    return room > static_lds ? room - static_lds : 0u;
 }
-constexpr uint32_t WIDE_WG_WAVES = 2, COOP_WG_WAVES = 4;
+constexpr uint32_t WIDE_WG_WAVES = 2, COOP_WG_WAVES = 4, WIDE_STATIC_LDS_PER_WAVE = 2048;
 
 static_assert(WIDE_BLOCK / WIDE_LANES == 8, "one verdict byte per tile");
 static_assert(WIDE_LAUNCH_MAX == WIDE_MAX && WIDE_SCRATCH_BYTES == 4 * WIDE_SCRATCH_WORDS, "kernels.h restates p256_wide29.h for the host");
@@ -196,7 +198,7 @@ hipError_t launch_p256_wide_pre(uint32_t n, const void* key_id, uint32_t nkeys, 
     const uint32_t tiles = (n + 7) / 8, W = tiles >= WIDE_WG_WAVES ? WIDE_WG_WAVES : 1u, wgs = (tiles + W - 1) / W;
     dim3 grid(wgs < 4096u ? wgs : 4096u), block(64 * W);
     auto k = W == 2 ? p256_wide_pre_kernel<2> : p256_wide_pre_kernel<1>;
-    hipLaunchKernelGGL(k, grid, block, spread_bytes(lds_spread, tiles, W), st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
+    hipLaunchKernelGGL(k, grid, block, spread_bytes(lds_spread, tiles, W, W * WIDE_STATIC_LDS_PER_WAVE), st, n, (const uint32_t*)key_id, nkeys, (const int32_t* const*)ktabs, (const uint8_t*)r,
                        (const uint8_t*)s, (const int32_t*)gtab, (int32_t*)scratch);
     return hipGetLastError();
 }
@@ -206,7 +208,7 @@ hipError_t launch_p256_wide_post(uint32_t n, const void* e, const void* r, const
     const uint32_t tiles = (n + 7) / 8, W = tiles >= WIDE_WG_WAVES ? WIDE_WG_WAVES : 1u, wgs = (tiles + W - 1) / W;
     dim3 grid(wgs < 4096u ? wgs : 4096u), block(64 * W);
     auto k = W == 2 ? p256_wide_post_kernel<2> : p256_wide_post_kernel<1>;
-    hipLaunchKernelGGL(k, grid, block, spread_bytes(lds_spread, tiles, W), st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
+    hipLaunchKernelGGL(k, grid, block, spread_bytes(lds_spread, tiles, W, W * WIDE_STATIC_LDS_PER_WAVE), st, n, (const uint8_t*)e, (const uint8_t*)r, (const int32_t*)gtab, (const int32_t*)scratch,
                        (uint8_t*)verdict_bits, (uint8_t*)status);
     return hipGetLastError();
 }
@@ -249,7 +251,7 @@ hipError_t launch_sha256_messages_coop(uint32_t n, const void* arena, size_t are
     pre.digests = (uint32_t*)pa.digests;
     const uint32_t nwaves = (n + SHAC_PER_WAVE - 1) / SHAC_PER_WAVE, W = nwaves >= COOP_WG_WAVES ? COOP_WG_WAVES : 1u;
     dim3 grid((nwaves + W - 1) / W), block(64 * W);
-    const uint32_t want = spread_bytes(lds_spread, nwaves, W), own = W * (uint32_t)SHAC_LDS_WORDS * 4;
+    const uint32_t want = spread_bytes(lds_spread, nwaves, W, 0), own = W * (uint32_t)SHAC_LDS_WORDS * 4;
     const uint32_t lds = want > own ? want : own;
     auto k = W == 4 ? sha256_messages_coop_kernel<4> : sha256_messages_coop_kernel<1>;
     hipLaunchKernelGGL(k, grid, block, lds, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, pre);
