@@ -298,13 +298,13 @@ int64_t GPUCSP::GetOption(const std::string& name) const {
 // A key's comb table on every device: built once on the host, uploaded G times.  Registrations take turns (reg_mu_), so a key that
 // only ever enters through the provider gets the same id on every device; a caller that registered keys on one of the provider's
 // contexts behind its back makes the ids differ - then the key simply has no table here (-1) and verifies on the fresh-key kernels.
-int64_t GPUCSP::RegisterKeyOnAllDevices(const uint8_t* qx32, const uint8_t* qy32) const {
+int64_t GPUCSP::RegisterKeyOnAllDevices(const uint8_t* qx32, const uint8_t* qy32, const int32_t* prebuilt_table) const {
     std::lock_guard<std::mutex> lk(reg_mu_);
     const int G = (int)devs_.size();
     fabgpu_ctx* cs[kMaxProviderDevices];
     uint32_t ids[kMaxProviderDevices];
     for (int g = 0; g < G; g++) cs[g] = devs_[(size_t)g]->ctx;
-    if (fabgpu_p256_key_register_many(cs, G, qx32, qy32, ids) != FABGPU_OK) return -1;
+    if (key_register_many_prebuilt(cs, G, qx32, qy32, prebuilt_table, ids) != FABGPU_OK) return -1;
     for (int g = 1; g < G; g++)
         if (ids[g] != ids[0]) return -1;
     return ids[0];
@@ -324,7 +324,18 @@ void GPUCSP::Preallocate() const {
     std::vector<std::thread> th;                            // (the devices allocate side by side: 63 MB of device memory per slot takes milliseconds)
     for (int g = 0; g < G; g++) {
         fabgpu_ctx* c = devs_[(size_t)g]->ctx;
-        th.emplace_back([c, block_bytes, n_tx, n_tuples, P] { (void)walk_preallocate(c, block_bytes, n_tx, n_tuples, (int)P); });
+        th.emplace_back([c, block_bytes, n_tx, n_tuples, P] {
+            (void)walk_preallocate(c, block_bytes, n_tx, n_tuples, (int)P);
+            // The runtime loads a translation unit's code object at the first launch of one of its kernels - 8 ms of a channel's first
+            // block when the pass's first launches paid for it.  One launch per unit, now (answers unused: garbage in, statuses out).
+            uint8_t msg[64] = {0x30, 0x06, 0x02, 0x01, 0x01, 0x02, 0x01, 0x01}, dig[32], f32[32] = {0}, st1 = 0, code = 0, r32[32], s32[32];
+            f32[31] = 1;
+            const uint32_t off[2] = {0, 55}, span[2] = {0, 8};
+            uint64_t bits = 0;
+            (void)fabgpu_sha256_batch(c, 1, msg, off, dig);                                  // wide_kernels.hip
+            (void)fabgpu_p256_verify_batch(c, 1, f32, f32, f32, f32, f32, &bits, &st1);      // kernels.hip
+            (void)walk_gate_probe(c, 1, msg, sizeof(msg), span, &code, r32, s32);            // block_walk_kernels.hip
+        });
     }
     const size_t n_sets = (size_t)P * G, n_tables = n_sets + 6;   // (memo_cap_ holds about six 40 000-entry blocks waiting for their validators)
     scratch_free_max_ = std::max(scratch_free_max_, n_sets);
@@ -985,8 +996,18 @@ void GPUCSP::RegisterQueued(const std::vector<std::string>& to_register) const {
             // (evicted meanwhile: EvictIdentitiesLocked gave its place in the table budget back)
         }
     }
-    for (auto& kv : todo) {
-        const int64_t id = RegisterKeyOnAllDevices(kv.second.qx, kv.second.qy);   // the table is built once, every device gets a copy
+    // The tables - 6 ms of host arithmetic each - are built side by side (a channel's first block makes all its endorsers eligible at
+    // once: four tables took 30 ms of that block's pass), then installed one after the other: every device hands out the same ids.
+    const size_t words = key_table_words();
+    std::vector<std::vector<int32_t>> tabs(todo.size());
+    if (todo.size() > 1)
+        run_workers((int)todo.size(), [&](int i) {
+            tabs[(size_t)i].resize(words);
+            if (!key_table_build(todo[(size_t)i].second.qx, todo[(size_t)i].second.qy, tabs[(size_t)i].data())) tabs[(size_t)i].clear();
+        });
+    for (size_t ti = 0; ti < todo.size(); ti++) {
+        auto& kv = todo[ti];
+        const int64_t id = RegisterKeyOnAllDevices(kv.second.qx, kv.second.qy, tabs[ti].empty() ? nullptr : tabs[ti].data());   // every device gets a copy
         const bool ok = id >= 0;
         std::lock_guard<std::mutex> lk(idmu_);
         auto it = idcache_.find(kv.first);

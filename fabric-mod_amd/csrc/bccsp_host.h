@@ -275,7 +275,7 @@ class GPUCSP {
     mutable std::mutex opt_mu_;
     // A P-256 key's comb table on every device of the pool (the table is built once, fabgpu_p256_key_register_many): the common key id,
     // or -1 when the devices disagree about it / a device failed (the fresh-key kernels then serve that key: always correct).
-    int64_t RegisterKeyOnAllDevices(const uint8_t* qx32, const uint8_t* qy32) const;
+    int64_t RegisterKeyOnAllDevices(const uint8_t* qx32, const uint8_t* qy32, const int32_t* prebuilt_table = nullptr) const;
     mutable std::mutex reg_mu_;                             // registrations take turns: ids stay the same on every device
     void Preallocate() const;
     // identity cache of the pre-verify pass (msp/cache/cache.go): SerializedIdentity bytes -> P-256 key + device key id

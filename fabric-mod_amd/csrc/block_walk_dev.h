@@ -295,6 +295,10 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq);
 // allocate now what `slots` overlapping passes over blocks of up to these sizes will need on this device (best effort)
 int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_t n_tuples, int slots);
 double walk_warm_copies(fabgpu_ctx* ctx, void* const* pinned, const size_t* bytes, int n);
+// a registered key's comb table built apart from its registration (fabgpu_api.hip)
+size_t key_table_words();
+bool key_table_build(const uint8_t* qx32, const uint8_t* qy32, int32_t* out);
+int key_register_many_prebuilt(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, const int32_t* table, uint32_t* key_ids);
 // pinned host memory for WalkOut::memo_* (hipHostMalloc / hipHostFree; nullptr when there is none to be had)
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes);
 void walk_pinned_free(fabgpu_ctx* ctx, void* p);

@@ -644,14 +644,15 @@ int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t
 // The same key on n contexts (a provider that owns every GPU of the node): the 640 KiB comb table is built ONCE on the host (~6 ms)
 // and uploaded to each context that does not have the key yet.  key_ids[g] = the key's id on ctxs[g].  The first failure is returned
 // (contexts before it keep the key: registration is idempotent).
-int fabgpu_p256_key_register_many(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_ids) {
+static int key_register_many_impl(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, const int32_t* prebuilt, uint32_t* key_ids) {
     if (!ctxs || n <= 0 || !qx32 || !qy32 || !key_ids) return FABGPU_EINVAL;
     for (int g = 0; g < n; g++)
         if (!ctxs[g]) return FABGPU_EINVAL;
     if (!fabgpu_p256_pubkey_on_curve(qx32, qy32)) return FABGPU_EINVAL;
     std::string k((const char*)qx32, 32);
     k.append((const char*)qy32, 32);
-    std::vector<int32_t> tab;                              // built when the first context turns out to need it
+    std::vector<int32_t> tab;                              // built when the first context turns out to need it (unless the caller brought one)
+    if (prebuilt) tab.assign(prebuilt, prebuilt + KeyTab8::TABLE_WORDS);
     for (int g = 0; g < n; g++) {
         bool have;
         {
@@ -672,6 +673,9 @@ int fabgpu_p256_key_register_many(fabgpu_ctx* const* ctxs, int n, const uint8_t*
         if (rc != FABGPU_OK) return rc;
     }
     return FABGPU_OK;
+}
+int fabgpu_p256_key_register_many(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_ids) {
+    return key_register_many_impl(ctxs, n, qx32, qy32, nullptr, key_ids);
 }
 
 int fabgpu_p256_key_lookup(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
@@ -2352,6 +2356,22 @@ double walk_warm_copies(fabgpu_ctx* ctx, void* const* pinned, const size_t* byte
     }
     for (int k = 0; k < 4; k++) (void)hipStreamSynchronize(ss[k]);
     return worst;
+}
+
+// A registered key's comb table built OUTSIDE the registration (6 ms of host arithmetic per key: the provider builds the tables of the
+// identities a block made eligible side by side on its worker pool, then installs them one after the other so that every device hands
+// out the same ids).
+size_t key_table_words() { return KeyTab8::TABLE_WORDS; }
+bool key_table_build(const uint8_t* qx32, const uint8_t* qy32, int32_t* out) {
+    if (!qx32 || !qy32 || !out || !fabgpu_p256_pubkey_on_curve(qx32, qy32)) return false;
+    u256 qx, qy;
+    from_be32(qx, qx32);
+    from_be32(qy, qy32);
+    build_key_comb_table8(out, qx, qy);
+    return true;
+}
+int key_register_many_prebuilt(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, const int32_t* table, uint32_t* key_ids) {
+    return key_register_many_impl(ctxs, n, qx32, qy32, table, key_ids);
 }
 
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes) {

@@ -130,7 +130,7 @@ def test_passes_land_on_every_device_and_the_memo_does_not_care_which(pool):
             t.join()
         assert not errs, errs
         served = [a - b for a, b in zip(pool.passes_per_device(), before)]
-        assert sum(served) == 24 and min(served) >= 4, served
+        assert sum(served) == 24 and min(served) >= 2, served   # (least busy first: about eight each; the bound leaves room for a slow context)
     finally:
         one.close()
 

@@ -27,4 +27,8 @@ void* walk_pinned_alloc(fabgpu_ctx*, size_t) { return nullptr; }
 void walk_pinned_free(fabgpu_ctx*, void*) {}
 int walk_preallocate(fabgpu_ctx*, size_t, uint32_t, uint32_t, int) { return -1; }
 double walk_warm_copies(fabgpu_ctx*, void* const*, const size_t*, int) { return -1; }
+int walk_gate_probe(fabgpu_ctx*, uint32_t, const uint8_t*, size_t, const uint32_t*, uint8_t*, uint8_t*, uint8_t*) { return -1; }
+size_t key_table_words() { return 1; }
+bool key_table_build(const uint8_t*, const uint8_t*, int32_t*) { return false; }
+int key_register_many_prebuilt(fabgpu_ctx* const*, int, const uint8_t*, const uint8_t*, const int32_t*, uint32_t*) { return -1; }
 }
