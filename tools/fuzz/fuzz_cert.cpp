@@ -15,7 +15,7 @@ int main() {
     std::vector<uint8_t> der;
     if (!PemToDer(pem.data(), pem.size(), der)) { printf("base pem does not decode\n"); return 1; }
     std::mt19937_64 rng(11);
-    size_t ok = 0, sigok = 0, parts = 0;
+    size_t ok = 0, sigok = 0, parts = 0, windowed = 0;
     for (int it = 0; it < 200000; it++) {
         std::vector<uint8_t> d = der;
         int k = 1 + rng() % 6;
@@ -35,6 +35,17 @@ int main() {
         {   // the walk the device's certificate decoder shares with the host (block_walk_core.h): the key must lie inside the certificate
             const int32_t at = walk::cert_der_p256_key_offset(heap, d.size());
             if (at >= 0 && (size_t)at + 64 > d.size()) { printf("KEY OFFSET OUT OF RANGE\n"); return 1; }
+            // ... and the same walk over a WINDOW of the certificate (the device decoder holds the first 3 KiB of a certificate of any
+            // length): an exact-size copy of the window - a read past it is ASan's to catch -, and the answer is the full walk's, or
+            // "the key lies beyond the window" (-2), never another offset and never "not a P-256 certificate" for one that is
+            const size_t avail = d.size() ? rng() % (d.size() + 1) : 0;
+            uint8_t* win = (uint8_t*)malloc(avail ? avail : 1);
+            memcpy(win, heap, avail);
+            const int32_t aw = walk::cert_der_p256_key_offset_window(win, avail, d.size());
+            free(win);
+            if (aw >= 0 && (aw != at || (size_t)aw + 64 > avail)) { printf("WINDOW WALK: ANOTHER OFFSET\n"); return 1; }
+            if (aw == -1 && at >= 0) { printf("WINDOW WALK: REFUSES A CERTIFICATE THE FULL WALK TAKES\n"); return 1; }
+            windowed += aw == -2;
         }
         {   // the parts crypto/x509 checkSignature looks at (x509 batch entry point): spans must stay inside the certificate
             Span tbs, sg;
@@ -73,5 +84,5 @@ int main() {
             free(hp);
         }
     }
-    printf("fuzz ok: %zu mutants still gave a P-256 key, %zu still split into TBS / signature, %zu signature slices unmarshalled\n", ok, parts, sigok);
+    printf("fuzz ok: %zu mutants still gave a P-256 key, %zu still split into TBS / signature, %zu signature slices unmarshalled, %zu window walks asked for more bytes\n", ok, parts, sigok, windowed);
 }
