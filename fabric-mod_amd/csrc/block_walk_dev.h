@@ -157,6 +157,10 @@ struct WalkArrays {
     // results
     const uint64_t* verdict_bits = nullptr;    // of the launch over rows [split ? n_creators : 0, n)
     const uint64_t* verdict_bits_c = nullptr;  // split: of the creators' launch
+    // the eight-lane kernels' second phase runs as ONE launch over all rows: bit `row` of this bitmap is the verdict of a class while
+    // its flag is set (a class that had to be verified again - keys carried along - goes back to its own bitmap above)
+    const uint64_t* verdict_bits_all = nullptr;
+    uint32_t all_creators = 0, all_others = 0;
     const uint8_t* dev_status = nullptr;       // by row
     const uint8_t* row_digests = nullptr;      // by row (null: not wanted)
     uint8_t* tuple_digests = nullptr;          // by tuple

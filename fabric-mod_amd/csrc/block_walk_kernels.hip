@@ -668,7 +668,8 @@ __device__ __forceinline__ void walk_status_part(const WalkArrays& a, uint32_t i
         if (gst == FABGPU_ST_VALID) {                                    // the device decided: exactly PreVerifyParsed's mapping
             const bool in_c = a.split && row < a.n_creators;
             const uint32_t j = in_c ? row : row - (a.split ? a.n_creators : 0u);
-            const bool bit = ((in_c ? a.verdict_bits_c : a.verdict_bits)[j >> 6] >> (j & 63)) & 1;
+            const bool from_all = in_c ? a.all_creators != 0 : a.all_others != 0;
+            const bool bit = from_all ? ((a.verdict_bits_all[row >> 6] >> (row & 63)) & 1) : (((in_c ? a.verdict_bits_c : a.verdict_bits)[j >> 6] >> (j & 63)) & 1);
             const uint8_t ds = a.dev_status[row];
             st = (bit && ds == FABGPU_ST_VALID) ? FABGPU_ST_VALID : (ds == FABGPU_ST_VALID ? FABGPU_ST_BAD_MATH : ds);
             hashed = 1;

@@ -1716,7 +1716,8 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
                  o_nymb = carve(n_msps ? ((size_t)tot.creators + 63) / 64 * 8 + 8 : 0), o_nymst = carve(n_msps ? (size_t)tot.creators + 64 : 0),
                  o_nymga = carve(n_msps ? (size_t)tot.creators * 4 + 256 : 0), o_nymsl = carve(n_msps ? (size_t)tot.creators * 4 : 0),
                  o_tqxy = carve(out.tuple_qxy ? (size_t)nt * 64 : 0), o_sparts = carve(((size_t)nt + 255) / 256 * sizeof(WalkSummary)),
-                 o_wide = carve(nt <= (uint32_t)WIDE_LAUNCH_MAX ? (size_t)nt * WIDE_SCRATCH_BYTES : 0);   // w and u2 Q of every row between the two phases of the wide kernels
+                 o_wide = carve(nt <= (uint32_t)WIDE_LAUNCH_MAX ? (size_t)nt * WIDE_SCRATCH_BYTES : 0),
+                 o_bita = carve(nt <= (uint32_t)WIDE_LAUNCH_MAX ? words * 8 : 0);                        // ... and the one bitmap of their second phase   // w and u2 Q of every row between the two phases of the wide kernels
     // the verdict memo, if the caller gave room for it (WalkOut::memo_*): built behind the status kernel, copied straight into that room
     const bool memo = out.memo_slots && out.memo_key_off && out.memo_keys && out.memo_status && out.memo_digests && out.memo_slot_cap >= 16 &&
                       (out.memo_slot_cap & (out.memo_slot_cap - 1)) == 0 && out.memo_slot_cap >= 2 * (uint64_t)nt && out.memo_keys_cap != 0 &&
@@ -1994,12 +1995,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         } else if (err == hipSuccess) {
             err = launch_sha256_spans(tot.creators, sl->d, arena_bytes, a.creator_spans, dt + o_dig, sc, exclusive ? 84u << 10 : 0u);
         }
-        if (err == hipSuccess && wide) {
-            // ... and behind their digests the second phase of the creators' verification, on this stream: rows [0, n_creators)
-            err = hipStreamWaitEvent(sc, ctx->ev_w[9], 0);
-            if (err == hipSuccess) err = launch_p256_wide_post(tot.creators, dt + o_dig, a.r, ctx->d_gtab, dt + o_wide, dt + o_bitc, dt + o_dst, sc, spread);
-            if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[4], sc);
-        }
+        if (err == hipSuccess && wide) err = hipEventRecord(ctx->ev_w[4], sc);   // "the creators' digests are in their rows" (the one `post` launch waits for it)
     }
     if (err == hipSuccess && np && !coop_messages) queue_midstates();
     if (err == hipSuccess && wide && !coop_messages) queue_messages();
@@ -2160,12 +2156,14 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (np && !wide) err = hipStreamWaitEvent(st, ctx->ev_w[1], 0);      // the mid-states (long done: they ran beside the gates)
     if (err != hipSuccess) return hip_to_rc(err);
     if (wide) {
-        // the second phase of everybody else's verification, behind their digests; the creators' runs on stream2 behind theirs
+        // the second phase of every row's verification as ONE launch, on this stream behind `pre`, once both kinds of digests are in
+        // their rows (the endorsements' hashes: stream3; the creators' scatter: stream2 - both long done when `pre` ends): one launch
+        // and one cross-stream wait fewer in front of the finish than a launch per class had
         err = hipStreamWaitEvent(st, ctx->ev_w[10], 0);
-        if (err == hipSuccess)
-            err = launch_p256_wide_post(nt - tot.creators, dt + o_dig + 32 * (size_t)tot.creators, a.r + 32 * (size_t)tot.creators, ctx->d_gtab,
-                                        dt + o_wide + WIDE_SCRATCH_BYTES * (size_t)tot.creators, dt + o_bits, dt + o_dst + tot.creators, st, spread);
         if (err == hipSuccess) err = hipStreamWaitEvent(st, ctx->ev_w[4], 0);
+        a.verdict_bits_all = (const uint64_t*)(dt + o_bita);
+        a.all_creators = a.all_others = 1;
+        if (err == hipSuccess) err = launch_p256_wide_post(nt, dt + o_dig, a.r, ctx->d_gtab, dt + o_wide, dt + o_bita, dt + o_dst, st, spread);
     } else if (a.split) {
         // creators on stream2 (two lanes per signature), everybody else on the main stream: side by side
         err = hipEventRecord(ctx->ev_w[3], st);                            // the submission arrays are complete
@@ -2204,6 +2202,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             if (redo_nym && (rc = run_nym(rq.summary.n_nym))) return rc;
             if (redo_c) {
                 keyed_c = false;
+                a.all_creators = 0;                                        // (their verdicts come from their own launch's bitmap now)
                 if ((rc = verify_creators(false))) return rc;
                 err = hipEventRecord(ctx->ev_w[4], s2);
                 if (err == hipSuccess) err = hipStreamWaitEvent(st, ctx->ev_w[4], 0);
@@ -2211,6 +2210,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
             }
             if (redo_o) {
                 keyed_o = false;
+                a.all_others = 0;
                 if (!a.split) keyed_c = false;
                 if (wide && np && (err = hipStreamWaitEvent(st, ctx->ev_w[1], 0)) != hipSuccess) return hip_to_rc(err);   // (wide: nobody waited for the mid-states yet)
                 if ((rc = a.split ? verify_rows(tot.creators, nt - tot.creators, np != 0, both_pair, false, dt + o_bits, st)

@@ -14,6 +14,9 @@ import numpy as np   # noqa: E402
 import blockgen   # noqa: E402
 import fabgpu   # noqa: E402
 
+if os.environ.get("PROBE_LIB"):          # A/B against another build of the library (same call, same box)
+    fabgpu._LIB_PATH = os.environ["PROBE_LIB"]
+
 
 def run(ntx, flags, passes, memo=False):
     blk, _ = blockgen.endorser_block(ntx, 31 + ntx)
