@@ -1970,8 +1970,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         ph.mid_ready = true;
         ph.digests = dt + o_dig + 32 * (size_t)tot.creators;
         if (np) ph.pre_idx = a.pre_idx + tot.creators;
-        if (!np || coop_messages) err = hipStreamWaitEvent(s3, ctx->ev_w[0], 0);
-        if (err == hipSuccess) err = hipStreamWaitEvent(s3, ctx->ev_w[3], 0);
+        err = hipStreamWaitEvent(s3, ctx->ev_w[3], 0);                     // (recorded behind the gates: the emit kernel's event is implied)
         if (err == hipSuccess)
             err = coop_messages ? launch_sha256_messages_coop(nt - tot.creators, sl->d, arena_bytes, a.off2 + 2 * (size_t)tot.creators, ph, s3, spread)
                                 : launch_sha256_messages(nt - tot.creators, sl->d, arena_bytes, a.off2 + 2 * (size_t)tot.creators, ph, s3);
@@ -1980,10 +1979,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (err == hipSuccess && wide) {
         err = hipEventRecord(ctx->ev_w[3], st);                            // the submission arrays are complete (the endorsements' hashes read them)
         // (the order of these calls is the order the kernels start in - the host's calls, 3 us each, set the pace of a small block - and
-        //  the hashes are the longer leg of what `post` waits for)
-        if (err == hipSuccess && coop_messages) queue_messages();
+        //  since the hashes run on eight lanes `pre` is the longer leg of what `post` waits for: 75 us against 62)
         if (err == hipSuccess) err = launch_p256_wide_pre(nt, a.key_id, nkeys, (const void*)kt, a.r, a.s, ctx->d_gtab, dt + o_wide, st, spread);
-        if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[9], st);   // "w and u2 Q of every row are in the scratch"
+        if (err == hipSuccess && coop_messages) queue_messages();
     }
     if (err == hipSuccess && a.split) {
         // stream2: the creators' digests into rows [0, n_creators), so that their launch only has the arithmetic left.  Either they
