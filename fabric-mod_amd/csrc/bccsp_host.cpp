@@ -392,7 +392,7 @@ void GPUCSP::Preallocate() const {
                 }
             }
         }
-        std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+        std::unique_lock<BigReaderLock> lk(memo_mu_);
         for (auto& bm : made) memo_free_.push_back(bm);
     }
     for (auto& t : th) t.join();
@@ -865,7 +865,7 @@ int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* 
     const size_t kl = MemoKeyBytes(siglen, dlen, issuer_hash32 != nullptr);
     MemoKeyWrite(key, issuer_hash32, qx32, qy32, sig, siglen, digest, dlen);
     const uint64_t h = MemoHash(sig, siglen, digest, dlen);
-    std::shared_lock<std::shared_timed_mutex> lk(memo_mu_);
+    std::shared_lock<BigReaderLock> lk(memo_mu_);
     for (auto it = memo_blocks_.rbegin(); it != memo_blocks_.rend(); ++it) {      // newest block first
         const BlockMemo& bm = **it;
         if (!bm.n) continue;
@@ -879,23 +879,23 @@ int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* 
                                            : (l == kl && memcmp(bm.keys_v + o, key, kl) == 0);
             if (same) {
                 if (status) *status = bm.status_v[e - 1];
-                memo_hits_.fetch_add(1, std::memory_order_relaxed);
+                memo_hits_.add(1);
                 return 0;
             }
         }
     }
-    memo_misses_.fetch_add(1, std::memory_order_relaxed);
+    memo_misses_.add(1);
     return 1;
 }
 size_t GPUCSP::MemoHasBlock(uint64_t block_seq) const {
-    std::shared_lock<std::shared_timed_mutex> lk(memo_mu_);
+    std::shared_lock<BigReaderLock> lk(memo_mu_);
     size_t n = 0;
     for (const auto& b : memo_blocks_)
         if (b->seq == block_seq) n += b->n;
     return n;
 }
 size_t GPUCSP::MemoEvictBlock(uint64_t block_seq) const {
-    std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+    std::unique_lock<BigReaderLock> lk(memo_mu_);
     size_t gone = 0;
     for (auto b = memo_blocks_.begin(); b != memo_blocks_.end();) {
         if ((*b)->seq != block_seq) { ++b; continue; }
@@ -907,7 +907,7 @@ size_t GPUCSP::MemoEvictBlock(uint64_t block_seq) const {
     return gone;
 }
 void GPUCSP::MemoStats(uint64_t* entries, uint64_t* hits, uint64_t* misses, uint64_t* evicted) const {
-    std::shared_lock<std::shared_timed_mutex> lk(memo_mu_);
+    std::shared_lock<BigReaderLock> lk(memo_mu_);
     uint64_t n = 0;
     for (const auto& b : memo_blocks_) n += b->n;
     if (entries) *entries = n;
@@ -916,7 +916,7 @@ void GPUCSP::MemoStats(uint64_t* entries, uint64_t* hits, uint64_t* misses, uint
     if (evicted) *evicted = memo_evicted_.load();
 }
 void GPUCSP::MemoSetCapacity(size_t max_entries) const {
-    std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+    std::unique_lock<BigReaderLock> lk(memo_mu_);
     memo_cap_ = max_entries ? max_entries : 1;
 }
 void GPUCSP::SetIdentityCacheLimits(size_t max_identities, size_t max_registered_keys, uint32_t register_after_hits) const {
@@ -1034,7 +1034,7 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
         } memo_clock{out, clk_memo};
         std::shared_ptr<BlockMemo> bm;
         {
-            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+            std::unique_lock<BigReaderLock> lk(memo_mu_);
             if (!memo_free_.empty()) {
                 bm = memo_free_.back();
                 memo_free_.pop_back();
@@ -1173,7 +1173,7 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
     }
 }
 void GPUCSP::PublishMemo(const std::shared_ptr<BlockMemo>& bm) const {
-    std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+    std::unique_lock<BigReaderLock> lk(memo_mu_);
     memo_blocks_.push_back(bm);
     size_t total = 0;
     for (const auto& b : memo_blocks_) total += b->n;
@@ -1434,7 +1434,7 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     std::shared_ptr<BlockMemo> dev_bm;
     if (dev_memo) {
         {
-            std::unique_lock<std::shared_timed_mutex> lk(memo_mu_);
+            std::unique_lock<BigReaderLock> lk(memo_mu_);
             // (prefer a recycled table that already owns pinned room)
             for (auto it = memo_free_.begin(); it != memo_free_.end(); ++it)
                 if ((*it)->pin) {
@@ -1580,7 +1580,7 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         std::shared_ptr<BlockMemo>& bm;
         ~MemoBack() {
             if (!bm) return;
-            std::unique_lock<std::shared_timed_mutex> lk(c->memo_mu_);
+            std::unique_lock<BigReaderLock> lk(c->memo_mu_);
             if (c->memo_free_.size() < c->memo_free_max_) c->memo_free_.push_back(bm);
         }
     } memo_back{this, dev_bm};

@@ -16,6 +16,8 @@
 #include <array>
 #include <atomic>
 #include <mutex>
+
+#include "reader_lock.h"
 #include <shared_mutex>
 #include <thread>
 #include <unordered_map>
@@ -344,10 +346,11 @@ class GPUCSP {
     void PublishMemo(const std::shared_ptr<BlockMemo>& bm) const;   // push under the lock, oldest blocks out while over capacity
     mutable std::vector<std::shared_ptr<BlockMemo>> memo_free_;    // evicted tables, recycled: 7 MB of fresh pages per block otherwise
     mutable size_t memo_free_max_ = 4, scratch_free_max_ = 4;      // (both grow with the pool and with ProviderOptions::concurrent_passes)
-    mutable std::shared_timed_mutex memo_mu_;
+    mutable BigReaderLock memo_mu_;                       // readers (every bccsp.Verify of every validator thread) share no cache line: reader_lock.h
     mutable std::deque<std::shared_ptr<BlockMemo>> memo_blocks_;   // oldest first
     mutable size_t memo_cap_ = (size_t)1 << 18;
-    mutable std::atomic<uint64_t> memo_hits_{0}, memo_misses_{0}, memo_evicted_{0};
+    mutable ShardedCounter memo_hits_, memo_misses_;      // (bumped per lookup by every validator thread)
+    mutable std::atomic<uint64_t> memo_evicted_{0};
     static size_t MemoPinLayout(uint32_t n_tuples, uint32_t n_creators, uint32_t* slot_cap, size_t* keys_cap, size_t* total, size_t* offs5 = nullptr);
     static size_t MemoKeyBytes(size_t siglen, size_t dlen, bool nym) { return 1 + (nym ? 32 : 0) + 64 + 4 + siglen + 4 + dlen; }
     static void MemoKeyWrite(uint8_t* out, const uint8_t* issuer_hash32, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,

@@ -5,3 +5,7 @@ set -e
 cd "$(dirname "$0")/../.."
 g++ -O1 -g -std=c++17 -fsanitize=thread -Ifabric-mod_amd/csrc tools/fuzz/tsan_coalescer.cpp -o /tmp/tsan_coalescer -lpthread
 /tmp/tsan_coalescer
+# ... and the verdict memo's reader-writer lock (csrc/reader_lock.h): 12 readers checking an invariant that 3 writers break and restore
+# under the write lock.  Expect: no report, invariant broken 0 times.
+g++ -O1 -g -std=c++17 -fsanitize=thread -Ifabric-mod_amd/csrc tools/fuzz/tsan_reader_lock.cpp -o /tmp/tsan_reader_lock -lpthread
+/tmp/tsan_reader_lock
