@@ -430,3 +430,66 @@ def test_certificate_walk_over_a_window_of_the_der(hosttest):
                 assert fn(bytes(m), avail, len(m)) in (-1, -2)
             n_not += 1
     assert n_not >= 80
+
+
+# ---- bench.py's compact line (a 23 KB line came back from the driver as `parsed: null`) ----
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_compact_line_from_round4_detail():
+    """the full object round 4 printed (23 KB, kept as profiles/r04_bench_final.json) -> one line under 4 KB with every contract key"""
+    import json
+    bench = _bench_module()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r04_bench_final.json")))
+    assert len(json.dumps(full)) > 20000
+    text = bench.compact_line(full)
+    assert "\n" not in text and len(text) < 4096, len(text)
+    line = json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError("non-strict JSON constant " + c)))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("BASELINE.json configs[1]")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "cpu_model"):
+        assert k in line["cpu_baseline"], k
+    assert abs(line["value"] - full["value"]) / full["value"] < 1e-5
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert line["validated_tx_per_s_block_pass"] > 1e6 and line["idemix_roofline_frac"] < 1
+    assert all(not isinstance(v, (dict, list)) or k in ("config", "roofline", "cpu_baseline", "fresh_provider_lone_passes_ms", "legs_with_errors") for k, v in line.items())
+
+
+def test_bench_compact_line_worst_case_stays_under_the_limit():
+    """every optional leg present, long strings everywhere, errors in legs: still < 4 KB, still strict JSON, contract keys never shed"""
+    import json
+    bench = _bench_module()
+    long = "x" * 5000
+    out = {"metric": "ECDSA P-256 verifies/sec (whole node)", "value": 1.23456789e8, "unit": "verifies/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+           "ms_per_step": 0.7123456789, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+           "data": "synthetic - DRY RUN of the multi-rank code path" + long,
+           "config": {"workload": long, "tuples_per_gpu": 30000, "tx_per_block": 10000, "endorsements_per_tx": 3, "seed": 20260921, "parallelism": "1 block per GPU"},
+           "roofline": {"bound": "valu-mac", "achieved": 1.3e13, "peak": 3.4e13, "unit": "MAC/s", "frac": 0.4, "traffic": 9.6e7, "traffic_source": "profiles/x.json",
+                        "kernel": "k<256> (" + long + ")", "kernel_ms": 0.68, "hbm": {"achieved": 7.0, "frac": 0.0009}, "model": long},
+           "cpu_baseline": {"value": 4.6e5, "unit": "verifies/s", "cores": 16, "kind": "port", "cpu_model": "AMD EPYC 9575F 64-Core Processor", "single_thread": {"value": 2.9e4},
+                            "thread_sweep": {str(i): {"best": 1.0, "median": 1.0} for i in range(300)}},
+           "parity": long, "configs2_strong": {"value": 4.0e7}, "configs2_inprocess": {"error": long}, "configs3_fused": {"value": 5.3e7},
+           "configs4_mixed": {"value": 2.6e7, "ms_per_step": 1.1, "roofline": {"frac": 0.083, "kernel_ms": 0.77}, "mixed_step_over_the_longer_kernel": 1.45},
+           "block_pass": {"error": long}, "block_pass_inprocess": {"error": long}, "rccl_ranks": 8,
+           "validated_tx_per_s": 1.4e7, "value_pcie_inclusive": 3.5e7}
+    text = bench.compact_line(out, "bench_detail_n8.json")
+    assert len(text) < 4096
+    line = json.loads(text)
+    assert line["n_gpus"] == 8 and line["data"].startswith("synthetic (DRY RUN")
+    assert set(line["legs_with_errors"]) == {"configs2_inprocess", "block_pass", "block_pass_inprocess"}
+    assert line["roofline"]["kernel"] == "k<256>" and line["detail"] == "bench_detail_n8.json"
+    # NaN / inf never reach the line as bare tokens a strict parser rejects
+    out["value_pcie_inclusive"] = float("nan")
+    out["roofline"]["traffic"] = float("inf")
+    again = bench.compact_line(out)
+    assert "NaN" not in again and "Infinity" not in again and json.loads(again)["roofline"]["traffic"] is None
