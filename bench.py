@@ -1119,7 +1119,9 @@ def main():
             # one block cut into N shards, beside the blocks-in-flight `value` (north_star: "the batch is split across the 8 GPUs")
             out["value_one_block_sharded"] = strong["value"]
             out["rccl_ranks"] = world if not dry else 0
-            out["configs2_inprocess"] = inprocess_multi_leg(world) if extras else None
+            # (a dry run has fewer GPUs than ranks: repeated ordinals, which the library answers with the host merge - and says so)
+            multi_devs = ",".join(str(i % torch.cuda.device_count()) for i in range(world))
+            out["configs2_inprocess"] = inprocess_multi_leg(world, extra=("--devices", multi_devs)) if extras else None
             if mixed_n is not None:
                 out["configs4_mixed"] = mixed_n
             # BASELINE's second metric on N GPUs: ONE provider (the process-global BCCSP) over all N devices, 2 N callers submitting blocks

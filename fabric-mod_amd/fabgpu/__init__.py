@@ -108,7 +108,7 @@ ABI_SYMBOLS = [
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
     "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",
     "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
-    "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev",
+    "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev", "fabgpu_multi_collective",
     "fabgpu_csp_pass_routes", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast", "fabgpu_identity_table_hash", "fabgpu_csp_gate_probe",
     "fabgpu_gate_sig_any", "fabgpu_identity_to_p256", "fabgpu_csp_idfix_probe", "fabgpu_csp_pass_stats",
     "fabgpu_p256_key_register_many", "fabgpu_csp_new2", "fabgpu_csp_device_count", "fabgpu_csp_ctx_of", "fabgpu_csp_passes_per_device",
@@ -226,6 +226,7 @@ def load():
     L.fabgpu_multi_plan.argtypes = [_sz, _u32p, ctypes.c_uint32, _u64p, _u64p, _u64p]
     L.fabgpu_multi_merged_bitmap_dev.argtypes = [_vp, ctypes.c_int]
     L.fabgpu_multi_merged_bitmap_dev.restype = _vp
+    L.fabgpu_multi_collective.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
     L.fabgpu_block_tuples.argtypes = [_u8p, _sz, ctypes.c_uint32, _u32p, _u32p, _u8p, _u32p, _u8p, ctypes.c_uint32, _u32p, _u32p]
     L.fabgpu_x509_p256_pubkey.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
@@ -549,6 +550,15 @@ class MultiContext:
 
     def device_count(self) -> int:
         return self._L.fabgpu_multi_device_count(self._h)
+
+    def collective(self):
+        """(rccl_ranks, why): rccl_ranks = G when the shard bitmaps are merged by ncclAllGather (self-checked at init), 0 when the host
+        merges them; why = the reason the library gives (fabgpu_multi_collective)"""
+        buf = ctypes.create_string_buffer(256)
+        r = self._L.fabgpu_multi_collective(self._h, buf, len(buf))
+        if r < 0:
+            raise FabgpuError("fabgpu_multi_collective: %s (%d)" % (strerror(r), r))
+        return r, buf.value.decode("utf-8", "replace")
 
     def p256_verify_batch(self, qx, qy, e, r, s, want_status=True):
         qx, qy, e, r, s = map(_a8, (qx, qy, e, r, s))

@@ -267,6 +267,12 @@ int fabgpu_multi_sha256_p256_verify_batch(fabgpu_multi* m, size_t n, const uint8
 /* the shard boundaries [lo[g], hi[g]) a batch of n tuples gets on n_devices devices (pure host): off == NULL by count, else by bytes */
 int fabgpu_multi_plan(size_t n, const uint32_t* off, uint32_t n_devices, uint64_t* lo, uint64_t* hi, uint64_t* words_per_rank);
 const void* fabgpu_multi_merged_bitmap_dev(fabgpu_multi* m, int g);
+/* How the shard bitmaps are merged.  fabgpu_multi_init never fails for want of a collective: one device, a repeated ordinal, no
+ * librccl, ncclCommInitAll failing, or the one-word ncclAllGather self-check it runs across its devices failing (wrong word, error,
+ * or no completion within FABGPU_MULTI_SELFCHECK_TIMEOUT_S, default 30 s) all end in the host merge (G small D2H copies, SURVEY.md
+ * 8(e)), and so does an ncclAllGather error on a later batch.  Returns the number of RCCL ranks (G) when the merge is the
+ * collective, 0 when the host merges; `why` (optional, NUL-terminated) says which. */
+int fabgpu_multi_collective(fabgpu_multi* m, char* why, size_t why_cap);
 
 /* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
  * launch stream.  Only for contexts created with FABGPU_FLAG_TIME_KERNELS; <0 otherwise / if nothing was launched. */

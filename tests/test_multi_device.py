@@ -77,11 +77,22 @@ def test_fake_backend_g_host_threads_and_memcpy_allgather(n, G, by_bytes):
 
 # ---------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,host_merge", [([0], False), ([0, 0, 0], True), ([0], True)])
+@pytest.mark.parametrize("devices,host_merge", [([0], False), ([0, 0, 0], True), ([0], True), ([0, 0], False)])
 def test_multi_dispatcher_equals_the_oracle_and_the_single_context_abi(devices, host_merge):
     m = fabgpu.MultiContext(devices, host_merge=host_merge)
     try:
         assert m.device_count() == len(devices)
+        ranks, why = m.collective()
+        if host_merge:
+            assert ranks == 0 and "HOST_MERGE" in why
+        elif len(set(devices)) < len(devices):
+            # a repeated ordinal cannot form a communicator: the library merges on the host instead of failing (round 5)
+            assert ranks == 0 and "repeated" in why
+            host_merge = True
+        else:
+            # the one-rank communicator of this box: RCCL's all-gather passed its one-word self-check at init - or the library says why not
+            assert ranks in (0, len(devices)) and why
+            assert ranks == len(devices), "RCCL unusable on this box: %s" % why
         for n in (1, 63, 64, 65, 1000, 30000):
             b = coracle.make_batch(n, seed=5150 + n, invalid_frac=0.2 if n > 4 else 0.0) if n < 30000 else fabgpu.synth_batch(n, seed=20260921, invalid_permille=10)
             want = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
@@ -115,6 +126,6 @@ def test_multi_dispatcher_equals_the_oracle_and_the_single_context_abi(devices, 
 @pytest.mark.gpu
 def test_multi_init_argument_errors():
     with pytest.raises(fabgpu.FabgpuError):
-        fabgpu.MultiContext([0, 0])                          # one device twice cannot form an RCCL communicator
-    with pytest.raises(fabgpu.FabgpuError):
         fabgpu.MultiContext([9999])
+    with pytest.raises(fabgpu.FabgpuError):
+        fabgpu.MultiContext([])

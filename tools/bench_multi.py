@@ -21,17 +21,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--host-merge", action="store_true")
+    ap.add_argument("--devices", default=None, help="comma-separated ordinals (default 0..gpus-1); a dry run on a smaller box repeats ordinals")
     args = ap.parse_args()
     import numpy as np
 
     import fabgpu
     t0 = time.perf_counter()
-    m = fabgpu.MultiContext(list(range(args.gpus)), host_merge=args.host_merge)
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    m = fabgpu.MultiContext(devices, host_merge=args.host_merge)
     init_s = time.perf_counter() - t0
-    out = {"tool": "tools/bench_multi.py", "n_gpus": args.gpus, "merge": "host D2H x G" if args.host_merge else "RCCL ncclAllGather (in-process, ncclCommInitAll)",
+    ranks, why = m.collective()
+    out = {"tool": "tools/bench_multi.py", "n_gpus": len(devices), "devices": devices,
+           "merge": "RCCL ncclAllGather (in-process, ncclCommInitAll)" if ranks else "host D2H x G",
+           "collective": "rccl" if ranks else "host_merge", "rccl_ranks": ranks, "collective_why": why,
            "init_s": init_s, "legs": []}
-    for n, label in ((30000, "BASELINE.json configs[2]: one 10k x 3 block (30000 tuples) cut into %d shards" % args.gpus),
-                     (300000, "300000 tuples (ten blocks' worth) cut into %d shards" % args.gpus)):
+    for n, label in ((30000, "BASELINE.json configs[2]: one 10k x 3 block (30000 tuples) cut into %d shards" % len(devices)),
+                     (300000, "300000 tuples (ten blocks' worth) cut into %d shards" % len(devices))):
         b = fabgpu.synth_batch(n, seed=20260921, invalid_permille=10)
         for _ in range(3):
             bits, _ = m.p256_verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"], want_status=False)
@@ -44,7 +49,7 @@ def main():
         med = statistics.median(wall)
         out["legs"].append({"workload": label, "tuples": n, "value": n / (med * 1e-3), "unit": "verifies/s", "median_ms": med,
                             "p95_ms": sorted(wall)[int(0.95 * (len(wall) - 1))], "min_ms": min(wall), "iters": len(wall),
-                            "shards": fabgpu.multi_plan(n, args.gpus)[0][:2] + ["..."], "parity": "bit-identical to the ground truth"})
+                            "shards": fabgpu.multi_plan(n, len(devices))[0][:2] + ["..."], "parity": "bit-identical to the ground truth"})
     m.close()
     print(json.dumps(out))
 
