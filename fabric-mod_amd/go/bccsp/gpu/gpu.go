@@ -377,6 +377,7 @@ func (p *Provider) PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSumm
 		p.m.passDone(time.Since(start), int(nTx), int(nTuples), int(seeded))
 		return &PassSummary{TxFlags: flags[:nTx], Tuples: int(nTuples), BlockSigs: int(nBlockSigs), MemoSeeded: int(seeded)}, nil
 	}
+	C.fabgpu_csp_block_pass_abandon(p.csp) // no retry will come: drop the upload the library kept for one
 	p.m.passFailed()
 	return nil, errors.New("fabgpu: block shape changed between attempts")
 }

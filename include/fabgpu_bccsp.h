@@ -167,6 +167,16 @@ typedef struct fabgpu_block_pass {
     int32_t device_context;
 } fabgpu_block_pass;
 int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* pass);
+/* FABGPU_ETOOBIG and the retry (both forms of the pass).  The block's upload starts before its shape is known; when the caller's arrays
+ * turn out too small the pass returns FABGPU_ETOOBIG with the counts set, NOTHING was launched, and the library keeps the finished upload
+ * for the retry.  Contract:
+ *  - by the time FABGPU_ETOOBIG is returned the upload has been waited for: the library never reads `block` after a call has returned
+ *    (cgo: no Go pointer is retained), so the caller may free or reuse the buffer;
+ *  - a retry finds the kept upload only if it passes the same pointer, length and block_seq, the block's first and last KiB are
+ *    unchanged, and it comes within one second; any other call uploads afresh (correct, just slower);
+ *  - a caller that will not retry calls fabgpu_csp_block_pass_abandon (returns 1 if an upload was dropped, 0 if none was kept);
+ *    otherwise the kept upload is dropped by the next pass that finds it older than a second, and its device counts as busy until then. */
+int fabgpu_csp_block_pass_abandon(fabgpu_csp* csp);
 /* 0: hit, *status = 0 valid / 1 arithmetic reject / 2 high-S / 3 r out of range (the reference rejects: ask bccsp/sw for its error
  * text); 1: miss -> bccsp/sw.  Never an infrastructure error: a miss is always a correct answer. */
 int fabgpu_csp_memo_lookup(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest,

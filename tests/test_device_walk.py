@@ -9,6 +9,7 @@ import base64
 import hashlib
 import json
 import os
+import ctypes
 import threading
 
 import numpy as np
@@ -946,6 +947,51 @@ def test_device_route_big_block_caps_and_concurrency(csp, monkeypatch):
     for t in th:
         t.join(timeout=300)
     assert not errors, errors[0]
+
+
+@pytest.mark.gpu
+def test_parked_upload_never_answers_for_another_block(csp):
+    """after FABGPU_ETOOBIG the library keeps the finished upload for the retry.  A caller that gives up and later
+    presents a DIFFERENT block of the same length at the same address (a re-used allocation) must get THAT block's verdicts: the kept
+    upload matches on pointer, length, block_seq and a fingerprint of the bytes.  Observable: the digests the DEVICE computed over the
+    bytes it read.  Also: fabgpu_csp_block_pass_abandon drops a kept upload, and the honest retry still finds its upload."""
+    rng = np.random.default_rng(77)
+    blk_a = big_block(2600, rng, bad_every=97)                                # 13 MB: staged by default, its upload is a thread
+    buf = np.frombuffer(bytearray(blk_a), dtype=np.uint8)                    # ONE allocation, lent to the library for every call below
+    L = csp._L
+    full_a = fabgpu.preverify_block2(csp, buf, block_seq=0)
+    i = int(np.nonzero((full_a["tuple_tx"] == 1300) & (full_a["tuple_kind"] == 0))[0][0])     # the creator tuple of transaction 1300
+    sp = [int(x) for x in full_a["tuple_spans"][i]]                           # (identity, prefix, suffix, signature) x (offset, length)
+    msg = lambda raw: bytes(raw[sp[2]:sp[2] + sp[3]]) + bytes(raw[sp[4]:sp[4] + sp[5]])
+    assert bytes(full_a["tuple_digest"][i]) == hashlib.sha256(msg(blk_a)).digest()
+
+    def small_call():
+        flags = np.zeros(16, np.uint8)
+        ps = fabgpu._BlockPass()
+        ps.block, ps.len, ps.block_seq, ps.cap_tx, ps.cap_tuples, ps.tx_flags = buf.ctypes.data, buf.size, 0, 16, 0, flags.ctypes.data
+        return L.fabgpu_csp_block_preverify2(csp._h, ctypes.byref(ps)), ps.n_tx
+    assert small_call() == (-5, 2600)                                         # FABGPU_ETOOBIG, counts set, the upload of block A is kept
+    # the caller gave up; the allocation now holds another block of the same length: other bytes in its first KiB (a block's header - number,
+    # previous hash - always differs) and one other byte deep inside transaction 1300's payload
+    blk_b = bytearray(blk_a)
+    at_hdr = blk_a.index(b"\x0a") + 2                                          # inside the header message
+    blk_b[at_hdr] ^= 0x01
+    blk_b[sp[4] + sp[5] // 2] ^= 0x40
+    buf[:] = np.frombuffer(bytes(blk_b), dtype=np.uint8)
+    got_b = fabgpu.preverify_block2(csp, buf, block_seq=0)
+    j = int(np.nonzero((got_b["tuple_tx"] == 1300) & (got_b["tuple_kind"] == 0))[0][0])
+    assert bytes(got_b["tuple_digest"][j]) == hashlib.sha256(msg(blk_b)).digest(), "the kept upload of block A answered for block B"
+    assert bytes(got_b["tuple_digest"][j]) != bytes(full_a["tuple_digest"][i])
+    # abandon: a kept upload is dropped exactly once
+    buf[:] = np.frombuffer(bytes(blk_a), dtype=np.uint8)
+    assert small_call()[0] == -5
+    assert L.fabgpu_csp_block_pass_abandon(csp._h) == 1
+    assert L.fabgpu_csp_block_pass_abandon(csp._h) == 0
+    # and the honest retry (same buffer, same bytes, at once) finds its upload and answers for block A
+    assert small_call()[0] == -5
+    again = fabgpu.preverify_block2(csp, buf, block_seq=0)
+    _same(full_a, again, ["tx_flags", "tuple_status", "tuple_digest"])
+    assert L.fabgpu_csp_block_pass_abandon(csp._h) == 0                       # the retry took it
 
 
 def _bench_block(n_tx):
