@@ -974,8 +974,8 @@ def test_parked_upload_never_answers_for_another_block(csp):
     # the caller gave up; the allocation now holds another block of the same length: other bytes in its first KiB (a block's header - number,
     # previous hash - always differs) and one other byte deep inside transaction 1300's payload
     blk_b = bytearray(blk_a)
-    at_hdr = blk_a.index(b"\x0a") + 2                                          # inside the header message
-    blk_b[at_hdr] ^= 0x01
+    assert blk_a[0] == 0x0a and blk_a[2] == 0x08                              # Block.header { number = varint at byte 3 ...
+    blk_b[3] ^= 0x02                                                          # ... another block number
     blk_b[sp[4] + sp[5] // 2] ^= 0x40
     buf[:] = np.frombuffer(bytes(blk_b), dtype=np.uint8)
     got_b = fabgpu.preverify_block2(csp, buf, block_seq=0)
