@@ -90,6 +90,7 @@ struct fabgpu_ctx {
     int device = 0;
     bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
     bool allow_quad = true;   // !FABGPU_FLAG_NO_QUAD (idemix: four lanes per signature for batches <= IDEMIX_QUAD_MAX)
+    bool nym_two_phase = true;   // !FABGPU_FLAG_NYM_FUSED_HASH (idemix four-lane form: commitments, then challenges with eight lanes on a message)
     bool allow_wide = true;   // !FABGPU_FLAG_NO_WIDE (registered keys: eight lanes per signature in two phases for launches <= WIDE_LAUNCH_MAX)
     int pair_table_lds = -1;       // the verify-only pair kernel's per-signature table: 1 in LDS, 0 in the global workspace, -1 by batch size (kernels.h)
     hipStream_t stream = nullptr;
@@ -288,7 +289,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!out) return FABGPU_EINVAL;
     *out = nullptr;
     if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS | FABGPU_FLAG_NO_QUAD | FABGPU_FLAG_PAIR_TABLE_LDS |
-                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL | FABGPU_FLAG_NO_WIDE)) != 0) return FABGPU_EINVAL;
+                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL | FABGPU_FLAG_NO_WIDE | FABGPU_FLAG_NYM_FUSED_HASH)) != 0) return FABGPU_EINVAL;
     if (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL)) return FABGPU_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
@@ -306,6 +307,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     ctx->walk_map.flags = hipHostMallocMapped | hipHostMallocCoherent;
     ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
     ctx->allow_quad = !(cfg && (cfg->flags & FABGPU_FLAG_NO_QUAD));
+    ctx->nym_two_phase = !(cfg && (cfg->flags & FABGPU_FLAG_NYM_FUSED_HASH));
     // (the wide form is built from the two-lane form's reasons: a context that may not use two lanes per signature does not use eight)
     ctx->allow_wide = ctx->allow_pair && !(cfg && (cfg->flags & FABGPU_FLAG_NO_WIDE));
     ctx->pair_table_lds = cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) ? 1 : (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL) ? 0 : pair_table_default());
@@ -567,7 +569,8 @@ static int nym_verify_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t a
     timed = timed && ctx->time_kernels;
     if (timed) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
-                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, ctx->allow_quad, spans, st, gather, lds_reserve);
+                                              proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, ctx->allow_quad, spans, st, gather, lds_reserve,
+                                              ctx->nym_two_phase);
     if (timed) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     if (timed) ctx->timed = true;

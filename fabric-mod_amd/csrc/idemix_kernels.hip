@@ -11,6 +11,7 @@
 #include "bn_quad29.h"
 #include "device_common.h"
 #include "kernels.h"
+#include "sha256_coop.h"
 
 namespace fab {
 
@@ -33,10 +34,12 @@ __device__ __forceinline__ void put_be32(uint32_t* hw, const u256& v) {
 // idemix/nymsignature.go:89-107 for one lane.  proofData = "sign" || 04 t.x t.y || 04 nym.x nym.y || ipk.Hash || msg :
 // a 166-byte header the lane assembles in registers (two whole SHA blocks + 38 bytes that share the third block with the
 // start of the message), then the message from the arena; c = digest mod r; ProofC' = SHA-256(c || nonce) mod r.
-__device__ __forceinline__ bool nym_challenge_matches(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t start, uint32_t len,
-                                                      bool active, const u256& tx, const u256& ty, const u256& nx, const u256& ny,
-                                                      const uint32_t ipk_hash[8], const u256& nonce, const u256& proof_c) {
-    uint32_t hw[48];
+// The first 166 bytes of proofData (idemix/nymsignature.go:89-99): "sign" || 04 t.x t.y || 04 nym.x nym.y || ipk.Hash, as 48 big-endian words
+// (the last 26 bytes zero).
+constexpr int NYM_HDR_BYTES = 166;
+constexpr int NYM_HDR_WORDS = 48;        // 192 bytes per row in the header buffer of the two-phase form
+__device__ __forceinline__ void nym_header_words(uint32_t hw[NYM_HDR_WORDS], const u256& tx, const u256& ty, const u256& nx, const u256& ny,
+                                                 const uint32_t ipk_hash[8]) {
 #pragma unroll
     for (int k = 0; k < 48; k++) hw[k] = 0;
     hw[0] = 0x7369676eu;                 // "sign" (idemix/signature.go:19)
@@ -51,25 +54,16 @@ __device__ __forceinline__ bool nym_challenge_matches(const uint32_t* __restrict
         hw[33 + j] |= ipk_hash[j] >> 16;
         hw[34 + j] |= ipk_hash[j] << 16;
     }
-    uint32_t h[8], w[16];
-    sha256_iv(h);
-#pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = hw[k];
-    sha256_compress(h, w);
-#pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = hw[16 + k];
-    sha256_compress(h, w);
-    uint32_t tailw[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) tailw[k] = hw[32 + k];
-    ShaTailRegs tail{tailw};
-    sha256_stream_t(arena32, arena_words, h, tail, 38u, start, len, 128u, active, true);
+}
 
+// idemix/nymsignature.go:100-107 behind the first hash: c = digest mod r; ProofC' = SHA-256(c || nonce) mod r; equal to ProofC?
+__device__ __forceinline__ bool nym_second_hash_matches(const uint32_t h1[8], const u256& nonce, const u256& proof_c) {
+    uint32_t h[8], w[16];
     u256 d, c;
 #pragma unroll
-    for (int k = 0; k < 8; k++) d.w[k] = h[7 - k];
+    for (int k = 0; k < 8; k++) d.w[k] = h1[7 - k];
     bn_mod_order(c, d);
-    // second hash: c (32 bytes) || nonce (32 bytes) = one block, then the padding block of a 64-byte message
+    // c (32 bytes) || nonce (32 bytes) = one block, then the padding block of a 64-byte message
     sha256_iv(h);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -89,6 +83,28 @@ __device__ __forceinline__ bool nym_challenge_matches(const uint32_t* __restrict
 #pragma unroll
     for (int k = 0; k < 8; k++) diff |= c.w[k] ^ proof_c.w[k];
     return diff == 0;
+}
+
+__device__ __forceinline__ bool nym_challenge_matches(const uint32_t* __restrict__ arena32, uint32_t arena_words, uint32_t start, uint32_t len,
+                                                      bool active, const u256& tx, const u256& ty, const u256& nx, const u256& ny,
+                                                      const uint32_t ipk_hash[8], const u256& nonce, const u256& proof_c) {
+    uint32_t hw[NYM_HDR_WORDS];
+    nym_header_words(hw, tx, ty, nx, ny, ipk_hash);
+    uint32_t h[8], w[16];
+    sha256_iv(h);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = hw[k];
+    sha256_compress(h, w);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = hw[16 + k];
+    sha256_compress(h, w);
+    uint32_t tailw[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) tailw[k] = hw[32 + k];
+    ShaTailRegs tail{tailw};
+    sha256_stream_t(arena32, arena_words, h, tail, 38u, start, len, 128u, active, true);
+
+    return nym_second_hash_matches(h, nonce, proof_c);
 }
 
 // One registered issuer on the device: comb tables of HSk and HRand, ipk.Hash as big-endian words.
@@ -205,14 +221,21 @@ __global__ void __launch_bounds__(BLOCK, 2)
 // Four lanes per signature (bn_quad29.h): 64 signatures per 256-thread workgroup = one verdict word per tile, for the batches the
 // idemix creators of one block make (a few thousand).  Lanes 4k .. 4k+3 of a wave own signature k: pair 0 computes
 // HSk s_sk - k1 Nym, pair 1 HRand s_rnym - k2 phi(Nym), every point operation on two lanes; lane 4k hashes and reports.
-template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 2)
+//
+// FUSED = false (the default since round 5, "two phases"): the kernel stops at the commitment - lane 4k writes the 166-byte header
+// "sign" || t || Nym || ipk.Hash of its signature (192 bytes per launch row) and its status so far into the workspace - and
+// idemix_nym_challenge_coop_kernel hashes behind it with EIGHT lanes on a message (sha256_coop.h).  In the fused form one lane of four
+// walks the 73 blocks of a 4.6 KB creator message alone - 1 512 instructions per block, a quarter of the kernel's stream with three
+// lanes of four idle - and a wave holds sixteen messages, twice what the cooperative form takes; splitting the phases lets each use
+// the lane count its arithmetic wants.
+template <int BLOCK, bool FUSED>
+__global__ void __launch_bounds__(BLOCK, FUSED ? 2 : 1)
     idemix_nym_verify_quad_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off,
                                   uint32_t spans, const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
                                   const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                                   const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
                                   uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status,
-                             const uint32_t* __restrict__ gather) {
+                             const uint32_t* __restrict__ gather, uint32_t* __restrict__ hdr_out, uint8_t* __restrict__ st_out) {
     // one table per PAIR: BLOCK / 2 of them in this workgroup's slot
     PairBNQTab qtab = PairBNQTab::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * (BLOCK / 2)), threadIdx.x >> 1);
     constexpr uint32_t PER_WG = BLOCK / 4;
@@ -246,12 +269,26 @@ __global__ void __launch_bounds__(BLOCK, 2)
         uint32_t ih[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) ih[k] = id->hash[k];
+        const bool lead = (threadIdx.x & 3u) == 0;
+        if (!FUSED) {
+            // phase 1 ends here: the header and the status so far, by LAUNCH row (rows of the tile's tail and idle rows too: phase 2 reads them)
+            if (!iss_ok) st = NYM_NEEDS_SW;
+            if (lead) {
+                uint32_t hw[NYM_HDR_WORDS];
+                nym_header_words(hw, tx, ty, nx, ny, ih);
+                uint4* dst = reinterpret_cast<uint4*>(hdr_out + (size_t)i * NYM_HDR_WORDS);
+#pragma unroll
+                for (int q = 0; q < 11; q++)         // 44 words cover the 166 bytes; stored as the BYTES they are (the hash phase reads an arena)
+                    dst[q] = make_uint4(__builtin_bswap32(hw[4 * q]), __builtin_bswap32(hw[4 * q + 1]), __builtin_bswap32(hw[4 * q + 2]), __builtin_bswap32(hw[4 * q + 3]));
+                st_out[i] = (uint8_t)(active ? st : 0xFFu);
+            }
+            continue;
+        }
         uint32_t start = spans ? off[2 * ic] : off[ic], len = (spans ? off[2 * ic + 1] : off[ic + 1]) - start;   // spans: (start, end) pairs
         bool match = nym_challenge_matches(arena32, arena_words, start, len, active, tx, ty, nx, ny, ih, nn, c);
         if (st == NYM_VALID) st = match ? NYM_VALID : NYM_BAD_PROOF;
         if (!iss_ok) st = NYM_NEEDS_SW;
         // 16 verdicts per wave sit on lanes 0, 4, 8, ...: squeeze every fourth bit of the ballot into 16 bits
-        const bool lead = (threadIdx.x & 3u) == 0;
         uint64_t x = __ballot(active && lead && st == 0u) & 0x1111111111111111ull;
         x = (x | (x >> 3)) & 0x0303030303030303ull;
         x = (x | (x >> 6)) & 0x000f000f000f000full;
@@ -261,6 +298,47 @@ __global__ void __launch_bounds__(BLOCK, 2)
         if ((threadIdx.x & 63u) == 0 && (i0 >> 6) < nwords) verdict16[i0 >> 4] = (uint16_t)x;   // every 16-bit part of every word has an owner
         if (status != nullptr && active && lead) status[i] = (uint8_t)st;
     }
+}
+
+// Phase 2 of the two-phase form: the Fiat-Shamir challenge of every launch row with EIGHT lanes on its message (sha256_coop.h: eight
+// consecutive blocks' schedules in parallel, then the rounds; ~1 060 instructions per block against 1 512).  The message of row i is
+// header[i] (166 bytes, phase 1 wrote them) || arena[start, start + len); c = digest mod r, ProofC' = SHA-256(c || nonce) mod r on every
+// lane of the group alike.  A wavefront holds eight rows = one byte of the verdict bitmap; W wavefronts per workgroup, no grid stride:
+// the launch covers ceil(n / 64) * 64 rows, so every byte of every verdict word has an owner.
+template <int W>
+__global__ void __launch_bounds__(64 * W)
+    idemix_nym_challenge_coop_kernel(uint32_t n, const uint32_t* __restrict__ arena32, uint32_t arena_words, const uint32_t* __restrict__ off, uint32_t spans,
+                                     const uint8_t* __restrict__ proof_c, const uint8_t* __restrict__ nonce, const uint32_t* __restrict__ hdr,
+                                     const uint8_t* __restrict__ st_in, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status,
+                                     const uint32_t* __restrict__ gather) {
+    extern __shared__ uint32_t shac_lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* lds = shac_lds + wave * SHAC_LDS_WORDS;
+    const uint32_t row0 = (blockIdx.x * W + wave) * SHAC_PER_WAVE;             // this wavefront's first row: a multiple of 8
+    const uint32_t i = row0 + (lane >> 3);
+    bool active = i < n;
+    uint32_t ic = active ? i : (n - 1);
+    if (gather != nullptr) {
+        const uint32_t g = gather[ic];
+        active = active && g != 0xFFFFFFFFu;
+        ic = g != 0xFFFFFFFFu ? g : 0u;
+    }
+    const uint32_t start = spans ? off[2 * ic] : off[ic], len = (spans ? off[2 * ic + 1] : off[ic + 1]) - start;
+    const uint32_t rows = ((n + 63u) / 64u) * 64u;
+    uint32_t h[8];
+    sha256_coop_ex(hdr, rows * NYM_HDR_WORDS, arena32, arena_words, (active ? i : 0u) * (NYM_HDR_WORDS * 4), NYM_HDR_BYTES, start, len, active, lds, lane, h);
+    u256 nn, pc;
+    load_be_field(nn, nonce, ic);
+    load_be_field(pc, proof_c, ic);
+    const bool match = nym_second_hash_matches(h, nn, pc);
+    uint32_t st = active ? st_in[i] : 0xFFu;
+    if (st == NYM_VALID) st = match ? NYM_VALID : NYM_BAD_PROOF;
+    const bool lead = (lane & 7u) == 0;
+    // eight verdicts per wave sit on lanes 0, 8, 16, ...: gather every eighth bit of the ballot into one byte
+    const uint64_t x = __ballot(active && lead && st == 0u) & 0x0101010101010101ull;
+    const uint8_t byte = (uint8_t)((x * 0x0102040810204080ull) >> 56);
+    if (lane == 0 && row0 < rows) reinterpret_cast<uint8_t*>(verdict_bits)[row0 >> 3] = byte;
+    if (status != nullptr && active && lead) status[i] = (uint8_t)st;
 }
 
 size_t idemix_issuer_dev_bytes() { return sizeof(IssuerDev); }
@@ -277,8 +355,11 @@ static uint32_t idemix_quad_wgs(uint32_t n) {
     const uint32_t tiles = (n + VERIFY_BLOCK / 4 - 1) / (VERIFY_BLOCK / 4);
     return tiles < (uint32_t)VERIFY_MAX_WGS ? tiles : (uint32_t)VERIFY_MAX_WGS;
 }
+static size_t idemix_quad_tables_bytes(uint32_t n) { return (size_t)idemix_quad_wgs(n) * (VERIFY_BLOCK / 2) * QWS_UINT4_PER_LANE * 16; }
+static size_t idemix_rows(uint32_t n) { return ((size_t)n + 63) / 64 * 64; }
 size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad) {
-    if (idemix_quad(n, allow_split, allow_quad)) return (size_t)idemix_quad_wgs(n) * (VERIFY_BLOCK / 2) * QWS_UINT4_PER_LANE * 16;
+    // four-lane form: the pairs' tables | two-phase form: + 192 bytes of header and one status byte per launch row
+    if (idemix_quad(n, allow_split, allow_quad)) return idemix_quad_tables_bytes(n) + idemix_rows(n) * (NYM_HDR_WORDS * 4 + 1) + 256;
     VerifyGeom g = verify_geom(n, allow_split);
     return (size_t)g.wgs * g.block * QWS_UINT4_PER_LANE * 16;
 }
@@ -286,14 +367,32 @@ size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad) {
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
-                                    bool allow_quad, bool spans, hipStream_t st, const void* gather, uint32_t lds_reserve) {
+                                    bool allow_quad, bool spans, hipStream_t st, const void* gather, uint32_t lds_reserve, bool two_phase) {
     if (n == 0) return hipSuccess;
     if (idemix_quad(n, allow_split, allow_quad)) {                             // four lanes per signature: 64 signatures per workgroup
         dim3 qgrid(idemix_quad_wgs(n)), qblock(VERIFY_BLOCK);
-        hipLaunchKernelGGL(idemix_nym_verify_quad_kernel<VERIFY_BLOCK>, qgrid, qblock, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+        if (!two_phase) {
+            hipLaunchKernelGGL((idemix_nym_verify_quad_kernel<VERIFY_BLOCK, true>), qgrid, qblock, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                               (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
+                               (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
+                               (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, (uint32_t*)nullptr, (uint8_t*)nullptr);
+            return hipGetLastError();
+        }
+        // two phases: the commitments (four lanes per signature), then the challenges (eight lanes per message) on the same stream
+        uint8_t* ws = (uint8_t*)qws;
+        uint32_t* hdr = (uint32_t*)(ws + ((idemix_quad_tables_bytes(n) + 255) & ~(size_t)255));
+        uint8_t* st_tmp = (uint8_t*)hdr + idemix_rows(n) * (NYM_HDR_WORDS * 4);
+        hipLaunchKernelGGL((idemix_nym_verify_quad_kernel<VERIFY_BLOCK, false>), qgrid, qblock, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                            (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                            (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
-                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather);
+                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, hdr, st_tmp);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        constexpr int W = 4;
+        dim3 cgrid((uint32_t)(idemix_rows(n) / (W * SHAC_PER_WAVE))), cblock(64 * W);
+        hipLaunchKernelGGL(idemix_nym_challenge_coop_kernel<W>, cgrid, cblock, (size_t)W * SHAC_LDS_WORDS * 4, st, n, (const uint32_t*)arena,
+                           (uint32_t)((arena_bytes + 3) / 4), (const uint32_t*)off, spans ? 1u : 0u, (const uint8_t*)proof_c, (const uint8_t*)nonce,
+                           (const uint32_t*)hdr, (const uint8_t*)st_tmp, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather);
         return hipGetLastError();
     }
     VerifyGeom g = verify_geom(n, allow_split);

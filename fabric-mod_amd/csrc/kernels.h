@@ -101,7 +101,8 @@ hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
                                     bool allow_quad, bool spans, hipStream_t st,    // spans: off = n x (start, end) instead of n + 1 running offsets
                                     const void* gather = nullptr,                 // gather: row i takes its inputs from row gather[i] (uint32; ~0 = an idle row)
-                                    uint32_t lds_reserve = 0);                    // unused LDS asked for: keeps other reserving kernels off this one's CUs
+                                    uint32_t lds_reserve = 0,                     // unused LDS asked for: keeps other reserving kernels off this one's CUs
+                                    bool two_phase = true);                       // four-lane form: commitments, then the challenges with eight lanes on a message
 // every LANE owns a 16-entry table in the one- and two-lane geometries, every lane PAIR in the four-lane one
 size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad);
 }  // namespace fab

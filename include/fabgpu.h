@@ -71,6 +71,9 @@ typedef struct fabgpu_ctx fabgpu_ctx;
 #define FABGPU_FLAG_NO_WIDE 32u          /* registered keys: never use the eight-lanes-per-signature, two-phase kernels that serve launches of up to
                                             8 192 signatures (parity tests run both forms) */
 
+#define FABGPU_FLAG_NYM_FUSED_HASH 64u   /* idemix, four-lanes-per-signature form: hash the challenge on one lane of four inside the same kernel (round 4's
+                                            form) instead of a second launch with eight lanes on a message (parity tests run both forms) */
+
 typedef struct fabgpu_cfg {
     int32_t device;      /* HIP device ordinal; -1 = the current device */
     uint32_t max_batch;  /* staging pre-allocation hint in tuples (0 = grow on demand) */
