@@ -1134,4 +1134,13 @@ hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStre
     return hipGetLastError();
 }
 
+// see warm_kernel_functions_kernels (kernels.hip): the walk's kernels, all of which a provider's FIRST block launches for the first time
+int warm_kernel_functions_walk() {
+    int ok = 0;
+    hipFuncAttributes a;
+    const void* fns[] = {(const void*)walk_status_finish_small_kernel, (const void*)walk_status_checks_kernel, (const void*)walk_scan_kernel, (const void*)walk_nym_pack_kernel, (const void*)walk_memo_write_kernel, (const void*)walk_memo_scan_kernel, (const void*)walk_memo_len_kernel, (const void*)walk_memo_late_kernel, (const void*)walk_idfix_probe_kernel, (const void*)walk_gate_probe_kernel, (const void*)walk_gate_kernel, (const void*)walk_finish_kernel, (const void*)walk_emit_kernel, (const void*)walk_creator_digest_kernel, (const void*)walk_count_staged_kernel, (const void*)walk_count_kernel};
+    for (const void* f : fns) ok += hipFuncGetAttributes(&a, f) == hipSuccess ? 1 : 0;
+    return ok;
+}
+
 }  // namespace fab

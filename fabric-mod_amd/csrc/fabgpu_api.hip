@@ -1470,6 +1470,19 @@ int walk_idtab_set(fabgpu_ctx* ctx, uint32_t n, const DevIdEntry* entries, const
         ctx->idtab_mask = 0;
         return hip_to_rc(err);
     }
+    // The verify launches of a pass are queued on a prediction of "every tuple of this class has a key table" (pred_keyed_*: what held for
+    // the previous block).  A table whose every P-256 identity HAS a key table is better evidence than the previous block: the second
+    // pass of a fresh provider - identities learned and registered during the first - used to run on the fresh-key kernels once more
+    // (2.9 ms instead of 2.0; profiles/r05_fresh_provider_probe.txt).  A wrong "keyed" guess only costs the relaunch of that class.
+    {
+        bool any = false, all = true;
+        for (uint32_t i = 0; i < n; i++)
+            if (entries[i].p256) {
+                any = true;
+                all = all && entries[i].key_id >= 0;
+            }
+        if (any && all) ctx->pred_keyed_creators = ctx->pred_keyed_others = true;
+    }
     ctx->d_idtab = d;
     ctx->idtab_n = n;
     ctx->idtab_mask = cap - 1;
@@ -2259,7 +2272,16 @@ int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_
     DeviceGuard g(ctx->device);
     int rc = FABGPU_OK;
     const size_t need = round_up(block_bytes, 64) + 128;
-    for (int i = 0; i < fabgpu_ctx::N_STAGED && i < slots; i++) {
+    // ALL staging slots, whatever `slots` says: fabgpu_arena_stage takes the least recently filled free slot, i.e. it walks round all
+    // N_STAGED of them even when passes never overlap - with two of three made here, the third pass of a fresh provider paid for the
+    // third slot's 57 MB hipMalloc inside its upload (1.5 ms instead of 1.05: profiles/r05_fresh_provider_probe.txt).
+    (void)slots;
+    // every kernel function the passes will launch, resolved now (kernels.h warm_kernel_functions_*)
+    (void)warm_kernel_functions_kernels();
+    (void)warm_kernel_functions_wide();
+    (void)warm_kernel_functions_idemix();
+    (void)warm_kernel_functions_walk();
+    for (int i = 0; i < fabgpu_ctx::N_STAGED; i++) {
         fabgpu_ctx::Staged& sl = ctx->staged_slots[i];
         std::lock_guard<std::mutex> lk(sl.m);
         if (sl.cap >= need + (64 << 10)) continue;
@@ -2279,6 +2301,19 @@ int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_
         std::lock_guard<std::mutex> plk(ctx->stage_pin_mu);
         if (block_bytes >= ((size_t)4 << 20) && ctx->stage_pin.ensure(block_bytes) != FABGPU_OK) rc = FABGPU_ENOMEM;
         if (!ctx->stage_pool) ctx->stage_pool.reset(new (std::nothrow) WorkerPool(4));
+    }
+    {
+        // the device's copy of the identity cache (walk_idtab_set): a fresh provider's first non-empty table arrives before its SECOND
+        // pass - its room and its three small synchronous uploads are rehearsed with a one-entry table, then the table is empty again
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            if (ctx->idtab_buf.ensure((size_t)1 << 20) != FABGPU_OK) rc = FABGPU_ENOMEM;
+        }
+        DevIdEntry e;
+        memset(&e, 0, sizeof(e));
+        e.len = 4;
+        const uint8_t four[4] = {0, 0, 0, 0};
+        if (walk_idtab_set(ctx, 1, &e, four, sizeof(four), 0) == FABGPU_OK) (void)walk_idtab_set(ctx, 0, nullptr, nullptr, 0, 0);
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t ne = n_tx, nt = n_tuples;

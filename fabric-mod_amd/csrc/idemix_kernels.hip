@@ -411,4 +411,15 @@ hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_
     return hipGetLastError();
 }
 
+// see warm_kernel_functions_kernels (kernels.hip)
+int warm_kernel_functions_idemix() {
+    int ok = 0;
+    hipFuncAttributes a;
+    const void* fns[] = {(const void*)idemix_nym_verify_kernel<VERIFY_BLOCK>, (const void*)idemix_nym_verify_split_kernel<VERIFY_BLOCK>,
+                         (const void*)idemix_nym_verify_quad_kernel<VERIFY_BLOCK, true>, (const void*)idemix_nym_verify_quad_kernel<VERIFY_BLOCK, false>,
+                         (const void*)idemix_nym_challenge_coop_kernel<4>};
+    for (const void* f : fns) ok += hipFuncGetAttributes(&a, f) == hipSuccess ? 1 : 0;
+    return ok;
+}
+
 }  // namespace fab

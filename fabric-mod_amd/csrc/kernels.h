@@ -105,4 +105,9 @@ hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_
                                     bool two_phase = true);                       // four-lane form: commitments, then the challenges with eight lanes on a message
 // every LANE owns a 16-entry table in the one- and two-lane geometries, every lane PAIR in the four-lane one
 size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad);
+// every kernel function of a translation unit resolved now instead of at its first launch (GPUCSP::Preallocate); returns how many
+int warm_kernel_functions_kernels();
+int warm_kernel_functions_wide();
+int warm_kernel_functions_idemix();
+int warm_kernel_functions_walk();
 }  // namespace fab

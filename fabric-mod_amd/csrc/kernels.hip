@@ -507,4 +507,20 @@ hipError_t launch_sha256_p256_verify_keyed(uint32_t n, const void* arena, size_t
     return hipGetLastError();
 }
 
+// The runtime resolves a kernel FUNCTION (symbol lookup, kernel object, argument layout) at its first launch, on the launching thread -
+// after the code object of its translation unit is loaded, which the provider's construction already rehearses with one launch per unit.
+// The keyed kernels are first launched by the second block of a fresh provider (its identities earn their tables during the first):
+// asking for every function's attributes now moves that work to construction too (GPUCSP::Preallocate).  Returns how many resolved.
+int warm_kernel_functions_kernels() {
+    int ok = 0;
+    hipFuncAttributes a;
+    const void* fns[] = {(const void*)p256_verify_kernel<VERIFY_BLOCK>, (const void*)p256_verify_pair_kernel<VERIFY_BLOCK>,
+                         (const void*)p256_verify_pair_lds_kernel<VERIFY_BLOCK>, (const void*)p256_verify_keyed_kernel<VERIFY_BLOCK>,
+                         (const void*)p256_verify_keyed_pair_kernel<VERIFY_BLOCK>, (const void*)sha256_p256_verify_keyed_kernel<VERIFY_BLOCK>,
+                         (const void*)sha256_p256_verify_keyed_pair_kernel<VERIFY_BLOCK>, (const void*)sha256_p256_verify_pair_kernel<VERIFY_BLOCK>,
+                         (const void*)sha256_p256_verify_kernel<VERIFY_BLOCK>, (const void*)sha256_midstate_kernel, (const void*)gather_spans_kernel};
+    for (const void* f : fns) ok += hipFuncGetAttributes(&a, f) == hipSuccess ? 1 : 0;
+    return ok;
+}
+
 }  // namespace fab

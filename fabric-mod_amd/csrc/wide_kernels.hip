@@ -258,4 +258,15 @@ hipError_t launch_sha256_messages_coop(uint32_t n, const void* arena, size_t are
     return hipGetLastError();
 }
 
+// see warm_kernel_functions_kernels (kernels.hip)
+int warm_kernel_functions_wide() {
+    int ok = 0;
+    hipFuncAttributes a;
+    const void* fns[] = {(const void*)p256_wide_pre_kernel<1>, (const void*)p256_wide_pre_kernel<2>, (const void*)p256_wide_post_kernel<1>,
+                         (const void*)p256_wide_post_kernel<2>, (const void*)sha256_messages_kernel, (const void*)sha256_messages_coop_kernel<1>,
+                         (const void*)sha256_messages_coop_kernel<4>, (const void*)sha256_mixed_kernel};
+    for (const void* f : fns) ok += hipFuncGetAttributes(&a, f) == hipSuccess ? 1 : 0;
+    return ok;
+}
+
 }  // namespace fab

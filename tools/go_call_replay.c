@@ -234,6 +234,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n_dev && i < 64; i++) devs[i] = visible > 0 ? i % visible : 0;
     o.devices = devs;
     o.concurrent_passes = 2;
+    o.pass_timing = getenv("GO_REPLAY_PASS_TIMING") ? 1 : 0; /* stage breakdown of every pass on stderr (probes only) */
     o.expect_block_bytes = len + 4096;
     o.expect_tuples = n_tuples + 64;
     char err[256];
