@@ -850,6 +850,7 @@ int fabgpu_csp_idemix_msp_register2(fabgpu_csp* csp, const char* channel, const 
     return FABGPU_OK;
 }
 
+int fabgpu_idemix_issuer_key_is_canonical(const uint8_t* ipk_raw, size_t len) { return IdemixCSP::IssuerKeyEncodingIsCanonical(ipk_raw, len) ? 1 : 0; }
 int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap) {
     if (!csp || !issuer_id) return FABGPU_EINVAL;
     // (every device of the provider gets the issuer's tables, under one id)

@@ -300,14 +300,55 @@ int64_t GPUCSP::GetOption(const std::string& name) const {
 // contexts behind its back makes the ids differ - then the key simply has no table here (-1) and verifies on the fresh-key kernels.
 int64_t GPUCSP::RegisterKeyOnAllDevices(const uint8_t* qx32, const uint8_t* qy32, const int32_t* prebuilt_table) const {
     std::lock_guard<std::mutex> lk(reg_mu_);
+    if (!HealPendingRegistrationsLocked()) return -1;       // (nothing new is installed while an earlier registration is still lopsided)
     const int G = (int)devs_.size();
     fabgpu_ctx* cs[kMaxProviderDevices];
     uint32_t ids[kMaxProviderDevices];
     for (int g = 0; g < G; g++) cs[g] = devs_[(size_t)g]->ctx;
-    if (key_register_many_prebuilt(cs, G, qx32, qy32, prebuilt_table, ids) != FABGPU_OK) return -1;
+    const int rc = key_register_many_prebuilt(cs, G, qx32, qy32, prebuilt_table, ids);
+    if (rc != FABGPU_OK) {
+        // did any device take it?  then the pool is lopsided until this key is on all of them
+        uint32_t id0 = 0;
+        bool some = false;
+        for (int g = 0; g < G; g++) some = some || fabgpu_p256_key_lookup(cs[g], qx32, qy32, &id0) == FABGPU_OK;
+        if (some) {
+            PendingKey pk;
+            memcpy(pk.qx, qx32, 32);
+            memcpy(pk.qy, qy32, 32);
+            pending_keys_.push_back(pk);
+        }
+        if (!reg_failure_logged_) {
+            reg_failure_logged_ = true;
+            fprintf(stderr, "fabgpu: a key table could not be installed on every device (%s)%s; the key verifies on the fresh-key kernels\n", fabgpu_strerror(rc),
+                    some ? " - it will be retried before the next registration" : "");
+        }
+        return -1;
+    }
     for (int g = 1; g < G; g++)
         if (ids[g] != ids[0]) return -1;
     return ids[0];
+}
+// Replays the registrations that reached only some devices (idempotent where the key / issuer already is).  Called with reg_mu_ held.
+bool GPUCSP::HealPendingRegistrationsLocked() const {
+    const int G = (int)devs_.size();
+    fabgpu_ctx* cs[kMaxProviderDevices];
+    uint32_t ids[kMaxProviderDevices];
+    for (int g = 0; g < G; g++) cs[g] = devs_[(size_t)g]->ctx;
+    while (!pending_keys_.empty()) {
+        const PendingKey& pk = pending_keys_.front();
+        if (key_register_many_prebuilt(cs, G, pk.qx, pk.qy, nullptr, ids) != FABGPU_OK) return false;
+        pending_keys_.erase(pending_keys_.begin());
+    }
+    while (!pending_issuers_.empty()) {
+        const std::string& raw = pending_issuers_.front();
+        for (int g = 0; g < G; g++) {
+            IdemixCSP ic(cs[g]);
+            IdemixIssuerPublicKey k;
+            if (!ic.IssuerKeyImport((const uint8_t*)raw.data(), raw.size(), k).ok() || k.issuer_id < 0) return false;
+        }
+        pending_issuers_.erase(pending_issuers_.begin());
+    }
+    return true;
 }
 // ProviderOptions::concurrent_passes: what that many overlapping passes per device need, made when the provider is made (DESIGN.md 8
 // "Next" item 1) - per device the staging slots, pinned staging and pass arrays (walk_preallocate), for the
@@ -418,17 +459,24 @@ size_t GPUCSP::MemoPinLayout(uint32_t n_tuples, uint32_t n_creators, uint32_t* s
 }
 int64_t GPUCSP::ImportIdemixIssuer(const uint8_t* ipk_raw, size_t len, std::string* err) const {
     std::lock_guard<std::mutex> lk(reg_mu_);
+    if (!HealPendingRegistrationsLocked()) {
+        if (err) *err = "an earlier registration has not reached every device yet";
+        return -1;
+    }
     int64_t id = -1;
     for (size_t g = 0; g < devs_.size(); g++) {
         IdemixCSP ic(devs_[g]->ctx);
         IdemixIssuerPublicKey k;
         Error e = ic.IssuerKeyImport(ipk_raw, len, k);
-        if (!e.ok()) {
-            if (err) *err = e.msg;
+        const bool took = e.ok() && k.issuer_id >= 0;
+        if (!took) {
+            if (err) *err = e.ok() ? "a device did not take the issuer key" : e.msg;
+            // (devices before g have it: replayed before the next registration, so that the per-device issuer ids stay aligned)
+            if (g > 0 && e.ok()) pending_issuers_.emplace_back((const char*)ipk_raw, len);
             return -1;
         }
         if (g == 0) id = k.issuer_id;
-        else if (k.issuer_id != id) return -1;              // (a device that did not take it, or ids that differ: not accelerated)
+        else if (k.issuer_id != id) return -1;              // (ids that differ: not accelerated)
     }
     return id;
 }
@@ -1016,7 +1064,7 @@ void GPUCSP::RegisterQueued(const std::vector<std::string>& to_register) const {
             if (ok) it->second->second.key_id = id;
             else if (id_registered_ > 0) id_registered_--;
         }
-        id_version_.fetch_add(1, std::memory_order_release);
+        if (ok) id_version_.fetch_add(1, std::memory_order_release);    // (a failed attempt changed nothing the devices' tables show)
     }
 }
 

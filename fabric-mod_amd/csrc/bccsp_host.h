@@ -279,6 +279,14 @@ class GPUCSP {
     // or -1 when the devices disagree about it / a device failed (the fresh-key kernels then serve that key: always correct).
     int64_t RegisterKeyOnAllDevices(const uint8_t* qx32, const uint8_t* qy32, const int32_t* prebuilt_table = nullptr) const;
     mutable std::mutex reg_mu_;                             // registrations take turns: ids stay the same on every device
+    // Registrations that reached SOME devices of the pool and failed on another (ENOMEM, a context's table limit): replayed, in order,
+    // before anything new is installed anywhere - so a transient failure heals and a lasting one stops further installs instead of
+    // leaving the per-device id counters offset for good.  Guarded by reg_mu_.
+    struct PendingKey { uint8_t qx[32], qy[32]; };
+    mutable std::vector<PendingKey> pending_keys_;
+    mutable std::vector<std::string> pending_issuers_;      // marshalled IssuerPublicKey bytes
+    mutable bool reg_failure_logged_ = false;
+    bool HealPendingRegistrationsLocked() const;            // true: nothing is pending any more
     void Preallocate() const;
     // identity cache of the pre-verify pass (msp/cache/cache.go): SerializedIdentity bytes -> P-256 key + device key id
     struct CachedIdentity {

@@ -97,6 +97,52 @@ static int issuer_key_fields(const uint8_t* raw, size_t len, IdemixIssuerPublicK
     if (!w.ok) return 0;
     return hsk && hrand && hash ? 2 : 1;
 }
+// Is `raw` exactly what golang/protobuf would produce when it marshals the IssuerPublicKey it unmarshalled from `raw` (idemix.proto:18-48)?
+// SetHash (idemix/issuerkey.go:171-182) hashes the RE-MARSHALLED key with Hash cleared; the library hashes the bytes it was given with
+// field 10 cut out.  The two agree exactly when the encoding is canonical: known fields only, all length-delimited, in ascending field
+// order (repeated only where the message repeats: 1 attribute_names, 4 h_attrs), single-byte tags, minimal length varints, no singular
+// bytes field present-but-empty (proto3 drops those when marshalling), and the same for the nested ECP / ECP2 messages.  Anything else
+// (out-of-order, duplicate or unknown fields, padded varints) is left to bccsp/idemix.
+static bool canonical_message(const uint8_t* b, size_t n, int max_field, uint32_t repeated_mask, uint32_t message_mask, uint32_t ecp2_mask, int depth) {
+    const uint8_t *p = b, *end = b + n;
+    int prev = 0;
+    while (p < end) {
+        const uint8_t tag = *p++;
+        if (tag & 0x80) return false;                                   // fields 1..15 have one-byte tags
+        const int num = tag >> 3;
+        if ((tag & 7) != 2 || num < 1 || num > max_field) return false;
+        if (num < prev || (num == prev && !((repeated_mask >> num) & 1))) return false;
+        prev = num;
+        uint64_t v = 0;
+        int k = 0;
+        for (;; k++) {
+            if (p >= end || k >= 5) return false;
+            const uint8_t c = *p++;
+            v |= (uint64_t)(c & 0x7F) << (7 * k);
+            if (!(c & 0x80)) {
+                if (k > 0 && c == 0) return false;                      // a padded (non-minimal) length
+                break;
+            }
+        }
+        if (v > (uint64_t)(end - p)) return false;
+        const bool is_msg = (message_mask >> num) & 1;
+        if (is_msg) {
+            if (depth >= 1) return false;
+            const bool ecp2 = (ecp2_mask >> num) & 1;
+            if (!canonical_message(p, (size_t)v, ecp2 ? 4 : 2, 0, 0, 0, depth + 1)) return false;
+        } else if (v == 0 && !((repeated_mask >> num) & 1)) {
+            return false;                                               // a singular bytes field that is empty is not marshalled at all
+        }
+        p += v;
+    }
+    return true;
+}
+static bool canonical_issuer_key(const uint8_t* raw, size_t len) {
+    // repeated: 1, 4; messages: 2 3 4 6 7 (ECP) and 5 (ECP2)
+    return canonical_message(raw, len, 10, (1u << 1) | (1u << 4), (1u << 2) | (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 7), 1u << 5, 0);
+}
+bool IdemixCSP::IssuerKeyEncodingIsCanonical(const uint8_t* raw, size_t len) { return raw && len && canonical_issuer_key(raw, len); }
+
 bool IdemixCSP::IssuerKeyFields(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out) {
     out.issuer_id = -1;
     return raw && len && issuer_key_fields(raw, len, out) == 2;
@@ -108,6 +154,7 @@ Error IdemixCSP::IssuerKeyImport(const uint8_t* raw, size_t len, IdemixIssuerPub
     if (got == 0) return Error("failed to unmarshal issuer public key");
     out.issuer_id = -1;
     if (got != 2) return Error();   // a key the device cannot take (odd field sizes): valid for bccsp/idemix, not accelerated
+    if (!canonical_issuer_key(raw, len)) return Error();   // Go would hash other bytes than these (see canonical_message): not accelerated
     // The reference never trusts field 10: IssuerPublicKey.Check ends in SetHash (idemix/issuerkey.go:171-182) - Hash = HashModOrder of the
     // key marshalled with Hash cleared - and the Go side's lookups carry THAT value.  The challenge of every pseudonym signature and
     // the memo's issuer binding hang on it, so the same is recomputed here (the marshalled key minus its field 10; SHA-256 on the device,

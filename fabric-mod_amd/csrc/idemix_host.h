@@ -43,6 +43,10 @@ class IdemixCSP {
     Error IssuerKeyImport(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out) const;
     // the fields alone (HSk, HRand, Hash as 32-byte halves), no device: false when the bytes do not parse or a field has another size
     static bool IssuerKeyFields(const uint8_t* raw, size_t len, IdemixIssuerPublicKey& out);
+    // Would golang/protobuf re-marshal the key it unmarshals from these bytes to the SAME bytes?  Only then does the library's issuer hash
+    // (the bytes minus field 10) equal SetHash's (idemix/issuerkey.go:171-182: the re-marshalled key with Hash cleared); a key in any
+    // other encoding is not accelerated (issuer_id -1).
+    static bool IssuerKeyEncodingIsCanonical(const uint8_t* raw, size_t len);
     // raw: x || y (bccsp/idemix/bridge/user.go:72-86 splits at len/2)
     Error NymKeyImport(const uint8_t* raw, size_t len, NymPublicKey& out) const;
     Error NymVerifyBatch(const std::vector<NymVerifyItem>& items, std::vector<VerifyResult>& results) const;

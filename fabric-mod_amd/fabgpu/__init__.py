@@ -104,7 +104,7 @@ ABI_SYMBOLS = [
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
     "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_csp_idemix_msp_register2", "fabgpu_block_hash_checks",
-    "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_block_pass_abandon", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_lookup_nym", "fabgpu_csp_memo_has_block", "fabgpu_csp_memo_evict_block",
+    "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_block_pass_abandon", "fabgpu_idemix_issuer_key_is_canonical", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_lookup_nym", "fabgpu_csp_memo_has_block", "fabgpu_csp_memo_evict_block",
     "fabgpu_csp_verify_coalesced", "fabgpu_csp_identity_verify_coalesced", "fabgpu_csp_coalescer_configure", "fabgpu_csp_coalescer_stats",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
     "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",

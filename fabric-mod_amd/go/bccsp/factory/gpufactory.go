@@ -26,6 +26,10 @@ type GPUOpts struct {
 	// channel's validator receives it (core/peer/peer.go:337-355), so "one provider per device" cannot be configured - one provider
 	// owns them all and routes each block pass to the least busy device (fabgpu_csp_new2, include/fabgpu_bccsp.h).
 	Devices []int `mapstructure:"devices" json:"devices" yaml:"Devices"`
+	// Device: DEPRECATED alias from the time a provider drove one device (`GPU: Device: N`).  mapstructure ignores unknown keys, so
+	// without this field an old core.yaml would silently mean "every visible device" - contexts and ConcurrentPasses' pinned memory
+	// on all of them.  Used only when Devices is empty: Devices = [Device].  Setting both to different things is an error.
+	Device *int `mapstructure:"device" json:"device,omitempty" yaml:"Device,omitempty"`
 	// ConcurrentPasses: per device, how many overlapping block passes to allocate for when the provider is made (staging slots, pinned
 	// memo tables, pass arrays) instead of when passes first overlap.  2 suits the arrival pipeline of one channel per device.
 	ConcurrentPasses int `mapstructure:"concurrentpasses" json:"concurrentpasses" yaml:"ConcurrentPasses"`
@@ -68,6 +72,13 @@ func (f *GPUFactory) Get(config *FactoryOpts) (bccsp.BCCSP, error) {
 	}
 	var opts gpu.Options
 	if g := config.GPUOpts; g != nil {
+		if g.Device != nil {
+			if len(g.Devices) == 0 {
+				g.Devices = []int{*g.Device}
+			} else if len(g.Devices) != 1 || g.Devices[0] != *g.Device {
+				return nil, errors.Errorf("Invalid GPU opts: the deprecated Device [%d] contradicts Devices %v", *g.Device, g.Devices)
+			}
+		}
 		opts = gpu.Options{Devices: g.Devices, ConcurrentPasses: g.ConcurrentPasses, ExpectBlockBytes: g.ExpectBlockBytes,
 			ExpectTuples: g.ExpectTuples, MemoBlocks: g.MemoBlocks, HostWalk: g.HostWalk, PassTiming: g.PassTiming}
 	}

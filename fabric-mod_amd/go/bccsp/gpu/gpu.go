@@ -92,7 +92,18 @@ type Provider struct {
 	// room for per-transaction flags, remembered from block to block (atomic max): the library answers FABGPU_ETOOBIG - before it has
 	// waited for the upload or launched anything, and the retry finds its upload again - only when a block outgrows every block before it
 	capTx uint32
-	m     *passMetrics // nil until RegisterMetrics
+	// metrics: published through an atomic.Value (RegisterMetrics may run while PreVerifyBlock goroutines are already reading it);
+	// the refresher goroutine is stopped by Close BEFORE the C provider is freed (ADVICE r4)
+	mv          atomic.Value // *passMetrics; empty until RegisterMetrics
+	metricsOnce sync.Once
+	stopMetrics chan struct{}
+	metricsDone chan struct{}
+}
+
+// metrics returns the registered pass metrics, or nil (every passMetrics method is nil-safe)
+func (p *Provider) metrics() *passMetrics {
+	m, _ := p.mv.Load().(*passMetrics)
+	return m
 }
 
 // Options is what GPUFactory reads from the `GPU:` section of the BCCSP configuration (bccsp/factory/gpufactory.go GPUOpts) - the
@@ -235,7 +246,15 @@ func (p *Provider) PassesPerDevice() []uint64 {
 
 // Close releases the device context (tests; a peer keeps its BCCSP for life).
 func (p *Provider) Close() {
-	p.closeOnce.Do(func() { C.fabgpu_csp_free(p.csp) })
+	p.closeOnce.Do(func() {
+		// the metrics refresher calls into the C provider: it must be gone before the provider is
+		p.metricsOnce.Do(func() {}) // (no refresher may be started from here on)
+		if p.stopMetrics != nil {
+			close(p.stopMetrics)
+			<-p.metricsDone
+		}
+		C.fabgpu_csp_free(p.csp)
+	})
 }
 
 // be32 is big.Int.FillBytes for Go 1.14: the value as exactly 32 big-endian bytes (callers guarantee BitLen <= 256).
@@ -371,14 +390,14 @@ func (p *Provider) PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSumm
 			continue
 		}
 		if rc != 0 {
-			p.m.passFailed()
+			p.metrics().passFailed()
 			return nil, errors.Errorf("fabgpu: %s", C.GoString(C.fabgpu_strerror(rc)))
 		}
-		p.m.passDone(time.Since(start), int(nTx), int(nTuples), int(seeded))
+		p.metrics().passDone(time.Since(start), int(nTx), int(nTuples), int(seeded))
 		return &PassSummary{TxFlags: flags[:nTx], Tuples: int(nTuples), BlockSigs: int(nBlockSigs), MemoSeeded: int(seeded)}, nil
 	}
 	C.fabgpu_csp_block_pass_abandon(p.csp) // no retry will come: drop the upload the library kept for one
-	p.m.passFailed()
+	p.metrics().passFailed()
 	return nil, errors.New("fabgpu: block shape changed between attempts")
 }
 
@@ -519,29 +538,42 @@ func (m *passMetrics) passFailed() {
 // metrics (internal/peer/node/start.go:243: metricsProvider := opsSystem.Provider - the patch line is in gpufactory_patch.txt); the
 // route and memo gauges are refreshed every refresh interval from the library's own counters (PassRoutes, PassesPerDevice, MemoStats).
 func (p *Provider) RegisterMetrics(mp metrics.Provider, refresh time.Duration) {
-	if mp == nil || p.m != nil {
+	if mp == nil {
 		return
 	}
-	p.m = &passMetrics{
-		duration: mp.NewHistogram(passDurationOpts), tx: mp.NewCounter(passTxOpts), sigs: mp.NewCounter(passSigOpts),
-		failed: mp.NewCounter(passFailedOpts), routes: mp.NewGauge(passRouteOpts), memo: mp.NewGauge(memoOpts),
-	}
-	if refresh <= 0 {
-		refresh = 5 * time.Second
-	}
-	go func() {
-		for range time.Tick(refresh) {
-			d, h, _ := p.PassRoutes()
-			p.m.routes.With("route", "device_walk").Set(float64(d))
-			p.m.routes.With("route", "host_walk").Set(float64(h))
-			for i, n := range p.PassesPerDevice() {
-				p.m.routes.With("route", "context_"+strconv.Itoa(i)).Set(float64(n))
-			}
-			e, hit, miss, ev := p.MemoStats()
-			p.m.memo.With("what", "entries").Set(float64(e))
-			p.m.memo.With("what", "hits").Set(float64(hit))
-			p.m.memo.With("what", "misses").Set(float64(miss))
-			p.m.memo.With("what", "evicted").Set(float64(ev))
+	p.metricsOnce.Do(func() {
+		m := &passMetrics{
+			duration: mp.NewHistogram(passDurationOpts), tx: mp.NewCounter(passTxOpts), sigs: mp.NewCounter(passSigOpts),
+			failed: mp.NewCounter(passFailedOpts), routes: mp.NewGauge(passRouteOpts), memo: mp.NewGauge(memoOpts),
 		}
-	}()
+		if refresh <= 0 {
+			refresh = 5 * time.Second
+		}
+		p.stopMetrics = make(chan struct{})
+		p.metricsDone = make(chan struct{})
+		p.mv.Store(m)
+		go func() {
+			defer close(p.metricsDone)
+			t := time.NewTicker(refresh)
+			defer t.Stop()
+			for {
+				select {
+				case <-p.stopMetrics:
+					return
+				case <-t.C:
+				}
+				d, h, _ := p.PassRoutes()
+				m.routes.With("route", "device_walk").Set(float64(d))
+				m.routes.With("route", "host_walk").Set(float64(h))
+				for i, n := range p.PassesPerDevice() {
+					m.routes.With("route", "context_"+strconv.Itoa(i)).Set(float64(n))
+				}
+				e, hit, miss, ev := p.MemoStats()
+				m.memo.With("what", "entries").Set(float64(e))
+				m.memo.With("what", "hits").Set(float64(hit))
+				m.memo.With("what", "misses").Set(float64(miss))
+				m.memo.With("what", "evicted").Set(float64(ev))
+			}
+		}()
+	})
 }

@@ -279,6 +279,11 @@ int fabgpu_block_tuples(const uint8_t* block, size_t len, uint32_t cap, uint32_t
 int fabgpu_csp_idemix_msp_register(fabgpu_csp* csp, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id);
 int fabgpu_csp_idemix_msp_register2(fabgpu_csp* csp, const char* channel, const char* mspid, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id);
 int fabgpu_csp_idemix_issuer_import(fabgpu_csp* csp, const uint8_t* ipk_raw, size_t len, int64_t* issuer_id, char* err, size_t errcap);
+/* 1: the marshalled idemix.IssuerPublicKey is in the encoding golang/protobuf itself produces (known fields only, ascending, single-byte
+ * tags, minimal length varints, no empty singular bytes fields; idemix.proto:18-48) - only such a key is accelerated, because only for
+ * it the library's issuer hash (the given bytes minus field 10) equals SetHash's (idemix/issuerkey.go:171-182, over the RE-MARSHALLED
+ * key).  0: any other encoding (the import entry points then answer *issuer_id = -1 and bccsp/idemix serves the key).  No device needed. */
+int fabgpu_idemix_issuer_key_is_canonical(const uint8_t* ipk_raw, size_t len);
 int fabgpu_csp_idemix_nym_verify_batch(fabgpu_csp* csp, int64_t issuer_id, size_t n, const uint8_t* nym_arena, const uint32_t* nym_off,
                                        const uint8_t* sig_arena, const uint32_t* sig_off, const uint8_t* msg_arena, const uint32_t* msg_off,
                                        uint8_t* valid, uint8_t* flags, char* errs, size_t errstride);

@@ -493,3 +493,60 @@ def test_bench_compact_line_worst_case_stays_under_the_limit():
     out["roofline"]["traffic"] = float("inf")
     again = bench.compact_line(out)
     assert "NaN" not in again and "Infinity" not in again and json.loads(again)["roofline"]["traffic"] is None
+
+
+# ---- idemix issuer keys: only the encoding golang/protobuf itself produces is accelerated (idemix/issuerkey.go:171-182) ----
+def _pb_fields(raw):
+    out, p = [], 0
+    while p < len(raw):
+        start = p
+        tag = raw[p]
+        p += 1
+        ln, k = 0, 0
+        while True:
+            c = raw[p]
+            p += 1
+            ln |= (c & 0x7F) << (7 * k)
+            k += 1
+            if not c & 0x80:
+                break
+        out.append((tag >> 3, raw[start:p + ln]))
+        p += ln
+    return out
+
+
+def test_issuer_key_canonical_encoding_gate():
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    L = fabgpu.load()
+    canon = lambda b: L.fabgpu_idemix_issuer_key_is_canonical(bytes(b), len(b))
+    fx = json.load(open(os.path.join(root, "tests", "golden", "idemix_fixtures.json")))["msps"]
+    for name, m in fx.items():
+        raw = bytes.fromhex(m["ipk"])
+        assert canon(raw) == 1, name                                         # the reference's own testdata keys (idemixgen output)
+        f = _pb_fields(raw)
+        assert b"".join(x for _, x in f) == raw
+        # the same fields in another order: proto.Unmarshal accepts it, proto.Marshal would emit other bytes -> SetHash hashes other bytes
+        swapped = list(f)
+        i2, i3 = [k for k, (n, _) in enumerate(f) if n == 2][0], [k for k, (n, _) in enumerate(f) if n == 3][0]
+        swapped[i2], swapped[i3] = swapped[i3], swapped[i2]
+        assert canon(b"".join(x for _, x in swapped)) == 0
+        # a duplicate singular field (last one wins on unmarshal, one copy is marshalled)
+        assert canon(raw + [x for n, x in f if n == 10][0]) == 0
+        # an unknown field (golang/protobuf keeps it in XXX_unrecognized and emits it at the END, wherever it stood) / a varint field
+        assert canon(raw[:4] + bytes([0x5A, 0x01, 0x00]) + raw[4:]) == 0     # field 11 in the middle
+        assert canon(raw + bytes([0x5A, 0x01, 0x00])) == 0                   # ... and at the end: not a field of idemix.proto:37-48 at all
+        assert canon(raw + bytes([0x58, 0x01])) == 0                         # field 11 as a varint
+        # a padded length varint (0xA0 0x00 for 32)
+        h = [x for n, x in f if n == 10][0]
+        padded = raw[:len(raw) - len(h)] + bytes([0x52, 0xA0, 0x00]) + h[2:]
+        assert _pb_fields(padded)[-1][0] == 10 and canon(padded) == 0
+        # an empty singular bytes field (proto3 does not marshal it) / an empty repeated string (it does)
+        assert canon(raw[:len(raw) - len(h)] + bytes([0x52, 0x00])) == 0
+        assert canon(bytes([0x0A, 0x00]) + raw) == 1
+        # a nested ECP with its coordinates the wrong way round
+        hsk = f[i2][1]
+        inner = _pb_fields(hsk[2:])
+        bad_hsk = hsk[:2] + inner[1][1] + inner[0][1]
+        assert canon(b"".join(bad_hsk if k == i2 else x for k, (_, x) in enumerate(f))) == 0
+    assert canon(b"") == 0 and L.fabgpu_idemix_issuer_key_is_canonical(None, 0) == 0
