@@ -43,7 +43,7 @@ type testSigner struct {
 	key   bccsp.Key
 }
 
-func newTestSigner(t *testing.T, g bccsp.BCCSP, mspID string, serial int64) *testSigner {
+func newTestSigner(t testing.TB, g bccsp.BCCSP, mspID string, serial int64) *testSigner {
 	priv, err := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
 	require.NoError(t, err)
 	tmpl := &x509.Certificate{SerialNumber: big.NewInt(serial), Subject: pkix.Name{CommonName: "fabgpu-test"},
@@ -70,7 +70,7 @@ func (s *testSigner) Sign(msg []byte) ([]byte, error) {
 	return utils.MarshalECDSASignature(r, sv)
 }
 
-func buildSignedBlock(t *testing.T, g bccsp.BCCSP, nTx, nEndorsers int) ([]byte, []blockTuple) {
+func buildSignedBlock(t testing.TB, g bccsp.BCCSP, nTx, nEndorsers int) ([]byte, []blockTuple) {
 	creator := newTestSigner(t, g, "Org1MSP", 1)
 	endorsers := make([]*testSigner, nEndorsers)
 	for i := range endorsers {
