@@ -577,25 +577,6 @@ int fabgpu_csp_identity_cache_size(fabgpu_csp* csp, uint64_t* identities) {
     return FABGPU_OK;
 }
 
-int fabgpu_csp_x509_check_signature_batch(fabgpu_csp* csp, size_t n, const uint8_t* cert_arena, const uint32_t* cert_off, const uint8_t* issuer_qx,
-                                          const uint8_t* issuer_qy, uint8_t* status) {
-    if (!csp || (n && (!cert_arena || !cert_off || !issuer_qx || !issuer_qy || !status))) return FABGPU_EINVAL;
-    for (size_t i = 0; i < n; i++)
-        if (cert_off[i + 1] < cert_off[i]) return FABGPU_EINVAL;
-    Error e = csp->csp->X509CheckSignatureBatch(n, cert_arena, cert_off, issuer_qx, issuer_qy, status);
-    return e.ok() ? FABGPU_OK : FABGPU_ELAUNCH;
-}
-
-// pure host: the parts of a DER certificate crypto/x509 checkSignature looks at
-int fabgpu_x509_signature_parts(const uint8_t* der, size_t len, uint32_t* tbs_off, uint32_t* tbs_len, uint32_t* sig_off, uint32_t* sig_len, int* ecdsa_sha256) {
-    if (!der || !tbs_off || !tbs_len || !sig_off || !sig_len || !ecdsa_sha256) return FABGPU_EINVAL;
-    Span tbs, sg;
-    bool ok = false;
-    if (!CertDerSignatureParts(der, len, tbs, sg, ok)) return 1;
-    *tbs_off = tbs.off; *tbs_len = tbs.len; *sig_off = sg.off; *sig_len = sg.len; *ecdsa_sha256 = ok ? 1 : 0;
-    return FABGPU_OK;
-}
-
 // pure host: structure of a marshalled block as the pre-verify pass sees it
 int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
                        char* channel_id, size_t channel_cap) {

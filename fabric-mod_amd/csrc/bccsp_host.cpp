@@ -805,78 +805,6 @@ Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& ou
     return PreVerifyParsed(block, pb, out, &up, opt);
 }
 
-// ---- x509 certificate signatures ----------------------------------------------------------------------------------------
-Error GPUCSP::X509CheckSignatureBatch(size_t n, const uint8_t* cert_arena, const uint32_t* cert_off, const uint8_t* issuer_qx,
-                                      const uint8_t* issuer_qy, uint8_t* status) const {
-    if (n == 0) return Error();
-    if (!cert_arena || !cert_off || !issuer_qx || !issuer_qy || !status) return Error("nil argument");
-    static const uint8_t N_BE[32] = {0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
-                                     0xbc, 0xe6, 0xfa, 0xad, 0xa7, 0x17, 0x9e, 0x84, 0xf3, 0xb9, 0xca, 0xc2, 0xfc, 0x63, 0x25, 0x51};
-    std::vector<uint32_t> sub, off;
-    std::vector<uint8_t> qx, qy, r, s;
-    for (size_t i = 0; i < n; i++) {
-        status[i] = 6;
-        if (cert_off[i + 1] < cert_off[i]) return Error("certificate offsets must not decrease");
-        const uint8_t* der = cert_arena + cert_off[i];
-        const size_t dl = cert_off[i + 1] - cert_off[i];
-        Span tbs, sg;
-        bool alg_ok = false;
-        if (!CertDerSignatureParts(der, dl, tbs, sg, alg_ok) || !alg_ok) continue;
-        if (!PublicKeyOnCurve(issuer_qx + 32 * i, issuer_qy + 32 * i)) continue;
-        // asn1.Unmarshal(signature, &ecdsaSignature{}) with an empty rest, then R, S > 0 (crypto/x509 checkSignature)
-        BigInt R, S;
-        status[i] = 5;
-        if (sg.len == 0) continue;
-        size_t hoff = 0;
-        TL tl = parse_tl(der + sg.off, sg.len, hoff, 0x30);
-        if (tl.err || hoff + tl.len != sg.len) continue;                  // "x509: trailing data after ECDSA signature"
-        if (!UnmarshalECDSASignature(der + sg.off, sg.len, R, S).ok()) continue;
-        status[i] = 1;                                                    // from here on: ecdsa.Verify's own answer
-        if (!R.fits256() || !S.fits256()) continue;                       // r, s >= n
-        uint8_t r32[32], s32[32];
-        R.to_be32(r32);
-        S.to_be32(s32);
-        if (memcmp(s32, N_BE, 32) >= 0) continue;
-        if (memcmp(s32, HALF_N_BE, 32) > 0) {                             // x509 accepts high-S: verify the low-S twin (r, n - s)
-            int borrow = 0;
-            for (int k = 31; k >= 0; k--) {
-                int d = (int)N_BE[k] - (int)s32[k] - borrow;
-                borrow = d < 0;
-                s32[k] = (uint8_t)(d + (borrow ? 256 : 0));
-            }
-        }
-        sub.push_back((uint32_t)i);
-        off.push_back(cert_off[i] + tbs.off);
-        off.push_back(cert_off[i] + tbs.off + tbs.len);
-        qx.insert(qx.end(), issuer_qx + 32 * i, issuer_qx + 32 * i + 32);
-        qy.insert(qy.end(), issuer_qy + 32 * i, issuer_qy + 32 * i + 32);
-        r.insert(r.end(), r32, r32 + 32);
-        s.insert(s.end(), s32, s32 + 32);
-    }
-    const size_t m = sub.size();
-    if (!m) return Error();
-    std::vector<uint64_t> bits((m + 63) / 64);
-    std::vector<uint8_t> st(m);
-    fabgpu_identity_batch d;
-    memset(&d, 0, sizeof(d));
-    d.n = m;
-    d.arena = cert_arena;
-    d.off = off.data();
-    d.qx = qx.data();
-    d.qy = qy.data();
-    d.r = r.data();
-    d.s = s.data();
-    d.verdict_bits = bits.data();
-    d.status = st.data();
-    d.flags = FABGPU_IDB_SPANS;
-    int rc = fabgpu_identity_verify_batch(flat_ctx(), &d);
-    if (rc != FABGPU_OK) return Error(std::string("GPU verify failed: ") + fabgpu_strerror(rc));
-    for (size_t j = 0; j < m; j++) {
-        const bool ok = ((bits[j >> 6] >> (j & 63)) & 1) && st[j] == FABGPU_ST_VALID;
-        status[sub[j]] = ok ? 0 : 1;
-    }
-    return Error();
-}
 
 // ---- verdict memo -------------------------------------------------------------------------------------------------------
 void GPUCSP::MemoKeyWrite(uint8_t* k, const uint8_t* issuer_hash32, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,

@@ -189,17 +189,6 @@ class GPUCSP {
     int WalkBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock& parsed, const char** why) const;
     // option pass_device_walk = 0 keeps every block on the host walk (A/B runs); default on
     bool DeviceWalkEnabled() const;
-    // ---- x509 certificate signatures ----
-    // The arithmetic of crypto/x509 Certificate.CheckSignatureFrom(parent) for ecdsa-with-SHA256 certificates under P-256 issuer keys -
-    // what msp identity validation runs per chain link on an msp-cache miss (msp/mspimplvalidate.go:21-52 -> msp/mspimpl.go:721-739 ->
-    // x509.Verify) and what the orderer's SigFilter pays for a new client (orderer/common/msgprocessor/sigfilter.go:50-80).  One fused
-    // SHA-256 + verify launch over the TBS bytes of n DER certificates.  x509 differs from bccsp/sw in two ways, reproduced here:
-    // trailing bytes after the signature SEQUENCE are an error, and high-S signatures are VALID (s is replaced by n - s on the host:
-    // (r, s) verifies iff (r, n - s) does).  status: 0 signature valid, 1 "x509: ECDSA verification failure", 5 signature does not parse
-    // (or R, S <= 0), 6 not ecdsa-with-SHA256 / issuer key not on P-256 / certificate does not parse: crypto/x509 decides.
-    // Validity periods, name constraints, key usage and chain building stay in Go.
-    Error X509CheckSignatureBatch(size_t n, const uint8_t* cert_arena, const uint32_t* cert_off, const uint8_t* issuer_qx, const uint8_t* issuer_qy,
-                                  uint8_t* status) const;
     // ---- verdict memo (second half) ----
     // The pass answers in advance the question the unchanged Go validators will ask one signature at a time:
     // bccsp.Verify(k, signature, digest) (msp/identities.go:188).  An entry is keyed on exactly those three byte strings - the

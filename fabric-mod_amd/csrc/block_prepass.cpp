@@ -74,34 +74,6 @@ bool CertDerToP256(const uint8_t* der, size_t len, uint8_t qx[32], uint8_t qy[32
     return true;
 }
 
-const uint8_t OID_ECDSA_WITH_SHA256[] = {0x2A, 0x86, 0x48, 0xCE, 0x3D, 0x04, 0x03, 0x02};   // 1.2.840.10045.4.3.2
-
-// Certificate ::= SEQUENCE { tbsCertificate, signatureAlgorithm, signatureValue BIT STRING }: the raw TBS TLV (what is hashed,
-// crypto/x509 Certificate.RawTBSCertificate), whether the OUTER algorithm is ecdsa-with-SHA256, and the DER signature inside the
-// BIT STRING.  false: not a certificate this walker understands.
-bool CertDerSignatureParts(const uint8_t* der, size_t len, Span& tbs, Span& sig, bool& ecdsa_sha256) {
-    Der top{der, der + len};
-    uint8_t tag;
-    const uint8_t* c;
-    size_t l;
-    if (!top.tlv(tag, c, l) || tag != 0x30) return false;
-    Der cert{c, c + l};
-    const uint8_t* tbs_start = cert.p;
-    if (!cert.tlv(tag, c, l) || tag != 0x30) return false;
-    tbs.off = (uint32_t)(tbs_start - der);
-    tbs.len = (uint32_t)(cert.p - tbs_start);
-    if (!cert.tlv(tag, c, l) || tag != 0x30) return false;            // AlgorithmIdentifier
-    Der alg{c, c + l};
-    const uint8_t* oc;
-    size_t ol;
-    if (!alg.tlv(tag, oc, ol) || tag != 0x06) return false;
-    ecdsa_sha256 = ol == sizeof(OID_ECDSA_WITH_SHA256) && memcmp(oc, OID_ECDSA_WITH_SHA256, ol) == 0;
-    if (!cert.tlv(tag, c, l) || tag != 0x03 || l < 1 || c[0] != 0x00) return false;   // BIT STRING, no unused bits
-    sig.off = (uint32_t)(c + 1 - der);
-    sig.len = (uint32_t)(l - 1);
-    return true;
-}
-
 bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy[32]) {
     const uint8_t* idb;
     size_t idl;

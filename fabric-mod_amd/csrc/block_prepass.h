@@ -106,9 +106,6 @@ bool IdentityToP256(const uint8_t* ident, size_t len, uint8_t qx[32], uint8_t qy
 // DER x509 certificate -> P-256 SubjectPublicKeyInfo point (exposed for tests against the reference's certificate fixtures)
 bool CertDerToP256(const uint8_t* der, size_t len, uint8_t qx[32], uint8_t qy[32]);
 bool PemToDer(const uint8_t* pem, size_t len, std::vector<uint8_t>& der);
-// DER x509 certificate -> spans (into der) of the raw TBSCertificate TLV and of the DER signature inside signatureValue, and whether the
-// outer signatureAlgorithm is ecdsa-with-SHA256 (crypto/x509 checkSignature's input)
-bool CertDerSignatureParts(const uint8_t* der, size_t len, Span& tbs, Span& sig, bool& ecdsa_sha256);
 // protoutil.BlockHeaderBytes (protoutil/blockutils.go:38-58): DER of SEQUENCE{INTEGER number, OCTET STRING previous_hash, OCTET STRING data_hash}
 void BlockHeaderBytes(uint64_t number, const uint8_t* prev, size_t prev_len, const uint8_t* data_hash, size_t dh_len, std::vector<uint8_t>& out);
 // does the 32-byte digest equal what the block says (hex string for HASH_TXID, raw bytes for HASH_PROPOSAL)?

@@ -107,7 +107,6 @@ ABI_SYMBOLS = [
     "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_block_pass_abandon", "fabgpu_idemix_issuer_key_is_canonical", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_lookup_nym", "fabgpu_csp_memo_has_block", "fabgpu_csp_memo_evict_block",
     "fabgpu_csp_verify_coalesced", "fabgpu_csp_identity_verify_coalesced", "fabgpu_csp_coalescer_configure", "fabgpu_csp_coalescer_stats",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
-    "fabgpu_csp_x509_check_signature_batch", "fabgpu_x509_signature_parts",
     "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
     "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev", "fabgpu_multi_collective",
     "fabgpu_csp_pass_routes", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast", "fabgpu_identity_table_hash", "fabgpu_csp_gate_probe",
@@ -216,8 +215,6 @@ def load():
     L.fabgpu_csp_idfix_probe.argtypes = [_vp, ctypes.c_uint32, _u8p, _sz, _u32p, _u8p, _u8p]
     L.fabgpu_identity_table_hash.argtypes = [ctypes.c_char_p, _sz]
     L.fabgpu_identity_table_hash.restype = ctypes.c_uint64
-    L.fabgpu_csp_x509_check_signature_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u8p, _u8p, _u8p]
-    L.fabgpu_x509_signature_parts.argtypes = [ctypes.c_char_p, _sz, _u32p, _u32p, _u32p, _u32p, ctypes.POINTER(ctypes.c_int)]
     L.fabgpu_multi_init.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(_vp)]
     L.fabgpu_multi_shutdown.argtypes = [_vp]
     L.fabgpu_multi_shutdown.restype = None
@@ -1020,29 +1017,6 @@ def gate_probe(csp: "GPUCSP", sigs: Sequence[bytes]):
 
 def identity_table_hash(b: bytes) -> int:
     return load().fabgpu_identity_table_hash(b, len(b))
-
-
-def x509_signature_parts(der: bytes):
-    """(tbs bytes, DER signature bytes, is_ecdsa_sha256) of a DER certificate, or None (pure host)."""
-    v = [ctypes.c_uint32(0) for _ in range(4)]
-    alg = ctypes.c_int(0)
-    rc = load().fabgpu_x509_signature_parts(der, len(der), *[ctypes.byref(x) for x in v], ctypes.byref(alg))
-    if rc != 0:
-        return None
-    return der[v[0].value:v[0].value + v[1].value], der[v[2].value:v[2].value + v[3].value], bool(alg.value)
-
-
-def x509_check_signature_batch(csp: "GPUCSP", certs: Sequence[bytes], issuer_keys: Sequence[Tuple[bytes, bytes]]) -> np.ndarray:
-    """fabgpu_csp_x509_check_signature_batch: crypto/x509 CheckSignatureFrom (the ECDSA part) for DER certificates under the given
-    issuer keys.  status per certificate: 0 valid, 1 verification failure, 5 signature does not parse, 6 crypto/x509 decides."""
-    n = len(certs)
-    arena, off = _ragged(certs)
-    qx = np.frombuffer(b"".join(k[0] for k in issuer_keys), dtype=np.uint8) if n else np.zeros(0, np.uint8)
-    qy = np.frombuffer(b"".join(k[1] for k in issuer_keys), dtype=np.uint8) if n else np.zeros(0, np.uint8)
-    st = np.zeros(n, dtype=np.uint8)
-    _check(csp._L.fabgpu_csp_x509_check_signature_batch(csp._h, n, _p8(arena), off.ctypes.data_as(_u32p), _p8(qx), _p8(qy), _p8(st)),
-           "fabgpu_csp_x509_check_signature_batch")
-    return st
 
 
 PASS_SEED_MEMO, PASS_NO_BLOCK_SIGS = 1, 2

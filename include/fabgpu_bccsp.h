@@ -230,20 +230,9 @@ int fabgpu_csp_idfix_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, si
 int fabgpu_csp_gate_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s);
 uint64_t fabgpu_identity_table_hash(const uint8_t* p, size_t len);
 
-/* ---- x509 certificate signatures in batch ----
- * crypto/x509 Certificate.CheckSignatureFrom(parent) - the ECDSA part - for n DER certificates (cert i = cert_arena[cert_off[i], cert_off[i+1]))
- * signed with ecdsa-with-SHA256 under P-256 issuer keys (issuer_qx / issuer_qy, n x 32): SHA-256 over the raw TBSCertificate fused ahead of
- * the verification, one launch.  This is what identity validation pays per chain link on an msp-cache miss (msp/mspimplvalidate.go:21-52,
- * msp/mspimpl.go:721-739; the cache holds 100 identities, msp/cache/cache.go:91-107) and the orderer's SigFilter for every new client
- * (orderer/common/msgprocessor/sigfilter.go:50-80).  x509 semantics, not bccsp/sw's: high-S signatures are valid, trailing bytes after
- * the signature SEQUENCE are not.  status[i]: 0 valid, 1 "x509: ECDSA verification failure", 5 signature does not parse / R, S <= 0,
- * 6 not decided here (other algorithm or curve, unparseable certificate): crypto/x509 decides.  Validity periods, constraints and chain
- * building stay in Go. */
-int fabgpu_csp_x509_check_signature_batch(fabgpu_csp* csp, size_t n, const uint8_t* cert_arena, const uint32_t* cert_off, const uint8_t* issuer_qx,
-                                          const uint8_t* issuer_qy, uint8_t* status);
-/* pure host: raw TBSCertificate and DER signature of a certificate (offsets into der); 1 = not a certificate */
-int fabgpu_x509_signature_parts(const uint8_t* der, size_t len, uint32_t* tbs_off, uint32_t* tbs_len, uint32_t* sig_off, uint32_t* sig_len, int* ecdsa_sha256);
-
+/* (An x509 chain-link batch - crypto/x509 CheckSignatureFrom for n certificates - was an entry point of rounds 2-4 WITHOUT a consumer:
+ * the only caller on this path is crypto/x509's own Verify (msp/mspimpl.go:721-739), which offers no hook for a pre-computed verdict, and
+ * using one as advice would have meant skipping or forking chain building, constraints and expiry.  Removed in round 5) */
 /* pure host helpers of the pass (no device): block structure, and the P-256 key of an x509 certificate */
 int fabgpu_block_parse(const uint8_t* block, size_t len, uint32_t* n_tx, uint32_t* n_tuples, uint32_t* n_prefixes, uint8_t* tx_type, uint32_t cap_tx,
                        char* channel_id, size_t channel_cap);
