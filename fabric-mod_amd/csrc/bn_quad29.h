@@ -238,11 +238,11 @@ struct bn_nym_quad_half {
     uint32_t early;
     bool dom;
 };
-__device__ __forceinline__ void bn_nym_quad_part1(bn_nym_quad_half& out, bool odd, bool half, const u256& nx, const u256& ny, const u256& c,
-                                                  const u256& s_sk, const u256& s_rnym, const int32_t* __restrict__ hsk,
-                                                  const int32_t* __restrict__ hrand, const PairBNQTab& qtab) {
-    jacbn N;
-    bn_nym_gates29(out.early, out.dom, N, nx, ny, c, s_sk, s_rnym);
+// This pair's fixed-base term: HSk * s_sk (pair 0) or HRand * s_rnym (pair 1) over the issuer's 8-bit comb tables - 32 mixed additions,
+// no doublings, no dependence on the signature's pseudonym.  Also runs on its own as idemix_nym_comb_quad_kernel, beside the
+// variable-base half (idemix_kernels.hip "three launches").
+__device__ __forceinline__ void bn_nym_quad_comb(pairbn_pt& S, bool& s_inf, bool odd, bool half, const u256& s_sk, const u256& s_rnym,
+                                                 const int32_t* __restrict__ hsk, const int32_t* __restrict__ hrand) {
     const int32_t* tab = half ? hrand : hsk;
     u256 sc;
     sel256(sc, half, s_rnym, s_sk);
@@ -250,11 +250,43 @@ __device__ __forceinline__ void bn_nym_quad_part1(bn_nym_quad_half& out, bool od
     fe_set_one(ONE);
     KeyTab8 t0{hsk};
     t0.load(0, 1u, gx, gy);
-    pairbn_pt seed, S, T;
+    pairbn_pt seed;
     seed.A = gx;
     fe_sel(seed.B, odd, ONE, gy);
-    bool s_inf, t_inf;
     pairbn_comb_mult(S, s_inf, sc, tab, seed, odd);
+}
+
+// The comb term as it travels from the comb launch to the commitment launch: 20 words per lane (A, B, s_inf, pad) = five uint4.
+constexpr int NYM_COMB_UINT4_PER_LANE = 5;
+__device__ __forceinline__ void bn_nym_comb_store(uint4* __restrict__ dst, const pairbn_pt& S, bool s_inf) {
+    dst[0] = make_uint4(S.A.v[0], S.A.v[1], S.A.v[2], S.A.v[3]);
+    dst[1] = make_uint4(S.A.v[4], S.A.v[5], S.A.v[6], S.A.v[7]);
+    dst[2] = make_uint4(S.A.v[8], S.B.v[0], S.B.v[1], S.B.v[2]);
+    dst[3] = make_uint4(S.B.v[3], S.B.v[4], S.B.v[5], S.B.v[6]);
+    dst[4] = make_uint4(S.B.v[7], S.B.v[8], s_inf ? 1u : 0u, 0u);
+}
+__device__ __forceinline__ void bn_nym_comb_load(const uint4* __restrict__ src, pairbn_pt& S, bool& s_inf) {
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+    S.A.v[0] = a.x; S.A.v[1] = a.y; S.A.v[2] = a.z; S.A.v[3] = a.w;
+    S.A.v[4] = b.x; S.A.v[5] = b.y; S.A.v[6] = b.z; S.A.v[7] = b.w;
+    S.A.v[8] = c.x; S.B.v[0] = c.y; S.B.v[1] = c.z; S.B.v[2] = c.w;
+    S.B.v[3] = d.x; S.B.v[4] = d.y; S.B.v[5] = d.z; S.B.v[6] = d.w;
+    S.B.v[7] = e.x; S.B.v[8] = e.y;
+    s_inf = e.z != 0u;
+}
+
+// comb_ready / comb_in: the comb launch's flag for this wavefront's rows and this lane's record (idemix_kernels.hip), or nullptr.  The
+// variable-base half runs first; THEN the comb term is taken from the comb launch if it has arrived (it runs beside this one and is a
+// quarter as long) - and computed here if it has not: the result is the same either way, only the time differs.
+__device__ __forceinline__ void bn_nym_quad_part1(bn_nym_quad_half& out, bool odd, bool half, const u256& nx, const u256& ny, const u256& c,
+                                                  const u256& s_sk, const u256& s_rnym, const int32_t* __restrict__ hsk,
+                                                  const int32_t* __restrict__ hrand, const PairBNQTab& qtab,
+                                                  const uint32_t* __restrict__ comb_ready = nullptr, const uint4* __restrict__ comb_in = nullptr) {
+    jacbn N;
+    bn_nym_gates29(out.early, out.dom, N, nx, ny, c, s_sk, s_rnym);
+    pairbn_pt S, T;
+    bool s_inf, t_inf;
+    if (comb_ready == nullptr) bn_nym_quad_comb(S, s_inf, odd, half, s_sk, s_rnym, hsk, hrand);
     // this pair's half of c * Nym
     u256 m1, m2, m;
     bool n1, n2;
@@ -269,6 +301,19 @@ __device__ __forceinline__ void bn_nym_quad_part1(bn_nym_quad_half& out, bool od
     // partial = S - (+-T): subtracting, so the Y of T (on E; O's B is Z) flips unless the half-scalar was negative
 #pragma unroll
     for (int l = 0; l < 9; l++) T.B.v[l] = (neg | odd) ? T.B.v[l] : -T.B.v[l];
+    if (comb_ready != nullptr) {
+        // has the comb launch delivered this wavefront's rows?  (one flag per wavefront, written behind its 64 records with release
+        // semantics; a few microseconds of patience, then the term is computed here)
+        uint32_t have = 0;
+#pragma unroll 1
+        for (int spin = 0; spin < 24 && !have; spin++) {
+            have = __hip_atomic_load(comb_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1u : 0u;
+            have = __builtin_amdgcn_readfirstlane(have);
+            if (!have) __builtin_amdgcn_s_sleep(64);
+        }
+        if (have) bn_nym_comb_load(comb_in, S, s_inf);
+        else bn_nym_quad_comb(S, s_inf, odd, half, s_sk, s_rnym, hsk, hrand);
+    }
     pairbn_final_add(out.P, out.inf, S, s_inf, T, t_inf, odd);
 }
 

@@ -90,6 +90,7 @@ struct fabgpu_ctx {
     int device = 0;
     bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
     bool allow_quad = true;   // !FABGPU_FLAG_NO_QUAD (idemix: four lanes per signature for batches <= IDEMIX_QUAD_MAX)
+    bool nym_side_stream = true; // !FABGPU_FLAG_NYM_NO_SIDE_STREAM (idemix four-lane form: the fixed-base terms on a second stream beside the commitments)
     bool nym_two_phase = true;   // !FABGPU_FLAG_NYM_FUSED_HASH (idemix four-lane form: commitments, then challenges with eight lanes on a message)
     bool allow_wide = true;   // !FABGPU_FLAG_NO_WIDE (registered keys: eight lanes per signature in two phases for launches <= WIDE_LAUNCH_MAX)
     int pair_table_lds = -1;       // the verify-only pair kernel's per-signature table: 1 in LDS, 0 in the global workspace, -1 by batch size (kernels.h)
@@ -117,6 +118,7 @@ struct fabgpu_ctx {
         hipEvent_t done = nullptr;
         bool reserved = false;   // handed to a launch that has not recorded `done` yet
         bool armed = false;      // `done` was recorded behind the launch that used it
+        NymSide nym_side;             // idemix four-lane form: the side stream of the fixed-base launch and its fork / join events (made on first use)
         hipStream_t last = nullptr;   // the stream of that launch: a later launch on the SAME stream runs behind it anyway and may
                                       // take the workspace without waiting (20 queued steps of a bench loop used to mean 20 workspaces
                                       // of 61 MB each, allocated inside the timed region)
@@ -289,7 +291,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!out) return FABGPU_EINVAL;
     *out = nullptr;
     if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS | FABGPU_FLAG_NO_QUAD | FABGPU_FLAG_PAIR_TABLE_LDS |
-                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL | FABGPU_FLAG_NO_WIDE | FABGPU_FLAG_NYM_FUSED_HASH)) != 0) return FABGPU_EINVAL;
+                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL | FABGPU_FLAG_NO_WIDE | FABGPU_FLAG_NYM_FUSED_HASH | FABGPU_FLAG_NYM_NO_SIDE_STREAM)) != 0) return FABGPU_EINVAL;
     if (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL)) return FABGPU_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
@@ -308,6 +310,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     ctx->allow_pair = !(cfg && (cfg->flags & FABGPU_FLAG_ONE_LANE_ONLY));
     ctx->allow_quad = !(cfg && (cfg->flags & FABGPU_FLAG_NO_QUAD));
     ctx->nym_two_phase = !(cfg && (cfg->flags & FABGPU_FLAG_NYM_FUSED_HASH));
+    ctx->nym_side_stream = !(cfg && (cfg->flags & FABGPU_FLAG_NYM_NO_SIDE_STREAM));
     // (the wide form is built from the two-lane form's reasons: a context that may not use two lanes per signature does not use eight)
     ctx->allow_wide = ctx->allow_pair && !(cfg && (cfg->flags & FABGPU_FLAG_NO_WIDE));
     ctx->pair_table_lds = cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) ? 1 : (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL) ? 0 : pair_table_default());
@@ -400,6 +403,9 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
             if (w.done) hipEventDestroy(w.done);
+            if (w.nym_side.stream) { hipStreamSynchronize(w.nym_side.stream); hipStreamDestroy(w.nym_side.stream); }
+            if (w.nym_side.fork) hipEventDestroy(w.nym_side.fork);
+            if (w.nym_side.join) hipEventDestroy(w.nym_side.join);
         }
         if (ctx->ev0) hipEventDestroy(ctx->ev0);
         if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -566,11 +572,28 @@ static int nym_verify_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t a
     void* wsp = nullptr;
     int rc = ctx->acquire_qws(idemix_workspace_bytes((uint32_t)n, ctx->allow_pair, ctx->allow_quad), &wi, &wsp, st);
     if (rc != FABGPU_OK) return rc;
+    // the side stream of this workspace slot (the slot is ours until release_qws: nobody else touches its entry)
+    NymSide side;
+    if (ctx->nym_two_phase && ctx->nym_side_stream) {
+        std::lock_guard<std::mutex> lk(ctx->qmu);
+        NymSide& sd = ctx->qws[wi].nym_side;
+        if (!sd.stream) {
+            NymSide made;
+            if (hipStreamCreateWithFlags(&made.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&made.fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&made.join, hipEventDisableTiming) == hipSuccess)
+                sd = made;
+            else {
+                if (made.fork) hipEventDestroy(made.fork);
+                if (made.stream) hipStreamDestroy(made.stream);
+            }
+        }
+        side = sd;
+    }
     timed = timed && ctx->time_kernels;
     if (timed) hipEventRecord(ctx->ev0, st);
     hipError_t err = launch_idemix_nym_verify((uint32_t)n, arena, arena_bytes, off, issuer_id, issuers, n_issuers, nym_x, nym_y, proof_c,
                                               proof_s_sk, proof_s_r_nym, nonce, wsp, verdict_bits, status, ctx->allow_pair, ctx->allow_quad, spans, st, gather, lds_reserve,
-                                              ctx->nym_two_phase);
+                                              ctx->nym_two_phase, side.stream ? &side : nullptr);
     if (timed) hipEventRecord(ctx->ev1, st);
     ctx->release_qws(wi, st);
     if (timed) ctx->timed = true;

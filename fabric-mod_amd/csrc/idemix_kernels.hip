@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(BLOCK, FUSED ? 2 : 1)
                                   const uint8_t* __restrict__ nym_x, const uint8_t* __restrict__ nym_y, const uint8_t* __restrict__ proof_c,
                                   const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
                                   uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status,
-                             const uint32_t* __restrict__ gather, uint32_t* __restrict__ hdr_out, uint8_t* __restrict__ st_out) {
+                             const uint32_t* __restrict__ gather, uint32_t* __restrict__ hdr_out, uint8_t* __restrict__ st_out,
+                             const uint32_t* __restrict__ comb_flags, const uint4* __restrict__ comb_rec) {
     // one table per PAIR: BLOCK / 2 of them in this workgroup's slot
     PairBNQTab qtab = PairBNQTab::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * (BLOCK / 2)), threadIdx.x >> 1);
     constexpr uint32_t PER_WG = BLOCK / 4;
@@ -264,7 +265,11 @@ __global__ void __launch_bounds__(BLOCK, FUSED ? 2 : 1)
         load_be_field(srn, s_rnym, ic);
         load_be_field(nn, nonce, ic);
         bn_nym_quad_half mine;
-        bn_nym_quad_part1(mine, odd, half, nx, ny, c, ssk, srn, id->hsk, id->hrand, qtab);
+        // (comb_flags: the fixed-base terms come from idemix_nym_comb_quad_kernel, launched beside this one - one flag per wavefront of
+        //  a tile, one 80-byte record per lane; nullptr: computed here)
+        bn_nym_quad_part1(mine, odd, half, nx, ny, c, ssk, srn, id->hsk, id->hrand, qtab,
+                          comb_flags != nullptr ? comb_flags + (size_t)tile * (BLOCK / 64) + (threadIdx.x >> 6) : nullptr,
+                          comb_rec != nullptr ? comb_rec + ((size_t)tile * BLOCK + threadIdx.x) * NYM_COMB_UINT4_PER_LANE : nullptr);
         uint32_t st = bn_nym_quad_part2(tx, ty, mine, odd);
         uint32_t ih[8];
 #pragma unroll
@@ -297,6 +302,44 @@ __global__ void __launch_bounds__(BLOCK, FUSED ? 2 : 1)
         const uint32_t i0 = tile * PER_WG + ((threadIdx.x & ~63u) >> 2);       // first signature of this wave: a multiple of 16
         if ((threadIdx.x & 63u) == 0 && (i0 >> 6) < nwords) verdict16[i0 >> 4] = (uint16_t)x;   // every 16-bit part of every word has an owner
         if (status != nullptr && active && lead) status[i] = (uint8_t)st;
+    }
+}
+
+// The fixed-base half of the commitments on its own (round 5, "three launches"): HSk * s_sk and HRand * s_rnym need nothing of the
+// pseudonym, are a quarter of the commitment kernel's stream (32 mixed additions of 135 doublings + 27 additions + a table), and 6 000
+// signatures leave 650 of 1 024 SIMDs idle - so this kernel runs BESIDE idemix_nym_verify_quad_kernel<.., false> on a second stream,
+// same geometry (tile, lane) -> same rows, and leaves per lane the pair state of its term (80 bytes) and per wavefront a flag, written
+// behind the wavefront's records with release semantics.  The commitment kernel picks the records up after its variable-base half if
+// the flag is there, and computes the term itself if it is not (a chip busy with other launches): same bits either way.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2)
+    idemix_nym_comb_quad_kernel(uint32_t n, const uint32_t* __restrict__ issuer_id, const IssuerDev* __restrict__ issuers, uint32_t n_issuers,
+                                const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint32_t* __restrict__ gather,
+                                uint32_t* __restrict__ comb_flags, uint4* __restrict__ comb_rec) {
+    constexpr uint32_t PER_WG = BLOCK / 4;
+    const uint32_t ntiles = (n + PER_WG - 1) / PER_WG;
+    const bool odd = (threadIdx.x & 1u) != 0;
+    const bool half = (threadIdx.x & 2u) != 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t i = tile * PER_WG + (threadIdx.x >> 2);
+        bool active = i < n;
+        uint32_t ic = active ? i : (n - 1);
+        if (gather != nullptr) {
+            const uint32_t g = gather[ic];
+            ic = g != 0xFFFFFFFFu ? g : 0u;
+        }
+        const uint32_t iss = issuer_id != nullptr ? issuer_id[ic] : 0u;
+        const IssuerDev* id = issuers + (iss < n_issuers ? iss : 0u);
+        u256 ssk, srn;
+        load_be_field(ssk, s_sk, ic);
+        load_be_field(srn, s_rnym, ic);
+        pairbn_pt S;
+        bool s_inf;
+        bn_nym_quad_comb(S, s_inf, odd, half, ssk, srn, id->hsk, id->hrand);
+        bn_nym_comb_store(comb_rec + ((size_t)tile * BLOCK + threadIdx.x) * NYM_COMB_UINT4_PER_LANE, S, s_inf);
+        // the wavefront's 64 records first, then its flag (a release store waits for the wavefront's outstanding stores)
+        if ((threadIdx.x & 63u) == 0)
+            __hip_atomic_store(comb_flags + (size_t)tile * (BLOCK / 64) + (threadIdx.x >> 6), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -359,7 +402,9 @@ static size_t idemix_quad_tables_bytes(uint32_t n) { return (size_t)idemix_quad_
 static size_t idemix_rows(uint32_t n) { return ((size_t)n + 63) / 64 * 64; }
 size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad) {
     // four-lane form: the pairs' tables | two-phase form: + 192 bytes of header and one status byte per launch row
-    if (idemix_quad(n, allow_split, allow_quad)) return idemix_quad_tables_bytes(n) + idemix_rows(n) * (NYM_HDR_WORDS * 4 + 1) + 256;
+    // (+ the comb launch's records, 80 bytes per lane = 320 per row, and one flag per wavefront)
+    if (idemix_quad(n, allow_split, allow_quad))
+        return idemix_quad_tables_bytes(n) + idemix_rows(n) * (NYM_HDR_WORDS * 4 + 1 + 4 * NYM_COMB_UINT4_PER_LANE * 16) + idemix_rows(n) / 16 * 4 + 1024;
     VerifyGeom g = verify_geom(n, allow_split);
     return (size_t)g.wgs * g.block * QWS_UINT4_PER_LANE * 16;
 }
@@ -367,7 +412,7 @@ size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad) {
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
-                                    bool allow_quad, bool spans, hipStream_t st, const void* gather, uint32_t lds_reserve, bool two_phase) {
+                                    bool allow_quad, bool spans, hipStream_t st, const void* gather, uint32_t lds_reserve, bool two_phase, const NymSide* side) {
     if (n == 0) return hipSuccess;
     if (idemix_quad(n, allow_split, allow_quad)) {                             // four lanes per signature: 64 signatures per workgroup
         dim3 qgrid(idemix_quad_wgs(n)), qblock(VERIFY_BLOCK);
@@ -375,17 +420,42 @@ hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_
             hipLaunchKernelGGL((idemix_nym_verify_quad_kernel<VERIFY_BLOCK, true>), qgrid, qblock, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                                (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                                (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
-                               (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, (uint32_t*)nullptr, (uint8_t*)nullptr);
+                               (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, (uint32_t*)nullptr, (uint8_t*)nullptr,
+                               (const uint32_t*)nullptr, (const uint4*)nullptr);
             return hipGetLastError();
         }
-        // two phases: the commitments (four lanes per signature), then the challenges (eight lanes per message) on the same stream
+        // three launches: the fixed-base terms on the side stream BESIDE the commitments (four lanes per signature each), then the
+        // challenges (eight lanes per message) - the last two on the caller's stream
         uint8_t* ws = (uint8_t*)qws;
         uint32_t* hdr = (uint32_t*)(ws + ((idemix_quad_tables_bytes(n) + 255) & ~(size_t)255));
         uint8_t* st_tmp = (uint8_t*)hdr + idemix_rows(n) * (NYM_HDR_WORDS * 4);
+        uint4* comb_rec = nullptr;
+        uint32_t* comb_flags = nullptr;
+        bool joined = true;
+        if (side != nullptr && side->stream != nullptr) {
+            uint4* rec = (uint4*)(((uintptr_t)(st_tmp + idemix_rows(n)) + 255) & ~(uintptr_t)255);
+            uint32_t* flags = (uint32_t*)(rec + idemix_rows(n) * 4 * NYM_COMB_UINT4_PER_LANE);
+            // flags to zero in stream order, the side stream behind them; any failure on the way: the commitment kernel simply does it all
+            if (hipMemsetAsync(flags, 0, idemix_rows(n) / 16 * 4, st) == hipSuccess && hipEventRecord(side->fork, st) == hipSuccess &&
+                hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
+                hipLaunchKernelGGL(idemix_nym_comb_quad_kernel<VERIFY_BLOCK>, qgrid, qblock, 0, side->stream, n, (const uint32_t*)issuer_id, (const IssuerDev*)issuers,
+                                   n_issuers, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint32_t*)gather, flags, rec);
+                const hipError_t ke = hipGetLastError();
+                // (the caller's stream must not run past this call's kernels before the side launch is through with the workspace)
+                joined = hipEventRecord(side->join, side->stream) == hipSuccess;
+                if (ke == hipSuccess) {
+                    comb_rec = rec;
+                    comb_flags = flags;
+                }
+                if (!joined) hipStreamSynchronize(side->stream);
+            }
+        }
         hipLaunchKernelGGL((idemix_nym_verify_quad_kernel<VERIFY_BLOCK, false>), qgrid, qblock, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
                            (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                            (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
-                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, hdr, st_tmp);
+                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, hdr, st_tmp, (const uint32_t*)comb_flags,
+                           (const uint4*)comb_rec);
+        if (comb_flags != nullptr && joined && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) hipStreamSynchronize(side->stream);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         constexpr int W = 4;
@@ -417,7 +487,7 @@ int warm_kernel_functions_idemix() {
     hipFuncAttributes a;
     const void* fns[] = {(const void*)idemix_nym_verify_kernel<VERIFY_BLOCK>, (const void*)idemix_nym_verify_split_kernel<VERIFY_BLOCK>,
                          (const void*)idemix_nym_verify_quad_kernel<VERIFY_BLOCK, true>, (const void*)idemix_nym_verify_quad_kernel<VERIFY_BLOCK, false>,
-                         (const void*)idemix_nym_challenge_coop_kernel<4>};
+                         (const void*)idemix_nym_challenge_coop_kernel<4>, (const void*)idemix_nym_comb_quad_kernel<VERIFY_BLOCK>};
     for (const void* f : fns) ok += hipFuncGetAttributes(&a, f) == hipSuccess ? 1 : 0;
     return ok;
 }

@@ -96,13 +96,20 @@ void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hr
 // one signature per lane; (allow_split and n <= VERIFY_PAIR_MAX) two lanes per signature; (allow_split, allow_quad and
 // n <= IDEMIX_QUAD_MAX) four lanes per signature, every point operation on a lane pair; workspace: idemix_workspace_bytes
 constexpr int IDEMIX_QUAD_MAX = 16384;     // 256 workgroups x 64 signatures: one round of the chip
+// a second stream for the fixed-base terms of the four-lane form (idemix_nym_comb_quad_kernel runs beside the commitment kernel) and the
+// two events that fork it off the caller's stream and join it again; owned by the caller (fabgpu_ctx keeps one per workspace slot)
+struct NymSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
                                     const void* s_rnym, const void* nonce, void* qws, void* verdict_bits, void* status, bool allow_split,
                                     bool allow_quad, bool spans, hipStream_t st,    // spans: off = n x (start, end) instead of n + 1 running offsets
                                     const void* gather = nullptr,                 // gather: row i takes its inputs from row gather[i] (uint32; ~0 = an idle row)
                                     uint32_t lds_reserve = 0,                     // unused LDS asked for: keeps other reserving kernels off this one's CUs
-                                    bool two_phase = true);                       // four-lane form: commitments, then the challenges with eight lanes on a message
+                                    bool two_phase = true,                        // four-lane form: commitments, then the challenges with eight lanes on a message
+                                    const NymSide* side = nullptr);               // ... and the fixed-base terms beside the commitments on this stream
 // every LANE owns a 16-entry table in the one- and two-lane geometries, every lane PAIR in the four-lane one
 size_t idemix_workspace_bytes(uint32_t n, bool allow_split, bool allow_quad);
 // every kernel function of a translation unit resolved now instead of at its first launch (GPUCSP::Preallocate); returns how many

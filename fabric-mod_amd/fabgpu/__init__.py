@@ -28,6 +28,7 @@ FABGPU_OK = 0
 FABGPU_EINVAL = -1
 FLAG_ONE_LANE_ONLY = 1   # fabgpu.h FABGPU_FLAG_ONE_LANE_ONLY
 FLAG_TIME_KERNELS = 2    # fabgpu.h FABGPU_FLAG_TIME_KERNELS
+FLAG_NYM_NO_SIDE_STREAM = 128  # fabgpu.h FABGPU_FLAG_NYM_NO_SIDE_STREAM (idemix four-lane form: fixed-base terms inside the commitment kernel)
 FLAG_NYM_FUSED_HASH = 64  # fabgpu.h FABGPU_FLAG_NYM_FUSED_HASH (idemix four-lane form: the challenge hashed inside the same kernel, round 4's form)
 FLAG_NO_QUAD = 4         # fabgpu.h FABGPU_FLAG_NO_QUAD (idemix: never the four-lanes-per-signature kernel)
 FLAG_PAIR_TABLE_LDS = 8      # fabgpu.h: the verify-only pair kernel keeps its per-signature table in LDS

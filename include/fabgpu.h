@@ -73,6 +73,8 @@ typedef struct fabgpu_ctx fabgpu_ctx;
 
 #define FABGPU_FLAG_NYM_FUSED_HASH 64u   /* idemix, four-lanes-per-signature form: hash the challenge on one lane of four inside the same kernel (round 4's
                                             form) instead of a second launch with eight lanes on a message (parity tests run both forms) */
+#define FABGPU_FLAG_NYM_NO_SIDE_STREAM 128u /* idemix, four-lanes-per-signature form: compute the fixed-base terms inside the commitment kernel instead of
+                                            a launch of their own on a second stream beside it (parity tests run both forms) */
 
 typedef struct fabgpu_cfg {
     int32_t device;      /* HIP device ordinal; -1 = the current device */

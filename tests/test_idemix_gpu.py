@@ -12,14 +12,15 @@ from idemix_common import be32, fixtures, make_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "four-lanes-fused", "two-lanes", "one-lane"])
+@pytest.fixture(scope="module", params=["auto", "four-lanes-one-stream", "four-lanes-fused", "two-lanes", "one-lane"])
 def env(request):
     """auto: batches up to 16 384 run on the four-lanes-per-signature kernel (bn_quad29.h), up to 32 768 on the two-lanes one, larger
     ones on the one-lane kernel; two-lanes = FABGPU_FLAG_NO_QUAD, one-lane = FABGPU_FLAG_ONE_LANE_ONLY.  The four-lane form runs in two
     phases since round 5 (commitments, then the challenges with eight lanes on a message); four-lanes-fused =
-    FABGPU_FLAG_NYM_FUSED_HASH is round 4's single kernel.  Every case goes through all four."""
+    FABGPU_FLAG_NYM_FUSED_HASH is round 4's single kernel; by default the fixed-base terms run as a launch of their own on a second stream
+    beside the commitments, four-lanes-one-stream = FABGPU_FLAG_NYM_NO_SIDE_STREAM keeps them inside.  Every case goes through all five."""
     fx = fixtures()
-    extra = {"auto": 0, "four-lanes-fused": fabgpu.FLAG_NYM_FUSED_HASH, "two-lanes": fabgpu.FLAG_NO_QUAD, "one-lane": fabgpu.FLAG_ONE_LANE_ONLY}[request.param]
+    extra = {"auto": 0, "four-lanes-one-stream": fabgpu.FLAG_NYM_NO_SIDE_STREAM, "four-lanes-fused": fabgpu.FLAG_NYM_FUSED_HASH, "two-lanes": fabgpu.FLAG_NO_QUAD, "one-lane": fabgpu.FLAG_ONE_LANE_ONLY}[request.param]
     ctx = fabgpu.Context(device=0, flags=fabgpu.FLAG_TIME_KERNELS | extra)
     issuers = []
     for name in ("MSP1OU1", "MSP2OU1"):

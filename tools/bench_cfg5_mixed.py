@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=12, help="untimed launches per timed leg (the chip needs ~10 ms of work to leave its idle clocks)")
     ap.add_argument("--no-quad", action="store_true", help="FABGPU_FLAG_NO_QUAD: the idemix share on the two-lanes-per-signature kernel (A/B)")
     ap.add_argument("--fused-hash", action="store_true", help="FABGPU_FLAG_NYM_FUSED_HASH: round 4's single four-lane kernel instead of the two phases (A/B)")
+    ap.add_argument("--no-side-stream", action="store_true", help="FABGPU_FLAG_NYM_NO_SIDE_STREAM: the fixed-base terms inside the commitment kernel (A/B)")
     ap.add_argument("--base", type=int, default=192, help="distinct oracle-signed pseudonym signatures that the batch replicates")
     args = ap.parse_args()
     import random
@@ -37,7 +38,7 @@ def main():
 
     fx = fixtures()
     ctx = fabgpu.Context(device=0, max_batch=args.n, flags=fabgpu.FLAG_TIME_KERNELS | (fabgpu.FLAG_NO_QUAD if args.no_quad else 0) |
-                         (fabgpu.FLAG_NYM_FUSED_HASH if args.fused_hash else 0))
+                         (fabgpu.FLAG_NYM_FUSED_HASH if args.fused_hash else 0) | (fabgpu.FLAG_NYM_NO_SIDE_STREAM if args.no_side_stream else 0))
     issuers = []
     t0 = time.perf_counter()
     for name in ("MSP1OU1", "MSP2OU1"):
