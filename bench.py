@@ -479,14 +479,15 @@ def mixed_cfg4_leg(torch, np, fabgpu, coracle, steps=20, n=30000, msg_len=4608, 
         peak = mac_peak or VALU_PEAK_MAC
         out.update({"idemix_alone": {"n": n_nym, "verifies_per_s": n_nym / dt_nym, "ms_per_step": dt_nym * 1e3},
                     "ecdsa_alone": {"n": n_ec, "verifies_per_s": n_ec / dt_ec, "ms_per_step": dt_ec * 1e3},
-                    "roofline": {"bound": "valu-mac", "kernel": "idemix_nym_verify_quad_kernel<256> (four lanes per signature)", "kernel_ms": k_s * 1e3,
+                    "roofline": {"bound": "valu-mac", "kernel": "idemix_nym_verify_quad_kernel<256,false> + idemix_nym_comb_quad_kernel<256> beside it + idemix_nym_challenge_coop_kernel<4> (the whole call)", "kernel_ms": k_s * 1e3,
                                  "achieved": n_nym / k_s * MAC_PER_NYM_VERIFY, "peak": peak, "unit": "MAC/s", "frac": n_nym / k_s * MAC_PER_NYM_VERIFY / peak,
                                  "traffic": None, "mac_per_verify": MAC_PER_NYM_VERIFY, "executed_mac_per_verify": EXECUTED_MAC_PER_NYM_VERIFY,
                                  "executed_frac": n_nym / k_s * EXECUTED_MAC_PER_NYM_VERIFY / peak,
                                  "model": "achieved = %d pseudonym signatures x 3.7e5 u32 MACs (2 678 field multiplications of NymSignature.Ver x 136: 8 x 8 limb product + word-by-word "
-                                          "Montgomery reduction of an unstructured prime) / the nym kernel's own launch duration (HIP events on its stream); peak = the sustained v_mad_i64_i32 "
-                                          "ceiling measured in this run.  6 000 signatures on four lanes each are 375 wavefronts for 1 024 SIMDs: the launch is latency-bound - its time is one "
-                                          "wavefront's instruction stream (DESIGN.md 4.5), a quarter of it the two SHA-256 over the 4.6 KB message" % n_nym},
+                                          "Montgomery reduction of an unstructured prime) / the duration of the call's three launches (HIP events on its stream: the commitments on four lanes per "
+                                          "signature with the fixed-base terms on a side stream beside them, then the challenges on eight lanes per message); peak = the sustained v_mad_i64_i32 "
+                                          "ceiling measured in this run.  6 000 signatures are 376 + 376 + 752 wavefronts for 1 024 SIMDs: latency-bound - the time is the serial chain of ONE "
+                                          "signature (135 doublings, 27 additions and a 16-entry table on a lane pair, two final additions, an inversion, 75 SHA-256 blocks; DESIGN.md 4.5)" % n_nym},
                     "mixed_step_over_the_longer_kernel": dt_mix / max(dt_nym, dt_ec)})
     return out
 
