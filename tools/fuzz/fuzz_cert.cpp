@@ -6,6 +6,7 @@
 #include <string>
 #include "block_prepass.h"
 #include "bccsp_host.h"
+#include "idemix_host.h"
 using namespace fab::bccsp;
 int main() {
     FILE* f = fopen("/tmp/cert.pem", "rb");
@@ -74,5 +75,36 @@ int main() {
             free(hp);
         }
     }
+    // idemix issuer keys (round 5): the canonical-encoding gate and the field extraction on mutants of a reference key, exact-size copies
+    size_t canon = 0, fields = 0;
+    if (FILE* fi = fopen("/tmp/ipk.bin", "rb")) {
+        std::vector<uint8_t> ipk(1 << 16);
+        ipk.resize(fread(ipk.data(), 1, ipk.size(), fi));
+        fclose(fi);
+        if (!IdemixCSP::IssuerKeyEncodingIsCanonical(ipk.data(), ipk.size())) { printf("THE REFERENCE'S OWN ISSUER KEY IS NOT CANONICAL\n"); return 1; }
+        for (int it = 0; it < 200000; it++) {
+            std::vector<uint8_t> d = ipk;
+            const int k = 1 + (int)(rng() % 4);
+            for (int j = 0; j < k; j++) {
+                const size_t pos = rng() % d.size();
+                switch (rng() % 5) {
+                    case 0: d[pos] ^= (uint8_t)(1u << (rng() % 8)); break;
+                    case 1: d[pos] = (uint8_t)rng(); break;
+                    case 2: d[pos] = 0x80; break;                      // padded varints
+                    case 3: d.insert(d.begin() + (long)pos, (uint8_t)rng()); break;
+                    default: if (d.size() > 8) d.resize(d.size() - rng() % 8); break;
+                }
+            }
+            uint8_t* hp = (uint8_t*)malloc(d.size() ? d.size() : 1);
+            memcpy(hp, d.data(), d.size());
+            IdemixIssuerPublicKey out;
+            const bool c = IdemixCSP::IssuerKeyEncodingIsCanonical(hp, d.size());
+            const bool fl = IdemixCSP::IssuerKeyFields(hp, d.size(), out);
+            canon += c;
+            fields += fl;
+            free(hp);
+        }
+    }
+    printf("issuer keys: %zu of 200000 mutants still canonical, %zu still yield HSk / HRand / Hash\n", canon, fields);
     printf("fuzz ok: %zu mutants still gave a P-256 key, %zu signature slices unmarshalled, %zu window walks asked for more bytes\n", ok, sigok, windowed);
 }

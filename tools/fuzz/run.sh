@@ -42,6 +42,7 @@ meta0 = bb.fbytes(1, b"\x0a\x02\x08\x05") + msig(0) + msig(1)
 blk = bb.fbytes(1, hdr) + bb.fbytes(2, b"".join(bb.fbytes(1, e) for e in envs)) + bb.fbytes(3, bb.fbytes(1, meta0) + bb.fbytes(1, b"") + bb.fbytes(1, b"\x00" * 40))
 open("/tmp/blk_small.bin", "wb").write(blk)
 open("/tmp/cert.pem", "w").write(ids[0]["pem"])
+open("/tmp/ipk.bin", "wb").write(bytes.fromhex(json.load(open(ROOT + "/tests/golden/idemix_fixtures.json"))["msps"]["MSP1OU1"]["ipk"]))
 PY
 $CXX $FLAGS tools/fuzz/fuzz_walk.cpp $SRC/block_prepass.cpp $SRC/idemix_host.cpp tools/fuzz/stubs.cpp -o /tmp/fuzz_walk -lpthread
 $CXX $FLAGS tools/fuzz/fuzz_cert.cpp $SRC/block_prepass.cpp $SRC/bccsp_host.cpp $SRC/idemix_host.cpp tools/fuzz/stubs.cpp -o /tmp/fuzz_cert -lpthread
