@@ -138,7 +138,8 @@ bool rccl_self_check(fabgpu_multi* m, std::string* why) {
             ok = hipSetDevice(ord) == hipSuccess && hipMalloc((void**)&d_one[(size_t)g], 8) == hipSuccess &&
                  hipMalloc((void**)&d_all[(size_t)g], 8 * (size_t)G) == hipSuccess &&
                  hipMemcpy(d_one[(size_t)g], &word, 8, hipMemcpyHostToDevice) == hipSuccess &&
-                 hipMemset(d_all[(size_t)g], 0, 8 * (size_t)G) == hipSuccess;
+                 hipMemset(d_all[(size_t)g], 0, 8 * (size_t)G) == hipSuccess &&
+                 hipDeviceSynchronize() == hipSuccess;   // (the shards' streams are non-blocking: nothing orders them behind the null stream's memset / copy)
             if (!ok) w = "self-check: device memory";
         }
         if (ok) {

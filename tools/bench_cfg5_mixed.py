@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--no-quad", action="store_true", help="FABGPU_FLAG_NO_QUAD: the idemix share on the two-lanes-per-signature kernel (A/B)")
     ap.add_argument("--fused-hash", action="store_true", help="FABGPU_FLAG_NYM_FUSED_HASH: round 4's single four-lane kernel instead of the two phases (A/B)")
     ap.add_argument("--no-side-stream", action="store_true", help="FABGPU_FLAG_NYM_NO_SIDE_STREAM: the fixed-base terms inside the commitment kernel (A/B)")
+    ap.add_argument("--prio", default="", help="stream priorities 'ec,nym' (e.g. -1,0: the ECDSA stream high; HIP: lower number = higher priority) - exploration")
     ap.add_argument("--base", type=int, default=192, help="distinct oracle-signed pseudonym signatures that the batch replicates")
     args = ap.parse_args()
     import random
@@ -81,7 +82,11 @@ def main():
     d_words_ec = torch.zeros((n_ec + 63) // 64, dtype=torch.int64, device="cuda")
     want_ec = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"]) == 0
 
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    if args.prio:
+        p1, p2 = [int(x) for x in args.prio.split(",")]
+        s1, s2 = torch.cuda.Stream(priority=p1), torch.cuda.Stream(priority=p2)
+    else:
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 
     def step_nym(st):
         ctx.idemix_nym_verify_batch_dev(n_nym, d_arena.data_ptr(), d_arena.numel(), d_off.data_ptr(), d_iid.data_ptr(), *[c.data_ptr() for c in d_cols],
