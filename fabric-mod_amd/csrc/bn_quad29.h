@@ -281,7 +281,7 @@ __device__ __forceinline__ void bn_nym_comb_load(const uint4* __restrict__ src, 
 __device__ __forceinline__ void bn_nym_quad_part1(bn_nym_quad_half& out, bool odd, bool half, const u256& nx, const u256& ny, const u256& c,
                                                   const u256& s_sk, const u256& s_rnym, const int32_t* __restrict__ hsk,
                                                   const int32_t* __restrict__ hrand, const PairBNQTab& qtab,
-                                                  const uint32_t* __restrict__ comb_ready = nullptr, const uint4* __restrict__ comb_in = nullptr) {
+                                                  uint32_t* __restrict__ comb_ready = nullptr, const uint4* __restrict__ comb_in = nullptr) {
     jacbn N;
     bn_nym_gates29(out.early, out.dom, N, nx, ny, c, s_sk, s_rnym);
     pairbn_pt S, T;
@@ -310,6 +310,15 @@ __device__ __forceinline__ void bn_nym_quad_part1(bn_nym_quad_half& out, bool od
             have = __hip_atomic_load(comb_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1u : 0u;
             have = __builtin_amdgcn_readfirstlane(have);
             if (!have) __builtin_amdgcn_s_sleep(64);
+        }
+        if (!have) {
+            // giving up: say so (0 -> 2), so that a comb launch that has not started this wavefront's rows yet skips them instead of
+            // making the caller's stream wait for work nobody will read; if the records arrived this very moment (the exchange finds 1)
+            // they are taken after all
+            uint32_t old = 0;
+            if ((threadIdx.x & 63u) == 0) old = atomicCAS(comb_ready, 0u, 2u);
+            have = __builtin_amdgcn_readfirstlane(old) == 1u ? 1u : 0u;
+            if (have) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         if (have) bn_nym_comb_load(comb_in, S, s_inf);
         else bn_nym_quad_comb(S, s_inf, odd, half, s_sk, s_rnym, hsk, hrand);

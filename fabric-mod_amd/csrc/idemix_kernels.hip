@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(BLOCK, FUSED ? 2 : 1)
                                   const uint8_t* __restrict__ s_sk, const uint8_t* __restrict__ s_rnym, const uint8_t* __restrict__ nonce,
                                   uint4* __restrict__ qws, uint64_t* __restrict__ verdict_bits, uint8_t* __restrict__ status,
                              const uint32_t* __restrict__ gather, uint32_t* __restrict__ hdr_out, uint8_t* __restrict__ st_out,
-                             const uint32_t* __restrict__ comb_flags, const uint4* __restrict__ comb_rec) {
+                             uint32_t* __restrict__ comb_flags, const uint4* __restrict__ comb_rec) {
     // one table per PAIR: BLOCK / 2 of them in this workgroup's slot
     PairBNQTab qtab = PairBNQTab::of(qws + (size_t)blockIdx.x * (QWS_UINT4_PER_LANE * (BLOCK / 2)), threadIdx.x >> 1);
     constexpr uint32_t PER_WG = BLOCK / 4;
@@ -321,6 +321,9 @@ __global__ void __launch_bounds__(BLOCK, 2)
     const bool odd = (threadIdx.x & 1u) != 0;
     const bool half = (threadIdx.x & 2u) != 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t* flag = comb_flags + (size_t)tile * (BLOCK / 64) + (threadIdx.x >> 6);
+        // the commitment kernel has already given up on this wavefront's rows (it computed them itself): nothing to do
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 2u) continue;
         uint32_t i = tile * PER_WG + (threadIdx.x >> 2);
         bool active = i < n;
         uint32_t ic = active ? i : (n - 1);
@@ -337,9 +340,12 @@ __global__ void __launch_bounds__(BLOCK, 2)
         bool s_inf;
         bn_nym_quad_comb(S, s_inf, odd, half, ssk, srn, id->hsk, id->hrand);
         bn_nym_comb_store(comb_rec + ((size_t)tile * BLOCK + threadIdx.x) * NYM_COMB_UINT4_PER_LANE, S, s_inf);
-        // the wavefront's 64 records first, then its flag (a release store waits for the wavefront's outstanding stores)
-        if ((threadIdx.x & 63u) == 0)
-            __hip_atomic_store(comb_flags + (size_t)tile * (BLOCK / 64) + (threadIdx.x >> 6), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // the wavefront's 64 records first, then its flag: 0 -> 1 with release semantics (the release waits for the wavefront's outstanding
+        // stores); a 2 that arrived meanwhile stays (the records are simply not read)
+        if ((threadIdx.x & 63u) == 0) {
+            uint32_t expect = 0u;
+            __hip_atomic_compare_exchange_strong(flag, &expect, 1u, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -421,7 +427,7 @@ hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_
                                (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
                                (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
                                (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, (uint32_t*)nullptr, (uint8_t*)nullptr,
-                               (const uint32_t*)nullptr, (const uint4*)nullptr);
+                               (uint32_t*)nullptr, (const uint4*)nullptr);
             return hipGetLastError();
         }
         // three launches: the fixed-base terms on the side stream BESIDE the commitments (four lanes per signature each), then the
@@ -431,33 +437,42 @@ hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_
         uint8_t* st_tmp = (uint8_t*)hdr + idemix_rows(n) * (NYM_HDR_WORDS * 4);
         uint4* comb_rec = nullptr;
         uint32_t* comb_flags = nullptr;
-        bool joined = true;
+        bool joined = true, side_launched = false, commit_launched = false;
+        hipError_t commit_err = hipSuccess;
+        auto launch_commitments = [&]() {
+            hipLaunchKernelGGL((idemix_nym_verify_quad_kernel<VERIFY_BLOCK, false>), qgrid, qblock, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
+                               (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
+                               (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
+                               (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, hdr, st_tmp, comb_flags, (const uint4*)comb_rec);
+            commit_err = hipGetLastError();
+            commit_launched = true;
+        };
         if (side != nullptr && side->stream != nullptr) {
             uint4* rec = (uint4*)(((uintptr_t)(st_tmp + idemix_rows(n)) + 255) & ~(uintptr_t)255);
             uint32_t* flags = (uint32_t*)(rec + idemix_rows(n) * 4 * NYM_COMB_UINT4_PER_LANE);
+            // TEST HOOK FABGPU_TEST_NYM_SIDE_AFTER (tests/test_idemix_gpu.py): the side launch is ordered BEHIND the commitment launch, so
+            // that every wavefront of the commitment kernel finds no records, gives up (flag 0 -> 2) and computes its terms itself, and
+            // every wavefront of the side launch finds the 2 and skips - both halves of the fallback, deterministically.
+            const bool side_after = getenv("FABGPU_TEST_NYM_SIDE_AFTER") != nullptr;
             // flags to zero in stream order, the side stream behind them; any failure on the way: the commitment kernel simply does it all
-            if (hipMemsetAsync(flags, 0, idemix_rows(n) / 16 * 4, st) == hipSuccess && hipEventRecord(side->fork, st) == hipSuccess &&
-                hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
-                hipLaunchKernelGGL(idemix_nym_comb_quad_kernel<VERIFY_BLOCK>, qgrid, qblock, 0, side->stream, n, (const uint32_t*)issuer_id, (const IssuerDev*)issuers,
-                                   n_issuers, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint32_t*)gather, flags, rec);
-                const hipError_t ke = hipGetLastError();
-                // (the caller's stream must not run past this call's kernels before the side launch is through with the workspace)
-                joined = hipEventRecord(side->join, side->stream) == hipSuccess;
-                if (ke == hipSuccess) {
-                    comb_rec = rec;
-                    comb_flags = flags;
+            if (hipMemsetAsync(flags, 0, idemix_rows(n) / 16 * 4, st) == hipSuccess) {
+                comb_rec = rec;
+                comb_flags = flags;
+                if (side_after) launch_commitments();
+                if (hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
+                    hipLaunchKernelGGL(idemix_nym_comb_quad_kernel<VERIFY_BLOCK>, qgrid, qblock, 0, side->stream, n, (const uint32_t*)issuer_id, (const IssuerDev*)issuers,
+                                       n_issuers, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint32_t*)gather, flags, rec);
+                    (void)hipGetLastError();   // (a side launch that did not happen leaves the flags at zero: the commitment kernel computes the terms itself)
+                    // the caller's stream must not run past this call's kernels before the side launch is through with the workspace
+                    side_launched = true;
+                    joined = hipEventRecord(side->join, side->stream) == hipSuccess;
+                    if (!joined) hipStreamSynchronize(side->stream);
                 }
-                if (!joined) hipStreamSynchronize(side->stream);
             }
         }
-        hipLaunchKernelGGL((idemix_nym_verify_quad_kernel<VERIFY_BLOCK, false>), qgrid, qblock, lds_reserve, st, n, (const uint32_t*)arena, (uint32_t)((arena_bytes + 3) / 4),
-                           (const uint32_t*)off, spans ? 1u : 0u, (const uint32_t*)issuer_id, (const IssuerDev*)issuers, n_issuers, (const uint8_t*)nym_x,
-                           (const uint8_t*)nym_y, (const uint8_t*)proof_c, (const uint8_t*)s_sk, (const uint8_t*)s_rnym, (const uint8_t*)nonce,
-                           (uint4*)qws, (uint64_t*)verdict_bits, (uint8_t*)status, (const uint32_t*)gather, hdr, st_tmp, (const uint32_t*)comb_flags,
-                           (const uint4*)comb_rec);
-        if (comb_flags != nullptr && joined && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) hipStreamSynchronize(side->stream);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
+        if (!commit_launched) launch_commitments();
+        if (side_launched && joined && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) hipStreamSynchronize(side->stream);
+        if (commit_err != hipSuccess) return commit_err;
         constexpr int W = 4;
         dim3 cgrid((uint32_t)(idemix_rows(n) / (W * SHAC_PER_WAVE))), cblock(64 * W);
         hipLaunchKernelGGL(idemix_nym_challenge_coop_kernel<W>, cgrid, cblock, (size_t)W * SHAC_LDS_WORDS * 4, st, n, (const uint32_t*)arena,

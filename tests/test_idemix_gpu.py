@@ -2,6 +2,8 @@
 status-exact on seeded batches that mix valid signatures with every kind of invalid / out-of-domain input, over two
 issuers of the reference's fixtures, every message-length class of the fused SHA-256, and a 30 000-signature batch checked
 through replication (the verdict of a copy is the verdict of its original)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,6 +88,31 @@ def test_every_message_length_class(env):
     ok, st, expect = _run(ctx, b)
     assert (expect == 0).all()
     assert np.array_equal(st, expect), [len(b.msgs[i]) for i in np.nonzero(st != expect)[0]]
+
+
+def test_side_launch_that_comes_too_late_changes_nothing(env, request):
+    """Three launches (round 5): the fixed-base terms run on a side stream beside the commitments; a commitment wavefront that does not
+    find its records gives up (flag 0 -> 2) and computes the terms itself, and a side wavefront that finds the 2 skips its rows.  The
+    test hook orders the side launch BEHIND the commitment launch, so every wavefront takes exactly that path - statuses must not move."""
+    ctx, issuers = env
+    os.environ["FABGPU_TEST_NYM_SIDE_AFTER"] = "1"
+    try:
+        for n, seed in ((1, 11), (65, 12), (700, 13), (6000, 14)):
+            if n <= 700:
+                b = make_batch(issuers, n, seed)
+                ok, st, expect = _run(ctx, b)
+            else:
+                base = make_batch(issuers, 200, seed)
+                arena, off, iid, cols, exp0 = base.arrays()
+                pick = np.random.default_rng(n).integers(0, 200, size=n)
+                off2 = np.zeros(n + 1, dtype=np.uint32)
+                off2[1:] = np.cumsum((off[1:] - off[:-1])[pick])
+                arena2 = np.concatenate([arena[off[i]:off[i + 1]] for i in pick])
+                ok, st = ctx.idemix_nym_verify_batch(arena2, off2, *[c[pick] for c in cols], issuer_id=iid[pick])
+                expect = exp0[pick]
+            assert np.array_equal(st, expect) and np.array_equal(ok, expect == 0), n
+    finally:
+        del os.environ["FABGPU_TEST_NYM_SIDE_AFTER"]
 
 
 def test_block_sized_batch_by_replication(env):
