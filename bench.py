@@ -561,8 +561,8 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
                 "stage_ms_median": {k_: statistics.median(s_[j] for s_ in stages) for j, k_ in enumerate(("outline_and_identity_table", "wait_for_upload", "device_phase", "bookkeeping"))}}
     try:
         for k in range(6):                                     # identities are learned and earn their device tables on the first passes
-            first = fabgpu.preverify_block2(csp, blk, lean=True)   # (one learn slot per table hash, keyed per provider: signers that meet
-            if k >= 2 and first["n_keyed"] == 4 * n_tx:        #  in a slot take a block longer)
+            first = fabgpu.preverify_block2(csp, blk, lean=True)   # (round 5: learned in the first pass, keyed from the second; the loop
+            if k >= 2 and first["n_keyed"] == 4 * n_tx:        #  is kept as a guard)
                 break
         assert (first["tx_flags"] == 0).all() and first["n_tuples"] == 4 * n_tx and first["n_keyed"] == 4 * n_tx, \
             "friendly block after %d passes: %d of %d tuples through key tables, %d flagged" % (k + 1, first["n_keyed"], 4 * n_tx, int((first["tx_flags"] != 0).sum()))

@@ -916,13 +916,13 @@ void GPUCSP::EvictIdentitiesLocked() const {
         idlru_.pop_back();
     }
 }
-void GPUCSP::InsertIdentityLocked(std::string&& key, CachedIdentity ci) const {
+void GPUCSP::InsertIdentityLocked(std::string&& key, CachedIdentity ci, bool evict_now) const {
     ci.table_hash = walk::id_hash_host((const uint8_t*)key.data(), (uint32_t)key.size(), idtab_seed_);
     ci.serial = id_next_serial_++;
     idlru_.emplace_front(std::move(key), ci);
     idcache_[idlru_.front().first] = idlru_.begin();
     idserial_[ci.serial] = idlru_.begin();
-    EvictIdentitiesLocked();
+    if (evict_now) EvictIdentitiesLocked();
 }
 void GPUCSP::PassStats(uint64_t out[4]) const {
     out[0] = pass_relaunches_.load(std::memory_order_relaxed);
@@ -1627,6 +1627,7 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     // What the host pass does per tuple for the cache - count who was named (a device comb table is earned by being named
     // id_register_after_ times) and keep the LRU order fresh - from the identity indices, when they came back.
     std::vector<std::string> to_register;
+    std::vector<uint64_t> hit_serials;                                  // who this block named: they stay in front of the block's newcomers
     if (!idtab_host_.empty()) {
         std::vector<uint32_t> hits(idtab_host_.size(), 0);
         for (size_t i = 0; i < nd; i++)
@@ -1636,6 +1637,7 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
             if (!hits[k]) continue;
             auto it = idserial_.find(idtab_host_[k]);
             if (it == idserial_.end()) continue;                        // (evicted since the table was made)
+            hit_serials.push_back(idtab_host_[k]);
             idlru_.splice(idlru_.begin(), idlru_, it->second);
             CachedIdentity& c = it->second->second;
             c.hits += hits[k];
@@ -1667,11 +1669,21 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
                 id_registered_++;
                 to_register.push_back(key);
             }
-            InsertIdentityLocked(std::move(key), ci);
+            InsertIdentityLocked(std::move(key), ci, /*evict_now=*/false);
             pass_learned_.fetch_add(1, std::memory_order_relaxed);
             grew = true;
         }
-        if (grew) id_version_.fetch_add(1, std::memory_order_release);
+        // The block's newcomers must not push out the identities the same block NAMED: with open-addressed learn slots a block can bring
+        // 128 of them, and a cache bound below that (tests; an operator's choice) would otherwise drop the channel's endorsers - named
+        // by every transaction, tables and all - because they were touched a moment BEFORE the newcomers were inserted in front of them.
+        if (grew) {
+            for (uint64_t serial : hit_serials) {
+                auto it = idserial_.find(serial);
+                if (it != idserial_.end()) idlru_.splice(idlru_.begin(), idlru_, it->second);
+            }
+            EvictIdentitiesLocked();
+            id_version_.fetch_add(1, std::memory_order_release);
+        }
     }
     RegisterQueued(to_register);
     constexpr int gate_max = 16;

@@ -298,7 +298,7 @@ class GPUCSP {
     mutable std::unordered_map<uint64_t, IdList::iterator> idserial_;
     mutable uint64_t id_next_serial_ = 1;
     // (idmu_ held) a new cache entry at the front of the LRU list; evicts what no longer fits
-    void InsertIdentityLocked(std::string&& key, CachedIdentity ci) const;
+    void InsertIdentityLocked(std::string&& key, CachedIdentity ci, bool evict_now = true) const;
     mutable size_t id_max_ = 4096, id_max_registered_ = 256, id_registered_ = 0;
     mutable uint32_t id_register_after_ = 64;
     // Every device of the pool holds a copy of this cache (Dev::idtab_*), rebuilt before a pass on that device whenever id_version_ moved.

@@ -69,8 +69,8 @@ struct DevIdemixMsp {
 static_assert(sizeof(DevIdemixMsp) == 128, "uploaded as raw bytes");
 
 // An identity the device decoded and the provider may want in its cache (and, once it has been named often enough, with a comb table):
-// one slot per table hash, first come first served - a block offers at most WALK_LEARN_SLOTS new identities, whoever is left shows up
-// again in the next block if it matters.
+// a slot found by open addressing from the table hash (eight probes) - a block offers at most WALK_LEARN_SLOTS new identities, whoever
+// finds eight other identities in a row shows up again in the next block.
 constexpr uint32_t WALK_LEARN_SLOTS = 128;
 struct WalkLearn {
     uint64_t tag;                  // 0: empty; else the identity's table hash | 1

@@ -467,15 +467,31 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
                 term += ((uint64_t)hi32 << 32) | lo32;
             }
             const uint64_t tag = bccsp::walk::id_hash_finish(term, t.identity.len) | 1ull;
-            WalkLearn* slot = a.learn + ((uint32_t)(tag >> 17) & (WALK_LEARN_SLOTS - 1));
-            uint32_t mine = 0;
+            // Open addressing, up to eight probes: round 4 gave every table hash ONE slot, first come first served - two of a channel's
+            // six signers met in a slot in one fresh provider of nine (128 slots, six keys: 11 %), the loser was learned a block later,
+            // and that block paid a relaunch on the fresh-key kernels plus 6 ms of table building (profiles/r05_fresh_provider_probe2.txt:
+            // lone passes 15.5 / 9.1 / 2.2 ms).  With eight probes a block has to bring dozens of new identities before one waits.
+            const uint32_t home = (uint32_t)(tag >> 17) & (WALK_LEARN_SLOTS - 1);
+            uint32_t mine = 0, at = home;
             if (lane == 0) {
-                unsigned long long old = __builtin_nontemporal_load((const unsigned long long*)&slot->tag);
-                if (old == 0ull) old = atomicCAS((unsigned long long*)&slot->tag, 0ull, (unsigned long long)tag);
-                mine = old == 0ull ? 1u : 0u;
-                // (hits only matter up to the registration threshold: a block naming one new identity thousands of times stops counting early)
-                if (old == (unsigned long long)tag && __builtin_nontemporal_load(&slot->hits) < 256u) atomicAdd(&slot->hits, 1u);
+                for (uint32_t probe = 0; probe < 8u; probe++) {
+                    WalkLearn* cand = a.learn + ((home + probe) & (WALK_LEARN_SLOTS - 1));
+                    unsigned long long old = __builtin_nontemporal_load((const unsigned long long*)&cand->tag);
+                    if (old == 0ull) old = atomicCAS((unsigned long long*)&cand->tag, 0ull, (unsigned long long)tag);
+                    if (old == 0ull) {                                         // an empty slot: this wavefront owns it now
+                        mine = 1u;
+                        at = (home + probe) & (WALK_LEARN_SLOTS - 1);
+                        break;
+                    }
+                    if (old == (unsigned long long)tag) {                      // this identity's slot, owned by an earlier tuple: a hit
+                        // (hits only matter up to the registration threshold: a block naming one new identity thousands of times stops counting early)
+                        if (__builtin_nontemporal_load(&cand->hits) < 256u) atomicAdd(&cand->hits, 1u);
+                        break;
+                    }
+                }                                                              // (eight other identities in a row: shows up again in the next block)
             }
+            at = __shfl(at, 0, 64);
+            WalkLearn* slot = a.learn + at;
             mine = __shfl(mine, 0, 64);
             if (mine) {
                 (lane < 32 ? slot->qx : slot->qy)[lane & 31u] = (uint8_t)key_byte;

@@ -750,8 +750,8 @@ def test_blocks_full_of_new_clients_stay_on_the_device_route(monkeypatch):
         friendly, _ = blockgen.endorser_block(300, 7)
         csp.set_option("pass_stage_min_bytes", 1)
         for k in range(6):                                                  # the six fixture signers are learned and earn their tables
-            out = fabgpu.preverify_block2(csp, friendly, block_seq=k)       # (one learn slot per table hash, keyed per provider: two signers
-            if k >= 2 and out["n_keyed"] == 1200 and out["n_device_decoded"] == 0:   #  that meet in a slot take a block longer)
+            out = fabgpu.preverify_block2(csp, friendly, block_seq=k)       # (learn slots: open addressing since round 5 - two signers
+            if k >= 2 and out["n_keyed"] == 1200 and out["n_device_decoded"] == 0:   #  whose hashes meet no longer wait a block)
                 break
         assert (out["tx_flags"] == 0).all() and out["n_keyed"] == 1200 and out["n_device_decoded"] == 0
         fresh = blockgen.fresh_identities(300, 99)
