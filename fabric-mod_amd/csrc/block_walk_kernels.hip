@@ -469,8 +469,8 @@ __global__ void __launch_bounds__(256) walk_gate_kernel(WalkArrays a) {
             const uint64_t tag = bccsp::walk::id_hash_finish(term, t.identity.len) | 1ull;
             // Open addressing, up to eight probes: round 4 gave every table hash ONE slot, first come first served - two of a channel's
             // six signers met in a slot in one fresh provider of nine (128 slots, six keys: 11 %), the loser was learned a block later,
-            // and that block paid a relaunch on the fresh-key kernels plus 6 ms of table building (profiles/r05_fresh_provider_probe2.txt:
-            // lone passes 15.5 / 9.1 / 2.2 ms).  With eight probes a block has to bring dozens of new identities before one waits.
+            // and that block paid a relaunch on the fresh-key kernels plus 6 ms of table building (lone passes 15.5 / 9.1 / 2.2 ms;
+            // DESIGN.md 4.4d "Round 5").  With eight probes a block has to bring dozens of new identities before one waits.
             const uint32_t home = (uint32_t)(tag >> 17) & (WALK_LEARN_SLOTS - 1);
             uint32_t mine = 0, at = home;
             if (lane == 0) {
