@@ -398,10 +398,7 @@ def mixed_cfg4_leg(torch, np, fabgpu, coracle, steps=20, n=30000, msg_len=4608, 
         d_ec = {k: torch.from_numpy(np.ascontiguousarray(b_all[k][lo_e:hi_e])).cuda() for k in ("qx", "qy", "e", "r", "s")}
         mg_nym = torch.zeros(sw_nym * world, dtype=torch.int64, device="cuda")
         mg_ec = torch.zeros(sw_ec * world, dtype=torch.int64, device="cuda")
-        # The ECDSA launch gets the high-priority stream: its 750 two-lane wavefronts are dispatched first and own their SIMDs, the idemix
-        # call's shorter launches fill what is left (measured in one call, tools/gpu_r05_prio_probe.sh: no priorities 0.99 ms per step,
-        # ECDSA high 0.90, idemix high 1.20, both high 1.18).
-        s1, s2 = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
         cur = torch.cuda.current_stream()
 
         def step_nym(st):

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--fused-hash", action="store_true", help="FABGPU_FLAG_NYM_FUSED_HASH: round 4's single four-lane kernel instead of the two phases (A/B)")
     ap.add_argument("--no-side-stream", action="store_true", help="FABGPU_FLAG_NYM_NO_SIDE_STREAM: the fixed-base terms inside the commitment kernel (A/B)")
     ap.add_argument("--prio", default="", help="stream priorities 'ec,nym' (e.g. -1,0: the ECDSA stream high; HIP: lower number = higher priority) - exploration")
+    ap.add_argument("--no-time-kernels", action="store_true", help="do not bracket launches with timing events (as bench.py's context)")
     ap.add_argument("--base", type=int, default=192, help="distinct oracle-signed pseudonym signatures that the batch replicates")
     args = ap.parse_args()
     import random
@@ -38,7 +39,7 @@ def main():
     from idemix_common import NymBatch, be32, fixtures
 
     fx = fixtures()
-    ctx = fabgpu.Context(device=0, max_batch=args.n, flags=fabgpu.FLAG_TIME_KERNELS | (fabgpu.FLAG_NO_QUAD if args.no_quad else 0) |
+    ctx = fabgpu.Context(device=0, max_batch=args.n, flags=(0 if args.no_time_kernels else fabgpu.FLAG_TIME_KERNELS) | (fabgpu.FLAG_NO_QUAD if args.no_quad else 0) |
                          (fabgpu.FLAG_NYM_FUSED_HASH if args.fused_hash else 0) | (fabgpu.FLAG_NYM_NO_SIDE_STREAM if args.no_side_stream else 0))
     issuers = []
     t0 = time.perf_counter()
