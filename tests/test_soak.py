@@ -11,3 +11,12 @@ def test_randomised_parity_soak():
     r = soak_parity.soak(float(os.environ.get("FABGPU_SOAK_SECONDS", "15")), seed=int(os.environ.get("FABGPU_SOAK_SEED", "7")))
     assert r["soak"] == "ok", r
     assert r["batches"] >= 3 and r["tuples"] > 1000
+
+
+@pytest.mark.gpu
+def test_randomised_idemix_soak():
+    """tests/soak_idemix.py for a few seconds (thousands of calls through one context: the side launch's flag protocol must never let a stale
+    or half-written record through); profiles/r05_soak_idemix.json is the 150-second run (147 562 calls, 240 M signatures)"""
+    import soak_idemix
+    r = soak_idemix.soak(float(os.environ.get("FABGPU_SOAK_SECONDS", "10")), seed=int(os.environ.get("FABGPU_SOAK_SEED", "7")))
+    assert r["calls"] >= 100 and r["signatures"] > 10000, r
