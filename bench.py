@@ -1098,6 +1098,9 @@ def main():
         mac_ceiling, mac_peak, mac_peak_what = None, VALU_PEAK_MAC, "the burst v_mad ceiling of earlier rounds (the sustained measurement was not taken)"
         if extras:
             try:
+                for _ in range(40):                                  # (the ceiling, too, is measured on a chip that has left its idle clocks)
+                    verify_only()
+                torch.cuda.synchronize()
                 mac_ceiling = mac_ceiling_leg()
                 mac_peak = mac_ceiling["peak_mac_per_s"]
                 mac_peak_what = "MAC/s of every SIMD issuing independent v_mad_i64_i32 for >= 5 ms, the best of 1 / 2 / 4 wavefronts per SIMD, measured in this run on this box"
