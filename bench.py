@@ -402,7 +402,14 @@ def mixed_cfg4_leg(torch, np, fabgpu, coracle, steps=20, n=30000, msg_len=4608, 
         d_ec = {k: torch.from_numpy(np.ascontiguousarray(b_all[k][lo_e:hi_e])).cuda() for k in ("qx", "qy", "e", "r", "s")}
         mg_nym = torch.zeros(sw_nym * world, dtype=torch.int64, device="cuda")
         mg_ec = torch.zeros(sw_ec * world, dtype=torch.int64, device="cuda")
-        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        # How the two calls are submitted (round 5, tools/gpu_r05_prio_probe.sh, six variants in one call): the ECDSA launch on a HIGH-PRIORITY
+        # stream with a plain event recorded behind it, the idemix call on a normal stream - 0.90-0.91 ms per step against 0.98-1.00 for
+        # every other combination (no priority; priority without the event; the event without priority; priorities the other way round
+        # 1.16-1.20).  The priority gives the ECDSA launch's 750 wavefronts first pick of the SIMDs; the event is a barrier in that queue, so
+        # the NEXT step's ECDSA launch cannot put its workgroups in front of the dispatcher while this step's idemix launches still wait.
+        s1, s2 = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+        ec_markers = [torch.cuda.Event(enable_timing=False) for _ in range(64)]
+        ec_k = [0]
         cur = torch.cuda.current_stream()
 
         def step_nym(st):
@@ -414,6 +421,8 @@ def mixed_cfg4_leg(torch, np, fabgpu, coracle, steps=20, n=30000, msg_len=4608, 
             if m_ec:
                 ctx.p256_verify_batch_dev(m_ec, d_ec["qx"].data_ptr(), d_ec["qy"].data_ptr(), d_ec["e"].data_ptr(), d_ec["r"].data_ptr(), d_ec["s"].data_ptr(),
                                           d_words_ec.data_ptr(), 0, st.cuda_stream)
+                ec_markers[ec_k[0] % 64].record(st)
+                ec_k[0] += 1
 
         def gather(dst, src):
             if not dry:

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--fused-hash", action="store_true", help="FABGPU_FLAG_NYM_FUSED_HASH: round 4's single four-lane kernel instead of the two phases (A/B)")
     ap.add_argument("--no-side-stream", action="store_true", help="FABGPU_FLAG_NYM_NO_SIDE_STREAM: the fixed-base terms inside the commitment kernel (A/B)")
     ap.add_argument("--prio", default="", help="stream priorities 'ec,nym' (e.g. -1,0: the ECDSA stream high; HIP: lower number = higher priority) - exploration")
+    ap.add_argument("--marker", choices=("", "timing", "plain"), default="", help="the caller records an event on the ECDSA stream after every ECDSA launch (exploration)")
     ap.add_argument("--no-time-kernels", action="store_true", help="do not bracket launches with timing events (as bench.py's context)")
     ap.add_argument("--base", type=int, default=192, help="distinct oracle-signed pseudonym signatures that the batch replicates")
     args = ap.parse_args()
@@ -93,9 +94,15 @@ def main():
         ctx.idemix_nym_verify_batch_dev(n_nym, d_arena.data_ptr(), d_arena.numel(), d_off.data_ptr(), d_iid.data_ptr(), *[c.data_ptr() for c in d_cols],
                                         d_words_nym.data_ptr(), 0, st.cuda_stream)
 
+    markers = [torch.cuda.Event(enable_timing=(args.marker == "timing")) for _ in range(64)] if args.marker else []
+    mk = [0]
+
     def step_ec(st):
         ctx.p256_verify_batch_dev(n_ec, d_ec["qx"].data_ptr(), d_ec["qy"].data_ptr(), d_ec["e"].data_ptr(), d_ec["r"].data_ptr(), d_ec["s"].data_ptr(),
                                   d_words_ec.data_ptr(), 0, st.cuda_stream)
+        if markers:
+            markers[mk[0] % 64].record(st)
+            mk[0] += 1
 
     def timed(fn):
         for _ in range(args.warmup):
