@@ -818,11 +818,26 @@ int fabgpu_p256_verify_batch(fabgpu_ctx* ctx, size_t n, const uint8_t* qx, const
     int rc;
     if ((rc = ctx->fields.ensure(5 * fb)) || (rc = ctx->out.ensure(st_off + n))) return rc;
     uint8_t* h = (uint8_t*)ctx->fields.h;
-    memcpy(h, qx, fb); memcpy(h + fb, qy, fb); memcpy(h + 2 * fb, e, fb); memcpy(h + 3 * fb, r, fb); memcpy(h + 4 * fb, s, fb);
     uint8_t* d = (uint8_t*)ctx->fields.d;
     uint8_t* dout = (uint8_t*)ctx->out.d;
-    hipError_t err = hipMemcpyAsync(d, h, 5 * fb, hipMemcpyHostToDevice, ctx->stream);
-    if (err != hipSuccess) return hip_to_rc(err);
+    // Field by field: the copy of a field into the pinned staging buffer, then ITS transfer - the DMA of field k runs while the host
+    // copies field k + 1 (round 5; one transfer of all five behind all five copies left the bus idle for the copies' 0.15 ms and the
+    // host idle for the transfer's 0.1 ms).  Small batches stay one transfer: five API calls would cost more than they hide.
+    const uint8_t* src[5] = {qx, qy, e, r, s};
+    hipError_t err = hipSuccess;
+    if (fb >= ((size_t)256 << 10)) {
+        for (int f = 0; f < 5 && err == hipSuccess; f++) {
+            memcpy(h + (size_t)f * fb, src[f], fb);
+            err = hipMemcpyAsync(d + (size_t)f * fb, h + (size_t)f * fb, fb, hipMemcpyHostToDevice, ctx->stream);
+        }
+    } else {
+        for (int f = 0; f < 5; f++) memcpy(h + (size_t)f * fb, src[f], fb);
+        err = hipMemcpyAsync(d, h, 5 * fb, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (err != hipSuccess) {
+        hipStreamSynchronize(ctx->stream);                  // (nothing may still be reading the staging buffer when the next call refills it)
+        return hip_to_rc(err);
+    }
     rc = fabgpu_p256_verify_batch_dev(ctx, n, d, d + fb, d + 2 * fb, d + 3 * fb, d + 4 * fb, dout, status ? dout + st_off : nullptr, ctx->stream);
     if (rc) return rc;
     err = hipMemcpyAsync(ctx->out.h, dout, status ? st_off + n : words * 8, hipMemcpyDeviceToHost, ctx->stream);
