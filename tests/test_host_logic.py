@@ -550,3 +550,24 @@ def test_issuer_key_canonical_encoding_gate():
         bad_hsk = hsk[:2] + inner[1][1] + inner[0][1]
         assert canon(b"".join(bad_hsk if k == i2 else x for k, (_, x) in enumerate(f))) == 0
     assert canon(b"") == 0 and L.fabgpu_idemix_issuer_key_is_canonical(None, 0) == 0
+
+
+# ---- every kernel of the product's translation units is resolved at provider construction (round 5: warm_kernel_functions_*) ----
+def test_every_global_kernel_is_in_its_units_warm_list():
+    """GPUCSP::Preallocate asks for the attributes of every __global__ function so that none is resolved at its first launch inside a
+    block's pass (DESIGN.md 4.4d "Round 5").  A kernel added to a unit must be added to that unit's list: this test reads the sources."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "fabric-mod_amd", "csrc")
+    for unit, fn in (("kernels.hip", "warm_kernel_functions_kernels"), ("wide_kernels.hip", "warm_kernel_functions_wide"),
+                     ("idemix_kernels.hip", "warm_kernel_functions_idemix"), ("block_walk_kernels.hip", "warm_kernel_functions_walk")):
+        src = open(os.path.join(csrc, unit)).read()
+        kernels = set(re.findall(r"__global__\s+void\s+(?:__launch_bounds__\([^)]*\)\s*)?(\w+)\s*\(", src))
+        assert len(kernels) >= 5, (unit, kernels)
+        body = src[src.index("int %s()" % fn):]
+        body = body[:body.index("return ok;")]
+        listed = set(re.findall(r"\(const void\*\)\s*\(?\s*(\w+)", body))
+        assert kernels <= listed, "%s: kernels missing from %s: %s" % (unit, fn, sorted(kernels - listed))
+    api = open(os.path.join(csrc, "fabgpu_api.hip")).read()
+    for fn in ("warm_kernel_functions_kernels", "warm_kernel_functions_wide", "warm_kernel_functions_idemix", "warm_kernel_functions_walk"):
+        assert "(void)%s();" % fn in api
