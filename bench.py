@@ -232,11 +232,15 @@ def compact_line(out, detail_path="bench_detail.json"):
         "validated_tx_per_s_block_pass_all_gpus": out.get("validated_tx_per_s_block_pass_all_gpus"),
         "block_pass_ms": _dig(bp, "flags_only", "median_ms_per_block"),
         "block_pass_pcie_frac": _dig(bp, "roofline", "single_pass", "frac"),
-        "validators_ms_per_block": _dig(go_, "sha_ni", "validators_ms_per_block_median"),
-        "validators_ms_per_block_without_sha_ni": _dig(go_, "no_sha_ni", "validators_ms_per_block_median"),
-        "block_data_hash_ms": _dig(go_, "sha_ni", "block_data_hash_ms"),
-        "block_data_hash_ms_without_sha_ni": _dig(go_, "no_sha_ni", "block_data_hash_ms"),
-        "fresh_provider_lone_passes_ms": _dig(go_, "sha_ni", "lone_passes_ms"),
+        "validated_tx_per_s_end_to_end_digest_memo_off": out.get("validated_tx_per_s_end_to_end_digest_memo_off"),
+        "validators_ms_per_block": _dig(go_, "digest_memo", "validators_ms_per_block_median"),
+        "validators_ms_per_block_digest_memo_off": _dig(go_, "digest_memo_off", "validators_ms_per_block_median"),
+        "validators_ms_per_block_digest_memo_off_without_sha_ni": _dig(go_, "digest_memo_off_no_sha_ni", "validators_ms_per_block_median"),
+        "digest_memo_hits_per_block": (_dig(go_, "digest_memo", "hash_memo_hits") or 0) // max(1, _dig(go_, "digest_memo", "blocks") or 1) if _dig(go_, "digest_memo", "hash_memo_hits") is not None else None,
+        "digest_memo_mismatches": _dig(go_, "digest_memo", "hash_memo_digest_mismatches"),
+        "block_data_hash_ms": _dig(go_, "digest_memo", "block_data_hash_ms"),
+        "block_data_hash_ms_without_sha_ni": _dig(go_, "digest_memo_no_sha_ni", "block_data_hash_ms"),
+        "fresh_provider_lone_passes_ms": _dig(go_, "digest_memo", "lone_passes_ms"),
         "block_100tx_ms": _dig(bp, "default_sized_blocks", "100_tx", "back_to_back", "median_ms_per_block"),
         "block_500tx_ms": _dig(bp, "default_sized_blocks", "500_tx", "back_to_back", "median_ms_per_block"),
         "cpu_validated_tx_per_s_block": _dig(bp, "cpu_baseline", "value"),
@@ -785,16 +789,21 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
             quota = cpu_quota_cores()
             pool_threads = max(1, int(round(quota))) if quota else min(64, len(os.sched_getaffinity(0)))
             replay = {}
-            for label, env_extra in (("sha_ni", {}), ("no_sha_ni", {"OPENSSL_ia32cap": ":~0x20000000"})):
-                r_ = subprocess.run([exe, path, "12", str(pool_threads), "1"], capture_output=True, text=True, timeout=180,
+            no_ni = {"OPENSSL_ia32cap": ":~0x20000000"}
+            # (label, hash memo on?, environment): the provider as shipped; the round-5 provider (Hash = bccsp/sw) with and without SHA-NI;
+            # the shipped provider without SHA-NI (only BlockDataHash and misses still hash on the CPU)
+            for label, hm, env_extra in (("digest_memo", "1", {}), ("digest_memo_off", "0", {}), ("digest_memo_off_no_sha_ni", "0", no_ni), ("digest_memo_no_sha_ni", "1", no_ni)):
+                r_ = subprocess.run([exe, path, "16", str(pool_threads), "1", hm], capture_output=True, text=True, timeout=180,
                                     env=dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fabric-mod_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""), **env_extra))
                 line = [l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")]
                 replay[label] = json.loads(line[-1]) if r_.returncode == 0 and line else {"error": "rc %d: %s" % (r_.returncode, (r_.stderr or r_.stdout)[-300:])}
             legs["as_the_go_binding_calls_it"] = {
                 "what": "tools/go_call_replay.c: a fresh provider (fabgpu_csp_new2, ConcurrentPasses 2), block k + 1 pre-verified at arrival (HasBlock, PreVerifyBlock with the "
-                        "provider's remembered cap_tx, FABGPU_PASS_SEED_MEMO, flags only) while block k is validated by validatorPoolSize = %d threads (per signature: SHA-256 of "
-                        "the validator's message bytes on the CPU + fabgpu_csp_memo_lookup), EvictBlock; fresh copy of the block per pass.  sha_ni: OpenSSL's SHA-256 with the SHA "
-                        "extensions; no_sha_ni: the same without them (Go 1.14's crypto/sha256 has AVX2 code only)" % pool_threads,
+                        "provider's remembered cap_tx, FABGPU_PASS_SEED_MEMO, flags only) while block k is validated by a pool of validatorPoolSize = %d threads - per signature "
+                        "identity.Verify's two calls: bccsp.Hash(msg) = fabgpu_csp_hash_lookup (the digest the pass computed, handed out only when the validator's bytes equal the "
+                        "block's; a miss hashes on the CPU) and bccsp.Verify = fabgpu_csp_memo_lookup -, EvictBlock; fresh copy of the block per pass.  digest_memo: the provider "
+                        "as shipped; digest_memo_off: Hash always on the CPU (round 5's provider) with OpenSSL's SHA-NI code; ..._no_sha_ni: the same without the SHA extensions "
+                        "(Go 1.14's crypto/sha256 has AVX2 code only)" % pool_threads,
                 **replay}
         except Exception as e:                                 # noqa: BLE001
             legs["as_the_go_binding_calls_it"] = {"error": repr(e)[:300]}
@@ -1237,8 +1246,9 @@ def main():
                     out["validated_tx_per_s_block_pass_pipelined_with_memo"] = out["block_pass"]["two_in_flight_arrival_pipeline_with_memo_seeding"].get("validated_tx_per_s")
                     # ... and as a peer sees it: the Go binding's call sequence with the validators' CPU residue (bccsp.Hash + memo lookups) behind the pass
                     go_ = out["block_pass"].get("as_the_go_binding_calls_it", {})
-                    out["validated_tx_per_s_end_to_end_cpu_residue"] = go_.get("sha_ni", {}).get("validated_tx_per_s_end_to_end")
-                    out["validated_tx_per_s_end_to_end_cpu_residue_without_sha_ni"] = go_.get("no_sha_ni", {}).get("validated_tx_per_s_end_to_end")
+                    out["validated_tx_per_s_end_to_end_cpu_residue"] = go_.get("digest_memo", {}).get("validated_tx_per_s_end_to_end")
+                    out["validated_tx_per_s_end_to_end_digest_memo_off"] = go_.get("digest_memo_off", {}).get("validated_tx_per_s_end_to_end")
+                    out["validated_tx_per_s_end_to_end_digest_memo_off_without_sha_ni"] = go_.get("digest_memo_off_no_sha_ni", {}).get("validated_tx_per_s_end_to_end")
                 except Exception as e:                                                                     # never let this leg cost the line
                     import traceback
                     out["block_pass"] = {"error": repr(e)[:300], "where": [ln.strip() for ln in traceback.format_exc().strip().splitlines()[-4:]]}

@@ -44,7 +44,7 @@ struct fabgpu_csp {
         mix(block + len - k, k);
         return h;
     }
-    std::unique_ptr<GPUCSP::BlockUpload> upload_for(const uint8_t* block, size_t len, uint64_t seq) {
+    std::unique_ptr<GPUCSP::BlockUpload> upload_for(const uint8_t* block, size_t len, uint64_t seq, bool keep_host_copy) {
         std::unique_ptr<GPUCSP::BlockUpload> up, stale;
         {
             std::lock_guard<std::mutex> lk(orphan_mu);
@@ -57,7 +57,7 @@ struct fabgpu_csp {
         stale.reset();                                       // (outside the lock)
         if (!up) {
             up.reset(new GPUCSP::BlockUpload);
-            csp->StartBlockUpload(*up, block, len, seq);     // the block travels while it is walked
+            csp->StartBlockUpload(*up, block, len, seq, keep_host_copy);     // the block travels while it is walked
         }
         return up;
     }
@@ -140,6 +140,8 @@ int fabgpu_csp_new2(const fabgpu_csp_opts* o, fabgpu_csp** out, char* err, size_
         po.pass_device_memo = v.pass_device_memo;
         po.pass_host_counts = v.pass_host_counts;
         po.pass_timing = v.pass_timing;
+        po.pass_hash_memo = v.pass_hash_memo;
+        po.hash_memo_blocks = v.hash_memo_blocks;
     }
     fabgpu_csp* h = new fabgpu_csp();
     Error e = GPUCSP::New(po, h->csp);
@@ -189,6 +191,16 @@ int fabgpu_csp_key_import(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* q
     return FABGPU_OK;
 }
 
+// bccsp.Hash(msg, &bccsp.SHA256Opts{}) answered from the digest memo: 0 hit (digest32 filled), 1 miss (hash on the CPU)
+int fabgpu_csp_hash_lookup(fabgpu_csp* csp, const uint8_t* msg, size_t len, uint8_t* digest32) {
+    if (!csp || !msg || !digest32) return 1;
+    return csp->csp->HashLookup(msg, len, digest32);
+}
+int fabgpu_csp_hash_memo_stats(fabgpu_csp* csp, uint64_t* hits, uint64_t* misses, uint64_t* blocks_held, uint64_t* bytes_held, uint64_t* refused) {
+    if (!csp) return FABGPU_EINVAL;
+    csp->csp->HashMemoStats(hits, misses, blocks_held, bytes_held, refused);
+    return FABGPU_OK;
+}
 int fabgpu_csp_hash(fabgpu_csp* csp, const uint8_t* msg, size_t len, const char* alg, uint8_t* digest32, char* err, size_t errcap) {
     if (!csp || !digest32) return FABGPU_EINVAL;
     HashOpts o;
@@ -313,7 +325,7 @@ int fabgpu_csp_block_preverify(fabgpu_csp* csp, const uint8_t* block, size_t len
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
-    std::unique_ptr<GPUCSP::BlockUpload> up_p = csp->upload_for(block, len, 0);   // the block travels while it is walked
+    std::unique_ptr<GPUCSP::BlockUpload> up_p = csp->upload_for(block, len, 0, false);   // the block travels while it is walked
     GPUCSP::BlockUpload& up = *up_p;
     const bool per_tuple = tuple_tx != nullptr || tuple_kind != nullptr || tuple_status != nullptr;
     static thread_local ParsedBlock pb;                     // storage reused from block to block (a few MB: no page faults per block)
@@ -376,7 +388,8 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* ps) {
     if (ps->flags & ~(uint32_t)(FABGPU_PASS_SEED_MEMO | FABGPU_PASS_NO_BLOCK_SIGS)) return FABGPU_EINVAL;
     auto t0 = std::chrono::steady_clock::now();
     const bool timing = csp->csp->GetOption("pass_timing") > 0;
-    std::unique_ptr<GPUCSP::BlockUpload> up_p = csp->upload_for(ps->block, ps->len, ps->block_seq);
+    // (a memo-seeding pass keeps the block's bytes in host memory of the device context: the digest memo compares bccsp.Hash callers' bytes with them)
+    std::unique_ptr<GPUCSP::BlockUpload> up_p = csp->upload_for(ps->block, ps->len, ps->block_seq, (ps->flags & FABGPU_PASS_SEED_MEMO) != 0);
     GPUCSP::BlockUpload& up = *up_p;
     // room for per-tuple answers only matters to a caller that asked for some (the Go binding asks for flags alone)
     const bool per_tuple = ps->tuple_tx || ps->tuple_kind || ps->tuple_status || ps->tuple_spans || ps->tuple_digest || ps->tuple_hashed || ps->tuple_qxy;

@@ -248,6 +248,7 @@ GPUCSP::~GPUCSP() {
 }
 GPUCSP::BlockUpload::~BlockUpload() {
     if (th.joinable()) th.join();
+    host_copy_release(&copy);                               // (a pass that published a memo table took it along: nothing left to release)
     if (routed && owner) owner->devs_[(size_t)dev]->in_flight.fetch_sub(1, std::memory_order_acq_rel);
 }
 int GPUCSP::RouteBlock(uint64_t block_seq) const {
@@ -270,7 +271,8 @@ const OptField kIntOpts[] = {{"pass_device_walk", &ProviderOptions::pass_device_
                              {"pass_device_memo", &ProviderOptions::pass_device_memo},
                              {"pass_host_counts", &ProviderOptions::pass_host_counts},
                              {"pass_skip_hash_checks", &ProviderOptions::pass_skip_hash_checks},
-                             {"pass_timing", &ProviderOptions::pass_timing}};
+                             {"pass_timing", &ProviderOptions::pass_timing},
+                             {"pass_hash_memo", &ProviderOptions::pass_hash_memo}};
 }  // namespace
 int64_t GPUCSP::SetOption(const std::string& name, int64_t value) const {
     std::lock_guard<std::mutex> lk(opt_mu_);
@@ -358,6 +360,9 @@ void GPUCSP::Preallocate() const {
     scratch_free_max_ = std::max<size_t>(4, (size_t)4 * G);
     memo_free_max_ = std::max<size_t>(4, (size_t)4 * G);
     const uint32_t P = opts_.concurrent_passes;
+    const uint32_t keep_blocks = opts_.hash_memo_blocks ? std::min<uint32_t>(opts_.hash_memo_blocks, 64u) : 8u;
+    const bool keep_on = opts_.pass_hash_memo >= 0;
+    for (int g = 0; g < G; g++) host_copy_limit(devs_[(size_t)g]->ctx, keep_blocks);
     if (!P) return;
     const size_t block_bytes = opts_.expect_block_bytes ? opts_.expect_block_bytes : (size_t)64 << 20;
     const uint32_t n_tuples = opts_.expect_tuples ? opts_.expect_tuples : 65536u;
@@ -365,8 +370,10 @@ void GPUCSP::Preallocate() const {
     std::vector<std::thread> th;                            // (the devices allocate side by side: 63 MB of device memory per slot takes milliseconds)
     for (int g = 0; g < G; g++) {
         fabgpu_ctx* c = devs_[(size_t)g]->ctx;
-        th.emplace_back([c, block_bytes, n_tx, n_tuples, P] {
+        th.emplace_back([c, block_bytes, n_tx, n_tuples, P, keep_on, keep_blocks] {
             (void)walk_preallocate(c, block_bytes, n_tx, n_tuples, (int)P);
+            // the digest memo keeps a host copy per block until its validators are through: the passes in flight plus two waiting, pinned now
+            if (keep_on) host_copy_preallocate(c, block_bytes, std::min<uint32_t>(keep_blocks, P + 2));
             // The runtime loads a translation unit's code object at the first launch of one of its kernels - 8 ms of a channel's first
             // block when the pass's first launches paid for it.  One launch per unit, now (answers unused: garbage in, statuses out).
             uint8_t msg[64] = {0x30, 0x06, 0x02, 0x01, 0x01, 0x02, 0x01, 0x01}, dig[32], f32[32] = {0}, st1 = 0, code = 0, r32[32], s32[32];
@@ -439,7 +446,7 @@ void GPUCSP::Preallocate() const {
     for (auto& t : th) t.join();
 }
 // where the arrays of a device-built memo table lie in its pinned room (one layout for the pass and for the pre-allocation)
-size_t GPUCSP::MemoPinLayout(uint32_t n_tuples, uint32_t n_creators, uint32_t* slot_cap, size_t* keys_cap, size_t* total, size_t* offs5) {
+size_t GPUCSP::MemoPinLayout(uint32_t n_tuples, uint32_t n_creators, uint32_t* slot_cap, size_t* keys_cap, size_t* total, size_t* offs7) {
     // a slot table of at least twice the tuples, offsets, statuses, digests, and keys of 109 (141 for a pseudonym signature) +
     // signature bytes each - 96 bytes of signature on average are allowed for (an ECDSA signature has <= 72; a block whose keys do
     // not fit gets more room at the end of the pass: WalkRequest::memo_grow)
@@ -448,12 +455,13 @@ size_t GPUCSP::MemoPinLayout(uint32_t n_tuples, uint32_t n_creators, uint32_t* s
     const size_t kc = (size_t)n_tuples * (109 + 96) + (size_t)n_creators * 32 + 256;
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t a_slots = 0, a_off = up256((size_t)cap * 4), a_st = a_off + up256(((size_t)n_tuples + 1) * 4), a_dig = a_st + up256(n_tuples),
-                 a_keys = a_dig + up256((size_t)n_tuples * 32);
+                 a_hslots = a_dig + up256((size_t)n_tuples * 32),      // the digest memo's index: a second slot table, four span words per entry
+                 a_hspans = a_hslots + up256((size_t)cap * 4), a_keys = a_hspans + up256((size_t)n_tuples * 16);
     if (slot_cap) *slot_cap = cap;
     if (keys_cap) *keys_cap = kc;
     if (total) *total = a_keys + up256(kc);
-    if (offs5) {
-        offs5[0] = a_slots; offs5[1] = a_off; offs5[2] = a_st; offs5[3] = a_dig; offs5[4] = a_keys;
+    if (offs7) {
+        offs7[0] = a_slots; offs7[1] = a_off; offs7[2] = a_st; offs7[3] = a_dig; offs7[4] = a_keys; offs7[5] = a_hslots; offs7[6] = a_hspans;
     }
     return a_keys + up256(kc);
 }
@@ -481,6 +489,7 @@ int64_t GPUCSP::ImportIdemixIssuer(const uint8_t* ipk_raw, size_t len, std::stri
     return id;
 }
 GPUCSP::BlockMemo::~BlockMemo() {
+    host_copy_release(&copy);
     if (pin) walk_pinned_free(pin_ctx, pin);
     if (pin_keys) walk_pinned_free(pin_ctx, pin_keys);
 }
@@ -773,7 +782,11 @@ void GPUCSP::CoalescerStats(uint64_t* calls, uint64_t* launches, uint64_t* large
 // ------------------------------------------------------------------------------------------------
 // block-level pre-verify pass (block_prepass.h)
 // ------------------------------------------------------------------------------------------------
-void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len, uint64_t block_seq) const {
+bool GPUCSP::HashMemoEnabled() const {
+    std::lock_guard<std::mutex> lk(opt_mu_);
+    return opts_.pass_hash_memo >= 0;
+}
+void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len, uint64_t block_seq, bool keep_host_copy) const {
     // The pass's device is chosen here - the block travels to it - and counts as busy until the upload object dies (pass_route.h).
     up.owner = this;
     up.dev = RouteBlock(block_seq);
@@ -785,7 +798,9 @@ void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len,
     // With the walk on the device every block is staged ahead - the device route answers a 5-transaction block in 0.63 ms against
     // 0.70 ms on the host walk, a 1 000-transaction block in 0.75 against 1.4 (round-2 probe gpu_dw_tiny.sh, since removed, gpu_dw_small.sh).  Without it
     // (pass_device_walk = 0) small blocks ride with the submission through pinned staging, as before.
-    size_t min_bytes = DeviceWalkEnabled() ? 1 : (size_t)4 << 20;
+    // (a memo-seeding pass is staged whatever the walk: the digest memo needs the library's own copy of the block, which the upload leaves behind)
+    const bool keep = keep_host_copy && HashMemoEnabled();
+    size_t min_bytes = DeviceWalkEnabled() || keep ? 1 : (size_t)4 << 20;
     {
         std::lock_guard<std::mutex> lk(opt_mu_);
         if (opts_.pass_stage_min_bytes > 0) min_bytes = (size_t)opts_.pass_stage_min_bytes;   // tests choose the route with it
@@ -794,7 +809,7 @@ void GPUCSP::StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len,
     fabgpu_ctx* c = devs_[(size_t)up.dev]->ctx;
     BlockUpload* u = &up;
     up.started = true;
-    up.th = std::thread([c, u, block, len] { u->rc = fabgpu_arena_stage(c, block, len, &u->token); });
+    up.th = std::thread([c, u, block, len, keep] { u->rc = keep ? arena_stage_keep(c, block, len, &u->token, &u->copy) : fabgpu_arena_stage(c, block, len, &u->token); });
 }
 
 Error GPUCSP::PreVerifyBlock(const uint8_t* block, size_t len, BlockVerdicts& out, const PassOptions& opt) const {
@@ -834,34 +849,171 @@ uint64_t GPUCSP::MemoHash(const uint8_t* sig, size_t siglen, const uint8_t* dige
     uint64_t h = (a ^ (b * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
     return h ^ (h >> 32);
 }
+// Where this thread's last lookup was answered: the validators ask in the order the block holds its signatures - identity.Verify is
+// Hash(msg) then Verify(k, sig, digest) (msp/identities.go:173-188), a transaction's creator before its endorsements - so the entry a
+// thread needs next is the one it just used (Verify after Hash) or its successor (the next signature of the transaction; entries are in
+// tuple order).  A HINT and nothing more: the hinted entry is compared like any other - every byte of the key / of the message - and a
+// thread that jumps elsewhere (another transaction, another block, a goroutine that moved to another OS thread between two cgo calls)
+// falls through to the table.  What it saves is the misses: the tables were written by DMA and are cold in every cache; a probe into the
+// wrong block's table plus the probe into the right one plus offsets, key, digest and status are eight to ten dependent DRAM round
+// trips per signature, the hinted entry's neighbours are one or two (measured through tools/go_call_replay.c, round 6: DESIGN.md 4.4e).
+namespace {
+struct LookupHint {
+    uint64_t gen = 0;        // BlockMemo::gen of the table (0: none)
+    uint32_t entry = 0;      // 0-based entry
+};
+thread_local LookupHint t_hint;
+std::atomic<uint64_t> g_memo_gen{1};
+inline void prefetch_span(const uint8_t* p, size_t n) {
+    // a message is a few KB: short for the hardware prefetcher to get going (its first lines arrive one DRAM latency apart); asked for
+    // all at once, they arrive together
+    for (size_t o = 0; o < n && o < 8192; o += 64) __builtin_prefetch(p + o, 0, 0);
+}
+}  // namespace
+
 int GPUCSP::MemoLookup(const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen, uint8_t* status,
                        const uint8_t* issuer_hash32) const {
     if (!qx32 || !qy32 || !sig || !digest || siglen == 0 || dlen == 0 || siglen > 1024 || dlen > 1024) return 1;
     uint8_t key[1 + 32 + 64 + 8 + 2048];
     const size_t kl = MemoKeyBytes(siglen, dlen, issuer_hash32 != nullptr);
     MemoKeyWrite(key, issuer_hash32, qx32, qy32, sig, siglen, digest, dlen);
-    const uint64_t h = MemoHash(sig, siglen, digest, dlen);
     std::shared_lock<BigReaderLock> lk(memo_mu_);
-    for (auto it = memo_blocks_.rbegin(); it != memo_blocks_.rend(); ++it) {      // newest block first
-        const BlockMemo& bm = **it;
-        if (!bm.n) continue;
+    // entry e (1-based) of bm holds exactly this key?
+    auto same_entry = [&](const BlockMemo& bm, uint32_t e) {
+        const uint32_t o = bm.key_off_v[e - 1], l = bm.key_off_v[e] - o;
+        return bm.digests_v ? (dlen == 32 && l == kl - 32 && memcmp(bm.keys_v + o, key, l) == 0 && memcmp(bm.digests_v + 32 * (size_t)(e - 1), digest, 32) == 0)
+                            : (l == kl && memcmp(bm.keys_v + o, key, kl) == 0);
+    };
+    auto hit = [&](const BlockMemo& bm, uint32_t e) {
+        if (status) *status = bm.status_v[e - 1];
+        t_hint.gen = bm.gen;
+        t_hint.entry = e - 1;
+        memo_hits_.add(1);
+        // What this thread will most likely ask next is Hash of the NEXT entry's message: its bytes in the block's host copy, its digest
+        // and its key are requested now, so that they travel while the validator builds that message (append(prp, endorser...)) instead of
+        // one DRAM round trip after the other inside the comparison.  (Entry e, 0-based, is the next one; its spans share a cache line
+        // with the spans just used.)
+        if (e < bm.n_entries && bm.hspans_v && bm.copy.p) {
+            const uint32_t* sp = bm.hspans_v + 4 * (size_t)e;
+            if ((uint64_t)sp[0] + sp[1] <= bm.copy.len) prefetch_span(bm.copy.p + sp[0], sp[1]);
+            if ((uint64_t)sp[2] + sp[3] <= bm.copy.len) prefetch_span(bm.copy.p + sp[2], sp[3]);
+            if (bm.digests_v) __builtin_prefetch(bm.digests_v + 32 * (size_t)e, 0, 3);
+            __builtin_prefetch(bm.keys_v + bm.key_off_v[e], 0, 3);
+            __builtin_prefetch(bm.keys_v + bm.key_off_v[e] + 64, 0, 3);
+        }
+        return 0;
+    };
+    const BlockMemo* hinted = nullptr;
+    if (t_hint.gen)
+        for (const auto& b : memo_blocks_)
+            if (b->gen == t_hint.gen) hinted = b.get();
+    if (hinted && hinted->n) {
+        // the entry this thread's Hash just found, or the one behind the entry its last Verify found
+        for (uint32_t e0 = t_hint.entry; e0 <= t_hint.entry + 1 && e0 < hinted->n_entries; e0++)
+            if (hinted->status_v[e0] <= FABGPU_ST_RANGE && same_entry(*hinted, e0 + 1)) return hit(*hinted, e0 + 1);
+    }
+    const uint64_t h = MemoHash(sig, siglen, digest, dlen);
+    auto probe_block = [&](const BlockMemo& bm) -> uint32_t {
+        if (!bm.n) return 0;
         for (uint32_t probe = 0, at = (uint32_t)h & bm.mask; probe <= bm.mask && probe < 4096; probe++, at = (at + 1) & bm.mask) {
             const uint32_t e = bm.slots_v[at];                             // (published under the lock: complete)
             if (!e) break;
             if (e > bm.n_entries) break;                                    // (never: an index past the entries)
-            const uint32_t o = bm.key_off_v[e - 1], l = bm.key_off_v[e] - o;
-            const bool same = bm.digests_v ? (dlen == 32 && l == kl - 32 && memcmp(bm.keys_v + o, key, l) == 0 &&
-                                              memcmp(bm.digests_v + 32 * (size_t)(e - 1), digest, 32) == 0)
-                                           : (l == kl && memcmp(bm.keys_v + o, key, kl) == 0);
-            if (same) {
-                if (status) *status = bm.status_v[e - 1];
-                memo_hits_.add(1);
-                return 0;
-            }
+            if (same_entry(bm, e)) return e;
         }
+        return 0;
+    };
+    if (hinted)
+        if (const uint32_t e = probe_block(*hinted)) return hit(*hinted, e);
+    for (auto it = memo_blocks_.rbegin(); it != memo_blocks_.rend(); ++it) {      // newest block first
+        if (it->get() == hinted) continue;
+        if (const uint32_t e = probe_block(**it)) return hit(**it, e);
     }
     memo_misses_.add(1);
     return 1;
+}
+// bccsp.Hash for bytes a pass has already hashed (bccsp_host.h).  The fingerprint (and the hint above) only choose where to look; what
+// is answered is decided by comparing the caller's bytes with the block's, every one of them.
+int GPUCSP::HashLookup(const uint8_t* msg, size_t len, uint8_t* digest32) const {
+    if (!msg || !digest32 || len < walk::HASH_MEMO_MIN_LEN || len > 0x7FFFFFF0ull) return 1;
+    std::shared_lock<BigReaderLock> lk(memo_mu_);
+    auto usable = [](const BlockMemo& bm) { return bm.n && bm.hslots_v && bm.hspans_v && bm.copy.p; };
+    // entry e0 (0-based) of bm: the device hashed and decided it, and its message is the caller's, byte for byte?
+    auto matches = [&](const BlockMemo& bm, uint32_t e0) {
+        const uint32_t* sp = bm.hspans_v + 4 * (size_t)e0;
+        if ((uint64_t)sp[1] + sp[3] != len) return false;
+        if (bm.status_v[e0] > FABGPU_ST_RANGE) return false;                // a candidate the device did not hash and decide: no digest to hand out
+        // where a span lies on the host: in the copy of the block, or (the orderers' signature messages) in the tail kept beside it
+        auto resolve = [&](uint32_t off, uint32_t l) -> const uint8_t* {
+            if ((uint64_t)off + l <= bm.copy.len) return bm.copy.p + off;
+            if (bm.tail_base && off >= bm.tail_base && (uint64_t)(off - bm.tail_base) + l <= bm.tail.size()) return bm.tail.data() + (off - bm.tail_base);
+            return nullptr;
+        };
+        const uint8_t* a = resolve(sp[0], sp[1]);
+        const uint8_t* b = resolve(sp[2], sp[3]);
+        if (!a || !b) return false;
+        prefetch_span(a, sp[1]);
+        prefetch_span(b, sp[3]);
+        __builtin_prefetch(bm.digests_v ? bm.digests_v + 32 * (size_t)e0 : bm.keys_v + bm.key_off_v[e0 + 1] - 32, 0, 3);
+        return memcmp(msg, a, sp[1]) == 0 && memcmp(msg + sp[1], b, sp[3]) == 0;
+    };
+    auto hit = [&](const BlockMemo& bm, uint32_t e0) {
+        const uint8_t* d = bm.digests_v ? bm.digests_v + 32 * (size_t)e0 : bm.keys_v + bm.key_off_v[e0 + 1] - 32;
+        memcpy(digest32, d, 32);
+        __builtin_prefetch(bm.keys_v + bm.key_off_v[e0], 0, 3);            // (the Verify that follows compares this entry's key)
+        t_hint.gen = bm.gen;
+        t_hint.entry = e0;
+        hash_hits_.add(1);
+        return 0;
+    };
+    const BlockMemo* hinted = nullptr;
+    if (t_hint.gen)
+        for (const auto& b : memo_blocks_)
+            if (b->gen == t_hint.gen) hinted = b.get();
+    if (hinted && !usable(*hinted)) hinted = nullptr;
+    if (hinted) {
+        // the message behind the one this thread asked about last (the next signature of the transaction), or that one again
+        if (t_hint.entry + 1 < hinted->n_entries && matches(*hinted, t_hint.entry + 1)) return hit(*hinted, t_hint.entry + 1);
+        if (t_hint.entry < hinted->n_entries && matches(*hinted, t_hint.entry)) return hit(*hinted, t_hint.entry);
+    }
+    const uint64_t h = walk::msg_fingerprint(msg, (uint32_t)len, nullptr, 0);
+    auto probe_block = [&](const BlockMemo& bm) -> int64_t {
+        uint32_t compared = 0;
+        for (uint32_t probe = 0, at = (uint32_t)h & bm.mask; probe <= bm.mask && probe < 256; probe++, at = (at + 1) & bm.mask) {
+            const uint32_t e = bm.hslots_v[at];
+            if (!e) break;
+            if (e > bm.n_entries) break;                                    // (never: an index past the entries)
+            const uint32_t* sp = bm.hspans_v + 4 * (size_t)(e - 1);
+            if ((uint64_t)sp[1] + sp[3] != len) continue;
+            if (matches(bm, e - 1)) return (int64_t)(e - 1);
+            if (++compared >= walk::HASH_MEMO_MAX_PROBES) break;            // equal lengths and fingerprints, other bytes: a bounded number of tries
+        }
+        return -1;
+    };
+    if (hinted) {
+        const int64_t e0 = probe_block(*hinted);
+        if (e0 >= 0) return hit(*hinted, (uint32_t)e0);
+    }
+    for (auto it = memo_blocks_.rbegin(); it != memo_blocks_.rend(); ++it) {      // newest block first
+        if (it->get() == hinted || !usable(**it)) continue;
+        const int64_t e0 = probe_block(**it);
+        if (e0 >= 0) return hit(**it, (uint32_t)e0);
+    }
+    hash_misses_.add(1);
+    return 1;
+}
+void GPUCSP::HashMemoStats(uint64_t* hits, uint64_t* misses, uint64_t* blocks_held, uint64_t* bytes_held, uint64_t* refused) const {
+    if (hits) *hits = hash_hits_.load();
+    if (misses) *misses = hash_misses_.load();
+    uint64_t h = 0, b = 0, r = 0;
+    for (const auto& d : devs_) {
+        uint64_t dh = 0, db = 0, dr = 0;
+        host_copy_stats(d->ctx, &dh, &db, &dr);
+        h += dh; b += db; r += dr;
+    }
+    if (blocks_held) *blocks_held = h;
+    if (bytes_held) *bytes_held = b;
+    if (refused) *refused = r;
 }
 size_t GPUCSP::MemoHasBlock(uint64_t block_seq) const {
     std::shared_lock<BigReaderLock> lk(memo_mu_);
@@ -876,6 +1028,7 @@ size_t GPUCSP::MemoEvictBlock(uint64_t block_seq) const {
     for (auto b = memo_blocks_.begin(); b != memo_blocks_.end();) {
         if ((*b)->seq != block_seq) { ++b; continue; }
         gone += (*b)->n;
+        (*b)->ReleaseCopy();                                                  // the host copy of the block goes back to its device's pool
         if (memo_free_.size() < memo_free_max_) memo_free_.push_back(*b);     // its buffers serve the next block (lookups hold the shared lock: none in flight here)
         b = memo_blocks_.erase(b);
     }
@@ -997,7 +1150,7 @@ void GPUCSP::RegisterQueued(const std::vector<std::string>& to_register) const {
 }
 
 void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, const PassOptions& opt, std::vector<uint32_t>& sel_scratch,
-                      int gate_max) const {
+                      int gate_max, BlockUpload* up) const {
     const size_t nt = pb.tuples.size();
     // verdict memo: one entry per tuple the device hashed and decided, keyed on (key, signature bytes, device digest).  The block's
     // table is built here, outside the memo lock, by the pass's worker threads; publishing it is one push under the lock.
@@ -1144,11 +1297,65 @@ void GPUCSP::SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts
             bm->status_v = bm->status.data();
             bm->digests_v = nullptr;
             bm->n_entries = m;
+            // The digest memo's index, the host's version of walk_memo_index_kernel: when the block's upload left a host copy of it
+            // (BlockUpload::copy), every entry's message spans and a slot found from walk::msg_fingerprint of the message as it lies in
+            // that copy.  Without a copy the table answers bccsp.Verify only.
+            host_copy_release(&bm->copy);
+            bm->hslots_v = bm->hspans_v = nullptr;
+            bm->tail.clear();
+            bm->tail_base = 0;
+            if (up) (void)up->join();                      // (usually long joined: the submission waited for it)
+            if (up && up->copy.p && HashMemoEnabled()) {
+                try {
+                    const size_t cap = (size_t)bm->mask + 1;
+                    bm->hslots.assign(cap, 0u);
+                    bm->hspans.assign((size_t)m * 4, 0u);
+                    const uint8_t* cp = up->copy.p;
+                    const size_t cl = up->copy.len;
+                    const uint32_t tb = pb.tail_base;
+                    auto resolve = [&](uint32_t off, uint32_t l) -> const uint8_t* {
+                        if ((uint64_t)off + l <= cl) return cp + off;
+                        if (tb && off >= tb && (uint64_t)(off - tb) + l <= pb.tail.size()) return pb.tail.data() + (off - tb);
+                        return nullptr;
+                    };
+                    uint32_t* hs = bm->hslots.data();
+                    uint32_t* sp = bm->hspans.data();
+                    const uint32_t mask = bm->mask;
+                    auto index_some = [&](int w) {
+                        for (size_t e = (size_t)m * w / ft; e < (size_t)m * (w + 1) / ft; e++) {
+                            const BlockTuple& tp = pb.tuples[sel[e]];
+                            const uint8_t* a = resolve(tp.prefix.off, tp.prefix.len);
+                            const uint8_t* b = resolve(tp.suffix.off, tp.suffix.len);
+                            if (!a || !b || (uint64_t)tp.prefix.len + tp.suffix.len < walk::HASH_MEMO_MIN_LEN) continue;   // (spans stay zero: no lookup matches)
+                            sp[4 * e] = tp.prefix.off; sp[4 * e + 1] = tp.prefix.len; sp[4 * e + 2] = tp.suffix.off; sp[4 * e + 3] = tp.suffix.len;
+                            uint32_t at = (uint32_t)walk::msg_fingerprint(a, tp.prefix.len, b, tp.suffix.len) & mask;
+                            for (;;) {
+                                uint32_t expect = 0;
+                                if (__atomic_compare_exchange_n(&hs[at], &expect, (uint32_t)e + 1, false, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) break;
+                                at = (at + 1) & mask;
+                            }
+                        }
+                    };
+                    if (ft == 1) index_some(0);
+                    else run_workers(ft, index_some);
+                    bm->hslots_v = bm->hslots.data();
+                    bm->hspans_v = bm->hspans.data();
+                    bm->copy = up->copy;
+                    up->copy = HostCopy();
+                    if (!pb.tail.empty()) {
+                        bm->tail = pb.tail;
+                        bm->tail_base = pb.tail_base;
+                    }
+                } catch (...) {                            // bad_alloc: the verdict memo stands, the digest memo does not
+                    bm->hslots_v = bm->hspans_v = nullptr;
+                }
+            }
             PublishMemo(bm);
         }
     }
 }
 void GPUCSP::PublishMemo(const std::shared_ptr<BlockMemo>& bm) const {
+    bm->gen = g_memo_gen.fetch_add(1, std::memory_order_relaxed);     // (a recycled table is a new table to every thread's hint)
     std::unique_lock<BigReaderLock> lk(memo_mu_);
     memo_blocks_.push_back(bm);
     size_t total = 0;
@@ -1156,6 +1363,7 @@ void GPUCSP::PublishMemo(const std::shared_ptr<BlockMemo>& bm) const {
     while (total > memo_cap_ && memo_blocks_.size() > 1) {        // bounded: the oldest block goes first
         total -= memo_blocks_.front()->n;
         memo_evicted_.fetch_add(memo_blocks_.front()->n, std::memory_order_relaxed);
+        memo_blocks_.front()->ReleaseCopy();
         if (memo_free_.size() < memo_free_max_) memo_free_.push_back(memo_blocks_.front());
         memo_blocks_.pop_front();
     }
@@ -1406,7 +1614,9 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         fabgpu_ctx* ctx = nullptr;
         BlockMemo* bm = nullptr;
         uint32_t n_creators_hint = 0;
+        bool hash_index = false;          // the upload left a host copy of the block: the device builds the digest memo's index too
     } sz{pb, out, ps, want_tuples, want_digests, want_qxy, host_memo && !msps.empty(), cap_tx, cap_tuples, n_skipped};
+    sz.hash_index = up.copy.p != nullptr && up.copy.len == len && po.pass_hash_memo >= 0;
     std::shared_ptr<BlockMemo> dev_bm;
     if (dev_memo) {
         {
@@ -1490,9 +1700,9 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
         if (z.bm && c.n_tuples) {
             // room for the memo (MemoPinLayout)
             uint32_t cap = 0;
-            size_t keys_cap = 0, total = 0, at[5];
+            size_t keys_cap = 0, total = 0, at[7];
             MemoPinLayout(c.n_tuples, c.n_creators, &cap, &keys_cap, &total, at);
-            const size_t a_slots = at[0], a_off = at[1], a_st = at[2], a_dig = at[3], a_keys = at[4];
+            const size_t a_slots = at[0], a_off = at[1], a_st = at[2], a_dig = at[3], a_keys = at[4], a_hslots = at[5], a_hspans = at[6];
             if (cap >= 2 * (uint64_t)c.n_tuples && keys_cap < 0xFFFFFFF0ull) {
                 if (z.bm->pin_cap < total) {
                     if (z.bm->pin) walk_pinned_free(z.bm->pin_ctx, z.bm->pin);
@@ -1515,6 +1725,13 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
                     z.bm->status_v = o.memo_status;
                     z.bm->digests_v = o.memo_digests;
                     z.bm->keys_v = o.memo_keys;
+                    z.bm->hslots_v = z.bm->hspans_v = nullptr;
+                    if (z.hash_index) {
+                        o.memo_hslots = (uint32_t*)(p + a_hslots);
+                        o.memo_hspans = (uint32_t*)(p + a_hspans);
+                        z.bm->hslots_v = o.memo_hslots;
+                        z.bm->hspans_v = o.memo_hspans;
+                    }
                 }
             }
         }
@@ -1687,13 +1904,27 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
     }
     RegisterQueued(to_register);
     constexpr int gate_max = 16;
-    if (host_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max);
+    if (host_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max, &up);
     if (dev_memo && dev_bm && rq.memo_live && dev_bm->slots_v) {
         auto clk_memo = std::chrono::steady_clock::now();
         dev_bm->seq = opt.block_seq;
         dev_bm->n = rq.memo_live;
         dev_bm->n_entries = rq.memo_n;
         out.memo_seeded = rq.memo_live;
+        // the digest memo: the block's host copy (and the orderers' signature messages, which are not in the block) travel with the table
+        host_copy_release(&dev_bm->copy);
+        dev_bm->tail.clear();
+        dev_bm->tail_base = 0;
+        if (dev_bm->hslots_v && dev_bm->hspans_v && up.copy.p) {
+            dev_bm->copy = up.copy;
+            up.copy = HostCopy();
+            if (rq.tail && rq.tail_len) {
+                dev_bm->tail.assign(rq.tail, rq.tail + rq.tail_len);
+                dev_bm->tail_base = rq.tail_base;
+            }
+        } else {
+            dev_bm->hslots_v = dev_bm->hspans_v = nullptr;
+        }
         PublishMemo(dev_bm);
         dev_bm.reset();                                                    // (published: not for the free list)
         out.ms_memo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk_memo).count();
@@ -2208,7 +2439,7 @@ Error GPUCSP::PreVerifyParsed(const uint8_t* block, const ParsedBlock& pb, Block
                                          : TX_ALL_SIGNATURES_VALID;
     }
     RegisterQueued(to_register);
-    if (opt.seed_memo) SeedMemo(block, pb, out, opt, ps_.sub, gate_max);
+    if (opt.seed_memo) SeedMemo(block, pb, out, opt, ps_.sub, gate_max, up);
     return Error();
 }
 

@@ -133,6 +133,9 @@ struct ProviderOptions {
     int pass_host_counts = 0;          // > 0: count the envelopes' tuples on the host while the block travels (default off)
     int pass_skip_hash_checks = 0;     // > 0: no TxID / proposal-hash digests (A/B timing only; default off)
     int pass_timing = 0;               // > 0: stage breakdown of every pass on stderr (default off)
+    int pass_hash_memo = 0;            // < 0: memo-seeding passes keep no host copy of their block and bccsp.Hash is never answered from the
+                                       // digest memo (default on: HashLookup)
+    uint32_t hash_memo_blocks = 0;     // per device: host copies of blocks kept at a time for the digest memo (0: 8; at most 64)
 };
 constexpr int kMaxProviderDevices = 64;   // contexts per provider (8 GPUs x up to 8 contexts each)
 
@@ -157,6 +160,16 @@ class GPUCSP {
     // key imported through BCCSP.KeyImport; false for keys merely unmarshalled from a flat batch.
     Error KeyImport(const uint8_t* qx32, const uint8_t* qy32, ECDSAPublicKey& out, bool device_table = false) const;
     Error Hash(const uint8_t* msg, size_t len, const HashOpts* opts, std::vector<uint8_t>& digest) const;
+    // bccsp.Hash(msg, &bccsp.SHA256Opts{}) for bytes a memo-seeding pass has ALREADY hashed on the device - the `digest = Hash(msg)` half of
+    // identity.Verify (msp/identities.go:173-181 -> bccsp/sw/impl.go:177-194), which the unchanged validators call once per signature.
+    // The pass keeps the block's bytes in host memory of its own until the block is evicted; each signed message is indexed by a
+    // fingerprint of a few sampled bytes (slot choice only), and the stored digest is handed out ONLY when every byte of `msg` equals the
+    // bytes the device hashed (memcmp, piecewise for prp || endorser).  0: hit, digest32 filled.  1: miss - the caller hashes on the CPU
+    // (always a correct answer).  Never an infrastructure error.
+    int HashLookup(const uint8_t* msg, size_t len, uint8_t* digest32) const;
+    // digest memo counters: lookups answered / left to the CPU, host copies of blocks held right now and their bytes, passes that
+    // wanted a copy and found the pool exhausted
+    void HashMemoStats(uint64_t* hits, uint64_t* misses, uint64_t* blocks_held, uint64_t* bytes_held, uint64_t* refused) const;
     VerifyResult Verify(const ECDSAPublicKey* k, const uint8_t* sig, size_t siglen, const uint8_t* digest, size_t dlen) const;
     Error VerifyBatch(const std::vector<VerifyItem>& items, std::vector<VerifyResult>& results) const;
     Error IdentityVerifyBatch(const std::vector<IdentityItem>& items, std::vector<std::string>& out) const;
@@ -222,6 +235,8 @@ class GPUCSP {
         const uint8_t* block = nullptr;   // what was uploaded (a retry of the same call finds its upload again: bccsp_capi.cpp)
         size_t len = 0;
         uint64_t seq = 0;
+        HostCopy copy;               // keep_host_copy: the block's bytes in memory the device context owns (p == nullptr: none) - handed to
+                                     // the block's memo table when the pass publishes one, released with the upload object otherwise
         uint64_t join() {
             if (th.joinable()) th.join();
             return rc == 0 ? token : 0;
@@ -232,7 +247,9 @@ class GPUCSP {
         ~BlockUpload();
     };
     // Chooses the pass's device (RouteBlock) and, for blocks of pass_stage_min_bytes and more, starts the upload to it.
-    void StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len, uint64_t block_seq = 0) const;
+    // keep_host_copy: the upload leaves the block's bytes in host memory of the context (BlockUpload::copy) for the digest memo.
+    void StartBlockUpload(BlockUpload& up, const uint8_t* block, size_t len, uint64_t block_seq = 0, bool keep_host_copy = false) const;
+    bool HashMemoEnabled() const;
     // An idemix MSP of the channel (msp/idemixmsp.go:99-173 Setup): its creators' pseudonym signatures are then verified by the
     // pre-verify pass too.  ipk_raw: marshalled idemix.IssuerPublicKey.  Returns the device issuer id, or -1 (not accelerated).
     int64_t RegisterIdemixMSP(const std::string& mspid, const uint8_t* ipk_raw, size_t len, const std::string& channel = std::string()) const;
@@ -309,13 +326,15 @@ class GPUCSP {
     mutable std::atomic<uint64_t> pass_relaunches_{0}, pass_decoded_{0}, pass_learned_{0}, pass_general_der_{0};
     void EvictIdentitiesLocked() const;
     void RegisterQueued(const std::vector<std::string>& to_register) const;
-    void SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, const PassOptions& opt, std::vector<uint32_t>& sel_scratch, int gate_max) const;
+    void SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, const PassOptions& opt, std::vector<uint32_t>& sel_scratch, int gate_max,
+                  BlockUpload* up = nullptr) const;
     // verdict memo
     // One table per BLOCK (seeded once by the pass, dropped whole when the block's validation returns): an open-addressed index over
     // length-framed keys stored back to back - no allocation per entry, filled by the pass's worker threads in parallel (a
     // 10 000-transaction block seeds 40 000 entries; a node-per-entry map cost more than the device call).  Lookups take a shared lock.
     struct BlockMemo {
         uint64_t seq = 0;
+        uint64_t gen = 0;                                 // unique per publication (the lookups' per-thread hints name a table by it)
         uint32_t n = 0, mask = 0;
         std::unique_ptr<std::atomic<uint32_t>[]> slots;   // entry index + 1; 0 = empty
         std::vector<uint32_t> key_off;                    // n + 1 offsets into keys
@@ -333,6 +352,20 @@ class GPUCSP {
         // them); it may hold entries without a slot (candidates that were not decided: status 255) - n counts the ones with a slot
         const uint8_t* digests_v = nullptr;
         uint32_t n_entries = 0;
+        // The block's DIGEST memo (HashLookup): the block's bytes in host memory of a device context (`copy`; the orderers' signature
+        // messages, which are not in the block, in `tail` at virtual offset tail_base), per entry the two spans of its signed message,
+        // and a second slot table over walk::msg_fingerprint of the message.  Device-built tables: hslots_v / hspans_v point into `pin`;
+        // host-built ones into the two vectors.  No copy, no index: every lookup misses.
+        const uint32_t* hslots_v = nullptr;
+        const uint32_t* hspans_v = nullptr;
+        std::vector<uint32_t> hslots, hspans;
+        HostCopy copy;
+        std::vector<uint8_t> tail;
+        uint32_t tail_base = 0;
+        void ReleaseCopy() {
+            host_copy_release(&copy);
+            hslots_v = hspans_v = nullptr;
+        }
         void* pin = nullptr;
         size_t pin_cap = 0;
         void* pin_keys = nullptr;                         // room of its own for the keys of a block whose signatures are far longer than usual
@@ -348,7 +381,8 @@ class GPUCSP {
     mutable size_t memo_cap_ = (size_t)1 << 18;
     mutable ShardedCounter memo_hits_, memo_misses_;      // (bumped per lookup by every validator thread)
     mutable std::atomic<uint64_t> memo_evicted_{0};
-    static size_t MemoPinLayout(uint32_t n_tuples, uint32_t n_creators, uint32_t* slot_cap, size_t* keys_cap, size_t* total, size_t* offs5 = nullptr);
+    static size_t MemoPinLayout(uint32_t n_tuples, uint32_t n_creators, uint32_t* slot_cap, size_t* keys_cap, size_t* total, size_t* offs7 = nullptr);
+    mutable ShardedCounter hash_hits_, hash_misses_;
     static size_t MemoKeyBytes(size_t siglen, size_t dlen, bool nym) { return 1 + (nym ? 32 : 0) + 64 + 4 + siglen + 4 + dlen; }
     static void MemoKeyWrite(uint8_t* out, const uint8_t* issuer_hash32, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,
                              const uint8_t* digest, size_t dlen);

@@ -829,6 +829,34 @@ inline uint64_t id_hash_host(const uint8_t* p, uint32_t len, uint64_t seed = 0) 
     return id_hash_finish(sum, len);
 }
 
+// ---- the block's DIGEST memo (bccsp_host.h BlockMemo "digest memo"; bccsp.Hash of bytes a pass has already hashed) ----------------
+// Slot choice only - a hit is decided by comparing EVERY byte of the caller's message with the block's: the length and eight 8-byte
+// samples spread evenly from the first to the last byte of the message a || b (b may be empty).  Endorsement messages of one
+// transaction share their first kilobyte (prp) and their last bytes (the PEM trailer of the endorser's certificate), which is why
+// first-and-last-bytes alone would not do; samples in between land in the certificates' bodies.  The same lines run on the device
+// (walk_memo_index_kernel, over the two spans of a tuple) and on the host (GPUCSP::HashLookup, over the caller's contiguous bytes).
+WALK_HD inline uint64_t msg_fingerprint(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen) {
+    const uint64_t n = (uint64_t)alen + blen;
+    uint64_t h = (n + 1) * 0x9E3779B97F4A7C15ull;
+    auto at = [&](uint64_t pos) -> uint64_t { return pos < alen ? a[pos] : b[pos - alen]; };
+    if (n < 8) {
+        for (uint64_t j = 0; j < n; j++) h = (h ^ at(j)) * 0x100000001B3ull;
+        return h ^ (h >> 32);
+    }
+    for (uint64_t k = 0; k < 8; k++) {
+        const uint64_t p = (n - 8) * k / 7;
+        uint64_t w = 0;
+        for (uint64_t j = 0; j < 8; j++) w |= at(p + j) << (8 * j);
+        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+        h ^= h >> 29;
+    }
+    return h ^ (h >> 32);
+}
+// messages shorter than this are not worth a lookup (one SHA-256 block costs less than the call); the C ABI answers "miss"
+constexpr uint32_t HASH_MEMO_MIN_LEN = 64;
+// entries with one fingerprint a lookup compares before it gives up (a sender can craft equal fingerprints; it cannot make a lookup expensive)
+constexpr uint32_t HASH_MEMO_MAX_PROBES = 16;
+
 }  // namespace walk
 }  // namespace bccsp
 }  // namespace fab

@@ -175,6 +175,11 @@ struct WalkArrays {
     uint8_t* memo_status = nullptr;            // by entry (255: a candidate that was not decided - it has no slot)
     uint8_t* memo_digests = nullptr;           // 32 bytes by entry
     uint32_t* memo_ent = nullptr;              // by tuple: its entry, ~0 = none
+    // ... and its DIGEST memo (bccsp.Hash of bytes this pass hashed): by entry the two spans of the signed message (prefix offset, length,
+    // suffix offset, length - into the block / its tail), and a second slot table of the same size over walk::msg_fingerprint of the
+    // message's bytes (entry index + 1).  Every candidate gets a slot, early; a lookup skips entries whose status says "not decided".
+    uint32_t* memo_hspans = nullptr;           // 4 per entry (null: no digest memo)
+    uint32_t* memo_hslots = nullptr;
     struct WalkMemoTotals* memo_totals = nullptr;
     const uint8_t* issuer_hashes = nullptr;    // 32 bytes per idemix MSP of idemix_msps: ipk.Hash of its issuer (a pseudonym entry is bound to it)
     uint8_t* tuple_qxy = nullptr;              // by tuple, 64 bytes: the key of a P-256 identity, zeros otherwise (null: not wanted)
@@ -257,6 +262,8 @@ struct WalkOut {
     size_t memo_keys_cap = 0;
     uint8_t* memo_status = nullptr;       // n_tuples
     uint8_t* memo_digests = nullptr;      // 32 n_tuples: the digest of entry e (the keys end with the digest's length field)
+    uint32_t* memo_hspans = nullptr;      // optional, with memo_hslots: 4 n_tuples - the digest memo's message spans by entry ...
+    uint32_t* memo_hslots = nullptr;      // ... and its slot table, memo_slot_cap entries
 };
 struct WalkRequest {
     uint64_t stage_token = 0;             // the block, uploaded with fabgpu_arena_stage
@@ -296,6 +303,22 @@ struct WalkRequest {
 };
 // FABGPU_OK, WALK_DECLINED, or a negative FABGPU_E*
 int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq);
+// The block's bytes in HOST memory the context owns, kept after the upload (fabgpu_arena_stage copies a block through pinned staging
+// anyway: with `keep` that staging buffer comes out of a small pool and stays with the caller until host_copy_release).  What the
+// digest memo compares a bccsp.Hash caller's bytes with: nothing of the CALLER's block is retained past the call (cgo pointer rules).
+// p == nullptr after the call: the pool had no buffer to spare (the upload itself went through; the block simply has no digest memo).
+struct HostCopy {
+    fabgpu_ctx* ctx = nullptr;
+    int idx = -1;
+    const uint8_t* p = nullptr;
+    size_t len = 0;
+};
+int arena_stage_keep(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token, HostCopy* keep);
+void host_copy_release(HostCopy* c);
+// at most `blocks` kept copies per context (default 8; each as large as its block)
+void host_copy_limit(fabgpu_ctx* ctx, uint32_t blocks);
+void host_copy_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n);
+void host_copy_stats(fabgpu_ctx* ctx, uint64_t* held, uint64_t* bytes_held, uint64_t* refused);
 // allocate now what `slots` overlapping passes over blocks of up to these sizes will need on this device (best effort)
 int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_t n_tuples, int slots);
 double walk_warm_copies(fabgpu_ctx* ctx, void* const* pinned, const size_t* bytes, int n);

@@ -1033,6 +1033,30 @@ __global__ void __launch_bounds__(256) walk_memo_write_kernel(WalkArrays a) {
     pos += t.sig.len;
     if (lane < 4) k[pos + lane] = lane == 0 ? 32 : 0;
 }
+// EARLY too: the DIGEST memo's index (bccsp_host.h BlockMemo; GPUCSP::HashLookup reads it) - one lane per candidate: the two spans of its
+// signed message by entry, and a slot in the second table found from walk::msg_fingerprint of the message's bytes as they lie in the
+// block (the lines the host runs over a bccsp.Hash caller's bytes).  Every candidate, decided or not: whether an entry's digest may be
+// handed out is its status byte's business (255 = not decided, written by the late half), checked by the lookup.
+__global__ void __launch_bounds__(256) walk_memo_index_kernel(WalkArrays a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_tuples) return;
+    const uint32_t e = a.memo_ent[i];
+    if (e == 0xFFFFFFFFu) return;
+    const BlockTuple t = a.tuples[i];
+    // (spans the walk emitted lie inside the arena; anything else gets spans no lookup can match and no slot)
+    const bool inside = t.prefix.off <= a.arena_len && t.prefix.len <= a.arena_len - t.prefix.off && t.suffix.off <= a.arena_len &&
+                        t.suffix.len <= a.arena_len - t.suffix.off && (uint64_t)t.prefix.len + t.suffix.len >= bccsp::walk::HASH_MEMO_MIN_LEN;
+    uint32_t* sp = a.memo_hspans + 4 * (size_t)e;
+    sp[0] = inside ? t.prefix.off : 0u;
+    sp[1] = inside ? t.prefix.len : 0u;
+    sp[2] = inside ? t.suffix.off : 0u;
+    sp[3] = inside ? t.suffix.len : 0u;
+    if (!inside) return;
+    const uint64_t h = bccsp::walk::msg_fingerprint(a.block + t.prefix.off, t.prefix.len, a.block + t.suffix.off, t.suffix.len);
+    uint32_t at = (uint32_t)h & a.memo_mask;
+    for (uint32_t probe = 0; probe <= a.memo_mask; probe++, at = (at + 1) & a.memo_mask)
+        if (atomicCAS(&a.memo_hslots[at], 0u, e + 1) == 0u) break;
+}
 // LATE: one lane per tuple - a candidate that was hashed and decided gets its digest, its status byte and its place in the slot table
 // (GPUCSP::MemoHash, linear probing, entry index + 1); the others get status 255 and no slot.
 __global__ void __launch_bounds__(256) walk_memo_late_kernel(WalkArrays a) {
@@ -1122,6 +1146,9 @@ hipError_t launch_walk_memo_early(const WalkArrays& a, hipStream_t st) {
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(walk_memo_write_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess || !a.memo_hspans || !a.memo_hslots) return e;
+    hipLaunchKernelGGL(walk_memo_index_kernel, dim3((a.n_tuples + 255) / 256), dim3(256), 0, st, a);   // (memo_hslots zeroed by the caller)
     return hipGetLastError();
 }
 hipError_t launch_walk_memo_late(const WalkArrays& a, hipStream_t st) {
@@ -1154,7 +1181,7 @@ hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStre
 int warm_kernel_functions_walk() {
     int ok = 0;
     hipFuncAttributes a;
-    const void* fns[] = {(const void*)walk_status_finish_small_kernel, (const void*)walk_status_checks_kernel, (const void*)walk_scan_kernel, (const void*)walk_nym_pack_kernel, (const void*)walk_memo_write_kernel, (const void*)walk_memo_scan_kernel, (const void*)walk_memo_len_kernel, (const void*)walk_memo_late_kernel, (const void*)walk_idfix_probe_kernel, (const void*)walk_gate_probe_kernel, (const void*)walk_gate_kernel, (const void*)walk_finish_kernel, (const void*)walk_emit_kernel, (const void*)walk_creator_digest_kernel, (const void*)walk_count_staged_kernel, (const void*)walk_count_kernel};
+    const void* fns[] = {(const void*)walk_status_finish_small_kernel, (const void*)walk_status_checks_kernel, (const void*)walk_scan_kernel, (const void*)walk_nym_pack_kernel, (const void*)walk_memo_write_kernel, (const void*)walk_memo_index_kernel, (const void*)walk_memo_scan_kernel, (const void*)walk_memo_len_kernel, (const void*)walk_memo_late_kernel, (const void*)walk_idfix_probe_kernel, (const void*)walk_gate_probe_kernel, (const void*)walk_gate_kernel, (const void*)walk_finish_kernel, (const void*)walk_emit_kernel, (const void*)walk_creator_digest_kernel, (const void*)walk_count_staged_kernel, (const void*)walk_count_kernel};
     for (const void* f : fns) ok += hipFuncGetAttributes(&a, f) == hipSuccess ? 1 : 0;
     return ok;
 }

@@ -9,6 +9,8 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <sys/mman.h>
+#include <set>
 #include <mutex>
 #include <new>
 #include <map>
@@ -65,22 +67,56 @@ struct DevBuf {  // growable device-only buffer
         cap = 0;
     }
 };
+// Pinned host memory on 2 MiB pages, for tables and block copies that the HOST reads at random (the verdict / digest memo: every
+// validator thread, every signature): transparent huge pages where the kernel grants them on request (THP "madvise" or "always"),
+// registered with the runtime so that DMA treats it like hipHostMalloc'd memory.  A memo lookup touches a handful of places in a few
+// tens of MB that DMA wrote - cold in every cache AND, on 4 KiB pages, in every TLB: each touch then pays for a page walk whose
+// entries are cold as well.  nullptr: not available here (the caller falls back to hipHostMalloc).
+static void* pinned_huge_alloc(size_t bytes) {
+    constexpr size_t huge = (size_t)2 << 20;
+    const size_t want = (bytes + huge - 1) & ~(huge - 1);
+    void* p = nullptr;
+    if (posix_memalign(&p, huge, want) != 0 || !p) return nullptr;
+    (void)madvise(p, want, MADV_HUGEPAGE);
+    for (size_t o = 0; o < want; o += 4096) ((volatile uint8_t*)p)[o] = 0;      // fault the pages in now (huge ones where granted), not inside a pass
+    if (hipHostRegister(p, want, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        free(p);
+        return nullptr;
+    }
+    return p;
+}
+static void pinned_huge_free(void* p) {
+    if (!p) return;
+    (void)hipHostUnregister(p);
+    free(p);
+}
+
 struct PinBuf {  // growable pinned host buffer
     void* h = nullptr;
     size_t cap = 0;
     unsigned flags = hipHostMallocDefault;
+    bool want_huge = false;   // try 2 MiB pages first (pinned_huge_alloc)
+    bool is_huge = false;
     int ensure(size_t bytes) {
         if (bytes <= cap) return FABGPU_OK;
         release();
         size_t want = bytes + bytes / 4 + 256;
+        if (want_huge && (h = pinned_huge_alloc(want)) != nullptr) {
+            is_huge = true;
+            cap = want;
+            return FABGPU_OK;
+        }
         if (hipHostMalloc(&h, want, flags) != hipSuccess) { h = nullptr; return FABGPU_ENOMEM; }
         cap = want;
         return FABGPU_OK;
     }
     void release() {
-        if (h) hipHostFree(h);
+        if (h && is_huge) pinned_huge_free(h);
+        else if (h) hipHostFree(h);
         h = nullptr;
         cap = 0;
+        is_huge = false;
     }
 };
 
@@ -172,6 +208,21 @@ struct fabgpu_ctx {
     DevBuf walk_env, walk_tup, idtab_buf;
     PinBuf stage_pin;                // fabgpu_arena_stage: pinned staging of arenas that arrive in pageable memory
     std::mutex stage_pin_mu;
+    // arena_stage_keep: staging buffers that STAY with the caller after the upload (block_walk_dev.h HostCopy - the host copy of a block
+    // the provider's digest memo compares bccsp.Hash callers' bytes with, until the block's validation has returned).  A small pool:
+    // buffers are made on demand up to keep_max, handed back by host_copy_release, and reused (pinning 64 MiB costs milliseconds).
+    struct KeepBuf {
+        PinBuf pin;
+        bool in_use = false;
+        KeepBuf() {
+            pin.flags = hipHostMallocPortable;
+            pin.want_huge = true;                 // read by the validators' threads, a few KB at 40 000 random places per block
+        }
+    };
+    std::mutex keep_mu;
+    std::vector<std::unique_ptr<KeepBuf>> keep_pool;
+    uint32_t keep_max = 8;
+    uint64_t keep_refused = 0;
     // The copiers of this context's uploads: threads of its own (made with the first big upload), so that the uploads of a provider's G
     // devices - each behind its own PCIe link - run side by side instead of taking turns on the process-wide pool of the host passes.
     std::unique_ptr<WorkerPool> stage_pool;
@@ -385,6 +436,8 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         for (auto sc : ctx->stream_copy_more)
             if (sc) hipStreamDestroy(sc);
         ctx->stage_pin.release();
+        for (auto& k : ctx->keep_pool) k->pin.release();
+        ctx->keep_pool.clear();
         for (auto& e : ctx->ev_w)
             if (e) hipEventDestroy(e);
         ctx->gath.release();
@@ -1080,7 +1133,100 @@ int fabgpu_identity_verify_batch_dev(fabgpu_ctx* ctx, const fabgpu_identity_batc
     return hip_to_rc(err);
 }
 
-int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token) {
+}  // extern "C"
+
+static int keep_acquire(fabgpu_ctx* ctx, size_t len);
+namespace fab {
+// `n` pool buffers of block_bytes each, pinned now (provider construction) instead of inside the first passes' uploads
+void host_copy_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n) {
+    if (!ctx || !block_bytes) return;
+    DeviceGuard g(ctx->device);
+    std::vector<int> got;
+    for (uint32_t i = 0; i < n; i++) {
+        const int idx = keep_acquire(ctx, block_bytes);
+        if (idx < 0) break;
+        got.push_back(idx);
+    }
+    std::lock_guard<std::mutex> lk(ctx->keep_mu);
+    for (int idx : got) ctx->keep_pool[(size_t)idx]->in_use = false;
+    ctx->keep_refused = 0;
+}
+void host_copy_release(HostCopy* c) {
+    if (!c || !c->ctx || c->idx < 0) {
+        if (c) *c = HostCopy();
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->ctx->keep_mu);
+        if ((size_t)c->idx < c->ctx->keep_pool.size()) c->ctx->keep_pool[(size_t)c->idx]->in_use = false;
+    }
+    *c = HostCopy();
+}
+void host_copy_limit(fabgpu_ctx* ctx, uint32_t blocks) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->keep_mu);
+    ctx->keep_max = blocks > 64 ? 64 : blocks;
+}
+void host_copy_stats(fabgpu_ctx* ctx, uint64_t* held, uint64_t* bytes_held, uint64_t* refused) {
+    uint64_t h = 0, b = 0, r = 0;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->keep_mu);
+        for (const auto& k : ctx->keep_pool)
+            if (k->in_use) {
+                h++;
+                b += k->pin.cap;
+            }
+        r = ctx->keep_refused;
+    }
+    if (held) *held = h;
+    if (bytes_held) *bytes_held = b;
+    if (refused) *refused = r;
+}
+}  // namespace fab
+
+// a buffer of the keep pool with room for `len` bytes, marked in use; -1: none to spare (or fault injection "oom")
+static int keep_acquire(fabgpu_ctx* ctx, size_t len) {
+    if (ctx->fault == 2) return -1;
+    int idx = -1;
+    {
+        std::lock_guard<std::mutex> lk(ctx->keep_mu);
+        if (ctx->keep_pool.capacity() < 64) ctx->keep_pool.reserve(64);   // (holders read their entry without the lock: the array never moves)
+        // a free buffer that is already large enough, else any free one, else a new one while the pool may grow
+        for (size_t i = 0; i < ctx->keep_pool.size() && idx < 0; i++)
+            if (!ctx->keep_pool[i]->in_use && ctx->keep_pool[i]->pin.cap >= len) idx = (int)i;
+        for (size_t i = 0; i < ctx->keep_pool.size() && idx < 0; i++)
+            if (!ctx->keep_pool[i]->in_use) idx = (int)i;
+        if (idx < 0 && ctx->keep_pool.size() < ctx->keep_max) {
+            ctx->keep_pool.emplace_back(new fabgpu_ctx::KeepBuf);
+            idx = (int)ctx->keep_pool.size() - 1;
+        }
+        if (idx < 0) {
+            ctx->keep_refused++;
+            return -1;
+        }
+        ctx->keep_pool[(size_t)idx]->in_use = true;
+    }
+    // (pinning outside the pool's lock: the buffer is ours)
+    if (ctx->keep_pool[(size_t)idx]->pin.ensure(len) != FABGPU_OK) {
+        std::lock_guard<std::mutex> lk(ctx->keep_mu);
+        ctx->keep_pool[(size_t)idx]->in_use = false;
+        ctx->keep_refused++;
+        return -1;
+    }
+    return idx;
+}
+
+static int arena_stage_impl(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token, fab::HostCopy* keep);
+
+extern "C" int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token) { return arena_stage_impl(ctx, arena, len, token, nullptr); }
+namespace fab {
+int arena_stage_keep(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token, HostCopy* keep) {
+    if (keep) *keep = HostCopy();
+    return arena_stage_impl(ctx, arena, len, token, keep);
+}
+}  // namespace fab
+
+static int arena_stage_impl(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t* token, fab::HostCopy* keep) {
     if (!ctx || !arena || !token || len == 0) return FABGPU_EINVAL;
     if (len > 0xFFFFFF00ull) return FABGPU_ETOOBIG;
     // the least recently filled slot nobody is using; all in use: wait for the oldest
@@ -1102,6 +1248,18 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
     }
     if (!slot_lk.owns_lock()) slot_lk = std::unique_lock<std::mutex>(sl->m);
     DeviceGuard g(ctx->device);
+    // the caller keeps a host copy: the bytes go through a pool buffer that is then his (whatever the arena's size)
+    const int keep_idx = keep ? keep_acquire(ctx, len) : -1;
+    struct KeepBack {                                      // an early exit hands the buffer back
+        fabgpu_ctx* c;
+        int idx;
+        ~KeepBack() {
+            if (idx < 0) return;
+            std::lock_guard<std::mutex> lk(c->keep_mu);
+            c->keep_pool[(size_t)idx]->in_use = false;
+        }
+    } keep_back{ctx, keep_idx};
+    uint8_t* const keep_pin = keep_idx >= 0 ? (uint8_t*)ctx->keep_pool[(size_t)keep_idx]->pin.h : nullptr;
     const size_t need = round_up(len, 64) + 128;          // + room for a batch's tail (fabgpu_identity_batch.tail) in the slack below
     sl->token.store(0);                                    // the previous upload is gone from here on
     sl->len = 0;
@@ -1124,10 +1282,15 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
     constexpr int stage_threads = 4;             // measured from 0 (the runtime's pageable path) to 16 in rounds 2-3; no difference from two up
     hipError_t err = hipSuccess;
     if (stage_threads == 0 || len < ((size_t)4 << 20)) {
-        err = hipMemcpy(sl->d, arena, len, hipMemcpyHostToDevice);
+        if (keep_pin) {                                                    // a small arena somebody keeps: one copy, then the DMA from pinned memory
+            memcpy(keep_pin, arena, len);
+            err = hipMemcpy(sl->d, keep_pin, len, hipMemcpyHostToDevice);
+        } else {
+            err = hipMemcpy(sl->d, arena, len, hipMemcpyHostToDevice);
+        }
     } else {
-        std::lock_guard<std::mutex> plk(ctx->stage_pin_mu);              // one staging buffer: uploads share the bus anyway
-        if (ctx->fault == 2 || ctx->stage_pin.ensure(len) != FABGPU_OK) return FABGPU_ENOMEM;
+        std::lock_guard<std::mutex> plk(ctx->stage_pin_mu);              // one upload at a time per device: uploads share the bus anyway
+        if (ctx->fault == 2 || (!keep_pin && ctx->stage_pin.ensure(len) != FABGPU_OK)) return FABGPU_ENOMEM;
         // pieces: 256 KiB, 512 KiB, 1 MiB, then 2 MiB each - the first DMA starts after 25 us of copying instead of 200
         std::vector<size_t> cut;
         constexpr size_t max_piece = (size_t)2048 << 10;
@@ -1139,7 +1302,7 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
         for (size_t k = 0; k < n_pieces; k++) done[k].store(0, std::memory_order_relaxed);
         int failed = 0;
         uint8_t* dst = (uint8_t*)sl->d;
-        uint8_t* pin = (uint8_t*)ctx->stage_pin.h;
+        uint8_t* pin = keep_pin ? keep_pin : (uint8_t*)ctx->stage_pin.h;
         const uint8_t* src = (const uint8_t*)arena;
         // Pieces go round-robin over four upload queues so that one piece's set-up overlaps another's transfer:
         // measured (round 3, 48.6 MB) 1.33 ms with one queue, 1.23 with two, 1.13 with four - 43 GB/s; the
@@ -1189,8 +1352,17 @@ int fabgpu_arena_stage(fabgpu_ctx* ctx, const void* arena, size_t len, uint64_t*
     }
     sl->token.store(t);
     *token = t;
+    if (keep && keep_idx >= 0) {
+        keep->ctx = ctx;
+        keep->idx = keep_idx;
+        keep->p = keep_pin;
+        keep->len = len;
+        keep_back.idx = -1;                                // (the caller's now: host_copy_release)
+    }
     return FABGPU_OK;
 }
+
+extern "C" {
 
 int fabgpu_identity_verify_batch(fabgpu_ctx* ctx, const fabgpu_identity_batch* b) {
     if (!ctx || !b) return FABGPU_EINVAL;
@@ -1782,6 +1954,9 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     const size_t o_ment = carve(memo ? (size_t)nt * 4 : 0), o_mslots = carve(memo ? (size_t)out.memo_slot_cap * 4 : 0),
                  o_mkoff = carve(memo ? ((size_t)nt + 1) * 4 : 0), o_mkeys = carve(memo ? dev_keys_cap : 0), o_mst = carve(memo ? nt : 0),
                  o_mtot = carve(memo ? sizeof(WalkMemoTotals) : 0), o_mdig = carve(memo ? (size_t)nt * 32 : 0);
+    // ... and the digest memo's index beside it (message spans by entry + a second slot table), if the caller gave room for that too
+    const bool hmemo = memo && out.memo_hspans && out.memo_hslots;
+    const size_t o_mhsp = carve(hmemo ? (size_t)nt * 16 : 0), o_mhsl = carve(hmemo ? (size_t)out.memo_slot_cap * 4 : 0);
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
     a.tuples = (bccsp::BlockTuple*)(dt + o_tup);
@@ -1841,6 +2016,10 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         a.memo_status = dt + o_mst;
         a.memo_totals = (WalkMemoTotals*)(dt + o_mtot);
         a.memo_digests = dt + o_mdig;
+        if (hmemo) {
+            a.memo_hspans = (uint32_t*)(dt + o_mhsp);
+            a.memo_hslots = (uint32_t*)(dt + o_mhsl);
+        }
         if (n_msps && rq.idemix_issuer_hashes) a.issuer_hashes = de + o_ihash;
     }
     a.dev_status = dt + o_dst;
@@ -2059,13 +2238,16 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     }
     mark("side streams queued");
     if (err == hipSuccess && memo_early_pending) {
-        err = hipStreamWaitEvent(s4, ctx->ev_w[7], 0);
+        if (hmemo) err = hipMemsetAsync(dt + o_mhsl, 0, (size_t)out.memo_slot_cap * 4, s4);   // (ahead of the wait for the gates)
+        if (err == hipSuccess) err = hipStreamWaitEvent(s4, ctx->ev_w[7], 0);
         if (err == hipSuccess) err = launch_walk_memo_early(a, s4);
         mark("memo early launched");
         if (err == hipSuccess) err = hipMemcpyAsync(out.memo_key_off, dt + o_mkoff, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, s4);
         mark("memo key_off copy queued");
         if (err == hipSuccess) err = hipMemcpyAsync(out.memo_keys, dt + o_mkeys, out.memo_keys_cap, hipMemcpyDeviceToHost, s4);
         mark("memo keys copy queued");
+        if (err == hipSuccess && hmemo) err = hipMemcpyAsync(out.memo_hspans, dt + o_mhsp, (size_t)nt * 16, hipMemcpyDeviceToHost, s4);
+        if (err == hipSuccess && hmemo) err = hipMemcpyAsync(out.memo_hslots, dt + o_mhsl, (size_t)out.memo_slot_cap * 4, hipMemcpyDeviceToHost, s4);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[8], s4);
     }
     // The block's idemix creators: ONE nym launch over their rows, packed (walk_nym_pack_kernel: 2 000 idemix creators among 10 000 are
@@ -2357,7 +2539,7 @@ int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_
     const size_t ne = n_tx, nt = n_tuples;
     // upper bounds of walk_block_pass's carves: per envelope 91 bytes of arrays + the count kernel's record slot, per tuple ~1.9 KB with the memo's key room (1 165 bytes)
     if (ctx->walk_env.ensure(ne * (128 + sizeof(bccsp::walk::EnvStash)) + ((size_t)256 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
-    if (ctx->walk_tup.ensure(nt * 2048 + ne * 256 + ((size_t)1 << 20)) != FABGPU_OK) rc = FABGPU_ENOMEM;
+    if (ctx->walk_tup.ensure(nt * 2112 + ne * 256 + ((size_t)1 << 20)) != FABGPU_OK) rc = FABGPU_ENOMEM;
     if (ctx->walk_pin.ensure(nt * 256 + ne * 160 + ((size_t)256 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
     if (ctx->walk_map.ensure(nt * 8 + ne * 8 + sizeof(WalkLearn) * WALK_LEARN_SLOTS + ((size_t)64 << 10)) != FABGPU_OK) rc = FABGPU_ENOMEM;
     const size_t gscr = ne * 4096 + ((size_t)64 << 10);                         // TxID + proposal-hash inputs: a few KB per transaction
@@ -2448,14 +2630,22 @@ int key_register_many_prebuilt(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx
     return key_register_many_impl(ctxs, n, qx32, qy32, table, key_ids);
 }
 
+static std::mutex g_huge_mu;
+static std::set<void*> g_huge_tables;      // memo tables that came from pinned_huge_alloc (the others from hipHostMalloc)
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes) {
     if (!ctx || bytes == 0) return nullptr;
     DeviceGuard g(ctx->device);
     static const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    void* p = nullptr;
-    // (portable: a memo table is recycled by whichever device of the provider's pool runs the next pass)
-    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+    // (portable: a memo table is recycled by whichever device of the provider's pool runs the next pass; on huge pages where the kernel
+    //  grants them: the table is probed at random by every validator thread)
+    void* p = pinned_huge_alloc(bytes);
+    if (p) {
+        std::lock_guard<std::mutex> lk(g_huge_mu);
+        g_huge_tables.insert(p);
+    } else if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        return nullptr;
+    }
     if (timing) fprintf(stderr, "fabgpu: %.1f MB of pinned memory for a memo table in %.2f ms\n", bytes / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return p;
 }
@@ -2464,7 +2654,13 @@ void walk_pinned_free(fabgpu_ctx* ctx, void* p) {
     static const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGuard g(ctx->device);
-    (void)hipHostFree(p);
+    bool huge = false;
+    {
+        std::lock_guard<std::mutex> lk(g_huge_mu);
+        huge = g_huge_tables.erase(p) != 0;
+    }
+    if (huge) pinned_huge_free(p);
+    else (void)hipHostFree(p);
     if (timing) fprintf(stderr, "fabgpu: a memo table's pinned memory freed in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
 

@@ -421,4 +421,8 @@ int hosttest_route_block(uint64_t block_seq, const uint32_t* in_flight, int n_de
 int hosttest_cert_key_offset_window(const uint8_t* der, size_t avail, size_t len) {
     return (int)bccsp::walk::cert_der_p256_key_offset_window(der, avail, len);
 }
+// the digest memo's slot choice (block_walk_core.h msg_fingerprint) over the message a || b
+uint64_t fabgpu_hosttest_msg_fingerprint(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen) {
+    return bccsp::walk::msg_fingerprint(a, alen, b, blen);
+}
 }

@@ -82,7 +82,8 @@ class _CspOpts(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint32), ("n_devices", ctypes.c_int32), ("devices", ctypes.POINTER(ctypes.c_int32)), ("ctx_flags", ctypes.c_uint32),
                 ("concurrent_passes", ctypes.c_uint32), ("expect_block_bytes", ctypes.c_uint64), ("expect_tuples", ctypes.c_uint32),
                 ("pass_device_walk", ctypes.c_int32), ("pass_stage_min_bytes", ctypes.c_int64), ("pass_device_memo", ctypes.c_int32),
-                ("pass_host_counts", ctypes.c_int32), ("pass_timing", ctypes.c_int32)]
+                ("pass_host_counts", ctypes.c_int32), ("pass_timing", ctypes.c_int32), ("pass_hash_memo", ctypes.c_int32),
+                ("hash_memo_blocks", ctypes.c_uint32)]
 
 
 class _Cfg(ctypes.Structure):
@@ -114,6 +115,7 @@ ABI_SYMBOLS = [
     "fabgpu_gate_sig_any", "fabgpu_identity_to_p256", "fabgpu_csp_idfix_probe", "fabgpu_csp_pass_stats",
     "fabgpu_p256_key_register_many", "fabgpu_csp_new2", "fabgpu_csp_device_count", "fabgpu_csp_ctx_of", "fabgpu_csp_passes_per_device",
     "fabgpu_csp_route_block", "fabgpu_csp_set_option", "fabgpu_csp_get_option",
+    "fabgpu_csp_hash_lookup", "fabgpu_csp_hash_memo_stats",
 ]
 
 _lib = None
@@ -203,6 +205,8 @@ def load():
     L.fabgpu_csp_memo_evict_block.argtypes = [_vp, ctypes.c_uint64, _u64p]
     L.fabgpu_csp_memo_stats.argtypes = [_vp, _u64p, _u64p, _u64p, _u64p]
     L.fabgpu_csp_memo_set_capacity.argtypes = [_vp, ctypes.c_uint64]
+    L.fabgpu_csp_hash_lookup.argtypes = [_vp, ctypes.c_char_p, _sz, ctypes.c_char_p]
+    L.fabgpu_csp_hash_memo_stats.argtypes = [_vp, _u64p, _u64p, _u64p, _u64p, _u64p]
     L.fabgpu_csp_identity_cache_limits.argtypes = [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
     L.fabgpu_csp_identity_cache_size.argtypes = [_vp, _u64p]
     L.fabgpu_csp_pass_routes.argtypes = [_vp, _u64p, _u64p, ctypes.c_char_p, _sz]
@@ -611,7 +615,8 @@ class GPUCSP:
                  expect_block_bytes: int = 0, expect_tuples: int = 0, **switches):
         """device: ONE context on that HIP ordinal (fabgpu_csp_new).  devices: one context per entry - an ordinal may repeat; an empty
         list means every visible device - behind ONE provider (fabgpu_csp_new2: what bccsp/factory builds from the `GPU:` section).
-        switches: pass_device_walk / pass_stage_min_bytes / pass_device_memo / pass_host_counts / pass_timing (0 default, > 0 on, < 0 off)."""
+        switches: pass_device_walk / pass_stage_min_bytes / pass_device_memo / pass_host_counts / pass_timing / pass_hash_memo (0 default,
+        > 0 on, < 0 off), hash_memo_blocks (host copies of blocks the digest memo keeps per device)."""
         L = load()
         h = _vp()
         err = ctypes.create_string_buffer(512)
@@ -1077,6 +1082,20 @@ def memo_lookup(csp: "GPUCSP", qx32: bytes, qy32: bytes, sig: bytes, digest: byt
     st = ctypes.c_uint8(255)
     rc = csp._L.fabgpu_csp_memo_lookup(csp._h, qx32, qy32, sig, len(sig), digest, len(digest), ctypes.byref(st))
     return int(st.value) if rc == 0 else None
+
+
+def hash_lookup(csp: "GPUCSP", msg: bytes) -> Optional[bytes]:
+    """The bccsp.Hash(msg, &bccsp.SHA256Opts{}) question against the digest memo (msp/identities.go:173-181): the digest the device computed
+    over exactly these bytes, or None (miss: hash on the CPU)."""
+    out = ctypes.create_string_buffer(32)
+    rc = csp._L.fabgpu_csp_hash_lookup(csp._h, msg, len(msg), out)
+    return out.raw if rc == 0 else None
+
+
+def hash_memo_stats(csp: "GPUCSP"):
+    v = [ctypes.c_uint64(0) for _ in range(5)]
+    _check(csp._L.fabgpu_csp_hash_memo_stats(csp._h, *[ctypes.byref(x) for x in v]), "fabgpu_csp_hash_memo_stats")
+    return dict(hits=v[0].value, misses=v[1].value, blocks_held=v[2].value, bytes_held=v[3].value, refused=v[4].value)
 
 
 def memo_has_block(csp: "GPUCSP", block_seq: int) -> int:

@@ -42,6 +42,12 @@ type GPUOpts struct {
 	// must not be smaller than what the payload buffer accepts ahead: peer.gossip.state.blockBufferSize (core.yaml, default 20; the
 	// arrival hook only pre-verifies blocks the buffer kept).  0 = the library's 2^18 entries (six 10 000-transaction blocks).
 	MemoBlocks int `mapstructure:"memoblocks" json:"memoblocks" yaml:"MemoBlocks"`
+	// NoHashMemo switches the digest memo off: bccsp.Hash always goes to bccsp/sw and no pass keeps a host copy of its block.  By default a
+	// pass keeps its block in pinned host memory of the library until the block is evicted (HashMemoBlocks copies per device at a time;
+	// 0: MemoBlocks + ConcurrentPasses, at least 8 - each as large as its block), and identity.Verify's Hash (msp/identities.go:173-181)
+	// is answered from it when the validator's bytes equal the block's, byte for byte.
+	NoHashMemo     bool `mapstructure:"nohashmemo" json:"nohashmemo" yaml:"NoHashMemo"`
+	HashMemoBlocks int  `mapstructure:"hashmemoblocks" json:"hashmemoblocks" yaml:"HashMemoBlocks"`
 	// HostWalk keeps the envelope walk of the block pass on the host (A/B runs); PassTiming prints every pass's stage breakdown.
 	HostWalk   bool `mapstructure:"hostwalk" json:"hostwalk" yaml:"HostWalk"`
 	PassTiming bool `mapstructure:"passtiming" json:"passtiming" yaml:"PassTiming"`
@@ -80,7 +86,8 @@ func (f *GPUFactory) Get(config *FactoryOpts) (bccsp.BCCSP, error) {
 			}
 		}
 		opts = gpu.Options{Devices: g.Devices, ConcurrentPasses: g.ConcurrentPasses, ExpectBlockBytes: g.ExpectBlockBytes,
-			ExpectTuples: g.ExpectTuples, MemoBlocks: g.MemoBlocks, HostWalk: g.HostWalk, PassTiming: g.PassTiming}
+			ExpectTuples: g.ExpectTuples, MemoBlocks: g.MemoBlocks, HostWalk: g.HostWalk, PassTiming: g.PassTiming,
+			NoHashMemo: g.NoHashMemo, HashMemoBlocks: g.HashMemoBlocks}
 	}
 	csp, err := gpu.New(swCSP, opts)
 	if err != nil {

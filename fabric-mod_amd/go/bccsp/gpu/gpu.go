@@ -19,9 +19,11 @@
 //      creator, endorsement and orderer signature of the block, which also seeds the verdict memo inside
 //      libfabgpu.so, keyed on (public key, signature bytes, digest the DEVICE computed).
 //   2. the validators then call identity.Verify per signature as before (msp/identities.go:169-196):
-//      bccsp.Hash stays on the CPU - the digest is what ties the caller's bytes to the memo entry - and
-//      bccsp.Verify finds the verdict in the memo.  A miss, a non-P-256 key, or any rejected signature goes to
-//      bccsp/sw, so error text and semantics are the reference's own in every case but "valid".
+//      bccsp.Hash finds the digest the pass computed in the library's DIGEST MEMO - handed out only when every byte of
+//      the validator's message equals the bytes the device hashed, so the digest still ties the caller's bytes to the
+//      memo entry (a miss: bccsp/sw hashes on the CPU) - and bccsp.Verify finds the verdict in the verdict memo.  A miss,
+//      a non-P-256 key, or any rejected signature goes to bccsp/sw, so error text and semantics are the reference's own
+//      in every case but "valid".
 //   3. when Validate returns, the wrapper evicts the block's entries: the memo never grows with the chain.
 // The device never decides alone: a verdict is only ever attached to the three byte strings the validator itself
 // presents, so a block whose bytes the pass parsed differently than the Go unmarshaller (or a device failure)
@@ -89,8 +91,11 @@ type Provider struct {
 	// orderer (Broadcast handlers behind SigFilter, orderer/common/msgprocessor/sigfilter.go:50-80).  Off by default: a
 	// lone call costs a launch (0.7 ms) where bccsp/sw costs 0.1 ms; the break-even is about sixteen calls in flight.
 	coalesce bool
-	// room for per-transaction flags, remembered from block to block (atomic max): the library answers FABGPU_ETOOBIG - before it has
-	// waited for the upload or launched anything, and the retry finds its upload again - only when a block outgrows every block before it
+	// noHashMemo: Options.NoHashMemo - Hash goes straight to bccsp/sw
+	noHashMemo bool
+	// room for per-transaction flags, remembered from block to block (atomic max): the library answers FABGPU_ETOOBIG - nothing was
+	// launched, the upload has been waited for (the library never reads the block after a call returned) and is kept for the retry,
+	// which finds it again - only when a block outgrows every block before it
 	capTx uint32
 	// metrics: published through an atomic.Value (RegisterMetrics may run while PreVerifyBlock goroutines are already reading it);
 	// the refresher goroutine is stopped by Close BEFORE the C provider is freed (ADVICE r4)
@@ -115,6 +120,8 @@ type Options struct {
 	ExpectBlockBytes int   // sizes that pre-allocation (0: 64 MiB) ...
 	ExpectTuples     int   // ... (0: 65 536 signatures per block)
 	MemoBlocks       int   // the verdict memo holds this many blocks' worth of entries (x ExpectTuples); 0: the library's 2^18 entries
+	NoHashMemo       bool  // bccsp.Hash never asks the digest memo and passes keep no host copy of their block (default: they do)
+	HashMemoBlocks   int   // per device: host copies of blocks kept for the digest memo at a time (0: MemoBlocks + ConcurrentPasses, at least 8)
 	HostWalk         bool  // keep the envelope walk on the host (A/B runs)
 	PassTiming       bool  // stage breakdown of every pass on stderr
 }
@@ -207,6 +214,21 @@ func New(swCSP bccsp.BCCSP, opts Options) (bccsp.BCCSP, error) {
 	if opts.PassTiming {
 		o.pass_timing = 1
 	}
+	if opts.NoHashMemo {
+		o.pass_hash_memo = -1
+	}
+	// a block's host copy lives as long as its memo entries: as many copies as blocks may wait for their validators, plus the passes in flight
+	keep := opts.HashMemoBlocks
+	if keep <= 0 {
+		keep = opts.MemoBlocks + opts.ConcurrentPasses
+		if keep < 8 {
+			keep = 8
+		}
+	}
+	if keep > 64 {
+		keep = 64
+	}
+	o.hash_memo_blocks = C.uint32_t(keep)
 	var csp *C.fabgpu_csp
 	errbuf := make([]byte, 256)
 	if rc := C.fabgpu_csp_new2(&o, &csp, (*C.char)(unsafe.Pointer(&errbuf[0])), C.size_t(len(errbuf))); rc != 0 {
@@ -221,7 +243,7 @@ func New(swCSP bccsp.BCCSP, opts Options) (bccsp.BCCSP, error) {
 		}
 		C.fabgpu_csp_memo_set_capacity(csp, C.uint64_t(opts.MemoBlocks)*C.uint64_t(tuples))
 	}
-	return &Provider{BCCSP: swCSP, csp: csp, capTx: 1024}, nil
+	return &Provider{BCCSP: swCSP, csp: csp, capTx: 1024, noHashMemo: opts.NoHashMemo}, nil
 }
 
 // Devices: how many device contexts this provider drives.
@@ -345,9 +367,36 @@ func (p *Provider) Verify(k bccsp.Key, signature, digest []byte, opts bccsp.Sign
 // (Sign, Encrypt, Decrypt, KeyDeriv, KeyGen, GetKey, GetHashOpt, GetHash are bccsp/sw's, reached through the embedded interface with
 // bccsp/sw's own key objects: nothing to unwrap.  INTEGRATION.md lists every bccsp.BCCSP method x key type with who answers.)
 
-// Hash stays on the CPU on purpose: a PCIe round trip costs more than SHA-256 of a few KB, and - more important -
-// the digest the validator computes over ITS bytes is what binds those bytes to a memo entry.
-func (p *Provider) Hash(msg []byte, opts bccsp.HashOpts) ([]byte, error) { return p.BCCSP.Hash(msg, opts) }
+// hashMemoMinLen: shorter messages are hashed by bccsp/sw without asking (one SHA-256 block costs less than a cgo call; the library
+// answers "miss" for them anyway).
+const hashMemoMinLen = 64
+
+// Hash: the `digest, err := id.msp.bccsp.Hash(msg, hashOpt)` half of identity.Verify (msp/identities.go:173-181).  For
+// *bccsp.SHA256Opts - what msp/identities.go:216-224 selects for the SHA2 family - the provider first asks the DIGEST MEMO
+// (fabgpu_csp_hash_lookup): a block pass that seeded the verdict memo has hashed exactly these bytes on the device and kept the block in
+// host memory the library owns; the stored digest comes back ONLY when every byte of msg equals the bytes the device hashed (the
+// library compares them all - a fingerprint merely chooses where to look), so the digest is still bound to the validator's own bytes.
+// A miss - any other message, an evicted block, a switched-off memo - and every other HashOpts (SHA3, SHA384, nil: bccsp/sw's error
+// text, bccsp/sw/impl.go:179-181) go to bccsp/sw.  No PCIe round trip either way: a hit is a table probe and a memcmp.
+// Before round 6 Hash always went to bccsp/sw: the validators then re-hashed on the CPU every byte the device had just hashed (100 MB
+// per 10 000-transaction block), which was three to four times the cost of the GPU pass itself.
+func (p *Provider) Hash(msg []byte, opts bccsp.HashOpts) ([]byte, error) {
+	if _, isSHA256 := opts.(*bccsp.SHA256Opts); isSHA256 && len(msg) >= hashMemoMinLen && !p.noHashMemo {
+		digest := make([]byte, 32)
+		if C.fabgpu_csp_hash_lookup(p.csp, (*C.uint8_t)(unsafe.Pointer(&msg[0])), C.size_t(len(msg)), (*C.uint8_t)(unsafe.Pointer(&digest[0]))) == 0 {
+			return digest, nil
+		}
+	}
+	return p.BCCSP.Hash(msg, opts)
+}
+
+// HashMemoStats is for metrics / tests: bccsp.Hash calls the digest memo answered, calls left to bccsp/sw, host copies of blocks the
+// library holds for it right now and their bytes, passes that found the pool of copies exhausted.
+func (p *Provider) HashMemoStats() (hits, misses, blocksHeld, bytesHeld, refused uint64) {
+	var h, m, b, y, r C.uint64_t
+	C.fabgpu_csp_hash_memo_stats(p.csp, &h, &m, &b, &y, &r)
+	return uint64(h), uint64(m), uint64(b), uint64(y), uint64(r)
+}
 
 // PreVerifyBlock: fabgpu_csp_block_preverify2 with FABGPU_PASS_SEED_MEMO.  blockBytes = proto.Marshal(block).
 func (p *Provider) PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSummary, error) {
@@ -369,9 +418,10 @@ func (p *Provider) PreVerifyBlock(blockBytes []byte, blockSeq uint64) (*PassSumm
 		close(done)
 	}()
 	// Room for the flags: what the largest block so far needed (atomic max).  No per-tuple array is asked for, so the tuple capacity is
-	// not checked at all; FABGPU_ETOOBIG can only mean "more transactions than any block before" - it is answered from the host's outline
-	// of the block, before the upload is waited for or anything is launched, and the retry below (same buffer, length and name) finds
-	// its upload again inside the library: growing costs the outline (0.15 ms per 10 000 transactions), once.
+	// not checked at all; FABGPU_ETOOBIG can only mean "more transactions than any block before" - it is decided from the host's outline
+	// of the block before anything is launched; the library then waits for the upload it had started (so that it never reads blockBytes
+	// after the call returned) and keeps it, and the retry below - same buffer, length and name, bytes unchanged, at once - finds that
+	// upload again: growing costs the outline (0.15 ms per 10 000 transactions) and no second transfer, once.
 	start := time.Now()
 	for attempt := 0; attempt < 3; attempt++ {
 		capTx := atomic.LoadUint32(&p.capTx)
@@ -508,7 +558,7 @@ var (
 	}
 	memoOpts = metrics.GaugeOpts{
 		Namespace: "bccsp", Subsystem: "gpu", Name: "verdict_memo",
-		Help: "Verdict memo: entries held, bccsp.Verify lookups answered (hits), lookups left to bccsp/sw (misses), entries evicted",
+		Help: "Verdict memo: entries held, bccsp.Verify lookups answered (hits), lookups left to bccsp/sw (misses), entries evicted; digest memo: bccsp.Hash calls answered (hash_hits) / left to bccsp/sw (hash_misses), block copies held, copies refused",
 		LabelNames: []string{"what"}, StatsdFormat: "%{#fqname}.%{what}",
 	}
 )
@@ -573,6 +623,11 @@ func (p *Provider) RegisterMetrics(mp metrics.Provider, refresh time.Duration) {
 				m.memo.With("what", "hits").Set(float64(hit))
 				m.memo.With("what", "misses").Set(float64(miss))
 				m.memo.With("what", "evicted").Set(float64(ev))
+				hh, hm, hb, _, hr := p.HashMemoStats()
+				m.memo.With("what", "hash_hits").Set(float64(hh))
+				m.memo.With("what", "hash_misses").Set(float64(hm))
+				m.memo.With("what", "hash_blocks_held").Set(float64(hb))
+				m.memo.With("what", "hash_copies_refused").Set(float64(hr))
 			}
 		}()
 	})

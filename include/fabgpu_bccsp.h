@@ -42,6 +42,10 @@ typedef struct fabgpu_csp_opts {
     int32_t pass_device_memo;      /* < 0: the verdict memo is seeded on the host also on the device route (default: built by the device) */
     int32_t pass_host_counts;      /* > 0: the envelopes' tuples are counted on the host while the block travels (default off) */
     int32_t pass_timing;           /* > 0: stage breakdown of every pass on stderr (default off) */
+    int32_t pass_hash_memo;        /* < 0: no digest memo - memo-seeding passes keep no host copy of their block and fabgpu_csp_hash_lookup
+                                      always misses (default on) */
+    uint32_t hash_memo_blocks;     /* per device: host copies of blocks the digest memo keeps at a time, each as large as its block, pinned
+                                      (0: 8; at most 64).  A block beyond that simply has no digest memo: its messages are hashed on the CPU */
 } fabgpu_csp_opts;
 int fabgpu_csp_new2(const fabgpu_csp_opts* opts, fabgpu_csp** out, char* err, size_t errcap);
 void fabgpu_csp_free(fabgpu_csp* csp);
@@ -52,7 +56,7 @@ fabgpu_ctx* fabgpu_csp_ctx_of(fabgpu_csp* csp, int d);
 int fabgpu_csp_passes_per_device(fabgpu_csp* csp, uint64_t* passes, int cap);
 int fabgpu_csp_route_block(fabgpu_csp* csp, uint64_t block_seq);   /* where a pass named block_seq would go right now */
 /* the switches above on a living provider (tests, A/B runs): "pass_device_walk", "pass_stage_min_bytes", "pass_device_memo",
- * "pass_host_counts", "pass_skip_hash_checks", "pass_timing" - same convention: 0 the default, > 0 on / the threshold, < 0 off; get also
+ * "pass_host_counts", "pass_skip_hash_checks", "pass_timing", "pass_hash_memo" - same convention: 0 the default, > 0 on / the threshold, < 0 off; get also
  * answers "n_devices".  FABGPU_EINVAL: no such option. */
 int fabgpu_csp_set_option(fabgpu_csp* csp, const char* name, int64_t value, int64_t* previous);
 int fabgpu_csp_get_option(fabgpu_csp* csp, const char* name, int64_t* value);
@@ -64,6 +68,23 @@ int fabgpu_csp_key_import(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* q
 
 /* alg == NULL mirrors opts == nil. */
 int fabgpu_csp_hash(fabgpu_csp* csp, const uint8_t* msg, size_t len, const char* alg, uint8_t* digest32, char* err, size_t errcap);
+
+/* BCCSP.Hash for bytes a memo-seeding block pass has ALREADY hashed on the device: the `digest, err := id.msp.bccsp.Hash(msg, hashOpt)` half
+ * of identity.Verify (msp/identities.go:173-181 -> bccsp/sw/impl.go:177-194), which the unchanged validators call once per creator /
+ * endorsement signature over bytes the pass hashed a moment earlier - 100 MB per 10 000-transaction block.  A pass with
+ * FABGPU_PASS_SEED_MEMO keeps the block's bytes in host memory THE LIBRARY owns (the pinned buffer the upload went through anyway; never the
+ * caller's buffer) until fabgpu_csp_memo_evict_block, and indexes every signed message by a fingerprint of a few sampled bytes.  The
+ * fingerprint only chooses where to look: the stored digest is returned ONLY when every byte of `msg` equals the bytes the device hashed
+ * (memcmp; piecewise for prp || endorser, validator_keylevel.go:246-258) - a flipped byte anywhere, another length, an evicted block, a
+ * message the device did not hash: miss.
+ * Returns 0: hit, digest32 = SHA-256(msg) as the device computed it (the digest the block's verdict-memo entries are keyed on);
+ * 1: miss - the caller computes the digest itself (bccsp/sw), always a correct answer.  Never an infrastructure error.  Messages shorter
+ * than 64 bytes always miss (one SHA-256 block costs less than the call).  Callers map *bccsp.SHA256Opts (what msp/identities.go:216-224
+ * selects for the SHA2 family) to this entry and every other HashOpts to bccsp/sw. */
+int fabgpu_csp_hash_lookup(fabgpu_csp* csp, const uint8_t* msg, size_t len, uint8_t* digest32);
+/* digest memo counters since the provider was made: lookups answered / left to the CPU; host copies of blocks held right now, their
+ * (pinned) bytes, and passes that wanted a copy when the pool was exhausted (any pointer may be NULL) */
+int fabgpu_csp_hash_memo_stats(fabgpu_csp* csp, uint64_t* hits, uint64_t* misses, uint64_t* blocks_held, uint64_t* bytes_held, uint64_t* refused);
 
 /* qx == NULL mirrors k == nil.  *valid = 0/1; err = Go error text or "".  *flags bit0: tuple must be decided by bccsp/sw. */
 int fabgpu_csp_verify(fabgpu_csp* csp, const uint8_t* qx32, const uint8_t* qy32, const uint8_t* sig, size_t siglen,

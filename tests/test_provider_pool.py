@@ -35,11 +35,11 @@ def test_provider_options_struct_is_the_headers():
 #include <stddef.h>
 #include "fabgpu_bccsp.h"
 int main(void) {
-    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(fabgpu_csp_opts), offsetof(fabgpu_csp_opts, size), offsetof(fabgpu_csp_opts, n_devices),
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(fabgpu_csp_opts), offsetof(fabgpu_csp_opts, size), offsetof(fabgpu_csp_opts, n_devices),
            offsetof(fabgpu_csp_opts, devices), offsetof(fabgpu_csp_opts, ctx_flags), offsetof(fabgpu_csp_opts, concurrent_passes),
            offsetof(fabgpu_csp_opts, expect_block_bytes), offsetof(fabgpu_csp_opts, expect_tuples), offsetof(fabgpu_csp_opts, pass_device_walk),
            offsetof(fabgpu_csp_opts, pass_stage_min_bytes), offsetof(fabgpu_csp_opts, pass_device_memo), offsetof(fabgpu_csp_opts, pass_host_counts),
-           offsetof(fabgpu_csp_opts, pass_timing));
+           offsetof(fabgpu_csp_opts, pass_timing), offsetof(fabgpu_csp_opts, pass_hash_memo), offsetof(fabgpu_csp_opts, hash_memo_blocks));
     return 0;
 }
 '''

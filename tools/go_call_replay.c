@@ -12,7 +12,9 @@
  *       pre.HasBlock(seq)                         fabgpu_csp_memo_has_block            (true: nothing to marshal, nothing to submit)
  *       the unchanged validator, validatorPoolSize goroutines (core/peer/config.go:255-257: NumCPU), one transaction each
  *       (core/committer/txvalidator/v20/validator.go:194-210); per signature identity.Verify (msp/identities.go:169-196):
- *           digest = bccsp.Hash(msg)              SHA-256 ON THE CPU (gpu.go Hash delegates to bccsp/sw by design) - here OpenSSL's
+ *           digest = bccsp.Hash(msg)              gpu.go Hash: fabgpu_csp_hash_lookup - the digest the pass computed, handed out only when every
+ *                                                 byte of msg equals the block's; a miss -> bccsp/sw's SHA-256 on the CPU (here OpenSSL's)
+ *                                                 (argument 5 = 0: the round-5 provider, whose Hash always went to bccsp/sw)
  *           bccsp.Verify(k, sig, digest)          fabgpu_csp_memo_lookup  ((true, nil) on a valid hit; else bccsp/sw - counted, not run)
  *       pre.EvictBlock(seq)                       fabgpu_csp_memo_evict_block
  * Block k + 1 arrives (its pass runs) while block k is validated: the steady state of one channel.
@@ -20,7 +22,7 @@
  * What it prints (one JSON line): the pass as the binding calls it (first block of a fresh provider, i.e. over its caps; warm blocks),
  * the validators' CPU residue per block (hashing + memo lookups on T threads), and end-to-end validated tx/s of the two-stage pipeline.
  *
- * usage: go_call_replay <block file> [blocks=12] [validator threads=16] [devices=1]
+ * usage: go_call_replay <block file> [blocks=12] [validator threads=16] [devices=1] [hash memo=1] [arrivals in flight=1] [blocks pre-verified ahead=arrivals]
  * Test / bench infrastructure: links the product library through its C ABI only (include/fabgpu*.h) + libcrypto for the CPU SHA-256.
  */
 #define _GNU_SOURCE
@@ -51,6 +53,7 @@ typedef struct {
 
 static fabgpu_csp* g_csp;
 static uint32_t g_cap_tx = 1024; /* gpu.go Provider.capTx */
+static int g_hash_memo = 1;      /* gpu.go Provider.Hash asks the digest memo first (0: round 5's pass-through to bccsp/sw) */
 
 /* gpu.go PreVerifyBlock */
 static int pre_verify_block(const uint8_t* blk, size_t len, uint64_t seq, uint32_t* n_tx, uint32_t* seeded, int* retries) {
@@ -92,14 +95,51 @@ typedef struct {
     const uint32_t* tx_first; /* n_tx + 1: first tuple of each transaction */
     uint32_t n_tx;
     uint32_t next;            /* atomic */
-    uint64_t hits, misses, hashed_bytes;
+    uint64_t hits, misses, hashed_bytes, hash_hits, hash_bytes;
+    int check;                /* also hash every message on the CPU and compare (block 0 only: outside the medians) */
+    uint64_t digest_mismatches;
+    double t_cat, t_hash, t_memo, t_thread; /* GO_REPLAY_PROFILE: thread-milliseconds in the copy, in Hash, in Verify, in the worker */
 } validate_job;
+static int g_profile;
+static pthread_mutex_t g_prof_mu = PTHREAD_MUTEX_INITIALIZER;
 
+/* bccsp/sw's Hash: SHA-256 on the CPU.
+ * (SHA256_Init / Update / Final, not the one-shot SHA256(): OpenSSL 3 routes that through an EVP fetch per call, whose locks
+ *  sixteen threads fight over - 42 ms per block instead of 6) */
+static void sw_hash(const uint8_t* msg, size_t n, uint8_t* digest) {
+    SHA256_CTX c;
+    SHA256_Init(&c);
+    SHA256_Update(&c, msg, n);
+    SHA256_Final(digest, &c);
+}
+/* gpu.go Provider.Hash(msg, &bccsp.SHA256Opts{}); returns 1 if the digest memo answered */
+static int provider_hash(const uint8_t* msg, size_t n, uint8_t* digest) {
+    if (g_hash_memo && n >= 64 && fabgpu_csp_hash_lookup(g_csp, msg, n, digest) == 0) return 1;
+    sw_hash(msg, n, digest);
+    return 0;
+}
+
+static void validate_some(validate_job* j);
+/* The pool is the peer's: validatorPoolSize workers that live as long as the channel does (a goroutine per transaction behind a semaphore of
+ * that size, core/committer/txvalidator/v20/validator.go:194-210, on GOMAXPROCS long-lived OS threads) - not threads made per block.  Two
+ * barriers per block: "here is a block", "the block is done". */
+static pthread_barrier_t g_go, g_done;
+static validate_job* volatile g_job;
+static volatile int g_quit;
 static void* validator(void* arg) {
-    validate_job* j = (validate_job*)arg;
-    uint64_t hits = 0, misses = 0, bytes = 0;
+    (void)arg;
+    for (;;) {
+        pthread_barrier_wait(&g_go);
+        if (g_quit) return NULL;
+        validate_some(g_job);
+        pthread_barrier_wait(&g_done);
+    }
+}
+static void validate_some(validate_job* j) {
+    uint64_t hits = 0, misses = 0, bytes = 0, hh = 0, hb = 0;
     uint8_t* cat = NULL;
     size_t cat_cap = 0;
+    double p_cat = 0, p_hash = 0, p_memo = 0, p0 = g_profile ? now_ms() : 0, pa = 0, pb = 0;
     for (;;) {
         uint32_t t = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
         if (t >= j->n_tx) break;
@@ -108,14 +148,14 @@ static void* validator(void* arg) {
             uint8_t digest[32];
             /* msp/identities.go:173-181: digest = bccsp.Hash(msg).  A creator signs Envelope.payload; an endorser prp || endorser
              * (validator_keylevel.go:246-258 builds that concatenation: append(prp, endorser...) - a copy, then one hash) */
-            /* (SHA256_Init / Update / Final, not the one-shot SHA256(): OpenSSL 3 routes that through an EVP fetch per call, whose locks
-             *  sixteen threads fight over - 42 ms per block instead of 6) */
-            SHA256_CTX c;
-            SHA256_Init(&c);
+            const uint8_t* msg;
+            size_t n;
+            if (g_profile) pa = now_ms();
             if (tp->pre_len == 0) {
-                SHA256_Update(&c, j->blk + tp->suf_off, tp->suf_len);
+                msg = j->blk + tp->suf_off;
+                n = tp->suf_len;
             } else {
-                size_t n = (size_t)tp->pre_len + tp->suf_len;
+                n = (size_t)tp->pre_len + tp->suf_len;
                 if (cat_cap < n) {
                     free(cat);
                     cat = (uint8_t*)malloc(n + n / 2);
@@ -123,21 +163,38 @@ static void* validator(void* arg) {
                 }
                 memcpy(cat, j->blk + tp->pre_off, tp->pre_len);
                 memcpy(cat + tp->pre_len, j->blk + tp->suf_off, tp->suf_len);
-                SHA256_Update(&c, cat, n);
+                msg = cat;
             }
-            SHA256_Final(digest, &c);
+            if (g_profile) { pb = now_ms(); p_cat += pb - pa; }
+            if (provider_hash(msg, n, digest)) {
+                hh++;
+                hb += n;
+                if (j->check) {
+                    uint8_t want[32];
+                    sw_hash(msg, n, want);
+                    if (memcmp(want, digest, 32) != 0) __atomic_fetch_add(&j->digest_mismatches, 1, __ATOMIC_RELAXED);
+                }
+            }
             bytes += (uint64_t)tp->pre_len + tp->suf_len;
+            if (g_profile) { pa = now_ms(); p_hash += pa - pb; }
             uint8_t st = 255;
             /* gpu.go Verify: xyOf(k) -> fabgpu_csp_memo_lookup; (true, nil) only on a valid hit */
             if (tp->has_key && fabgpu_csp_memo_lookup(g_csp, tp->xy, tp->xy + 32, j->blk + tp->sig_off, tp->sig_len, digest, 32, &st) == 0 && st == FABGPU_ST_VALID) hits++;
             else misses++; /* -> bccsp/sw (not run here: the replay is about the path's own cost) */
+            if (g_profile) p_memo += now_ms() - pa;
         }
     }
     free(cat);
+    if (g_profile) {
+        pthread_mutex_lock(&g_prof_mu);
+        j->t_cat += p_cat; j->t_hash += p_hash; j->t_memo += p_memo; j->t_thread += now_ms() - p0;
+        pthread_mutex_unlock(&g_prof_mu);
+    }
     __atomic_fetch_add(&j->hits, hits, __ATOMIC_RELAXED);
     __atomic_fetch_add(&j->misses, misses, __ATOMIC_RELAXED);
     __atomic_fetch_add(&j->hashed_bytes, bytes, __ATOMIC_RELAXED);
-    return NULL;
+    __atomic_fetch_add(&j->hash_hits, hh, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&j->hash_bytes, hb, __ATOMIC_RELAXED);
 }
 
 /* ---- the arrival goroutine of one block ---- */
@@ -160,6 +217,32 @@ static void* arrival(void* arg) {
     return NULL;
 }
 
+/* ---- the arrival goroutines of the channel (see main) ---- */
+static arrival_job* g_arr;
+static int g_n_blocks, g_next_arrival, g_validation_started, g_arrivals = 1, g_window = 1;
+static unsigned char g_arr_done[4096];
+static pthread_mutex_t g_arr_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_arr_cv = PTHREAD_COND_INITIALIZER;
+static void* arrival_worker(void* arg) {
+    (void)arg;
+    for (;;) {
+        pthread_mutex_lock(&g_arr_mu);
+        const int i = g_next_arrival;
+        if (i >= g_n_blocks) {
+            pthread_mutex_unlock(&g_arr_mu);
+            return NULL;
+        }
+        g_next_arrival = i + 1;
+        while (g_validation_started < i - g_window) pthread_cond_wait(&g_arr_cv, &g_arr_mu);
+        pthread_mutex_unlock(&g_arr_mu);
+        arrival(&g_arr[i]);
+        pthread_mutex_lock(&g_arr_mu);
+        g_arr_done[i] = 1;
+        pthread_cond_broadcast(&g_arr_cv);
+        pthread_mutex_unlock(&g_arr_mu);
+    }
+}
+
 static int cmp_d(const void* a, const void* b) { return (*(const double*)a > *(const double*)b) - (*(const double*)a < *(const double*)b); }
 static double median(double* v, int n) {
     qsort(v, (size_t)n, sizeof(double), cmp_d);
@@ -168,11 +251,20 @@ static double median(double* v, int n) {
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <block file> [blocks=12] [validator threads=16] [devices=1]\n", argv[0]);
+        fprintf(stderr, "usage: %s <block file> [blocks=12] [validator threads=16] [devices=1] [hash memo=1] [arrivals in flight=1] [window=arrivals]\n", argv[0]);
         return 2;
     }
     int n_blocks = argc > 2 ? atoi(argv[2]) : 12, n_thr = argc > 3 ? atoi(argv[3]) : 16, n_dev = argc > 4 ? atoi(argv[4]) : 1;
+    g_hash_memo = argc > 5 ? atoi(argv[5]) != 0 : 1;
+    g_arrivals = argc > 6 ? atoi(argv[6]) : 1;
+    if (g_arrivals < 1) g_arrivals = 1;
+    if (g_arrivals > 4) g_arrivals = 4;                /* maxArrivalPasses */
+    g_window = argc > 7 ? atoi(argv[7]) : g_arrivals;  /* blocks that may be pre-verified ahead of the one being validated (gossip's payload buffer) */
+    if (g_window < g_arrivals) g_window = g_arrivals;
+    if (g_window > 5) g_window = 5;                    /* (the library's default memo holds six 40 000-signature blocks) */
+    g_profile = getenv("GO_REPLAY_PROFILE") != NULL; /* (probes only: a clock read around every step of every signature) */
     if (n_blocks < 3) n_blocks = 3;
+    if (n_blocks > 4096) n_blocks = 4096;
     if (n_thr < 1) n_thr = 1;
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
@@ -233,7 +325,8 @@ int main(int argc, char** argv) {
     int visible = fabgpu_device_count(NULL);
     for (int i = 0; i < n_dev && i < 64; i++) devs[i] = visible > 0 ? i % visible : 0;
     o.devices = devs;
-    o.concurrent_passes = 2;
+    o.concurrent_passes = g_arrivals > 2 ? (uint32_t)g_arrivals : 2; /* GPUOpts.ConcurrentPasses */
+    o.pass_hash_memo = g_hash_memo ? 0 : -1;   /* (GPUOpts.HashMemo: on unless the operator switched it off) */
     o.pass_timing = getenv("GO_REPLAY_PASS_TIMING") ? 1 : 0; /* stage breakdown of every pass on stderr (probes only) */
     o.expect_block_bytes = len + 4096;
     o.expect_tuples = n_tuples + 64;
@@ -255,8 +348,11 @@ int main(int argc, char** argv) {
     arrival_job* arr = (arrival_job*)calloc((size_t)n_blocks, sizeof(arrival_job));
     double* val_ms = (double*)calloc((size_t)n_blocks, sizeof(double));
     double* has_ms = (double*)calloc((size_t)n_blocks, sizeof(double));
-    uint64_t hits = 0, misses = 0, hashed = 0;
+    uint64_t hits = 0, misses = 0, hashed = 0, hash_hits = 0, hash_bytes = 0, mismatches = 0;
     pthread_t* pool = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_thr);
+    pthread_barrier_init(&g_go, NULL, (unsigned)n_thr + 1);
+    pthread_barrier_init(&g_done, NULL, (unsigned)n_thr + 1);
+    for (int t = 0; t < n_thr; t++) pthread_create(&pool[t], NULL, validator, NULL);
 
     /* The first blocks of a fresh process, one after the other.  Block 0 pays what a process pays once - code objects loaded at their
      * first launch, the signers' certificates decoded and their comb tables built - AND finds the provider's caps at the initial 1 024
@@ -280,12 +376,25 @@ int main(int argc, char** argv) {
     }
     double warm4 = warm_ms[3] < warm_ms[4] ? warm_ms[3] : warm_ms[4];
     arrival(&arr[0]);
+    /* The arrival goroutines (preverify_on_arrival.go: at most maxArrivalPasses = 4 passes in flight per channel; here g_arrivals of them):
+     * block i's pass may start once the validation of block i - g_window has started.  Window 1, one arrival: block k + 1 arrives while
+     * block k is validated (a channel that receives a block per validated block).  A wider window with two arrivals in flight: a channel
+     * whose blocks arrive faster than it validates them (catch-up, a saturated orderer) - passes overlap on the device and the payload
+     * buffer (gossip/state: blockBufferSize) holds pre-verified blocks for the committer. */
+    g_arr = arr;
+    g_arr_done[0] = 1;
+    g_n_blocks = n_blocks;
+    g_next_arrival = 1;
+    g_validation_started = -1;
+    pthread_t arr_th[8];
+    for (int a = 0; a < g_arrivals; a++) pthread_create(&arr_th[a], NULL, arrival_worker, NULL);
     double wall0 = now_ms();
     for (int k = 0; k < n_blocks; k++) {
-        /* block k + 1 arrives now; block k is validated meanwhile */
-        pthread_t th_arr;
-        int started = 0;
-        if (k + 1 < n_blocks) started = pthread_create(&th_arr, NULL, arrival, &arr[k + 1]) == 0;
+        pthread_mutex_lock(&g_arr_mu);
+        g_validation_started = k;                           /* blocks up to k + g_arrivals may travel now */
+        pthread_cond_broadcast(&g_arr_cv);
+        while (!g_arr_done[k]) pthread_cond_wait(&g_arr_cv, &g_arr_mu);
+        pthread_mutex_unlock(&g_arr_mu);
         if (arr[k].rc != 0) { printf("{\"error\": \"pass of block %d: %s\"}\n", k, fabgpu_strerror(arr[k].rc)); return 1; }
         double v0 = now_ms();
         uint64_t have = 0;
@@ -298,15 +407,24 @@ int main(int argc, char** argv) {
         job.tuples = tuples;
         job.tx_first = tx_first;
         job.n_tx = n_tx;
-        for (int t = 0; t < n_thr; t++) pthread_create(&pool[t], NULL, validator, &job);
-        for (int t = 0; t < n_thr; t++) pthread_join(pool[t], NULL);
+        job.check = k == 0;
+        g_job = &job;
+        pthread_barrier_wait(&g_go);
+        pthread_barrier_wait(&g_done);
         uint64_t ev = 0;
         fabgpu_csp_memo_evict_block(g_csp, arr[k].seq, &ev); /* preverify.go: defer EvictBlock */
         val_ms[k] = now_ms() - v0;
+        if (g_profile)
+            fprintf(stderr, "block %d: validators %.2f ms wall; thread-ms: copy %.2f hash %.2f verify-memo %.2f in-worker %.2f (of %d threads)\n", k, val_ms[k], job.t_cat, job.t_hash,
+                    job.t_memo, job.t_thread, n_thr);
         hits += job.hits; misses += job.misses; hashed += job.hashed_bytes;
-        if (started) pthread_join(th_arr, NULL);
+        hash_hits += job.hash_hits; hash_bytes += job.hash_bytes; mismatches += job.digest_mismatches;
     }
     double wall = now_ms() - wall0;
+    for (int a = 0; a < g_arrivals; a++) pthread_join(arr_th[a], NULL);
+    g_quit = 1;
+    pthread_barrier_wait(&g_go);
+    for (int t = 0; t < n_thr; t++) pthread_join(pool[t], NULL);
 
     /* protoutil.BlockDataHash (protoutil/blockutils.go:65-68, called by MCS VerifyBlock at internal/peer/gossip/mcs.go:156): ONE serial
      * SHA-256 over the concatenated envelopes = the block's bytes less a few bytes of framing per envelope.  It stays on the CPU
@@ -340,12 +458,13 @@ int main(int argc, char** argv) {
            "\"lone_passes_ms\": [%.3f, %.3f, %.3f, %.3f, %.3f], "
            "\"over_caps_on_a_warm_provider\": {\"ms\": %.3f, \"etoobig_retries\": %d, \"warm_lone_pass_ms\": %.3f, \"over_warm\": %.3f}, "
            "\"pipelined_pass_ms_median\": %.3f, "
-           "\"validators_ms_per_block_median\": %.3f, \"block_data_hash_ms\": %.3f, \"has_block_ms\": %.4f, \"cpu_sha256_MB_per_block\": %.2f, \"memo_hits\": %llu, \"memo_misses\": %llu, "
+           "\"validators_ms_per_block_median\": %.3f, \"block_data_hash_ms\": %.3f, \"has_block_ms\": %.4f, \"arrivals_in_flight\": %d, \"arrival_window\": %d, \"hash_memo\": %d, \"cpu_sha256_MB_per_block\": %.2f, \"hash_memo_MB_per_block\": %.2f, \"hash_memo_hits\": %llu, \"hash_memo_digest_mismatches\": %llu, \"memo_hits\": %llu, \"memo_misses\": %llu, "
            "\"pipeline_wall_ms\": %.3f, \"ms_per_block_end_to_end\": %.3f, \"validated_tx_per_s_end_to_end\": %.1f, "
            "\"passes_on_device_route\": %llu, \"passes_on_host_route\": %llu, \"passes_per_context\": [",
            len, n_tx, n_env_tuples, n_blocks, n_thr, n_dev, t_new, warm_ms[0], warmup[0].retries, g_cap_tx, warm_ms[0], warm_ms[1], warm_ms[2], warm_ms[3], warm_ms[4],
            warm_ms[5], warmup[5].retries, warm4, warm4 > 0 ? warm_ms[5] / warm4 : 0, warm_med,
-           val_med, bdh_med, has_ms[n_blocks / 2], hashed / 1e6 / n_blocks, (unsigned long long)hits, (unsigned long long)misses, wall, wall / n_blocks,
+           val_med, bdh_med, has_ms[n_blocks / 2], g_arrivals, g_window, g_hash_memo, (hashed - hash_bytes) / 1e6 / n_blocks, hash_bytes / 1e6 / n_blocks, (unsigned long long)hash_hits,
+           (unsigned long long)mismatches, (unsigned long long)hits, (unsigned long long)misses, wall, wall / n_blocks,
            (double)n_tx * n_blocks / (wall * 1e-3), (unsigned long long)dw, (unsigned long long)hw);
     for (int d = 0; d < nd; d++) printf("%s%llu", d ? ", " : "", (unsigned long long)per_dev[d]);
     printf("]}\n");
