@@ -326,6 +326,8 @@ double walk_warm_copies(fabgpu_ctx* ctx, void* const* pinned, const size_t* byte
 size_t key_table_words();
 bool key_table_build(const uint8_t* qx32, const uint8_t* qy32, int32_t* out);
 int key_register_many_prebuilt(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, const int32_t* table, uint32_t* key_ids);
+// the duration of the last timed launch of a FABGPU_FLAG_TIME_KERNELS context (ms; < 0: none) - read by the test-hook library
+float ctx_last_kernel_ms(fabgpu_ctx* ctx);
 // pinned host memory for WalkOut::memo_* (hipHostMalloc / hipHostFree; nullptr when there is none to be had)
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes);
 void walk_pinned_free(fabgpu_ctx* ctx, void* p);

@@ -467,7 +467,9 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
     delete ctx;
 }
 
-float fabgpu_last_kernel_ms(fabgpu_ctx* ctx) {
+}  // extern "C"
+// what the test-hook library's fabgpu_last_kernel_ms reads (FABGPU_FLAG_TIME_KERNELS contexts; block_walk_dev.h)
+float fab::ctx_last_kernel_ms(fabgpu_ctx* ctx) {
     if (!ctx || !ctx->timed) return -1.0f;
     DeviceGuard g(ctx->device);
     if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
@@ -475,6 +477,7 @@ float fabgpu_last_kernel_ms(fabgpu_ctx* ctx) {
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
     return ms;
 }
+extern "C" {
 
 // ---- device-resident entry points ----------------------------------------------------------------
 int fabgpu_p256_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* qx, const void* qy, const void* e, const void* r,

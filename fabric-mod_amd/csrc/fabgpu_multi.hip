@@ -61,6 +61,7 @@ struct Dev {
     int ordinal = 0;
     fabgpu_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_verified = nullptr;   // "this shard's verify launch (and status copy) is queued": recorded in front of the collective
     void* h_in = nullptr;      // pinned staging of the shard: fields (+ message bytes + offsets in hash mode)
     void* d_in = nullptr;
     size_t in_cap = 0, din_cap = 0;
@@ -94,7 +95,9 @@ struct fabgpu_multi {
     Rccl rccl;
     bool host_merge = false;
     std::string why;            // why the merge is what it is (fabgpu_multi_collective)
-    bool comms_poisoned = false;  // a collective never came back: the communicators are abandoned, not destroyed
+    bool comms_poisoned = false;  // a collective never came back / failed half-way: the communicators are abandoned, not destroyed
+    bool devices_suspect = false; // ... and one may still sit on a device: shutdown neither synchronises nor frees there (it would wait for it)
+    int selfcheck_deadline_s = 10;
     std::mutex mu;
 };
 
@@ -103,6 +106,19 @@ namespace {
 void to_host_merge(fabgpu_multi* m, const char* why) {
     m->host_merge = true;
     m->why = why;
+}
+// A collective that never came back, or a group call that failed half-way: the communicators are never touched again (not even
+// destroyed: destroying one with a collective in flight can hang too), and the streams it sits on are abandoned with it - the shards
+// get fresh ones, so that the host merge's copies are not queued behind it.  may_still_run: something may still occupy the devices
+// (shutdown then leaks their memory rather than wait for it).
+void abandon_collective(fabgpu_multi* m, bool may_still_run) {
+    m->comms_poisoned = true;
+    m->devices_suspect = m->devices_suspect || may_still_run;
+    for (size_t g = 0; g < m->dev.size(); g++) {
+        Dev& d = m->dev[g];
+        hipStream_t fresh = nullptr;
+        if (hipSetDevice(d.ordinal) == hipSuccess && hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) d.stream = fresh;   // (the old one leaks)
+    }
 }
 
 // One all-gather of ONE word per device through the communicators just made, checked on EVERY device, with a deadline: a node whose
@@ -171,19 +187,12 @@ bool rccl_self_check(fabgpu_multi* m, std::string* why) {
         sh->done = true;
         sh->cv.notify_all();
     });
-    int deadline_s = 30;
-    if (const char* e = getenv("FABGPU_MULTI_SELFCHECK_TIMEOUT_S")) deadline_s = atoi(e) > 0 ? atoi(e) : deadline_s;
+    const int deadline_s = m->selfcheck_deadline_s;           // FABGPU_MULTI_SELFCHECK_SECONDS(s) of the init flags; 10 s by default
     std::unique_lock<std::mutex> lk(sh->mu);
     if (!sh->cv.wait_for(lk, std::chrono::seconds(deadline_s), [&] { return sh->done; })) {
         lk.unlock();
         t.detach();
-        m->comms_poisoned = true;
-        // the streams the stuck collective sits on are abandoned with it: the shards get fresh ones
-        for (int g = 0; g < G; g++) {
-            Dev& d = m->dev[(size_t)g];
-            hipStream_t fresh = nullptr;
-            if (hipSetDevice(d.ordinal) == hipSuccess && hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) d.stream = fresh;
-        }
+        abandon_collective(m, /*may_still_run=*/true);
         *why = "self-check: the all-gather did not complete within " + std::to_string(deadline_s) + " s";
         return false;
     }
@@ -199,13 +208,14 @@ extern "C" {
 
 int fabgpu_multi_init(const int32_t* devices, int n_devices, uint32_t flags, fabgpu_multi** out) {
     if (!out || n_devices <= 0 || n_devices > 64) return FABGPU_EINVAL;
-    if (flags & ~(uint32_t)FABGPU_MULTI_HOST_MERGE) return FABGPU_EINVAL;
+    if (flags & ~(uint32_t)(FABGPU_MULTI_HOST_MERGE | 0xFF00u)) return FABGPU_EINVAL;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
     fabgpu_multi* m = new (std::nothrow) fabgpu_multi();
     if (!m) return FABGPU_ENOMEM;
     m->host_merge = (flags & FABGPU_MULTI_HOST_MERGE) != 0;
+    if ((flags >> 8) & 0xFFu) m->selfcheck_deadline_s = (int)((flags >> 8) & 0xFFu);
     m->dev.resize((size_t)n_devices);
     int rc = FABGPU_OK;
     std::vector<int> ords((size_t)n_devices);
@@ -219,7 +229,9 @@ int fabgpu_multi_init(const int32_t* devices, int n_devices, uint32_t flags, fab
         cfg.device = o;
         rc = fabgpu_init(&cfg, &m->dev[g].ctx);                 // generator comb table per device: replicated, as the survey says
         if (rc != FABGPU_OK) break;
-        if (hipSetDevice(o) != hipSuccess || hipStreamCreateWithFlags(&m->dev[g].stream, hipStreamNonBlocking) != hipSuccess) rc = FABGPU_ENODEV;
+        if (hipSetDevice(o) != hipSuccess || hipStreamCreateWithFlags(&m->dev[g].stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&m->dev[g].ev_verified, hipEventDisableTiming) != hipSuccess)
+            rc = FABGPU_ENODEV;
     }
     if (rc == FABGPU_OK && m->host_merge) m->why = "FABGPU_MULTI_HOST_MERGE asked for it";
     if (rc == FABGPU_OK && !m->host_merge) {
@@ -253,6 +265,18 @@ int fabgpu_multi_init(const int32_t* devices, int n_devices, uint32_t flags, fab
 
 void fabgpu_multi_shutdown(fabgpu_multi* m) {
     if (!m) return;
+    if (m->devices_suspect) {
+        // a collective that never completed may still occupy a device: hipStreamSynchronize, hipFree and fabgpu_shutdown would all wait for
+        // it, possibly for ever.  The process keeps its device memory until it exits; what can be released without touching a device is.
+        fprintf(stderr, "fabgpu_multi_shutdown: a collective was abandoned on these devices; their buffers are left to process exit\n");
+        for (size_t g = 0; g < m->dev.size(); g++) {
+            Dev& d = m->dev[g];
+            if (d.h_in) hipHostFree(d.h_in);
+            if (d.h_out) hipHostFree(d.h_out);
+        }
+        delete m;
+        return;
+    }
     for (size_t g = 0; g < m->dev.size(); g++) {
         Dev& d = m->dev[g];
         hipSetDevice(d.ordinal);
@@ -271,6 +295,7 @@ void fabgpu_multi_shutdown(fabgpu_multi* m) {
         if (d.d_merged) hipFree(d.d_merged);
         if (d.d_status) hipFree(d.d_status);
         if (d.stream) hipStreamDestroy(d.stream);
+        if (d.ev_verified) hipEventDestroy(d.ev_verified);
         if (d.ctx) fabgpu_shutdown(d.ctx);
     }
     delete m;
@@ -407,6 +432,7 @@ static int multi_verify(fabgpu_multi* m, size_t n, const uint8_t* arena, const u
             err = hipMemcpyAsync((uint8_t*)d.h_out + round_up((size_t)G * wpr * 8, 64), d.d_status, cnt, hipMemcpyDeviceToHost, d.stream);
             if (err != hipSuccess) out = hip_rc(err);
         }
+        if (out == FABGPU_OK && d.ev_verified && hipEventRecord(d.ev_verified, d.stream) != hipSuccess) out = FABGPU_ELAUNCH;
     });
     for (uint32_t g = 0; g < G; g++)
         if (rcs[g] != FABGPU_OK) return rcs[g];
@@ -426,7 +452,17 @@ static int multi_verify(fabgpu_multi* m, size_t n, const uint8_t* arena, const u
             hipError_t err = hipMemcpyAsync(d0.h_out, d0.d_merged, (size_t)G * wpr * 8, hipMemcpyDeviceToHost, d0.stream);
             if (err != hipSuccess) return hip_rc(err);
         } else {
-            to_host_merge(m, "ncclAllGather returned an error on a batch: host merge from here on");   // this batch and every later one
+            // this batch and every later one are merged by the host - on fresh streams: a group call that failed half-way may have queued
+            // some ranks' share of the collective, and neither the copies below nor shutdown may wait behind those
+            to_host_merge(m, "ncclAllGather returned an error on a batch: host merge from here on");
+            abandon_collective(m, /*may_still_run=*/true);
+            for (uint32_t g = 0; g < G; g++) {             // the fresh streams wait for the verify launches queued on the old ones - not for the collective
+                Dev& d = m->dev[g];
+                hipSetDevice(d.ordinal);
+                if (!d.ev_verified) return FABGPU_ELAUNCH;
+                hipError_t e2 = hipStreamWaitEvent(d.stream, d.ev_verified, 0);
+                if (e2 != hipSuccess) return hip_rc(e2);
+            }
         }
     }
     if (m->host_merge) {

@@ -7,7 +7,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/fabgpu_bccsp.h"
+#include "fabgpu_testhooks.h"
 #include "p256_tables.h"
 
 using namespace fab;

@@ -101,24 +101,61 @@ ABI_SYMBOLS = [
     "fabgpu_identity_verify_batch", "fabgpu_identity_verify_batch_dev", "fabgpu_arena_stage",
     "fabgpu_idemix_issuer_register", "fabgpu_idemix_issuer_count", "fabgpu_idemix_nym_verify_batch", "fabgpu_idemix_nym_verify_batch_dev",
     "fabgpu_bn256_g1_on_curve",
-    "fabgpu_last_kernel_ms", "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
+    "fabgpu_ecdsa_unmarshal_signature", "fabgpu_ecdsa_is_low_s",
     "fabgpu_p256_pubkey_on_curve", "fabgpu_hash_to_int",
     "fabgpu_csp_new", "fabgpu_csp_free", "fabgpu_csp_ctx", "fabgpu_csp_key_import", "fabgpu_csp_hash", "fabgpu_csp_verify",
     "fabgpu_csp_verify_batch", "fabgpu_csp_identity_verify_batch", "fabgpu_csp_block_preverify", "fabgpu_block_parse", "fabgpu_x509_p256_pubkey",
     "fabgpu_csp_idemix_issuer_import", "fabgpu_csp_idemix_nym_verify_batch", "fabgpu_csp_idemix_msp_register", "fabgpu_csp_idemix_msp_register2", "fabgpu_block_hash_checks",
-    "fabgpu_synth_batch", "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_block_pass_abandon", "fabgpu_idemix_issuer_key_is_canonical", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_lookup_nym", "fabgpu_csp_memo_has_block", "fabgpu_csp_memo_evict_block",
+    "fabgpu_block_tuples", "fabgpu_csp_block_preverify2", "fabgpu_csp_block_pass_abandon", "fabgpu_idemix_issuer_key_is_canonical", "fabgpu_csp_memo_lookup", "fabgpu_csp_memo_lookup_nym", "fabgpu_csp_memo_has_block", "fabgpu_csp_memo_evict_block",
     "fabgpu_csp_verify_coalesced", "fabgpu_csp_identity_verify_coalesced", "fabgpu_csp_coalescer_configure", "fabgpu_csp_coalescer_stats",
     "fabgpu_csp_memo_stats", "fabgpu_csp_memo_set_capacity", "fabgpu_csp_identity_cache_limits", "fabgpu_csp_identity_cache_size",
     "fabgpu_multi_init", "fabgpu_multi_shutdown", "fabgpu_multi_device_count", "fabgpu_multi_p256_verify_batch",
     "fabgpu_multi_sha256_p256_verify_batch", "fabgpu_multi_plan", "fabgpu_multi_merged_bitmap_dev", "fabgpu_multi_collective",
-    "fabgpu_csp_pass_routes", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast", "fabgpu_identity_table_hash", "fabgpu_csp_gate_probe",
-    "fabgpu_gate_sig_any", "fabgpu_identity_to_p256", "fabgpu_csp_idfix_probe", "fabgpu_csp_pass_stats",
+    "fabgpu_csp_pass_routes",
+    "fabgpu_identity_to_p256", "fabgpu_csp_pass_stats",
     "fabgpu_p256_key_register_many", "fabgpu_csp_new2", "fabgpu_csp_device_count", "fabgpu_csp_ctx_of", "fabgpu_csp_passes_per_device",
     "fabgpu_csp_route_block", "fabgpu_csp_set_option", "fabgpu_csp_get_option",
     "fabgpu_csp_hash_lookup", "fabgpu_csp_hash_memo_stats",
 ]
 
+# what libfabgpu_testhooks.so exports (fabric-mod_amd/csrc/fabgpu_testhooks.h): probes, walker comparisons, the synthetic block generator, the
+# kernel timer - test and bench infrastructure that is NOT part of the product's C ABI and not in libfabgpu.so
+HOOK_SYMBOLS = [
+    "fabgpu_synth_batch", "fabgpu_last_kernel_ms", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast",
+    "fabgpu_gate_sig_any", "fabgpu_csp_idfix_probe", "fabgpu_csp_gate_probe", "fabgpu_identity_table_hash",
+]
+_HOOKS_PATH = os.path.join(os.path.dirname(_LIB_PATH), "libfabgpu_testhooks.so")
+
 _lib = None
+_hooks = None
+
+
+def hooks_path() -> str:
+    return _HOOKS_PATH
+
+
+def load_hooks():
+    """libfabgpu_testhooks.so, next to (and linked against) the product library; tests, bench.py and tools only."""
+    global _hooks
+    if _hooks is not None:
+        return _hooks
+    load()                                               # the product library first: the hooks resolve against it
+    if not os.path.exists(_HOOKS_PATH):
+        raise FabgpuError("libfabgpu_testhooks.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % _HOOKS_PATH)
+    H = ctypes.CDLL(_HOOKS_PATH)
+    H.fabgpu_last_kernel_ms.argtypes = [_vp]
+    H.fabgpu_last_kernel_ms.restype = ctypes.c_float
+    H.fabgpu_csp_block_walk_compare.argtypes = [_vp, _u8p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
+    H.fabgpu_block_walk_twopass_compare.argtypes = [_u8p, _sz, ctypes.c_char_p, _sz]
+    H.fabgpu_gate_sig_fast.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
+    H.fabgpu_csp_gate_probe.argtypes = [_vp, ctypes.c_uint32, _u8p, _sz, _u32p, _u8p, _u8p, _u8p]
+    H.fabgpu_gate_sig_any.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
+    H.fabgpu_csp_idfix_probe.argtypes = [_vp, ctypes.c_uint32, _u8p, _sz, _u32p, _u8p, _u8p]
+    H.fabgpu_identity_table_hash.argtypes = [ctypes.c_char_p, _sz]
+    H.fabgpu_identity_table_hash.restype = ctypes.c_uint64
+    H.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
+    _hooks = H
+    return H
 
 
 def lib_path() -> str:
@@ -160,8 +197,6 @@ def load():
     L.fabgpu_idemix_nym_verify_batch.argtypes = [_vp, _sz, _u8p, _u32p, _u32p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u64p, _u8p]
     L.fabgpu_idemix_nym_verify_batch_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.fabgpu_bn256_g1_on_curve.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
-    L.fabgpu_last_kernel_ms.argtypes = [_vp]
-    L.fabgpu_last_kernel_ms.restype = ctypes.c_float
     L.fabgpu_ecdsa_unmarshal_signature.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     L.fabgpu_ecdsa_is_low_s.argtypes = [ctypes.c_char_p]
     L.fabgpu_p256_pubkey_on_curve.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
@@ -210,16 +245,8 @@ def load():
     L.fabgpu_csp_identity_cache_limits.argtypes = [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
     L.fabgpu_csp_identity_cache_size.argtypes = [_vp, _u64p]
     L.fabgpu_csp_pass_routes.argtypes = [_vp, _u64p, _u64p, ctypes.c_char_p, _sz]
-    L.fabgpu_csp_block_walk_compare.argtypes = [_vp, _u8p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
-    L.fabgpu_block_walk_twopass_compare.argtypes = [_u8p, _sz, ctypes.c_char_p, _sz]
-    L.fabgpu_gate_sig_fast.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
-    L.fabgpu_csp_gate_probe.argtypes = [_vp, ctypes.c_uint32, _u8p, _sz, _u32p, _u8p, _u8p, _u8p]
-    L.fabgpu_gate_sig_any.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
     L.fabgpu_identity_to_p256.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p]
     L.fabgpu_csp_pass_stats.argtypes = [_vp, _u64p]
-    L.fabgpu_csp_idfix_probe.argtypes = [_vp, ctypes.c_uint32, _u8p, _sz, _u32p, _u8p, _u8p]
-    L.fabgpu_identity_table_hash.argtypes = [ctypes.c_char_p, _sz]
-    L.fabgpu_identity_table_hash.restype = ctypes.c_uint64
     L.fabgpu_multi_init.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(_vp)]
     L.fabgpu_multi_shutdown.argtypes = [_vp]
     L.fabgpu_multi_shutdown.restype = None
@@ -232,7 +259,6 @@ def load():
     L.fabgpu_multi_collective.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
     L.fabgpu_block_tuples.argtypes = [_u8p, _sz, ctypes.c_uint32, _u32p, _u32p, _u8p, _u32p, _u8p, ctypes.c_uint32, _u32p, _u32p]
     L.fabgpu_x509_p256_pubkey.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
-    L.fabgpu_synth_batch.argtypes = [_sz, ctypes.c_uint64, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_int]
     _lib = L
     return L
 
@@ -291,11 +317,11 @@ def hash_to_int(digest: bytes) -> bytes:
 
 
 def synth_batch(n: int, seed: int = 20260921, invalid_permille: int = 0, e_in: Optional[np.ndarray] = None, threads: int = 0):
-    """Synthetic tuples; see include/fabgpu_bccsp.h fabgpu_synth_batch."""
+    """Synthetic tuples; see fabric-mod_amd/csrc/fabgpu_testhooks.h fabgpu_synth_batch (test-hook library)."""
     qx, qy, e, r, s = (np.zeros((n, 32), np.uint8) for _ in range(5))
     kind = np.zeros(n, np.uint8)
     ein = None if e_in is None else _a8(e_in)
-    _check(load().fabgpu_synth_batch(n, seed, invalid_permille, _p8(ein), _p8(qx), _p8(qy), _p8(e), _p8(r), _p8(s), _p8(kind), threads),
+    _check(load_hooks().fabgpu_synth_batch(n, seed, invalid_permille, _p8(ein), _p8(qx), _p8(qy), _p8(e), _p8(r), _p8(s), _p8(kind), threads),
            "fabgpu_synth_batch")
     return dict(qx=qx, qy=qy, e=e, r=r, s=s, kind=kind)
 
@@ -511,7 +537,7 @@ class Context:
                "fabgpu_p256_verify_batch_keyed_dev")
 
     def last_kernel_ms(self) -> float:
-        return float(self._L.fabgpu_last_kernel_ms(self._h))
+        return float(load_hooks().fabgpu_last_kernel_ms(self._h))
 
 
 MULTI_HOST_MERGE = 1
@@ -532,11 +558,13 @@ def multi_plan(n: int, n_devices: int, off=None):
 class MultiContext:
     """fabgpu_multi_*: one batch cut over the GPUs of the node, RCCL all-gather of the verdict bitmaps (SURVEY 8(e), configs[2])."""
 
-    def __init__(self, devices: Sequence[int], host_merge: bool = False):
+    def __init__(self, devices: Sequence[int], host_merge: bool = False, selfcheck_seconds: int = 0):
+        """selfcheck_seconds: FABGPU_MULTI_SELFCHECK_SECONDS - the deadline of the init-time all-gather self-check (0: the library's 10 s)"""
         self._L = load()
         self._h = _vp()
         d = (ctypes.c_int32 * len(devices))(*devices)
-        rc = self._L.fabgpu_multi_init(d, len(devices), MULTI_HOST_MERGE if host_merge else 0, ctypes.byref(self._h))
+        flags = (MULTI_HOST_MERGE if host_merge else 0) | ((int(selfcheck_seconds) & 0xFF) << 8)
+        rc = self._L.fabgpu_multi_init(d, len(devices), flags, ctypes.byref(self._h))
         if rc != FABGPU_OK:
             raise FabgpuError("fabgpu_multi_init failed: %s (%d)" % (strerror(rc), rc))
 
@@ -957,7 +985,7 @@ def block_walk_compare(csp: "GPUCSP", block: bytes):
     buf = np.frombuffer(block, dtype=np.uint8)
     declined = ctypes.c_int(0)
     diff = ctypes.create_string_buffer(256)
-    rc = csp._L.fabgpu_csp_block_walk_compare(csp._h, _p8(buf), buf.size, ctypes.byref(declined), diff, 256)
+    rc = load_hooks().fabgpu_csp_block_walk_compare(csp._h, _p8(buf), buf.size, ctypes.byref(declined), diff, 256)
     if rc < 0:
         raise FabgpuError("fabgpu_csp_block_walk_compare failed: %s (%d)" % (strerror(rc), rc))
     return rc == 0, bool(declined.value), diff.value.decode(errors="replace")
@@ -968,7 +996,7 @@ def block_walk_twopass_compare(block: bytes):
     (identical, text); None when both refuse the framing."""
     buf = np.frombuffer(block, dtype=np.uint8)
     diff = ctypes.create_string_buffer(256)
-    rc = load().fabgpu_block_walk_twopass_compare(_p8(buf), buf.size, diff, 256)
+    rc = load_hooks().fabgpu_block_walk_twopass_compare(_p8(buf), buf.size, diff, 256)
     if rc == FABGPU_EINVAL:
         return None
     return rc == 0, diff.value.decode(errors="replace")
@@ -977,7 +1005,7 @@ def block_walk_twopass_compare(block: bytes):
 def gate_sig_fast(sig: bytes):
     """TEST HOOK (pure host): the device's signature gate -> (code, r32, s32); code 0 submit, 1 high-S, 2 empty, 3 declined."""
     r, s2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
-    code = load().fabgpu_gate_sig_fast(sig, len(sig), r, s2)
+    code = load_hooks().fabgpu_gate_sig_fast(sig, len(sig), r, s2)
     return code, r.raw, s2.raw
 
 
@@ -985,7 +1013,7 @@ def gate_sig_any(sig: bytes):
     """TEST HOOK (pure host): the gate the device route applies to every signature -> (code, r32, s32); code 0 submit, 1 high-S, 2 empty,
     4 does not unmarshal / r, s <= 0, 5 r of more than 256 bits."""
     r, s2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
-    code = load().fabgpu_gate_sig_any(sig, len(sig), r, s2)
+    code = load_hooks().fabgpu_gate_sig_any(sig, len(sig), r, s2)
     return code, r.raw, s2.raw
 
 
@@ -1004,7 +1032,7 @@ def idfix_probe(csp: "GPUCSP", idents: Sequence[bytes]):
     spans[:, 1] = ends
     spans[1:, 0] = ends[:-1]
     code, key = np.zeros(n, np.uint8), np.zeros((n, 64), np.uint8)
-    _check(csp._L.fabgpu_csp_idfix_probe(csp._h, n, _p8(arena), arena.size, spans.ctypes.data_as(_u32p), _p8(code), _p8(key)), "fabgpu_csp_idfix_probe")
+    _check(load_hooks().fabgpu_csp_idfix_probe(csp._h, n, _p8(arena), arena.size, spans.ctypes.data_as(_u32p), _p8(code), _p8(key)), "fabgpu_csp_idfix_probe")
     return code, key
 
 
@@ -1017,12 +1045,12 @@ def gate_probe(csp: "GPUCSP", sigs: Sequence[bytes]):
     spans[:, 1] = ends
     spans[1:, 0] = ends[:-1]
     code, r, s2 = np.zeros(n, np.uint8), np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
-    _check(csp._L.fabgpu_csp_gate_probe(csp._h, n, _p8(arena), arena.size, spans.ctypes.data_as(_u32p), _p8(code), _p8(r), _p8(s2)), "fabgpu_csp_gate_probe")
+    _check(load_hooks().fabgpu_csp_gate_probe(csp._h, n, _p8(arena), arena.size, spans.ctypes.data_as(_u32p), _p8(code), _p8(r), _p8(s2)), "fabgpu_csp_gate_probe")
     return code, r, s2
 
 
 def identity_table_hash(b: bytes) -> int:
-    return load().fabgpu_identity_table_hash(b, len(b))
+    return load_hooks().fabgpu_identity_table_hash(b, len(b))
 
 
 PASS_SEED_MEMO, PASS_NO_BLOCK_SIGS = 1, 2

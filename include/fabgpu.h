@@ -65,7 +65,7 @@ typedef struct fabgpu_ctx fabgpu_ctx;
 /* fabgpu_cfg.flags */
 #define FABGPU_FLAG_ONE_LANE_ONLY 1u /* never use the two-lanes-per-signature kernel (parity tests run both variants) */
 #define FABGPU_FLAG_NO_QUAD 4u       /* idemix: never use the four-lanes-per-signature kernel (parity tests run all three variants) */
-#define FABGPU_FLAG_TIME_KERNELS 2u  /* bracket every launch with timing events so that fabgpu_last_kernel_ms answers (tools only) */
+#define FABGPU_FLAG_TIME_KERNELS 2u  /* bracket every launch with timing events (tools only: read back through the test-hook library's fabgpu_last_kernel_ms) */
 #define FABGPU_FLAG_PAIR_TABLE_LDS 8u    /* two-lanes-per-signature verify kernel: per-signature table in LDS (8 entries, 65 signed 4-bit windows) */
 #define FABGPU_FLAG_PAIR_TABLE_GLOBAL 16u /* ... in the global workspace (16 entries, 52 signed 5-bit windows).  Neither: the default */
 #define FABGPU_FLAG_NO_WIDE 32u          /* registered keys: never use the eight-lanes-per-signature, two-phase kernels that serve launches of up to
@@ -262,6 +262,9 @@ int fabgpu_bn256_g1_on_curve(const uint8_t* x32, const uint8_t* y32);
  * stream; this entry point is for batches beyond one GPU's saturation point, N blocks in flight are N contexts. */
 typedef struct fabgpu_multi fabgpu_multi;
 #define FABGPU_MULTI_HOST_MERGE 1u
+/* bits 8-15 of `flags`: the deadline, in seconds, of the one-word all-gather self-check fabgpu_multi_init runs (0: 10 s).  Init blocks
+ * for at most that long on a node whose collective never completes, then merges on the host. */
+#define FABGPU_MULTI_SELFCHECK_SECONDS(s) (((uint32_t)(s) & 0xFFu) << 8)
 int fabgpu_multi_init(const int32_t* devices, int n_devices, uint32_t flags, fabgpu_multi** out);
 void fabgpu_multi_shutdown(fabgpu_multi* m);
 int fabgpu_multi_device_count(fabgpu_multi* m);
@@ -274,14 +277,12 @@ int fabgpu_multi_plan(size_t n, const uint32_t* off, uint32_t n_devices, uint64_
 const void* fabgpu_multi_merged_bitmap_dev(fabgpu_multi* m, int g);
 /* How the shard bitmaps are merged.  fabgpu_multi_init never fails for want of a collective: one device, a repeated ordinal, no
  * librccl, ncclCommInitAll failing, or the one-word ncclAllGather self-check it runs across its devices failing (wrong word, error,
- * or no completion within FABGPU_MULTI_SELFCHECK_TIMEOUT_S, default 30 s) all end in the host merge (G small D2H copies, SURVEY.md
- * 8(e)), and so does an ncclAllGather error on a later batch.  Returns the number of RCCL ranks (G) when the merge is the
+ * or no completion within the deadline of FABGPU_MULTI_SELFCHECK_SECONDS, 10 s by default) all end in the host merge (G small D2H
+ * copies), and so does an ncclAllGather error on a later batch - the communicators are then abandoned (never used or
+ * destroyed again), the shards move to fresh streams, and fabgpu_multi_shutdown leaves the device buffers to process exit instead of
+ * waiting for a collective that may never finish.  Returns the number of RCCL ranks (G) when the merge is the
  * collective, 0 when the host merges; `why` (optional, NUL-terminated) says which. */
 int fabgpu_multi_collective(fabgpu_multi* m, char* why, size_t why_cap);
-
-/* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
- * launch stream.  Only for contexts created with FABGPU_FLAG_TIME_KERNELS; <0 otherwise / if nothing was launched. */
-float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);
 
 /* ---- host-side gates the Go provider calls before marshalling a tuple (pure CPU, no device) ---- */
 

@@ -114,15 +114,6 @@ int fabgpu_csp_identity_verify_batch(fabgpu_csp* csp, size_t n, const uint8_t* q
                                      const uint32_t* msg_off, const uint8_t* sig_arena, const uint32_t* sig_off, char* errs,
                                      size_t errstride);
 
-/* Synthetic block generator: n tuples, fresh P-256 keypair per signature, low-S, `invalid_permille`
- * of them mutated (equal parts 1: flipped digest bit, 2: wrong key, 3: s -> n-s, 4: r+1); kind[i] in 0..4 records the
- * mutation.  e_in (n x 32) gives the digests to sign (e.g. SHA-256 of synthetic messages computed by
- * fabgpu_sha256_batch); NULL draws random digests.  e_out receives the digest the verifier should be given (for kind 1
- * it differs from the signed one in one bit; callers in hash mode flip a message bit instead).  Pure host code,
- * deterministic in (seed, n, e_in). */
-int fabgpu_synth_batch(size_t n, uint64_t seed, uint32_t invalid_permille, const uint8_t* e_in, uint8_t* qx, uint8_t* qy,
-                       uint8_t* e_out, uint8_t* r, uint8_t* s, uint8_t* kind, int threads);
-
 /* ---- block-level pre-verify pass (extensions/validation/validation.go:48-64 is the hook) ----
  * One fused launch for every signature of a marshalled common.Block:
  *   creator:      SignatureHeader.creator over Envelope.payload            (core/common/validation/msgvalidation.go:258-298)
@@ -223,7 +214,7 @@ int fabgpu_csp_identity_cache_size(fabgpu_csp* csp, uint64_t* identities);
  * bccsp/utils/ecdsa.go:43-92 decides it -, identity lookup, certificates of identities nobody has met decoded by a wavefront each,
  * submission arrays, digest comparisons and flags as kernels; block_walk_dev.h).  The host walk answers what is left: blocks that were
  * not staged, blocks on a provider with idemix MSPs, a certificate longer than the device decoder's buffer (3 KiB of DER), a block
- * without any signature for the device to decide.  Same answers either way.  FABGPU_PASS_DEVICE_WALK=0 keeps every block on the host
+ * without any signature for the device to decide. Same answers either way.  The provider option pass_device_walk < 0 keeps every block on the host
  * walk.  This reports how many passes went which way and why the last block was declined by the device walk. */
 int fabgpu_csp_pass_routes(fabgpu_csp* csp, uint64_t* device_walks, uint64_t* host_walks, char* last_decline, size_t cap);
 /* Device-route statistics since the provider was made: out4[0] verify launches repeated because the prediction "every signer of this
@@ -231,25 +222,9 @@ int fabgpu_csp_pass_routes(fabgpu_csp* csp, uint64_t* device_walks, uint64_t* ho
  * identity was not in the device's table (certificate decoded on the device), [2] identities that entered the cache that way,
  * [3] signatures outside the common DER shape (decided by the general parser, on the device). */
 int fabgpu_csp_pass_stats(fabgpu_csp* csp, uint64_t* out4);
-/* TEST HOOK: the device walker against the host walker on one block, record for record.  0 identical (*declined = 1: the device walk
- * declined the block, `diff` says why), 1 they differ (`diff` says where). */
-int fabgpu_csp_block_walk_compare(fabgpu_csp* csp, const uint8_t* block, size_t len, int* declined, char* diff, size_t cap);
-/* TEST HOOKS (pure host, no device): the device walk's two-run procedure (count, prefix sum, write) carried out serially on the host
- * and compared with the host walker (0 identical, 1 different, FABGPU_EINVAL framing refused); the device's signature gate (0 submit,
- * 1 high-S, 2 empty, 3 declined: the general parser decides); the identity-table hash. */
-int fabgpu_block_walk_twopass_compare(const uint8_t* block, size_t len, char* diff, size_t cap);
-int fabgpu_gate_sig_fast(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32);
-/* ... and the gate the device route applies to every signature (the fast gate, then the general parser for what that declines):
- * 0 submit (r32 / s32 set), 1 high-S, 2 empty, 4 does not unmarshal or r, s <= 0, 5 r of more than 256 bits ((false, nil)) */
-int fabgpu_gate_sig_any(const uint8_t* sig, size_t len, uint8_t* r32, uint8_t* s32);
-/* what the host route makes of a SerializedIdentity: 0 = PEM x509 certificate with an on-curve P-256 key (qxy64 = X || Y), 1 = anything else */
+/* what the host route makes of a SerializedIdentity: 0 = PEM x509 certificate with an on-curve P-256 key (qxy64 = X || Y), 1 = anything else
+ * (pure host; callers that hold identities as bytes - tools/go_call_replay.c - take the key bccsp.KeyImport would have remembered from it) */
 int fabgpu_identity_to_p256(const uint8_t* ident, size_t len, uint8_t* qxy64);
-/* TEST HOOK (device): the device route's identity decoder (one wavefront per identity) over n identities = arena[spans[2i], spans[2i+1]):
- * code 0 P-256 key (key[64 i ..] = X || Y), 1 not such an identity, 2 undecided (left to the host) */
-int fabgpu_csp_idfix_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* key);
-/* TEST HOOK (device): the same gate in the wavefront form the kernels run, over n signatures = arena[spans[2i], spans[2i+1]) */
-int fabgpu_csp_gate_probe(fabgpu_csp* csp, uint32_t n, const uint8_t* arena, size_t arena_len, const uint32_t* spans, uint8_t* code, uint8_t* r, uint8_t* s);
-uint64_t fabgpu_identity_table_hash(const uint8_t* p, size_t len);
 
 /* (An x509 chain-link batch - crypto/x509 CheckSignatureFrom for n certificates - was an entry point of rounds 2-4 WITHOUT a consumer:
  * the only caller on this path is crypto/x509's own Verify (msp/mspimpl.go:721-739), which offers no hook for a pre-computed verdict, and

@@ -45,6 +45,21 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(fabgpu.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(L, sym), sym
+    # ... and NOTHING else named fabgpu_*: the product library's C surface is the two public headers.  Probes, walker
+    # comparisons, the synthetic generator and the kernel timer live in libfabgpu_testhooks.so (fabric-mod_amd/csrc/fabgpu_testhooks.h).
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", fabgpu.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith("fabgpu_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    assert not [s_ for s_ in exported if any(w in s_ for w in ("probe", "compare", "synth", "last_kernel", "hosttest"))]
+    H = fabgpu.load_hooks()
+    nm = subprocess.run(["nm", "-D", "--defined-only", fabgpu.hooks_path()], capture_output=True, text=True, check=True).stdout
+    hooks = {ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith("fabgpu_")}
+    assert hooks == set(fabgpu.HOOK_SYMBOLS) and not (hooks & declared)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "fabric-mod_amd", "csrc", "fabgpu_testhooks.h")).read(), flags=re.S)
+    assert set(re.findall(r"\b(fabgpu_[a-z0-9_]+)\s*\(", hdr)) == hooks
+    for sym in hooks:
+        assert hasattr(H, sym), sym
     assert L.fabgpu_abi_version() == 6      # 6: fabgpu_block_pass.ms_stage / device_context, fabgpu_csp_new2 (5: n_device_decoded; 4: pseudonym signatures ride along)
     assert fabgpu.strerror(0) == "ok" and "bccsp/sw" in fabgpu.strerror(-2)
 

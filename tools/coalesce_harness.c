@@ -1,6 +1,7 @@
 /* Native driver of the coalescer through the C ABI only (plain C99 + pthreads, like a cgo caller would behave): T threads, each calling
  * fabgpu_csp_verify_coalesced (bccsp.Verify) in a loop on its own tuples; prints calls per second, launches and the mean batch.
- *   gcc -O2 -std=gnu99 -Iinclude tools/coalesce_harness.c -Lfabric-mod_amd/lib -lfabgpu -lpthread -o /tmp/coalesce
+ *   gcc -O2 -std=gnu99 -Iinclude -Ifabric-mod_amd/csrc tools/coalesce_harness.c -Lfabric-mod_amd/lib -lfabgpu_testhooks -lfabgpu -lpthread -o /tmp/coalesce
+ *   (the synthetic signatures come from the test-hook library: fabgpu_testhooks.h)
  *   LD_LIBRARY_PATH=fabric-mod_amd/lib /tmp/coalesce <threads> <calls per thread> [window_us]                                        */
 #include <pthread.h>
 #include <stdio.h>
@@ -9,6 +10,7 @@
 #include <time.h>
 
 #include "fabgpu_bccsp.h"
+#include "fabgpu_testhooks.h"
 
 #define N 4096
 static uint8_t qx[N * 32], qy[N * 32], e[N * 32], r[N * 32], s[N * 32], kind[N];
