@@ -179,6 +179,9 @@ def _sig(x, digits=6):
 
 def _dig(d, *path, default=None):
     for k in path:
+        if isinstance(d, list) and isinstance(k, int) and -len(d) <= k < len(d):
+            d = d[k]
+            continue
         if not isinstance(d, dict) or k not in d:
             return default
         d = d[k]
@@ -220,6 +223,12 @@ def compact_line(out, detail_path="bench_detail.json"):
         "kernel_ms_median_events": _dig(out, "dispersion", "median_ms"),
         "configs2_strong_value": _dig(out, "configs2_strong", "value"),
         "configs3_fused_value": _dig(out, "configs3_fused", "value"),
+        "value_two_blocks_in_flight": _dig(out, "two_blocks_in_flight", "value"),
+        "configs2_inprocess_value": _dig(out, "shard_of_8", "configs2_inprocess_value") if out.get("n_gpus", 1) == 1 else _dig(out, "configs2_inprocess", "legs", 0, "value"),
+        "configs2_shard_of_8_ms": _dig(out, "shard_of_8", "configs2_shard_of_8_ms"),
+        "configs2_inprocess_shard_of_8_ms": _dig(out, "shard_of_8", "configs2_inprocess_shard_of_8_ms"),
+        "predicted_strong_speedup_8": _dig(out, "shard_of_8", "predicted_strong_speedup_8_inprocess"),
+        "configs4_shard_of_8_ms": _dig(out, "shard_of_8", "configs4_shard_of_8_ms"),
         "configs4_mixed_value": _dig(out, "configs4_mixed", "value"),
         "configs4_mixed_ms_per_step": _dig(out, "configs4_mixed", "ms_per_step"),
         "idemix_kernel_ms": _dig(out, "configs4_mixed", "roofline", "kernel_ms"),
@@ -346,6 +355,70 @@ def mac_ceiling_leg():
 MAC_PER_NYM_VERIFY = 3.7e5
 # v_mad_i64_i32 the nym kernels execute per signature: ~1 740 products x 162 + ~1 000 squares x 126 in the 9 x 29-bit representation
 EXECUTED_MAC_PER_NYM_VERIFY = 4.1e5
+
+
+def shard_of_8_leg(ctx, torch, np, fabgpu, coracle, block, dev, got, n, full_kernel_ms, steps=20):
+    """What ONE GPU of an 8-GPU node would be handed by the two BASELINE configs that name 8 GPUs, timed HERE on the one GPU there is
+    (rows (e) / J2 have never run on hardware; these are predictions a SCALE run can be checked against):
+      configs[2] "same 10k x 3 block sharded across 8": rank 0's shard of the product's own plan (fabgpu_multi_plan: contiguous, 64-aligned)
+        - the kernel alone with the shard resident in HBM, and the whole in-process path fabgpu_multi takes per device (host pointers:
+        staging, H2D, kernel, verdict words back) through a one-device MultiContext; the same two figures for the WHOLE block give the
+        predicted strong speed-up at 8 GPUs = whole-block latency / shard latency (the all-gather of 8 x 59 words not included: it adds).
+      configs[4] "80 % ECDSA + 20 % idemix, 8 GPUs": 3 000 + 750 signatures on two streams (mixed_cfg4_leg at n / 8)."""
+    (lo, hi), wpr = fabgpu.multi_plan(n, 8)[0][0], fabgpu.multi_plan(n, 8)[1]
+    cnt = hi - lo
+    leg = {"what": "per-GPU share of the 8-GPU configs, timed on one GPU", "configs2_shard_tuples": cnt, "configs2_words_per_rank": wpr}
+    # the kernel on the shard, HBM-resident (the fields' first `cnt` rows: the plan's rank-0 shard starts at 0)
+    assert lo == 0
+    words = torch.zeros((cnt + 63) // 64, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.p256_verify_batch_dev(cnt, dev["qx"].data_ptr(), dev["qy"].data_ptr(), dev["e"].data_ptr(), dev["r"].data_ptr(), dev["s"].data_ptr(), words.data_ptr(), 0, stream)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    shard_kernel_ms = ev0.elapsed_time(ev1) / steps
+    assert (fabgpu.unpack_bits(words.cpu().numpy().view(np.uint64), cnt) == got[:cnt]).all(), "shard verdicts differ"
+    leg["configs2_shard_of_8_ms"] = shard_kernel_ms
+    leg["configs2_whole_block_ms"] = full_kernel_ms
+    leg["predicted_strong_speedup_8_hbm_resident"] = full_kernel_ms / shard_kernel_ms
+    # the product's in-process path (fabgpu_multi: what `configs2_inprocess` runs with G devices) on one device: the whole block, then the shard
+    m = fabgpu.MultiContext([0])
+    try:
+        def wall(k):
+            f = [block[x][:k] for x in ("qx", "qy", "e", "r", "s")]
+            for _ in range(3):
+                bits, _ = m.p256_verify_batch(*f, want_status=False)
+            t = []
+            for _ in range(steps):
+                c0 = time.perf_counter()
+                bits, _ = m.p256_verify_batch(*f, want_status=False)
+                t.append((time.perf_counter() - c0) * 1e3)
+            assert (bits == got[:k]).all(), "fabgpu_multi verdicts differ"
+            return statistics.median(t)
+        whole_ms, shard_ms = wall(n), wall(cnt)
+    finally:
+        m.close()
+    leg["configs2_inprocess_ms"] = whole_ms
+    leg["configs2_inprocess_value"] = n / (whole_ms * 1e-3)
+    leg["configs2_inprocess_shard_of_8_ms"] = shard_ms
+    leg["predicted_strong_speedup_8_inprocess"] = whole_ms / shard_ms
+    leg["predicted_configs2_value_at_8_gpus"] = n / (shard_ms * 1e-3)
+    try:
+        mixed = mixed_cfg4_leg(torch, np, fabgpu, coracle, steps=steps, n=n // 8)
+        leg["configs4_shard_of_8_ms"] = mixed.get("ms_per_step")
+        leg["configs4_shard_signatures"] = n // 8
+        leg["predicted_configs4_value_at_8_gpus"] = n / (mixed["ms_per_step"] * 1e-3) if mixed.get("ms_per_step") else None
+    except Exception as e:                                              # noqa: BLE001
+        leg["configs4_shard_error"] = repr(e)[:200]
+    return leg
 
 
 def mixed_cfg4_leg(torch, np, fabgpu, coracle, steps=20, n=30000, msg_len=4608, base=192, rank=0, world=1, dist=None, sharding=None, dry=False, mac_peak=None,
@@ -913,8 +986,9 @@ def main():
                     "(the batch is synthesised on the CPU while the GPU idles; after 0.2 s of idle the first ~25 launches run at 0.735 ms, then 0.635: "
                     "tools/gpu_r05_gap_probe.py).  0 = round 4's protocol")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--two-streams", action="store_true", help="also report two blocks in flight on one GPU (alternating HIP streams); off by default: its "
-                    "overlapped launches of the same kernel would distort a rocprofv3 average taken over the run")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the leg that runs two blocks in flight on one GPU (alternating HIP streams; reported as "
+                    "value_two_blocks_in_flight, never as `value`)")
+    ap.add_argument("--two-streams", action="store_true", help="(accepted for compatibility: the two-blocks-in-flight leg runs by default since round 6)")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (no pcie / configs[2] / configs[3] / cpu legs)")
     ap.add_argument("--tx", type=int, default=N_TX, help="tx per block (default = BASELINE configs[1]; other values are exploration only)")
     ap.add_argument("--pair-table", choices=("auto", "lds", "global"), default="auto", help="where the two-lane verify kernel keeps its per-signature table "
@@ -1196,7 +1270,14 @@ def main():
             out["pcie_inclusive"] = {"value": n / (med * 1e-3), "unit": "verifies/s", "median_ms": med, "p95_ms": pctl(wall, 0.95), "min_ms": min(wall), "iters": len(wall),
                                      "what": "fabgpu_p256_verify_batch (host pointers): 5 field copies into pinned staging + H2D 4.8 MB + kernel + D2H bitmap, "
                                              "wall clock around the blocking C-ABI call (through ctypes)"}
-        if world == 1 and extras and args.two_streams:
+        if world == 1 and extras and n_tx == N_TX:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import coracle as _co8
+                out["shard_of_8"] = shard_of_8_leg(ctx, torch, np, fabgpu, _co8, block, dev, got, n, ms_per_step, steps=args.steps)
+            except Exception as e:                                                                         # noqa: BLE001
+                out["shard_of_8"] = {"error": repr(e)[:300]}
+        if world == 1 and extras and not args.no_two_streams:
             # Two blocks in flight on ONE GPU (two channels validating at once): a 30 000-tuple block is one wave per SIMD, and a lone wave
             # issues one instruction per ~4.3 cycles - a second block on a second stream fills the issue slots the first leaves empty.
             # Reported beside the headline, never as `value`: the contract's step is one block at a time on one stream.

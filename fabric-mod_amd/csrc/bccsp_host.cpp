@@ -293,6 +293,8 @@ int64_t GPUCSP::GetOption(const std::string& name) const {
     std::lock_guard<std::mutex> lk(opt_mu_);
     if (name == "pass_stage_min_bytes") return opts_.pass_stage_min_bytes;
     if (name == "n_devices") return (int64_t)devs_.size();
+    if (name == "registrations_dropped") return (int64_t)reg_dropped_.load(std::memory_order_relaxed);        // (read-only counters)
+    if (name == "registration_id_mismatches") return (int64_t)reg_id_mismatches_.load(std::memory_order_relaxed);
     for (const OptField& o : kIntOpts)
         if (name == o.name) return opts_.*(o.f);
     return INT64_MIN;
@@ -330,23 +332,73 @@ int64_t GPUCSP::RegisterKeyOnAllDevices(const uint8_t* qx32, const uint8_t* qy32
         if (ids[g] != ids[0]) return -1;
     return ids[0];
 }
+// A batch of keys on every device of the pool, tables built on the devices (key_register_batch).  true: ids[i] = the common id of key
+// i, or -1 where the devices disagree (that key verifies on the fresh-key kernels).  false: some device could not - nothing is recorded as
+// pending (whatever a device did install is complete and idempotent), the caller registers key by key with host-built tables instead.
+bool GPUCSP::RegisterKeysOnAllDevices(const std::vector<std::pair<std::string, CachedIdentity>>& keys, std::vector<int64_t>& ids) const {
+    if (keys.empty()) return true;
+    std::lock_guard<std::mutex> lk(reg_mu_);
+    if (!HealPendingRegistrationsLocked()) return false;
+    const int G = (int)devs_.size(), n = (int)keys.size();
+    std::vector<uint8_t> qxy((size_t)64 * n);
+    for (int i = 0; i < n; i++) {
+        memcpy(&qxy[64 * (size_t)i], keys[(size_t)i].second.qx, 32);
+        memcpy(&qxy[64 * (size_t)i + 32], keys[(size_t)i].second.qy, 32);
+    }
+    std::vector<std::vector<uint32_t>> got((size_t)G, std::vector<uint32_t>((size_t)n, 0));
+    std::vector<int> rcs((size_t)G, FABGPU_OK);
+    auto one = [&](int g) { rcs[(size_t)g] = key_register_batch(devs_[(size_t)g]->ctx, n, qxy.data(), got[(size_t)g].data()); };
+    if (G == 1) one(0);
+    else run_workers(G, one);
+    for (int g = 0; g < G; g++)
+        if (rcs[(size_t)g] != FABGPU_OK) return false;
+    for (int i = 0; i < n; i++) {
+        bool same = true;
+        for (int g = 1; g < G; g++) same = same && got[(size_t)g][(size_t)i] == got[0][(size_t)i];
+        ids[(size_t)i] = same ? (int64_t)got[0][(size_t)i] : -1;
+    }
+    return true;
+}
 // Replays the registrations that reached only some devices (idempotent where the key / issuer already is).  Called with reg_mu_ held.
 bool GPUCSP::HealPendingRegistrationsLocked() const {
     const int G = (int)devs_.size();
     fabgpu_ctx* cs[kMaxProviderDevices];
     uint32_t ids[kMaxProviderDevices];
     for (int g = 0; g < G; g++) cs[g] = devs_[(size_t)g]->ctx;
+    // A replay that keeps failing (a device out of memory for good, its key or issuer table full) must not stop every later registration
+    // for the life of the provider: after kMaxHealAttempts the entry is DROPPED and counted.  The pool's per-device ids may
+    // then differ for what is registered afterwards - RegisterKeyOnAllDevices / ImportIdemixIssuer answer -1 for such a key or issuer
+    // (the fresh-key kernels / bccsp/idemix serve it: slower, never wrong), they do not fail.
+    constexpr uint32_t kMaxHealAttempts = 3;
+    auto give_up = [&](const char* what) {
+        heal_attempts_ = 0;
+        reg_dropped_.fetch_add(1, std::memory_order_relaxed);
+        fprintf(stderr, "fabgpu: %s could not be installed on every device after %u attempts; dropped - registrations go on, ids may differ between devices\n", what,
+                kMaxHealAttempts);
+    };
     while (!pending_keys_.empty()) {
         const PendingKey& pk = pending_keys_.front();
-        if (key_register_many_prebuilt(cs, G, pk.qx, pk.qy, nullptr, ids) != FABGPU_OK) return false;
+        if (key_register_many_prebuilt(cs, G, pk.qx, pk.qy, nullptr, ids) != FABGPU_OK) {
+            if (++heal_attempts_ < kMaxHealAttempts) return false;
+            give_up("a key table");
+        } else {
+            heal_attempts_ = 0;
+        }
         pending_keys_.erase(pending_keys_.begin());
     }
     while (!pending_issuers_.empty()) {
         const std::string& raw = pending_issuers_.front();
-        for (int g = 0; g < G; g++) {
+        bool ok = true;
+        for (int g = 0; g < G && ok; g++) {
             IdemixCSP ic(cs[g]);
             IdemixIssuerPublicKey k;
-            if (!ic.IssuerKeyImport((const uint8_t*)raw.data(), raw.size(), k).ok() || k.issuer_id < 0) return false;
+            ok = ic.IssuerKeyImport((const uint8_t*)raw.data(), raw.size(), k).ok() && k.issuer_id >= 0;
+        }
+        if (!ok) {
+            if (++heal_attempts_ < kMaxHealAttempts) return false;
+            give_up("an idemix issuer key");
+        } else {
+            heal_attempts_ = 0;
         }
         pending_issuers_.erase(pending_issuers_.begin());
     }
@@ -484,7 +536,18 @@ int64_t GPUCSP::ImportIdemixIssuer(const uint8_t* ipk_raw, size_t len, std::stri
             return -1;
         }
         if (g == 0) id = k.issuer_id;
-        else if (k.issuer_id != id) return -1;              // (ids that differ: not accelerated)
+        else if (k.issuer_id != id) {
+            // ids are handed out in order per context: once they differ they differ for every later issuer too.  Nothing to replay -
+            // every device HAS the key - but it is counted and said once, and the issuer is not accelerated (bccsp/idemix serves it).
+            reg_id_mismatches_.fetch_add(1, std::memory_order_relaxed);
+            if (!issuer_mismatch_logged_) {
+                issuer_mismatch_logged_ = true;
+                fprintf(stderr, "fabgpu: the devices of the pool gave an idemix issuer different ids (%lld on device 0, %lld on device %zu): not accelerated\n", (long long)id,
+                        (long long)k.issuer_id, g);
+            }
+            if (err) *err = "the devices of the pool disagree about the issuer's id";
+            return -1;
+        }
     }
     return id;
 }
@@ -1125,18 +1188,23 @@ void GPUCSP::RegisterQueued(const std::vector<std::string>& to_register) const {
             // (evicted meanwhile: EvictIdentitiesLocked gave its place in the table budget back)
         }
     }
-    // The tables - 6 ms of host arithmetic each - are built side by side (a channel's first block makes all its endorsers eligible at
-    // once: four tables took 30 ms of that block's pass), then installed one after the other: every device hands out the same ids.
+    // Round 6: the tables are built ON THE DEVICE, the whole batch in three launches per device (keytab_kernels.hip: 0.7-0.9 ms for a
+    // channel's six signers against 6 ms of host arithmetic per key - eight of the fifteen milliseconds of a fresh provider's first pass),
+    // the devices of the pool side by side, every device installing the keys in the same order: the same ids everywhere.  A device that
+    // cannot (memory, a failed launch) sends the batch down the old road: host-built tables, one key after the other.
+    std::vector<int64_t> batch_ids(todo.size(), -1);
+    const bool batch_ok = RegisterKeysOnAllDevices(todo, batch_ids);
     const size_t words = key_table_words();
     std::vector<std::vector<int32_t>> tabs(todo.size());
-    if (todo.size() > 1)
+    if (!batch_ok && todo.size() > 1)
         run_workers((int)todo.size(), [&](int i) {
             tabs[(size_t)i].resize(words);
             if (!key_table_build(todo[(size_t)i].second.qx, todo[(size_t)i].second.qy, tabs[(size_t)i].data())) tabs[(size_t)i].clear();
         });
     for (size_t ti = 0; ti < todo.size(); ti++) {
         auto& kv = todo[ti];
-        const int64_t id = RegisterKeyOnAllDevices(kv.second.qx, kv.second.qy, tabs[ti].empty() ? nullptr : tabs[ti].data());   // every device gets a copy
+        const int64_t id = batch_ok ? batch_ids[ti]
+                                    : RegisterKeyOnAllDevices(kv.second.qx, kv.second.qy, tabs[ti].empty() ? nullptr : tabs[ti].data());   // every device gets a copy
         const bool ok = id >= 0;
         std::lock_guard<std::mutex> lk(idmu_);
         auto it = idcache_.find(kv.first);

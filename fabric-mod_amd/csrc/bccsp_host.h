@@ -291,7 +291,9 @@ class GPUCSP {
     struct PendingKey { uint8_t qx[32], qy[32]; };
     mutable std::vector<PendingKey> pending_keys_;
     mutable std::vector<std::string> pending_issuers_;      // marshalled IssuerPublicKey bytes
-    mutable bool reg_failure_logged_ = false;
+    mutable bool reg_failure_logged_ = false, issuer_mismatch_logged_ = false;
+    mutable uint32_t heal_attempts_ = 0;                    // failed replays of the front pending entry (reg_mu_)
+    mutable std::atomic<uint64_t> reg_dropped_{0}, reg_id_mismatches_{0};   // GetOption("registrations_dropped" / "registration_id_mismatches")
     bool HealPendingRegistrationsLocked() const;            // true: nothing is pending any more
     void Preallocate() const;
     // identity cache of the pre-verify pass (msp/cache/cache.go): SerializedIdentity bytes -> P-256 key + device key id
@@ -326,6 +328,7 @@ class GPUCSP {
     mutable std::atomic<uint64_t> pass_relaunches_{0}, pass_decoded_{0}, pass_learned_{0}, pass_general_der_{0};
     void EvictIdentitiesLocked() const;
     void RegisterQueued(const std::vector<std::string>& to_register) const;
+    bool RegisterKeysOnAllDevices(const std::vector<std::pair<std::string, CachedIdentity>>& keys, std::vector<int64_t>& ids) const;
     void SeedMemo(const uint8_t* block, const ParsedBlock& pb, BlockVerdicts& out, const PassOptions& opt, std::vector<uint32_t>& sel_scratch, int gate_max,
                   BlockUpload* up = nullptr) const;
     // verdict memo

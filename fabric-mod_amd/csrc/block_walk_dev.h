@@ -325,9 +325,14 @@ double walk_warm_copies(fabgpu_ctx* ctx, void* const* pinned, const size_t* byte
 // a registered key's comb table built apart from its registration (fabgpu_api.hip)
 size_t key_table_words();
 bool key_table_build(const uint8_t* qx32, const uint8_t* qy32, int32_t* out);
+// n keys (qxy: n x 64 bytes X || Y, all on the curve) on one context, their comb tables built on the device (keytab_kernels.hip)
+int key_register_batch(fabgpu_ctx* ctx, int n, const uint8_t* qxy, uint32_t* key_ids);
+int key_table_copy(fabgpu_ctx* ctx, uint32_t key_id, int32_t* out);   // TEST HOOK support: a registered key's device table, to the host
 int key_register_many_prebuilt(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, const int32_t* table, uint32_t* key_ids);
 // the duration of the last timed launch of a FABGPU_FLAG_TIME_KERNELS context (ms; < 0: none) - read by the test-hook library
 float ctx_last_kernel_ms(fabgpu_ctx* ctx);
+// TEST HOOK: the idemix four-lane form orders its side launch BEHIND the commitment launch while this is on
+void ctx_test_nym_side_after(fabgpu_ctx* ctx, bool on);
 // pinned host memory for WalkOut::memo_* (hipHostMalloc / hipHostFree; nullptr when there is none to be had)
 void* walk_pinned_alloc(fabgpu_ctx* ctx, size_t bytes);
 void walk_pinned_free(fabgpu_ctx* ctx, void* p);

@@ -127,6 +127,7 @@ struct fabgpu_ctx {
     bool allow_pair = true;   // !FABGPU_FLAG_ONE_LANE_ONLY
     bool allow_quad = true;   // !FABGPU_FLAG_NO_QUAD (idemix: four lanes per signature for batches <= IDEMIX_QUAD_MAX)
     bool nym_side_stream = true; // !FABGPU_FLAG_NYM_NO_SIDE_STREAM (idemix four-lane form: the fixed-base terms on a second stream beside the commitments)
+    std::atomic<bool> test_nym_side_after{false};   // TEST HOOK (fab::ctx_test_nym_side_after; read once per nym launch, handed to the launcher as a parameter)
     bool nym_two_phase = true;   // !FABGPU_FLAG_NYM_FUSED_HASH (idemix four-lane form: commitments, then challenges with eight lanes on a message)
     bool allow_wide = true;   // !FABGPU_FLAG_NO_WIDE (registered keys: eight lanes per signature in two phases for launches <= WIDE_LAUNCH_MAX)
     int pair_table_lds = -1;       // the verify-only pair kernel's per-signature table: 1 in LDS, 0 in the global workspace, -1 by batch size (kernels.h)
@@ -468,6 +469,9 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
 }
 
 }  // extern "C"
+void fab::ctx_test_nym_side_after(fabgpu_ctx* ctx, bool on) {
+    if (ctx) ctx->test_nym_side_after.store(on);
+}
 // what the test-hook library's fabgpu_last_kernel_ms reads (FABGPU_FLAG_TIME_KERNELS contexts; block_walk_dev.h)
 float fab::ctx_last_kernel_ms(fabgpu_ctx* ctx) {
     if (!ctx || !ctx->timed) return -1.0f;
@@ -644,6 +648,7 @@ static int nym_verify_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t a
             }
         }
         side = sd;
+        side.test_side_after = ctx->test_nym_side_after;
     }
     timed = timed && ctx->time_kernels;
     if (timed) hipEventRecord(ctx->ev0, st);
@@ -666,6 +671,7 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
 
 // ---- registered public keys -------------------------------------------------------------------------
 // one key's comb table into one context: id of the key there (idempotent per (qx, qy)); `tab` = the table, built by the caller
+static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32_t* d, uint32_t* key_id);
 static int key_install(fabgpu_ctx* ctx, const std::string& k, const std::vector<int32_t>* tab_in, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
     std::lock_guard<std::mutex> lk(ctx->kmu);
     auto it = ctx->key_ids.find(k);
@@ -691,6 +697,14 @@ static int key_install(fabgpu_ctx* ctx, const std::string& k, const std::vector<
         hipFree(d);
         return FABGPU_ELAUNCH;
     }
+    return key_install_table_locked(ctx, k, d, key_id);
+}
+// (kmu held, the context's device current) a finished table in device memory becomes key number ktabs.size(); takes ownership of d
+static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32_t* d, uint32_t* key_id) {
+    if (ctx->ktabs.size() >= FABGPU_MAX_KEYS) {
+        hipFree(d);
+        return FABGPU_ENOMEM;
+    }
     // grow the device-side pointer array by doubling; the old array is only released at shutdown, so launches already in
     // flight on other streams keep reading a valid (shorter) array
     if (ctx->ktabs.size() + 1 > ctx->d_ktabs_cap) {
@@ -715,11 +729,84 @@ static int key_install(fabgpu_ctx* ctx, const std::string& k, const std::vector<
     return FABGPU_OK;
 }
 
+// n keys (qxy: n x 64 bytes, X || Y; every one an affine point of the curve - the caller's gate) registered on ONE context with their
+// comb tables built ON THE DEVICE (keytab_kernels.hip: three launches for the whole batch, 0.7-0.9 ms, against 6 ms of host arithmetic
+// per key).  key_ids[i] = the key's id (keys the context already has keep theirs); ids are handed out in the order of qxy.  Any failure:
+// nothing was installed by this call that is not complete, the error is returned and the caller may fall back to the host builder.
+static int key_register_batch_dev(fabgpu_ctx* ctx, int n, const uint8_t* qxy, uint32_t* key_ids) {
+    if (!ctx || n <= 0 || !qxy || !key_ids) return FABGPU_EINVAL;
+    if (ctx->fault) return ctx->fault == 2 ? FABGPU_ENOMEM : FABGPU_ELAUNCH;
+    std::vector<int> todo;                                     // indices into qxy that need a table (first occurrence of a key only)
+    std::vector<std::string> names((size_t)n);
+    {
+        std::lock_guard<std::mutex> lk(ctx->kmu);
+        for (int i = 0; i < n; i++) {
+            names[(size_t)i].assign((const char*)qxy + 64 * (size_t)i, 64);
+            bool dup = false;
+            for (int j : todo) dup = dup || names[(size_t)j] == names[(size_t)i];
+            if (!dup && ctx->key_ids.find(names[(size_t)i]) == ctx->key_ids.end()) todo.push_back(i);
+        }
+        if (ctx->ktabs.size() + todo.size() > FABGPU_MAX_KEYS) return FABGPU_ENOMEM;
+    }
+    const uint32_t m = (uint32_t)todo.size();
+    std::vector<int32_t*> tabs(m, nullptr);
+    void *d_in = nullptr, *d_scr = nullptr;
+    hipStream_t st = nullptr;
+    int rc = FABGPU_OK;
+    if (m) {
+        DeviceGuard g(ctx->device);
+        auto fail = [&](int code) {
+            for (auto* t : tabs)
+                if (t) hipFree(t);
+            if (d_in) hipFree(d_in);
+            if (d_scr) hipFree(d_scr);
+            if (st) hipStreamDestroy(st);
+            return code;
+        };
+        for (uint32_t t = 0; t < m; t++)
+            if (hipMalloc((void**)&tabs[t], sizeof(int32_t) * KeyTab8::TABLE_WORDS) != hipSuccess) return fail(FABGPU_ENOMEM);
+        // one small upload: the keys, then the table pointers
+        const size_t in_bytes = (size_t)64 * m + sizeof(void*) * m;
+        std::vector<uint8_t> in(in_bytes);
+        for (uint32_t t = 0; t < m; t++) memcpy(&in[64 * (size_t)t], qxy + 64 * (size_t)todo[t], 64);
+        memcpy(&in[(size_t)64 * m], tabs.data(), sizeof(void*) * m);
+        if (hipMalloc(&d_in, in_bytes) != hipSuccess || hipMalloc(&d_scr, keytab_scratch_bytes(m)) != hipSuccess) return fail(FABGPU_ENOMEM);
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(FABGPU_ELAUNCH);
+        hipError_t e = hipMemcpyAsync(d_in, in.data(), in_bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = launch_keytab_build(m, d_in, (void* const*)((uint8_t*)d_in + (size_t)64 * m), d_scr, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(hip_to_rc(e));
+        hipFree(d_in);
+        hipFree(d_scr);
+        hipStreamDestroy(st);
+        d_in = d_scr = nullptr;
+        st = nullptr;
+    }
+    std::lock_guard<std::mutex> lk(ctx->kmu);
+    DeviceGuard g(ctx->device);
+    for (uint32_t t = 0; t < m; t++) {
+        const std::string& k = names[(size_t)todo[t]];
+        uint32_t id = 0;
+        if (rc == FABGPU_OK && ctx->key_ids.find(k) == ctx->key_ids.end()) rc = key_install_table_locked(ctx, k, tabs[t], &id);   // (takes the table, also on failure)
+        else hipFree(tabs[t]);                                  // (somebody registered it meanwhile, or an earlier install failed)
+        tabs[t] = nullptr;
+    }
+    if (rc != FABGPU_OK) return rc;
+    for (int i = 0; i < n; i++) {
+        auto it = ctx->key_ids.find(names[(size_t)i]);
+        if (it == ctx->key_ids.end()) return FABGPU_ELAUNCH;
+        key_ids[i] = it->second;
+    }
+    return FABGPU_OK;
+}
+
 int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
     if (!ctx || !qx32 || !qy32 || !key_id) return FABGPU_EINVAL;
     if (!fabgpu_p256_pubkey_on_curve(qx32, qy32)) return FABGPU_EINVAL;   // KeyImport gate: such keys stay with bccsp/sw
     std::string k((const char*)qx32, 32);
     k.append((const char*)qy32, 32);
+    // the table is built on the device; should that fail (memory, a launch), by the host builder as before round 6
+    if (key_register_batch_dev(ctx, 1, (const uint8_t*)k.data(), key_id) == FABGPU_OK) return FABGPU_OK;
     return key_install(ctx, k, nullptr, qx32, qy32, key_id);
 }
 
@@ -744,6 +831,7 @@ static int key_register_many_impl(fabgpu_ctx* const* ctxs, int n, const uint8_t*
             if (have) key_ids[g] = it->second;
         }
         if (have) continue;
+        if (tab.empty() && key_register_batch_dev(ctxs[g], 1, (const uint8_t*)k.data(), &key_ids[g]) == FABGPU_OK) continue;   // built on that device
         if (tab.empty()) {
             u256 qx, qy;
             from_be32(qx, qx32);
@@ -1149,6 +1237,13 @@ void host_copy_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n) {
         const int idx = keep_acquire(ctx, block_bytes);
         if (idx < 0) break;
         got.push_back(idx);
+    }
+    // ... and sent through the DMA path once, whole: the first transfer out of a freshly registered range costs milliseconds (measured
+    // with tools/gpu_r06_first_memo_probe.py: 2.2 ms "wait for upload" on a provider's first memo-seeding pass against 0.2-0.3 after)
+    void* d = nullptr;
+    if (!got.empty() && hipMalloc(&d, block_bytes) == hipSuccess) {
+        for (int idx : got) (void)hipMemcpy(d, ctx->keep_pool[(size_t)idx]->pin.h, block_bytes, hipMemcpyHostToDevice);
+        hipFree(d);
     }
     std::lock_guard<std::mutex> lk(ctx->keep_mu);
     for (int idx : got) ctx->keep_pool[(size_t)idx]->in_use = false;
@@ -2504,6 +2599,7 @@ int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_
     (void)warm_kernel_functions_wide();
     (void)warm_kernel_functions_idemix();
     (void)warm_kernel_functions_walk();
+    (void)warm_kernel_functions_keytab();
     for (int i = 0; i < fabgpu_ctx::N_STAGED; i++) {
         fabgpu_ctx::Staged& sl = ctx->staged_slots[i];
         std::lock_guard<std::mutex> lk(sl.m);
@@ -2628,6 +2724,19 @@ bool key_table_build(const uint8_t* qx32, const uint8_t* qy32, int32_t* out) {
     from_be32(qy, qy32);
     build_key_comb_table8(out, qx, qy);
     return true;
+}
+int key_register_batch(fabgpu_ctx* ctx, int n, const uint8_t* qxy, uint32_t* key_ids) { return key_register_batch_dev(ctx, n, qxy, key_ids); }
+// TEST HOOK support: the device's table of key `key_id` copied to the host (KeyTab8::TABLE_WORDS words)
+int key_table_copy(fabgpu_ctx* ctx, uint32_t key_id, int32_t* out) {
+    if (!ctx || !out) return FABGPU_EINVAL;
+    int32_t* d = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->kmu);
+        if (key_id >= ctx->ktabs.size()) return FABGPU_EINVAL;
+        d = ctx->ktabs[key_id];
+    }
+    DeviceGuard g(ctx->device);
+    return hip_to_rc(hipMemcpy(out, d, sizeof(int32_t) * KeyTab8::TABLE_WORDS, hipMemcpyDeviceToHost));
 }
 int key_register_many_prebuilt(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, const int32_t* table, uint32_t* key_ids) {
     return key_register_many_impl(ctxs, n, qx32, qy32, table, key_ids);

@@ -15,6 +15,13 @@ extern "C" {
 /* Duration in milliseconds of the most recent kernel launched through ctx, measured with HIP events on the
  * launch stream.  Only for contexts created with FABGPU_FLAG_TIME_KERNELS; <0 otherwise / if nothing was launched. */
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);
+/* TEST HOOKS: the comb table of registered key `key_id` as it lies on the device (built there since round 6: keytab_kernels.hip), and the
+ * table the host builder (p256_tables29.h) makes for a key - 32 windows x 256 entries x 20 words; the two must be byte-identical. */
+int fabgpu_test_key_table(fabgpu_ctx* ctx, uint32_t key_id, int32_t* out_words, size_t cap_words);
+int fabgpu_test_key_table_host(const uint8_t* qx32, const uint8_t* qy32, int32_t* out_words, size_t cap_words);
+/* TEST HOOK: while on, the idemix four-lane form queues its side launch (the fixed-base terms) BEHIND the commitment launch, so that
+ * every commitment wavefront gives up on its records and computes the terms itself, and every side wavefront skips its rows. */
+void fabgpu_test_nym_side_after(fabgpu_ctx* ctx, int on);
 
 
 /* Synthetic block generator: n tuples, fresh P-256 keypair per signature, low-S, `invalid_permille`

@@ -340,8 +340,11 @@ __global__ void __launch_bounds__(BLOCK, 2)
         bool s_inf;
         bn_nym_quad_comb(S, s_inf, odd, half, ssk, srn, id->hsk, id->hrand);
         bn_nym_comb_store(comb_rec + ((size_t)tile * BLOCK + threadIdx.x) * NYM_COMB_UINT4_PER_LANE, S, s_inf);
-        // the wavefront's 64 records first, then its flag: 0 -> 1 with release semantics (the release waits for the wavefront's outstanding
-        // stores); a 2 that arrived meanwhile stays (the records are simply not read)
+        // the wavefront's 64 records first, then its flag: 0 -> 1 with release semantics; a 2 that arrived meanwhile stays (the records are
+        // simply not read).  EVERY lane fences its own record stores at agent scope before lane 0 publishes the flag: lane 0's release
+        // orders lane 0's stores only, as far as the memory model is concerned - that the hardware's s_waitcnt covers the whole
+        // wavefront is how it happened to work before, not what the code may rely on.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if ((threadIdx.x & 63u) == 0) {
             uint32_t expect = 0u;
             __hip_atomic_compare_exchange_strong(flag, &expect, 1u, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -450,10 +453,10 @@ hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_
         if (side != nullptr && side->stream != nullptr) {
             uint4* rec = (uint4*)(((uintptr_t)(st_tmp + idemix_rows(n)) + 255) & ~(uintptr_t)255);
             uint32_t* flags = (uint32_t*)(rec + idemix_rows(n) * 4 * NYM_COMB_UINT4_PER_LANE);
-            // TEST HOOK FABGPU_TEST_NYM_SIDE_AFTER (tests/test_idemix_gpu.py): the side launch is ordered BEHIND the commitment launch, so
+            // TEST HOOK NymSide::test_side_after (tests/test_idemix_gpu.py): the side launch is ordered BEHIND the commitment launch, so
             // that every wavefront of the commitment kernel finds no records, gives up (flag 0 -> 2) and computes its terms itself, and
             // every wavefront of the side launch finds the 2 and skips - both halves of the fallback, deterministically.
-            const bool side_after = getenv("FABGPU_TEST_NYM_SIDE_AFTER") != nullptr;
+            const bool side_after = side->test_side_after;       // (set through the test-hook library only: fabgpu_test_nym_side_after)
             // flags to zero in stream order, the side stream behind them; any failure on the way: the commitment kernel simply does it all
             if (hipMemsetAsync(flags, 0, idemix_rows(n) / 16 * 4, st) == hipSuccess) {
                 comb_rec = rec;

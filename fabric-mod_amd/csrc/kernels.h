@@ -101,6 +101,7 @@ constexpr int IDEMIX_QUAD_MAX = 16384;     // 256 workgroups x 64 signatures: on
 struct NymSide {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    bool test_side_after = false;   // TEST HOOK: order the side launch behind the commitment launch (both halves of the fallback, deterministically)
 };
 hipError_t launch_idemix_nym_verify(uint32_t n, const void* arena, size_t arena_bytes, const void* off, const void* issuer_id, const void* issuers,
                                     uint32_t n_issuers, const void* nym_x, const void* nym_y, const void* proof_c, const void* s_sk,
@@ -117,4 +118,8 @@ int warm_kernel_functions_kernels();
 int warm_kernel_functions_wide();
 int warm_kernel_functions_idemix();
 int warm_kernel_functions_walk();
+int warm_kernel_functions_keytab();
+// keytab_kernels.hip: comb tables of registered P-256 keys built on the device (qxy, tabs: device memory; see the unit's header)
+size_t keytab_scratch_bytes(uint32_t n_keys);
+hipError_t launch_keytab_build(uint32_t n_keys, const void* qxy, void* const* tabs, void* scratch, hipStream_t st);
 }  // namespace fab

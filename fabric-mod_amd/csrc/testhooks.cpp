@@ -29,6 +29,17 @@ extern "C" {
 
 // Duration in milliseconds of the most recent kernel launched through ctx (FABGPU_FLAG_TIME_KERNELS contexts only)
 float fabgpu_last_kernel_ms(fabgpu_ctx* ctx) { return fab::ctx_last_kernel_ms(ctx); }
+// a registered key's comb table as it lies on the device, and the host builder's for the same key (both KeyTab8::TABLE_WORDS = 163 840 words)
+int fabgpu_test_key_table(fabgpu_ctx* ctx, uint32_t key_id, int32_t* out_words, size_t cap_words) {
+    if (cap_words < fab::key_table_words()) return FABGPU_ETOOBIG;
+    return fab::key_table_copy(ctx, key_id, out_words);
+}
+int fabgpu_test_key_table_host(const uint8_t* qx32, const uint8_t* qy32, int32_t* out_words, size_t cap_words) {
+    if (cap_words < fab::key_table_words()) return FABGPU_ETOOBIG;
+    return fab::key_table_build(qx32, qy32, out_words) ? FABGPU_OK : FABGPU_EINVAL;
+}
+// the idemix four-lane form: order the side launch behind the commitment launch (idemix_kernels.hip: both halves of the fallback)
+void fabgpu_test_nym_side_after(fabgpu_ctx* ctx, int on) { fab::ctx_test_nym_side_after(ctx, on != 0); }
 
 // TEST HOOK: the device walker against the host walker on one block.  0: identical (or *declined = 1: the device declined, nothing
 // compared); 1: they differ, `diff` says where.

@@ -122,7 +122,8 @@ ABI_SYMBOLS = [
 # kernel timer - test and bench infrastructure that is NOT part of the product's C ABI and not in libfabgpu.so
 HOOK_SYMBOLS = [
     "fabgpu_synth_batch", "fabgpu_last_kernel_ms", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast",
-    "fabgpu_gate_sig_any", "fabgpu_csp_idfix_probe", "fabgpu_csp_gate_probe", "fabgpu_identity_table_hash",
+    "fabgpu_gate_sig_any", "fabgpu_csp_idfix_probe", "fabgpu_csp_gate_probe", "fabgpu_identity_table_hash", "fabgpu_test_nym_side_after",
+    "fabgpu_test_key_table", "fabgpu_test_key_table_host",
 ]
 _HOOKS_PATH = os.path.join(os.path.dirname(_LIB_PATH), "libfabgpu_testhooks.so")
 
@@ -145,6 +146,10 @@ def load_hooks():
     H = ctypes.CDLL(_HOOKS_PATH)
     H.fabgpu_last_kernel_ms.argtypes = [_vp]
     H.fabgpu_last_kernel_ms.restype = ctypes.c_float
+    H.fabgpu_test_nym_side_after.argtypes = [_vp, ctypes.c_int]
+    H.fabgpu_test_nym_side_after.restype = None
+    H.fabgpu_test_key_table.argtypes = [_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int32), _sz]
+    H.fabgpu_test_key_table_host.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _sz]
     H.fabgpu_csp_block_walk_compare.argtypes = [_vp, _u8p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
     H.fabgpu_block_walk_twopass_compare.argtypes = [_u8p, _sz, ctypes.c_char_p, _sz]
     H.fabgpu_gate_sig_fast.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
@@ -535,6 +540,25 @@ class Context:
     def p256_verify_batch_keyed_dev(self, n, key_id, e, r, s, verdict_bits, status, stream=0):
         _check(self._L.fabgpu_p256_verify_batch_keyed_dev(self._h, n, key_id, e, r, s, verdict_bits, status or None, stream or None),
                "fabgpu_p256_verify_batch_keyed_dev")
+
+    KEY_TABLE_WORDS = 32 * 256 * 20
+
+    def test_key_table(self, key_id: int) -> np.ndarray:
+        """TEST HOOK: the comb table of a registered key as it lies on the device (int32[32 * 256 * 20])."""
+        out = np.zeros(self.KEY_TABLE_WORDS, dtype=np.int32)
+        _check(load_hooks().fabgpu_test_key_table(self._h, key_id, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), out.size), "fabgpu_test_key_table")
+        return out
+
+    @staticmethod
+    def test_key_table_host(qx32: bytes, qy32: bytes) -> np.ndarray:
+        """TEST HOOK: the same table as the host builder makes it."""
+        out = np.zeros(Context.KEY_TABLE_WORDS, dtype=np.int32)
+        _check(load_hooks().fabgpu_test_key_table_host(qx32, qy32, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), out.size), "fabgpu_test_key_table_host")
+        return out
+
+    def test_nym_side_after(self, on: bool) -> None:
+        """TEST HOOK (libfabgpu_testhooks.so): the idemix side launch behind the commitment launch while on."""
+        load_hooks().fabgpu_test_nym_side_after(self._h, 1 if on else 0)
 
     def last_kernel_ms(self) -> float:
         return float(load_hooks().fabgpu_last_kernel_ms(self._h))

@@ -57,7 +57,9 @@ int fabgpu_csp_passes_per_device(fabgpu_csp* csp, uint64_t* passes, int cap);
 int fabgpu_csp_route_block(fabgpu_csp* csp, uint64_t block_seq);   /* where a pass named block_seq would go right now */
 /* the switches above on a living provider (tests, A/B runs): "pass_device_walk", "pass_stage_min_bytes", "pass_device_memo",
  * "pass_host_counts", "pass_skip_hash_checks", "pass_timing", "pass_hash_memo" - same convention: 0 the default, > 0 on / the threshold, < 0 off; get also
- * answers "n_devices".  FABGPU_EINVAL: no such option. */
+ * answers "n_devices" and two counters: "registrations_dropped" (key / issuer tables that could not be brought onto every device of the
+ * pool after three attempts - those identities verify on the fresh-key kernels / bccsp/idemix) and "registration_id_mismatches".
+ * FABGPU_EINVAL: no such option. */
 int fabgpu_csp_set_option(fabgpu_csp* csp, const char* name, int64_t value, int64_t* previous);
 int fabgpu_csp_get_option(fabgpu_csp* csp, const char* name, int64_t* value);
 

@@ -279,6 +279,39 @@ def test_registered_keys_pool_vs_oracle_and_vs_the_unkeyed_kernel(ctx, n, nkeys)
     assert (st2 == st).all() and (bits2 == bits).all()
 
 
+def test_key_tables_built_on_the_device_equal_the_host_builders_byte_for_byte(ctx):
+    """Round 6: a registered key's comb table (T[w][d] = d 2^(8w) Q, 32 x 255 affine points in the fe29 Montgomery form of their canonical
+    residues) is built by three kernels (csrc/keytab_kernels.hip) instead of 6 ms of host arithmetic.  Ground truth: the host builder
+    (p256_tables29.h, unchanged - itself held against big-integer point arithmetic by tests/test_host_logic.py): all 163 840 words
+    equal, for random keys, for the generator and 2G (a table the generator comb's tests know), and for keys registered in one batch
+    by the provider.  Entry 0 of every window and the two pad words of every entry are zero; an independent spot check recomputes a
+    few entries with the Python oracle."""
+    b = coracle.make_pool_batch(8, seed=606, nkeys=5)
+    keys = [(b["pool_qx"][j].tobytes(), b["pool_qy"][j].tobytes()) for j in range(5)]
+    G = (po.GX.to_bytes(32, "big"), po.GY.to_bytes(32, "big"))
+    g2 = po.pt_mul(2, (po.GX, po.GY))
+    keys += [G, (g2[0].to_bytes(32, "big"), g2[1].to_bytes(32, "big"))]
+    for qx, qy in keys:
+        kid = ctx.key_register(qx, qy)
+        dev = ctx.test_key_table(kid)
+        host = fabgpu.Context.test_key_table_host(qx, qy)
+        assert dev.shape == host.shape == (32 * 256 * 20,)
+        assert np.array_equal(dev, host), "first differing word %d" % int(np.nonzero(dev != host)[0][0])
+        t = dev.reshape(32, 256, 20)
+        assert not t[:, 0, :].any() and not t[:, :, 18:].any()
+    # the meaning of an entry, independently: limbs -> integer -> divide by R = 2^261 -> the affine coordinates of d 2^(8w) Q
+    qx, qy = keys[0]
+    t = ctx.test_key_table(ctx.key_register(qx, qy)).reshape(32, 256, 20)
+    rinv = pow(1 << 261, -1, po.P)
+
+    def plain(limbs):
+        return sum(int(v) << (29 * i) for i, v in enumerate(limbs)) * rinv % po.P
+    Q = (int.from_bytes(qx, "big"), int.from_bytes(qy, "big"))
+    for w, d in ((0, 1), (0, 255), (7, 128), (31, 3), (31, 255), (16, 77)):
+        want = po.pt_mul(d << (8 * w), Q)
+        assert (plain(t[w, d, :9]), plain(t[w, d, 9:18])) == want, (w, d)
+
+
 def test_registered_keys_every_signer_its_own_key_edge_vectors_and_bad_ids(ctx):
     # the edge vectors (x(R) >= n, u1 = 0, final addition = doubling / infinity, window corners ...) through the keyed path
     vs = [v for v in _load("edge_kats.json") if len(v["e"]) == 64 and po.on_curve(int(v["qx"], 16), int(v["qy"], 16))

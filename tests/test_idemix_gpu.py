@@ -95,7 +95,7 @@ def test_side_launch_that_comes_too_late_changes_nothing(env, request):
     find its records gives up (flag 0 -> 2) and computes the terms itself, and a side wavefront that finds the 2 skips its rows.  The
     test hook orders the side launch BEHIND the commitment launch, so every wavefront takes exactly that path - statuses must not move."""
     ctx, issuers = env
-    os.environ["FABGPU_TEST_NYM_SIDE_AFTER"] = "1"
+    ctx.test_nym_side_after(True)
     try:
         for n, seed in ((1, 11), (65, 12), (700, 13), (6000, 14)):
             if n <= 700:
@@ -112,7 +112,7 @@ def test_side_launch_that_comes_too_late_changes_nothing(env, request):
                 expect = exp0[pick]
             assert np.array_equal(st, expect) and np.array_equal(ok, expect == 0), n
     finally:
-        del os.environ["FABGPU_TEST_NYM_SIDE_AFTER"]
+        ctx.test_nym_side_after(False)
 
 
 def test_block_sized_batch_by_replication(env):
