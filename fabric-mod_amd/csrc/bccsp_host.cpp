@@ -1970,7 +1970,13 @@ int GPUCSP::PreVerifyBlockOnDevice(const uint8_t* block, size_t len, ParsedBlock
             id_version_.fetch_add(1, std::memory_order_release);
         }
     }
-    RegisterQueued(to_register);
+    {
+        const auto tq = std::chrono::steady_clock::now();
+        RegisterQueued(to_register);
+        if (po.pass_timing > 0 && !to_register.empty())
+            fprintf(stderr, "fabgpu pass: %zu identities earned their comb tables: %.2f ms\n", to_register.size(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq).count());
+    }
     constexpr int gate_max = 16;
     if (host_memo) SeedMemo(block, pb, out, opt, ps.sub, gate_max, &up);
     if (dev_memo && dev_bm && rq.memo_live && dev_bm->slots_v) {

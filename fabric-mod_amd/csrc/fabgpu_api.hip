@@ -168,6 +168,19 @@ struct fabgpu_ctx {
     const int32_t** d_ktabs = nullptr;
     size_t d_ktabs_cap = 0;
     std::vector<void*> retired;   // outgrown d_ktabs arrays, freed at shutdown
+    // Where the tables live: slabs of KTAB_SLAB tables (a table is never freed before shutdown, and hipMalloc / hipFree per table were
+    // most of what a registration cost once the tables were built on the device: 4.7 ms of runtime calls around 0.8 ms of kernels for a
+    // channel's six signers).  ktab_free: tables whose installation failed.  All under kmu.
+    static constexpr size_t KTAB_SLAB = 32;
+    std::vector<void*> ktab_slabs;
+    size_t ktab_slab_used = KTAB_SLAB;
+    std::vector<int32_t*> ktab_free;
+    // the device builder's room (keytab_kernels.hip): keys + table pointers in, the chain's and the affine bases' scratch; its own stream
+    std::mutex ktab_build_mu;
+    void* d_ktab_in = nullptr;
+    void* d_ktab_scr = nullptr;
+    size_t ktab_in_cap = 0, ktab_scr_cap = 0;
+    hipStream_t stream_keytab = nullptr;
     // Registered idemix issuers: a fixed-capacity device array of slots (idemix_kernels.hip IssuerDev); a slot is written
     // before n_issuers is raised, so launches in flight never read a half-written one.
     std::mutex imu;
@@ -423,8 +436,11 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->offs.release();
         ctx->out.release();
         if (ctx->d_gtab) hipFree(ctx->d_gtab);
-        for (auto* t : ctx->ktabs) hipFree(t);
+        for (auto* t : ctx->ktab_slabs) hipFree(t);              // (every key table lies in a slab)
         for (auto* t : ctx->retired) hipFree(t);
+        if (ctx->d_ktab_in) hipFree(ctx->d_ktab_in);
+        if (ctx->d_ktab_scr) hipFree(ctx->d_ktab_scr);
+        if (ctx->stream_keytab) hipStreamDestroy(ctx->stream_keytab);
         for (auto* t : ctx->itabs) hipFree(t);
         if (ctx->d_issuers) hipFree(ctx->d_issuers);
         ctx->nym.release();
@@ -634,7 +650,7 @@ static int nym_verify_dev(fabgpu_ctx* ctx, size_t n, const void* arena, size_t a
     if (rc != FABGPU_OK) return rc;
     // the side stream of this workspace slot (the slot is ours until release_qws: nobody else touches its entry)
     NymSide side;
-    if (ctx->nym_two_phase && ctx->nym_side_stream) {
+    if (ctx->nym_two_phase && ctx->nym_side_stream && n <= (size_t)NYM_SIDE_STREAM_MAX) {
         std::lock_guard<std::mutex> lk(ctx->qmu);
         NymSide& sd = ctx->qws[wi].nym_side;
         if (!sd.stream) {
@@ -672,6 +688,23 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
 // ---- registered public keys -------------------------------------------------------------------------
 // one key's comb table into one context: id of the key there (idempotent per (qx, qy)); `tab` = the table, built by the caller
 static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32_t* d, uint32_t* key_id);
+// (kmu held, the context's device current) room for one table: out of the current slab, a new slab when that is used up
+static int32_t* ktab_alloc_locked(fabgpu_ctx* ctx) {
+    if (!ctx->ktab_free.empty()) {
+        int32_t* d = ctx->ktab_free.back();
+        ctx->ktab_free.pop_back();
+        return d;
+    }
+    constexpr size_t table_bytes = sizeof(int32_t) * KeyTab8::TABLE_WORDS;
+    if (ctx->ktab_slab_used >= fabgpu_ctx::KTAB_SLAB) {
+        if (ctx->fault == 2) return nullptr;
+        void* slab = nullptr;
+        if (hipMalloc(&slab, table_bytes * fabgpu_ctx::KTAB_SLAB) != hipSuccess) return nullptr;
+        ctx->ktab_slabs.push_back(slab);
+        ctx->ktab_slab_used = 0;
+    }
+    return (int32_t*)((uint8_t*)ctx->ktab_slabs.back() + table_bytes * ctx->ktab_slab_used++);
+}
 static int key_install(fabgpu_ctx* ctx, const std::string& k, const std::vector<int32_t>* tab_in, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
     std::lock_guard<std::mutex> lk(ctx->kmu);
     auto it = ctx->key_ids.find(k);
@@ -691,10 +724,10 @@ static int key_install(fabgpu_ctx* ctx, const std::string& k, const std::vector<
         tab_in = &own;
     }
     const std::vector<int32_t>& tab = *tab_in;
-    int32_t* d = nullptr;
-    if (hipMalloc((void**)&d, sizeof(int32_t) * KeyTab8::TABLE_WORDS) != hipSuccess) return FABGPU_ENOMEM;
+    int32_t* d = ktab_alloc_locked(ctx);
+    if (!d) return FABGPU_ENOMEM;
     if (hipMemcpy(d, tab.data(), sizeof(int32_t) * KeyTab8::TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) {
-        hipFree(d);
+        ctx->ktab_free.push_back(d);
         return FABGPU_ELAUNCH;
     }
     return key_install_table_locked(ctx, k, d, key_id);
@@ -702,7 +735,7 @@ static int key_install(fabgpu_ctx* ctx, const std::string& k, const std::vector<
 // (kmu held, the context's device current) a finished table in device memory becomes key number ktabs.size(); takes ownership of d
 static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32_t* d, uint32_t* key_id) {
     if (ctx->ktabs.size() >= FABGPU_MAX_KEYS) {
-        hipFree(d);
+        ctx->ktab_free.push_back(d);
         return FABGPU_ENOMEM;
     }
     // grow the device-side pointer array by doubling; the old array is only released at shutdown, so launches already in
@@ -711,7 +744,7 @@ static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32
         size_t cap = ctx->d_ktabs_cap ? ctx->d_ktabs_cap * 2 : 64;
         const int32_t** nd = nullptr;
         if (hipMalloc((void**)&nd, cap * sizeof(int32_t*)) != hipSuccess) {
-            hipFree(d);
+            ctx->ktab_free.push_back(d);
             return FABGPU_ENOMEM;
         }
         if (!ctx->ktabs.empty()) hipMemcpy((void*)nd, ctx->ktabs.data(), ctx->ktabs.size() * sizeof(int32_t*), hipMemcpyHostToDevice);
@@ -720,7 +753,7 @@ static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32
         ctx->d_ktabs_cap = cap;
     }
     if (hipMemcpy((void*)(ctx->d_ktabs + ctx->ktabs.size()), &d, sizeof(int32_t*), hipMemcpyHostToDevice) != hipSuccess) {
-        hipFree(d);
+        ctx->ktab_free.push_back(d);
         return FABGPU_ELAUNCH;
     }
     ctx->ktabs.push_back(d);
@@ -736,8 +769,14 @@ static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32
 static int key_register_batch_dev(fabgpu_ctx* ctx, int n, const uint8_t* qxy, uint32_t* key_ids) {
     if (!ctx || n <= 0 || !qxy || !key_ids) return FABGPU_EINVAL;
     if (ctx->fault) return ctx->fault == 2 ? FABGPU_ENOMEM : FABGPU_ELAUNCH;
+    static const bool timing = getenv("FABGPU_PASS_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    std::lock_guard<std::mutex> blk(ctx->ktab_build_mu);        // one batch at a time per context: the builder's room and stream are one
+    DeviceGuard g(ctx->device);
     std::vector<int> todo;                                     // indices into qxy that need a table (first occurrence of a key only)
     std::vector<std::string> names((size_t)n);
+    std::vector<int32_t*> tabs;
     {
         std::lock_guard<std::mutex> lk(ctx->kmu);
         for (int i = 0; i < n; i++) {
@@ -747,57 +786,74 @@ static int key_register_batch_dev(fabgpu_ctx* ctx, int n, const uint8_t* qxy, ui
             if (!dup && ctx->key_ids.find(names[(size_t)i]) == ctx->key_ids.end()) todo.push_back(i);
         }
         if (ctx->ktabs.size() + todo.size() > FABGPU_MAX_KEYS) return FABGPU_ENOMEM;
+        for (size_t t = 0; t < todo.size(); t++) {
+            int32_t* d = ktab_alloc_locked(ctx);
+            if (!d) {
+                for (auto* x : tabs) ctx->ktab_free.push_back(x);
+                return FABGPU_ENOMEM;
+            }
+            tabs.push_back(d);
+        }
     }
     const uint32_t m = (uint32_t)todo.size();
-    std::vector<int32_t*> tabs(m, nullptr);
-    void *d_in = nullptr, *d_scr = nullptr;
-    hipStream_t st = nullptr;
-    int rc = FABGPU_OK;
+    auto give_back = [&](int code) {
+        std::lock_guard<std::mutex> lk(ctx->kmu);
+        for (auto* x : tabs)
+            if (x) ctx->ktab_free.push_back(x);
+        return code;
+    };
+    double t_room = 0, t_build = 0;
     if (m) {
-        DeviceGuard g(ctx->device);
-        auto fail = [&](int code) {
-            for (auto* t : tabs)
-                if (t) hipFree(t);
-            if (d_in) hipFree(d_in);
-            if (d_scr) hipFree(d_scr);
-            if (st) hipStreamDestroy(st);
-            return code;
-        };
-        for (uint32_t t = 0; t < m; t++)
-            if (hipMalloc((void**)&tabs[t], sizeof(int32_t) * KeyTab8::TABLE_WORDS) != hipSuccess) return fail(FABGPU_ENOMEM);
-        // one small upload: the keys, then the table pointers
-        const size_t in_bytes = (size_t)64 * m + sizeof(void*) * m;
+        // one small upload: the keys, then the table pointers; the builder's room grows with the largest batch so far
+        const size_t in_bytes = (size_t)64 * m + sizeof(void*) * m, scr_bytes = keytab_scratch_bytes(m);
+        if (ctx->ktab_in_cap < in_bytes) {
+            if (ctx->d_ktab_in) hipFree(ctx->d_ktab_in);
+            ctx->d_ktab_in = nullptr;
+            ctx->ktab_in_cap = 0;
+            if (hipMalloc(&ctx->d_ktab_in, in_bytes * 2) != hipSuccess) return give_back(FABGPU_ENOMEM);
+            ctx->ktab_in_cap = in_bytes * 2;
+        }
+        if (ctx->ktab_scr_cap < scr_bytes) {
+            if (ctx->d_ktab_scr) hipFree(ctx->d_ktab_scr);
+            ctx->d_ktab_scr = nullptr;
+            ctx->ktab_scr_cap = 0;
+            if (hipMalloc(&ctx->d_ktab_scr, scr_bytes * 2) != hipSuccess) return give_back(FABGPU_ENOMEM);
+            ctx->ktab_scr_cap = scr_bytes * 2;
+        }
+        if (!ctx->stream_keytab && hipStreamCreateWithFlags(&ctx->stream_keytab, hipStreamNonBlocking) != hipSuccess) return give_back(FABGPU_ELAUNCH);
         std::vector<uint8_t> in(in_bytes);
         for (uint32_t t = 0; t < m; t++) memcpy(&in[64 * (size_t)t], qxy + 64 * (size_t)todo[t], 64);
         memcpy(&in[(size_t)64 * m], tabs.data(), sizeof(void*) * m);
-        if (hipMalloc(&d_in, in_bytes) != hipSuccess || hipMalloc(&d_scr, keytab_scratch_bytes(m)) != hipSuccess) return fail(FABGPU_ENOMEM);
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(FABGPU_ELAUNCH);
-        hipError_t e = hipMemcpyAsync(d_in, in.data(), in_bytes, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = launch_keytab_build(m, d_in, (void* const*)((uint8_t*)d_in + (size_t)64 * m), d_scr, st);
+        t_room = since();
+        hipStream_t st = ctx->stream_keytab;
+        hipError_t e = hipMemcpyAsync(ctx->d_ktab_in, in.data(), in_bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = launch_keytab_build(m, ctx->d_ktab_in, (void* const*)((uint8_t*)ctx->d_ktab_in + (size_t)64 * m), ctx->d_ktab_scr, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return fail(hip_to_rc(e));
-        hipFree(d_in);
-        hipFree(d_scr);
-        hipStreamDestroy(st);
-        d_in = d_scr = nullptr;
-        st = nullptr;
+        if (e != hipSuccess) return give_back(hip_to_rc(e));
+        t_build = since();
     }
-    std::lock_guard<std::mutex> lk(ctx->kmu);
-    DeviceGuard g(ctx->device);
-    for (uint32_t t = 0; t < m; t++) {
-        const std::string& k = names[(size_t)todo[t]];
-        uint32_t id = 0;
-        if (rc == FABGPU_OK && ctx->key_ids.find(k) == ctx->key_ids.end()) rc = key_install_table_locked(ctx, k, tabs[t], &id);   // (takes the table, also on failure)
-        else hipFree(tabs[t]);                                  // (somebody registered it meanwhile, or an earlier install failed)
-        tabs[t] = nullptr;
+    int rc = FABGPU_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->kmu);
+        for (uint32_t t = 0; t < m; t++) {
+            const std::string& k = names[(size_t)todo[t]];
+            uint32_t id = 0;
+            if (rc == FABGPU_OK && ctx->key_ids.find(k) == ctx->key_ids.end()) rc = key_install_table_locked(ctx, k, tabs[t], &id);   // (takes the table, also on failure)
+            else ctx->ktab_free.push_back(tabs[t]);             // (somebody registered it meanwhile, or an earlier install failed)
+            tabs[t] = nullptr;
+        }
+        if (rc == FABGPU_OK)
+            for (int i = 0; i < n; i++) {
+                auto it = ctx->key_ids.find(names[(size_t)i]);
+                if (it == ctx->key_ids.end()) {
+                    rc = FABGPU_ELAUNCH;
+                    break;
+                }
+                key_ids[i] = it->second;
+            }
     }
-    if (rc != FABGPU_OK) return rc;
-    for (int i = 0; i < n; i++) {
-        auto it = ctx->key_ids.find(names[(size_t)i]);
-        if (it == ctx->key_ids.end()) return FABGPU_ELAUNCH;
-        key_ids[i] = it->second;
-    }
-    return FABGPU_OK;
+    if (timing && m) fprintf(stderr, "fabgpu: %u key tables on the device: room %.2f ms, build %.2f ms, installed after %.2f ms\n", m, t_room, t_build - t_room, since());
+    return rc;
 }
 
 int fabgpu_p256_key_register(fabgpu_ctx* ctx, const uint8_t* qx32, const uint8_t* qy32, uint32_t* key_id) {
@@ -2633,6 +2689,21 @@ int walk_preallocate(fabgpu_ctx* ctx, size_t block_bytes, uint32_t n_tx, uint32_
         e.len = 4;
         const uint8_t four[4] = {0, 0, 0, 0};
         if (walk_idtab_set(ctx, 1, &e, four, sizeof(four), 0) == FABGPU_OK) (void)walk_idtab_set(ctx, 0, nullptr, nullptr, 0, 0);
+    }
+    {
+        // what the first registrations of a channel's signers need (keytab_kernels.hip): a slab of key tables, the builder's room for
+        // sixteen keys, its stream - a provider's FIRST block makes its signers eligible, and hipMalloc inside that pass cost more than the build
+        std::lock_guard<std::mutex> bl(ctx->ktab_build_mu);
+        std::lock_guard<std::mutex> kl(ctx->kmu);
+        if (ctx->ktab_slabs.empty()) {
+            int32_t* first = ktab_alloc_locked(ctx);
+            if (first) ctx->ktab_free.push_back(first);
+            else rc = FABGPU_ENOMEM;
+        }
+        const size_t in_bytes = (size_t)(64 + sizeof(void*)) * 16 * 2, scr_bytes = keytab_scratch_bytes(16) * 2;
+        if (ctx->ktab_in_cap < in_bytes && hipMalloc(&ctx->d_ktab_in, in_bytes) == hipSuccess) ctx->ktab_in_cap = in_bytes;
+        if (ctx->ktab_scr_cap < scr_bytes && hipMalloc(&ctx->d_ktab_scr, scr_bytes) == hipSuccess) ctx->ktab_scr_cap = scr_bytes;
+        if (!ctx->stream_keytab) (void)hipStreamCreateWithFlags(&ctx->stream_keytab, hipStreamNonBlocking);
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t ne = n_tx, nt = n_tuples;

@@ -98,6 +98,11 @@ void idemix_issuer_dev_fill(void* host_slot, const void* d_hsk, const void* d_hr
 constexpr int IDEMIX_QUAD_MAX = 16384;     // 256 workgroups x 64 signatures: one round of the chip
 // a second stream for the fixed-base terms of the four-lane form (idemix_nym_comb_quad_kernel runs beside the commitment kernel) and the
 // two events that fork it off the caller's stream and join it again; owned by the caller (fabgpu_ctx keeps one per workspace slot)
+// The fixed-base terms of the idemix four-lane form run on a side stream BESIDE the commitment launch only while that launch leaves
+// SIMDs free: at 12 288 signatures it occupies 768 of the chip's 1 024; beyond, the side launch cannot be co-resident, the commitment
+// wavefronts spin for records that are not coming and then compute the terms themselves.  Measured (round 6,
+// tools/bench_cfg5_mixed.py, idemix alone): 10 000 signatures 0.745 ms with the side stream / 0.810 without; 16 000: 1.010 / 0.815.
+constexpr uint32_t NYM_SIDE_STREAM_MAX = 12288;
 struct NymSide {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
