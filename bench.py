@@ -206,7 +206,7 @@ def compact_line(out, detail_path="bench_detail.json"):
                       "endorsements_per_tx": cfg.get("endorsements_per_tx"), "seed": cfg.get("seed"), "parallelism": cfg.get("parallelism"),
                       "clock_warmup_launches": cfg.get("clock_warmup_launches")}
     line["roofline"] = {"bound": rf.get("bound"), "achieved": rf.get("achieved"), "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": rf.get("frac"),
-                        "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"), "algorithmic_bytes": rf.get("algorithmic_bytes"),
+                        "traffic": rf.get("traffic"), "traffic_source": str(rf.get("traffic_source") or "")[:110], "algorithmic_bytes": rf.get("algorithmic_bytes"),
                         "kernel": str(rf.get("kernel", "")).split(" (")[0], "kernel_ms": rf.get("kernel_ms"),
                         "hbm_achieved_GBps": _dig(rf, "hbm", "achieved"), "hbm_frac": _dig(rf, "hbm", "frac")}
     if cb:
@@ -324,6 +324,47 @@ def inprocess_multi_leg(world, tool="bench_multi.py", extra=()):
         return {"error": "timeout after 240 s"}
     except Exception as e:                                          # never let this leg cost the line
         return {"error": repr(e)}
+
+
+def measured_traffic_leg(kernel_prefix="p256_verify_pair_lds_kernel", timeout_s=150):
+    """HBM-side bytes per launch of the dominant kernel, MEASURED IN THIS RUN (rounds 2-5 read the figure from a
+    committed file): two rocprofv3 passes of their own - --pmc FETCH_SIZE, --pmc WRITE_SIZE, with --kernel-trace only, as
+    MI355X_MICROARCH.md's HBM section prescribes - over tools/gpu_pmc_kernels.py (the same 30 000-tuple launch, six times), read out of the
+    rocpd database; traffic = 2 x FETCH_SIZE (gfx950 counts half the bytes of 16 B/lane reads) + WRITE_SIZE, counters in KiB.  Runs in
+    subprocesses beside this one; skipped (the caller falls back to the committed file) when this process is itself being profiled."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCP_", "ROCPROF", "ROCTRACER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("this process runs under a profiler: nested rocprofv3 passes skipped")
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fabgpu_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "gpu_pmc_kernels.py"), "verify"],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True), key=os.path.getsize)
+            if not dbs:
+                raise RuntimeError("rocprofv3 --pmc %s left no database (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:]))
+            c = sqlite3.connect(dbs[-1])
+            vals = [v for (v,) in c.execute("select value from counters_collection where counter_name = ? and kernel_name like ?", (counter, kernel_prefix + "%"))]
+            c.close()
+            if not vals:
+                raise RuntimeError("no %s rows for %s" % (counter, kernel_prefix))
+            kb[counter] = (sum(vals) / len(vals), len(vals))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = (2 * kb["FETCH_SIZE"][0] + kb["WRITE_SIZE"][0]) * 1024.0
+    return {"traffic_bytes_per_launch": traffic, "fetch_size_kb": kb["FETCH_SIZE"][0], "write_size_kb": kb["WRITE_SIZE"][0], "launches": kb["FETCH_SIZE"][1],
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/gpu_pmc_kernels.py verify, "
+                      "mean of %d launches of %s; 2 x FETCH_SIZE + WRITE_SIZE" % (kb["FETCH_SIZE"][1], kernel_prefix)}
 
 
 def mac_ceiling_leg():
@@ -986,6 +1027,7 @@ def main():
                     "(the batch is synthesised on the CPU while the GPU idles; after 0.2 s of idle the first ~25 launches run at 0.735 ms, then 0.635: "
                     "tools/gpu_r05_gap_probe.py).  0 = round 4's protocol")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with two nested rocprofv3 --pmc passes (the committed figure of profiles/ is reported instead)")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the leg that runs two blocks in flight on one GPU (alternating HIP streams; reported as "
                     "value_two_blocks_in_flight, never as `value`)")
     ap.add_argument("--two-streams", action="store_true", help="(accepted for compatibility: the two-blocks-in-flight leg runs by default since round 6)")
@@ -1181,12 +1223,19 @@ def main():
         # HBM/fabric bytes per launch from the rocprofv3 PMC passes of this same command (profiles/*_pmc_traffic.json:
         # 2 x FETCH_SIZE per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), only valid for the BASELINE workload
         traffic, traffic_source = None, None
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if n_tx == N_TX and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("traffic_gb_per_launch") * 1e9   # bytes per launch
                 traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, 2 x FETCH_SIZE + WRITE_SIZE; read from the file, NOT measured in this run)" % name
                 break
+        traffic_measured = None
+        if extras and world == 1 and n_tx == N_TX and not args.no_pmc:
+            try:
+                traffic_measured = measured_traffic_leg()
+                traffic, traffic_source = traffic_measured["traffic_bytes_per_launch"], traffic_measured["source"]
+            except Exception as e:                                                                     # noqa: BLE001
+                traffic_measured = {"error": repr(e)[:300], "fallback": traffic_source}
         mac_ceiling, mac_peak, mac_peak_what = None, VALU_PEAK_MAC, "the burst v_mad ceiling of earlier rounds (the sustained measurement was not taken)"
         if extras:
             try:
@@ -1220,7 +1269,7 @@ def main():
             "roofline": {"bound": "valu-mac", "achieved": n / kernel_s * MAC_PER_VERIFY, "peak": mac_peak, "unit": "MAC/s",
                          "frac": n / kernel_s * MAC_PER_VERIFY / mac_peak,
                          "traffic": traffic, "traffic_unit": "HBM bytes/launch from the PMC passes (algorithmic: %d)" % int(ALGO_BYTES_PER_VERIFY * n),
-                         "traffic_source": traffic_source, "algorithmic_bytes": int(ALGO_BYTES_PER_VERIFY * n),
+                         "traffic_source": traffic_source, "traffic_measured": traffic_measured, "algorithmic_bytes": int(ALGO_BYTES_PER_VERIFY * n),
                          "kernel": ("p256_verify_pair_lds_kernel<256> (two lanes per signature, per-signature table in LDS)" if n > 16384 else "p256_verify_pair_kernel<256> (two lanes per signature)") if n <= 32768 else "p256_verify_kernel<256>", "kernel_ms": kernel_s * 1e3,
                          "kernel_ms_per_launch_events": kernel_ms,
                          "model": "achieved = verifies/s x 3.1e5 u32 MACs per verify (SURVEY 8(d) canonical count: 4 512 field products x 64 + the mod-n reductions); "

@@ -195,3 +195,40 @@ func BenchmarkVerifyFromMemo(b *testing.B) {
 	_, hits, _, _ := p.MemoStats()
 	b.ReportMetric(float64(hits), "memo_hits")
 }
+
+// identity.Verify as the validators run it after a pass - Hash(msg) then Verify(k, sig, digest) per signature - with the digest memo
+// answering Hash (round 6) and with bccsp/sw hashing (GPUOpts.NoHashMemo: round 5's provider).  ns/op is per signature.
+func benchIdentityVerifyAfterPass(b *testing.B, noHashMemo bool) {
+	ref, err := sw.NewDefaultSecurityLevelWithKeystore(sw.NewDummyKeyStore())
+	require.NoError(b, err)
+	g, err := New(ref, Options{Devices: []int{0}, NoHashMemo: noHashMemo})
+	if err != nil {
+		b.Skipf("no MI355X here: %s", err)
+	}
+	p := g.(*Provider)
+	defer p.Close()
+	raw, tuples := buildSignedBlock(b, g, 1000, 3)
+	_, err = p.PreVerifyBlock(raw, 44)
+	require.NoError(b, err)
+	b.ResetTimer()
+	b.RunParallel(func(pb *testing.PB) {
+		i := 0
+		for pb.Next() {
+			t := &tuples[i%len(tuples)]
+			i++
+			digest, err := g.Hash(t.Msg, &bccsp.SHA256Opts{})
+			if err != nil {
+				b.Fatal(err)
+			}
+			if ok, err := g.Verify(t.Key, t.Sig, digest, nil); !ok || err != nil {
+				b.Fatalf("memo answer for a valid signature: %v %v", ok, err)
+			}
+		}
+	})
+	hits, misses, _, _, _ := p.HashMemoStats()
+	b.ReportMetric(float64(hits), "hash_memo_hits")
+	b.ReportMetric(float64(misses), "hash_memo_misses")
+}
+
+func BenchmarkIdentityVerifyAfterPass(b *testing.B)           { benchIdentityVerifyAfterPass(b, false) }
+func BenchmarkIdentityVerifyAfterPassNoHashMemo(b *testing.B) { benchIdentityVerifyAfterPass(b, true) }

@@ -180,3 +180,54 @@ func TestPreVerifyBlockSeedsTheMemoAndEvicts(t *testing.T) {
 	entries, _, _, _ := p.MemoStats()
 	require.Equal(t, uint64(0), entries)
 }
+
+// identity.Verify hashes before it verifies (msp/identities.go:173-181).  After a pass, Hash(msg, &bccsp.SHA256Opts{}) for a message of
+// the block comes from the digest memo - and equals bccsp/sw's digest, because a hit is byte equality with what the device hashed; one
+// flipped byte, another length, other HashOpts, an evicted block: bccsp/sw's answer (same digest by definition, counted as a miss).
+func TestHashFromTheDigestMemo(t *testing.T) {
+	g, ref := providers(t)
+	p := g.(*Provider)
+	blockBytes, tuples := buildSignedBlock(t, g, 50, 3)
+	_, err := p.PreVerifyBlock(blockBytes, 43)
+	require.NoError(t, err)
+	hits0, _, held, _, _ := p.HashMemoStats()
+	require.Equal(t, uint64(1), held)
+	for _, tu := range tuples {
+		want, err := ref.Hash(tu.Msg, &bccsp.SHA256Opts{})
+		require.NoError(t, err)
+		got, err := g.Hash(tu.Msg, &bccsp.SHA256Opts{})
+		require.NoError(t, err)
+		require.Equal(t, want, got)
+		ok, err := g.Verify(tu.Key, tu.Sig, got, nil) // Hash then Verify, as identity.Verify does
+		require.NoError(t, err)
+		require.True(t, ok)
+	}
+	hits1, miss1, _, _, _ := p.HashMemoStats()
+	require.Equal(t, uint64(len(tuples)), hits1-hits0)
+	// anything but the block's own bytes is hashed by bccsp/sw - with bccsp/sw's result
+	for i, tu := range tuples {
+		bad := append([]byte(nil), tu.Msg...)
+		bad[(i*131)%len(bad)] ^= 0x20
+		want, _ := ref.Hash(bad, &bccsp.SHA256Opts{})
+		got, err := g.Hash(bad, &bccsp.SHA256Opts{})
+		require.NoError(t, err)
+		require.Equal(t, want, got)
+		want384, _ := ref.Hash(tu.Msg, &bccsp.SHA384Opts{}) // other HashOpts never ask the memo
+		got384, err := g.Hash(tu.Msg, &bccsp.SHA384Opts{})
+		require.NoError(t, err)
+		require.Equal(t, want384, got384)
+	}
+	_, errNil := g.Hash(tuples[0].Msg, nil) // bccsp/sw's error for nil opts (bccsp/sw/impl.go:179-181)
+	_, errRef := ref.Hash(tuples[0].Msg, nil)
+	require.Error(t, errNil)
+	require.Equal(t, errRef.Error(), errNil.Error())
+	_, miss2, _, _, _ := p.HashMemoStats()
+	require.Equal(t, uint64(len(tuples)), miss2-miss1) // the flipped messages (SHA384 and nil opts never reached the library)
+	p.EvictBlock(43)
+	_, _, held, _, _ = p.HashMemoStats()
+	require.Equal(t, uint64(0), held)
+	got, err := g.Hash(tuples[0].Msg, &bccsp.SHA256Opts{})
+	require.NoError(t, err)
+	want, _ := ref.Hash(tuples[0].Msg, &bccsp.SHA256Opts{})
+	require.Equal(t, want, got)
+}

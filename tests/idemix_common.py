@@ -51,8 +51,20 @@ class NymBatch:
 MSG_LENGTHS = [0, 1, 2, 17, 25, 26, 27, 63, 64, 89, 90, 91, 154, 155, 500, 1856, 4608]   # 26: header + msg = 3 whole blocks; 90: 4
 
 
+_BATCH_CACHE = {}
+
+
 def make_batch(issuers, n, seed, tamper=True):
-    """issuers: list of (ipk, sk).  A mix of valid signatures and every kind of invalid / out-of-domain input."""
+    """issuers: list of (ipk, sk).  A mix of valid signatures and every kind of invalid / out-of-domain input.
+    Deterministic in its arguments and read-only to its users, so the (pure-Python, seconds per hundred signatures) signing is done once
+    per process: the GPU suite runs every case under five kernel configurations (the suite's time)."""
+    key = (tuple(bytes(ipk.hash) for ipk, _ in issuers), n, seed, tamper)
+    if key not in _BATCH_CACHE:
+        _BATCH_CACHE[key] = _make_batch(issuers, n, seed, tamper)
+    return _BATCH_CACHE[key]
+
+
+def _make_batch(issuers, n, seed, tamper=True):
     rng = random.Random(seed)
     b = NymBatch()
     for i in range(n):
