@@ -354,7 +354,7 @@ def measured_traffic_leg(kernel_prefix="p256_verify_pair_lds_kernel", timeout_s=
             if not dbs:
                 raise RuntimeError("rocprofv3 --pmc %s left no database (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:]))
             c = sqlite3.connect(dbs[-1])
-            vals = [v for (v,) in c.execute("select value from counters_collection where counter_name = ? and kernel_name like ?", (counter, kernel_prefix + "%"))]
+            vals = [v for (v,) in c.execute("select value from counters_collection where counter_name = ? and kernel_name like ?", (counter, "%" + kernel_prefix + "%"))]
             c.close()
             if not vals:
                 raise RuntimeError("no %s rows for %s" % (counter, kernel_prefix))
@@ -430,23 +430,16 @@ def shard_of_8_leg(ctx, torch, np, fabgpu, coracle, block, dev, got, n, full_ker
     leg["configs2_shard_of_8_ms"] = shard_kernel_ms
     leg["configs2_whole_block_ms"] = full_kernel_ms
     leg["predicted_strong_speedup_8_hbm_resident"] = full_kernel_ms / shard_kernel_ms
-    # the product's in-process path (fabgpu_multi: what `configs2_inprocess` runs with G devices) on one device: the whole block, then the shard
-    m = fabgpu.MultiContext([0])
-    try:
-        def wall(k):
-            f = [block[x][:k] for x in ("qx", "qy", "e", "r", "s")]
-            for _ in range(3):
-                bits, _ = m.p256_verify_batch(*f, want_status=False)
-            t = []
-            for _ in range(steps):
-                c0 = time.perf_counter()
-                bits, _ = m.p256_verify_batch(*f, want_status=False)
-                t.append((time.perf_counter() - c0) * 1e3)
-            assert (bits == got[:k]).all(), "fabgpu_multi verdicts differ"
-            return statistics.median(t)
-        whole_ms, shard_ms = wall(n), wall(cnt)
-    finally:
-        m.close()
+    # the product's in-process path (fabgpu_multi: what `configs2_inprocess` runs with G devices) on one device: the whole block, then the
+    # shard - in a subprocess (tools/bench_multi.py --shard-of 8): RCCL prints its version banner on stdout when a communicator is made,
+    # and this process's stdout must END with the bench line
+    sub = inprocess_multi_leg(1, extra=("--shard-of", "8", "--iters", str(max(10, steps))))
+    if "error" in sub:
+        raise RuntimeError("tools/bench_multi.py: %s" % sub["error"])
+    whole_ms = next(l["median_ms"] for l in sub["legs"] if l["tuples"] == n and not l.get("shard_of"))
+    shard_ms = next(l["median_ms"] for l in sub["legs"] if l.get("shard_of") == 8)
+    assert next(l["tuples"] for l in sub["legs"] if l.get("shard_of") == 8) == cnt
+    leg["configs2_inprocess_collective"] = sub.get("collective")
     leg["configs2_inprocess_ms"] = whole_ms
     leg["configs2_inprocess_value"] = n / (whole_ms * 1e-3)
     leg["configs2_inprocess_shard_of_8_ms"] = shard_ms

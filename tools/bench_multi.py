@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--host-merge", action="store_true")
+    ap.add_argument("--shard-of", type=int, default=0, help="also time rank 0's shard of the 30000-tuple block as fabgpu_multi_plan cuts it for this many devices "
+                    "(bench.py's shard_of_8 leg: what one GPU of eight would be handed, on the devices there are)")
     ap.add_argument("--devices", default=None, help="comma-separated ordinals (default 0..gpus-1); a dry run on a smaller box repeats ordinals")
     args = ap.parse_args()
     import numpy as np
@@ -50,6 +52,23 @@ def main():
         out["legs"].append({"workload": label, "tuples": n, "value": n / (med * 1e-3), "unit": "verifies/s", "median_ms": med,
                             "p95_ms": sorted(wall)[int(0.95 * (len(wall) - 1))], "min_ms": min(wall), "iters": len(wall),
                             "shards": fabgpu.multi_plan(n, len(devices))[0][:2] + ["..."], "parity": "bit-identical to the ground truth"})
+    if args.shard_of > 1:
+        n = 30000
+        (lo, hi) = fabgpu.multi_plan(n, args.shard_of)[0][0]
+        b = fabgpu.synth_batch(n, seed=20260921, invalid_permille=10)
+        f = [b[k][lo:hi] for k in ("qx", "qy", "e", "r", "s")]
+        for _ in range(3):
+            bits, _ = m.p256_verify_batch(*f, want_status=False)
+        wall = []
+        for _ in range(args.iters):
+            c0 = time.perf_counter()
+            bits, _ = m.p256_verify_batch(*f, want_status=False)
+            wall.append((time.perf_counter() - c0) * 1e3)
+        assert (bits == (b["kind"][lo:hi] == 0)).all(), "shard bitmap differs from the generator's ground truth"
+        med = statistics.median(wall)
+        out["legs"].append({"workload": "rank 0's shard of the 30000-tuple block cut for %d devices, through this process's %d device(s)" % (args.shard_of, len(devices)),
+                            "shard_of": args.shard_of, "tuples": int(hi - lo), "value": (hi - lo) / (med * 1e-3), "unit": "verifies/s", "median_ms": med,
+                            "min_ms": min(wall), "iters": len(wall), "parity": "bit-identical to the ground truth"})
     m.close()
     print(json.dumps(out))
 
