@@ -20,3 +20,14 @@ def test_randomised_idemix_soak():
     import soak_idemix
     r = soak_idemix.soak(float(os.environ.get("FABGPU_SOAK_SECONDS", "10")), seed=int(os.environ.get("FABGPU_SOAK_SEED", "7")))
     assert r["calls"] >= 100 and r["signatures"] > 10000, r
+
+
+@pytest.mark.gpu
+def test_digest_memo_soak_under_churn():
+    """tests/soak_hash_memo.py for a few seconds: passes, evictions and lookups from six threads at once over a pool of three kept block
+    copies - a hit is always SHA-256 of the bytes that were asked about, a mutated message never hits, the verdict memo answers with the
+    pass's status or misses; profiles/r06_soak_hash_memo.json is the long run"""
+    import soak_hash_memo
+    r = soak_hash_memo.soak(float(os.environ.get("FABGPU_SOAK_SECONDS", "8")), seed=int(os.environ.get("FABGPU_SOAK_SEED", "7")))
+    assert r["soak"] == "ok", r
+    assert r["hash_hits"] > 100 and r["mutants_asked"] > 50 and r["evictions"] > 3, r
