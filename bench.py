@@ -326,7 +326,7 @@ def inprocess_multi_leg(world, tool="bench_multi.py", extra=()):
         return {"error": repr(e)}
 
 
-def measured_traffic_leg(kernel_prefix="p256_verify_pair_lds_kernel", timeout_s=150):
+def measured_traffic_leg(kernel_prefix="p256_verify_pair_lds_kernel", timeout_s=90):
     """HBM-side bytes per launch of the dominant kernel, MEASURED IN THIS RUN (rounds 2-5 read the figure from a
     committed file): two rocprofv3 passes of their own - --pmc FETCH_SIZE, --pmc WRITE_SIZE, with --kernel-trace only, as
     MI355X_MICROARCH.md's HBM section prescribes - over tools/gpu_pmc_kernels.py (the same 30 000-tuple launch, six times), read out of the
