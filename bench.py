@@ -899,11 +899,21 @@ def block_pass_leg(np, fabgpu, coracle, n_tx=10000, steps=10):
             no_ni = {"OPENSSL_ia32cap": ":~0x20000000"}
             # (label, hash memo on?, environment): the provider as shipped; the round-5 provider (Hash = bccsp/sw) with and without SHA-NI;
             # the shipped provider without SHA-NI (only BlockDataHash and misses still hash on the CPU)
-            for label, hm, env_extra in (("digest_memo", "1", {}), ("digest_memo_off", "0", {}), ("digest_memo_off_no_sha_ni", "0", no_ni), ("digest_memo_no_sha_ni", "1", no_ni)):
+            def one_replay(hm, env_extra):
                 r_ = subprocess.run([exe, path, "16", str(pool_threads), "1", hm], capture_output=True, text=True, timeout=180,
                                     env=dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fabric-mod_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""), **env_extra))
                 line = [l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")]
-                replay[label] = json.loads(line[-1]) if r_.returncode == 0 and line else {"error": "rc %d: %s" % (r_.returncode, (r_.stderr or r_.stdout)[-300:])}
+                return json.loads(line[-1]) if r_.returncode == 0 and line else {"error": "rc %d: %s" % (r_.returncode, (r_.stderr or r_.stdout)[-300:])}
+            for label, hm, env_extra in (("digest_memo", "1", {}), ("digest_memo_off", "0", {}), ("digest_memo_off_no_sha_ni", "0", no_ni), ("digest_memo_no_sha_ni", "1", no_ni)):
+                replay[label] = one_replay(hm, env_extra)
+            # The shipped form three times in all (fresh processes: where the scheduler puts the sixteen validator threads relative to the
+            # pinned tables - two sockets - moves the figure by +-15 % from run to run): the run with the MEDIAN end-to-end rate is reported,
+            # all three rates are kept beside it
+            runs = [replay["digest_memo"]] + [one_replay("1", {}) for _ in range(2)]
+            good = sorted((r_ for r_ in runs if "validated_tx_per_s_end_to_end" in r_), key=lambda r_: r_["validated_tx_per_s_end_to_end"])
+            if good:
+                replay["digest_memo"] = dict(good[len(good) // 2], end_to_end_rates_of_the_runs=[r_["validated_tx_per_s_end_to_end"] for r_ in good],
+                                             validators_ms_of_the_runs=[r_["validators_ms_per_block_median"] for r_ in good])
             legs["as_the_go_binding_calls_it"] = {
                 "what": "tools/go_call_replay.c: a fresh provider (fabgpu_csp_new2, ConcurrentPasses 2), block k + 1 pre-verified at arrival (HasBlock, PreVerifyBlock with the "
                         "provider's remembered cap_tx, FABGPU_PASS_SEED_MEMO, flags only) while block k is validated by a pool of validatorPoolSize = %d threads - per signature "

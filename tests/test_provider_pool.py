@@ -165,6 +165,20 @@ def test_flat_batches_and_idemix_issuers_on_every_device_of_the_pool(pool):
     assert pool.passes_per_device() == [2, 2, 2]
     for o in outs[1:]:
         _same(outs[0], o)
+    # the digest memo is the provider's, whichever device kept the block's copy: every message a pass hashed - the idemix creators'
+    # payloads among them (their entries carry SHA-256(message) too) - is answered with hashlib's digest, six blocks' copies held on three devices
+    import hashlib
+    st = fabgpu.hash_memo_stats(pool)
+    assert st["blocks_held"] == 6 and st["refused"] == 0
+    o, asked = outs[-1], 0
+    for i in range(len(o["tuple_status"])):
+        if not o["tuple_hashed"][i] or o["tuple_status"][i] > 3:
+            continue
+        sp = [int(x) for x in o["tuple_spans"][i]]
+        msg = o["arena"][sp[2]:sp[2] + sp[3]] + o["arena"][sp[4]:sp[4] + sp[5]]
+        assert fabgpu.hash_lookup(pool, msg) == hashlib.sha256(msg).digest() == bytes(o["tuple_digest"][i])
+        asked += 1
+    assert asked > 300
     ipk_hash = bytes(fixtures()["MSP1OU1"]["ipk"].hash)
     o = outs[-1]                                                                   # (device 2's pass)
     n = 0
