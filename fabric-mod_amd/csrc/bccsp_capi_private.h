@@ -23,7 +23,7 @@ struct fabgpu_csp {
     std::unique_ptr<fab::bccsp::GPUCSP::BlockUpload> orphan;
     std::chrono::steady_clock::time_point orphan_at;
     uint64_t orphan_print = 0;
-    // FNV-1a over the length and the first and last KiB: cheap (2 KiB), and enough to tell a different block that happens to sit at a
+    // FNV-1a over the length, the first and last KiB and 64 samples in between: cheap (6 KiB), and enough to tell a different block that happens to sit at a
     // re-used address with the same length from the block that was uploaded (verdicts never depend on it being collision-free against
     // an adversary: a peer's caller retries with ITS OWN buffer; this guards against an honest caller's allocator)
     static uint64_t fingerprint(const uint8_t* block, size_t len) {
@@ -34,6 +34,11 @@ struct fabgpu_csp {
         const size_t k = len < 1024 ? len : 1024;
         mix(block, k);
         mix(block + len - k, k);
+        // ... and 64 bytes at each of 64 places spread over the rest (a buffer changed in its MIDDLE between the attempts
+        // used to pass; the contract still says the caller must leave the buffer alone between them - this narrows what an honest
+        // caller's reused allocation can get past, it is not a guarantee)
+        if (len > 4096)
+            for (size_t i = 1; i <= 64; i++) mix(block + (len - 64) / 65 * i, 64);
         return h;
     }
     std::unique_ptr<fab::bccsp::GPUCSP::BlockUpload> upload_for(const uint8_t* block, size_t len, uint64_t seq, bool keep_host_copy) {

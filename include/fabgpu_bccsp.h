@@ -186,8 +186,10 @@ int fabgpu_csp_block_preverify2(fabgpu_csp* csp, fabgpu_block_pass* pass);
  * for the retry.  Contract:
  *  - by the time FABGPU_ETOOBIG is returned the upload has been waited for: the library never reads `block` after a call has returned
  *    (cgo: no Go pointer is retained), so the caller may free or reuse the buffer;
- *  - a retry finds the kept upload only if it passes the same pointer, length and block_seq, the block's first and last KiB are
- *    unchanged, and it comes within one second; any other call uploads afresh (correct, just slower);
+ *  - a retry finds the kept upload only if it passes the same pointer, length and block_seq, a fingerprint of the buffer (its first and
+ *    last KiB and 64 samples between them) is unchanged, and it comes within one second; any other call uploads afresh (correct, just
+ *    slower).  The caller MUST NOT modify the buffer between the attempts: the fingerprint is a guard against an allocator handing the
+ *    same address to another block, not a proof that every byte is the one that was uploaded;
  *  - a caller that will not retry calls fabgpu_csp_block_pass_abandon (returns 1 if an upload was dropped, 0 if none was kept);
  *    otherwise the kept upload is dropped by the next pass that finds it older than a second, and its device counts as busy until then. */
 int fabgpu_csp_block_pass_abandon(fabgpu_csp* csp);
