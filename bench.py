@@ -300,7 +300,30 @@ def emit(out):
     sys.stderr.write(json.dumps(out) + "\n")
     sys.stderr.flush()
     sys.stdout.flush()
-    print(compact_line(out, name), flush=True)
+    line = compact_line(out, name)
+    if _LINE_FD is not None:
+        os.write(_LINE_FD, (line + "\n").encode())          # the process's REAL stdout (see keep_stdout_for_the_line)
+    else:
+        print(line, flush=True)
+
+
+# The contract: rank 0 prints ONE JSON line.  Libraries loaded into this process write to the C-level stdout too - RCCL prints a
+# five-line version banner when its first communicator is made (torch.distributed's nccl backend at --gpus N; fabgpu_multi), through C
+# stdio, which is flushed AT EXIT: behind the line.  So the process's file descriptor 1 is pointed at stderr for the whole run and the
+# line alone goes to the descriptor stdout was when bench.py started.
+_LINE_FD = None
+
+
+def keep_stdout_for_the_line():
+    global _LINE_FD
+    if _LINE_FD is not None:
+        return
+    try:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+    except OSError:
+        _LINE_FD = None
 
 
 def inprocess_multi_leg(world, tool="bench_multi.py", extra=()):
@@ -1022,6 +1045,7 @@ def fused_cfg3_leg(ctx, torch, np, fabgpu, coracle, steps):
 
 
 def main():
+    keep_stdout_for_the_line()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
