@@ -33,7 +33,9 @@ typedef struct fabgpu_csp_opts {
     const int32_t* devices;        /* n_devices HIP ordinals, or NULL = 0 .. n_devices-1 */
     uint32_t ctx_flags;            /* FABGPU_FLAG_* for every context */
     uint32_t concurrent_passes;    /* per device: what this many overlapping block passes need - staging slots, pinned memo tables, pass
-                                      arrays - is allocated NOW, not when passes first overlap (0: on demand) */
+                                      arrays, kept block copies (concurrent_passes + 2 of them), a slab of key tables - is allocated NOW, not
+                                      when passes first overlap (0: on demand).  Any value > 0 makes ALL THREE staging slots of a device
+                                      (3 x expect_block_bytes of device memory): uploads walk round all of them even when passes never overlap */
     uint64_t expect_block_bytes;   /* sizes that pre-allocation (0: 64 MiB) */
     uint32_t expect_tuples;        /* (0: 65 536) */
     /* switches that were environment variables through round 3: 0 = the default, > 0 on, < 0 off (a zeroed struct is all defaults) */
