@@ -405,10 +405,24 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
         }
         if (const char* fi = getenv("FABGPU_FAULT_INJECT")) ctx->fault = !strcmp(fi, "launch") ? 1 : (!strcmp(fi, "oom") ? 2 : 0);
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = FABGPU_ENODEV; break; }
-        std::vector<int32_t> tab(GTab16::TABLE_WORDS);   // 80 MiB, ~0.2 s on 16 host threads
-        build_g_comb_table16(tab.data());
         if (hipMalloc((void**)&ctx->d_gtab, sizeof(int32_t) * GTab16::TABLE_WORDS) != hipSuccess) { rc = FABGPU_ENOMEM; break; }
-        if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(int32_t) * GTab16::TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
+        // The generator's comb (80 MiB) is built on the device since round 6 (keytab_kernels.hip launch_gtab_build: one million lanes, a
+        // few milliseconds) - byte-identical to p256_tables29.h's, which took 0.2 s on sixteen host threads plus the upload and which is
+        // what a failed device build falls back to.  FABGPU_GTAB_HOST=1 (tests, A/B) takes the host builder.
+        bool built = false;
+        if (!getenv("FABGPU_GTAB_HOST") && ctx->fault == 0) {
+            void* scr = nullptr;
+            if (hipMalloc(&scr, gtab_scratch_bytes()) == hipSuccess) {
+                built = launch_gtab_build(ctx->d_gtab, scr, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+                hipFree(scr);
+            }
+            if (!built) (void)hipGetLastError();
+        }
+        if (!built) {
+            std::vector<int32_t> tab(GTab16::TABLE_WORDS);   // 80 MiB, ~0.2 s on 16 host threads
+            build_g_comb_table16(tab.data());
+            if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(int32_t) * GTab16::TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
+        }
         if (cfg && cfg->max_batch) {
             size_t n = cfg->max_batch;
             if ((rc = ctx->fields.ensure(n * 160)) || (rc = ctx->offs.ensure((n + 1) * 4)) || (rc = ctx->out.ensure(n * 41 + 64))) break;
@@ -2795,6 +2809,17 @@ bool key_table_build(const uint8_t* qx32, const uint8_t* qy32, int32_t* out) {
     from_be32(qy, qy32);
     build_key_comb_table8(out, qx, qy);
     return true;
+}
+// TEST HOOK support: the first word at which the context's generator comb differs from the host builder's table (-1: identical; -2: error)
+int64_t gtab_compare_with_host(fabgpu_ctx* ctx) {
+    if (!ctx || !ctx->d_gtab) return -2;
+    std::vector<int32_t> host(GTab16::TABLE_WORDS), dev(GTab16::TABLE_WORDS);
+    build_g_comb_table16(host.data());
+    DeviceGuard g(ctx->device);
+    if (hipMemcpy(dev.data(), ctx->d_gtab, sizeof(int32_t) * GTab16::TABLE_WORDS, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    for (size_t i = 0; i < host.size(); i++)
+        if (host[i] != dev[i]) return (int64_t)i;
+    return -1;
 }
 int key_register_batch(fabgpu_ctx* ctx, int n, const uint8_t* qxy, uint32_t* key_ids) { return key_register_batch_dev(ctx, n, qxy, key_ids); }
 // TEST HOOK support: the device's table of key `key_id` copied to the host (KeyTab8::TABLE_WORDS words)

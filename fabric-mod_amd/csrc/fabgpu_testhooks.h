@@ -19,6 +19,9 @@ float fabgpu_last_kernel_ms(fabgpu_ctx* ctx);
  * table the host builder (p256_tables29.h) makes for a key - 32 windows x 256 entries x 20 words; the two must be byte-identical. */
 int fabgpu_test_key_table(fabgpu_ctx* ctx, uint32_t key_id, int32_t* out_words, size_t cap_words);
 int fabgpu_test_key_table_host(const uint8_t* qx32, const uint8_t* qy32, int32_t* out_words, size_t cap_words);
+/* TEST HOOK: the context's generator comb (80 MiB, built on the device at fabgpu_init since round 6) against the host builder's: the
+ * index of the first differing 32-bit word, -1 identical, -2 error */
+long long fabgpu_test_gtab_compare_with_host(fabgpu_ctx* ctx);
 /* TEST HOOK: while on, the idemix four-lane form queues its side launch (the fixed-base terms) BEHIND the commitment launch, so that
  * every commitment wavefront gives up on its records and computes the terms itself, and every side wavefront skips its rows. */
 void fabgpu_test_nym_side_after(fabgpu_ctx* ctx, int on);

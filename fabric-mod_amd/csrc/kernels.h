@@ -127,4 +127,7 @@ int warm_kernel_functions_keytab();
 // keytab_kernels.hip: comb tables of registered P-256 keys built on the device (qxy, tabs: device memory; see the unit's header)
 size_t keytab_scratch_bytes(uint32_t n_keys);
 hipError_t launch_keytab_build(uint32_t n_keys, const void* qxy, void* const* tabs, void* scratch, hipStream_t st);
+// ... and the generator's 16-bit comb (80 MiB) at fabgpu_init
+size_t gtab_scratch_bytes();
+hipError_t launch_gtab_build(void* d_tab, void* scratch, hipStream_t st);
 }  // namespace fab

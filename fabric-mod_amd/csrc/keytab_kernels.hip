@@ -47,7 +47,9 @@ __device__ void jac_to_affine_canon(fe& x, fe& y, const jac29& p) {
 
 }  // namespace
 
+template <class Tab>
 __global__ void __launch_bounds__(64) keytab_chain_kernel(uint32_t n_keys, const uint8_t* __restrict__ qxy, jac29* __restrict__ bases) {
+    constexpr int BITS = 256 / Tab::WINDOWS;
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_keys) return;
     u256 qx, qy;
@@ -57,14 +59,14 @@ __global__ void __launch_bounds__(64) keytab_chain_kernel(uint32_t n_keys, const
     fe_to_mont(acc.X, qx);
     fe_to_mont(acc.Y, qy);
     fe_set_one(acc.Z);
-    bases[(size_t)k * KeyTab8::WINDOWS] = acc;
-    for (int w = 1; w < KeyTab8::WINDOWS; w++) {
-        for (int b = 0; b < 8; b++) {
+    bases[(size_t)k * Tab::WINDOWS] = acc;
+    for (int w = 1; w < Tab::WINDOWS; w++) {
+        for (int b = 0; b < BITS; b++) {
             jac29 t;
             pt_dbl29(t, acc);
             acc = t;
         }
-        bases[(size_t)k * KeyTab8::WINDOWS + w] = acc;
+        bases[(size_t)k * Tab::WINDOWS + w] = acc;
     }
 }
 
@@ -77,18 +79,20 @@ __global__ void __launch_bounds__(64) keytab_affine_kernel(uint32_t n_bases, con
     aff[i] = a;
 }
 
+template <class Tab>
 __global__ void __launch_bounds__(256) keytab_entries_kernel(uint32_t n_keys, const KeyBaseAffine* __restrict__ aff, int32_t* const* __restrict__ tabs) {
-    constexpr uint32_t PER_KEY = (uint32_t)KeyTab8::WINDOWS * 256u;
+    constexpr int BITS = 256 / Tab::WINDOWS;
+    constexpr uint32_t PER_KEY = (uint32_t)Tab::WINDOWS << BITS;
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t key = id / PER_KEY, rem = id % PER_KEY, w = rem >> 8, d = rem & 255u;
+    const uint32_t key = id / PER_KEY, rem = id % PER_KEY, w = rem >> BITS, d = rem & ((1u << BITS) - 1u);
     if (key >= n_keys) return;
-    int32_t* e = tabs[key] + KeyTab8::index((int)w, d);
+    int32_t* e = tabs[key] + Tab::index((int)w, d);
     if (d == 0) {
 #pragma unroll
         for (int l = 0; l < COMB_ENTRY_WORDS; l++) e[l] = 0;
         return;
     }
-    const KeyBaseAffine base = aff[(size_t)key * KeyTab8::WINDOWS + w];
+    const KeyBaseAffine base = aff[(size_t)key * Tab::WINDOWS + w];
     fe x = base.x, y = base.y;
     if (d != 1) {
         jac29 acc;
@@ -117,33 +121,66 @@ __global__ void __launch_bounds__(256) keytab_entries_kernel(uint32_t n_keys, co
     e[19] = 0;
 }
 
-size_t keytab_scratch_bytes(uint32_t n_keys) {
-    return (size_t)n_keys * KeyTab8::WINDOWS * (sizeof(jac29) + sizeof(KeyBaseAffine)) + 256;
+template <class Tab>
+static size_t comb_scratch_bytes(uint32_t n_keys) {
+    return (size_t)n_keys * Tab::WINDOWS * (sizeof(jac29) + sizeof(KeyBaseAffine)) + 256;
+}
+size_t keytab_scratch_bytes(uint32_t n_keys) { return comb_scratch_bytes<KeyTab8>(n_keys); }
+size_t gtab_scratch_bytes() { return comb_scratch_bytes<GTab16>(1) + 64 + sizeof(void*) + 64; }
+
+template <class Tab>
+static hipError_t launch_comb_build(uint32_t n_keys, const void* qxy, void* const* tabs, void* scratch, hipStream_t st) {
+    if (n_keys == 0) return hipSuccess;
+    constexpr int BITS = 256 / Tab::WINDOWS;
+    jac29* bases = (jac29*)scratch;
+    KeyBaseAffine* aff = (KeyBaseAffine*)(((uintptr_t)(bases + (size_t)n_keys * Tab::WINDOWS) + 15) & ~(uintptr_t)15);
+    hipLaunchKernelGGL(keytab_chain_kernel<Tab>, dim3((n_keys + 63) / 64), dim3(64), 0, st, n_keys, (const uint8_t*)qxy, bases);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint32_t nb = n_keys * (uint32_t)Tab::WINDOWS;
+    hipLaunchKernelGGL(keytab_affine_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, nb, (const jac29*)bases, aff);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint64_t lanes = ((uint64_t)n_keys * Tab::WINDOWS) << BITS;
+    hipLaunchKernelGGL(keytab_entries_kernel<Tab>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, n_keys, (const KeyBaseAffine*)aff, (int32_t* const*)tabs);
+    return hipGetLastError();
 }
 
 // qxy: n_keys x 64 bytes (X || Y, big-endian) on the device; tabs: n_keys device pointers (on the device) to tables of KeyTab8::TABLE_WORDS
 // words each; scratch: keytab_scratch_bytes(n_keys).  Every key must be an affine point of the curve (the callers' gate).
 hipError_t launch_keytab_build(uint32_t n_keys, const void* qxy, void* const* tabs, void* scratch, hipStream_t st) {
-    if (n_keys == 0) return hipSuccess;
-    jac29* bases = (jac29*)scratch;
-    KeyBaseAffine* aff = (KeyBaseAffine*)(((uintptr_t)(bases + (size_t)n_keys * KeyTab8::WINDOWS) + 15) & ~(uintptr_t)15);
-    hipLaunchKernelGGL(keytab_chain_kernel, dim3((n_keys + 63) / 64), dim3(64), 0, st, n_keys, (const uint8_t*)qxy, bases);
-    hipError_t e = hipGetLastError();
+    return launch_comb_build<KeyTab8>(n_keys, qxy, tabs, scratch, st);
+}
+
+// The GENERATOR's comb (CombTab<16>: 16 windows x 65 535 affine points, 80 MiB) built the same way at fabgpu_init: one million lanes of
+// at most fifteen doublings and fifteen mixed additions each - 2-3 ms of kernels against 0.2 s on sixteen host threads plus an 80 MiB
+// upload (and every test context of the GPU suite used to pay that).  d_tab: GTab16::TABLE_WORDS words of device memory; scratch:
+// gtab_scratch_bytes() of device memory (its tail holds G's coordinates and the table pointer, which this function uploads).
+hipError_t launch_gtab_build(void* d_tab, void* scratch, hipStream_t st) {
+    // (the generator's affine coordinates as plain integers, least significant word first: SEC 2 secp256r1; the same literals as p256_tables.h)
+    const u256 gx = {{0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u, 0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u}};
+    const u256 gy = {{0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u, 0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u}};
+    struct Tail {
+        uint8_t qxy[64];
+        void* tab;
+    } tail;
+    to_be32(tail.qxy, gx);
+    to_be32(tail.qxy + 32, gy);
+    tail.tab = d_tab;
+    uint8_t* d_tail = (uint8_t*)scratch + ((comb_scratch_bytes<GTab16>(1) + 63) & ~(size_t)63);
+    hipError_t e = hipMemcpyAsync(d_tail, &tail, sizeof(tail), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return e;
-    const uint32_t nb = n_keys * (uint32_t)KeyTab8::WINDOWS;
-    hipLaunchKernelGGL(keytab_affine_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, nb, (const jac29*)bases, aff);
-    e = hipGetLastError();
+    e = hipStreamSynchronize(st);                              // (`tail` lives on this stack frame)
     if (e != hipSuccess) return e;
-    const uint64_t lanes = (uint64_t)n_keys * KeyTab8::WINDOWS * 256u;
-    hipLaunchKernelGGL(keytab_entries_kernel, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, n_keys, (const KeyBaseAffine*)aff, (int32_t* const*)tabs);
-    return hipGetLastError();
+    return launch_comb_build<GTab16>(1, d_tail, (void* const*)(d_tail + offsetof(Tail, tab)), scratch, st);
 }
 
 // see warm_kernel_functions_kernels (kernels.hip)
 int warm_kernel_functions_keytab() {
     int ok = 0;
     hipFuncAttributes a;
-    const void* fns[] = {(const void*)keytab_chain_kernel, (const void*)keytab_affine_kernel, (const void*)keytab_entries_kernel};
+    const void* fns[] = {(const void*)keytab_chain_kernel<KeyTab8>, (const void*)keytab_affine_kernel, (const void*)keytab_entries_kernel<KeyTab8>,
+                         (const void*)keytab_chain_kernel<GTab16>, (const void*)keytab_entries_kernel<GTab16>};
     for (const void* f : fns) ok += hipFuncGetAttributes(&a, f) == hipSuccess ? 1 : 0;
     return ok;
 }

@@ -34,6 +34,7 @@ int fabgpu_test_key_table(fabgpu_ctx* ctx, uint32_t key_id, int32_t* out_words, 
     if (cap_words < fab::key_table_words()) return FABGPU_ETOOBIG;
     return fab::key_table_copy(ctx, key_id, out_words);
 }
+long long fabgpu_test_gtab_compare_with_host(fabgpu_ctx* ctx) { return (long long)fab::gtab_compare_with_host(ctx); }
 int fabgpu_test_key_table_host(const uint8_t* qx32, const uint8_t* qy32, int32_t* out_words, size_t cap_words) {
     if (cap_words < fab::key_table_words()) return FABGPU_ETOOBIG;
     return fab::key_table_build(qx32, qy32, out_words) ? FABGPU_OK : FABGPU_EINVAL;

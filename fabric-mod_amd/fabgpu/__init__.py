@@ -123,7 +123,7 @@ ABI_SYMBOLS = [
 HOOK_SYMBOLS = [
     "fabgpu_synth_batch", "fabgpu_last_kernel_ms", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast",
     "fabgpu_gate_sig_any", "fabgpu_csp_idfix_probe", "fabgpu_csp_gate_probe", "fabgpu_identity_table_hash", "fabgpu_test_nym_side_after",
-    "fabgpu_test_key_table", "fabgpu_test_key_table_host",
+    "fabgpu_test_key_table", "fabgpu_test_key_table_host", "fabgpu_test_gtab_compare_with_host",
 ]
 _HOOKS_PATH = os.path.join(os.path.dirname(_LIB_PATH), "libfabgpu_testhooks.so")
 
@@ -150,6 +150,8 @@ def load_hooks():
     H.fabgpu_test_nym_side_after.restype = None
     H.fabgpu_test_key_table.argtypes = [_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int32), _sz]
     H.fabgpu_test_key_table_host.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _sz]
+    H.fabgpu_test_gtab_compare_with_host.argtypes = [_vp]
+    H.fabgpu_test_gtab_compare_with_host.restype = ctypes.c_longlong
     H.fabgpu_csp_block_walk_compare.argtypes = [_vp, _u8p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
     H.fabgpu_block_walk_twopass_compare.argtypes = [_u8p, _sz, ctypes.c_char_p, _sz]
     H.fabgpu_gate_sig_fast.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
@@ -555,6 +557,10 @@ class Context:
         out = np.zeros(Context.KEY_TABLE_WORDS, dtype=np.int32)
         _check(load_hooks().fabgpu_test_key_table_host(qx32, qy32, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), out.size), "fabgpu_test_key_table_host")
         return out
+
+    def test_gtab_compare_with_host(self) -> int:
+        """TEST HOOK: first differing word of the device-built generator comb against the host builder's table; -1 = identical."""
+        return int(load_hooks().fabgpu_test_gtab_compare_with_host(self._h))
 
     def test_nym_side_after(self, on: bool) -> None:
         """TEST HOOK (libfabgpu_testhooks.so): the idemix side launch behind the commitment launch while on."""

@@ -312,6 +312,32 @@ def test_key_tables_built_on_the_device_equal_the_host_builders_byte_for_byte(ct
         assert (plain(t[w, d, :9]), plain(t[w, d, 9:18])) == want, (w, d)
 
 
+def test_generator_comb_built_on_the_device_equals_the_host_builders(ctx):
+    """fabgpu_init builds the generator's 16-bit comb (16 windows x 65 535 affine points, 80 MiB) on the device since round 6
+    (csrc/keytab_kernels.hip launch_gtab_build) instead of on sixteen host threads: all 20 971 520 words equal the host builder's
+    (p256_tables29.h, the table every verify kernel gathered from through round 5).  And a context made with the host builder
+    (FABGPU_GTAB_HOST=1, read once at fabgpu_init) agrees with itself the same way."""
+    import time
+    assert ctx.test_gtab_compare_with_host() == -1
+    os.environ["FABGPU_GTAB_HOST"] = "1"
+    try:
+        t0 = time.perf_counter()
+        c2 = fabgpu.Context(device=0)
+        host_s = time.perf_counter() - t0
+    finally:
+        del os.environ["FABGPU_GTAB_HOST"]
+    try:
+        assert c2.test_gtab_compare_with_host() == -1
+    finally:
+        c2.close()
+    t0 = time.perf_counter()
+    c3 = fabgpu.Context(device=0)
+    dev_s = time.perf_counter() - t0
+    c3.close()
+    print("fabgpu_init: %.0f ms with the generator comb built on the device, %.0f ms with the host builder" % (dev_s * 1e3, host_s * 1e3))
+    assert dev_s < host_s
+
+
 def test_registered_keys_every_signer_its_own_key_edge_vectors_and_bad_ids(ctx):
     # the edge vectors (x(R) >= n, u1 = 0, final addition = doubling / infinity, window corners ...) through the keyed path
     vs = [v for v in _load("edge_kats.json") if len(v["e"]) == 64 and po.on_curve(int(v["qx"], 16), int(v["qy"], 16))
