@@ -243,7 +243,13 @@ func New(swCSP bccsp.BCCSP, opts Options) (bccsp.BCCSP, error) {
 		}
 		C.fabgpu_csp_memo_set_capacity(csp, C.uint64_t(opts.MemoBlocks)*C.uint64_t(tuples))
 	}
-	return &Provider{BCCSP: swCSP, csp: csp, capTx: 1024, noHashMemo: opts.NoHashMemo}, nil
+	// room for per-transaction flags to start with: a block has fewer transactions than signatures, so an operator who sized the
+	// provider (ExpectTuples) has already said how large it needs to be - the first big block then costs no FABGPU_ETOOBIG round trip
+	capTx := uint32(1024)
+	if opts.ExpectTuples > 1024 {
+		capTx = uint32(opts.ExpectTuples)
+	}
+	return &Provider{BCCSP: swCSP, csp: csp, capTx: capTx, noHashMemo: opts.NoHashMemo}, nil
 }
 
 // Devices: how many device contexts this provider drives.

@@ -330,6 +330,8 @@ int main(int argc, char** argv) {
     o.pass_timing = getenv("GO_REPLAY_PASS_TIMING") ? 1 : 0; /* stage breakdown of every pass on stderr (probes only) */
     o.expect_block_bytes = len + 4096;
     o.expect_tuples = n_tuples + 64;
+    if (o.expect_tuples > g_cap_tx) g_cap_tx = o.expect_tuples; /* gpu.go New: capTx starts at max(1024, Options.ExpectTuples) */
+    const uint32_t cap_tx_start = g_cap_tx;
     char err[256];
     double t_new = now_ms();
     int rc = fabgpu_csp_new2(&o, &g_csp, err, sizeof(err));
@@ -453,7 +455,7 @@ int main(int argc, char** argv) {
     char why[128];
     fabgpu_csp_pass_routes(g_csp, &dw, &hw, why, sizeof(why));
     printf("{\"block_bytes\": %zu, \"n_tx\": %u, \"signatures_per_block\": %u, \"blocks\": %d, \"validator_threads\": %d, \"device_contexts\": %d, "
-           "\"provider_new_ms\": %.3f, \"first_block_of_a_fresh_process\": {\"ms\": %.3f, \"etoobig_retries\": %d, \"cap_tx_before\": 1024, \"cap_tx_after\": %u, "
+           "\"provider_new_ms\": %.3f, \"first_block_of_a_fresh_process\": {\"ms\": %.3f, \"etoobig_retries\": %d, \"cap_tx_before\": %u, \"cap_tx_after\": %u, "
            "\"what\": \"code objects loaded at first launch, six certificates decoded, caps grown: once per process\"}, "
            "\"lone_passes_ms\": [%.3f, %.3f, %.3f, %.3f, %.3f], "
            "\"over_caps_on_a_warm_provider\": {\"ms\": %.3f, \"etoobig_retries\": %d, \"warm_lone_pass_ms\": %.3f, \"over_warm\": %.3f}, "
@@ -461,7 +463,7 @@ int main(int argc, char** argv) {
            "\"validators_ms_per_block_median\": %.3f, \"block_data_hash_ms\": %.3f, \"has_block_ms\": %.4f, \"arrivals_in_flight\": %d, \"arrival_window\": %d, \"hash_memo\": %d, \"cpu_sha256_MB_per_block\": %.2f, \"hash_memo_MB_per_block\": %.2f, \"hash_memo_hits\": %llu, \"hash_memo_digest_mismatches\": %llu, \"memo_hits\": %llu, \"memo_misses\": %llu, "
            "\"pipeline_wall_ms\": %.3f, \"ms_per_block_end_to_end\": %.3f, \"validated_tx_per_s_end_to_end\": %.1f, "
            "\"passes_on_device_route\": %llu, \"passes_on_host_route\": %llu, \"passes_per_context\": [",
-           len, n_tx, n_env_tuples, n_blocks, n_thr, n_dev, t_new, warm_ms[0], warmup[0].retries, g_cap_tx, warm_ms[0], warm_ms[1], warm_ms[2], warm_ms[3], warm_ms[4],
+           len, n_tx, n_env_tuples, n_blocks, n_thr, n_dev, t_new, warm_ms[0], warmup[0].retries, cap_tx_start, g_cap_tx, warm_ms[0], warm_ms[1], warm_ms[2], warm_ms[3], warm_ms[4],
            warm_ms[5], warmup[5].retries, warm4, warm4 > 0 ? warm_ms[5] / warm4 : 0, warm_med,
            val_med, bdh_med, has_ms[n_blocks / 2], g_arrivals, g_window, g_hash_memo, (hashed - hash_bytes) / 1e6 / n_blocks, hash_bytes / 1e6 / n_blocks, (unsigned long long)hash_hits,
            (unsigned long long)mismatches, (unsigned long long)hits, (unsigned long long)misses, wall, wall / n_blocks,
