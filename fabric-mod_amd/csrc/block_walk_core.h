@@ -835,22 +835,38 @@ inline uint64_t id_hash_host(const uint8_t* p, uint32_t len, uint64_t seed = 0) 
 // transaction share their first kilobyte (prp) and their last bytes (the PEM trailer of the endorser's certificate), which is why
 // first-and-last-bytes alone would not do; samples in between land in the certificates' bodies.  The same lines run on the device
 // (walk_memo_index_kernel, over the two spans of a tuple) and on the host (GPUCSP::HashLookup, over the caller's contiguous bytes).
-WALK_HD inline uint64_t msg_fingerprint(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen) {
-    const uint64_t n = (uint64_t)alen + blen;
+// (in two pieces so that the device can gather a message's 64 sampled bytes with one load per lane of a wavefront - walk_memo_write_kernel -
+//  and still run THESE lines over them: where sample k starts in a message of n >= 8 bytes, and the mixing of the eight samples)
+WALK_HD WALK_FORCEINLINE uint64_t msg_fingerprint_sample_pos(uint64_t n, uint32_t k) { return (n - 8) * k / 7; }
+WALK_HD WALK_FORCEINLINE uint64_t msg_fingerprint_mix(uint64_t n, const uint64_t (&w)[8]) {
     uint64_t h = (n + 1) * 0x9E3779B97F4A7C15ull;
-    auto at = [&](uint64_t pos) -> uint64_t { return pos < alen ? a[pos] : b[pos - alen]; };
-    if (n < 8) {
-        for (uint64_t j = 0; j < n; j++) h = (h ^ at(j)) * 0x100000001B3ull;
-        return h ^ (h >> 32);
-    }
-    for (uint64_t k = 0; k < 8; k++) {
-        const uint64_t p = (n - 8) * k / 7;
-        uint64_t w = 0;
-        for (uint64_t j = 0; j < 8; j++) w |= at(p + j) << (8 * j);
-        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+    for (int k = 0; k < 8; k++) {
+        h = (h ^ w[k]) * 0xD6E8FEB86659FD93ull;
         h ^= h >> 29;
     }
     return h ^ (h >> 32);
+}
+WALK_HD inline uint64_t msg_fingerprint(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen) {
+    const uint64_t n = (uint64_t)alen + blen;
+    auto at = [&](uint64_t pos) -> uint64_t { return pos < alen ? a[pos] : b[pos - alen]; };
+    if (n < 8) {
+        uint64_t h = (n + 1) * 0x9E3779B97F4A7C15ull;
+        for (uint64_t j = 0; j < n; j++) h = (h ^ at(j)) * 0x100000001B3ull;
+        return h ^ (h >> 32);
+    }
+    uint64_t w[8];
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint64_t p = msg_fingerprint_sample_pos(n, k);
+        if (p + 8 <= alen) {
+            w[k] = load_le64(a + p);                                       // a sample inside one span: ONE (unaligned) eight-byte load ...
+        } else if (p >= alen) {
+            w[k] = load_le64(b + (p - alen));
+        } else {                                                           // ... the one that straddles the two spans: byte by byte
+            w[k] = 0;
+            for (uint64_t j = 0; j < 8; j++) w[k] |= at(p + j) << (8 * j);
+        }
+    }
+    return msg_fingerprint_mix(n, w);
 }
 // messages shorter than this are not worth a lookup (one SHA-256 block costs less than the call); the C ABI answers "miss"
 constexpr uint32_t HASH_MEMO_MIN_LEN = 64;

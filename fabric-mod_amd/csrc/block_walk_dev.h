@@ -175,6 +175,7 @@ struct WalkArrays {
     uint8_t* memo_status = nullptr;            // by entry (255: a candidate that was not decided - it has no slot)
     uint8_t* memo_digests = nullptr;           // 32 bytes by entry
     uint32_t* memo_ent = nullptr;              // by tuple: its entry, ~0 = none
+    void* memo_tiles = nullptr;                // scratch of the entry scan: 24 bytes per tile of 2 048 tuples (walk_memo_tile_*_kernel)
     // ... and its DIGEST memo (bccsp.Hash of bytes this pass hashed): by entry the two spans of the signed message (prefix offset, length,
     // suffix offset, length - into the block / its tail), and a second slot table of the same size over walk::msg_fingerprint of the
     // message's bytes (entry index + 1).  Every candidate gets a slot, early; a lookup skips entries whose status says "not decided".
@@ -215,7 +216,8 @@ hipError_t launch_walk_idfix_probe(uint32_t n, const void* arena, const void* sp
 // the idemix creators among [0, n_creators), counted off: nym_slot[rank] = its row in the nym launch, gather[row] = rank for row < cap
 hipError_t launch_walk_nym_pack(const WalkArrays& a, uint32_t* gather, uint32_t cap, hipStream_t st);
 // the verdict memo of the pass: keys, entry indices and offsets as soon as the gates are through; digests, statuses and slots behind the status kernel
-hipError_t launch_walk_memo_early(const WalkArrays& a, hipStream_t st);
+hipError_t launch_walk_memo_early(const WalkArrays& a, hipStream_t st, hipEvent_t scanned = nullptr);   // scanned: recorded behind the scan, in front of the key bytes
+hipError_t launch_walk_memo_index(const WalkArrays& a, hipStream_t st);   // the digest memo's index (needs the scan; its own stream)
 hipError_t launch_walk_memo_late(const WalkArrays& a, hipStream_t st);
 hipError_t launch_walk_status_checks(const WalkArrays& a, uint32_t n_checks, hipStream_t st);   // tuple statuses + digest comparisons (one launch)
 // per-transaction flags and everything the host reads, written to host-mapped memory; the last workgroup raises h.flag

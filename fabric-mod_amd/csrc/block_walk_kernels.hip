@@ -931,69 +931,126 @@ __global__ void __launch_bounds__(256) walk_memo_len_kernel(WalkArrays a) {
                       t.sig.off <= a.arena_len && t.sig.len <= a.arena_len - t.sig.off;
     a.memo_ent[i] = cand ? 1u + (nym ? 32u : 0u) + 64u + 4u + t.sig.len + 4u : 0u;
 }
-// key lengths -> entry indices and offsets: ONE workgroup (the scan of walk_scan_kernel); says whether the keys fit the caller's room
-__global__ void __launch_bounds__(1024) walk_memo_scan_kernel(WalkArrays a) {
-    // (round 4: the wavefront-shuffle scan of walk_scan_kernel, and a thread's lengths loaded eight at a time - independent loads - instead
-    //  of one dependent load per tuple.  Measured: 150 us for 40 000 tuples either way - it runs beside the verify launches, its sixteen
-    //  wavefronts on a CU whose SIMDs those occupy; it is off the critical path, behind the memo's early half.)
-    __shared__ uint32_t wn[16];
-    __shared__ uint64_t wb[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, n = a.n_tuples;
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    uint32_t k = 0;
-    uint64_t b = 0;
-    for (uint32_t i = lo; i < hi; i += 8) {
-        uint32_t l[8];
+// key lengths -> entry indices and offsets, and whether the keys fit the caller's room.  Round 6: three small launches over tiles of
+// 2 048 tuples - tile sums, one workgroup over the tiles, assignment - instead of ONE workgroup over everything: that one took 145 us for
+// a 40 000-tuple block (profiles/r06_timeline_10000tx_memo.txt), sat between the gates and the keys' copy, and with the digest memo's
+// index behind it the memo's early half no longer fitted beside the verify launches (it ended 0.2 ms after them).
+constexpr uint32_t MEMO_TILE = 2048;                                       // 256 threads x 8 tuples
+struct MemoTile {
+    uint32_t cnt, bytes;          // candidates and key bytes of the tile (<= 2 048 x 1 165 bytes)
+    uint32_t cnt_before, pad;
+    uint64_t bytes_before;
+};
+static_assert(sizeof(MemoTile) == 24, "carved as raw bytes");
+// a thread's eight lengths, and their (count, bytes)
+__device__ __forceinline__ void memo_tile_load(const WalkArrays& a, uint32_t first, uint32_t (&l)[8], uint32_t& k, uint32_t& b) {
+    k = b = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) l[j] = i + j < hi ? a.memo_ent[i + j] : 0u;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            k += l[j] ? 1u : 0u;
-            b += l[j];
-        }
+    for (int j = 0; j < 8; j++) {
+        l[j] = first + j < a.n_tuples ? a.memo_ent[first + j] : 0u;
+        k += l[j] ? 1u : 0u;
+        b += l[j];
     }
-    uint32_t ik = k;                                                       // inclusive sums
-    uint64_t ib = b;
+}
+// exclusive scan of (k, b) over the 256 threads of a workgroup; tk / tb: the workgroup's totals
+__device__ __forceinline__ void memo_tile_scan(uint32_t& k, uint32_t& b, uint32_t& tk, uint32_t& tb) {
+    __shared__ uint32_t wk[4], wb[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t ik = k, ib = b;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t vk = __shfl_up(ik, o, 64), blo = __shfl_up((uint32_t)ib, o, 64), bhi = __shfl_up((uint32_t)(ib >> 32), o, 64);
-        if (lane >= (uint32_t)o) { ik += vk; ib += ((uint64_t)bhi << 32) | blo; }
+        const uint32_t vk = __shfl_up(ik, o, 64), vb = __shfl_up(ib, o, 64);
+        if (lane >= (uint32_t)o) { ik += vk; ib += vb; }
     }
-    if (lane == 63) { wn[wave] = ik; wb[wave] = ib; }
+    if (lane == 63) { wk[wave] = ik; wb[wave] = ib; }
     __syncthreads();
-    uint32_t total_n = 0;
-    uint64_t total_b = 0;
-    for (uint32_t w = 0; w < 16; w++) {
-        if (w < wave) { ik += wn[w]; ib += wb[w]; }
-        total_n += wn[w];
-        total_b += wb[w];
+    tk = tb = 0;
+    uint32_t bk = 0, bb = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        if (w < wave) { bk += wk[w]; bb += wb[w]; }
+        tk += wk[w];
+        tb += wb[w];
     }
-    const bool fits = total_b <= (uint64_t)a.memo_keys_cap;
-    uint32_t e = ik - k;
-    uint64_t off = ib - b;
-    for (uint32_t i = lo; i < hi; i += 8) {
-        uint32_t l[8];
+    k = bk + ik - k;                                                       // exclusive
+    b = bb + ib - b;
+}
+__global__ void __launch_bounds__(256) walk_memo_tile_sums_kernel(WalkArrays a, MemoTile* tiles) {
+    uint32_t l[8], k, b, tk, tb;
+    memo_tile_load(a, blockIdx.x * MEMO_TILE + threadIdx.x * 8u, l, k, b);
+    memo_tile_scan(k, b, tk, tb);
+    if (threadIdx.x == 0) {
+        tiles[blockIdx.x].cnt = tk;
+        tiles[blockIdx.x].bytes = tb;
+    }
+}
+// one workgroup over the tiles (1 024 at a time): what lies before each, the totals, and the verdict "fits"
+__global__ void __launch_bounds__(1024) walk_memo_tile_offsets_kernel(WalkArrays a, MemoTile* tiles, uint32_t n_tiles) {
+    __shared__ uint32_t wn[16];
+    __shared__ uint64_t wb[16];
+    __shared__ uint32_t carry_n;
+    __shared__ uint64_t carry_b;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) { carry_n = 0; carry_b = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t t = base + tid;
+        const uint32_t k = t < n_tiles ? tiles[t].cnt : 0u;
+        const uint64_t b = t < n_tiles ? tiles[t].bytes : 0u;
+        uint32_t ik = k;
+        uint64_t ib = b;
 #pragma unroll
-        for (int j = 0; j < 8; j++) l[j] = i + j < hi ? a.memo_ent[i + j] : 0u;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (i + j >= hi) break;
-            if (l[j] && fits) {
-                a.memo_key_off[e] = (uint32_t)off;
-                a.memo_ent[i + j] = e;
-                e++;
-                off += l[j];
-            } else {
-                a.memo_ent[i + j] = 0xFFFFFFFFu;
-            }
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t vk = __shfl_up(ik, o, 64), blo = __shfl_up((uint32_t)ib, o, 64), bhi = __shfl_up((uint32_t)(ib >> 32), o, 64);
+            if (lane >= (uint32_t)o) { ik += vk; ib += ((uint64_t)bhi << 32) | blo; }
         }
+        if (lane == 63) { wn[wave] = ik; wb[wave] = ib; }
+        __syncthreads();
+        uint32_t bk = carry_n, tn = 0;
+        uint64_t bb = carry_b, tbv = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wave) { bk += wn[w]; bb += wb[w]; }
+            tn += wn[w];
+            tbv += wb[w];
+        }
+        if (t < n_tiles) {
+            tiles[t].cnt_before = bk + ik - k;
+            tiles[t].bytes_before = bb + ib - b;
+        }
+        __syncthreads();
+        if (tid == 0) { carry_n += tn; carry_b += tbv; }
+        __syncthreads();
     }
-    if (tid == 1023) {
+    if (tid == 0) {
+        const uint32_t total_n = carry_n;
+        const uint64_t total_b = carry_b;
+        const bool fits = total_b <= (uint64_t)a.memo_keys_cap;
         a.memo_key_off[fits ? total_n : 0u] = fits ? (uint32_t)total_b : 0u;
         a.memo_totals->n = fits ? total_n : 0u;
         a.memo_totals->overflow = fits ? 0u : 1u;
         a.memo_totals->bytes = fits ? total_b : 0u;
+    }
+}
+// every tuple's entry index and every entry's key offset (or "no entry" for all of them when the keys do not fit)
+__global__ void __launch_bounds__(256) walk_memo_tile_assign_kernel(WalkArrays a, const MemoTile* tiles) {
+    uint32_t l[8], k, b, tk, tb;
+    const uint32_t first = blockIdx.x * MEMO_TILE + threadIdx.x * 8u;
+    memo_tile_load(a, first, l, k, b);
+    memo_tile_scan(k, b, tk, tb);
+    const bool fits = a.memo_totals->overflow == 0u;
+    uint32_t e = tiles[blockIdx.x].cnt_before + k;
+    uint64_t off = tiles[blockIdx.x].bytes_before + b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (first + j >= a.n_tuples) break;
+        if (l[j] && fits) {
+            a.memo_key_off[e] = (uint32_t)off;
+            a.memo_ent[first + j] = e;
+            e++;
+            off += l[j];
+        } else {
+            a.memo_ent[first + j] = 0xFFFFFFFFu;
+        }
     }
 }
 // one wavefront per candidate: its framed key up to the digest
@@ -1033,10 +1090,11 @@ __global__ void __launch_bounds__(256) walk_memo_write_kernel(WalkArrays a) {
     pos += t.sig.len;
     if (lane < 4) k[pos + lane] = lane == 0 ? 32 : 0;
 }
-// EARLY too: the DIGEST memo's index (bccsp_host.h BlockMemo; GPUCSP::HashLookup reads it) - one lane per candidate: the two spans of its
-// signed message by entry, and a slot in the second table found from walk::msg_fingerprint of the message's bytes as they lie in the
-// block (the lines the host runs over a bccsp.Hash caller's bytes).  Every candidate, decided or not: whether an entry's digest may be
-// handed out is its status byte's business (255 = not decided, written by the late half), checked by the lookup.
+// EARLY too, BESIDE the write kernel (its own stream): the DIGEST memo's index (bccsp_host.h BlockMemo; GPUCSP::HashLookup reads it) - one
+// lane per candidate: the two spans of its signed message by entry, and a slot in the second table found from walk::msg_fingerprint of
+// the message's bytes as they lie in the block (the lines the host runs over a bccsp.Hash caller's bytes; eight unaligned 8-byte loads).
+// Every candidate, decided or not: whether an entry's digest may be handed out is its status byte's business (255 = not decided,
+// written by the late half), checked by the lookup.
 __global__ void __launch_bounds__(256) walk_memo_index_kernel(WalkArrays a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_tuples) return;
@@ -1046,11 +1104,12 @@ __global__ void __launch_bounds__(256) walk_memo_index_kernel(WalkArrays a) {
     // (spans the walk emitted lie inside the arena; anything else gets spans no lookup can match and no slot)
     const bool inside = t.prefix.off <= a.arena_len && t.prefix.len <= a.arena_len - t.prefix.off && t.suffix.off <= a.arena_len &&
                         t.suffix.len <= a.arena_len - t.suffix.off && (uint64_t)t.prefix.len + t.suffix.len >= bccsp::walk::HASH_MEMO_MIN_LEN;
-    uint32_t* sp = a.memo_hspans + 4 * (size_t)e;
-    sp[0] = inside ? t.prefix.off : 0u;
-    sp[1] = inside ? t.prefix.len : 0u;
-    sp[2] = inside ? t.suffix.off : 0u;
-    sp[3] = inside ? t.suffix.len : 0u;
+    uint4 sp;
+    sp.x = inside ? t.prefix.off : 0u;
+    sp.y = inside ? t.prefix.len : 0u;
+    sp.z = inside ? t.suffix.off : 0u;
+    sp.w = inside ? t.suffix.len : 0u;
+    reinterpret_cast<uint4*>(a.memo_hspans)[e] = sp;
     if (!inside) return;
     const uint64_t h = bccsp::walk::msg_fingerprint(a.block + t.prefix.off, t.prefix.len, a.block + t.suffix.off, t.suffix.len);
     uint32_t at = (uint32_t)h & a.memo_mask;
@@ -1137,18 +1196,31 @@ hipError_t launch_walk_nym_pack(const WalkArrays& a, uint32_t* gather, uint32_t 
     hipLaunchKernelGGL(walk_nym_pack_kernel, dim3(1), dim3(1024), 0, st, a, gather, cap);
     return hipGetLastError();
 }
-hipError_t launch_walk_memo_early(const WalkArrays& a, hipStream_t st) {
-    if (a.n_tuples == 0 || !a.memo_ent) return hipSuccess;
+hipError_t launch_walk_memo_early(const WalkArrays& a, hipStream_t st, hipEvent_t scanned) {
+    if (a.n_tuples == 0 || !a.memo_ent || !a.memo_tiles) return hipSuccess;
     hipLaunchKernelGGL(walk_memo_len_kernel, dim3((a.n_tuples + 255) / 256), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(walk_memo_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    const uint32_t n_tiles = (a.n_tuples + MEMO_TILE - 1) / MEMO_TILE;
+    MemoTile* tiles = (MemoTile*)a.memo_tiles;
+    hipLaunchKernelGGL(walk_memo_tile_sums_kernel, dim3(n_tiles), dim3(256), 0, st, a, tiles);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(walk_memo_write_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(walk_memo_tile_offsets_kernel, dim3(1), dim3(1024), 0, st, a, tiles, n_tiles);
     e = hipGetLastError();
-    if (e != hipSuccess || !a.memo_hspans || !a.memo_hslots) return e;
-    hipLaunchKernelGGL(walk_memo_index_kernel, dim3((a.n_tuples + 255) / 256), dim3(256), 0, st, a);   // (memo_hslots zeroed by the caller)
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(walk_memo_tile_assign_kernel, dim3(n_tiles), dim3(256), 0, st, a, (const MemoTile*)tiles);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (scanned && (e = hipEventRecord(scanned, st)) != hipSuccess) return e;     // entry indices and offsets are assigned: the index kernel may start
+    hipLaunchKernelGGL(walk_memo_write_kernel, dim3((a.n_tuples + 3) / 4), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+// the digest memo's index; needs what launch_walk_memo_early's scan assigned (the caller orders it behind that, on a stream of its own
+// beside the write kernel; memo_hslots zeroed by the caller)
+hipError_t launch_walk_memo_index(const WalkArrays& a, hipStream_t st) {
+    if (a.n_tuples == 0 || !a.memo_ent || !a.memo_hspans || !a.memo_hslots) return hipSuccess;
+    hipLaunchKernelGGL(walk_memo_index_kernel, dim3((a.n_tuples + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_walk_memo_late(const WalkArrays& a, hipStream_t st) {
@@ -1181,7 +1253,7 @@ hipError_t launch_walk_finish(const WalkArrays& a, const WalkHostOut& h, hipStre
 int warm_kernel_functions_walk() {
     int ok = 0;
     hipFuncAttributes a;
-    const void* fns[] = {(const void*)walk_status_finish_small_kernel, (const void*)walk_status_checks_kernel, (const void*)walk_scan_kernel, (const void*)walk_nym_pack_kernel, (const void*)walk_memo_write_kernel, (const void*)walk_memo_index_kernel, (const void*)walk_memo_scan_kernel, (const void*)walk_memo_len_kernel, (const void*)walk_memo_late_kernel, (const void*)walk_idfix_probe_kernel, (const void*)walk_gate_probe_kernel, (const void*)walk_gate_kernel, (const void*)walk_finish_kernel, (const void*)walk_emit_kernel, (const void*)walk_creator_digest_kernel, (const void*)walk_count_staged_kernel, (const void*)walk_count_kernel};
+    const void* fns[] = {(const void*)walk_status_finish_small_kernel, (const void*)walk_status_checks_kernel, (const void*)walk_scan_kernel, (const void*)walk_nym_pack_kernel, (const void*)walk_memo_write_kernel, (const void*)walk_memo_index_kernel, (const void*)walk_memo_tile_sums_kernel, (const void*)walk_memo_tile_offsets_kernel, (const void*)walk_memo_tile_assign_kernel, (const void*)walk_memo_len_kernel, (const void*)walk_memo_late_kernel, (const void*)walk_idfix_probe_kernel, (const void*)walk_gate_probe_kernel, (const void*)walk_gate_kernel, (const void*)walk_finish_kernel, (const void*)walk_emit_kernel, (const void*)walk_creator_digest_kernel, (const void*)walk_count_staged_kernel, (const void*)walk_count_kernel};
     for (const void* f : fns) ok += hipFuncGetAttributes(&a, f) == hipSuccess ? 1 : 0;
     return ok;
 }

@@ -2125,6 +2125,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     // ... and the digest memo's index beside it (message spans by entry + a second slot table), if the caller gave room for that too
     const bool hmemo = memo && out.memo_hspans && out.memo_hslots;
     const size_t o_mhsp = carve(hmemo ? (size_t)nt * 16 : 0), o_mhsl = carve(hmemo ? (size_t)out.memo_slot_cap * 4 : 0);
+    const size_t o_mtiles = carve(memo ? ((size_t)nt / 2048 + 2) * 24 : 0);                     // the entry scan's tiles (walk_memo_tile_*_kernel)
     if ((rc = ctx->walk_tup.ensure(o))) return rc;
     uint8_t* dt = (uint8_t*)ctx->walk_tup.d;
     a.tuples = (bccsp::BlockTuple*)(dt + o_tup);
@@ -2184,6 +2185,7 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
         a.memo_status = dt + o_mst;
         a.memo_totals = (WalkMemoTotals*)(dt + o_mtot);
         a.memo_digests = dt + o_mdig;
+        a.memo_tiles = dt + o_mtiles;
         if (hmemo) {
             a.memo_hspans = (uint32_t*)(dt + o_mhsp);
             a.memo_hslots = (uint32_t*)(dt + o_mhsl);
@@ -2408,12 +2410,18 @@ int walk_block_pass(fabgpu_ctx* ctx, WalkRequest& rq) {
     if (err == hipSuccess && memo_early_pending) {
         if (hmemo) err = hipMemsetAsync(dt + o_mhsl, 0, (size_t)out.memo_slot_cap * 4, s4);   // (ahead of the wait for the gates)
         if (err == hipSuccess) err = hipStreamWaitEvent(s4, ctx->ev_w[7], 0);
-        if (err == hipSuccess) err = launch_walk_memo_early(a, s4);
+        // len, the tiled scan (entry indices, key offsets), then the key bytes on stream4 and - beside them, on stream3 - the digest
+        // memo's index: both only need the scan (round 6: one after the other they were 85 us between the gates and the keys' copy)
+        if (err == hipSuccess) err = launch_walk_memo_early(a, s4, hmemo ? ctx->ev_w[9] : nullptr);
+        if (err == hipSuccess && hmemo) err = hipStreamWaitEvent(s3, ctx->ev_w[9], 0);          // "the scan is through"
+        if (err == hipSuccess && hmemo) err = launch_walk_memo_index(a, s3);
+        if (err == hipSuccess && hmemo) err = hipEventRecord(ctx->ev_w[11], s3);
         mark("memo early launched");
         if (err == hipSuccess) err = hipMemcpyAsync(out.memo_key_off, dt + o_mkoff, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, s4);
         mark("memo key_off copy queued");
         if (err == hipSuccess) err = hipMemcpyAsync(out.memo_keys, dt + o_mkeys, out.memo_keys_cap, hipMemcpyDeviceToHost, s4);
         mark("memo keys copy queued");
+        if (err == hipSuccess && hmemo) err = hipStreamWaitEvent(s4, ctx->ev_w[11], 0);
         if (err == hipSuccess && hmemo) err = hipMemcpyAsync(out.memo_hspans, dt + o_mhsp, (size_t)nt * 16, hipMemcpyDeviceToHost, s4);
         if (err == hipSuccess && hmemo) err = hipMemcpyAsync(out.memo_hslots, dt + o_mhsl, (size_t)out.memo_slot_cap * 4, hipMemcpyDeviceToHost, s4);
         if (err == hipSuccess) err = hipEventRecord(ctx->ev_w[8], s4);
