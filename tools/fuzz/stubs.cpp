@@ -31,4 +31,10 @@ int walk_gate_probe(fabgpu_ctx*, uint32_t, const uint8_t*, size_t, const uint32_
 size_t key_table_words() { return 1; }
 bool key_table_build(const uint8_t*, const uint8_t*, int32_t*) { return false; }
 int key_register_many_prebuilt(fabgpu_ctx* const*, int, const uint8_t*, const uint8_t*, const int32_t*, uint32_t*) { return -1; }
+int key_register_batch(fabgpu_ctx*, int, const uint8_t*, uint32_t*) { return -1; }
+int arena_stage_keep(fabgpu_ctx*, const void*, size_t, uint64_t*, HostCopy*) { return -1; }
+void host_copy_release(HostCopy* c) { if (c) *c = HostCopy(); }
+void host_copy_limit(fabgpu_ctx*, uint32_t) {}
+void host_copy_preallocate(fabgpu_ctx*, size_t, uint32_t) {}
+void host_copy_stats(fabgpu_ctx*, uint64_t* a, uint64_t* b, uint64_t* c) { if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; }
 }
