@@ -153,7 +153,7 @@ __device__ __forceinline__ void pairbn_final_add(pairbn_pt& Rr, bool& r_inf, con
     D = sb;
     pairbn_pt Rp = S;
     QB_ADD(Rp, C, D);
-    bool hz = fe_is_zero(tH);               // h on both lanes
+    bool hz = fe_is_zero(tH);               // E: h, O: -h
     bool rz_own = fe_is_zero(tRR);          // rr lives on E
     int32_t rz_other = pair_swap_i32(rz_own ? 1 : 0);
     bool rz = odd ? (rz_other != 0) : rz_own;

@@ -101,6 +101,17 @@ class Program:
         for i in range(9):
             self.ins.append(("swp_mov", d[i], a[i]))
 
+    def bce(self, d, a):                      # d = the EVEN lane's a, on both lanes of the pair (quad_perm:[0,0,2,2])
+        for i in range(9):
+            self.ins.append(("bc_mov", d[i], a[i], 0))
+
+    def bco(self, d, a):                      # d = the ODD lane's a, on both lanes (quad_perm:[1,1,3,3])
+        for i in range(9):
+            self.ins.append(("bc_mov", d[i], a[i], 1))
+
+    def lane_const(self, d, odd, even):       # one register: lane is odd ? odd : even  (inline constants)
+        self.ins.append(("sel", d, odd, even))
+
     def swp_sub(self, d, a, b):               # d = partner's a - own b
         for i in range(9):
             self.ins.append(("swp_sub", d[i], a[i], b[i]))
@@ -121,12 +132,16 @@ class Program:
         self.ins.append(("add", d[8], a[8], c[7]))
 
     # ---- Montgomery product / square (fe29.h FE29_REDUCE_COLUMN) ---------------------------------------------------
-    def _columns(self, r, products):
+    def _columns(self, r, products, addend=None, coef=None):
+        """addend / coef: r = product + coef * addend (Montgomery domain: the addend's digit j joins column 9 + j, its top digit the
+        last carry) - coef is a register, possibly lane-specific; the output digits are balanced whatever was added."""
         first = True
         for k in range(17):
             for (x, y) in products(k):
                 self.ins.append(("mad0" if first else "mad", "acc", x, y))
                 first = False
+            if addend is not None and k >= 9:
+                self.ins.append(("mad", "acc", addend[k - 9], coef))
             if self.field is None:
                 for (dd, c) in RED:
                     if k >= dd and k - dd <= 8:
@@ -148,15 +163,19 @@ class Program:
                 self.ins.append(("round28", "acc"))               # acc += 2^28
                 self.ins.append(("ashr64", "acc", 29))
                 if k == 16:
+                    if addend is not None:
+                        self.ins.append(("mad", "acc", addend[8], coef))
                     self.ins.append(("movacc", r[8], "acc"))
 
-    def mul(self, r, a, b):
+    def mul(self, r, a, b, addend=None, coef=None):
         assert r[0] != a[0] and r[0] != b[0], "mul destination must not alias a source"
-        self._columns(r, lambda k: [(a[i], b[k - i]) for i in range(9) if 0 <= k - i < 9])
+        assert addend is None or addend[0] not in (r[0],)
+        self._columns(r, lambda k: [(a[i], b[k - i]) for i in range(9) if 0 <= k - i < 9], addend, coef)
 
-    def sqr(self, r, a, t):
+    def sqr(self, r, a, t, addend=None, coef=None):
         """t: scratch fe for the doubled limbs (8 used)."""
         assert r[0] != a[0] and t[0] != a[0] and t[0] != r[0]
+        assert addend is None or addend[0] not in (r[0], t[0])
         for i in range(8):
             self.ins.append(("shl", t[i], a[i], 1))
 
@@ -169,7 +188,7 @@ class Program:
                 if j == i:
                     out.append((a[i], a[i]))
             return out
-        self._columns(r, prods)
+        self._columns(r, prods, addend, coef)
 
     # ---- interpreter -------------------------------------------------------------------------------------------------
     def run(self, regs_even, regs_odd):
@@ -185,6 +204,11 @@ class Program:
             return L[lane][x]
         for ins in self.ins:
             op = ins[0]
+            if op == "bc_mov":
+                v = val(ins[3], ins[2])
+                for lane in (0, 1):
+                    L[lane][ins[1]] = v
+                continue
             if op in ("swp_mov", "swp_sub", "swp_add"):
                 new = []
                 for lane in (0, 1):
@@ -268,6 +292,7 @@ class Program:
                 return str(x)
             return "%%%d" % num[x]
         DPP = " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        DPP_BC = (" quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf", " quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
         lines = []
         last_write = {}
         nops = 0
@@ -303,6 +328,8 @@ class Program:
                 put("v_mov_b32_e64 %s, %s" % (o(ins[1]), o(ins[2])), ins[1])
             elif op == "swp_mov":
                 put("v_mov_b32_dpp %s, %s%s" % (o(ins[1]), o(ins[2]), DPP), ins[1], dpp_src=ins[2])
+            elif op == "bc_mov":
+                put("v_mov_b32_dpp %s, %s%s" % (o(ins[1]), o(ins[2]), DPP_BC[ins[3]]), ins[1], dpp_src=ins[2])
             elif op == "swp_sub":
                 put("v_sub_u32_dpp %s, %s, %s%s" % (o(ins[1]), o(ins[2]), o(ins[3]), DPP), ins[1], dpp_src=ins[2])
             elif op == "swp_add":

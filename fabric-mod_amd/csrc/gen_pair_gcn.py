@@ -21,7 +21,10 @@ from gcn_dsl import GenericField, Program
 
 
 def build_pair_dbl():
-    """(A, B) <- 2 * (A, B).   in: L(X) <= 2, L(Y) <= 3, L(Z) <= 3;  out: L(X) = 1, L(Y) = 3, L(Z) = 1."""
+    """(A, B) <- 2 * (A, B).   in: L(X) <= 2, L(Y) <= 3, L(Z) <= 2 (2Y x Z: 6 x 2);  out: L(X) = 1, L(Y) = 1, L(Z) = 1.
+    Round 6: X3 = alpha^2 - 2 beta4 and Y3 = yy - 2 gg leave their PRODUCTS already subtracted and with balanced digits (nine more
+    MACs each on the high columns, Program._columns' addend) instead of a subtraction, a carry pass and a select after them: 746
+    instructions, were 787."""
     p = Program("PAIR29_DBL")
     A = p.fe("A", "io")
     B = p.fe("B", "io")
@@ -44,27 +47,26 @@ def build_pair_dbl():
     p.shladd(T0, U2, 1, U2)          #                           O: alpha = 3m
     p.shl(T1, U1, 1)                 # E: 2 gamma
     p.sel(W3, T0, T1)
-    p.sqr(U3, W3, TD)                # E: gg = 4 gamma^2         O: a2 = alpha^2
-    p.shl(T0, U2, 1)                 # E: 2 beta4
-    p.swp_sub(T1, U3, T0)            # E: alpha^2 - 8 beta   (L3)
-    p.wnorm(A, T1, TD)               # E: X3
+    p.swp(T0, U2)                    #                           O: beta4
+    p.lane_const(TD[8], -2, 0)       # (the square's scratch uses TD[0..7])
+    p.sqr(U3, W3, TD, T0, TD[8])     # E: gg = 4 gamma^2         O: X3 = alpha^2 - 2 beta4
+    p.swp(A, U3)                     # E: X3                     (O: gg - its A is don't-care)
     p.sub(T0, U2, A)                 # E: beta4 - X3         (L2)
     p.swp(T1, W3)                    # E: alpha
     p.swp(P1, B)                     #                           O: Y
     p.shl(P1, P1, 1)                 #                           O: 2Y
     p.sel(P1, P1, T1)
     p.sel(P2, B, T0)                 #                           O: Z
-    p.mul(U1, P1, P2)                # E: yy = alpha (4 beta - X3)   O: Z3 = 2 Y Z
-    p.shl(T0, U3, 1)                 # E: 2 gg
-    p.sub(T0, U1, T0)                # E: Y3 = yy - 8 gamma^2 (L3)
-    p.sel(B, U1, T0)
+    p.lane_const(TD[0], 0, -2)
+    p.mul(B, P1, P2, U3, TD[0])      # E: Y3 = alpha (beta4 - X3) - 2 gg      O: Z3 = 2 Y Z
     return p
 
 
 def build_pair_add(name="PAIR29_ADD", field=None):
     """(A, B) <- (A, B) + P2 with P2 handed over CROSSED:  E: C = Z2,  O: C = X2, D = Y2.
-    in: L(X1) <= 2, L(Y1) <= 3, L(Z1) = 1, L(X2) = 1, L(Y2) <= 3, L(Z2) = 1;  out: L(X) = 1, L(Y) = 2, L(Z) = 1.
-    H (both lanes: h = u2 - u1) and RR (E: s2 - s1) are left for the caller's P == +-Q test."""
+    in: L(X1) <= 2, L(Y1) <= 3, L(Z1) = 1, L(X2) = 1, L(Y2) <= 3, L(Z2) = 1;  out: L(X) = 1, L(Y) = 1, L(Z) = 1
+    (round 6: Y3 leaves its last product already subtracted, Program._columns' addend).
+    H (E: h = u2 - u1, O: -h) and RR (E: s2 - s1) are left for the caller's P == +-Q test (a test for zero)."""
     p = Program(name, field)
     A = p.fe("A", "io")
     B = p.fe("B", "io")
@@ -90,40 +92,35 @@ def build_pair_add(name="PAIR29_ADD", field=None):
     p.mul(U3, W, U1)                 # E: Z2^3                   O: Z1^3
     p.sel(P1, D, B)                  # E: Y1                     O: Y2
     p.mul(U4, P1, U3)                # E: s1                     O: s2
-    p.swp_sub(H, U2, U2)             # E: h = u2 - u1            O: -h
+    p.swp_sub(H, U2, U2)             # E: h = u2 - u1            O: -h     (round 6: O keeps -h; what it costs is a sign, see the last step)
     p.swp_sub(RR, U4, U4)            # E: rr = s2 - s1           O: -rr
-    p.neg(T0, H)
-    p.sel(H, T0, H)                  # h on both lanes
     p.sel(P1, RR, H)
     U5 = W                           # W is dead
     p.sqr(U5, P1, TD)                # E: hh                     O: r2 = rr^2
-    p.swp(T0, U5)                    #                           O: hh
-    p.sel(P1, H, U2)                 # E: u1                     O: h
-    p.sel(P2, T0, U5)                # hh on both lanes
-    p.mul(U6, P1, P2)                # E: v = u1 hh              O: hhh
+    p.sel(P1, H, U2)                 # E: u1                     O: -h
+    p.bce(P2, U5)                    # hh on both lanes
+    p.mul(U6, P1, P2)                # E: v = u1 hh              O: -hhh
     p.shl(T0, U6, 1)                 # E: 2v
-    p.swp_add(T0, U6, T0)            # E: hhh + 2v
-    p.swp_sub(T1, U5, T0)            # E: r2 - hhh - 2v      (L4)
+    p.swp_sub(T0, U6, T0)            # E: -hhh - 2v
+    p.swp_add(T1, U5, T0)            # E: r2 - hhh - 2v      (L4)
     p.wnorm(A, T1, TD)               # E: X3
-    p.sub(T0, U6, A)                 # E: v - X3             (L2)
+    p.sub(T0, A, U6)                 # E: X3 - v             (L2)
     p.swp(T1, C)                     #                           O: Z2
-    p.sel(P1, B, RR)                 # E: rr                     O: Z1
-    p.sel(P2, T1, T0)
+    p.swp(P2, U6)                    # E: -hhh
+    p.sel(P1, B, U4)                 # E: s1                     O: Z1
+    p.sel(P2, T1, P2)
     U7 = U1                          # U1 is dead
-    p.mul(U7, P1, P2)                # E: y1 = rr (v - X3)       O: zz = Z1 Z2
-    p.swp(T0, U6)                    # E: hhh
-    p.sel(P1, U7, U4)                # E: s1                     O: zz
-    p.sel(P2, H, T0)                 # E: hhh                    O: h
-    U8 = U3                          # U3 is dead
-    p.mul(U8, P1, P2)                # E: y2 = s1 hhh            O: Z3 = zz h
-    p.sub(T0, U7, U8)                # E: Y3 = y1 - y2       (L2)
-    p.sel(B, U8, T0)
+    p.mul(U7, P1, P2)                # E: -y2 = s1 (-hhh)        O: zz = Z1 Z2
+    p.sel(P1, U7, RR)                # E: rr                     O: zz
+    p.sel(P2, H, T0)                 # E: X3 - v                 O: -h
+    p.lane_const(TD[0], 0, -1)
+    p.mul(B, P1, P2, U7, TD[0])      # E: -Y3 = rr (X3 - v) + y2    O: -Z3 = zz (-h)        (X3, -Y3, -Z3) is the same point as (X3, Y3, Z3)
     return p
 
 
 def build_pair_madd(name="PAIR29_MADD", field=None):
     """(A, B) <- (A, B) + (x2, y2) affine, handed over as  E: C = x2,  O: D = y2.
-    in: L(X1) = 1, L(Y1) <= 3, L(Z1) = 1, x2 / y2 normalised;  out: L(X) = 1, L(Y) = 2, L(Z) = 1."""
+    in: L(X1) = 1, L(Y1) <= 2, L(Z1) = 1, x2 / y2 normalised;  out: L(X) = 1, L(Y) = 2, L(Z) = 1."""
     p = Program(name, field)
     A = p.fe("A", "io")
     B = p.fe("B", "io")
@@ -141,16 +138,14 @@ def build_pair_madd(name="PAIR29_MADD", field=None):
     C = p.fe("C", "in")
     D = p.fe("D", "in")
     p.sqr(U1, B, TD)                 #                           O: z1z1
-    p.swp(T0, U1)                    # E: z1z1
     p.sel(P1, B, C)                  # E: x2                     O: Z1
-    p.sel(P2, U1, T0)                # z1z1 on both lanes
+    p.bco(P2, U1)                    # z1z1 on both lanes
     p.mul(U2, P1, P2)                # E: u2 = x2 z1z1           O: Z1^3
     p.sub(H, U2, A)                  # E: h = u2 - X1        (L2)
     p.sel(P1, D, H)                  # E: h                      O: y2
     p.sel(P2, U2, H)                 # E: h                      O: Z1^3
     p.mul(U3, P1, P2)                # E: hh                     O: s2
-    p.swp_sub(T0, B, U3)             #                           O: Y1 - s2 = -rr   (L4)
-    p.wnorm(RR, T0, TD)              #                           O: -rr
+    p.swp_sub(RR, B, U3)             #                           O: Y1 - s2 = -rr   (L3: round 6, every producer of a state leaves L(Y) <= 2 - no carry pass)
     p.sel(P1, RR, U3)                # E: hh                     O: -rr
     p.sel(P2, RR, H)                 # E: h                      O: -rr
     p.mul(U4, P1, P2)                # E: hhh                    O: r2
@@ -225,7 +220,7 @@ def build_bn_pair_dbl():
     """(A, B) <- 2 * (A, B) on a curve with a = 0 (FP256BN's G1), two lanes per point, formulas of bn_nym29.h::pt_dbl29:
         A2 = X^2, Bq = Y^2, c4 = (2 Bq)^2, D = 4 X Bq, E = 3 A2, F = E^2, X3 = F - 2 D, Y3 = E (D - X3) - 2 c4, Z3 = 2 Y Z.
     Seven field operations in four paired steps (the last one has an idle odd slot).
-    in: L(X) = 1, L(Y) <= 3, L(Z) <= 2;  out: L(X) = 1, L(Y) = 3, L(Z) = 2.   E holds A = X, B = Y; O holds B = Z."""
+    in: L(X) = 1, L(Y) <= 3, L(Z) <= 2;  out: L(X) = 1, L(Y) = 1, L(Z) = 2.   E holds A = X, B = Y; O holds B = Z."""
     p = Program("PAIRBN_DBL", bn_field())
     A = p.fe("A", "io")
     B = p.fe("B", "io")
@@ -249,17 +244,16 @@ def build_bn_pair_dbl():
     p.shl(T0, U1, 1)                 # E: 2 Bq  (L2)
     p.shladd(T1, U1, 1, U1)          #                           O: E3 = 3 A2  (L3)
     p.sel(P1, T1, T0)                # E: 2 Bq                   O: E3
-    p.sqr(U3, P1, TD)                # E: c4 = 4 Bq^2 [2x2]      O: F = E3^2   [3x3]
-    p.shl(T0, U2, 1)                 # E: 2D    (L2)
-    p.swp_sub(T1, U3, T0)            # E: F - 2D    (L3)
-    p.wnorm(A, T1, TD)               # E: X3
+    p.swp(T0, U2)                    #                           O: D
+    p.lane_const(TD[8], -2, 0)
+    p.sqr(U3, P1, TD, T0, TD[8])     # E: c4 = 4 Bq^2 [2x2]      O: X3 = E3^2 - 2 D   [3x3]   (round 6: subtracted inside the square)
+    p.swp(A, U3)                     # E: X3
     p.sub(T0, U2, A)                 # E: D - X3    (L2)
     p.swp(T1, P1)                    # E: E3 (O's P1)
-    p.mul(U4, T1, T0)                # E: yy = E3 (D - X3) [3x2] O: (idle slot: product of leftovers)
-    p.shl(T0, U3, 1)                 # E: 2 c4  (L2)
-    p.sub(T0, U4, T0)                # E: Y3 = yy - 2 c4  (L3)
+    p.lane_const(TD[0], 0, -2)
+    p.mul(U4, T1, T0, U3, TD[0])     # E: Y3 = E3 (D - X3) - 2 c4  [3x2]      O: (idle slot: product of leftovers)
     p.shl(T1, U2, 1)                 #                           O: Z3 = 2 yz  (L2)
-    p.sel(B, T1, T0)
+    p.sel(B, T1, U4)
     return p
 
 

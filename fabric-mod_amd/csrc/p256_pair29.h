@@ -299,7 +299,7 @@ __device__ __forceinline__ void pair_final_add29(pair_pt& Rr, bool& r_inf, const
     D = sb;
     pair_pt Rp = S;
     PAIR_ADD(Rp, C, D);
-    bool hz = fe_is_zero(tH);               // h on both lanes
+    bool hz = fe_is_zero(tH);               // E: h, O: -h
     bool rz_own = fe_is_zero(tRR);          // rr lives on E
     int32_t rz_other = pair_swap_i32(rz_own ? 1 : 0);
     bool rz = odd ? (rz_other != 0) : rz_own;

@@ -1,7 +1,7 @@
 """CPU execution of the two-lanes-per-signature GCN programs (fabric-mod_amd/csrc/gen_pair_gcn.py) in the reference
 interpreter of gcn_dsl.py: the exact instruction lists the pair kernel runs, with 32/64-bit wrap-around semantics and an
 explicit (even, odd) lane pair, checked against big-integer point arithmetic of the oracle.  Chained so that the lazy
-limb ranges the kernel produces (L(Y) = 3 after a doubling, L(Y) = 2 after an addition) are what the next program eats."""
+limb ranges the kernel produces (L(Y) = 1 after a doubling or an addition, 2 after a mixed addition) are what the next program eats."""
 import os
 import random
 import sys
@@ -163,8 +163,8 @@ def test_pair_scalar_multiplication_chain(progs):
                     put(ce, "C", to_fe(Z2)); put(ce, "D", [0] * 9)
                     put(co, "C", to_fe(X2)); put(co, "D", to_fe(Y2))
                     st.run(progs["add"], ce, co)
-                    # H on both lanes and RR on E are the caller's exceptional-case probes: non-zero here
-                    assert val(st.e, "H") != 0 and val(st.o, "H") == val(st.e, "H") and val(st.e, "RR") != 0
+                    # H (E: h, O: -h) and RR on E are the caller's exceptional-case probes: non-zero here
+                    assert val(st.e, "H") != 0 and (val(st.o, "H") + val(st.e, "H")) % P == 0 and val(st.e, "RR") != 0
                 else:
                     ce, co = {}, {}
                     put(ce, "C", to_fe(base[0])); put(ce, "D", [0] * 9)
@@ -238,6 +238,60 @@ def test_bn_pair_programs_scalar_multiplication_chain():
                     st.run(progs["madd"], ce, co)
                 acc = io.g1_add(acc, base)
                 assert st.point() == acc
+
+
+def test_pair_programs_at_the_edge_of_their_limb_contracts(progs):
+    """Every input digit at +-L 2^28, the extreme its docstring allows (signs: all plus, all minus, alternating, random): the 64-bit column
+    sums must not wrap - the interpreter's arithmetic is exact 64-bit, so a wrap shows as a wrong value against the formulas in big
+    integers (evaluated on the VALUES the digits represent: such inputs are not curve points, the formulas do not care)."""
+    rng = random.Random(80)
+
+    def edge(L, pattern):
+        m = L << 28
+        sign = {"plus": lambda i: 1, "minus": lambda i: -1, "alt": lambda i: 1 if i & 1 else -1, "rnd": lambda i: rng.choice((1, -1))}[pattern]
+        # (the top digit carries the value's magnitude, not a digit range: L times p's top digit, 2^24)
+        return [sign(i) * (m - (0 if L == 1 and sign(i) < 0 else 1)) for i in range(8)] + [sign(8) * (L << 24)]
+
+    def v(d):
+        return sum(x << (29 * i) for i, x in enumerate(d)) * RI % P
+    for pattern in ("plus", "minus", "alt", "rnd", "rnd", "rnd"):
+        # doubling: L(X) <= 2, L(Y) <= 3, L(Z) <= 2
+        X, Y, Z = edge(2, pattern), edge(3, pattern), edge(2, pattern)
+        e, o = {}, {}
+        put(e, "A", X); put(e, "B", Y); put(o, "A", edge(1, "rnd")); put(o, "B", Z)
+        re, ro = progs["dbl"].run(e, o)
+        x, y, z = v(X), v(Y), v(Z)
+        g, d = y * y % P, z * z % P
+        b4, al = 4 * x * g % P, 3 * (x - d) * (x + d) % P
+        x3 = (al * al - 2 * b4) % P
+        assert val(re, "A") == x3 and val(re, "B") == (al * (b4 - x3) - 8 * g * g) % P and val(ro, "B") == 2 * y * z % P
+        assert all(abs(re["%s.%d" % (n, i)]) <= 1 << 28 for n in "AB" for i in range(8)) and all(abs(ro["B.%d" % i]) <= 1 << 28 for i in range(8))
+        # addition: L(X1) <= 2, L(Y1) <= 3, L(Z1) = 1, L(X2) = 1, L(Y2) <= 3, L(Z2) = 1
+        X1, Y1, Z1, X2, Y2, Z2 = edge(2, pattern), edge(3, pattern), edge(1, pattern), edge(1, "rnd"), edge(3, pattern), edge(1, "rnd")
+        e, o = {}, {}
+        put(e, "A", X1); put(e, "B", Y1); put(e, "C", Z2); put(e, "D", [0] * 9)
+        put(o, "A", edge(1, "rnd")); put(o, "B", Z1); put(o, "C", X2); put(o, "D", Y2)
+        re, ro = progs["add"].run(e, o)
+        x1, y1, z1, x2, y2, z2 = v(X1), v(Y1), v(Z1), v(X2), v(Y2), v(Z2)
+        u1, u2 = x1 * z2 * z2 % P, x2 * z1 * z1 % P
+        s1, s2 = y1 * z2 ** 3 % P, y2 * z1 ** 3 % P
+        h, rr = (u2 - u1) % P, (s2 - s1) % P
+        x3 = (rr * rr - h ** 3 - 2 * u1 * h * h) % P
+        y3 = (rr * (u1 * h * h - x3) - s1 * h ** 3) % P
+        z3 = z1 * z2 * h % P
+        got = (val(re, "A"), val(re, "B"), val(ro, "B"))
+        assert got in ((x3, y3, z3), (x3, (-y3) % P, (-z3) % P)), pattern           # (X, -Y, -Z) is the same point
+        # mixed addition: L(X1) = 1, L(Y1) <= 2, L(Z1) = 1, x2 / y2 normalised
+        X1, Y1, Z1, X2, Y2 = edge(1, pattern), edge(2, pattern), edge(1, pattern), edge(1, "rnd"), edge(1, pattern)
+        e, o = {}, {}
+        put(e, "A", X1); put(e, "B", Y1); put(e, "C", X2); put(e, "D", [0] * 9)
+        put(o, "A", edge(1, "rnd")); put(o, "B", Z1); put(o, "C", [0] * 9); put(o, "D", Y2)
+        re, ro = progs["madd"].run(e, o)
+        x1, y1, z1, x2, y2 = v(X1), v(Y1), v(Z1), v(X2), v(Y2)
+        u2, s2 = x2 * z1 * z1 % P, y2 * z1 ** 3 % P
+        h, rr = (u2 - x1) % P, (s2 - y1) % P
+        x3 = (rr * rr - h ** 3 - 2 * x1 * h * h) % P
+        assert (val(re, "A"), val(re, "B"), val(ro, "B")) == (x3, (rr * (x1 * h * h - x3) - y1 * h ** 3) % P, z1 * h % P), pattern
 
 
 def test_pair_add_reports_the_exceptional_cases(progs):
