@@ -23,8 +23,8 @@ from gcn_dsl import GenericField, Program
 def build_pair_dbl():
     """(A, B) <- 2 * (A, B).   in: L(X) <= 2, L(Y) <= 3, L(Z) <= 2 (2Y x Z: 6 x 2);  out: L(X) = 1, L(Y) = 1, L(Z) = 1.
     Round 6: X3 = alpha^2 - 2 beta4 and Y3 = yy - 2 gg leave their PRODUCTS already subtracted and with balanced digits (nine more
-    MACs each on the high columns, Program._columns' addend) instead of a subtraction, a carry pass and a select after them: 746
-    instructions, were 787."""
+    MACs each on the high columns, Program._columns' addend) instead of a subtraction, a carry pass and a select after them, and the
+    factors 2 and 4 of gamma ride in the addend's coefficient: 739 instructions, were 787."""
     p = Program("PAIR29_DBL")
     A = p.fe("A", "io")
     B = p.fe("B", "io")
@@ -40,25 +40,24 @@ def build_pair_dbl():
     p.sqr(U1, B, TD)                 # E: gamma = Y^2            O: delta = Z^2
     p.swp_sub(P1, A, U1)             #                           O: X - delta
     p.swp_add(P2, A, U1)             #                           O: X + delta
-    p.shl(T0, A, 2)                  # E: 4X
-    p.sel(P1, P1, T0)
-    p.sel(P2, P2, U1)                # E: gamma
-    p.mul(U2, P1, P2)                # E: beta4 = 4 X gamma      O: m = (X - delta)(X + delta)
+    p.shl(T0, U1, 2)                 # E: 4 gamma  (L4)
+    p.sel(P1, P1, A)                 # E: X
+    p.sel(P2, P2, T0)
+    p.mul(U2, P1, P2)                # E: beta4 = X (4 gamma)    O: m = (X - delta)(X + delta)
     p.shladd(T0, U2, 1, U2)          #                           O: alpha = 3m
-    p.shl(T1, U1, 1)                 # E: 2 gamma
-    p.sel(W3, T0, T1)
+    p.sel(W3, T0, U1)                # E: gamma
     p.swp(T0, U2)                    #                           O: beta4
     p.lane_const(TD[8], -2, 0)       # (the square's scratch uses TD[0..7])
-    p.sqr(U3, W3, TD, T0, TD[8])     # E: gg = 4 gamma^2         O: X3 = alpha^2 - 2 beta4
-    p.swp(A, U3)                     # E: X3                     (O: gg - its A is don't-care)
+    p.sqr(U3, W3, TD, T0, TD[8])     # E: g2 = gamma^2           O: X3 = alpha^2 - 2 beta4
+    p.swp(A, U3)                     # E: X3                     (O: g2 - its A is don't-care)
     p.sub(T0, U2, A)                 # E: beta4 - X3         (L2)
     p.swp(T1, W3)                    # E: alpha
     p.swp(P1, B)                     #                           O: Y
     p.shl(P1, P1, 1)                 #                           O: 2Y
     p.sel(P1, P1, T1)
     p.sel(P2, B, T0)                 #                           O: Z
-    p.lane_const(TD[0], 0, -2)
-    p.mul(B, P1, P2, U3, TD[0])      # E: Y3 = alpha (beta4 - X3) - 2 gg      O: Z3 = 2 Y Z
+    p.lane_const(TD[0], 0, -8)
+    p.mul(B, P1, P2, U3, TD[0])      # E: Y3 = alpha (beta4 - X3) - 8 gamma^2      O: Z3 = 2 Y Z
     return p
 
 
@@ -236,22 +235,21 @@ def build_bn_pair_dbl():
     p.swp(T0, A)                     #                           O: X
     p.sel(P1, T0, B)                 # E: Y                      O: X
     p.sqr(U1, P1, TD)                # E: Bq = Y^2   [3x3]       O: A2 = X^2   [1x1]
-    p.shl(T0, A, 2)                  # E: 4X    (L4)
+    p.shl(T0, U1, 2)                 # E: 4 Bq  (L4)
     p.swp(T1, B)                     #                           O: Y
-    p.sel(P1, T1, T0)                # E: 4X                     O: Y
-    p.sel(P2, B, U1)                 # E: Bq                     O: Z
-    p.mul(U2, P1, P2)                # E: D = 4 X Bq [4x1]       O: yz = Y Z   [3x2]
-    p.shl(T0, U1, 1)                 # E: 2 Bq  (L2)
+    p.sel(P1, T1, A)                 # E: X                      O: Y
+    p.sel(P2, B, T0)                 # E: 4 Bq                   O: Z
+    p.mul(U2, P1, P2)                # E: D = X (4 Bq) [1x4]     O: yz = Y Z   [3x2]
     p.shladd(T1, U1, 1, U1)          #                           O: E3 = 3 A2  (L3)
-    p.sel(P1, T1, T0)                # E: 2 Bq                   O: E3
+    p.sel(P1, T1, U1)                # E: Bq                     O: E3
     p.swp(T0, U2)                    #                           O: D
     p.lane_const(TD[8], -2, 0)
-    p.sqr(U3, P1, TD, T0, TD[8])     # E: c4 = 4 Bq^2 [2x2]      O: X3 = E3^2 - 2 D   [3x3]   (round 6: subtracted inside the square)
+    p.sqr(U3, P1, TD, T0, TD[8])     # E: b2 = Bq^2  [1x1]       O: X3 = E3^2 - 2 D   [3x3]   (round 6: subtracted inside the square)
     p.swp(A, U3)                     # E: X3
     p.sub(T0, U2, A)                 # E: D - X3    (L2)
     p.swp(T1, P1)                    # E: E3 (O's P1)
-    p.lane_const(TD[0], 0, -2)
-    p.mul(U4, T1, T0, U3, TD[0])     # E: Y3 = E3 (D - X3) - 2 c4  [3x2]      O: (idle slot: product of leftovers)
+    p.lane_const(TD[0], 0, -8)
+    p.mul(U4, T1, T0, U3, TD[0])     # E: Y3 = E3 (D - X3) - 8 Bq^2  [3x2]    O: (idle slot: product of leftovers)
     p.shl(T1, U2, 1)                 #                           O: Z3 = 2 yz  (L2)
     p.sel(B, T1, U4)
     return p
