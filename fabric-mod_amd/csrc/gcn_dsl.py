@@ -132,8 +132,10 @@ class Program:
         self.ins.append(("add", d[8], a[8], c[7]))
 
     # ---- Montgomery product / square (fe29.h FE29_REDUCE_COLUMN) ---------------------------------------------------
-    def _columns(self, r, products, addend=None, coef=None):
-        """addend / coef: r = product + coef * addend (Montgomery domain: the addend's digit j joins column 9 + j, its top digit the
+    def _columns(self, r, products, addend=None, coef=None, unsigned=False):
+        """unsigned: the output digits are the low 29 bits of their columns as they are, in [0, 2^29) - two instructions per high column
+        instead of three (no rounding add); for products whose consumers have the headroom (Program.run_intervals proves it).
+        addend / coef: r = product + coef * addend (Montgomery domain: the addend's digit j joins column 9 + j, its top digit the
         last carry) - coef is a register, possibly lane-specific; the output digits are balanced whatever was added."""
         first = True
         for k in range(17):
@@ -159,20 +161,23 @@ class Program:
                     self.ins.append(("mad", "acc", r[k], "pb0"))
                 self.ins.append(("ashr64", "acc", 29))
             else:
-                self.ins.append(("bfe29", r[k - 9], "acc"))       # balanced output digit
-                self.ins.append(("round28", "acc"))               # acc += 2^28
+                if unsigned:
+                    self.ins.append(("q29", r[k - 9], "acc"))     # output digit in [0, 2^29)
+                else:
+                    self.ins.append(("bfe29", r[k - 9], "acc"))   # balanced output digit
+                    self.ins.append(("round28", "acc"))           # acc += 2^28
                 self.ins.append(("ashr64", "acc", 29))
                 if k == 16:
                     if addend is not None:
                         self.ins.append(("mad", "acc", addend[8], coef))
                     self.ins.append(("movacc", r[8], "acc"))
 
-    def mul(self, r, a, b, addend=None, coef=None):
+    def mul(self, r, a, b, addend=None, coef=None, unsigned=False):
         assert r[0] != a[0] and r[0] != b[0], "mul destination must not alias a source"
         assert addend is None or addend[0] not in (r[0],)
-        self._columns(r, lambda k: [(a[i], b[k - i]) for i in range(9) if 0 <= k - i < 9], addend, coef)
+        self._columns(r, lambda k: [(a[i], b[k - i]) for i in range(9) if 0 <= k - i < 9], addend, coef, unsigned)
 
-    def sqr(self, r, a, t, addend=None, coef=None):
+    def sqr(self, r, a, t, addend=None, coef=None, unsigned=False):
         """t: scratch fe for the doubled limbs (8 used)."""
         assert r[0] != a[0] and t[0] != a[0] and t[0] != r[0]
         assert addend is None or addend[0] not in (r[0], t[0])
@@ -188,7 +193,7 @@ class Program:
                 if j == i:
                     out.append((a[i], a[i]))
             return out
-        self._columns(r, prods, addend, coef)
+        self._columns(r, prods, addend, coef, unsigned)
 
     # ---- interpreter -------------------------------------------------------------------------------------------------
     def run(self, regs_even, regs_odd):
@@ -259,6 +264,101 @@ class Program:
                     acc[lane] = s64(acc[lane] + (1 << 28))
                 elif op == "movacc":
                     R[ins[1]] = s32(acc[lane])
+                else:
+                    raise ValueError(op)
+        return L[0], L[1]
+
+    # ---- interval interpreter: the proof that no accumulator and no limb ever wraps ---------------------------------------
+    def run_intervals(self, regs_even, regs_odd):
+        """regs_*: dict "fe.i" -> (lo, hi), the range of the register on that lane; a register that is absent is GARBAGE (a lane's
+        don't-care value: whatever is computed from it is garbage too and is not checked - it must not reach anything that matters,
+        which the caller sees as a missing output).  Executes the program on ranges: every 64-bit accumulator value must stay inside
+        int64 and every 32-bit result inside int32 for ALL inputs in the given ranges (interval arithmetic: sound, not tight).
+        Returns the dicts of output ranges."""
+        L = [dict(regs_even), dict(regs_odd)]
+        acc = [None, None]
+        I32 = (-(1 << 31), (1 << 31) - 1)
+        I64 = (-(1 << 63), (1 << 63) - 1)
+
+        def val(lane, x):
+            if isinstance(x, int):
+                return (x, x)
+            if x in self.consts:
+                return (self.consts[x], self.consts[x])
+            return L[lane].get(x)
+
+        def fit(iv, box, what):
+            if iv is not None and not (box[0] <= iv[0] and iv[1] <= box[1]):
+                raise OverflowError("%s: %s leaves [%d, %d]: [%d, %d]" % (self.name, what, box[0], box[1], iv[0], iv[1]))
+            return iv
+
+        def mul(a, b):
+            if a is None or b is None:
+                return None
+            c = (a[0] * b[0], a[0] * b[1], a[1] * b[0], a[1] * b[1])
+            return (min(c), max(c))
+
+        def add(a, b):
+            return None if a is None or b is None else (a[0] + b[0], a[1] + b[1])
+
+        def sub(a, b):
+            return None if a is None or b is None else (a[0] - b[1], a[1] - b[0])
+
+        def low29(a, signed):
+            if a is None:
+                return None
+            box = (-(1 << 28), (1 << 28) - 1) if signed else (0, (1 << 29) - 1)
+            return a if box[0] <= a[0] and a[1] <= box[1] else box
+        for n, ins in enumerate(self.ins):
+            op = ins[0]
+            what = "%s #%d -> %s" % (op, n, ins[1])
+            if op == "bc_mov":
+                v = val(ins[3], ins[2])
+                for lane in (0, 1):
+                    L[lane][ins[1]] = v
+                continue
+            if op in ("swp_mov", "swp_sub", "swp_add"):
+                new = []
+                for lane in (0, 1):
+                    pv = val(1 - lane, ins[2])
+                    v = pv if op == "swp_mov" else (sub(pv, val(lane, ins[3])) if op == "swp_sub" else add(pv, val(lane, ins[3])))
+                    new.append(fit(v, I32, what))
+                for lane in (0, 1):
+                    L[lane][ins[1]] = new[lane]
+                continue
+            for lane in (0, 1):
+                R = L[lane]
+                if op in ("add", "addc"):
+                    R[ins[1]] = fit(add(val(lane, ins[2]), val(lane, ins[3])), I32, what)
+                elif op == "sub":
+                    R[ins[1]] = fit(sub(val(lane, ins[2]), val(lane, ins[3])), I32, what)
+                elif op == "shl":
+                    R[ins[1]] = fit(mul(val(lane, ins[2]), (1 << ins[3], 1 << ins[3])), I32, what)
+                elif op == "shladd":
+                    R[ins[1]] = fit(add(mul(val(lane, ins[2]), (1 << ins[3], 1 << ins[3])), val(lane, ins[4])), I32, what)
+                elif op == "ashr":
+                    a = val(lane, ins[2])
+                    R[ins[1]] = None if a is None else (a[0] >> ins[3], a[1] >> ins[3])
+                elif op == "sel":
+                    R[ins[1]] = val(lane, ins[2]) if lane == 1 else val(lane, ins[3])
+                elif op == "mov":
+                    R[ins[1]] = val(lane, ins[2])
+                elif op == "bfe29":
+                    R[ins[1]] = low29(acc[lane] if ins[2] == "acc" else val(lane, ins[2]), True)
+                elif op == "mad0":
+                    acc[lane] = fit(mul(val(lane, ins[2]), val(lane, ins[3])), I64, what)
+                elif op == "mad":
+                    acc[lane] = fit(add(acc[lane], mul(val(lane, ins[2]), val(lane, ins[3]))), I64, what)
+                elif op == "q29":
+                    R[ins[1]] = low29(acc[lane], False)
+                elif op == "qn0":
+                    R[ins[1]] = None if acc[lane] is None else (0, (1 << 29) - 1)
+                elif op == "ashr64":
+                    acc[lane] = None if acc[lane] is None else (acc[lane][0] >> ins[2], acc[lane][1] >> ins[2])
+                elif op == "round28":
+                    acc[lane] = fit(add(acc[lane], (1 << 28, 1 << 28)), I64, what)
+                elif op == "movacc":
+                    R[ins[1]] = fit(acc[lane], I32, what)
                 else:
                     raise ValueError(op)
         return L[0], L[1]

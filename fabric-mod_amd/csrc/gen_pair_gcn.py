@@ -19,12 +19,21 @@ The single-lane field product / square of fe29.h are generated from the same DSL
 """
 from gcn_dsl import GenericField, Program
 
+# Product steps (numbered in program order) whose output digits are left unsigned - [0, 2^29), two instructions per high column instead
+# of three.  Which steps can is decided by Program.run_intervals over the closed state contract (tests/test_pair_programs.py).
+UNSIGNED_DBL = (2, 3)
+UNSIGNED_ADD = (0, 1, 2, 3, 4, 5, 6, 7)
+UNSIGNED_MADD = (0, 1, 3, 4, 5)
+UNSIGNED_BN_DBL = ()
+UNSIGNED_BN_ADD = ()
+UNSIGNED_BN_MADD = ()
 
-def build_pair_dbl():
+
+def build_pair_dbl(uns=UNSIGNED_DBL):
     """(A, B) <- 2 * (A, B).   in: L(X) <= 2, L(Y) <= 3, L(Z) <= 2 (2Y x Z: 6 x 2);  out: L(X) = 1, L(Y) = 1, L(Z) = 1.
     Round 6: X3 = alpha^2 - 2 beta4 and Y3 = yy - 2 gg leave their PRODUCTS already subtracted and with balanced digits (nine more
-    MACs each on the high columns, Program._columns' addend) instead of a subtraction, a carry pass and a select after them, and the
-    factors 2 and 4 of gamma ride in the addend's coefficient: 739 instructions, were 787."""
+    MACs each on the high columns, Program._columns' addend) instead of a subtraction, a carry pass and a select after them: 746
+    instructions, were 787."""
     p = Program("PAIR29_DBL")
     A = p.fe("A", "io")
     B = p.fe("B", "io")
@@ -37,31 +46,32 @@ def build_pair_dbl():
     T0 = p.fe("T0", "tmp")
     T1 = p.fe("T1", "tmp")
     TD = p.fe("TD", "tmp")
-    p.sqr(U1, B, TD)                 # E: gamma = Y^2            O: delta = Z^2
+    p.sqr(U1, B, TD, unsigned=0 in uns)                 # E: gamma = Y^2            O: delta = Z^2
     p.swp_sub(P1, A, U1)             #                           O: X - delta
     p.swp_add(P2, A, U1)             #                           O: X + delta
-    p.shl(T0, U1, 2)                 # E: 4 gamma  (L4)
-    p.sel(P1, P1, A)                 # E: X
-    p.sel(P2, P2, T0)
-    p.mul(U2, P1, P2)                # E: beta4 = X (4 gamma)    O: m = (X - delta)(X + delta)
+    p.shl(T0, A, 2)                  # E: 4X
+    p.sel(P1, P1, T0)
+    p.sel(P2, P2, U1)                # E: gamma
+    p.mul(U2, P1, P2, unsigned=1 in uns)                # E: beta4 = 4 X gamma      O: m = (X - delta)(X + delta)
     p.shladd(T0, U2, 1, U2)          #                           O: alpha = 3m
-    p.sel(W3, T0, U1)                # E: gamma
+    p.shl(T1, U1, 1)                 # E: 2 gamma
+    p.sel(W3, T0, T1)
     p.swp(T0, U2)                    #                           O: beta4
     p.lane_const(TD[8], -2, 0)       # (the square's scratch uses TD[0..7])
-    p.sqr(U3, W3, TD, T0, TD[8])     # E: g2 = gamma^2           O: X3 = alpha^2 - 2 beta4
-    p.swp(A, U3)                     # E: X3                     (O: g2 - its A is don't-care)
+    p.sqr(U3, W3, TD, T0, TD[8], unsigned=2 in uns)     # E: gg = 4 gamma^2         O: X3 = alpha^2 - 2 beta4
+    p.swp(A, U3)                     # E: X3                     (O: gg - its A is don't-care)
     p.sub(T0, U2, A)                 # E: beta4 - X3         (L2)
     p.swp(T1, W3)                    # E: alpha
     p.swp(P1, B)                     #                           O: Y
     p.shl(P1, P1, 1)                 #                           O: 2Y
     p.sel(P1, P1, T1)
     p.sel(P2, B, T0)                 #                           O: Z
-    p.lane_const(TD[0], 0, -8)
-    p.mul(B, P1, P2, U3, TD[0])      # E: Y3 = alpha (beta4 - X3) - 8 gamma^2      O: Z3 = 2 Y Z
+    p.lane_const(TD[0], 0, -2)
+    p.mul(B, P1, P2, U3, TD[0], unsigned=3 in uns)      # E: Y3 = alpha (beta4 - X3) - 2 gg      O: Z3 = 2 Y Z
     return p
 
 
-def build_pair_add(name="PAIR29_ADD", field=None):
+def build_pair_add(name="PAIR29_ADD", field=None, uns=UNSIGNED_ADD):
     """(A, B) <- (A, B) + P2 with P2 handed over CROSSED:  E: C = Z2,  O: C = X2, D = Y2.
     in: L(X1) <= 2, L(Y1) <= 3, L(Z1) = 1, L(X2) = 1, L(Y2) <= 3, L(Z2) = 1;  out: L(X) = 1, L(Y) = 1, L(Z) = 1
     (round 6: Y3 leaves its last product already subtracted, Program._columns' addend).
@@ -85,20 +95,20 @@ def build_pair_add(name="PAIR29_ADD", field=None):
     C = p.fe("C", "in")
     D = p.fe("D", "in")
     p.sel(W, B, C)                   # E: Z2                     O: Z1
-    p.sqr(U1, W, TD)                 # E: z2z2                   O: z1z1
+    p.sqr(U1, W, TD, unsigned=0 in uns)                 # E: z2z2                   O: z1z1
     p.sel(P1, C, A)                  # E: X1                     O: X2
-    p.mul(U2, P1, U1)                # E: u1 = X1 z2z2           O: u2 = X2 z1z1
-    p.mul(U3, W, U1)                 # E: Z2^3                   O: Z1^3
+    p.mul(U2, P1, U1, unsigned=1 in uns)                # E: u1 = X1 z2z2           O: u2 = X2 z1z1
+    p.mul(U3, W, U1, unsigned=2 in uns)                 # E: Z2^3                   O: Z1^3
     p.sel(P1, D, B)                  # E: Y1                     O: Y2
-    p.mul(U4, P1, U3)                # E: s1                     O: s2
+    p.mul(U4, P1, U3, unsigned=3 in uns)                # E: s1                     O: s2
     p.swp_sub(H, U2, U2)             # E: h = u2 - u1            O: -h     (round 6: O keeps -h; what it costs is a sign, see the last step)
     p.swp_sub(RR, U4, U4)            # E: rr = s2 - s1           O: -rr
     p.sel(P1, RR, H)
     U5 = W                           # W is dead
-    p.sqr(U5, P1, TD)                # E: hh                     O: r2 = rr^2
+    p.sqr(U5, P1, TD, unsigned=4 in uns)                # E: hh                     O: r2 = rr^2
     p.sel(P1, H, U2)                 # E: u1                     O: -h
     p.bce(P2, U5)                    # hh on both lanes
-    p.mul(U6, P1, P2)                # E: v = u1 hh              O: -hhh
+    p.mul(U6, P1, P2, unsigned=5 in uns)                # E: v = u1 hh              O: -hhh
     p.shl(T0, U6, 1)                 # E: 2v
     p.swp_sub(T0, U6, T0)            # E: -hhh - 2v
     p.swp_add(T1, U5, T0)            # E: r2 - hhh - 2v      (L4)
@@ -109,15 +119,15 @@ def build_pair_add(name="PAIR29_ADD", field=None):
     p.sel(P1, B, U4)                 # E: s1                     O: Z1
     p.sel(P2, T1, P2)
     U7 = U1                          # U1 is dead
-    p.mul(U7, P1, P2)                # E: -y2 = s1 (-hhh)        O: zz = Z1 Z2
+    p.mul(U7, P1, P2, unsigned=6 in uns)                # E: -y2 = s1 (-hhh)        O: zz = Z1 Z2
     p.sel(P1, U7, RR)                # E: rr                     O: zz
     p.sel(P2, H, T0)                 # E: X3 - v                 O: -h
     p.lane_const(TD[0], 0, -1)
-    p.mul(B, P1, P2, U7, TD[0])      # E: -Y3 = rr (X3 - v) + y2    O: -Z3 = zz (-h)        (X3, -Y3, -Z3) is the same point as (X3, Y3, Z3)
+    p.mul(B, P1, P2, U7, TD[0], unsigned=7 in uns)      # E: -Y3 = rr (X3 - v) + y2    O: -Z3 = zz (-h)        (X3, -Y3, -Z3) is the same point as (X3, Y3, Z3)
     return p
 
 
-def build_pair_madd(name="PAIR29_MADD", field=None):
+def build_pair_madd(name="PAIR29_MADD", field=None, uns=UNSIGNED_MADD):
     """(A, B) <- (A, B) + (x2, y2) affine, handed over as  E: C = x2,  O: D = y2.
     in: L(X1) = 1, L(Y1) <= 2, L(Z1) = 1, x2 / y2 normalised;  out: L(X) = 1, L(Y) = 2, L(Z) = 1."""
     p = Program(name, field)
@@ -136,23 +146,23 @@ def build_pair_madd(name="PAIR29_MADD", field=None):
     TD = p.fe("TD", "tmp")
     C = p.fe("C", "in")
     D = p.fe("D", "in")
-    p.sqr(U1, B, TD)                 #                           O: z1z1
+    p.sqr(U1, B, TD, unsigned=0 in uns)                 #                           O: z1z1
     p.sel(P1, B, C)                  # E: x2                     O: Z1
     p.bco(P2, U1)                    # z1z1 on both lanes
-    p.mul(U2, P1, P2)                # E: u2 = x2 z1z1           O: Z1^3
+    p.mul(U2, P1, P2, unsigned=1 in uns)                # E: u2 = x2 z1z1           O: Z1^3
     p.sub(H, U2, A)                  # E: h = u2 - X1        (L2)
     p.sel(P1, D, H)                  # E: h                      O: y2
     p.sel(P2, U2, H)                 # E: h                      O: Z1^3
-    p.mul(U3, P1, P2)                # E: hh                     O: s2
+    p.mul(U3, P1, P2, unsigned=2 in uns)                # E: hh                     O: s2
     p.swp_sub(RR, B, U3)             #                           O: Y1 - s2 = -rr   (L3: round 6, every producer of a state leaves L(Y) <= 2 - no carry pass)
     p.sel(P1, RR, U3)                # E: hh                     O: -rr
     p.sel(P2, RR, H)                 # E: h                      O: -rr
-    p.mul(U4, P1, P2)                # E: hhh                    O: r2
+    p.mul(U4, P1, P2, unsigned=3 in uns)                # E: hhh                    O: r2
     p.swp(T0, H)                     #                           O: h
     p.sel(P1, B, A)                  # E: X1                     O: Z1
     p.sel(P2, T0, U3)                # E: hh                     O: h
     U5 = U1                          # U1 is dead
-    p.mul(U5, P1, P2)                # E: v = X1 hh              O: Z3 = Z1 h
+    p.mul(U5, P1, P2, unsigned=4 in uns)                # E: v = X1 hh              O: Z3 = Z1 h
     p.shl(T0, U5, 1)                 # E: 2v
     p.swp_sub(T1, U4, U4)            # E: r2 - hhh
     p.sub(T1, T1, T0)                # E: r2 - hhh - 2v      (L4)
@@ -162,7 +172,7 @@ def build_pair_madd(name="PAIR29_MADD", field=None):
     p.sel(P1, RR, B)                 # E: Y1                     O: -rr
     p.sel(P2, T1, U4)                # E: hhh                    O: X3 - v
     U6 = U3                          # U3 is dead
-    p.mul(U6, P1, P2)                # E: y2 = Y1 hhh            O: y1 = (-rr)(X3 - v)
+    p.mul(U6, P1, P2, unsigned=5 in uns)                # E: y2 = Y1 hhh            O: y1 = (-rr)(X3 - v)
     p.swp_sub(T0, U6, U6)            # E: Y3 = y1 - y2       (L2)
     p.sel(B, U5, T0)                 #                           O: Z3
     return p
@@ -212,10 +222,66 @@ def build_bn_sqr():
     return p
 
 
+# ---- limb contracts, proved by interval arithmetic (Program.run_intervals) -------------------------------------------------
+# The STATE of a lane pair between point operations: digits 0..7 of X (E's A), Y (E's B), Z (O's B) as (lo, hi) and the top digit - which
+# carries the value's magnitude - as (top lo, top hi).  state_outputs() runs the three programs on ranges: every table entry is a state that
+# was stored earlier (Y possibly negated), a comb entry is an affine point in Montgomery form.  contracts_closed() is the proof that
+# whatever sequence of operations a kernel runs, no 64-bit column and no 32-bit limb ever wraps: the outputs of every program lie inside
+# the contract its inputs were drawn from.  emit() refuses to generate headers otherwise; tests/test_pair_programs.py runs it too.
+B28, B24 = 1 << 28, 1 << 24
+STATE_P256 = {"X": (-(B28 + 4), 2 * B28 - 1, -5 * B24, 4 * B24), "Y": (-2 * B28, 2 * B28, -4 * B24, 3 * B24), "Z": (-B28, 2 * B28 - 1, -B24, 2 * B24)}
+STATE_BN = {"X": (-(B28 + 4), B28 + 4, -5 * B24, 4 * B24), "Y": (-2 * B28, 2 * B28, -4 * B24, 3 * B24), "Z": (-2 * B28, 2 * B28, -B24, 3 * B24)}
+AFFINE = (-B28, B28 - 1, 0, B24)        # fe_to_mont of a canonical residue: balanced digits, top digit of a value below p
+
+
+def fe_range(name, c):
+    d = {"%s.%d" % (name, i): (c[0], c[1]) for i in range(8)}
+    d["%s.8" % name] = (c[2], c[3])
+    return d
+
+
+def state_outputs(progs, C):
+    """progs: {"dbl", "add", "madd"}; C: a state contract.  Returns {"X" | "Y" | "Z": (lo, hi, top lo, top hi)}, the union over the three
+    programs of what they leave; raises OverflowError where a column or a limb can wrap."""
+    def state():
+        e, o = {}, {}
+        e.update(fe_range("A", C["X"])); e.update(fe_range("B", C["Y"])); o.update(fe_range("B", C["Z"]))
+        return e, o
+    y = C["Y"]
+    ny = (min(y[0], -y[1]), max(y[1], -y[0]), min(y[2], -y[3]), max(y[3], -y[2]))
+    outs = []
+    e, o = state()
+    outs.append(progs["dbl"].run_intervals(e, o))
+    e, o = state()
+    e.update(fe_range("C", C["Z"])); o.update(fe_range("C", C["X"])); o.update(fe_range("D", ny))
+    outs.append(progs["add"].run_intervals(e, o))
+    e, o = state()
+    e.update(fe_range("C", AFFINE)); o.update(fe_range("D", AFFINE))
+    outs.append(progs["madd"].run_intervals(e, o))
+    U = {}
+    for re_, ro in outs:
+        for nm, regs, fe in (("X", re_, "A"), ("Y", re_, "B"), ("Z", ro, "B")):
+            lo = min(regs["%s.%d" % (fe, i)][0] for i in range(8))
+            hi = max(regs["%s.%d" % (fe, i)][1] for i in range(8))
+            t = regs[fe + ".8"]
+            cur = U.get(nm)
+            U[nm] = (lo, hi, t[0], t[1]) if cur is None else (min(cur[0], lo), max(cur[1], hi), min(cur[2], t[0]), max(cur[3], t[1]))
+    return U
+
+
+def contracts_closed(progs, C):
+    U = state_outputs(progs, C)
+    for k in ("X", "Y", "Z"):
+        u, c = U[k], C[k]
+        if not (c[0] <= u[0] and u[1] <= c[1] and c[2] <= u[2] and u[3] <= c[3]):
+            raise OverflowError("%s leaves the state contract: %r not inside %r" % (k, u, c))
+    return U
+
+
 FIELD_PROGRAMS = [build_fe_mul, build_fe_sqr]
 BN_FIELD_PROGRAMS = [build_bn_mul, build_bn_sqr]
 
-def build_bn_pair_dbl():
+def build_bn_pair_dbl(uns=UNSIGNED_BN_DBL):
     """(A, B) <- 2 * (A, B) on a curve with a = 0 (FP256BN's G1), two lanes per point, formulas of bn_nym29.h::pt_dbl29:
         A2 = X^2, Bq = Y^2, c4 = (2 Bq)^2, D = 4 X Bq, E = 3 A2, F = E^2, X3 = F - 2 D, Y3 = E (D - X3) - 2 c4, Z3 = 2 Y Z.
     Seven field operations in four paired steps (the last one has an idle odd slot).
@@ -234,28 +300,37 @@ def build_bn_pair_dbl():
     TD = p.fe("TD", "tmp")
     p.swp(T0, A)                     #                           O: X
     p.sel(P1, T0, B)                 # E: Y                      O: X
-    p.sqr(U1, P1, TD)                # E: Bq = Y^2   [3x3]       O: A2 = X^2   [1x1]
-    p.shl(T0, U1, 2)                 # E: 4 Bq  (L4)
+    p.sqr(U1, P1, TD, unsigned=0 in uns)                # E: Bq = Y^2   [3x3]       O: A2 = X^2   [1x1]
+    p.shl(T0, A, 2)                  # E: 4X    (L4)
     p.swp(T1, B)                     #                           O: Y
-    p.sel(P1, T1, A)                 # E: X                      O: Y
-    p.sel(P2, B, T0)                 # E: 4 Bq                   O: Z
-    p.mul(U2, P1, P2)                # E: D = X (4 Bq) [1x4]     O: yz = Y Z   [3x2]
+    p.sel(P1, T1, T0)                # E: 4X                     O: Y
+    p.sel(P2, B, U1)                 # E: Bq                     O: Z
+    p.mul(U2, P1, P2, unsigned=1 in uns)                # E: D = 4 X Bq [4x1]       O: yz = Y Z   [3x2]
+    p.shl(T0, U1, 1)                 # E: 2 Bq  (L2)
     p.shladd(T1, U1, 1, U1)          #                           O: E3 = 3 A2  (L3)
-    p.sel(P1, T1, U1)                # E: Bq                     O: E3
+    p.sel(P1, T1, T0)                # E: 2 Bq                   O: E3
     p.swp(T0, U2)                    #                           O: D
     p.lane_const(TD[8], -2, 0)
-    p.sqr(U3, P1, TD, T0, TD[8])     # E: b2 = Bq^2  [1x1]       O: X3 = E3^2 - 2 D   [3x3]   (round 6: subtracted inside the square)
+    p.sqr(U3, P1, TD, T0, TD[8], unsigned=2 in uns)     # E: c4 = 4 Bq^2 [2x2]      O: X3 = E3^2 - 2 D   [3x3]   (round 6: subtracted inside the square)
     p.swp(A, U3)                     # E: X3
     p.sub(T0, U2, A)                 # E: D - X3    (L2)
     p.swp(T1, P1)                    # E: E3 (O's P1)
-    p.lane_const(TD[0], 0, -8)
-    p.mul(U4, T1, T0, U3, TD[0])     # E: Y3 = E3 (D - X3) - 8 Bq^2  [3x2]    O: (idle slot: product of leftovers)
+    p.lane_const(TD[0], 0, -2)
+    p.mul(U4, T1, T0, U3, TD[0], unsigned=3 in uns)     # E: Y3 = E3 (D - X3) - 2 c4  [3x2]      O: (idle slot: product of leftovers)
     p.shl(T1, U2, 1)                 #                           O: Z3 = 2 yz  (L2)
     p.sel(B, T1, U4)
     return p
 
 
-BN_PAIR_PROGRAMS = [build_bn_pair_dbl, lambda: build_pair_add("PAIRBN_ADD", bn_field()), lambda: build_pair_madd("PAIRBN_MADD", bn_field())]
+def build_bn_pair_add(uns=UNSIGNED_BN_ADD):
+    return build_pair_add("PAIRBN_ADD", bn_field(), uns)
+
+
+def build_bn_pair_madd(uns=UNSIGNED_BN_MADD):
+    return build_pair_madd("PAIRBN_MADD", bn_field(), uns)
+
+
+BN_PAIR_PROGRAMS = [build_bn_pair_dbl, build_bn_pair_add, build_bn_pair_madd]
 
 PROGRAMS = [build_pair_dbl, build_pair_add, build_pair_madd]
 
@@ -269,6 +344,10 @@ ALIGN_NOTE = """// Every instruction below is 8 bytes (VOP3, VOP2 + DPP, or VOP2
 
 def emit(path_kind):
     progs = {"field": FIELD_PROGRAMS, "bnfield": BN_FIELD_PROGRAMS, "bnpair": BN_PAIR_PROGRAMS}.get(path_kind, PROGRAMS)
+    if path_kind == "bnpair":
+        contracts_closed({"dbl": build_bn_pair_dbl(), "add": build_bn_pair_add(), "madd": build_bn_pair_madd()}, STATE_BN)
+    elif path_kind == "pair":
+        contracts_closed({"dbl": build_pair_dbl(), "add": build_pair_add(), "madd": build_pair_madd()}, STATE_P256)
     if path_kind == "bnpair":
         print("// GENERATED by gen_pair_gcn.py bnpair - do not edit.  Two-lanes-per-point operations on FP256BN's G1 (a = 0): the point")
         print("// operations of the four-lanes-per-signature idemix kernel (bn_quad29.h); verified in the DSL interpreter against big integers")

@@ -183,7 +183,7 @@ def test_bn_pair_programs_scalar_multiplication_chain():
     from idemix_common import fixtures
     BP = bc.P
     BRI = pow(R, -1, BP)
-    progs = {"dbl": gp.build_bn_pair_dbl(), "add": gp.build_pair_add("PAIRBN_ADD", gp.bn_field()), "madd": gp.build_pair_madd("PAIRBN_MADD", gp.bn_field())}
+    progs = {"dbl": gp.build_bn_pair_dbl(), "add": gp.build_bn_pair_add(), "madd": gp.build_bn_pair_madd()}
     sizes = {k: pr.emit_asm({n: "(%s)" % n for n in pr.order})[1]["instructions"] for k, pr in progs.items()}
     assert sizes["dbl"] < 1000 and sizes["add"] < 1950 and sizes["madd"] < 1550        # one lane: ~1500 / ~3500 / ~2400
 
@@ -240,37 +240,66 @@ def test_bn_pair_programs_scalar_multiplication_chain():
                 assert st.point() == acc
 
 
-def test_pair_programs_at_the_edge_of_their_limb_contracts(progs):
-    """Every input digit at +-L 2^28, the extreme its docstring allows (signs: all plus, all minus, alternating, random): the 64-bit column
-    sums must not wrap - the interpreter's arithmetic is exact 64-bit, so a wrap shows as a wrong value against the formulas in big
-    integers (evaluated on the VALUES the digits represent: such inputs are not curve points, the formulas do not care)."""
-    rng = random.Random(80)
+def test_limb_contracts_are_closed_under_every_program():
+    """The proof that no 64-bit column and no 32-bit limb of the pair programs can wrap, whatever sequence of operations a kernel runs:
+    gcn_dsl.Program.run_intervals executes each program on RANGES (interval arithmetic over the very instruction list the kernel runs) and
+    the outputs of every program lie inside the state contract its inputs were drawn from (gen_pair_gcn.STATE_P256 / STATE_BN).  The
+    generator refuses to emit headers otherwise; this is the same check, plus the one-lane consumers of a state (pair_x_equals_r29 squares Z,
+    fe_is_zero multiplies H / RR by one)."""
+    p256 = {"dbl": gp.build_pair_dbl(), "add": gp.build_pair_add(), "madd": gp.build_pair_madd()}
+    bn = {"dbl": gp.build_bn_pair_dbl(), "add": gp.build_bn_pair_add(), "madd": gp.build_bn_pair_madd()}
+    for progs_, C in ((p256, gp.STATE_P256), (bn, gp.STATE_BN)):
+        U = gp.contracts_closed(progs_, C)
+        # a state that starts as an affine point is inside the contract too
+        assert all(C[k][0] <= gp.AFFINE[0] and gp.AFFINE[1] <= C[k][1] and C[k][2] <= 0 and gp.AFFINE[3] <= C[k][3] for k in "XYZ")
+        assert U["X"][1] < 1 << 30 and U["Y"][1] <= 1 << 29
+    # ... and a contract that is too generous is refused: the tool can say no
+    wide = dict(gp.STATE_P256, Y=(-4 << 28, 4 << 28, -4 << 24, 3 << 24))
+    with pytest.raises(OverflowError):
+        gp.contracts_closed(p256, wide)
+    # one-lane consumers: Z^2 (any lane's B), r Z^2, and a * 1 of fe_is_zero on differences of states
+    sq, mu = gp.build_fe_sqr(), gp.build_fe_mul()
+    for c in (gp.STATE_P256["Z"], gp.STATE_P256["Y"], gp.STATE_BN["Z"]):
+        e = gp.fe_range("A", c)
+        sq.run_intervals(e, e)
+    d3 = (-3 << 28, 3 << 28, -8 << 24, 8 << 24)
+    e = dict(gp.fe_range("A", d3)); e.update(gp.fe_range("B", gp.AFFINE))
+    mu.run_intervals(e, e)
 
-    def edge(L, pattern):
-        m = L << 28
-        sign = {"plus": lambda i: 1, "minus": lambda i: -1, "alt": lambda i: 1 if i & 1 else -1, "rnd": lambda i: rng.choice((1, -1))}[pattern]
-        # (the top digit carries the value's magnitude, not a digit range: L times p's top digit, 2^24)
-        return [sign(i) * (m - (0 if L == 1 and sign(i) < 0 else 1)) for i in range(8)] + [sign(8) * (L << 24)]
+
+def test_pair_programs_at_the_edge_of_their_limb_contracts(progs):
+    """Every input digit at an extreme of the state contract (signs: all high, all low, alternating, random): the 64-bit column sums must
+    not wrap - the interpreter's arithmetic is exact 64-bit, so a wrap shows as a wrong value against the formulas in big integers
+    (evaluated on the VALUES the digits represent: such inputs are not curve points, the formulas do not care).  The interval proof above
+    says this cannot fail; this is the same statement on concrete numbers."""
+    rng = random.Random(80)
+    S = gp.STATE_P256
+
+    def edge(c, pattern):
+        pick = {"hi": lambda i: 1, "lo": lambda i: 0, "alt": lambda i: i & 1, "rnd": lambda i: rng.randrange(2)}[pattern]
+        return [c[1] if pick(i) else c[0] for i in range(8)] + [c[3] if pick(8) else c[2]]
 
     def v(d):
         return sum(x << (29 * i) for i, x in enumerate(d)) * RI % P
-    for pattern in ("plus", "minus", "alt", "rnd", "rnd", "rnd"):
-        # doubling: L(X) <= 2, L(Y) <= 3, L(Z) <= 2
-        X, Y, Z = edge(2, pattern), edge(3, pattern), edge(2, pattern)
+
+    def inside(regs, name, c):
+        return all(c[0] <= regs["%s.%d" % (name, i)] <= c[1] for i in range(8)) and c[2] <= regs["%s.8" % name] <= c[3]
+    negY = (-S["Y"][1], -S["Y"][0], -S["Y"][3], -S["Y"][2])
+    for pattern in ("hi", "lo", "alt", "rnd", "rnd", "rnd", "rnd", "rnd"):
+        X, Y, Z = edge(S["X"], pattern), edge(S["Y"], pattern), edge(S["Z"], pattern)
         e, o = {}, {}
-        put(e, "A", X); put(e, "B", Y); put(o, "A", edge(1, "rnd")); put(o, "B", Z)
+        put(e, "A", X); put(e, "B", Y); put(o, "A", edge(gp.AFFINE, "rnd")); put(o, "B", Z)
         re, ro = progs["dbl"].run(e, o)
         x, y, z = v(X), v(Y), v(Z)
         g, d = y * y % P, z * z % P
         b4, al = 4 * x * g % P, 3 * (x - d) * (x + d) % P
         x3 = (al * al - 2 * b4) % P
         assert val(re, "A") == x3 and val(re, "B") == (al * (b4 - x3) - 8 * g * g) % P and val(ro, "B") == 2 * y * z % P
-        assert all(abs(re["%s.%d" % (n, i)]) <= 1 << 28 for n in "AB" for i in range(8)) and all(abs(ro["B.%d" % i]) <= 1 << 28 for i in range(8))
-        # addition: L(X1) <= 2, L(Y1) <= 3, L(Z1) = 1, L(X2) = 1, L(Y2) <= 3, L(Z2) = 1
-        X1, Y1, Z1, X2, Y2, Z2 = edge(2, pattern), edge(3, pattern), edge(1, pattern), edge(1, "rnd"), edge(3, pattern), edge(1, "rnd")
+        assert inside(re, "A", S["X"]) and inside(re, "B", S["Y"]) and inside(ro, "B", S["Z"])
+        X1, Y1, Z1, X2, Y2, Z2 = edge(S["X"], pattern), edge(S["Y"], pattern), edge(S["Z"], pattern), edge(S["X"], "rnd"), edge(negY, pattern), edge(S["Z"], "rnd")
         e, o = {}, {}
         put(e, "A", X1); put(e, "B", Y1); put(e, "C", Z2); put(e, "D", [0] * 9)
-        put(o, "A", edge(1, "rnd")); put(o, "B", Z1); put(o, "C", X2); put(o, "D", Y2)
+        put(o, "A", edge(gp.AFFINE, "rnd")); put(o, "B", Z1); put(o, "C", X2); put(o, "D", Y2)
         re, ro = progs["add"].run(e, o)
         x1, y1, z1, x2, y2, z2 = v(X1), v(Y1), v(Z1), v(X2), v(Y2), v(Z2)
         u1, u2 = x1 * z2 * z2 % P, x2 * z1 * z1 % P
@@ -279,19 +308,19 @@ def test_pair_programs_at_the_edge_of_their_limb_contracts(progs):
         x3 = (rr * rr - h ** 3 - 2 * u1 * h * h) % P
         y3 = (rr * (u1 * h * h - x3) - s1 * h ** 3) % P
         z3 = z1 * z2 * h % P
-        got = (val(re, "A"), val(re, "B"), val(ro, "B"))
-        assert got in ((x3, y3, z3), (x3, (-y3) % P, (-z3) % P)), pattern           # (X, -Y, -Z) is the same point
-        # mixed addition: L(X1) = 1, L(Y1) <= 2, L(Z1) = 1, x2 / y2 normalised
-        X1, Y1, Z1, X2, Y2 = edge(1, pattern), edge(2, pattern), edge(1, pattern), edge(1, "rnd"), edge(1, pattern)
+        assert (val(re, "A"), val(re, "B"), val(ro, "B")) == (x3, (-y3) % P, (-z3) % P), pattern           # (X, -Y, -Z) is the same point
+        assert inside(re, "A", S["X"]) and inside(re, "B", S["Y"]) and inside(ro, "B", S["Z"])
+        X1, Y1, Z1, X2, Y2 = edge(S["X"], pattern), edge(S["Y"], pattern), edge(S["Z"], pattern), edge(gp.AFFINE, "rnd"), edge(gp.AFFINE, pattern)
         e, o = {}, {}
         put(e, "A", X1); put(e, "B", Y1); put(e, "C", X2); put(e, "D", [0] * 9)
-        put(o, "A", edge(1, "rnd")); put(o, "B", Z1); put(o, "C", [0] * 9); put(o, "D", Y2)
+        put(o, "A", edge(gp.AFFINE, "rnd")); put(o, "B", Z1); put(o, "C", [0] * 9); put(o, "D", Y2)
         re, ro = progs["madd"].run(e, o)
         x1, y1, z1, x2, y2 = v(X1), v(Y1), v(Z1), v(X2), v(Y2)
         u2, s2 = x2 * z1 * z1 % P, y2 * z1 ** 3 % P
         h, rr = (u2 - x1) % P, (s2 - y1) % P
         x3 = (rr * rr - h ** 3 - 2 * x1 * h * h) % P
         assert (val(re, "A"), val(re, "B"), val(ro, "B")) == (x3, (rr * (x1 * h * h - x3) - y1 * h ** 3) % P, z1 * h % P), pattern
+        assert inside(re, "A", S["X"]) and inside(re, "B", S["Y"]) and inside(ro, "B", S["Z"])
 
 
 def test_pair_add_reports_the_exceptional_cases(progs):
@@ -328,13 +357,21 @@ def test_generated_streams_on_gpu_match_the_interpreter_register_for_register(pr
             X1, Y1, Z1 = jac_of(p1, rng)
             X2, Y2, Z2 = jac_of(p2, rng)
             junk = lambda: [rng.randrange(-(1 << 28), 1 << 28) for _ in range(9)]
-            e = {"A": to_fe(X1), "B": to_fe(Y1)}
-            o = {"A": junk(), "B": to_fe(Z1)}
-            if name == "add":
-                e.update(C=to_fe(Z2), D=junk()); o.update(C=to_fe(X2), D=to_fe(Y2))
-            elif name == "madd":
-                e.update(C=to_fe(p2[0]), D=junk()); o.update(C=junk(), D=to_fe(p2[1]))
+            S = gp.STATE_P256
+            anyof = lambda c: [rng.choice((c[0], c[1], rng.randrange(c[0], c[1] + 1))) for _ in range(8)] + [rng.randrange(c[2], c[3] + 1)]
+            if k & 1:      # not curve points: digits anywhere in the state contract, its extremes included (the comparison is with the interpreter)
+                e = {"A": anyof(S["X"]), "B": anyof(S["Y"])}
+                o = {"A": junk(), "B": anyof(S["Z"])}
+                if name == "add":
+                    e.update(C=anyof(S["Z"]), D=junk()); o.update(C=anyof(S["X"]), D=anyof(S["Y"]))
             else:
+                e = {"A": to_fe(X1), "B": to_fe(Y1)}
+                o = {"A": junk(), "B": to_fe(Z1)}
+                if name == "add":
+                    e.update(C=to_fe(Z2), D=junk()); o.update(C=to_fe(X2), D=to_fe(Y2))
+            if name == "madd":
+                e.update(C=to_fe(p2[0]), D=junk()); o.update(C=junk(), D=to_fe(p2[1]))
+            elif name == "dbl":
                 e.update(C=junk(), D=junk()); o.update(C=junk(), D=junk())
             for lane, regs in ((2 * k, e), (2 * k + 1, o)):
                 inp[lane] = regs["A"] + regs["B"] + regs["C"] + regs["D"]
@@ -369,7 +406,7 @@ def test_bn_pair_streams_on_gpu_match_the_interpreter_register_for_register():
     from idemix_common import fixtures
     BP = bc.P
     lib = ctypes.CDLL(os.path.join(ROOT, "fabric-mod_amd", "lib", "libfabgpu_gputest.so"))
-    progs = {"dbl": gp.build_bn_pair_dbl(), "add": gp.build_pair_add("PAIRBN_ADD", gp.bn_field()), "madd": gp.build_pair_madd("PAIRBN_MADD", gp.bn_field())}
+    progs = {"dbl": gp.build_bn_pair_dbl(), "add": gp.build_bn_pair_add(), "madd": gp.build_bn_pair_madd()}
     rng = random.Random(91)
     base = fixtures()["MSP2OU1"]["ipk"].h_rand
 
