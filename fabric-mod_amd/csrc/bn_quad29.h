@@ -46,8 +46,8 @@ __device__ __forceinline__ void pairbn_sel(pairbn_pt& r, bool c, const pairbn_pt
 
 #define QB_TMPS __attribute__((unused)) fbn tU1, tU2, tU3, tU4, tU6, tW, tH, tRR, tP1, tP2, tT0, tT1, tTD
 #define QB_DBL(P) PAIRBN_DBL((P).A, (P).B, tU1, tU2, tU3, tU4, tP1, tP2, tT0, tT1, tTD)
-#define QB_ADD(P, C, D) PAIRBN_ADD((P).A, (P).B, tH, tRR, tW, tU1, tU2, tU3, tU4, tU6, tP1, tP2, tT0, tT1, tTD, C, D)
-#define QB_MADD(P, C, D) PAIRBN_MADD((P).A, (P).B, tU1, tU2, tU3, tU4, tH, tRR, tP1, tP2, tT0, tT1, tTD, C, D)
+#define QB_ADD(R, P, C, D) PAIRBN_ADD((R).A, (R).B, (P).A, (P).B, tH, tRR, tW, tU1, tU2, tU3, tU4, tU6, tP1, tP2, tT0, tT1, tTD, C, D)
+#define QB_MADD(R, P, C, D) PAIRBN_MADD((R).A, (R).B, (P).A, (P).B, tU1, tU2, tU3, tU4, tH, tRR, tP1, tP2, tT0, tT1, tTD, C, D)
 
 // Per-PAIR table j*Q (j = 1..16) in the global workspace: entry j of pair k is the 128-byte line slot + (k * 16 + j - 1) * 128 - the
 // layout of PairQTab (p256_pair29.h): cells 0..4 = X[9] Y[9] pad (E stores them), cells 5..7 = Z[9] pad (O).
@@ -126,8 +126,8 @@ __device__ __forceinline__ void pairbn_comb_mult(pairbn_pt& S, bool& s_inf, cons
         int inext = i + 1 < KeyTab8::WINDOWS ? i + 1 : i;
         nd = KeyTab8::digit(k, inext);
         pairbn_comb_load(tab, inext, nd ? nd : 1u, odd, nxy);
-        pairbn_pt sum = S;
-        QB_MADD(sum, xy, xy);
+        pairbn_pt sum;
+        QB_MADD(sum, S, xy, xy);
         bool take_ent = s_inf & (d != 0);
         bool take_sum = (!s_inf) & (d != 0);
         pairbn_sel(S, take_sum, sum, S);
@@ -151,14 +151,12 @@ __device__ __forceinline__ void pairbn_final_add(pairbn_pt& Rr, bool& r_inf, con
     pairbn_swap_fe(sb, T.B);                // E: Z_T    O: Y_T
     fe_sel(C, odd, sa, sb);
     D = sb;
-    pairbn_pt Rp = S;
-    QB_ADD(Rp, C, D);
+    pairbn_pt Rp;
+    QB_ADD(Rp, S, C, D);
     bool hz = fe_is_zero(tH);               // E: h, O: -h
     bool rz_own = fe_is_zero(tRR);          // rr lives on E
     int32_t rz_other = pair_swap_i32(rz_own ? 1 : 0);
     bool rz = odd ? (rz_other != 0) : rz_own;
-    pairbn_pt Rd = T;
-    QB_DBL(Rd);
     r_inf = t_inf & s_inf;
     bool use_T = s_inf & !t_inf;
     bool use_S = t_inf & !s_inf;
@@ -166,7 +164,11 @@ __device__ __forceinline__ void pairbn_final_add(pairbn_pt& Rr, bool& r_inf, con
     bool use_dbl = both & hz & rz;
     r_inf = r_inf | (both & hz & !rz);
     Rr = Rp;
-    pairbn_sel(Rr, use_dbl, Rd, Rr);
+    if (__any(use_dbl)) {                   // S == T: crafted inputs only
+        pairbn_pt Rd = T;
+        QB_DBL(Rd);
+        pairbn_sel(Rr, use_dbl, Rd, Rr);
+    }
     pairbn_sel(Rr, use_T, T, Rr);
     pairbn_sel(Rr, use_S, S, Rr);
 }
@@ -190,8 +192,9 @@ __device__ __forceinline__ void pairbn_booth_mult(pairbn_pt& T, bool& t_inf, con
         QB_DBL(d);
         qtab.store_state(j, d, odd);
         if (j < 16) {
-            QB_MADD(d, QX, QY);
-            qtab.store_state(j + 1, d, odd);
+            pairbn_pt d1;
+            QB_MADD(d1, d, QX, QY);
+            qtab.store_state(j + 1, d1, odd);
         }
     }
     uint32_t kw[9];
@@ -211,10 +214,13 @@ __device__ __forceinline__ void pairbn_booth_mult(pairbn_pt& T, bool& t_inf, con
 #pragma unroll 1
             for (int k = 0; k < 5; k++) QB_DBL(T);
         }
+        {
+            const int32_t nm = neg ? -1 : 0, nc = neg ? 1 : 0;        // -y = (y ^ -1) + 1: one v_xad_u32 per limb instead of a negation and a select
 #pragma unroll
-        for (int l = 0; l < 9; l++) D.v[l] = neg ? -D.v[l] : D.v[l];   // -Y2 (lives on O)
-        pairbn_pt sum = T;
-        QB_ADD(sum, C, D);
+            for (int l = 0; l < 9; l++) D.v[l] = (D.v[l] ^ nm) + nc;  // -Y2 (lives on O)
+        }
+        pairbn_pt sum;
+        QB_ADD(sum, T, C, D);
         bool take_ent = t_inf & (mag != 0);
         bool take_sum = (!t_inf) & (mag != 0);
         pairbn_sel(T, take_sum, sum, T);

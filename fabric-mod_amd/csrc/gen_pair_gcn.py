@@ -72,13 +72,15 @@ def build_pair_dbl(uns=UNSIGNED_DBL):
 
 
 def build_pair_add(name="PAIR29_ADD", field=None, uns=UNSIGNED_ADD):
-    """(A, B) <- (A, B) + P2 with P2 handed over CROSSED:  E: C = Z2,  O: C = X2, D = Y2.
+    """(AO, BO) <- (A, B) + P2 with P2 handed over CROSSED:  E: C = Z2,  O: C = X2, D = Y2.
     in: L(X1) <= 2, L(Y1) <= 3, L(Z1) = 1, L(X2) = 1, L(Y2) <= 3, L(Z2) = 1;  out: L(X) = 1, L(Y) = 1, L(Z) = 1
     (round 6: Y3 leaves its last product already subtracted, Program._columns' addend).
     H (E: h = u2 - u1, O: -h) and RR (E: s2 - s1) are left for the caller's P == +-Q test (a test for zero)."""
     p = Program(name, field)
-    A = p.fe("A", "io")
-    B = p.fe("B", "io")
+    AO = p.fe("AO", "tmp")         # the sum, out of place (round 6): the caller keeps the addend-free state for digits that are zero
+    BO = p.fe("BO", "tmp")         # without copying it first
+    A = p.fe("A", "in")
+    B = p.fe("B", "in")
     H = p.fe("H", "tmp")
     RR = p.fe("RR", "tmp")
     W = p.fe("W", "tmp")
@@ -112,8 +114,8 @@ def build_pair_add(name="PAIR29_ADD", field=None, uns=UNSIGNED_ADD):
     p.shl(T0, U6, 1)                 # E: 2v
     p.swp_sub(T0, U6, T0)            # E: -hhh - 2v
     p.swp_add(T1, U5, T0)            # E: r2 - hhh - 2v      (L4)
-    p.wnorm(A, T1, TD)               # E: X3
-    p.sub(T0, A, U6)                 # E: X3 - v             (L2)
+    p.wnorm(AO, T1, TD)               # E: X3
+    p.sub(T0, AO, U6)                 # E: X3 - v             (L2)
     p.swp(T1, C)                     #                           O: Z2
     p.swp(P2, U6)                    # E: -hhh
     p.sel(P1, B, U4)                 # E: s1                     O: Z1
@@ -123,16 +125,18 @@ def build_pair_add(name="PAIR29_ADD", field=None, uns=UNSIGNED_ADD):
     p.sel(P1, U7, RR)                # E: rr                     O: zz
     p.sel(P2, H, T0)                 # E: X3 - v                 O: -h
     p.lane_const(TD[0], 0, -1)
-    p.mul(B, P1, P2, U7, TD[0], unsigned=7 in uns)      # E: -Y3 = rr (X3 - v) + y2    O: -Z3 = zz (-h)        (X3, -Y3, -Z3) is the same point as (X3, Y3, Z3)
+    p.mul(BO, P1, P2, U7, TD[0], unsigned=7 in uns)      # E: -Y3 = rr (X3 - v) + y2    O: -Z3 = zz (-h)        (X3, -Y3, -Z3) is the same point as (X3, Y3, Z3)
     return p
 
 
 def build_pair_madd(name="PAIR29_MADD", field=None, uns=UNSIGNED_MADD):
-    """(A, B) <- (A, B) + (x2, y2) affine, handed over as  E: C = x2,  O: D = y2.
+    """(AO, BO) <- (A, B) + (x2, y2) affine, handed over as  E: C = x2,  O: D = y2.
     in: L(X1) = 1, L(Y1) <= 2, L(Z1) = 1, x2 / y2 normalised;  out: L(X) = 1, L(Y) = 2, L(Z) = 1."""
     p = Program(name, field)
-    A = p.fe("A", "io")
-    B = p.fe("B", "io")
+    AO = p.fe("AO", "tmp")         # out of place, as in the addition
+    BO = p.fe("BO", "tmp")
+    A = p.fe("A", "in")
+    B = p.fe("B", "in")
     U1 = p.fe("U1", "tmp")
     U2 = p.fe("U2", "tmp")
     U3 = p.fe("U3", "tmp")
@@ -166,15 +170,15 @@ def build_pair_madd(name="PAIR29_MADD", field=None, uns=UNSIGNED_MADD):
     p.shl(T0, U5, 1)                 # E: 2v
     p.swp_sub(T1, U4, U4)            # E: r2 - hhh
     p.sub(T1, T1, T0)                # E: r2 - hhh - 2v      (L4)
-    p.wnorm(A, T1, TD)               # E: X3
-    p.sub(T0, A, U5)                 # E: X3 - v             (L2)
+    p.wnorm(AO, T1, TD)               # E: X3
+    p.sub(T0, AO, U5)                 # E: X3 - v             (L2)
     p.swp(T1, T0)                    #                           O: X3 - v
     p.sel(P1, RR, B)                 # E: Y1                     O: -rr
     p.sel(P2, T1, U4)                # E: hhh                    O: X3 - v
     U6 = U3                          # U3 is dead
     p.mul(U6, P1, P2, unsigned=5 in uns)                # E: y2 = Y1 hhh            O: y1 = (-rr)(X3 - v)
     p.swp_sub(T0, U6, U6)            # E: Y3 = y1 - y2       (L2)
-    p.sel(B, U5, T0)                 #                           O: Z3
+    p.sel(BO, U5, T0)                 #                           O: Z3
     return p
 
 
@@ -260,7 +264,8 @@ def state_outputs(progs, C):
     outs.append(progs["madd"].run_intervals(e, o))
     U = {}
     for re_, ro in outs:
-        for nm, regs, fe in (("X", re_, "A"), ("Y", re_, "B"), ("Z", ro, "B")):
+        oa, ob = ("AO", "BO") if "AO.0" in re_ else ("A", "B")
+        for nm, regs, fe in (("X", re_, oa), ("Y", re_, ob), ("Z", ro, ob)):
             lo = min(regs["%s.%d" % (fe, i)][0] for i in range(8))
             hi = max(regs["%s.%d" % (fe, i)][1] for i in range(8))
             t = regs[fe + ".8"]

@@ -42,15 +42,23 @@ __global__ void __launch_bounds__(64, 1) gputest_pair_kernel(int op, const int32
     } else if (op == 0) {
         PAIR_DBL(P);
     } else if (op == 1) {
-        PAIR_ADD(P, C, D);
+        pair_pt R;
+        PAIR_ADD(R, P, C, D);
+        P = R;
     } else if (op == 2) {
-        PAIR_MADD(P, C, D);
+        pair_pt R;
+        PAIR_MADD(R, P, C, D);
+        P = R;
     } else if (op == 4) {           // the same three programs for FP256BN's field and a = 0 (pair29_bn_gcn.h)
         PAIRBN_DBL(P.A, P.B, tU1, tU2, tU3, tU4, tP1, tP2, tT0, tT1, tTD);
     } else if (op == 5) {
-        PAIRBN_ADD(P.A, P.B, tH, tRR, tW, tU1, tU2, tU3, tU4, tU6, tP1, tP2, tT0, tT1, tTD, C, D);
+        pair_pt R;
+        PAIRBN_ADD(R.A, R.B, P.A, P.B, tH, tRR, tW, tU1, tU2, tU3, tU4, tU6, tP1, tP2, tT0, tT1, tTD, C, D);
+        P = R;
     } else {
-        PAIRBN_MADD(P.A, P.B, tU1, tU2, tU3, tU4, tH, tRR, tP1, tP2, tT0, tT1, tTD, C, D);
+        pair_pt R;
+        PAIRBN_MADD(R.A, R.B, P.A, P.B, tU1, tU2, tU3, tU4, tH, tRR, tP1, tP2, tT0, tT1, tTD, C, D);
+        P = R;
     }
     int32_t* o = out + threadIdx.x * 36;
     for (int i = 0; i < 9; i++) {

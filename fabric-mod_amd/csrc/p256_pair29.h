@@ -34,8 +34,8 @@ __device__ __forceinline__ void pair_sel(pair_pt& r, bool c, const pair_pt& a, c
 
 #define PAIR_TMPS __attribute__((unused)) fe tU1, tU2, tU3, tU4, tU6, tW, tH, tRR, tP1, tP2, tT0, tT1, tTD
 #define PAIR_DBL(P) PAIR29_DBL((P).A, (P).B, tU1, tU2, tU3, tW, tP1, tP2, tT0, tT1, tTD)
-#define PAIR_ADD(P, C, D) PAIR29_ADD((P).A, (P).B, tH, tRR, tW, tU1, tU2, tU3, tU4, tU6, tP1, tP2, tT0, tT1, tTD, C, D)
-#define PAIR_MADD(P, C, D) PAIR29_MADD((P).A, (P).B, tU1, tU2, tU3, tU4, tH, tRR, tP1, tP2, tT0, tT1, tTD, C, D)
+#define PAIR_ADD(R, P, C, D) PAIR29_ADD((R).A, (R).B, (P).A, (P).B, tH, tRR, tW, tU1, tU2, tU3, tU4, tU6, tP1, tP2, tT0, tT1, tTD, C, D)
+#define PAIR_MADD(R, P, C, D) PAIR29_MADD((R).A, (R).B, (P).A, (P).B, tU1, tU2, tU3, tU4, tH, tRR, tP1, tP2, tT0, tT1, tTD, C, D)
 
 // Per-signature table j*Q (j = 1..16) in the global workspace.  Per workgroup slot: [entry][q 0..7][pair NP] x 16 bytes;
 // q 0..4 = X[9] Y[9] pad, q 5..7 = Z[9] pad.  E stores / owns the X,Y quads, O the Z quads.
@@ -272,8 +272,8 @@ __device__ __forceinline__ void pair_comb_mult29(pair_pt& S, bool& s_inf, const 
         int inext = i + 1 < Tab::WINDOWS ? i + 1 : i;
         nd = Tab::digit(k, inext);
         pair_comb_load<Tab>(tab, inext, nd ? nd : 1u, odd, nxy);
-        pair_pt sum = S;
-        PAIR_MADD(sum, xy, xy);
+        pair_pt sum;
+        PAIR_MADD(sum, S, xy, xy);
         bool take_ent = s_inf & (d != 0);
         bool take_sum = (!s_inf) & (d != 0);
         pair_sel(S, take_sum, sum, S);
@@ -297,14 +297,12 @@ __device__ __forceinline__ void pair_final_add29(pair_pt& Rr, bool& r_inf, const
     pair_swap_fe(sb, T.B);                  // E: Z_T    O: Y_T
     fe_sel(C, odd, sa, sb);
     D = sb;
-    pair_pt Rp = S;
-    PAIR_ADD(Rp, C, D);
+    pair_pt Rp;
+    PAIR_ADD(Rp, S, C, D);
     bool hz = fe_is_zero(tH);               // E: h, O: -h
     bool rz_own = fe_is_zero(tRR);          // rr lives on E
     int32_t rz_other = pair_swap_i32(rz_own ? 1 : 0);
     bool rz = odd ? (rz_other != 0) : rz_own;
-    pair_pt Rd = T;
-    PAIR_DBL(Rd);
     r_inf = t_inf & s_inf;
     bool use_T = s_inf & !t_inf;
     bool use_S = t_inf & !s_inf;
@@ -312,7 +310,11 @@ __device__ __forceinline__ void pair_final_add29(pair_pt& Rr, bool& r_inf, const
     bool use_dbl = both & hz & rz;
     r_inf = r_inf | (both & hz & !rz);
     Rr = Rp;
-    pair_sel(Rr, use_dbl, Rd, Rr);
+    if (__any(use_dbl)) {                   // S == T: only a crafted signature gets here - no wavefront of honest ones pays for the doubling
+        pair_pt Rd = T;
+        PAIR_DBL(Rd);
+        pair_sel(Rr, use_dbl, Rd, Rr);
+    }
     pair_sel(Rr, use_T, T, Rr);
     pair_sel(Rr, use_S, S, Rr);
 }
@@ -348,8 +350,9 @@ __device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, c
         PAIR_DBL(d);
         qtab.store_state(j, d, odd);
         if (j < TAB) {
-            PAIR_MADD(d, QX, QY);
-            qtab.store_state(j + 1, d, odd);
+            pair_pt d1;
+            PAIR_MADD(d1, d, QX, QY);
+            qtab.store_state(j + 1, d1, odd);
         }
     }
 
@@ -379,10 +382,13 @@ __device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, c
 #pragma unroll 1
             for (int k = 0; k < W; k++) PAIR_DBL(T);
         }
+        {
+            const int32_t nm = neg ? -1 : 0, nc = neg ? 1 : 0;        // -y = (y ^ -1) + 1: one v_xad_u32 per limb instead of a negation and a select
 #pragma unroll
-        for (int l = 0; l < 9; l++) D.v[l] = neg ? -D.v[l] : D.v[l];   // -Y2 (lives on O)
-        pair_pt sum = T;
-        PAIR_ADD(sum, C, D);
+            for (int l = 0; l < 9; l++) D.v[l] = (D.v[l] ^ nm) + nc;  // -Y2 (lives on O)
+        }
+        pair_pt sum;
+        PAIR_ADD(sum, T, C, D);
         bool take_ent = t_inf & (mag != 0);
         bool take_sum = (!t_inf) & (mag != 0);
         pair_sel(T, take_sum, sum, T);
