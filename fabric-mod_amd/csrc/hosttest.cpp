@@ -61,6 +61,16 @@ void hosttest_modinv(int which, const uint8_t* a32, uint8_t* out32) {
     modinv(r, a, which ? PI : NI);
     to_be32(out32, r);
 }
+// modinv_divsteps30_column (what a lane of the pair kernels runs) against modinv_divsteps30: returns 0 when the two columns are the
+// full matrix's and the zetas agree
+int hosttest_divsteps_columns(int32_t zeta, uint32_t f0, uint32_t g0) {
+    trans2x2 t;
+    const int32_t z = modinv_divsteps30(zeta, f0, g0, t);
+    int32_t u = 1, q = 0, v = 0, r = 1;
+    const int32_t z1 = modinv_divsteps30_column(zeta, f0, g0, u, q);
+    const int32_t z2 = modinv_divsteps30_column(zeta, f0, g0, v, r);
+    return (z == z1 && z == z2 && u == t.u && q == t.q && v == t.v && r == t.r) ? 0 : 1;
+}
 void hosttest_gtab29_entry(int window, int digit, uint8_t* x32, uint8_t* y32) {
     GTab16 gt{gtab29()};
     fe x, y;

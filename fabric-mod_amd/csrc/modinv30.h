@@ -87,6 +87,32 @@ FAB_HD int32_t modinv_divsteps30(int32_t zeta, uint32_t f0, uint32_t g0, trans2x
     return zeta;
 }
 
+// The same 30 division steps with ONE COLUMN of the transition matrix: the recurrences of (u, q) and of (v, r) are the same code on
+// different initial values - (1, 0) and (0, 1) - so the two lanes of a signature's pair compute a column each (p256_pair29.h pair_modinv)
+// and exchange them: six instructions less per division step than both lanes computing all four entries.  a, b: in = the column's
+// initial values, out = its entries (u, q) or (v, r).
+FAB_HD int32_t modinv_divsteps30_column(int32_t zeta, uint32_t f0, uint32_t g0, int32_t& a, int32_t& b) {
+    uint32_t u = (uint32_t)a, q = (uint32_t)b;
+    uint32_t f = f0, g = g0;
+#pragma unroll
+    for (int i = 0; i < 30; i++) {
+        uint32_t neg = (uint32_t)(zeta >> 31);
+        uint32_t odd = 0u - (g & 1u);
+        uint32_t x = (f ^ neg) - neg, y = (u ^ neg) - neg;
+        g += x & odd;
+        q += y & odd;
+        uint32_t swap = neg & odd;
+        zeta = (int32_t)(((uint32_t)zeta ^ swap) - 1u);
+        f += g & swap;
+        u += q & swap;
+        g >>= 1;
+        u <<= 1;
+    }
+    a = (int32_t)u;
+    b = (int32_t)q;
+    return zeta;
+}
+
 // (f, g) <- t * (f, g) / 2^30  (exact)
 FAB_HD void modinv_update_fg(s30& f, s30& g, const trans2x2& t) {
     int64_t cf = (int64_t)t.u * f.v[0] + (int64_t)t.v * g.v[0];

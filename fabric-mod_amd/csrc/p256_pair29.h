@@ -179,7 +179,8 @@ __device__ __forceinline__ void pair_comb_load(const int32_t* __restrict__ tab, 
     for (int l = 0; l < 9; l++) xy.v[l] = e[l];
 }
 
-// w = x^-1 mod M on a lane pair (modinv30.h).  The 30 division steps of a batch are computed by both lanes; then the EVEN
+// w = x^-1 mod M on a lane pair (modinv30.h).  The 30 division steps of a batch are computed by both lanes (round 6: each with one
+// column of the transition matrix); then the EVEN
 // lane applies the transition matrix to (f, g) and the ODD lane to (d, e) - one update per lane per batch instead of two.
 // Both run the (d, e) update code: for (f, g) the modulus correction is forced to zero (t (f, g) is divisible by 2^30 by
 // construction, so the same shift is exact).  The result is returned on both lanes.
@@ -197,8 +198,15 @@ __device__ __forceinline__ void pair_modinv(u256& out, const u256& x, const modi
     for (int it = 0; it < 20; it++) {
         int32_t fo = pair_swap_i32(a.v[0]), go = pair_swap_i32(b.v[0]);
         uint32_t f0 = (uint32_t)(odd ? fo : a.v[0]), g0 = (uint32_t)(odd ? go : b.v[0]);
+        // the division steps with one column of the transition matrix per lane - E: (u, q) from (1, 0), O: (v, r) from (0, 1) - then exchanged
+        int32_t ca0 = odd ? 0 : 1, cb0 = odd ? 1 : 0;
+        zeta = modinv_divsteps30_column(zeta, f0, g0, ca0, cb0);
+        const int32_t pa = pair_swap_i32(ca0), pb = pair_swap_i32(cb0);
         trans2x2 t;
-        zeta = modinv_divsteps30(zeta, f0, g0, t);
+        t.u = odd ? pa : ca0;
+        t.q = odd ? pb : cb0;
+        t.v = odd ? ca0 : pa;
+        t.r = odd ? cb0 : pb;
         // modinv_update_de with the correction masked off on the even lane
         int32_t sa = a.v[8] >> 31, sb = b.v[8] >> 31;
         int32_t ma = (t.u & sa) + (t.v & sb);

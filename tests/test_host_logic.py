@@ -225,6 +225,11 @@ def test_safegcd_inversion_against_python_pow(hosttest):
         for a in vals:
             assert inv(which, a % m) == pow(a % m, -1, m), (which, hex(a))
         assert inv(which, 0) == 0
+    # the pair kernels' lanes compute ONE column of a batch's transition matrix each (modinv_divsteps30_column): same entries, same zeta
+    for _ in range(4000):
+        zeta = rng.randrange(-600, 2)
+        f0 = rng.getrandbits(32) | 1
+        assert hosttest.hosttest_divsteps_columns(zeta, f0, rng.getrandbits(32)) == 0
 
 
 def test_generator_comb_table_fe29(hosttest):
