@@ -24,9 +24,9 @@ from gcn_dsl import GenericField, Program
 UNSIGNED_DBL = (2, 3)
 UNSIGNED_ADD = (0, 1, 2, 3, 4, 5, 6, 7)
 UNSIGNED_MADD = (0, 1, 3, 4, 5)
-UNSIGNED_BN_DBL = ()
-UNSIGNED_BN_ADD = ()
-UNSIGNED_BN_MADD = ()
+UNSIGNED_BN_DBL = (2, 3)
+UNSIGNED_BN_ADD = (0, 1, 2, 3, 4, 5, 6, 7)
+UNSIGNED_BN_MADD = (0, 1, 3, 4, 5)
 
 
 def build_pair_dbl(uns=UNSIGNED_DBL):
@@ -234,7 +234,7 @@ def build_bn_sqr():
 # the contract its inputs were drawn from.  emit() refuses to generate headers otherwise; tests/test_pair_programs.py runs it too.
 B28, B24 = 1 << 28, 1 << 24
 STATE_P256 = {"X": (-(B28 + 4), 2 * B28 - 1, -5 * B24, 4 * B24), "Y": (-2 * B28, 2 * B28, -4 * B24, 3 * B24), "Z": (-B28, 2 * B28 - 1, -B24, 2 * B24)}
-STATE_BN = {"X": (-(B28 + 4), B28 + 4, -5 * B24, 4 * B24), "Y": (-2 * B28, 2 * B28, -4 * B24, 3 * B24), "Z": (-2 * B28, 2 * B28, -B24, 3 * B24)}
+STATE_BN = {"X": (-(B28 + 4), 2 * B28 - 1, -5 * B24, 4 * B24), "Y": (-2 * B28, 2 * B28, -4 * B24, 3 * B24), "Z": (-2 * B28, 2 * B28, -B24, 3 * B24)}
 AFFINE = (-B28, B28 - 1, 0, B24)        # fe_to_mont of a canonical residue: balanced digits, top digit of a value below p
 
 

@@ -271,6 +271,11 @@ def test_limb_contracts_are_closed_under_every_program():
     d3 = (-3 << 28, 3 << 28, -8 << 24, 8 << 24)
     e = dict(gp.fe_range("A", d3)); e.update(gp.fe_range("B", gp.AFFINE))
     mu.run_intervals(e, e)
+    # FP256BN: bn_nym_quad_part2 multiplies a state's X and Y by powers of 1 / Z (balanced digits)
+    bmu = gp.build_bn_mul()
+    for c in (gp.STATE_BN["X"], gp.STATE_BN["Y"], gp.STATE_BN["Z"]):
+        e = dict(gp.fe_range("A", c)); e.update(gp.fe_range("B", (-(1 << 28), 1 << 28, -(2 << 24), 2 << 24)))
+        bmu.run_intervals(e, e)
 
 
 def test_pair_programs_at_the_edge_of_their_limb_contracts(progs):
