@@ -18,6 +18,7 @@
 
 #if defined(__HIP__)
 #define FAB_HD __host__ __device__ inline __attribute__((always_inline))
+#define FAB_D __device__ inline __attribute__((always_inline))        // device only (generated one29_gcn.h and what calls it)
 #else
 #define FAB_HD inline __attribute__((always_inline))
 #endif

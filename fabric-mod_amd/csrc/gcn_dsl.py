@@ -137,13 +137,16 @@ class Program:
         instead of three (no rounding add); for products whose consumers have the headroom (Program.run_intervals proves it).
         addend / coef: r = product + coef * addend (Montgomery domain: the addend's digit j joins column 9 + j, its top digit the
         last carry) - coef is a register, possibly lane-specific; the output digits are balanced whatever was added."""
+        addends = [] if addend is None else (list(addend) if coef is None else [(addend, coef)])   # [(fe, coefficient), ...]
+        self.ins.append(("prod_begin",))       # (markers for emit_cxx: one asm statement per product; the other back ends skip them)
         first = True
         for k in range(17):
             for (x, y) in products(k):
                 self.ins.append(("mad0" if first else "mad", "acc", x, y))
                 first = False
-            if addend is not None and k >= 9:
-                self.ins.append(("mad", "acc", addend[k - 9], coef))
+            if k >= 9:
+                for (ad, cf) in addends:
+                    self.ins.append(("mad", "acc", ad[k - 9], cf))
             if self.field is None:
                 for (dd, c) in RED:
                     if k >= dd and k - dd <= 8:
@@ -168,19 +171,18 @@ class Program:
                     self.ins.append(("round28", "acc"))           # acc += 2^28
                 self.ins.append(("ashr64", "acc", 29))
                 if k == 16:
-                    if addend is not None:
-                        self.ins.append(("mad", "acc", addend[8], coef))
+                    for (ad, cf) in addends:
+                        self.ins.append(("mad", "acc", ad[8], cf))
                     self.ins.append(("movacc", r[8], "acc"))
+        self.ins.append(("prod_end",))
 
     def mul(self, r, a, b, addend=None, coef=None, unsigned=False):
         assert r[0] != a[0] and r[0] != b[0], "mul destination must not alias a source"
-        assert addend is None or addend[0] not in (r[0],)
         self._columns(r, lambda k: [(a[i], b[k - i]) for i in range(9) if 0 <= k - i < 9], addend, coef, unsigned)
 
     def sqr(self, r, a, t, addend=None, coef=None, unsigned=False):
         """t: scratch fe for the doubled limbs (8 used)."""
         assert r[0] != a[0] and t[0] != a[0] and t[0] != r[0]
-        assert addend is None or addend[0] not in (r[0], t[0])
         for i in range(8):
             self.ins.append(("shl", t[i], a[i], 1))
 
@@ -209,6 +211,8 @@ class Program:
             return L[lane][x]
         for ins in self.ins:
             op = ins[0]
+            if op in ("prod_begin", "prod_end"):
+                continue
             if op == "bc_mov":
                 v = val(ins[3], ins[2])
                 for lane in (0, 1):
@@ -311,6 +315,8 @@ class Program:
             return a if box[0] <= a[0] and a[1] <= box[1] else box
         for n, ins in enumerate(self.ins):
             op = ins[0]
+            if op in ("prod_begin", "prod_end"):
+                continue
             what = "%s #%d -> %s" % (op, n, ins[1])
             if op == "bc_mov":
                 v = val(ins[3], ins[2])
@@ -363,6 +369,121 @@ class Program:
                     raise ValueError(op)
         return L[0], L[1]
 
+    # ---- C++ back end: one asm statement per PRODUCT, limb-wise operations as C++ --------------------------------------------
+    def emit_cxx(self, fn_name, params, ftype="fe"):
+        """For one-lane programs (no lane routing): a __device__ function whose field products are one asm statement each - the same
+        columns, constants and digits as emit_asm would produce - and whose limb-wise operations are plain C++, so that the compiler
+        allocates registers and schedules around the products as it does for hand-written code (a whole point operation as ONE asm
+        statement pins every temporary to a register of its own: fine at one wavefront per SIMD, not at two).
+        params: [(fe name, "in" | "out")] in signature order; every other fe is a local.  Returns (text, stats)."""
+        kinds = dict(params)
+
+        def cx(reg):
+            name, i = reg.rsplit(".", 1)
+            return "%s.v[%s]" % (name, i)
+
+        def ev(x):
+            return str(x) if isinstance(x, int) else cx(x)
+        body = []
+        n_asm_ins = 0
+        n_cxx = 0
+        i = 0
+        ins_list = self.ins
+        cnames = ("c9", "c18", "cm21", "c24") if self.field is None else tuple("pb%d" % j for j in range(9)) + ("n0",)
+        while i < len(ins_list):
+            ins = ins_list[i]
+            op = ins[0]
+            if op == "prod_begin":
+                j = i + 1
+                while ins_list[j][0] != "prod_end":
+                    j += 1
+                group = ins_list[i + 1:j]
+                written, read = [], []
+                for g in group:
+                    if g[0] in ("q29", "qn0", "bfe29", "movacc") and g[1] != "acc" and g[1] not in written:
+                        written.append(g[1])
+                for g in group:
+                    for x in g[2:]:
+                        if isinstance(x, str) and "." in x and x not in written and x not in read:
+                            read.append(x)
+                num = {}
+                outs = []
+                for r in written:
+                    num[r] = len(outs)
+                    outs.append('"=&v"(%s)' % cx(r))
+                ins_ = []
+                for r in read:
+                    num[r] = len(outs) + len(ins_)
+                    ins_.append('"v"(%s)' % cx(r))
+                for c in cnames:
+                    num[c] = len(outs) + len(ins_)
+                    ins_.append('"s"(%d)' % self.consts[c])
+                num["c28q"] = len(outs) + len(ins_)
+                ins_.append('"s"((int64_t)268435456)')
+
+                def o(x):
+                    return str(x) if isinstance(x, int) else "%%%d" % num[x]
+                lines = []
+                for g in group:
+                    gop = g[0]
+                    if gop == "mad0":
+                        lines.append("v_mad_i64_i32 v[0:1], vcc, %s, %s, 0" % (o(g[2]), o(g[3])))
+                    elif gop == "mad":
+                        lines.append("v_mad_i64_i32 v[0:1], vcc, %s, %s, v[0:1]" % (o(g[2]), o(g[3])))
+                    elif gop == "q29":
+                        lines.append("v_and_b32 %s, 0x1fffffff, v0" % o(g[1]))
+                    elif gop == "qn0":
+                        lines.append("v_mul_lo_u32 %s, v0, %s" % (o(g[1]), o("n0")))
+                        lines.append("v_and_b32 %s, 0x1fffffff, %s" % (o(g[1]), o(g[1])))
+                    elif gop == "bfe29":
+                        assert g[2] == "acc"
+                        lines.append("v_bfe_i32 %s, v0, 0, 29" % o(g[1]))
+                    elif gop == "ashr64":
+                        lines.append("v_ashrrev_i64 v[0:1], %d, v[0:1]" % g[2])
+                    elif gop == "round28":
+                        lines.append("v_lshl_add_u64 v[0:1], v[0:1], 0, %s" % o("c28q"))
+                    elif gop == "movacc":
+                        lines.append("v_mov_b32_e64 %s, v0" % o(g[1]))
+                    else:
+                        raise ValueError(gop)
+                n_asm_ins += len(lines)
+                body.append("    asm(FE29_GCN_ALIGN")
+                for l in lines:
+                    body.append('        "%s\\n\\t"' % l)
+                body.append("        : %s" % ", ".join(outs))
+                body.append("        : %s" % ", ".join(ins_))
+                body.append('        : "v0", "v1", "vcc");')
+                i = j + 1
+                continue
+            n_cxx += 1
+            if op in ("add", "addc"):
+                body.append("    %s = %s + %s;" % (cx(ins[1]), ev(ins[2]) if ins[2] not in self.consts else str(self.consts[ins[2]]), ev(ins[3]) if ins[3] not in self.consts else str(self.consts[ins[3]])))
+            elif op == "sub":
+                body.append("    %s = %s - %s;" % (cx(ins[1]), ev(ins[2]), ev(ins[3])))
+            elif op == "shl":
+                body.append("    %s = (int32_t)((uint32_t)%s << %d);" % (cx(ins[1]), ev(ins[2]), ins[3]))
+            elif op == "shladd":
+                body.append("    %s = (int32_t)(((uint32_t)%s << %d) + (uint32_t)%s);" % (cx(ins[1]), ev(ins[2]), ins[3], ev(ins[4])))
+            elif op == "ashr":
+                body.append("    %s = %s >> %d;" % (cx(ins[1]), ev(ins[2]), ins[3]))
+            elif op == "mov":
+                body.append("    %s = %s;" % (cx(ins[1]), ev(ins[2])))
+            elif op == "bfe29":
+                body.append("    %s = (int32_t)((uint32_t)%s << 3) >> 3;" % (cx(ins[1]), ev(ins[2])))
+            else:
+                raise ValueError("emit_cxx: %s has no one-lane C++ form" % op)
+            i += 1
+        sig = ", ".join(("const %s& %s" if k == "in" else "%s& %s") % (ftype, n) for n, k in params)
+        local = [n for n in self.order if n not in kinds]
+        text = ["// %s: %d instructions in %d product statements + %d limb-wise C++ operations" % (
+            fn_name, n_asm_ins, sum(1 for x in self.ins if x[0] == "prod_begin"), n_cxx)]
+        text.append("FAB_D void %s(%s) {" % (fn_name, sig))
+        if local:
+            text.append("    %s %s;" % (ftype, ", ".join(local)))
+        text += body
+        text.append("}")
+        return "\n".join(text) + "\n", {"instructions": n_asm_ins + n_cxx}
+
     # ---- asm back end -------------------------------------------------------------------------------------------------
     def emit_asm(self, macro_args):
         """macro_args: dict fe name -> C expression of the `fe` lvalue.  Returns (text of the #define, stats)."""
@@ -412,6 +533,8 @@ class Program:
             count += 1
         for ins in self.ins:
             op = ins[0]
+            if op in ("prod_begin", "prod_end"):
+                continue
             if op == "add" or op == "addc":
                 put("v_add_u32_e64 %s, %s, %s" % (o(ins[1]), o(ins[2]), o(ins[3])), ins[1])
             elif op == "sub":

@@ -283,6 +283,136 @@ def contracts_closed(progs, C):
     return U
 
 
+# ---- one lane per signature: the point operations of p256_verify29.h / ec29.h for the device (round 6) ----------------------------------
+# The same formulas as the C++ bodies (which stay: host build, specification), with this round's shortcuts - subtractions made inside the
+# products, no carry passes, unsigned digits where proved safe - emitted by Program.emit_cxx as device functions whose products are one
+# asm statement each.  Which product steps leave unsigned digits: UNSIGNED_ONE_* (decided by one_contracts_closed, as for the pairs).
+UNSIGNED_ONE_DBL = (0, 3, 4, 5, 6, 7)
+UNSIGNED_ONE_ADD = tuple(range(16))
+UNSIGNED_ONE_MADD = tuple(range(11))
+
+
+def build_one_dbl(uns=None):
+    """(X3, Y3, Z3) = 2 (X, Y, Z), a = -3 (pt_dbl29): 4M + 4S."""
+    uns = UNSIGNED_ONE_DBL if uns is None else uns
+    p = Program("ONE29_DBL")
+    X3, Y3, Z3 = p.fe("X3", "tmp"), p.fe("Y3", "tmp"), p.fe("Z3", "tmp")
+    X, Y, Z = p.fe("X", "in"), p.fe("Y", "in"), p.fe("Z", "in")
+    DL, GM, T1, T2, M, AL, B4, GG, TD = (p.fe(n, "tmp") for n in ("DL", "GM", "T1", "T2", "M", "AL", "B4", "GG", "TD"))
+    p.sqr(DL, Z, TD, unsigned=0 in uns)                  # delta = Z^2
+    p.sqr(GM, Y, TD, unsigned=1 in uns)                  # gamma = Y^2
+    p.sub(T1, X, DL)
+    p.add(T2, X, DL)
+    p.mul(M, T1, T2, unsigned=2 in uns)                  # (X - delta)(X + delta)
+    p.shladd(AL, M, 1, M)                                # alpha = 3 m
+    p.shl(T1, X, 2)                                      # 4X
+    p.mul(B4, T1, GM, unsigned=3 in uns)                 # beta4 = 4 X gamma
+    p.sqr(X3, AL, TD, [(B4, -2)], unsigned=4 in uns)     # X3 = alpha^2 - 2 beta4
+    p.shl(T2, Y, 1)
+    p.mul(Z3, T2, Z, unsigned=5 in uns)                  # Z3 = 2 Y Z
+    p.shl(T1, GM, 1)
+    p.sqr(GG, T1, TD, unsigned=6 in uns)                 # 4 gamma^2
+    p.sub(T1, B4, X3)
+    p.mul(Y3, AL, T1, [(GG, -2)], unsigned=7 in uns)     # Y3 = alpha (beta4 - X3) - 8 gamma^2
+    return p
+
+
+def build_one_add(uns=None):
+    """(X3, Y3, Z3) = (X1, Y1, Z1) + (X2, Y2, Z2) (pt_add29): 12M + 4S; H = u2 - u1 and RR = s2 - s1 for the caller's P == +-Q test."""
+    uns = UNSIGNED_ONE_ADD if uns is None else uns
+    p = Program("ONE29_ADD")
+    X3, Y3, Z3, H, RR = (p.fe(n, "tmp") for n in ("X3", "Y3", "Z3", "H", "RR"))
+    X1, Y1, Z1, X2, Y2, Z2 = (p.fe(n, "in") for n in ("X1", "Y1", "Z1", "X2", "Y2", "Z2"))
+    Z11, Z22, U1, U2, S1, S2, T, HH, HHH, V, TD = (p.fe(n, "tmp") for n in ("Z11", "Z22", "U1", "U2", "S1", "S2", "T", "HH", "HHH", "V", "TD"))
+    p.sqr(Z11, Z1, TD, unsigned=0 in uns)
+    p.sqr(Z22, Z2, TD, unsigned=1 in uns)
+    p.mul(U1, X1, Z22, unsigned=2 in uns)
+    p.mul(U2, X2, Z11, unsigned=3 in uns)
+    p.mul(T, Z2, Z22, unsigned=4 in uns)
+    p.mul(S1, Y1, T, unsigned=5 in uns)
+    T2 = p.fe("T2", "tmp")
+    p.mul(T2, Z1, Z11, unsigned=6 in uns)
+    p.mul(S2, Y2, T2, unsigned=7 in uns)
+    p.sub(H, U2, U1)
+    p.sub(RR, S2, S1)
+    p.sqr(HH, H, TD, unsigned=8 in uns)
+    p.mul(HHH, HH, H, unsigned=9 in uns)
+    p.mul(V, U1, HH, unsigned=10 in uns)
+    p.sqr(X3, RR, TD, [(HHH, -1), (V, -2)], unsigned=11 in uns)      # X3 = rr^2 - h^3 - 2 v
+    p.sub(T, V, X3)
+    Y2P = p.fe("Y2P", "tmp")
+    p.mul(Y2P, S1, HHH, unsigned=12 in uns)
+    p.mul(Y3, RR, T, [(Y2P, -1)], unsigned=13 in uns)                # Y3 = rr (v - X3) - s1 h^3
+    ZZ = p.fe("ZZ", "tmp")
+    p.mul(ZZ, Z1, Z2, unsigned=14 in uns)
+    p.mul(Z3, ZZ, H, unsigned=15 in uns)
+    return p
+
+
+def build_one_madd(uns=None):
+    """(X3, Y3, Z3) = (X1, Y1, Z1) + (x2, y2) affine (pt_add_mixed29): 8M + 3S."""
+    uns = UNSIGNED_ONE_MADD if uns is None else uns
+    p = Program("ONE29_MADD")
+    X3, Y3, Z3, H, RR = (p.fe(n, "tmp") for n in ("X3", "Y3", "Z3", "H", "RR"))
+    X1, Y1, Z1, X2, Y2 = (p.fe(n, "in") for n in ("X1", "Y1", "Z1", "X2", "Y2"))
+    Z11, U2, S2, T, HH, HHH, V, Y2P, TD = (p.fe(n, "tmp") for n in ("Z11", "U2", "S2", "T", "HH", "HHH", "V", "Y2P", "TD"))
+    p.sqr(Z11, Z1, TD, unsigned=0 in uns)
+    p.mul(U2, X2, Z11, unsigned=1 in uns)
+    p.mul(T, Z1, Z11, unsigned=2 in uns)
+    p.mul(S2, Y2, T, unsigned=3 in uns)
+    p.sub(H, U2, X1)
+    p.sub(RR, S2, Y1)                                                # (no carry pass: every producer leaves |Y| digits <= 2 * 2^28)
+    p.sqr(HH, H, TD, unsigned=4 in uns)
+    p.mul(HHH, HH, H, unsigned=5 in uns)
+    p.mul(V, X1, HH, unsigned=6 in uns)
+    p.sqr(X3, RR, TD, [(HHH, -1), (V, -2)], unsigned=7 in uns)
+    p.sub(T, V, X3)
+    p.mul(Y2P, Y1, HHH, unsigned=8 in uns)
+    p.mul(Y3, RR, T, [(Y2P, -1)], unsigned=9 in uns)
+    p.mul(Z3, Z1, H, unsigned=10 in uns)
+    return p
+
+
+STATE_ONE = {"X": (-B28, 2 * B28 - 1, -5 * B24, 4 * B24), "Y": (-B28, 2 * B28 - 1, -4 * B24, 3 * B24), "Z": (-B28, 2 * B28 - 1, -B24, 2 * B24)}
+
+
+def one_state_outputs(progs, C):
+    """As state_outputs, for the one-lane programs: all three coordinates on the same lane."""
+    y = C["Y"]
+    ny = (min(y[0], -y[1]), max(y[1], -y[0]), min(y[2], -y[3]), max(y[3], -y[2]))
+    outs = []
+    e = {}
+    e.update(fe_range("X", C["X"])); e.update(fe_range("Y", C["Y"])); e.update(fe_range("Z", C["Z"]))
+    outs.append(progs["dbl"].run_intervals(e, e)[0])
+    for y2 in (C["Y"], ny):
+        e = {}
+        e.update(fe_range("X1", C["X"])); e.update(fe_range("Y1", C["Y"])); e.update(fe_range("Z1", C["Z"]))
+        e.update(fe_range("X2", C["X"])); e.update(fe_range("Y2", y2)); e.update(fe_range("Z2", C["Z"]))
+        outs.append(progs["add"].run_intervals(e, e)[0])
+    e = {}
+    e.update(fe_range("X1", C["X"])); e.update(fe_range("Y1", C["Y"])); e.update(fe_range("Z1", C["Z"]))
+    e.update(fe_range("X2", AFFINE)); e.update(fe_range("Y2", AFFINE))
+    outs.append(progs["madd"].run_intervals(e, e)[0])
+    U = {}
+    for regs in outs:
+        for nm, fe in (("X", "X3"), ("Y", "Y3"), ("Z", "Z3")):
+            lo = min(regs["%s.%d" % (fe, i)][0] for i in range(8))
+            hi = max(regs["%s.%d" % (fe, i)][1] for i in range(8))
+            t = regs[fe + ".8"]
+            cur = U.get(nm)
+            U[nm] = (lo, hi, t[0], t[1]) if cur is None else (min(cur[0], lo), max(cur[1], hi), min(cur[2], t[0]), max(cur[3], t[1]))
+    return U
+
+
+def one_contracts_closed(progs, C):
+    U = one_state_outputs(progs, C)
+    for k in ("X", "Y", "Z"):
+        u, c = U[k], C[k]
+        if not (c[0] <= u[0] and u[1] <= c[1] and c[2] <= u[2] and u[3] <= c[3]):
+            raise OverflowError("%s leaves the one-lane state contract: %r not inside %r" % (k, u, c))
+    return U
+
+
 FIELD_PROGRAMS = [build_fe_mul, build_fe_sqr]
 BN_FIELD_PROGRAMS = [build_bn_mul, build_bn_sqr]
 
@@ -349,6 +479,25 @@ ALIGN_NOTE = """// Every instruction below is 8 bytes (VOP3, VOP2 + DPP, or VOP2
 
 def emit(path_kind):
     progs = {"field": FIELD_PROGRAMS, "bnfield": BN_FIELD_PROGRAMS, "bnpair": BN_PAIR_PROGRAMS}.get(path_kind, PROGRAMS)
+    if path_kind == "one":
+        one_contracts_closed({"dbl": build_one_dbl(), "add": build_one_add(), "madd": build_one_madd()}, STATE_ONE)
+        print("// GENERATED by gen_pair_gcn.py one - do not edit.  The point operations of p256_verify29.h / ec29.h for one lane per signature on the")
+        print("// device: the formulas of pt_dbl29 / pt_add29 / pt_add_mixed29 with the subtractions made inside the products and unsigned digits")
+        print("// where gen_pair_gcn.one_contracts_closed proves the headroom; one asm statement per field product (gcn_dsl.Program.emit_cxx).")
+        print("#pragma once")
+        print('#include "fe29_gcn.h"   // FE29_GCN_ALIGN')
+        print()
+        print("namespace fab {")
+        print()
+        for fn, b, params in (("one29_dbl", build_one_dbl, [("X3", "out"), ("Y3", "out"), ("Z3", "out"), ("X", "in"), ("Y", "in"), ("Z", "in")]),
+                              ("one29_add", build_one_add, [("X3", "out"), ("Y3", "out"), ("Z3", "out"), ("H", "out"), ("RR", "out"), ("X1", "in"), ("Y1", "in"),
+                                                            ("Z1", "in"), ("X2", "in"), ("Y2", "in"), ("Z2", "in")]),
+                              ("one29_madd", build_one_madd, [("X3", "out"), ("Y3", "out"), ("Z3", "out"), ("H", "out"), ("RR", "out"), ("X1", "in"), ("Y1", "in"),
+                                                              ("Z1", "in"), ("X2", "in"), ("Y2", "in")])):
+            text, st = b().emit_cxx(fn, params)
+            print(text)
+        print("}  // namespace fab")
+        return
     if path_kind == "bnpair":
         contracts_closed({"dbl": build_bn_pair_dbl(), "add": build_bn_pair_add(), "madd": build_bn_pair_madd()}, STATE_BN)
     elif path_kind == "pair":
@@ -383,7 +532,7 @@ def emit(path_kind):
 
 def main():
     import sys
-    emit(sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("field", "bnfield", "bnpair") else "pair")
+    emit(sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("field", "bnfield", "bnpair", "one") else "pair")
 
 
 if __name__ == "__main__":

@@ -334,6 +334,65 @@ def test_pair_programs_at_the_edge_of_their_limb_contracts(progs):
         assert inside(re, "AO", S["X"]) and inside(re, "BO", S["Y"]) and inside(ro, "BO", S["Z"])
 
 
+def test_one_lane_programs_chain_and_contract():
+    """one29_gcn.h (gen_pair_gcn.py one): the device's pt_dbl29 / pt_add29 / pt_add_mixed29 for one lane per signature.  The instruction
+    lists behind the generated C++ run in the interpreter: a double-and-add chain against the oracle after every step (Jacobian and affine
+    addends, negated ones too), the probes h / rr of the exceptional cases, and the interval proof that the one-lane state contract is closed."""
+    rng = random.Random(81)
+    G = (po.GX, po.GY)
+    dbl, add, madd = gp.build_one_dbl(), gp.build_one_add(), gp.build_one_madd()
+    gp.one_contracts_closed({"dbl": dbl, "add": add, "madd": madd}, gp.STATE_ONE)
+    with pytest.raises(OverflowError):
+        gp.one_contracts_closed({"dbl": dbl, "add": add, "madd": madd}, dict(gp.STATE_ONE, Y=(-4 << 28, 4 << 28, -4 << 24, 3 << 24)))
+
+    def state_of(regs, names):
+        return {("XYZ"[i] + ".%d" % l): regs["%s.%d" % (n, l)] for i, n in enumerate(names) for l in range(9)}
+    for trial in range(3):
+        base = po.pt_mul(rng.randrange(1, po.N), G)
+        k = rng.randrange(1 << 39, 1 << 40)
+        X, Y, Z = jac_of(base, rng)
+        st = {}
+        put(st, "X", to_fe(X)); put(st, "Y", to_fe(Y)); put(st, "Z", to_fe(Z))
+        acc = base
+        for bit in bin(k)[3:]:
+            out, _ = dbl.run(st, st)
+            st = state_of(out, ("X3", "Y3", "Z3"))
+            acc = po.pt_add(acc, acc)
+            assert affine(val(st, "X"), val(st, "Y"), val(st, "Z")) == acc
+            if bit == "1":
+                sign = rng.choice((1, -1))
+                addend = (base[0], base[1] * sign % P)
+                e = {k2.replace("X.", "X1.").replace("Y.", "Y1.").replace("Z.", "Z1."): v for k2, v in st.items()}
+                if rng.random() < 0.5:
+                    X2, Y2, Z2 = jac_of(base, rng)
+                    y2 = to_fe(Y2) if sign == 1 else [-d for d in to_fe(Y2)]          # negated the way the kernels do it: digit by digit
+                    put(e, "X2", to_fe(X2)); put(e, "Y2", y2); put(e, "Z2", to_fe(Z2))
+                    out, _ = add.run(e, e)
+                else:
+                    put(e, "X2", to_fe(addend[0])); put(e, "Y2", to_fe(addend[1]))
+                    out, _ = madd.run(e, e)
+                assert val(out, "H") != 0 and val(out, "RR") != 0
+                st = state_of(out, ("X3", "Y3", "Z3"))
+                acc = po.pt_add(acc, addend)
+                assert affine(val(st, "X"), val(st, "Y"), val(st, "Z")) == acc
+            assert all(gp.STATE_ONE[c][0] <= st["%s.%d" % (c, l)] <= gp.STATE_ONE[c][1] for c in "XYZ" for l in range(8))
+    # P == +-Q: h == 0, and rr == 0 exactly for the doubling case
+    pt = po.pt_mul(rng.randrange(1, po.N), G)
+    for sign in (1, -1):
+        X1, Y1, Z1 = jac_of(pt, rng)
+        X2, Y2, Z2 = jac_of((pt[0], pt[1] * sign % P), rng)
+        e = {}
+        for n, v_ in (("X1", X1), ("Y1", Y1), ("Z1", Z1), ("X2", X2), ("Y2", Y2), ("Z2", Z2)):
+            put(e, n, to_fe(v_))
+        out, _ = add.run(e, e)
+        assert val(out, "H") == 0 and (val(out, "RR") == 0) == (sign == 1)
+        e = {}
+        for n, v_ in (("X1", X1), ("Y1", Y1), ("Z1", Z1), ("X2", pt[0]), ("Y2", pt[1] * sign % P)):
+            put(e, n, to_fe(v_))
+        out, _ = madd.run(e, e)
+        assert val(out, "H") == 0 and (val(out, "RR") == 0) == (sign == 1)
+
+
 def test_pair_add_reports_the_exceptional_cases(progs):
     rng = random.Random(78)
     G = (po.GX, po.GY)
@@ -465,11 +524,11 @@ def test_bn_pair_streams_on_gpu_match_the_interpreter_register_for_register():
 
 
 def test_tracked_generated_headers_are_what_the_generators_produce():
-    """pair29_gcn.h, pair29_bn_gcn.h, fe29_gcn.h, bn29_gcn.h and bn29_consts.h are tracked AND have Makefile rules: a header that is
+    """pair29_gcn.h, one29_gcn.h, pair29_bn_gcn.h, fe29_gcn.h, bn29_gcn.h and bn29_consts.h are tracked AND have Makefile rules: a header that is
     older than its generator by content (not by timestamp) would compile silently.  Regenerate each and compare byte for byte."""
     import subprocess
     csrc = os.path.join(ROOT, "fabric-mod_amd", "csrc")
-    for args, header in ((["gen_pair_gcn.py", "field"], "fe29_gcn.h"), (["gen_pair_gcn.py"], "pair29_gcn.h"), (["gen_pair_gcn.py", "bnfield"], "bn29_gcn.h"),
+    for args, header in ((["gen_pair_gcn.py", "field"], "fe29_gcn.h"), (["gen_pair_gcn.py"], "pair29_gcn.h"), (["gen_pair_gcn.py", "one"], "one29_gcn.h"), (["gen_pair_gcn.py", "bnfield"], "bn29_gcn.h"),
                          (["gen_pair_gcn.py", "bnpair"], "pair29_bn_gcn.h"), (["gen_bn_consts.py"], "bn29_consts.h")):
         fresh = subprocess.run([sys.executable] + args, cwd=csrc, check=True, capture_output=True).stdout
         assert fresh == open(os.path.join(csrc, header), "rb").read(), "%s is stale: run make -C fabric-mod_amd/csrc %s" % (header, header)
