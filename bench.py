@@ -56,8 +56,9 @@ HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8 TB/s spec
 # 1.09 ns (wall clock, i.e. at whatever frequency the chip sustains for that stream) = 64 lanes / t x 1024 SIMDs.
 VALU_PEAK_MAC = 64 / 1.902e-9 * 1024
 VALU_PEAK_ALU32 = 64 / 1.09e-9 * 1024
-# v_mad_i64_i32 the verify kernels actually execute per signature (static count x trip counts)
-EXECUTED_MAC_PER_VERIFY = 3.4e5
+# v_mad_i64_i32 the dominant kernel actually executes per signature (static count x trip counts, DESIGN.md section 5 "Round 6"): 177 912 in
+# the point programs + 1 760 in the inversion mod n per wavefront of 32 signatures, x 64 lanes (rounds 1-5 reported with 3.4e5)
+EXECUTED_MAC_PER_VERIFY = 3.6e5
 
 
 def pctl(xs, q):

@@ -235,7 +235,7 @@ def build_bn_sqr():
 B28, B24 = 1 << 28, 1 << 24
 STATE_P256 = {"X": (-(B28 + 4), 2 * B28 - 1, -5 * B24, 4 * B24), "Y": (-2 * B28, 2 * B28, -4 * B24, 3 * B24), "Z": (-B28, 2 * B28 - 1, -B24, 2 * B24)}
 STATE_BN = {"X": (-(B28 + 4), 2 * B28 - 1, -5 * B24, 4 * B24), "Y": (-2 * B28, 2 * B28, -4 * B24, 3 * B24), "Z": (-2 * B28, 2 * B28, -B24, 3 * B24)}
-AFFINE = (-B28, B28 - 1, 0, B24)        # fe_to_mont of a canonical residue: balanced digits, top digit of a value below p
+AFFINE = (-B28, B28 - 1, -B24, 2 * B24)  # fe_to_mont of a residue (comb entries, the key): balanced digits, a value in (-p, 2p) - generous
 
 
 def fe_range(name, c):

@@ -257,7 +257,7 @@ def test_limb_contracts_are_closed_under_every_program():
     for progs_, C in ((p256, gp.STATE_P256), (bn, gp.STATE_BN)):
         U = gp.contracts_closed(progs_, C)
         # a state that starts as an affine point is inside the contract too
-        assert all(C[k][0] <= gp.AFFINE[0] and gp.AFFINE[1] <= C[k][1] and C[k][2] <= 0 and gp.AFFINE[3] <= C[k][3] for k in "XYZ")
+        assert all(C[k][0] <= gp.AFFINE[0] and gp.AFFINE[1] <= C[k][1] and C[k][2] <= gp.AFFINE[2] and gp.AFFINE[3] <= C[k][3] for k in "XYZ")
         assert U["X"][1] < 1 << 30 and U["Y"][1] <= 1 << 29
     # ... and a contract that is too generous is refused: the tool can say no
     wide = dict(gp.STATE_P256, Y=(-4 << 28, 4 << 28, -4 << 24, 3 << 24))
