@@ -6,15 +6,22 @@ A Program is a list of abstract instructions over symbolic registers:
     "acc"          the 64-bit column accumulator, hard-wired to v[0:1] (inline asm cannot name half of a 64-bit operand)
     constants      wave-uniform SGPR operands (the Montgomery multipliers 2^9, 2^18, -2^21, 2^24, the rounding 2^28,
                    and the lane-parity mask of the two-lanes-per-signature programs)
-Two back ends consume the same list:
+Four consumers of the same list:
     emit_asm()     one GNU inline-asm statement (operands numbered outputs-first), every instruction encoded in 8 bytes
                    (VOP3, VOP2+DPP, or VOP2+literal) so that a `.p2align 3` block never leaves 8-byte alignment, with the
                    gfx940-family hazard "VALU writes a VGPR, a DPP instruction reads it as its DPP source: 2 wait states"
                    padded by s_nop where the program order does not already provide the distance (only v_mov / v_add / v_sub
                    are used in DPP form: v_subrev_u32_dpp did not compute src1 - dpp(src0) on MI355X, probed in gputest.hip);
+    emit_cxx()     (round 6) for programs without lane routing: a device function whose field products are one asm statement
+                   each and whose limb-wise operations are C++ - the compiler keeps the register allocation (one29_gcn.h);
     run()          a reference interpreter with exact 32/64-bit wrap-around semantics on an explicit (even, odd) lane
                    pair - tests/test_pair_programs.py executes the very programs the kernels run against big-integer
-                   point arithmetic, without a GPU.
+                   point arithmetic, without a GPU;
+    run_intervals()  (round 6) the same interpreter on RANGES: the proof that no 64-bit column and no 32-bit limb can wrap for
+                   any input inside a contract (gen_pair_gcn.contracts_closed / one_contracts_closed; the generator refuses
+                   to emit a header whose contract is not closed).
+A field product may take addends (r = a b + c d + ...: the addend's digits join the high columns) and may leave unsigned
+digits (two instructions per high column instead of three) - both decided per product by the generator (gen_pair_gcn.py).
 """
 
 M32 = (1 << 32) - 1

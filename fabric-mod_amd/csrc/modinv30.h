@@ -210,6 +210,19 @@ FAB_HD void modinv(u256& out, const u256& x, const modinv_info& mi) {
 #pragma unroll 1
 #endif
     for (int it = 0; it < 20; it++) {
+        // 600 division steps is the PROVED bound for 256 bits; uniformly random inputs need 502-531 (17 or 18 batches), and once g == 0 further
+        // batches only move d by multiples of M.  The inputs are public (r, s of a signature), so nothing is given away by stopping when
+        // every lane of the wavefront is done - a crafted input simply runs the full count.
+        if (it >= 17) {
+            uint32_t nz = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) nz |= (uint32_t)g.v[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (__builtin_amdgcn_ballot_w64(nz != 0) == 0) break;
+#else
+            if (nz == 0) break;
+#endif
+        }
         trans2x2 t;
         zeta = modinv_divsteps30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
         modinv_update_de(d, e, t, mi);

@@ -196,6 +196,12 @@ __device__ __forceinline__ void pair_modinv(u256& out, const u256& x, const modi
     int32_t zeta = -1;
 #pragma unroll 1
     for (int it = 0; it < 20; it++) {
+        if (it >= 17) {      // (modinv30.h modinv: random inputs are done after 17 or 18 batches; g lives on the even lanes)
+            uint32_t nz = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) nz |= (uint32_t)b.v[i];
+            if (!__any(!odd && nz != 0)) break;
+        }
         int32_t fo = pair_swap_i32(a.v[0]), go = pair_swap_i32(b.v[0]);
         uint32_t f0 = (uint32_t)(odd ? fo : a.v[0]), g0 = (uint32_t)(odd ? go : b.v[0]);
         // the division steps with one column of the transition matrix per lane - E: (u, q) from (1, 0), O: (v, r) from (0, 1) - then exchanged
