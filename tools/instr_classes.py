@@ -26,6 +26,8 @@ def classes(prog):
     text, stats = prog.emit_asm({n: "(%s)" % n for n in prog.order})
     out = {"mac": 0, "carry": 0, "route": 0, "field": 0, "hazard": stats["nops"]}
     for ins in prog.ins:
+        if ins[0] in ("prod_begin", "prod_end"):      # markers for emit_cxx, not instructions
+            continue
         c = CLASS[ins[0]]
         out[c] += 2 if ins[0] == "qn0" else 1
     # bfe29 inside wnorm is a field op, not a column carry: gcn_dsl.wnorm emits 16 of them (plus adds) per call
