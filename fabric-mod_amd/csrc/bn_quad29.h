@@ -6,7 +6,7 @@
 //     lanes 4k, 4k+1 (pair 0):  HSk   * s_sk    -  k1 * Nym                 (c = k1 + k2 lambda, bn_glv_decompose)
 //     lanes 4k+2, 4k+3 (pair 1): HRand * s_rnym  -  k2 * phi(Nym)
 // - the same split of the equation as bn_nym_split_part1 - and INSIDE a pair every point operation is one of the generated
-// two-lanes-per-point programs of pair29_bn_gcn.h (PAIRBN_DBL 985 / PAIRBN_ADD 1895 / PAIRBN_MADD 1509 instructions against
+// two-lanes-per-point programs of pair29_bn_gcn.h (PAIRBN_DBL 939 / PAIRBN_ADD 1796 / PAIRBN_MADD 1428 instructions against
 // ~1 500 / ~3 500 / ~2 600 of the one-lane formulas), exactly as p256_pair29.h does it for P-256: E (even lane) holds A = X, B = Y,
 // O (odd lane) holds B = Z between operations; limbs cross lanes with DPP quad_perm:[1,0,3,2].  The two pairs exchange their partial
 // sums with quad_perm:[2,3,0,1] (E meets E, O meets O: the pair layout survives the move) and both finish t = (pair 0) + (pair 1);

@@ -4,7 +4,7 @@
 Why: BASELINE config 2 (30 000 signatures) is 469 wavefronts for 1024 SIMDs and every wave issues one VALU instruction per
 ~4.2 cycles whatever it is - the one-signature-per-lane kernel is bound by the LENGTH of its instruction stream.  The
 eight field products of a doubling have dependency depth four, the sixteen of an addition depth eight: on a lane pair
-(even lane "E", odd lane "O", exchanged with DPP quad_perm:[1,0,3,2]) the stream is 779 / 1455 / 1169 instructions
+(even lane "E", odd lane "O", exchanged with DPP quad_perm:[1,0,3,2]) the stream is 732 / 1364 / 1104 instructions (round 6; 787 / 1463 / 1185 in rounds 2-5)
 instead of 1339 / 2678 / 1900.
 
 Lane roles are static.  Between operations   E holds A = X, B = Y   and   O holds B = Z   (O's A is don't-care).

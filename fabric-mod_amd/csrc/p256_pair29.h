@@ -4,7 +4,7 @@
 // bit: tests/test_gpu_parity.py runs both against the oracle); what changes is the shape of the instruction stream.  A
 // 30 000-signature block is 469 wavefronts on 1024 SIMDs and one wave issues one VALU instruction per ~4.2 cycles, so the
 // kernel time is the LENGTH of the per-wave stream.  Lanes 2k (E) and 2k+1 (O) share signature k: the point operations are
-// the generated programs of pair29_gcn.h (787 / 1463 / 1185 instructions for dbl / add / madd against 1339 / 2678 / 1900),
+// the generated programs of pair29_gcn.h (732 / 1364 / 1104 instructions for dbl / add / madd - round 6; one lane: 1201 / 2374 / 1642),
 // every field product is executed by both lanes on different operands, limbs cross lanes with DPP quad_perm:[1,0,3,2].
 // Between operations  E holds A = X, B = Y  and  O holds B = Z.  The scalar part (gates, s^-1 mod n, u1, u2, digits) is
 // computed redundantly by both lanes.
