@@ -1162,8 +1162,27 @@ def main():
     # 7-8 % below what the same launches do from the 26th on - `dispersion`, measured afterwards, always showed the faster figure).  A peer
     # that validates blocks does not idle between them; the steady state is what the metric means.  These launches are untimed, carry no
     # collective and come BEFORE the contract's W warm-up steps; the line reports their number (config.clock_warmup_launches).
+    clock_warmup_done = 0
     for _ in range(max(0, args.clock_warmup)):
         verify_only()
+        clock_warmup_done += 1
+    # ... and (round 6) until the launches stop getting faster: one run of the round met a box whose clocks were still climbing 100 ms after
+    # the first launch (the timed steps took 0.628 ms, the same launches 0.591 a moment later).  Groups of 20 launches, each timed with a HIP
+    # event pair on the launch stream; two consecutive groups within 1 % of each other end the warm-up, 12 groups at most.
+    if args.clock_warmup > 0:
+        prev = None
+        for _ in range(12):
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record(stream)
+            for _ in range(20):
+                verify_only()
+            g1.record(stream)
+            g1.synchronize()
+            clock_warmup_done += 20
+            ms = g0.elapsed_time(g1)
+            if prev is not None and abs(ms - prev) <= 0.01 * prev:
+                break
+            prev = ms
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -1288,7 +1307,7 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]" if n_tx == N_TX else "EXPLORATION (not the BASELINE config)") + ": block of %d tx x 3 endorsements = %d P-256 tuples per GPU, " % (n_tx, n) +
                                    "verify-only kernel via the C ABI, fresh keypair per signature, 1% invalid" +
                                    ("; %d GPUs = %d such blocks in flight (one per GPU: blocks-in-flight throughput, NOT one block sharded - that is configs2_strong)" % (world, world) if world > 1 else ""),
-                       "tuples_per_gpu": n, "tx_per_block": n_tx, "endorsements_per_tx": N_ENDORSE, "seed": SEED, "clock_warmup_launches": max(0, args.clock_warmup),
+                       "tuples_per_gpu": n, "tx_per_block": n_tx, "endorsements_per_tx": N_ENDORSE, "seed": SEED, "clock_warmup_launches": clock_warmup_done,
                        "parallelism": "1 block per GPU%s" % (" + RCCL all-gather of verdict bitmaps" if world > 1 else "")},
             "validated_tx_per_s": n_tx * world / (dt / args.steps),
             "value_from_idle_clocks": from_idle,

@@ -3,12 +3,17 @@
 kernel's launches INSIDE the contract's timed region.  bench.py launches p256_verify_pair_lds_kernel<256> in this order: --clock-warmup
 (60) launches, W warm-up steps, the K timed steps, then the dispersion leg and the other legs (whose launches of the same kernel - the
 mixed leg's run beside the idemix kernels - are in the --stats average but have nothing to do with `roofline.kernel_ms`).
-usage: timed_region_rocprof.py <results.db> [clock_warmup=60 W=5 K=20]"""
+usage: timed_region_rocprof.py <results.db> [clock_warmup=60 W=5 K=20]     clock_warmup may be the path of the bench line of the same run:
+its config.clock_warmup_launches is then used (round 6: the warm-up lasts until the launches stop getting faster, so the number varies)."""
 import sqlite3
 import sys
 
 db = sys.argv[1]
-cw, w, k = (int(x) for x in (sys.argv[2:5] + ["60", "5", "20"][len(sys.argv) - 2:]))
+args = sys.argv[2:5] + ["60", "5", "20"][len(sys.argv) - 2:]
+if not args[0].isdigit():
+    import json
+    args[0] = str(json.loads(open(args[0]).read().strip().splitlines()[-1])["config"]["clock_warmup_launches"])
+cw, w, k = (int(x) for x in args)
 c = sqlite3.connect(db)
 rows = sorted((s, e) for name, s, e in c.execute("select name, start, end from kernels") if "p256_verify_pair_lds_kernel" in name)
 d = [(e - s) / 1e3 for s, e in rows]

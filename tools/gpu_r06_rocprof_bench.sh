@@ -12,7 +12,7 @@ for i in 1 2; do
   tail -n1 $O/r06_rocprof_run${i}.out > $O/r06_rocprof_run${i}_line.json
   f=$(find /tmp/prof_bench -name "*.db" -printf "%s %p\n" 2>/dev/null | sort -n | tail -1 | cut -d" " -f2)
   python $R/profiles/summarize_rocprof.py "$f" > $O/r06_rocprof_run${i}_stats.txt 2>&1
-  python $R/profiles/timed_region_rocprof.py "$f" 60 5 20 >> $O/r06_rocprof_run${i}_stats.txt 2>&1
+  python $R/profiles/timed_region_rocprof.py "$f" $O/r06_rocprof_run${i}_line.json 5 20 >> $O/r06_rocprof_run${i}_stats.txt 2>&1
   tail -8 $O/r06_rocprof_run${i}_stats.txt
   python3 - "$f" <<'PY'
 import sqlite3, sys
