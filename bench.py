@@ -225,6 +225,8 @@ def compact_line(out, detail_path="bench_detail.json"):
         "configs2_strong_value": _dig(out, "configs2_strong", "value"),
         "configs3_fused_value": _dig(out, "configs3_fused", "value"),
         "value_two_blocks_in_flight": _dig(out, "two_blocks_in_flight", "value"),
+        "registered_keys_value": _dig(out, "registered_keys", "tables_8bit", "value"),
+        "registered_keys_value_16bit_tables": _dig(out, "registered_keys", "tables_16bit", "value"),
         "configs2_inprocess_value": _dig(out, "shard_of_8", "configs2_inprocess_value") if out.get("n_gpus", 1) == 1 else _dig(out, "configs2_inprocess", "legs", 0, "value"),
         "configs2_shard_of_8_ms": _dig(out, "shard_of_8", "configs2_shard_of_8_ms"),
         "configs2_inprocess_shard_of_8_ms": _dig(out, "shard_of_8", "configs2_inprocess_shard_of_8_ms"),
@@ -1373,6 +1375,20 @@ def main():
                 out["shard_of_8"] = shard_of_8_leg(ctx, torch, np, fabgpu, _co8, block, dev, got, n, ms_per_step, steps=args.steps)
             except Exception as e:                                                                         # noqa: BLE001
                 out["shard_of_8"] = {"error": repr(e)[:300]}
+        if world == 1 and extras and n_tx == N_TX:
+            # Registered keys (BCCSP.KeyImport; SURVEY 8(d) "realistic" variant: the endorsers of a channel are a pool of 16 keys, msp/cache/cache.go:14-18):
+            # tools/bench_keyed.py in processes of their own - a context as the peer makes it, and one with FABGPU_FLAG_KEY_TABLES_16BIT
+            # (round 6: 80 MiB comb tables for the registered keys).  Reported beside the headline, never as `value`.
+            try:
+                import subprocess
+                rk = {}
+                for name, extra in (("tables_8bit", []), ("tables_16bit", ["--tables16"])):
+                    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_keyed.py"), "--n", str(n), "--keys", "16", "--steps", "50"] + extra,
+                                        capture_output=True, text=True, timeout=120)
+                    rk[name] = json.loads(pr.stdout.strip().splitlines()[-1]) if pr.returncode == 0 and pr.stdout.strip() else {"error": (pr.stderr or "")[-300:]}
+                out["registered_keys"] = rk
+            except Exception as e:                                                                         # noqa: BLE001
+                out["registered_keys"] = {"error": repr(e)[:300]}
         if world == 1 and extras and not args.no_two_streams:
             # Two blocks in flight on ONE GPU (two channels validating at once): a 30 000-tuple block is one wave per SIMD, and a lone wave
             # issues one instruction per ~4.3 cycles - a second block on a second stream fills the issue slots the first leaves empty.

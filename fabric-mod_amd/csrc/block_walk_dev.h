@@ -330,6 +330,7 @@ bool key_table_build(const uint8_t* qx32, const uint8_t* qy32, int32_t* out);
 // n keys (qxy: n x 64 bytes X || Y, all on the curve) on one context, their comb tables built on the device (keytab_kernels.hip)
 int key_register_batch(fabgpu_ctx* ctx, int n, const uint8_t* qxy, uint32_t* key_ids);
 int64_t gtab_compare_with_host(fabgpu_ctx* ctx);   // TEST HOOK support: first differing word of the generator comb vs the host builder's, -1 = identical
+int64_t key_tables16_check(fabgpu_ctx* ctx, uint32_t key_id);   // TEST HOOK support: waits for the 16-bit key tables, cross-checks one against the key's 8-bit table
 int key_table_copy(fabgpu_ctx* ctx, uint32_t key_id, int32_t* out);   // TEST HOOK support: a registered key's device table, to the host
 int key_register_many_prebuilt(fabgpu_ctx* const* ctxs, int n, const uint8_t* qx32, const uint8_t* qy32, const int32_t* table, uint32_t* key_ids);
 // the duration of the last timed launch of a FABGPU_FLAG_TIME_KERNELS context (ms; < 0: none) - read by the test-hook library

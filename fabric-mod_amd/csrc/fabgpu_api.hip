@@ -165,9 +165,22 @@ struct fabgpu_ctx {
     std::mutex kmu;
     std::vector<int32_t*> ktabs;
     std::map<std::string, uint32_t> key_ids;   // qx||qy -> id
-    const int32_t** d_ktabs = nullptr;
-    size_t d_ktabs_cap = 0;
+    const int32_t** d_ktabs = nullptr;      // KTAB_STRIDE pointers per key: [2 k] the 8-bit comb, [2 k + 1] the 16-bit comb or nullptr
+    size_t d_ktabs_cap = 0;                 // (in keys)
     std::vector<void*> retired;   // outgrown d_ktabs arrays, freed at shutdown
+    // Round 6, FABGPU_FLAG_KEY_TABLES_16BIT: a registered key also gets a 16-bit comb (CombTab<16>, 80 MiB - the generator's own format),
+    // built on stream_keytab BEHIND the registration (nobody waits for it; its pointer reaches d_ktabs[2 k + 1] by a copy queued after
+    // the build, so a launch sees nullptr or a finished table).  Up to KTAB16_MAX keys: 5 GiB of a 288 GB device.  All under kmu.
+    bool key_tables_16 = false;
+    hipStream_t stream_keytab16 = nullptr;  // (its own: a registration waits on stream_keytab for the 8-bit table and must not find an 80 MiB build queued there)
+    static constexpr size_t KTAB16_MAX = 64;
+    std::vector<void*> ktab16;              // per key id: the table, or nullptr
+    std::vector<void*> ktab16_slabs;        // tables come from slabs of KTAB16_SLAB (the first one at fabgpu_init: a registration must not pay for an 80 MiB hipMalloc)
+    static constexpr size_t KTAB16_SLAB = 8;
+    size_t ktab16_carved = 0;               // tables handed out of the slabs so far
+    void* ktab16_rooms = nullptr;           // KTAB16_MAX builders' rooms (key + pointer + scratch), one allocation
+    size_t ktab16_room_bytes = 0;
+    size_t ktab16_count = 0;
     // Where the tables live: slabs of KTAB_SLAB tables (a table is never freed before shutdown, and hipMalloc / hipFree per table were
     // most of what a registration cost once the tables were built on the device: 4.7 ms of runtime calls around 0.8 ms of kernels for a
     // channel's six signers).  ktab_free: tables whose installation failed.  All under kmu.
@@ -356,7 +369,8 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     if (!out) return FABGPU_EINVAL;
     *out = nullptr;
     if (cfg && (cfg->flags & ~(uint32_t)(FABGPU_FLAG_ONE_LANE_ONLY | FABGPU_FLAG_TIME_KERNELS | FABGPU_FLAG_NO_QUAD | FABGPU_FLAG_PAIR_TABLE_LDS |
-                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL | FABGPU_FLAG_NO_WIDE | FABGPU_FLAG_NYM_FUSED_HASH | FABGPU_FLAG_NYM_NO_SIDE_STREAM)) != 0) return FABGPU_EINVAL;
+                                          FABGPU_FLAG_PAIR_TABLE_GLOBAL | FABGPU_FLAG_NO_WIDE | FABGPU_FLAG_NYM_FUSED_HASH | FABGPU_FLAG_NYM_NO_SIDE_STREAM |
+                                          FABGPU_FLAG_KEY_TABLES_16BIT)) != 0) return FABGPU_EINVAL;
     if (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL)) return FABGPU_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FABGPU_ENODEV;
@@ -376,6 +390,7 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
     ctx->allow_quad = !(cfg && (cfg->flags & FABGPU_FLAG_NO_QUAD));
     ctx->nym_two_phase = !(cfg && (cfg->flags & FABGPU_FLAG_NYM_FUSED_HASH));
     ctx->nym_side_stream = !(cfg && (cfg->flags & FABGPU_FLAG_NYM_NO_SIDE_STREAM));
+    ctx->key_tables_16 = cfg && (cfg->flags & FABGPU_FLAG_KEY_TABLES_16BIT);
     // (the wide form is built from the two-lane form's reasons: a context that may not use two lanes per signature does not use eight)
     ctx->allow_wide = ctx->allow_pair && !(cfg && (cfg->flags & FABGPU_FLAG_NO_WIDE));
     ctx->pair_table_lds = cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_LDS) ? 1 : (cfg && (cfg->flags & FABGPU_FLAG_PAIR_TABLE_GLOBAL) ? 0 : pair_table_default());
@@ -422,6 +437,22 @@ int fabgpu_init(const fabgpu_cfg* cfg, fabgpu_ctx** out) {
             std::vector<int32_t> tab(GTab16::TABLE_WORDS);   // 80 MiB, ~0.2 s on 16 host threads
             build_g_comb_table16(tab.data());
             if (hipMemcpy(ctx->d_gtab, tab.data(), sizeof(int32_t) * GTab16::TABLE_WORDS, hipMemcpyHostToDevice) != hipSuccess) { rc = FABGPU_ELAUNCH; break; }
+        }
+        if (ctx->key_tables_16) {
+            // FABGPU_FLAG_KEY_TABLES_16BIT: the first slab of 16-bit key tables (8 x 80 MiB), the builders' rooms and their stream now, so that a
+            // registration only queues launches (best effort: without them the keys are served by their 8-bit combs)
+            void* slab = nullptr;
+            if (hipMalloc(&slab, sizeof(int32_t) * GTab16::TABLE_WORDS * fabgpu_ctx::KTAB16_SLAB) == hipSuccess) ctx->ktab16_slabs.push_back(slab);
+            else (void)hipGetLastError();
+            ctx->ktab16_room_bytes = (keytab16_scratch_bytes() + 128 + 255) & ~(size_t)255;
+            if (hipMalloc(&ctx->ktab16_rooms, ctx->ktab16_room_bytes * fabgpu_ctx::KTAB16_MAX) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->ktab16_rooms = nullptr;
+            }
+            if (hipStreamCreateWithFlags(&ctx->stream_keytab16, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->stream_keytab16 = nullptr;
+            }
         }
         if (cfg && cfg->max_batch) {
             size_t n = cfg->max_batch;
@@ -483,7 +514,11 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         ctx->idtab_buf.release();
         for (auto& sl : ctx->staged_slots)
             if (sl.d) hipFree(sl.d);
+        if (ctx->stream_keytab16) { hipStreamSynchronize(ctx->stream_keytab16); hipStreamDestroy(ctx->stream_keytab16); }       // (16-bit key tables may still be building)
         if (ctx->d_ktabs) hipFree((void*)ctx->d_ktabs);
+        for (void* t : ctx->ktab16_slabs)
+            if (t) hipFree(t);
+        if (ctx->ktab16_rooms) hipFree(ctx->ktab16_rooms);
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
             if (w.done) hipEventDestroy(w.done);
@@ -702,6 +737,7 @@ int fabgpu_idemix_nym_verify_batch_dev(fabgpu_ctx* ctx, size_t n, const void* ar
 // ---- registered public keys -------------------------------------------------------------------------
 // one key's comb table into one context: id of the key there (idempotent per (qx, qy)); `tab` = the table, built by the caller
 static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32_t* d, uint32_t* key_id);
+static void key_queue_table16_locked(fabgpu_ctx* ctx, const std::string& k, uint32_t id);
 // (kmu held, the context's device current) room for one table: out of the current slab, a new slab when that is used up
 static int32_t* ktab_alloc_locked(fabgpu_ctx* ctx) {
     if (!ctx->ktab_free.empty()) {
@@ -747,6 +783,50 @@ static int key_install(fabgpu_ctx* ctx, const std::string& k, const std::vector<
     return key_install_table_locked(ctx, k, d, key_id);
 }
 // (kmu held, the context's device current) a finished table in device memory becomes key number ktabs.size(); takes ownership of d
+// FABGPU_FLAG_KEY_TABLES_16BIT: queue the build of key `id`'s 16-bit comb on stream_keytab and, behind it, the copy of its pointer into
+// d_ktabs[2 id + 1].  Nothing waits: the registration returns, launches on other streams use the 8-bit comb until the pointer is there.
+// kmu is held.  Failures (memory, a launch) leave the key without a 16-bit comb.
+static void key_queue_table16_locked(fabgpu_ctx* ctx, const std::string& k, uint32_t id) {
+    if (ctx->ktab16_count >= fabgpu_ctx::KTAB16_MAX || ctx->fault) return;
+    if (ctx->ktab16.size() <= id) ctx->ktab16.resize((size_t)id + 1, nullptr);
+    if (!ctx->stream_keytab16 && hipStreamCreateWithFlags(&ctx->stream_keytab16, hipStreamNonBlocking) != hipSuccess) return;
+    const size_t tab_bytes = sizeof(int32_t) * GTab16::TABLE_WORDS;
+    if (!ctx->ktab16_rooms) {
+        ctx->ktab16_room_bytes = (keytab16_scratch_bytes() + 128 + 255) & ~(size_t)255;
+        if (hipMalloc(&ctx->ktab16_rooms, ctx->ktab16_room_bytes * fabgpu_ctx::KTAB16_MAX) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->ktab16_rooms = nullptr;
+            return;
+        }
+    }
+    if (ctx->ktab16_carved == ctx->ktab16_slabs.size() * fabgpu_ctx::KTAB16_SLAB) {
+        void* slab = nullptr;
+        if (hipMalloc(&slab, tab_bytes * fabgpu_ctx::KTAB16_SLAB) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        ctx->ktab16_slabs.push_back(slab);
+    }
+    void* tab = (uint8_t*)ctx->ktab16_slabs.back() + tab_bytes * (ctx->ktab16_carved % fabgpu_ctx::KTAB16_SLAB);
+    void* room = (uint8_t*)ctx->ktab16_rooms + ctx->ktab16_room_bytes * ctx->ktab16_count;
+    hipStream_t st = ctx->stream_keytab16;
+    // room: [0, 64) the key, [64, 72) the table's address (what the entries kernel reads), [128, ...) scratch
+    uint8_t head[72];
+    memcpy(head, k.data(), 64);
+    memcpy(head + 64, &tab, sizeof(void*));
+    hipError_t e = hipMemcpyAsync(room, head, sizeof(head), hipMemcpyHostToDevice, st);     // (pageable source: staged by the runtime before the call returns)
+    if (e == hipSuccess) e = launch_keytab16_build(1, room, (void* const*)((uint8_t*)room + 64), (uint8_t*)room + 128, st);
+    if (e == hipSuccess) e = hipMemcpyAsync((void*)(ctx->d_ktabs + KTAB_STRIDE * (size_t)id + 1), (uint8_t*)room + 64, sizeof(void*), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        hipStreamSynchronize(st);                       // (the table's place in the slab and the room are simply used again by the next key)
+        return;
+    }
+    ctx->ktab16[id] = tab;
+    ctx->ktab16_carved++;
+    ctx->ktab16_count++;
+}
+
 static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32_t* d, uint32_t* key_id) {
     if (ctx->ktabs.size() >= FABGPU_MAX_KEYS) {
         ctx->ktab_free.push_back(d);
@@ -757,22 +837,33 @@ static int key_install_table_locked(fabgpu_ctx* ctx, const std::string& k, int32
     if (ctx->ktabs.size() + 1 > ctx->d_ktabs_cap) {
         size_t cap = ctx->d_ktabs_cap ? ctx->d_ktabs_cap * 2 : 64;
         const int32_t** nd = nullptr;
-        if (hipMalloc((void**)&nd, cap * sizeof(int32_t*)) != hipSuccess) {
+        if (hipMalloc((void**)&nd, cap * KTAB_STRIDE * sizeof(int32_t*)) != hipSuccess) {
             ctx->ktab_free.push_back(d);
             return FABGPU_ENOMEM;
         }
-        if (!ctx->ktabs.empty()) hipMemcpy((void*)nd, ctx->ktabs.data(), ctx->ktabs.size() * sizeof(int32_t*), hipMemcpyHostToDevice);
+        if (!ctx->ktabs.empty()) {
+            // (the 16-bit builds queued on stream_keytab write their pointers into the OLD array: let them land before it is copied)
+            if (ctx->ktab16_count && ctx->stream_keytab16) hipStreamSynchronize(ctx->stream_keytab16);
+            std::vector<const int32_t*> both(ctx->ktabs.size() * KTAB_STRIDE, nullptr);
+            for (size_t i = 0; i < ctx->ktabs.size(); i++) {
+                both[KTAB_STRIDE * i] = ctx->ktabs[i];
+                both[KTAB_STRIDE * i + 1] = i < ctx->ktab16.size() ? (const int32_t*)ctx->ktab16[i] : nullptr;
+            }
+            hipMemcpy((void*)nd, both.data(), both.size() * sizeof(int32_t*), hipMemcpyHostToDevice);
+        }
         if (ctx->d_ktabs) ctx->retired.push_back((void*)ctx->d_ktabs);
         ctx->d_ktabs = nd;
         ctx->d_ktabs_cap = cap;
     }
-    if (hipMemcpy((void*)(ctx->d_ktabs + ctx->ktabs.size()), &d, sizeof(int32_t*), hipMemcpyHostToDevice) != hipSuccess) {
+    const int32_t* slot[KTAB_STRIDE] = {d, nullptr};
+    if (hipMemcpy((void*)(ctx->d_ktabs + KTAB_STRIDE * ctx->ktabs.size()), slot, sizeof(slot), hipMemcpyHostToDevice) != hipSuccess) {
         ctx->ktab_free.push_back(d);
         return FABGPU_ELAUNCH;
     }
     ctx->ktabs.push_back(d);
     *key_id = (uint32_t)(ctx->ktabs.size() - 1);
     ctx->key_ids[k] = *key_id;
+    if (ctx->key_tables_16) key_queue_table16_locked(ctx, k, *key_id);    // (best effort: a key without one is served by its 8-bit comb)
     return FABGPU_OK;
 }
 
@@ -2828,6 +2919,39 @@ int64_t gtab_compare_with_host(fabgpu_ctx* ctx) {
     for (size_t i = 0; i < host.size(); i++)
         if (host[i] != dev[i]) return (int64_t)i;
     return -1;
+}
+// TEST HOOK support (FABGPU_FLAG_KEY_TABLES_16BIT): waits for the queued builds, then checks key `key_id`'s 16-bit comb against its 8-bit
+// comb - T16[w][d] = T8[2 w][d] and T16[w][256 d] = T8[2 w + 1][d] for d = 1 .. 255, entry for entry (two tables built by different
+// launches that must agree where they overlap).  Returns the number of 16-bit tables of the context; -1: the key has none; -2: error;
+// -(1000 + w): window w disagrees.
+int64_t key_tables16_check(fabgpu_ctx* ctx, uint32_t key_id) {
+    if (!ctx) return -2;
+    DeviceGuard g(ctx->device);
+    void* t16 = nullptr;
+    int32_t* t8 = nullptr;
+    int64_t count = 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->kmu);
+        if (ctx->stream_keytab16 && hipStreamSynchronize(ctx->stream_keytab16) != hipSuccess) return -2;
+        if (key_id >= ctx->ktabs.size()) return -2;
+        count = (int64_t)ctx->ktab16_count;
+        t8 = ctx->ktabs[key_id];
+        t16 = key_id < ctx->ktab16.size() ? ctx->ktab16[key_id] : nullptr;
+    }
+    if (!t16) return -1;
+    const int32_t* slot[KTAB_STRIDE] = {nullptr, nullptr};
+    if (hipMemcpy(slot, (const void*)(ctx->d_ktabs + KTAB_STRIDE * (size_t)key_id), sizeof(slot), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    if (slot[0] != t8 || slot[1] != (const int32_t*)t16) return -2;       // the device's pointer array says the same
+    std::vector<int32_t> h8(KeyTab8::TABLE_WORDS), e16(COMB_ENTRY_WORDS);
+    if (hipMemcpy(h8.data(), t8, sizeof(int32_t) * KeyTab8::TABLE_WORDS, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    for (int w = 0; w < GTab16::WINDOWS; w++)
+        for (uint32_t d = 1; d < 256; d++)
+            for (int hi = 0; hi < 2; hi++) {
+                const size_t at16 = GTab16::index(w, hi ? d << 8 : d), at8 = KeyTab8::index(2 * w + hi, d);
+                if (hipMemcpy(e16.data(), (const int32_t*)t16 + at16, sizeof(int32_t) * COMB_ENTRY_WORDS, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+                if (memcmp(e16.data(), &h8[at8], sizeof(int32_t) * COMB_ENTRY_WORDS) != 0) return -(1000 + w);
+            }
+    return count;
 }
 int key_register_batch(fabgpu_ctx* ctx, int n, const uint8_t* qxy, uint32_t* key_ids) { return key_register_batch_dev(ctx, n, qxy, key_ids); }
 // TEST HOOK support: the device's table of key `key_id` copied to the host (KeyTab8::TABLE_WORDS words)

@@ -22,6 +22,9 @@ int fabgpu_test_key_table_host(const uint8_t* qx32, const uint8_t* qy32, int32_t
 /* TEST HOOK: the context's generator comb (80 MiB, built on the device at fabgpu_init since round 6) against the host builder's: the
  * index of the first differing 32-bit word, -1 identical, -2 error */
 long long fabgpu_test_gtab_compare_with_host(fabgpu_ctx* ctx);
+/* FABGPU_FLAG_KEY_TABLES_16BIT: waits for the queued builds; the number of 16-bit key tables, after key_id's was checked entry for entry against
+ * the key's 8-bit table where the two overlap (-1: the key has none, -2: error, -(1000 + w): window w disagrees) */
+long long fabgpu_test_key_tables16(fabgpu_ctx* ctx, uint32_t key_id);
 /* TEST HOOK: while on, the idemix four-lane form queues its side launch (the fixed-base terms) BEHIND the commitment launch, so that
  * every commitment wavefront gives up on its records and computes the terms itself, and every side wavefront skips its rows. */
 void fabgpu_test_nym_side_after(fabgpu_ctx* ctx, int on);

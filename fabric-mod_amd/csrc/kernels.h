@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 namespace fab {
+constexpr int KTAB_STRIDE = 2;       // the device's array of key tables: [2 k] the 8-bit comb of key k (CombTab<8>, 640 KiB), [2 k + 1] its 16-bit comb (80 MiB) or nullptr
 constexpr int VERIFY_BLOCK = 256;         // 4 wavefronts per workgroup, one per SIMD
 constexpr int VERIFY_MAX_WGS = 256;       // persistent workgroup slots: one per CU (see kernels.hip for why not two)
 constexpr int VERIFY_PAIR_MAX = 32768;    // up to here two lanes per signature (one round of 256 workgroups x 128 signatures)
@@ -130,4 +131,7 @@ hipError_t launch_keytab_build(uint32_t n_keys, const void* qxy, void* const* ta
 // ... and the generator's 16-bit comb (80 MiB) at fabgpu_init
 size_t gtab_scratch_bytes();
 hipError_t launch_gtab_build(void* d_tab, void* scratch, hipStream_t st);
+// ... and a registered key's 16-bit comb in the same format (FABGPU_FLAG_KEY_TABLES_16BIT); scratch: keytab16_scratch_bytes() per key
+size_t keytab16_scratch_bytes();
+hipError_t launch_keytab16_build(uint32_t n_keys, const void* qxy, void* const* tabs, void* scratch, hipStream_t st);
 }  // namespace fab

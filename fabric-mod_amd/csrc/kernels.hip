@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(BLOCK, 1) p256_verify_pair_lds_kernel(uint32_t
 }
 
 // Registered public keys (fabgpu_p256_key_register): every signature names a key whose 8-bit comb table is resident on the
-// device, so u2*Q is 32 mixed additions like u1*G: no doublings, no per-lane table, no workspace.  ktabs[k] = table of key k.
+// device, so u2*Q is 32 mixed additions like u1*G: no doublings, no per-lane table, no workspace.  ktabs[KTAB_STRIDE k] = table of key k,
+// ktabs[KTAB_STRIDE k + 1] = its 16-bit comb or nullptr (round 6, FABGPU_FLAG_KEY_TABLES_16BIT: 16 mixed additions when a whole wavefront has them).
 // An out-of-range key id reports status 4 ("use bccsp/sw"), never a verdict.
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 2) p256_verify_keyed_kernel(uint32_t n, const uint32_t* __restrict__ key_id, uint32_t nkeys,
@@ -170,12 +171,13 @@ __global__ void __launch_bounds__(BLOCK, 2) p256_verify_keyed_kernel(uint32_t n,
         uint32_t ic = active ? i : (n - 1);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
-        KeyTab8 kt{ktabs[kok ? kid : 0]};
+        KeyTab8 kt{ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0)]};
+        const int32_t* kt16 = ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0) + 1];
         u256 ve, vr, vs;
         load_be_field(ve, e, ic);
         load_be_field(vr, r, ic);
         load_be_field(vs, s, ic);
-        uint32_t st = p256_verify_keyed_core29(ve, vr, vs, gt, kt);
+        uint32_t st = __all(kt16 != nullptr) ? p256_verify_keyed_core29(ve, vr, vs, gt, GTab16{kt16}) : p256_verify_keyed_core29(ve, vr, vs, gt, kt);
         if (!kok) st = ST_OFF_CURVE;
         emit_verdict(i, active, st, verdict_bits, status);
     }
@@ -197,12 +199,13 @@ __global__ void __launch_bounds__(BLOCK, 2) p256_verify_keyed_pair_kernel(uint32
         uint32_t ic = active ? i : (n - 1);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
-        const int32_t* kt = ktabs[kok ? kid : 0];
+        const int32_t* kt = ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0)];
+        const int32_t* kt16 = ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0) + 1];
         u256 ve, vr, vs;
         load_be_field(ve, e, ic);
         load_be_field(vr, r, ic);
         load_be_field(vs, s, ic);
-        uint32_t st = p256_verify_keyed_pair29(ve, vr, vs, gtab, kt, odd);
+        uint32_t st = p256_verify_keyed_pair29(ve, vr, vs, gtab, kt, kt16, odd);
         if (!kok) st = ST_OFF_CURVE;
         pair_emit_verdict(i, n, active, odd, st, verdict32, status);
     }
@@ -227,13 +230,14 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_kernel(uint
         emit_digest(pre, i, active, h);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
-        KeyTab8 kt{ktabs[kok ? kid : 0]};
+        KeyTab8 kt{ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0)]};
+        const int32_t* kt16 = ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0) + 1];
         u256 ve, vr, vs;
 #pragma unroll
         for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];
         load_be_field(vr, r, ic);
         load_be_field(vs, s, ic);
-        uint32_t st = p256_verify_keyed_core29(ve, vr, vs, gt, kt);
+        uint32_t st = __all(kt16 != nullptr) ? p256_verify_keyed_core29(ve, vr, vs, gt, GTab16{kt16}) : p256_verify_keyed_core29(ve, vr, vs, gt, kt);
         if (!kok) st = ST_OFF_CURVE;
         emit_verdict(i, active, st, verdict_bits, status);
     }
@@ -259,13 +263,14 @@ __global__ void __launch_bounds__(BLOCK, 2) sha256_p256_verify_keyed_pair_kernel
         emit_digest(pre, i, active && !odd, h);
         uint32_t kid = key_id[ic];
         bool kok = kid < nkeys;
-        const int32_t* kt = ktabs[kok ? kid : 0];
+        const int32_t* kt = ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0)];
+        const int32_t* kt16 = ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0) + 1];
         u256 ve, vr, vs;
 #pragma unroll
         for (int k = 0; k < 8; k++) ve.w[k] = h[7 - k];
         load_be_field(vr, r, ic);
         load_be_field(vs, s, ic);
-        uint32_t st = p256_verify_keyed_pair29(ve, vr, vs, gtab, kt, odd);
+        uint32_t st = p256_verify_keyed_pair29(ve, vr, vs, gtab, kt, kt16, odd);
         if (!kok) st = ST_OFF_CURVE;
         pair_emit_verdict(i, n, active, odd, st, verdict32, status);
     }

@@ -152,6 +152,12 @@ hipError_t launch_keytab_build(uint32_t n_keys, const void* qxy, void* const* ta
     return launch_comb_build<KeyTab8>(n_keys, qxy, tabs, scratch, st);
 }
 
+// A registered key's 16-bit comb (FABGPU_FLAG_KEY_TABLES_16BIT): the generator's format for any base point, same three launches.
+size_t keytab16_scratch_bytes() { return comb_scratch_bytes<GTab16>(1); }
+hipError_t launch_keytab16_build(uint32_t n_keys, const void* qxy, void* const* tabs, void* scratch, hipStream_t st) {
+    return launch_comb_build<GTab16>(n_keys, qxy, tabs, scratch, st);
+}
+
 // The GENERATOR's comb (CombTab<16>: 16 windows x 65 535 affine points, 80 MiB) built the same way at fabgpu_init: one million lanes of
 // at most fifteen doublings and fifteen mixed additions each - 2-3 ms of kernels against 0.2 s on sixteen host threads plus an 80 MiB
 // upload (and every test context of the GPU suite used to pay that).  d_tab: GTab16::TABLE_WORDS words of device memory; scratch:

@@ -442,6 +442,7 @@ __device__ __forceinline__ void pair_combined_mult29(pair_pt& Rr, bool& r_inf, c
 }
 
 // R = u1*G + u2*Q with both points on comb tables (registered key): 16 + 32 pair mixed additions.
+template <class KTab = KeyTab8>
 __device__ __forceinline__ void pair_combined_mult_keyed29(pair_pt& Rr, bool& r_inf, const u256& u1, const u256& u2,
                                                            const int32_t* __restrict__ gtab, const int32_t* __restrict__ ktab, bool odd) {
     const fe ONE = {FE29_R1};
@@ -452,7 +453,7 @@ __device__ __forceinline__ void pair_combined_mult_keyed29(pair_pt& Rr, bool& r_
     seed.A = gx;
     fe_sel(seed.B, odd, ONE, gy);
     bool s_inf, t_inf;
-    pair_comb_mult29<KeyTab8>(T, t_inf, u2, ktab, seed, odd);
+    pair_comb_mult29<KTab>(T, t_inf, u2, ktab, seed, odd);
     pair_comb_mult29<GTab16>(S, s_inf, u1, gtab, seed, odd);
     pair_final_add29(Rr, r_inf, S, s_inf, T, t_inf, odd);
 }
@@ -507,14 +508,17 @@ __device__ __forceinline__ uint32_t p256_verify_pair29(const u256& qx, const u25
 }
 
 // Registered key (p256_verify_keyed_core29): status valid on the EVEN lane.
+// ktab16: the key's 16-bit comb (round 6: FABGPU_FLAG_KEY_TABLES_16BIT; nullptr while the key has none) - a wavefront all of whose keys
+// have one does 16 mixed additions for u2*Q instead of 32.
 __device__ __forceinline__ uint32_t p256_verify_keyed_pair29(const u256& e, const u256& r, const u256& s, const int32_t* __restrict__ gtab,
-                                                              const int32_t* __restrict__ ktab, bool odd) {
+                                                              const int32_t* __restrict__ ktab, const int32_t* __restrict__ ktab16, bool odd) {
     uint32_t early = range_status(r, s);
     u256 u1, u2;
     pair_ecdsa_scalars29(u1, u2, e, r, s, odd);
     pair_pt Rr;
     bool r_inf;
-    pair_combined_mult_keyed29(Rr, r_inf, u1, u2, gtab, ktab, odd);
+    if (__all(ktab16 != nullptr)) pair_combined_mult_keyed29<GTab16>(Rr, r_inf, u1, u2, gtab, ktab16, odd);
+    else pair_combined_mult_keyed29<KeyTab8>(Rr, r_inf, u1, u2, gtab, ktab, odd);
     bool ok = pair_x_equals_r29(Rr, r_inf, r);
     uint32_t st = ok ? ST_VALID : ST_BAD_MATH;
     return early != ST_VALID ? early : st;

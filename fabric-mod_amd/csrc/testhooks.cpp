@@ -35,6 +35,7 @@ int fabgpu_test_key_table(fabgpu_ctx* ctx, uint32_t key_id, int32_t* out_words, 
     return fab::key_table_copy(ctx, key_id, out_words);
 }
 long long fabgpu_test_gtab_compare_with_host(fabgpu_ctx* ctx) { return (long long)fab::gtab_compare_with_host(ctx); }
+long long fabgpu_test_key_tables16(fabgpu_ctx* ctx, uint32_t key_id) { return (long long)fab::key_tables16_check(ctx, key_id); }
 int fabgpu_test_key_table_host(const uint8_t* qx32, const uint8_t* qy32, int32_t* out_words, size_t cap_words) {
     if (cap_words < fab::key_table_words()) return FABGPU_ETOOBIG;
     return fab::key_table_build(qx32, qy32, out_words) ? FABGPU_OK : FABGPU_EINVAL;

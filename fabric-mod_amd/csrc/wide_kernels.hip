@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(64 * W, 1) p256_wide_pre_kernel(uint32_t n, co
         const uint32_t ic = active ? i : (n - 1);
         const uint32_t kid = key_id[ic];
         const bool kok = kid < nkeys;
-        KeyTab8 kt{ktabs[kok ? kid : 0]};
+        KeyTab8 kt{ktabs[KTAB_STRIDE * (size_t)(kok ? kid : 0)]};
         u256 vr, vs;
         load_be_field(vr, r, ic);
         load_be_field(vs, s, ic);

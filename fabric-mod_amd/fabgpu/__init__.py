@@ -33,6 +33,7 @@ FLAG_NYM_FUSED_HASH = 64  # fabgpu.h FABGPU_FLAG_NYM_FUSED_HASH (idemix four-lan
 FLAG_NO_QUAD = 4         # fabgpu.h FABGPU_FLAG_NO_QUAD (idemix: never the four-lanes-per-signature kernel)
 FLAG_PAIR_TABLE_LDS = 8      # fabgpu.h: the verify-only pair kernel keeps its per-signature table in LDS
 FLAG_PAIR_TABLE_GLOBAL = 16  # ... in the global workspace
+FLAG_KEY_TABLES_16BIT = 256  # fabgpu.h: registered keys also get a 16-bit comb (80 MiB each, built behind the registration)
 FLAG_NO_WIDE = 32            # fabgpu.h: registered keys never on the eight-lanes-per-signature two-phase kernels (launches <= 8 192 signatures)
 ST_VALID, ST_BAD_MATH, ST_HIGH_S, ST_RANGE, ST_OFF_CURVE = 0, 1, 2, 3, 4
 
@@ -123,7 +124,7 @@ ABI_SYMBOLS = [
 HOOK_SYMBOLS = [
     "fabgpu_synth_batch", "fabgpu_last_kernel_ms", "fabgpu_csp_block_walk_compare", "fabgpu_block_walk_twopass_compare", "fabgpu_gate_sig_fast",
     "fabgpu_gate_sig_any", "fabgpu_csp_idfix_probe", "fabgpu_csp_gate_probe", "fabgpu_identity_table_hash", "fabgpu_test_nym_side_after",
-    "fabgpu_test_key_table", "fabgpu_test_key_table_host", "fabgpu_test_gtab_compare_with_host",
+    "fabgpu_test_key_table", "fabgpu_test_key_table_host", "fabgpu_test_gtab_compare_with_host", "fabgpu_test_key_tables16",
 ]
 _HOOKS_PATH = os.path.join(os.path.dirname(_LIB_PATH), "libfabgpu_testhooks.so")
 
@@ -152,6 +153,8 @@ def load_hooks():
     H.fabgpu_test_key_table_host.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _sz]
     H.fabgpu_test_gtab_compare_with_host.argtypes = [_vp]
     H.fabgpu_test_gtab_compare_with_host.restype = ctypes.c_longlong
+    H.fabgpu_test_key_tables16.argtypes = [_vp, ctypes.c_uint32]
+    H.fabgpu_test_key_tables16.restype = ctypes.c_longlong
     H.fabgpu_csp_block_walk_compare.argtypes = [_vp, _u8p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _sz]
     H.fabgpu_block_walk_twopass_compare.argtypes = [_u8p, _sz, ctypes.c_char_p, _sz]
     H.fabgpu_gate_sig_fast.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p]
@@ -561,6 +564,11 @@ class Context:
     def test_gtab_compare_with_host(self) -> int:
         """TEST HOOK: first differing word of the device-built generator comb against the host builder's table; -1 = identical."""
         return int(load_hooks().fabgpu_test_gtab_compare_with_host(self._h))
+
+    def test_key_tables16(self, key_id: int) -> int:
+        """TEST HOOK (FLAG_KEY_TABLES_16BIT): waits for the queued 16-bit key tables; their number, after key_id's was cross-checked against its
+        8-bit table (-1: the key has none; -2: error; -(1000 + w): window w disagrees)."""
+        return int(load_hooks().fabgpu_test_key_tables16(self._h, key_id))
 
     def test_nym_side_after(self, on: bool) -> None:
         """TEST HOOK (libfabgpu_testhooks.so): the idemix side launch behind the commitment launch while on."""

@@ -122,6 +122,7 @@ type Options struct {
 	MemoBlocks       int   // the verdict memo holds this many blocks' worth of entries (x ExpectTuples); 0: the library's 2^18 entries
 	NoHashMemo       bool  // bccsp.Hash never asks the digest memo and passes keep no host copy of their block (default: they do)
 	HashMemoBlocks   int   // per device: host copies of blocks kept for the digest memo at a time (0: MemoBlocks + ConcurrentPasses, at least 8)
+	KeyTables16      bool  // FABGPU_FLAG_KEY_TABLES_16BIT: every imported key also gets a 16-bit comb table on the device (80 MiB each, the first 64 keys)
 	HostWalk         bool  // keep the envelope walk on the host (A/B runs)
 	PassTiming       bool  // stage breakdown of every pass on stderr
 }
@@ -208,6 +209,9 @@ func New(swCSP bccsp.BCCSP, opts Options) (bccsp.BCCSP, error) {
 	o.concurrent_passes = C.uint32_t(opts.ConcurrentPasses)
 	o.expect_block_bytes = C.uint64_t(opts.ExpectBlockBytes)
 	o.expect_tuples = C.uint32_t(opts.ExpectTuples)
+	if opts.KeyTables16 {
+		o.ctx_flags |= 256 // fabgpu.h FABGPU_FLAG_KEY_TABLES_16BIT
+	}
 	if opts.HostWalk {
 		o.pass_device_walk = -1
 	}

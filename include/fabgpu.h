@@ -76,6 +76,12 @@ typedef struct fabgpu_ctx fabgpu_ctx;
 #define FABGPU_FLAG_NYM_NO_SIDE_STREAM 128u /* idemix, four-lanes-per-signature form: compute the fixed-base terms inside the commitment kernel instead of
                                             a launch of their own on a second stream beside it (parity tests run both forms) */
 
+#define FABGPU_FLAG_KEY_TABLES_16BIT 256u   /* registered keys (fabgpu_p256_key_register): each key also gets a 16-bit comb table - 80 MiB, the
+                                            generator's format, built on the device BEHIND the registration (nobody waits for it), up to
+                                            64 keys = 5 GiB of the device's 288 GB.  A wavefront all of whose keys have one computes
+                                            u2*Q in 16 mixed additions instead of 32; any other wavefront uses the 8-bit combs as before.
+                                            For a peer whose channels have a few dozen signers (msp/cache/cache.go:14-18) */
+
 typedef struct fabgpu_cfg {
     int32_t device;      /* HIP device ordinal; -1 = the current device */
     uint32_t max_batch;  /* staging pre-allocation hint in tuples (0 = grow on demand) */

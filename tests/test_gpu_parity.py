@@ -279,6 +279,62 @@ def test_registered_keys_pool_vs_oracle_and_vs_the_unkeyed_kernel(ctx, n, nkeys)
     assert (st2 == st).all() and (bits2 == bits).all()
 
 
+def test_registered_keys_with_16_bit_tables():
+    """Round 6, FABGPU_FLAG_KEY_TABLES_16BIT: every registered key also gets a 16-bit comb (80 MiB, built behind the registration); a
+    wavefront all of whose keys have one takes 16 mixed additions for u2 Q instead of 32.  (1) The statuses are the oracle's BEFORE the
+    tables are there (8-bit path), AFTER (16-bit path) and for a batch that mixes keys with and without one (the 65th key gets none:
+    wavefronts that meet it fall back) - in both geometries, verify-only and fused.  (2) Each 16-bit table agrees with the key's 8-bit
+    table entry for entry where the two overlap (the test hook reads both from the device)."""
+    ctx = fabgpu.Context(device=0, flags=fabgpu.FLAG_KEY_TABLES_16BIT)
+    try:
+        nkeys = 6
+        b = coracle.make_pool_batch(40000, seed=9191, nkeys=nkeys, invalid_frac=0.1)
+        ids = np.array([ctx.key_register(b["pool_qx"][j].tobytes(), b["pool_qy"][j].tobytes()) for j in range(nkeys)], dtype=np.uint32)
+        want = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
+        for n in (3000, 40000):                                                      # pair and one-lane geometry, tables possibly still building
+            bits, st = ctx.p256_verify_batch_keyed(ids[b["key_index"][:n]], b["e"][:n], b["r"][:n], b["s"][:n])
+            assert (st == want[:n]).all() and (bits == (want[:n] == 0)).all()
+        for j in range(nkeys):
+            assert ctx.test_key_tables16(int(ids[j])) == nkeys                        # waits for the builds; cross-checks table j
+        for n in (1, 77, 3000, 9000, 30000, 40000):
+            bits, st = ctx.p256_verify_batch_keyed(ids[b["key_index"][:n]], b["e"][:n], b["r"][:n], b["s"][:n])
+            assert (st == want[:n]).all() and (bits == (want[:n] == 0)).all(), n
+        # fused hash + verify over keys that have their 16-bit tables (3 000: two lanes per signature; 40 000: one)
+        for n in (3000, 40000):
+            rng = np.random.default_rng(18 + n)
+            lens = rng.integers(0, 300, size=n)
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+            arena = rng.integers(0, 256, size=int(off[-1]) + 1, dtype=np.uint8)
+            fb = coracle.make_pool_batch(n, seed=9191, nkeys=nkeys, invalid_frac=0.2, digests=coracle.sha256_batch(arena, off))
+            assert (fb["pool_qx"] == b["pool_qx"]).all()                              # (the pool depends on the seed only: the same six keys)
+            bits, st = ctx.sha256_p256_verify_batch_keyed(arena, off, ids[fb["key_index"]], fb["r"], fb["s"])
+            wantf = coracle.sha256_verify_batch(arena, off, fb["qx"], fb["qy"], fb["r"], fb["s"])
+            assert (st == wantf).all() and (bits == (wantf == 0)).all(), n
+        # the edge vectors (u1 = 0, final addition = doubling / infinity, window corners) through the 16-bit path
+        vs = [v for v in _load("edge_kats.json") if len(v["e"]) == 64 and po.on_curve(int(v["qx"], 16), int(v["qy"], 16))
+              and 0 <= int(v["r"], 16) < 1 << 256 and 0 <= int(v["s"], 16) < 1 << 256][:40]
+        eids = np.array([ctx.key_register(_h32(v["qx"]), _h32(v["qy"])) for v in vs], dtype=np.uint32)
+        assert ctx.test_key_tables16(int(eids[-1])) >= nkeys
+        e = np.frombuffer(b"".join(_h32(v["e"]) for v in vs), dtype=np.uint8).reshape(-1, 32)
+        r = np.frombuffer(b"".join(_h32(v["r"]) for v in vs), dtype=np.uint8).reshape(-1, 32)
+        s_ = np.frombuffer(b"".join(_h32(v["s"]) for v in vs), dtype=np.uint8).reshape(-1, 32)
+        qx = np.frombuffer(b"".join(_h32(v["qx"]) for v in vs), dtype=np.uint8).reshape(-1, 32)
+        qy = np.frombuffer(b"".join(_h32(v["qy"]) for v in vs), dtype=np.uint8).reshape(-1, 32)
+        bits, st = ctx.p256_verify_batch_keyed(eids, e, r, s_)
+        assert (st == coracle.verify_batch(qx, qy, e, r, s_)).all()
+        # more keys than 16-bit tables: keys beyond the 64th are served by their 8-bit combs, and so is every wavefront that meets one
+        many = coracle.make_pool_batch(6000, seed=9393, nkeys=70, invalid_frac=0.1)
+        mids = np.array([ctx.key_register(many["pool_qx"][j].tobytes(), many["pool_qy"][j].tobytes()) for j in range(70)], dtype=np.uint32)
+        total = ctx.test_key_tables16(int(mids[0]))
+        assert total == 64, total
+        assert ctx.test_key_tables16(int(mids[-1])) == -1
+        bits, st = ctx.p256_verify_batch_keyed(mids[many["key_index"]], many["e"], many["r"], many["s"])
+        wantm = coracle.verify_batch(many["qx"], many["qy"], many["e"], many["r"], many["s"])
+        assert (st == wantm).all() and (bits == (wantm == 0)).all()
+    finally:
+        ctx.close()
+
+
 def test_key_tables_built_on_the_device_equal_the_host_builders_byte_for_byte(ctx):
     """Round 6: a registered key's comb table (T[w][d] = d 2^(8w) Q, 32 x 255 affine points in the fe29 Montgomery form of their canonical
     residues) is built by three kernels (csrc/keytab_kernels.hip) instead of 6 ms of host arithmetic.  Ground truth: the host builder

@@ -92,10 +92,10 @@ def test_no_device_fails_loudly_never_falls_back():
     L = fabgpu.load()
     assert L.fabgpu_init(None, None) == -1
     assert L.fabgpu_p256_verify_batch(None, 1, None, None, None, None, None, None, None) == -1
-    # unknown configuration bits are refused before anything else (fabgpu.h: FABGPU_FLAG_* are 1, 2, 4, ... 128), and so are the two
+    # unknown configuration bits are refused before anything else (fabgpu.h: FABGPU_FLAG_* are 1, 2, 4, ... 256), and so are the two
     # contradictory table flags together
     import ctypes
-    for bad in (256, 8 | 16):
+    for bad in (512, 8 | 16):
         cfg = fabgpu._Cfg(device=-1, max_batch=0, max_arena=0, flags=bad)
         h = ctypes.c_void_p()
         assert L.fabgpu_init(ctypes.byref(cfg), ctypes.byref(h)) == -1 and not h.value

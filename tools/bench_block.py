@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--block-file", help="a marshalled block made by tools/make_bench_blocks.py (all signatures valid) instead of building one here")
     ap.add_argument("--idemix", action="store_true", help="register the fixtures' IdemixMSP1 first (blocks of make_bench_blocks.py idemix ...)")
     ap.add_argument("--tables", type=int, default=256, help="device comb tables the identity cache may build (6 signers: fewer than 6 leaves newcomers on the fresh-key path)")
+    ap.add_argument("--tables16", action="store_true", help="FABGPU_FLAG_KEY_TABLES_16BIT on every context: 16-bit comb tables for the registered keys (round 6)")
     ap.add_argument("--host-walk", action="store_true", help="provider option pass_device_walk off: the block is walked on the host (the round-2 route)")
     ap.add_argument("--timing", action="store_true", help="provider option pass_timing: per-stage times of every pass on stderr")
     ap.add_argument("--register-after", type=int, default=1, help="an identity earns its comb table after being named this often (the provider's default: 64)")
@@ -65,7 +66,7 @@ def main():
         switches["pass_device_walk"] = -1
     if args.timing:
         switches["pass_timing"] = 1
-    csp = fabgpu.GPUCSP(devices=[0], **switches)
+    csp = fabgpu.GPUCSP(devices=[0], flags=fabgpu.FLAG_KEY_TABLES_16BIT if args.tables16 else 0, **switches)
     if args.idemix:
         raw_ipk = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "idemix_fixtures.json")))["msps"]["MSP1OU1"]["ipk"])
         assert csp.idemix_msp_register("IdemixMSP1", raw_ipk) >= 0

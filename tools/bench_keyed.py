@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--keys", type=int, default=16)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tables16", action="store_true", help="FABGPU_FLAG_KEY_TABLES_16BIT: 16-bit combs for the registered keys (round 6)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -28,10 +29,15 @@ def main():
     import fabgpu
     n = args.n
     b = coracle.make_pool_batch(n, seed=20260921, nkeys=args.keys, invalid_frac=0.01)
-    ctx = fabgpu.Context(device=0, max_batch=n)
+    ctx = fabgpu.Context(device=0, max_batch=n, flags=fabgpu.FLAG_KEY_TABLES_16BIT if args.tables16 else 0)
     t0 = time.perf_counter()
     ids = np.array([ctx.key_register(b["pool_qx"][j].tobytes(), b["pool_qy"][j].tobytes()) for j in range(args.keys)], dtype=np.uint32)
     reg_ms = (time.perf_counter() - t0) * 1e3 / args.keys
+    tables16_ms = None
+    if args.tables16:
+        ready = ctx.test_key_tables16(int(ids[0]))                  # waits for the builds queued behind the registrations
+        tables16_ms = (time.perf_counter() - t0) * 1e3
+        assert ready == min(args.keys, 64), ready
     kid = torch.from_numpy(ids[b["key_index"]].view(np.int32)).cuda()
     dev = {k: torch.from_numpy(b[k]).cuda() for k in ("e", "r", "s")}
     words = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
@@ -53,7 +59,7 @@ def main():
     assert (got == (want == 0)).all(), "keyed verdicts differ from the oracle"
     print(json.dumps({"metric": "ECDSA P-256 verifies/sec, registered keys", "value": n / dt, "unit": "verifies/s", "ms_per_step": dt * 1e3,
                       "config": {"workload": "%d tuples signed by a pool of %d registered keys, 1%% invalid, 1 GPU" % (n, args.keys)},
-                      "key_register_ms_per_key": reg_ms, "parity": "verdict bitmap bit-identical to the CPU oracle"}))
+                      "key_register_ms_per_key": reg_ms, "tables_16bit": bool(args.tables16), "all_16bit_tables_built_and_one_checked_after_ms": tables16_ms, "parity": "verdict bitmap bit-identical to the CPU oracle"}))
     ctx.close()
 
 
