@@ -278,6 +278,60 @@ def test_limb_contracts_are_closed_under_every_program():
         bmu.run_intervals(e, e)
 
 
+def test_the_interval_proof_rejects_the_withdrawn_doubling():
+    """Round 6 committed a 739-instruction doubling for one commit: E squares gamma instead of 2 gamma and the factor rides in the addend's
+    coefficient - Y3 = alpha (beta4 - X3) - 8 gamma^2.  It computed the right point on every input the suites have (this test runs it on a
+    chain too), and it has NO closed contract: a Montgomery product leaves a b / R plus up to p, the -8 multiplies that slack by eight where
+    the kept form multiplies it by two, and the worst-case value of Y grows from doubling to doubling.  The proof is what found it; this
+    keeps the finding: the same instruction list, correct on numbers, refused on ranges."""
+    from gcn_dsl import Program
+
+    def withdrawn():
+        p = Program("PAIR29_DBL_WITHDRAWN")
+        A = p.fe("A", "io"); B = p.fe("B", "io")
+        U1, U2, U3, W3, P1, P2, T0, T1, TD = (p.fe(n, "tmp") for n in ("U1", "U2", "U3", "W3", "P1", "P2", "T0", "T1", "TD"))
+        p.sqr(U1, B, TD)                                  # E: gamma          O: delta
+        p.swp_sub(P1, A, U1); p.swp_add(P2, A, U1)
+        p.shl(T0, U1, 2)                                  # E: 4 gamma
+        p.sel(P1, P1, A); p.sel(P2, P2, T0)
+        p.mul(U2, P1, P2)                                 # E: beta4          O: m
+        p.shladd(T0, U2, 1, U2)                           #                   O: alpha
+        p.sel(W3, T0, U1)                                 # E: gamma
+        p.swp(T0, U2)
+        p.lane_const(TD[8], -2, 0)
+        p.sqr(U3, W3, TD, T0, TD[8])                      # E: gamma^2        O: X3
+        p.swp(A, U3); p.sub(T0, U2, A); p.swp(T1, W3); p.swp(P1, B); p.shl(P1, P1, 1)
+        p.sel(P1, P1, T1); p.sel(P2, B, T0)
+        p.lane_const(TD[0], 0, -8)
+        p.mul(B, P1, P2, U3, TD[0])                       # E: Y3 = yy - 8 gamma^2     O: Z3
+        return p
+    bad = withdrawn()
+    # right on numbers ...
+    rng = random.Random(82)
+    pt = po.pt_mul(rng.randrange(1, po.N), (po.GX, po.GY))
+    st = Pair(*jac_of(pt, rng), rng)
+    acc = pt
+    for _ in range(12):
+        st.run(bad)
+        acc = po.pt_add(acc, acc)
+        assert st.point() == acc
+    # ... and without a contract: iterating the outputs back into the inputs never closes (the kept doubling closes in a few rounds)
+    def closes(dbl):
+        progs_ = {"dbl": dbl, "add": gp.build_pair_add(), "madd": gp.build_pair_madd()}
+        C = {"X": gp.AFFINE, "Y": gp.AFFINE, "Z": gp.AFFINE}
+        try:
+            for _ in range(40):
+                U = gp.state_outputs(progs_, C)
+                new = {k: (min(C[k][0], U[k][0]), max(C[k][1], U[k][1]), min(C[k][2], U[k][2]), max(C[k][3], U[k][3])) for k in C}
+                if new == C:
+                    return True
+                C = new
+        except OverflowError:
+            return False
+        return False
+    assert closes(gp.build_pair_dbl()) and not closes(bad)
+
+
 def test_pair_programs_at_the_edge_of_their_limb_contracts(progs):
     """Every input digit at an extreme of the state contract (signs: all high, all low, alternating, random): the 64-bit column sums must
     not wrap - the interpreter's arithmetic is exact 64-bit, so a wrap shows as a wrong value against the formulas in big integers
