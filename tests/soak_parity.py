@@ -14,7 +14,7 @@ for p in ("fabric-mod_amd", "oracle"):
     sys.path.insert(0, os.path.join(ROOT, p))
 
 
-def soak(seconds, seed):
+def soak(seconds, seed, tables16=False, keyed_only=False):
     import types
     args = types.SimpleNamespace(seconds=seconds, seed=seed)
     import numpy as np
@@ -22,14 +22,16 @@ def soak(seconds, seed):
     import coracle
     import fabgpu
     rng = np.random.default_rng(args.seed)
-    ctx = fabgpu.Context(device=0)
+    # tables16: FABGPU_FLAG_KEY_TABLES_16BIT - the keyed batches then verify while their keys' 16-bit tables are still being built behind
+    # the registrations (a wavefront sees each table or not yet: both must give the oracle's statuses), and beyond the 64th key without one
+    ctx = fabgpu.Context(device=0, flags=fabgpu.FLAG_KEY_TABLES_16BIT if tables16 else 0)
     t_end = time.time() + args.seconds
     stats = {"batches": 0, "tuples": 0, "invalid": 0, "verify_only": 0, "fused": 0, "keyed": 0, "pair_geometry": 0, "one_lane_geometry": 0}
     it = 0
     while time.time() < t_end:
         it += 1
         n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 33000), rng.integers(33000, 90000)], p=[0.2, 0.5, 0.3]))
-        mode = it % 3
+        mode = 2 if keyed_only else it % 3
         b = fabgpu.synth_batch(n, seed=int(rng.integers(1, 1 << 40)), invalid_permille=int(rng.choice([0, 10, 200, 500])))
         if mode == 0:
             want = coracle.verify_batch(b["qx"], b["qy"], b["e"], b["r"], b["s"])
@@ -68,8 +70,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--tables16", action="store_true", help="a context with FABGPU_FLAG_KEY_TABLES_16BIT (round 6)")
+    ap.add_argument("--keyed-only", action="store_true", help="registered-key batches only")
     a = ap.parse_args()
-    r = soak(a.seconds, a.seed)
+    r = soak(a.seconds, a.seed, a.tables16, a.keyed_only)
+    r["tables16"], r["keyed_only"] = a.tables16, a.keyed_only
     print(json.dumps(r))
     sys.exit(0 if r["soak"] == "ok" else 1)
 
