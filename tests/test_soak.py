@@ -14,7 +14,6 @@ def test_randomised_parity_soak():
 
 
 @pytest.mark.gpu
-@pytest.mark.gpu
 def test_registered_keys_soak_while_their_16_bit_tables_are_being_built():
     """tests/soak_parity.py, registered-key batches only, on a context with FABGPU_FLAG_KEY_TABLES_16BIT: every batch registers new keys and
     verifies at once - wavefronts meet keys whose 16-bit table is finished, still building, or (past the 64th key) never coming."""
@@ -23,6 +22,7 @@ def test_registered_keys_soak_while_their_16_bit_tables_are_being_built():
     assert r["keyed"] >= 3
 
 
+@pytest.mark.gpu
 def test_randomised_idemix_soak():
     """tests/soak_idemix.py for a few seconds (thousands of calls through one context: the side launch's flag protocol must never let a stale
     or half-written record through); profiles/r05_soak_idemix.json is the 150-second run (147 562 calls, 240 M signatures)"""
