@@ -179,6 +179,7 @@ struct fabgpu_ctx {
     static constexpr size_t KTAB16_SLAB = 8;
     size_t ktab16_carved = 0;               // tables handed out of the slabs so far
     void* ktab16_rooms = nullptr;           // KTAB16_MAX builders' rooms (key + pointer + scratch), one allocation
+    uint8_t* ktab16_heads = nullptr;        // pinned host memory, KTAB16_MAX x 128 bytes: what each build's upload reads (never reused: the copies are asynchronous)
     size_t ktab16_room_bytes = 0;
     size_t ktab16_count = 0;
     // Where the tables live: slabs of KTAB_SLAB tables (a table is never freed before shutdown, and hipMalloc / hipFree per table were
@@ -519,6 +520,7 @@ void fabgpu_shutdown(fabgpu_ctx* ctx) {
         for (void* t : ctx->ktab16_slabs)
             if (t) hipFree(t);
         if (ctx->ktab16_rooms) hipFree(ctx->ktab16_rooms);
+        if (ctx->ktab16_heads) hipHostFree(ctx->ktab16_heads);
         for (auto& w : ctx->qws) {
             if (w.p) hipFree(w.p);
             if (w.done) hipEventDestroy(w.done);
@@ -811,10 +813,15 @@ static void key_queue_table16_locked(fabgpu_ctx* ctx, const std::string& k, uint
     void* room = (uint8_t*)ctx->ktab16_rooms + ctx->ktab16_room_bytes * ctx->ktab16_count;
     hipStream_t st = ctx->stream_keytab16;
     // room: [0, 64) the key, [64, 72) the table's address (what the entries kernel reads), [128, ...) scratch
-    uint8_t head[72];
+    if (!ctx->ktab16_heads && hipHostMalloc((void**)&ctx->ktab16_heads, 128 * fabgpu_ctx::KTAB16_MAX, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->ktab16_heads = nullptr;
+        return;
+    }
+    uint8_t* head = ctx->ktab16_heads + 128 * ctx->ktab16_count;
     memcpy(head, k.data(), 64);
     memcpy(head + 64, &tab, sizeof(void*));
-    hipError_t e = hipMemcpyAsync(room, head, sizeof(head), hipMemcpyHostToDevice, st);     // (pageable source: staged by the runtime before the call returns)
+    hipError_t e = hipMemcpyAsync(room, head, 72, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_keytab16_build(1, room, (void* const*)((uint8_t*)room + 64), (uint8_t*)room + 128, st);
     if (e == hipSuccess) e = hipMemcpyAsync((void*)(ctx->d_ktabs + KTAB_STRIDE * (size_t)id + 1), (uint8_t*)room + 64, sizeof(void*), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) {
